@@ -1,0 +1,111 @@
+"""Seeded synthetic camera frames for tests, smoke and bench.
+
+uint8 grayscale, row-major, stride = width: low-frequency background + random filled rectangles and
+discs of random intensity + uniform noise of +-3, so FAST fires across all cells and both threshold
+tiers (iniThFAST 20 / minThFAST 7) occur.  A stereo pair is the same scene with every object shifted
+left by its own disparity in [1, 0.25*fx] px plus independent noise.  Intrinsics follow
+Examples/Stereo/EuRoC.yaml of the reference scaled to the image width.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EUROC = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375, width=752, height=480, bf_over_fx=0.110074)
+
+
+def intrinsics(width: int, height: int) -> dict:
+    """EuRoC-like pinhole intrinsics scaled to (width, height); mbf = bf, mb = mbf / fx."""
+    sx = width / EUROC["width"]
+    sy = height / EUROC["height"]
+    fx = np.float32(EUROC["fx"] * sx)
+    fy = np.float32(EUROC["fy"] * sy)
+    cx = np.float32(EUROC["cx"] * sx)
+    cy = np.float32(EUROC["cy"] * sy)
+    mbf = np.float32(np.float32(EUROC["bf_over_fx"]) * fx)
+    mb = np.float32(mbf / fx)
+    return dict(fx=fx, fy=fy, cx=cx, cy=cy, mbf=mbf, mb=mb)
+
+
+def _background(rng: np.random.Generator, w: int, h: int) -> np.ndarray:
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    bg = np.full((h, w), 110.0, np.float32)
+    for _ in range(4):
+        fx_, fy_ = rng.uniform(0.5, 3.0, 2) * 2 * np.pi / np.array([w, h])
+        ph = rng.uniform(0, 2 * np.pi)
+        bg += rng.uniform(8, 25) * np.sin(fx_ * x + fy_ * y + ph)
+    return bg
+
+
+def _objects(rng: np.random.Generator, w: int, h: int, fx: float, density: float):
+    n = max(8, int(density * w * h / 1500.0))
+    objs = []
+    for _ in range(n):
+        kind = int(rng.integers(0, 3))  # 0 rect, 1 disc, 2 small speckle rect
+        cx = float(rng.uniform(-10, w + 10))
+        cy = float(rng.uniform(-10, h + 10))
+        if kind == 2:
+            sw, sh = rng.integers(2, 7, 2)
+        else:
+            sw, sh = rng.integers(6, max(8, w // 12), 2)
+        val = float(rng.uniform(15, 240))
+        disp = float(rng.uniform(1.0, 0.25 * fx))
+        objs.append((kind, cx, cy, int(sw), int(sh), val, disp))
+    # far objects first so near ones (large disparity) occlude them in both views
+    objs.sort(key=lambda o: o[6])
+    return objs
+
+
+def _render(bg: np.ndarray, objs, shift_sign: float) -> np.ndarray:
+    h, w = bg.shape
+    img = bg.copy()
+    for kind, cx, cy, sw, sh, val, disp in objs:
+        ox = cx - shift_sign * disp
+        x0, x1 = int(round(ox - sw / 2)), int(round(ox + sw / 2))
+        y0, y1 = int(round(cy - sh / 2)), int(round(cy + sh / 2))
+        xa, xb, ya, yb = max(x0, 0), min(x1, w), max(y0, 0), min(y1, h)
+        if xa >= xb or ya >= yb:
+            continue
+        if kind == 1:
+            yy, xx = np.mgrid[ya:yb, xa:xb]
+            rx, ry = max(sw / 2.0, 1.0), max(sh / 2.0, 1.0)
+            m = ((xx - ox) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1.0
+            img[ya:yb, xa:xb][m] = val
+        else:
+            img[ya:yb, xa:xb] = val
+    return img
+
+
+def _finish(rng: np.random.Generator, img: np.ndarray) -> np.ndarray:
+    noise = rng.integers(-3, 4, img.shape).astype(np.float32)
+    return np.clip(np.rint(img + noise), 0, 255).astype(np.uint8)
+
+
+def make_image(width: int, height: int, seed: int, density: float = 1.0) -> np.ndarray:
+    """One synthetic frame (height, width) uint8, C-contiguous."""
+    rng = np.random.default_rng(seed)
+    fx = float(intrinsics(width, height)["fx"])
+    bg = _background(rng, width, height)
+    objs = _objects(rng, width, height, fx, density)
+    return np.ascontiguousarray(_finish(rng, _render(bg, objs, 0.0)))
+
+
+def make_stereo_pair(width: int, height: int, seed: int, density: float = 1.0):
+    """(left, right) synthetic rectified pair; right = objects shifted left by their disparity."""
+    rng = np.random.default_rng(seed)
+    fx = float(intrinsics(width, height)["fx"])
+    bg = _background(rng, width, height)
+    objs = _objects(rng, width, height, fx, density)
+    left = _finish(rng, _render(bg, objs, 0.0))
+    right = _finish(rng, _render(bg, objs, 1.0))
+    return np.ascontiguousarray(left), np.ascontiguousarray(right)
+
+
+def make_flat(width: int, height: int, value: int = 128) -> np.ndarray:
+    """Featureless frame: exercises the empty-cell / zero-keypoint paths."""
+    return np.full((height, width), value, np.uint8)
+
+
+def make_noise(width: int, height: int, seed: int) -> np.ndarray:
+    """Uniform random bytes: worst case for candidate counts (dense FAST responses)."""
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (height, width), dtype=np.uint8)

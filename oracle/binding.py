@@ -1,0 +1,389 @@
+"""ctypes binding of oracle/liborb_oracle.so - TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never from the
+product package (fasttrack_amd/).  See oracle/orb_oracle.h for the role of the oracle and the
+"parity unpinned" caveat.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liborb_oracle.so")
+
+
+class KeyPoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int), ("class_id", C.c_int)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28 == C.sizeof(KeyPoint)
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int)
+f32p = C.POINTER(C.c_float)
+
+
+class Frame(C.Structure):
+    _fields_ = [("N", C.c_int), ("Nleft", C.c_int),
+                ("mnMinX", C.c_float), ("mnMinY", C.c_float), ("mnMaxX", C.c_float), ("mnMaxY", C.c_float),
+                ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("mbf", C.c_float), ("mb", C.c_float),
+                ("keys", C.c_void_p), ("keys_right", C.c_void_p), ("descriptors", C.c_void_p),
+                ("uright", C.c_void_p), ("holder_obs", C.c_void_p), ("left_to_right", C.c_void_p),
+                ("right_to_left", C.c_void_p), ("cam_model", C.c_int), ("cam", C.c_float * 8),
+                ("Trl", C.c_float * 12), ("scale_factors", C.c_void_p), ("nlevels", C.c_int)]
+
+
+class LocalPoints(C.Structure):
+    _fields_ = [("M", C.c_int), ("skip", C.c_void_p), ("in_view", C.c_void_p), ("in_view_r", C.c_void_p),
+                ("level", C.c_void_p), ("level_r", C.c_void_p), ("view_cos", C.c_void_p),
+                ("view_cos_r", C.c_void_p), ("proj_x", C.c_void_p), ("proj_y", C.c_void_p),
+                ("proj_xr", C.c_void_p), ("proj_yr", C.c_void_p), ("descriptors", C.c_void_p),
+                ("observations", C.c_void_p)]
+
+
+class LastPoints(C.Structure):
+    _fields_ = [("N", C.c_int), ("valid", C.c_void_p), ("world_pos", C.c_void_p), ("descriptors", C.c_void_p),
+                ("observations", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile) if the .so is missing or stale."""
+    src = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "orb_oracle.h", "orb_pattern.inc", "Makefile")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_extractor_create.restype = C.c_void_p
+        L.orc_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_extractor_destroy.argtypes = [C.c_void_p]
+        L.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int, i32p]
+        L.orc_compute_pyramid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        for f in (L.orc_get_level, L.orc_get_blurred):
+            f.argtypes = [C.c_void_p, C.c_int, C.POINTER(u8p), i32p, i32p, i32p]
+        L.orc_get_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_get_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+        L.orc_brief_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_cv_round_f.argtypes = [C.c_float]
+        L.orc_cv_round_d.argtypes = [C.c_double]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_gaussian_blur7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_gaussian_kernel7_fixed.argtypes = [C.c_void_p]
+        L.orc_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_is_corner.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_fast_corner_score.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_fast_mask_has_arc9.argtypes = [C.c_uint]
+        L.orc_scale_factors.argtypes = [C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_features_per_level.argtypes = [C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orc_umax.argtypes = [C.c_void_p]
+        L.orc_level_sizes.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_pattern.restype = C.POINTER(C.c_int8)
+        L.orc_distribute_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int]
+        L.orc_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_fisheye_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_features_in_area.argtypes = [C.POINTER(Frame), C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_int]
+        L.orc_search_local_points.argtypes = [C.POINTER(Frame), C.POINTER(LocalPoints), C.c_float, C.c_float] + [C.c_void_p] * 11
+        L.orc_search_last_frame.argtypes = [C.POINTER(Frame), C.POINTER(LastPoints), C.c_void_p, C.c_float,
+                                            C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.orc_three_maxima.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------------------------------------
+# thin numpy-level helpers
+# ---------------------------------------------------------------------------------------------
+def scale_factors(sf: float, nlevels: int):
+    a = np.zeros(nlevels, np.float32)
+    b = np.zeros(nlevels, np.float32)
+    lib().orc_scale_factors(sf, nlevels, _p(a), _p(b))
+    return a, b
+
+
+def features_per_level(nfeatures: int, sf: float, nlevels: int):
+    a = np.zeros(nlevels, np.int32)
+    lib().orc_features_per_level(nfeatures, sf, nlevels, _p(a))
+    return a
+
+
+def umax():
+    a = np.zeros(16, np.int32)
+    lib().orc_umax(_p(a))
+    return a
+
+
+def level_sizes(w, h, sf, nlevels):
+    a = np.zeros(nlevels, np.int32)
+    b = np.zeros(nlevels, np.int32)
+    lib().orc_level_sizes(w, h, sf, nlevels, _p(a), _p(b))
+    return a, b
+
+
+def pattern():
+    return np.ctypeslib.as_array(lib().orc_pattern(), shape=(1024,)).copy()
+
+
+def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src: np.ndarray) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().orc_gaussian_blur7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def gaussian_kernel7():
+    a = np.zeros(7, np.int32)
+    lib().orc_gaussian_kernel7_fixed(_p(a))
+    return a
+
+
+def fast9_16(img: np.ndarray, threshold: int, nonmax: bool = True) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orc_fast9_16(_p(img), img.shape[1], img.shape[0], img.strides[0], threshold, int(nonmax), _p(out), cap)
+    return out[:n].copy()
+
+
+def distribute_octree(xys: np.ndarray, minX, maxX, minY, maxY, N) -> np.ndarray:
+    xys = np.ascontiguousarray(xys, np.int32)
+    n = xys.shape[0]
+    out = np.zeros(max(n, 1), np.int32)
+    k = lib().orc_distribute_octree(_p(xys), n, minX, maxX, minY, maxY, N, _p(out), n)
+    return out[:k].copy()
+
+
+def descriptor_distance(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+class Extractor:
+    """Mirror of ORB_SLAM3::ORBextractor (CPU branch) over the oracle."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.nfeatures, self.scale_factor, self.nlevels = nfeatures, scale_factor, nlevels
+        self.ini_th, self.min_th = ini_th, min_th
+        self._h = lib().orc_extractor_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_extractor_destroy(self._h)
+            self._h = None
+
+    def extract(self, img: np.ndarray, lap=(0, 0)):
+        """returns (keypoints[KP_DTYPE], descriptors[n,32], n_mono)"""
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = self.nfeatures + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        nm = C.c_int(0)
+        h, w = (img.shape if img.size else (0, 0))
+        n = lib().orc_extract(self._h, _p(img) if img.size else None, w, h, img.strides[0] if img.size else 0,
+                              lap[0], lap[1], _p(kps), _p(desc), cap, C.byref(nm))
+        if n < 0:
+            return None, None, -1
+        assert n <= cap
+        return kps[:n].copy(), desc[:n].copy(), nm.value
+
+    def pyramid(self, img: np.ndarray):
+        img = np.ascontiguousarray(img, np.uint8)
+        lib().orc_compute_pyramid(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0])
+        return [self.level(l) for l in range(self.nlevels)]
+
+    def _img(self, fn, level):
+        d = u8p()
+        w, h, s = C.c_int(), C.c_int(), C.c_int()
+        if fn(self._h, level, C.byref(d), C.byref(w), C.byref(h), C.byref(s)) != 0:
+            return None
+        return np.ctypeslib.as_array(d, shape=(h.value, s.value))[:, :w.value].copy()
+
+    def level(self, level):
+        return self._img(lib().orc_get_level, level)
+
+    def blurred(self, level):
+        return self._img(lib().orc_get_blurred, level)
+
+    def candidates(self, level) -> np.ndarray:
+        n = lib().orc_get_candidates(self._h, level, None, 0)
+        out = np.zeros((max(n, 1), 3), np.int32)
+        lib().orc_get_candidates(self._h, level, _p(out), n)
+        return out[:n]
+
+    def level_keypoints(self, level):
+        n = lib().orc_get_level_keypoints(self._h, level, None, None, 0)
+        kps = np.zeros(max(n, 1), KP_DTYPE)
+        desc = np.zeros((max(n, 1), 32), np.uint8)
+        lib().orc_get_level_keypoints(self._h, level, _p(kps), _p(desc), n)
+        return kps[:n], desc[:n]
+
+
+def stereo_match(exL: Extractor, exR: Extractor, keysL, keysR, descL, descR, mbf, mb, median_cut=True):
+    """Frame::ComputeStereoMatches.  returns dict(uright, depth, sad, hamming_idx, n)"""
+    nL, nR = len(keysL), len(keysR)
+    keysL = np.ascontiguousarray(keysL)
+    keysR = np.ascontiguousarray(keysR)
+    descL = np.ascontiguousarray(descL, np.uint8)
+    descR = np.ascontiguousarray(descR, np.uint8)
+    ur = np.zeros(max(nL, 1), np.float32)
+    dp = np.zeros(max(nL, 1), np.float32)
+    sad = np.zeros(max(nL, 1), np.int32)
+    hi = np.zeros(max(nL, 1), np.int32)
+    n = lib().orc_stereo_match(exL._h, exR._h, _p(keysL), nL, _p(keysR), nR, _p(descL), _p(descR),
+                               float(mbf), float(mb), _p(ur), _p(dp), _p(sad), _p(hi), int(median_cut))
+    return dict(uright=ur[:nL], depth=dp[:nL], sad=sad[:nL], hamming_idx=hi[:nL], n=n)
+
+
+def fisheye_match(descL, descR):
+    descL = np.ascontiguousarray(descL, np.uint8)
+    descR = np.ascontiguousarray(descR, np.uint8)
+    nL, nR = len(descL), len(descR)
+    m = np.zeros(max(nL, 1), np.int32)
+    b = np.zeros(max(nL, 1), np.int32)
+    s = np.zeros(max(nL, 1), np.int32)
+    n = lib().orc_fisheye_match(_p(descL), nL, _p(descR), nR, _p(m), _p(b), _p(s))
+    return dict(matches=m[:nL], best=b[:nL], second=s[:nL], n=n)
+
+
+class FrameView:
+    """Owns the numpy arrays behind an orc_frame."""
+
+    def __init__(self, keys, descriptors, scale_factors_, bounds, mbf=0.0, mb=0.0, uright=None,
+                 holder_obs=None, keys_right=None, left_to_right=None, right_to_left=None, cam_model=0,
+                 cam=None, Trl=None):
+        self.keys = np.ascontiguousarray(keys)
+        self.keys_right = None if keys_right is None else np.ascontiguousarray(keys_right)
+        nleft = -1 if keys_right is None else len(self.keys)
+        n = len(self.keys) + (0 if keys_right is None else len(self.keys_right))
+        self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
+        assert self.descriptors.shape == (n, 32)
+        self.sf = np.ascontiguousarray(scale_factors_, np.float32)
+        self.uright = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        self.holder_obs = (np.full(n, -1, np.int32) if holder_obs is None
+                           else np.ascontiguousarray(holder_obs, np.int32).copy())
+        self.l2r = None if left_to_right is None else np.ascontiguousarray(left_to_right, np.int32)
+        self.r2l = None if right_to_left is None else np.ascontiguousarray(right_to_left, np.int32)
+        minx, miny, maxx, maxy = [np.float32(v) for v in bounds]
+        f = Frame()
+        f.N, f.Nleft = n, nleft
+        f.mnMinX, f.mnMinY, f.mnMaxX, f.mnMaxY = minx, miny, maxx, maxy
+        f.grid_inv_w = np.float32(64) / np.float32(maxx - minx)
+        f.grid_inv_h = np.float32(48) / np.float32(maxy - miny)
+        f.mbf, f.mb = float(mbf), float(mb)
+        f.keys = _p(self.keys)
+        f.keys_right = _p(self.keys_right)
+        f.descriptors = _p(self.descriptors)
+        f.uright = _p(self.uright)
+        f.holder_obs = _p(self.holder_obs)
+        f.left_to_right = _p(self.l2r)
+        f.right_to_left = _p(self.r2l)
+        f.cam_model = cam_model
+        cam = np.zeros(8, np.float32) if cam is None else np.asarray(cam, np.float32)
+        for i in range(8):
+            f.cam[i] = float(cam[i]) if i < len(cam) else 0.0
+        Trl = np.eye(3, 4, dtype=np.float32) if Trl is None else np.asarray(Trl, np.float32).reshape(3, 4)
+        for i in range(12):
+            f.Trl[i] = float(Trl.flat[i])
+        f.scale_factors = _p(self.sf)
+        f.nlevels = len(self.sf)
+        self.c = f
+        self.N, self.Nleft = n, nleft
+
+
+def features_in_area(F: FrameView, x, y, r, min_level=-1, max_level=-1, right=False):
+    out = np.zeros(max(F.N, 1), np.int32)
+    n = lib().orc_features_in_area(C.byref(F.c), x, y, r, min_level, max_level, int(right), _p(out), F.N)
+    return out[:n].copy()
+
+
+def search_local_points(F: FrameView, pts: dict, th: float, nn_ratio: float = 0.8):
+    """pts: dict of arrays (skip,in_view,in_view_r,level,level_r,view_cos,view_cos_r,proj_x,proj_y,proj_xr,
+    proj_yr,descriptors,observations).  Mutates F.holder_obs like the reference mutates mvpMapPoints."""
+    M = len(pts["skip"])
+    keep = {}
+
+    def arr(k, dt):
+        keep[k] = np.ascontiguousarray(pts[k], dt)
+        return _p(keep[k])
+
+    P = LocalPoints()
+    P.M = M
+    P.skip, P.in_view, P.in_view_r = arr("skip", np.uint8), arr("in_view", np.uint8), arr("in_view_r", np.uint8)
+    P.level, P.level_r = arr("level", np.int32), arr("level_r", np.int32)
+    P.view_cos, P.view_cos_r = arr("view_cos", np.float32), arr("view_cos_r", np.float32)
+    P.proj_x, P.proj_y = arr("proj_x", np.float32), arr("proj_y", np.float32)
+    P.proj_xr, P.proj_yr = arr("proj_xr", np.float32), arr("proj_yr", np.float32)
+    P.descriptors, P.observations = arr("descriptors", np.uint8), arr("observations", np.int32)
+    assign = np.zeros(max(F.N, 1), np.int32)
+    outs = [np.zeros(max(M, 1), np.int32) for _ in range(10)]
+    n = lib().orc_search_local_points(C.byref(F.c), C.byref(P), th, nn_ratio, _p(assign), *[_p(o) for o in outs])
+    names = ["best_dist", "best_dist2", "best_level", "best_level2", "best_idx",
+             "best_dist_r", "best_dist2_r", "best_level_r", "best_level2_r", "best_idx_r"]
+    r = {k: o[:M] for k, o in zip(names, outs)}
+    r["assign"] = assign[:F.N]
+    r["n"] = n
+    return r
+
+
+def search_last_frame(Cur: FrameView, last: dict, Tcw, th, forward=False, backward=False, check_orientation=True):
+    """last: dict(valid, world_pos[N,3], descriptors, observations, octave, angle)."""
+    N = len(last["valid"])
+    keep = {}
+
+    def arr(k, dt):
+        keep[k] = np.ascontiguousarray(last[k], dt)
+        return _p(keep[k])
+
+    Lp = LastPoints()
+    Lp.N = N
+    Lp.valid, Lp.world_pos = arr("valid", np.uint8), arr("world_pos", np.float32)
+    Lp.descriptors, Lp.observations = arr("descriptors", np.uint8), arr("observations", np.int32)
+    Lp.octave, Lp.angle = arr("octave", np.int32), arr("angle", np.float32)
+    T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(3, 4))
+    assign = np.zeros(max(Cur.N, 1), np.int32)
+    outs = [np.zeros(max(N, 1), np.int32) for _ in range(4)]
+    n = lib().orc_search_last_frame(C.byref(Cur.c), C.byref(Lp), _p(T), th, int(forward), int(backward),
+                                    int(check_orientation), _p(assign), *[_p(o) for o in outs])
+    names = ["best_dist", "best_idx", "best_dist_r", "best_idx_r"]
+    r = {k: o[:N] for k, o in zip(names, outs)}
+    r["assign"] = assign[:Cur.N]
+    r["n"] = n
+    return r
