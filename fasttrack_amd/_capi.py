@@ -1,0 +1,127 @@
+"""ctypes loader of libfasttrack_amd.so (the C ABI declared in include/fasttrack_amd.h).
+
+The library is the product; there is no Python or CPU fallback.  Loading fails loudly when the shared
+object is missing, and every compute call raises FastTrackError when no usable gfx950 device exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libfasttrack_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "fasttrack_amd.h")
+
+FT_OK, FT_ERR_INVALID, FT_ERR_NO_DEVICE, FT_ERR_HIP, FT_ERR_CAPACITY, FT_ERR_EMPTY = 0, -1, -2, -3, -4, -5
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class FastTrackError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"fasttrack_amd status {status}: {message}")
+        self.status = status
+
+
+class FrameView(C.Structure):
+    _fields_ = [("N", C.c_int), ("Nleft", C.c_int),
+                ("mnMinX", C.c_float), ("mnMinY", C.c_float), ("mnMaxX", C.c_float), ("mnMaxY", C.c_float),
+                ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("mbf", C.c_float), ("mb", C.c_float),
+                ("keys", C.c_void_p), ("keys_right", C.c_void_p), ("descriptors", C.c_void_p),
+                ("uright", C.c_void_p), ("holder_obs", C.c_void_p), ("left_to_right", C.c_void_p),
+                ("right_to_left", C.c_void_p), ("cam_model", C.c_int), ("cam", C.c_float * 8),
+                ("Trl", C.c_float * 12), ("scale_factors", C.c_void_p), ("nlevels", C.c_int)]
+
+
+class LocalPoints(C.Structure):
+    _fields_ = [("M", C.c_int), ("skip", C.c_void_p), ("in_view", C.c_void_p), ("in_view_r", C.c_void_p),
+                ("level", C.c_void_p), ("level_r", C.c_void_p), ("view_cos", C.c_void_p),
+                ("view_cos_r", C.c_void_p), ("proj_x", C.c_void_p), ("proj_y", C.c_void_p),
+                ("proj_xr", C.c_void_p), ("proj_yr", C.c_void_p), ("descriptors", C.c_void_p),
+                ("observations", C.c_void_p)]
+
+
+class LastPoints(C.Structure):
+    _fields_ = [("N", C.c_int), ("valid", C.c_void_p), ("world_pos", C.c_void_p), ("descriptors", C.c_void_p),
+                ("observations", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p)]
+
+
+def declared_symbols() -> list[str]:
+    """Every FT_API entry point declared in include/fasttrack_amd.h."""
+    text = open(HEADER_PATH).read()
+    return sorted(set(re.findall(r"FT_API[^;(]*?\b(ft_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (RTLD_LOCAL | RTLD_DEEPBIND so it binds to the system ROCm runtime even
+    when another HIP runtime, e.g. the one bundled with PyTorch, is present in the process)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C fasttrack_amd/csrc`).  fasttrack_amd has no CPU fallback.")
+    mode = os.RTLD_LOCAL | os.RTLD_NOW | getattr(os, "RTLD_DEEPBIND", 0)
+    L = C.CDLL(LIB_PATH, mode=mode)
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    ip = C.POINTER(C.c_int)
+    L.ft_version.restype = C.c_char_p
+    L.ft_last_error.restype = C.c_char_p
+    L.ft_device_count.restype = i
+    L.ft_context_create.argtypes = [i, i, C.POINTER(vp)]
+    L.ft_context_destroy.argtypes = [vp]
+    L.ft_context_synchronize.argtypes = [vp]
+    L.ft_context_device_name.argtypes = [vp, C.c_char_p, i]
+    L.ft_context_host_threads.argtypes = [vp]
+    L.ft_context_save_stats.argtypes = [vp, C.c_char_p]
+    L.ft_device_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.ft_device_free.argtypes = [vp, vp]
+    L.ft_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.ft_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.ft_extractor_create.argtypes = [vp, i, f, i, i, i, i, i, i, C.POINTER(vp)]
+    L.ft_extractor_destroy.argtypes = [vp]
+    L.ft_extractor_levels.argtypes = [vp]
+    L.ft_extractor_max_batch.argtypes = [vp]
+    L.ft_extractor_max_keypoints.argtypes = [vp]
+    L.ft_extractor_scale_factors.argtypes = [vp, vp, vp, vp, vp]
+    L.ft_extractor_features_per_level.argtypes = [vp, vp]
+    L.ft_extractor_level_size.argtypes = [vp, i, ip, ip]
+    L.ft_extract.argtypes = [vp, vp, i, i, i, i, i, vp, vp, i, ip, ip]
+    L.ft_extract_batch.argtypes = [vp, vp, i, i, i, i, i, i, i, vp, vp, i, vp, vp]
+    L.ft_extractor_download_level.argtypes = [vp, i, i, vp, i]
+    L.ft_extractor_device_level.argtypes = [vp, i, i, C.POINTER(vp), ip]
+    L.ft_extractor_download_candidates.argtypes = [vp, i, i, vp, i, ip]
+    L.ft_stereo_match.argtypes = [vp, vp, i, vp, i, vp, i, vp, vp, f, f, i, vp, vp, vp, ip]
+    L.ft_stereo_frontend_create.argtypes = [vp, i, f, i, i, i, i, i, i, f, f, C.POINTER(vp)]
+    L.ft_stereo_frontend_destroy.argtypes = [vp]
+    L.ft_stereo_frontend_left.argtypes = [vp]
+    L.ft_stereo_frontend_left.restype = vp
+    L.ft_stereo_frontend_right.argtypes = [vp]
+    L.ft_stereo_frontend_right.restype = vp
+    L.ft_stereo_frontend_process.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp, i, vp, vp, vp]
+    L.ft_fisheye_match.argtypes = [vp, vp, i, vp, i, vp, vp, vp]
+    L.ft_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LocalPoints), f, f, vp, ip] + [vp] * 10
+    L.ft_search_last_frame.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LastPoints), vp, f, i, i, i, vp, ip] + [vp] * 4
+    L.ft_descriptor_distance.argtypes = [vp, vp, vp, i, vp]
+    L.ft_octree_distribute.argtypes = [vp, i, i, i, i, i, i, vp, i, ip]
+    L.ft_level_geometry.argtypes = [i, i, i, f, i, vp, vp, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != FT_OK:
+        raise FastTrackError(status, lib().ft_last_error().decode(errors="replace"))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

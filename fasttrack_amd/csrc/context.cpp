@@ -1,0 +1,143 @@
+// Library / device context: replaces KernelController::setCUDADevice / initializeKernels /
+// shutdownKernels / saveKernelsStats (reference include/Kernels/KernelController.h:15-29).
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "ft_host.h"
+
+static thread_local std::string g_lastError;
+
+void ft_set_error(const std::string &msg) { g_lastError = msg; }
+
+int ft_hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    g_lastError = buf;
+    // a missing device must be unmistakable: there is no CPU fallback behind this ABI
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) return FT_ERR_NO_DEVICE;
+    return FT_ERR_HIP;
+}
+
+int ft_set_device(const ft_context *ctx) {
+    FT_HIP(hipSetDevice(ctx->device));
+    return FT_OK;
+}
+
+extern "C" {
+
+const char *ft_version(void) { return "fasttrack_amd 0.1 (gfx950)"; }
+
+const char *ft_last_error(void) { return g_lastError.c_str(); }
+
+int ft_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ft_context_create(int device, int host_threads, ft_context **out) {
+    if (!out) {
+        ft_set_error("ft_context_create: out is null");
+        return FT_ERR_INVALID;
+    }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        ft_set_error("no HIP device available: the fasttrack_amd kernels need a gfx950 GPU (there is no CPU fallback)");
+        return FT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        ft_set_error("ft_context_create: device index out of range");
+        return FT_ERR_INVALID;
+    }
+    FT_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FT_HIP(hipGetDeviceProperties(&prop, device));
+    ft_context *ctx = new ft_context();
+    ctx->device = device;
+    ctx->deviceName = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (host_threads <= 0) host_threads = (int)std::thread::hardware_concurrency();
+    if (host_threads < 1) host_threads = 1;
+    ctx->pool = new ft::ThreadPool(host_threads - 1);
+    hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete ctx->pool;
+        delete ctx;
+        return ft_hip_fail(se, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+    }
+    *out = ctx;
+    return FT_OK;
+}
+
+int ft_context_destroy(ft_context *ctx) {
+    if (!ctx) return FT_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->scratchDev) hipFree(ctx->scratchDev);
+    if (ctx->scratchPin) hipHostFree(ctx->scratchPin);
+    delete ctx->pool;
+    delete ctx;
+    return FT_OK;
+}
+
+int ft_context_synchronize(ft_context *ctx) {
+    if (!ctx) return FT_ERR_INVALID;
+    FT_HIP(hipSetDevice(ctx->device));
+    FT_HIP(hipDeviceSynchronize());
+    return FT_OK;
+}
+
+int ft_context_device_name(ft_context *ctx, char *buf, int len) {
+    if (!ctx || !buf || len <= 0) return FT_ERR_INVALID;
+    snprintf(buf, len, "%s", ctx->deviceName.c_str());
+    return FT_OK;
+}
+
+int ft_context_host_threads(const ft_context *ctx) { return ctx ? ctx->pool->size() : 0; }
+
+int ft_context_save_stats(ft_context *ctx, const char *path) {
+    if (!ctx || !path) return FT_ERR_INVALID;
+    FILE *f = fopen(path, "w");
+    if (!f) {
+        ft_set_error(std::string("cannot open ") + path);
+        return FT_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(ctx->statsMutex);
+    for (auto &kv : ctx->stats)
+        fprintf(f, "%s: %.4f ms total, %ld calls, %.4f ms/call\n", kv.first.c_str(), kv.second.first, kv.second.second,
+                kv.second.second ? kv.second.first / kv.second.second : 0.0);
+    fclose(f);
+    return FT_OK;
+}
+
+int ft_device_malloc(ft_context *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return FT_ERR_INVALID;
+    FT_HIP(hipSetDevice(ctx->device));
+    FT_HIP(hipMalloc(dptr, bytes));
+    return FT_OK;
+}
+
+int ft_device_free(ft_context *ctx, void *dptr) {
+    if (!ctx) return FT_ERR_INVALID;
+    FT_HIP(hipSetDevice(ctx->device));
+    FT_HIP(hipFree(dptr));
+    return FT_OK;
+}
+
+int ft_memcpy_h2d(ft_context *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return FT_ERR_INVALID;
+    FT_HIP(hipSetDevice(ctx->device));
+    FT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return FT_OK;
+}
+
+int ft_memcpy_d2h(ft_context *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return FT_ERR_INVALID;
+    FT_HIP(hipSetDevice(ctx->device));
+    FT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return FT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,580 @@
+// Host orchestration of the ORB extractor: replaces ORB_SLAM3::ORBextractor (reference
+// include/ORBextractor.h:100-197, src/ORBextractor.cc).  Geometry/tables are computed here exactly as
+// the reference's CPU branch does (float arithmetic, cvRound = half-to-even); pixels are only ever
+// touched by the HIP kernels in kernels_extract.hip.  Compiled with -ffp-contract=off.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "ft_host.h"
+
+namespace {
+
+inline int cvRoundF(float v) { return (int)lrintf(v); }
+inline short satShort(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+#define FT_REQUIRE(cond, msg)                      \
+    do {                                           \
+        if (!(cond)) {                             \
+            ft_set_error(std::string(msg));        \
+            return FT_ERR_INVALID;                 \
+        }                                          \
+    } while (0)
+
+// cv::resize INTER_LINEAR coefficient tables: index + two 11-bit weights per output
+// column / row.  scale = 1 / (dsize / ssize) in double, fx in float, weights via cvRound.
+void buildTaps(int ssize, int dsize, bool clampIndex, FtTap *out) {
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        if (clampIndex) {  // columns: OpenCV resets the fraction at both ends; rows are only clipped
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        out[d].s = (short)s;
+        out[d].a0 = satShort(cvRoundF((1.f - f) * 2048));
+        out[d].a1 = satShort(cvRoundF(f * 2048));
+        out[d].pad = 0;
+    }
+}
+
+int buildGeometry(ft_extractor *ex, std::vector<FtTap> &taps) {
+    const int L = ex->nlevels;
+    FtGeom &g = ex->geom;
+    memset(&g, 0, sizeof g);
+    g.nlevels = L;
+    // ORBextractor.cc:398-414, 445-452
+    ex->sf.assign(L, 1.f);
+    ex->sigma2.assign(L, 1.f);
+    for (int i = 1; i < L; i++) {
+        ex->sf[i] = ex->sf[i - 1] * ex->scaleFactor;
+        ex->sigma2[i] = ex->sf[i] * ex->sf[i];
+    }
+    ex->invsf.resize(L);
+    ex->invsigma2.resize(L);
+    for (int i = 0; i < L; i++) {
+        ex->invsf[i] = 1.0f / ex->sf[i];
+        ex->invsigma2[i] = 1.0f / ex->sigma2[i];
+        g.sf[i] = ex->sf[i];
+        g.invsf[i] = ex->invsf[i];
+    }
+    // per-level quotas, ORBextractor.cc:454-465
+    ex->quota.assign(L, 0);
+    {
+        float factor = 1.0f / ex->scaleFactor;
+        float nDesired = ex->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+        int sum = 0;
+        for (int level = 0; level < L - 1; level++) {
+            ex->quota[level] = cvRoundF(nDesired);
+            sum += ex->quota[level];
+            nDesired *= factor;
+        }
+        ex->quota[L - 1] = std::max(ex->nfeatures - sum, 0);
+    }
+    int pyrOff = 0, cellBase = 0, stageBase = 0, candBase = 0, tapOff = 0, maxKp = 0;
+    ex->levelMax.assign(L, 0);
+    for (int l = 0; l < L; l++) {
+        FtLevelGeom &v = g.lv[l];
+        // ORBextractor.cc:1499-1500
+        v.w = cvRoundF((float)ex->width * ex->invsf[l]);
+        v.h = cvRoundF((float)ex->height * ex->invsf[l]);
+        FT_REQUIRE(v.w < 4096 && v.h < 4096, "image too large: candidate packing holds 12-bit coordinates");
+        v.pitch = (v.w + 63) & ~63;
+        v.off = pyrOff;
+        pyrOff += v.pitch * v.h;
+        pyrOff = (pyrOff + 255) & ~255;
+        // ORBextractor.cc:1120-1134
+        const int minB = FT_EDGE_THRESHOLD - 3;
+        v.maxBX = v.w - FT_EDGE_THRESHOLD + 3;
+        v.maxBY = v.h - FT_EDGE_THRESHOLD + 3;
+        const float W = 35;
+        const float width = (float)(v.maxBX - minB), height = (float)(v.maxBY - minB);
+        int nCols = (int)(width / W), nRows = (int)(height / W);
+        if (nCols < 1 || nRows < 1) {
+            nCols = nRows = 0;  // level too small for one cell (the reference would divide by zero)
+            v.wCell = v.hCell = 1;
+        } else {
+            v.wCell = (int)std::ceil(width / nCols);
+            v.hCell = (int)std::ceil(height / nRows);
+        }
+        v.nCols = nCols;
+        v.nRows = nRows;
+        v.cellBase = cellBase;
+        v.cellCap = ((v.wCell + 1) / 2) * ((v.hCell + 1) / 2);  // strict 3x3 maxima cannot be adjacent
+        v.stageBase = stageBase;
+        v.candBase = candBase;
+        v.candCap = nCols * nRows * v.cellCap;
+        cellBase += nCols * nRows;
+        stageBase += v.candCap;
+        candBase += v.candCap;
+        if (l >= 1) {
+            const FtLevelGeom &p = g.lv[l - 1];
+            v.area2x = (p.w == 2 * v.w && p.h == 2 * v.h) ? 1 : 0;
+            v.xtab = tapOff;
+            tapOff += v.w;
+            v.ytab = tapOff;
+            tapOff += v.h;
+        }
+        ex->levelMax[l] = ft::octree_max_result(minB, v.maxBX, minB, v.maxBY, ex->quota[l]);
+        maxKp += ex->levelMax[l];
+    }
+    g.totalCells = cellBase;
+    g.stagePerSlot = stageBase;
+    g.candPerSlot = candBase;
+    g.pyrPerSlot = pyrOff;
+    g.maxKp = maxKp;
+    taps.assign(std::max(tapOff, 1), FtTap{0, 0, 0, 0});
+    for (int l = 1; l < L; l++) {
+        buildTaps(g.lv[l - 1].w, g.lv[l].w, true, &taps[g.lv[l].xtab]);
+        buildTaps(g.lv[l - 1].h, g.lv[l].h, false, &taps[g.lv[l].ytab]);
+    }
+    return FT_OK;
+}
+
+template <typename T>
+int devAlloc(T **p, size_t n) {
+    FT_HIP(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return FT_OK;
+}
+template <typename T>
+int pinAlloc(T **p, size_t n, unsigned flags = hipHostMallocDefault) {
+    FT_HIP(hipHostMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T), flags));
+    return FT_OK;
+}
+
+void freeAll(ft_extractor *ex) {
+    hipSetDevice(ex->ctx->device);
+    if (ex->stream) hipStreamSynchronize(ex->stream);
+    hipFree(ex->d_pyr);
+    hipFree(ex->d_taps);
+    hipFree(ex->d_cellCount);
+    hipFree(ex->d_stage);
+    hipFree((void *)ex->d_l0);
+    hipFree(ex->d_sel);
+    hipFree(ex->d_nSel);
+    hipFree(ex->d_keys);
+    hipFree(ex->d_desc);
+    hipFree(ex->d_stKeys);
+    hipFree(ex->d_stDesc);
+    hipFree(ex->d_stOut);
+    hipFree(ex->d_stInt);
+    hipHostFree((void *)ex->h_l0);
+    hipHostFree(ex->h_cand);
+    hipHostFree(ex->h_candCount);
+    hipHostFree(ex->h_sel);
+    hipHostFree(ex->h_nSel);
+    hipHostFree(ex->h_keys);
+    hipHostFree(ex->h_desc);
+    if (ex->stream) hipStreamDestroy(ex->stream);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// stages
+// ------------------------------------------------------------------------------------------------
+int ft_extract_stage_a(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
+                       int height, int stride) {
+    FT_REQUIRE(ex && images, "extract: null handle or image list");
+    FT_REQUIRE(batch >= 1 && batch <= ex->maxBatch, "extract: batch outside [1, max_batch]");
+    FT_REQUIRE(width == ex->width && height == ex->height, "extract: image size differs from the extractor's");
+    FT_REQUIRE(stride >= width, "extract: stride smaller than width");
+    int rc = ft_set_device(ex->ctx);
+    if (rc != FT_OK) return rc;
+    const FtGeom &g = ex->geom;
+    for (int b = 0; b < batch; b++) {
+        if (!images[b]) {
+            ft_set_error("extract: empty image");
+            return FT_ERR_EMPTY;
+        }
+        uint8_t *slot0 = ex->d_pyr + (size_t)b * g.pyrPerSlot + g.lv[0].off;
+        if (on_device) {
+            ex->h_l0[b] = images[b];
+        } else {
+            ex->h_l0[b] = slot0;
+            FT_HIP(hipMemcpy2DAsync(slot0, g.lv[0].pitch, images[b], stride, width, height, hipMemcpyHostToDevice,
+                                    ex->stream));
+        }
+    }
+    ex->l0External = on_device != 0;
+    ex->l0pitch = on_device ? stride : g.lv[0].pitch;
+    ex->lastBatch = batch;
+    FT_HIP(hipMemcpyAsync((void *)ex->d_l0, (const void *)ex->h_l0, sizeof(uint8_t *) * batch, hipMemcpyHostToDevice,
+                          ex->stream));
+    rc = ft_launch_pyramid(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->d_taps);
+    if (rc != FT_OK) return rc;
+    return ft_launch_fast(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->iniTh, ex->minTh,
+                          ex->d_cellCount, ex->d_stage, ex->d_cand, ex->d_candCount);
+}
+
+int ft_extract_octree(ft_extractor *ex, int batch) {
+    const FtGeom &g = ex->geom;
+    const int L = g.nlevels;
+    // per (slot, level) results land in disjoint sub-ranges of h_sel, then are packed per slot
+    std::vector<int> levelOff(L + 1, 0);
+    for (int l = 0; l < L; l++) levelOff[l + 1] = levelOff[l] + ex->levelMax[l];
+    std::vector<int> counts((size_t)batch * L, 0);
+    std::vector<FtSelKp> tmp((size_t)batch * g.maxKp);
+    auto task = [&](int t, int) {
+        static thread_local ft::OctreeWorkspace ws;
+        static thread_local std::vector<int> keep;
+        const int slot = t / L, level = t - slot * L;
+        const FtLevelGeom &v = g.lv[level];
+        int n = ex->h_candCount[slot * L + level];
+        const uint32_t *cand = ex->h_cand + (size_t)slot * g.candPerSlot + v.candBase;
+        keep.clear();
+        const int minB = FT_EDGE_THRESHOLD - 3;
+        int k = ft::distribute_octree(cand, n, minB, v.maxBX, minB, v.maxBY, ex->quota[level], ws, keep);
+        k = std::min(k, ex->levelMax[level]);
+        FtSelKp *dst = tmp.data() + (size_t)slot * g.maxKp + levelOff[level];
+        for (int i = 0; i < k; i++) {
+            const uint32_t c = cand[keep[i]];
+            // ORBextractor.cc:1211-1217: add the border offset back
+            dst[i].x = (short)((c & 0xfffu) + minB);
+            dst[i].y = (short)(((c >> 12) & 0xfffu) + minB);
+            dst[i].level = (short)level;
+            dst[i].response = (short)(c >> 24);
+        }
+        counts[(size_t)slot * L + level] = k;
+    };
+    ex->ctx->pool->parallel_for(batch * L, task);
+    for (int b = 0; b < batch; b++) {
+        int n = 0;
+        FtSelKp *dst = ex->h_sel + (size_t)b * g.maxKp;
+        for (int l = 0; l < L; l++) {
+            const int k = counts[(size_t)b * L + l];
+            memcpy(dst + n, tmp.data() + (size_t)b * g.maxKp + levelOff[l], sizeof(FtSelKp) * k);
+            n += k;
+        }
+        ex->h_nSel[b] = n;
+    }
+    return FT_OK;
+}
+
+int ft_extract_stage_b(ft_extractor *ex, int batch) {
+    const FtGeom &g = ex->geom;
+    int maxN = 0;
+    for (int b = 0; b < batch; b++) maxN = std::max(maxN, ex->h_nSel[b]);
+    FT_HIP(hipMemcpyAsync(ex->d_nSel, ex->h_nSel, sizeof(int) * batch, hipMemcpyHostToDevice, ex->stream));
+    if (maxN == 0) return FT_OK;
+    FT_HIP(hipMemcpy2DAsync(ex->d_sel, sizeof(FtSelKp) * g.maxKp, ex->h_sel, sizeof(FtSelKp) * g.maxKp,
+                            sizeof(FtSelKp) * maxN, batch, hipMemcpyHostToDevice, ex->stream));
+    int rc = ft_launch_orient_desc(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->d_sel, ex->d_nSel,
+                                   ex->d_keys, ex->d_desc);
+    return rc;
+}
+
+static int downloadResults(ft_extractor *ex, int batch) {
+    const FtGeom &g = ex->geom;
+    int maxN = 0;
+    for (int b = 0; b < batch; b++) maxN = std::max(maxN, ex->h_nSel[b]);
+    if (maxN > 0) {
+        FT_HIP(hipMemcpy2DAsync(ex->h_keys, sizeof(ft_keypoint) * g.maxKp, ex->d_keys, sizeof(ft_keypoint) * g.maxKp,
+                                sizeof(ft_keypoint) * maxN, batch, hipMemcpyDeviceToHost, ex->stream));
+        FT_HIP(hipMemcpy2DAsync(ex->h_desc, (size_t)32 * g.maxKp, ex->d_desc, (size_t)32 * g.maxKp, (size_t)32 * maxN,
+                                batch, hipMemcpyDeviceToHost, ex->stream));
+    }
+    FT_HIP(hipStreamSynchronize(ex->stream));
+    return FT_OK;
+}
+
+// ORBextractor.cc:1466-1487: keypoints inside the lapping area fill from the back
+static int assembleOutputs(ft_extractor *ex, int batch, int lap0, int lap1, ft_keypoint *keypoints,
+                           uint8_t *descriptors, int capacity, int *n_keypoints, int *n_mono) {
+    const FtGeom &g = ex->geom;
+    for (int b = 0; b < batch; b++) {
+        const int n = ex->h_nSel[b];
+        if (n > capacity) {
+            ft_set_error("extract: output capacity too small (use ft_extractor_max_keypoints)");
+            return FT_ERR_CAPACITY;
+        }
+        const ft_keypoint *src = ex->h_keys + (size_t)b * g.maxKp;
+        const uint8_t *sd = ex->h_desc + (size_t)b * g.maxKp * 32;
+        ft_keypoint *dk = keypoints ? keypoints + (size_t)b * capacity : nullptr;
+        uint8_t *dd = descriptors ? descriptors + (size_t)b * capacity * 32 : nullptr;
+        int monoIndex = 0, stereoIndex = n - 1;
+        for (int i = 0; i < n; i++) {
+            const ft_keypoint &kp = src[i];
+            int dst;
+            if (kp.x >= lap0 && kp.x <= lap1) dst = stereoIndex--;
+            else dst = monoIndex++;
+            if (dk) dk[dst] = kp;
+            if (dd) memcpy(dd + (size_t)dst * 32, sd + (size_t)i * 32, 32);
+        }
+        if (n_keypoints) n_keypoints[b] = n;
+        if (n_mono) n_mono[b] = monoIndex;
+    }
+    return FT_OK;
+}
+
+extern "C" {
+
+int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                        int min_th_fast, int image_width, int image_height, int max_batch, ft_extractor **out) {
+    FT_REQUIRE(ctx && out, "ft_extractor_create: null argument");
+    *out = nullptr;
+    FT_REQUIRE(nfeatures > 0, "nfeatures must be positive");
+    FT_REQUIRE(nlevels >= 1 && nlevels <= FT_MAX_LEVELS, "nlevels outside [1, 12]");
+    FT_REQUIRE(scale_factor > 1.0f, "scaleFactor must exceed 1");
+    FT_REQUIRE(min_th_fast >= 1 && ini_th_fast >= min_th_fast && ini_th_fast < 255,
+               "FAST thresholds must satisfy 1 <= minThFAST <= iniThFAST < 255");
+    FT_REQUIRE(image_width >= 2 * FT_EDGE_THRESHOLD + 8 && image_height >= 2 * FT_EDGE_THRESHOLD + 8,
+               "image smaller than the 19-px border allows");
+    FT_REQUIRE(max_batch >= 1 && max_batch <= 4096, "max_batch outside [1, 4096]");
+    int rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    ft_extractor *ex = new ft_extractor();
+    ex->ctx = ctx;
+    ex->nfeatures = nfeatures;
+    ex->scaleFactor = scale_factor;
+    ex->nlevels = nlevels;
+    ex->iniTh = ini_th_fast;
+    ex->minTh = min_th_fast;
+    ex->width = image_width;
+    ex->height = image_height;
+    ex->maxBatch = max_batch;
+    std::vector<FtTap> taps;
+    rc = buildGeometry(ex, taps);
+    if (rc != FT_OK) {
+        delete ex;
+        return rc;
+    }
+    const FtGeom &g = ex->geom;
+    const size_t B = max_batch;
+#define FT_TRY(x)            \
+    do {                     \
+        rc = (x);            \
+        if (rc != FT_OK) {   \
+            freeAll(ex);     \
+            delete ex;       \
+            return rc;       \
+        }                    \
+    } while (0)
+    hipError_t se = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete ex;
+        return ft_hip_fail(se, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+    }
+    FT_TRY(devAlloc(&ex->d_pyr, B * g.pyrPerSlot));
+    FT_TRY(devAlloc(&ex->d_taps, taps.size()));
+    FT_TRY(devAlloc(&ex->d_cellCount, B * g.totalCells));
+    FT_TRY(devAlloc(&ex->d_stage, B * g.stagePerSlot));
+    FT_TRY(devAlloc(&ex->d_l0, B));
+    FT_TRY(devAlloc(&ex->d_sel, B * g.maxKp));
+    FT_TRY(devAlloc(&ex->d_nSel, B));
+    FT_TRY(devAlloc(&ex->d_keys, B * g.maxKp));
+    FT_TRY(devAlloc(&ex->d_desc, B * g.maxKp * 32));
+    FT_TRY(pinAlloc(&ex->h_l0, B));
+    FT_TRY(pinAlloc(&ex->h_cand, B * g.candPerSlot, hipHostMallocMapped | hipHostMallocCoherent));
+    FT_TRY(pinAlloc(&ex->h_candCount, B * g.nlevels, hipHostMallocMapped | hipHostMallocCoherent));
+    FT_TRY(pinAlloc(&ex->h_sel, B * g.maxKp));
+    FT_TRY(pinAlloc(&ex->h_nSel, B));
+    FT_TRY(pinAlloc(&ex->h_keys, B * g.maxKp));
+    FT_TRY(pinAlloc(&ex->h_desc, B * g.maxKp * 32));
+    {
+        void *dp = nullptr;
+        hipError_t e = hipHostGetDevicePointer(&dp, ex->h_cand, 0);
+        if (e == hipSuccess) {
+            ex->d_cand = (uint32_t *)dp;
+            e = hipHostGetDevicePointer(&dp, ex->h_candCount, 0);
+            ex->d_candCount = (int *)dp;
+        }
+        if (e != hipSuccess) {
+            freeAll(ex);
+            delete ex;
+            return ft_hip_fail(e, "hipHostGetDevicePointer", __FILE__, __LINE__);
+        }
+    }
+    {
+        hipError_t e = hipMemcpy(ex->d_taps, taps.data(), taps.size() * sizeof(FtTap), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(ex->d_nSel, 0, sizeof(int) * B);
+        if (e != hipSuccess) {
+            freeAll(ex);
+            delete ex;
+            return ft_hip_fail(e, "upload resize tables", __FILE__, __LINE__);
+        }
+    }
+    memset(ex->h_nSel, 0, sizeof(int) * B);
+#undef FT_TRY
+    *out = ex;
+    return FT_OK;
+}
+
+int ft_octree_distribute(const int *xys, int n, int minX, int maxX, int minY, int maxY, int N, int *out_idx,
+                         int capacity, int *n_out) {
+    FT_REQUIRE(n >= 0 && (n == 0 || xys) && n_out, "ft_octree_distribute: bad argument");
+    FT_REQUIRE(maxX > minX && maxY > minY && N >= 0, "ft_octree_distribute: empty region");
+    std::vector<uint32_t> packed(n);
+    for (int i = 0; i < n; i++) {
+        FT_REQUIRE(xys[3 * i] >= 0 && xys[3 * i] < 4096 && xys[3 * i + 1] >= 0 && xys[3 * i + 1] < 4096 &&
+                       xys[3 * i + 2] >= 0 && xys[3 * i + 2] < 256,
+                   "ft_octree_distribute: candidate out of range");
+        packed[i] = ft_pack_cand(xys[3 * i], xys[3 * i + 1], xys[3 * i + 2]);
+    }
+    ft::OctreeWorkspace ws;
+    std::vector<int> keep;
+    const int k = ft::distribute_octree(packed.data(), n, minX, maxX, minY, maxY, N, ws, keep);
+    *n_out = k;
+    if (k > capacity) {
+        ft_set_error("ft_octree_distribute: capacity too small");
+        return FT_ERR_CAPACITY;
+    }
+    for (int i = 0; i < k; i++) out_idx[i] = keep[i];
+    return FT_OK;
+}
+
+int ft_level_geometry(int width, int height, int nfeatures, float scale_factor, int nlevels, int *level_w,
+                      int *level_h, int *quota, int *n_cols, int *n_rows, int *w_cell, int *h_cell) {
+    FT_REQUIRE(nlevels >= 1 && nlevels <= FT_MAX_LEVELS && scale_factor > 1.0f && nfeatures > 0, "bad parameters");
+    ft_extractor ex;
+    ex.nfeatures = nfeatures;
+    ex.scaleFactor = scale_factor;
+    ex.nlevels = nlevels;
+    ex.width = width;
+    ex.height = height;
+    std::vector<FtTap> taps;
+    int rc = buildGeometry(&ex, taps);
+    if (rc != FT_OK) return rc;
+    for (int l = 0; l < nlevels; l++) {
+        const FtLevelGeom &v = ex.geom.lv[l];
+        if (level_w) level_w[l] = v.w;
+        if (level_h) level_h[l] = v.h;
+        if (quota) quota[l] = ex.quota[l];
+        if (n_cols) n_cols[l] = v.nCols;
+        if (n_rows) n_rows[l] = v.nRows;
+        if (w_cell) w_cell[l] = v.wCell;
+        if (h_cell) h_cell[l] = v.hCell;
+    }
+    return FT_OK;
+}
+
+int ft_extractor_destroy(ft_extractor *ex) {
+    if (!ex) return FT_OK;
+    freeAll(ex);
+    delete ex;
+    return FT_OK;
+}
+
+int ft_extractor_levels(const ft_extractor *ex) { return ex ? ex->nlevels : 0; }
+int ft_extractor_max_batch(const ft_extractor *ex) { return ex ? ex->maxBatch : 0; }
+int ft_extractor_max_keypoints(const ft_extractor *ex) { return ex ? ex->geom.maxKp : 0; }
+
+int ft_extractor_scale_factors(const ft_extractor *ex, float *scale, float *inv_scale, float *sigma2,
+                               float *inv_sigma2) {
+    FT_REQUIRE(ex, "null extractor");
+    for (int i = 0; i < ex->nlevels; i++) {
+        if (scale) scale[i] = ex->sf[i];
+        if (inv_scale) inv_scale[i] = ex->invsf[i];
+        if (sigma2) sigma2[i] = ex->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = ex->invsigma2[i];
+    }
+    return FT_OK;
+}
+
+int ft_extractor_features_per_level(const ft_extractor *ex, int *quota) {
+    FT_REQUIRE(ex && quota, "null argument");
+    for (int i = 0; i < ex->nlevels; i++) quota[i] = ex->quota[i];
+    return FT_OK;
+}
+
+int ft_extractor_level_size(const ft_extractor *ex, int level, int *width, int *height) {
+    FT_REQUIRE(ex && level >= 0 && level < ex->nlevels, "level out of range");
+    if (width) *width = ex->geom.lv[level].w;
+    if (height) *height = ex->geom.lv[level].h;
+    return FT_OK;
+}
+
+int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
+                     int height, int stride, int lap0, int lap1, ft_keypoint *keypoints, uint8_t *descriptors,
+                     int capacity, int *n_keypoints, int *n_mono) {
+    FT_REQUIRE(ex, "null extractor");
+    if (!images || width <= 0 || height <= 0) {
+        ft_set_error("extract: empty image");
+        return FT_ERR_EMPTY;
+    }
+    FtTimer tAll;
+    int rc = ft_extract_stage_a(ex, images, batch, on_device, width, height, stride);
+    if (rc != FT_OK) return rc;
+    FT_HIP(hipStreamSynchronize(ex->stream));
+    ex->ctx->addStat("extract.stageA(pyramid+fast)", tAll.ms());
+    FtTimer tO;
+    rc = ft_extract_octree(ex, batch);
+    if (rc != FT_OK) return rc;
+    ex->ctx->addStat("extract.octree(host)", tO.ms());
+    FtTimer tB;
+    rc = ft_extract_stage_b(ex, batch);
+    if (rc != FT_OK) return rc;
+    rc = downloadResults(ex, batch);
+    if (rc != FT_OK) return rc;
+    ex->ctx->addStat("extract.stageB(orient+desc+d2h)", tB.ms());
+    rc = assembleOutputs(ex, batch, lap0, lap1, keypoints, descriptors, capacity, n_keypoints, n_mono);
+    ex->ctx->addStat("extract.total", tAll.ms());
+    return rc;
+}
+
+int ft_extract(ft_extractor *ex, const uint8_t *image, int width, int height, int stride, int lap0, int lap1,
+               ft_keypoint *keypoints, uint8_t *descriptors, int capacity, int *n_keypoints, int *n_mono) {
+    if (!image || width <= 0 || height <= 0) {
+        ft_set_error("extract: empty image");
+        return FT_ERR_EMPTY;
+    }
+    const uint8_t *imgs[1] = {image};
+    return ft_extract_batch(ex, imgs, 1, 0, width, height, stride, lap0, lap1, keypoints, descriptors, capacity,
+                            n_keypoints, n_mono);
+}
+
+int ft_extractor_device_level(ft_extractor *ex, int slot, int level, const uint8_t **dptr, int *pitch) {
+    FT_REQUIRE(ex && dptr && pitch, "null argument");
+    FT_REQUIRE(slot >= 0 && slot < ex->lastBatch, "slot holds no image");
+    FT_REQUIRE(level >= 0 && level < ex->nlevels, "level out of range");
+    const FtGeom &g = ex->geom;
+    if (level == 0) {
+        *dptr = ex->h_l0[slot];
+        *pitch = ex->l0pitch;
+    } else {
+        *dptr = ex->d_pyr + (size_t)slot * g.pyrPerSlot + g.lv[level].off;
+        *pitch = g.lv[level].pitch;
+    }
+    return FT_OK;
+}
+
+int ft_extractor_download_level(ft_extractor *ex, int slot, int level, uint8_t *dst, int dst_stride) {
+    FT_REQUIRE(dst, "null destination");
+    const uint8_t *src = nullptr;
+    int pitch = 0;
+    int rc = ft_extractor_device_level(ex, slot, level, &src, &pitch);
+    if (rc != FT_OK) return rc;
+    rc = ft_set_device(ex->ctx);
+    if (rc != FT_OK) return rc;
+    const FtLevelGeom &v = ex->geom.lv[level];
+    FT_REQUIRE(dst_stride >= v.w, "destination stride smaller than the level width");
+    FT_HIP(hipStreamSynchronize(ex->stream));
+    FT_HIP(hipMemcpy2D(dst, dst_stride, src, pitch, v.w, v.h, hipMemcpyDeviceToHost));
+    return FT_OK;
+}
+
+int ft_extractor_download_candidates(ft_extractor *ex, int slot, int level, int *xys, int capacity, int *n) {
+    FT_REQUIRE(ex && n, "null argument");
+    FT_REQUIRE(slot >= 0 && slot < ex->lastBatch, "slot holds no image");
+    FT_REQUIRE(level >= 0 && level < ex->nlevels, "level out of range");
+    int rc = ft_set_device(ex->ctx);
+    if (rc != FT_OK) return rc;
+    FT_HIP(hipStreamSynchronize(ex->stream));
+    const FtGeom &g = ex->geom;
+    const int cnt = ex->h_candCount[slot * g.nlevels + level];
+    *n = cnt;
+    if (xys) {
+        const uint32_t *c = ex->h_cand + (size_t)slot * g.candPerSlot + g.lv[level].candBase;
+        for (int i = 0; i < cnt && i < capacity; i++) {
+            xys[3 * i] = (int)(c[i] & 0xfffu);
+            xys[3 * i + 1] = (int)((c[i] >> 12) & 0xfffu);
+            xys[3 * i + 2] = (int)(c[i] >> 24);
+        }
+    }
+    return FT_OK;
+}
+
+}  // extern "C"

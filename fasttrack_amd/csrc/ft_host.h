@@ -1,0 +1,95 @@
+// Host-side object definitions behind the opaque C handles.
+#pragma once
+
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ft_internal.h"
+#include "octree.h"
+#include "thread_pool.h"
+
+struct ft_context {
+    int device = 0;
+    std::string deviceName;
+    ft::ThreadPool *pool = nullptr;
+    hipStream_t stream = nullptr;  // context-level stream for the stand-alone matchers
+    // grow-only scratch of the stand-alone matchers (one call at a time per context)
+    std::mutex matchMutex;
+    void *scratchDev = nullptr, *scratchPin = nullptr;
+    size_t scratchDevBytes = 0, scratchPinBytes = 0;
+    std::mutex statsMutex;
+    std::map<std::string, std::pair<double, long>> stats;  // name -> (total ms, calls)
+    void addStat(const char *name, double ms) {
+        std::lock_guard<std::mutex> lk(statsMutex);
+        auto &s = stats[name];
+        s.first += ms;
+        s.second += 1;
+    }
+};
+
+struct FtTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+
+struct ft_extractor {
+    ft_context *ctx = nullptr;
+    int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, width = 0, height = 0, maxBatch = 0;
+    float scaleFactor = 1.2f;
+    std::vector<float> sf, invsf, sigma2, invsigma2;
+    std::vector<int> quota;
+    std::vector<int> levelMax;  // per-level bound of octree results
+    FtGeom geom{};
+    hipStream_t stream = nullptr;
+    // device buffers
+    uint8_t *d_pyr = nullptr;
+    FtTap *d_taps = nullptr;
+    int *d_cellCount = nullptr;
+    uint32_t *d_stage = nullptr;
+    const uint8_t **d_l0 = nullptr;
+    const uint8_t **h_l0 = nullptr;  // pinned
+    float *d_sf = nullptr;           // scale factors on device [nlevels] then inverse [nlevels]
+    // host-mapped pinned buffers written by the device
+    uint32_t *h_cand = nullptr, *d_cand = nullptr;
+    int *h_candCount = nullptr, *d_candCount = nullptr;
+    // selected keypoints host -> device
+    FtSelKp *h_sel = nullptr, *d_sel = nullptr;
+    int *h_nSel = nullptr, *d_nSel = nullptr;
+    // results device -> host
+    ft_keypoint *d_keys = nullptr, *h_keys = nullptr;
+    uint8_t *d_desc = nullptr, *h_desc = nullptr;
+    // scratch of the host-array stereo API (ft_stereo_match), allocated on first use
+    ft_keypoint *d_stKeys = nullptr;  // [2 * maxKp] left then right
+    uint8_t *d_stDesc = nullptr;      // [2 * maxKp * 32]
+    float *d_stOut = nullptr;         // [2 * maxKp] uright then depth
+    int *d_stInt = nullptr;           // [2 * stCap + 4] sad, hamming idx, then nL nR nMatches
+    int stCap = 0;
+    // state of the last call (consumed by the stereo matcher)
+    int lastBatch = 0;
+    int l0pitch = 0;
+    bool l0External = false;
+};
+
+struct ft_stereo_frontend {
+    ft_context *ctx = nullptr;
+    ft_extractor *exL = nullptr, *exR = nullptr;
+    float mbf = 0, mb = 0;
+    int capacity = 0;
+    float *d_uright = nullptr, *d_depth = nullptr, *h_uright = nullptr, *h_depth = nullptr;
+    int *d_sad = nullptr, *d_nMatches = nullptr, *h_nMatches = nullptr;
+    hipEvent_t evR = nullptr;
+};
+
+int ft_set_device(const ft_context *ctx);
+// stage A: pyramid + FAST + ordered compaction (async on ex->stream)
+int ft_extract_stage_a(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
+                       int height, int stride);
+// host octree over the candidates of the last stage A (after the stream is synchronised)
+int ft_extract_octree(ft_extractor *ex, int batch);
+// stage B: upload selection, orientation + descriptors -> d_keys/d_desc (async on ex->stream)
+int ft_extract_stage_b(ft_extractor *ex, int batch);

@@ -1,0 +1,105 @@
+// Internal types shared by the host orchestration (.cpp) and the HIP kernels (.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/fasttrack_amd.h"
+
+#define FT_MAX_LEVELS 12
+#define FT_EDGE_THRESHOLD 19  // include/ORBextractor.h:31 of the reference
+#define FT_PATCH_SIZE 31
+#define FT_HALF_PATCH 15
+#define FT_TH_HIGH 100  // src/ORBmatcher.cc:41
+#define FT_TH_LOW 50
+#define FT_HISTO_LENGTH 30
+#define FT_GRID_COLS 64  // include/Frame.h:47
+#define FT_GRID_ROWS 48
+
+// Geometry of one pyramid level; identical for every image slot of an extractor.
+struct FtLevelGeom {
+    int w, h, pitch;   // level size and row pitch (bytes) inside the slot's pyramid buffer
+    int off;           // byte offset of the level inside the slot's pyramid buffer (level 0 unused
+                       // when the caller's frame is already in HBM)
+    int maxBX, maxBY;  // w-16, h-16 (minBorder is always 16 = EDGE_THRESHOLD-3)
+    int nCols, nRows, wCell, hCell;  // FAST cell grid (ORBextractor.cc:1128-1134)
+    int cellBase;      // first cell of this level in the per-slot cell arrays
+    int cellCap;       // staging entries per cell of this level
+    int stageBase;     // entry offset of the level's first cell in the slot's staging buffer
+    int candBase;      // entry offset of the level's dense candidate list
+    int candCap;       // capacity of that list
+    int xtab, ytab;    // offsets of the resize tables of this level (level >= 1)
+    int area2x;        // level is an exact 2x decimation of the previous one (INTER_AREA path)
+};
+
+struct FtGeom {
+    int nlevels;
+    int totalCells;
+    int stagePerSlot;  // staging entries per slot
+    int candPerSlot;   // dense candidate entries per slot
+    int pyrPerSlot;    // pyramid bytes per slot
+    int maxKp;         // keypoint capacity per slot
+    float sf[FT_MAX_LEVELS];     // mvScaleFactor
+    float invsf[FT_MAX_LEVELS];  // mvInvScaleFactor
+    FtLevelGeom lv[FT_MAX_LEVELS];
+};
+
+// candidate / keypoint packing: x | y << 12 | score << 24 (x, y < 4096; score <= 254)
+static inline __host__ __device__ uint32_t ft_pack_cand(int x, int y, int s) {
+    return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24);
+}
+
+// selected keypoint handed from the host octree to the orientation/descriptor kernel
+struct FtSelKp {
+    short x, y;  // level coordinates (border included)
+    short level;
+    short response;
+};
+
+// resize tap: source index and the two 11-bit fixed-point weights
+struct FtTap {
+    short s, a0, a1, pad;
+};
+
+void ft_set_error(const std::string &msg);
+int ft_hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define FT_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t _e = (call);                                                   \
+        if (_e != hipSuccess) return ft_hip_fail(_e, #call, __FILE__, __LINE__);  \
+    } while (0)
+
+// ---- kernel launchers (kernels_extract.hip) -------------------------------------------------
+// l0: device array [batch] of level-0 pointers; pyr: base of the slot pyramids
+int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
+                      uint8_t *pyr, const FtTap *taps);
+int ft_launch_fast(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
+                   const uint8_t *pyr, int iniTh, int minTh, int *cellCount, uint32_t *stage, uint32_t *cand,
+                   int *candCount);
+int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
+                          const uint8_t *pyr, const FtSelKp *sel, const int *nSel, ft_keypoint *keys,
+                          uint8_t *desc);
+size_t ft_fast_smem_bytes(const FtGeom &g);
+
+// ---- kernel launchers (kernels_match.hip) ---------------------------------------------------
+struct FtStereoArgs {
+    const ft_keypoint *keysL, *keysR;  // device
+    const uint8_t *descL, *descR;      // device, n x 32
+    const int *nL, *nR;                // device [batch]
+    int capacity;                      // stride (entries) between images in the arrays above
+    float mbf, mb;
+    float *uright, *depth;             // device [batch*capacity]
+    int *sad;                          // device [batch*capacity]
+    int *hamIdx;                       // device [batch*capacity] (debug tap, may be null)
+    int *nMatches;                     // device [batch]
+    int applyMedianCut;
+};
+int ft_launch_stereo(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
+                     const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
+                     const uint8_t *pyrR, const FtStereoArgs &a);
+int ft_launch_fisheye(hipStream_t st, const uint8_t *descL, int nL, const uint8_t *descR, int nR, int *matches,
+                      int *best, int *second);
+int ft_launch_hamming_pairs(hipStream_t st, const uint8_t *a, const uint8_t *b, int n, int *dist);

@@ -1,0 +1,61 @@
+// Device-side views used by the projection-search kernels (kernels_search.hip / search.cpp).
+#pragma once
+
+#include "ft_internal.h"
+
+struct FtDevFrame {
+    int N, Nleft;
+    float mnMinX, mnMinY, mnMaxX, mnMaxY, invW, invH, mbf, mb;
+    const ft_keypoint *keys, *keysR;  // device
+    const uint8_t *desc;              // device N x 32
+    const float *uright;              // device or null
+    const int *holderObs;             // device [N] pre-call Observations() of mvpMapPoints[i] (-1 = none)
+    const int *l2r, *r2l;             // device or null
+    int camModel;
+    float cam[8];
+    float Trl[12];
+    float sf[FT_MAX_LEVELS];
+    int nlevels;
+};
+
+struct FtDevLocalPoints {
+    int M;
+    const uint8_t *skip, *inView, *inViewR;
+    const int *level, *levelR;
+    const float *viewCos, *viewCosR, *projX, *projY, *projXR, *projYR;
+    const uint8_t *desc;
+};
+
+struct FtDevLastPoints {
+    int N;
+    const uint8_t *valid;
+    const float *worldPos;
+    const uint8_t *desc;
+    const int *octave;
+};
+
+// writer lists of the previous pass: head[kp] -> slot s (= 4*point + write kind), next[s]
+struct FtClaims {
+    const int *head, *next;
+    const int *obs;  // Observations() per map point
+};
+
+struct FtPose {
+    float m[12];
+};
+
+struct FtLocalRaw {
+    int *bestDist, *bestDist2, *bestLevel, *bestLevel2, *bestIdx;
+    int *bestDistR, *bestDist2R, *bestLevelR, *bestLevel2R, *bestIdxR;
+};
+struct FtLastRaw {
+    int *bestDist, *bestIdx, *bestDistR, *bestIdxR;
+};
+
+int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v);
+int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
+                           float nnRatio, int *res, const FtLocalRaw &raw);
+int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
+                          const FtPose &Tcw, float th, int forward, int backward, int *res, const FtLastRaw &raw);
+int ft_launch_build_claims(hipStream_t st, const int *res, const int *prevRes, int nPoints, int nKp, int *head,
+                           int *next, int *changed);

@@ -1,0 +1,281 @@
+// HIP kernels of the Hamming matchers for gfx950 (wave64): 256-bit descriptors as 4 x uint64 with
+// __popcll, wave-wide argmin on packed (distance, index) keys so ties resolve exactly like the
+// reference's sequential "dist < bestDist" scans.
+//   k_stereo_match   Frame::ComputeStereoMatches  (reference src/Frame.cc:835-989)
+//   k_stereo_median  the 1.5*1.4*median SAD cut    (src/Frame.cc:991-1004)
+//   k_fisheye_2nn    BFMatcher knnMatch(k=2)+ratio (src/Frame.cc:1231-1255)
+//   k_hamming_pairs  ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2256-2272)
+#include "ft_internal.h"
+
+namespace {
+
+__device__ __forceinline__ const uint8_t *level_ptr(const FtGeom &g, int level, int slot, const uint8_t *const *l0,
+                                                    int l0pitch, const uint8_t *pyr, int &pitch) {
+    if (level == 0) {
+        pitch = l0pitch;
+        return l0[slot];
+    }
+    pitch = g.lv[level].pitch;
+    return pyr + (size_t)slot * g.pyrPerSlot + g.lv[level].off;
+}
+
+__device__ __forceinline__ int hamming256(const unsigned long long a[4], const unsigned long long *b) {
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per left keypoint.
+__global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *const *l0L, const uint8_t *const *l0R,
+                                                      int l0pitchL, int l0pitchR, const uint8_t *pyrL,
+                                                      const uint8_t *pyrR, FtStereoArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.y;
+    const int iL = blockIdx.x * 4 + wave;
+    const int nL = a.nL[slot], nR = a.nR[slot];
+    if (iL >= nL) return;
+    const size_t base = (size_t)slot * a.capacity;
+    float outU = -1.0f, outD = -1.0f;
+    int outSad = -1, outHam = -1;
+    const ft_keypoint kpL = a.keysL[base + iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const int nRows = g.lv[0].h;
+    const int row = (int)vL;
+    const float minZ = a.mb;
+    const float minD = 0.f;
+    const float maxD = __fdiv_rn(a.mbf, minZ);
+    const float minU = __fsub_rn(uL, maxD);
+    const float maxU = __fsub_rn(uL, minD);
+    unsigned long long dL[4];
+    {
+        const unsigned long long *p = (const unsigned long long *)(a.descL + (base + iL) * 32);
+        dL[0] = p[0]; dL[1] = p[1]; dL[2] = p[2]; dL[3] = p[3];
+    }
+    unsigned best = 0xffffffffu;  // (dist << 16) | iR
+    if (row >= 0 && row < nRows && !(maxU < 0)) {
+        for (int iR = lane; iR < nR; iR += 64) {
+            const ft_keypoint kpR = a.keysR[base + iR];
+            // row band of the right keypoint (Frame.cc:852-862): rows floor(y-r) .. ceil(y+r), r = 2*sf[octave]
+            const float r = __fmul_rn(2.0f, g.sf[kpR.octave]);
+            const int maxr = (int)ceilf(__fadd_rn(kpR.y, r));
+            const int minr = (int)floorf(__fsub_rn(kpR.y, r));
+            if (row < minr || row > maxr) continue;
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = hamming256(dL, (const unsigned long long *)(a.descR + (base + iR) * 32));
+                best = min(best, ((unsigned)dist << 16) | (unsigned)iR);
+            }
+        }
+    }
+    best = wave_min_u32(best);
+    const int bestDist = (int)(best >> 16);
+    const int thOrbDist = (FT_TH_HIGH + FT_TH_LOW) / 2;
+    // bestDist starts at TH_HIGH in the reference, so only dist < TH_HIGH ever registers; < thOrbDist is stricter
+    if (best != 0xffffffffu && bestDist < thOrbDist) {
+        const int bestIdxR = (int)(best & 0xffffu);
+        outHam = bestIdxR;
+        const float uR0 = a.keysR[base + bestIdxR].x;
+        const float scaleFactor = g.invsf[levelL];
+        const float scaleduL = roundf(__fmul_rn(kpL.x, scaleFactor));
+        const float scaledvL = roundf(__fmul_rn(kpL.y, scaleFactor));
+        const float scaleduR0 = roundf(__fmul_rn(uR0, scaleFactor));
+        const int w = 5, Ls = 5;
+        int pitchL, pitchR;
+        const uint8_t *imL = level_ptr(g, levelL, slot, l0L, l0pitchL, pyrL, pitchL);
+        const uint8_t *imR = level_ptr(g, levelL, slot, l0R, l0pitchR, pyrR, pitchR);
+        const int lw = g.lv[levelL].w, lh = g.lv[levelL].h;
+        const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)Ls), (float)w);
+        const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)Ls), (float)w), 1.0f);
+        const int yl0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w), xr00 = (int)scaleduR0 - Ls - w;
+        bool ok = !(iniu < 0 || endu >= (float)lw);
+        // windows that would leave the level make cv::Mat::rowRange/colRange throw in the reference;
+        // unreachable for extractor keypoints (>= 19 px inside), guarded against stray reads
+        ok = ok && yl0 >= 0 && yl0 + 2 * w + 1 <= lh && xl0 >= 0 && xl0 + 2 * w + 1 <= lw && xr00 >= 0 &&
+             xr00 + 2 * (w + Ls) + 1 <= lw;
+        if (ok) {
+            // 11x11 left patch: each lane owns pixels lane and lane+64 (< 121)
+            const int p0 = lane, p1 = lane + 64;
+            const int r0 = p0 / 11, c0 = p0 - r0 * 11, r1 = p1 / 11, c1 = p1 - r1 * 11;
+            const int a0 = imL[(size_t)(yl0 + r0) * pitchL + xl0 + c0];
+            const int a1 = p1 < 121 ? imL[(size_t)(yl0 + r1) * pitchL + xl0 + c1] : 0;
+            int bestS = 0x7fffffff, bestinc = 0;
+            float dists[11];
+#pragma unroll
+            for (int s = 0; s < 11; s++) {
+                const int xr = xr00 + s;
+                int d = abs(a0 - (int)imR[(size_t)(yl0 + r0) * pitchR + xr + c0]);
+                if (p1 < 121) d += abs(a1 - (int)imR[(size_t)(yl0 + r1) * pitchR + xr + c1]);
+                d = wave_sum_i32(d);
+                dists[s] = (float)d;
+                if (d < bestS) {
+                    bestS = d;
+                    bestinc = s - Ls;
+                }
+            }
+            if (!(bestinc == -Ls || bestinc == Ls)) {
+                float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+                for (int s = 1; s < 10; s++)
+                    if (s == bestinc + Ls) {
+                        dist1 = dists[s - 1];
+                        dist2 = dists[s];
+                        dist3 = dists[s + 1];
+                    }
+                const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2)));
+                const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3), den);
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = __fmul_rn(g.sf[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+                    float disparity = __fsub_rn(uL, bestuR);
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) {
+                            disparity = 0.01f;
+                            bestuR = (float)((double)uL - 0.01);
+                        }
+                        outD = __fdiv_rn(a.mbf, disparity);
+                        outU = bestuR;
+                        outSad = bestS;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        a.uright[base + iL] = outU;
+        a.depth[base + iL] = outD;
+        a.sad[base + iL] = outSad;
+        if (a.hamIdx) a.hamIdx[base + iL] = outHam;
+    }
+}
+
+// One workgroup per pair: median of the accepted SADs (element size/2 of the sorted list) by a bitwise
+// search on the value, then drop every match with SAD >= 1.5f*1.4f*median.
+__global__ __launch_bounds__(256) void k_stereo_median(FtStereoArgs a) {
+    __shared__ int s_cnt;
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const int nL = a.nL[slot];
+    const size_t base = (size_t)slot * a.capacity;
+    int m = 0;
+    for (int i = tid; i < nL; i += 256) m += a.sad[base + i] >= 0 ? 1 : 0;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    atomicAdd(&s_cnt, m);
+    __syncthreads();
+    const int total = s_cnt;
+    __syncthreads();
+    if (total == 0 || !a.applyMedianCut) {
+        if (tid == 0) a.nMatches[slot] = total;
+        return;
+    }
+    const int k = total / 2;  // 0-based rank in ascending order
+    // smallest v with count(sad <= v) >= k + 1; SAD <= 121*255 < 2^15
+    int lo = 0;
+    for (int bit = 14; bit >= 0; bit--) {
+        const int probe = lo + (1 << bit) - 1;  // is the answer <= probe ?
+        int c = 0;
+        for (int i = tid; i < nL; i += 256) {
+            const int s = a.sad[base + i];
+            c += (s >= 0 && s <= probe) ? 1 : 0;
+        }
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        atomicAdd(&s_cnt, c);
+        __syncthreads();
+        if (s_cnt < k + 1) lo += 1 << bit;
+        __syncthreads();
+    }
+    const float median = (float)lo;
+    const float thDist = __fmul_rn(1.5f * 1.4f, median);
+    int removed = 0;
+    for (int i = tid; i < nL; i += 256) {
+        const int s = a.sad[base + i];
+        if (s >= 0 && !((float)s < thDist)) {
+            a.uright[base + i] = -1.f;
+            a.depth[base + i] = -1.f;
+            a.sad[base + i] = -1;
+            removed++;
+        }
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    atomicAdd(&s_cnt, removed);
+    __syncthreads();
+    if (tid == 0) a.nMatches[slot] = total - s_cnt;
+}
+
+// Brute-force 2-NN: one wave per query, lanes stride over the train set; the two smallest
+// (distance, index) keys of the wave are the reference's (best, second) with earlier index first.
+__global__ __launch_bounds__(256) void k_fisheye_2nn(const uint8_t *descL, int nL, const uint8_t *descR, int nR,
+                                                     int *matches, int *bestOut, int *secondOut) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= nL) return;
+    unsigned long long q[4];
+    {
+        const unsigned long long *p = (const unsigned long long *)(descL + (size_t)i * 32);
+        q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
+    }
+    unsigned k0 = 0xffffffffu, k1 = 0xffffffffu;  // two smallest keys seen by this lane
+    for (int j = lane; j < nR; j += 64) {
+        const unsigned key = ((unsigned)hamming256(q, (const unsigned long long *)(descR + (size_t)j * 32)) << 20) | (unsigned)j;
+        if (key < k0) { k1 = k0; k0 = key; }
+        else if (key < k1) k1 = key;
+    }
+    const unsigned m0 = wave_min_u32(k0);
+    // second smallest overall: lanes whose k0 was the global minimum contribute their k1 instead
+    const unsigned cand = (k0 == m0) ? k1 : k0;
+    const unsigned m1 = wave_min_u32(cand);
+    if (lane == 0) {
+        const int d0 = (int)(m0 >> 20), d1 = (int)(m1 >> 20);
+        int match = -1;
+        if (nR >= 2 && (double)(float)d0 < (double)(float)d1 * 0.7) match = (int)(m0 & 0xfffffu);
+        matches[i] = match;
+        if (bestOut) bestOut[i] = nR >= 1 ? d0 : -1;
+        if (secondOut) secondOut[i] = nR >= 2 ? d1 : -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hamming_pairs(const uint8_t *a, const uint8_t *b, int n, int *dist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long *pa = (const unsigned long long *)(a + (size_t)i * 32);
+    unsigned long long q[4] = {pa[0], pa[1], pa[2], pa[3]};
+    dist[i] = hamming256(q, (const unsigned long long *)(b + (size_t)i * 32));
+}
+
+}  // namespace
+
+int ft_launch_stereo(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
+                     const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
+                     const uint8_t *pyrR, const FtStereoArgs &a) {
+    dim3 grid((a.capacity + 3) / 4, batch, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(k_stereo_match, grid, block, 0, st, g, l0L, l0R, l0pitchL, l0pitchR, pyrL, pyrR, a);
+    hipLaunchKernelGGL(k_stereo_median, dim3(batch), block, 0, st, a);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_fisheye(hipStream_t st, const uint8_t *descL, int nL, const uint8_t *descR, int nR, int *matches,
+                      int *best, int *second) {
+    if (nL <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_fisheye_2nn, dim3((nL + 3) / 4), dim3(256), 0, st, descL, nL, descR, nR, matches, best, second);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_hamming_pairs(hipStream_t st, const uint8_t *a, const uint8_t *b, int n, int *dist) {
+    if (n <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_hamming_pairs, dim3((n + 255) / 256), dim3(256), 0, st, a, b, n, dist);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}

@@ -1,0 +1,391 @@
+// HIP kernels of the two projection searches for gfx950 (wave64).
+//   k_search_local  ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>, th, ...)  (reference
+//                   src/ORBmatcher.cc:49-225 + Frame::GetFeaturesInArea src/Frame.cc:681-747)
+//   k_search_last   ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)  (:1775-1960)
+//
+// One wave per map point; lanes stride over the frame's keypoints and test the 64x48-grid cell window,
+// the level band and the box exactly as GetFeaturesInArea does, so no per-cell lists are needed (the
+// reference's fixed 20-per-cell matrix overflows).  The scan order of the CPU loop,
+// (cell x, cell y, keypoint index), is folded into a 64-bit key (distance, cx, cy, index): the two
+// smallest keys of the wave are the CPU's (best, second best) including which octaves they carry.
+//
+// In-call claiming (a keypoint taken by an earlier map point with Observations() > 0 is skipped by
+// later ones, ORBmatcher.cc:101-103,142) makes the CPU loop sequential.  It is reproduced exactly by a
+// Jacobi iteration on that triangular dependency: every pass recomputes all points in parallel
+// against the writes of the previous pass (per-keypoint linked lists of writers); point i is final
+// after at most i+1 passes and the iteration stops when a pass changes nothing - the unique fixed
+// point is the sequential result.
+#include "ft_search.h"
+
+namespace {
+
+__device__ __forceinline__ int hamming256(const unsigned long long a[4], const unsigned long long *b) {
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+#define KEY_NONE 0xffffffffffffffffull
+__device__ __forceinline__ unsigned long long make_key(int dist, int cx, int cy, int idx) {
+    return ((unsigned long long)dist << 40) | ((unsigned long long)cx << 34) | ((unsigned long long)cy << 28) |
+           (unsigned long long)idx;
+}
+__device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 40); }
+__device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(k & 0xfffffffull); }
+
+// F.mvpMapPoints[kp] && ->Observations() > 0 as seen by map point i: the last writer j < i of the
+// previous pass, else the pre-call holder
+__device__ __forceinline__ bool is_locked(const FtDevFrame &F, const FtClaims &C, int kp, int i) {
+    int best = -1;
+    for (int s = C.head[kp]; s >= 0; s = C.next[s]) {
+        const int j = s >> 2;
+        if (j < i && j > best) best = j;
+    }
+    return best >= 0 ? C.obs[best] > 0 : F.holderObs[kp] > 0;
+}
+
+struct Window {
+    int minCX, maxCX, minCY, maxCY;
+    bool empty;
+};
+
+// Frame::GetFeaturesInArea cell window (src/Frame.cc:689-711)
+__device__ __forceinline__ Window cell_window(const FtDevFrame &F, float x, float y, float r) {
+    Window w;
+    w.empty = false;
+    w.minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, F.mnMinX), r), F.invW)));
+    if (w.minCX >= FT_GRID_COLS) w.empty = true;
+    w.maxCX = min(FT_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, F.mnMinX), r), F.invW)));
+    if (w.maxCX < 0) w.empty = true;
+    w.minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, F.mnMinY), r), F.invH)));
+    if (w.minCY >= FT_GRID_ROWS) w.empty = true;
+    w.maxCY = min(FT_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, F.mnMinY), r), F.invH)));
+    if (w.maxCY < 0) w.empty = true;
+    return w;
+}
+
+// geometric part of GetFeaturesInArea for one keypoint: grid cell (Frame::PosInGrid, :749-759) inside
+// the window, level band, box test.  Returns false when the keypoint is not a candidate.
+__device__ __forceinline__ bool in_area(const FtDevFrame &F, const ft_keypoint &kp, const Window &w, float x, float y,
+                                        float r, int minLevel, int maxLevel, int &cx, int &cy) {
+    cx = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.mnMinX), F.invW));
+    cy = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.mnMinY), F.invH));
+    if (cx < 0 || cx >= FT_GRID_COLS || cy < 0 || cy >= FT_GRID_ROWS) return false;  // never entered the grid
+    if (cx < w.minCX || cx > w.maxCX || cy < w.minCY || cy > w.maxCY) return false;
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    if (checkLevels) {
+        if (kp.octave < minLevel) return false;
+        if (maxLevel >= 0 && kp.octave > maxLevel) return false;
+    }
+    const float dx = __fsub_rn(kp.x, x), dy = __fsub_rn(kp.y, y);
+    return fabsf(dx) < r && fabsf(dy) < r;
+}
+
+// two smallest keys of the wave (k0 < k1)
+__device__ __forceinline__ void wave_two_min(unsigned long long &k0, unsigned long long &k1) {
+    const unsigned long long m0 = wave_min_u64(k0);
+    const unsigned long long cand = (k0 == m0) ? k1 : k0;
+    const unsigned long long m1 = wave_min_u64(cand);
+    k0 = m0;
+    k1 = m1;
+}
+
+__global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPoints P, FtClaims C, float th,
+                                                      float nnRatio, int *res, FtLocalRaw raw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= P.M) return;
+    int primL = -1, sideL = -1, primR = -1, sideR = -1;
+    int bd = 256, bd2 = 256, bl = -1, bl2 = -1, bi = -1;
+    int bdr = 256, bd2r = 256, blr = -1, bl2r = -1, bir = -1;
+    bool skipRight = false;
+    unsigned long long q[4];
+    {
+        const unsigned long long *p = (const unsigned long long *)(P.desc + (size_t)i * 32);
+        q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
+    }
+    if (!P.skip[i]) {
+        const int nLeft = F.Nleft == -1 ? F.N : F.Nleft;
+        if (P.inView[i]) {
+            const int level = P.level[i];
+            float r = ((double)P.viewCos[i] > 0.998) ? 2.5f : 4.0f;  // RadiusByViewingCos, ORBmatcher.cc:314-320
+            if ((double)th != 1.0) r = __fmul_rn(r, th);
+            const float rad = __fmul_rn(r, F.sf[level]);
+            const float x = P.projX[i], y = P.projY[i];
+            const Window w = cell_window(F, x, y, rad);
+            unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
+            if (!w.empty) {
+                for (int idx = lane; idx < nLeft; idx += 64) {
+                    const ft_keypoint kp = F.keys[idx];
+                    int cx, cy;
+                    if (!in_area(F, kp, w, x, y, rad, level - 1, level, cx, cy)) continue;
+                    if (is_locked(F, C, idx, i)) continue;
+                    if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
+                        const float er = fabsf(__fsub_rn(P.projXR[i], F.uright[idx]));
+                        if (er > rad) continue;
+                    }
+                    const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
+                    const unsigned long long key = make_key(dist, cx, cy, idx);
+                    if (key < k0) { k1 = k0; k0 = key; }
+                    else if (key < k1) k1 = key;
+                }
+            }
+            wave_two_min(k0, k1);
+            if (k0 != KEY_NONE) {
+                bd = key_dist(k0);
+                bi = key_idx(k0);
+                bl = F.keys[bi].octave;
+            }
+            if (k1 != KEY_NONE) {
+                bd2 = key_dist(k1);
+                bl2 = F.keys[key_idx(k1)].octave;
+            }
+            if (bd <= FT_TH_HIGH) {
+                if (bl == bl2 && (float)bd > __fmul_rn(nnRatio, (float)bd2)) {
+                    skipRight = true;  // the reference's `continue` also skips the right-camera block
+                } else {
+                    primL = bi;
+                    if (F.Nleft != -1 && F.l2r[bi] != -1) sideL = F.l2r[bi] + F.Nleft;
+                }
+            }
+        }
+        if (F.Nleft != -1 && P.inViewR[i] && !skipRight) {
+            const int level = P.levelR[i];
+            if (level != -1) {
+                const float r = ((double)P.viewCosR[i] > 0.998) ? 2.5f : 4.0f;
+                const float rad = __fmul_rn(r, F.sf[level]);
+                const float x = P.projXR[i], y = P.projYR[i];
+                const Window w = cell_window(F, x, y, rad);
+                const int nRight = F.N - F.Nleft;
+                unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
+                if (!w.empty) {
+                    for (int idx = lane; idx < nRight; idx += 64) {
+                        const ft_keypoint kp = F.keysR[idx];
+                        int cx, cy;
+                        if (!in_area(F, kp, w, x, y, rad, level - 1, level, cx, cy)) continue;
+                        const int g = idx + F.Nleft;
+                        // this point's own left-block side write precedes its right-block search
+                        const bool locked = (g == sideL) ? (C.obs[i] > 0) : is_locked(F, C, g, i);
+                        if (locked) continue;
+                        const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)g * 32));
+                        const unsigned long long key = make_key(dist, cx, cy, idx);
+                        if (key < k0) { k1 = k0; k0 = key; }
+                        else if (key < k1) k1 = key;
+                    }
+                }
+                wave_two_min(k0, k1);
+                if (k0 != KEY_NONE) {
+                    bdr = key_dist(k0);
+                    bir = key_idx(k0);
+                    blr = F.keysR[bir].octave;
+                }
+                if (k1 != KEY_NONE) {
+                    bd2r = key_dist(k1);
+                    bl2r = F.keysR[key_idx(k1)].octave;
+                }
+                if (bdr <= FT_TH_HIGH && !(blr == bl2r && (float)bdr > __fmul_rn(nnRatio, (float)bd2r))) {
+                    if (F.r2l[bir] != -1) sideR = F.r2l[bir];
+                    primR = bir + F.Nleft;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        res[4 * i] = primL;
+        res[4 * i + 1] = sideL;
+        res[4 * i + 2] = primR;
+        res[4 * i + 3] = sideR;
+        raw.bestDist[i] = bd; raw.bestDist2[i] = bd2; raw.bestLevel[i] = bl; raw.bestLevel2[i] = bl2; raw.bestIdx[i] = bi;
+        raw.bestDistR[i] = bdr; raw.bestDist2R[i] = bd2r; raw.bestLevelR[i] = blr; raw.bestLevel2R[i] = bl2r; raw.bestIdxR[i] = bir;
+    }
+}
+
+// camera models: src/CameraModels/Pinhole.cpp:43-49, KannalaBrandt8.cpp:67-84
+__device__ __forceinline__ void project_cam(const FtDevFrame &F, const float p[3], float uv[2]) {
+    if (F.camModel == 0) {
+        uv[0] = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[0], p[0]), p[2]), F.cam[2]);
+        uv[1] = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[1], p[1]), p[2]), F.cam[3]);
+    } else {
+        const float x2y2 = __fadd_rn(__fmul_rn(p[0], p[0]), __fmul_rn(p[1], p[1]));
+        const float theta = atan2f(__fsqrt_rn(x2y2), p[2]);
+        const float psi = atan2f(p[1], p[0]);
+        const float t2 = __fmul_rn(theta, theta);
+        const float t3 = __fmul_rn(theta, t2);
+        const float t5 = __fmul_rn(t3, t2);
+        const float t7 = __fmul_rn(t5, t2);
+        const float t9 = __fmul_rn(t7, t2);
+        const float r = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(theta, __fmul_rn(F.cam[4], t3)), __fmul_rn(F.cam[5], t5)),
+                                            __fmul_rn(F.cam[6], t7)),
+                                  __fmul_rn(F.cam[7], t9));
+        uv[0] = __fadd_rn(__fmul_rn(__fmul_rn(F.cam[0], r), cosf(psi)), F.cam[2]);
+        uv[1] = __fadd_rn(__fmul_rn(__fmul_rn(F.cam[1], r), sinf(psi)), F.cam[3]);
+    }
+}
+
+__device__ __forceinline__ void transform34(const float *T, const float x[3], float y[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        y[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4 * r], x[0]), __fmul_rn(T[4 * r + 1], x[1])),
+                                   __fmul_rn(T[4 * r + 2], x[2])),
+                         T[4 * r + 3]);
+}
+
+__global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoints Lp, FtClaims C, FtPose Tcw, float th,
+                                                     int bForward, int bBackward, int *res, FtLastRaw raw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= Lp.N) return;
+    int primL = -1, primR = -1;
+    int bd = 256, bi = -1, bdr = 256, bir = -1;
+    if (Lp.valid[i]) {
+        float xw[3] = {Lp.worldPos[3 * i], Lp.worldPos[3 * i + 1], Lp.worldPos[3 * i + 2]};
+        float xc[3];
+        transform34(Tcw.m, xw, xc);
+        const float invzc = (float)(1.0 / (double)xc[2]);
+        float uv[2];
+        bool go = !(invzc < 0);
+        if (go) {
+            project_cam(F, xc, uv);
+            if (uv[0] < F.mnMinX || uv[0] > F.mnMaxX) go = false;
+            if (uv[1] < F.mnMinY || uv[1] > F.mnMaxY) go = false;
+        }
+        if (go) {
+            const int oct = Lp.octave[i];
+            const float radius = __fmul_rn(th, F.sf[oct]);
+            int minLevel, maxLevel;
+            if (bForward) { minLevel = oct; maxLevel = -1; }
+            else if (bBackward) { minLevel = 0; maxLevel = oct; }
+            else { minLevel = oct - 1; maxLevel = oct + 1; }
+            unsigned long long q[4];
+            {
+                const unsigned long long *p = (const unsigned long long *)(Lp.desc + (size_t)i * 32);
+                q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
+            }
+            const int nLeft = F.Nleft == -1 ? F.N : F.Nleft;
+            const Window w = cell_window(F, uv[0], uv[1], radius);
+            unsigned long long k0 = KEY_NONE;
+            int anyCand = 0;
+            if (!w.empty) {
+                for (int idx = lane; idx < nLeft; idx += 64) {
+                    const ft_keypoint kp = F.keys[idx];
+                    int cx, cy;
+                    if (!in_area(F, kp, w, uv[0], uv[1], radius, minLevel, maxLevel, cx, cy)) continue;
+                    anyCand = 1;
+                    if (is_locked(F, C, idx, i)) continue;
+                    if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
+                        const float ur = __fsub_rn(uv[0], __fmul_rn(F.mbf, invzc));
+                        const float er = fabsf(__fsub_rn(ur, F.uright[idx]));
+                        if (er > radius) continue;
+                    }
+                    const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
+                    const unsigned long long key = make_key(dist, cx, cy, idx);
+                    k0 = key < k0 ? key : k0;
+                }
+            }
+            anyCand = __any(anyCand);
+            k0 = wave_min_u64(k0);
+            // `if(vIndices2.empty()) continue;` (ORBmatcher.cc:1836) also skips the right-camera block
+            if (anyCand) {
+                if (k0 != KEY_NONE) {
+                    bd = key_dist(k0);
+                    bi = key_idx(k0);
+                }
+                if (bd <= FT_TH_HIGH) primL = bi;
+                if (F.Nleft != -1) {
+                    float xr[3], uvr[2];
+                    transform34(F.Trl, xc, xr);
+                    project_cam(F, xr, uvr);
+                    const Window wr = cell_window(F, uvr[0], uvr[1], radius);
+                    const int nRight = F.N - F.Nleft;
+                    unsigned long long kr = KEY_NONE;
+                    if (!wr.empty) {
+                        for (int idx = lane; idx < nRight; idx += 64) {
+                            const ft_keypoint kp = F.keysR[idx];
+                            int cx, cy;
+                            if (!in_area(F, kp, wr, uvr[0], uvr[1], radius, minLevel, maxLevel, cx, cy)) continue;
+                            if (is_locked(F, C, idx + F.Nleft, i)) continue;
+                            const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)(idx + F.Nleft) * 32));
+                            const unsigned long long key = make_key(dist, cx, cy, idx);
+                            kr = key < kr ? key : kr;
+                        }
+                    }
+                    kr = wave_min_u64(kr);
+                    if (kr != KEY_NONE) {
+                        bdr = key_dist(kr);
+                        bir = key_idx(kr);
+                    }
+                    if (bdr <= FT_TH_HIGH) primR = bir + F.Nleft;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        res[4 * i] = primL;
+        res[4 * i + 1] = -1;
+        res[4 * i + 2] = primR;
+        res[4 * i + 3] = -1;
+        raw.bestDist[i] = bd; raw.bestIdx[i] = bi; raw.bestDistR[i] = bdr; raw.bestIdxR[i] = bir;
+    }
+}
+
+// rebuild the per-keypoint writer lists from this pass's results and flag any change against the
+// previous pass
+__global__ __launch_bounds__(256) void k_build_claims(const int *res, const int *prevRes, int n4, int *head, int *next,
+                                                      int *changed) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n4) return;
+    const int kp = res[s];
+    if (kp != prevRes[s]) atomicOr(changed, 1);
+    if (kp >= 0) next[s] = atomicExch(&head[kp], s);
+}
+
+__global__ __launch_bounds__(256) void k_fill_i32(int *p, int n, int v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v) {
+    if (n <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, st, p, n, v);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
+                           float nnRatio, int *res, const FtLocalRaw &raw) {
+    if (P.M <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_search_local, dim3((P.M + 3) / 4), dim3(256), 0, st, F, P, C, th, nnRatio, res, raw);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
+                          const FtPose &Tcw, float th, int forward, int backward, int *res, const FtLastRaw &raw) {
+    if (L.N <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_search_last, dim3((L.N + 3) / 4), dim3(256), 0, st, F, L, C, Tcw, th, forward, backward, res, raw);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_build_claims(hipStream_t st, const int *res, const int *prevRes, int nPoints, int nKp, int *head,
+                           int *next, int *changed) {
+    int rc = ft_launch_fill_i32(st, head, nKp, -1);
+    if (rc != FT_OK) return rc;
+    rc = ft_launch_fill_i32(st, changed, 1, 0);
+    if (rc != FT_OK) return rc;
+    const int n4 = 4 * nPoints;
+    if (n4 > 0) hipLaunchKernelGGL(k_build_claims, dim3((n4 + 255) / 256), dim3(256), 0, st, res, prevRes, n4, head, next, changed);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}

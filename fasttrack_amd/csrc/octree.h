@@ -1,0 +1,41 @@
+// Host octree keypoint distribution - the serial stage that stays on the host in both branches of the
+// reference (SURVEY.md section 3 "Hot loops", section 8 row a5).  Semantics of
+// ORBextractor::DistributeOctTree / ExtractorNode::DivideNode / compareNodes
+// (reference src/ORBextractor.cc:660-884, :510-566, :626-641): same node visiting order, same
+// front-insertion order, same std::sort call on the same (size, UL.x) sequence, same first-maximum
+// pick - so the retained keypoints AND their output order are identical.
+//
+// Implementation is index based: candidates are never copied; every node owns a sub-range of one
+// permutation array that is stably 4-way partitioned in place when the node splits, and the
+// std::list of the reference becomes an intrusive doubly linked list over a node pool.
+#pragma once
+
+#include <stdint.h>
+
+#include <utility>
+#include <vector>
+
+namespace ft {
+
+struct OctreeWorkspace {
+    struct Node {
+        int x0, y0, x1, y1;  // UL = (x0,y0), BR = (x1,y1)
+        int begin, end;      // candidate sub-range in perm
+        int prev, next;      // list links (-1 = none)
+        bool noMore;
+    };
+    std::vector<Node> pool;
+    std::vector<int> perm, scratch;
+    std::vector<std::pair<int, int>> sizeAndNode, prevSizeAndNode;  // (size, node index)
+};
+
+// cand: n packed candidates (x | y<<12 | score<<24), coordinates relative to (minX, minY), in the
+// emission order of the FAST stage.  Appends the indices of the retained candidates to `out` in the
+// reference's result order and returns how many were retained.
+int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
+                      OctreeWorkspace &ws, std::vector<int> &out);
+
+// upper bound of what distribute_octree can return for a level (used to size output buffers)
+int octree_max_result(int minX, int maxX, int minY, int maxY, int N);
+
+}  // namespace ft

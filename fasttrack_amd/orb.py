@@ -1,0 +1,391 @@
+"""Python driver over the C ABI, mirroring the reference's operator interface for the hot path:
+
+  ORBextractor            <- ORB_SLAM3::ORBextractor        (reference include/ORBextractor.h:100-197)
+  StereoFrontend          <- Frame::Frame(stereo) extraction threads + ComputeStereoMatches (src/Frame.cc:102-230)
+  KernelController.*      <- KernelController::launch*      (reference include/Kernels/KernelController.h:31-46)
+
+Python is only the test / bench driver here: every number comes out of the HIP kernels behind
+libfasttrack_amd.so.  The C++ mirror for ORB-SLAM3 builds is include/fasttrack_amd.hpp.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import KP_DTYPE, FastTrackError, check, lib, ptr
+
+__all__ = ["Context", "ORBextractor", "StereoFrontend", "KernelController", "FrameView", "KP_DTYPE", "FastTrackError"]
+
+
+class Context:
+    """One per GPU: KernelController::setCUDADevice + initializeKernels (KernelController.h:15-25)."""
+
+    def __init__(self, device: int = 0, host_threads: int = 0):
+        self._h = C.c_void_p()
+        check(lib().ft_context_create(device, host_threads, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ft_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib().ft_context_synchronize(self._h))
+
+    @property
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        check(lib().ft_context_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    @property
+    def host_threads(self) -> int:
+        return lib().ft_context_host_threads(self._h)
+
+    def save_stats(self, path: str):
+        check(lib().ft_context_save_stats(self._h, path.encode()))
+
+    # frames resident in HBM
+    def to_device(self, arr: np.ndarray) -> "DeviceBuffer":
+        arr = np.ascontiguousarray(arr)
+        d = C.c_void_p()
+        check(lib().ft_device_malloc(self._h, arr.nbytes, C.byref(d)))
+        check(lib().ft_memcpy_h2d(self._h, d, ptr(arr), arr.nbytes))
+        return DeviceBuffer(self, d, arr.nbytes)
+
+
+class DeviceBuffer:
+    def __init__(self, ctx: Context, dptr, nbytes: int):
+        self.ctx, self.ptr, self.nbytes = ctx, dptr, nbytes
+
+    def free(self):
+        if self.ptr:
+            lib().ft_device_free(self.ctx._h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                self.free()
+        except Exception:
+            pass
+
+
+def _image_ptrs(images, on_device):
+    n = len(images)
+    arr = (C.c_void_p * n)()
+    keep = []
+    for b, im in enumerate(images):
+        if on_device:
+            arr[b] = im.ptr if isinstance(im, DeviceBuffer) else im
+        else:
+            a = np.ascontiguousarray(im, np.uint8)
+            keep.append(a)
+            arr[b] = a.ctypes.data
+    return arr, keep
+
+
+class ORBextractor:
+    """ORB_SLAM3::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, imageWidth, imageHeight)."""
+
+    def __init__(self, ctx: Context, nfeatures: int, scale_factor: float, nlevels: int, ini_th_fast: int,
+                 min_th_fast: int, image_width: int, image_height: int, max_batch: int = 1, _handle=None):
+        self.ctx = ctx
+        self.width, self.height = image_width, image_height
+        self._owned = _handle is None
+        if _handle is None:
+            self._h = C.c_void_p()
+            check(lib().ft_extractor_create(ctx._h, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast,
+                                            image_width, image_height, max_batch, C.byref(self._h)))
+        else:
+            self._h = C.c_void_p(_handle)
+        self.nlevels = lib().ft_extractor_levels(self._h)
+        self.max_batch = lib().ft_extractor_max_batch(self._h)
+        self.max_keypoints = lib().ft_extractor_max_keypoints(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._owned and self.ctx._h:
+            lib().ft_extractor_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # getters of include/ORBextractor.h:117-144
+    def GetLevels(self):
+        return self.nlevels
+
+    def _sf(self, which):
+        out = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        check(lib().ft_extractor_scale_factors(self._h, *[ptr(o) for o in out]))
+        return out[which]
+
+    def GetScaleFactors(self):
+        return self._sf(0)
+
+    def GetInverseScaleFactors(self):
+        return self._sf(1)
+
+    def GetScaleSigmaSquares(self):
+        return self._sf(2)
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._sf(3)
+
+    def features_per_level(self):
+        q = np.zeros(self.nlevels, np.int32)
+        check(lib().ft_extractor_features_per_level(self._h, ptr(q)))
+        return q
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        check(lib().ft_extractor_level_size(self._h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def __call__(self, image: np.ndarray, lapping_area=(0, 0)):
+        """operator(): returns (keypoints[KP_DTYPE], descriptors[n,32] uint8, n_mono); -1 for an empty image."""
+        if image is None or image.size == 0:
+            st = lib().ft_extract(self._h, None, 0, 0, 0, 0, 0, None, None, 0, None, None)
+            if st == _capi.FT_ERR_EMPTY:
+                return None, None, -1
+            check(st)
+        image = np.ascontiguousarray(image, np.uint8)
+        cap = self.max_keypoints
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n, nm = C.c_int(), C.c_int()
+        check(lib().ft_extract(self._h, ptr(image), image.shape[1], image.shape[0], image.strides[0],
+                               lapping_area[0], lapping_area[1], ptr(kps), ptr(desc), cap, C.byref(n), C.byref(nm)))
+        return kps[:n.value].copy(), desc[:n.value].copy(), nm.value
+
+    def extract_batch(self, images, lapping_area=(0, 0), on_device=False, width=None, height=None, stride=None):
+        """images: list of host arrays or DeviceBuffers (frames already in HBM)."""
+        B = len(images)
+        if not on_device:
+            width, height = images[0].shape[1], images[0].shape[0]
+            stride = width
+            images = [np.ascontiguousarray(im, np.uint8) for im in images]
+        ptrs, keep = _image_ptrs(images, on_device)
+        cap = self.max_keypoints
+        kps = np.zeros((B, cap), KP_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        nm = np.zeros(B, np.int32)
+        check(lib().ft_extract_batch(self._h, ptrs, B, int(on_device), width, height, stride, lapping_area[0],
+                                     lapping_area[1], ptr(kps), ptr(desc), cap, ptr(n), ptr(nm)))
+        return [(kps[b, :n[b]].copy(), desc[b, :n[b]].copy(), int(nm[b])) for b in range(B)]
+
+    # mvImagePyramid[level] (host copy) of image slot `slot`
+    def image_pyramid_level(self, level, slot=0) -> np.ndarray:
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        check(lib().ft_extractor_download_level(self._h, slot, level, ptr(out), w))
+        return out
+
+    def candidates(self, level, slot=0) -> np.ndarray:
+        n = C.c_int()
+        check(lib().ft_extractor_download_candidates(self._h, slot, level, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.int32)
+        check(lib().ft_extractor_download_candidates(self._h, slot, level, ptr(out), n.value, C.byref(n)))
+        return out[:n.value]
+
+
+class FrameView:
+    """Owns the arrays behind an ft_frame_view (the fields CudaFrame::setMemory marshals)."""
+
+    def __init__(self, keys, descriptors, scale_factors, bounds, mbf=0.0, mb=0.0, uright=None, holder_obs=None,
+                 keys_right=None, left_to_right=None, right_to_left=None, cam_model=0, cam=None, Trl=None):
+        self.keys = np.ascontiguousarray(keys)
+        self.keys_right = None if keys_right is None else np.ascontiguousarray(keys_right)
+        nleft = -1 if keys_right is None else len(self.keys)
+        n = len(self.keys) + (0 if keys_right is None else len(self.keys_right))
+        self.descriptors = np.ascontiguousarray(descriptors, np.uint8).reshape(n, 32)
+        self.sf = np.ascontiguousarray(scale_factors, np.float32)
+        self.uright = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        self.holder_obs = (np.full(n, -1, np.int32) if holder_obs is None
+                           else np.ascontiguousarray(holder_obs, np.int32).copy())
+        self.l2r = None if left_to_right is None else np.ascontiguousarray(left_to_right, np.int32)
+        self.r2l = None if right_to_left is None else np.ascontiguousarray(right_to_left, np.int32)
+        minx, miny, maxx, maxy = [np.float32(v) for v in bounds]
+        f = _capi.FrameView()
+        f.N, f.Nleft = n, nleft
+        f.mnMinX, f.mnMinY, f.mnMaxX, f.mnMaxY = minx, miny, maxx, maxy
+        f.grid_inv_w = np.float32(64) / np.float32(maxx - minx)   # Frame.cc:184-185
+        f.grid_inv_h = np.float32(48) / np.float32(maxy - miny)
+        f.mbf, f.mb = float(mbf), float(mb)
+        f.keys, f.keys_right, f.descriptors = ptr(self.keys), ptr(self.keys_right), ptr(self.descriptors)
+        f.uright, f.holder_obs = ptr(self.uright), ptr(self.holder_obs)
+        f.left_to_right, f.right_to_left = ptr(self.l2r), ptr(self.r2l)
+        f.cam_model = cam_model
+        cam = np.zeros(8, np.float32) if cam is None else np.asarray(cam, np.float32)
+        for i in range(8):
+            f.cam[i] = float(cam[i]) if i < len(cam) else 0.0
+        Trl = np.eye(3, 4, dtype=np.float32) if Trl is None else np.asarray(Trl, np.float32).reshape(3, 4)
+        for i in range(12):
+            f.Trl[i] = float(Trl.flat[i])
+        f.scale_factors, f.nlevels = ptr(self.sf), len(self.sf)
+        self.c, self.N, self.Nleft = f, n, nleft
+
+
+class KernelController:
+    """Static facade of the reference (include/Kernels/KernelController.h), minus the run-mode flags:
+    this build has no CPU twin to switch to."""
+
+    @staticmethod
+    def launchStereoMatchKernel(exL: ORBextractor, exR: ORBextractor, keysL, keysR, descL, descR, mbf, mb,
+                                median_cut=True, slot=0):
+        """-> dict(uright=mvuRight, depth=mvDepth, sad, n).  KernelController.h:31-36 / Frame.cc:1007-1063."""
+        keysL, keysR = np.ascontiguousarray(keysL), np.ascontiguousarray(keysR)
+        descL, descR = np.ascontiguousarray(descL, np.uint8), np.ascontiguousarray(descR, np.uint8)
+        nL, nR = len(keysL), len(keysR)
+        ur = np.zeros(max(nL, 1), np.float32)
+        dp = np.zeros(max(nL, 1), np.float32)
+        sad = np.zeros(max(nL, 1), np.int32)
+        nm = C.c_int()
+        check(lib().ft_stereo_match(exL._h, exR._h, slot, ptr(keysL), nL, ptr(keysR), nR, ptr(descL), ptr(descR),
+                                    float(mbf), float(mb), int(median_cut), ptr(ur), ptr(dp), ptr(sad), C.byref(nm)))
+        return dict(uright=ur[:nL], depth=dp[:nL], sad=sad[:nL], n=nm.value)
+
+    @staticmethod
+    def launchFisheyeStereoMatchKernel(ctx: Context, descL, descR):
+        """-> dict(matches, best, second).  KernelController.h:38 / Frame.cc:1231-1255."""
+        descL, descR = np.ascontiguousarray(descL, np.uint8), np.ascontiguousarray(descR, np.uint8)
+        nL, nR = len(descL), len(descR)
+        m = np.full(max(nL, 1), -1, np.int32)
+        b = np.zeros(max(nL, 1), np.int32)
+        s = np.zeros(max(nL, 1), np.int32)
+        check(lib().ft_fisheye_match(ctx._h, ptr(descL), nL, ptr(descR), nR, ptr(m), ptr(b), ptr(s)))
+        return dict(matches=m[:nL], best=b[:nL], second=s[:nL], n=int((m[:nL] >= 0).sum()))
+
+    @staticmethod
+    def launchSearchLocalPointsKernel(ctx: Context, F: FrameView, pts: dict, th: float, nn_ratio: float = 0.8):
+        """KernelController.h:40-42 + the acceptance loop of ORBmatcher.cc:241-308."""
+        M = len(pts["skip"])
+        keep = {}
+
+        def arr(k, dt):
+            keep[k] = np.ascontiguousarray(pts[k], dt)
+            return ptr(keep[k])
+
+        P = _capi.LocalPoints()
+        P.M = M
+        P.skip, P.in_view, P.in_view_r = arr("skip", np.uint8), arr("in_view", np.uint8), arr("in_view_r", np.uint8)
+        P.level, P.level_r = arr("level", np.int32), arr("level_r", np.int32)
+        P.view_cos, P.view_cos_r = arr("view_cos", np.float32), arr("view_cos_r", np.float32)
+        P.proj_x, P.proj_y = arr("proj_x", np.float32), arr("proj_y", np.float32)
+        P.proj_xr, P.proj_yr = arr("proj_xr", np.float32), arr("proj_yr", np.float32)
+        P.descriptors, P.observations = arr("descriptors", np.uint8), arr("observations", np.int32)
+        assign = np.zeros(max(F.N, 1), np.int32)
+        outs = [np.zeros(max(M, 1), np.int32) for _ in range(10)]
+        nm = C.c_int()
+        check(lib().ft_search_local_points(ctx._h, C.byref(F.c), C.byref(P), th, nn_ratio, ptr(assign), C.byref(nm),
+                                           *[ptr(o) for o in outs]))
+        names = ["best_dist", "best_dist2", "best_level", "best_level2", "best_idx",
+                 "best_dist_r", "best_dist2_r", "best_level_r", "best_level2_r", "best_idx_r"]
+        r = {k: o[:M] for k, o in zip(names, outs)}
+        r["assign"], r["n"] = assign[:F.N], nm.value
+        return r
+
+    @staticmethod
+    def launchPoseEstimationKernel(ctx: Context, Cur: FrameView, last: dict, Tcw, th, forward=False, backward=False,
+                                   check_orientation=True):
+        """KernelController.h:44-46 + the histogram loop of ORBmatcher.cc:2013-2081."""
+        N = len(last["valid"])
+        keep = {}
+
+        def arr(k, dt):
+            keep[k] = np.ascontiguousarray(last[k], dt)
+            return ptr(keep[k])
+
+        Lp = _capi.LastPoints()
+        Lp.N = N
+        Lp.valid, Lp.world_pos = arr("valid", np.uint8), arr("world_pos", np.float32)
+        Lp.descriptors, Lp.observations = arr("descriptors", np.uint8), arr("observations", np.int32)
+        Lp.octave, Lp.angle = arr("octave", np.int32), arr("angle", np.float32)
+        T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(3, 4))
+        assign = np.zeros(max(Cur.N, 1), np.int32)
+        outs = [np.zeros(max(N, 1), np.int32) for _ in range(4)]
+        nm = C.c_int()
+        check(lib().ft_search_last_frame(ctx._h, C.byref(Cur.c), C.byref(Lp), ptr(T), th, int(forward), int(backward),
+                                         int(check_orientation), ptr(assign), C.byref(nm), *[ptr(o) for o in outs]))
+        names = ["best_dist", "best_idx", "best_dist_r", "best_idx_r"]
+        r = {k: o[:N] for k, o in zip(names, outs)}
+        r["assign"], r["n"] = assign[:Cur.N], nm.value
+        return r
+
+    @staticmethod
+    def descriptor_distance(ctx: Context, a, b):
+        a, b = np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)
+        n = len(a)
+        d = np.zeros(max(n, 1), np.int32)
+        check(lib().ft_descriptor_distance(ctx._h, ptr(a), ptr(b), n, ptr(d)))
+        return d[:n]
+
+
+class StereoFrontend:
+    """Fused extract(left) + extract(right) + ComputeStereoMatches for batches of rectified pairs."""
+
+    def __init__(self, ctx: Context, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, width, height,
+                 max_batch, mbf, mb):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        check(lib().ft_stereo_frontend_create(ctx._h, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast,
+                                              width, height, max_batch, float(mbf), float(mb), C.byref(self._h)))
+        self.width, self.height, self.max_batch = width, height, max_batch
+        args = (ctx, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, width, height, max_batch)
+        self.left = ORBextractor(*args, _handle=lib().ft_stereo_frontend_left(self._h))
+        self.right = ORBextractor(*args, _handle=lib().ft_stereo_frontend_right(self._h))
+        self.capacity = self.left.max_keypoints
+        B, cap = max_batch, self.capacity
+        self._kL = np.zeros((B, cap), KP_DTYPE)
+        self._kR = np.zeros((B, cap), KP_DTYPE)
+        self._dL = np.zeros((B, cap, 32), np.uint8)
+        self._dR = np.zeros((B, cap, 32), np.uint8)
+        self._nL = np.zeros(B, np.int32)
+        self._nR = np.zeros(B, np.int32)
+        self._ur = np.zeros((B, cap), np.float32)
+        self._dp = np.zeros((B, cap), np.float32)
+        self._nm = np.zeros(B, np.int32)
+
+    def close(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib().ft_stereo_frontend_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_raw(self, ptrsL, ptrsR, batch, on_device, stride):
+        """No per-call allocation: results land in the preallocated arrays (used by bench.py)."""
+        check(lib().ft_stereo_frontend_process(self._h, ptrsL, ptrsR, batch, int(on_device), self.width, self.height,
+                                               stride, ptr(self._kL), ptr(self._dL), ptr(self._nL), ptr(self._kR),
+                                               ptr(self._dR), ptr(self._nR), self.capacity, ptr(self._ur),
+                                               ptr(self._dp), ptr(self._nm)))
+
+    def process(self, imagesL, imagesR, on_device=False, stride=None):
+        B = len(imagesL)
+        pL, keepL = _image_ptrs(imagesL, on_device)
+        pR, keepR = _image_ptrs(imagesR, on_device)
+        self.process_raw(pL, pR, B, on_device, stride or self.width)
+        out = []
+        for b in range(B):
+            nl, nr = int(self._nL[b]), int(self._nR[b])
+            out.append(dict(keysL=self._kL[b, :nl].copy(), descL=self._dL[b, :nl].copy(),
+                            keysR=self._kR[b, :nr].copy(), descR=self._dR[b, :nr].copy(),
+                            uright=self._ur[b, :nl].copy(), depth=self._dp[b, :nl].copy(), n=int(self._nm[b])))
+        return out

@@ -1,0 +1,255 @@
+/*
+ * fasttrack_amd.h - C ABI of the MI355X-native ORB tracking front end.
+ *
+ * This is the drop-in boundary: every entry point replaces one seam of the reference
+ * (sfu-rsl/FastTrack, paths relative to its root) and takes plain pointers and sizes only - no
+ * OpenCV / Eigen / torch types - so it binds from C++, C or ctypes alike.  INTEGRATION.md shows the
+ * adapter a maintainer adds on the ORB-SLAM3 side.
+ *
+ * Conventions
+ *  - every function returns FT_OK (0) or a negative ft_status; ft_last_error() returns the message of
+ *    the calling thread's last failure (the reference prints and exit()s: src/Kernels/CudaUtils.cu:17-22).
+ *  - handles are bound to one device; calls on different handles are re-entrant (the reference calls
+ *    the left and right extractor from two host threads: src/Frame.cc:127-130); calls on the same
+ *    handle must be serialised by the caller.
+ *  - all compute runs in hand-written HIP kernels on the handle's device.  There is no CPU fallback:
+ *    without a usable gfx950 device every compute entry point fails with FT_ERR_NO_DEVICE.
+ *  - ft_keypoint has the field order and size (28 B) of cv::KeyPoint, so a std::vector<cv::KeyPoint>
+ *    can be passed as ft_keypoint* directly.
+ */
+#ifndef FASTTRACK_AMD_H
+#define FASTTRACK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FT_API __attribute__((visibility("default")))
+
+typedef enum ft_status {
+    FT_OK = 0,
+    FT_ERR_INVALID = -1,   /* bad argument */
+    FT_ERR_NO_DEVICE = -2, /* no usable HIP device / extension not functional */
+    FT_ERR_HIP = -3,       /* a HIP runtime call failed */
+    FT_ERR_CAPACITY = -4,  /* caller buffer too small */
+    FT_ERR_EMPTY = -5      /* empty input image (ORBextractor::operator() returns -1, ORBextractor.cc:1360) */
+} ft_status;
+
+/* cv::KeyPoint layout: pt.x pt.y size angle response octave class_id */
+typedef struct ft_keypoint {
+    float x, y, size, angle, response;
+    int octave, class_id;
+} ft_keypoint;
+
+/* ------------------------------------------------------------------------------------------------
+ * Library / device context.
+ * Replaces KernelController::setCUDADevice / initializeKernels / shutdownKernels / saveKernelsStats
+ * (include/Kernels/KernelController.h:15-29) and CudaUtils::loadSetting (include/Kernels/CudaUtils.h:21).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ft_context ft_context;
+
+FT_API const char *ft_version(void);
+FT_API const char *ft_last_error(void);
+FT_API int ft_device_count(void); /* number of HIP devices, 0 if none (never fails) */
+/* host_threads: workers for the host-side octree stage (0 = hardware_concurrency) */
+FT_API int ft_context_create(int device, int host_threads, ft_context **out);
+FT_API int ft_context_destroy(ft_context *ctx);
+FT_API int ft_context_synchronize(ft_context *ctx);
+FT_API int ft_context_device_name(ft_context *ctx, char *buf, int len);
+FT_API int ft_context_host_threads(const ft_context *ctx);
+/* per-stage wall/GPU timings of the calls made so far; the reference's REGISTER_STATS analogue
+ * (include/Kernels/CudaUtils.h:14, src/Stats.cc:31-60).  Writes "<name>: <ms>" lines. */
+FT_API int ft_context_save_stats(ft_context *ctx, const char *path);
+/* device memory helpers so that a caller (or bench.py) can keep frames resident in HBM */
+FT_API int ft_device_malloc(ft_context *ctx, size_t bytes, void **dptr);
+FT_API int ft_device_free(ft_context *ctx, void *dptr);
+FT_API int ft_memcpy_h2d(ft_context *ctx, void *dst, const void *src, size_t bytes);
+FT_API int ft_memcpy_d2h(ft_context *ctx, void *dst, const void *src, size_t bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * ORB extractor.  Replaces ORB_SLAM3::ORBextractor (include/ORBextractor.h:100-197):
+ *   ctor (nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, imageWidth, imageHeight)  :105-106
+ *   int operator()(image, mask, keypoints, descriptors, vLappingArea)                       :113-115
+ *   GetLevels/GetScaleFactor(s)/GetInverseScaleFactors/GetScaleSigmaSquares/...             :117-144
+ *   mvImagePyramid (:146) and GetGPUPyramid() (:126-128)
+ * Results equal the reference's CPU branch (KernelController::orbExtractionKernelRunStatus == 0).
+ * max_batch image slots are allocated; slot b keeps the pyramid of the b-th image of the last call
+ * resident in HBM for the stereo matcher.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ft_extractor ft_extractor;
+
+FT_API int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                               int min_th_fast, int image_width, int image_height, int max_batch,
+                               ft_extractor **out);
+FT_API int ft_extractor_destroy(ft_extractor *ex);
+FT_API int ft_extractor_levels(const ft_extractor *ex);
+FT_API int ft_extractor_max_batch(const ft_extractor *ex);
+/* upper bound of keypoints operator() can return per image (octree may exceed nfeatures slightly) */
+FT_API int ft_extractor_max_keypoints(const ft_extractor *ex);
+/* any of the four output arrays may be NULL; each holds nlevels floats */
+FT_API int ft_extractor_scale_factors(const ft_extractor *ex, float *scale, float *inv_scale, float *sigma2,
+                                      float *inv_sigma2);
+FT_API int ft_extractor_features_per_level(const ft_extractor *ex, int *quota);
+FT_API int ft_extractor_level_size(const ft_extractor *ex, int level, int *width, int *height);
+
+/* ORBextractor::operator() for one host image (row stride in bytes).  keypoints/descriptors receive
+ * up to `capacity` entries laid out exactly as the reference does (ORBextractor.cc:1466-1487):
+ * keypoints with x in [lap0, lap1] fill from the back, the others from the front; *n_mono is the
+ * reference's return value.  FT_ERR_EMPTY for a null/empty image. */
+FT_API int ft_extract(ft_extractor *ex, const uint8_t *image, int width, int height, int stride, int lap0,
+                      int lap1, ft_keypoint *keypoints, uint8_t *descriptors, int capacity, int *n_keypoints,
+                      int *n_mono);
+
+/* The same for `batch` <= max_batch images of identical size.  images[b] is a host pointer
+ * (on_device = 0) or a device pointer on this context's device (on_device = 1, frames already in HBM).
+ * Outputs are host arrays: keypoints[b*capacity + i], descriptors[(b*capacity + i)*32]. */
+FT_API int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
+                            int height, int stride, int lap0, int lap1, ft_keypoint *keypoints,
+                            uint8_t *descriptors, int capacity, int *n_keypoints, int *n_mono);
+
+/* mvImagePyramid[level] of slot `slot` copied to host (tight or strided rows) */
+FT_API int ft_extractor_download_level(ft_extractor *ex, int slot, int level, uint8_t *dst, int dst_stride);
+/* GetGPUPyramid(): device pointer + pitch of one level of one slot */
+FT_API int ft_extractor_device_level(ft_extractor *ex, int slot, int level, const uint8_t **dptr, int *pitch);
+/* stage taps for parity tests: FAST candidates handed to the octree, in the CPU's emission order,
+ * as (x, y, score) triples relative to the level's (minBorderX, minBorderY) (ORBextractor.cc:1196-1198) */
+FT_API int ft_extractor_download_candidates(ft_extractor *ex, int slot, int level, int *xys, int capacity,
+                                            int *n);
+
+/* Host-only stages, callable without a GPU (they never touch pixels):
+ * ft_octree_distribute = ORBextractor::DistributeOctTree (ORBextractor.cc:660-884), the serial stage
+ * that stays on the host in both branches of the reference.  xys: n (x, y, score) candidates relative to
+ * (minX, minY) in FAST emission order; out_idx receives the retained candidate indices in the
+ * reference's result order; *n_out their number (may exceed N by a few, as in the reference).
+ * ft_level_geometry = the level / cell-grid / quota arithmetic of ORBextractor.cc:398-465,1120-1134,1499-1500;
+ * every output array holds nlevels ints and may be NULL. */
+FT_API int ft_octree_distribute(const int *xys, int n, int minX, int maxX, int minY, int maxY, int N, int *out_idx,
+                                int capacity, int *n_out);
+FT_API int ft_level_geometry(int width, int height, int nfeatures, float scale_factor, int nlevels, int *level_w,
+                             int *level_h, int *quota, int *n_cols, int *n_rows, int *w_cell, int *h_cell);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stereo matching, rectified pinhole pair.
+ * Replaces KernelController::launchStereoMatchKernel (include/Kernels/KernelController.h:31-36) as
+ * called from Frame::ComputeStereoMatchesGPU (src/Frame.cc:1007-1063); semantics follow the CPU
+ * branch Frame::ComputeStereoMatches (src/Frame.cc:835-1005): row-band Hamming search, 11x11 SAD at
+ * 11 shifts, parabola fit, and (apply_median_cut != 0) the 1.5*1.4*median SAD cut.
+ * The pyramids are those resident in slot `slot` of exL / exR from their last extract call.
+ * uright/depth: mvuRight / mvDepth (-1 = no match); sad (may be NULL): best SAD of kept matches, -1 else.
+ * ---------------------------------------------------------------------------------------------- */
+FT_API int ft_stereo_match(ft_extractor *exL, ft_extractor *exR, int slot, const ft_keypoint *keysL, int nL,
+                           const ft_keypoint *keysR, int nR, const uint8_t *descL, const uint8_t *descR,
+                           float mbf, float mb, int apply_median_cut, float *uright, float *depth, int *sad,
+                           int *n_matches);
+
+/* Fused stereo front end for throughput: extract left + right and stereo-match `batch` pairs with
+ * keypoints and descriptors kept on the device between the stages (one stream per GPU).
+ * Outputs per pair b (host arrays, `capacity` entries per image): keysL/descL/keysR/descR as
+ * ft_extract_batch, uright/depth for the left keypoints. */
+typedef struct ft_stereo_frontend ft_stereo_frontend;
+FT_API int ft_stereo_frontend_create(ft_context *ctx, int nfeatures, float scale_factor, int nlevels,
+                                     int ini_th_fast, int min_th_fast, int image_width, int image_height,
+                                     int max_batch, float mbf, float mb, ft_stereo_frontend **out);
+FT_API int ft_stereo_frontend_destroy(ft_stereo_frontend *fe);
+FT_API ft_extractor *ft_stereo_frontend_left(ft_stereo_frontend *fe);
+FT_API ft_extractor *ft_stereo_frontend_right(ft_stereo_frontend *fe);
+FT_API int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *imagesL,
+                                      const uint8_t *const *imagesR, int batch, int on_device, int width,
+                                      int height, int stride, ft_keypoint *keysL, uint8_t *descL, int *nL,
+                                      ft_keypoint *keysR, uint8_t *descR, int *nR, int capacity, float *uright,
+                                      float *depth, int *n_matches);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fisheye stereo matching (matching part).
+ * Replaces KernelController::launchFisheyeStereoMatchKernel(N, Nr, descL, descR, matches)
+ * (include/Kernels/KernelController.h:38); semantics follow Frame::ComputeStereoFishEyeMatches
+ * (src/Frame.cc:1231-1255): BFMatcher(NORM_HAMMING).knnMatch(k=2) + Lowe ratio 0.7.  The caller passes
+ * the lapping-area subsets like the CPU branch (src/Frame.cc:1233-1237).  matches[i] = index into
+ * descR or -1; best/second (may be NULL) = the two smallest distances.
+ * ---------------------------------------------------------------------------------------------- */
+FT_API int ft_fisheye_match(ft_context *ctx, const uint8_t *descL, int nL, const uint8_t *descR, int nR,
+                            int *matches, int *best, int *second);
+
+/* ------------------------------------------------------------------------------------------------
+ * Frame view for the projection matchers: the fields of ORB_SLAM3::Frame that
+ * DATA_WRAPPER::CudaFrame::setMemory marshals (src/Kernels/CudaWrappers/CudaFrame.cu:77-181).
+ * The 64x48 grid (Frame::AssignFeaturesToGrid, src/Frame.cc:409-440) is rebuilt on the device.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ft_frame_view {
+    int N;     /* all keypoints (left + right when Nleft != -1) */
+    int Nleft; /* -1: mono / rectified stereo (keys = mvKeysUn); else keys = mvKeys, keys_right = mvKeysRight */
+    float mnMinX, mnMinY, mnMaxX, mnMaxY;
+    float grid_inv_w, grid_inv_h; /* mfGridElementWidthInv / mfGridElementHeightInv */
+    float mbf, mb;
+    const ft_keypoint *keys;
+    const ft_keypoint *keys_right;
+    const uint8_t *descriptors; /* N x 32 (left rows then right rows) */
+    const float *uright;        /* mvuRight[N] when Nleft == -1, NULL = all -1 */
+    int *holder_obs;            /* in/out [N]: Observations() of mvpMapPoints[i], -1 when NULL */
+    const int *left_to_right;   /* mvLeftToRightMatch[Nleft] or NULL */
+    const int *right_to_left;   /* mvRightToLeftMatch[N-Nleft] or NULL */
+    int cam_model;              /* 0 Pinhole, 1 KannalaBrandt8 */
+    float cam[8];               /* fx fy cx cy k1 k2 k3 k4 */
+    float Trl[12];              /* row-major 3x4 GetRelativePoseTrl() */
+    const float *scale_factors; /* mvScaleFactors[nlevels] */
+    int nlevels;
+} ft_frame_view;
+
+/* SoA arrays of the local map points, exactly what SearchLocalPointsKernel::launch builds
+ * (src/Kernels/SearchLocalPointsKernel.cu:369-390) plus Observations(). */
+typedef struct ft_local_points {
+    int M;
+    const uint8_t *skip; /* (!mbTrackInView && !mbTrackInViewR) || (bFarPoints && depth > thFar) || isBad() */
+    const uint8_t *in_view, *in_view_r;
+    const int *level, *level_r;           /* mnTrackScaleLevel, mnTrackScaleLevelR */
+    const float *view_cos, *view_cos_r;   /* mTrackViewCos, mTrackViewCosR */
+    const float *proj_x, *proj_y;         /* mTrackProjX, mTrackProjY */
+    const float *proj_xr, *proj_yr;       /* mTrackProjXR, mTrackProjYR */
+    const uint8_t *descriptors;           /* M x 32 */
+    const int *observations;              /* pMP->Observations() */
+} ft_local_points;
+
+/* Replaces KernelController::launchSearchLocalPointsKernel (include/Kernels/KernelController.h:40-42)
+ * AND the acceptance loop around it (src/ORBmatcher.cc:241-308); semantics follow the CPU branch of
+ * ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>, th, bFarPoints, thFarPoints)
+ * (src/ORBmatcher.cc:49-225) including its in-call claiming order.
+ * assign[i] (size F->N) = index of the map point written to F.mvpMapPoints[i], else -1;
+ * F->holder_obs is updated like mvpMapPoints.  The ten raw arrays (size M, any may be NULL) are the
+ * reference kernel's outputs.  *n_matches = the reference's return value. */
+FT_API int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_points *P, float th,
+                                  float nn_ratio, int *assign, int *n_matches, int *best_dist, int *best_dist2,
+                                  int *best_level, int *best_level2, int *best_idx, int *best_dist_r,
+                                  int *best_dist2_r, int *best_level_r, int *best_level2_r, int *best_idx_r);
+
+/* Last-frame map points for the motion-model search. */
+typedef struct ft_last_points {
+    int N;                      /* LastFrame.N */
+    const uint8_t *valid;       /* mvpMapPoints[i] != NULL && !mvbOutlier[i] */
+    const float *world_pos;     /* N x 3, pMP->GetWorldPos() */
+    const uint8_t *descriptors; /* N x 32, pMP->GetDescriptor() */
+    const int *observations;
+    const int *octave; /* octave of last-frame keypoint i */
+    const float *angle; /* angle of last-frame keypoint i (rotation histogram) */
+} ft_last_points;
+
+/* Replaces KernelController::launchPoseEstimationKernel (include/Kernels/KernelController.h:44-46) and
+ * the histogram loop around it (src/ORBmatcher.cc:2013-2081); semantics follow the CPU branch of
+ * ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1775-1990).
+ * Tcw: row-major 3x4 current pose; forward/backward as computed at :1794-1795.
+ * assign[i] (size Cur->N) = last-frame index whose map point ends up in CurrentFrame.mvpMapPoints[i]. */
+FT_API int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_points *L, const float *Tcw,
+                                float th, int forward, int backward, int check_orientation, int *assign,
+                                int *n_matches, int *best_dist, int *best_idx, int *best_dist_r,
+                                int *best_idx_r);
+
+/* ORBmatcher::DescriptorDistance for n pairs on the device (src/ORBmatcher.cc:2256-2272,
+ * device copy src/Kernels/CudaUtils.cu:42-56).  a, b: n x 32 host bytes; dist: n ints. */
+FT_API int ft_descriptor_distance(ft_context *ctx, const uint8_t *a, const uint8_t *b, int n, int *dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTTRACK_AMD_H */

@@ -830,6 +830,7 @@ int orc_stereo_match(const orc_extractor *exL, const orc_extractor *exR, const o
             // cv::Mat::rowRange/colRange would assert on a window leaving the level; keypoints are
             // >= 19 px inside so this cannot trigger, guarded for safety
             if (yl0 < 0 || yl0 + 2 * w + 1 > imL.h || xl0 < 0 || xl0 + 2 * w + 1 > imL.w) continue;
+            if ((int)scaleduR0 - L - w < 0) continue;  // the reference only tests +L (:938-940); same remark
             for (int incR = -L; incR <= +L; incR++) {
                 const int xr0 = (int)(scaleduR0 + incR - w);
                 int sad = 0;

@@ -1,0 +1,129 @@
+"""Seeded synthetic scenarios shared by the oracle tests (CPU) and the parity tests (GPU)."""
+import numpy as np
+
+from fasttrack_amd import synth
+from oracle import binding as ob
+
+KP = ob.KP_DTYPE
+
+
+def oracle_stereo_frame(width, height, nfeatures, seed):
+    """Extract a synthetic pair with the oracle; returns dict with images, extractors, keys, descriptors."""
+    L, R = synth.make_stereo_pair(width, height, seed)
+    exL, exR = ob.Extractor(nfeatures), ob.Extractor(nfeatures)
+    kL, dL, _ = exL.extract(L)
+    kR, dR, _ = exR.extract(R)
+    intr = synth.intrinsics(width, height)
+    return dict(L=L, R=R, exL=exL, exR=exR, kL=kL, dL=dL, kR=kR, dR=dR, intr=intr)
+
+
+def frame_bounds(width, height):
+    # rectified / undistorted pinhole: mnMinX = 0, mnMaxX = cols (Frame::ComputeImageBounds, no distortion)
+    return (0.0, 0.0, float(width), float(height))
+
+
+def random_pose(rng, trans=0.05, rot=0.01):
+    """small SE(3) step as a row-major 3x4 float32 matrix"""
+    w = rng.normal(0, rot, 3)
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    Rm = np.eye(3) + (np.sin(th) / th) * K + ((1 - np.cos(th)) / th ** 2) * K @ K if th > 1e-12 else np.eye(3)
+    t = rng.normal(0, trans, 3)
+    return np.concatenate([Rm, t[:, None]], 1).astype(np.float32)
+
+
+def local_points_scenario(keys, desc, sf, width, height, seed, M=1500, zero_obs_frac=0.15, uright=None,
+                          mbf=40.0, dense=False):
+    """Local map points built from a frame's own keypoints: projections jittered around keypoints,
+    descriptors with a few flipped bits, a share of zero-observation points and skipped points.
+    dense=True packs the projections so that windows overlap and in-call claiming matters."""
+    rng = np.random.default_rng(seed)
+    N = len(keys)
+    src = rng.integers(0, N, M)
+    if dense:
+        src = rng.integers(0, max(N // 6, 1), M)
+    jitter = rng.normal(0, 2.0, (M, 2)).astype(np.float32)
+    px = (keys["x"][src] + jitter[:, 0]).astype(np.float32)
+    py = (keys["y"][src] + jitter[:, 1]).astype(np.float32)
+    d = desc[src].copy()
+    flips = rng.integers(0, 256, (M, 12))
+    for k in range(12):
+        m = rng.random(M) < 0.5
+        d[m, flips[m, k] // 8] ^= (1 << (flips[m, k] % 8)).astype(np.uint8)
+    level = np.clip(keys["octave"][src] + rng.integers(0, 2, M), 0, len(sf) - 1).astype(np.int32)
+    view_cos = np.where(rng.random(M) < 0.5, 0.9995, 0.9).astype(np.float32)
+    obs = np.where(rng.random(M) < zero_obs_frac, 0, rng.integers(1, 6, M)).astype(np.int32)
+    skip = (rng.random(M) < 0.05).astype(np.uint8)
+    if uright is not None:
+        ur = uright[src]
+        pxr = np.where(ur > 0, ur + rng.normal(0, 1.0, M), px - 5.0).astype(np.float32)
+    else:
+        pxr = (px - 5.0).astype(np.float32)
+    return dict(skip=skip, in_view=np.ones(M, np.uint8), in_view_r=np.zeros(M, np.uint8), level=level,
+                level_r=np.full(M, -1, np.int32), view_cos=view_cos, view_cos_r=view_cos.copy(), proj_x=px,
+                proj_y=py, proj_xr=pxr, proj_yr=py.copy(), descriptors=d, observations=obs)
+
+
+def fisheye_frame_scenario(width, height, nfeatures, seed):
+    """Two-camera (Nleft != -1) frame: left/right keypoints from the oracle on a synthetic pair, a
+    brute-force left<->right match table, and local points visible in both cameras."""
+    fr = oracle_stereo_frame(width, height, nfeatures, seed)
+    m = ob.fisheye_match(fr["dL"], fr["dR"])
+    l2r = m["matches"].astype(np.int32)
+    r2l = np.full(len(fr["kR"]), -1, np.int32)
+    for i, j in enumerate(l2r):
+        if j >= 0:
+            r2l[j] = i
+    fr["l2r"], fr["r2l"] = l2r, r2l
+    return fr
+
+
+def two_camera_points(fr, sf, seed, M=1200, zero_obs_frac=0.2):
+    rng = np.random.default_rng(seed)
+    kL, kR, dL = fr["kL"], fr["kR"], fr["dL"]
+    NL, NR = len(kL), len(kR)
+    srcL = rng.integers(0, max(NL // 4, 1), M)
+    srcR = rng.integers(0, max(NR // 4, 1), M)
+    d = dL[srcL].copy()
+    flips = rng.integers(0, 256, (M, 10))
+    for k in range(10):
+        mm = rng.random(M) < 0.5
+        d[mm, flips[mm, k] // 8] ^= (1 << (flips[mm, k] % 8)).astype(np.uint8)
+    both = rng.random(M)
+    return dict(skip=(rng.random(M) < 0.04).astype(np.uint8), in_view=(both < 0.8).astype(np.uint8),
+                in_view_r=(both > 0.3).astype(np.uint8),
+                level=np.clip(kL["octave"][srcL] + rng.integers(0, 2, M), 0, len(sf) - 1).astype(np.int32),
+                level_r=np.where(rng.random(M) < 0.1, -1,
+                                 np.clip(kR["octave"][srcR] + rng.integers(0, 2, M), 0, len(sf) - 1)).astype(np.int32),
+                view_cos=np.where(rng.random(M) < 0.5, 0.9995, 0.9).astype(np.float32),
+                view_cos_r=np.where(rng.random(M) < 0.5, 0.9995, 0.9).astype(np.float32),
+                proj_x=(kL["x"][srcL] + rng.normal(0, 2, M)).astype(np.float32),
+                proj_y=(kL["y"][srcL] + rng.normal(0, 2, M)).astype(np.float32),
+                proj_xr=(kR["x"][srcR] + rng.normal(0, 2, M)).astype(np.float32),
+                proj_yr=(kR["y"][srcR] + rng.normal(0, 2, M)).astype(np.float32),
+                descriptors=d,
+                observations=np.where(rng.random(M) < zero_obs_frac, 0, rng.integers(1, 6, M)).astype(np.int32))
+
+
+def last_frame_scenario(keys, desc, uright, depth, intr, width, height, seed, zero_obs_frac=0.15, cam_model=0,
+                        cam_extra=None):
+    """Last-frame map points: back-project keypoints that have stereo depth with the frame's intrinsics,
+    then move the camera by a small random SE(3) step."""
+    rng = np.random.default_rng(seed)
+    N = len(keys)
+    z = np.where(depth > 0, depth, rng.uniform(2.0, 10.0, N)).astype(np.float32)
+    fx, fy, cx, cy = [float(intr[k]) for k in ("fx", "fy", "cx", "cy")]
+    X = (keys["x"] - cx) / fx * z
+    Y = (keys["y"] - cy) / fy * z
+    world = np.stack([X, Y, z], 1).astype(np.float32)
+    valid = (rng.random(N) < 0.8).astype(np.uint8)
+    d = desc.copy()
+    flips = rng.integers(0, 256, (N, 8))
+    for k in range(8):
+        m = rng.random(N) < 0.5
+        d[m, flips[m, k] // 8] ^= (1 << (flips[m, k] % 8)).astype(np.uint8)
+    obs = np.where(rng.random(N) < zero_obs_frac, 0, rng.integers(1, 6, N)).astype(np.int32)
+    Tcw = random_pose(rng)
+    angle = (keys["angle"] + rng.normal(0, 3.0, N)).astype(np.float32) % np.float32(360.0)
+    return dict(valid=valid, world_pos=world, descriptors=d, observations=obs, octave=keys["octave"].astype(np.int32),
+                angle=angle.astype(np.float32)), Tcw

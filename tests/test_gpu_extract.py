@@ -1,0 +1,155 @@
+"""Parity of the HIP extractor against the oracle, stage by stage and end to end (needs an MI355X).
+
+Bar (BASELINE.json north_star): keypoint coordinates / scores / octaves, descriptor bytes and pyramid
+pixels bit-exact; orientation floats within 1e-4 (they are in fact compared bit-exactly first).
+"""
+import numpy as np
+import pytest
+
+from fasttrack_amd import orb, synth
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [  # (width, height, nfeatures) of BASELINE.json configs 2, 3, 4
+    (640, 480, 1000),
+    (752, 480, 1200),
+    (512, 512, 2000),
+]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = orb.Context(0)
+    yield c
+    c.close()
+
+
+def _check_same(gk, gd, ok, od):
+    assert len(gk) == len(ok)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(gk[f], ok[f]), f
+    assert np.allclose(gk["angle"], ok["angle"], rtol=0, atol=1e-4)
+    assert np.array_equal(gk["angle"], ok["angle"]), "angles agree to 1e-4 but not bit-exactly"
+    assert np.array_equal(gd, od)
+
+
+@pytest.mark.parametrize("w,h,nf", CONFIGS)
+def test_pyramid_and_candidates_bit_exact(ctx, w, h, nf):
+    img = synth.make_image(w, h, seed=11)
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
+    oex = ob.Extractor(nf)
+    ex(img)
+    oex.extract(img)
+    for level in range(8):
+        assert np.array_equal(ex.image_pyramid_level(level), oex.level(level)), f"pyramid level {level}"
+        gc, oc = ex.candidates(level), oex.candidates(level)
+        assert gc.shape == oc.shape and np.array_equal(gc, oc), f"FAST candidates level {level}"
+        assert len(gc) > 0
+
+
+@pytest.mark.parametrize("w,h,nf", CONFIGS + [(1280, 720, 2000)])
+def test_extract_bit_exact(ctx, w, h, nf):
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
+    oex = ob.Extractor(nf)
+    for seed in (1, 2):
+        img = synth.make_image(w, h, seed=seed)
+        gk, gd, gm = ex(img)
+        ok, od, om = oex.extract(img)
+        _check_same(gk, gd, ok, od)
+        assert gm == om
+        assert len(gk) >= nf * 0.9
+
+
+def test_lapping_area_partition(ctx):
+    """fisheye / monocular callers pass a lapping area: keypoints inside fill from the back (ORBextractor.cc:1476-1485)"""
+    w, h, nf = 512, 512, 2000
+    img = synth.make_image(w, h, seed=5)
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
+    oex = ob.Extractor(nf)
+    for lap in [(0, 511), (0, 1000), (200, 300), (0, 0)]:
+        gk, gd, gm = ex(img, lap)
+        ok, od, om = oex.extract(img, lap)
+        _check_same(gk, gd, ok, od)
+        assert gm == om
+    assert ex(img, (0, 1000))[2] == 0  # monocular: everything is written from the back
+
+
+def test_edge_images(ctx):
+    w, h, nf = 640, 480, 1000
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
+    oex = ob.Extractor(nf)
+    # featureless: no keypoints at all
+    flat = synth.make_flat(w, h)
+    gk, gd, gm = ex(flat)
+    assert len(gk) == 0 and gm == 0
+    assert len(oex.extract(flat)[0]) == 0
+    # uniform noise: dense candidates (capacity paths), low-contrast: the minThFAST tier
+    for img in (synth.make_noise(w, h, 3), (synth.make_image(w, h, 9) // 4 + 90).astype(np.uint8)):
+        gk, gd, gm = ex(img)
+        ok, od, om = oex.extract(img)
+        _check_same(gk, gd, ok, od)
+    # empty input: ORBextractor::operator() returns -1
+    assert ex(np.zeros((0, 0), np.uint8))[2] == -1
+    # strided rows
+    big = np.zeros((h, w + 24), np.uint8)
+    img = synth.make_image(w, h, 4)
+    big[:, :w] = img
+    import ctypes as C
+    from fasttrack_amd._capi import lib, ptr, check, KP_DTYPE
+    cap = ex.max_keypoints
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n, nm = C.c_int(), C.c_int()
+    check(lib().ft_extract(ex._h, ptr(big), w, h, big.strides[0], 0, 0, ptr(kps), ptr(desc), cap, C.byref(n), C.byref(nm)))
+    ok, od, _ = oex.extract(img)
+    _check_same(kps[:n.value], desc[:n.value], ok, od)
+
+
+def test_small_and_odd_sizes(ctx):
+    for (w, h, nf, levels) in [(97, 83, 200, 3), (160, 120, 300, 4), (333, 257, 500, 8), (1000, 96, 400, 2)]:
+        img = synth.make_image(w, h, seed=w)
+        ex = orb.ORBextractor(ctx, nf, 1.2, levels, 20, 7, w, h)
+        oex = ob.Extractor(nf, 1.2, levels)
+        gk, gd, gm = ex(img)
+        ok, od, om = oex.extract(img)
+        _check_same(gk, gd, ok, od)
+
+
+def test_other_parameters(ctx):
+    w, h = 640, 480
+    img = synth.make_image(w, h, seed=21)
+    for (nf, sf, levels, ini, mn) in [(500, 1.5, 5, 30, 10), (1500, 1.1, 10, 12, 5), (800, 2.0, 4, 20, 7)]:
+        ex = orb.ORBextractor(ctx, nf, sf, levels, ini, mn, w, h)
+        oex = ob.Extractor(nf, sf, levels, ini, mn)
+        gk, gd, gm = ex(img)
+        ok, od, om = oex.extract(img)
+        _check_same(gk, gd, ok, od)
+
+
+def test_batch_equals_single_and_device_resident(ctx):
+    w, h, nf, B = 752, 480, 1200, 5
+    imgs = [synth.make_image(w, h, seed=100 + b) for b in range(B)]
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=B)
+    oex = ob.Extractor(nf)
+    res = ex.extract_batch(imgs)
+    dev = [ctx.to_device(im) for im in imgs]
+    res_dev = ex.extract_batch(dev, on_device=True, width=w, height=h, stride=w)
+    for b in range(B):
+        ok, od, om = oex.extract(imgs[b])
+        _check_same(res[b][0], res[b][1], ok, od)
+        _check_same(res_dev[b][0], res_dev[b][1], ok, od)
+    # pyramids of every slot stay resident
+    for b in (0, B - 1):
+        oex.extract(imgs[b])
+        assert np.array_equal(ex.image_pyramid_level(3, slot=b), oex.level(3))
+
+
+def test_getters_match_oracle_tables(ctx):
+    ex = orb.ORBextractor(ctx, 1200, 1.2, 8, 20, 7, 752, 480)
+    sf, inv = ob.scale_factors(1.2, 8)
+    assert np.array_equal(ex.GetScaleFactors(), sf) and np.array_equal(ex.GetInverseScaleFactors(), inv)
+    assert np.array_equal(ex.GetScaleSigmaSquares(), sf * sf)
+    assert np.array_equal(ex.features_per_level(), ob.features_per_level(1200, 1.2, 8))
+    lw, lh = ob.level_sizes(752, 480, 1.2, 8)
+    assert [ex.level_size(l) for l in range(8)] == list(zip(lw.tolist(), lh.tolist()))

@@ -1,0 +1,201 @@
+"""Parity of the HIP matchers against the oracle (needs an MI355X): stereo (row-band Hamming + SAD +
+parabola + median cut), fisheye 2-NN, both projection searches, DescriptorDistance."""
+import numpy as np
+import pytest
+
+from fasttrack_amd import orb, synth
+from oracle import binding as ob
+from tests import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = orb.Context(0)
+    yield c
+    c.close()
+
+
+def test_descriptor_distance(ctx):
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (5000, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (5000, 32), dtype=np.uint8)
+    b[:100] = a[:100]
+    b[100:200] = ~a[100:200]
+    g = orb.KernelController.descriptor_distance(ctx, a, b)
+    o = np.array([ob.descriptor_distance(a[i], b[i]) for i in range(len(a))])
+    assert np.array_equal(g, o) and g[:100].max() == 0 and g[100:200].min() == 256
+
+
+@pytest.mark.parametrize("w,h,nf,seed", [(752, 480, 1200, 3), (1280, 720, 2000, 4), (640, 480, 1000, 5)])
+def test_stereo_match_bit_exact(ctx, w, h, nf, seed):
+    fr = sc.oracle_stereo_frame(w, h, nf, seed)
+    exL = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
+    exR = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
+    exL(fr["L"])
+    exR(fr["R"])
+    mbf, mb = fr["intr"]["mbf"], fr["intr"]["mb"]
+    for cut in (False, True):
+        o = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], mbf, mb, median_cut=cut)
+        g = orb.KernelController.launchStereoMatchKernel(exL, exR, fr["kL"], fr["kR"], fr["dL"], fr["dR"], mbf, mb,
+                                                         median_cut=cut)
+        assert g["n"] == o["n"] and o["n"] > 20
+        assert np.array_equal(g["uright"] >= 0, o["uright"] >= 0)
+        assert np.allclose(g["uright"], o["uright"], rtol=0, atol=1e-4)
+        assert np.allclose(g["depth"], o["depth"], rtol=1e-6, atol=1e-4)
+        assert np.array_equal(g["uright"], o["uright"]) and np.array_equal(g["depth"], o["depth"])
+        if not cut:
+            assert np.array_equal(g["sad"], o["sad"])
+
+
+def test_stereo_edge_cases(ctx):
+    w, h, nf = 640, 480, 1000
+    fr = sc.oracle_stereo_frame(w, h, nf, 8)
+    exL = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
+    exR = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
+    exL(fr["L"])
+    exR(fr["R"])
+    mbf, mb = fr["intr"]["mbf"], fr["intr"]["mb"]
+    # no right keypoints / no left keypoints
+    g = orb.KernelController.launchStereoMatchKernel(exL, exR, fr["kL"], fr["kR"][:0], fr["dL"], fr["dR"][:0], mbf, mb)
+    assert g["n"] == 0 and (g["uright"] == -1).all()
+    g = orb.KernelController.launchStereoMatchKernel(exL, exR, fr["kL"][:0], fr["kR"], fr["dL"][:0], fr["dR"], mbf, mb)
+    assert g["n"] == 0
+    # identical images: zero disparity -> the reference clamps to 0.01 (Frame.cc:979-983)
+    exR(fr["L"])
+    fr["exR"].extract(fr["L"])
+    o = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kL"], fr["dL"], fr["dL"], mbf, mb)
+    g = orb.KernelController.launchStereoMatchKernel(exL, exR, fr["kL"], fr["kL"], fr["dL"], fr["dL"], mbf, mb)
+    assert g["n"] == o["n"] and np.array_equal(g["uright"], o["uright"]) and np.array_equal(g["depth"], o["depth"])
+    assert (o["depth"] > 0).sum() > 100
+
+
+@pytest.mark.parametrize("w,h,nf,B", [(752, 480, 1200, 3), (1280, 720, 2000, 2)])
+def test_stereo_frontend_fused(ctx, w, h, nf, B):
+    intr = synth.intrinsics(w, h)
+    fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
+    pairs = [synth.make_stereo_pair(w, h, 40 + b) for b in range(B)]
+    outs = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
+    devL = [ctx.to_device(p[0]) for p in pairs]
+    devR = [ctx.to_device(p[1]) for p in pairs]
+    outs_dev = fe.process(devL, devR, on_device=True, stride=w)
+    for b in range(B):
+        oL, oR = ob.Extractor(nf), ob.Extractor(nf)
+        kL, dL, _ = oL.extract(pairs[b][0])
+        kR, dR, _ = oR.extract(pairs[b][1])
+        o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+        for out in (outs[b], outs_dev[b]):
+            assert np.array_equal(out["keysL"], kL) and np.array_equal(out["keysR"], kR)
+            assert np.array_equal(out["descL"], dL) and np.array_equal(out["descR"], dR)
+            assert out["n"] == o["n"]
+            assert np.array_equal(out["uright"], o["uright"]) and np.array_equal(out["depth"], o["depth"])
+
+
+def test_fisheye_match(ctx):
+    rng = np.random.default_rng(2)
+    fr = sc.oracle_stereo_frame(512, 512, 2000, 6)
+    for (dL, dR) in [(fr["dL"], fr["dR"]), (fr["dL"][:700], fr["dR"][:1]), (fr["dL"][:5], fr["dR"][:0]),
+                     (rng.integers(0, 256, (300, 32), dtype=np.uint8), rng.integers(0, 256, (2500, 32), dtype=np.uint8))]:
+        o = ob.fisheye_match(dL, dR)
+        g = orb.KernelController.launchFisheyeStereoMatchKernel(ctx, dL, dR)
+        assert np.array_equal(g["matches"], o["matches"])
+        if len(dR) >= 2:
+            assert np.array_equal(g["best"], o["best"]) and np.array_equal(g["second"], o["second"])
+    # ties: duplicated train rows -> the earlier index wins and the ratio test fails (best == second)
+    dR = np.concatenate([fr["dR"][:50], fr["dR"][:50]])
+    o = ob.fisheye_match(fr["dR"][:50], dR)
+    g = orb.KernelController.launchFisheyeStereoMatchKernel(ctx, fr["dR"][:50], dR)
+    assert np.array_equal(g["matches"], o["matches"]) and (g["best"] == 0).all() and (g["second"] == 0).all()
+
+
+def _frame_views(fr, sf, w, h, uright=None, holder=None):
+    args = dict(keys=fr["kL"], descriptors=fr["dL"], bounds=sc.frame_bounds(w, h), mbf=fr["intr"]["mbf"],
+                mb=fr["intr"]["mb"], uright=uright, holder_obs=holder,
+                cam=[fr["intr"][k] for k in ("fx", "fy", "cx", "cy")])
+    return ob.FrameView(scale_factors_=sf, **args), orb.FrameView(scale_factors=sf, **args)
+
+
+@pytest.mark.parametrize("th,dense", [(1.0, False), (3.0, False), (7.0, True), (15.0, True)])
+def test_search_local_points_mono_stereo(ctx, th, dense):
+    w, h, nf = 752, 480, 1200
+    fr = sc.oracle_stereo_frame(w, h, nf, 12)
+    sf, _ = ob.scale_factors(1.2, 8)
+    sm = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], fr["intr"]["mbf"], fr["intr"]["mb"])
+    rng = np.random.default_rng(5)
+    holder = np.where(rng.random(len(fr["kL"])) < 0.1, rng.integers(0, 3, len(fr["kL"])), -1).astype(np.int32)
+    pts = sc.local_points_scenario(fr["kL"], fr["dL"], sf, w, h, seed=int(th * 10), M=1800, uright=sm["uright"], dense=dense)
+    oF, gF = _frame_views(fr, sf, w, h, uright=sm["uright"], holder=holder)
+    o = ob.search_local_points(oF, pts, th)
+    g = orb.KernelController.launchSearchLocalPointsKernel(ctx, gF, pts, th)
+    assert o["n"] > 50
+    assert g["n"] == o["n"] and np.array_equal(g["assign"], o["assign"])
+    assert np.array_equal(gF.holder_obs, oF.holder_obs)
+    for k in ("best_dist", "best_dist2", "best_level", "best_level2", "best_idx"):
+        assert np.array_equal(g[k], o[k]), k
+
+
+def test_search_local_points_two_cameras(ctx):
+    w, h, nf = 512, 512, 1500
+    fr = sc.fisheye_frame_scenario(w, h, nf, 9)
+    sf, _ = ob.scale_factors(1.2, 8)
+    pts = sc.two_camera_points(fr, sf, 3)
+    kw = dict(keys=fr["kL"], keys_right=fr["kR"], descriptors=np.concatenate([fr["dL"], fr["dR"]]),
+              bounds=sc.frame_bounds(w, h), left_to_right=fr["l2r"], right_to_left=fr["r2l"])
+    oF = ob.FrameView(scale_factors_=sf, **kw)
+    gF = orb.FrameView(scale_factors=sf, **kw)
+    o = ob.search_local_points(oF, pts, 1.0)
+    g = orb.KernelController.launchSearchLocalPointsKernel(ctx, gF, pts, 1.0)
+    assert o["n"] > 50 and (o["assign"][len(fr["kL"]):] >= 0).sum() > 10
+    assert g["n"] == o["n"] and np.array_equal(g["assign"], o["assign"])
+    assert np.array_equal(gF.holder_obs, oF.holder_obs)
+    for k in ("best_dist", "best_dist2", "best_level", "best_level2", "best_idx", "best_dist_r", "best_dist2_r",
+              "best_level_r", "best_level2_r", "best_idx_r"):
+        assert np.array_equal(g[k], o[k]), k
+
+
+@pytest.mark.parametrize("th,fwd,bwd,ori", [(7.0, False, False, True), (15.0, True, False, True), (15.0, False, True, False)])
+def test_search_last_frame_pinhole(ctx, th, fwd, bwd, ori):
+    w, h, nf = 752, 480, 1200
+    fr = sc.oracle_stereo_frame(w, h, nf, 14)
+    sf, _ = ob.scale_factors(1.2, 8)
+    sm = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], fr["intr"]["mbf"], fr["intr"]["mb"])
+    last, Tcw = sc.last_frame_scenario(fr["kL"], fr["dL"], sm["uright"], sm["depth"], fr["intr"], w, h, seed=2)
+    oF, gF = _frame_views(fr, sf, w, h, uright=sm["uright"])
+    o = ob.search_last_frame(oF, last, Tcw, th, fwd, bwd, ori)
+    g = orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, Tcw, th, fwd, bwd, ori)
+    assert o["n"] > 100
+    assert g["n"] == o["n"] and np.array_equal(g["assign"], o["assign"])
+    assert np.array_equal(g["best_dist"], o["best_dist"]) and np.array_equal(g["best_idx"], o["best_idx"])
+    assert np.array_equal(gF.holder_obs, oF.holder_obs)
+
+
+def test_search_last_frame_two_cameras_kb8(ctx):
+    """fisheye stereo (config 4): KannalaBrandt8 projection, right-camera search through Trl.  Projection
+    uses libm atan2f/cosf/sinf on the host and OCML on the device: indices must agree, floats within 1e-4."""
+    w, h, nf = 512, 512, 1500
+    fr = sc.fisheye_frame_scenario(w, h, nf, 10)
+    sf, _ = ob.scale_factors(1.2, 8)
+    cam = [190.978, 190.973, 254.93, 256.90, 0.0034, 0.0007, -0.0020, 0.00020]  # TUM-VI-like KB8
+    rng = np.random.default_rng(1)
+    N = len(fr["kL"])
+    # back-project left keypoints through an approximate inverse (pinhole-ish near the centre is enough)
+    z = rng.uniform(2, 8, N).astype(np.float32)
+    X = ((fr["kL"]["x"] - cam[2]) / cam[0] * z).astype(np.float32)
+    Y = ((fr["kL"]["y"] - cam[3]) / cam[1] * z).astype(np.float32)
+    last = dict(valid=(rng.random(N) < 0.8).astype(np.uint8), world_pos=np.stack([X, Y, z], 1),
+                descriptors=fr["dL"].copy(), observations=rng.integers(0, 4, N).astype(np.int32),
+                octave=fr["kL"]["octave"].astype(np.int32), angle=fr["kL"]["angle"].copy())
+    Tcw = sc.random_pose(rng, 0.02, 0.005)
+    Trl = np.concatenate([np.eye(3), [[-0.1], [0.0], [0.0]]], 1).astype(np.float32)
+    kw = dict(keys=fr["kL"], keys_right=fr["kR"], descriptors=np.concatenate([fr["dL"], fr["dR"]]),
+              bounds=sc.frame_bounds(w, h), left_to_right=fr["l2r"], right_to_left=fr["r2l"], cam_model=1, cam=cam,
+              Trl=Trl)
+    oF = ob.FrameView(scale_factors_=sf, **kw)
+    gF = orb.FrameView(scale_factors=sf, **kw)
+    o = ob.search_last_frame(oF, last, Tcw, 15.0, False, False, True)
+    g = orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, Tcw, 15.0, False, False, True)
+    assert o["n"] > 30
+    assert g["n"] == o["n"] and np.array_equal(g["assign"], o["assign"])
+    for k in ("best_dist", "best_idx", "best_dist_r", "best_idx_r"):
+        assert np.array_equal(g[k], o[k]), k
