@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py - frames/s of the tracking front end hot path (extract + stereo match) on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic rectified stereo pairs that are
+already resident in HBM: ORB extraction of the left and right image (pyramid, FAST-9 + NMS per cell,
+octree distribution, orientation, blur, rBRIEF) followed by Frame::ComputeStereoMatches, with the
+keypoints / descriptors / mvuRight / mvDepth delivered to host arrays as the reference's callers
+expect.  Default workload = BASELINE.json config 5's per-GPU shard: one 1280x720 stereo stream,
+nFeatures 2000, 8 levels, scale 1.2, FAST 20/7.  One process per GPU; streams are independent, so N
+GPUs run N shards with no collective on the data path (weak scaling); torch.distributed (gloo) is
+used only for the barrier and the max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
+  roofline      dominant kernel (FAST cells): algorithmic bytes per launch / HIP-event duration vs 8 TB/s
+  cpu_baseline  the oracle (restated CPU path of the reference) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from fasttrack_amd import orb, synth  # noqa: E402
+
+WORKLOADS = {
+    # name: (width, height, nfeatures, BASELINE.json config it mirrors)
+    "stereo_1280x720_nf2000": (1280, 720, 2000, "configs[4] per-GPU shard: synthetic 1280x720 stereo stream, nFeatures=2000"),
+    "stereo_752x480_nf1200": (752, 480, 1200, "configs[2] shape: EuRoC-like 752x480 stereo, extract + ComputeStereoMatches"),
+    "stereo_640x480_nf1000": (640, 480, 1000, "configs[1] size with stereo matching"),
+}
+NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def level_pixels(w, h):
+    P = []
+    sf = np.float32(1.0)
+    for l in range(NLEVELS):
+        inv = np.float32(1.0) / sf
+        lw = int(np.rint(np.float32(w) * inv))
+        lh = int(np.rint(np.float32(h) * inv))
+        P.append(lw * lh)
+        sf = np.float32(sf * np.float32(SCALE))
+    return P
+
+
+def cpu_baseline(w, h, nf, pairs, budget_s=20.0):
+    """Oracle (oracle/, kind 'port') on host cores: extract L + R + ComputeStereoMatches per pair.
+    One worker per pair across all cores (ctypes releases the GIL); bounded by ~budget_s of wall time.
+    Also times the reference's own threading (left/right extraction on two threads, src/Frame.cc:127-130)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import binding as ob
+    intr = synth.intrinsics(w, h)
+    cores = os.cpu_count() or 1
+
+    def one(pair):
+        L, R = pair
+        exL, exR = ob.Extractor(nf, SCALE, NLEVELS, INI_TH, MIN_TH), ob.Extractor(nf, SCALE, NLEVELS, INI_TH, MIN_TH)
+        kL, dL, _ = exL.extract(L)
+        kR, dR, _ = exR.extract(R)
+        ob.stereo_match(exL, exR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+        return len(kL) + len(kR)
+
+    t0 = time.perf_counter()
+    one(pairs[0])
+    t1 = time.perf_counter() - t0
+    # reference threading: two threads for the two extractions of ONE pair
+    exL, exR = ob.Extractor(nf, SCALE, NLEVELS, INI_TH, MIN_TH), ob.Extractor(nf, SCALE, NLEVELS, INI_TH, MIN_TH)
+    n_ref = max(2, min(16, int(4.0 / max(t1, 1e-3))))
+    with ThreadPoolExecutor(2) as tp:
+        t0 = time.perf_counter()
+        for i in range(n_ref):
+            L, R = pairs[i % len(pairs)]
+            fa, fb = tp.submit(exL.extract, L), tp.submit(exR.extract, R)
+            (kL, dL, _), (kR, dR, _) = fa.result(), fb.result()
+            ob.stereo_match(exL, exR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+        ref_fps = n_ref / (time.perf_counter() - t0)
+    n_all = max(cores, min(64 * cores, int(budget_s * cores / max(t1, 1e-3))))
+    n_all = (n_all // cores) * cores
+    with ThreadPoolExecutor(cores) as tp:
+        t0 = time.perf_counter()
+        list(tp.map(one, [pairs[i % len(pairs)] for i in range(n_all)]))
+        dt = time.perf_counter() - t0
+    return {"value": n_all / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n_all} synthetic {w}x{h} stereo pairs (nFeatures {nf}), oracle extract L+R + stereo match, "
+                      f"{cores} worker threads one pair each, {dt:.1f} s; reference threading (2 threads per pair, "
+                      f"matcher single-threaded): {ref_fps:.2f} frames/s over {n_ref} pairs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="stereo_1280x720_nf2000", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=32, help="stereo pairs per step per GPU")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
+    ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stats", default="", help="write per-stage timings to this file")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        # plumbing only: CPU tensors over gloo, the data path has no exchange step
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    w, h, nf, cfg_note = WORKLOADS[args.workload]
+    B = args.batch
+    host_threads = args.host_threads or max(1, (os.cpu_count() or 1) // max(world, 1))
+    ctx = orb.Context(local_rank, host_threads)
+    intr = synth.intrinsics(w, h)
+    fe = orb.StereoFrontend(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, B, intr["mbf"], intr["mb"])
+
+    # synthetic stream, resident in HBM before the timed region (seeds are per rank: one stream per GPU)
+    D = max(1, min(args.distinct, B))
+    pairs = [synth.make_stereo_pair(w, h, seed=1000 * rank + i) for i in range(D)]
+    devL = [ctx.to_device(p[0]) for p in pairs]
+    devR = [ctx.to_device(p[1]) for p in pairs]
+    import ctypes as C
+    ptrsL = (C.c_void_p * B)(*[devL[b % D].ptr for b in range(B)])
+    ptrsR = (C.c_void_p * B)(*[devR[b % D].ptr for b in range(B)])
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        fe.process_raw(ptrsL, ptrsR, B, True, w)
+    ctx.reset_stats()
+    ctx.set_kernel_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fe.process_raw(ptrsL, ptrsR, B, True, w)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    kps = int(fe._nL[:B].sum() + fe._nR[:B].sum())
+    matches = int(fe._nm[:B].sum())
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        c = torch.tensor([kps, matches], dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        kps, matches = int(c[0]), int(c[1])
+
+    if args.stats:
+        ctx.save_stats(args.stats + (f".rank{rank}" if world > 1 else ""))
+
+    if rank == 0:
+        frames = B * args.steps * world
+        fps = frames / elapsed
+        P = level_pixels(w, h)
+        sumP = sum(P)
+        # dominant kernel: k_fast_cells.  Algorithmic bytes: FAST + NMS reads every pyramid
+        # pixel once = sum(P_l) bytes per image; one launch covers B images (one launch per camera).
+        ms, launches = ctx.get_stat("kernel.fast_cells")
+        kern = {}
+        for name in ("kernel.pyr_down(all levels)", "kernel.fast_cells", "kernel.compact", "kernel.orient_desc",
+                     "kernel.stereo_match", "kernel.stereo_median"):
+            m, n = ctx.get_stat(name)
+            kern[name] = {"ms_per_launch": (m / n) if n else None, "launches": n}
+        host = {}
+        for name in ("stereo.octree(host,both)", "stereo.process.total"):
+            m, n = ctx.get_stat(name)
+            host[name] = (m / n) if n else None
+        bytes_per_launch = float(B * sumP)
+        roof = None
+        if launches:
+            dur_s = ms / launches / 1e3
+            achieved = bytes_per_launch / dur_s / 1e9
+            roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                    "avg_launch_ms": ms / launches, "launches_timed": launches}
+        R_pair = 2 * (3 * sumP - P[-1])  # read bytes per stereo pair, unfused accounting
+        out = {
+            "metric": "frames/sec extract+match", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": args.workload, "note": cfg_note, "frame": "one rectified stereo pair",
+                       "image": [w, h], "nfeatures": nf, "nlevels": NLEVELS, "scale_factor": SCALE,
+                       "fast_thresholds": [INI_TH, MIN_TH], "batch_pairs_per_gpu": B, "distinct_pairs": D,
+                       "parallelism": f"{world} independent stream(s), one per GPU, no collective",
+                       "host_threads_per_gpu": ctx.host_threads, "device": ctx.device_name},
+            "keypoints_per_s": kps * args.steps / elapsed if world == 1 else kps * args.steps / elapsed,
+            "stereo_matches_per_frame": matches / (B * world),
+            "pipeline_hbm_read_frac": fps * R_pair / (HBM_PEAK_GBS * 1e9),
+            "kernels": kern, "host_ms_per_step": host,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, h, nf, pairs)
+            out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,9 @@ def lib() -> C.CDLL:
     L.ft_context_device_name.argtypes = [vp, C.c_char_p, i]
     L.ft_context_host_threads.argtypes = [vp]
     L.ft_context_save_stats.argtypes = [vp, C.c_char_p]
+    L.ft_context_set_kernel_timing.argtypes = [vp, i]
+    L.ft_context_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    L.ft_context_reset_stats.argtypes = [vp]
     L.ft_device_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.ft_device_free.argtypes = [vp, vp]
     L.ft_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]

@@ -112,6 +112,28 @@ int ft_context_save_stats(ft_context *ctx, const char *path) {
     return FT_OK;
 }
 
+int ft_context_set_kernel_timing(ft_context *ctx, int enabled) {
+    if (!ctx) return FT_ERR_INVALID;
+    ctx->kernelTiming = enabled != 0;
+    return FT_OK;
+}
+
+int ft_context_get_stat(ft_context *ctx, const char *name, double *total_ms, long *calls) {
+    if (!ctx || !name) return FT_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->statsMutex);
+    auto it = ctx->stats.find(name);
+    if (total_ms) *total_ms = it == ctx->stats.end() ? 0.0 : it->second.first;
+    if (calls) *calls = it == ctx->stats.end() ? 0 : it->second.second;
+    return FT_OK;
+}
+
+int ft_context_reset_stats(ft_context *ctx) {
+    if (!ctx) return FT_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->statsMutex);
+    ctx->stats.clear();
+    return FT_OK;
+}
+
 int ft_device_malloc(ft_context *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return FT_ERR_INVALID;
     FT_HIP(hipSetDevice(ctx->device));

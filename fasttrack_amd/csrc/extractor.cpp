@@ -148,6 +148,7 @@ int pinAlloc(T **p, size_t n, unsigned flags = hipHostMallocDefault) {
 void freeAll(ft_extractor *ex) {
     hipSetDevice(ex->ctx->device);
     if (ex->stream) hipStreamSynchronize(ex->stream);
+    ex->evt.destroy();
     hipFree(ex->d_pyr);
     hipFree(ex->d_taps);
     hipFree(ex->d_cellCount);
@@ -204,10 +205,20 @@ int ft_extract_stage_a(ft_extractor *ex, const uint8_t *const *images, int batch
     ex->lastBatch = batch;
     FT_HIP(hipMemcpyAsync((void *)ex->d_l0, (const void *)ex->h_l0, sizeof(uint8_t *) * batch, hipMemcpyHostToDevice,
                           ex->stream));
+    const bool tm = ex->ctx->kernelTiming;
+    ex->evt.begin(tm, "kernel.pyr_down(all levels)", ex->stream);
     rc = ft_launch_pyramid(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->d_taps);
+    ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
-    return ft_launch_fast(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->iniTh, ex->minTh,
-                          ex->d_cellCount, ex->d_stage, ex->d_cand, ex->d_candCount);
+    ex->evt.begin(tm, "kernel.fast_cells", ex->stream);
+    rc = ft_launch_fast_cells(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->iniTh, ex->minTh,
+                              ex->d_cellCount, ex->d_stage);
+    ex->evt.end(tm, ex->stream);
+    if (rc != FT_OK) return rc;
+    ex->evt.begin(tm, "kernel.compact", ex->stream);
+    rc = ft_launch_compact(ex->stream, g, batch, ex->d_cellCount, ex->d_stage, ex->d_cand, ex->d_candCount);
+    ex->evt.end(tm, ex->stream);
+    return rc;
 }
 
 int ft_extract_octree(ft_extractor *ex, int batch) {
@@ -262,8 +273,11 @@ int ft_extract_stage_b(ft_extractor *ex, int batch) {
     if (maxN == 0) return FT_OK;
     FT_HIP(hipMemcpy2DAsync(ex->d_sel, sizeof(FtSelKp) * g.maxKp, ex->h_sel, sizeof(FtSelKp) * g.maxKp,
                             sizeof(FtSelKp) * maxN, batch, hipMemcpyHostToDevice, ex->stream));
+    const bool tm = ex->ctx->kernelTiming;
+    ex->evt.begin(tm, "kernel.orient_desc", ex->stream);
     int rc = ft_launch_orient_desc(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->d_sel, ex->d_nSel,
                                    ex->d_keys, ex->d_desc);
+    ex->evt.end(tm, ex->stream);
     return rc;
 }
 
@@ -278,6 +292,7 @@ static int downloadResults(ft_extractor *ex, int batch) {
                                 batch, hipMemcpyDeviceToHost, ex->stream));
     }
     FT_HIP(hipStreamSynchronize(ex->stream));
+    ex->evt.resolve(ex->ctx);
     return FT_OK;
 }
 

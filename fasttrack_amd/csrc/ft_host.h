@@ -20,6 +20,7 @@ struct ft_context {
     std::mutex matchMutex;
     void *scratchDev = nullptr, *scratchPin = nullptr;
     size_t scratchDevBytes = 0, scratchPinBytes = 0;
+    bool kernelTiming = false;  // ft_context_set_kernel_timing
     std::mutex statsMutex;
     std::map<std::string, std::pair<double, long>> stats;  // name -> (total ms, calls)
     void addStat(const char *name, double ms) {
@@ -27,6 +28,49 @@ struct ft_context {
         auto &s = stats[name];
         s.first += ms;
         s.second += 1;
+    }
+};
+
+// HIP-event timing of kernel groups on the stream they are launched on (bench.py's roofline leg).
+// begin()/end() bracket launches; resolve() is called after the stream has been synchronised.
+struct FtEventTimer {
+    struct Rec {
+        const char *name;
+        hipEvent_t a, b;
+    };
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    std::vector<Rec> recs;
+    hipEvent_t get() {
+        if (used == pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+    void begin(bool enabled, const char *name, hipStream_t st) {
+        if (!enabled) return;
+        Rec r{name, get(), get()};
+        if (!r.a || !r.b) return;
+        hipEventRecord(r.a, st);
+        recs.push_back(r);
+    }
+    void end(bool enabled, hipStream_t st) {
+        if (!enabled || recs.empty()) return;
+        hipEventRecord(recs.back().b, st);
+    }
+    void resolve(ft_context *ctx) {
+        for (auto &r : recs) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) ctx->addStat(r.name, ms);
+        }
+        recs.clear();
+        used = 0;
+    }
+    void destroy() {
+        for (auto e : pool) hipEventDestroy(e);
+        pool.clear();
     }
 };
 
@@ -69,6 +113,7 @@ struct ft_extractor {
     float *d_stOut = nullptr;         // [2 * maxKp] uright then depth
     int *d_stInt = nullptr;           // [2 * stCap + 4] sad, hamming idx, then nL nR nMatches
     int stCap = 0;
+    FtEventTimer evt;
     // state of the last call (consumed by the stereo matcher)
     int lastBatch = 0;
     int l0pitch = 0;

@@ -76,9 +76,10 @@ int ft_hip_fail(hipError_t e, const char *what, const char *file, int line);
 // l0: device array [batch] of level-0 pointers; pyr: base of the slot pyramids
 int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                       uint8_t *pyr, const FtTap *taps);
-int ft_launch_fast(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                   const uint8_t *pyr, int iniTh, int minTh, int *cellCount, uint32_t *stage, uint32_t *cand,
-                   int *candCount);
+int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
+                         const uint8_t *pyr, int iniTh, int minTh, int *cellCount, uint32_t *stage);
+int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cellCount, const uint32_t *stage,
+                      uint32_t *cand, int *candCount);
 int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                           const uint8_t *pyr, const FtSelKp *sel, const int *nSel, ft_keypoint *keys,
                           uint8_t *desc);
@@ -97,9 +98,10 @@ struct FtStereoArgs {
     int *nMatches;                     // device [batch]
     int applyMedianCut;
 };
-int ft_launch_stereo(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
-                     const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
-                     const uint8_t *pyrR, const FtStereoArgs &a);
+int ft_launch_stereo_match(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
+                           const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
+                           const uint8_t *pyrR, const FtStereoArgs &a);
+int ft_launch_stereo_median(hipStream_t st, int batch, const FtStereoArgs &a);
 int ft_launch_fisheye(hipStream_t st, const uint8_t *descL, int nL, const uint8_t *descR, int nR, int *matches,
                       int *best, int *second);
 int ft_launch_hamming_pairs(hipStream_t st, const uint8_t *a, const uint8_t *b, int n, int *dist);

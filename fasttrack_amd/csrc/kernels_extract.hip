@@ -434,15 +434,20 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
     return FT_OK;
 }
 
-int ft_launch_fast(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                   const uint8_t *pyr, int iniTh, int minTh, int *cellCount, uint32_t *stage, uint32_t *cand,
-                   int *candCount) {
+int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
+                         const uint8_t *pyr, int iniTh, int minTh, int *cellCount, uint32_t *stage) {
     dim3 grid(g.totalCells, batch, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_fast_cells, grid, block, ft_fast_smem_bytes(g), st, g, l0, l0pitch, pyr, iniTh, minTh,
                        cellCount, stage);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cellCount, const uint32_t *stage,
+                      uint32_t *cand, int *candCount) {
     int maxCells = 0;
     for (int l = 0; l < g.nlevels; l++) maxCells = std::max(maxCells, g.lv[l].nCols * g.lv[l].nRows);
-    dim3 grid2(g.nlevels, batch, 1);
+    dim3 grid2(g.nlevels, batch, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_compact, grid2, block, (size_t)(maxCells + 1) * sizeof(int), st, g, cellCount, stage, cand,
                        candCount);
     FT_HIP(hipGetLastError());

@@ -255,12 +255,17 @@ __global__ __launch_bounds__(256) void k_hamming_pairs(const uint8_t *a, const u
 
 }  // namespace
 
-int ft_launch_stereo(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
-                     const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
-                     const uint8_t *pyrR, const FtStereoArgs &a) {
+int ft_launch_stereo_match(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
+                           const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
+                           const uint8_t *pyrR, const FtStereoArgs &a) {
     dim3 grid((a.capacity + 3) / 4, batch, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_stereo_match, grid, block, 0, st, g, l0L, l0R, l0pitchL, l0pitchR, pyrL, pyrR, a);
-    hipLaunchKernelGGL(k_stereo_median, dim3(batch), block, 0, st, a);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_stereo_median(hipStream_t st, int batch, const FtStereoArgs &a) {
+    hipLaunchKernelGGL(k_stereo_median, dim3(batch), dim3(256), 0, st, a);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -84,8 +84,10 @@ int ft_stereo_match(ft_extractor *exL, ft_extractor *exR, int slot, const ft_key
     a.hamIdx = exL->d_stInt + C;
     a.nMatches = d_hdr + 2;
     a.applyMedianCut = apply_median_cut;
-    rc = ft_launch_stereo(st, g, 1, exL->d_l0 + slot, exR->d_l0 + slot, exL->l0pitch, exR->l0pitch,
-                          exL->d_pyr + (size_t)slot * g.pyrPerSlot, exR->d_pyr + (size_t)slot * g.pyrPerSlot, a);
+    rc = ft_launch_stereo_match(st, g, 1, exL->d_l0 + slot, exR->d_l0 + slot, exL->l0pitch, exR->l0pitch,
+                                exL->d_pyr + (size_t)slot * g.pyrPerSlot, exR->d_pyr + (size_t)slot * g.pyrPerSlot, a);
+    if (rc != FT_OK) return rc;
+    rc = ft_launch_stereo_median(st, 1, a);
     if (rc != FT_OK) return rc;
     FT_HIP(hipMemcpyAsync(uright, a.uright, sizeof(float) * nL, hipMemcpyDeviceToHost, st));
     FT_HIP(hipMemcpyAsync(depth, a.depth, sizeof(float) * nL, hipMemcpyDeviceToHost, st));
@@ -202,7 +204,14 @@ int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *ima
     a.hamIdx = nullptr;
     a.nMatches = fe->d_nMatches;
     a.applyMedianCut = 1;
-    rc = ft_launch_stereo(L->stream, g, batch, L->d_l0, R->d_l0, L->l0pitch, R->l0pitch, L->d_pyr, R->d_pyr, a);
+    const bool tm = fe->ctx->kernelTiming;
+    L->evt.begin(tm, "kernel.stereo_match", L->stream);
+    rc = ft_launch_stereo_match(L->stream, g, batch, L->d_l0, R->d_l0, L->l0pitch, R->l0pitch, L->d_pyr, R->d_pyr, a);
+    L->evt.end(tm, L->stream);
+    if (rc != FT_OK) return rc;
+    L->evt.begin(tm, "kernel.stereo_median", L->stream);
+    rc = ft_launch_stereo_median(L->stream, batch, a);
+    L->evt.end(tm, L->stream);
     if (rc != FT_OK) return rc;
     int maxNL = 0, maxNR = 0;
     for (int b = 0; b < batch; b++) {
@@ -223,6 +232,8 @@ int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *ima
     }
     FT_HIP(hipMemcpyAsync(fe->h_nMatches, fe->d_nMatches, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
     FT_HIP(hipStreamSynchronize(st));
+    L->evt.resolve(fe->ctx);
+    R->evt.resolve(fe->ctx);
     for (int b = 0; b < batch; b++) {
         const int nl = L->h_nSel[b], nr = R->h_nSel[b];
         if (nl > capacity || nr > capacity) {

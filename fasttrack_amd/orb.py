@@ -51,6 +51,18 @@ class Context:
     def host_threads(self) -> int:
         return lib().ft_context_host_threads(self._h)
 
+    def set_kernel_timing(self, enabled: bool):
+        check(lib().ft_context_set_kernel_timing(self._h, int(enabled)))
+
+    def get_stat(self, name: str):
+        """-> (total_ms, calls) of a stat / kernel-timing series"""
+        ms, n = C.c_double(), C.c_long()
+        check(lib().ft_context_get_stat(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def reset_stats(self):
+        check(lib().ft_context_reset_stats(self._h))
+
     def save_stats(self, path: str):
         check(lib().ft_context_save_stats(self._h, path.encode()))
 

@@ -63,6 +63,10 @@ FT_API int ft_context_host_threads(const ft_context *ctx);
 /* per-stage wall/GPU timings of the calls made so far; the reference's REGISTER_STATS analogue
  * (include/Kernels/CudaUtils.h:14, src/Stats.cc:31-60).  Writes "<name>: <ms>" lines. */
 FT_API int ft_context_save_stats(ft_context *ctx, const char *path);
+/* kernel timing with HIP events on the launching stream (off by default); names are "kernel.<name>" */
+FT_API int ft_context_set_kernel_timing(ft_context *ctx, int enabled);
+FT_API int ft_context_get_stat(ft_context *ctx, const char *name, double *total_ms, long *calls);
+FT_API int ft_context_reset_stats(ft_context *ctx);
 /* device memory helpers so that a caller (or bench.py) can keep frames resident in HBM */
 FT_API int ft_device_malloc(ft_context *ctx, size_t bytes, void **dptr);
 FT_API int ft_device_free(ft_context *ctx, void *dptr);

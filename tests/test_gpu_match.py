@@ -65,10 +65,14 @@ def test_stereo_edge_cases(ctx):
     # identical images: zero disparity -> the reference clamps to 0.01 (Frame.cc:979-983)
     exR(fr["L"])
     fr["exR"].extract(fr["L"])
-    o = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kL"], fr["dL"], fr["dL"], mbf, mb)
-    g = orb.KernelController.launchStereoMatchKernel(exL, exR, fr["kL"], fr["kL"], fr["dL"], fr["dL"], mbf, mb)
-    assert g["n"] == o["n"] and np.array_equal(g["uright"], o["uright"]) and np.array_equal(g["depth"], o["depth"])
-    assert (o["depth"] > 0).sum() > 100
+    # (with every SAD == 0 the median cut removes all matches: thDist = 0 and `dist < thDist` never holds)
+    for cut, expect in ((True, 0), (False, 100)):
+        o = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kL"], fr["dL"], fr["dL"], mbf, mb, median_cut=cut)
+        g = orb.KernelController.launchStereoMatchKernel(exL, exR, fr["kL"], fr["kL"], fr["dL"], fr["dL"], mbf, mb,
+                                                         median_cut=cut)
+        assert g["n"] == o["n"] and np.array_equal(g["uright"], o["uright"]) and np.array_equal(g["depth"], o["depth"])
+        assert (o["depth"] > 0).sum() >= expect
+    assert np.isclose(o["uright"][o["depth"] > 0], fr["kL"]["x"][o["depth"] > 0], atol=1.0).all()
 
 
 @pytest.mark.parametrize("w,h,nf,B", [(752, 480, 1200, 3), (1280, 720, 2000, 2)])
