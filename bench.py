@@ -49,7 +49,7 @@ def level_pixels(w, h):
     return P
 
 
-def cpu_baseline(w, h, nf, pairs, budget_s=20.0):
+def cpu_baseline(w, h, nf, pairs, budget_s=12.0):
     """Oracle (oracle/, kind 'port') on host cores: extract L + R + ComputeStereoMatches per pair.
     One worker per pair across all cores (ctypes releases the GIL); bounded by ~budget_s of wall time.
     Also times the reference's own threading (left/right extraction on two threads, src/Frame.cc:127-130)."""
@@ -80,12 +80,16 @@ def cpu_baseline(w, h, nf, pairs, budget_s=20.0):
             (kL, dL, _), (kR, dR, _) = fa.result(), fb.result()
             ob.stereo_match(exL, exR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
         ref_fps = n_ref / (time.perf_counter() - t0)
-    n_all = max(cores, min(64 * cores, int(budget_s * cores / max(t1, 1e-3))))
-    n_all = (n_all // cores) * cores
+    # all cores, one pair per worker; rounds of `cores` pairs until ~budget_s of wall time is spent
+    n_all, dt = 0, 0.0
     with ThreadPoolExecutor(cores) as tp:
         t0 = time.perf_counter()
-        list(tp.map(one, [pairs[i % len(pairs)] for i in range(n_all)]))
-        dt = time.perf_counter() - t0
+        while True:
+            list(tp.map(one, [pairs[(n_all + i) % len(pairs)] for i in range(cores)]))
+            n_all += cores
+            dt = time.perf_counter() - t0
+            if dt >= budget_s or n_all >= 4096:
+                break
     return {"value": n_all / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n_all} synthetic {w}x{h} stereo pairs (nFeatures {nf}), oracle extract L+R + stereo match, "
                       f"{cores} worker threads one pair each, {dt:.1f} s; reference threading (2 threads per pair, "

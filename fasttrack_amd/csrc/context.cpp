@@ -57,7 +57,7 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
     FT_HIP(hipGetDeviceProperties(&prop, device));
     ft_context *ctx = new ft_context();
     ctx->device = device;
-    ctx->deviceName = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    ctx->deviceName = std::string(prop.name[0] ? prop.name : "AMD GPU") + " (" + prop.gcnArchName + ")";
     if (host_threads <= 0) host_threads = (int)std::thread::hardware_concurrency();
     if (host_threads < 1) host_threads = 1;
     ctx->pool = new ft::ThreadPool(host_threads - 1);
