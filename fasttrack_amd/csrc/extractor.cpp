@@ -201,18 +201,25 @@ int ft_extract_stage_a(ft_extractor *ex, const uint8_t *const *images, int batch
         }
     }
     ex->l0External = on_device != 0;
+    // dword tile loads need 4-byte aligned rows; the slot pyramids always are, caller frames may not be
+    ex->l0Aligned = true;
+    if (on_device) {
+        if (stride & 3) ex->l0Aligned = false;
+        for (int b = 0; b < batch; b++)
+            if ((uintptr_t)images[b] & 3) ex->l0Aligned = false;
+    }
     ex->l0pitch = on_device ? stride : g.lv[0].pitch;
     ex->lastBatch = batch;
     FT_HIP(hipMemcpyAsync((void *)ex->d_l0, (const void *)ex->h_l0, sizeof(uint8_t *) * batch, hipMemcpyHostToDevice,
                           ex->stream));
     const bool tm = ex->ctx->kernelTiming;
     ex->evt.begin(tm, "kernel.pyr_down(all levels)", ex->stream);
-    rc = ft_launch_pyramid(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->d_taps);
+    rc = ft_launch_pyramid(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->d_taps, ex->l0Aligned ? 1 : 0);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.fast_cells", ex->stream);
     rc = ft_launch_fast_cells(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->iniTh, ex->minTh,
-                              ex->d_cellCount, ex->d_stage);
+                              ex->l0Aligned ? 1 : 0, ex->d_cellCount, ex->d_stage);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.compact", ex->stream);
@@ -275,8 +282,8 @@ int ft_extract_stage_b(ft_extractor *ex, int batch) {
                             sizeof(FtSelKp) * maxN, batch, hipMemcpyHostToDevice, ex->stream));
     const bool tm = ex->ctx->kernelTiming;
     ex->evt.begin(tm, "kernel.orient_desc", ex->stream);
-    int rc = ft_launch_orient_desc(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->d_sel, ex->d_nSel,
-                                   ex->d_keys, ex->d_desc);
+    int rc = ft_launch_orient_desc(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->l0Aligned ? 1 : 0,
+                                   ex->d_sel, ex->d_nSel, ex->d_keys, ex->d_desc);
     ex->evt.end(tm, ex->stream);
     return rc;
 }

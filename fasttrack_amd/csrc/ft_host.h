@@ -118,6 +118,7 @@ struct ft_extractor {
     int lastBatch = 0;
     int l0pitch = 0;
     bool l0External = false;
+    bool l0Aligned = true;
 };
 
 struct ft_stereo_frontend {

@@ -75,13 +75,14 @@ int ft_hip_fail(hipError_t e, const char *what, const char *file, int line);
 // ---- kernel launchers (kernels_extract.hip) -------------------------------------------------
 // l0: device array [batch] of level-0 pointers; pyr: base of the slot pyramids
 int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                      uint8_t *pyr, const FtTap *taps);
+                      uint8_t *pyr, const FtTap *taps, int alignedLoads);
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                         const uint8_t *pyr, int iniTh, int minTh, int *cellCount, uint32_t *stage);
+                         const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
+                         uint32_t *stage);
 int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cellCount, const uint32_t *stage,
                       uint32_t *cand, int *candCount);
 int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                          const uint8_t *pyr, const FtSelKp *sel, const int *nSel, ft_keypoint *keys,
+                          const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *nSel, ft_keypoint *keys,
                           uint8_t *desc);
 size_t ft_fast_smem_bytes(const FtGeom &g);
 

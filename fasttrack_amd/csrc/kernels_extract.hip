@@ -28,29 +28,73 @@ __device__ __forceinline__ const uint8_t *level_ptr(const FtGeom &g, int level, 
 // ------------------------------------------------------------------------------------------------
 // Pyramid: level l from level l-1 (one launch per level; grid.z = image slot)
 // ------------------------------------------------------------------------------------------------
+// Output tile 64 x 16 per workgroup.  The source footprint of the tile (rows sy(first)..sy(last)+1,
+// columns sx(first)..sx(last)+1) is staged in LDS with aligned dword loads; every output then reads its
+// 2x2 taps from LDS.
+#define PD_TW 64
+#define PD_TH 16
 __global__ __launch_bounds__(256) void k_pyr_down(FtGeom g, int level, const uint8_t *const *l0, int l0pitch,
-                                                  uint8_t *pyr, const FtTap *taps) {
-    const int dx = blockIdx.x * 64 + threadIdx.x;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
+                                                  uint8_t *pyr, const FtTap *taps, int alignedLoads, int ldsPitch,
+                                                  int ldsRows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
     const int slot = blockIdx.z;
     const FtLevelGeom &D = g.lv[level];
-    if (dx >= D.w || dy >= D.h) return;
+    const int dx0 = blockIdx.x * PD_TW, dy0 = blockIdx.y * PD_TH;
+    const int dx1 = min(dx0 + PD_TW, D.w) - 1, dy1 = min(dy0 + PD_TH, D.h) - 1;  // last output col / row
     int spitch;
     const uint8_t *S = level_ptr(g, level - 1, slot, l0, l0pitch, pyr, spitch);
     const int sw = g.lv[level - 1].w, sh = g.lv[level - 1].h;
-    uint8_t *out = pyr + (size_t)slot * g.pyrPerSlot + D.off + (size_t)dy * D.pitch + dx;
+    int sxa, sxb, sya, syb;  // source footprint (inclusive)
     if (D.area2x) {
-        const uint8_t *r0 = S + (size_t)(2 * dy) * spitch + 2 * dx, *r1 = r0 + spitch;
-        *out = (uint8_t)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2);
+        sxa = 2 * dx0; sxb = 2 * dx1 + 1; sya = 2 * dy0; syb = 2 * dy1 + 1;
+    } else {
+        sxa = taps[D.xtab + dx0].s;
+        sxb = min(taps[D.xtab + dx1].s + 1, sw - 1);
+        sya = min(max((int)taps[D.ytab + dy0].s, 0), sh - 1);
+        syb = min(max((int)taps[D.ytab + dy1].s + 1, 0), sh - 1);
+    }
+    const int rows = syb - sya + 1;
+    int ax = 0;
+    if (alignedLoads) {
+        ax = sxa & 3;
+        const int nd = (sxb - sxa + 1 + ax + 3) >> 2;  // dwords per row; may read <= 3 bytes past sxb, still inside the pitch
+        const uint8_t *src = S + (size_t)sya * spitch + (sxa - ax);
+        const int ndl = ldsPitch >> 2;
+        for (int i = tid; i < nd * rows; i += 256) {
+            const int y = i / nd, x = i - y * nd;
+            ((unsigned *)smem)[y * ndl + x] = *(const unsigned *)(src + (size_t)y * spitch + 4 * x);
+        }
+    } else {
+        const int cw = sxb - sxa + 1;
+        const uint8_t *src = S + (size_t)sya * spitch + sxa;
+        for (int i = tid; i < cw * rows; i += 256) {
+            const int y = i / cw, x = i - y * cw;
+            smem[y * ldsPitch + x] = src[(size_t)y * spitch + x];
+        }
+    }
+    __syncthreads();
+    const uint8_t *T = smem + ax;  // source pixel (sx, sy) at T[(sy - sya) * ldsPitch + (sx - sxa)]
+    const int dx = dx0 + (tid & 63);
+    if (dx > dx1) return;
+    uint8_t *outBase = pyr + (size_t)slot * g.pyrPerSlot + D.off + dx;
+    if (D.area2x) {
+        for (int dy = dy0 + (tid >> 6); dy <= dy1; dy += 4) {
+            const uint8_t *r0 = T + (2 * dy - sya) * ldsPitch + (2 * dx - sxa), *r1 = r0 + ldsPitch;
+            outBase[(size_t)dy * D.pitch] = (uint8_t)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2);
+        }
         return;
     }
-    const FtTap xt = taps[D.xtab + dx], yt = taps[D.ytab + dy];
-    const int sx0 = xt.s, sx1 = min(sx0 + 1, sw - 1);
-    const int sy0 = min(max((int)yt.s, 0), sh - 1), sy1 = min(max((int)yt.s + 1, 0), sh - 1);
-    const uint8_t *r0 = S + (size_t)sy0 * spitch, *r1 = S + (size_t)sy1 * spitch;
-    const int h0 = r0[sx0] * xt.a0 + r0[sx1] * xt.a1;
-    const int h1 = r1[sx0] * xt.a0 + r1[sx1] * xt.a1;
-    *out = (uint8_t)((((yt.a0 * (h0 >> 4)) >> 16) + ((yt.a1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    const FtTap xt = taps[D.xtab + dx];
+    const int cx0 = xt.s - sxa, cx1 = min(xt.s + 1, sw - 1) - sxa;
+    for (int dy = dy0 + (tid >> 6); dy <= dy1; dy += 4) {
+        const FtTap yt = taps[D.ytab + dy];
+        const int sy0 = min(max((int)yt.s, 0), sh - 1) - sya, sy1 = min(max((int)yt.s + 1, 0), sh - 1) - sya;
+        const uint8_t *r0 = T + sy0 * ldsPitch, *r1 = T + sy1 * ldsPitch;
+        const int h0 = r0[cx0] * xt.a0 + r0[cx1] * xt.a1;
+        const int h1 = r1[cx0] * xt.a0 + r1[cx1] * xt.a1;
+        outBase[(size_t)dy * D.pitch] = (uint8_t)((((yt.a0 * (h0 >> 4)) >> 16) + ((yt.a1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -99,11 +143,29 @@ __device__ __forceinline__ int fast_score(const int d[16]) {
     return max(best, -worst) - 1;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch,
-                                                    const uint8_t *pyr, int iniTh, int minTh, int *cellCount,
-                                                    uint32_t *stage) {
+// LDS hand-off between the lanes of ONE wave: the LDS queue of a wave is served in order, so only the
+// compiler has to be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One WAVE per (cell, image): no workgroup barrier anywhere, so the 24+ cells resident on a CU hide
+// each other's load and LDS latency.  TP = LDS pitch of the tile and of the score plane; TP > 0 makes
+// every ring / neighbour offset an instruction immediate, TP == 0 is the any-size fallback.
+// LDS carve (bytes): tile th*tp | score (ph+2)*tp | candidate list 2*npx ; the survivor flags reuse the
+// tile once the scores are final.
+__host__ __device__ __forceinline__ int fc_pitch(int wCell, int TP) { return TP ? TP : ((wCell + 12) & ~3); }
+__host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int TP) { return (((hCell + 6) * fc_pitch(wCell, TP)) + 15) & ~15; }
+__host__ __device__ __forceinline__ int fc_score_bytes(int wCell, int hCell, int TP) { return (((hCell + 2) * fc_pitch(wCell, TP)) + 15) & ~15; }
+__host__ __device__ __forceinline__ int fc_list_bytes(int wCell, int hCell) { return ((2 * wCell * hCell) + 15) & ~15; }
+
+template <int TP>
+__global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
+                                                   int iniTh, int minTh, int alignedLoads, int *cellCount,
+                                                   uint32_t *stage) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     const int slot = blockIdx.y, cell = blockIdx.x;
     int level = 0;
     while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cellBase) level++;
@@ -116,89 +178,119 @@ __global__ __launch_bounds__(256) void k_fast_cells(FtGeom g, const uint8_t *con
     const int tw = maxX - iniX, th = maxY - iniY;
     // ORBextractor.cc:1141,1150 skip rules; cv::FAST finds nothing in a sub-image under 7 px
     if (iniX >= L.maxBX - 6 || iniY >= L.maxBY - 3 || tw < 7 || th < 7) {
-        if (tid == 0) *cnt = 0;
+        if (lane == 0) *cnt = 0;
         return;
     }
-    const int tp = (tw + 3) & ~3;            // tile pitch
-    const int pw = tw - 6, ph = th - 6;      // tested region
-    const int sp = pw + 2;                   // score plane pitch (1-px zero rim)
-    uint8_t *tile = smem;                    // th * tp
-    uint8_t *score = tile + (((L.hCell + 6) * ((L.wCell + 6 + 3) & ~3) + 15) & ~15);
-    int *wcnt = (int *)(score + ((((L.hCell + 2) * (L.wCell + 2)) + 15) & ~15));
+    const int pw = tw - 6, ph = th - 6;  // tested region
+    const int npx = pw * ph;
+    const int tp = TP ? TP : fc_pitch(L.wCell, 0);
+    const unsigned pwMagic = 0xffffffffu / (unsigned)pw + 1u;  // i / pw == umulhi(i, magic) for i < 2^32 / pw
+    uint8_t *tile = smem;
+    uint8_t *score = tile + fc_tile_bytes(L.wCell, L.hCell, TP);
+    unsigned short *list = (unsigned short *)(score + fc_score_bytes(L.wCell, L.hCell, TP));
+    uint8_t *surv = tile;
     int pitch;
     const uint8_t *img = level_ptr(g, level, slot, l0, l0pitch, pyr, pitch);
-    const uint8_t *src = img + (size_t)iniY * pitch + iniX;
-    for (int i = tid; i < tw * th; i += 256) {
-        int y = i / tw, x = i - y * tw;
-        tile[y * tp + x] = src[(size_t)y * pitch + x];
+    // ---- stage the tile: aligned dword rows when the level allows it (coalesced 4-byte lanes) ----
+    int ax = 0;
+    if (alignedLoads) {
+        ax = iniX & 3;
+        const int nd = (tw + ax + 3) >> 2;
+        const unsigned ndMagic = 0xffffffffu / (unsigned)nd + 1u;
+        const uint8_t *src = img + (size_t)iniY * pitch + (iniX - ax);
+        for (int i = lane; i < nd * th; i += 64) {
+            const int y = (int)__umulhi((unsigned)i, ndMagic), x = i - y * nd;
+            *(unsigned *)(tile + y * tp + 4 * x) = *(const unsigned *)(src + (size_t)y * pitch + 4 * x);
+        }
+    } else {
+        const unsigned twMagic = 0xffffffffu / (unsigned)tw + 1u;
+        const uint8_t *src = img + (size_t)iniY * pitch + iniX;
+        for (int i = lane; i < tw * th; i += 64) {
+            const int y = (int)__umulhi((unsigned)i, twMagic), x = i - y * tw;
+            tile[y * tp + x] = src[(size_t)y * pitch + x];
+        }
     }
-    for (int i = tid; i < sp * (ph + 2); i += 256) score[i] = 0;
-    __syncthreads();
-    const int npx = pw * ph;
-    for (int i = tid; i < npx; i += 256) {
-        const int y = i / pw, x = i - y * pw;
-        const uint8_t *cpx = tile + (y + 3) * tp + (x + 3);
+    for (int i = lane; i < (tp * (ph + 2)) >> 2; i += 64) ((unsigned *)score)[i] = 0;
+    wave_lds_sync();
+    const uint8_t *t0 = tile + ax;  // pixel (x, y) of the cell sub-image at t0[y * tp + x]
+    // ---- phase A: high-speed rejection (OpenCV's opposite-pair test without the polarity): a 9-arc
+    // contains one pixel of every opposite pair, so min over the four even pairs of max(|d_k|, |d_k+8|)
+    // must exceed the threshold.  Survivors are appended, in row-major order, to the candidate list.
+    int nc = 0;
+    for (int base = 0; base < npx; base += 64) {
+        const int i = base + lane;
+        bool pass = false;
+        if (i < npx) {
+            const int y = (int)__umulhi((unsigned)i, pwMagic), x = i - y * pw;
+            const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
+            const unsigned v = cpx[0];
+#define FT_AD(ox, oy) __builtin_amdgcn_sad_u8(v, (unsigned)cpx[(oy)*tp + (ox)], 0u)
+            const unsigned m0 = max(FT_AD(0, 3), FT_AD(0, -3));
+            const unsigned m1 = max(FT_AD(3, 0), FT_AD(-3, 0));
+            const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
+            const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
+#undef FT_AD
+            pass = min(min(m0, m1), min(m2, m3)) > (unsigned)minTh;
+        }
+        const unsigned long long b = __ballot(pass);
+        if (pass) list[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)i;
+        nc += __popcll(b);
+    }
+    wave_lds_sync();
+    // ---- phase B: score = largest threshold at which the pixel is still a corner (cornerScore<16>);
+    // corner at minThFAST <=> score >= minThFAST, so no separate mask test is needed ----
+    for (int j = lane; j < nc; j += 64) {
+        const int i = list[j];
+        const int y = (int)__umulhi((unsigned)i, pwMagic), x = i - y * pw;
+        const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
         const int v = cpx[0];
         int d[16];
 #define FT_LD(k, ox, oy) d[k] = v - (int)cpx[(oy)*tp + (ox)];
         FT_RING(FT_LD)
 #undef FT_LD
-        unsigned dark = 0, bright = 0;  // ring pixel darker / brighter than the centre by more than minTh
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            dark |= (d[k] > minTh ? 1u : 0u) << k;
-            bright |= (d[k] < -minTh ? 1u : 0u) << k;
+        const int sc = fast_score(d);
+        if (sc >= minTh) score[(y + 1) * tp + (x + 1)] = (uint8_t)sc;
+    }
+    wave_lds_sync();
+    // ---- NMS over the candidates: strictly greater than the 8 neighbours (cv::FAST); the flags reuse
+    // the tile (no longer read) ----
+    int anyHi = 0;
+    for (int base = 0; base < nc; base += 64) {
+        const int j = base + lane;
+        int fl = 0;
+        if (j < nc) {
+            const int i = list[j];
+            const int y = (int)__umulhi((unsigned)i, pwMagic), x = i - y * pw;
+            const uint8_t *s = score + (y + 1) * tp + (x + 1);
+            const int v = s[0];
+            const bool keep = v > 0 && v > s[-1] && v > s[1] && v > s[-tp - 1] && v > s[-tp] && v > s[-tp + 1] &&
+                              v > s[tp - 1] && v > s[tp] && v > s[tp + 1];
+            fl = keep ? (v >= iniTh ? 2 : 1) : 0;
+            surv[j] = (uint8_t)fl;
         }
-        if (has_arc9(dark) || has_arc9(bright)) score[(y + 1) * sp + (x + 1)] = (uint8_t)fast_score(d);
+        anyHi |= __any(fl == 2);
     }
-    __syncthreads();
-    // NMS: strictly greater than the 8 neighbours (cv::FAST); the result replaces the raw tile
-    uint8_t *surv = tile;
-    int localHi = 0;
-    for (int i = tid; i < npx; i += 256) {
-        const int y = i / pw, x = i - y * pw;
-        const uint8_t *s = score + (y + 1) * sp + (x + 1);
-        const int v = s[0];
-        bool keep = v > 0 && v > s[-1] && v > s[1] && v > s[-sp - 1] && v > s[-sp] && v > s[-sp + 1] &&
-                    v > s[sp - 1] && v > s[sp] && v > s[sp + 1];
-        surv[i] = keep ? 1 : 0;
-        if (keep && v >= iniTh) localHi = 1;
-    }
+    wave_lds_sync();
     // cell-level threshold fallback (ORBextractor.cc:1157-1177): if any survivor reaches iniThFAST only
-    // those are emitted, otherwise every minThFAST survivor is
-    const int anyHi = __syncthreads_or(localHi);
-    const int emitTh = anyHi ? iniTh : minTh;
+    // those are emitted, otherwise every minThFAST survivor is.  Emission keeps the list (row-major) order.
+    const int need = anyHi ? 2 : 1;
     uint32_t *out = stage + (size_t)slot * g.stagePerSlot + L.stageBase + (size_t)c * L.cellCap;
-    int running = 0;
-    for (int base = 0; base < npx; base += 256) {
-        const int i = base + tid;
-        int y = 0, x = 0, sc = 0;
-        bool f = false;
-        if (i < npx) {
-            y = i / pw;
-            x = i - y * pw;
-            sc = score[(y + 1) * sp + (x + 1)];
-            f = surv[i] && sc >= emitTh;
-        }
+    int run = 0;
+    for (int base = 0; base < nc; base += 64) {
+        const int j = base + lane;
+        const bool f = j < nc && surv[j] >= need;
         const unsigned long long b = __ballot(f);
-        if (lane == 0) wcnt[wave] = __popcll(b);
-        __syncthreads();
-        int woff = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const int cw = wcnt[w];
-            if (w < wave) woff += cw;
-            tot += cw;
-        }
         if (f) {
-            const int pos = running + woff + __popcll(b & ((1ull << lane) - 1ull));
+            const int i = list[j];
+            const int y = (int)__umulhi((unsigned)i, pwMagic), x = i - y * pw;
+            const int pos = run + __popcll(b & ((1ull << lane) - 1ull));
             // keypoint (x+3, y+3) in the cell sub-image, shifted by (j*wCell, i*hCell): ORBextractor.cc:1196-1197
-            if (pos < L.cellCap) out[pos] = ft_pack_cand(x + 3 + cj * L.wCell, y + 3 + ci * L.hCell, sc);
+            if (pos < L.cellCap)
+                out[pos] = ft_pack_cand(x + 3 + cj * L.wCell, y + 3 + ci * L.hCell, score[(y + 1) * tp + (x + 1)]);
         }
-        running += tot;
-        __syncthreads();
+        run += __popcll(b);
     }
-    if (tid == 0) *cnt = min(running, L.cellCap);
+    if (lane == 0) *cnt = min(run, L.cellCap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -264,9 +356,12 @@ __global__ __launch_bounds__(256) void k_compact(FtGeom g, const int *cellCount,
 // ------------------------------------------------------------------------------------------------
 #define OD_R 21                 // patch radius: 18 (max rotated pattern offset) + 3 (blur)
 #define OD_P (2 * OD_R + 1)     // 43
-#define OD_PP 44                // raw pitch
+#define OD_PP 48                // raw pitch: 12 dwords cover the 43 bytes at any 4-byte phase
 #define OD_B 37                 // blurred window
-#define OD_WAVE_BYTES (OD_P * OD_PP + OD_P * OD_B * 2 + OD_B * OD_B + 3)
+#define OD_RAW_BYTES (OD_P * OD_PP)                  // 2064
+#define OD_HB_BYTES (OD_P * OD_B * 2)                // 3182
+#define OD_WAVE_BYTES ((OD_RAW_BYTES + OD_HB_BYTES + 15) & ~15)
+#define OD_WAVES 4
 
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (i < 0) i = -i;
@@ -297,45 +392,54 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-__global__ __launch_bounds__(256) void k_orient_desc(FtGeom g, const uint8_t *const *l0, int l0pitch,
-                                                     const uint8_t *pyr, const FtSelKp *sel, const int *nSel,
-                                                     ft_keypoint *keysOut, uint8_t *descOut) {
+__global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const uint8_t *const *l0, int l0pitch,
+                                                               const uint8_t *pyr, int alignedLoads, const FtSelKp *sel,
+                                                               const int *nSel, ft_keypoint *keysOut, uint8_t *descOut) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = blockIdx.y;
-    const int k = blockIdx.x * 4 + wave;
-    const bool valid = k < nSel[slot];
-    uint8_t *raw = smem + (size_t)wave * ((OD_WAVE_BYTES + 15) & ~15);
-    unsigned short *hb = (unsigned short *)(raw + OD_P * OD_PP);
-    uint8_t *bl = (uint8_t *)(hb + OD_P * OD_B);
-    int cx = 0, cy = 0, level = 0, response = 0;
-    if (valid) {
-        const FtSelKp s = sel[(size_t)slot * g.maxKp + k];
-        cx = s.x;
-        cy = s.y;
-        level = s.level;
-        response = s.response;
-        int pitch;
-        const uint8_t *img = level_ptr(g, level, slot, l0, l0pitch, pyr, pitch);
-        const int w = g.lv[level].w, h = g.lv[level].h;
+    const int k = blockIdx.x * OD_WAVES + wave;
+    if (k >= nSel[slot]) return;  // waves are independent: no workgroup barrier below
+    uint8_t *raw = smem + (size_t)wave * OD_WAVE_BYTES;
+    unsigned short *hb = (unsigned short *)(raw + OD_RAW_BYTES);
+    uint8_t *bl = raw;  // the blurred window overwrites the raw patch once it is no longer needed
+    const FtSelKp s = sel[(size_t)slot * g.maxKp + k];
+    const int cx = s.x, cy = s.y, level = s.level, response = s.response;
+    int pitch;
+    const uint8_t *img = level_ptr(g, level, slot, l0, l0pitch, pyr, pitch);
+    const int w = g.lv[level].w, h = g.lv[level].h;
+    const int px0 = cx - OD_R, py0 = cy - OD_R;
+    int ax = px0 & 3;
+    const bool interior = alignedLoads && px0 >= 0 && py0 >= 0 && py0 + OD_P <= h && (px0 - ax) + OD_PP <= w;
+    if (interior) {
+        // 43 rows x 12 aligned dwords: coalesced 4-byte lanes, pixel (r, c) lands at raw[r*48 + ax + c]
+        const uint8_t *src = img + (size_t)py0 * pitch + (px0 - ax);
+        for (int i = lane; i < OD_P * 12; i += 64) {
+            const int r = i / 12, c = i - r * 12;
+            ((unsigned *)raw)[i] = *(const unsigned *)(src + (size_t)r * pitch + 4 * c);
+        }
+    } else {
+        // BORDER_REFLECT_101 of the blur at the level's edges (keypoints are >= 19 px inside, the
+        // patch reaches 21) or unaligned caller frames
+        ax = 0;
         for (int i = lane; i < OD_P * OD_P; i += 64) {
             const int r = i / OD_P, c = i - r * OD_P;
-            const int gy = reflect101(cy - OD_R + r, h), gx = reflect101(cx - OD_R + c, w);
+            const int gy = reflect101(py0 + r, h), gx = reflect101(px0 + c, w);
             raw[r * OD_PP + c] = img[(size_t)gy * pitch + gx];
         }
     }
-    __syncthreads();
-    float angle = 0.f;
-    if (valid) {
-        // IC_Angle: integer moments over the 31-px disc (two patch rows per step: lanes 0-31 / 32-63)
-        int m10 = 0, m01 = 0;
+    wave_lds_sync();
+    const uint8_t *rp = raw + ax;
+    // IC_Angle: integer moments over the 31-px disc (two patch rows per step: lanes 0-31 / 32-63)
+    int m10 = 0, m01 = 0;
+    {
         const int u = (lane & 31) - 15;
         for (int r = 0; r < 32; r += 2) {
             const int v = r + (lane >> 5) - 15;
             if (v <= 15 && u <= 15) {
                 const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
                 if (au <= c_umax[av]) {
-                    const int I = raw[(OD_R + v) * OD_PP + (OD_R + u)];
+                    const int I = rp[(OD_R + v) * OD_PP + (OD_R + u)];
                     m10 += u * I;
                     m01 += v * I;
                 }
@@ -346,99 +450,125 @@ __global__ __launch_bounds__(256) void k_orient_desc(FtGeom g, const uint8_t *co
             m10 += __shfl_xor(m10, o);
             m01 += __shfl_xor(m01, o);
         }
-        angle = fast_atan2_deg((float)m01, (float)m10);
-        // horizontal 7-tap pass: hb[r][c] for r in 0..42, c in 0..36 (16-bit, <= 255*256)
-        for (int i = lane; i < OD_P * OD_B; i += 64) {
-            const int r = i / OD_B, c = i - r * OD_B;
-            const uint8_t *p = raw + r * OD_PP + c;
-            unsigned a = 0;
-#pragma unroll
-            for (int t = 0; t < 7; t++) a += (unsigned)c_gauss[t] * p[t];
-            hb[r * OD_B + c] = (unsigned short)a;
-        }
     }
-    __syncthreads();
-    if (valid) {
-        for (int i = lane; i < OD_B * OD_B; i += 64) {
-            const int r = i / OD_B, c = i - r * OD_B;
-            unsigned a = 0;
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // horizontal 7-tap pass, sliding window: a task = (row, run of <= 10 outputs) reads <= 16 bytes once
+    for (int t = lane; t < OD_P * 4; t += 64) {
+        const int r = t >> 2, sgm = t & 3;
+        const int c0 = sgm * 10, n = sgm == 3 ? 7 : 10;
+        const uint8_t *p = rp + r * OD_PP + c0;
+        unsigned v[16];
 #pragma unroll
-            for (int t = 0; t < 7; t++) a += (unsigned)c_gauss[t] * hb[(r + t) * OD_B + c];
-            bl[i] = (uint8_t)((a + 32768u) >> 16);
-        }
+        for (int j = 0; j < 16; j++) v[j] = (j < n + 6) ? p[j] : 0;
+        unsigned short *o = hb + r * OD_B + c0;
+#pragma unroll
+        for (int j = 0; j < 10; j++)
+            if (j < n)
+                o[j] = (unsigned short)(18u * (v[j] + v[j + 6]) + 34u * (v[j + 1] + v[j + 5]) + 48u * (v[j + 2] + v[j + 4]) +
+                                        56u * v[j + 3]);
     }
-    __syncthreads();
-    if (valid) {
-        // computeOrbDescriptor: angle in radians as float, cos/sin in double then narrowed
-        const float factorPI = (float)(3.14159265358979323846 / 180.f);
-        const float ar = __fmul_rn(angle, factorPI);
-        const float ca = (float)cos((double)ar), sb = (float)sin((double)ar);
-        unsigned long long words[4];
+    wave_lds_sync();
+    // vertical pass: a task = (column, run of <= 10 rows); result (v + 2^15) >> 16
+    for (int t = lane; t < OD_B * 4; t += 64) {
+        const int c = t % OD_B, sgm = t / OD_B;
+        const int r0 = sgm * 10, n = sgm == 3 ? 7 : 10;
+        const unsigned short *p = hb + r0 * OD_B + c;
+        unsigned v[16];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int p = q * 64 + lane;  // pair index: byte p/8, bit p%8
-            const float x0 = (float)c_pattern[4 * p], y0 = (float)c_pattern[4 * p + 1];
-            const float x1 = (float)c_pattern[4 * p + 2], y1 = (float)c_pattern[4 * p + 3];
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
-            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
-            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
-            const int t0 = bl[(18 + r0) * OD_B + (18 + c0)];
-            const int t1 = bl[(18 + r1) * OD_B + (18 + c1)];
-            words[q] = __ballot(t0 < t1);
-        }
-        if (lane == 0) {
-            const size_t o = (size_t)slot * g.maxKp + k;
-            // ORBextractor.cc:1209-1221 (octave, size = int(PATCH_SIZE * sf)) and :1472-1475 (pt *= scale)
-            const float scale = g.sf[level];
-            ft_keypoint kp;
-            kp.x = level ? __fmul_rn((float)cx, scale) : (float)cx;
-            kp.y = level ? __fmul_rn((float)cy, scale) : (float)cy;
-            kp.size = (float)(int)__fmul_rn((float)FT_PATCH_SIZE, scale);
-            kp.angle = angle;
-            kp.response = (float)response;
-            kp.octave = level;
-            kp.class_id = -1;
-            keysOut[o] = kp;
-            unsigned long long *d = (unsigned long long *)(descOut + o * 32);
-            d[0] = words[0];
-            d[1] = words[1];
-            d[2] = words[2];
-            d[3] = words[3];
-        }
+        for (int j = 0; j < 16; j++) v[j] = (j < n + 6) ? p[j * OD_B] : 0;
+        uint8_t *o = bl + r0 * OD_B + c;
+#pragma unroll
+        for (int j = 0; j < 10; j++)
+            if (j < n)
+                o[j * OD_B] = (uint8_t)((18u * (v[j] + v[j + 6]) + 34u * (v[j + 1] + v[j + 5]) + 48u * (v[j + 2] + v[j + 4]) +
+                                         56u * v[j + 3] + 32768u) >> 16);
+    }
+    wave_lds_sync();
+    // computeOrbDescriptor: angle in radians as float, cos/sin in double then narrowed
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float ar = __fmul_rn(angle, factorPI);
+    const float ca = (float)cos((double)ar), sb = (float)sin((double)ar);
+    unsigned long long words[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int p = q * 64 + lane;  // pair index: byte p/8, bit p%8
+        const float x0 = (float)c_pattern[4 * p], y0 = (float)c_pattern[4 * p + 1];
+        const float x1 = (float)c_pattern[4 * p + 2], y1 = (float)c_pattern[4 * p + 3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
+        const int t0 = bl[(18 + r0) * OD_B + (18 + c0)];
+        const int t1 = bl[(18 + r1) * OD_B + (18 + c1)];
+        words[q] = __ballot(t0 < t1);
+    }
+    if (lane == 0) {
+        const size_t o = (size_t)slot * g.maxKp + k;
+        // ORBextractor.cc:1209-1221 (octave, size = int(PATCH_SIZE * sf)) and :1472-1475 (pt *= scale)
+        const float scale = g.sf[level];
+        ft_keypoint kp;
+        kp.x = level ? __fmul_rn((float)cx, scale) : (float)cx;
+        kp.y = level ? __fmul_rn((float)cy, scale) : (float)cy;
+        kp.size = (float)(int)__fmul_rn((float)FT_PATCH_SIZE, scale);
+        kp.angle = angle;
+        kp.response = (float)response;
+        kp.octave = level;
+        kp.class_id = -1;
+        keysOut[o] = kp;
+        unsigned long long *d = (unsigned long long *)(descOut + o * 32);
+        d[0] = words[0];
+        d[1] = words[1];
+        d[2] = words[2];
+        d[3] = words[3];
     }
 }
 
 }  // namespace
 
+static int fast_tile_pitch(const FtGeom &g) {
+    // 64-byte LDS pitch (all ring offsets immediates) when every level's cell fits: wCell + 6 + 3 <= 64
+    for (int l = 0; l < g.nlevels; l++)
+        if (g.lv[l].nCols * g.lv[l].nRows > 0 && g.lv[l].wCell + 9 > 64) return 0;
+    return 64;
+}
+
 size_t ft_fast_smem_bytes(const FtGeom &g) {
+    const int TP = fast_tile_pitch(g);
     size_t mx = 0;
     for (int l = 0; l < g.nlevels; l++) {
         const FtLevelGeom &L = g.lv[l];
-        size_t tile = (size_t)(((L.hCell + 6) * ((L.wCell + 6 + 3) & ~3) + 15) & ~15);
-        size_t sc = (size_t)((((L.hCell + 2) * (L.wCell + 2)) + 15) & ~15);
-        // surv bytes reuse the tile: needs wCell*hCell <= tile bytes (true: (w+6)*(h+6) > w*h)
-        mx = std::max(mx, tile + sc + 16);
+        mx = std::max(mx, (size_t)fc_tile_bytes(L.wCell, L.hCell, TP) + fc_score_bytes(L.wCell, L.hCell, TP) +
+                              fc_list_bytes(L.wCell, L.hCell));
     }
     return mx;
 }
 
 int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                      uint8_t *pyr, const FtTap *taps) {
+                      uint8_t *pyr, const FtTap *taps, int alignedLoads) {
     for (int level = 1; level < g.nlevels; level++) {
-        const FtLevelGeom &D = g.lv[level];
-        dim3 grid((D.w + 63) / 64, (D.h + 3) / 4, batch), block(64, 4, 1);
-        hipLaunchKernelGGL(k_pyr_down, grid, block, 0, st, g, level, l0, l0pitch, pyr, taps);
+        const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
+        // LDS footprint of a 64 x 16 output tile: ceil(tile * scale) + the second tap + alignment slack
+        const int cols = (int)((long long)PD_TW * P.w / D.w) + 4, rowsN = (int)((long long)PD_TH * P.h / D.h) + 4;
+        const int ldsPitch = (cols + 3 + 3) & ~3;
+        dim3 grid((D.w + PD_TW - 1) / PD_TW, (D.h + PD_TH - 1) / PD_TH, batch), block(256, 1, 1);
+        hipLaunchKernelGGL(k_pyr_down, grid, block, (size_t)ldsPitch * rowsN, st, g, level, l0, l0pitch, pyr, taps,
+                           alignedLoads, ldsPitch, rowsN);
     }
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
 
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                         const uint8_t *pyr, int iniTh, int minTh, int *cellCount, uint32_t *stage) {
-    dim3 grid(g.totalCells, batch, 1), block(256, 1, 1);
-    hipLaunchKernelGGL(k_fast_cells, grid, block, ft_fast_smem_bytes(g), st, g, l0, l0pitch, pyr, iniTh, minTh,
-                       cellCount, stage);
+                         const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
+                         uint32_t *stage) {
+    dim3 grid(g.totalCells, batch, 1), block(64, 1, 1);
+    const size_t smem = ft_fast_smem_bytes(g);
+    if (fast_tile_pitch(g) == 64)
+        hipLaunchKernelGGL(k_fast_cells<64>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
+                           cellCount, stage);
+    else
+        hipLaunchKernelGGL(k_fast_cells<0>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
+                           cellCount, stage);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
@@ -455,11 +585,11 @@ int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cel
 }
 
 int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                          const uint8_t *pyr, const FtSelKp *sel, const int *nSel, ft_keypoint *keys,
+                          const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *nSel, ft_keypoint *keys,
                           uint8_t *desc) {
-    dim3 grid((g.maxKp + 3) / 4, batch, 1), block(256, 1, 1);
-    const size_t smem = 4 * (size_t)((OD_WAVE_BYTES + 15) & ~15);
-    hipLaunchKernelGGL(k_orient_desc, grid, block, smem, st, g, l0, l0pitch, pyr, sel, nSel, keys, desc);
+    dim3 grid((g.maxKp + OD_WAVES - 1) / OD_WAVES, batch, 1), block(64 * OD_WAVES, 1, 1);
+    const size_t smem = OD_WAVES * (size_t)OD_WAVE_BYTES;
+    hipLaunchKernelGGL(k_orient_desc, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, nSel, keys, desc);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -1,50 +1,37 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 output directory written by tools/profile_bench.sh:
+"""Summarise a rocprofv3 output directory written by tools/profile_bench.sh (rocpd sqlite output):
 per-kernel launch count / average / total time from the kernel trace, and per-launch FETCH_SIZE /
-WRITE_SIZE (KB as reported by rocprofv3; see MI355X_MICROARCH.md for the gfx950 correction)."""
-import csv
+WRITE_SIZE (KB as rocprofv3 reports them; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly half
+of a wide coalesced stream, other widths uncalibrated)."""
 import glob
 import os
+import sqlite3
 import sys
-from collections import defaultdict
 
 
 def short(name):
-    name = name.split("(")[0]
-    return name.split("::")[-1][:60]
+    name = name.split("(anonymous namespace)::")[-1]
+    return name.split("(")[0][:48]
 
 
 def main(root):
-    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
-        print("== kernel stats:", os.path.relpath(f, root))
-        print(open(f).read())
-    tr = glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True)
-    if tr:
-        agg = defaultdict(lambda: [0, 0.0])
-        with open(tr[0]) as fh:
-            for r in csv.DictReader(fh):
-                d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-                a = agg[short(r["Kernel_Name"])]
-                a[0] += 1
-                a[1] += d
-        tot = sum(v[1] for v in agg.values())
-        print("== kernel trace summary (us)")
-        print(f"{'kernel':40s} {'calls':>7s} {'avg_us':>10s} {'total_us':>12s} {'pct':>6s}")
-        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            print(f"{k:40s} {v[0]:7d} {v[1]/v[0]:10.1f} {v[1]:12.1f} {100*v[1]/tot:6.1f}")
+    for f in glob.glob(os.path.join(root, "trace", "**", "*.db"), recursive=True):
+        db = sqlite3.connect(f)
+        print("== rocprofv3 --kernel-trace --stats:", os.path.relpath(f, root))
+        print(f"{'kernel':48s} {'calls':>7s} {'avg_us':>10s} {'total_us':>12s} {'pct':>6s} {'vgpr':>5s} {'lds':>6s}")
+        rows = db.execute("select name, count(*), avg(duration), sum(duration), max(vgpr_count), max(lds_size) "
+                          "from kernels group by name order by sum(duration) desc").fetchall()
+        tot = sum(r[3] for r in rows) or 1
+        for n, c, a, s, v, l in rows:
+            print(f"{short(n):48s} {c:7d} {a/1e3:10.1f} {s/1e3:12.1f} {100*s/tot:6.1f} {v:5d} {l:6d}")
     for which in ("pmc_fetch", "pmc_write"):
-        for f in glob.glob(os.path.join(root, which, "**", "*counter_collection.csv"), recursive=True):
-            agg = defaultdict(lambda: [0, 0.0])
-            cname = None
-            with open(f) as fh:
-                for r in csv.DictReader(fh):
-                    cname = r["Counter_Name"]
-                    a = agg[short(r["Kernel_Name"])]
-                    a[0] += 1
-                    a[1] += float(r["Counter_Value"])
-            print(f"== {which}: {cname} per launch (raw counter units as reported)")
-            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                print(f"{k:40s} launches {v[0]:6d}  per-launch {v[1]/v[0]:14.1f}")
+        for f in glob.glob(os.path.join(root, which, "**", "*.db"), recursive=True):
+            db = sqlite3.connect(f)
+            rows = db.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                              "group by kernel_name, counter_name order by avg(value) desc").fetchall()
+            print(f"== {which}: per-launch counter value (KB as reported by rocprofv3)")
+            for n, cn, c, a in rows:
+                print(f"{short(n):48s} {cn:12s} launches {c:6d}  per-launch {a:14.1f} KB")
 
 
 if __name__ == "__main__":
