@@ -25,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from fasttrack_amd import orb, synth  # noqa: E402
+from fasttrack_amd import orb, shard, synth  # noqa: E402
 
 WORKLOADS = {
     # name: (width, height, nfeatures, BASELINE.json config it mirrors)
@@ -109,16 +109,9 @@ def main():
     ap.add_argument("--stats", default="", help="write per-stage timings to this file")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        # plumbing only: CPU tensors over gloo, the data path has no exchange step
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rank, local_rank, world = shard.env()
+    # plumbing only: CPU tensors over gloo; the data path has no exchange step
+    dist = shard.init(rank, world)
 
     w, h, nf, cfg_note = WORKLOADS[args.workload]
     B = args.batch
@@ -129,7 +122,7 @@ def main():
 
     # synthetic stream, resident in HBM before the timed region (seeds are per rank: one stream per GPU)
     D = max(1, min(args.distinct, B))
-    pairs = [synth.make_stereo_pair(w, h, seed=1000 * rank + i) for i in range(D)]
+    pairs = [synth.make_stereo_pair(w, h, seed=s) for s in shard.stream_seeds(rank, D)]
     devL = [ctx.to_device(p[0]) for p in pairs]
     devR = [ctx.to_device(p[1]) for p in pairs]
     import ctypes as C
@@ -137,9 +130,8 @@ def main():
     ptrsR = (C.c_void_p * B)(*[devR[b % D].ptr for b in range(B)])
 
     def barrier():
-        ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
+        ctx.synchronize()  # hipDeviceSynchronize on this rank's device (the library owns its HIP runtime)
+        shard.barrier(dist)
 
     for _ in range(args.warmup):
         fe.process_raw(ptrsL, ptrsR, B, True, w)
@@ -155,14 +147,8 @@ def main():
     kps = int(fe._nL[:B].sum() + fe._nR[:B].sum())
     matches = int(fe._nm[:B].sum())
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        c = torch.tensor([kps, matches], dtype=torch.float64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        kps, matches = int(c[0]), int(c[1])
+    elapsed = shard.reduce_max(dist, elapsed)
+    kps, matches = [int(v) for v in shard.reduce_sum(dist, [kps, matches])]
 
     if args.stats:
         ctx.save_stats(args.stats + (f".rank{rank}" if world > 1 else ""))
@@ -202,7 +188,7 @@ def main():
                        "fast_thresholds": [INI_TH, MIN_TH], "batch_pairs_per_gpu": B, "distinct_pairs": D,
                        "parallelism": f"{world} independent stream(s), one per GPU, no collective",
                        "host_threads_per_gpu": ctx.host_threads, "device": ctx.device_name},
-            "keypoints_per_s": kps * args.steps / elapsed if world == 1 else kps * args.steps / elapsed,
+            "keypoints_per_s": kps * args.steps / elapsed,
             "stereo_matches_per_frame": matches / (B * world),
             "pipeline_hbm_read_frac": fps * R_pair / (HBM_PEAK_GBS * 1e9),
             "kernels": kern, "host_ms_per_step": host,
@@ -214,9 +200,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    shard.finish(dist)
 
 
 if __name__ == "__main__":

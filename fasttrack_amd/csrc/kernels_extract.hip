@@ -487,7 +487,9 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     // computeOrbDescriptor: angle in radians as float, cos/sin in double then narrowed
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = __fmul_rn(angle, factorPI);
-    const float ca = (float)cos((double)ar), sb = (float)sin((double)ar);
+    double sd, cd;
+    sincos((double)ar, &sd, &cd);
+    const float ca = (float)cd, sb = (float)sd;
     unsigned long long words[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {

@@ -1,0 +1,198 @@
+// fasttrack_amd.hpp - header-only C++ mirror of the reference's operator interface for the hot path,
+// on top of the C ABI (fasttrack_amd.h).  Same names, argument meaning and return conventions as
+//   ORB_SLAM3::ORBextractor           (reference include/ORBextractor.h:100-197)
+//   KernelController::launch*         (reference include/Kernels/KernelController.h:13-55)
+// but free of OpenCV / Eigen: images are (pointer, width, height, stride), keypoints are any struct
+// with cv::KeyPoint's 28-byte layout (ft_keypoint, or cv::KeyPoint itself in an ORB-SLAM3 build), and
+// descriptors are row-major N x 32 bytes (what a CV_8U cv::Mat holds).  INTEGRATION.md shows the
+// few lines that bind it to cv::Mat / ORB_SLAM3::Frame.
+//
+// Errors: the reference prints and exit()s (src/Kernels/CudaUtils.cu:17-22); here every failure throws
+// fasttrack::Error carrying ft_last_error().  There is no CPU run mode to fall back to: the five
+// setGPURunMode flags of the reference have no equivalent.
+#pragma once
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "fasttrack_amd.h"
+
+namespace fasttrack {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string &m) : std::runtime_error("fasttrack_amd: " + m), status(s) {}
+};
+inline void check(int status) {
+    if (status != FT_OK) throw Error(status, ft_last_error());
+}
+
+// KernelController::setCUDADevice + initializeKernels + shutdownKernels + saveKernelsStats
+class Context {
+public:
+    explicit Context(int device = 0, int hostThreads = 0) { check(ft_context_create(device, hostThreads, &h_)); }
+    ~Context() { ft_context_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    ft_context *handle() const { return h_; }
+    void synchronize() { check(ft_context_synchronize(h_)); }
+    void saveKernelsStats(const std::string &file_path) { check(ft_context_save_stats(h_, file_path.c_str())); }
+
+private:
+    ft_context *h_ = nullptr;
+};
+
+// Non-owning 8-bit single-channel image (cv::Mat of type CV_8UC1: data, cols, rows, step[0]).
+struct ImageView {
+    const uint8_t *data = nullptr;
+    int cols = 0, rows = 0, step = 0;
+    bool empty() const { return !data || cols <= 0 || rows <= 0; }
+};
+
+template <class KeyPointT = ft_keypoint>
+class ORBextractor {
+    static_assert(sizeof(KeyPointT) == sizeof(ft_keypoint), "KeyPointT must have cv::KeyPoint's 28-byte layout");
+
+public:
+    // ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int imageWidth, int imageHeight)
+    ORBextractor(Context &ctx, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                 int imageWidth, int imageHeight, int maxBatch = 1)
+        : nfeatures(nfeatures), scaleFactor(scaleFactor), nlevels(nlevels), iniThFAST(iniThFAST), minThFAST(minThFAST) {
+        check(ft_extractor_create(ctx.handle(), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, imageWidth,
+                                  imageHeight, maxBatch, &h_));
+        mvScaleFactor.resize(nlevels);
+        mvInvScaleFactor.resize(nlevels);
+        mvLevelSigma2.resize(nlevels);
+        mvInvLevelSigma2.resize(nlevels);
+        check(ft_extractor_scale_factors(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                                         mvInvLevelSigma2.data()));
+    }
+    ~ORBextractor() { ft_extractor_destroy(h_); }
+    ORBextractor(const ORBextractor &) = delete;
+    ORBextractor &operator=(const ORBextractor &) = delete;
+
+    // int operator()(InputArray image, InputArray mask, vector<KeyPoint>& keypoints, OutputArray descriptors,
+    //                std::vector<int>& vLappingArea)        (the mask is ignored by the reference too)
+    // descriptors: resized to keypoints.size() * 32 bytes (rows of a CV_8U N x 32 matrix).
+    // Returns the reference's monoIndex, or -1 for an empty image (ORBextractor.cc:1360-1361).
+    int operator()(const ImageView &image, std::vector<KeyPointT> &keypoints, std::vector<uint8_t> &descriptors,
+                   const std::vector<int> &vLappingArea) {
+        if (image.empty()) return -1;
+        const int cap = ft_extractor_max_keypoints(h_);
+        keypoints.resize(cap);
+        descriptors.resize((size_t)cap * 32);
+        int n = 0, nMono = 0;
+        const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+        const int st = ft_extract(h_, image.data, image.cols, image.rows, image.step, lap0, lap1,
+                                  reinterpret_cast<ft_keypoint *>(keypoints.data()), descriptors.data(), cap, &n, &nMono);
+        if (st == FT_ERR_EMPTY) return -1;
+        check(st);
+        keypoints.resize(n);
+        descriptors.resize((size_t)n * 32);
+        return nMono;
+    }
+
+    int inline GetLevels() { return nlevels; }
+    float inline GetScaleFactor() { return scaleFactor; }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // mvImagePyramid[level]: host copy of one level of the last image (the reference keeps bordered
+    // cv::Mat ROIs; nothing on the path reads the border, so tight rows are returned)
+    std::vector<uint8_t> imagePyramidLevel(int level, int &cols, int &rows, int slot = 0) {
+        check(ft_extractor_level_size(h_, level, &cols, &rows));
+        std::vector<uint8_t> out((size_t)cols * rows);
+        check(ft_extractor_download_level(h_, slot, level, out.data(), cols));
+        return out;
+    }
+    // GetGPUPyramid(): device pointer + pitch of a level
+    const uint8_t *GetGPUPyramid(int level, int &pitch, int slot = 0) {
+        const uint8_t *p = nullptr;
+        check(ft_extractor_device_level(h_, slot, level, &p, &pitch));
+        return p;
+    }
+    ft_extractor *handle() const { return h_; }
+
+    const int nfeatures;
+    const float scaleFactor;
+    const int nlevels, iniThFAST, minThFAST;
+
+private:
+    ft_extractor *h_ = nullptr;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+// Static facade with the reference's launch* names.  Outputs follow the reference's own conventions:
+// vectors are resized by the callee, int arrays are caller-allocated.
+struct KernelController {
+    // launchStereoMatchKernel(vRowIndices, d_pyrL, d_pyrR, pyrL, pyrR, keysL, keysR, descL, descR, minD, maxD,
+    //                         thOrbDist, mbf, pyramidOnGpu, vDistIdx, mvuRight, mvDepth)     KernelController.h:31-36
+    // The row table and the pyramids live on the device already (slot `slot` of both extractors), minD/maxD
+    // follow from mb/mbf as in Frame.cc:864-867.  vDistIdx receives (SAD, iL) of every refined match so the
+    // caller's median cut (Frame.cc:1049-1062) runs unchanged when applyMedianCut is false.
+    template <class KP>
+    static void launchStereoMatchKernel(ORBextractor<KP> &left, ORBextractor<KP> &right, const std::vector<KP> &mvKeys,
+                                        const std::vector<KP> &mvKeysRight, const uint8_t *mDescriptors,
+                                        const uint8_t *mDescriptorsRight, float mbf, float mb, bool applyMedianCut,
+                                        std::vector<std::pair<int, int>> &vDistIdx, std::vector<float> &mvuRight,
+                                        std::vector<float> &mvDepth, int slot = 0) {
+        const int N = (int)mvKeys.size(), Nr = (int)mvKeysRight.size();
+        mvuRight.assign(N, -1.0f);
+        mvDepth.assign(N, -1.0f);
+        std::vector<int> sad(N > 0 ? N : 1, -1);
+        int nm = 0;
+        check(ft_stereo_match(left.handle(), right.handle(), slot, reinterpret_cast<const ft_keypoint *>(mvKeys.data()), N,
+                              reinterpret_cast<const ft_keypoint *>(mvKeysRight.data()), Nr, mDescriptors,
+                              mDescriptorsRight, mbf, mb, applyMedianCut ? 1 : 0, mvuRight.data(), mvDepth.data(),
+                              sad.data(), &nm));
+        vDistIdx.clear();
+        for (int i = 0; i < N; i++)
+            if (sad[i] >= 0) vDistIdx.push_back(std::make_pair(sad[i], i));
+    }
+
+    // launchFisheyeStereoMatchKernel(N, Nr, descL, descR, matches)                         KernelController.h:38
+    static void launchFisheyeStereoMatchKernel(Context &ctx, int N, int Nr, const uint8_t *mDescriptors,
+                                               const uint8_t *mDescriptorsRight, int *matches) {
+        check(ft_fisheye_match(ctx.handle(), mDescriptors, N, mDescriptorsRight, Nr, matches, nullptr, nullptr));
+    }
+
+    // launchSearchLocalPointsKernel(F, vmp, th, bFarPoints, thFarPoints, 10 x int*)        KernelController.h:40-42
+    // F / P are the POD views of Frame and of the map points (INTEGRATION.md shows how they are filled);
+    // in addition to the ten raw arrays the call returns the final assignment and nmatches, i.e. the
+    // acceptance loop of ORBmatcher.cc:241-308 is included.
+    static int launchSearchLocalPointsKernel(Context &ctx, ft_frame_view &F, const ft_local_points &P, float th,
+                                             float mfNNratio, std::vector<int> &assign, int *h_bestLevel,
+                                             int *h_bestLevel2, int *h_bestDist, int *h_bestDist2, int *h_bestIdx,
+                                             int *h_bestLevelR, int *h_bestLevelR2, int *h_bestDistR, int *h_bestDistR2,
+                                             int *h_bestIdxR) {
+        assign.assign(F.N > 0 ? F.N : 1, -1);
+        int nm = 0;
+        check(ft_search_local_points(ctx.handle(), &F, &P, th, mfNNratio, assign.data(), &nm, h_bestDist, h_bestDist2,
+                                     h_bestLevel, h_bestLevel2, h_bestIdx, h_bestDistR, h_bestDistR2,
+                                     h_bestLevelR, h_bestLevelR2, h_bestIdxR));
+        assign.resize(F.N);
+        return nm;
+    }
+
+    // launchPoseEstimationKernel(Cur, Last, th, bForward, bBackward, Tcw, 4 x int*)        KernelController.h:44-46
+    // Tcw: row-major 3x4 (the top rows of the reference's Eigen::Matrix4f).
+    static int launchPoseEstimationKernel(Context &ctx, ft_frame_view &CurrentFrame, const ft_last_points &LastFrame,
+                                          float th, bool bForward, bool bBackward, const float *Tcw,
+                                          bool mbCheckOrientation, std::vector<int> &assign, int *h_bestDist,
+                                          int *h_bestIdx2, int *h_bestDistR, int *h_bestIdxR2) {
+        assign.assign(CurrentFrame.N > 0 ? CurrentFrame.N : 1, -1);
+        int nm = 0;
+        check(ft_search_last_frame(ctx.handle(), &CurrentFrame, &LastFrame, Tcw, th, bForward ? 1 : 0, bBackward ? 1 : 0,
+                                   mbCheckOrientation ? 1 : 0, assign.data(), &nm, h_bestDist, h_bestIdx2, h_bestDistR,
+                                   h_bestIdxR2));
+        assign.resize(CurrentFrame.N);
+        return nm;
+    }
+};
+
+}  // namespace fasttrack

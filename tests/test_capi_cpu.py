@@ -1,0 +1,116 @@
+"""C-ABI library checks that need no GPU: it loads, exports every declared symbol, fails loudly without
+a device, and its host-only stages (octree, level geometry) equal the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from fasttrack_amd import _capi
+from oracle import binding as ob
+
+
+def test_library_exports_every_declared_symbol():
+    L = _capi.lib()
+    declared = _capi.declared_symbols()
+    assert len(declared) >= 38
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    # and nothing internal leaks: exported ft_* symbols are exactly the declared ones
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _capi.LIB_PATH]).decode()
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T ft_" in l)
+    assert exported == declared
+    assert L.ft_version().decode().startswith("fasttrack_amd")
+
+
+def test_keypoint_layout_is_cv_keypoint():
+    assert _capi.KP_DTYPE.itemsize == 28
+    assert [_capi.KP_DTYPE.fields[n][1] for n in ("x", "y", "size", "angle", "response", "octave", "class_id")] == \
+        [0, 4, 8, 12, 16, 20, 24]
+
+
+def test_no_device_fails_loudly():
+    """No CPU fallback: on a box without a GPU every compute entry point is unreachable because no
+    context can be created."""
+    L = _capi.lib()
+    if L.ft_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    st = L.ft_context_create(0, 0, C.byref(h))
+    assert st == _capi.FT_ERR_NO_DEVICE and not h.value
+    assert b"no CPU fallback" in L.ft_last_error()
+    from fasttrack_amd import orb
+    with pytest.raises(_capi.FastTrackError):
+        orb.Context(0)
+
+
+def test_missing_library_is_an_import_error(tmp_path, monkeypatch):
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        _capi.lib()
+
+
+def _octree(xys, minX, maxX, minY, maxY, N):
+    L = _capi.lib()
+    xys = np.ascontiguousarray(xys, np.int32)
+    out = np.zeros(len(xys) + 8, np.int32)
+    n = C.c_int()
+    st = L.ft_octree_distribute(_capi.ptr(xys), len(xys), minX, maxX, minY, maxY, N, _capi.ptr(out), len(out), C.byref(n))
+    assert st == 0, L.ft_last_error()
+    return out[:n.value].copy()
+
+
+def test_host_octree_equals_oracle():
+    rng = np.random.default_rng(11)
+    for trial in range(150):
+        W, H = int(rng.integers(40, 1300)), int(rng.integers(40, 720))
+        n, N = int(rng.integers(1, 6000)), int(rng.integers(1, 500))
+        pts = np.unique(np.stack([rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)], 1), axis=0)
+        rng.shuffle(pts)
+        # few distinct scores and sizes -> many (size, UL.x) ties inside std::sort
+        xys = np.concatenate([pts, rng.integers(7, 12, (len(pts), 1))], 1).astype(np.int32)
+        a = ob.distribute_octree(xys, 16, 16 + W, 16, 16 + H, N)
+        b = _octree(xys, 16, 16 + W, 16, 16 + H, N)
+        assert np.array_equal(a, b), (trial, W, H, n, N)
+    # clustered candidates (deep subdivision) and an emission-ordered (cell-major) input
+    cl = (rng.normal(0, 6, (3000, 2)) + [200, 100]).astype(int).clip(3, 396)
+    cl = np.unique(cl, axis=0)
+    xys = np.concatenate([cl, rng.integers(7, 200, (len(cl), 1))], 1).astype(np.int32)
+    assert np.array_equal(ob.distribute_octree(xys, 16, 416, 16, 316, 200), _octree(xys, 16, 416, 16, 316, 200))
+    ex = ob.Extractor(1000)
+    from fasttrack_amd import synth
+    ex.extract(synth.make_image(640, 480, 3))
+    for level in (0, 3, 7):
+        c = ex.candidates(level)
+        lw, lh = ob.level_sizes(640, 480, 1.2, 8)
+        q = ob.features_per_level(1000, 1.2, 8)[level]
+        assert np.array_equal(ob.distribute_octree(c, 16, int(lw[level]) - 16, 16, int(lh[level]) - 16, int(q)),
+                              _octree(c, 16, int(lw[level]) - 16, 16, int(lh[level]) - 16, int(q)))
+
+
+def test_level_geometry_equals_oracle_and_survey_tables():
+    L = _capi.lib()
+    for (w, h, nf) in [(752, 480, 1200), (640, 480, 1000), (512, 512, 2000), (1280, 720, 2000), (333, 257, 500)]:
+        arrs = [np.zeros(8, np.int32) for _ in range(7)]
+        assert L.ft_level_geometry(w, h, nf, 1.2, 8, *[_capi.ptr(a) for a in arrs]) == 0
+        lw, lh, quota, ncols, nrows, wcell, hcell = arrs
+        ow, oh = ob.level_sizes(w, h, 1.2, 8)
+        assert np.array_equal(lw, ow) and np.array_equal(lh, oh)
+        assert np.array_equal(quota, ob.features_per_level(nf, 1.2, 8))
+    # FAST cell grid at level 0
+    for (w, h, grid) in [(752, 480, (20, 12, 36, 38)), (640, 480, (17, 12, 36, 38)), (512, 512, (13, 13, 37, 37)),
+                         (1280, 720, (35, 19, 36, 37))]:
+        arrs = [np.zeros(8, np.int32) for _ in range(7)]
+        L.ft_level_geometry(w, h, 1000, 1.2, 8, *[_capi.ptr(a) for a in arrs])
+        assert (arrs[3][0], arrs[4][0], arrs[5][0], arrs[6][0]) == grid
+
+
+def test_bad_arguments_are_rejected():
+    L = _capi.lib()
+    n = C.c_int()
+    xy = np.array([[5000, 1, 9]], np.int32)
+    assert L.ft_octree_distribute(_capi.ptr(xy), 1, 16, 100, 16, 100, 5, None, 0, C.byref(n)) == _capi.FT_ERR_INVALID
+    assert L.ft_level_geometry(640, 480, 1000, 1.0, 8, *[None] * 7) == _capi.FT_ERR_INVALID
+    assert L.ft_extractor_create(None, 1000, 1.2, 8, 20, 7, 640, 480, 1, None) == _capi.FT_ERR_INVALID

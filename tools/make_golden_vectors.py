@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz: small input/expected-output vectors for the hot path.
+
+The reference (C++/OpenCV/CUDA) cannot be built or imported here, so these vectors are
+produced by the repo's own oracle (oracle/) from seeded synthetic frames; they pin the oracle against
+silent drift and give the GPU tests a fixed target that does not depend on the oracle being rebuilt.
+Each file holds only data: inputs (images, parameters) and expected outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fasttrack_amd import synth  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+from tests import scenarios as sc  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def extract_case(name, w, h, nf, levels, seed, lap=(0, 0)):
+    img = synth.make_image(w, h, seed)
+    ex = ob.Extractor(nf, 1.2, levels, 20, 7)
+    k, d, nm = ex.extract(img, lap)
+    cands = [ex.candidates(l) for l in range(levels)]
+    lv = [ex.level(l) for l in range(levels)]
+    np.savez_compressed(os.path.join(G, name), image=img, nfeatures=nf, nlevels=levels, lap=np.array(lap),
+                        keypoints=k, descriptors=d, n_mono=nm,
+                        cand_counts=np.array([len(c) for c in cands]),
+                        cand_level0=cands[0], cand_last=cands[-1],
+                        level1=lv[1], level_last=lv[-1],
+                        blurred_level1_crc=np.array([int(ex.blurred(1).astype(np.uint64).sum())]))
+
+
+def stereo_case(name, w, h, nf, seed):
+    fr = sc.oracle_stereo_frame(w, h, nf, seed)
+    mbf, mb = fr["intr"]["mbf"], fr["intr"]["mb"]
+    sm = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], mbf, mb)
+    sm0 = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], mbf, mb, median_cut=False)
+    fm = ob.fisheye_match(fr["dL"], fr["dR"])
+    np.savez_compressed(os.path.join(G, name), left=fr["L"], right=fr["R"], nfeatures=nf, mbf=mbf, mb=mb,
+                        keysL=fr["kL"], keysR=fr["kR"], descL=fr["dL"], descR=fr["dR"],
+                        uright=sm["uright"], depth=sm["depth"], n=sm["n"], sad_nocut=sm0["sad"],
+                        hamming_idx=sm0["hamming_idx"], fisheye_matches=fm["matches"], fisheye_best=fm["best"],
+                        fisheye_second=fm["second"])
+
+
+def search_case(name, w, h, nf, seed):
+    fr = sc.oracle_stereo_frame(w, h, nf, seed)
+    sf, _ = ob.scale_factors(1.2, 8)
+    mbf, mb = fr["intr"]["mbf"], fr["intr"]["mb"]
+    sm = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], mbf, mb)
+    pts = sc.local_points_scenario(fr["kL"], fr["dL"], sf, w, h, seed=3, M=600, uright=sm["uright"], dense=True)
+    F = ob.FrameView(keys=fr["kL"], descriptors=fr["dL"], scale_factors_=sf, bounds=sc.frame_bounds(w, h), mbf=mbf,
+                     mb=mb, uright=sm["uright"])
+    lo = ob.search_local_points(F, pts, 3.0)
+    last, Tcw = sc.last_frame_scenario(fr["kL"], fr["dL"], sm["uright"], sm["depth"], fr["intr"], w, h, seed=4)
+    F2 = ob.FrameView(keys=fr["kL"], descriptors=fr["dL"], scale_factors_=sf, bounds=sc.frame_bounds(w, h), mbf=mbf,
+                      mb=mb, uright=sm["uright"], cam=[fr["intr"][k] for k in ("fx", "fy", "cx", "cy")])
+    la = ob.search_last_frame(F2, last, Tcw, 7.0, False, False, True)
+    np.savez_compressed(os.path.join(G, name), width=w, height=h, keys=fr["kL"], descriptors=fr["dL"], sf=sf,
+                        uright=sm["uright"], mbf=mbf, mb=mb, cam=np.array([fr["intr"][k] for k in ("fx", "fy", "cx", "cy")], np.float32),
+                        **{"lp_" + k: v for k, v in pts.items()}, lp_th=3.0, lp_assign=lo["assign"], lp_n=lo["n"],
+                        lp_best_dist=lo["best_dist"], lp_best_dist2=lo["best_dist2"], lp_best_idx=lo["best_idx"],
+                        **{"lf_" + k: v for k, v in last.items()}, lf_Tcw=Tcw, lf_th=7.0, lf_assign=la["assign"],
+                        lf_n=la["n"], lf_best_dist=la["best_dist"], lf_best_idx=la["best_idx"])
+
+
+if __name__ == "__main__":
+    extract_case("extract_160x120_s1.npz", 160, 120, 300, 4, 1)
+    extract_case("extract_320x240_s2_lap.npz", 320, 240, 500, 8, 2, lap=(100, 200))
+    stereo_case("stereo_320x240_s3.npz", 320, 240, 500, 3)
+    search_case("search_320x240_s5.npz", 320, 240, 500, 5)
+    print({f: os.path.getsize(os.path.join(G, f)) for f in sorted(os.listdir(G))})
