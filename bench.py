@@ -37,6 +37,18 @@ NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def usable_cpus():
+    """CPUs this process may use: affinity, capped by a cgroup v2 CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        pass
+    return max(n, 1)
+
+
 def level_pixels(w, h):
     P = []
     sf = np.float32(1.0)
@@ -56,7 +68,7 @@ def cpu_baseline(w, h, nf, pairs, budget_s=12.0):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import binding as ob
     intr = synth.intrinsics(w, h)
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
 
     def one(pair):
         L, R = pair
@@ -115,7 +127,7 @@ def main():
 
     w, h, nf, cfg_note = WORKLOADS[args.workload]
     B = args.batch
-    host_threads = args.host_threads or max(1, (os.cpu_count() or 1) // max(world, 1))
+    host_threads = args.host_threads or max(1, usable_cpus() // max(world, 1))
     ctx = orb.Context(local_rank, host_threads)
     intr = synth.intrinsics(w, h)
     fe = orb.StereoFrontend(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, B, intr["mbf"], intr["mb"])
@@ -170,13 +182,14 @@ def main():
         for name in ("stereo.octree(host,both)", "stereo.process.total"):
             m, n = ctx.get_stat(name)
             host[name] = (m / n) if n else None
-        bytes_per_launch = float(B * sumP)
+        # the batch is processed in sub-batches (software pipeline), so bytes per launch = algorithmic
+        # bytes of the whole timed region / number of launches in it
+        total_bytes = float(args.steps) * 2.0 * B * sumP
         roof = None
         if launches:
-            dur_s = ms / launches / 1e3
-            achieved = bytes_per_launch / dur_s / 1e9
+            achieved = total_bytes / (ms / 1e3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": total_bytes / launches,
                     "avg_launch_ms": ms / launches, "launches_timed": launches}
         R_pair = 2 * (3 * sumP - P[-1])  # read bytes per stereo pair, unfused accounting
         out = {

@@ -88,6 +88,8 @@ def lib() -> C.CDLL:
     L.ft_context_reset_stats.argtypes = [vp]
     L.ft_device_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.ft_device_free.argtypes = [vp, vp]
+    L.ft_host_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.ft_host_free.argtypes = [vp, vp]
     L.ft_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.ft_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     L.ft_extractor_create.argtypes = [vp, i, f, i, i, i, i, i, i, C.POINTER(vp)]

@@ -1,6 +1,10 @@
 // Library / device context: replaces KernelController::setCUDADevice / initializeKernels /
 // shutdownKernels / saveKernelsStats (reference include/Kernels/KernelController.h:15-29).
+#include <sched.h>
+
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -17,6 +21,37 @@ int ft_hip_fail(hipError_t e, const char *what, const char *file, int line) {
     // a missing device must be unmistakable: there is no CPU fallback behind this ABI
     if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) return FT_ERR_NO_DEVICE;
     return FT_ERR_HIP;
+}
+
+// CPUs this process may actually use: hardware threads, capped by the scheduler affinity and by a
+// cgroup CPU quota (containers often expose 256 logical CPUs with a 16-CPU quota; oversubscribing the
+// quota gets every thread throttled).
+int ft_usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, CPU_COUNT(&set));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char q[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long quota = atol(q);
+            if (quota > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+        }
+        fclose(f);
+    } else {
+        long quota = -1, period = 0;
+        if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(fq, "%ld", &quota) != 1) quota = -1;
+            fclose(fq);
+        }
+        if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(fp, "%ld", &period) != 1) period = 0;
+            fclose(fp);
+        }
+        if (quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+    }
+    return std::max(n, 1);
 }
 
 int ft_set_device(const ft_context *ctx) {
@@ -58,7 +93,7 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
     ft_context *ctx = new ft_context();
     ctx->device = device;
     ctx->deviceName = std::string(prop.name[0] ? prop.name : "AMD GPU") + " (" + prop.gcnArchName + ")";
-    if (host_threads <= 0) host_threads = (int)std::thread::hardware_concurrency();
+    if (host_threads <= 0) host_threads = ft_usable_cpus();
     if (host_threads < 1) host_threads = 1;
     ctx->pool = new ft::ThreadPool(host_threads - 1);
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -145,6 +180,20 @@ int ft_device_free(ft_context *ctx, void *dptr) {
     if (!ctx) return FT_ERR_INVALID;
     FT_HIP(hipSetDevice(ctx->device));
     FT_HIP(hipFree(dptr));
+    return FT_OK;
+}
+
+int ft_host_malloc(ft_context *ctx, size_t bytes, void **ptr) {
+    if (!ctx || !ptr) return FT_ERR_INVALID;
+    FT_HIP(hipSetDevice(ctx->device));
+    FT_HIP(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return FT_OK;
+}
+
+int ft_host_free(ft_context *ctx, void *ptr) {
+    if (!ctx) return FT_ERR_INVALID;
+    FT_HIP(hipSetDevice(ctx->device));
+    FT_HIP(hipHostFree(ptr));
     return FT_OK;
 }
 

@@ -4,6 +4,7 @@
 // touched by the HIP kernels in kernels_extract.hip.  Compiled with -ffp-contract=off.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "ft_host.h"
@@ -148,7 +149,13 @@ int pinAlloc(T **p, size_t n, unsigned flags = hipHostMallocDefault) {
 void freeAll(ft_extractor *ex) {
     hipSetDevice(ex->ctx->device);
     if (ex->stream) hipStreamSynchronize(ex->stream);
+    if (ex->streamB) hipStreamSynchronize(ex->streamB);
     ex->evt.destroy();
+    for (int i = 0; i < FT_PIPE_MAX; i++) {
+        if (ex->evA[i]) hipEventDestroy(ex->evA[i]);
+        if (ex->evB[i]) hipEventDestroy(ex->evB[i]);
+    }
+    if (ex->streamB) hipStreamDestroy(ex->streamB);
     hipFree(ex->d_pyr);
     hipFree(ex->d_taps);
     hipFree(ex->d_cellCount);
@@ -175,9 +182,18 @@ void freeAll(ft_extractor *ex) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// stages
+// stages.  A batch is cut into sub-batches of consecutive slots so that the host octree of one
+// sub-batch overlaps with the kernels of the next (stage A on ex->stream, stage B on ex->streamB).
 // ------------------------------------------------------------------------------------------------
-int ft_extract_stage_a(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
+int ft_pipeline_depth(int batch) {
+    static const int envDepth = [] {
+        const char *e = getenv("FT_PIPELINE_DEPTH");
+        return e ? std::max(1, std::min(FT_PIPE_MAX, atoi(e))) : 2;
+    }();
+    return std::max(1, std::min(envDepth, batch / 4 > 0 ? batch / 4 : 1));
+}
+
+int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
                        int height, int stride) {
     FT_REQUIRE(ex && images, "extract: null handle or image list");
     FT_REQUIRE(batch >= 1 && batch <= ex->maxBatch, "extract: batch outside [1, max_batch]");
@@ -212,42 +228,57 @@ int ft_extract_stage_a(ft_extractor *ex, const uint8_t *const *images, int batch
     ex->lastBatch = batch;
     FT_HIP(hipMemcpyAsync((void *)ex->d_l0, (const void *)ex->h_l0, sizeof(uint8_t *) * batch, hipMemcpyHostToDevice,
                           ex->stream));
+    return FT_OK;
+}
+
+// stage A of slots [b0, b0+nb): pyramid + FAST + ordered compaction on ex->stream; `done` is recorded after it
+int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done) {
+    const FtGeom &g = ex->geom;
     const bool tm = ex->ctx->kernelTiming;
+    const int al = ex->l0Aligned ? 1 : 0;
+    const uint8_t *const *l0 = ex->d_l0 + b0;
+    uint8_t *pyr = ex->d_pyr + (size_t)b0 * g.pyrPerSlot;
+    int *cellCount = ex->d_cellCount + (size_t)b0 * g.totalCells;
+    uint32_t *stage = ex->d_stage + (size_t)b0 * g.stagePerSlot;
     ex->evt.begin(tm, "kernel.pyr_down(all levels)", ex->stream);
-    rc = ft_launch_pyramid(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->d_taps, ex->l0Aligned ? 1 : 0);
+    int rc = ft_launch_pyramid(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->d_taps, al);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.fast_cells", ex->stream);
-    rc = ft_launch_fast_cells(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->iniTh, ex->minTh,
-                              ex->l0Aligned ? 1 : 0, ex->d_cellCount, ex->d_stage);
+    rc = ft_launch_fast_cells(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->iniTh, ex->minTh, al, cellCount, stage);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.compact", ex->stream);
-    rc = ft_launch_compact(ex->stream, g, batch, ex->d_cellCount, ex->d_stage, ex->d_cand, ex->d_candCount);
+    rc = ft_launch_compact(ex->stream, g, nb, cellCount, stage, ex->d_cand + (size_t)b0 * g.candPerSlot,
+                           ex->d_candCount + (size_t)b0 * g.nlevels);
     ex->evt.end(tm, ex->stream);
-    return rc;
+    if (rc != FT_OK) return rc;
+    if (done) FT_HIP(hipEventRecord(done, ex->stream));
+    return FT_OK;
 }
 
-int ft_extract_octree(ft_extractor *ex, int batch) {
-    const FtGeom &g = ex->geom;
+// host octree over the candidates of slots [b0, b0+nb) of one or two extractors (their stage A must
+// have completed).  One task per (camera, level, image), issued level-major so the big level-0 trees
+// start first; results land in disjoint sub-ranges of a preallocated scratch and are packed per slot.
+int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb) {
+    ft_extractor *e0 = exs[0];
+    const FtGeom &g = e0->geom;
     const int L = g.nlevels;
-    // per (slot, level) results land in disjoint sub-ranges of h_sel, then are packed per slot
-    std::vector<int> levelOff(L + 1, 0);
-    for (int l = 0; l < L; l++) levelOff[l + 1] = levelOff[l] + ex->levelMax[l];
-    std::vector<int> counts((size_t)batch * L, 0);
-    std::vector<FtSelKp> tmp((size_t)batch * g.maxKp);
+    const int perEx = nb * L;
     auto task = [&](int t, int) {
         static thread_local ft::OctreeWorkspace ws;
         static thread_local std::vector<int> keep;
-        const int slot = t / L, level = t - slot * L;
+        ft_extractor *ex = exs[t / perEx];
+        const int r = t % perEx;
+        const int level = r / nb, rel = r - level * nb, slot = b0 + rel;
         const FtLevelGeom &v = g.lv[level];
-        int n = ex->h_candCount[slot * L + level];
+        const int n = ex->h_candCount[slot * L + level];
         const uint32_t *cand = ex->h_cand + (size_t)slot * g.candPerSlot + v.candBase;
         keep.clear();
         const int minB = FT_EDGE_THRESHOLD - 3;
         int k = ft::distribute_octree(cand, n, minB, v.maxBX, minB, v.maxBY, ex->quota[level], ws, keep);
         k = std::min(k, ex->levelMax[level]);
-        FtSelKp *dst = tmp.data() + (size_t)slot * g.maxKp + levelOff[level];
+        FtSelKp *dst = ex->selTmp.data() + (size_t)slot * g.maxKp + ex->levelOff[level];
         for (int i = 0; i < k; i++) {
             const uint32_t c = cand[keep[i]];
             // ORBextractor.cc:1211-1217: add the border offset back
@@ -256,50 +287,60 @@ int ft_extract_octree(ft_extractor *ex, int batch) {
             dst[i].level = (short)level;
             dst[i].response = (short)(c >> 24);
         }
-        counts[(size_t)slot * L + level] = k;
+        ex->selCount[(size_t)slot * L + level] = k;
     };
-    ex->ctx->pool->parallel_for(batch * L, task);
-    for (int b = 0; b < batch; b++) {
-        int n = 0;
-        FtSelKp *dst = ex->h_sel + (size_t)b * g.maxKp;
-        for (int l = 0; l < L; l++) {
-            const int k = counts[(size_t)b * L + l];
-            memcpy(dst + n, tmp.data() + (size_t)b * g.maxKp + levelOff[l], sizeof(FtSelKp) * k);
-            n += k;
+    e0->ctx->pool->parallel_for(nex * perEx, task);
+    for (int e = 0; e < nex; e++) {
+        ft_extractor *ex = exs[e];
+        for (int slot = b0; slot < b0 + nb; slot++) {
+            int n = 0;
+            FtSelKp *dst = ex->h_sel + (size_t)slot * g.maxKp;
+            for (int l = 0; l < L; l++) {
+                const int k = ex->selCount[(size_t)slot * L + l];
+                memcpy(dst + n, ex->selTmp.data() + (size_t)slot * g.maxKp + ex->levelOff[l], sizeof(FtSelKp) * k);
+                n += k;
+            }
+            ex->h_nSel[slot] = n;
         }
-        ex->h_nSel[b] = n;
     }
     return FT_OK;
 }
 
-int ft_extract_stage_b(ft_extractor *ex, int batch) {
-    const FtGeom &g = ex->geom;
+int ft_extract_octree(ft_extractor *ex, int b0, int nb) { return ft_extract_octree_multi(&ex, 1, b0, nb); }
+
+static int rangeMaxN(const ft_extractor *ex, int b0, int nb) {
     int maxN = 0;
-    for (int b = 0; b < batch; b++) maxN = std::max(maxN, ex->h_nSel[b]);
-    FT_HIP(hipMemcpyAsync(ex->d_nSel, ex->h_nSel, sizeof(int) * batch, hipMemcpyHostToDevice, ex->stream));
+    for (int b = b0; b < b0 + nb; b++) maxN = std::max(maxN, ex->h_nSel[b]);
+    return maxN;
+}
+
+// stage B of slots [b0, b0+nb): upload the selection, orientation + descriptors -> d_keys / d_desc, on `st`
+int ft_extract_launch_b(ft_extractor *ex, int b0, int nb, hipStream_t st) {
+    const FtGeom &g = ex->geom;
+    const int maxN = rangeMaxN(ex, b0, nb);
+    FT_HIP(hipMemcpyAsync(ex->d_nSel + b0, ex->h_nSel + b0, sizeof(int) * nb, hipMemcpyHostToDevice, st));
     if (maxN == 0) return FT_OK;
-    FT_HIP(hipMemcpy2DAsync(ex->d_sel, sizeof(FtSelKp) * g.maxKp, ex->h_sel, sizeof(FtSelKp) * g.maxKp,
-                            sizeof(FtSelKp) * maxN, batch, hipMemcpyHostToDevice, ex->stream));
+    FT_HIP(hipMemcpy2DAsync(ex->d_sel + (size_t)b0 * g.maxKp, sizeof(FtSelKp) * g.maxKp, ex->h_sel + (size_t)b0 * g.maxKp,
+                            sizeof(FtSelKp) * g.maxKp, sizeof(FtSelKp) * maxN, nb, hipMemcpyHostToDevice, st));
     const bool tm = ex->ctx->kernelTiming;
-    ex->evt.begin(tm, "kernel.orient_desc", ex->stream);
-    int rc = ft_launch_orient_desc(ex->stream, g, batch, ex->d_l0, ex->l0pitch, ex->d_pyr, ex->l0Aligned ? 1 : 0,
-                                   ex->d_sel, ex->d_nSel, ex->d_keys, ex->d_desc);
-    ex->evt.end(tm, ex->stream);
+    ex->evt.begin(tm, "kernel.orient_desc", st);
+    int rc = ft_launch_orient_desc(st, g, nb, ex->d_l0 + b0, ex->l0pitch, ex->d_pyr + (size_t)b0 * g.pyrPerSlot,
+                                   ex->l0Aligned ? 1 : 0, ex->d_sel + (size_t)b0 * g.maxKp, ex->d_nSel + b0,
+                                   ex->d_keys + (size_t)b0 * g.maxKp, ex->d_desc + (size_t)b0 * g.maxKp * 32);
+    ex->evt.end(tm, st);
     return rc;
 }
 
-static int downloadResults(ft_extractor *ex, int batch) {
+// async D2H of the keypoints / descriptors of slots [b0, b0+nb) on `st`
+int ft_extract_download(ft_extractor *ex, int b0, int nb, hipStream_t st) {
     const FtGeom &g = ex->geom;
-    int maxN = 0;
-    for (int b = 0; b < batch; b++) maxN = std::max(maxN, ex->h_nSel[b]);
-    if (maxN > 0) {
-        FT_HIP(hipMemcpy2DAsync(ex->h_keys, sizeof(ft_keypoint) * g.maxKp, ex->d_keys, sizeof(ft_keypoint) * g.maxKp,
-                                sizeof(ft_keypoint) * maxN, batch, hipMemcpyDeviceToHost, ex->stream));
-        FT_HIP(hipMemcpy2DAsync(ex->h_desc, (size_t)32 * g.maxKp, ex->d_desc, (size_t)32 * g.maxKp, (size_t)32 * maxN,
-                                batch, hipMemcpyDeviceToHost, ex->stream));
-    }
-    FT_HIP(hipStreamSynchronize(ex->stream));
-    ex->evt.resolve(ex->ctx);
+    const int maxN = rangeMaxN(ex, b0, nb);
+    if (maxN == 0) return FT_OK;
+    const size_t o = (size_t)b0 * g.maxKp;
+    FT_HIP(hipMemcpy2DAsync(ex->h_keys + o, sizeof(ft_keypoint) * g.maxKp, ex->d_keys + o, sizeof(ft_keypoint) * g.maxKp,
+                            sizeof(ft_keypoint) * maxN, nb, hipMemcpyDeviceToHost, st));
+    FT_HIP(hipMemcpy2DAsync(ex->h_desc + o * 32, (size_t)32 * g.maxKp, ex->d_desc + o * 32, (size_t)32 * g.maxKp,
+                            (size_t)32 * maxN, nb, hipMemcpyDeviceToHost, st));
     return FT_OK;
 }
 
@@ -376,9 +417,15 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         }                    \
     } while (0)
     hipError_t se = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&ex->streamB, hipStreamNonBlocking);
+    for (int i = 0; i < FT_PIPE_MAX && se == hipSuccess; i++) {
+        se = hipEventCreateWithFlags(&ex->evA[i], hipEventDisableTiming);
+        if (se == hipSuccess) se = hipEventCreateWithFlags(&ex->evB[i], hipEventDisableTiming);
+    }
     if (se != hipSuccess) {
+        freeAll(ex);
         delete ex;
-        return ft_hip_fail(se, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+        return ft_hip_fail(se, "stream / event creation", __FILE__, __LINE__);
     }
     FT_TRY(devAlloc(&ex->d_pyr, B * g.pyrPerSlot));
     FT_TRY(devAlloc(&ex->d_taps, taps.size()));
@@ -420,6 +467,10 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         }
     }
     memset(ex->h_nSel, 0, sizeof(int) * B);
+    ex->levelOff.assign(nlevels + 1, 0);
+    for (int l = 0; l < nlevels; l++) ex->levelOff[l + 1] = ex->levelOff[l] + ex->levelMax[l];
+    ex->selTmp.resize(B * g.maxKp);
+    ex->selCount.assign(B * nlevels, 0);
 #undef FT_TRY
     *out = ex;
     return FT_OK;
@@ -518,20 +569,31 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
         return FT_ERR_EMPTY;
     }
     FtTimer tAll;
-    int rc = ft_extract_stage_a(ex, images, batch, on_device, width, height, stride);
+    int rc = ft_extract_prepare(ex, images, batch, on_device, width, height, stride);
     if (rc != FT_OK) return rc;
+    const int S = ft_pipeline_depth(batch);
+    const int sb = (batch + S - 1) / S;
+    for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
+        rc = ft_extract_launch_a(ex, b0, std::min(sb, batch - b0), ex->evA[s]);
+        if (rc != FT_OK) return rc;
+    }
+    double tOct = 0;
+    for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
+        const int nb = std::min(sb, batch - b0);
+        FT_HIP(hipEventSynchronize(ex->evA[s]));
+        FtTimer tO;
+        rc = ft_extract_octree(ex, b0, nb);
+        if (rc != FT_OK) return rc;
+        tOct += tO.ms();
+        rc = ft_extract_launch_b(ex, b0, nb, ex->streamB);
+        if (rc != FT_OK) return rc;
+        rc = ft_extract_download(ex, b0, nb, ex->streamB);
+        if (rc != FT_OK) return rc;
+    }
+    FT_HIP(hipStreamSynchronize(ex->streamB));
     FT_HIP(hipStreamSynchronize(ex->stream));
-    ex->ctx->addStat("extract.stageA(pyramid+fast)", tAll.ms());
-    FtTimer tO;
-    rc = ft_extract_octree(ex, batch);
-    if (rc != FT_OK) return rc;
-    ex->ctx->addStat("extract.octree(host)", tO.ms());
-    FtTimer tB;
-    rc = ft_extract_stage_b(ex, batch);
-    if (rc != FT_OK) return rc;
-    rc = downloadResults(ex, batch);
-    if (rc != FT_OK) return rc;
-    ex->ctx->addStat("extract.stageB(orient+desc+d2h)", tB.ms());
+    ex->evt.resolve(ex->ctx);
+    ex->ctx->addStat("extract.octree(host)", tOct);
     rc = assembleOutputs(ex, batch, lap0, lap1, keypoints, descriptors, capacity, n_keypoints, n_mono);
     ex->ctx->addStat("extract.total", tAll.ms());
     return rc;
@@ -574,6 +636,7 @@ int ft_extractor_download_level(ft_extractor *ex, int slot, int level, uint8_t *
     const FtLevelGeom &v = ex->geom.lv[level];
     FT_REQUIRE(dst_stride >= v.w, "destination stride smaller than the level width");
     FT_HIP(hipStreamSynchronize(ex->stream));
+    FT_HIP(hipStreamSynchronize(ex->streamB));
     FT_HIP(hipMemcpy2D(dst, dst_stride, src, pitch, v.w, v.h, hipMemcpyDeviceToHost));
     return FT_OK;
 }

@@ -11,6 +11,8 @@
 #include "octree.h"
 #include "thread_pool.h"
 
+#define FT_PIPE_MAX 8
+
 struct ft_context {
     int device = 0;
     std::string deviceName;
@@ -88,8 +90,13 @@ struct ft_extractor {
     std::vector<float> sf, invsf, sigma2, invsigma2;
     std::vector<int> quota;
     std::vector<int> levelMax;  // per-level bound of octree results
+    std::vector<int> levelOff;  // prefix sums of levelMax
+    std::vector<FtSelKp> selTmp;  // octree scratch [maxBatch * maxKp]
+    std::vector<int> selCount;    // [maxBatch * nlevels]
     FtGeom geom{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // stage A (pyramid, FAST, compaction)
+    hipStream_t streamB = nullptr;  // stage B (orientation + descriptors), matching, result copies
+    hipEvent_t evA[FT_PIPE_MAX] = {}, evB[FT_PIPE_MAX] = {};
     // device buffers
     uint8_t *d_pyr = nullptr;
     FtTap *d_taps = nullptr;
@@ -132,10 +139,14 @@ struct ft_stereo_frontend {
 };
 
 int ft_set_device(const ft_context *ctx);
-// stage A: pyramid + FAST + ordered compaction (async on ex->stream)
-int ft_extract_stage_a(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
-                       int height, int stride);
-// host octree over the candidates of the last stage A (after the stream is synchronised)
-int ft_extract_octree(ft_extractor *ex, int batch);
-// stage B: upload selection, orientation + descriptors -> d_keys/d_desc (async on ex->stream)
-int ft_extract_stage_b(ft_extractor *ex, int batch);
+int ft_usable_cpus();
+int ft_pipeline_depth(int batch);
+// validation, level-0 pointers / uploads of a whole batch (async on ex->stream)
+int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width, int height,
+                       int stride);
+// per sub-batch of slots [b0, b0+nb): see extractor.cpp
+int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done);
+int ft_extract_octree(ft_extractor *ex, int b0, int nb);
+int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb);
+int ft_extract_launch_b(ft_extractor *ex, int b0, int nb, hipStream_t st);
+int ft_extract_download(ft_extractor *ex, int b0, int nb, hipStream_t st);

@@ -12,8 +12,8 @@ __constant__ signed char c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-// fixed-point taps of GaussianBlur(7x7, sigma 2): error-diffused, sum 256
-__constant__ int c_gauss[7] = {18, 34, 48, 56, 48, 34, 18};
+// GaussianBlur(7x7, sigma 2) fixed-point taps {18,34,48,56,48,34,18} (error-diffused, sum 256) are literals in k_orient_desc
+
 
 __device__ __forceinline__ const uint8_t *level_ptr(const FtGeom &g, int level, int slot, const uint8_t *const *l0,
                                                     int l0pitch, const uint8_t *pyr, int &pitch) {

@@ -59,6 +59,8 @@ int ft_stereo_match(ft_extractor *exL, ft_extractor *exR, int slot, const ft_key
     const int C = exL->stCap;
     hipStream_t st = exL->stream;
     FT_HIP(hipStreamSynchronize(exR->stream));  // right pyramid must be complete
+    FT_HIP(hipStreamSynchronize(exR->streamB));
+    FT_HIP(hipStreamSynchronize(exL->streamB));
     FT_HIP(hipMemcpyAsync(exL->d_stKeys, keysL, sizeof(ft_keypoint) * nL, hipMemcpyHostToDevice, st));
     FT_HIP(hipMemcpyAsync(exL->d_stDesc, descL, (size_t)32 * nL, hipMemcpyHostToDevice, st));
     if (nR > 0) {
@@ -168,84 +170,128 @@ int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *ima
     ft_extractor *L = fe->exL, *R = fe->exR;
     const FtGeom &g = L->geom;
     FtTimer tAll;
-    int rc = ft_extract_stage_a(L, imagesL, batch, on_device, width, height, stride);
+    int rc = ft_extract_prepare(L, imagesL, batch, on_device, width, height, stride);
     if (rc != FT_OK) return rc;
-    rc = ft_extract_stage_a(R, imagesR, batch, on_device, width, height, stride);
+    rc = ft_extract_prepare(R, imagesR, batch, on_device, width, height, stride);
     if (rc != FT_OK) return rc;
-    FT_HIP(hipStreamSynchronize(L->stream));
-    FtTimer tO;
-    rc = ft_extract_octree(L, batch);  // overlaps with the right image's stage A still running
-    if (rc != FT_OK) return rc;
-    FT_HIP(hipStreamSynchronize(R->stream));
-    rc = ft_extract_octree(R, batch);
-    if (rc != FT_OK) return rc;
-    fe->ctx->addStat("stereo.octree(host,both)", tO.ms());
-    rc = ft_extract_stage_b(L, batch);
-    if (rc != FT_OK) return rc;
-    rc = ft_extract_stage_b(R, batch);
-    if (rc != FT_OK) return rc;
-    FT_HIP(hipEventRecord(fe->evR, R->stream));
-    FT_HIP(hipStreamWaitEvent(L->stream, fe->evR, 0));
-    // keypoints stay on the device between extraction and matching: pinhole stereo passes the lapping
-    // area (0,0) (src/Frame.cc:127), no keypoint has x == 0, so mono order == extraction order.
-    FtStereoArgs a;
-    a.keysL = L->d_keys;
-    a.keysR = R->d_keys;
-    a.descL = L->d_desc;
-    a.descR = R->d_desc;
-    a.nL = L->d_nSel;
-    a.nR = R->d_nSel;
-    a.capacity = g.maxKp;
-    a.mbf = fe->mbf;
-    a.mb = fe->mb;
-    a.uright = fe->d_uright;
-    a.depth = fe->d_depth;
-    a.sad = fe->d_sad;
-    a.hamIdx = nullptr;
-    a.nMatches = fe->d_nMatches;
-    a.applyMedianCut = 1;
+    // software pipeline over sub-batches: while the host distributes the keypoints of sub-batch s, the
+    // GPU already runs pyramid + FAST of sub-batch s+1 (stage-A streams) and descriptors / matching of
+    // sub-batch s-1 (stage-B streams)
+    const int S = ft_pipeline_depth(batch);
+    const int sb = (batch + S - 1) / S;
+    for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
+        const int nb = std::min(sb, batch - b0);
+        rc = ft_extract_launch_a(L, b0, nb, L->evA[s]);
+        if (rc != FT_OK) return rc;
+        rc = ft_extract_launch_a(R, b0, nb, R->evA[s]);
+        if (rc != FT_OK) return rc;
+    }
     const bool tm = fe->ctx->kernelTiming;
-    L->evt.begin(tm, "kernel.stereo_match", L->stream);
-    rc = ft_launch_stereo_match(L->stream, g, batch, L->d_l0, R->d_l0, L->l0pitch, R->l0pitch, L->d_pyr, R->d_pyr, a);
-    L->evt.end(tm, L->stream);
-    if (rc != FT_OK) return rc;
-    L->evt.begin(tm, "kernel.stereo_median", L->stream);
-    rc = ft_launch_stereo_median(L->stream, batch, a);
-    L->evt.end(tm, L->stream);
-    if (rc != FT_OK) return rc;
-    int maxNL = 0, maxNR = 0;
-    for (int b = 0; b < batch; b++) {
-        maxNL = std::max(maxNL, L->h_nSel[b]);
-        maxNR = std::max(maxNR, R->h_nSel[b]);
-    }
-    hipStream_t st = L->stream;
+    hipStream_t st = L->streamB;
+    double tOct = 0;
+    // result arrays in pinned host memory (ft_host_malloc) are filled by the D2H copies directly; pageable
+    // ones go through the library's pinned staging buffers and a host memcpy
+    auto pinned = [](const void *p) {
+        if (!p) return true;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return at.type == hipMemoryTypeHost;
+    };
+    const bool direct = pinned(keysL) && pinned(descL) && pinned(keysR) && pinned(descR) && pinned(uright) && pinned(depth);
     const size_t kp = sizeof(ft_keypoint);
-    if (maxNL > 0) {
-        FT_HIP(hipMemcpy2DAsync(L->h_keys, kp * g.maxKp, L->d_keys, kp * g.maxKp, kp * maxNL, batch, hipMemcpyDeviceToHost, st));
-        FT_HIP(hipMemcpy2DAsync(L->h_desc, (size_t)32 * g.maxKp, L->d_desc, (size_t)32 * g.maxKp, (size_t)32 * maxNL, batch, hipMemcpyDeviceToHost, st));
-        FT_HIP(hipMemcpy2DAsync(fe->h_uright, 4 * (size_t)g.maxKp, fe->d_uright, 4 * (size_t)g.maxKp, 4 * (size_t)maxNL, batch, hipMemcpyDeviceToHost, st));
-        FT_HIP(hipMemcpy2DAsync(fe->h_depth, 4 * (size_t)g.maxKp, fe->d_depth, 4 * (size_t)g.maxKp, 4 * (size_t)maxNL, batch, hipMemcpyDeviceToHost, st));
+    auto d2h = [&](void *user, void *staging, const void *dev, size_t elem, int b0, int nb, int maxN) -> hipError_t {
+        // rows of `elem`-byte records: device/staging stride maxKp, user stride capacity
+        const size_t o = (size_t)b0 * g.maxKp * elem;
+        if (direct) {
+            if (!user) return hipSuccess;
+            return hipMemcpy2DAsync((uint8_t *)user + (size_t)b0 * capacity * elem, elem * capacity, (const uint8_t *)dev + o,
+                                    elem * g.maxKp, elem * maxN, nb, hipMemcpyDeviceToHost, st);
+        }
+        return hipMemcpy2DAsync((uint8_t *)staging + o, elem * g.maxKp, (const uint8_t *)dev + o, elem * g.maxKp, elem * maxN,
+                                nb, hipMemcpyDeviceToHost, st);
+    };
+    for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
+        const int nb = std::min(sb, batch - b0);
+        FT_HIP(hipEventSynchronize(L->evA[s]));
+        FT_HIP(hipEventSynchronize(R->evA[s]));
+        FtTimer tO;
+        ft_extractor *both[2] = {L, R};
+        rc = ft_extract_octree_multi(both, 2, b0, nb);  // one job for both cameras: one critical path
+        if (rc != FT_OK) return rc;
+        tOct += tO.ms();
+        rc = ft_extract_launch_b(L, b0, nb, L->streamB);
+        if (rc != FT_OK) return rc;
+        rc = ft_extract_launch_b(R, b0, nb, R->streamB);
+        if (rc != FT_OK) return rc;
+        FT_HIP(hipEventRecord(R->evB[s], R->streamB));
+        FT_HIP(hipStreamWaitEvent(st, R->evB[s], 0));
+        // keypoints stay on the device between extraction and matching: pinhole stereo passes the lapping
+        // area (0,0) (src/Frame.cc:127), no keypoint has x == 0, so mono order == extraction order.
+        const size_t o = (size_t)b0 * g.maxKp;
+        FtStereoArgs a;
+        a.keysL = L->d_keys + o;
+        a.keysR = R->d_keys + o;
+        a.descL = L->d_desc + o * 32;
+        a.descR = R->d_desc + o * 32;
+        a.nL = L->d_nSel + b0;
+        a.nR = R->d_nSel + b0;
+        a.capacity = g.maxKp;
+        a.mbf = fe->mbf;
+        a.mb = fe->mb;
+        a.uright = fe->d_uright + o;
+        a.depth = fe->d_depth + o;
+        a.sad = fe->d_sad + o;
+        a.hamIdx = nullptr;
+        a.nMatches = fe->d_nMatches + b0;
+        a.applyMedianCut = 1;
+        L->evt.begin(tm, "kernel.stereo_match", st);
+        rc = ft_launch_stereo_match(st, g, nb, L->d_l0 + b0, R->d_l0 + b0, L->l0pitch, R->l0pitch,
+                                    L->d_pyr + (size_t)b0 * g.pyrPerSlot, R->d_pyr + (size_t)b0 * g.pyrPerSlot, a);
+        L->evt.end(tm, st);
+        if (rc != FT_OK) return rc;
+        L->evt.begin(tm, "kernel.stereo_median", st);
+        rc = ft_launch_stereo_median(st, nb, a);
+        L->evt.end(tm, st);
+        if (rc != FT_OK) return rc;
+        int maxNL = 0, maxNR = 0;
+        for (int b = b0; b < b0 + nb; b++) {
+            maxNL = std::max(maxNL, L->h_nSel[b]);
+            maxNR = std::max(maxNR, R->h_nSel[b]);
+        }
+        if (maxNL > capacity || maxNR > capacity) {
+            ft_set_error("stereo front end: output capacity too small (use ft_extractor_max_keypoints)");
+            return FT_ERR_CAPACITY;
+        }
+        if (maxNL > 0) {
+            FT_HIP(d2h(keysL, L->h_keys, L->d_keys, kp, b0, nb, maxNL));
+            FT_HIP(d2h(descL, L->h_desc, L->d_desc, 32, b0, nb, maxNL));
+            FT_HIP(d2h(uright, fe->h_uright, fe->d_uright, 4, b0, nb, maxNL));
+            FT_HIP(d2h(depth, fe->h_depth, fe->d_depth, 4, b0, nb, maxNL));
+        }
+        if (maxNR > 0) {
+            FT_HIP(d2h(keysR, R->h_keys, R->d_keys, kp, b0, nb, maxNR));
+            FT_HIP(d2h(descR, R->h_desc, R->d_desc, 32, b0, nb, maxNR));
+        }
+        FT_HIP(hipMemcpyAsync(fe->h_nMatches + b0, fe->d_nMatches + b0, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
     }
-    if (maxNR > 0) {
-        FT_HIP(hipMemcpy2DAsync(R->h_keys, kp * g.maxKp, R->d_keys, kp * g.maxKp, kp * maxNR, batch, hipMemcpyDeviceToHost, st));
-        FT_HIP(hipMemcpy2DAsync(R->h_desc, (size_t)32 * g.maxKp, R->d_desc, (size_t)32 * g.maxKp, (size_t)32 * maxNR, batch, hipMemcpyDeviceToHost, st));
-    }
-    FT_HIP(hipMemcpyAsync(fe->h_nMatches, fe->d_nMatches, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
     FT_HIP(hipStreamSynchronize(st));
+    FT_HIP(hipStreamSynchronize(R->streamB));
+    fe->ctx->addStat("stereo.octree(host,both)", tOct);
     L->evt.resolve(fe->ctx);
     R->evt.resolve(fe->ctx);
     for (int b = 0; b < batch; b++) {
         const int nl = L->h_nSel[b], nr = R->h_nSel[b];
-        if (nl > capacity || nr > capacity) {
-            ft_set_error("stereo front end: output capacity too small (use ft_extractor_max_keypoints)");
-            return FT_ERR_CAPACITY;
+        if (!direct) {
+            if (keysL) memcpy(keysL + (size_t)b * capacity, L->h_keys + (size_t)b * g.maxKp, kp * nl);
+            if (descL) memcpy(descL + (size_t)b * capacity * 32, L->h_desc + (size_t)b * g.maxKp * 32, (size_t)32 * nl);
+            if (keysR) memcpy(keysR + (size_t)b * capacity, R->h_keys + (size_t)b * g.maxKp, kp * nr);
+            if (descR) memcpy(descR + (size_t)b * capacity * 32, R->h_desc + (size_t)b * g.maxKp * 32, (size_t)32 * nr);
+            if (uright) memcpy(uright + (size_t)b * capacity, fe->h_uright + (size_t)b * g.maxKp, 4 * (size_t)nl);
+            if (depth) memcpy(depth + (size_t)b * capacity, fe->h_depth + (size_t)b * g.maxKp, 4 * (size_t)nl);
         }
-        if (keysL) memcpy(keysL + (size_t)b * capacity, L->h_keys + (size_t)b * g.maxKp, kp * nl);
-        if (descL) memcpy(descL + (size_t)b * capacity * 32, L->h_desc + (size_t)b * g.maxKp * 32, (size_t)32 * nl);
-        if (keysR) memcpy(keysR + (size_t)b * capacity, R->h_keys + (size_t)b * g.maxKp, kp * nr);
-        if (descR) memcpy(descR + (size_t)b * capacity * 32, R->h_desc + (size_t)b * g.maxKp * 32, (size_t)32 * nr);
-        if (uright) memcpy(uright + (size_t)b * capacity, fe->h_uright + (size_t)b * g.maxKp, 4 * (size_t)nl);
-        if (depth) memcpy(depth + (size_t)b * capacity, fe->h_depth + (size_t)b * g.maxKp, 4 * (size_t)nl);
         if (nL) nL[b] = nl;
         if (nR) nR[b] = nr;
         if (n_matches) n_matches[b] = fe->h_nMatches[b];

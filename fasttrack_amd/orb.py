@@ -29,6 +29,9 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in getattr(self, "_pinned", []):
+                lib().ft_host_free(self._h, p)
+            self._pinned = []
             lib().ft_context_destroy(self._h)
             self._h = None
 
@@ -65,6 +68,19 @@ class Context:
 
     def save_stats(self, path: str):
         check(lib().ft_context_save_stats(self._h, path.encode()))
+
+    def pinned_array(self, shape, dtype) -> np.ndarray:
+        """numpy array in pinned host memory (ft_host_malloc): device copies land in it directly.
+        The memory lives as long as the context."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        check(lib().ft_host_malloc(self._h, max(n, 1), C.byref(p)))
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        arr[...] = np.zeros((), dtype)
+        self._pinned = getattr(self, "_pinned", []) + [p]
+        return arr
 
     # frames resident in HBM
     def to_device(self, arr: np.ndarray) -> "DeviceBuffer":
@@ -350,7 +366,7 @@ class StereoFrontend:
     """Fused extract(left) + extract(right) + ComputeStereoMatches for batches of rectified pairs."""
 
     def __init__(self, ctx: Context, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, width, height,
-                 max_batch, mbf, mb):
+                 max_batch, mbf, mb, pinned_outputs=True):
         self.ctx = ctx
         self._h = C.c_void_p()
         check(lib().ft_stereo_frontend_create(ctx._h, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast,
@@ -361,14 +377,15 @@ class StereoFrontend:
         self.right = ORBextractor(*args, _handle=lib().ft_stereo_frontend_right(self._h))
         self.capacity = self.left.max_keypoints
         B, cap = max_batch, self.capacity
-        self._kL = np.zeros((B, cap), KP_DTYPE)
-        self._kR = np.zeros((B, cap), KP_DTYPE)
-        self._dL = np.zeros((B, cap, 32), np.uint8)
-        self._dR = np.zeros((B, cap, 32), np.uint8)
+        alloc = ctx.pinned_array if pinned_outputs else (lambda shape, dt: np.zeros(shape, dt))
+        self._kL = alloc((B, cap), KP_DTYPE)
+        self._kR = alloc((B, cap), KP_DTYPE)
+        self._dL = alloc((B, cap, 32), np.uint8)
+        self._dR = alloc((B, cap, 32), np.uint8)
         self._nL = np.zeros(B, np.int32)
         self._nR = np.zeros(B, np.int32)
-        self._ur = np.zeros((B, cap), np.float32)
-        self._dp = np.zeros((B, cap), np.float32)
+        self._ur = alloc((B, cap), np.float32)
+        self._dp = alloc((B, cap), np.float32)
         self._nm = np.zeros(B, np.int32)
 
     def close(self):

@@ -54,7 +54,8 @@ typedef struct ft_context ft_context;
 FT_API const char *ft_version(void);
 FT_API const char *ft_last_error(void);
 FT_API int ft_device_count(void); /* number of HIP devices, 0 if none (never fails) */
-/* host_threads: workers for the host-side octree stage (0 = hardware_concurrency) */
+/* host_threads: workers for the host-side octree stage (0 = the CPUs this process may use:
+ * hardware threads capped by affinity and by a cgroup CPU quota) */
 FT_API int ft_context_create(int device, int host_threads, ft_context **out);
 FT_API int ft_context_destroy(ft_context *ctx);
 FT_API int ft_context_synchronize(ft_context *ctx);
@@ -70,6 +71,9 @@ FT_API int ft_context_reset_stats(ft_context *ctx);
 /* device memory helpers so that a caller (or bench.py) can keep frames resident in HBM */
 FT_API int ft_device_malloc(ft_context *ctx, size_t bytes, void **dptr);
 FT_API int ft_device_free(ft_context *ctx, void *dptr);
+/* pinned host memory: result arrays allocated here are filled by the device copies directly */
+FT_API int ft_host_malloc(ft_context *ctx, size_t bytes, void **ptr);
+FT_API int ft_host_free(ft_context *ctx, void *ptr);
 FT_API int ft_memcpy_h2d(ft_context *ctx, void *dst, const void *src, size_t bytes);
 FT_API int ft_memcpy_d2h(ft_context *ctx, void *dst, const void *src, size_t bytes);
 

@@ -75,12 +75,14 @@ def test_stereo_edge_cases(ctx):
     assert np.isclose(o["uright"][o["depth"] > 0], fr["kL"]["x"][o["depth"] > 0], atol=1.0).all()
 
 
-@pytest.mark.parametrize("w,h,nf,B", [(752, 480, 1200, 3), (1280, 720, 2000, 2)])
+@pytest.mark.parametrize("w,h,nf,B", [(752, 480, 1200, 3), (1280, 720, 2000, 2), (640, 480, 1000, 9)])
 def test_stereo_frontend_fused(ctx, w, h, nf, B):
     intr = synth.intrinsics(w, h)
     fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
+    fe_pageable = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"], pinned_outputs=False)
     pairs = [synth.make_stereo_pair(w, h, 40 + b) for b in range(B)]
     outs = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
+    outs_pg = fe_pageable.process([p[0] for p in pairs], [p[1] for p in pairs])
     devL = [ctx.to_device(p[0]) for p in pairs]
     devR = [ctx.to_device(p[1]) for p in pairs]
     outs_dev = fe.process(devL, devR, on_device=True, stride=w)
@@ -89,7 +91,7 @@ def test_stereo_frontend_fused(ctx, w, h, nf, B):
         kL, dL, _ = oL.extract(pairs[b][0])
         kR, dR, _ = oR.extract(pairs[b][1])
         o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
-        for out in (outs[b], outs_dev[b]):
+        for out in (outs[b], outs_dev[b], outs_pg[b]):
             assert np.array_equal(out["keysL"], kL) and np.array_equal(out["keysR"], kR)
             assert np.array_equal(out["descL"], dL) and np.array_equal(out["descR"], dR)
             assert out["n"] == o["n"]
