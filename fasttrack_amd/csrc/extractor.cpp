@@ -186,11 +186,14 @@ void freeAll(ft_extractor *ex) {
 // sub-batch overlaps with the kernels of the next (stage A on ex->stream, stage B on ex->streamB).
 // ------------------------------------------------------------------------------------------------
 int ft_pipeline_depth(int batch) {
+    // sub-batches of ~16 images keep every launch large enough to fill the 256 CUs while the host octree
+    // of one sub-batch hides behind the kernels of the next; FT_PIPELINE_DEPTH overrides (1 = no pipelining)
     static const int envDepth = [] {
         const char *e = getenv("FT_PIPELINE_DEPTH");
-        return e ? std::max(1, std::min(FT_PIPE_MAX, atoi(e))) : 2;
+        return e ? std::max(1, std::min(FT_PIPE_MAX, atoi(e))) : 0;
     }();
-    return std::max(1, std::min(envDepth, batch / 4 > 0 ? batch / 4 : 1));
+    if (envDepth) return std::max(1, std::min(envDepth, batch));
+    return std::max(1, std::min(FT_PIPE_MAX, batch / 16));
 }
 
 int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,

@@ -15,6 +15,11 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 // GaussianBlur(7x7, sigma 2) fixed-point taps {18,34,48,56,48,34,18} (error-diffused, sum 256) are literals in k_orient_desc
 
 
+// i / d for small operands with a precomputed magic = floor(2^32 / d) + 1 (exact for i < 2^32 / d);
+// d == 1 makes the magic wrap to 0, so it is special-cased.
+__device__ __forceinline__ unsigned div_magic_of(unsigned d) { return d > 1 ? 0xffffffffu / d + 1u : 0u; }
+__device__ __forceinline__ int div_by(int i, unsigned magic) { return magic ? (int)__umulhi((unsigned)i, magic) : i; }
+
 __device__ __forceinline__ const uint8_t *level_ptr(const FtGeom &g, int level, int slot, const uint8_t *const *l0,
                                                     int l0pitch, const uint8_t *pyr, int &pitch) {
     if (level == 0) {
@@ -61,15 +66,17 @@ __global__ __launch_bounds__(256) void k_pyr_down(FtGeom g, int level, const uin
         const int nd = (sxb - sxa + 1 + ax + 3) >> 2;  // dwords per row; may read <= 3 bytes past sxb, still inside the pitch
         const uint8_t *src = S + (size_t)sya * spitch + (sxa - ax);
         const int ndl = ldsPitch >> 2;
+        const unsigned ndMagic = div_magic_of((unsigned)nd);
         for (int i = tid; i < nd * rows; i += 256) {
-            const int y = i / nd, x = i - y * nd;
+            const int y = div_by(i, ndMagic), x = i - y * nd;
             ((unsigned *)smem)[y * ndl + x] = *(const unsigned *)(src + (size_t)y * spitch + 4 * x);
         }
     } else {
         const int cw = sxb - sxa + 1;
+        const unsigned cwMagic = div_magic_of((unsigned)cw);
         const uint8_t *src = S + (size_t)sya * spitch + sxa;
         for (int i = tid; i < cw * rows; i += 256) {
-            const int y = i / cw, x = i - y * cw;
+            const int y = div_by(i, cwMagic), x = i - y * cw;
             smem[y * ldsPitch + x] = src[(size_t)y * spitch + x];
         }
     }
@@ -150,15 +157,22 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// One WAVE per (cell, image): no workgroup barrier anywhere, so the 24+ cells resident on a CU hide
-// each other's load and LDS latency.  TP = LDS pitch of the tile and of the score plane; TP > 0 makes
-// every ring / neighbour offset an instruction immediate, TP == 0 is the any-size fallback.
-// LDS carve (bytes): tile th*tp | score (ph+2)*tp | candidate list 2*npx ; the survivor flags reuse the
-// tile once the scores are final.
+// One WAVE per (cell, image): no workgroup barrier anywhere, so the ~29 cells resident on a CU hide
+// each other's load and LDS latency (the kernel is occupancy bound: LDS per wave is kept near 5.5 KB).
+// TP = LDS pitch of the tile and of the score plane; TP > 0 makes every ring / neighbour offset an
+// instruction immediate, TP == 0 is the any-size fallback.
+// LDS carve (bytes): tile th*tp | score (ph+2)*tp | candidate ring FC_CAND u16 | corner list FC_CORN u16 ;
+// the survivor flags reuse the tile once the scores are final.
+#define FC_CAND 512   // candidates buffered between the rejection test and the score pass
+#define FC_CORN 256   // corners kept for NMS / emission; a cell with more falls back to scanning the plane
 __host__ __device__ __forceinline__ int fc_pitch(int wCell, int TP) { return TP ? TP : ((wCell + 12) & ~3); }
-__host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int TP) { return (((hCell + 6) * fc_pitch(wCell, TP)) + 15) & ~15; }
+__host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int TP) {
+    // the flags of the slow path need one byte per tested pixel
+    const int t = (hCell + 6) * fc_pitch(wCell, TP), f = wCell * hCell;
+    return ((t > f ? t : f) + 15) & ~15;
+}
 __host__ __device__ __forceinline__ int fc_score_bytes(int wCell, int hCell, int TP) { return (((hCell + 2) * fc_pitch(wCell, TP)) + 15) & ~15; }
-__host__ __device__ __forceinline__ int fc_list_bytes(int wCell, int hCell) { return ((2 * wCell * hCell) + 15) & ~15; }
+__host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + FC_CORN); }
 
 template <int TP>
 __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
@@ -184,10 +198,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     const int pw = tw - 6, ph = th - 6;  // tested region
     const int npx = pw * ph;
     const int tp = TP ? TP : fc_pitch(L.wCell, 0);
-    const unsigned pwMagic = 0xffffffffu / (unsigned)pw + 1u;  // i / pw == umulhi(i, magic) for i < 2^32 / pw
+    const unsigned pwMagic = div_magic_of((unsigned)pw);
     uint8_t *tile = smem;
     uint8_t *score = tile + fc_tile_bytes(L.wCell, L.hCell, TP);
-    unsigned short *list = (unsigned short *)(score + fc_score_bytes(L.wCell, L.hCell, TP));
+    unsigned short *cand = (unsigned short *)(score + fc_score_bytes(L.wCell, L.hCell, TP));
+    unsigned short *corn = cand + FC_CAND;
     uint8_t *surv = tile;
     int pitch;
     const uint8_t *img = level_ptr(g, level, slot, l0, l0pitch, pyr, pitch);
@@ -196,32 +211,34 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     if (alignedLoads) {
         ax = iniX & 3;
         const int nd = (tw + ax + 3) >> 2;
-        const unsigned ndMagic = 0xffffffffu / (unsigned)nd + 1u;
+        const unsigned ndMagic = div_magic_of((unsigned)nd);
         const uint8_t *src = img + (size_t)iniY * pitch + (iniX - ax);
         for (int i = lane; i < nd * th; i += 64) {
-            const int y = (int)__umulhi((unsigned)i, ndMagic), x = i - y * nd;
+            const int y = div_by(i, ndMagic), x = i - y * nd;
             *(unsigned *)(tile + y * tp + 4 * x) = *(const unsigned *)(src + (size_t)y * pitch + 4 * x);
         }
     } else {
-        const unsigned twMagic = 0xffffffffu / (unsigned)tw + 1u;
+        const unsigned twMagic = div_magic_of((unsigned)tw);
         const uint8_t *src = img + (size_t)iniY * pitch + iniX;
         for (int i = lane; i < tw * th; i += 64) {
-            const int y = (int)__umulhi((unsigned)i, twMagic), x = i - y * tw;
+            const int y = div_by(i, twMagic), x = i - y * tw;
             tile[y * tp + x] = src[(size_t)y * pitch + x];
         }
     }
     for (int i = lane; i < (tp * (ph + 2)) >> 2; i += 64) ((unsigned *)score)[i] = 0;
     wave_lds_sync();
     const uint8_t *t0 = tile + ax;  // pixel (x, y) of the cell sub-image at t0[y * tp + x]
-    // ---- phase A: high-speed rejection (OpenCV's opposite-pair test without the polarity): a 9-arc
-    // contains one pixel of every opposite pair, so min over the four even pairs of max(|d_k|, |d_k+8|)
-    // must exceed the threshold.  Survivors are appended, in row-major order, to the candidate list.
-    int nc = 0;
+    // ---- phase A / B rounds.  A: high-speed rejection (OpenCV's opposite-pair test without the
+    // polarity): a 9-arc contains one pixel of every opposite pair, so min over the four even pairs of
+    // max(|d_k|, |d_k+8|) must exceed the threshold; survivors are appended in row-major order to the
+    // candidate ring.  B (whenever the ring fills, and at the end): score = largest threshold at which
+    // the pixel is still a corner (cornerScore<16>); corner at minThFAST <=> score >= minThFAST.
+    int nc = 0, ncorn = 0;
     for (int base = 0; base < npx; base += 64) {
         const int i = base + lane;
         bool pass = false;
         if (i < npx) {
-            const int y = (int)__umulhi((unsigned)i, pwMagic), x = i - y * pw;
+            const int y = div_by(i, pwMagic), x = i - y * pw;
             const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
             const unsigned v = cpx[0];
 #define FT_AD(ox, oy) __builtin_amdgcn_sad_u8(v, (unsigned)cpx[(oy)*tp + (ox)], 0u)
@@ -233,56 +250,74 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             pass = min(min(m0, m1), min(m2, m3)) > (unsigned)minTh;
         }
         const unsigned long long b = __ballot(pass);
-        if (pass) list[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)i;
+        if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)i;
         nc += __popcll(b);
-    }
-    wave_lds_sync();
-    // ---- phase B: score = largest threshold at which the pixel is still a corner (cornerScore<16>);
-    // corner at minThFAST <=> score >= minThFAST, so no separate mask test is needed ----
-    for (int j = lane; j < nc; j += 64) {
-        const int i = list[j];
-        const int y = (int)__umulhi((unsigned)i, pwMagic), x = i - y * pw;
-        const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
-        const int v = cpx[0];
-        int d[16];
+        if (nc > FC_CAND - 64 || base + 64 >= npx) {  // wave-uniform
+            wave_lds_sync();
+            for (int jb = 0; jb < nc; jb += 64) {
+                const int j = jb + lane;
+                bool isCorner = false;
+                int ci2 = 0;
+                if (j < nc) {
+                    ci2 = cand[j];
+                    const int y = div_by(ci2, pwMagic), x = ci2 - y * pw;
+                    const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
+                    const int v = cpx[0];
+                    int d[16];
 #define FT_LD(k, ox, oy) d[k] = v - (int)cpx[(oy)*tp + (ox)];
-        FT_RING(FT_LD)
+                    FT_RING(FT_LD)
 #undef FT_LD
-        const int sc = fast_score(d);
-        if (sc >= minTh) score[(y + 1) * tp + (x + 1)] = (uint8_t)sc;
+                    const int sc = fast_score(d);
+                    if (sc >= minTh) {
+                        score[(y + 1) * tp + (x + 1)] = (uint8_t)sc;
+                        isCorner = true;
+                    }
+                }
+                const unsigned long long cb = __ballot(isCorner);
+                if (isCorner) {
+                    const int pos = ncorn + __popcll(cb & ((1ull << lane) - 1ull));
+                    if (pos < FC_CORN) corn[pos] = (unsigned short)ci2;
+                }
+                ncorn += __popcll(cb);
+            }
+            nc = 0;
+            wave_lds_sync();
+        }
     }
     wave_lds_sync();
-    // ---- NMS over the candidates: strictly greater than the 8 neighbours (cv::FAST); the flags reuse
-    // the tile (no longer read) ----
+    // ---- NMS (strictly greater than the 8 neighbours, cv::FAST), cell-level threshold fallback
+    // (ORBextractor.cc:1157-1177: if any survivor reaches iniThFAST only those are emitted, otherwise every
+    // minThFAST survivor is) and ordered emission.  The corner list is in row-major order; a cell with more
+    // than FC_CORN corners scans the score plane instead (same order).
+    const bool useList = ncorn <= FC_CORN;
+    const int nItems = useList ? ncorn : npx;
+    auto nms = [&](int item, int &pix) -> int {
+        pix = useList ? (int)corn[item] : item;
+        const int y = div_by(pix, pwMagic), x = pix - y * pw;
+        const uint8_t *s = score + (y + 1) * tp + (x + 1);
+        const int v = s[0];
+        const bool keep = v > 0 && v > s[-1] && v > s[1] && v > s[-tp - 1] && v > s[-tp] && v > s[-tp + 1] &&
+                          v > s[tp - 1] && v > s[tp] && v > s[tp + 1];
+        return keep ? (v >= iniTh ? 2 : 1) : 0;
+    };
     int anyHi = 0;
-    for (int base = 0; base < nc; base += 64) {
-        const int j = base + lane;
-        int fl = 0;
-        if (j < nc) {
-            const int i = list[j];
-            const int y = (int)__umulhi((unsigned)i, pwMagic), x = i - y * pw;
-            const uint8_t *s = score + (y + 1) * tp + (x + 1);
-            const int v = s[0];
-            const bool keep = v > 0 && v > s[-1] && v > s[1] && v > s[-tp - 1] && v > s[-tp] && v > s[-tp + 1] &&
-                              v > s[tp - 1] && v > s[tp] && v > s[tp + 1];
-            fl = keep ? (v >= iniTh ? 2 : 1) : 0;
-            surv[j] = (uint8_t)fl;
-        }
+    for (int base = 0; base < nItems; base += 64) {
+        const int it = base + lane;
+        int fl = 0, pix;
+        if (it < nItems) fl = nms(it, pix);
         anyHi |= __any(fl == 2);
     }
-    wave_lds_sync();
-    // cell-level threshold fallback (ORBextractor.cc:1157-1177): if any survivor reaches iniThFAST only
-    // those are emitted, otherwise every minThFAST survivor is.  Emission keeps the list (row-major) order.
     const int need = anyHi ? 2 : 1;
     uint32_t *out = stage + (size_t)slot * g.stagePerSlot + L.stageBase + (size_t)c * L.cellCap;
     int run = 0;
-    for (int base = 0; base < nc; base += 64) {
-        const int j = base + lane;
-        const bool f = j < nc && surv[j] >= need;
+    for (int base = 0; base < nItems; base += 64) {
+        const int it = base + lane;
+        int fl = 0, pix = 0;
+        if (it < nItems) fl = nms(it, pix);
+        const bool f = fl >= need;
         const unsigned long long b = __ballot(f);
         if (f) {
-            const int i = list[j];
-            const int y = (int)__umulhi((unsigned)i, pwMagic), x = i - y * pw;
+            const int y = div_by(pix, pwMagic), x = pix - y * pw;
             const int pos = run + __popcll(b & ((1ull << lane) - 1ull));
             // keypoint (x+3, y+3) in the cell sub-image, shifted by (j*wCell, i*hCell): ORBextractor.cc:1196-1197
             if (pos < L.cellCap)
@@ -290,6 +325,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         }
         run += __popcll(b);
     }
+    (void)surv;
     if (lane == 0) *cnt = min(run, L.cellCap);
 }
 
@@ -528,10 +564,11 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
 }  // namespace
 
 static int fast_tile_pitch(const FtGeom &g) {
-    // 64-byte LDS pitch (all ring offsets immediates) when every level's cell fits: wCell + 6 + 3 <= 64
+    // fixed LDS pitch (all ring offsets immediates) when every level's cell fits: wCell + 6 + 3 <= TP
+    int need = 0;
     for (int l = 0; l < g.nlevels; l++)
-        if (g.lv[l].nCols * g.lv[l].nRows > 0 && g.lv[l].wCell + 9 > 64) return 0;
-    return 64;
+        if (g.lv[l].nCols * g.lv[l].nRows > 0) need = std::max(need, g.lv[l].wCell + 9);
+    return need <= 48 ? 48 : (need <= 64 ? 64 : 0);
 }
 
 size_t ft_fast_smem_bytes(const FtGeom &g) {
@@ -540,7 +577,7 @@ size_t ft_fast_smem_bytes(const FtGeom &g) {
     for (int l = 0; l < g.nlevels; l++) {
         const FtLevelGeom &L = g.lv[l];
         mx = std::max(mx, (size_t)fc_tile_bytes(L.wCell, L.hCell, TP) + fc_score_bytes(L.wCell, L.hCell, TP) +
-                              fc_list_bytes(L.wCell, L.hCell));
+                              fc_list_bytes());
     }
     return mx;
 }
@@ -563,9 +600,14 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
                          uint32_t *stage) {
+    if (g.totalCells == 0) return FT_OK;  // every level is too small for a 35-px cell: no candidates
     dim3 grid(g.totalCells, batch, 1), block(64, 1, 1);
     const size_t smem = ft_fast_smem_bytes(g);
-    if (fast_tile_pitch(g) == 64)
+    const int TP = fast_tile_pitch(g);
+    if (TP == 48)
+        hipLaunchKernelGGL(k_fast_cells<48>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
+                           cellCount, stage);
+    else if (TP == 64)
         hipLaunchKernelGGL(k_fast_cells<64>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
                            cellCount, stage);
     else

@@ -107,13 +107,16 @@ def test_edge_images(ctx):
 
 
 def test_small_and_odd_sizes(ctx):
-    for (w, h, nf, levels) in [(97, 83, 200, 3), (160, 120, 300, 4), (333, 257, 500, 8), (1000, 96, 400, 2)]:
+    for (w, h, nf, levels) in [(97, 83, 200, 3), (160, 120, 300, 4), (333, 257, 500, 8), (1000, 96, 400, 2),
+                               (1919, 1079, 1500, 8), (64, 400, 100, 1)]:
         img = synth.make_image(w, h, seed=w)
         ex = orb.ORBextractor(ctx, nf, 1.2, levels, 20, 7, w, h)
         oex = ob.Extractor(nf, 1.2, levels)
         gk, gd, gm = ex(img)
         ok, od, om = oex.extract(img)
         _check_same(gk, gd, ok, od)
+        for level in range(levels):
+            assert np.array_equal(ex.image_pyramid_level(level), oex.level(level)), (w, h, level)
 
 
 def test_other_parameters(ctx):
