@@ -175,7 +175,7 @@ def main():
         ms, launches = ctx.get_stat("kernel.fast_cells")
         kern = {}
         for name in ("kernel.pyr_down(all levels)", "kernel.fast_cells", "kernel.compact", "kernel.orient_desc",
-                     "kernel.stereo_match", "kernel.stereo_median"):
+                     "kernel.stereo_rowsort", "kernel.stereo_match", "kernel.stereo_median"):
             m, n = ctx.get_stat(name)
             kern[name] = {"ms_per_launch": (m / n) if n else None, "launches": n}
         host = {}

@@ -135,6 +135,7 @@ struct ft_stereo_frontend {
     int capacity = 0;
     float *d_uright = nullptr, *d_depth = nullptr, *h_uright = nullptr, *h_depth = nullptr;
     int *d_sad = nullptr, *d_nMatches = nullptr, *h_nMatches = nullptr;
+    int *d_order = nullptr, *d_rowStart = nullptr;  // right keypoints bucketed by row (k_stereo_rowsort)
     hipEvent_t evR = nullptr;
 };
 

@@ -98,11 +98,15 @@ struct FtStereoArgs {
     int *hamIdx;                       // device [batch*capacity] (debug tap, may be null)
     int *nMatches;                     // device [batch]
     int applyMedianCut;
+    int *rowStart;                     // device [batch * rowStride]: right keypoints bucketed by (int)y
+    int *order;                        // device [batch * capacity]: right keypoint indices in bucket order
+    int rowStride;                     // >= level-0 height + 2
 };
 int ft_launch_stereo_match(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
                            const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
                            const uint8_t *pyrR, const FtStereoArgs &a);
 int ft_launch_stereo_median(hipStream_t st, int batch, const FtStereoArgs &a);
+int ft_launch_stereo_rowsort(hipStream_t st, const FtGeom &g, int batch, const FtStereoArgs &a);
 int ft_launch_fisheye(hipStream_t st, const uint8_t *descL, int nL, const uint8_t *descR, int nR, int *matches,
                       int *best, int *second);
 int ft_launch_hamming_pairs(hipStream_t st, const uint8_t *a, const uint8_t *b, int n, int *dist);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = blockIdx.y;
     const int iL = blockIdx.x * 4 + wave;
-    const int nL = a.nL[slot], nR = a.nR[slot];
+    const int nL = a.nL[slot];
     if (iL >= nL) return;
     const size_t base = (size_t)slot * a.capacity;
     float outU = -1.0f, outD = -1.0f;
@@ -63,7 +63,16 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
     }
     unsigned best = 0xffffffffu;  // (dist << 16) | iR
     if (row >= 0 && row < nRows && !(maxU < 0)) {
-        for (int iR = lane; iR < nR; iR += 64) {
+        // right keypoints are bucketed by (int)y (k_stereo_rowsort); the band of keypoint iR covers `row` only
+        // if |y_R - row| < r + 1 with r = 2 * sf[octave] <= 2 * max scale factor, so scanning the buckets
+        // [row - reach, row + reach] sees every candidate of the reference's vRowIndices[row]; the exact band,
+        // octave and disparity tests are applied to each of them.
+        const int reach = (int)ceilf(2.0f * g.sf[g.nlevels - 1]) + 1;
+        const int *rs = a.rowStart + (size_t)slot * a.rowStride;
+        const int t0 = rs[max(row - reach, 0)], t1 = rs[min(row + reach + 1, nRows)];
+        const int *ord = a.order + base;
+        for (int t = t0 + lane; t < t1; t += 64) {
+            const int iR = ord[t];
             const ft_keypoint kpR = a.keysR[base + iR];
             // row band of the right keypoint (Frame.cc:852-862): rows floor(y-r) .. ceil(y+r), r = 2*sf[octave]
             const float r = __fmul_rn(2.0f, g.sf[kpR.octave]);
@@ -155,6 +164,55 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
         a.depth[base + iL] = outD;
         a.sad[base + iL] = outSad;
         if (a.hamIdx) a.hamIdx[base + iL] = outHam;
+    }
+}
+
+// Counting sort of the right keypoints of one pair by (int)y: rowStart[r] .. rowStart[r+1] index `order`.
+// Keypoints outside [0, H) (cannot come from the extractor) are dropped, as the reference's unchecked
+// vRowIndices access would be out of bounds for them.
+__global__ __launch_bounds__(256) void k_stereo_rowsort(FtGeom g, FtStereoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int sh[];  // H + 1 counters
+    __shared__ int wsum[4];
+    const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = g.lv[0].h;
+    const int nR = a.nR[slot];
+    const size_t base = (size_t)slot * a.capacity;
+    for (int i = tid; i <= H; i += 256) sh[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nR; i += 256) {
+        const int y = (int)a.keysR[base + i].y;
+        if (y >= 0 && y < H) atomicAdd(&sh[y], 1);
+    }
+    __syncthreads();
+    // exclusive scan of sh[0..H): each thread owns a contiguous chunk
+    const int per = (H + 255) / 256;
+    const int c0 = min(tid * per, H), c1 = min(c0 + per, H);
+    int local = 0;
+    for (int c = c0; c < c1; c++) local += sh[c];
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += wsum[w];
+    int run = wbase + incl - local;
+    int *rs = a.rowStart + (size_t)slot * a.rowStride;
+    for (int c = c0; c < c1; c++) {
+        const int n = sh[c];
+        rs[c] = run;
+        sh[c] = run;  // becomes the scatter cursor
+        run += n;
+    }
+    if (tid == 255) rs[H] = run;  // the last thread's chunk ends at H
+    __syncthreads();
+    int *ord = a.order + base;
+    for (int i = tid; i < nR; i += 256) {
+        const int y = (int)a.keysR[base + i].y;
+        if (y >= 0 && y < H) ord[atomicAdd(&sh[y], 1)] = i;
     }
 }
 
@@ -260,6 +318,12 @@ int ft_launch_stereo_match(hipStream_t st, const FtGeom &g, int batch, const uin
                            const uint8_t *pyrR, const FtStereoArgs &a) {
     dim3 grid((a.capacity + 3) / 4, batch, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_stereo_match, grid, block, 0, st, g, l0L, l0R, l0pitchL, l0pitchR, pyrL, pyrR, a);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_stereo_rowsort(hipStream_t st, const FtGeom &g, int batch, const FtStereoArgs &a) {
+    hipLaunchKernelGGL(k_stereo_rowsort, dim3(batch), dim3(256), (size_t)(g.lv[0].h + 1) * sizeof(int), st, g, a);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

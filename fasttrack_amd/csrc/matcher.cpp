@@ -53,7 +53,7 @@ int ft_stereo_match(ft_extractor *exL, ft_extractor *exR, int slot, const ft_key
         FT_HIP(hipMalloc((void **)&exL->d_stKeys, sizeof(ft_keypoint) * 2 * need));
         FT_HIP(hipMalloc((void **)&exL->d_stDesc, (size_t)64 * need));
         FT_HIP(hipMalloc((void **)&exL->d_stOut, sizeof(float) * 2 * need));
-        FT_HIP(hipMalloc((void **)&exL->d_stInt, sizeof(int) * (2 * need + 4)));
+        FT_HIP(hipMalloc((void **)&exL->d_stInt, sizeof(int) * (3 * (size_t)need + 8 + exL->height + 2)));
         exL->stCap = need;
     }
     const int C = exL->stCap;
@@ -86,6 +86,11 @@ int ft_stereo_match(ft_extractor *exL, ft_extractor *exR, int slot, const ft_key
     a.hamIdx = exL->d_stInt + C;
     a.nMatches = d_hdr + 2;
     a.applyMedianCut = apply_median_cut;
+    a.order = exL->d_stInt + 2 * C + 4;
+    a.rowStart = a.order + C;
+    a.rowStride = exL->height + 2;
+    rc = ft_launch_stereo_rowsort(st, g, 1, a);
+    if (rc != FT_OK) return rc;
     rc = ft_launch_stereo_match(st, g, 1, exL->d_l0 + slot, exR->d_l0 + slot, exL->l0pitch, exR->l0pitch,
                                 exL->d_pyr + (size_t)slot * g.pyrPerSlot, exR->d_pyr + (size_t)slot * g.pyrPerSlot, a);
     if (rc != FT_OK) return rc;
@@ -126,6 +131,8 @@ int ft_stereo_frontend_create(ft_context *ctx, int nfeatures, float scale_factor
     if (e == hipSuccess) e = hipMalloc((void **)&fe->d_depth, sizeof(float) * n);
     if (e == hipSuccess) e = hipMalloc((void **)&fe->d_sad, sizeof(int) * n);
     if (e == hipSuccess) e = hipMalloc((void **)&fe->d_nMatches, sizeof(int) * max_batch);
+    if (e == hipSuccess) e = hipMalloc((void **)&fe->d_order, sizeof(int) * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&fe->d_rowStart, sizeof(int) * (size_t)max_batch * (image_height + 2));
     if (e == hipSuccess) e = hipHostMalloc((void **)&fe->h_uright, sizeof(float) * n, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&fe->h_depth, sizeof(float) * n, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&fe->h_nMatches, sizeof(int) * max_batch, hipHostMallocDefault);
@@ -147,6 +154,8 @@ int ft_stereo_frontend_destroy(ft_stereo_frontend *fe) {
     hipFree(fe->d_depth);
     hipFree(fe->d_sad);
     hipFree(fe->d_nMatches);
+    hipFree(fe->d_order);
+    hipFree(fe->d_rowStart);
     hipHostFree(fe->h_uright);
     hipHostFree(fe->h_depth);
     hipHostFree(fe->h_nMatches);
@@ -247,6 +256,13 @@ int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *ima
         a.hamIdx = nullptr;
         a.nMatches = fe->d_nMatches + b0;
         a.applyMedianCut = 1;
+        a.rowStride = L->height + 2;
+        a.rowStart = fe->d_rowStart + (size_t)b0 * a.rowStride;
+        a.order = fe->d_order + o;
+        L->evt.begin(tm, "kernel.stereo_rowsort", st);
+        rc = ft_launch_stereo_rowsort(st, g, nb, a);
+        L->evt.end(tm, st);
+        if (rc != FT_OK) return rc;
         L->evt.begin(tm, "kernel.stereo_match", st);
         rc = ft_launch_stereo_match(st, g, nb, L->d_l0 + b0, R->d_l0 + b0, L->l0pitch, R->l0pitch,
                                     L->d_pyr + (size_t)b0 * g.pyrPerSlot, R->d_pyr + (size_t)b0 * g.pyrPerSlot, a);
