@@ -4,6 +4,7 @@
 // touched by the HIP kernels in kernels_extract.hip.  Compiled with -ffp-contract=off.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 

@@ -393,9 +393,9 @@ __global__ __launch_bounds__(256) void k_compact(FtGeom g, const int *cellCount,
 #define OD_R 21                 // patch radius: 18 (max rotated pattern offset) + 3 (blur)
 #define OD_P (2 * OD_R + 1)     // 43
 #define OD_PP 48                // raw pitch: 12 dwords cover the 43 bytes at any 4-byte phase
-#define OD_B 37                 // blurred window
+#define OD_HP 40                // pitch (u16) of the horizontally blurred rows: raw byte positions 0..39
 #define OD_RAW_BYTES (OD_P * OD_PP)                  // 2064
-#define OD_HB_BYTES (OD_P * OD_B * 2)                // 3182
+#define OD_HB_BYTES (OD_P * OD_HP * 2)               // 3440
 #define OD_WAVE_BYTES ((OD_RAW_BYTES + OD_HB_BYTES + 15) & ~15)
 #define OD_WAVES 4
 
@@ -438,7 +438,6 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     if (k >= nSel[slot]) return;  // waves are independent: no workgroup barrier below
     uint8_t *raw = smem + (size_t)wave * OD_WAVE_BYTES;
     unsigned short *hb = (unsigned short *)(raw + OD_RAW_BYTES);
-    uint8_t *bl = raw;  // the blurred window overwrites the raw patch once it is no longer needed
     const FtSelKp s = sel[(size_t)slot * g.maxKp + k];
     const int cx = s.x, cy = s.y, level = s.level, response = s.response;
     int pitch;
@@ -488,36 +487,28 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
         }
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // horizontal 7-tap pass, sliding window: a task = (row, run of <= 10 outputs) reads <= 16 bytes once
-    for (int t = lane; t < OD_P * 4; t += 64) {
-        const int r = t >> 2, sgm = t & 3;
-        const int c0 = sgm * 10, n = sgm == 3 ? 7 : 10;
-        const uint8_t *p = rp + r * OD_PP + c0;
-        unsigned v[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) v[j] = (j < n + 6) ? p[j] : 0;
-        unsigned short *o = hb + r * OD_B + c0;
-#pragma unroll
-        for (int j = 0; j < 10; j++)
-            if (j < n)
-                o[j] = (unsigned short)(18u * (v[j] + v[j + 6]) + 34u * (v[j + 1] + v[j + 5]) + 48u * (v[j + 2] + v[j + 4]) +
-                                        56u * v[j + 3]);
-    }
-    wave_lds_sync();
-    // vertical pass: a task = (column, run of <= 10 rows); result (v + 2^15) >> 16
-    for (int t = lane; t < OD_B * 4; t += 64) {
-        const int c = t % OD_B, sgm = t / OD_B;
-        const int r0 = sgm * 10, n = sgm == 3 ? 7 : 10;
-        const unsigned short *p = hb + r0 * OD_B + c;
-        unsigned v[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) v[j] = (j < n + 6) ? p[j * OD_B] : 0;
-        uint8_t *o = bl + r0 * OD_B + c;
-#pragma unroll
-        for (int j = 0; j < 10; j++)
-            if (j < n)
-                o[j * OD_B] = (uint8_t)((18u * (v[j] + v[j + 6]) + 34u * (v[j + 1] + v[j + 5]) + 48u * (v[j + 2] + v[j + 4]) +
-                                         56u * v[j + 3] + 32768u) >> 16);
+    // horizontal 7-tap pass on the packed bytes: a task = (row, aligned group of 4 raw byte positions);
+    // two v_dot4_u32_u8 per output on byte windows cut out with v_alignbyte.  hb[r][b] = sum_t k[t] *
+    // raw[r][b + t] for raw byte positions b in [0, 40) (16 bit, <= 255 * 256); output column c of the
+    // blurred window is b = ax + c.
+    {
+        const unsigned K0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K1 = 48u | (34u << 8) | (18u << 16);
+        for (int t = lane; t < OD_P * 10; t += 64) {
+            const int r = t / 10, gq = t - r * 10;
+            const unsigned *rw = (const unsigned *)(raw + r * OD_PP) + gq;
+            const unsigned d0 = rw[0], d1 = rw[1], d2 = rw[2];
+            unsigned h0 = __builtin_amdgcn_udot4(d1, K1, __builtin_amdgcn_udot4(d0, K0, 0u, false), false);
+            unsigned h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1,
+                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false), false);
+            unsigned h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1,
+                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false), false);
+            unsigned h3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1,
+                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
+            uint2 pk;
+            pk.x = h0 | (h1 << 16);
+            pk.y = h2 | (h3 << 16);
+            *(uint2 *)(hb + r * OD_HP + 4 * gq) = pk;
+        }
     }
     wave_lds_sync();
     // computeOrbDescriptor: angle in radians as float, cos/sin in double then narrowed
@@ -526,6 +517,15 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     double sd, cd;
     sincos((double)ar, &sd, &cd);
     const float ca = (float)cd, sb = (float)sd;
+    // vertical 7-tap pass only where the pattern samples (512 of the 1369 window positions): the blurred
+    // pixel at offset (r, c) from the keypoint is (sum_s k[s] * hb[18 + r + s][ax + 18 + c] + 2^15) >> 16
+    const unsigned short *hcol = hb + ax + 18;
+    auto blurred = [&](int r, int c) -> int {
+        const unsigned short *p = hcol + (18 + r) * OD_HP + c;
+        const unsigned v = 18u * ((unsigned)p[0] + p[6 * OD_HP]) + 34u * ((unsigned)p[OD_HP] + p[5 * OD_HP]) +
+                           48u * ((unsigned)p[2 * OD_HP] + p[4 * OD_HP]) + 56u * (unsigned)p[3 * OD_HP];
+        return (int)((v + 32768u) >> 16);
+    };
     unsigned long long words[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -536,9 +536,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
-        const int t0 = bl[(18 + r0) * OD_B + (18 + c0)];
-        const int t1 = bl[(18 + r1) * OD_B + (18 + c1)];
-        words[q] = __ballot(t0 < t1);
+        words[q] = __ballot(blurred(r0, c0) < blurred(r1, c1));
     }
     if (lane == 0) {
         const size_t o = (size_t)slot * g.maxKp + k;
