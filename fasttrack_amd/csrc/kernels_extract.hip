@@ -164,6 +164,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 // LDS carve (bytes): tile th*tp | score (ph+2)*tp | candidate ring FC_CAND u16 | corner list FC_CORN u16 ;
 // the survivor flags reuse the tile once the scores are final.
 #define FC_CAND 512   // candidates buffered between the rejection test and the score pass
+#ifndef FC_UNROLL
+#define FC_UNROLL 2
+#endif
 #define FC_CORN 256   // corners kept for NMS / emission; a cell with more falls back to scanning the plane
 __host__ __device__ __forceinline__ int fc_pitch(int wCell, int TP) { return TP ? TP : ((wCell + 12) & ~3); }
 __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int TP) {
@@ -234,25 +237,43 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     // candidate ring.  B (whenever the ring fills, and at the end): score = largest threshold at which
     // the pixel is still a corner (cornerScore<16>); corner at minThFAST <=> score >= minThFAST.
     int nc = 0, ncorn = 0;
-    for (int base = 0; base < npx; base += 64) {
-        const int i = base + lane;
-        bool pass = false;
-        if (i < npx) {
-            const int y = div_by(i, pwMagic), x = i - y * pw;
-            const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
-            const unsigned v = cpx[0];
 #define FT_AD(ox, oy) __builtin_amdgcn_sad_u8(v, (unsigned)cpx[(oy)*tp + (ox)], 0u)
+    // FC_UNROLL 64-pixel chunks per trip: their LDS reads are independent, which cuts the number of exposed
+    // LDS round trips of this latency-bound loop
+    for (int base = 0; base < npx; base += 64 * FC_UNROLL) {
+        unsigned m01[FC_UNROLL];
+        const uint8_t *cp[FC_UNROLL];
+        unsigned mAny = 0;
+#pragma unroll
+        for (int u = 0; u < FC_UNROLL; u++) {
+            const int i = base + 64 * u + lane;
+            const int ii = min(i, npx - 1);
+            const int y = div_by(ii, pwMagic), x = ii - y * pw;
+            const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
+            cp[u] = cpx;
+            const unsigned v = cpx[0];
             const unsigned m0 = max(FT_AD(0, 3), FT_AD(0, -3));
             const unsigned m1 = max(FT_AD(3, 0), FT_AD(-3, 0));
-            const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
-            const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
-#undef FT_AD
-            pass = min(min(m0, m1), min(m2, m3)) > (unsigned)minTh;
+            m01[u] = i < npx ? min(m0, m1) : 0u;
+            mAny = max(mAny, m01[u]);
         }
-        const unsigned long long b = __ballot(pass);
-        if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)i;
-        nc += __popcll(b);
-        if (nc > FC_CAND - 64 || base + 64 >= npx) {  // wave-uniform
+        // wave-level early out: when the compass pairs already reject every pixel of the trip (flat regions) the two
+        // diagonal pairs are not even read
+        if (__any(mAny > (unsigned)minTh)) {
+#pragma unroll
+            for (int u = 0; u < FC_UNROLL; u++) {
+                const int i = base + 64 * u + lane;
+                const uint8_t *cpx = cp[u];
+                const unsigned v = cpx[0];
+                const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
+                const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
+                const bool pass = min(m01[u], min(m2, m3)) > (unsigned)minTh;
+                const unsigned long long b = __ballot(pass);
+                if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)i;
+                nc += __popcll(b);
+            }
+        }
+        if (nc > FC_CAND - 64 * FC_UNROLL || base + 64 * FC_UNROLL >= npx) {  // wave-uniform
             wave_lds_sync();
             for (int jb = 0; jb < nc; jb += 64) {
                 const int j = jb + lane;
@@ -284,6 +305,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             wave_lds_sync();
         }
     }
+#undef FT_AD
     wave_lds_sync();
     // ---- NMS (strictly greater than the 8 neighbours, cv::FAST), cell-level threshold fallback
     // (ORBextractor.cc:1157-1177: if any survivor reaches iniThFAST only those are emitted, otherwise every
