@@ -164,6 +164,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 // LDS carve (bytes): tile th*tp | score (ph+2)*tp | candidate ring FC_CAND u16 | corner list FC_CORN u16 ;
 // the survivor flags reuse the tile once the scores are final.
 #define FC_CAND 512   // candidates buffered between the rejection test and the score pass
+#ifndef FC_XCD_RUN
+#define FC_XCD_RUN 8
+#endif
 #ifndef FC_UNROLL
 #define FC_UNROLL 2
 #endif
@@ -183,7 +186,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
                                                    uint32_t *stage) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
-    const int slot = blockIdx.y, cell = blockIdx.x;
+    const int slot = blockIdx.y;
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed placement, used for speed only).  Runs of
+    // FC_XCD_RUN consecutive cells are dealt round-robin to the XCDs, so horizontally neighbouring cells,
+    // whose tiles overlap by 6 px and share 64-B lines, hit the same private L2 instead of fetching the
+    // lines once per XCD, while every XCD still gets the same mix of levels.
+    const int j = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+    const int cell = ((j / FC_XCD_RUN) * 8 + xcd) * FC_XCD_RUN + (j % FC_XCD_RUN);
+    if (cell >= g.totalCells) return;
     int level = 0;
     while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cellBase) level++;
     const FtLevelGeom &L = g.lv[level];
@@ -621,7 +631,8 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
                          uint32_t *stage) {
     if (g.totalCells == 0) return FT_OK;  // every level is too small for a 35-px cell: no candidates
-    dim3 grid(g.totalCells, batch, 1), block(64, 1, 1);
+    const int runBlock = 8 * FC_XCD_RUN;  // grid padded to whole rounds of the XCD mapping
+    dim3 grid(((g.totalCells + runBlock - 1) / runBlock) * runBlock, batch, 1), block(64, 1, 1);
     const size_t smem = ft_fast_smem_bytes(g);
     const int TP = fast_tile_pitch(g);
     if (TP == 48)
