@@ -179,7 +179,8 @@ def main():
             m, n = ctx.get_stat(name)
             kern[name] = {"ms_per_launch": (m / n) if n else None, "launches": n}
         host = {}
-        for name in ("stereo.octree(host,both)", "stereo.process.total"):
+        for name in ("stereo.octree(host,both)", "stereo.host_wait_stageA", "stereo.host_launch_stageB",
+                     "stereo.host_tail_sync", "stereo.process.total"):
             m, n = ctx.get_stat(name)
             host[name] = (m / n) if n else None
         # the batch is processed in sub-batches (software pipeline), so bytes per launch = algorithmic

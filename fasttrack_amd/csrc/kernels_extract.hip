@@ -30,19 +30,25 @@ __device__ __forceinline__ const uint8_t *level_ptr(const FtGeom &g, int level, 
     return pyr + (size_t)slot * g.pyrPerSlot + g.lv[level].off;
 }
 
+// LDS hand-off between the lanes of ONE wave: the LDS queue of a wave is served in order, so only the
+// compiler has to be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pyramid: level l from level l-1 (one launch per level; grid.z = image slot)
 // ------------------------------------------------------------------------------------------------
-// Output tile 64 x 16 per workgroup.  The source footprint of the tile (rows sy(first)..sy(last)+1,
-// columns sx(first)..sx(last)+1) is staged in LDS with aligned dword loads; every output then reads its
-// 2x2 taps from LDS.
+// One WAVE per 64 x 8 output tile (no workgroup barrier, like k_fast_cells): the source footprint of the
+// tile (rows sy(first)..sy(last)+1, columns sx(first)..sx(last)+1) is staged in LDS with aligned dword
+// loads, then every lane produces the 8 outputs of its column from 2x2 taps read from LDS.
 #define PD_TW 64
-#define PD_TH 16
-__global__ __launch_bounds__(256) void k_pyr_down(FtGeom g, int level, const uint8_t *const *l0, int l0pitch,
-                                                  uint8_t *pyr, const FtTap *taps, int alignedLoads, int ldsPitch,
-                                                  int ldsRows) {
+#define PD_TH 8
+__global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint8_t *const *l0, int l0pitch,
+                                                 uint8_t *pyr, const FtTap *taps, int alignedLoads, int ldsPitch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const int slot = blockIdx.z;
     const FtLevelGeom &D = g.lv[level];
     const int dx0 = blockIdx.x * PD_TW, dy0 = blockIdx.y * PD_TH;
@@ -63,30 +69,29 @@ __global__ __launch_bounds__(256) void k_pyr_down(FtGeom g, int level, const uin
     int ax = 0;
     if (alignedLoads) {
         ax = sxa & 3;
-        const int nd = (sxb - sxa + 1 + ax + 3) >> 2;  // dwords per row; may read <= 3 bytes past sxb, still inside the pitch
+        const int nd = (sxb - sxa + 1 + ax + 3) >> 2;  // dwords per row; over-read stays inside the aligned row pitch
         const uint8_t *src = S + (size_t)sya * spitch + (sxa - ax);
-        const int ndl = ldsPitch >> 2;
         const unsigned ndMagic = div_magic_of((unsigned)nd);
-        for (int i = tid; i < nd * rows; i += 256) {
+        for (int i = lane; i < nd * rows; i += 64) {
             const int y = div_by(i, ndMagic), x = i - y * nd;
-            ((unsigned *)smem)[y * ndl + x] = *(const unsigned *)(src + (size_t)y * spitch + 4 * x);
+            *(unsigned *)(smem + y * ldsPitch + 4 * x) = *(const unsigned *)(src + (size_t)y * spitch + 4 * x);
         }
     } else {
         const int cw = sxb - sxa + 1;
         const unsigned cwMagic = div_magic_of((unsigned)cw);
         const uint8_t *src = S + (size_t)sya * spitch + sxa;
-        for (int i = tid; i < cw * rows; i += 256) {
+        for (int i = lane; i < cw * rows; i += 64) {
             const int y = div_by(i, cwMagic), x = i - y * cw;
             smem[y * ldsPitch + x] = src[(size_t)y * spitch + x];
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     const uint8_t *T = smem + ax;  // source pixel (sx, sy) at T[(sy - sya) * ldsPitch + (sx - sxa)]
-    const int dx = dx0 + (tid & 63);
+    const int dx = dx0 + lane;
     if (dx > dx1) return;
     uint8_t *outBase = pyr + (size_t)slot * g.pyrPerSlot + D.off + dx;
     if (D.area2x) {
-        for (int dy = dy0 + (tid >> 6); dy <= dy1; dy += 4) {
+        for (int dy = dy0; dy <= dy1; dy++) {
             const uint8_t *r0 = T + (2 * dy - sya) * ldsPitch + (2 * dx - sxa), *r1 = r0 + ldsPitch;
             outBase[(size_t)dy * D.pitch] = (uint8_t)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2);
         }
@@ -94,8 +99,11 @@ __global__ __launch_bounds__(256) void k_pyr_down(FtGeom g, int level, const uin
     }
     const FtTap xt = taps[D.xtab + dx];
     const int cx0 = xt.s - sxa, cx1 = min(xt.s + 1, sw - 1) - sxa;
-    for (int dy = dy0 + (tid >> 6); dy <= dy1; dy += 4) {
-        const FtTap yt = taps[D.ytab + dy];
+#pragma unroll
+    for (int k = 0; k < PD_TH; k++) {
+        const int dy = dy0 + k;
+        if (dy > dy1) break;
+        const FtTap yt = taps[D.ytab + dy];  // wave-uniform
         const int sy0 = min(max((int)yt.s, 0), sh - 1) - sya, sy1 = min(max((int)yt.s + 1, 0), sh - 1) - sya;
         const uint8_t *r0 = T + sy0 * ldsPitch, *r1 = T + sy1 * ldsPitch;
         const int h0 = r0[cx0] * xt.a0 + r0[cx1] * xt.a1;
@@ -148,13 +156,6 @@ __device__ __forceinline__ int fast_score(const int d[16]) {
         worst = min(worst, mx9);
     }
     return max(best, -worst) - 1;
-}
-
-// LDS hand-off between the lanes of ONE wave: the LDS queue of a wave is served in order, so only the
-// compiler has to be kept from moving accesses across this point.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
 }
 
 // One WAVE per (cell, image): no workgroup barrier anywhere, so the ~29 cells resident on a CU hide
@@ -616,12 +617,12 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
                       uint8_t *pyr, const FtTap *taps, int alignedLoads) {
     for (int level = 1; level < g.nlevels; level++) {
         const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
-        // LDS footprint of a 64 x 16 output tile: ceil(tile * scale) + the second tap + alignment slack
+        // LDS footprint of a 64 x 8 output tile: ceil(tile * scale) + the second tap + alignment slack
         const int cols = (int)((long long)PD_TW * P.w / D.w) + 4, rowsN = (int)((long long)PD_TH * P.h / D.h) + 4;
         const int ldsPitch = (cols + 3 + 3) & ~3;
-        dim3 grid((D.w + PD_TW - 1) / PD_TW, (D.h + PD_TH - 1) / PD_TH, batch), block(256, 1, 1);
+        dim3 grid((D.w + PD_TW - 1) / PD_TW, (D.h + PD_TH - 1) / PD_TH, batch), block(64, 1, 1);
         hipLaunchKernelGGL(k_pyr_down, grid, block, (size_t)ldsPitch * rowsN, st, g, level, l0, l0pitch, pyr, taps,
-                           alignedLoads, ldsPitch, rowsN);
+                           alignedLoads, ldsPitch);
     }
     FT_HIP(hipGetLastError());
     return FT_OK;

@@ -197,7 +197,7 @@ int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *ima
     }
     const bool tm = fe->ctx->kernelTiming;
     hipStream_t st = L->streamB;
-    double tOct = 0;
+    double tOct = 0, tWait = 0, tLaunch = 0;
     // result arrays in pinned host memory (ft_host_malloc) are filled by the D2H copies directly; pageable
     // ones go through the library's pinned staging buffers and a host memcpy
     auto pinned = [](const void *p) {
@@ -224,13 +224,16 @@ int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *ima
     };
     for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
         const int nb = std::min(sb, batch - b0);
+        FtTimer tW;
         FT_HIP(hipEventSynchronize(L->evA[s]));
         FT_HIP(hipEventSynchronize(R->evA[s]));
+        tWait += tW.ms();
         FtTimer tO;
         ft_extractor *both[2] = {L, R};
         rc = ft_extract_octree_multi(both, 2, b0, nb);  // one job for both cameras: one critical path
         if (rc != FT_OK) return rc;
         tOct += tO.ms();
+        FtTimer tL;
         rc = ft_extract_launch_b(L, b0, nb, L->streamB);
         if (rc != FT_OK) return rc;
         rc = ft_extract_launch_b(R, b0, nb, R->streamB);
@@ -292,10 +295,15 @@ int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *ima
             FT_HIP(d2h(descR, R->h_desc, R->d_desc, 32, b0, nb, maxNR));
         }
         FT_HIP(hipMemcpyAsync(fe->h_nMatches + b0, fe->d_nMatches + b0, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+        tLaunch += tL.ms();
     }
+    FtTimer tTail;
     FT_HIP(hipStreamSynchronize(st));
     FT_HIP(hipStreamSynchronize(R->streamB));
     fe->ctx->addStat("stereo.octree(host,both)", tOct);
+    fe->ctx->addStat("stereo.host_wait_stageA", tWait);
+    fe->ctx->addStat("stereo.host_launch_stageB", tLaunch);
+    fe->ctx->addStat("stereo.host_tail_sync", tTail.ms());
     L->evt.resolve(fe->ctx);
     R->evt.resolve(fe->ctx);
     for (int b = 0; b < batch; b++) {
