@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="one front end, every step fully drained before the next")
     ap.add_argument("--stats", default="", help="write per-stage timings to this file")
     args = ap.parse_args()
 
@@ -130,7 +131,11 @@ def main():
     host_threads = args.host_threads or max(1, usable_cpus() // max(world, 1))
     ctx = orb.Context(local_rank, host_threads)
     intr = synth.intrinsics(w, h)
-    fe = orb.StereoFrontend(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, B, intr["mbf"], intr["mb"])
+    # two front ends used alternately: while one batch drains (last descriptors, matching, result copies) the
+    # next batch's pyramid / FAST / octree already run (ft_stereo_frontend_submit / _wait)
+    fes = [orb.StereoFrontend(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, B, intr["mbf"], intr["mb"])
+           for _ in range(1 if args.sync_steps else 2)]
+    fe = fes[0]
 
     # synthetic stream, resident in HBM before the timed region (seeds are per rank: one stream per GPU)
     D = max(1, min(args.distinct, B))
@@ -145,14 +150,24 @@ def main():
         ctx.synchronize()  # hipDeviceSynchronize on this rank's device (the library owns its HIP runtime)
         shard.barrier(dist)
 
-    for _ in range(args.warmup):
-        fe.process_raw(ptrsL, ptrsR, B, True, w)
+    def run(steps):
+        """`steps` passes over the batch; every pass is complete (results in host arrays) on return"""
+        if len(fes) == 1:
+            for _ in range(steps):
+                fe.process_raw(ptrsL, ptrsR, B, True, w)
+            return
+        for k in range(steps):
+            fes[k & 1].submit_raw(ptrsL, ptrsR, B, True, w)
+            if k > 0:
+                fes[(k - 1) & 1].wait()
+        fes[(steps - 1) & 1].wait()
+
+    run(max(args.warmup, 1))
     ctx.reset_stats()
     ctx.set_kernel_timing(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fe.process_raw(ptrsL, ptrsR, B, True, w)
+    run(args.steps)
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -180,7 +195,7 @@ def main():
             kern[name] = {"ms_per_launch": (m / n) if n else None, "launches": n}
         host = {}
         for name in ("stereo.octree(host,both)", "stereo.host_wait_stageA", "stereo.host_launch_stageB",
-                     "stereo.host_tail_sync", "stereo.process.total"):
+                     "stereo.host_tail_sync", "stereo.submit.total"):
             m, n = ctx.get_stat(name)
             host[name] = (m / n) if n else None
         # the batch is processed in sub-batches (software pipeline), so bytes per launch = algorithmic
@@ -200,6 +215,7 @@ def main():
             "config": {"workload": args.workload, "note": cfg_note, "frame": "one rectified stereo pair",
                        "image": [w, h], "nfeatures": nf, "nlevels": NLEVELS, "scale_factor": SCALE,
                        "fast_thresholds": [INI_TH, MIN_TH], "batch_pairs_per_gpu": B, "distinct_pairs": D,
+                       "batches_in_flight": len(fes),
                        "parallelism": f"{world} independent stream(s), one per GPU, no collective",
                        "host_threads_per_gpu": ctx.host_threads, "device": ctx.device_name},
             "keypoints_per_s": kps * args.steps / elapsed,

@@ -113,6 +113,8 @@ def lib() -> C.CDLL:
     L.ft_stereo_frontend_right.argtypes = [vp]
     L.ft_stereo_frontend_right.restype = vp
     L.ft_stereo_frontend_process.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp, i, vp, vp, vp]
+    L.ft_stereo_frontend_submit.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp, i, vp, vp, vp]
+    L.ft_stereo_frontend_wait.argtypes = [vp]
     L.ft_fisheye_match.argtypes = [vp, vp, i, vp, i, vp, vp, vp]
     L.ft_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LocalPoints), f, f, vp, ip] + [vp] * 10
     L.ft_search_last_frame.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LastPoints), vp, f, i, i, i, vp, ip] + [vp] * 4

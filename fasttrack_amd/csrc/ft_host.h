@@ -137,6 +137,14 @@ struct ft_stereo_frontend {
     int *d_sad = nullptr, *d_nMatches = nullptr, *h_nMatches = nullptr;
     int *d_order = nullptr, *d_rowStart = nullptr;  // right keypoints bucketed by row (k_stereo_rowsort)
     hipEvent_t evR = nullptr;
+    struct Pending {  // batch enqueued by ft_stereo_frontend_submit, finished by ft_stereo_frontend_wait
+        bool active = false, direct = false;
+        int batch = 0, capacity = 0;
+        ft_keypoint *keysL = nullptr, *keysR = nullptr;
+        uint8_t *descL = nullptr, *descR = nullptr;
+        int *nL = nullptr, *nR = nullptr, *nMatches = nullptr;
+        float *uright = nullptr, *depth = nullptr;
+    } pending;
 };
 
 int ft_set_device(const ft_context *ctx);

@@ -167,11 +167,12 @@ int ft_stereo_frontend_destroy(ft_stereo_frontend *fe) {
 ft_extractor *ft_stereo_frontend_left(ft_stereo_frontend *fe) { return fe ? fe->exL : nullptr; }
 ft_extractor *ft_stereo_frontend_right(ft_stereo_frontend *fe) { return fe ? fe->exR : nullptr; }
 
-int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *imagesL, const uint8_t *const *imagesR,
-                               int batch, int on_device, int width, int height, int stride, ft_keypoint *keysL,
-                               uint8_t *descL, int *nL, ft_keypoint *keysR, uint8_t *descR, int *nR, int capacity,
-                               float *uright, float *depth, int *n_matches) {
+int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imagesL, const uint8_t *const *imagesR,
+                              int batch, int on_device, int width, int height, int stride, ft_keypoint *keysL,
+                              uint8_t *descL, int *nL, ft_keypoint *keysR, uint8_t *descR, int *nR, int capacity,
+                              float *uright, float *depth, int *n_matches) {
     FT_REQUIRE(fe, "null front end");
+    FT_REQUIRE(!fe->pending.active, "stereo front end: a submitted batch has not been waited for");
     if (!imagesL || !imagesR || width <= 0 || height <= 0) {
         ft_set_error("stereo front end: empty image");
         return FT_ERR_EMPTY;
@@ -297,31 +298,67 @@ int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *ima
         FT_HIP(hipMemcpyAsync(fe->h_nMatches + b0, fe->d_nMatches + b0, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
         tLaunch += tL.ms();
     }
-    FtTimer tTail;
-    FT_HIP(hipStreamSynchronize(st));
-    FT_HIP(hipStreamSynchronize(R->streamB));
     fe->ctx->addStat("stereo.octree(host,both)", tOct);
     fe->ctx->addStat("stereo.host_wait_stageA", tWait);
     fe->ctx->addStat("stereo.host_launch_stageB", tLaunch);
+    fe->ctx->addStat("stereo.submit.total", tAll.ms());
+    // everything is enqueued; ft_stereo_frontend_wait drains the streams and finishes the outputs
+    auto &P = fe->pending;
+    P.active = true;
+    P.batch = batch;
+    P.capacity = capacity;
+    P.direct = direct;
+    P.keysL = keysL; P.descL = descL; P.nL = nL;
+    P.keysR = keysR; P.descR = descR; P.nR = nR;
+    P.uright = uright; P.depth = depth; P.nMatches = n_matches;
+    return FT_OK;
+}
+
+int ft_stereo_frontend_wait(ft_stereo_frontend *fe) {
+    FT_REQUIRE(fe, "null front end");
+    auto &P = fe->pending;
+    if (!P.active) return FT_OK;
+    int rc = ft_set_device(fe->ctx);
+    if (rc != FT_OK) return rc;
+    ft_extractor *L = fe->exL, *R = fe->exR;
+    const FtGeom &g = L->geom;
+    FtTimer tTail;
+    P.active = false;
+    FT_HIP(hipStreamSynchronize(L->streamB));
+    FT_HIP(hipStreamSynchronize(R->streamB));
     fe->ctx->addStat("stereo.host_tail_sync", tTail.ms());
     L->evt.resolve(fe->ctx);
     R->evt.resolve(fe->ctx);
-    for (int b = 0; b < batch; b++) {
+    const size_t kp = sizeof(ft_keypoint);
+    const int capacity = P.capacity;
+    for (int b = 0; b < P.batch; b++) {
         const int nl = L->h_nSel[b], nr = R->h_nSel[b];
-        if (!direct) {
-            if (keysL) memcpy(keysL + (size_t)b * capacity, L->h_keys + (size_t)b * g.maxKp, kp * nl);
-            if (descL) memcpy(descL + (size_t)b * capacity * 32, L->h_desc + (size_t)b * g.maxKp * 32, (size_t)32 * nl);
-            if (keysR) memcpy(keysR + (size_t)b * capacity, R->h_keys + (size_t)b * g.maxKp, kp * nr);
-            if (descR) memcpy(descR + (size_t)b * capacity * 32, R->h_desc + (size_t)b * g.maxKp * 32, (size_t)32 * nr);
-            if (uright) memcpy(uright + (size_t)b * capacity, fe->h_uright + (size_t)b * g.maxKp, 4 * (size_t)nl);
-            if (depth) memcpy(depth + (size_t)b * capacity, fe->h_depth + (size_t)b * g.maxKp, 4 * (size_t)nl);
+        if (!P.direct) {
+            if (P.keysL) memcpy(P.keysL + (size_t)b * capacity, L->h_keys + (size_t)b * g.maxKp, kp * nl);
+            if (P.descL) memcpy(P.descL + (size_t)b * capacity * 32, L->h_desc + (size_t)b * g.maxKp * 32, (size_t)32 * nl);
+            if (P.keysR) memcpy(P.keysR + (size_t)b * capacity, R->h_keys + (size_t)b * g.maxKp, kp * nr);
+            if (P.descR) memcpy(P.descR + (size_t)b * capacity * 32, R->h_desc + (size_t)b * g.maxKp * 32, (size_t)32 * nr);
+            if (P.uright) memcpy(P.uright + (size_t)b * capacity, fe->h_uright + (size_t)b * g.maxKp, 4 * (size_t)nl);
+            if (P.depth) memcpy(P.depth + (size_t)b * capacity, fe->h_depth + (size_t)b * g.maxKp, 4 * (size_t)nl);
         }
-        if (nL) nL[b] = nl;
-        if (nR) nR[b] = nr;
-        if (n_matches) n_matches[b] = fe->h_nMatches[b];
+        if (P.nL) P.nL[b] = nl;
+        if (P.nR) P.nR[b] = nr;
+        if (P.nMatches) P.nMatches[b] = fe->h_nMatches[b];
     }
-    fe->ctx->addStat("stereo.process.total", tAll.ms());
     return FT_OK;
+}
+
+int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *imagesL, const uint8_t *const *imagesR,
+                               int batch, int on_device, int width, int height, int stride, ft_keypoint *keysL,
+                               uint8_t *descL, int *nL, ft_keypoint *keysR, uint8_t *descR, int *nR, int capacity,
+                               float *uright, float *depth, int *n_matches) {
+    FtTimer tAll;
+    int rc = ft_stereo_frontend_submit(fe, imagesL, imagesR, batch, on_device, width, height, stride, keysL, descL, nL,
+                                       keysR, descR, nR, capacity, uright, depth, n_matches);
+    if (rc != FT_OK) return rc;
+    rc = ft_stereo_frontend_wait(fe);
+    if (rc == FT_OK) fe->ctx->addStat("stereo.process.total", tAll.ms());
+    return rc;
 }
 
 // ---- fisheye 2-NN and descriptor distance --------------------------------------------------------

@@ -45,18 +45,24 @@ struct NodeList {
 };
 
 // ExtractorNode::DivideNode: split node `ni` into four children occupying the parent's key range.
-// Children are appended to the pool (not yet linked); returns their pool indices in n1..n4 order.
-void divide(const uint32_t *cand, OctreeWorkspace &ws, int ni, int child[4]) {
+// Keys are (candidate | index << 32) records that ping-pong between two buffers: one counting pass
+// (quadrant codes kept in a byte array) and one stable scatter, no copy back, no indirection.
+// Only non-empty children are created; child[q] = -1 otherwise.  Candidate coordinates are small
+// non-negative integers, so the reference's float comparisons `pt.x < UR.x` are exact as int compares.
+void divide(OctreeWorkspace &ws, int ni, int child[4]) {
     const OctreeWorkspace::Node nd = ws.pool[ni];
     const int halfX = (int)std::ceil(static_cast<float>(nd.x1 - nd.x0) / 2);
     const int halfY = (int)std::ceil(static_cast<float>(nd.y1 - nd.y0) / 2);
     const int mx = nd.x0 + halfX, my = nd.y0 + halfY;
+    const uint64_t *src = (nd.buf ? ws.keysB : ws.keysA).data();
+    uint64_t *dst = (nd.buf ? ws.keysA : ws.keysB).data();
+    uint8_t *quad = ws.quad.data();
     int cnt[4] = {0, 0, 0, 0};
-    int *perm = ws.perm.data(), *tmp = ws.scratch.data();
     // quadrant: 0 = n1 (left, top) 1 = n2 (right, top) 2 = n3 (left, bottom) 3 = n4 (right, bottom)
     for (int k = nd.begin; k < nd.end; k++) {
-        const uint32_t c = cand[perm[k]];
-        const int q = (candX(c) < mx ? 0 : 1) + (candY(c) < my ? 0 : 2);
+        const uint32_t c = (uint32_t)src[k];
+        const int q = ((int)(c & 0xfffu) < mx ? 0 : 1) + ((int)((c >> 12) & 0xfffu) < my ? 0 : 2);
+        quad[k] = (uint8_t)q;
         cnt[q]++;
     }
     int off[4];
@@ -65,14 +71,13 @@ void divide(const uint32_t *cand, OctreeWorkspace &ws, int ni, int child[4]) {
     off[2] = off[1] + cnt[1];
     off[3] = off[2] + cnt[2];
     int cur[4] = {off[0], off[1], off[2], off[3]};
-    for (int k = nd.begin; k < nd.end; k++) {
-        const uint32_t c = cand[perm[k]];
-        const int q = (candX(c) < mx ? 0 : 1) + (candY(c) < my ? 0 : 2);
-        tmp[cur[q]++] = perm[k];
-    }
-    std::copy(tmp + nd.begin, tmp + nd.end, perm + nd.begin);
+    for (int k = nd.begin; k < nd.end; k++) dst[cur[quad[k]]++] = src[k];
     const int bx[4][4] = {{nd.x0, nd.y0, mx, my}, {mx, nd.y0, nd.x1, my}, {nd.x0, my, mx, nd.y1}, {mx, my, nd.x1, nd.y1}};
     for (int q = 0; q < 4; q++) {
+        if (cnt[q] == 0) {
+            child[q] = -1;
+            continue;
+        }
         OctreeWorkspace::Node ch;
         ch.x0 = bx[q][0];
         ch.y0 = bx[q][1];
@@ -82,6 +87,7 @@ void divide(const uint32_t *cand, OctreeWorkspace &ws, int ni, int child[4]) {
         ch.end = off[q] + cnt[q];
         ch.prev = ch.next = -1;
         ch.noMore = cnt[q] == 1;
+        ch.buf = nd.buf ^ 1;
         child[q] = (int)ws.pool.size();
         ws.pool.push_back(ch);
     }
@@ -100,14 +106,16 @@ int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY,
     if (n <= 0) return 0;
     ws.pool.clear();
     ws.pool.reserve(4 * (size_t)std::max(N, 64) + 64);
-    ws.perm.resize(n);
-    ws.scratch.resize(n);
+    ws.keysA.resize(n);
+    ws.keysB.resize(n);
+    ws.quad.resize(n);
     int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
     if (nIni < 1) nIni = 1;  // the reference divides by zero here for very tall images
     const float hX = static_cast<float>(maxX - minX) / nIni;
     NodeList list(ws.pool);
     // initial column nodes; keys are bucketed stably so each node sees them in emission order
-    std::vector<int> &slotOf = ws.scratch;  // reused as temp for the bucket id
+    std::vector<int> &slotOf = ws.scratch;
+    slotOf.resize(n);
     std::vector<int> cnt(nIni + 1, 0);
     for (int i = 0; i < n; i++) {
         int s = (int)(candX(cand[i]) / hX);
@@ -118,7 +126,7 @@ int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY,
     for (int s = 0; s < nIni; s++) cnt[s + 1] += cnt[s];
     {
         std::vector<int> cur(cnt.begin(), cnt.end() - 1);
-        for (int i = 0; i < n; i++) ws.perm[cur[slotOf[i]]++] = i;
+        for (int i = 0; i < n; i++) ws.keysA[cur[slotOf[i]]++] = (uint64_t)cand[i] | ((uint64_t)i << 32);
     }
     for (int s = 0; s < nIni; s++) {
         OctreeWorkspace::Node nd;
@@ -130,6 +138,7 @@ int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY,
         nd.end = cnt[s + 1];
         nd.prev = nd.next = -1;
         nd.noMore = (nd.end - nd.begin) == 1;
+        nd.buf = 0;
         ws.pool.push_back(nd);
         if (nd.end > nd.begin) list.push_back((int)ws.pool.size() - 1);  // empty nodes are erased at once
     }
@@ -144,8 +153,8 @@ int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY,
     auto pushChildren = [&](const int child[4], int *nToExpand) {
         for (int q = 0; q < 4; q++) {
             const int ci = child[q];
+            if (ci < 0) continue;
             const int sz = ws.pool[ci].end - ws.pool[ci].begin;
-            if (sz == 0) continue;
             list.push_front(ci);
             if (sz > 1) {
                 if (nToExpand) (*nToExpand)++;
@@ -165,7 +174,7 @@ int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY,
                 continue;
             }
             int child[4];
-            divide(cand, ws, it, child);
+            divide(ws, it, child);
             pushChildren(child, &nToExpand);
             it = list.erase(it);
         }
@@ -179,7 +188,7 @@ int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY,
                 std::sort(vPrev.begin(), vPrev.end(), cmp);
                 for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
                     int child[4];
-                    divide(cand, ws, vPrev[j].second, child);
+                    divide(ws, vPrev[j].second, child);
                     pushChildren(child, nullptr);
                     list.erase(vPrev[j].second);
                     if (list.size >= N) break;
@@ -191,16 +200,17 @@ int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY,
     int kept = 0;
     for (int it = list.head; it >= 0; it = ws.pool[it].next) {
         const OctreeWorkspace::Node &nd = ws.pool[it];
-        int best = ws.perm[nd.begin];
-        float maxResponse = candR(cand[best]);
+        const uint64_t *keys = (nd.buf ? ws.keysB : ws.keysA).data();
+        uint64_t best = keys[nd.begin];
+        unsigned maxResponse = (uint32_t)best >> 24;
         for (int k = nd.begin + 1; k < nd.end; k++) {
-            const float r = candR(cand[ws.perm[k]]);
+            const unsigned r = (uint32_t)keys[k] >> 24;
             if (r > maxResponse) {
-                best = ws.perm[k];
+                best = keys[k];
                 maxResponse = r;
             }
         }
-        out.push_back(best);
+        out.push_back((int)(best >> 32));
         kept++;
     }
     return kept;

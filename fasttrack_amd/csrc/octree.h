@@ -5,9 +5,9 @@
 // front-insertion order, same std::sort call on the same (size, UL.x) sequence, same first-maximum
 // pick - so the retained keypoints AND their output order are identical.
 //
-// Implementation is index based: candidates are never copied; every node owns a sub-range of one
-// permutation array that is stably 4-way partitioned in place when the node splits, and the
-// std::list of the reference becomes an intrusive doubly linked list over a node pool.
+// Implementation: every node owns a contiguous sub-range of a key array (packed candidate + original
+// index) that is stably 4-way partitioned into a second array when the node splits (ping-pong, no
+// indirection), and the std::list of the reference becomes an intrusive doubly linked list over a pool.
 #pragma once
 
 #include <stdint.h>
@@ -23,9 +23,12 @@ struct OctreeWorkspace {
         int begin, end;      // candidate sub-range in perm
         int prev, next;      // list links (-1 = none)
         bool noMore;
+        uint8_t buf;         // which key buffer holds the range (keys ping-pong on every split)
     };
     std::vector<Node> pool;
-    std::vector<int> perm, scratch;
+    std::vector<uint64_t> keysA, keysB;  // candidate | index << 32
+    std::vector<uint8_t> quad;
+    std::vector<int> scratch;
     std::vector<std::pair<int, int>> sizeAndNode, prevSizeAndNode;  // (size, node index)
 };
 

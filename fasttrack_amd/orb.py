@@ -406,6 +406,16 @@ class StereoFrontend:
                                                ptr(self._dR), ptr(self._nR), self.capacity, ptr(self._ur),
                                                ptr(self._dp), ptr(self._nm)))
 
+    def submit_raw(self, ptrsL, ptrsR, batch, on_device, stride):
+        """Asynchronous half: enqueue a batch; results are valid after wait()."""
+        check(lib().ft_stereo_frontend_submit(self._h, ptrsL, ptrsR, batch, int(on_device), self.width, self.height,
+                                              stride, ptr(self._kL), ptr(self._dL), ptr(self._nL), ptr(self._kR),
+                                              ptr(self._dR), ptr(self._nR), self.capacity, ptr(self._ur),
+                                              ptr(self._dp), ptr(self._nm)))
+
+    def wait(self):
+        check(lib().ft_stereo_frontend_wait(self._h))
+
     def process(self, imagesL, imagesR, on_device=False, stride=None):
         B = len(imagesL)
         pL, keepL = _image_ptrs(imagesL, on_device)

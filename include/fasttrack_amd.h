@@ -164,6 +164,17 @@ FT_API int ft_stereo_frontend_create(ft_context *ctx, int nfeatures, float scale
 FT_API int ft_stereo_frontend_destroy(ft_stereo_frontend *fe);
 FT_API ft_extractor *ft_stereo_frontend_left(ft_stereo_frontend *fe);
 FT_API ft_extractor *ft_stereo_frontend_right(ft_stereo_frontend *fe);
+/* Asynchronous halves of ft_stereo_frontend_process: submit enqueues everything (it returns once the host
+ * octree of the last sub-batch is done and its kernels are queued), wait drains the device and finishes
+ * the outputs.  With two front ends used alternately the drain of one batch overlaps with the next batch:
+ *   submit(fe[k & 1], batch k);  wait(fe[(k - 1) & 1]);
+ * Output arrays of a submitted batch must stay untouched until its wait returns. */
+FT_API int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imagesL,
+                                     const uint8_t *const *imagesR, int batch, int on_device, int width, int height,
+                                     int stride, ft_keypoint *keysL, uint8_t *descL, int *nL, ft_keypoint *keysR,
+                                     uint8_t *descR, int *nR, int capacity, float *uright, float *depth,
+                                     int *n_matches);
+FT_API int ft_stereo_frontend_wait(ft_stereo_frontend *fe);
 FT_API int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *const *imagesL,
                                       const uint8_t *const *imagesR, int batch, int on_device, int width,
                                       int height, int stride, ft_keypoint *keysL, uint8_t *descL, int *nL,

@@ -98,6 +98,35 @@ def test_stereo_frontend_fused(ctx, w, h, nf, B):
             assert np.array_equal(out["uright"], o["uright"]) and np.array_equal(out["depth"], o["depth"])
 
 
+def test_stereo_frontend_submit_wait_two_in_flight(ctx):
+    """bench.py's double buffering: two front ends, the next batch submitted before the previous is waited for"""
+    import ctypes as C
+    w, h, nf, B = 752, 480, 1200, 4
+    intr = synth.intrinsics(w, h)
+    fes = [orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"]) for _ in range(2)]
+    batches = [[synth.make_stereo_pair(w, h, 70 + 10 * k + b) for b in range(B)] for k in range(3)]
+    dev = [[(ctx.to_device(p[0]), ctx.to_device(p[1])) for p in bt] for bt in batches]
+    ptrs = [((C.c_void_p * B)(*[d[0].ptr for d in dv]), (C.c_void_p * B)(*[d[1].ptr for d in dv])) for dv in dev]
+    got = []
+    for k in range(3):
+        fes[k & 1].submit_raw(ptrs[k][0], ptrs[k][1], B, True, w)
+        if k > 0:
+            f = fes[(k - 1) & 1]
+            f.wait()
+            got.append([(f._kL[b, :f._nL[b]].copy(), f._dL[b, :f._nL[b]].copy(), f._ur[b, :f._nL[b]].copy(), int(f._nm[b])) for b in range(B)])
+    f = fes[0]
+    f.wait()
+    got.append([(f._kL[b, :f._nL[b]].copy(), f._dL[b, :f._nL[b]].copy(), f._ur[b, :f._nL[b]].copy(), int(f._nm[b])) for b in range(B)])
+    for k in range(3):
+        for b in range(B):
+            oL, oR = ob.Extractor(nf), ob.Extractor(nf)
+            kL, dL, _ = oL.extract(batches[k][b][0])
+            kR, dR, _ = oR.extract(batches[k][b][1])
+            o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+            gk, gd, gu, gn = got[k][b]
+            assert np.array_equal(gk, kL) and np.array_equal(gd, dL) and np.array_equal(gu, o["uright"]) and gn == o["n"]
+
+
 def test_fisheye_match(ctx):
     rng = np.random.default_rng(2)
     fr = sc.oracle_stereo_frame(512, 512, 2000, 6)
