@@ -216,46 +216,53 @@ __global__ __launch_bounds__(256) void k_stereo_rowsort(FtGeom g, FtStereoArgs a
     }
 }
 
-// One workgroup per pair: median of the accepted SADs (element size/2 of the sorted list) by a bitwise
-// search on the value, then drop every match with SAD >= 1.5f*1.4f*median.
-__global__ __launch_bounds__(256) void k_stereo_median(FtStereoArgs a) {
-    __shared__ int s_cnt;
-    const int slot = blockIdx.x, tid = threadIdx.x;
+// One WAVE per pair (no barriers, no atomics): the accepted SADs are pulled into registers once, the
+// median (element size/2 of the sorted list) is found by a bitwise search on the value with ballot-free
+// wave sums, then every match with SAD >= 1.5f*1.4f*median is dropped (src/Frame.cc:991-1004).
+#define SM_PER_LANE 40  // 64 * 40 = 2560 left keypoints per pair; larger inputs take the looped path
+__global__ __launch_bounds__(64) void k_stereo_median(FtStereoArgs a) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
     const int nL = a.nL[slot];
     const size_t base = (size_t)slot * a.capacity;
+    const bool inRegs = nL <= 64 * SM_PER_LANE;
+    int v[SM_PER_LANE];
     int m = 0;
-    for (int i = tid; i < nL; i += 256) m += a.sad[base + i] >= 0 ? 1 : 0;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    atomicAdd(&s_cnt, m);
-    __syncthreads();
-    const int total = s_cnt;
-    __syncthreads();
+    if (inRegs) {
+#pragma unroll
+        for (int k = 0; k < SM_PER_LANE; k++) {
+            const int i = k * 64 + lane;
+            v[k] = i < nL ? a.sad[base + i] : -1;
+            m += v[k] >= 0 ? 1 : 0;
+        }
+    } else {
+        for (int i = lane; i < nL; i += 64) m += a.sad[base + i] >= 0 ? 1 : 0;
+    }
+    const int total = wave_sum_i32(m);
     if (total == 0 || !a.applyMedianCut) {
-        if (tid == 0) a.nMatches[slot] = total;
+        if (lane == 0) a.nMatches[slot] = total;
         return;
     }
     const int k = total / 2;  // 0-based rank in ascending order
-    // smallest v with count(sad <= v) >= k + 1; SAD <= 121*255 < 2^15
+    // smallest value with count(sad <= value) >= k + 1; SAD <= 121*255 < 2^15
     int lo = 0;
     for (int bit = 14; bit >= 0; bit--) {
         const int probe = lo + (1 << bit) - 1;  // is the answer <= probe ?
         int c = 0;
-        for (int i = tid; i < nL; i += 256) {
-            const int s = a.sad[base + i];
-            c += (s >= 0 && s <= probe) ? 1 : 0;
+        if (inRegs) {
+#pragma unroll
+            for (int q = 0; q < SM_PER_LANE; q++) c += (v[q] >= 0 && v[q] <= probe) ? 1 : 0;
+        } else {
+            for (int i = lane; i < nL; i += 64) {
+                const int s = a.sad[base + i];
+                c += (s >= 0 && s <= probe) ? 1 : 0;
+            }
         }
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        atomicAdd(&s_cnt, c);
-        __syncthreads();
-        if (s_cnt < k + 1) lo += 1 << bit;
-        __syncthreads();
+        if (wave_sum_i32(c) < k + 1) lo += 1 << bit;
     }
     const float median = (float)lo;
     const float thDist = __fmul_rn(1.5f * 1.4f, median);
     int removed = 0;
-    for (int i = tid; i < nL; i += 256) {
+    for (int i = lane; i < nL; i += 64) {
         const int s = a.sad[base + i];
         if (s >= 0 && !((float)s < thDist)) {
             a.uright[base + i] = -1.f;
@@ -264,11 +271,8 @@ __global__ __launch_bounds__(256) void k_stereo_median(FtStereoArgs a) {
             removed++;
         }
     }
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    atomicAdd(&s_cnt, removed);
-    __syncthreads();
-    if (tid == 0) a.nMatches[slot] = total - s_cnt;
+    removed = wave_sum_i32(removed);
+    if (lane == 0) a.nMatches[slot] = total - removed;
 }
 
 // Brute-force 2-NN: one wave per query, lanes stride over the train set; the two smallest
@@ -329,7 +333,7 @@ int ft_launch_stereo_rowsort(hipStream_t st, const FtGeom &g, int batch, const F
 }
 
 int ft_launch_stereo_median(hipStream_t st, int batch, const FtStereoArgs &a) {
-    hipLaunchKernelGGL(k_stereo_median, dim3(batch), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_stereo_median, dim3(batch), dim3(64), 0, st, a);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
