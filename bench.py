@@ -202,11 +202,35 @@ def main():
         # bytes of the whole timed region / number of launches in it
         total_bytes = float(args.steps) * 2.0 * B * sumP
         roof = None
+        traffic = None
+        try:  # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if args.workload == "stereo_1280x720_nf2000" and B // max(1, min(8, B // 16)) == 16:
+                traffic = tj["kernels"]["k_fast_cells"]["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         if launches:
             achieved = total_bytes / (ms / 1e3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": total_bytes / launches,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                      "calibrated by tools/hbm_calib.sh)" if traffic else None,
+                    "bytes_per_launch": total_bytes / launches,
                     "avg_launch_ms": ms / launches, "launches_timed": launches}
+        # the other two large kernels, same accounting: the 7 pyramid launches of a sub-batch read
+        # P - P7 and write P - P0 per image; orientation + descriptor read 1849 B and write 60 B per keypoint
+        also = []
+        m, n = ctx.get_stat("kernel.pyr_down(all levels)")
+        if n:
+            b_ = float(args.steps) * 2.0 * B * ((sumP - P[-1]) + (sumP - P[0]))
+            also.append({"kernel": "k_pyr_down (7 launches per sub-batch, timed as a group)", "bound": "hbm",
+                         "achieved": b_ / (m / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": b_ / (m / 1e3) / 1e9 / HBM_PEAK_GBS, "avg_group_ms": m / n})
+        m, n = ctx.get_stat("kernel.orient_desc")
+        if n:
+            b_ = float(kps) * args.steps * (43 * 43 + 60)
+            also.append({"kernel": "k_orient_desc", "bound": "hbm", "achieved": b_ / (m / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": b_ / (m / 1e3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": m / n})
         R_pair = 2 * (3 * sumP - P[-1])  # read bytes per stereo pair, unfused accounting
         out = {
             "metric": "frames/sec extract+match", "value": fps, "unit": "frames/s", "n_gpus": world,
@@ -223,6 +247,7 @@ def main():
             "pipeline_hbm_read_frac": fps * R_pair / (HBM_PEAK_GBS * 1e9),
             "kernels": kern, "host_ms_per_step": host,
             "roofline": roof,
+            "roofline_other_kernels": also,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h, nf, pairs)
