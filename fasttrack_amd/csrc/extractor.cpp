@@ -493,7 +493,14 @@ int ft_octree_distribute(const int *xys, int n, int minX, int maxX, int minY, in
     }
     ft::OctreeWorkspace ws;
     std::vector<int> keep;
-    const int k = ft::distribute_octree(packed.data(), n, minX, maxX, minY, maxY, N, ws, keep);
+    // FT_OCTREE_PATHS=1 routes this host entry point through the path-code formulation the device runs
+    static const bool usePaths = getenv("FT_OCTREE_PATHS") && getenv("FT_OCTREE_PATHS")[0] == '1';
+    const int k = (usePaths && n < 65535) ? ft::distribute_octree_paths(packed.data(), n, minX, maxX, minY, maxY, N, keep)
+                                          : ft::distribute_octree(packed.data(), n, minX, maxX, minY, maxY, N, ws, keep);
+    if (k < 0) {
+        ft_set_error("ft_octree_distribute: path-code workspace overflow");
+        return FT_ERR_CAPACITY;
+    }
     *n_out = k;
     if (k > capacity) {
         ft_set_error("ft_octree_distribute: capacity too small");

@@ -1,6 +1,7 @@
 // See octree.h.  Compiled with -ffp-contract=off: the float expressions below must evaluate exactly
 // as the reference's (src/ORBextractor.cc:510-566, 660-884).
 #include "octree.h"
+#include "octree_paths.h"
 
 #include <algorithm>
 #include <cmath>
@@ -214,6 +215,40 @@ int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY,
         kept++;
     }
     return kept;
+}
+
+// Single-thread host run of the path-code formulation (octree_paths.h) that the device kernel executes:
+// codes -> sort by (code, index) -> tree replay.  Used by tests to check the formulation against
+// distribute_octree on the CPU before it ever runs on a GPU.
+int distribute_octree_paths(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
+                            std::vector<int> &out) {
+    if (n <= 0) return 0;
+    const op::Roots R = op::make_roots(minX, maxX, minY, maxY);
+    std::vector<uint64_t> keys(n);
+    for (int i = 0; i < n; i++)
+        keys[i] = ((uint64_t)op::path_code(R, (int)(cand[i] & 0xfffu), (int)((cand[i] >> 12) & 0xfffu)) << 32) | (uint32_t)i;
+    std::sort(keys.begin(), keys.end());
+    std::vector<uint32_t> codes(n);
+    for (int i = 0; i < n; i++) codes[i] = (uint32_t)(keys[i] >> 32);
+    const int poolCap = N + 4 * R.nIni + 16;
+    std::vector<op::Node> pool(poolCap);
+    std::vector<uint16_t> freeList(poolCap);
+    std::vector<op::SortElem> vSize(poolCap), vPrev(poolCap);
+    op::Workspace ws{pool.data(), freeList.data(), vSize.data(), vPrev.data(), poolCap};
+    auto bestOf = [&](int lo, int hi) {
+        int best = (int)(uint32_t)keys[lo];
+        for (int k = lo + 1; k < hi; k++) {
+            const int i = (int)(uint32_t)keys[k];
+            const unsigned r = cand[i] >> 24, rb = cand[best] >> 24;
+            if (r > rb || (r == rb && i < best)) best = i;
+        }
+        return best;
+    };
+    std::vector<int> res(std::max(N + 8, 4 * R.nIni + 8));
+    const int k = op::distribute(codes.data(), n, R, N, ws, bestOf, res.data(), (int)res.size());
+    if (k < 0) return -1;
+    for (int i = 0; i < k && i < (int)res.size(); i++) out.push_back(res[i]);
+    return k;
 }
 
 }  // namespace ft

@@ -38,6 +38,11 @@ struct OctreeWorkspace {
 int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
                       OctreeWorkspace &ws, std::vector<int> &out);
 
+// the same result through the path-code formulation of octree_paths.h (what the device kernel runs),
+// single-threaded on the host; returns -1 when n or N exceed what the 16-bit node records hold
+int distribute_octree_paths(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
+                            std::vector<int> &out);
+
 // upper bound of what distribute_octree can return for a level (used to size output buffers)
 int octree_max_result(int minX, int maxX, int minY, int maxY, int N);
 

@@ -114,3 +114,40 @@ def test_bad_arguments_are_rejected():
     assert L.ft_octree_distribute(_capi.ptr(xy), 1, 16, 100, 16, 100, 5, None, 0, C.byref(n)) == _capi.FT_ERR_INVALID
     assert L.ft_level_geometry(640, 480, 1000, 1.0, 8, *[None] * 7) == _capi.FT_ERR_INVALID
     assert L.ft_extractor_create(None, 1000, 1.2, 8, 20, 7, 640, 480, 1, None) == _capi.FT_ERR_INVALID
+
+
+def test_std_sort_replay_matches_libstdcxx(tmp_path):
+    """octree_paths.h replays libstdc++'s introsort move by move (the device octree cannot call std::sort)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tsr")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(root, "tests", "cpp", "test_sort_replay.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout + out.stderr
+
+
+def test_path_code_octree_equals_oracle(monkeypatch):
+    """The path-code formulation the device kernel runs (octree_paths.h), executed single-threaded on the host
+    through ft_octree_distribute with FT_OCTREE_PATHS=1, equals the oracle - in a fresh process because the
+    switch is read once."""
+    code = r'''
+import numpy as np, ctypes as C, sys
+sys.path.insert(0, %r)
+from fasttrack_amd import _capi
+from oracle import binding as ob
+L = _capi.lib()
+def octree(xys, a, b, c, d, N):
+    xys = np.ascontiguousarray(xys, np.int32); out = np.zeros(len(xys) + 64, np.int32); n = C.c_int()
+    assert L.ft_octree_distribute(_capi.ptr(xys), len(xys), a, b, c, d, N, _capi.ptr(out), len(out), C.byref(n)) == 0
+    return out[:n.value].copy()
+rng = np.random.default_rng(5)
+for trial in range(300):
+    W, H = int(rng.integers(40, 1300)), int(rng.integers(40, 720))
+    n, N = int(rng.integers(1, 5000)), int(rng.integers(1, 500))
+    pts = np.unique(np.stack([rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)], 1), axis=0); rng.shuffle(pts)
+    xys = np.concatenate([pts, rng.integers(7, 12, (len(pts), 1))], 1).astype(np.int32)
+    assert np.array_equal(ob.distribute_octree(xys, 16, 16 + W, 16, 16 + H, N), octree(xys, 16, 16 + W, 16, 16 + H, N)), trial
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FT_OCTREE_PATHS="1")
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
