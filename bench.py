@@ -189,13 +189,13 @@ def main():
         # pixel once = sum(P_l) bytes per image; one launch covers B images (one launch per camera).
         ms, launches = ctx.get_stat("kernel.fast_cells")
         kern = {}
-        for name in ("kernel.pyr_down(all levels)", "kernel.fast_cells", "kernel.compact", "kernel.orient_desc",
+        for name in ("kernel.pyr_down(all levels)", "kernel.fast_cells", "kernel.compact", "kernel.octree", "kernel.orient_desc",
                      "kernel.stereo_rowsort", "kernel.stereo_match", "kernel.stereo_median"):
             m, n = ctx.get_stat(name)
             kern[name] = {"ms_per_launch": (m / n) if n else None, "launches": n}
         host = {}
         for name in ("stereo.octree(host,both)", "stereo.host_wait_stageA", "stereo.host_launch_stageB",
-                     "stereo.host_tail_sync", "stereo.submit.total"):
+                     "stereo.host_tail_sync", "stereo.submit.total", "stereo.device_octree_fallbacks"):
             m, n = ctx.get_stat(name)
             host[name] = (m / n) if n else None
         # the batch is processed in sub-batches (software pipeline), so bytes per launch = algorithmic

@@ -151,11 +151,28 @@ void freeAll(ft_extractor *ex) {
     hipSetDevice(ex->ctx->device);
     if (ex->stream) hipStreamSynchronize(ex->stream);
     if (ex->streamB) hipStreamSynchronize(ex->streamB);
+    for (int i = 0; i < FT_OCT_STREAMS; i++)
+        if (ex->streamO[i]) hipStreamSynchronize(ex->streamO[i]);
+    if (ex->octLayout.prof) {  // FT_OCT_PROFILE=1: phase times of the octree kernel (slot 0 of every launch)
+        unsigned long long h[FT_MAX_LEVELS * 8];
+        if (hipMemcpy(h, ex->octLayout.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int l = 0; l < ex->nlevels; l++)
+                fprintf(stderr, "[oct profile] level %d: codes %.1f us  sort %.1f us  rounds %.1f us (std::sort replay %.1f us, %llu elems in %llu sorts)  pick %.1f us\n",
+                        l, h[l * 8] * 0.01, h[l * 8 + 1] * 0.01, h[l * 8 + 2] * 0.01, h[l * 8 + 4] * 0.01, h[l * 8 + 5], h[l * 8 + 6], h[l * 8 + 3] * 0.01);
+        hipFree(ex->octLayout.prof);
+        ex->octLayout.prof = nullptr;
+    }
     ex->evt.destroy();
     for (int i = 0; i < FT_PIPE_MAX; i++) {
         if (ex->evA[i]) hipEventDestroy(ex->evA[i]);
         if (ex->evB[i]) hipEventDestroy(ex->evB[i]);
+        if (ex->evO[i]) hipEventDestroy(ex->evO[i]);
     }
+    for (int i = 0; i < FT_OCT_STREAMS; i++)
+        if (ex->streamO[i]) {
+            hipStreamSynchronize(ex->streamO[i]);
+            hipStreamDestroy(ex->streamO[i]);
+        }
     if (ex->streamB) hipStreamDestroy(ex->streamB);
     hipFree(ex->d_pyr);
     hipFree(ex->d_taps);
@@ -164,6 +181,12 @@ void freeAll(ft_extractor *ex) {
     hipFree((void *)ex->d_l0);
     hipFree(ex->d_sel);
     hipFree(ex->d_nSel);
+    hipFree(ex->d_selCount);
+    hipFree(ex->d_overflow);
+    hipFree(ex->d_candDev);
+    hipFree(ex->d_candCountDev);
+    hipHostFree(ex->h_selCount);
+    hipHostFree(ex->h_overflow);
     hipFree(ex->d_keys);
     hipFree(ex->d_desc);
     hipFree(ex->d_stKeys);
@@ -253,11 +276,35 @@ int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done) {
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.compact", ex->stream);
-    rc = ft_launch_compact(ex->stream, g, nb, cellCount, stage, ex->d_cand + (size_t)b0 * g.candPerSlot,
-                           ex->d_candCount + (size_t)b0 * g.nlevels);
+    uint32_t *candDst = ex->deviceOctree ? ex->d_candDev : ex->d_cand;
+    int *cntDst = ex->deviceOctree ? ex->d_candCountDev : ex->d_candCount;
+    rc = ft_launch_compact(ex->stream, g, nb, cellCount, stage, candDst + (size_t)b0 * g.candPerSlot,
+                           cntDst + (size_t)b0 * g.nlevels);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     if (done) FT_HIP(hipEventRecord(done, ex->stream));
+    return FT_OK;
+}
+
+// device octree of slots [b0, b0+nb) of sub-batch `sub`: waits for their stage A (evA[sub], recorded here on
+// ex->stream), runs on one of the octree streams and records `done`
+int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent_t done) {
+    const FtGeom &g = ex->geom;
+    hipStream_t so = ex->streamO[sub % FT_OCT_STREAMS];
+    FT_HIP(hipEventRecord(ex->evO[sub], ex->stream));
+    FT_HIP(hipStreamWaitEvent(so, ex->evO[sub], 0));
+    FtOctArgs a = ex->octLayout;
+    a.cand = ex->d_candDev + (size_t)b0 * g.candPerSlot;
+    a.candCount = ex->d_candCountDev + (size_t)b0 * g.nlevels;
+    a.sel = ex->d_sel + (size_t)b0 * g.maxKp;
+    a.selCount = ex->d_selCount + (size_t)b0 * g.nlevels;
+    a.overflow = ex->d_overflow;
+    const bool tm = ex->ctx->kernelTiming;
+    ex->evt.begin(tm, "kernel.octree", so);
+    int rc = ft_launch_octree(so, g, nb, a);
+    ex->evt.end(tm, so);
+    if (rc != FT_OK) return rc;
+    if (done) FT_HIP(hipEventRecord(done, so));
     return FT_OK;
 }
 
@@ -282,7 +329,7 @@ int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb) {
         const int minB = FT_EDGE_THRESHOLD - 3;
         int k = ft::distribute_octree(cand, n, minB, v.maxBX, minB, v.maxBY, ex->quota[level], ws, keep);
         k = std::min(k, ex->levelMax[level]);
-        FtSelKp *dst = ex->selTmp.data() + (size_t)slot * g.maxKp + ex->levelOff[level];
+        FtSelKp *dst = ex->h_sel + (size_t)slot * g.maxKp + ex->levelOff[level];
         for (int i = 0; i < k; i++) {
             const uint32_t c = cand[keep[i]];
             // ORBextractor.cc:1211-1217: add the border offset back
@@ -291,19 +338,14 @@ int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb) {
             dst[i].level = (short)level;
             dst[i].response = (short)(c >> 24);
         }
-        ex->selCount[(size_t)slot * L + level] = k;
+        ex->h_selCount[(size_t)slot * L + level] = k;
     };
     e0->ctx->pool->parallel_for(nex * perEx, task);
     for (int e = 0; e < nex; e++) {
         ft_extractor *ex = exs[e];
         for (int slot = b0; slot < b0 + nb; slot++) {
             int n = 0;
-            FtSelKp *dst = ex->h_sel + (size_t)slot * g.maxKp;
-            for (int l = 0; l < L; l++) {
-                const int k = ex->selCount[(size_t)slot * L + l];
-                memcpy(dst + n, ex->selTmp.data() + (size_t)slot * g.maxKp + ex->levelOff[l], sizeof(FtSelKp) * k);
-                n += k;
-            }
+            for (int l = 0; l < L; l++) n += ex->h_selCount[(size_t)slot * L + l];
             ex->h_nSel[slot] = n;
         }
     }
@@ -313,26 +355,39 @@ int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb) {
 int ft_extract_octree(ft_extractor *ex, int b0, int nb) { return ft_extract_octree_multi(&ex, 1, b0, nb); }
 
 static int rangeMaxN(const ft_extractor *ex, int b0, int nb) {
+    if (ex->deviceOctree) return ex->geom.maxKp;  // totals are not known on the host yet: copy whole rows
     int maxN = 0;
     for (int b = b0; b < b0 + nb; b++) maxN = std::max(maxN, ex->h_nSel[b]);
     return maxN;
 }
 
-// stage B of slots [b0, b0+nb): upload the selection, orientation + descriptors -> d_keys / d_desc, on `st`
+// stage B of slots [b0, b0+nb) on `st`: (host octree only) upload the per-level selection and its counts,
+// then orientation + descriptors -> d_keys / d_desc packed in level order, per-image totals -> d_nSel
 int ft_extract_launch_b(ft_extractor *ex, int b0, int nb, hipStream_t st) {
     const FtGeom &g = ex->geom;
-    const int maxN = rangeMaxN(ex, b0, nb);
-    FT_HIP(hipMemcpyAsync(ex->d_nSel + b0, ex->h_nSel + b0, sizeof(int) * nb, hipMemcpyHostToDevice, st));
-    if (maxN == 0) return FT_OK;
-    FT_HIP(hipMemcpy2DAsync(ex->d_sel + (size_t)b0 * g.maxKp, sizeof(FtSelKp) * g.maxKp, ex->h_sel + (size_t)b0 * g.maxKp,
-                            sizeof(FtSelKp) * g.maxKp, sizeof(FtSelKp) * maxN, nb, hipMemcpyHostToDevice, st));
+    if (!ex->deviceOctree) {
+        FT_HIP(hipMemcpyAsync(ex->d_selCount + (size_t)b0 * g.nlevels, ex->h_selCount + (size_t)b0 * g.nlevels,
+                              sizeof(int) * nb * g.nlevels, hipMemcpyHostToDevice, st));
+        FT_HIP(hipMemcpyAsync(ex->d_sel + (size_t)b0 * g.maxKp, ex->h_sel + (size_t)b0 * g.maxKp,
+                              sizeof(FtSelKp) * (size_t)nb * g.maxKp, hipMemcpyHostToDevice, st));
+    }
     const bool tm = ex->ctx->kernelTiming;
     ex->evt.begin(tm, "kernel.orient_desc", st);
     int rc = ft_launch_orient_desc(st, g, nb, ex->d_l0 + b0, ex->l0pitch, ex->d_pyr + (size_t)b0 * g.pyrPerSlot,
-                                   ex->l0Aligned ? 1 : 0, ex->d_sel + (size_t)b0 * g.maxKp, ex->d_nSel + b0,
+                                   ex->l0Aligned ? 1 : 0, ex->d_sel + (size_t)b0 * g.maxKp,
+                                   ex->d_selCount + (size_t)b0 * g.nlevels, ex->octLayout, ex->d_nSel + b0,
                                    ex->d_keys + (size_t)b0 * g.maxKp, ex->d_desc + (size_t)b0 * g.maxKp * 32);
     ex->evt.end(tm, st);
     return rc;
+}
+
+// device octree: the host learns the per-image totals (and whether a level exceeded the kernel's limits)
+// only at the end of the batch
+int ft_extract_finish_counts(ft_extractor *ex, int batch, hipStream_t st) {
+    if (!ex->deviceOctree) return FT_OK;
+    FT_HIP(hipMemcpyAsync(ex->h_nSel, ex->d_nSel, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
+    FT_HIP(hipMemcpyAsync(ex->h_overflow, ex->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+    return FT_OK;
 }
 
 // async D2H of the keypoints / descriptors of slots [b0, b0+nb) on `st`
@@ -422,9 +477,11 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     } while (0)
     hipError_t se = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&ex->streamB, hipStreamNonBlocking);
+    for (int i = 0; i < FT_OCT_STREAMS && se == hipSuccess; i++) se = hipStreamCreateWithFlags(&ex->streamO[i], hipStreamNonBlocking);
     for (int i = 0; i < FT_PIPE_MAX && se == hipSuccess; i++) {
         se = hipEventCreateWithFlags(&ex->evA[i], hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&ex->evB[i], hipEventDisableTiming);
+        if (se == hipSuccess) se = hipEventCreateWithFlags(&ex->evO[i], hipEventDisableTiming);
     }
     if (se != hipSuccess) {
         freeAll(ex);
@@ -438,6 +495,10 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     FT_TRY(devAlloc(&ex->d_l0, B));
     FT_TRY(devAlloc(&ex->d_sel, B * g.maxKp));
     FT_TRY(devAlloc(&ex->d_nSel, B));
+    FT_TRY(devAlloc(&ex->d_selCount, B * g.nlevels));
+    FT_TRY(devAlloc(&ex->d_overflow, 1));
+    FT_TRY(pinAlloc(&ex->h_selCount, B * g.nlevels));
+    FT_TRY(pinAlloc(&ex->h_overflow, 1));
     FT_TRY(devAlloc(&ex->d_keys, B * g.maxKp));
     FT_TRY(devAlloc(&ex->d_desc, B * g.maxKp * 32));
     FT_TRY(pinAlloc(&ex->h_l0, B));
@@ -473,8 +534,42 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     memset(ex->h_nSel, 0, sizeof(int) * B);
     ex->levelOff.assign(nlevels + 1, 0);
     for (int l = 0; l < nlevels; l++) ex->levelOff[l + 1] = ex->levelOff[l] + ex->levelMax[l];
-    ex->selTmp.resize(B * g.maxKp);
-    ex->selCount.assign(B * nlevels, 0);
+    memset(ex->h_selCount, 0, sizeof(int) * B * nlevels);
+    ex->h_overflow[0] = 0;
+    {
+        FtOctArgs &o = ex->octLayout;
+        memset(&o, 0, sizeof o);
+        int maxQ = 0, need = 0;
+        for (int l = 0; l < nlevels; l++) {
+            o.quota[l] = ex->quota[l];
+            o.levelMax[l] = ex->levelMax[l];
+            o.selOff[l] = ex->levelOff[l];
+            maxQ = std::max(maxQ, ex->quota[l]);
+            const int minB = FT_EDGE_THRESHOLD - 3;
+            int nIni = (int)std::round(static_cast<float>(g.lv[l].maxBX - minB) / (g.lv[l].maxBY - minB));
+            if (nIni < 1) nIni = 1;
+            need = std::max(need, ex->quota[l] + 4 * nIni);  // live nodes never exceed max(N + 2, 4 * nIni), + 4 in flight
+        }
+        o.poolCap = need + 16;
+        // FT_DEVICE_OCTREE=0 keeps the octree on the host (also the path when a quota exceeds the kernel's limit)
+        const char *e = getenv("FT_DEVICE_OCTREE");
+        ex->deviceOctree = !(e && e[0] == '0') && maxQ <= FT_OCT_MAXQ && o.poolCap < 60000;
+        if (ex->deviceOctree && ft_octree_smem_bytes(o.poolCap) > 160 * 1024) ex->deviceOctree = false;
+        if (ex->deviceOctree) {
+            if (getenv("FT_OCT_PROFILE")) {
+                FT_TRY(devAlloc(&o.prof, (size_t)FT_MAX_LEVELS * 8));
+                hipMemset(o.prof, 0, sizeof(unsigned long long) * FT_MAX_LEVELS * 8);
+            }
+            FT_TRY(devAlloc(&ex->d_candDev, B * g.candPerSlot));
+            FT_TRY(devAlloc(&ex->d_candCountDev, B * g.nlevels));
+            hipError_t me = hipMemset(ex->d_overflow, 0, sizeof(int));
+            if (me != hipSuccess) {
+                freeAll(ex);
+                delete ex;
+                return ft_hip_fail(me, "hipMemset", __FILE__, __LINE__);
+            }
+        }
+    }
 #undef FT_TRY
     *out = ex;
     return FT_OK;
@@ -493,10 +588,13 @@ int ft_octree_distribute(const int *xys, int n, int minX, int maxX, int minY, in
     }
     ft::OctreeWorkspace ws;
     std::vector<int> keep;
-    // FT_OCTREE_PATHS=1 routes this host entry point through the path-code formulation the device runs
-    static const bool usePaths = getenv("FT_OCTREE_PATHS") && getenv("FT_OCTREE_PATHS")[0] == '1';
-    const int k = (usePaths && n < 65535) ? ft::distribute_octree_paths(packed.data(), n, minX, maxX, minY, maxY, N, keep)
-                                          : ft::distribute_octree(packed.data(), n, minX, maxX, minY, maxY, N, ws, keep);
+    // FT_OCTREE_PATHS=1 / 2 route this host entry point through the path-code formulations the device kernel
+    // is built from (1: node list replay, 2: round formulation), so they can be checked without a GPU
+    static const int usePaths = getenv("FT_OCTREE_PATHS") ? atoi(getenv("FT_OCTREE_PATHS")) : 0;
+    int k;
+    if (usePaths == 2 && n < 65535) k = ft::distribute_octree_rounds(packed.data(), n, minX, maxX, minY, maxY, N, keep);
+    else if (usePaths == 1 && n < 65535) k = ft::distribute_octree_paths(packed.data(), n, minX, maxX, minY, maxY, N, keep);
+    else k = ft::distribute_octree(packed.data(), n, minX, maxX, minY, maxY, N, ws, keep);
     if (k < 0) {
         ft_set_error("ft_octree_distribute: path-code workspace overflow");
         return FT_ERR_CAPACITY;
@@ -584,27 +682,50 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
     if (rc != FT_OK) return rc;
     const int S = ft_pipeline_depth(batch);
     const int sb = (batch + S - 1) / S;
-    for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
-        rc = ft_extract_launch_a(ex, b0, std::min(sb, batch - b0), ex->evA[s]);
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 1 only when the device octree met a level beyond its limits: same batch, host octree
+        if (pass == 1) {
+            if (!(ex->deviceOctree && ex->h_overflow[0])) break;
+            ex->h_overflow[0] = 0;
+            FT_HIP(hipMemsetAsync(ex->d_overflow, 0, sizeof(int), ex->stream));
+            ex->deviceOctree = false;
+            ex->ctx->addStat("extract.device_octree_fallbacks", 1);
+        }
+        const bool dev = ex->deviceOctree;
+        for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
+            const int nb = std::min(sb, batch - b0);
+            rc = ft_extract_launch_a(ex, b0, nb, dev ? nullptr : ex->evA[s]);
+            if (rc != FT_OK) return rc;
+            if (dev) {
+                rc = ft_extract_launch_octree(ex, s, b0, nb, ex->evA[s]);
+                if (rc != FT_OK) return rc;
+            }
+        }
+        double tOct = 0;
+        for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
+            const int nb = std::min(sb, batch - b0);
+            if (dev) {
+                FT_HIP(hipStreamWaitEvent(ex->streamB, ex->evA[s], 0));
+            } else {
+                FT_HIP(hipEventSynchronize(ex->evA[s]));
+                FtTimer tO;
+                rc = ft_extract_octree(ex, b0, nb);
+                if (rc != FT_OK) return rc;
+                tOct += tO.ms();
+            }
+            rc = ft_extract_launch_b(ex, b0, nb, ex->streamB);
+            if (rc != FT_OK) return rc;
+            rc = ft_extract_download(ex, b0, nb, ex->streamB);
+            if (rc != FT_OK) return rc;
+        }
+        rc = ft_extract_finish_counts(ex, batch, ex->streamB);
         if (rc != FT_OK) return rc;
+        FT_HIP(hipStreamSynchronize(ex->streamB));
+        FT_HIP(hipStreamSynchronize(ex->stream));
+        ex->evt.resolve(ex->ctx);
+        if (!dev) ex->ctx->addStat("extract.octree(host)", tOct);
+        if (pass == 1) ex->deviceOctree = true;
     }
-    double tOct = 0;
-    for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
-        const int nb = std::min(sb, batch - b0);
-        FT_HIP(hipEventSynchronize(ex->evA[s]));
-        FtTimer tO;
-        rc = ft_extract_octree(ex, b0, nb);
-        if (rc != FT_OK) return rc;
-        tOct += tO.ms();
-        rc = ft_extract_launch_b(ex, b0, nb, ex->streamB);
-        if (rc != FT_OK) return rc;
-        rc = ft_extract_download(ex, b0, nb, ex->streamB);
-        if (rc != FT_OK) return rc;
-    }
-    FT_HIP(hipStreamSynchronize(ex->streamB));
-    FT_HIP(hipStreamSynchronize(ex->stream));
-    ex->evt.resolve(ex->ctx);
-    ex->ctx->addStat("extract.octree(host)", tOct);
     rc = assembleOutputs(ex, batch, lap0, lap1, keypoints, descriptors, capacity, n_keypoints, n_mono);
     ex->ctx->addStat("extract.total", tAll.ms());
     return rc;
@@ -660,10 +781,19 @@ int ft_extractor_download_candidates(ft_extractor *ex, int slot, int level, int 
     if (rc != FT_OK) return rc;
     FT_HIP(hipStreamSynchronize(ex->stream));
     const FtGeom &g = ex->geom;
-    const int cnt = ex->h_candCount[slot * g.nlevels + level];
+    std::vector<uint32_t> tmp;
+    const uint32_t *c = ex->h_cand + (size_t)slot * g.candPerSlot + g.lv[level].candBase;
+    int cnt = ex->h_candCount[slot * g.nlevels + level];
+    if (ex->deviceOctree) {  // the lists never left the device
+        FT_HIP(hipStreamSynchronize(ex->streamB));
+        FT_HIP(hipMemcpy(&cnt, ex->d_candCountDev + slot * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+        tmp.resize(std::max(cnt, 1));
+        FT_HIP(hipMemcpy(tmp.data(), ex->d_candDev + (size_t)slot * g.candPerSlot + g.lv[level].candBase,
+                         sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
+        c = tmp.data();
+    }
     *n = cnt;
     if (xys) {
-        const uint32_t *c = ex->h_cand + (size_t)slot * g.candPerSlot + g.lv[level].candBase;
         for (int i = 0; i < cnt && i < capacity; i++) {
             xys[3 * i] = (int)(c[i] & 0xfffu);
             xys[3 * i + 1] = (int)((c[i] >> 12) & 0xfffu);

@@ -12,6 +12,7 @@
 #include "thread_pool.h"
 
 #define FT_PIPE_MAX 8
+#define FT_OCT_STREAMS 4
 
 struct ft_context {
     int device = 0;
@@ -91,12 +92,14 @@ struct ft_extractor {
     std::vector<int> quota;
     std::vector<int> levelMax;  // per-level bound of octree results
     std::vector<int> levelOff;  // prefix sums of levelMax
-    std::vector<FtSelKp> selTmp;  // octree scratch [maxBatch * maxKp]
-    std::vector<int> selCount;    // [maxBatch * nlevels]
     FtGeom geom{};
     hipStream_t stream = nullptr;   // stage A (pyramid, FAST, compaction)
     hipStream_t streamB = nullptr;  // stage B (orientation + descriptors), matching, result copies
     hipEvent_t evA[FT_PIPE_MAX] = {}, evB[FT_PIPE_MAX] = {};
+    // the device octree is a long, narrow kernel (one wave per level and image): it runs on its own streams
+    // so that the wide stage-A kernels of the following sub-batches are not queued behind it
+    hipStream_t streamO[FT_OCT_STREAMS] = {};
+    hipEvent_t evO[FT_PIPE_MAX] = {};
     // device buffers
     uint8_t *d_pyr = nullptr;
     FtTap *d_taps = nullptr;
@@ -108,6 +111,13 @@ struct ft_extractor {
     // host-mapped pinned buffers written by the device
     uint32_t *h_cand = nullptr, *d_cand = nullptr;
     int *h_candCount = nullptr, *d_candCount = nullptr;
+    // device octree (kernels_octree.hip): candidates, selection and counts never leave the device
+    bool deviceOctree = false;
+    uint32_t *d_candDev = nullptr;
+    int *d_candCountDev = nullptr;
+    int *d_selCount = nullptr, *h_selCount = nullptr;  // [maxBatch * nlevels]
+    int *d_overflow = nullptr, *h_overflow = nullptr;
+    FtOctArgs octLayout{};
     // selected keypoints host -> device
     FtSelKp *h_sel = nullptr, *d_sel = nullptr;
     int *h_nSel = nullptr, *d_nSel = nullptr;
@@ -140,6 +150,8 @@ struct ft_stereo_frontend {
     struct Pending {  // batch enqueued by ft_stereo_frontend_submit, finished by ft_stereo_frontend_wait
         bool active = false, direct = false;
         int batch = 0, capacity = 0;
+        std::vector<const uint8_t *> imagesL, imagesR;  // kept for the host-octree fallback
+        int onDevice = 0, width = 0, height = 0, stride = 0;
         ft_keypoint *keysL = nullptr, *keysR = nullptr;
         uint8_t *descL = nullptr, *descR = nullptr;
         int *nL = nullptr, *nR = nullptr, *nMatches = nullptr;
@@ -157,5 +169,7 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
 int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done);
 int ft_extract_octree(ft_extractor *ex, int b0, int nb);
 int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb);
+int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent_t done);  // device octree, own streams
 int ft_extract_launch_b(ft_extractor *ex, int b0, int nb, hipStream_t st);
+int ft_extract_finish_counts(ft_extractor *ex, int batch, hipStream_t st);  // device mode: totals + overflow flag to host
 int ft_extract_download(ft_extractor *ex, int b0, int nb, hipStream_t st);

@@ -63,6 +63,21 @@ struct FtTap {
     short s, a0, a1, pad;
 };
 
+// device octree (kernels_octree.hip): limits of the one-wave-per-level kernel; beyond them the batch is
+// redone with the host octree
+#define FT_OCT_MAXN 4096  // candidates of one level of one image (sorted in LDS)
+#define FT_OCT_MAXQ 1024  // per-level quota (node pool in LDS)
+struct FtOctArgs {
+    const uint32_t *cand;   // device dense candidate lists [slot * candPerSlot + candBase]
+    const int *candCount;   // device [slot * nlevels + level]
+    FtSelKp *sel;           // device [slot * maxKp + selOff[level] + i]
+    int *selCount;          // device [slot * nlevels + level]
+    int *overflow;          // device flag
+    int quota[FT_MAX_LEVELS], levelMax[FT_MAX_LEVELS], selOff[FT_MAX_LEVELS];
+    int poolCap, keyBytes;
+    unsigned long long *prof;  // FT_OCT_PROFILE=1: per-level phase times of slot 0 (wall_clock64 ticks), else null
+};
+
 void ft_set_error(const std::string &msg);
 int ft_hip_fail(hipError_t e, const char *what, const char *file, int line);
 
@@ -81,9 +96,13 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
                          uint32_t *stage);
 int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cellCount, const uint32_t *stage,
                       uint32_t *cand, int *candCount);
+// sel is laid out per level (slot * maxKp + selOff[level] + i) with per-level counts; the kernel packs the
+// results in level order (slot * maxKp + k) and stores the per-image total in nSel
 int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                          const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *nSel, ft_keypoint *keys,
-                          uint8_t *desc);
+                          const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *selCount,
+                          const FtOctArgs &layout, int *nSel, ft_keypoint *keys, uint8_t *desc);
+int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a);
+size_t ft_octree_smem_bytes(int poolCap);
 size_t ft_fast_smem_bytes(const FtGeom &g);
 
 // ---- kernel launchers (kernels_match.hip) ---------------------------------------------------

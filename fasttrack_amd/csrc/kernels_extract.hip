@@ -463,15 +463,28 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 
 __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const uint8_t *const *l0, int l0pitch,
                                                                const uint8_t *pyr, int alignedLoads, const FtSelKp *sel,
-                                                               const int *nSel, ft_keypoint *keysOut, uint8_t *descOut) {
+                                                               const int *selCount, FtOctArgs lay, int *nSel,
+                                                               ft_keypoint *keysOut, uint8_t *descOut) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = blockIdx.y;
     const int k = blockIdx.x * OD_WAVES + wave;
-    if (k >= nSel[slot]) return;  // waves are independent: no workgroup barrier below
+    // the octree leaves its result per level; keypoint k of the image (level order) is entry k - prefix of
+    // the level that contains it
+    int selLevel = -1, prefix = 0, total = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int c = selCount[slot * g.nlevels + l];
+        if (selLevel < 0 && k < total + c) {
+            selLevel = l;
+            prefix = total;
+        }
+        total += c;
+    }
+    if (k == 0 && lane == 0) nSel[slot] = total;
+    if (selLevel < 0) return;  // k >= total; waves are independent: no workgroup barrier below
     uint8_t *raw = smem + (size_t)wave * OD_WAVE_BYTES;
     unsigned short *hb = (unsigned short *)(raw + OD_RAW_BYTES);
-    const FtSelKp s = sel[(size_t)slot * g.maxKp + k];
+    const FtSelKp s = sel[(size_t)slot * g.maxKp + lay.selOff[selLevel] + (k - prefix)];
     const int cx = s.x, cy = s.y, level = s.level, response = s.response;
     int pitch;
     const uint8_t *img = level_ptr(g, level, slot, l0, l0pitch, pyr, pitch);
@@ -661,11 +674,12 @@ int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cel
 }
 
 int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                          const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *nSel, ft_keypoint *keys,
-                          uint8_t *desc) {
+                          const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *selCount,
+                          const FtOctArgs &layout, int *nSel, ft_keypoint *keys, uint8_t *desc) {
     dim3 grid((g.maxKp + OD_WAVES - 1) / OD_WAVES, batch, 1), block(64 * OD_WAVES, 1, 1);
     const size_t smem = OD_WAVES * (size_t)OD_WAVE_BYTES;
-    hipLaunchKernelGGL(k_orient_desc, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, nSel, keys, desc);
+    hipLaunchKernelGGL(k_orient_desc, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, selCount, layout,
+                       nSel, keys, desc);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

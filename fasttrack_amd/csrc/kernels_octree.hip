@@ -1,0 +1,474 @@
+// Device octree keypoint distribution (ORBextractor::DistributeOctTree, reference
+// src/ORBextractor.cc:660-884) for gfx950: one wave per (level, image), everything in LDS.
+//
+//   1. path code per candidate (octree_paths.h), lane-parallel
+//   2. bitonic sort of (code, index) keys: afterwards every node of the tree owns a contiguous key range
+//   3. ROUNDS (octree.cpp distribute_octree_rounds is the single-thread statement of the same thing, checked
+//      against the oracle on the CPU): the node list is an array; a whole pass of the reference - all nodes
+//      of a breadth-first pass, or the leading nodes of the size-sorted careful pass - is split at once, one
+//      lane per node (three boundary searches in the node's key range), and the new list positions are
+//      prefix sums: children of the processed nodes in reverse push order, then the untouched nodes.
+//      Only the careful pass's std::sort is sequential: its tie order is the reference's, so it is replayed
+//      literally on lane 0 (octree_paths.h std_sort_replay).
+//   4. per retained node the first-maximum response pick, one lane per node.
+//
+// The result - retained candidates AND their order - equals the host octree (octree.cpp), which stays as the
+// path for inputs beyond this kernel's limits (more than FT_OCT_MAXN candidates in one level or a quota
+// above FT_OCT_MAXQ): the kernel then raises `overflow` and the host re-runs that batch.
+#include "ft_internal.h"
+#include "octree_paths.h"
+
+namespace {
+
+using ft::op::kMaxDepth;
+using ft::op::Roots;
+using ft::op::SortElem;
+using ft::op::SortFrame;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// exclusive prefix sum over the wave; total = sum of all lanes
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+
+// LDS layout of one wave's workspace (offsets in bytes from the dynamic LDS base)
+struct OctLds {
+    int keys, lohi[2], x01[2], dep[2], vSize, vPrev, ord, bq, pq, mark, stack, total;
+};
+
+__host__ __device__ inline OctLds oct_lds_layout(int cap) {
+    OctLds o;
+    int p = 0;
+    auto take = [&](int bytes) {
+        const int at = p;
+        p += (bytes + 15) & ~15;
+        return at;
+    };
+    o.keys = take(FT_OCT_MAXN * 8);
+    for (int i = 0; i < 2; i++) {
+        o.lohi[i] = take(2 * cap * 4);
+        o.x01[i] = take(2 * cap * 4);
+        o.dep[i] = take(2 * cap);
+    }
+    o.vSize = take(cap * 8);
+    o.vPrev = take(cap * 8);
+    o.ord = take(cap * 2);
+    o.bq = take(cap * 8);  // b1, b2, b3 of a processed node (u16 x 3, one pad)
+    o.pq = take(cap * 4);  // exclusive prefixes: children | children with more than one key << 16
+    o.mark = take(2 * cap);
+    o.stack = take(64 * sizeof(SortFrame));
+    o.total = p;
+    return o;
+}
+
+// std::sort(a, a + n, compareNodes) of libstdc++ with one wave: the steps of octree_paths.h
+// std_sort_replay_steps (checked against libstdc++ on the CPU), each of them lane-parallel.
+__device__ void wave_std_sort(SortElem *a, int n, SortFrame *stack, uint16_t *posA, uint16_t *posB, SortElem *tmp, int lane) {
+    if (n <= 1) return;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) lg++;
+    int sp = 0;
+    if (lane == 0) stack[0] = SortFrame{0, (uint16_t)n, (uint16_t)(2 * lg), 0};
+    sp = 1;
+    wave_lds_sync();
+    const unsigned long long below = (1ull << lane) - 1;
+    while (sp > 0) {
+        const SortFrame fr = stack[--sp];
+        int f = fr.f, l = fr.l, depth = fr.depth;
+        wave_lds_sync();  // the frame is read before a later push overwrites the slot
+        while (l - f > 16) {
+            if (depth == 0) {
+                if (lane == 0) ft::op::ss_heap_sort(a + f, a + l);
+                wave_lds_sync();
+                break;
+            }
+            --depth;
+            // __move_median_to_first(first, first + 1, mid, last - 1)
+            const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
+            const uint32_t ka = a[ia].key, kb = a[ib].key, kc = a[ic].key;
+            int pick;
+            if (ka < kb) pick = (kb < kc) ? ib : (ka < kc) ? ic : ia;
+            else pick = (ka < kc) ? ia : (kb < kc) ? ic : ib;
+            const uint32_t pv = (pick == ia) ? ka : (pick == ib) ? kb : kc;
+            if (lane == 0) {
+                const SortElem t0 = a[f], t1 = a[pick];
+                a[f] = t1;
+                a[pick] = t0;
+            }
+            wave_lds_sync();
+            // candidates: A ascending, B ascending (read back reversed)
+            int nA = 0, nB = 0;
+            for (int i0 = f + 1; i0 < l; i0 += 64) {
+                const int i = i0 + lane;
+                const bool valid = i < l;
+                const uint32_t x = valid ? a[i].key : 0u;
+                const bool isA = valid && !(x < pv), isB = valid && !(pv < x);
+                const unsigned long long bA = __ballot(isA), bB = __ballot(isB);
+                if (isA) posA[nA + __popcll(bA & below)] = (uint16_t)i;
+                if (isB) posB[nB + __popcll(bB & below)] = (uint16_t)i;
+                nA += __popcll(bA);
+                nB += __popcll(bB);
+            }
+            wave_lds_sync();
+            int K = 0;
+            const int nPair = min(nA, nB);
+            for (int k0 = 0; k0 < nPair; k0 += 64) {
+                const int k = k0 + lane;
+                bool sw = false;
+                int pa = 0, pb = 0;
+                if (k < nPair) {
+                    pa = posA[k];
+                    pb = posB[nB - 1 - k];
+                    sw = pa < pb;
+                }
+                const unsigned long long bs = __ballot(sw);
+                if (sw) {
+                    const SortElem t0 = a[pa], t1 = a[pb];
+                    a[pa] = t1;
+                    a[pb] = t0;
+                }
+                K += __popcll(bs);
+                if (bs != ~0ull) break;
+            }
+            const int bK = K ? (int)posB[nB - K] : l;
+            const int aK = K < nA ? (int)posA[K] : 0x7fffffff;
+            const int cut = aK < bK ? aK : bK;
+            wave_lds_sync();
+            if (sp < 64) {
+                if (lane == 0) stack[sp] = SortFrame{(uint16_t)cut, (uint16_t)l, (uint16_t)depth, 0};
+                sp++;
+            }
+            l = cut;
+        }
+        wave_lds_sync();
+    }
+    // __final_insertion_sort as a windowed stable rank
+    for (int i = lane; i < n; i += 64) {
+        const SortElem e = a[i];
+        int pos = i;
+        for (int j = max(i - 16, 0); j < i; j++) pos -= a[j].key > e.key;
+        for (int j = i + 1; j <= min(i + 16, n - 1); j++) pos += a[j].key < e.key;
+        tmp[pos] = e;
+    }
+    wave_lds_sync();
+    for (int i = lane; i < n; i += 64) a[i] = tmp[i];
+    wave_lds_sync();
+}
+
+constexpr int OCT_THREADS = 256;  // codes + key sort use the whole block, the rounds only its first wave
+
+__global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int level = blockIdx.x, slot = blockIdx.y;
+    const FtLevelGeom &L = g.lv[level];
+    const int n = a.candCount[slot * g.nlevels + level];
+    const int N = a.quota[level];
+    int *cntOut = a.selCount + slot * g.nlevels + level;
+    if (n <= 0) {
+        if (tid == 0) *cntOut = 0;
+        return;
+    }
+    if (n > FT_OCT_MAXN || N > FT_OCT_MAXQ) {
+        if (tid == 0) {
+            *cntOut = 0;
+            atomicOr(a.overflow, 1);
+        }
+        return;
+    }
+    const uint32_t *cand = a.cand + (size_t)slot * g.candPerSlot + L.candBase;
+    const int minB = FT_EDGE_THRESHOLD - 3;
+    const Roots R = ft::op::make_roots(minB, L.maxBX, minB, L.maxBY);
+    const int cap = a.poolCap;
+    const OctLds o = oct_lds_layout(cap);
+    unsigned long long *keys = (unsigned long long *)(smem + o.keys);  // code << 32 | index
+    const uint32_t *codes = (const uint32_t *)keys;                     // codes[2 * i + 1]
+    uint32_t *lohiB[2] = {(uint32_t *)(smem + o.lohi[0]), (uint32_t *)(smem + o.lohi[1])};
+    uint32_t *x01B[2] = {(uint32_t *)(smem + o.x01[0]), (uint32_t *)(smem + o.x01[1])};
+    uint8_t *depB[2] = {smem + o.dep[0], smem + o.dep[1]};
+    SortElem *vSize = (SortElem *)(smem + o.vSize);
+    SortElem *vPrev = (SortElem *)(smem + o.vPrev);
+    uint16_t *ord = (uint16_t *)(smem + o.ord);
+    uint16_t *bq = (uint16_t *)(smem + o.bq);
+    uint32_t *pq = (uint32_t *)(smem + o.pq);
+    uint8_t *mark = smem + o.mark;
+    SortFrame *stack = (SortFrame *)(smem + o.stack);
+
+    const bool prof = a.prof && slot == 0;
+    unsigned long long tPrev = prof ? wall_clock64() : 0;
+    int profIdx = 0;
+    auto tick = [&]() {
+        if (!prof) return;
+        const unsigned long long t = wall_clock64();
+        if (tid == 0 && profIdx < 8) a.prof[level * 8 + profIdx] += t - tPrev;
+        profIdx++;
+        tPrev = t;
+    };
+    // ---- 1. path codes ----
+    int nPad = 64;
+    while (nPad < n) nPad <<= 1;
+    for (int i = tid; i < nPad; i += OCT_THREADS) {
+        unsigned long long k = ~0ull;
+        if (i < n) {
+            const uint32_t c = cand[i];
+            k = ((unsigned long long)ft::op::path_code(R, (int)(c & 0xfffu), (int)((c >> 12) & 0xfffu)) << 32) | (unsigned)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    tick();  // 0: codes
+    // ---- 2. bitonic sort (keys are unique, so the order equals a stable sort by code) ----
+    for (int k = 2; k <= nPad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (nPad >> 1); t += OCT_THREADS) {
+                const int i = ((t / j) * (j << 1)) + (t % j);  // j is a power of two: shifts / masks
+                const int l = i + j;
+                const unsigned long long x = keys[i], y = keys[l];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) {
+                    keys[i] = y;
+                    keys[l] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    tick();  // 1: sort
+    if (tid >= 64) return;  // the rest is one wave: no block barrier below this line
+    auto lower_bound = [&](int lo, int hi, uint32_t target) {
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (codes[2 * mid + 1] < target) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    };
+    // ---- 3. rounds ----
+    int curB = 0, start = cap, m = 0;
+    for (int s0 = 0; s0 < R.nIni; s0 += 64) {  // root nodes (:672-705), empty ones dropped
+        const int s = s0 + lane;
+        int lo = 0, hi = 0;
+        if (s < R.nIni) {
+            lo = lower_bound(0, n, (uint32_t)s << (2 * kMaxDepth));
+            hi = lower_bound(lo, n, (uint32_t)(s + 1) << (2 * kMaxDepth));
+        }
+        const bool has = hi > lo;
+        const unsigned long long bal = __ballot(has);
+        if (has) {
+            const int pos = start + m + __popcll(bal & ((1ull << lane) - 1));
+            int x0, x1;
+            ft::op::root_bounds(R, s, x0, x1);
+            lohiB[0][pos] = (uint32_t)lo | ((uint32_t)hi << 16);
+            x01B[0][pos] = (uint32_t)x0 | ((uint32_t)x1 << 16);
+            depB[0][pos] = 0;
+        }
+        m += __popcll(bal);
+    }
+    wave_lds_sync();
+    int nV = 0;
+    // splits the nodes ord[0..nOrd) of the current list in that order (with useStop: until the list holds N)
+    auto split_round = [&](int nOrd, bool useStop) {
+        const uint32_t *cl = lohiB[curB], *cx = x01B[curB];
+        const uint8_t *cd = depB[curB];
+        uint32_t *nl = lohiB[curB ^ 1], *nx = x01B[curB ^ 1];
+        uint8_t *ndp = depB[curB ^ 1];
+        // pass A: boundaries, child counts, prefixes, stop
+        int carryP = 0, carryQ = 0, cum = m, nproc = nOrd;
+        for (int r0 = 0; r0 < nOrd; r0 += 64) {
+            const int r = r0 + lane;
+            int nch = 0, nbig = 0;
+            if (r < nOrd) {
+                const int t = ord[r];
+                const uint32_t lh = cl[t];
+                const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16), d = cd[t];
+                int b1 = hi, b2 = hi, b3 = hi;
+                if (d < kMaxDepth) {
+                    const int shift = 2 * (kMaxDepth - 1 - d);
+                    const uint32_t prefix = codes[2 * lo + 1] >> (shift + 2);
+                    b1 = lower_bound(lo, hi, ((prefix << 2) | 1u) << shift);
+                    b2 = lower_bound(b1, hi, ((prefix << 2) | 2u) << shift);
+                    b3 = lower_bound(b2, hi, ((prefix << 2) | 3u) << shift);
+                }
+                bq[4 * r] = (uint16_t)b1;
+                bq[4 * r + 1] = (uint16_t)b2;
+                bq[4 * r + 2] = (uint16_t)b3;
+                nch = (b1 > lo) + (b2 > b1) + (b3 > b2) + (hi > b3);
+                nbig = (b1 - lo > 1) + (b2 - b1 > 1) + (b3 - b2 > 1) + (hi - b3 > 1);
+            }
+            int totP, totQ;
+            const int exP = wave_excl_scan(nch, lane, totP);
+            const int exQ = wave_excl_scan(nbig, lane, totQ);
+            if (r < nOrd) pq[r] = (uint32_t)(carryP + exP) | ((uint32_t)(carryQ + exQ) << 16);
+            if (useStop) {
+                // list size after processing ranks <= r
+                const int cumR = cum + (exP + nch) - (lane + 1);
+                const unsigned long long hit = __ballot(r < nOrd && cumR >= N);
+                if (hit) {
+                    const int f = __ffsll((long long)hit) - 1;
+                    nproc = r0 + f + 1;
+                    carryP += __shfl(exP + nch, f);
+                    carryQ += __shfl(exQ + nbig, f);
+                    break;
+                }
+            }
+            const int cntHere = min(64, nOrd - r0);
+            carryP += totP;
+            carryQ += totQ;
+            cum += totP - cntHere;
+        }
+        const int C = carryP;
+        // marks
+        for (int t = start + lane; t < start + m; t += 64) mark[t] = 0;
+        wave_lds_sync();
+        for (int r = lane; r < nproc; r += 64) mark[ord[r]] = 1;
+        wave_lds_sync();
+        // pass C: children of the processed nodes
+        for (int r = lane; r < nproc; r += 64) {
+            const int t = ord[r];
+            const uint32_t lh = cl[t], xx = cx[t];
+            const int d = cd[t];
+            const int x0 = (int)(xx & 0xffffu), x1 = (int)(xx >> 16);
+            const int mx = x0 + ((x1 - x0 + 1) >> 1);
+            const int b[5] = {(int)(lh & 0xffffu), bq[4 * r], bq[4 * r + 1], bq[4 * r + 2], (int)(lh >> 16)};
+            const uint32_t pp = pq[r];
+            int k = (int)(pp & 0xffffu), kb = (int)(pp >> 16);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int cnt = b[c + 1] - b[c];
+                if (cnt == 0) continue;
+                const int pos = cap - 1 - k;
+                const int cx0 = (c & 1) ? mx : x0, cx1 = (c & 1) ? x1 : mx;
+                nl[pos] = (uint32_t)b[c] | ((uint32_t)b[c + 1] << 16);
+                nx[pos] = (uint32_t)cx0 | ((uint32_t)cx1 << 16);
+                ndp[pos] = (uint8_t)(d + 1);
+                if (cnt > 1) {
+                    SortElem e;
+                    e.key = ((uint32_t)cnt << 16) | (uint32_t)cx0;
+                    e.val = (uint32_t)pos;
+                    vSize[kb] = e;
+                    kb++;
+                }
+                k++;
+            }
+        }
+        // pass D: untouched nodes keep their order behind the new ones
+        int u = 0;
+        for (int t0 = start; t0 < start + m; t0 += 64) {
+            const int t = t0 + lane;
+            const bool keep = t < start + m && !mark[t];
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const int pos = cap + u + __popcll(bal & ((1ull << lane) - 1));
+                nl[pos] = cl[t];
+                nx[pos] = cx[t];
+                ndp[pos] = cd[t];
+            }
+            u += __popcll(bal);
+        }
+        wave_lds_sync();
+        start = cap - C;
+        m = C + u;
+        nV = carryQ;
+        curB ^= 1;
+    };
+    bool finish = false;
+    while (!finish) {
+        int prevSize = m;
+        // breadth-first pass (:719-797): every node with more than one key is split, in list order
+        int nOrd = 0;
+        {
+            const uint32_t *cl = lohiB[curB];
+            for (int t0 = start; t0 < start + m; t0 += 64) {
+                const int t = t0 + lane;
+                bool big = false;
+                if (t < start + m) {
+                    const uint32_t lh = cl[t];
+                    big = (int)(lh >> 16) - (int)(lh & 0xffffu) > 1;
+                }
+                const unsigned long long bal = __ballot(big);
+                if (big) ord[nOrd + __popcll(bal & ((1ull << lane) - 1))] = (uint16_t)t;
+                nOrd += __popcll(bal);
+            }
+            wave_lds_sync();
+        }
+        split_round(nOrd, false);
+        if (m >= N || m == prevSize) {
+            finish = true;
+        } else if (m + 3 * nV > N) {
+            // careful phase (:799-875): largest nodes first, stop as soon as the list holds N
+            while (!finish) {
+                prevSize = m;
+                const int nPrev = nV;
+                for (int k = lane; k < nPrev; k += 64) vPrev[k] = vSize[k];
+                wave_lds_sync();
+                const unsigned long long ts = prof ? wall_clock64() : 0;
+                wave_std_sort(vPrev, nPrev, stack, bq, bq + cap, vSize, lane);
+                if (prof && lane == 0) {
+                    a.prof[level * 8 + 4] += wall_clock64() - ts;
+                    a.prof[level * 8 + 5] += (unsigned long long)nPrev;
+                    a.prof[level * 8 + 6] += 1;
+                }
+                for (int r = lane; r < nPrev; r += 64) ord[r] = (uint16_t)vPrev[nPrev - 1 - r].val;
+                wave_lds_sync();
+                split_round(nPrev, true);
+                if (m >= N || m == prevSize) finish = true;
+            }
+        }
+    }
+    tick();  // 2: rounds
+    // ---- 4. per retained node: largest response, earliest original index on ties ----
+    const int kept = min(m, a.levelMax[level]);
+    const uint32_t *cl = lohiB[curB];
+    FtSelKp *out = a.sel + (size_t)slot * g.maxKp + a.selOff[level];
+    for (int t = lane; t < kept; t += 64) {
+        const unsigned lh = cl[start + t];
+        const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
+        unsigned bestIdx = (unsigned)keys[lo];
+        unsigned bestC = cand[bestIdx];
+        for (int k = lo + 1; k < hi; k++) {
+            const unsigned i = (unsigned)keys[k];
+            const unsigned c = cand[i];
+            const unsigned r = c >> 24, rb = bestC >> 24;
+            if (r > rb || (r == rb && i < bestIdx)) {
+                bestIdx = i;
+                bestC = c;
+            }
+        }
+        FtSelKp s;
+        s.x = (short)((bestC & 0xfffu) + minB);  // ORBextractor.cc:1211-1217: add the border offset back
+        s.y = (short)(((bestC >> 12) & 0xfffu) + minB);
+        s.level = (short)level;
+        s.response = (short)(bestC >> 24);
+        out[t] = s;
+    }
+    tick();  // 3: pick
+    if (lane == 0) *cntOut = kept;
+}
+
+}  // namespace
+
+size_t ft_octree_smem_bytes(int poolCap) { return (size_t)oct_lds_layout(poolCap).total; }
+
+int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a) {
+    const size_t smem = ft_octree_smem_bytes(a.poolCap);
+    static bool attrSet = false;
+    if (!attrSet && smem > 64 * 1024) {
+        FT_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attrSet = true;
+    }
+    hipLaunchKernelGGL(k_octree, dim3(g.nlevels, batch), dim3(OCT_THREADS), smem, st, g, a);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}

@@ -189,11 +189,17 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     // sub-batch s-1 (stage-B streams)
     const int S = ft_pipeline_depth(batch);
     const int sb = (batch + S - 1) / S;
+    // device octree: candidates, selection and counts stay on the device, so the whole batch is enqueued
+    // without a single host synchronisation; otherwise the host octree of sub-batch s runs between the stages
+    const bool dev = L->deviceOctree && R->deviceOctree;
+    if (!dev) L->deviceOctree = R->deviceOctree = false;
     for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
         const int nb = std::min(sb, batch - b0);
-        rc = ft_extract_launch_a(L, b0, nb, L->evA[s]);
+        rc = ft_extract_launch_a(L, b0, nb, dev ? nullptr : L->evA[s]);
+        if (rc == FT_OK && dev) rc = ft_extract_launch_octree(L, s, b0, nb, L->evA[s]);
         if (rc != FT_OK) return rc;
-        rc = ft_extract_launch_a(R, b0, nb, R->evA[s]);
+        rc = ft_extract_launch_a(R, b0, nb, dev ? nullptr : R->evA[s]);
+        if (rc == FT_OK && dev) rc = ft_extract_launch_octree(R, s, b0, nb, R->evA[s]);
         if (rc != FT_OK) return rc;
     }
     const bool tm = fe->ctx->kernelTiming;
@@ -210,7 +216,10 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
         }
         return at.type == hipMemoryTypeHost;
     };
-    const bool direct = pinned(keysL) && pinned(descL) && pinned(keysR) && pinned(descR) && pinned(uright) && pinned(depth);
+    // (with the device octree the per-image counts are unknown until the end: whole rows are copied, which the
+    // caller's arrays must be able to hold)
+    const bool direct = pinned(keysL) && pinned(descL) && pinned(keysR) && pinned(descR) && pinned(uright) &&
+                        pinned(depth) && (!dev || capacity >= g.maxKp);
     const size_t kp = sizeof(ft_keypoint);
     auto d2h = [&](void *user, void *staging, const void *dev, size_t elem, int b0, int nb, int maxN) -> hipError_t {
         // rows of `elem`-byte records: device/staging stride maxKp, user stride capacity
@@ -225,15 +234,20 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     };
     for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
         const int nb = std::min(sb, batch - b0);
-        FtTimer tW;
-        FT_HIP(hipEventSynchronize(L->evA[s]));
-        FT_HIP(hipEventSynchronize(R->evA[s]));
-        tWait += tW.ms();
-        FtTimer tO;
-        ft_extractor *both[2] = {L, R};
-        rc = ft_extract_octree_multi(both, 2, b0, nb);  // one job for both cameras: one critical path
-        if (rc != FT_OK) return rc;
-        tOct += tO.ms();
+        if (dev) {
+            FT_HIP(hipStreamWaitEvent(L->streamB, L->evA[s], 0));
+            FT_HIP(hipStreamWaitEvent(R->streamB, R->evA[s], 0));
+        } else {
+            FtTimer tW;
+            FT_HIP(hipEventSynchronize(L->evA[s]));
+            FT_HIP(hipEventSynchronize(R->evA[s]));
+            tWait += tW.ms();
+            FtTimer tO;
+            ft_extractor *both[2] = {L, R};
+            rc = ft_extract_octree_multi(both, 2, b0, nb);  // one job for both cameras: one critical path
+            if (rc != FT_OK) return rc;
+            tOct += tO.ms();
+        }
         FtTimer tL;
         rc = ft_extract_launch_b(L, b0, nb, L->streamB);
         if (rc != FT_OK) return rc;
@@ -278,10 +292,10 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
         if (rc != FT_OK) return rc;
         int maxNL = 0, maxNR = 0;
         for (int b = b0; b < b0 + nb; b++) {
-            maxNL = std::max(maxNL, L->h_nSel[b]);
-            maxNR = std::max(maxNR, R->h_nSel[b]);
+            maxNL = std::max(maxNL, dev ? g.maxKp : L->h_nSel[b]);
+            maxNR = std::max(maxNR, dev ? g.maxKp : R->h_nSel[b]);
         }
-        if (maxNL > capacity || maxNR > capacity) {
+        if (!dev && (maxNL > capacity || maxNR > capacity)) {
             ft_set_error("stereo front end: output capacity too small (use ft_extractor_max_keypoints)");
             return FT_ERR_CAPACITY;
         }
@@ -298,12 +312,21 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
         FT_HIP(hipMemcpyAsync(fe->h_nMatches + b0, fe->d_nMatches + b0, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
         tLaunch += tL.ms();
     }
-    fe->ctx->addStat("stereo.octree(host,both)", tOct);
+    rc = ft_extract_finish_counts(L, batch, st);
+    if (rc == FT_OK) rc = ft_extract_finish_counts(R, batch, st);
+    if (rc != FT_OK) return rc;
+    if (!dev) fe->ctx->addStat("stereo.octree(host,both)", tOct);
     fe->ctx->addStat("stereo.host_wait_stageA", tWait);
     fe->ctx->addStat("stereo.host_launch_stageB", tLaunch);
     fe->ctx->addStat("stereo.submit.total", tAll.ms());
     // everything is enqueued; ft_stereo_frontend_wait drains the streams and finishes the outputs
     auto &P = fe->pending;
+    P.imagesL.assign(imagesL, imagesL + batch);
+    P.imagesR.assign(imagesR, imagesR + batch);
+    P.onDevice = on_device;
+    P.width = width;
+    P.height = height;
+    P.stride = stride;
     P.active = true;
     P.batch = batch;
     P.capacity = capacity;
@@ -329,10 +352,31 @@ int ft_stereo_frontend_wait(ft_stereo_frontend *fe) {
     fe->ctx->addStat("stereo.host_tail_sync", tTail.ms());
     L->evt.resolve(fe->ctx);
     R->evt.resolve(fe->ctx);
+    if ((L->deviceOctree && L->h_overflow[0]) || (R->deviceOctree && R->h_overflow[0])) {
+        // a level exceeded the device octree's limits (FT_OCT_MAXN candidates): redo this batch with the host
+        // octree.  Same inputs, same outputs, only slower.
+        fe->ctx->addStat("stereo.device_octree_fallbacks", 1);
+        L->h_overflow[0] = R->h_overflow[0] = 0;
+        FT_HIP(hipMemset(L->d_overflow, 0, sizeof(int)));
+        FT_HIP(hipMemset(R->d_overflow, 0, sizeof(int)));
+        const bool dl = L->deviceOctree, dr = R->deviceOctree;
+        L->deviceOctree = R->deviceOctree = false;
+        std::vector<const uint8_t *> il = P.imagesL, ir = P.imagesR;
+        rc = ft_stereo_frontend_submit(fe, il.data(), ir.data(), P.batch, P.onDevice, P.width, P.height, P.stride, P.keysL,
+                                       P.descL, P.nL, P.keysR, P.descR, P.nR, P.capacity, P.uright, P.depth, P.nMatches);
+        if (rc == FT_OK) rc = ft_stereo_frontend_wait(fe);
+        L->deviceOctree = dl;
+        R->deviceOctree = dr;
+        return rc;
+    }
     const size_t kp = sizeof(ft_keypoint);
     const int capacity = P.capacity;
     for (int b = 0; b < P.batch; b++) {
         const int nl = L->h_nSel[b], nr = R->h_nSel[b];
+        if (nl > capacity || nr > capacity) {
+            ft_set_error("stereo front end: output capacity too small (use ft_extractor_max_keypoints)");
+            return FT_ERR_CAPACITY;
+        }
         if (!P.direct) {
             if (P.keysL) memcpy(P.keysL + (size_t)b * capacity, L->h_keys + (size_t)b * g.maxKp, kp * nl);
             if (P.descL) memcpy(P.descL + (size_t)b * capacity * 32, L->h_desc + (size_t)b * g.maxKp * 32, (size_t)32 * nl);

@@ -235,20 +235,144 @@ int distribute_octree_paths(const uint32_t *cand, int n, int minX, int maxX, int
     std::vector<uint16_t> freeList(poolCap);
     std::vector<op::SortElem> vSize(poolCap), vPrev(poolCap);
     op::Workspace ws{pool.data(), freeList.data(), vSize.data(), vPrev.data(), poolCap};
-    auto bestOf = [&](int lo, int hi) {
+    std::vector<int> res;
+    auto emit = [&](int, int lo, int hi) {
         int best = (int)(uint32_t)keys[lo];
         for (int k = lo + 1; k < hi; k++) {
             const int i = (int)(uint32_t)keys[k];
             const unsigned r = cand[i] >> 24, rb = cand[best] >> 24;
             if (r > rb || (r == rb && i < best)) best = i;
         }
-        return best;
+        res.push_back(best);
     };
-    std::vector<int> res(std::max(N + 8, 4 * R.nIni + 8));
-    const int k = op::distribute(codes.data(), n, R, N, ws, bestOf, res.data(), (int)res.size());
+    const int k = op::distribute([&](int i) { return codes[i]; }, n, R, N, ws, emit);
     if (k < 0) return -1;
     for (int i = 0; i < k && i < (int)res.size(); i++) out.push_back(res[i]);
     return k;
+}
+
+// Single-thread host statement of the ROUND formulation the device kernel executes (kernels_octree.hip):
+// the node list is an array, and a whole pass of the reference - every node of a breadth-first pass, or
+// the first `nproc` nodes of the size-sorted careful pass - is split at once.  The list after a pass is
+//   [children of the last processed node, n4..n1] ... [children of the first processed node, n4..n1]
+//   followed by the nodes that were not split, in their old order
+// (std::list::push_front of every child + erase of the parent, ORBextractor.cc:741-789 / :808-848), so
+// every position is a prefix sum.  Only the careful pass's std::sort stays sequential (replayed literally).
+int distribute_octree_rounds(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
+                             std::vector<int> &out) {
+    if (n <= 0) return 0;
+    if (n > 65535) return -1;
+    const op::Roots R = op::make_roots(minX, maxX, minY, maxY);
+    std::vector<uint64_t> keys(n);
+    for (int i = 0; i < n; i++)
+        keys[i] = ((uint64_t)op::path_code(R, (int)(cand[i] & 0xfffu), (int)((cand[i] >> 12) & 0xfffu)) << 32) | (uint32_t)i;
+    std::sort(keys.begin(), keys.end());
+    auto codeAt = [&](int i) -> uint32_t { return (uint32_t)(keys[i] >> 32); };
+    struct RNode {
+        int lo, hi, x0, x1, depth;
+    };
+    const int cap = std::max(N + 3, 4 * R.nIni) + 16;
+    std::vector<RNode> bufA(2 * cap), bufB(2 * cap);
+    RNode *cur = bufA.data(), *nxt = bufB.data();
+    std::vector<op::SortElem> vSize(cap), vPrev(cap);
+    std::vector<int> ord(cap), P(cap), Q(cap), b1(cap), b2(cap), b3(cap);
+    std::vector<uint8_t> mark(2 * cap);
+    int start = cap, m = 0;
+    for (int s = 0; s < R.nIni; s++) {
+        const int lo = op::lower_bound_code(codeAt, 0, n, (uint32_t)s << (2 * op::kMaxDepth));
+        const int hi = op::lower_bound_code(codeAt, lo, n, (uint32_t)(s + 1) << (2 * op::kMaxDepth));
+        if (hi == lo) continue;
+        int x0, x1;
+        op::root_bounds(R, s, x0, x1);
+        cur[start + m++] = RNode{lo, hi, x0, x1, 0};
+    }
+    int nV = 0;
+    // splits ord[0..nOrd) (absolute positions in cur) in that order; with useStop the pass ends after the
+    // split that brings the list to N nodes
+    auto split_round = [&](int nOrd, bool useStop) {
+        int cum = m, nproc = nOrd, p = 0, q = 0;
+        for (int r = 0; r < nOrd; r++) {
+            const RNode nd = cur[ord[r]];
+            int b[5] = {nd.lo, nd.hi, nd.hi, nd.hi, nd.hi};
+            if (nd.depth < op::kMaxDepth) {
+                const int shift = 2 * (op::kMaxDepth - 1 - nd.depth);
+                const uint32_t prefix = codeAt(nd.lo) >> (shift + 2);
+                for (int k = 1; k < 4; k++) b[k] = op::lower_bound_code(codeAt, b[k - 1], nd.hi, ((prefix << 2) | (uint32_t)k) << shift);
+            }
+            b1[r] = b[1]; b2[r] = b[2]; b3[r] = b[3];
+            int nch = 0, nbig = 0;
+            for (int k = 0; k < 4; k++) {
+                nch += b[k + 1] > b[k];
+                nbig += b[k + 1] - b[k] > 1;
+            }
+            P[r] = p; Q[r] = q;
+            p += nch; q += nbig;
+            cum += nch - 1;
+            if (useStop && cum >= N) {
+                nproc = r + 1;
+                break;
+            }
+        }
+        const int C = p;
+        for (int t = start; t < start + m; t++) mark[t] = 0;
+        for (int r = 0; r < nproc; r++) mark[ord[r]] = 1;
+        for (int r = 0; r < nproc; r++) {
+            const RNode nd = cur[ord[r]];
+            const int b[5] = {nd.lo, b1[r], b2[r], b3[r], nd.hi};
+            const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);
+            int k = 0, kb = 0;
+            for (int c = 0; c < 4; c++) {
+                const int cnt = b[c + 1] - b[c];
+                if (cnt == 0) continue;
+                const int pos = cap - 1 - (P[r] + k);
+                nxt[pos] = RNode{b[c], b[c + 1], (c & 1) ? mx : nd.x0, (c & 1) ? nd.x1 : mx, nd.depth + 1};
+                if (cnt > 1) {
+                    vSize[Q[r] + kb].key = ((uint32_t)cnt << 16) | (uint32_t)nxt[pos].x0;
+                    vSize[Q[r] + kb].val = (uint32_t)pos;
+                    kb++;
+                }
+                k++;
+            }
+        }
+        int u = 0;
+        for (int t = start; t < start + m; t++)
+            if (!mark[t]) nxt[cap + u++] = cur[t];
+        start = cap - C;
+        m = C + u;
+        nV = q;
+        std::swap(cur, nxt);
+    };
+    bool finish = false;
+    while (!finish) {
+        int prevSize = m;
+        int nOrd = 0;
+        for (int t = start; t < start + m; t++)
+            if (cur[t].hi - cur[t].lo > 1) ord[nOrd++] = t;
+        split_round(nOrd, false);
+        if (m >= N || m == prevSize) {
+            finish = true;
+        } else if (m + 3 * nV > N) {
+            while (!finish) {
+                prevSize = m;
+                const int nPrev = nV;
+                for (int k = 0; k < nPrev; k++) vPrev[k] = vSize[k];
+                op::std_sort_replay(vPrev.data(), vPrev.data() + nPrev);
+                for (int r = 0; r < nPrev; r++) ord[r] = (int)vPrev[nPrev - 1 - r].val;
+                split_round(nPrev, true);
+                if (m >= N || m == prevSize) finish = true;
+            }
+        }
+    }
+    for (int t = start; t < start + m; t++) {
+        int best = (int)(uint32_t)keys[cur[t].lo];
+        for (int k = cur[t].lo + 1; k < cur[t].hi; k++) {
+            const int i = (int)(uint32_t)keys[k];
+            const unsigned r = cand[i] >> 24, rb = cand[best] >> 24;
+            if (r > rb || (r == rb && i < best)) best = i;
+        }
+        out.push_back(best);
+    }
+    return m;
 }
 
 }  // namespace ft

@@ -43,6 +43,11 @@ int distribute_octree(const uint32_t *cand, int n, int minX, int maxX, int minY,
 int distribute_octree_paths(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
                             std::vector<int> &out);
 
+// the same result through the round formulation (arrays + prefix sums, see octree.cpp) that the device
+// kernel executes with one wave per level
+int distribute_octree_rounds(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
+                             std::vector<int> &out);
+
 // upper bound of what distribute_octree can return for a level (used to size output buffers)
 int octree_max_result(int minX, int maxX, int minY, int maxY, int N);
 

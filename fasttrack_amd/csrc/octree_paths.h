@@ -137,32 +137,33 @@ OP_HD inline SortElem *ss_partition_pivot(SortElem *first, SortElem *last) {
 }
 
 // std::sort(first, last, compareNodes).  The recursion of __introsort_loop (recurse right, loop left) is
-// unrolled with an explicit stack of (first, last, depth) ranges processed in the same order.
-OP_HD inline void std_sort_replay(SortElem *first, SortElem *last) {
+// unrolled with an explicit stack of (first, last, depth) ranges processed in the same order; `stack` holds
+// 64 frames (the device passes LDS, a private array would live in scratch memory).
+struct SortFrame {
+    uint16_t f, l, depth, pad;
+};
+
+OP_HD inline void std_sort_replay(SortElem *first, SortElem *last, SortFrame *stack) {
     const int n = (int)(last - first);
     if (n <= 0) return;
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) lg++;
-    struct Frame {
-        SortElem *f, *l;
-        int depth;
-    };
-    Frame stack[64];
     int sp = 0;
-    stack[sp++] = Frame{first, last, 2 * lg};
+    stack[sp++] = SortFrame{0, (uint16_t)n, (uint16_t)(2 * lg), 0};
     while (sp > 0) {
-        Frame fr = stack[--sp];
-        while (fr.l - fr.f > 16) {
-            if (fr.depth == 0) {
-                ss_heap_sort(fr.f, fr.l);
+        const SortFrame fr = stack[--sp];
+        int f = fr.f, l = fr.l, depth = fr.depth;
+        while (l - f > 16) {
+            if (depth == 0) {
+                ss_heap_sort(first + f, first + l);
                 break;
             }
-            --fr.depth;
-            SortElem *cut = ss_partition_pivot(fr.f, fr.l);
+            --depth;
+            const int cut = (int)(ss_partition_pivot(first + f, first + l) - first);
             // the reference recurses into [cut, last) first and then continues with [first, cut): the two
             // ranges are disjoint, so running the left one now and the right one later gives the same array
-            if (sp < 64) stack[sp++] = Frame{cut, fr.l, fr.depth};
-            fr.l = cut;
+            if (sp < 64) stack[sp++] = SortFrame{(uint16_t)cut, (uint16_t)l, (uint16_t)depth, 0};
+            l = cut;
         }
     }
     // __final_insertion_sort
@@ -172,6 +173,76 @@ OP_HD inline void std_sort_replay(SortElem *first, SortElem *last) {
     } else {
         ss_insertion_sort(first, last);
     }
+}
+
+OP_HD inline void std_sort_replay(SortElem *first, SortElem *last) {
+    SortFrame stack[64];
+    std_sort_replay(first, last, stack);
+}
+
+// ---- the same std::sort as data-parallel steps (what the device kernel executes with one wave) ----------
+// (a) __unguarded_partition is a two-pointer loop, but which elements it swaps is a closed form: with
+//     A = positions of [first+1, last) holding an element that is not < pivot, ascending, and
+//     B = positions holding an element that is not > pivot, descending, it swaps A[k] <-> B[k] for every
+//     k < K, K = number of leading pairs with A[k] < B[k] (all swaps touch positions outside (A[k], B[k]), so
+//     the scans between them see original data), and returns min(A[K], B[K-1]) (B[-1] = last).
+// (b) __final_insertion_sort is a stable insertion sort of an array whose inversions all lie inside the
+//     <= 16-element ranges introsort left unsorted: every element moves to
+//     i - #{j in [i-16, i): key_j > key_i} + #{j in (i, i+16]: key_j < key_i}.
+// This host statement exists so that the claim is checked against libstdc++ on the CPU
+// (tests/cpp/test_sort_replay.cpp); posA / posB / tmp hold (last - first) entries.
+inline int ss_partition_pairs(SortElem *a, int f, int l, uint16_t *posA, uint16_t *posB) {
+    SortElem *first = a + f;
+    SortElem *pa = first + 1, *pb = first + (l - f) / 2, *pc = a + l - 1;
+    if (se_less(*pa, *pb)) {
+        if (se_less(*pb, *pc)) se_swap(*first, *pb);
+        else if (se_less(*pa, *pc)) se_swap(*first, *pc);
+        else se_swap(*first, *pa);
+    } else if (se_less(*pa, *pc)) se_swap(*first, *pa);
+    else if (se_less(*pb, *pc)) se_swap(*first, *pc);
+    else se_swap(*first, *pb);
+    const uint32_t pv = first->key;
+    int nA = 0, nB = 0;
+    for (int i = f + 1; i < l; i++)
+        if (!(a[i].key < pv)) posA[nA++] = (uint16_t)i;
+    for (int i = l - 1; i > f; i--)
+        if (!(pv < a[i].key)) posB[nB++] = (uint16_t)i;
+    int K = 0;
+    while (K < nA && K < nB && posA[K] < posB[K]) K++;
+    for (int k = 0; k < K; k++) se_swap(a[posA[k]], a[posB[k]]);
+    const int bK = K ? posB[K - 1] : l;
+    return (K < nA && posA[K] < bK) ? posA[K] : bK;
+}
+
+inline void std_sort_replay_steps(SortElem *first, SortElem *last, SortFrame *stack, uint16_t *posA, uint16_t *posB,
+                                  SortElem *tmp) {
+    const int n = (int)(last - first);
+    if (n <= 0) return;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) lg++;
+    int sp = 0;
+    stack[sp++] = SortFrame{0, (uint16_t)n, (uint16_t)(2 * lg), 0};
+    while (sp > 0) {
+        const SortFrame fr = stack[--sp];
+        int f = fr.f, l = fr.l, depth = fr.depth;
+        while (l - f > 16) {
+            if (depth == 0) {
+                ss_heap_sort(first + f, first + l);
+                break;
+            }
+            --depth;
+            const int cut = ss_partition_pairs(first, f, l, posA, posB);
+            if (sp < 64) stack[sp++] = SortFrame{(uint16_t)cut, (uint16_t)l, (uint16_t)depth, 0};
+            l = cut;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        int pos = i;
+        for (int j = (i > 16 ? i - 16 : 0); j < i; j++) pos -= first[j].key > first[i].key;
+        for (int j = i + 1; j <= i + 16 && j < n; j++) pos += first[j].key < first[i].key;
+        tmp[pos] = first[i];
+    }
+    for (int i = 0; i < n; i++) first[i] = tmp[i];
 }
 
 // ---- path codes ---------------------------------------------------------------------------------------
@@ -232,25 +303,25 @@ struct Workspace {
     int poolCap;
 };
 
-// first index in [lo, hi) whose code is >= target (codes ascending)
-OP_HD inline int lower_bound_code(const uint32_t *codes, int lo, int hi, uint32_t target) {
+// first index in [lo, hi) whose code is >= target (codes ascending); codeAt(i) returns the i-th sorted code
+template <class CodeAt>
+OP_HD inline int lower_bound_code(CodeAt codeAt, int lo, int hi, uint32_t target) {
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (codes[mid] < target) lo = mid + 1;
+        if (codeAt(mid) < target) lo = mid + 1;
         else hi = mid;
     }
     return lo;
 }
 
 // Replays DistributeOctTree on keys sorted by (path code, original index).
-//   codes[n]      ascending path codes
-//   best_of(lo,hi) must return the ORIGINAL index of the key with the largest response in the sorted range,
-//                 earliest original index on ties (the reference keeps the first maximum in emission order)
-//   out[]         receives those indices in the reference's result (list) order
-// returns the number of retained keys, or -1 when the workspace is too small.
-template <class BestOf>
-OP_HD inline int distribute(const uint32_t *codes, int n, const Roots &R, int N, Workspace &ws, BestOf best_of, int *out,
-                            int outCap) {
+//   codeAt(i)      i-th path code of the sorted keys, i in [0, n)
+//   emit(pos, lo, hi) is called once per retained node in the reference's result (list) order with the node's
+//                  range in the sorted array; the caller picks the key with the largest response there,
+//                  earliest original index on ties (the reference keeps the first maximum in emission order)
+// returns the number of retained nodes, or -1 when the workspace is too small.
+template <class CodeAt, class Emit>
+OP_HD inline int distribute(CodeAt codeAt, int n, const Roots &R, int N, Workspace &ws, Emit emit) {
     if (n <= 0) return 0;
     Node *pool = ws.pool;
     int nFree = 0, poolUsed = 0;
@@ -288,8 +359,8 @@ OP_HD inline int distribute(const uint32_t *codes, int n, const Roots &R, int N,
     };
     // roots: keys of root s are the codes with top bits == s
     for (int s = 0; s < R.nIni; s++) {
-        const int lo = lower_bound_code(codes, 0, n, (uint32_t)s << (2 * kMaxDepth));
-        const int hi = lower_bound_code(codes, lo, n, (uint32_t)(s + 1) << (2 * kMaxDepth));
+        const int lo = lower_bound_code(codeAt, 0, n, (uint32_t)s << (2 * kMaxDepth));
+        const int hi = lower_bound_code(codeAt, lo, n, (uint32_t)(s + 1) << (2 * kMaxDepth));
         if (hi == lo) continue;  // empty initial nodes are erased at once (:704-705)
         const int i = alloc();
         if (i < 0) return -1;
@@ -317,8 +388,8 @@ OP_HD inline int distribute(const uint32_t *codes, int n, const Roots &R, int N,
             b[1] = b[2] = b[3] = nd.hi;
         } else {
             const int shift = 2 * (kMaxDepth - 1 - d);
-            const uint32_t prefix = codes[nd.lo] >> (shift + 2);
-            for (int q = 1; q < 4; q++) b[q] = lower_bound_code(codes, b[q - 1], nd.hi, ((prefix << 2) | (uint32_t)q) << shift);
+            const uint32_t prefix = codeAt((int)nd.lo) >> (shift + 2);
+            for (int q = 1; q < 4; q++) b[q] = lower_bound_code(codeAt, b[q - 1], nd.hi, ((prefix << 2) | (uint32_t)q) << shift);
         }
         const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
         const int bx[4][4] = {{nd.x0, nd.y0, mx, my}, {mx, nd.y0, nd.x1, my}, {nd.x0, my, mx, nd.y1}, {mx, my, nd.x1, nd.y1}};
@@ -386,7 +457,7 @@ OP_HD inline int distribute(const uint32_t *codes, int n, const Roots &R, int N,
     if (overflow) return -1;
     int kept = 0;
     for (int it = head; it != kNil; it = pool[it].next) {
-        if (kept < outCap) out[kept] = best_of((int)pool[it].lo, (int)pool[it].hi);
+        emit(kept, (int)pool[it].lo, (int)pool[it].hi);
         kept++;
     }
     return kept;

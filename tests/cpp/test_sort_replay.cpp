@@ -20,10 +20,19 @@ int main() {
         if (trial % 7 == 0) std::sort(a.begin(), a.end(), [](const SortElem &x, const SortElem &y) { return x.key < y.key; });
         if (trial % 11 == 0) std::reverse(a.begin(), a.end());
         b = a;
+        const std::vector<SortElem> orig = a;
         std::sort(a.begin(), a.end(), [](const SortElem &x, const SortElem &y) { return x.key < y.key; });
         ft::op::std_sort_replay(b.data(), b.data() + n);
         for (int i = 0; i < n; i++)
             if (a[i].key != b[i].key || a[i].val != b[i].val) { bad++; break; }
+        {  // the data-parallel statement of the same sort (what the device kernel runs)
+            std::vector<SortElem> e = orig, tmp(n + 1);
+            std::vector<uint16_t> pa(n + 1), pb(n + 1);
+            ft::op::SortFrame stack[64];
+            ft::op::std_sort_replay_steps(e.data(), e.data() + n, stack, pa.data(), pb.data(), tmp.data());
+            for (int i = 0; i < n; i++)
+                if (a[i].key != e[i].key || a[i].val != e[i].val) { bad++; break; }
+        }
         // heap-sort fallback path
         std::vector<SortElem> c(n), d;
         for (int i = 0; i < n; i++) c[i] = SortElem{(uint32_t)(rng() % distinct), (uint32_t)i};
@@ -39,11 +48,14 @@ int main() {
         // Musser's construction: evens ascending then odds pattern
         for (int i = 0; i < n / 2; i++) { a[i] = SortElem{(uint32_t)(i % 2 ? i + n / 2 : i / 2 * 2 + 1 + (uint32_t)0), (uint32_t)i}; }
         for (int i = n / 2; i < n; i++) a[i] = SortElem{(uint32_t)((i - n / 2) * 2), (uint32_t)i};
-        std::vector<SortElem> b = a;
+        std::vector<SortElem> b = a, e = a, tmp(n + 1);
+        std::vector<uint16_t> pa(n + 1), pb(n + 1);
+        ft::op::SortFrame stack[64];
         std::sort(a.begin(), a.end(), [](const SortElem &x, const SortElem &y) { return x.key < y.key; });
         ft::op::std_sort_replay(b.data(), b.data() + n);
+        ft::op::std_sort_replay_steps(e.data(), e.data() + n, stack, pa.data(), pb.data(), tmp.data());
         for (int i = 0; i < n; i++)
-            if (a[i].key != b[i].key || a[i].val != b[i].val) { bad++; break; }
+            if (a[i].key != b[i].key || a[i].val != b[i].val || a[i].key != e[i].key || a[i].val != e[i].val) { bad++; break; }
     }
     std::printf("mismatches %d\n", bad);
     return bad ? 1 : 0;
