@@ -692,6 +692,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
             ex->ctx->addStat("extract.device_octree_fallbacks", 1);
         }
         const bool dev = ex->deviceOctree;
+        if (dev) ex->ctx->addStat("extract.device_octree_batches", 0);
         for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
             const int nb = std::min(sb, batch - b0);
             rc = ft_extract_launch_a(ex, b0, nb, dev ? nullptr : ex->evA[s]);

@@ -166,7 +166,7 @@ __device__ void wave_std_sort(SortElem *a, int n, SortFrame *stack, uint16_t *po
     wave_lds_sync();
 }
 
-constexpr int OCT_THREADS = 256;  // codes + key sort use the whole block, the rounds only its first wave
+constexpr int OCT_THREADS = 512;  // codes + key sort use the whole block, the rounds only its first wave
 
 __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

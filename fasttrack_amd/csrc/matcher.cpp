@@ -193,6 +193,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     // without a single host synchronisation; otherwise the host octree of sub-batch s runs between the stages
     const bool dev = L->deviceOctree && R->deviceOctree;
     if (!dev) L->deviceOctree = R->deviceOctree = false;
+    if (dev) fe->ctx->addStat("stereo.device_octree_batches", 0);
     for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
         const int nb = std::min(sb, batch - b0);
         rc = ft_extract_launch_a(L, b0, nb, dev ? nullptr : L->evA[s]);

@@ -125,10 +125,12 @@ def test_std_sort_replay_matches_libstdcxx(tmp_path):
     assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout + out.stderr
 
 
-def test_path_code_octree_equals_oracle(monkeypatch):
-    """The path-code formulation the device kernel runs (octree_paths.h), executed single-threaded on the host
-    through ft_octree_distribute with FT_OCTREE_PATHS=1, equals the oracle - in a fresh process because the
-    switch is read once."""
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_path_code_octree_equals_oracle(mode):
+    """The path-code formulations the device kernel is built from (octree_paths.h; 1 = node-list replay over
+    sorted path codes, 2 = the round formulation k_octree executes: array list + prefix sums), executed
+    single-threaded on the host through ft_octree_distribute with FT_OCTREE_PATHS=<mode>, equal the oracle -
+    in a fresh process because the switch is read once."""
     code = r'''
 import numpy as np, ctypes as C, sys
 sys.path.insert(0, %r)
@@ -142,12 +144,13 @@ def octree(xys, a, b, c, d, N):
 rng = np.random.default_rng(5)
 for trial in range(300):
     W, H = int(rng.integers(40, 1300)), int(rng.integers(40, 720))
+    if trial %% 7 == 0: W, H = int(rng.integers(300, 2000)), int(rng.integers(20, 60))  # many root nodes
     n, N = int(rng.integers(1, 5000)), int(rng.integers(1, 500))
     pts = np.unique(np.stack([rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)], 1), axis=0); rng.shuffle(pts)
     xys = np.concatenate([pts, rng.integers(7, 12, (len(pts), 1))], 1).astype(np.int32)
     assert np.array_equal(ob.distribute_octree(xys, 16, 16 + W, 16, 16 + H, N), octree(xys, 16, 16 + W, 16, 16 + H, N)), trial
 print("ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FT_OCTREE_PATHS="1")
+    env = dict(os.environ, FT_OCTREE_PATHS=mode)
     out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

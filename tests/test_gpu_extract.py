@@ -156,3 +156,56 @@ def test_getters_match_oracle_tables(ctx):
     assert np.array_equal(ex.features_per_level(), ob.features_per_level(1200, 1.2, 8))
     lw, lh = ob.level_sizes(752, 480, 1.2, 8)
     assert [ex.level_size(l) for l in range(8)] == list(zip(lw.tolist(), lh.tolist()))
+
+
+def _calls(ctx, name):
+    try:
+        return ctx.get_stat(name)[1]
+    except Exception:
+        return 0
+
+
+def test_device_octree_equals_host_octree(ctx, monkeypatch):
+    """k_octree (default) and the host octree (FT_DEVICE_OCTREE=0, read when the extractor is created) select
+    the same keypoints in the same order - and both equal the oracle."""
+    for (w, h, nf) in [(752, 480, 1200), (1280, 720, 2000), (320, 240, 500)]:
+        monkeypatch.setenv("FT_DEVICE_OCTREE", "0")
+        ex_host = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=3)
+        monkeypatch.delenv("FT_DEVICE_OCTREE")
+        ex_dev = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=3)
+        imgs = [synth.make_image(w, h, seed=40 + i, density=d) for i, d in enumerate((1.0, 0.3, 2.0))]
+        before = _calls(ctx, "extract.device_octree_batches"), _calls(ctx, "extract.device_octree_fallbacks")
+        rh = ex_host.extract_batch(imgs)
+        assert _calls(ctx, "extract.device_octree_batches") == before[0], "FT_DEVICE_OCTREE=0 must keep the octree on the host"
+        rd = ex_dev.extract_batch(imgs)
+        assert _calls(ctx, "extract.device_octree_batches") == before[0] + 1, "the device octree did not run"
+        assert _calls(ctx, "extract.device_octree_fallbacks") == before[1], "unexpected fallback to the host octree"
+        oex = ob.Extractor(nf)
+        for img, (hk, hd, hm), (dk, dd, dm) in zip(imgs, rh, rd):
+            ok, od, om = oex.extract(img)
+            _check_same(dk, dd, ok, od)
+            _check_same(hk, hd, ok, od)
+            assert hm == om and dm == om
+
+
+def test_device_octree_overflow_falls_back_to_host(ctx):
+    """more candidates in one level than k_octree sorts in LDS (FT_OCT_MAXN = 4096): the kernel raises its
+    overflow flag and the batch is redone with the host octree - same result as the oracle, and the next
+    batch goes back to the device."""
+    w, h, nf = 1280, 720, 2000
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=2)
+    oex = ob.Extractor(nf)
+    noisy, calm = synth.make_noise(w, h, seed=3), synth.make_image(w, h, seed=4)
+    f0, b0 = _calls(ctx, "extract.device_octree_fallbacks"), _calls(ctx, "extract.device_octree_batches")
+    res = ex.extract_batch([noisy, calm])
+    oex.extract(noisy)
+    assert max(len(oex.candidates(l)) for l in range(8)) > 4096, "test input no longer overflows"
+    assert _calls(ctx, "extract.device_octree_fallbacks") == f0 + 1
+    for img, (gk, gd, gm) in zip([noisy, calm], res):
+        ok, od, om = oex.extract(img)
+        _check_same(gk, gd, ok, od)
+    res = ex.extract_batch([calm, calm])
+    assert _calls(ctx, "extract.device_octree_fallbacks") == f0 + 1
+    assert _calls(ctx, "extract.device_octree_batches") == b0 + 2
+    ok, od, om = oex.extract(calm)
+    _check_same(res[1][0], res[1][1], ok, od)

@@ -127,6 +127,35 @@ def test_stereo_frontend_submit_wait_two_in_flight(ctx):
             assert np.array_equal(gk, kL) and np.array_equal(gd, dL) and np.array_equal(gu, o["uright"]) and gn == o["n"]
 
 
+def test_stereo_frontend_device_octree_overflow(ctx):
+    """a pair whose level-0 candidates exceed what k_octree sorts in LDS: wait() re-submits the batch with the
+    host octree; the outputs still equal the oracle's, and the following batch runs on the device again"""
+    w, h, nf, B = 1280, 720, 2000, 2
+    intr = synth.intrinsics(w, h)
+    fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
+
+    def calls(name):
+        try:
+            return ctx.get_stat(name)[1]
+        except Exception:
+            return 0
+    f0, b0 = calls("stereo.device_octree_fallbacks"), calls("stereo.device_octree_batches")
+    noisy = (synth.make_noise(w, h, seed=8), synth.make_noise(w, h, seed=9))
+    calm = synth.make_stereo_pair(w, h, 21)
+    for k, pairs in enumerate(([noisy, calm], [calm, calm])):
+        outs = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
+        for (imL, imR), out in zip(pairs, outs):
+            oL, oR = ob.Extractor(nf), ob.Extractor(nf)
+            kL, dL, _ = oL.extract(imL)
+            kR, dR, _ = oR.extract(imR)
+            o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+            assert np.array_equal(out["keysL"], kL) and np.array_equal(out["keysR"], kR)
+            assert np.array_equal(out["descL"], dL) and np.array_equal(out["descR"], dR)
+            assert out["n"] == o["n"] and np.array_equal(out["uright"], o["uright"]) and np.array_equal(out["depth"], o["depth"])
+        assert calls("stereo.device_octree_fallbacks") == f0 + 1, k
+    assert calls("stereo.device_octree_batches") == b0 + 2
+
+
 def test_fisheye_match(ctx):
     rng = np.random.default_rng(2)
     fr = sc.oracle_stereo_frame(512, 512, 2000, 6)
