@@ -212,3 +212,17 @@ int ft_memcpy_d2h(ft_context *ctx, void *dst, const void *src, size_t bytes) {
 }
 
 }  // extern "C"
+
+int ft_debug_repeat(const char *name) {
+    static const char *env = getenv("FT_DEBUG_REPEAT");
+    if (!env || !*env) return 1;
+    const size_t n = strlen(name);
+    for (const char *p = env; *p;) {
+        const char *e = strchr(p, ',');
+        const size_t len = e ? (size_t)(e - p) : strlen(p);
+        if (len == n && strncmp(p, name, n) == 0) return 2;
+        p += len;
+        if (*p == ',') p++;
+    }
+    return 1;
+}

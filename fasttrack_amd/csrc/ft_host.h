@@ -161,7 +161,7 @@ struct ft_stereo_frontend {
 
 int ft_set_device(const ft_context *ctx);
 int ft_usable_cpus();
-int ft_pipeline_depth(int batch);
+int ft_pipeline_depth(int batch, bool deviceOctree);
 // validation, level-0 pointers / uploads of a whole batch (async on ex->stream)
 int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width, int height,
                        int stride);

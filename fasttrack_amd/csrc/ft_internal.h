@@ -79,6 +79,11 @@ struct FtOctArgs {
 };
 
 void ft_set_error(const std::string &msg);
+// Profiling aid: FT_DEBUG_REPEAT=<name>[,<name>...] makes the launcher of that kernel (pyr, fast, compact, octree,
+// orient, rowsort, stereo, median) enqueue it twice.  Every kernel is idempotent, so results do not change; the
+// increase of the step time is the kernel's marginal cost inside the overlapped pipeline, which neither the
+// per-launch event times nor the rocprof durations (both inflated by concurrency) show.
+int ft_debug_repeat(const char *name);
 int ft_hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 #define FT_HIP(call)                                                              \

@@ -171,6 +171,9 @@ __device__ __forceinline__ int fast_score(const int d[16]) {
 #ifndef FC_UNROLL
 #define FC_UNROLL 2
 #endif
+#ifndef FC_ROWS
+#define FC_ROWS 4     // rows per trip of the column-mapped rejection pass (>= 3)
+#endif
 #define FC_CORN 256   // corners kept for NMS / emission; a cell with more falls back to scanning the plane
 __host__ __device__ __forceinline__ int fc_pitch(int wCell, int TP) { return TP ? TP : ((wCell + 12) & ~3); }
 __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int TP) {
@@ -181,22 +184,44 @@ __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int 
 __host__ __device__ __forceinline__ int fc_score_bytes(int wCell, int hCell, int TP) { return (((hCell + 2) * fc_pitch(wCell, TP)) + 15) & ~15; }
 __host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + FC_CORN); }
 
+#ifdef FT_FAST_PROF  // developer build only: wall-clock ticks (10 ns) per phase summed over all waves
+__device__ unsigned long long g_fastProf[8];
+#define FT_PROF_T(i)                                                         \
+    {                                                                        \
+        const unsigned long long t_ = wall_clock64();                        \
+        if (lane == 0 && (blockIdx.x & 31) == 0) atomicAdd(&g_fastProf[i], t_ - tProf); \
+        tProf = t_;                                                          \
+    }
+#else
+#define FT_PROF_T(i)
+#endif
+
+#ifndef FC_WPB
+#define FC_WPB 1  // independent waves (cells) per workgroup: the CU holds at most 16 workgroups, so one-wave groups cap it at 16 waves
+#endif
+
 template <int TP>
-__global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
+__global__ __launch_bounds__(64 * FC_WPB) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
                                                    int iniTh, int minTh, int alignedLoads, int *cellCount,
-                                                   uint32_t *stage) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = threadIdx.x;
+                                                   uint32_t *stage, int ldsPerWave) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemAll[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint8_t *smem = smemAll + (size_t)wv * ldsPerWave;
     const int slot = blockIdx.y;
+#ifdef FT_FAST_PROF
+    unsigned long long tProf = wall_clock64();
+#endif
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed placement, used for speed only).  Runs of
     // FC_XCD_RUN consecutive cells are dealt round-robin to the XCDs, so horizontally neighbouring cells,
     // whose tiles overlap by 6 px and share 64-B lines, hit the same private L2 instead of fetching the
     // lines once per XCD, while every XCD still gets the same mix of levels.
     const int j = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
-    const int cell = ((j / FC_XCD_RUN) * 8 + xcd) * FC_XCD_RUN + (j % FC_XCD_RUN);
+    constexpr int BPR = FC_XCD_RUN / FC_WPB;  // workgroups per run
+    const int cell = ((j / BPR) * 8 + xcd) * FC_XCD_RUN + (j % BPR) * FC_WPB + wv;
     if (cell >= g.totalCells) return;
     int level = 0;
     while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cellBase) level++;
+    FT_PROF_T(4)  // level search
     const FtLevelGeom &L = g.lv[level];
     const int c = cell - L.cellBase;
     const int ci = c / L.nCols, cj = c - ci * L.nCols;
@@ -220,6 +245,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     uint8_t *surv = tile;
     int pitch;
     const uint8_t *img = level_ptr(g, level, slot, l0, l0pitch, pyr, pitch);
+#ifdef FT_FAST_PROF
+    if (__builtin_amdgcn_readfirstlane((int)(size_t)img) == 1) return;  // forces the pointer to be resident here
+#endif
+    FT_PROF_T(5)  // geometry + image pointer
     // ---- stage the tile: aligned dword rows when the level allows it (coalesced 4-byte lanes) ----
     int ax = 0;
     if (alignedLoads) {
@@ -241,6 +270,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     }
     for (int i = lane; i < (tp * (ph + 2)) >> 2; i += 64) ((unsigned *)score)[i] = 0;
     wave_lds_sync();
+    FT_PROF_T(0)  // staging
     const uint8_t *t0 = tile + ax;  // pixel (x, y) of the cell sub-image at t0[y * tp + x]
     // ---- phase A / B rounds.  A: high-speed rejection (OpenCV's opposite-pair test without the
     // polarity): a 9-arc contains one pixel of every opposite pair, so min over the four even pairs of
@@ -248,72 +278,127 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     // candidate ring.  B (whenever the ring fills, and at the end): score = largest threshold at which
     // the pixel is still a corner (cornerScore<16>); corner at minThFAST <=> score >= minThFAST.
     int nc = 0, ncorn = 0;
-#define FT_AD(ox, oy) __builtin_amdgcn_sad_u8(v, (unsigned)cpx[(oy)*tp + (ox)], 0u)
-    // FC_UNROLL 64-pixel chunks per trip: their LDS reads are independent, which cuts the number of exposed
-    // LDS round trips of this latency-bound loop
-    for (int base = 0; base < npx; base += 64 * FC_UNROLL) {
-        unsigned m01[FC_UNROLL];
-        const uint8_t *cp[FC_UNROLL];
-        unsigned mAny = 0;
-#pragma unroll
-        for (int u = 0; u < FC_UNROLL; u++) {
-            const int i = base + 64 * u + lane;
-            const int ii = min(i, npx - 1);
-            const int y = div_by(ii, pwMagic), x = ii - y * pw;
-            const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
-            cp[u] = cpx;
-            const unsigned v = cpx[0];
-            const unsigned m0 = max(FT_AD(0, 3), FT_AD(0, -3));
-            const unsigned m1 = max(FT_AD(3, 0), FT_AD(-3, 0));
-            m01[u] = i < npx ? min(m0, m1) : 0u;
-            mAny = max(mAny, m01[u]);
+    // phase B over the buffered candidates: score, corner list (row-major), ring reset
+    auto flushB = [&]() {
+        wave_lds_sync();
+        FT_PROF_T(1)  // phase A
+        for (int jb = 0; jb < nc; jb += 64) {
+            const int j = jb + lane;
+            bool isCorner = false;
+            int ci2 = 0;
+            if (j < nc) {
+                ci2 = cand[j];
+                const int y = div_by(ci2, pwMagic), x = ci2 - y * pw;
+                const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
+                const int v = cpx[0];
+                int d[16];
+#define FT_LD(k, ox, oy) d[k] = v - (int)cpx[(oy)*tp + (ox)];
+                FT_RING(FT_LD)
+#undef FT_LD
+                const int sc = fast_score(d);
+                if (sc >= minTh) {
+                    score[(y + 1) * tp + (x + 1)] = (uint8_t)sc;
+                    isCorner = true;
+                }
+            }
+            const unsigned long long cb = __ballot(isCorner);
+            if (isCorner) {
+                const int pos = ncorn + __popcll(cb & ((1ull << lane) - 1ull));
+                if (pos < FC_CORN) corn[pos] = (unsigned short)ci2;
+            }
+            ncorn += __popcll(cb);
         }
-        // wave-level early out: when the compass pairs already reject every pixel of the trip (flat regions) the two
-        // diagonal pairs are not even read
-        if (__any(mAny > (unsigned)minTh)) {
+        nc = 0;
+        wave_lds_sync();
+        FT_PROF_T(2)  // phase B
+    };
+#define FT_AD(ox, oy) __builtin_amdgcn_sad_u8(v, (unsigned)cpx[(oy)*tp + (ox)], 0u)
+    if constexpr (TP > 0) {
+        // Fixed pitch (pw <= TP - 6 < 64): lane = column, rows walked top to bottom three at a time.  Every tile
+        // offset is an immediate; the vertical differences |p(y) - p(y+3)| serve row y (south) and row y + 3
+        // (north), and the centre of row y + 3 is the south pixel of row y, so a row costs three LDS reads and
+        // seven VALU instructions per lane before the wave-level early out.
+        const bool act = lane < pw;
+        const uint8_t *col = t0 + min(lane, pw - 1) + 3;  // (x + 3, tile row 0)
+        unsigned pA = col[3 * TP], pB = col[4 * TP], pC = col[5 * TP];
+        unsigned dA = __builtin_amdgcn_sad_u8(pA, (unsigned)col[0], 0u);
+        unsigned dB = __builtin_amdgcn_sad_u8(pB, (unsigned)col[TP], 0u);
+        unsigned dC = __builtin_amdgcn_sad_u8(pC, (unsigned)col[2 * TP], 0u);
+        // FC_ROWS rows per trip: all their LDS reads are issued before the first use, one wave-level early out
+        // covers the trip
+        for (int y = 0; y < ph; y += FC_ROWS) {
+            const uint8_t *r = col + y * TP;
+            unsigned pv[FC_ROWS + 3], m01[FC_ROWS], dSv[FC_ROWS], mAny = 0;
+            pv[0] = pA; pv[1] = pB; pv[2] = pC;
+#pragma unroll
+            for (int k = 0; k < FC_ROWS; k++) pv[k + 3] = r[(k + 6) * TP];
+#pragma unroll
+            for (int k = 0; k < FC_ROWS; k++) {
+                const unsigned v = pv[k];
+                const uint8_t *cpx = r + (k + 3) * TP;
+                const unsigned dS = dSv[k] = __builtin_amdgcn_sad_u8(v, pv[k + 3], 0u);
+                const unsigned dN = k == 0 ? dA : k == 1 ? dB : k == 2 ? dC : dSv[k >= 3 ? k - 3 : 0];
+                const unsigned m1 = max(FT_AD(3, 0), FT_AD(-3, 0));
+                m01[k] = (act && y + k < ph) ? min(max(dN, dS), m1) : 0u;
+                mAny = max(mAny, m01[k]);
+            }
+            dA = dSv[FC_ROWS - 3]; dB = dSv[FC_ROWS - 2]; dC = dSv[FC_ROWS - 1];
+            pA = pv[FC_ROWS]; pB = pv[FC_ROWS + 1]; pC = pv[FC_ROWS + 2];
+            if (__any(mAny > (unsigned)minTh)) {
+                bool pass[FC_ROWS];
+#pragma unroll
+                for (int k = 0; k < FC_ROWS; k++) {
+                    const unsigned v = pv[k];
+                    const uint8_t *cpx = r + (k + 3) * TP;
+                    const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
+                    const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
+                    pass[k] = min(m01[k], min(m2, m3)) > (unsigned)minTh;
+                }
+#pragma unroll
+                for (int k = 0; k < FC_ROWS; k++) {
+                    const unsigned long long b = __ballot(pass[k]);
+                    if (pass[k]) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)((y + k) * pw + lane);
+                    nc += __popcll(b);
+                }
+            }
+            if (nc > FC_CAND - FC_ROWS * 64 || y + FC_ROWS >= ph) flushB();  // wave-uniform
+        }
+    } else {
+        // any-size fallback: pixels in linear order, FC_UNROLL 64-pixel chunks per trip
+        for (int base = 0; base < npx; base += 64 * FC_UNROLL) {
+            unsigned m01[FC_UNROLL];
+            const uint8_t *cp[FC_UNROLL];
+            unsigned mAny = 0;
 #pragma unroll
             for (int u = 0; u < FC_UNROLL; u++) {
                 const int i = base + 64 * u + lane;
-                const uint8_t *cpx = cp[u];
+                const int ii = min(i, npx - 1);
+                const int y = div_by(ii, pwMagic), x = ii - y * pw;
+                const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
+                cp[u] = cpx;
                 const unsigned v = cpx[0];
-                const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
-                const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
-                const bool pass = min(m01[u], min(m2, m3)) > (unsigned)minTh;
-                const unsigned long long b = __ballot(pass);
-                if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)i;
-                nc += __popcll(b);
+                const unsigned m0 = max(FT_AD(0, 3), FT_AD(0, -3));
+                const unsigned m1 = max(FT_AD(3, 0), FT_AD(-3, 0));
+                m01[u] = i < npx ? min(m0, m1) : 0u;
+                mAny = max(mAny, m01[u]);
             }
-        }
-        if (nc > FC_CAND - 64 * FC_UNROLL || base + 64 * FC_UNROLL >= npx) {  // wave-uniform
-            wave_lds_sync();
-            for (int jb = 0; jb < nc; jb += 64) {
-                const int j = jb + lane;
-                bool isCorner = false;
-                int ci2 = 0;
-                if (j < nc) {
-                    ci2 = cand[j];
-                    const int y = div_by(ci2, pwMagic), x = ci2 - y * pw;
-                    const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
-                    const int v = cpx[0];
-                    int d[16];
-#define FT_LD(k, ox, oy) d[k] = v - (int)cpx[(oy)*tp + (ox)];
-                    FT_RING(FT_LD)
-#undef FT_LD
-                    const int sc = fast_score(d);
-                    if (sc >= minTh) {
-                        score[(y + 1) * tp + (x + 1)] = (uint8_t)sc;
-                        isCorner = true;
-                    }
+            // wave-level early out: when the compass pairs already reject every pixel of the trip (flat regions)
+            // the two diagonal pairs are not even read
+            if (__any(mAny > (unsigned)minTh)) {
+#pragma unroll
+                for (int u = 0; u < FC_UNROLL; u++) {
+                    const int i = base + 64 * u + lane;
+                    const uint8_t *cpx = cp[u];
+                    const unsigned v = cpx[0];
+                    const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
+                    const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
+                    const bool pass = min(m01[u], min(m2, m3)) > (unsigned)minTh;
+                    const unsigned long long b = __ballot(pass);
+                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)i;
+                    nc += __popcll(b);
                 }
-                const unsigned long long cb = __ballot(isCorner);
-                if (isCorner) {
-                    const int pos = ncorn + __popcll(cb & ((1ull << lane) - 1ull));
-                    if (pos < FC_CORN) corn[pos] = (unsigned short)ci2;
-                }
-                ncorn += __popcll(cb);
             }
-            nc = 0;
-            wave_lds_sync();
+            if (nc > FC_CAND - 64 * FC_UNROLL || base + 64 * FC_UNROLL >= npx) flushB();  // wave-uniform
         }
     }
 #undef FT_AD
@@ -360,6 +445,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     }
     (void)surv;
     if (lane == 0) *cnt = min(run, L.cellCap);
+    FT_PROF_T(3)  // NMS + emission
+#ifdef FT_FAST_PROF
+    if (lane == 0 && (blockIdx.x & 31) == 0) atomicAdd(&g_fastProf[7], 1ull);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -607,6 +696,18 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
 
 }  // namespace
 
+#ifdef FT_FAST_PROF
+static void fast_prof_dump() {
+    static int launches = 0;
+    if (++launches % 64) return;
+    (void)hipDeviceSynchronize();
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fastProf), sizeof h) == hipSuccess && h[7])
+        fprintf(stderr, "[fast prof] per cell: level search %.2f us  geometry+ptr %.2f us  tile loads %.2f us  phase A %.2f us  phase B %.2f us  nms+emit %.2f us  (%llu cells)\n",
+                h[4] * 0.01 / h[7], h[5] * 0.01 / h[7], h[0] * 0.01 / h[7], h[1] * 0.01 / h[7], h[2] * 0.01 / h[7], h[3] * 0.01 / h[7], h[7]);
+}
+#endif
+
 static int fast_tile_pitch(const FtGeom &g) {
     // fixed LDS pitch (all ring offsets immediates) when every level's cell fits: wCell + 6 + 3 <= TP
     int need = 0;
@@ -628,6 +729,7 @@ size_t ft_fast_smem_bytes(const FtGeom &g) {
 
 int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                       uint8_t *pyr, const FtTap *taps, int alignedLoads) {
+    for (int rep = ft_debug_repeat("pyr"); rep > 0; rep--)
     for (int level = 1; level < g.nlevels; level++) {
         const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
         // LDS footprint of a 64 x 8 output tile: ceil(tile * scale) + the second tap + alignment slack
@@ -645,20 +747,30 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
                          uint32_t *stage) {
     if (g.totalCells == 0) return FT_OK;  // every level is too small for a 35-px cell: no candidates
+    static_assert(FC_XCD_RUN % FC_WPB == 0, "a run of cells is a whole number of workgroups");
     const int runBlock = 8 * FC_XCD_RUN;  // grid padded to whole rounds of the XCD mapping
-    dim3 grid(((g.totalCells + runBlock - 1) / runBlock) * runBlock, batch, 1), block(64, 1, 1);
-    const size_t smem = ft_fast_smem_bytes(g);
+    dim3 grid(((g.totalCells + runBlock - 1) / runBlock) * runBlock / FC_WPB, batch, 1), block(64 * FC_WPB, 1, 1);
+    const int perWave = (int)((ft_fast_smem_bytes(g) + 15) & ~(size_t)15);
+    const size_t smem = (size_t)perWave * FC_WPB;
     const int TP = fast_tile_pitch(g);
+    if (smem > 64 * 1024) {  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
+        const void *fn = TP == 48 ? (const void *)k_fast_cells<48> : TP == 64 ? (const void *)k_fast_cells<64> : (const void *)k_fast_cells<0>;
+        FT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
     if (TP == 48)
         hipLaunchKernelGGL(k_fast_cells<48>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
-                           cellCount, stage);
+                           cellCount, stage, perWave);
     else if (TP == 64)
         hipLaunchKernelGGL(k_fast_cells<64>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
-                           cellCount, stage);
+                           cellCount, stage, perWave);
     else
         hipLaunchKernelGGL(k_fast_cells<0>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
-                           cellCount, stage);
+                           cellCount, stage, perWave);
     FT_HIP(hipGetLastError());
+#ifdef FT_FAST_PROF
+    fast_prof_dump();
+#endif
     return FT_OK;
 }
 
@@ -667,6 +779,7 @@ int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cel
     int maxCells = 0;
     for (int l = 0; l < g.nlevels; l++) maxCells = std::max(maxCells, g.lv[l].nCols * g.lv[l].nRows);
     dim3 grid2(g.nlevels, batch, 1), block(256, 1, 1);
+    for (int rep = ft_debug_repeat("compact"); rep > 0; rep--)
     hipLaunchKernelGGL(k_compact, grid2, block, (size_t)(maxCells + 1) * sizeof(int), st, g, cellCount, stage, cand,
                        candCount);
     FT_HIP(hipGetLastError());
@@ -678,6 +791,7 @@ int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint
                           const FtOctArgs &layout, int *nSel, ft_keypoint *keys, uint8_t *desc) {
     dim3 grid((g.maxKp + OD_WAVES - 1) / OD_WAVES, batch, 1), block(64 * OD_WAVES, 1, 1);
     const size_t smem = OD_WAVES * (size_t)OD_WAVE_BYTES;
+    for (int rep = ft_debug_repeat("orient"); rep > 0; rep--)
     hipLaunchKernelGGL(k_orient_desc, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, selCount, layout,
                        nSel, keys, desc);
     FT_HIP(hipGetLastError());

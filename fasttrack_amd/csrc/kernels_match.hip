@@ -321,12 +321,14 @@ int ft_launch_stereo_match(hipStream_t st, const FtGeom &g, int batch, const uin
                            const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
                            const uint8_t *pyrR, const FtStereoArgs &a) {
     dim3 grid((a.capacity + 3) / 4, batch, 1), block(256, 1, 1);
+    for (int rep = ft_debug_repeat("stereo"); rep > 0; rep--)
     hipLaunchKernelGGL(k_stereo_match, grid, block, 0, st, g, l0L, l0R, l0pitchL, l0pitchR, pyrL, pyrR, a);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
 
 int ft_launch_stereo_rowsort(hipStream_t st, const FtGeom &g, int batch, const FtStereoArgs &a) {
+    for (int rep = ft_debug_repeat("rowsort"); rep > 0; rep--)
     hipLaunchKernelGGL(k_stereo_rowsort, dim3(batch), dim3(256), (size_t)(g.lv[0].h + 1) * sizeof(int), st, g, a);
     FT_HIP(hipGetLastError());
     return FT_OK;

@@ -223,7 +223,10 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
         unsigned long long k = ~0ull;
         if (i < n) {
             const uint32_t c = cand[i];
-            k = ((unsigned long long)ft::op::path_code(R, (int)(c & 0xfffu), (int)((c >> 12) & 0xfffu)) << 32) | (unsigned)i;
+            // codes are unique (a depth-12 path identifies the pixel), so the low word never decides the order:
+            // it carries the response and the original index for the pick at the end
+            k = ((unsigned long long)ft::op::path_code(R, (int)(c & 0xfffu), (int)((c >> 12) & 0xfffu)) << 32) |
+                ((c >> 24) << 16) | (unsigned)i;
         }
         keys[i] = k;
     }
@@ -435,17 +438,10 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     for (int t = lane; t < kept; t += 64) {
         const unsigned lh = cl[start + t];
         const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
-        unsigned bestIdx = (unsigned)keys[lo];
-        unsigned bestC = cand[bestIdx];
-        for (int k = lo + 1; k < hi; k++) {
-            const unsigned i = (unsigned)keys[k];
-            const unsigned c = cand[i];
-            const unsigned r = c >> 24, rb = bestC >> 24;
-            if (r > rb || (r == rb && i < bestIdx)) {
-                bestIdx = i;
-                bestC = c;
-            }
-        }
+        // maximise (response, -index): first maximum in emission order (:863-881)
+        unsigned best = (unsigned)keys[lo] ^ 0xffffu;
+        for (int k = lo + 1; k < hi; k++) best = max(best, (unsigned)keys[k] ^ 0xffffu);
+        const unsigned bestC = cand[(best & 0xffffu) ^ 0xffffu];
         FtSelKp s;
         s.x = (short)((bestC & 0xfffu) + minB);  // ORBextractor.cc:1211-1217: add the border offset back
         s.y = (short)(((bestC >> 12) & 0xfffu) + minB);
@@ -468,6 +464,7 @@ int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs
         FT_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attrSet = true;
     }
+    for (int rep = ft_debug_repeat("octree"); rep > 0; rep--)
     hipLaunchKernelGGL(k_octree, dim3(g.nlevels, batch), dim3(OCT_THREADS), smem, st, g, a);
     FT_HIP(hipGetLastError());
     return FT_OK;

@@ -187,7 +187,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     // software pipeline over sub-batches: while the host distributes the keypoints of sub-batch s, the
     // GPU already runs pyramid + FAST of sub-batch s+1 (stage-A streams) and descriptors / matching of
     // sub-batch s-1 (stage-B streams)
-    const int S = ft_pipeline_depth(batch);
+    const int S = ft_pipeline_depth(batch, L->deviceOctree && R->deviceOctree);
     const int sb = (batch + S - 1) / S;
     // device octree: candidates, selection and counts stay on the device, so the whole batch is enqueued
     // without a single host synchronisation; otherwise the host octree of sub-batch s runs between the stages
