@@ -51,6 +51,41 @@ static inline __host__ __device__ uint32_t ft_pack_cand(int x, int y, int s) {
     return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24);
 }
 
+// Image -> XCD placement for kernels that read patches of an image's pyramid (k_orient_desc, k_stereo_match).
+// Workgroup b of a 1-D launch lands on XCD b % 8 (round-robin placement of the dispatcher, used for speed only:
+// a different placement changes nothing but the hit rate).  With the plain (blocksPerSlot, batch) grid every
+// XCD touches every image, so each of the eight private 4 MB L2s tries to hold all pyramids of the launch; here
+// all workgroups of an image run on one XCD and an XCD walks its images one after the other, so the L2 holds
+// the ~3 MB pyramid it is currently sampling.  Launches with fewer than 8 images keep the plain grid (all XCDs
+// busy on one image).  Returns false for the padding workgroups.
+struct FtSlotGrid {
+    int blocksPerSlot, batch, xcdMap;
+    unsigned magic;  // floor(2^32 / blocksPerSlot) + 1, 0 for blocksPerSlot == 1
+};
+static inline FtSlotGrid ft_slot_grid(int blocksPerSlot, int batch, dim3 &grid) {
+    FtSlotGrid sg;
+    sg.blocksPerSlot = blocksPerSlot;
+    sg.batch = batch;
+    sg.xcdMap = batch >= 8;
+    sg.magic = blocksPerSlot > 1 ? 0xffffffffu / (unsigned)blocksPerSlot + 1u : 0u;
+    grid = sg.xcdMap ? dim3((unsigned)blocksPerSlot * 8u * (unsigned)((batch + 7) / 8), 1, 1) : dim3(blocksPerSlot, batch, 1);
+    return sg;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool ft_slot_block(const FtSlotGrid &sg, int &slot, int &blk) {
+    if (!sg.xcdMap) {
+        slot = blockIdx.y;
+        blk = blockIdx.x;
+        return true;
+    }
+    const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+    const int grp = sg.magic ? (int)__umulhi((unsigned)j, sg.magic) : j;
+    blk = j - grp * sg.blocksPerSlot;
+    slot = grp * 8 + xcd;
+    return slot < sg.batch;
+}
+#endif
+
 // selected keypoint handed from the host octree to the orientation/descriptor kernel
 struct FtSelKp {
     short x, y;  // level coordinates (border included)

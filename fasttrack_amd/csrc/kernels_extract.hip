@@ -8,10 +8,49 @@
 
 namespace {
 
-__constant__ signed char c_pattern[1024] = {
-#include "orb_pattern.inc"
+// umax of IC_Angle (ORBextractor.cc:478-493): 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3
+
+// IC_Angle with v_dot4_u32_u8: row v of the 31-px disc is eight dwords of four pixels, dword j holding
+// u = -15 + 4j .. -12 + 4j.  W has u + 16 in the bytes inside the disc (|u| <= umax[|v|]), M has 1 there; both
+// are 0 outside, so m10 = sum dot4(D, W) - 16 * dot4(D, M) and m01 = sum v * dot4(D, M).  Row 16 is all zero
+// (padding of the 4 x 8-row walk).
+struct FtMomentTab {
+    unsigned W[17 * 8], M[17 * 8];
 };
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+constexpr FtMomentTab ft_make_moment_tab() {
+    constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    FtMomentTab t{};
+    for (int av = 0; av < 16; av++)
+        for (int j = 0; j < 8; j++)
+            for (int k = 0; k < 4; k++) {
+                const int u = -15 + 4 * j + k;
+                const int au = u < 0 ? -u : u;
+                if (u <= 15 && au <= umax[av]) {
+                    t.W[av * 8 + j] |= (unsigned)(u + 16) << (8 * k);
+                    t.M[av * 8 + j] |= 1u << (8 * k);
+                }
+            }
+    return t;
+}
+__constant__ FtMomentTab c_mom = ft_make_moment_tab();
+// the rBRIEF pattern as floats: (x0, y0, x1, y1) per test
+struct FtPatternF {
+    float4 p[256];
+};
+constexpr FtPatternF ft_make_pattern_f() {
+    constexpr signed char pat[1024] = {
+#include "orb_pattern.inc"
+    };
+    FtPatternF t{};
+    for (int i = 0; i < 256; i++) {
+        t.p[i].x = (float)pat[4 * i];
+        t.p[i].y = (float)pat[4 * i + 1];
+        t.p[i].z = (float)pat[4 * i + 2];
+        t.p[i].w = (float)pat[4 * i + 3];
+    }
+    return t;
+}
+__constant__ FtPatternF c_patternF = ft_make_pattern_f();
 // GaussianBlur(7x7, sigma 2) fixed-point taps {18,34,48,56,48,34,18} (error-diffused, sum 256) are literals in k_orient_desc
 
 
@@ -184,44 +223,22 @@ __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int 
 __host__ __device__ __forceinline__ int fc_score_bytes(int wCell, int hCell, int TP) { return (((hCell + 2) * fc_pitch(wCell, TP)) + 15) & ~15; }
 __host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + FC_CORN); }
 
-#ifdef FT_FAST_PROF  // developer build only: wall-clock ticks (10 ns) per phase summed over all waves
-__device__ unsigned long long g_fastProf[8];
-#define FT_PROF_T(i)                                                         \
-    {                                                                        \
-        const unsigned long long t_ = wall_clock64();                        \
-        if (lane == 0 && (blockIdx.x & 31) == 0) atomicAdd(&g_fastProf[i], t_ - tProf); \
-        tProf = t_;                                                          \
-    }
-#else
-#define FT_PROF_T(i)
-#endif
-
-#ifndef FC_WPB
-#define FC_WPB 1  // independent waves (cells) per workgroup: the CU holds at most 16 workgroups, so one-wave groups cap it at 16 waves
-#endif
-
 template <int TP>
-__global__ __launch_bounds__(64 * FC_WPB) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
+__global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
                                                    int iniTh, int minTh, int alignedLoads, int *cellCount,
-                                                   uint32_t *stage, int ldsPerWave) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smemAll[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint8_t *smem = smemAll + (size_t)wv * ldsPerWave;
+                                                   uint32_t *stage) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x;
     const int slot = blockIdx.y;
-#ifdef FT_FAST_PROF
-    unsigned long long tProf = wall_clock64();
-#endif
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed placement, used for speed only).  Runs of
     // FC_XCD_RUN consecutive cells are dealt round-robin to the XCDs, so horizontally neighbouring cells,
     // whose tiles overlap by 6 px and share 64-B lines, hit the same private L2 instead of fetching the
     // lines once per XCD, while every XCD still gets the same mix of levels.
     const int j = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
-    constexpr int BPR = FC_XCD_RUN / FC_WPB;  // workgroups per run
-    const int cell = ((j / BPR) * 8 + xcd) * FC_XCD_RUN + (j % BPR) * FC_WPB + wv;
+    const int cell = ((j / FC_XCD_RUN) * 8 + xcd) * FC_XCD_RUN + (j % FC_XCD_RUN);
     if (cell >= g.totalCells) return;
     int level = 0;
     while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cellBase) level++;
-    FT_PROF_T(4)  // level search
     const FtLevelGeom &L = g.lv[level];
     const int c = cell - L.cellBase;
     const int ci = c / L.nCols, cj = c - ci * L.nCols;
@@ -245,10 +262,6 @@ __global__ __launch_bounds__(64 * FC_WPB) void k_fast_cells(FtGeom g, const uint
     uint8_t *surv = tile;
     int pitch;
     const uint8_t *img = level_ptr(g, level, slot, l0, l0pitch, pyr, pitch);
-#ifdef FT_FAST_PROF
-    if (__builtin_amdgcn_readfirstlane((int)(size_t)img) == 1) return;  // forces the pointer to be resident here
-#endif
-    FT_PROF_T(5)  // geometry + image pointer
     // ---- stage the tile: aligned dword rows when the level allows it (coalesced 4-byte lanes) ----
     int ax = 0;
     if (alignedLoads) {
@@ -270,7 +283,6 @@ __global__ __launch_bounds__(64 * FC_WPB) void k_fast_cells(FtGeom g, const uint
     }
     for (int i = lane; i < (tp * (ph + 2)) >> 2; i += 64) ((unsigned *)score)[i] = 0;
     wave_lds_sync();
-    FT_PROF_T(0)  // staging
     const uint8_t *t0 = tile + ax;  // pixel (x, y) of the cell sub-image at t0[y * tp + x]
     // ---- phase A / B rounds.  A: high-speed rejection (OpenCV's opposite-pair test without the
     // polarity): a 9-arc contains one pixel of every opposite pair, so min over the four even pairs of
@@ -281,8 +293,7 @@ __global__ __launch_bounds__(64 * FC_WPB) void k_fast_cells(FtGeom g, const uint
     // phase B over the buffered candidates: score, corner list (row-major), ring reset
     auto flushB = [&]() {
         wave_lds_sync();
-        FT_PROF_T(1)  // phase A
-        for (int jb = 0; jb < nc; jb += 64) {
+            for (int jb = 0; jb < nc; jb += 64) {
             const int j = jb + lane;
             bool isCorner = false;
             int ci2 = 0;
@@ -310,8 +321,7 @@ __global__ __launch_bounds__(64 * FC_WPB) void k_fast_cells(FtGeom g, const uint
         }
         nc = 0;
         wave_lds_sync();
-        FT_PROF_T(2)  // phase B
-    };
+        };
 #define FT_AD(ox, oy) __builtin_amdgcn_sad_u8(v, (unsigned)cpx[(oy)*tp + (ox)], 0u)
     if constexpr (TP > 0) {
         // Fixed pitch (pw <= TP - 6 < 64): lane = column, rows walked top to bottom three at a time.  Every tile
@@ -445,10 +455,6 @@ __global__ __launch_bounds__(64 * FC_WPB) void k_fast_cells(FtGeom g, const uint
     }
     (void)surv;
     if (lane == 0) *cnt = min(run, L.cellCap);
-    FT_PROF_T(3)  // NMS + emission
-#ifdef FT_FAST_PROF
-    if (lane == 0 && (blockIdx.x & 31) == 0) atomicAdd(&g_fastProf[7], 1ull);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -553,11 +559,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const uint8_t *const *l0, int l0pitch,
                                                                const uint8_t *pyr, int alignedLoads, const FtSelKp *sel,
                                                                const int *selCount, FtOctArgs lay, int *nSel,
-                                                               ft_keypoint *keysOut, uint8_t *descOut) {
+                                                               ft_keypoint *keysOut, uint8_t *descOut, FtSlotGrid sg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slot = blockIdx.y;
-    const int k = blockIdx.x * OD_WAVES + wave;
+    int slot, blk;
+    if (!ft_slot_block(sg, slot, blk)) return;
+    const int k = blk * OD_WAVES + wave;
     // the octree leaves its result per level; keypoint k of the image (level order) is entry k - prefix of
     // the level that contains it
     int selLevel = -1, prefix = 0, total = 0;
@@ -582,11 +589,18 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     int ax = px0 & 3;
     const bool interior = alignedLoads && px0 >= 0 && py0 >= 0 && py0 + OD_P <= h && (px0 - ax) + OD_PP <= w;
     if (interior) {
-        // 43 rows x 12 aligned dwords: coalesced 4-byte lanes, pixel (r, c) lands at raw[r*48 + ax + c]
+        // 43 rows x 12 aligned dwords: coalesced 4-byte lanes, pixel (r, c) lands at raw[r*48 + ax + c].  Five rows
+        // per step on lanes 0-59 with a fixed (row, dword) per lane, so a step is one load and one LDS store with
+        // immediate offsets.
         const uint8_t *src = img + (size_t)py0 * pitch + (px0 - ax);
-        for (int i = lane; i < OD_P * 12; i += 64) {
-            const int r = i / 12, c = i - r * 12;
-            ((unsigned *)raw)[i] = *(const unsigned *)(src + (size_t)r * pitch + 4 * c);
+        const int rr = (lane * 43) >> 9, cc = lane - rr * 12;  // lane / 12 for lane < 64
+        const unsigned laneOff = (unsigned)(rr * pitch + 4 * cc);
+        unsigned *rawLane = (unsigned *)raw + rr * 12 + cc;
+        if (lane < 60) {
+#pragma unroll
+            for (int it = 0; it < 9; it++) {
+                if (it < 8 || rr < 3) rawLane[it * 60] = *(const unsigned *)(src + (size_t)(it * 5) * pitch + laneOff);
+            }
         }
     } else {
         // BORDER_REFLECT_101 of the blur at the level's edges (keypoints are >= 19 px inside, the
@@ -599,21 +613,25 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
         }
     }
     wave_lds_sync();
-    const uint8_t *rp = raw + ax;
-    // IC_Angle: integer moments over the 31-px disc (two patch rows per step: lanes 0-31 / 32-63)
+    // IC_Angle: integer moments over the 31-px disc, four pixels per v_dot4 (tables above): lane = (row of an
+    // 8-row group, dword of the row), four groups cover rows v = -15 .. 16 (row 16 has zero weights)
     int m10 = 0, m01 = 0;
     {
-        const int u = (lane & 31) - 15;
-        for (int r = 0; r < 32; r += 2) {
-            const int v = r + (lane >> 5) - 15;
-            if (v <= 15 && u <= 15) {
-                const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-                if (au <= c_umax[av]) {
-                    const int I = rp[(OD_R + v) * OD_PP + (OD_R + u)];
-                    m10 += u * I;
-                    m01 += v * I;
-                }
-            }
+        const int rsub = lane >> 3, jd = lane & 7;
+        const int sh = (ax + 6) & 3;
+        // dword j of row v starts at raw byte (v + 21) * 48 + ax + 6 + 4j
+        const unsigned *w = (const unsigned *)raw + (rsub + 6) * 12 + ((ax + 6) >> 2) + jd;
+        int v = rsub - 15;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const unsigned lo = w[it * 96], hi = w[it * 96 + 1];
+            const unsigned D = __builtin_amdgcn_alignbyte(hi, lo, sh);
+            const int av = v < 0 ? -v : v;
+            const unsigned dw = __builtin_amdgcn_udot4(D, c_mom.W[av * 8 + jd], 0u, false);
+            const unsigned dm = __builtin_amdgcn_udot4(D, c_mom.M[av * 8 + jd], 0u, false);
+            m10 += (int)dw - 16 * (int)dm;
+            m01 += v * (int)dm;
+            v += 8;
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
@@ -628,21 +646,28 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     // blurred window is b = ax + c.
     {
         const unsigned K0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K1 = 48u | (34u << 8) | (18u << 16);
-        for (int t = lane; t < OD_P * 10; t += 64) {
-            const int r = t / 10, gq = t - r * 10;
-            const unsigned *rw = (const unsigned *)(raw + r * OD_PP) + gq;
-            const unsigned d0 = rw[0], d1 = rw[1], d2 = rw[2];
-            unsigned h0 = __builtin_amdgcn_udot4(d1, K1, __builtin_amdgcn_udot4(d0, K0, 0u, false), false);
-            unsigned h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1,
-                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false), false);
-            unsigned h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1,
-                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false), false);
-            unsigned h3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1,
-                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
-            uint2 pk;
-            pk.x = h0 | (h1 << 16);
-            pk.y = h2 | (h3 << 16);
-            *(uint2 *)(hb + r * OD_HP + 4 * gq) = pk;
+        // six rows per step on lanes 0-59, (row, group) fixed per lane: every LDS offset of a step is an immediate
+        const int rr = (lane * 13) >> 7, gq = lane - rr * 10;  // lane / 10 for lane < 64
+        const unsigned *rwLane = (const unsigned *)(raw + rr * OD_PP) + gq;
+        unsigned short *hbLane = hb + rr * OD_HP + 4 * gq;
+        if (lane < 60) {
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                if (it == 7 && rr > 0) break;  // rows 42 .. 47: only row 42 exists
+                const unsigned *rw = rwLane + it * (6 * OD_PP / 4);
+                const unsigned d0 = rw[0], d1 = rw[1], d2 = rw[2];
+                unsigned h0 = __builtin_amdgcn_udot4(d1, K1, __builtin_amdgcn_udot4(d0, K0, 0u, false), false);
+                unsigned h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1,
+                                                     __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false), false);
+                unsigned h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1,
+                                                     __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false), false);
+                unsigned h3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1,
+                                                     __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
+                uint2 pk;
+                pk.x = h0 | (h1 << 16);
+                pk.y = h2 | (h3 << 16);
+                *(uint2 *)(hbLane + it * 6 * OD_HP) = pk;
+            }
         }
     }
     wave_lds_sync();
@@ -665,8 +690,8 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int p = q * 64 + lane;  // pair index: byte p/8, bit p%8
-        const float x0 = (float)c_pattern[4 * p], y0 = (float)c_pattern[4 * p + 1];
-        const float x1 = (float)c_pattern[4 * p + 2], y1 = (float)c_pattern[4 * p + 3];
+        const float4 pt = c_patternF.p[p];
+        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
@@ -695,18 +720,6 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
 }
 
 }  // namespace
-
-#ifdef FT_FAST_PROF
-static void fast_prof_dump() {
-    static int launches = 0;
-    if (++launches % 64) return;
-    (void)hipDeviceSynchronize();
-    unsigned long long h[8];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fastProf), sizeof h) == hipSuccess && h[7])
-        fprintf(stderr, "[fast prof] per cell: level search %.2f us  geometry+ptr %.2f us  tile loads %.2f us  phase A %.2f us  phase B %.2f us  nms+emit %.2f us  (%llu cells)\n",
-                h[4] * 0.01 / h[7], h[5] * 0.01 / h[7], h[0] * 0.01 / h[7], h[1] * 0.01 / h[7], h[2] * 0.01 / h[7], h[3] * 0.01 / h[7], h[7]);
-}
-#endif
 
 static int fast_tile_pitch(const FtGeom &g) {
     // fixed LDS pitch (all ring offsets immediates) when every level's cell fits: wCell + 6 + 3 <= TP
@@ -747,11 +760,9 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
                          uint32_t *stage) {
     if (g.totalCells == 0) return FT_OK;  // every level is too small for a 35-px cell: no candidates
-    static_assert(FC_XCD_RUN % FC_WPB == 0, "a run of cells is a whole number of workgroups");
     const int runBlock = 8 * FC_XCD_RUN;  // grid padded to whole rounds of the XCD mapping
-    dim3 grid(((g.totalCells + runBlock - 1) / runBlock) * runBlock / FC_WPB, batch, 1), block(64 * FC_WPB, 1, 1);
-    const int perWave = (int)((ft_fast_smem_bytes(g) + 15) & ~(size_t)15);
-    const size_t smem = (size_t)perWave * FC_WPB;
+    dim3 grid(((g.totalCells + runBlock - 1) / runBlock) * runBlock, batch, 1), block(64, 1, 1);
+    const size_t smem = ft_fast_smem_bytes(g);
     const int TP = fast_tile_pitch(g);
     if (smem > 64 * 1024) {  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
         const void *fn = TP == 48 ? (const void *)k_fast_cells<48> : TP == 64 ? (const void *)k_fast_cells<64> : (const void *)k_fast_cells<0>;
@@ -760,17 +771,14 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
     for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
     if (TP == 48)
         hipLaunchKernelGGL(k_fast_cells<48>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
-                           cellCount, stage, perWave);
+                           cellCount, stage);
     else if (TP == 64)
         hipLaunchKernelGGL(k_fast_cells<64>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
-                           cellCount, stage, perWave);
+                           cellCount, stage);
     else
         hipLaunchKernelGGL(k_fast_cells<0>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
-                           cellCount, stage, perWave);
+                           cellCount, stage);
     FT_HIP(hipGetLastError());
-#ifdef FT_FAST_PROF
-    fast_prof_dump();
-#endif
     return FT_OK;
 }
 
@@ -789,11 +797,12 @@ int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cel
 int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                           const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *selCount,
                           const FtOctArgs &layout, int *nSel, ft_keypoint *keys, uint8_t *desc) {
-    dim3 grid((g.maxKp + OD_WAVES - 1) / OD_WAVES, batch, 1), block(64 * OD_WAVES, 1, 1);
+    dim3 grid, block(64 * OD_WAVES, 1, 1);
+    const FtSlotGrid sg = ft_slot_grid((g.maxKp + OD_WAVES - 1) / OD_WAVES, batch, grid);
     const size_t smem = OD_WAVES * (size_t)OD_WAVE_BYTES;
     for (int rep = ft_debug_repeat("orient"); rep > 0; rep--)
     hipLaunchKernelGGL(k_orient_desc, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, selCount, layout,
-                       nSel, keys, desc);
+                       nSel, keys, desc, sg);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

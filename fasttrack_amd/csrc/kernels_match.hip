@@ -37,10 +37,11 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // One wave per left keypoint.
 __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *const *l0L, const uint8_t *const *l0R,
                                                       int l0pitchL, int l0pitchR, const uint8_t *pyrL,
-                                                      const uint8_t *pyrR, FtStereoArgs a) {
+                                                      const uint8_t *pyrR, FtStereoArgs a, FtSlotGrid sg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = blockIdx.y;
-    const int iL = blockIdx.x * 4 + wave;
+    int slot, blk;
+    if (!ft_slot_block(sg, slot, blk)) return;
+    const int iL = blk * 4 + wave;
     const int nL = a.nL[slot];
     if (iL >= nL) return;
     const size_t base = (size_t)slot * a.capacity;
@@ -320,9 +321,10 @@ __global__ __launch_bounds__(256) void k_hamming_pairs(const uint8_t *a, const u
 int ft_launch_stereo_match(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
                            const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
                            const uint8_t *pyrR, const FtStereoArgs &a) {
-    dim3 grid((a.capacity + 3) / 4, batch, 1), block(256, 1, 1);
+    dim3 grid, block(256, 1, 1);
+    const FtSlotGrid sg = ft_slot_grid((a.capacity + 3) / 4, batch, grid);
     for (int rep = ft_debug_repeat("stereo"); rep > 0; rep--)
-    hipLaunchKernelGGL(k_stereo_match, grid, block, 0, st, g, l0L, l0R, l0pitchL, l0pitchR, pyrL, pyrR, a);
+    hipLaunchKernelGGL(k_stereo_match, grid, block, 0, st, g, l0L, l0R, l0pitchL, l0pitchR, pyrL, pyrR, a, sg);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

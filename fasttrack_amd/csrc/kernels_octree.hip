@@ -172,6 +172,8 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    // a thin kernel that runs next to wide ones: its single critical wave per level should win the issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     const int level = blockIdx.x, slot = blockIdx.y;
     const FtLevelGeom &L = g.lv[level];
     const int n = a.candCount[slot * g.nlevels + level];
