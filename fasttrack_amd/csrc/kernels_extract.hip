@@ -84,8 +84,13 @@ __device__ __forceinline__ void wave_lds_sync() {
 // loads, then every lane produces the 8 outputs of its column from 2x2 taps read from LDS.
 #define PD_TW 64
 #define PD_TH 8
+// A wave's life is a chain of memory round trips, so the chain is kept short: the source footprint of the tile is
+// bounded arithmetically (fixed-point scale with a two-pixel margin instead of reading the first and last tap),
+// and the taps the outputs need - one per lane in x, eight wave-uniform ones in y - are requested together with
+// the footprint, before anything waits.
 __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint8_t *const *l0, int l0pitch,
-                                                 uint8_t *pyr, const FtTap *taps, int alignedLoads, int ldsPitch) {
+                                                 uint8_t *pyr, const FtTap *taps, int alignedLoads, int ldsPitch,
+                                                 unsigned sxQ16, unsigned syQ16) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
     const int slot = blockIdx.z;
@@ -99,10 +104,18 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
     if (D.area2x) {
         sxa = 2 * dx0; sxb = 2 * dx1 + 1; sya = 2 * dy0; syb = 2 * dy1 + 1;
     } else {
-        sxa = taps[D.xtab + dx0].s;
-        sxb = min(taps[D.xtab + dx1].s + 1, sw - 1);
-        sya = min(max((int)taps[D.ytab + dy0].s, 0), sh - 1);
-        syb = min(max((int)taps[D.ytab + dy1].s + 1, 0), sh - 1);
+        // first tap of output d is floor((d + 0.5) * scale - 0.5); ((2d + 1) * scaleQ16) >> 17 is within one of it
+        sxa = max((int)(((unsigned)(2 * dx0 + 1) * sxQ16) >> 17) - 2, 0);
+        sxb = min((int)(((unsigned)(2 * dx1 + 1) * sxQ16) >> 17) + 2, sw - 1);
+        sya = max((int)(((unsigned)(2 * dy0 + 1) * syQ16) >> 17) - 2, 0);
+        syb = min((int)(((unsigned)(2 * dy1 + 1) * syQ16) >> 17) + 2, sh - 1);
+    }
+    const int dx = min(dx0 + lane, dx1);
+    FtTap xt, yt[PD_TH];
+    if (!D.area2x) {
+        xt = taps[D.xtab + dx];
+#pragma unroll
+        for (int k = 0; k < PD_TH; k++) yt[k] = taps[D.ytab + min(dy0 + k, dy1)];  // wave-uniform
     }
     const int rows = syb - sya + 1;
     int ax = 0;
@@ -126,8 +139,7 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
     }
     wave_lds_sync();
     const uint8_t *T = smem + ax;  // source pixel (sx, sy) at T[(sy - sya) * ldsPitch + (sx - sxa)]
-    const int dx = dx0 + lane;
-    if (dx > dx1) return;
+    if (dx0 + lane > dx1) return;
     uint8_t *outBase = pyr + (size_t)slot * g.pyrPerSlot + D.off + dx;
     if (D.area2x) {
         for (int dy = dy0; dy <= dy1; dy++) {
@@ -136,18 +148,16 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
         }
         return;
     }
-    const FtTap xt = taps[D.xtab + dx];
     const int cx0 = xt.s - sxa, cx1 = min(xt.s + 1, sw - 1) - sxa;
 #pragma unroll
     for (int k = 0; k < PD_TH; k++) {
         const int dy = dy0 + k;
         if (dy > dy1) break;
-        const FtTap yt = taps[D.ytab + dy];  // wave-uniform
-        const int sy0 = min(max((int)yt.s, 0), sh - 1) - sya, sy1 = min(max((int)yt.s + 1, 0), sh - 1) - sya;
+        const int sy0 = min(max((int)yt[k].s, 0), sh - 1) - sya, sy1 = min(max((int)yt[k].s + 1, 0), sh - 1) - sya;
         const uint8_t *r0 = T + sy0 * ldsPitch, *r1 = T + sy1 * ldsPitch;
         const int h0 = r0[cx0] * xt.a0 + r0[cx1] * xt.a1;
         const int h1 = r1[cx0] * xt.a0 + r1[cx1] * xt.a1;
-        outBase[(size_t)dy * D.pitch] = (uint8_t)((((yt.a0 * (h0 >> 4)) >> 16) + ((yt.a1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        outBase[(size_t)dy * D.pitch] = (uint8_t)((((yt[k].a0 * (h0 >> 4)) >> 16) + ((yt[k].a1 * (h1 >> 4)) >> 16) + 2) >> 2);
     }
 }
 
@@ -745,12 +755,16 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
     for (int rep = ft_debug_repeat("pyr"); rep > 0; rep--)
     for (int level = 1; level < g.nlevels; level++) {
         const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
-        // LDS footprint of a 64 x 8 output tile: ceil(tile * scale) + the second tap + alignment slack
-        const int cols = (int)((long long)PD_TW * P.w / D.w) + 4, rowsN = (int)((long long)PD_TH * P.h / D.h) + 4;
+        // LDS footprint of a 64 x 8 output tile: ceil(tile * scale) + the second tap + the margin of the
+        // arithmetic footprint bound + alignment slack
+        const int cols = (int)((long long)PD_TW * P.w / D.w) + 8, rowsN = (int)((long long)PD_TH * P.h / D.h) + 8;
         const int ldsPitch = (cols + 3 + 3) & ~3;
+        // scale = source size / destination size in 16.16, rounded up (the error stays far below one pixel)
+        const unsigned sxQ16 = (unsigned)(((unsigned long long)P.w << 16) / (unsigned)D.w) + 1u;
+        const unsigned syQ16 = (unsigned)(((unsigned long long)P.h << 16) / (unsigned)D.h) + 1u;
         dim3 grid((D.w + PD_TW - 1) / PD_TW, (D.h + PD_TH - 1) / PD_TH, batch), block(64, 1, 1);
         hipLaunchKernelGGL(k_pyr_down, grid, block, (size_t)ldsPitch * rowsN, st, g, level, l0, l0pitch, pyr, taps,
-                           alignedLoads, ldsPitch);
+                           alignedLoads, ldsPitch, sxQ16, syQ16);
     }
     FT_HIP(hipGetLastError());
     return FT_OK;
