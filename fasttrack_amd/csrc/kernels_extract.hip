@@ -83,7 +83,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // tile (rows sy(first)..sy(last)+1, columns sx(first)..sx(last)+1) is staged in LDS with aligned dword
 // loads, then every lane produces the 8 outputs of its column from 2x2 taps read from LDS.
 #define PD_TW 64
-#define PD_TH 8
+#define PD_TH 16
 // A wave's life is a chain of memory round trips, so the chain is kept short: the source footprint of the tile is
 // bounded arithmetically (fixed-point scale with a two-pixel margin instead of reading the first and last tap),
 // and the taps the outputs need - one per lane in x, eight wave-uniform ones in y - are requested together with
