@@ -204,9 +204,10 @@ def main():
         roof = None
         traffic = None
         try:  # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if args.workload == "stereo_1280x720_nf2000" and B // max(1, min(8, B // 16)) == 16:
-                traffic = tj["kernels"]["k_fast_cells"]["traffic_bytes_per_launch"]
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]["k_fast_cells"]
+            imgs = args.steps * 2.0 * B / launches if launches else 0
+            if args.workload == "stereo_1280x720_nf2000" and abs(imgs - tj["images_per_launch"]) < 0.5:
+                traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
         if launches:

@@ -10,7 +10,7 @@ import sys
 FETCH_FACTOR = {"k_fast_cells": 1.0, "k_pyr_down": 1.0, "k_orient_desc": 1.0}  # row-segment tile loads
 
 
-def main(summary, out):
+def main(summary, out, images_per_step=256, steps=7):
     d = {}
     for line in open(summary):
         m = re.match(r"(\S+)\s+(FETCH_SIZE|WRITE_SIZE)\s+launches\s+(\d+)\s+per-launch\s+([\d.]+) KB", line)
@@ -23,10 +23,12 @@ def main(summary, out):
         f = FETCH_FACTOR.get(k, 2.0)
         e["fetch_factor"] = f
         e["traffic_bytes_per_launch"] = (e.get("fetch_kb", 0) * f + e.get("write_kb", 0)) * 1024
-    json.dump({"source": summary, "note": "per launch; bench --batch 128 (sub-batches of 16 pairs), 1280x720", "kernels": d},
-              open(out, "w"), indent=1)
+    for k, e in d.items():  # images one launch covers (bench under the profiler: `steps` passes over the batch)
+        e["images_per_launch"] = images_per_step * steps / e["launches"] if e["launches"] else None
+    json.dump({"source": summary, "note": "per launch; default bench (128 pairs of 1280x720 per step, %d steps profiled)" % steps,
+               "kernels": d}, open(out, "w"), indent=1)
     print(json.dumps(d.get("k_fast_cells"), indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], *(int(a) for a in sys.argv[3:5]))
