@@ -51,6 +51,21 @@ class LastPoints(C.Structure):
                 ("observations", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p)]
 
 
+class FramePose(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("tlr", C.c_float * 3)]
+
+
+class MapPoints(C.Structure):
+    _fields_ = [("M", C.c_int), ("skip", C.c_void_p), ("world_pos", C.c_void_p), ("normal", C.c_void_p),
+                ("max_distance", C.c_void_p), ("min_distance", C.c_void_p), ("descriptors", C.c_void_p),
+                ("observations", C.c_void_p)]
+
+
+class FrustumResult(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("in_view", "in_view_r", "level", "level_r", "view_cos", "view_cos_r",
+                                          "proj_x", "proj_y", "proj_xr", "proj_yr", "depth", "depth_r")]
+
+
 def declared_symbols() -> list[str]:
     """Every FT_API entry point declared in include/fasttrack_amd.h."""
     text = open(HEADER_PATH).read()
@@ -118,6 +133,16 @@ def lib() -> C.CDLL:
     L.ft_fisheye_match.argtypes = [vp, vp, i, vp, i, vp, vp, vp]
     L.ft_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LocalPoints), f, f, vp, ip] + [vp] * 10
     L.ft_search_last_frame.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LastPoints), vp, f, i, i, i, vp, ip] + [vp] * 4
+    L.ft_is_in_frustum.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FramePose), C.POINTER(MapPoints), f, f,
+                                   C.POINTER(FrustumResult), ip]
+    L.ft_tracked_frame_create.argtypes = [vp, i, i, C.POINTER(vp)]
+    L.ft_tracked_frame_destroy.argtypes = [vp]
+    L.ft_tracked_frame_upload.argtypes = [vp, C.POINTER(FrameView)]
+    L.ft_tracked_frame_bind_stereo.argtypes = [vp, vp, i, C.POINTER(FrameView)]
+    L.ft_tracked_frame_search_last_frame.argtypes = [vp, C.POINTER(LastPoints), vp, f, i, i, i, vp, ip]
+    L.ft_tracked_frame_track_local_map.argtypes = [vp, C.POINTER(FramePose), C.POINTER(MapPoints), f, f, f, f, i, f,
+                                                   C.POINTER(FrustumResult), ip, vp, ip]
+    L.ft_tracked_frame_holder_obs.argtypes = [vp, vp]
     L.ft_descriptor_distance.argtypes = [vp, vp, vp, i, vp]
     L.ft_octree_distribute.argtypes = [vp, i, i, i, i, i, i, vp, i, ip]
     L.ft_level_geometry.argtypes = [i, i, i, f, i, vp, vp, vp, vp, vp, vp, vp]

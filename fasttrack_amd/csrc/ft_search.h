@@ -52,7 +52,26 @@ struct FtLastRaw {
     int *bestDist, *bestIdx, *bestDistR, *bestIdxR;
 };
 
+// Frame::isInFrustum inputs / outputs (kernels_search.hip k_frustum)
+struct FtDevMapPoints {
+    int M;
+    const uint8_t *skip;  // may be null
+    const float *worldPos, *normal, *maxDist, *minDist;
+};
+struct FtFrustumPose {
+    float R[2][9], t[2][3], twc[2][3];  // [0] left camera (mRcw, mtcw, mOw), [1] right camera (Frame.cc:1314-1320)
+};
+struct FtFrustumOut {
+    uint8_t *inView, *inViewR;
+    int *level, *levelR;
+    float *viewCos, *viewCosR, *projX, *projY, *projXR, *projYR, *depth, *depthR;
+    uint8_t *searchSkip;  // may be null: the `continue` conditions of ORBmatcher.cc:66-74 for the search that follows
+    int *count;           // nToMatch (atomic; zeroed by the launcher)
+};
+
 int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v);
+int ft_launch_frustum(hipStream_t st, const FtDevFrame &F, const FtFrustumPose &T, const FtDevMapPoints &P,
+                      float viewingCosLimit, float logScaleFactor, int farPoints, float thFar, const FtFrustumOut &O);
 int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
                            float nnRatio, int *res, const FtLocalRaw &raw);
 int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,

@@ -204,8 +204,10 @@ __global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPo
         res[4 * i + 1] = sideL;
         res[4 * i + 2] = primR;
         res[4 * i + 3] = sideR;
-        raw.bestDist[i] = bd; raw.bestDist2[i] = bd2; raw.bestLevel[i] = bl; raw.bestLevel2[i] = bl2; raw.bestIdx[i] = bi;
-        raw.bestDistR[i] = bdr; raw.bestDist2R[i] = bd2r; raw.bestLevelR[i] = blr; raw.bestLevel2R[i] = bl2r; raw.bestIdxR[i] = bir;
+        if (raw.bestDist) {  // the reference kernel's raw outputs are optional (the resident-frame path skips them)
+            raw.bestDist[i] = bd; raw.bestDist2[i] = bd2; raw.bestLevel[i] = bl; raw.bestLevel2[i] = bl2; raw.bestIdx[i] = bi;
+            raw.bestDistR[i] = bdr; raw.bestDist2R[i] = bd2r; raw.bestLevelR[i] = blr; raw.bestLevel2R[i] = bl2r; raw.bestIdxR[i] = bir;
+        }
     }
 }
 
@@ -216,7 +218,7 @@ __device__ __forceinline__ void project_cam(const FtDevFrame &F, const float p[3
         uv[1] = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[1], p[1]), p[2]), F.cam[3]);
     } else {
         const float x2y2 = __fadd_rn(__fmul_rn(p[0], p[0]), __fmul_rn(p[1], p[1]));
-        const float theta = atan2f(__fsqrt_rn(x2y2), p[2]);
+        const float theta = atan2f(sqrtf(x2y2), p[2]);
         const float psi = atan2f(p[1], p[0]);
         const float t2 = __fmul_rn(theta, theta);
         const float t3 = __fmul_rn(theta, t2);
@@ -333,8 +335,99 @@ __global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoin
         res[4 * i + 1] = -1;
         res[4 * i + 2] = primR;
         res[4 * i + 3] = -1;
-        raw.bestDist[i] = bd; raw.bestIdx[i] = bi; raw.bestDistR[i] = bdr; raw.bestIdxR[i] = bir;
+        if (raw.bestDist) {
+            raw.bestDist[i] = bd; raw.bestIdx[i] = bi; raw.bestDistR[i] = bdr; raw.bestIdxR[i] = bir;
+        }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame::isInFrustum / isInFrustumChecks (src/Frame.cc:536-610, 1308-1382) with MapPoint::PredictScale
+// (src/MapPoint.cc:531-546): one thread per local map point.  Float expressions are evaluated in the
+// order the oracle states (no contraction); logf(ratio) is taken as the narrowed double logarithm.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(const float *a, const float *b) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(a[0], b[0]), __fmul_rn(a[1], b[1])), __fmul_rn(a[2], b[2]));
+}
+// sqrtf is correctly rounded here (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn maps to the native approximation
+__device__ __forceinline__ float norm3(const float *a) { return sqrtf(dot3(a, a)); }
+
+__device__ __forceinline__ int predict_scale(float maxDistanceRaw, float dist, float logScaleFactor, int nLevels) {
+    const float ratio = __fdiv_rn(maxDistanceRaw, dist);
+    const float lg = (float)log((double)ratio);
+    int nScale = (int)ceilf(__fdiv_rn(lg, logScaleFactor));
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nLevels) nScale = nLevels - 1;
+    return nScale;
+}
+
+__global__ __launch_bounds__(256) void k_frustum(FtDevFrame F, FtFrustumPose T, FtDevMapPoints P, float viewingCosLimit,
+                                                 float logScaleFactor, int farPoints, float thFar, FtFrustumOut O) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.M) return;
+    bool inView = false, inViewR = false;
+    int level = -1, levelR = -1;
+    float viewCosL = 0.f, viewCosR = 0.f, px = -1.f, py = -1.f, pxr = -1.f, pyr = -1.f, depth = 0.f, depthR = 0.f;
+    if (!(P.skip && P.skip[i])) {
+        const float Pw[3] = {P.worldPos[3 * i], P.worldPos[3 * i + 1], P.worldPos[3 * i + 2]};
+        const float Pn[3] = {P.normal[3 * i], P.normal[3 * i + 1], P.normal[3 * i + 2]};
+        const float maxRaw = P.maxDist[i];
+        const float maxDistance = __fmul_rn(1.2f, maxRaw), minDistance = __fmul_rn(0.8f, P.minDist[i]);
+        const int nCams = F.Nleft == -1 ? 1 : 2;
+        for (int cam = 0; cam < nCams; cam++) {
+            float Pc[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) Pc[r] = __fadd_rn(dot3(T.R[cam] + 3 * r, Pw), T.t[cam][r]);
+            const float PcDist = norm3(Pc);
+            if (Pc[2] < 0.0f) continue;
+            float uv[2];
+            project_cam(F, Pc, uv);
+            if (uv[0] < F.mnMinX || uv[0] > F.mnMaxX) continue;
+            if (uv[1] < F.mnMinY || uv[1] > F.mnMaxY) continue;
+            if (F.Nleft == -1) {  // Frame.cc:564-565: set before the remaining checks
+                px = uv[0];
+                py = uv[1];
+            }
+            const float PO[3] = {__fsub_rn(Pw[0], T.twc[cam][0]), __fsub_rn(Pw[1], T.twc[cam][1]), __fsub_rn(Pw[2], T.twc[cam][2])};
+            const float dist = norm3(PO);
+            if (dist < minDistance || dist > maxDistance) continue;
+            const float viewCos = __fdiv_rn(dot3(PO, Pn), dist);
+            if (viewCos < viewingCosLimit) continue;
+            const int lv = predict_scale(maxRaw, dist, logScaleFactor, F.nlevels);
+            if (cam == 0) {
+                inView = true;
+                px = uv[0];
+                py = uv[1];
+                level = lv;
+                viewCosL = viewCos;
+                depth = PcDist;
+                if (F.Nleft == -1) pxr = __fsub_rn(uv[0], __fmul_rn(F.mbf, __fdiv_rn(1.0f, Pc[2])));  // mTrackProjXR (:587)
+            } else {
+                inViewR = true;
+                pxr = uv[0];
+                pyr = uv[1];
+                levelR = lv;
+                viewCosR = viewCos;
+                depthR = PcDist;
+            }
+        }
+    }
+    O.inView[i] = inView;
+    O.inViewR[i] = inViewR;
+    O.level[i] = level;
+    O.levelR[i] = levelR;
+    O.viewCos[i] = viewCosL;
+    O.viewCosR[i] = viewCosR;
+    O.projX[i] = px;
+    O.projY[i] = py;
+    O.projXR[i] = pxr;
+    O.projYR[i] = pyr;
+    O.depth[i] = depth;
+    O.depthR[i] = depthR;
+    // ORBmatcher.cc:66-74: not in view of either camera, or farther than thFarPoints (the caller's skip holds isBad())
+    if (O.searchSkip)
+        O.searchSkip[i] = (!inView && !inViewR) || (farPoints && depth > thFar) || (P.skip && P.skip[i]);
+    if (inView || inViewR) atomicAdd(O.count, 1);
 }
 
 // rebuild the per-keypoint writer lists from this pass's results and flag any change against the
@@ -358,6 +451,17 @@ __global__ __launch_bounds__(256) void k_fill_i32(int *p, int n, int v) {
 int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v) {
     if (n <= 0) return FT_OK;
     hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, st, p, n, v);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_frustum(hipStream_t st, const FtDevFrame &F, const FtFrustumPose &T, const FtDevMapPoints &P,
+                      float viewingCosLimit, float logScaleFactor, int farPoints, float thFar, const FtFrustumOut &O) {
+    int rc = ft_launch_fill_i32(st, O.count, 1, 0);
+    if (rc != FT_OK) return rc;
+    if (P.M <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_frustum, dim3((P.M + 255) / 256), dim3(256), 0, st, F, T, P, viewingCosLimit, logScaleFactor, farPoints,
+                       thFar, O);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

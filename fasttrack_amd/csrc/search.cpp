@@ -146,7 +146,154 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, int *resA,
     return FT_OK;
 }
 
+// frame constants of a view (no arrays)
+FtDevFrame devFrameConstants(const ft_frame_view *F) {
+    FtDevFrame D;
+    memset(&D, 0, sizeof D);
+    D.N = F->N;
+    D.Nleft = F->Nleft;
+    D.mnMinX = F->mnMinX; D.mnMinY = F->mnMinY; D.mnMaxX = F->mnMaxX; D.mnMaxY = F->mnMaxY;
+    D.invW = F->grid_inv_w; D.invH = F->grid_inv_h;
+    D.mbf = F->mbf; D.mb = F->mb;
+    D.camModel = F->cam_model;
+    memcpy(D.cam, F->cam, sizeof D.cam);
+    memcpy(D.Trl, F->Trl, sizeof D.Trl);
+    for (int i = 0; i < F->nlevels && i < FT_MAX_LEVELS; i++) D.sf[i] = F->scale_factors ? F->scale_factors[i] : 1.f;
+    D.nlevels = F->nlevels;
+    return D;
+}
+
+// camera poses of isInFrustumChecks (Frame.cc:1312-1325); compiled without contraction, evaluated left to right
+FtFrustumPose frustumPose(const ft_frame_view *F, const ft_frame_pose *T) {
+    FtFrustumPose P;
+    memcpy(P.R[0], T->Rcw, sizeof P.R[0]);
+    memcpy(P.t[0], T->tcw, sizeof P.t[0]);
+    memcpy(P.twc[0], T->Ow, sizeof P.twc[0]);
+    const float *Trl = F->Trl;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            P.R[1][3 * i + j] = (Trl[4 * i] * T->Rcw[j] + Trl[4 * i + 1] * T->Rcw[3 + j]) + Trl[4 * i + 2] * T->Rcw[6 + j];
+        P.t[1][i] = ((Trl[4 * i] * T->tcw[0] + Trl[4 * i + 1] * T->tcw[1]) + Trl[4 * i + 2] * T->tcw[2]) + Trl[4 * i + 3];
+        P.twc[1][i] = ((T->Rcw[i] * T->tlr[0] + T->Rcw[3 + i] * T->tlr[1]) + T->Rcw[6 + i] * T->tlr[2]) + T->Ow[i];
+    }
+    return P;
+}
+
+FtFrustumPose frustumPose_fromDev(const FtDevFrame &DF, const ft_frame_pose *T) {
+    ft_frame_view v;
+    memset(&v, 0, sizeof v);
+    memcpy(v.Trl, DF.Trl, sizeof v.Trl);
+    return frustumPose(&v, T);
+}
+
+int checkMapPoints(const ft_map_points *P, bool forSearch) {
+    FT_REQUIRE(P && P->M >= 0 && P->M < (1 << 22), "map point count out of range");
+    FT_REQUIRE(P->M == 0 || (P->world_pos && P->normal && P->max_distance && P->min_distance), "map point arrays are null");
+    FT_REQUIRE(!forSearch || P->M == 0 || (P->descriptors && P->observations), "map point descriptors / observations are null");
+    return FT_OK;
+}
+
+struct FrustumLayout {
+    size_t skip, pos, nrm, maxd, mind;                                      // inputs
+    size_t inV, inVR, lvl, lvlR, vc, vcR, px, py, pxr, pyr, dep, depR, sskip, count;  // outputs
+};
+
+void layoutFrustum(int M, bool hasSkip, Arena &a, FrustumLayout &L, size_t *inputEnd) {
+    const size_t m = (size_t)std::max(M, 1);
+    L.skip = a.take(hasSkip ? m : 1);
+    L.pos = a.take(12 * m);
+    L.nrm = a.take(12 * m);
+    L.maxd = a.take(4 * m);
+    L.mind = a.take(4 * m);
+    *inputEnd = a.off;
+    L.inV = a.take(m); L.inVR = a.take(m);
+    L.lvl = a.take(4 * m); L.lvlR = a.take(4 * m);
+    L.vc = a.take(4 * m); L.vcR = a.take(4 * m);
+    L.px = a.take(4 * m); L.py = a.take(4 * m); L.pxr = a.take(4 * m); L.pyr = a.take(4 * m);
+    L.dep = a.take(4 * m); L.depR = a.take(4 * m);
+    L.sskip = a.take(m);
+    L.count = a.take(64);
+}
+
+void stageFrustum(const ft_map_points *P, const FrustumLayout &L, uint8_t *pin) {
+    const size_t M = (size_t)P->M;
+    if (!M) return;
+    if (P->skip) memcpy(pin + L.skip, P->skip, M);
+    memcpy(pin + L.pos, P->world_pos, 12 * M);
+    memcpy(pin + L.nrm, P->normal, 12 * M);
+    memcpy(pin + L.maxd, P->max_distance, 4 * M);
+    memcpy(pin + L.mind, P->min_distance, 4 * M);
+}
+
+FtDevMapPoints devMapPoints(const ft_map_points *P, const FrustumLayout &L, uint8_t *dev) {
+    FtDevMapPoints D;
+    D.M = P->M;
+    D.skip = P->skip ? dev + L.skip : nullptr;
+    D.worldPos = (const float *)(dev + L.pos);
+    D.normal = (const float *)(dev + L.nrm);
+    D.maxDist = (const float *)(dev + L.maxd);
+    D.minDist = (const float *)(dev + L.mind);
+    return D;
+}
+
+FtFrustumOut devFrustumOut(const FrustumLayout &L, uint8_t *dev) {
+    FtFrustumOut O;
+    O.inView = dev + L.inV; O.inViewR = dev + L.inVR;
+    O.level = (int *)(dev + L.lvl); O.levelR = (int *)(dev + L.lvlR);
+    O.viewCos = (float *)(dev + L.vc); O.viewCosR = (float *)(dev + L.vcR);
+    O.projX = (float *)(dev + L.px); O.projY = (float *)(dev + L.py);
+    O.projXR = (float *)(dev + L.pxr); O.projYR = (float *)(dev + L.pyr);
+    O.depth = (float *)(dev + L.dep); O.depthR = (float *)(dev + L.depR);
+    O.searchSkip = dev + L.sskip;
+    O.count = (int *)(dev + L.count);
+    return O;
+}
+
+// D2H of the frustum fields the caller asked for (one contiguous copy of the output block, then scatter)
+int downloadFrustum(hipStream_t st, int M, const FrustumLayout &L, size_t outBegin, size_t outEnd, uint8_t *dev, uint8_t *pin,
+                    const ft_frustum_result *R, int *n_to_match) {
+    FT_HIP(hipMemcpyAsync(pin, dev + outBegin, outEnd - outBegin, hipMemcpyDeviceToHost, st));
+    FT_HIP(hipStreamSynchronize(st));
+    auto at = [&](size_t off) { return pin + (off - outBegin); };
+    if (n_to_match) *n_to_match = *(const int *)at(L.count);
+    if (!R || !M) return FT_OK;
+    const size_t m = (size_t)M;
+    if (R->in_view) memcpy(R->in_view, at(L.inV), m);
+    if (R->in_view_r) memcpy(R->in_view_r, at(L.inVR), m);
+    if (R->level) memcpy(R->level, at(L.lvl), 4 * m);
+    if (R->level_r) memcpy(R->level_r, at(L.lvlR), 4 * m);
+    if (R->view_cos) memcpy(R->view_cos, at(L.vc), 4 * m);
+    if (R->view_cos_r) memcpy(R->view_cos_r, at(L.vcR), 4 * m);
+    if (R->proj_x) memcpy(R->proj_x, at(L.px), 4 * m);
+    if (R->proj_y) memcpy(R->proj_y, at(L.py), 4 * m);
+    if (R->proj_xr) memcpy(R->proj_xr, at(L.pxr), 4 * m);
+    if (R->proj_yr) memcpy(R->proj_yr, at(L.pyr), 4 * m);
+    if (R->depth) memcpy(R->depth, at(L.dep), 4 * m);
+    if (R->depth_r) memcpy(R->depth_r, at(L.depR), 4 * m);
+    return FT_OK;
+}
+
 }  // namespace
+
+// Device-resident frame (ft_tracked_frame_*): owns (or borrows from a stereo front end) the keypoint / descriptor
+// arrays in HBM; the scalar part of the frame, the host copy of the keypoints (angles for the rotation histogram)
+// and the authoritative holder_obs live on the host and are cheap (a few KB per frame).
+struct ft_tracked_frame {
+    ft_context *ctx = nullptr;
+    int maxKp = 0, maxPts = 0;
+    // owned device storage
+    ft_keypoint *d_keys = nullptr, *d_keysR = nullptr;
+    uint8_t *d_desc = nullptr;
+    float *d_uright = nullptr;
+    int *d_holder = nullptr, *d_l2r = nullptr, *d_r2l = nullptr;
+    uint8_t *d_work = nullptr, *h_work = nullptr;  // per-call arena (points, passes, outputs) and its pinned mirror
+    size_t workBytes = 0;
+    // current frame
+    bool loaded = false;
+    FtDevFrame DF;
+    std::vector<float> angles;  // angle of keypoint i (left then right)
+    std::vector<int> holder;
+};
 
 extern "C" {
 
@@ -390,6 +537,351 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     if (n_matches) *n_matches = nm;
     ctx->addStat("search_last_frame.total", tAll.ms());
     ctx->addStat("search_last_frame.passes", passes);
+    return FT_OK;
+}
+
+int ft_is_in_frustum(ft_context *ctx, const ft_frame_view *F, const ft_frame_pose *pose, const ft_map_points *P,
+                     float viewing_cos_limit, float log_scale_factor, const ft_frustum_result *out, int *n_to_match) {
+    FT_REQUIRE(ctx && F && pose, "ft_is_in_frustum: null argument");
+    FT_REQUIRE(F->nlevels >= 1 && F->nlevels <= FT_MAX_LEVELS, "ft_is_in_frustum: nlevels out of range");
+    FT_REQUIRE(F->cam_model == 0 || F->cam_model == 1, "unknown camera model");
+    int rc = checkMapPoints(P, false);
+    if (rc != FT_OK) return rc;
+    if (n_to_match) *n_to_match = 0;
+    if (P->M == 0) return FT_OK;
+    rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    FtTimer tAll;
+    Arena a;
+    FrustumLayout L;
+    size_t inputEnd = 0;
+    layoutFrustum(P->M, P->skip != nullptr, a, L, &inputEnd);
+    rc = ensureScratch(ctx, a.off, a.off);
+    if (rc != FT_OK) return rc;
+    uint8_t *pin = (uint8_t *)ctx->scratchPin, *dev = (uint8_t *)ctx->scratchDev;
+    stageFrustum(P, L, pin);
+    hipStream_t st = ctx->stream;
+    FT_HIP(hipMemcpyAsync(dev, pin, inputEnd, hipMemcpyHostToDevice, st));
+    const FtDevFrame DF = devFrameConstants(F);
+    rc = ft_launch_frustum(st, DF, frustumPose(F, pose), devMapPoints(P, L, dev), viewing_cos_limit, log_scale_factor, 0, 0.f,
+                           devFrustumOut(L, dev));
+    if (rc != FT_OK) return rc;
+    rc = downloadFrustum(st, P->M, L, inputEnd, a.off, dev, pin, out, n_to_match);
+    ctx->addStat("is_in_frustum.total", tAll.ms());
+    return rc;
+}
+
+int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, ft_tracked_frame **out) {
+    FT_REQUIRE(ctx && out && max_keypoints > 0 && max_points > 0, "ft_tracked_frame_create: bad argument");
+    FT_REQUIRE(max_keypoints < (1 << 24) && max_points < (1 << 22), "ft_tracked_frame_create: capacity out of range");
+    int rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    ft_tracked_frame *tf = new ft_tracked_frame();
+    tf->ctx = ctx;
+    tf->maxKp = max_keypoints;
+    tf->maxPts = max_points;
+    const size_t K = (size_t)max_keypoints, M = (size_t)max_points;
+    // arena of one call: map points (<= 72 B) + frustum outputs (<= 48 B) + passes / raw outputs (<= 104 B) per point
+    tf->workBytes = 256 * M + 8 * K + 4096;
+    hipError_t e = hipMalloc((void **)&tf->d_keys, sizeof(ft_keypoint) * K);
+    if (e == hipSuccess) e = hipMalloc((void **)&tf->d_keysR, sizeof(ft_keypoint) * K);
+    if (e == hipSuccess) e = hipMalloc((void **)&tf->d_desc, 32 * K);
+    if (e == hipSuccess) e = hipMalloc((void **)&tf->d_uright, sizeof(float) * K);
+    if (e == hipSuccess) e = hipMalloc((void **)&tf->d_holder, sizeof(int) * K);
+    if (e == hipSuccess) e = hipMalloc((void **)&tf->d_l2r, sizeof(int) * K);
+    if (e == hipSuccess) e = hipMalloc((void **)&tf->d_r2l, sizeof(int) * K);
+    if (e == hipSuccess) e = hipMalloc((void **)&tf->d_work, tf->workBytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_work, tf->workBytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ft_tracked_frame_destroy(tf);
+        return ft_hip_fail(e, "ft_tracked_frame_create", __FILE__, __LINE__);
+    }
+    *out = tf;
+    return FT_OK;
+}
+
+int ft_tracked_frame_destroy(ft_tracked_frame *tf) {
+    if (!tf) return FT_OK;
+    ft_set_device(tf->ctx);
+    hipStreamSynchronize(tf->ctx->stream);
+    hipFree(tf->d_keys); hipFree(tf->d_keysR); hipFree(tf->d_desc); hipFree(tf->d_uright);
+    hipFree(tf->d_holder); hipFree(tf->d_l2r); hipFree(tf->d_r2l); hipFree(tf->d_work);
+    if (tf->h_work) hipHostFree(tf->h_work);
+    delete tf;
+    return FT_OK;
+}
+
+int ft_tracked_frame_upload(ft_tracked_frame *tf, const ft_frame_view *F) {
+    FT_REQUIRE(tf, "null tracked frame");
+    int rc = checkFrame(F);
+    if (rc != FT_OK) return rc;
+    FT_REQUIRE(F->N <= tf->maxKp, "ft_tracked_frame_upload: more keypoints than the frame was created for");
+    rc = ft_set_device(tf->ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(tf->ctx->matchMutex);
+    hipStream_t st = tf->ctx->stream;
+    const int nL = F->Nleft == -1 ? F->N : F->Nleft, nR = F->Nleft == -1 ? 0 : F->N - F->Nleft;
+    // pageable sources: the copies are staged by the runtime and complete before the call returns
+    if (nL) FT_HIP(hipMemcpyAsync(tf->d_keys, F->keys, sizeof(ft_keypoint) * nL, hipMemcpyHostToDevice, st));
+    if (nR) FT_HIP(hipMemcpyAsync(tf->d_keysR, F->keys_right, sizeof(ft_keypoint) * nR, hipMemcpyHostToDevice, st));
+    if (F->N) FT_HIP(hipMemcpyAsync(tf->d_desc, F->descriptors, (size_t)32 * F->N, hipMemcpyHostToDevice, st));
+    if (F->uright && F->N) FT_HIP(hipMemcpyAsync(tf->d_uright, F->uright, sizeof(float) * F->N, hipMemcpyHostToDevice, st));
+    if (F->Nleft != -1) {
+        if (nL) FT_HIP(hipMemcpyAsync(tf->d_l2r, F->left_to_right, sizeof(int) * nL, hipMemcpyHostToDevice, st));
+        if (nR) FT_HIP(hipMemcpyAsync(tf->d_r2l, F->right_to_left, sizeof(int) * nR, hipMemcpyHostToDevice, st));
+    }
+    if (F->N) FT_HIP(hipMemcpyAsync(tf->d_holder, F->holder_obs, sizeof(int) * F->N, hipMemcpyHostToDevice, st));
+    FT_HIP(hipStreamSynchronize(st));
+    tf->DF = devFrameConstants(F);
+    tf->DF.keys = tf->d_keys;
+    tf->DF.keysR = tf->d_keysR;
+    tf->DF.desc = tf->d_desc;
+    tf->DF.uright = F->uright ? tf->d_uright : nullptr;
+    tf->DF.holderObs = tf->d_holder;
+    tf->DF.l2r = F->Nleft != -1 ? tf->d_l2r : nullptr;
+    tf->DF.r2l = F->Nleft != -1 ? tf->d_r2l : nullptr;
+    tf->angles.resize(F->N);
+    for (int i = 0; i < nL; i++) tf->angles[i] = F->keys[i].angle;
+    for (int i = 0; i < nR; i++) tf->angles[nL + i] = F->keys_right[i].angle;
+    tf->holder.assign(F->holder_obs, F->holder_obs + F->N);
+    tf->loaded = true;
+    return FT_OK;
+}
+
+int ft_tracked_frame_bind_stereo(ft_tracked_frame *tf, ft_stereo_frontend *fe, int slot, const ft_frame_view *meta) {
+    FT_REQUIRE(tf && fe && meta, "ft_tracked_frame_bind_stereo: null argument");
+    FT_REQUIRE(tf->ctx == fe->ctx, "tracked frame and front end belong to different contexts");
+    FT_REQUIRE(!fe->pending.active, "ft_tracked_frame_bind_stereo: the front end has a submitted batch that was not waited for");
+    ft_extractor *L = fe->exL;
+    FT_REQUIRE(slot >= 0 && slot < L->maxBatch, "ft_tracked_frame_bind_stereo: slot out of range");
+    const int N = L->h_nSel[slot];
+    FT_REQUIRE(meta->Nleft == -1, "ft_tracked_frame_bind_stereo: the stereo front end produces rectified frames (Nleft == -1)");
+    FT_REQUIRE(meta->N == N, "ft_tracked_frame_bind_stereo: meta->N differs from the keypoint count of the slot");
+    FT_REQUIRE(N <= tf->maxKp, "ft_tracked_frame_bind_stereo: more keypoints than the frame was created for");
+    FT_REQUIRE(meta->scale_factors && meta->nlevels >= 1 && meta->nlevels <= FT_MAX_LEVELS, "scale factors missing");
+    FT_REQUIRE(N == 0 || meta->keys, "ft_tracked_frame_bind_stereo: meta->keys (host copy of the keypoints) is null");
+    int rc = ft_set_device(tf->ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(tf->ctx->matchMutex);
+    tf->DF = devFrameConstants(meta);
+    tf->DF.keys = L->d_keys + (size_t)slot * L->geom.maxKp;
+    tf->DF.keysR = tf->d_keysR;
+    tf->DF.desc = L->d_desc + (size_t)slot * L->geom.maxKp * 32;
+    tf->DF.uright = fe->d_uright + (size_t)slot * fe->capacity;
+    tf->DF.holderObs = tf->d_holder;
+    tf->DF.l2r = nullptr;
+    tf->DF.r2l = nullptr;
+    tf->holder.assign(N, -1);
+    if (meta->holder_obs) tf->holder.assign(meta->holder_obs, meta->holder_obs + N);
+    tf->angles.resize(N);
+    for (int i = 0; i < N; i++) tf->angles[i] = meta->keys[i].angle;
+    if (N) FT_HIP(hipMemcpy(tf->d_holder, tf->holder.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+    tf->loaded = true;
+    return FT_OK;
+}
+
+int ft_tracked_frame_holder_obs(ft_tracked_frame *tf, int *holder_obs) {
+    FT_REQUIRE(tf && tf->loaded && holder_obs, "ft_tracked_frame_holder_obs: no frame loaded");
+    if (!tf->holder.empty()) memcpy(holder_obs, tf->holder.data(), sizeof(int) * tf->holder.size());
+    return FT_OK;
+}
+
+int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_points *L, const float *Tcw, float th,
+                                       int forward, int backward, int check_orientation, int *assign, int *n_matches) {
+    FT_REQUIRE(tf && tf->loaded && L && Tcw && assign, "ft_tracked_frame_search_last_frame: null argument / no frame loaded");
+    ft_context *ctx = tf->ctx;
+    const int M = L->N, N = tf->DF.N;
+    FT_REQUIRE(M >= 0 && M <= tf->maxPts, "last-frame point count beyond the frame's capacity");
+    FT_REQUIRE(M == 0 || (L->valid && L->world_pos && L->descriptors && L->observations && L->octave && L->angle),
+               "last-frame arrays are null");
+    for (int i = 0; i < N; i++) assign[i] = -1;
+    if (n_matches) *n_matches = 0;
+    if (M == 0 || N == 0) return FT_OK;
+    for (int i = 0; i < M; i++)
+        FT_REQUIRE(!L->valid[i] || (L->octave[i] >= 0 && L->octave[i] < tf->DF.nlevels), "last-frame octave out of range");
+    int rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    FtTimer tAll;
+    Arena a;
+    const size_t oValid = a.take(M), oPos = a.take(12 * (size_t)M), oDesc = a.take(32 * (size_t)M),
+                 oObs = a.take(4 * (size_t)M), oOct = a.take(4 * (size_t)M);
+    const size_t inputBytes = a.off;
+    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(4 * (size_t)N),
+                 oNext = a.take(16 * (size_t)M), oChanged = a.take(64);
+    FT_REQUIRE(a.off <= tf->workBytes, "tracked frame work arena too small");
+    uint8_t *pin = tf->h_work, *dev = tf->d_work;
+    memcpy(pin + oValid, L->valid, M);
+    memcpy(pin + oPos, L->world_pos, 12 * (size_t)M);
+    memcpy(pin + oDesc, L->descriptors, 32 * (size_t)M);
+    memcpy(pin + oObs, L->observations, 4 * (size_t)M);
+    memcpy(pin + oOct, L->octave, 4 * (size_t)M);
+    hipStream_t st = ctx->stream;
+    FT_HIP(hipMemcpyAsync(dev, pin, inputBytes, hipMemcpyHostToDevice, st));
+    FtDevLastPoints DL;
+    DL.N = M;
+    DL.valid = dev + oValid;
+    DL.worldPos = (const float *)(dev + oPos);
+    DL.desc = dev + oDesc;
+    DL.octave = (const int *)(dev + oOct);
+    FtClaims C;
+    C.head = (const int *)(dev + oHead);
+    C.next = (const int *)(dev + oNext);
+    C.obs = (const int *)(dev + oObs);
+    FtPose pose;
+    memcpy(pose.m, Tcw, sizeof pose.m);
+    FtLastRaw raw = {nullptr, nullptr, nullptr, nullptr};
+    int *resFinal = nullptr, passes = 0;
+    const FtDevFrame DF = tf->DF;
+    rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oNext),
+                    (int *)(dev + oChanged),
+                    [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
+                    &resFinal, &passes);
+    if (rc != FT_OK) return rc;
+    int *hRes = (int *)pin;
+    FT_HIP(hipMemcpyAsync(hRes, resFinal, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
+    FT_HIP(hipStreamSynchronize(st));
+    int nm = 0;
+    std::vector<int> rotHist[FT_HISTO_LENGTH];
+    const float factor = 1.0f / FT_HISTO_LENGTH;
+    for (int i = 0; i < M; i++) {
+        const int w2[2] = {hRes[4 * i], hRes[4 * i + 2]};
+        for (int k = 0; k < 2; k++) {
+            const int kp = w2[k];
+            if (kp < 0) continue;
+            tf->holder[kp] = L->observations[i];
+            assign[kp] = i;
+            nm++;
+            if (check_orientation) {
+                float rot = L->angle[i] - tf->angles[kp];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == FT_HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < FT_HISTO_LENGTH) rotHist[bin].push_back(kp);
+            }
+        }
+    }
+    if (check_orientation) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < FT_HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) {
+                max3 = max2; max2 = max1; max1 = sz;
+                ind3 = ind2; ind2 = ind1; ind1 = i;
+            } else if (sz > max2) {
+                max3 = max2; max2 = sz;
+                ind3 = ind2; ind2 = i;
+            } else if (sz > max3) {
+                max3 = sz; ind3 = i;
+            }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < FT_HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int kp : rotHist[i]) {
+                    assign[kp] = -1;
+                    tf->holder[kp] = -1;
+                    nm--;
+                }
+    }
+    // the occupancy the next search sees
+    memcpy(pin, tf->holder.data(), sizeof(int) * N);
+    FT_HIP(hipMemcpyAsync(tf->d_holder, pin, sizeof(int) * N, hipMemcpyHostToDevice, st));
+    FT_HIP(hipStreamSynchronize(st));
+    if (n_matches) *n_matches = nm;
+    ctx->addStat("tracked.search_last_frame.total", tAll.ms());
+    ctx->addStat("tracked.search_last_frame.passes", passes);
+    return FT_OK;
+}
+
+int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *pose, const ft_map_points *P,
+                                     float viewing_cos_limit, float log_scale_factor, float th, float nn_ratio,
+                                     int far_points, float th_far_points, const ft_frustum_result *frustum, int *n_to_match,
+                                     int *assign, int *n_matches) {
+    FT_REQUIRE(tf && tf->loaded && pose && assign, "ft_tracked_frame_track_local_map: null argument / no frame loaded");
+    int rc = checkMapPoints(P, true);
+    if (rc != FT_OK) return rc;
+    ft_context *ctx = tf->ctx;
+    const int M = P->M, N = tf->DF.N;
+    FT_REQUIRE(M <= tf->maxPts, "map point count beyond the frame's capacity");
+    for (int i = 0; i < N; i++) assign[i] = -1;
+    if (n_matches) *n_matches = 0;
+    if (n_to_match) *n_to_match = 0;
+    if (M == 0) return FT_OK;
+    rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    FtTimer tAll;
+    Arena a;
+    FrustumLayout FL;
+    size_t fInputEnd = 0;
+    layoutFrustum(M, P->skip != nullptr, a, FL, &fInputEnd);
+    const size_t fOutEnd = a.off;
+    const size_t oDesc = a.take(32 * (size_t)M), oObs = a.take(4 * (size_t)M);
+    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(4 * (size_t)std::max(N, 1)),
+                 oNext = a.take(16 * (size_t)M), oChanged = a.take(64);
+    FT_REQUIRE(a.off <= tf->workBytes, "tracked frame work arena too small");
+    uint8_t *pin = tf->h_work, *dev = tf->d_work;
+    stageFrustum(P, FL, pin);
+    memcpy(pin + oDesc, P->descriptors, 32 * (size_t)M);
+    memcpy(pin + oObs, P->observations, 4 * (size_t)M);
+    hipStream_t st = ctx->stream;
+    FT_HIP(hipMemcpyAsync(dev, pin, fInputEnd, hipMemcpyHostToDevice, st));
+    FT_HIP(hipMemcpyAsync(dev + oDesc, pin + oDesc, oObs + 4 * (size_t)M - oDesc, hipMemcpyHostToDevice, st));
+    const FtDevFrame DF = tf->DF;
+    const FtFrustumOut FO = devFrustumOut(FL, dev);
+    rc = ft_launch_frustum(st, DF, frustumPose_fromDev(DF, pose), devMapPoints(P, FL, dev), viewing_cos_limit, log_scale_factor,
+                           far_points, th_far_points, FO);
+    if (rc != FT_OK) return rc;
+    int nm = 0, passes = 0;
+    if (N > 0) {
+        // the frustum fields are the search's inputs where they are: no host round trip in between
+        FtDevLocalPoints DP;
+        DP.M = M;
+        DP.skip = FO.searchSkip; DP.inView = FO.inView; DP.inViewR = FO.inViewR;
+        DP.level = FO.level; DP.levelR = FO.levelR;
+        DP.viewCos = FO.viewCos; DP.viewCosR = FO.viewCosR;
+        DP.projX = FO.projX; DP.projY = FO.projY; DP.projXR = FO.projXR; DP.projYR = FO.projYR;
+        DP.desc = dev + oDesc;
+        FtClaims C;
+        C.head = (const int *)(dev + oHead);
+        C.next = (const int *)(dev + oNext);
+        C.obs = (const int *)(dev + oObs);
+        FtLocalRaw raw;
+        memset(&raw, 0, sizeof raw);
+        int *resFinal = nullptr;
+        rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oNext),
+                        (int *)(dev + oChanged),
+                        [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); }, &resFinal,
+                        &passes);
+        if (rc != FT_OK) return rc;
+        int *hRes = (int *)(pin + fOutEnd);
+        FT_HIP(hipMemcpyAsync(hRes, resFinal, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
+        rc = downloadFrustum(st, M, FL, fInputEnd, fOutEnd, dev, pin, frustum, n_to_match);
+        if (rc != FT_OK) return rc;
+        for (int i = 0; i < M; i++) {
+            const int obs = P->observations[i];
+            const int order[4] = {hRes[4 * i], hRes[4 * i + 1], hRes[4 * i + 3], hRes[4 * i + 2]};  // primL sideL sideR primR
+            for (int k = 0; k < 4; k++) {
+                const int kp = order[k];
+                if (kp < 0) continue;
+                tf->holder[kp] = obs;
+                assign[kp] = i;
+                nm++;
+            }
+        }
+        memcpy(pin, tf->holder.data(), sizeof(int) * N);
+        FT_HIP(hipMemcpyAsync(tf->d_holder, pin, sizeof(int) * N, hipMemcpyHostToDevice, st));
+        FT_HIP(hipStreamSynchronize(st));
+    } else {
+        rc = downloadFrustum(st, M, FL, fInputEnd, fOutEnd, dev, pin, frustum, n_to_match);
+        if (rc != FT_OK) return rc;
+    }
+    if (n_matches) *n_matches = nm;
+    ctx->addStat("tracked.track_local_map.total", tAll.ms());
+    ctx->addStat("tracked.track_local_map.passes", passes);
     return FT_OK;
 }
 

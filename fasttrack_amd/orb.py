@@ -428,3 +428,123 @@ class StereoFrontend:
                             keysR=self._kR[b, :nr].copy(), descR=self._dR[b, :nr].copy(),
                             uright=self._ur[b, :nl].copy(), depth=self._dp[b, :nl].copy(), n=int(self._nm[b])))
         return out
+
+
+FRUSTUM_FIELDS = [("in_view", np.uint8), ("in_view_r", np.uint8), ("level", np.int32), ("level_r", np.int32),
+                  ("view_cos", np.float32), ("view_cos_r", np.float32), ("proj_x", np.float32), ("proj_y", np.float32),
+                  ("proj_xr", np.float32), ("proj_yr", np.float32), ("depth", np.float32), ("depth_r", np.float32)]
+
+
+def make_pose(Rcw, tcw, tlr=(0, 0, 0)):
+    """ft_frame_pose from mRcw / mtcw; mOw = -Rcw^T tcw in float32 (Frame::UpdatePoseMatrices)."""
+    Rcw = np.asarray(Rcw, np.float32).reshape(3, 3)
+    tcw = np.asarray(tcw, np.float32).reshape(3)
+    Ow = (-(Rcw.T.astype(np.float32) @ tcw)).astype(np.float32)
+    T = _capi.FramePose()
+    T.Rcw[:] = [float(v) for v in Rcw.reshape(-1)]
+    T.tcw[:] = [float(v) for v in tcw]
+    T.Ow[:] = [float(v) for v in Ow]
+    T.tlr[:] = [float(v) for v in np.asarray(tlr, np.float32)]
+    return T
+
+
+def _map_points(pts: dict, keep: dict):
+    M = len(pts["world_pos"])
+    P = _capi.MapPoints()
+    P.M = M
+
+    def arr(k, dt):
+        if pts.get(k) is None:
+            return None
+        keep[k] = np.ascontiguousarray(pts[k], dt)
+        return ptr(keep[k])
+    P.skip = arr("skip", np.uint8)
+    P.world_pos, P.normal = arr("world_pos", np.float32), arr("normal", np.float32)
+    P.max_distance, P.min_distance = arr("max_distance", np.float32), arr("min_distance", np.float32)
+    P.descriptors, P.observations = arr("descriptors", np.uint8), arr("observations", np.int32)
+    return P, M
+
+
+def _frustum_result(M):
+    outs = {k: np.zeros(max(M, 1), dt) for k, dt in FRUSTUM_FIELDS}
+    R = _capi.FrustumResult()
+    for k, _ in FRUSTUM_FIELDS:
+        setattr(R, k, ptr(outs[k]))
+    return R, outs
+
+
+def is_in_frustum(ctx: Context, F: "FrameView", pose, pts: dict, viewing_cos_limit: float, log_scale_factor: float):
+    """Frame::isInFrustum for all points (ft_is_in_frustum); pts: world_pos, normal, max_distance, min_distance[, skip]."""
+    keep = {}
+    P, M = _map_points(pts, keep)
+    R, outs = _frustum_result(M)
+    n = C.c_int()
+    check(lib().ft_is_in_frustum(ctx._h, C.byref(F.c), C.byref(pose), C.byref(P), viewing_cos_limit, log_scale_factor,
+                                 C.byref(R), C.byref(n)))
+    r = {k: v[:M] for k, v in outs.items()}
+    r["n"] = n.value
+    return r
+
+
+class TrackedFrame:
+    """Device-resident frame for the projection searches (ft_tracked_frame_*)."""
+
+    def __init__(self, ctx: Context, max_keypoints: int, max_points: int):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        check(lib().ft_tracked_frame_create(ctx._h, max_keypoints, max_points, C.byref(self._h)))
+        self.N = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib().ft_tracked_frame_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, F: "FrameView"):
+        check(lib().ft_tracked_frame_upload(self._h, C.byref(F.c)))
+        self.N = F.c.N
+
+    def bind_stereo(self, fe: "StereoFrontend", slot: int, meta: "FrameView"):
+        check(lib().ft_tracked_frame_bind_stereo(self._h, fe._h, slot, C.byref(meta.c)))
+        self.N = meta.c.N
+
+    def holder_obs(self):
+        out = np.zeros(max(self.N, 1), np.int32)
+        check(lib().ft_tracked_frame_holder_obs(self._h, ptr(out)))
+        return out[:self.N]
+
+    def search_last_frame(self, last: dict, Tcw, th, forward=False, backward=False, check_orientation=True):
+        N = len(last["valid"])
+        keep = {k: np.ascontiguousarray(last[k], dt) for k, dt in
+                (("valid", np.uint8), ("world_pos", np.float32), ("descriptors", np.uint8), ("observations", np.int32),
+                 ("octave", np.int32), ("angle", np.float32))}
+        Lp = _capi.LastPoints()
+        Lp.N = N
+        for k in keep:
+            setattr(Lp, k, ptr(keep[k]))
+        T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(3, 4))
+        assign = np.zeros(max(self.N, 1), np.int32)
+        n = C.c_int()
+        check(lib().ft_tracked_frame_search_last_frame(self._h, C.byref(Lp), ptr(T), th, int(forward), int(backward),
+                                                       int(check_orientation), ptr(assign), C.byref(n)))
+        return dict(assign=assign[:self.N], n=n.value)
+
+    def track_local_map(self, pose, pts: dict, viewing_cos_limit, log_scale_factor, th, nn_ratio=0.8, far_points=False,
+                        th_far_points=0.0):
+        keep = {}
+        P, M = _map_points(pts, keep)
+        R, outs = _frustum_result(M)
+        assign = np.zeros(max(self.N, 1), np.int32)
+        n, nt = C.c_int(), C.c_int()
+        check(lib().ft_tracked_frame_track_local_map(self._h, C.byref(pose), C.byref(P), viewing_cos_limit, log_scale_factor,
+                                                     th, nn_ratio, int(far_points), th_far_points, C.byref(R), C.byref(nt),
+                                                     ptr(assign), C.byref(n)))
+        r = {k: v[:M] for k, v in outs.items()}
+        r.update(assign=assign[:self.N], n=n.value, n_to_match=nt.value)
+        return r

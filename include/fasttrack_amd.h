@@ -264,6 +264,79 @@ FT_API int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_la
                                 int *n_matches, int *best_dist, int *best_idx, int *best_dist_r,
                                 int *best_idx_r);
 
+/* ------------------------------------------------------------------------------------------------
+ * Frustum test + scale prediction for the local map points: Frame::isInFrustum /
+ * isInFrustumChecks (src/Frame.cc:536-610, 1308-1382) with MapPoint::PredictScale (src/MapPoint.cc:531-546),
+ * the host loop in front of SearchByProjection (src/Tracking.cc:3503-3522).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ft_frame_pose {
+    float Rcw[9]; /* mRcw, row-major */
+    float tcw[3]; /* mtcw */
+    float Ow[3];  /* mOw */
+    float tlr[3]; /* mTlr.translation(), two-camera frames only (Frame.cc:1319) */
+} ft_frame_pose;
+
+typedef struct ft_map_points {
+    int M;
+    const uint8_t *skip;       /* NULL or: mnLastFrameSeen == frame id || isBad() (Tracking.cc:3507-3510) */
+    const float *world_pos;    /* M x 3, GetWorldPos() */
+    const float *normal;       /* M x 3, GetNormal() */
+    const float *max_distance; /* mfMaxDistance (GetMaxDistanceInvariance() is 1.2f times this) */
+    const float *min_distance; /* mfMinDistance (GetMinDistanceInvariance() is 0.8f times this) */
+    const uint8_t *descriptors; /* M x 32, GetDescriptor()  - read by the searches only */
+    const int *observations;    /* Observations()           - read by the searches only */
+} ft_map_points;
+
+/* The MapPoint tracking fields isInFrustum writes (arrays of M, each may be NULL): mbTrackInView(R),
+ * mnTrackScaleLevel(R), mTrackViewCos(R), mTrackProjX/Y, mTrackProjXR/YR, mTrackDepth(R).  Fields the
+ * reference leaves untouched for a point read level -1, view_cos 0, proj -1, depth 0. */
+typedef struct ft_frustum_result {
+    uint8_t *in_view, *in_view_r;
+    int *level, *level_r;
+    float *view_cos, *view_cos_r;
+    float *proj_x, *proj_y, *proj_xr, *proj_yr;
+    float *depth, *depth_r;
+} ft_frustum_result;
+
+/* F supplies the frame constants only (Nleft, bounds, camera, Trl, mbf, nlevels); its keypoint arrays are not
+ * read.  log_scale_factor = Frame::mfLogScaleFactor.  *n_to_match = number of points in view of a camera. */
+FT_API int ft_is_in_frustum(ft_context *ctx, const ft_frame_view *F, const ft_frame_pose *pose, const ft_map_points *P,
+                            float viewing_cos_limit, float log_scale_factor, const ft_frustum_result *out,
+                            int *n_to_match);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident frame for the projection searches.  The reference re-marshals the whole
+ * Frame into a CudaFrame on every kernel call (src/Kernels/CudaWrappers/CudaFrame.cu:77-181).  Here the frame
+ * is uploaded once (or bound to the buffers a stereo front end already holds in HBM: no copy at all) and is
+ * then used by isInFrustum, SearchByProjection(last frame) and SearchByProjection(local map); the occupancy
+ * of mvpMapPoints (holder_obs) carries over from one search to the next as in Tracking::TrackWithMotionModel
+ * followed by Tracking::SearchLocalPoints, and the frustum outputs feed the local-map search without
+ * leaving the device.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ft_tracked_frame ft_tracked_frame;
+FT_API int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, ft_tracked_frame **out);
+FT_API int ft_tracked_frame_destroy(ft_tracked_frame *tf);
+/* copies keys / descriptors / uright / match tables / holder_obs of F to the device */
+FT_API int ft_tracked_frame_upload(ft_tracked_frame *tf, const ft_frame_view *F);
+/* pair `slot` of the batch the front end processed last (rectified stereo, Nleft == -1): keypoints, descriptors
+ * and mvuRight are used where ft_stereo_frontend_* left them in HBM.  meta supplies the frame constants and
+ * meta->keys (host copy, for the rotation histogram); holder_obs starts at meta->holder_obs or all -1.
+ * The binding is valid until the front end processes another batch. */
+FT_API int ft_tracked_frame_bind_stereo(ft_tracked_frame *tf, ft_stereo_frontend *fe, int slot, const ft_frame_view *meta);
+/* ft_search_last_frame on the resident frame; updates the resident holder_obs */
+FT_API int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_points *L, const float *Tcw, float th,
+                                              int forward, int backward, int check_orientation, int *assign,
+                                              int *n_matches);
+/* Tracking::SearchLocalPoints on the resident frame: isInFrustum (viewing_cos_limit, log_scale_factor) for all
+ * points, then SearchByProjection(F, points, th, far_points, th_far_points) on the device-resident results.
+ * frustum (may be NULL) receives the isInFrustum fields; assign / n_matches as in ft_search_local_points. */
+FT_API int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *pose, const ft_map_points *P,
+                                            float viewing_cos_limit, float log_scale_factor, float th, float nn_ratio,
+                                            int far_points, float th_far_points, const ft_frustum_result *frustum,
+                                            int *n_to_match, int *assign, int *n_matches);
+/* current holder_obs (size N of the resident frame) */
+FT_API int ft_tracked_frame_holder_obs(ft_tracked_frame *tf, int *holder_obs);
+
 /* ORBmatcher::DescriptorDistance for n pairs on the device (src/ORBmatcher.cc:2256-2272,
  * device copy src/Kernels/CudaUtils.cu:42-56).  a, b: n x 32 host bytes; dist: n ints. */
 FT_API int ft_descriptor_distance(ft_context *ctx, const uint8_t *a, const uint8_t *b, int n, int *dist);

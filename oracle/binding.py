@@ -53,6 +53,15 @@ class LastPoints(C.Structure):
                 ("observations", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p)]
 
 
+class FramePose(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("tlr", C.c_float * 3)]
+
+
+class MapPoints(C.Structure):
+    _fields_ = [("M", C.c_int), ("skip", C.c_void_p), ("world_pos", C.c_void_p), ("normal", C.c_void_p),
+                ("max_distance", C.c_void_p), ("min_distance", C.c_void_p)]
+
+
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile) if the .so is missing or stale."""
     src = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "orb_oracle.h", "orb_pattern.inc", "Makefile")]
@@ -385,5 +394,48 @@ def search_last_frame(Cur: FrameView, last: dict, Tcw, th, forward=False, backwa
     names = ["best_dist", "best_idx", "best_dist_r", "best_idx_r"]
     r = {k: o[:N] for k, o in zip(names, outs)}
     r["assign"] = assign[:Cur.N]
+    r["n"] = n
+    return r
+
+
+FRUSTUM_FIELDS = [("in_view", np.uint8), ("in_view_r", np.uint8), ("level", np.int32), ("level_r", np.int32),
+                  ("view_cos", np.float32), ("view_cos_r", np.float32), ("proj_x", np.float32), ("proj_y", np.float32),
+                  ("proj_xr", np.float32), ("proj_yr", np.float32), ("depth", np.float32), ("depth_r", np.float32)]
+
+
+def make_pose(Rcw, tcw, tlr=(0, 0, 0)):
+    """-> FramePose with mOw = -Rcw^T tcw evaluated in float32 like Frame::UpdatePoseMatrices (Frame.cc:487-497)"""
+    Rcw = np.asarray(Rcw, np.float32).reshape(3, 3)
+    tcw = np.asarray(tcw, np.float32).reshape(3)
+    Ow = (-(Rcw.T.astype(np.float32) @ tcw)).astype(np.float32)
+    T = FramePose()
+    T.Rcw[:] = [float(v) for v in Rcw.reshape(-1)]
+    T.tcw[:] = [float(v) for v in tcw]
+    T.Ow[:] = [float(v) for v in Ow]
+    T.tlr[:] = [float(v) for v in np.asarray(tlr, np.float32)]
+    return T
+
+
+def is_in_frustum(F: FrameView, pose: FramePose, pts: dict, viewing_cos_limit: float, log_scale_factor: float):
+    """pts: dict(world_pos[M,3], normal[M,3], max_distance[M], min_distance[M], skip[M] optional)."""
+    M = len(pts["world_pos"])
+    keep = {}
+
+    def arr(k, dt):
+        keep[k] = np.ascontiguousarray(pts[k], dt)
+        return _p(keep[k])
+
+    P = MapPoints()
+    P.M = M
+    P.skip = arr("skip", np.uint8) if pts.get("skip") is not None else None
+    P.world_pos, P.normal = arr("world_pos", np.float32), arr("normal", np.float32)
+    P.max_distance, P.min_distance = arr("max_distance", np.float32), arr("min_distance", np.float32)
+    outs = [np.zeros(max(M, 1), dt) for _, dt in FRUSTUM_FIELDS]
+    lib().orc_is_in_frustum.restype = C.c_int
+    lib().orc_is_in_frustum.argtypes = [C.POINTER(Frame), C.POINTER(FramePose), C.POINTER(MapPoints), C.c_float,
+                                        C.c_float] + [C.c_void_p] * 12
+    n = lib().orc_is_in_frustum(C.byref(F.c), C.byref(pose), C.byref(P), viewing_cos_limit, log_scale_factor,
+                                *[_p(o) for o in outs])
+    r = {k: o[:M] for (k, _), o in zip(FRUSTUM_FIELDS, outs)}
     r["n"] = n
     return r

@@ -1228,4 +1228,106 @@ int orc_search_last_frame(orc_frame *Cur, const orc_last_points *Lp, const float
     return nmatches;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Frame::isInFrustum (src/Frame.cc:536-610), Frame::isInFrustumChecks (:1308-1382),
+// MapPoint::PredictScale (src/MapPoint.cc:531-546).  Eigen fixed-size float expressions are evaluated
+// left to right without contraction: (a0*b0 + a1*b1) + a2*b2, norm = sqrt((x*x + y*y) + z*z).
+// `log(ratio)` binds to logf (float argument, `using namespace std` reaches MapPoint.cc through
+// include/Kernels/KernelController.h:11), `ceil` to ceilf.
+// ------------------------------------------------------------------------------------------------
+static inline float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline float norm3(const float *a) { return sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); }
+
+static int predictScale(float maxDistanceRaw, float currentDist, float logScaleFactor, int nLevels) {
+    const float ratio = maxDistanceRaw / currentDist;
+    int nScale = (int)ceilf(logf(ratio) / logScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nLevels) nScale = nLevels - 1;
+    return nScale;
+}
+
+int orc_is_in_frustum(const orc_frame *F, const orc_frame_pose *T, const orc_map_points *P, float viewingCosLimit,
+                      float logScaleFactor, uint8_t *in_view, uint8_t *in_view_r, int *level, int *level_r,
+                      float *view_cos, float *view_cos_r, float *proj_x, float *proj_y, float *proj_xr,
+                      float *proj_yr, float *depth, float *depth_r) {
+    // right camera (Frame.cc:1314-1320): mR = Rrl * mRcw, mt = Rrl * mtcw + trl, twc = mRwc * tlr + mOw
+    float Rr[9], tr[3], twcR[3];
+    {
+        const float *Trl = F->Trl;
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++)
+                Rr[3 * i + j] = (Trl[4 * i] * T->Rcw[j] + Trl[4 * i + 1] * T->Rcw[3 + j]) + Trl[4 * i + 2] * T->Rcw[6 + j];
+            tr[i] = ((Trl[4 * i] * T->tcw[0] + Trl[4 * i + 1] * T->tcw[1]) + Trl[4 * i + 2] * T->tcw[2]) + Trl[4 * i + 3];
+            // mRwc = mRcw^T
+            twcR[i] = ((T->Rcw[i] * T->tlr[0] + T->Rcw[3 + i] * T->tlr[1]) + T->Rcw[6 + i] * T->tlr[2]) + T->Ow[i];
+        }
+    }
+    int nToMatch = 0;
+    for (int i = 0; i < P->M; i++) {
+        in_view[i] = 0; in_view_r[i] = 0;
+        level[i] = -1; level_r[i] = -1;
+        view_cos[i] = 0; view_cos_r[i] = 0;
+        proj_x[i] = -1; proj_y[i] = -1; proj_xr[i] = -1; proj_yr[i] = -1;
+        depth[i] = 0; depth_r[i] = 0;
+        if (P->skip && P->skip[i]) continue;
+        const float *Pw = P->world_pos + 3 * i, *Pn = P->normal + 3 * i;
+        const float maxDistance = 1.2f * P->max_distance[i], minDistance = 0.8f * P->min_distance[i];
+        if (F->Nleft == -1) {  // Frame.cc:538-597
+            float Pc[3];
+            for (int r = 0; r < 3; r++) Pc[r] = dot3(T->Rcw + 3 * r, Pw) + T->tcw[r];
+            const float Pc_dist = norm3(Pc);
+            const float PcZ = Pc[2];
+            const float invz = 1.0f / PcZ;
+            if (PcZ < 0.0f) continue;
+            float uv[2];
+            projectCam(F, Pc, uv);
+            if (uv[0] < F->mnMinX || uv[0] > F->mnMaxX) continue;
+            if (uv[1] < F->mnMinY || uv[1] > F->mnMaxY) continue;
+            proj_x[i] = uv[0];
+            proj_y[i] = uv[1];
+            const float PO[3] = {Pw[0] - T->Ow[0], Pw[1] - T->Ow[1], Pw[2] - T->Ow[2]};
+            const float dist = norm3(PO);
+            if (dist < minDistance || dist > maxDistance) continue;
+            const float viewCos = dot3(PO, Pn) / dist;
+            if (viewCos < viewingCosLimit) continue;
+            const int nPredictedLevel = predictScale(P->max_distance[i], dist, logScaleFactor, F->nlevels);
+            in_view[i] = 1;
+            proj_xr[i] = uv[0] - F->mbf * invz;
+            depth[i] = Pc_dist;
+            level[i] = nPredictedLevel;
+            view_cos[i] = viewCos;
+            nToMatch++;
+        } else {  // Frame.cc:599-609 -> isInFrustumChecks for both cameras
+            for (int right = 0; right < 2; right++) {
+                const float *R = right ? Rr : T->Rcw, *t = right ? tr : T->tcw, *twc = right ? twcR : T->Ow;
+                float Pc[3];
+                for (int r = 0; r < 3; r++) Pc[r] = dot3(R + 3 * r, Pw) + t[r];
+                const float Pc_dist = norm3(Pc);
+                if (Pc[2] < 0.0f) continue;
+                float uv[2];
+                projectCam(F, Pc, uv);  // mpCamera2 has the parameters of mpCamera in this POD view
+                if (uv[0] < F->mnMinX || uv[0] > F->mnMaxX) continue;
+                if (uv[1] < F->mnMinY || uv[1] > F->mnMaxY) continue;
+                const float PO[3] = {Pw[0] - twc[0], Pw[1] - twc[1], Pw[2] - twc[2]};
+                const float dist = norm3(PO);
+                if (dist < minDistance || dist > maxDistance) continue;
+                const float viewCos = dot3(PO, Pn) / dist;
+                if (viewCos < viewingCosLimit) continue;
+                const int nPredictedLevel = predictScale(P->max_distance[i], dist, logScaleFactor, F->nlevels);
+                if (right) {
+                    in_view_r[i] = 1;
+                    proj_xr[i] = uv[0]; proj_yr[i] = uv[1];
+                    level_r[i] = nPredictedLevel; view_cos_r[i] = viewCos; depth_r[i] = Pc_dist;
+                } else {
+                    in_view[i] = 1;
+                    proj_x[i] = uv[0]; proj_y[i] = uv[1];
+                    level[i] = nPredictedLevel; view_cos[i] = viewCos; depth[i] = Pc_dist;
+                }
+            }
+            if (in_view[i] || in_view_r[i]) nToMatch++;
+        }
+    }
+    return nToMatch;
+}
+
 }  // extern "C"

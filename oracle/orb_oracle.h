@@ -153,6 +153,30 @@ int orc_search_last_frame(orc_frame *Cur, const orc_last_points *L, const float 
                           int *best_dist_r, int *best_idx_r);
 void orc_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3);
 
+/* ---- Frame::isInFrustum / isInFrustumChecks + MapPoint::PredictScale
+ *      (src/Frame.cc:536-610, 1308-1382; src/MapPoint.cc:531-546): the per-map-point step in front of
+ *      SearchByProjection (src/Tracking.cc:3503-3522) ---- */
+typedef struct orc_frame_pose {
+    float Rcw[9]; /* mRcw row-major */
+    float tcw[3]; /* mtcw */
+    float Ow[3];  /* mOw */
+    float tlr[3]; /* mTlr.translation() (two-camera frames only) */
+} orc_frame_pose;
+typedef struct orc_map_points {
+    int M;
+    const uint8_t *skip;       /* mnLastFrameSeen == frame id || isBad(): not tested (Tracking.cc:3507-3510) */
+    const float *world_pos;    /* M x 3 GetWorldPos() */
+    const float *normal;       /* M x 3 GetNormal() */
+    const float *max_distance; /* mfMaxDistance (GetMaxDistanceInvariance = 1.2f * this) */
+    const float *min_distance; /* mfMinDistance (GetMinDistanceInvariance = 0.8f * this) */
+} orc_map_points;
+/* outputs (size M): the MapPoint tracking fields; values the reference leaves untouched are written as
+ * level -1, view_cos 0, proj -1, depth 0.  returns the number of points with in_view || in_view_r (nToMatch). */
+int orc_is_in_frustum(const orc_frame *F, const orc_frame_pose *T, const orc_map_points *P, float viewing_cos_limit,
+                      float log_scale_factor, uint8_t *in_view, uint8_t *in_view_r, int *level, int *level_r,
+                      float *view_cos, float *view_cos_r, float *proj_x, float *proj_y, float *proj_xr,
+                      float *proj_yr, float *depth, float *depth_r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,3 +127,55 @@ def last_frame_scenario(keys, desc, uright, depth, intr, width, height, seed, ze
     angle = (keys["angle"] + rng.normal(0, 3.0, N)).astype(np.float32) % np.float32(360.0)
     return dict(valid=valid, world_pos=world, descriptors=d, observations=obs, octave=keys["octave"].astype(np.int32),
                 angle=angle.astype(np.float32)), Tcw
+
+
+def map_points_scenario(keys, desc, depth, intr, nlevels, sf, seed, M=2500, tlr=None):
+    """Local map points for Frame::isInFrustum: back-projected keypoints (stereo depth where available) seen from
+    a camera that moved by a small SE(3) step, plus points behind the camera, outside the image, outside their
+    scale-invariance range and seen at a grazing angle, so that every early return is taken."""
+    rng = np.random.default_rng(seed)
+    N = len(keys)
+    src = rng.integers(0, N, M)
+    z = np.where(depth[src] > 0, depth[src], rng.uniform(1.0, 12.0, M)).astype(np.float32)
+    fx, fy, cx, cy = [float(intr[k]) for k in ("fx", "fy", "cx", "cy")]
+    X = ((keys["x"][src] + rng.normal(0, 1.5, M)) - cx) / fx * z
+    Y = ((keys["y"][src] + rng.normal(0, 1.5, M)) - cy) / fy * z
+    world = np.stack([X, Y, z], 1).astype(np.float32)
+    kind = rng.random(M)
+    world[kind < 0.05, 2] *= -1.0                       # behind the camera
+    world[(kind >= 0.05) & (kind < 0.12), 0] *= 6.0     # outside the image
+    T = random_pose(rng, trans=0.1, rot=0.02)
+    Rcw, tcw = T[:, :3].copy(), T[:, 3].copy()
+    Ow = -(Rcw.T @ tcw)
+    PO = world - Ow[None, :]
+    dist = np.linalg.norm(PO, axis=1)
+    # normals: mean viewing direction with noise; a share at grazing angles
+    nrm = PO / dist[:, None] + rng.normal(0, 0.25, (M, 3))  # mNormalVector: mean unit vector camera -> point
+    graze = rng.random(M) < 0.1
+    nrm[graze] = np.cross(PO[graze], rng.normal(0, 1, (int(graze.sum()), 3)))
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1), 1e-9)[:, None]
+    # scale invariance range: the point was observed at level `lv` from distance d0
+    lv = np.clip(keys["octave"][src], 0, nlevels - 1)
+    d0 = dist * rng.uniform(0.6, 1.6, M)
+    max_d = (d0 * sf[lv]).astype(np.float32)
+    min_d = (max_d / sf[nlevels - 1]).astype(np.float32)
+    d = desc[src].copy()
+    flips = rng.integers(0, 256, (M, 10))
+    for k in range(10):
+        m = rng.random(M) < 0.5
+        d[m, flips[m, k] // 8] ^= (1 << (flips[m, k] % 8)).astype(np.uint8)
+    obs = np.where(rng.random(M) < 0.15, 0, rng.integers(1, 6, M)).astype(np.int32)
+    pts = dict(world_pos=world, normal=nrm.astype(np.float32), max_distance=max_d, min_distance=min_d,
+               skip=(rng.random(M) < 0.04).astype(np.uint8), descriptors=d, observations=obs)
+    return pts, Rcw.astype(np.float32), tcw.astype(np.float32)
+
+
+def local_points_from_frustum(fr: dict, pts: dict, far_points=False, th_far=0.0):
+    """what ORBmatcher::SearchByProjection reads from the MapPoints after isInFrustum (ORBmatcher.cc:66-74)"""
+    skip = (~(fr["in_view"].astype(bool) | fr["in_view_r"].astype(bool))) | pts["skip"].astype(bool)
+    if far_points:
+        skip |= fr["depth"] > np.float32(th_far)
+    return dict(skip=skip.astype(np.uint8), in_view=fr["in_view"], in_view_r=fr["in_view_r"], level=fr["level"],
+                level_r=fr["level_r"], view_cos=fr["view_cos"], view_cos_r=fr["view_cos_r"], proj_x=fr["proj_x"],
+                proj_y=fr["proj_y"], proj_xr=fr["proj_xr"], proj_yr=fr["proj_yr"], descriptors=pts["descriptors"],
+                observations=pts["observations"])

@@ -263,3 +263,122 @@ def test_search_last_frame_two_cameras_kb8(ctx):
     assert g["n"] == o["n"] and np.array_equal(g["assign"], o["assign"])
     for k in ("best_dist", "best_idx", "best_dist_r", "best_idx_r"):
         assert np.array_equal(g[k], o[k]), k
+
+
+LOG_SF = float(np.float32(np.log(np.float32(1.2))))  # Frame::mfLogScaleFactor = log(mfScaleFactor) stored as float
+
+
+def _frustum_case(w, h, nf, seed):
+    fr = sc.oracle_stereo_frame(w, h, nf, seed)
+    sf, _ = ob.scale_factors(1.2, 8)
+    sm = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], fr["intr"]["mbf"], fr["intr"]["mb"])
+    pts, Rcw, tcw = sc.map_points_scenario(fr["kL"], fr["dL"], sm["depth"], fr["intr"], 8, sf, seed + 100)
+    return fr, sf, sm, pts, Rcw, tcw
+
+
+def test_is_in_frustum_pinhole_bit_exact(ctx):
+    """Frame::isInFrustum + PredictScale for rectified stereo (Nleft == -1): every flag, level and float field equals
+    the oracle's bit for bit (pinhole projection is plain float arithmetic)."""
+    w, h = 752, 480
+    fr, sf, sm, pts, Rcw, tcw = _frustum_case(w, h, 1200, 21)
+    oF, gF = _frame_views(fr, sf, w, h, uright=sm["uright"])
+    for limit in (0.5, 0.9):
+        o = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw), pts, limit, LOG_SF)
+        g = orb.is_in_frustum(ctx, gF, orb.make_pose(Rcw, tcw), pts, limit, LOG_SF)
+        assert 200 < o["n"] < len(pts["world_pos"]) - 200
+        assert g["n"] == o["n"]
+        for k, _ in ob.FRUSTUM_FIELDS:
+            assert np.array_equal(g[k], o[k]), k
+    empty = {k: v[:0] for k, v in pts.items()}
+    assert orb.is_in_frustum(ctx, gF, orb.make_pose(Rcw, tcw), empty, 0.5, LOG_SF)["n"] == 0
+
+
+def test_is_in_frustum_two_cameras_kb8(ctx):
+    """fisheye stereo (Nleft != -1): both cameras through isInFrustumChecks, right camera pose composed from Trl / Tlr.
+    KannalaBrandt8 uses atan2f/cosf/sinf (libm on the host, OCML on the device): flags and levels must agree away
+    from decision boundaries, floats within 1e-3 px / 1e-6."""
+    w, h = 512, 512
+    fr = sc.fisheye_frame_scenario(w, h, 1500, 10)
+    sf, _ = ob.scale_factors(1.2, 8)
+    cam = [190.978, 190.973, 254.93, 256.90, 0.0034, 0.0007, -0.0020, 0.00020]
+    Trl = np.concatenate([np.eye(3), [[-0.1], [0.0], [0.0]]], 1).astype(np.float32)
+    kw = dict(keys=fr["kL"], keys_right=fr["kR"], descriptors=np.concatenate([fr["dL"], fr["dR"]]),
+              bounds=sc.frame_bounds(w, h), left_to_right=fr["l2r"], right_to_left=fr["r2l"], cam_model=1, cam=cam, Trl=Trl)
+    oF, gF = ob.FrameView(scale_factors_=sf, **kw), orb.FrameView(scale_factors=sf, **kw)
+    intr = dict(fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+    pts, Rcw, tcw = sc.map_points_scenario(fr["kL"], fr["dL"], np.zeros(len(fr["kL"]), np.float32), intr, 8, sf, 77)
+    tlr = (0.1, 0.0, 0.0)
+    o = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, tlr), pts, 0.5, LOG_SF)
+    g = orb.is_in_frustum(ctx, gF, orb.make_pose(Rcw, tcw, tlr), pts, 0.5, LOG_SF)
+    assert o["in_view"].sum() > 200 and o["in_view_r"].sum() > 200 and (o["in_view"] != o["in_view_r"]).sum() > 5
+    same = (g["in_view"] == o["in_view"]) & (g["in_view_r"] == o["in_view_r"])
+    assert same.mean() > 0.999, "flags differ on more than boundary cases"
+    assert abs(g["n"] - o["n"]) <= (~same).sum()
+    for k in ("level", "level_r"):
+        assert np.array_equal(g[k][same], o[k][same]), k
+    for k in ("proj_x", "proj_y", "proj_xr", "proj_yr"):
+        assert np.allclose(g[k][same], o[k][same], rtol=0, atol=1e-3), k
+    for k in ("view_cos", "view_cos_r", "depth", "depth_r"):
+        assert np.array_equal(g[k][same], o[k][same]), k  # no transcendental on these paths
+
+
+def _oracle_tracking_sequence(oF, last, Tcw_last, pts, Rcw, tcw, th_last, th_local, far, th_far):
+    """TrackWithMotionModel's search followed by SearchLocalPoints on the same frame (holder_obs carries over)"""
+    o1 = ob.search_last_frame(oF, last, Tcw_last, th_last, False, False, True)
+    ofr = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw), pts, 0.5, LOG_SF)
+    o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, pts, far, th_far), th_local)
+    return o1, ofr, o2
+
+
+@pytest.mark.parametrize("far", [False, True])
+def test_tracked_frame_sequence_equals_oracle(ctx, far):
+    """ft_tracked_frame: upload once, then SearchByProjection(last frame) and isInFrustum + SearchByProjection(local
+    map) on the resident frame - assignments, frustum fields and the final mvpMapPoints occupancy equal the oracle
+    running the same sequence; the frustum outputs never visit the host between the two kernels."""
+    w, h = 752, 480
+    fr, sf, sm, pts, Rcw, tcw = _frustum_case(w, h, 1200, 23)
+    last, Tcw_last = sc.last_frame_scenario(fr["kL"], fr["dL"], sm["uright"], sm["depth"], fr["intr"], w, h, seed=4)
+    oF, gF = _frame_views(fr, sf, w, h, uright=sm["uright"])
+    th_far = float(np.percentile(sm["depth"][sm["depth"] > 0], 85)) if far else 0.0
+    o1, ofr, o2 = _oracle_tracking_sequence(oF, last, Tcw_last, pts, Rcw, tcw, 15.0, 3.0, far, th_far)
+    tf = orb.TrackedFrame(ctx, max_keypoints=4096, max_points=4096)
+    tf.upload(gF)
+    g1 = tf.search_last_frame(last, Tcw_last, 15.0)
+    assert o1["n"] > 100 and g1["n"] == o1["n"] and np.array_equal(g1["assign"], o1["assign"])
+    g2 = tf.track_local_map(orb.make_pose(Rcw, tcw), pts, 0.5, LOG_SF, 3.0, far_points=far, th_far_points=th_far)
+    for k, _ in ob.FRUSTUM_FIELDS:
+        assert np.array_equal(g2[k], ofr[k]), k
+    assert g2["n_to_match"] == ofr["n"]
+    assert o2["n"] > 30 and g2["n"] == o2["n"] and np.array_equal(g2["assign"], o2["assign"])
+    assert np.array_equal(tf.holder_obs(), oF.holder_obs)
+    # a second frame through the same object
+    tf.upload(gF)
+    assert np.array_equal(tf.holder_obs(), gF.holder_obs)
+    tf.close()
+
+
+def test_tracked_frame_bound_to_stereo_frontend(ctx):
+    """the same sequence with the frame bound to what the stereo front end left in HBM (keypoints, descriptors,
+    mvuRight of pair 1 of the batch): no upload of the frame arrays at all"""
+    w, h, nf, B = 752, 480, 1200, 2
+    intr = synth.intrinsics(w, h)
+    fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
+    pairs = [synth.make_stereo_pair(w, h, 31 + b) for b in range(B)]
+    outs = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
+    out = outs[1]
+    sf, _ = ob.scale_factors(1.2, 8)
+    fr = dict(kL=out["keysL"], dL=out["descL"], intr=intr)
+    pts, Rcw, tcw = sc.map_points_scenario(out["keysL"], out["descL"], out["depth"], intr, 8, sf, 55)
+    last, Tcw_last = sc.last_frame_scenario(out["keysL"], out["descL"], out["uright"], out["depth"], intr, w, h, seed=6)
+    oF, gF = _frame_views(fr, sf, w, h, uright=out["uright"])
+    o1, ofr, o2 = _oracle_tracking_sequence(oF, last, Tcw_last, pts, Rcw, tcw, 15.0, 3.0, False, 0.0)
+    tf = orb.TrackedFrame(ctx, max_keypoints=fe.capacity, max_points=4096)
+    tf.bind_stereo(fe, 1, gF)
+    g1 = tf.search_last_frame(last, Tcw_last, 15.0)
+    g2 = tf.track_local_map(orb.make_pose(Rcw, tcw), pts, 0.5, LOG_SF, 3.0)
+    assert g1["n"] == o1["n"] and np.array_equal(g1["assign"], o1["assign"])
+    assert g2["n"] == o2["n"] and np.array_equal(g2["assign"], o2["assign"]) and o2["n"] > 50
+    assert np.array_equal(tf.holder_obs(), oF.holder_obs)
+    with pytest.raises(Exception):
+        tf.bind_stereo(fe, 5, gF)  # slot out of range
+    tf.close()

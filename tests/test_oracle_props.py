@@ -219,3 +219,45 @@ def test_features_in_area_against_numpy():
         # the grid window can only drop keypoints whose rounded cell falls outside it; never add any
         assert set(got.tolist()) <= set(np.nonzero(m)[0].tolist())
         assert len(got) >= m.sum() - 3
+
+
+def test_is_in_frustum_against_numpy():
+    """orc_is_in_frustum (Frame::isInFrustum + PredictScale) against a float64 numpy statement of the same tests:
+    flags and levels agree except for points within 1e-4 of a decision boundary, floats within 1e-4."""
+    from tests import scenarios as sc
+    fr = sc.oracle_stereo_frame(640, 480, 1000, 3)
+    sf = ob.scale_factors(1.2, 8)[0]
+    o = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], fr["intr"]["mbf"], fr["intr"]["mb"])
+    pts, Rcw, tcw = sc.map_points_scenario(fr["kL"], fr["dL"], o["depth"], fr["intr"], 8, sf, 17)
+    intr = fr["intr"]
+    cam = [intr["fx"], intr["fy"], intr["cx"], intr["cy"]]
+    F = ob.FrameView(fr["kL"], fr["dL"], sf, sc.frame_bounds(640, 480), mbf=intr["mbf"], mb=intr["mb"], uright=o["uright"],
+                     cam=cam)
+    pose = ob.make_pose(Rcw, tcw)
+    lsf = float(np.float32(np.log(np.float32(1.2))))
+    r = ob.is_in_frustum(F, pose, pts, 0.5, lsf)
+    P = pts["world_pos"].astype(np.float64)
+    Pc = P @ Rcw.astype(np.float64).T + tcw.astype(np.float64)
+    Ow = np.array([pose.Ow[i] for i in range(3)], np.float64)
+    z = Pc[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = cam[0] * Pc[:, 0] / z + cam[2]
+        v = cam[1] * Pc[:, 1] / z + cam[3]
+    PO = P - Ow
+    dist = np.linalg.norm(PO, axis=1)
+    vc = (PO * pts["normal"]).sum(1) / dist
+    maxd, mind = 1.2 * pts["max_distance"].astype(np.float64), 0.8 * pts["min_distance"].astype(np.float64)
+    margins = np.stack([z, u - 0, 640 - u, v - 0, 480 - v, dist - mind, maxd - dist, vc - 0.5], 1)
+    ok = (margins >= 0).all(1) & ~pts["skip"].astype(bool)
+    safe = (np.abs(margins) > 1e-3).all(1)
+    assert np.array_equal(r["in_view"].astype(bool)[safe], ok[safe])
+    assert r["n"] == int(r["in_view"].sum()) and 0.2 < ok.mean() < 0.9
+    m = ok & safe
+    assert np.allclose(r["proj_x"][m], u[m], atol=1e-3) and np.allclose(r["proj_y"][m], v[m], atol=1e-3)
+    assert np.allclose(r["view_cos"][m], vc[m], atol=1e-5) and np.allclose(r["depth"][m], np.linalg.norm(Pc, axis=1)[m], rtol=1e-5)
+    assert np.allclose(r["proj_xr"][m], (u - intr["mbf"] / z)[m], atol=1e-3)
+    q = np.log(pts["max_distance"].astype(np.float64) / dist) / lsf
+    lv = np.clip(np.ceil(q), 0, 7).astype(np.int32)
+    exact = np.abs(q - np.round(q)) > 1e-4
+    assert np.array_equal(r["level"][m & exact], lv[m & exact])
+    assert (r["level"][~r["in_view"].astype(bool)] == -1).all()
