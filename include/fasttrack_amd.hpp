@@ -195,4 +195,91 @@ struct KernelController {
     }
 };
 
+// Frame::isInFrustum for all local map points (src/Frame.cc:536-610, 1308-1382; the loop of
+// src/Tracking.cc:3503-3522).  The vectors receive the MapPoint tracking fields; returns nToMatch.
+struct FrustumFields {
+    std::vector<uint8_t> mbTrackInView, mbTrackInViewR;
+    std::vector<int> mnTrackScaleLevel, mnTrackScaleLevelR;
+    std::vector<float> mTrackViewCos, mTrackViewCosR, mTrackProjX, mTrackProjY, mTrackProjXR, mTrackProjYR, mTrackDepth,
+        mTrackDepthR;
+    ft_frustum_result view(int M) {
+        const size_t m = M > 0 ? (size_t)M : 1;
+        mbTrackInView.assign(m, 0); mbTrackInViewR.assign(m, 0);
+        mnTrackScaleLevel.assign(m, -1); mnTrackScaleLevelR.assign(m, -1);
+        for (auto *v : {&mTrackViewCos, &mTrackViewCosR, &mTrackProjX, &mTrackProjY, &mTrackProjXR, &mTrackProjYR, &mTrackDepth,
+                        &mTrackDepthR})
+            v->assign(m, 0.f);
+        ft_frustum_result r;
+        r.in_view = mbTrackInView.data(); r.in_view_r = mbTrackInViewR.data();
+        r.level = mnTrackScaleLevel.data(); r.level_r = mnTrackScaleLevelR.data();
+        r.view_cos = mTrackViewCos.data(); r.view_cos_r = mTrackViewCosR.data();
+        r.proj_x = mTrackProjX.data(); r.proj_y = mTrackProjY.data();
+        r.proj_xr = mTrackProjXR.data(); r.proj_yr = mTrackProjYR.data();
+        r.depth = mTrackDepth.data(); r.depth_r = mTrackDepthR.data();
+        return r;
+    }
+};
+
+inline int isInFrustum(Context &ctx, const ft_frame_view &F, const ft_frame_pose &pose, const ft_map_points &P,
+                       float viewingCosLimit, float mfLogScaleFactor, FrustumFields &out) {
+    const ft_frustum_result r = out.view(P.M);
+    int n = 0;
+    check(ft_is_in_frustum(ctx.handle(), &F, &pose, &P, viewingCosLimit, mfLogScaleFactor, &r, &n));
+    return n;
+}
+
+// Device-resident Frame for the projection searches (ft_tracked_frame_*): upload (or bind to a stereo front end
+// slot) once per frame, then SearchByProjection(last frame) and SearchLocalPoints without re-marshalling.
+class TrackedFrame {
+public:
+    TrackedFrame(Context &ctx, int maxKeypoints, int maxPoints) {
+        check(ft_tracked_frame_create(ctx.handle(), maxKeypoints, maxPoints, &h_));
+    }
+    ~TrackedFrame() { ft_tracked_frame_destroy(h_); }
+    TrackedFrame(const TrackedFrame &) = delete;
+    TrackedFrame &operator=(const TrackedFrame &) = delete;
+    void upload(const ft_frame_view &F) {
+        check(ft_tracked_frame_upload(h_, &F));
+        N_ = F.N;
+    }
+    void bindStereo(ft_stereo_frontend *fe, int slot, const ft_frame_view &meta) {
+        check(ft_tracked_frame_bind_stereo(h_, fe, slot, &meta));
+        N_ = meta.N;
+    }
+    // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)                       ORBmatcher.cc:1775
+    int SearchByProjection(const ft_last_points &LastFrame, const float *Tcw, float th, bool bForward, bool bBackward,
+                           bool mbCheckOrientation, std::vector<int> &assign) {
+        assign.assign(N_ > 0 ? N_ : 1, -1);
+        int nm = 0;
+        check(ft_tracked_frame_search_last_frame(h_, &LastFrame, Tcw, th, bForward, bBackward, mbCheckOrientation,
+                                                 assign.data(), &nm));
+        assign.resize(N_);
+        return nm;
+    }
+    // Tracking::SearchLocalPoints: isInFrustum(pMP, 0.5) for every point + SearchByProjection(F, points, th, ...)
+    int SearchLocalPoints(const ft_frame_pose &pose, const ft_map_points &P, float viewingCosLimit, float mfLogScaleFactor,
+                          float th, float mfNNratio, bool bFarPoints, float thFarPoints, FrustumFields *fields,
+                          int *nToMatch, std::vector<int> &assign) {
+        assign.assign(N_ > 0 ? N_ : 1, -1);
+        ft_frustum_result r;
+        if (fields) r = fields->view(P.M);
+        int nm = 0;
+        check(ft_tracked_frame_track_local_map(h_, &pose, &P, viewingCosLimit, mfLogScaleFactor, th, mfNNratio, bFarPoints,
+                                               thFarPoints, fields ? &r : nullptr, nToMatch, assign.data(), &nm));
+        assign.resize(N_);
+        return nm;
+    }
+    std::vector<int> holderObservations() {
+        std::vector<int> h(N_ > 0 ? N_ : 1);
+        check(ft_tracked_frame_holder_obs(h_, h.data()));
+        h.resize(N_);
+        return h;
+    }
+    ft_tracked_frame *handle() { return h_; }
+
+private:
+    ft_tracked_frame *h_ = nullptr;
+    int N_ = 0;
+};
+
 }  // namespace fasttrack
