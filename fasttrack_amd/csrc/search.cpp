@@ -114,7 +114,11 @@ FtDevFrame devFrame(const ft_frame_view *F, const FrameLayout &L, uint8_t *dev) 
     return D;
 }
 
-// runs `search` passes until a pass changes nothing; leaves the final results in resFinal (device)
+// runs `search` passes until a pass changes nothing; leaves the final results in resFinal (device).
+// Passes are enqueued in bursts of FT_PASS_BURST without waiting in between: a pass after the fixed point
+// reproduces its input, so running a few too many costs microseconds of GPU time while every avoided
+// round trip (4-byte D2H + stream sync) costs tens.  `changed` holds one flag per pass of a burst.
+#define FT_PASS_BURST 3
 template <typename SearchFn>
 int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, int *resA, int *resB, int *head, int *next,
                int *changed, SearchFn search, int **resFinal, int *passes) {
@@ -124,18 +128,20 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, int *resA,
     if (rc != FT_OK) return rc;
     int *cur = resA, *prev = resB;
     int pass = 0;
-    const int maxPasses = 2 * nPoints + 4;
+    const int maxPasses = 2 * nPoints + 4 + FT_PASS_BURST;
     for (;;) {
-        rc = search(cur);
-        if (rc != FT_OK) return rc;
-        rc = ft_launch_build_claims(st, cur, prev, nPoints, nKp, head, next, changed);
-        if (rc != FT_OK) return rc;
-        int h = 0;
-        FT_HIP(hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, st));
+        for (int b = 0; b < FT_PASS_BURST; b++) {
+            rc = search(cur);
+            if (rc != FT_OK) return rc;
+            rc = ft_launch_build_claims(st, cur, prev, nPoints, nKp, head, next, changed + b);
+            if (rc != FT_OK) return rc;
+            std::swap(cur, prev);
+            pass++;
+        }
+        int h[FT_PASS_BURST];
+        FT_HIP(hipMemcpyAsync(h, changed, sizeof h, hipMemcpyDeviceToHost, st));
         FT_HIP(hipStreamSynchronize(st));
-        std::swap(cur, prev);
-        pass++;
-        if (!h) break;
+        if (!h[FT_PASS_BURST - 1]) break;  // the last pass of the burst changed nothing: `prev` is the fixed point
         if (pass >= maxPasses) {
             ft_set_error("projection search: claim resolution did not converge");
             return FT_ERR_HIP;
