@@ -209,3 +209,35 @@ def test_device_octree_overflow_falls_back_to_host(ctx):
     assert _calls(ctx, "extract.device_octree_batches") == b0 + 2
     ok, od, om = oex.extract(calm)
     _check_same(res[1][0], res[1][1], ok, od)
+
+
+def test_two_host_threads_two_extractors(ctx):
+    """Frame's constructor runs the left and the right extractor on two host threads (src/Frame.cc:127-130): two
+    extractors of one context called concurrently (ctypes releases the GIL) give the single-threaded results, and a
+    second context on the same device works next to the first."""
+    import threading
+    w, h, nf = 752, 480, 1200
+    imgs = [synth.make_image(w, h, seed=60 + i) for i in range(6)]
+    exL = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
+    ref = [exL(im) for im in imgs]
+    ctx2 = orb.Context(0)
+    for other in (ctx, ctx2):  # same context (the reference's layout), then a second context on the device
+        exR = orb.ORBextractor(other, nf, 1.2, 8, 20, 7, w, h)
+        got = {0: [], 1: []}
+        err = []
+
+        def work(k, ex):
+            try:
+                for _ in range(3):
+                    got[k] = [ex(im) for im in imgs]
+            except Exception as e:  # pragma: no cover
+                err.append(e)
+        ts = [threading.Thread(target=work, args=(0, exL)), threading.Thread(target=work, args=(1, exR))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not err, err
+        for k in (0, 1):
+            for (rk, rd, rm), (gk, gd, gm) in zip(ref, got[k]):
+                assert np.array_equal(rk, gk) and np.array_equal(rd, gd) and rm == gm
+        del exR
+    ctx2.close()
