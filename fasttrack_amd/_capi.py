@@ -51,6 +51,11 @@ class LastPoints(C.Structure):
                 ("observations", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p)]
 
 
+class FisheyeRig(C.Structure):
+    _fields_ = [("cam1", C.c_float * 8), ("cam2", C.c_float * 8), ("precision", C.c_float), ("Rlr", C.c_float * 9),
+                ("tlr", C.c_float * 3)]
+
+
 class FramePose(C.Structure):
     _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("tlr", C.c_float * 3)]
 
@@ -133,6 +138,7 @@ def lib() -> C.CDLL:
     L.ft_fisheye_match.argtypes = [vp, vp, i, vp, i, vp, vp, vp]
     L.ft_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LocalPoints), f, f, vp, ip] + [vp] * 10
     L.ft_search_last_frame.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LastPoints), vp, f, i, i, i, vp, ip] + [vp] * 4
+    L.ft_fisheye_stereo.argtypes = [vp, C.POINTER(FisheyeRig), vp, vp, i, vp, vp, i, vp, i, vp, vp, vp, ip]
     L.ft_is_in_frustum.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FramePose), C.POINTER(MapPoints), f, f,
                                    C.POINTER(FrustumResult), ip]
     L.ft_tracked_frame_create.argtypes = [vp, i, i, C.POINTER(vp)]

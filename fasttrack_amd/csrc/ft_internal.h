@@ -161,6 +161,14 @@ struct FtStereoArgs {
     int *order;                        // device [batch * capacity]: right keypoint indices in bucket order
     int rowStride;                     // >= level-0 height + 2
 };
+struct FtFisheyeRig {
+    float cam1[8], cam2[8], precision, Rlr[9], tlr[3];
+    float sigma2[FT_MAX_LEVELS];
+};
+// KannalaBrandt8::TriangulateMatches for every left keypoint with a 2-NN match (matches[i] >= 0); rejected pairs
+// get matches[i] = -1; nMatches counts the survivors
+int ft_launch_fisheye_triangulate(hipStream_t st, const FtFisheyeRig &rig, const ft_keypoint *keysL, int nL,
+                                  const ft_keypoint *keysR, int *matches, float *depth, float *p3d, int *nMatches);
 int ft_launch_stereo_match(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
                            const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
                            const uint8_t *pyrR, const FtStereoArgs &a);

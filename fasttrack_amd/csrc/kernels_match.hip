@@ -316,6 +316,190 @@ __global__ __launch_bounds__(256) void k_hamming_pairs(const uint8_t *a, const u
     dist[i] = hamming256(q, (const unsigned long long *)(b + (size_t)i * 32));
 }
 
+// ------------------------------------------------------------------------------------------------
+// KannalaBrandt8::TriangulateMatches (src/CameraModels/KannalaBrandt8.cpp:306-372) for the pairs that passed the
+// ratio test: one thread per left keypoint.  Float steps follow the reference's order without contraction; the
+// null vector of the 4x4 system comes from a one-sided Jacobi SVD in double (see fasttrack_amd.h).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fdot3(const float *a, const float *b) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(a[0], b[0]), __fmul_rn(a[1], b[1])), __fmul_rn(a[2], b[2]));
+}
+__device__ __forceinline__ float fnorm3(const float *a) { return sqrtf(fdot3(a, a)); }
+
+__device__ void kb8_unproject(const float *cam, float precision, float px, float py, float r[3]) {
+    const float pwx = __fdiv_rn(__fsub_rn(px, cam[2]), cam[0]), pwy = __fdiv_rn(__fsub_rn(py, cam[3]), cam[1]);
+    float scale = 1.f;
+    float theta_d = sqrtf(__fadd_rn(__fmul_rn(pwx, pwx), __fmul_rn(pwy, pwy)));
+    theta_d = fminf(fmaxf((float)(-3.1415926535897932384626433832795 / 2.f), theta_d), (float)(3.1415926535897932384626433832795 / 2.f));
+    if ((double)theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float t2 = __fmul_rn(theta, theta), t4 = __fmul_rn(t2, t2), t6 = __fmul_rn(t4, t2), t8 = __fmul_rn(t4, t4);
+            const float k0 = __fmul_rn(cam[4], t2), k1 = __fmul_rn(cam[5], t4), k2 = __fmul_rn(cam[6], t6), k3 = __fmul_rn(cam[7], t8);
+            const float num = __fsub_rn(__fmul_rn(theta, __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(1.f, k0), k1), k2), k3)), theta_d);
+            const float den = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(1.f, __fmul_rn(3.f, k0)), __fmul_rn(5.f, k1)), __fmul_rn(7.f, k2)),
+                                        __fmul_rn(9.f, k3));
+            const float fix = __fdiv_rn(num, den);
+            theta = __fsub_rn(theta, fix);
+            if (fabsf(fix) < precision) break;
+        }
+        scale = __fdiv_rn(tanf(theta), theta_d);
+    }
+    r[0] = __fmul_rn(pwx, scale);
+    r[1] = __fmul_rn(pwy, scale);
+    r[2] = 1.f;
+}
+
+__device__ void kb8_project(const float *cam, const float p[3], float uv[2]) {
+    const float x2y2 = __fadd_rn(__fmul_rn(p[0], p[0]), __fmul_rn(p[1], p[1]));
+    const float theta = atan2f(sqrtf(x2y2), p[2]);
+    const float psi = atan2f(p[1], p[0]);
+    const float t2 = __fmul_rn(theta, theta), t3 = __fmul_rn(theta, t2), t5 = __fmul_rn(t3, t2), t7 = __fmul_rn(t5, t2),
+                t9 = __fmul_rn(t7, t2);
+    const float r = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(theta, __fmul_rn(cam[4], t3)), __fmul_rn(cam[5], t5)), __fmul_rn(cam[6], t7)),
+                              __fmul_rn(cam[7], t9));
+    uv[0] = __fadd_rn(__fmul_rn(__fmul_rn(cam[0], r), cosf(psi)), cam[2]);
+    uv[1] = __fadd_rn(__fmul_rn(__fmul_rn(cam[1], r), sinf(psi)), cam[3]);
+}
+
+// right singular vector of the smallest singular value of a 4x4 matrix: one-sided (Hestenes) Jacobi in double
+__device__ void null_vector4(const double A[16], double v[4]) {
+    double U[16], V[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        U[i] = A[i];
+        V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    alpha = __dadd_rn(alpha, __dmul_rn(U[4 * i + p], U[4 * i + p]));
+                    beta = __dadd_rn(beta, __dmul_rn(U[4 * i + q], U[4 * i + q]));
+                    gamma = __dadd_rn(gamma, __dmul_rn(U[4 * i + p], U[4 * i + q]));
+                }
+                if (fabs(gamma) <= __dmul_rn(1e-15, sqrt(__dmul_rn(alpha, beta))) || gamma == 0.0) continue;
+                rotated = true;
+                const double zeta = __ddiv_rn(__dsub_rn(beta, alpha), __dmul_rn(2.0, gamma));
+                const double t = __ddiv_rn(zeta >= 0 ? 1.0 : -1.0, __dadd_rn(fabs(zeta), sqrt(__dadd_rn(1.0, __dmul_rn(zeta, zeta)))));
+                const double c = __ddiv_rn(1.0, sqrt(__dadd_rn(1.0, __dmul_rn(t, t)))), sn = __dmul_rn(c, t);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double up = U[4 * i + p], uq = U[4 * i + q];
+                    U[4 * i + p] = __dsub_rn(__dmul_rn(c, up), __dmul_rn(sn, uq));
+                    U[4 * i + q] = __dadd_rn(__dmul_rn(sn, up), __dmul_rn(c, uq));
+                    const double vp = V[4 * i + p], vq = V[4 * i + q];
+                    V[4 * i + p] = __dsub_rn(__dmul_rn(c, vp), __dmul_rn(sn, vq));
+                    V[4 * i + q] = __dadd_rn(__dmul_rn(sn, vp), __dmul_rn(c, vq));
+                }
+            }
+        if (!rotated) break;
+    }
+    int best = 0;
+    double bn = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double nj = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) nj = __dadd_rn(nj, __dmul_rn(U[4 * i + j], U[4 * i + j]));
+        if (j == 0 || nj < bn) {
+            bn = nj;
+            best = j;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = best == 0 ? V[4 * i] : best == 1 ? V[4 * i + 1] : best == 2 ? V[4 * i + 2] : V[4 * i + 3];
+}
+
+__device__ float kb8_triangulate_matches(const FtFisheyeRig &g, float x1, float y1, float x2, float y2, float sigmaLevel, float unc,
+                                         float p3D[3]) {
+    float r1[3], r2[3];
+    kb8_unproject(g.cam1, g.precision, x1, y1, r1);
+    kb8_unproject(g.cam2, g.precision, x2, y2, r2);
+    const float *R12 = g.Rlr, *t12 = g.tlr;
+    float r21[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) r21[i] = fdot3(R12 + 3 * i, r2);
+    const float cosParallaxRays = __fdiv_rn(fdot3(r1, r21), __fmul_rn(fnorm3(r1), fnorm3(r21)));
+    if ((double)cosParallaxRays > 0.9998) return -1.f;
+    float R21[9], t2[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) R21[3 * i + j] = R12[3 * j + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) t2[i] = -fdot3(R21 + 3 * i, t12);
+    // rows of A: p.x * T.row(2) - T.row(0), p.y * T.row(2) - T.row(1) with Tcw1 = [I | 0], Tcw2 = [R21 | t2]
+    const float T1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    float T2[12];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) T2[4 * i + j] = R21[3 * i + j];
+        T2[4 * i + 3] = t2[i];
+    }
+    double A[16], v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        A[j] = (double)__fsub_rn(__fmul_rn(r1[0], T1[8 + j]), T1[j]);
+        A[4 + j] = (double)__fsub_rn(__fmul_rn(r1[1], T1[8 + j]), T1[4 + j]);
+        A[8 + j] = (double)__fsub_rn(__fmul_rn(r2[0], T2[8 + j]), T2[j]);
+        A[12 + j] = (double)__fsub_rn(__fmul_rn(r2[1], T2[8 + j]), T2[4 + j]);
+    }
+    null_vector4(A, v);
+    const float h3 = (float)v[3];
+    const float x3D[3] = {__fdiv_rn((float)v[0], h3), __fdiv_rn((float)v[1], h3), __fdiv_rn((float)v[2], h3)};
+    const float z1 = x3D[2];
+    if (z1 <= 0) return -2.f;
+    const float z2 = __fadd_rn(fdot3(R21 + 6, x3D), T2[11]);
+    if (z2 <= 0) return -3.f;
+    float uv1[2];
+    kb8_project(g.cam1, x3D, uv1);
+    const float ex1 = __fsub_rn(uv1[0], x1), ey1 = __fsub_rn(uv1[1], y1);
+    if ((double)__fadd_rn(__fmul_rn(ex1, ex1), __fmul_rn(ey1, ey1)) > 5.991 * (double)sigmaLevel) return -4.f;
+    float x3D2[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) x3D2[i] = __fadd_rn(fdot3(R21 + 3 * i, x3D), t2[i]);
+    float uv2[2];
+    kb8_project(g.cam2, x3D2, uv2);
+    const float ex2 = __fsub_rn(uv2[0], x2), ey2 = __fsub_rn(uv2[1], y2);
+    if ((double)__fadd_rn(__fmul_rn(ex2, ex2), __fmul_rn(ey2, ey2)) > 5.991 * (double)unc) return -5.f;
+    p3D[0] = x3D[0];
+    p3D[1] = x3D[1];
+    p3D[2] = x3D[2];
+    return z1;
+}
+
+__global__ __launch_bounds__(64) void k_fisheye_triangulate(FtFisheyeRig rig, const ft_keypoint *keysL, int nL, const ft_keypoint *keysR,
+                                                           int *matches, float *depth, float *p3d, int *nMatches) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nL) return;
+    const int j = matches[i];
+    float d = -1.0f, p[3] = {0.f, 0.f, 0.f};
+    int m = -1;
+    if (j >= 0) {
+        const ft_keypoint a = keysL[i], b = keysR[j];
+        const float z = kb8_triangulate_matches(rig, a.x, a.y, b.x, b.y, rig.sigma2[a.octave], rig.sigma2[b.octave], p);
+        if (z > 0.0001f) {  // Frame.cc:1263
+            d = z;
+            m = j;
+            atomicAdd(nMatches, 1);
+        } else {
+            p[0] = p[1] = p[2] = 0.f;
+        }
+    }
+    matches[i] = m;
+    depth[i] = d;
+    p3d[3 * i] = p[0];
+    p3d[3 * i + 1] = p[1];
+    p3d[3 * i + 2] = p[2];
+}
+
 }  // namespace
 
 int ft_launch_stereo_match(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
@@ -353,6 +537,14 @@ int ft_launch_fisheye(hipStream_t st, const uint8_t *descL, int nL, const uint8_
 int ft_launch_hamming_pairs(hipStream_t st, const uint8_t *a, const uint8_t *b, int n, int *dist) {
     if (n <= 0) return FT_OK;
     hipLaunchKernelGGL(k_hamming_pairs, dim3((n + 255) / 256), dim3(256), 0, st, a, b, n, dist);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_fisheye_triangulate(hipStream_t st, const FtFisheyeRig &rig, const ft_keypoint *keysL, int nL,
+                                  const ft_keypoint *keysR, int *matches, float *depth, float *p3d, int *nMatches) {
+    if (nL <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_fisheye_triangulate, dim3((nL + 63) / 64), dim3(64), 0, st, rig, keysL, nL, keysR, matches, depth, p3d, nMatches);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

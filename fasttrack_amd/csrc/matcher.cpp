@@ -436,6 +436,60 @@ int ft_fisheye_match(ft_context *ctx, const uint8_t *descL, int nL, const uint8_
     return rc;
 }
 
+int ft_fisheye_stereo(ft_context *ctx, const ft_fisheye_rig *rig, const uint8_t *descL, const ft_keypoint *keysL, int nL,
+                      const uint8_t *descR, const ft_keypoint *keysR, int nR, const float *level_sigma2, int nlevels,
+                      int *matches, float *depth, float *p3d, int *n_matches) {
+    FT_REQUIRE(ctx && rig && matches && depth && p3d && level_sigma2, "ft_fisheye_stereo: null argument");
+    FT_REQUIRE(nL >= 0 && nR >= 0 && nR < (1 << 20), "ft_fisheye_stereo: count out of range");
+    FT_REQUIRE(nlevels >= 1 && nlevels <= FT_MAX_LEVELS, "ft_fisheye_stereo: nlevels out of range");
+    FT_REQUIRE((nL == 0 || (descL && keysL)) && (nR == 0 || (descR && keysR)), "ft_fisheye_stereo: null keypoints / descriptors");
+    for (int i = 0; i < nL; i++) FT_REQUIRE(keysL[i].octave >= 0 && keysL[i].octave < nlevels, "ft_fisheye_stereo: left octave out of range");
+    for (int i = 0; i < nR; i++) FT_REQUIRE(keysR[i].octave >= 0 && keysR[i].octave < nlevels, "ft_fisheye_stereo: right octave out of range");
+    if (n_matches) *n_matches = 0;
+    if (nL == 0) return FT_OK;
+    int rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    FtFisheyeRig G;
+    memset(&G, 0, sizeof G);
+    memcpy(G.cam1, rig->cam1, sizeof G.cam1);
+    memcpy(G.cam2, rig->cam2, sizeof G.cam2);
+    G.precision = rig->precision;
+    memcpy(G.Rlr, rig->Rlr, sizeof G.Rlr);
+    memcpy(G.tlr, rig->tlr, sizeof G.tlr);
+    for (int i = 0; i < nlevels; i++) G.sigma2[i] = level_sigma2[i];
+    uint8_t *dL = nullptr, *dR = nullptr;
+    ft_keypoint *kL = nullptr, *kR = nullptr;
+    int *dM = nullptr;
+    float *dOut = nullptr;
+    hipStream_t st = ctx->stream;
+    const size_t nRa = (size_t)std::max(nR, 1);
+    hipError_t e = hipMalloc((void **)&dL, (size_t)32 * nL);
+    if (e == hipSuccess) e = hipMalloc((void **)&dR, 32 * nRa);
+    if (e == hipSuccess) e = hipMalloc((void **)&kL, sizeof(ft_keypoint) * nL);
+    if (e == hipSuccess) e = hipMalloc((void **)&kR, sizeof(ft_keypoint) * nRa);
+    if (e == hipSuccess) e = hipMalloc((void **)&dM, sizeof(int) * (3 * (size_t)nL + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&dOut, sizeof(float) * 4 * (size_t)nL);
+    if (e == hipSuccess) e = hipMemcpyAsync(dL, descL, (size_t)32 * nL, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(kL, keysL, sizeof(ft_keypoint) * nL, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nR > 0) e = hipMemcpyAsync(dR, descR, (size_t)32 * nR, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nR > 0) e = hipMemcpyAsync(kR, keysR, sizeof(ft_keypoint) * nR, hipMemcpyHostToDevice, st);
+    int *dCount = dM + 3 * (size_t)nL;
+    if (e == hipSuccess) e = hipMemsetAsync(dCount, 0, sizeof(int), st);
+    rc = FT_OK;
+    if (e == hipSuccess) rc = ft_launch_fisheye(st, dL, nL, dR, nR, dM, dM + nL, dM + 2 * (size_t)nL);
+    if (e == hipSuccess && rc == FT_OK) rc = ft_launch_fisheye_triangulate(st, G, kL, nL, kR, dM, dOut, dOut + nL, dCount);
+    int hCount = 0;
+    if (e == hipSuccess && rc == FT_OK) e = hipMemcpyAsync(matches, dM, sizeof(int) * nL, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && rc == FT_OK) e = hipMemcpyAsync(depth, dOut, sizeof(float) * nL, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && rc == FT_OK) e = hipMemcpyAsync(p3d, dOut + nL, sizeof(float) * 3 * (size_t)nL, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && rc == FT_OK) e = hipMemcpyAsync(&hCount, dCount, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(dL); hipFree(dR); hipFree(kL); hipFree(kR); hipFree(dM); hipFree(dOut);
+    if (e != hipSuccess) return ft_hip_fail(e, "ft_fisheye_stereo", __FILE__, __LINE__);
+    if (n_matches) *n_matches = hCount;
+    return rc;
+}
+
 int ft_descriptor_distance(ft_context *ctx, const uint8_t *a, const uint8_t *b, int n, int *dist) {
     FT_REQUIRE(ctx && n >= 0 && (n == 0 || (a && b && dist)), "ft_descriptor_distance: bad argument");
     if (n == 0) return FT_OK;

@@ -548,3 +548,24 @@ class TrackedFrame:
         r = {k: v[:M] for k, v in outs.items()}
         r.update(assign=assign[:self.N], n=n.value, n_to_match=nt.value)
         return r
+
+
+def fisheye_stereo(ctx: Context, cam1, cam2, Rlr, tlr, descL, keysL, descR, keysR, level_sigma2, precision=1e-6):
+    """Frame::ComputeStereoFishEyeMatches on the lapping-area subsets (ft_fisheye_stereo)."""
+    rig = _capi.FisheyeRig()
+    rig.cam1[:] = [float(v) for v in cam1]
+    rig.cam2[:] = [float(v) for v in cam2]
+    rig.precision = precision
+    rig.Rlr[:] = [float(v) for v in np.asarray(Rlr, np.float32).reshape(-1)]
+    rig.tlr[:] = [float(v) for v in np.asarray(tlr, np.float32).reshape(-1)]
+    descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
+    keysL = np.ascontiguousarray(keysL); keysR = np.ascontiguousarray(keysR)
+    ls2 = np.ascontiguousarray(level_sigma2, np.float32)
+    nL, nR = len(descL), len(descR)
+    m = np.full(max(nL, 1), -1, np.int32)
+    d = np.zeros(max(nL, 1), np.float32)
+    p = np.zeros((max(nL, 1), 3), np.float32)
+    n = C.c_int()
+    check(lib().ft_fisheye_stereo(ctx._h, C.byref(rig), ptr(descL), ptr(keysL), nL, ptr(descR), ptr(keysR), nR, ptr(ls2),
+                                  len(ls2), ptr(m), ptr(d), ptr(p), C.byref(n)))
+    return dict(matches=m[:nL], depth=d[:nL], p3d=p[:nL], n=n.value)

@@ -192,6 +192,23 @@ FT_API int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *con
 FT_API int ft_fisheye_match(ft_context *ctx, const uint8_t *descL, int nL, const uint8_t *descR, int nR,
                             int *matches, int *best, int *second);
 
+/* Complete Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1231-1271): the 2-NN + ratio test
+ * above followed, on the device, by KannalaBrandt8::TriangulateMatches per surviving pair
+ * (src/CameraModels/KannalaBrandt8.cpp:306-372: Newton unprojection, parallax, linear triangulation, depth and
+ * reprojection tests).  keysL / keysR are the keypoints of the lapping-area subsets descL / descR refer to.
+ * matches[i] = index into the right subset or -1 (mvLeftToRightMatch), depth[i] = mvDepth or -1,
+ * p3d[3i..3i+2] = mvStereo3Dpoints.  The null vector of the 4x4 triangulation system is computed by a one-sided
+ * Jacobi SVD in double (the reference uses Eigen::JacobiSVD in float): depth / p3d agree with the reference to
+ * its own rounding error, not bit for bit. */
+typedef struct ft_fisheye_rig {
+    float cam1[8], cam2[8]; /* fx fy cx cy k1 k2 k3 k4 of mpCamera / mpCamera2 */
+    float precision;        /* KannalaBrandt8::precision */
+    float Rlr[9], tlr[3];   /* mRlr (row-major), mtlr */
+} ft_fisheye_rig;
+FT_API int ft_fisheye_stereo(ft_context *ctx, const ft_fisheye_rig *rig, const uint8_t *descL, const ft_keypoint *keysL,
+                             int nL, const uint8_t *descR, const ft_keypoint *keysR, int nR, const float *level_sigma2,
+                             int nlevels, int *matches, float *depth, float *p3d, int *n_matches);
+
 /* ------------------------------------------------------------------------------------------------
  * Frame view for the projection matchers: the fields of ORB_SLAM3::Frame that
  * DATA_WRAPPER::CudaFrame::setMemory marshals (src/Kernels/CudaWrappers/CudaFrame.cu:77-181).

@@ -161,6 +161,24 @@ struct KernelController {
         check(ft_fisheye_match(ctx.handle(), mDescriptors, N, mDescriptorsRight, Nr, matches, nullptr, nullptr));
     }
 
+    // Frame::ComputeStereoFishEyeMatches complete (src/Frame.cc:1231-1271): ratio-tested 2-NN matches filtered by
+    // KannalaBrandt8::TriangulateMatches.  Arrays are indexed like the lapping-area subsets.
+    static int computeStereoFishEyeMatches(Context &ctx, const ft_fisheye_rig &rig, int N, int Nr, const uint8_t *descL,
+                                           const ft_keypoint *keysL, const uint8_t *descR, const ft_keypoint *keysR,
+                                           const std::vector<float> &mvLevelSigma2, std::vector<int> &leftToRight,
+                                           std::vector<float> &mvDepth, std::vector<float> &mvStereo3Dpoints) {
+        leftToRight.assign(N > 0 ? N : 1, -1);
+        mvDepth.assign(N > 0 ? N : 1, -1.0f);
+        mvStereo3Dpoints.assign(3 * (size_t)(N > 0 ? N : 1), 0.f);
+        int nm = 0;
+        check(ft_fisheye_stereo(ctx.handle(), &rig, descL, keysL, N, descR, keysR, Nr, mvLevelSigma2.data(),
+                                (int)mvLevelSigma2.size(), leftToRight.data(), mvDepth.data(), mvStereo3Dpoints.data(), &nm));
+        leftToRight.resize(N);
+        mvDepth.resize(N);
+        mvStereo3Dpoints.resize(3 * (size_t)N);
+        return nm;
+    }
+
     // launchSearchLocalPointsKernel(F, vmp, th, bFarPoints, thFarPoints, 10 x int*)        KernelController.h:40-42
     // F / P are the POD views of Frame and of the map points (INTEGRATION.md shows how they are filled);
     // in addition to the ten raw arrays the call returns the final assignment and nmatches, i.e. the

@@ -53,6 +53,21 @@ class LastPoints(C.Structure):
                 ("observations", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p)]
 
 
+class FisheyeRig(C.Structure):
+    _fields_ = [("cam1", C.c_float * 8), ("cam2", C.c_float * 8), ("precision", C.c_float), ("Rlr", C.c_float * 9),
+                ("tlr", C.c_float * 3)]
+
+
+def make_rig(cam1, cam2, Rlr, tlr, precision=1e-6):
+    r = FisheyeRig()
+    r.cam1[:] = [float(v) for v in cam1]
+    r.cam2[:] = [float(v) for v in cam2]
+    r.precision = precision
+    r.Rlr[:] = [float(v) for v in np.asarray(Rlr, np.float32).reshape(-1)]
+    r.tlr[:] = [float(v) for v in np.asarray(tlr, np.float32).reshape(-1)]
+    return r
+
+
 class FramePose(C.Structure):
     _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("tlr", C.c_float * 3)]
 
@@ -439,3 +454,29 @@ def is_in_frustum(F: FrameView, pose: FramePose, pts: dict, viewing_cos_limit: f
     r = {k: o[:M] for (k, _), o in zip(FRUSTUM_FIELDS, outs)}
     r["n"] = n
     return r
+
+
+def kb8_triangulate(rig: FisheyeRig, xy1, xy2, sigma1, sigma2):
+    """KannalaBrandt8::TriangulateMatches per pair -> (code[n], p3d[n,3])"""
+    xy1 = np.ascontiguousarray(xy1, np.float32); xy2 = np.ascontiguousarray(xy2, np.float32)
+    s1 = np.ascontiguousarray(sigma1, np.float32); s2 = np.ascontiguousarray(sigma2, np.float32)
+    n = len(xy1)
+    code = np.zeros(max(n, 1), np.float32); p3d = np.zeros((max(n, 1), 3), np.float32)
+    lib().orc_kb8_triangulate.restype = None
+    lib().orc_kb8_triangulate.argtypes = [C.POINTER(FisheyeRig), C.c_int] + [C.c_void_p] * 6
+    lib().orc_kb8_triangulate(C.byref(rig), n, _p(xy1), _p(xy2), _p(s1), _p(s2), _p(code), _p(p3d))
+    return code[:n], p3d[:n]
+
+
+def fisheye_stereo(rig: FisheyeRig, descL, keysL, descR, keysR, level_sigma2):
+    """Frame::ComputeStereoFishEyeMatches on the lapping-area subsets -> dict(matches, depth, p3d, n)"""
+    descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
+    keysL = np.ascontiguousarray(keysL); keysR = np.ascontiguousarray(keysR)
+    ls2 = np.ascontiguousarray(level_sigma2, np.float32)
+    nL, nR = len(descL), len(descR)
+    m = np.full(max(nL, 1), -1, np.int32); d = np.zeros(max(nL, 1), np.float32); p = np.zeros((max(nL, 1), 3), np.float32)
+    lib().orc_fisheye_stereo.restype = C.c_int
+    lib().orc_fisheye_stereo.argtypes = [C.POINTER(FisheyeRig), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = lib().orc_fisheye_stereo(C.byref(rig), _p(descL), _p(keysL), nL, _p(descR), _p(keysR), nR, _p(ls2), _p(m), _p(d), _p(p))
+    return dict(matches=m[:nL], depth=d[:nL], p3d=p[:nL], n=n)

@@ -1330,4 +1330,164 @@ int orc_is_in_frustum(const orc_frame *F, const orc_frame_pose *T, const orc_map
     return nToMatch;
 }
 
+// ------------------------------------------------------------------------------------------------
+// KannalaBrandt8::unproject (:114-143), ::project (:67-84), ::Triangulate (:397-409), ::TriangulateMatches
+// (:306-372), Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1231-1271)
+// ------------------------------------------------------------------------------------------------
+static void kb8Unproject(const float *cam, float precision, float px, float py, float r[3]) {
+    const float pwx = (px - cam[2]) / cam[0], pwy = (py - cam[3]) / cam[1];
+    float scale = 1.f;
+    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+    theta_d = fminf(fmaxf((float)(-3.1415926535897932384626433832795 / 2.f), theta_d), (float)(3.1415926535897932384626433832795 / 2.f));
+    if (theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+            const float k0_theta2 = cam[4] * theta2, k1_theta4 = cam[5] * theta4;
+            const float k2_theta6 = cam[6] * theta6, k3_theta8 = cam[7] * theta8;
+            const float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                    (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+            theta = theta - theta_fix;
+            if (fabsf(theta_fix) < precision) break;
+        }
+        scale = tanf(theta) / theta_d;
+    }
+    r[0] = pwx * scale;
+    r[1] = pwy * scale;
+    r[2] = 1.f;
+}
+
+static void kb8Project(const float *cam, const float p[3], float uv[2]) {
+    orc_frame f;
+    memset(&f, 0, sizeof f);
+    f.cam_model = 1;
+    memcpy(f.cam, cam, sizeof f.cam);
+    projectCam(&f, p, uv);
+}
+
+// right singular vector of the smallest singular value of the 4x4 matrix A (row-major), one-sided Jacobi in double
+static void nullVector4(const double A[16], double v[4]) {
+    double U[16], V[16];
+    for (int i = 0; i < 16; i++) { U[i] = A[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p < 3; p++)
+            for (int q = p + 1; q < 4; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 4; i++) {
+                    alpha += U[4 * i + p] * U[4 * i + p];
+                    beta += U[4 * i + q] * U[4 * i + q];
+                    gamma += U[4 * i + p] * U[4 * i + q];
+                }
+                if (fabs(gamma) <= 1e-15 * sqrt(alpha * beta) || gamma == 0.0) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < 4; i++) {
+                    const double up = U[4 * i + p], uq = U[4 * i + q];
+                    U[4 * i + p] = c * up - sn * uq;
+                    U[4 * i + q] = sn * up + c * uq;
+                    const double vp = V[4 * i + p], vq = V[4 * i + q];
+                    V[4 * i + p] = c * vp - sn * vq;
+                    V[4 * i + q] = sn * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    int best = 0;
+    double bn = 0;
+    for (int j = 0; j < 4; j++) {
+        double nj = 0;
+        for (int i = 0; i < 4; i++) nj += U[4 * i + j] * U[4 * i + j];
+        if (j == 0 || nj < bn) { bn = nj; best = j; }
+    }
+    for (int i = 0; i < 4; i++) v[i] = V[4 * i + best];
+}
+
+static float kb8TriangulateMatches(const orc_fisheye_rig *rig, float x1, float y1, float x2, float y2, float sigmaLevel,
+                                   float unc, float p3D[3]) {
+    float r1[3], r2[3];
+    kb8Unproject(rig->cam1, rig->precision, x1, y1, r1);
+    kb8Unproject(rig->cam2, rig->precision, x2, y2, r2);
+    const float *R12 = rig->Rlr, *t12 = rig->tlr;
+    float r21[3];
+    for (int i = 0; i < 3; i++) r21[i] = dot3(R12 + 3 * i, r2);
+    const float cosParallaxRays = dot3(r1, r21) / (norm3(r1) * norm3(r21));
+    if (cosParallaxRays > 0.9998) return -1;
+    // Tcw1 = [I | 0], Tcw2 = [R21 | -R21 t12], R21 = R12^T
+    float R21[9], t2[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R21[3 * i + j] = R12[3 * j + i];
+    for (int i = 0; i < 3; i++) t2[i] = -dot3(R21 + 3 * i, t12);  // (-R21) * t12, negation is exact
+    float Tcw1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, Tcw2[12];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Tcw2[4 * i + j] = R21[3 * i + j];
+        Tcw2[4 * i + 3] = t2[i];
+    }
+    // Triangulate: rows p.x*T.row(2) - T.row(0), p.y*T.row(2) - T.row(1) in float (:400-403)
+    float Af[16];
+    for (int j = 0; j < 4; j++) {
+        Af[j] = r1[0] * Tcw1[8 + j] - Tcw1[j];
+        Af[4 + j] = r1[1] * Tcw1[8 + j] - Tcw1[4 + j];
+        Af[8 + j] = r2[0] * Tcw2[8 + j] - Tcw2[j];
+        Af[12 + j] = r2[1] * Tcw2[8 + j] - Tcw2[4 + j];
+    }
+    double A[16], v[4];
+    for (int i = 0; i < 16; i++) A[i] = Af[i];
+    nullVector4(A, v);
+    const float x3Dh[4] = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    const float x3D[3] = {x3Dh[0] / x3Dh[3], x3Dh[1] / x3Dh[3], x3Dh[2] / x3Dh[3]};
+    const float z1 = x3D[2];
+    if (z1 <= 0) return -2;
+    const float z2 = dot3(R21 + 6, x3D) + Tcw2[11];
+    if (z2 <= 0) return -3;
+    float uv1[2];
+    kb8Project(rig->cam1, x3D, uv1);
+    const float errX1 = uv1[0] - x1, errY1 = uv1[1] - y1;
+    if ((errX1 * errX1 + errY1 * errY1) > 5.991 * sigmaLevel) return -4;
+    float x3D2[3];
+    for (int i = 0; i < 3; i++) x3D2[i] = dot3(R21 + 3 * i, x3D) + t2[i];
+    float uv2[2];
+    kb8Project(rig->cam2, x3D2, uv2);
+    const float errX2 = uv2[0] - x2, errY2 = uv2[1] - y2;
+    if ((errX2 * errX2 + errY2 * errY2) > 5.991 * unc) return -5;
+    p3D[0] = x3D[0]; p3D[1] = x3D[1]; p3D[2] = x3D[2];
+    return z1;
+}
+
+void orc_kb8_triangulate(const orc_fisheye_rig *rig, int n, const float *xy1, const float *xy2, const float *sigma1,
+                         const float *sigma2, float *code, float *p3d) {
+    for (int i = 0; i < n; i++) {
+        float p[3] = {0, 0, 0};
+        code[i] = kb8TriangulateMatches(rig, xy1[2 * i], xy1[2 * i + 1], xy2[2 * i], xy2[2 * i + 1], sigma1[i], sigma2[i], p);
+        p3d[3 * i] = p[0]; p3d[3 * i + 1] = p[1]; p3d[3 * i + 2] = p[2];
+    }
+}
+
+int orc_fisheye_stereo(const orc_fisheye_rig *rig, const uint8_t *descL, const orc_keypoint *keysL, int nL,
+                       const uint8_t *descR, const orc_keypoint *keysR, int nR, const float *level_sigma2, int *matches,
+                       float *depth, float *p3d) {
+    std::vector<int> knn(nL > 0 ? nL : 1);
+    orc_fisheye_match(descL, nL, descR, nR, knn.data(), nullptr, nullptr);
+    int nMatches = 0;
+    for (int i = 0; i < nL; i++) {
+        matches[i] = -1;
+        depth[i] = -1.0f;
+        p3d[3 * i] = p3d[3 * i + 1] = p3d[3 * i + 2] = 0.f;
+        const int j = knn[i];
+        if (j < 0) continue;
+        float p[3];
+        const float d = kb8TriangulateMatches(rig, keysL[i].x, keysL[i].y, keysR[j].x, keysR[j].y,
+                                              level_sigma2[keysL[i].octave], level_sigma2[keysR[j].octave], p);
+        if (d > 0.0001f) {
+            matches[i] = j;
+            depth[i] = d;
+            p3d[3 * i] = p[0]; p3d[3 * i + 1] = p[1]; p3d[3 * i + 2] = p[2];
+            nMatches++;
+        }
+    }
+    return nMatches;
+}
+
 }  // extern "C"

@@ -153,6 +153,27 @@ int orc_search_last_frame(orc_frame *Cur, const orc_last_points *L, const float 
                           int *best_dist_r, int *best_idx_r);
 void orc_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3);
 
+/* ---- Frame::ComputeStereoFishEyeMatches complete (src/Frame.cc:1231-1271): 2-NN + ratio test, then
+ *      KannalaBrandt8::TriangulateMatches per surviving pair (src/CameraModels/KannalaBrandt8.cpp:306-372:
+ *      unproject by Newton iteration :114-143, parallax, Triangulate :397-409, depth and reprojection tests).
+ *      Eigen::JacobiSVD is not available here: the null vector of the 4x4 system is computed by a one-sided
+ *      Jacobi SVD in double and narrowed to float (the reference's float JacobiSVD agrees to its own rounding
+ *      error) - floating-point outputs of this function are compared with a tolerance. ---- */
+typedef struct orc_fisheye_rig {
+    float cam1[8], cam2[8]; /* fx fy cx cy k1..k4 of mpCamera / mpCamera2 */
+    float precision;        /* KannalaBrandt8::precision (1e-6) */
+    float Rlr[9], tlr[3];   /* mRlr, mtlr */
+} orc_fisheye_rig;
+/* code[i]: the value TriangulateMatches returns (-1 parallax, -2 z1 <= 0, -3 z2 <= 0, -4 / -5 reprojection, else z1);
+ * p3d receives x3D when code > 0 */
+void orc_kb8_triangulate(const orc_fisheye_rig *rig, int n, const float *xy1, const float *xy2, const float *sigma1,
+                         const float *sigma2, float *code, float *p3d);
+/* keysL / keysR: the lapping-area subsets like descL / descR; level_sigma2 = mvLevelSigma2.
+ * matches[i] = j or -1, depth[i] = z1 or -1, p3d[3i..] = mvStereo3Dpoints; returns nMatches. */
+int orc_fisheye_stereo(const orc_fisheye_rig *rig, const uint8_t *descL, const orc_keypoint *keysL, int nL,
+                       const uint8_t *descR, const orc_keypoint *keysR, int nR, const float *level_sigma2,
+                       int *matches, float *depth, float *p3d);
+
 /* ---- Frame::isInFrustum / isInFrustumChecks + MapPoint::PredictScale
  *      (src/Frame.cc:536-610, 1308-1382; src/MapPoint.cc:531-546): the per-map-point step in front of
  *      SearchByProjection (src/Tracking.cc:3503-3522) ---- */

@@ -179,3 +179,38 @@ def local_points_from_frustum(fr: dict, pts: dict, far_points=False, th_far=0.0)
                 level_r=fr["level_r"], view_cos=fr["view_cos"], view_cos_r=fr["view_cos_r"], proj_x=fr["proj_x"],
                 proj_y=fr["proj_y"], proj_xr=fr["proj_xr"], proj_yr=fr["proj_yr"], descriptors=pts["descriptors"],
                 observations=pts["observations"])
+
+
+KB8_CAM = [190.978, 190.973, 254.93, 256.90, 0.0034, 0.0007, -0.0020, 0.00020]  # TUM-VI-like
+
+
+def kb8_project64(cam, P):
+    """KannalaBrandt8::project in float64 (independent statement for the tests)"""
+    P = np.asarray(P, np.float64)
+    r2 = P[:, 0] ** 2 + P[:, 1] ** 2
+    theta = np.arctan2(np.sqrt(r2), P[:, 2])
+    psi = np.arctan2(P[:, 1], P[:, 0])
+    r = theta + cam[4] * theta ** 3 + cam[5] * theta ** 5 + cam[6] * theta ** 7 + cam[7] * theta ** 9
+    return np.stack([cam[0] * r * np.cos(psi) + cam[2], cam[1] * r * np.sin(psi) + cam[3]], 1)
+
+
+def fisheye_rig_scenario(seed, n=1500, noise=0.3):
+    """A stereo fisheye rig (baseline 0.1 m, small relative rotation) and n point pairs: most are projections of one
+    3-D point into both cameras (+ pixel noise), the rest are wrong associations, far points (no parallax) and
+    points behind a camera, so that every return code of TriangulateMatches occurs."""
+    rng = np.random.default_rng(seed)
+    w = rng.normal(0, 0.01, 3)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    Rlr = (np.eye(3) + K + 0.5 * K @ K).astype(np.float32)     # x_l = Rlr x_r + tlr
+    tlr = np.array([0.1, 0.002, -0.001], np.float32)
+    z = rng.uniform(0.3, 2.2, n)   # 0.1 m baseline: beyond ~3 m the parallax test (cos > 0.9998) rejects
+    z[rng.random(n) < 0.08] = rng.uniform(80, 400, int((rng.random(n) < 0.08).sum()) or 1)[0]
+    Xl = np.stack([rng.uniform(-1.2, 1.2, n) * z, rng.uniform(-1.0, 1.0, n) * z, z], 1)
+    Xr = (Xl - tlr[None, :].astype(np.float64)) @ Rlr.astype(np.float64)   # Rlr^T (x_l - tlr)
+    xy1 = kb8_project64(KB8_CAM, Xl) + rng.normal(0, noise, (n, 2))
+    xy2 = kb8_project64(KB8_CAM, Xr) + rng.normal(0, noise, (n, 2))
+    wrong = rng.random(n) < 0.12
+    xy2[wrong] = xy2[rng.permutation(n)][wrong]
+    octave1, octave2 = rng.integers(0, 8, n), rng.integers(0, 8, n)
+    return dict(Rlr=Rlr, tlr=tlr, xy1=xy1.astype(np.float32), xy2=xy2.astype(np.float32), Xl=Xl, wrong=wrong,
+                octave1=octave1, octave2=octave2)

@@ -382,3 +382,33 @@ def test_tracked_frame_bound_to_stereo_frontend(ctx):
     with pytest.raises(Exception):
         tf.bind_stereo(fe, 5, gF)  # slot out of range
     tf.close()
+
+
+def test_fisheye_stereo_with_triangulation(ctx):
+    """complete ComputeStereoFishEyeMatches: 2-NN + ratio on the device, then KannalaBrandt8::TriangulateMatches per
+    pair.  Floating point (Newton unprojection with tanf, atan2f/cosf/sinf in the reprojection, Jacobi SVD in double):
+    accept / reject must agree except for pairs on a decision boundary, depth and 3-D points within 1e-4 relative."""
+    S = sc.fisheye_rig_scenario(9, n=2000)
+    rng = np.random.default_rng(4)
+    n = len(S["xy1"])
+    dL = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    perm = rng.permutation(n)
+    dR = dL[perm].copy()
+    flips = rng.integers(0, 256, (n, 6))
+    for k in range(6):
+        dR[np.arange(n), flips[:, k] // 8] ^= (1 << (flips[:, k] % 8)).astype(np.uint8)
+    kL = np.zeros(n, ob.KP_DTYPE); kR = np.zeros(n, ob.KP_DTYPE)
+    kL["x"], kL["y"], kL["octave"] = S["xy1"][:, 0], S["xy1"][:, 1], S["octave1"]
+    kR["x"], kR["y"], kR["octave"] = S["xy2"][perm, 0], S["xy2"][perm, 1], S["octave2"][perm]
+    ls2 = (ob.scale_factors(1.2, 8)[0] ** 2).astype(np.float32)
+    o = ob.fisheye_stereo(ob.make_rig(sc.KB8_CAM, sc.KB8_CAM, S["Rlr"], S["tlr"]), dL, kL, dR, kR, ls2)
+    g = orb.fisheye_stereo(ctx, sc.KB8_CAM, sc.KB8_CAM, S["Rlr"], S["tlr"], dL, kL, dR, kR, ls2)
+    assert o["n"] > 1000
+    same = g["matches"] == o["matches"]
+    assert same.mean() > 0.998 and abs(g["n"] - o["n"]) <= (~same).sum()
+    both = same & (o["matches"] >= 0)
+    assert np.allclose(g["depth"][both], o["depth"][both], rtol=1e-4, atol=0)
+    assert np.allclose(g["p3d"][both], o["p3d"][both], rtol=1e-4, atol=1e-5)
+    assert (g["depth"][g["matches"] < 0] == -1).all()
+    e = orb.fisheye_stereo(ctx, sc.KB8_CAM, sc.KB8_CAM, S["Rlr"], S["tlr"], dL[:0], kL[:0], dR, kR, ls2)
+    assert e["n"] == 0

@@ -261,3 +261,28 @@ def test_is_in_frustum_against_numpy():
     exact = np.abs(q - np.round(q)) > 1e-4
     assert np.array_equal(r["level"][m & exact], lv[m & exact])
     assert (r["level"][~r["in_view"].astype(bool)] == -1).all()
+
+
+def test_kb8_triangulate_recovers_points():
+    """orc_kb8_triangulate (KannalaBrandt8::TriangulateMatches): consistent pairs come back with the 3-D point they
+    were projected from, every rejection code occurs, and wrong associations are rejected."""
+    from tests import scenarios as sc
+    S = sc.fisheye_rig_scenario(5, noise=0.05)
+    rig = ob.make_rig(sc.KB8_CAM, sc.KB8_CAM, S["Rlr"], S["tlr"])
+    ls2 = (ob.scale_factors(1.2, 8)[0] ** 2).astype(np.float32)
+    code, p3d = ob.kb8_triangulate(rig, S["xy1"], S["xy2"], ls2[S["octave1"]], ls2[S["octave2"]])
+    ok = code > 0
+    good = ~S["wrong"] & (np.linalg.norm(S["Xl"], axis=1) < 2.5)
+    assert ok[good].mean() > 0.97
+    err = np.linalg.norm(p3d[ok & good] - S["Xl"][ok & good], axis=1) / S["Xl"][ok & good][:, 2]
+    assert np.median(err) < 1e-2 and err.max() < 0.3   # 0.05 px noise on a 0.1 m baseline
+    assert np.allclose(code[ok], p3d[ok][:, 2])
+    S0 = sc.fisheye_rig_scenario(6, noise=0.0)          # exact projections: the point itself comes back
+    c0, p0 = ob.kb8_triangulate(ob.make_rig(sc.KB8_CAM, sc.KB8_CAM, S0["Rlr"], S0["tlr"]), S0["xy1"], S0["xy2"],
+                                ls2[S0["octave1"]], ls2[S0["octave2"]])
+    g0 = ~S0["wrong"] & (c0 > 0)
+    e0 = np.linalg.norm(p0[g0] - S0["Xl"][g0], axis=1) / S0["Xl"][g0][:, 2]
+    assert g0.sum() > 500 and np.median(e0) < 2e-4 and e0.max() < 2e-2
+    assert ok[S["wrong"]].mean() < 0.1
+    neg = set(np.unique(code[~ok]).tolist())
+    assert neg >= {-1.0, -4.0} and len(neg) >= 3, neg
