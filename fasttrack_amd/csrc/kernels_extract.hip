@@ -365,19 +365,21 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             dA = dSv[FC_ROWS - 3]; dB = dSv[FC_ROWS - 2]; dC = dSv[FC_ROWS - 1];
             pA = pv[FC_ROWS]; pB = pv[FC_ROWS + 1]; pC = pv[FC_ROWS + 2];
             if (__any(mAny > (unsigned)minTh)) {
-                bool pass[FC_ROWS];
+                // rows without a survivor of the compass test skip the diagonal test, rows without a candidate the append
+                unsigned long long rowAny[FC_ROWS];
+#pragma unroll
+                for (int k = 0; k < FC_ROWS; k++) rowAny[k] = __ballot(m01[k] > (unsigned)minTh);
 #pragma unroll
                 for (int k = 0; k < FC_ROWS; k++) {
+                    if (!rowAny[k]) continue;  // wave-uniform
                     const unsigned v = pv[k];
                     const uint8_t *cpx = r + (k + 3) * TP;
                     const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
                     const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
-                    pass[k] = min(m01[k], min(m2, m3)) > (unsigned)minTh;
-                }
-#pragma unroll
-                for (int k = 0; k < FC_ROWS; k++) {
-                    const unsigned long long b = __ballot(pass[k]);
-                    if (pass[k]) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)((y + k) * pw + lane);
+                    const bool pass = min(m01[k], min(m2, m3)) > (unsigned)minTh;
+                    const unsigned long long b = __ballot(pass);
+                    if (!b) continue;  // wave-uniform
+                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)((y + k) * pw + lane);
                     nc += __popcll(b);
                 }
             }
