@@ -129,7 +129,9 @@ def main():
     w, h, nf, cfg_note = WORKLOADS[args.workload]
     B = args.batch
     host_threads = args.host_threads or max(1, usable_cpus() // max(world, 1))
-    ctx = orb.Context(local_rank, host_threads)
+    # one device per rank; FT_BENCH_DEVICE_MOD=<n> folds the ranks onto n devices (plumbing check on a smaller box)
+    ndev_mod = int(os.environ.get("FT_BENCH_DEVICE_MOD", "0"))
+    ctx = orb.Context(local_rank % ndev_mod if ndev_mod > 0 else local_rank, host_threads)
     intr = synth.intrinsics(w, h)
     # two front ends used alternately: while one batch drains (last descriptors, matching, result copies) the
     # next batch's pyramid / FAST / octree already run (ft_stereo_frontend_submit / _wait)
