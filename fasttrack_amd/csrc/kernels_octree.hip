@@ -183,7 +183,13 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
         if (tid == 0) *cntOut = 0;
         return;
     }
-    if (n > FT_OCT_MAXN || N > FT_OCT_MAXQ) {
+    const unsigned wMagic = L.wCell > 1 ? 0xffffffffu / (unsigned)L.wCell + 1u : 0u;
+    const unsigned hMagic = L.hCell > 1 ? 0xffffffffu / (unsigned)L.hCell + 1u : 0u;
+    // the sort key holds a 28-bit path code (at most 16 root nodes) and 7-bit cell / in-cell coordinates
+    const int minB = FT_EDGE_THRESHOLD - 3;
+    const Roots R = ft::op::make_roots(minB, L.maxBX, minB, L.maxBY);
+    const bool keyFits = L.nCols <= 128 && L.nRows <= 128 && L.wCell <= 128 && L.hCell <= 128 && R.nIni <= 15;
+    if (n > FT_OCT_MAXN || N > FT_OCT_MAXQ || !keyFits) {
         if (tid == 0) {
             *cntOut = 0;
             atomicOr(a.overflow, 1);
@@ -191,12 +197,10 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
         return;
     }
     const uint32_t *cand = a.cand + (size_t)slot * g.candPerSlot + L.candBase;
-    const int minB = FT_EDGE_THRESHOLD - 3;
-    const Roots R = ft::op::make_roots(minB, L.maxBX, minB, L.maxBY);
     const int cap = a.poolCap;
     const OctLds o = oct_lds_layout(cap);
     unsigned long long *keys = (unsigned long long *)(smem + o.keys);  // code << 32 | index
-    const uint32_t *codes = (const uint32_t *)keys;                     // codes[2 * i + 1]
+    const uint32_t *codes = (const uint32_t *)keys;                     // codes[2 * i + 1] = code << 4 | response >> 4
     uint32_t *lohiB[2] = {(uint32_t *)(smem + o.lohi[0]), (uint32_t *)(smem + o.lohi[1])};
     uint32_t *x01B[2] = {(uint32_t *)(smem + o.x01[0]), (uint32_t *)(smem + o.x01[1])};
     uint8_t *depB[2] = {smem + o.dep[0], smem + o.dep[1]};
@@ -225,10 +229,17 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
         unsigned long long k = ~0ull;
         if (i < n) {
             const uint32_t c = cand[i];
-            // codes are unique (a depth-12 path identifies the pixel), so the low word never decides the order:
-            // it carries the response and the original index for the pick at the end
-            k = ((unsigned long long)ft::op::path_code(R, (int)(c & 0xfffu), (int)((c >> 12) & 0xfffu)) << 32) |
-                ((c >> 24) << 16) | (unsigned)i;
+            // key = path code << 36 | response << 28 | emission rank.  Codes are unique (a depth-12 path identifies
+            // the pixel), so the low 36 bits never decide the order; they carry what the pick at the end needs: the
+            // response and the candidate's rank in the reference's emission order - cell row, cell column, then
+            // row-major inside the cell (ORBextractor.cc:1136-1199) - which is a function of its coordinates, so the
+            // order in which the FAST stage delivers the candidates does not matter.
+            const int x = (int)(c & 0xfffu), y = (int)((c >> 12) & 0xfffu);
+            const int cj = min(wMagic ? (int)__umulhi((unsigned)(x - 3), wMagic) : x - 3, L.nCols - 1);
+            const int ci = min(hMagic ? (int)__umulhi((unsigned)(y - 3), hMagic) : y - 3, L.nRows - 1);
+            const unsigned ekey = ((unsigned)ci << 21) | ((unsigned)cj << 14) | ((unsigned)(y - 3 - ci * L.hCell) << 7) |
+                                  (unsigned)(x - 3 - cj * L.wCell);
+            k = ((unsigned long long)ft::op::path_code(R, x, y) << 36) | ((unsigned long long)(c >> 24) << 28) | ekey;
         }
         keys[i] = k;
     }
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     auto lower_bound = [&](int lo, int hi, uint32_t target) {
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (codes[2 * mid + 1] < target) lo = mid + 1;
+            if (codes[2 * mid + 1] < (target << 4)) lo = mid + 1;
             else hi = mid;
         }
         return lo;
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
                 int b1 = hi, b2 = hi, b3 = hi;
                 if (d < kMaxDepth) {
                     const int shift = 2 * (kMaxDepth - 1 - d);
-                    const uint32_t prefix = codes[2 * lo + 1] >> (shift + 2);
+                    const uint32_t prefix = codes[2 * lo + 1] >> (shift + 2 + 4);
                     b1 = lower_bound(lo, hi, ((prefix << 2) | 1u) << shift);
                     b2 = lower_bound(b1, hi, ((prefix << 2) | 2u) << shift);
                     b3 = lower_bound(b2, hi, ((prefix << 2) | 3u) << shift);
@@ -440,10 +451,14 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     for (int t = lane; t < kept; t += 64) {
         const unsigned lh = cl[start + t];
         const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
-        // maximise (response, -index): first maximum in emission order (:863-881)
-        unsigned best = (unsigned)keys[lo] ^ 0xffffu;
-        for (int k = lo + 1; k < hi; k++) best = max(best, (unsigned)keys[k] ^ 0xffffu);
-        const unsigned bestC = cand[(best & 0xffffu) ^ 0xffffu];
+        // maximise (response, -emission rank): the first maximum in emission order (:863-881)
+        const unsigned long long low = (1ull << 36) - 1, inv = (1ull << 28) - 1;
+        unsigned long long best = (keys[lo] & low) ^ inv;
+        for (int k = lo + 1; k < hi; k++) best = max(best, (keys[k] & low) ^ inv);
+        const unsigned ek = (unsigned)(~best) & (unsigned)inv;
+        const int bx = (int)((ek >> 14) & 127u) * L.wCell + (int)(ek & 127u) + 3;
+        const int by = (int)((ek >> 21) & 127u) * L.hCell + (int)((ek >> 7) & 127u) + 3;
+        const unsigned bestC = ft_pack_cand(bx, by, (int)(best >> 28));
         FtSelKp s;
         s.x = (short)((bestC & 0xfffu) + minB);  // ORBextractor.cc:1211-1217: add the border offset back
         s.y = (short)(((bestC >> 12) & 0xfffu) + minB);
