@@ -275,7 +275,9 @@ int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done) {
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.fast_cells", ex->stream);
-    rc = ft_launch_fast_cells(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->iniTh, ex->minTh, al, cellCount, stage);
+    // the device octree ranks candidates by their coordinates: FAST need not deliver them in the reference's order
+    rc = ft_launch_fast_cells(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->iniTh, ex->minTh, al, cellCount, stage,
+                              ex->deviceOctree ? 0 : 1);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.compact", ex->stream);
@@ -794,6 +796,16 @@ int ft_extractor_download_candidates(ft_extractor *ex, int slot, int level, int 
         tmp.resize(std::max(cnt, 1));
         FT_HIP(hipMemcpy(tmp.data(), ex->d_candDev + (size_t)slot * g.candPerSlot + g.lv[level].candBase,
                          sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
+        // the device path delivers every cell's candidates in arbitrary order (k_octree ranks them by their
+        // coordinates); present them in the reference's emission order: cell row, cell column, row-major in the cell
+        const FtLevelGeom &L = g.lv[level];
+        auto rank = [&](uint32_t v) -> uint64_t {
+            const int x = (int)(v & 0xfffu) - 3, y = (int)((v >> 12) & 0xfffu) - 3;
+            const int cj = std::min(x / std::max(L.wCell, 1), std::max(L.nCols - 1, 0));
+            const int ci = std::min(y / std::max(L.hCell, 1), std::max(L.nRows - 1, 0));
+            return ((uint64_t)ci << 48) | ((uint64_t)cj << 32) | ((uint64_t)y << 16) | (uint64_t)x;
+        };
+        std::sort(tmp.begin(), tmp.begin() + cnt, [&](uint32_t a, uint32_t b) { return rank(a) < rank(b); });
         c = tmp.data();
     }
     *n = cnt;

@@ -223,6 +223,7 @@ __device__ __forceinline__ int fast_score(const int d[16]) {
 #ifndef FC_ROWS
 #define FC_ROWS 4     // rows per trip of the column-mapped rejection pass (>= 3)
 #endif
+#define FC_NMS_REG 2  // corner-list chunks (64 corners each) whose NMS flags stay in registers
 #define FC_CORN 256   // corners kept for NMS / emission; a cell with more falls back to scanning the plane
 __host__ __device__ __forceinline__ int fc_pitch(int wCell, int TP) { return TP ? TP : ((wCell + 12) & ~3); }
 __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int TP) {
@@ -233,7 +234,10 @@ __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int 
 __host__ __device__ __forceinline__ int fc_score_bytes(int wCell, int hCell, int TP) { return (((hCell + 2) * fc_pitch(wCell, TP)) + 15) & ~15; }
 __host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + FC_CORN); }
 
-template <int TP>
+// ORDERED = false (device octree, which ranks candidates by their coordinates): the rejection pass is free to
+// visit the pixels in any order and uses all 64 lanes (see below); ORDERED = true delivers every cell's
+// candidates row-major, as the host octree expects them.
+template <int TP, bool ORDERED>
 __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
                                                    int iniTh, int minTh, int alignedLoads, int *cellCount,
                                                    uint32_t *stage) {
@@ -333,7 +337,86 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         wave_lds_sync();
         };
 #define FT_AD(ox, oy) __builtin_amdgcn_sad_u8(v, (unsigned)cpx[(oy)*tp + (ox)], 0u)
-    if constexpr (TP > 0) {
+    if constexpr (TP > 0 && !ORDERED) {
+        // Two half-cells side by side: lanes 0-31 walk the rows of the upper half, lanes 32-63 the rows of the lower
+        // half, 32 columns each (a 36-pixel-wide cell fills 56 % of a 64-lane row, two 32-wide halves fill it); the
+        // columns beyond 32 are tested afterwards in linear order.  Inside a half the rows slide as in the ordered
+        // pass (shared vertical differences, immediates only).
+        const int half = lane >> 5, cx = lane & 31;
+        const int hRows = (ph + 1) >> 1;          // rows of the upper half; the lower half has ph - hRows
+        const int y0h = half * hRows;              // first row of this lane's half
+        const int nRowsH = half ? ph - hRows : hRows;
+        const int wMain = min(pw, 32);
+        const bool actC = cx < wMain;
+        const uint8_t *col = t0 + min(cx, wMain - 1) + 3 + y0h * TP;  // (x + 3, tile row y0h)
+        unsigned pA = col[3 * TP], pB = col[4 * TP], pC = col[5 * TP];
+        unsigned dA = __builtin_amdgcn_sad_u8(pA, (unsigned)col[0], 0u);
+        unsigned dB = __builtin_amdgcn_sad_u8(pB, (unsigned)col[TP], 0u);
+        unsigned dC = __builtin_amdgcn_sad_u8(pC, (unsigned)col[2 * TP], 0u);
+        for (int y = 0; y < hRows; y += FC_ROWS) {
+            const uint8_t *r = col + y * TP;
+            unsigned pv[FC_ROWS + 3], m01[FC_ROWS], dSv[FC_ROWS], mAny = 0;
+            pv[0] = pA; pv[1] = pB; pv[2] = pC;
+#pragma unroll
+            for (int k = 0; k < FC_ROWS; k++) pv[k + 3] = r[(k + 6) * TP];
+#pragma unroll
+            for (int k = 0; k < FC_ROWS; k++) {
+                const unsigned v = pv[k];
+                const uint8_t *cpx = r + (k + 3) * TP;
+                const unsigned dS = dSv[k] = __builtin_amdgcn_sad_u8(v, pv[k + 3], 0u);
+                const unsigned dN = k == 0 ? dA : k == 1 ? dB : k == 2 ? dC : dSv[k >= 3 ? k - 3 : 0];
+                const unsigned m1 = max(FT_AD(3, 0), FT_AD(-3, 0));
+                m01[k] = (actC && y + k < nRowsH) ? min(max(dN, dS), m1) : 0u;
+                mAny = max(mAny, m01[k]);
+            }
+            dA = dSv[FC_ROWS - 3]; dB = dSv[FC_ROWS - 2]; dC = dSv[FC_ROWS - 1];
+            pA = pv[FC_ROWS]; pB = pv[FC_ROWS + 1]; pC = pv[FC_ROWS + 2];
+            if (__any(mAny > (unsigned)minTh)) {
+                unsigned long long rowAny[FC_ROWS];
+#pragma unroll
+                for (int k = 0; k < FC_ROWS; k++) rowAny[k] = __ballot(m01[k] > (unsigned)minTh);
+#pragma unroll
+                for (int k = 0; k < FC_ROWS; k++) {
+                    if (!rowAny[k]) continue;  // wave-uniform
+                    const unsigned v = pv[k];
+                    const uint8_t *cpx = r + (k + 3) * TP;
+                    const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
+                    const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
+                    const bool pass = min(m01[k], min(m2, m3)) > (unsigned)minTh;
+                    const unsigned long long b = __ballot(pass);
+                    if (!b) continue;  // wave-uniform
+                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)((y0h + y + k) * pw + cx);
+                    nc += __popcll(b);
+                }
+            }
+            if (nc > FC_CAND - FC_ROWS * 64) flushB();  // wave-uniform
+        }
+        // columns 32 .. pw-1 (four of them for a 36-pixel cell), every row, in linear order
+        const int wRem = pw - wMain, nRem = wRem * ph;
+        if (wRem > 0) {
+            const unsigned remMagic = div_magic_of((unsigned)wRem);
+            for (int base = 0; base < nRem; base += 64) {
+                const int i = base + lane;
+                const int ii = min(i, nRem - 1);
+                const int yy = div_by(ii, remMagic), xx = wMain + ii - yy * wRem;
+                const uint8_t *cpx = t0 + (yy + 3) * TP + (xx + 3);
+                const unsigned v = cpx[0];
+                const unsigned m0 = max(FT_AD(0, 3), FT_AD(0, -3));
+                const unsigned m1 = max(FT_AD(3, 0), FT_AD(-3, 0));
+                const unsigned m01r = i < nRem ? min(m0, m1) : 0u;
+                if (__any(m01r > (unsigned)minTh)) {
+                    const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
+                    const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
+                    const bool pass = min(m01r, min(m2, m3)) > (unsigned)minTh;
+                    const unsigned long long b = __ballot(pass);
+                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)(yy * pw + xx);
+                    nc += __popcll(b);
+                }
+                if (nc > FC_CAND - 64) flushB();  // wave-uniform
+            }
+        }
+        flushB();
+    } else if constexpr (TP > 0) {
         // Fixed pitch (pw <= TP - 6 < 64): lane = column, rows walked top to bottom three at a time.  Every tile
         // offset is an immediate; the vertical differences |p(y) - p(y+3)| serve row y (south) and row y + 3
         // (north), and the centre of row y + 3 is the south pixel of row y, so a row costs three LDS reads and
@@ -440,20 +523,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
                           v > s[tp - 1] && v > s[tp] && v > s[tp + 1];
         return keep ? (v >= iniTh ? 2 : 1) : 0;
     };
-    int anyHi = 0;
-    for (int base = 0; base < nItems; base += 64) {
-        const int it = base + lane;
-        int fl = 0, pix;
-        if (it < nItems) fl = nms(it, pix);
-        anyHi |= __any(fl == 2);
-    }
-    const int need = anyHi ? 2 : 1;
     uint32_t *out = stage + (size_t)slot * g.stagePerSlot + L.stageBase + (size_t)c * L.cellCap;
     int run = 0;
-    for (int base = 0; base < nItems; base += 64) {
-        const int it = base + lane;
-        int fl = 0, pix = 0;
-        if (it < nItems) fl = nms(it, pix);
+    auto emit = [&](int fl, int pix, int need) {
         const bool f = fl >= need;
         const unsigned long long b = __ballot(f);
         if (f) {
@@ -464,6 +536,38 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
                 out[pos] = ft_pack_cand(x + 3 + cj * L.wCell, y + 3 + ci * L.hCell, score[(y + 1) * tp + (x + 1)]);
         }
         run += __popcll(b);
+    };
+    if (nItems <= 64 * FC_NMS_REG) {
+        // the usual case: the NMS flags of the whole cell stay in registers, the corner list is read once
+        int fl[FC_NMS_REG], px[FC_NMS_REG], anyHi = 0;
+#pragma unroll
+        for (int q = 0; q < FC_NMS_REG; q++) {
+            fl[q] = 0;
+            px[q] = 0;
+            if (q * 64 < nItems) {  // wave-uniform
+                if (q * 64 + lane < nItems) fl[q] = nms(q * 64 + lane, px[q]);
+                anyHi |= __any(fl[q] == 2);
+            }
+        }
+        const int need = anyHi ? 2 : 1;
+#pragma unroll
+        for (int q = 0; q < FC_NMS_REG; q++)
+            if (q * 64 < nItems) emit(fl[q], px[q], need);
+    } else {
+        int anyHi = 0;
+        for (int base = 0; base < nItems; base += 64) {
+            const int it = base + lane;
+            int fl = 0, pix;
+            if (it < nItems) fl = nms(it, pix);
+            anyHi |= __any(fl == 2);
+        }
+        const int need = anyHi ? 2 : 1;
+        for (int base = 0; base < nItems; base += 64) {
+            const int it = base + lane;
+            int fl = 0, pix = 0;
+            if (it < nItems) fl = nms(it, pix);
+            emit(fl, pix, need);
+        }
     }
     (void)surv;
     if (lane == 0) *cnt = min(run, L.cellCap);
@@ -774,26 +878,20 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
 
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
-                         uint32_t *stage) {
+                         uint32_t *stage, int ordered) {
     if (g.totalCells == 0) return FT_OK;  // every level is too small for a 35-px cell: no candidates
     const int runBlock = 8 * FC_XCD_RUN;  // grid padded to whole rounds of the XCD mapping
     dim3 grid(((g.totalCells + runBlock - 1) / runBlock) * runBlock, batch, 1), block(64, 1, 1);
     const size_t smem = ft_fast_smem_bytes(g);
     const int TP = fast_tile_pitch(g);
-    if (smem > 64 * 1024) {  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
-        const void *fn = TP == 48 ? (const void *)k_fast_cells<48> : TP == 64 ? (const void *)k_fast_cells<64> : (const void *)k_fast_cells<0>;
-        FT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    }
+    typedef void (*FastFn)(FtGeom, const uint8_t *const *, int, const uint8_t *, int, int, int, int *, uint32_t *);
+    const FastFn fn = TP == 48 ? (ordered ? k_fast_cells<48, true> : k_fast_cells<48, false>)
+                      : TP == 64 ? (ordered ? k_fast_cells<64, true> : k_fast_cells<64, false>)
+                                 : k_fast_cells<0, true>;  // any-size cells: the linear pass is ordered anyway
+    if (smem > 64 * 1024)  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
+        FT_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
-    if (TP == 48)
-        hipLaunchKernelGGL(k_fast_cells<48>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
-                           cellCount, stage);
-    else if (TP == 64)
-        hipLaunchKernelGGL(k_fast_cells<64>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
-                           cellCount, stage);
-    else
-        hipLaunchKernelGGL(k_fast_cells<0>, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads,
-                           cellCount, stage);
+        hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
