@@ -110,12 +110,17 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
         sya = max((int)(((unsigned)(2 * dy0 + 1) * syQ16) >> 17) - 2, 0);
         syb = min((int)(((unsigned)(2 * dy1 + 1) * syQ16) >> 17) + 2, sh - 1);
     }
-    const int dx = min(dx0 + lane, dx1);
-    FtTap xt, yt[PD_TH];
+    // compute mapping: lane = (group of 4 output columns, group of 4 output rows): 16 x 4 groups cover the 64 x 16 tile,
+    // every lane produces a 4 x 4 block and stores it as four dwords (a row of the tile is 64 B = one store segment)
+    const int xg = lane & 15, yg = lane >> 4;
+    const int bx = dx0 + 4 * xg, by = dy0 + 4 * yg;
+    FtTap xt[4], yt[4];
     if (!D.area2x) {
-        xt = taps[D.xtab + dx];
 #pragma unroll
-        for (int k = 0; k < PD_TH; k++) yt[k] = taps[D.ytab + min(dy0 + k, dy1)];  // wave-uniform
+        for (int k = 0; k < 4; k++) {
+            xt[k] = taps[D.xtab + min(bx + k, dx1)];
+            yt[k] = taps[D.ytab + min(by + k, dy1)];
+        }
     }
     const int rows = syb - sya + 1;
     int ax = 0;
@@ -139,25 +144,46 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
     }
     wave_lds_sync();
     const uint8_t *T = smem + ax;  // source pixel (sx, sy) at T[(sy - sya) * ldsPitch + (sx - sxa)]
-    if (dx0 + lane > dx1) return;
-    uint8_t *outBase = pyr + (size_t)slot * g.pyrPerSlot + D.off + dx;
+    if (bx > dx1 || by > dy1) return;
+    uint8_t *outBase = pyr + (size_t)slot * g.pyrPerSlot + D.off + bx;
+    // the row pitch of a level is a multiple of 64 B, so the dword store may run past the last column of the level
+    // (into the row's padding) but never into the next row
     if (D.area2x) {
-        for (int dy = dy0; dy <= dy1; dy++) {
-            const uint8_t *r0 = T + (2 * dy - sya) * ldsPitch + (2 * dx - sxa), *r1 = r0 + ldsPitch;
-            outBase[(size_t)dy * D.pitch] = (uint8_t)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int dy = by + j;
+            if (dy > dy1) break;
+            unsigned pk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int dxk = min(bx + k, dx1);
+                const uint8_t *r0 = T + (2 * dy - sya) * ldsPitch + (2 * dxk - sxa), *r1 = r0 + ldsPitch;
+                pk |= (unsigned)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2) << (8 * k);
+            }
+            *(unsigned *)(outBase + (size_t)dy * D.pitch) = pk;
         }
         return;
     }
-    const int cx0 = xt.s - sxa, cx1 = min(xt.s + 1, sw - 1) - sxa;
+    int cx0[4], cx1[4];
 #pragma unroll
-    for (int k = 0; k < PD_TH; k++) {
-        const int dy = dy0 + k;
+    for (int k = 0; k < 4; k++) {
+        cx0[k] = xt[k].s - sxa;
+        cx1[k] = min(xt[k].s + 1, sw - 1) - sxa;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int dy = by + j;
         if (dy > dy1) break;
-        const int sy0 = min(max((int)yt[k].s, 0), sh - 1) - sya, sy1 = min(max((int)yt[k].s + 1, 0), sh - 1) - sya;
+        const int sy0 = min(max((int)yt[j].s, 0), sh - 1) - sya, sy1 = min(max((int)yt[j].s + 1, 0), sh - 1) - sya;
         const uint8_t *r0 = T + sy0 * ldsPitch, *r1 = T + sy1 * ldsPitch;
-        const int h0 = r0[cx0] * xt.a0 + r0[cx1] * xt.a1;
-        const int h1 = r1[cx0] * xt.a0 + r1[cx1] * xt.a1;
-        outBase[(size_t)dy * D.pitch] = (uint8_t)((((yt[k].a0 * (h0 >> 4)) >> 16) + ((yt[k].a1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        unsigned pk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int h0 = r0[cx0[k]] * xt[k].a0 + r0[cx1[k]] * xt[k].a1;
+            const int h1 = r1[cx0[k]] * xt[k].a0 + r1[cx1[k]] * xt[k].a1;
+            pk |= (unsigned)((((yt[j].a0 * (h0 >> 4)) >> 16) + ((yt[j].a1 * (h1 >> 4)) >> 16) + 2) >> 2) << (8 * k);
+        }
+        *(unsigned *)(outBase + (size_t)dy * D.pitch) = pk;
     }
 }
 
