@@ -176,6 +176,7 @@ void freeAll(ft_extractor *ex) {
     if (ex->streamB) hipStreamDestroy(ex->streamB);
     hipFree(ex->d_pyr);
     hipFree(ex->d_taps);
+    hipFree(ex->d_cellTab);
     hipFree(ex->d_cellCount);
     hipFree(ex->d_stage);
     hipFree((void *)ex->d_l0);
@@ -277,7 +278,7 @@ int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done) {
     ex->evt.begin(tm, "kernel.fast_cells", ex->stream);
     // the device octree ranks candidates by their coordinates: FAST need not deliver them in the reference's order
     rc = ft_launch_fast_cells(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->iniTh, ex->minTh, al, cellCount, stage,
-                              ex->deviceOctree ? 0 : 1);
+                              ex->deviceOctree ? 0 : 1, ex->d_cellTab);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.compact", ex->stream);
@@ -495,6 +496,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     }
     FT_TRY(devAlloc(&ex->d_pyr, B * g.pyrPerSlot));
     FT_TRY(devAlloc(&ex->d_taps, taps.size()));
+    FT_TRY(devAlloc(&ex->d_cellTab, (size_t)std::max(g.totalCells, 1)));
     FT_TRY(devAlloc(&ex->d_cellCount, B * g.totalCells));
     FT_TRY(devAlloc(&ex->d_stage, B * g.stagePerSlot));
     FT_TRY(devAlloc(&ex->d_l0, B));
@@ -528,7 +530,13 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         }
     }
     {
-        hipError_t e = hipMemcpy(ex->d_taps, taps.data(), taps.size() * sizeof(FtTap), hipMemcpyHostToDevice);
+        std::vector<uint32_t> cellTab(std::max(g.totalCells, 1), 0u);
+        for (int l = 0; l < nlevels; l++)
+            for (int ci = 0; ci < g.lv[l].nRows; ci++)
+                for (int cj = 0; cj < g.lv[l].nCols; cj++)
+                    cellTab[g.lv[l].cellBase + ci * g.lv[l].nCols + cj] = (uint32_t)l | ((uint32_t)ci << 8) | ((uint32_t)cj << 20);
+        hipError_t e = hipMemcpy(ex->d_cellTab, cellTab.data(), cellTab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ex->d_taps, taps.data(), taps.size() * sizeof(FtTap), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(ex->d_nSel, 0, sizeof(int) * B);
         if (e != hipSuccess) {
             freeAll(ex);

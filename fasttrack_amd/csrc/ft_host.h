@@ -108,6 +108,7 @@ struct ft_extractor {
     // device buffers
     uint8_t *d_pyr = nullptr;
     FtTap *d_taps = nullptr;
+    uint32_t *d_cellTab = nullptr;  // per FAST cell: level | cell row << 8 | cell column << 20
     int *d_cellCount = nullptr;
     uint32_t *d_stage = nullptr;
     const uint8_t **d_l0 = nullptr;

@@ -133,7 +133,7 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
                       uint8_t *pyr, const FtTap *taps, int alignedLoads);
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
-                         uint32_t *stage, int ordered);
+                         uint32_t *stage, int ordered, const uint32_t *cellTab);
 int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cellCount, const uint32_t *stage,
                       uint32_t *cand, int *candCount);
 // sel is laid out per level (slot * maxKp + selOff[level] + i) with per-level counts; the kernel packs the

@@ -266,10 +266,11 @@ __host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + 
 template <int TP, bool ORDERED>
 __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
                                                    int iniTh, int minTh, int alignedLoads, int *cellCount,
-                                                   uint32_t *stage) {
+                                                   uint32_t *stage, const uint32_t *cellTab) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
     const int slot = blockIdx.y;
+    const uint8_t *img0 = l0[slot];  // level 0 is the caller's frame; requested before anything depends on the level
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed placement, used for speed only).  Runs of
     // FC_XCD_RUN consecutive cells are dealt round-robin to the XCDs, so horizontally neighbouring cells,
     // whose tiles overlap by 6 px and share 64-B lines, hit the same private L2 instead of fetching the
@@ -277,11 +278,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     const int j = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
     const int cell = ((j / FC_XCD_RUN) * 8 + xcd) * FC_XCD_RUN + (j % FC_XCD_RUN);
     if (cell >= g.totalCells) return;
-    int level = 0;
-    while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cellBase) level++;
+    // (level, cell row, cell column) of the cell from a table built with the extractor: no search, no division
+    const uint32_t ct = cellTab[cell];
+    const int level = (int)(ct & 0xffu), ci = (int)((ct >> 8) & 0xfffu), cj = (int)(ct >> 20);
     const FtLevelGeom &L = g.lv[level];
     const int c = cell - L.cellBase;
-    const int ci = c / L.nCols, cj = c - ci * L.nCols;
     const int iniX = 16 + cj * L.wCell, iniY = 16 + ci * L.hCell;
     const int maxX = min(iniX + L.wCell + 6, L.maxBX), maxY = min(iniY + L.hCell + 6, L.maxBY);
     int *cnt = cellCount + (size_t)slot * g.totalCells + cell;
@@ -300,8 +301,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     unsigned short *cand = (unsigned short *)(score + fc_score_bytes(L.wCell, L.hCell, TP));
     unsigned short *corn = cand + FC_CAND;
     uint8_t *surv = tile;
-    int pitch;
-    const uint8_t *img = level_ptr(g, level, slot, l0, l0pitch, pyr, pitch);
+    const int pitch = level ? L.pitch : l0pitch;
+    const uint8_t *img = level ? pyr + (size_t)slot * g.pyrPerSlot + L.off : img0;
     // ---- stage the tile: aligned dword rows when the level allows it (coalesced 4-byte lanes) ----
     int ax = 0;
     if (alignedLoads) {
@@ -904,20 +905,20 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
 
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
-                         uint32_t *stage, int ordered) {
+                         uint32_t *stage, int ordered, const uint32_t *cellTab) {
     if (g.totalCells == 0) return FT_OK;  // every level is too small for a 35-px cell: no candidates
     const int runBlock = 8 * FC_XCD_RUN;  // grid padded to whole rounds of the XCD mapping
     dim3 grid(((g.totalCells + runBlock - 1) / runBlock) * runBlock, batch, 1), block(64, 1, 1);
     const size_t smem = ft_fast_smem_bytes(g);
     const int TP = fast_tile_pitch(g);
-    typedef void (*FastFn)(FtGeom, const uint8_t *const *, int, const uint8_t *, int, int, int, int *, uint32_t *);
+    typedef void (*FastFn)(FtGeom, const uint8_t *const *, int, const uint8_t *, int, int, int, int *, uint32_t *, const uint32_t *);
     const FastFn fn = TP == 48 ? (ordered ? k_fast_cells<48, true> : k_fast_cells<48, false>)
                       : TP == 64 ? (ordered ? k_fast_cells<64, true> : k_fast_cells<64, false>)
                                  : k_fast_cells<0, true>;  // any-size cells: the linear pass is ordered anyway
     if (smem > 64 * 1024)  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
         FT_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
-        hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage);
+        hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
