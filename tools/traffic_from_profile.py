@@ -13,7 +13,7 @@ FETCH_FACTOR = {"k_fast_cells": 1.0, "k_pyr_down": 1.0, "k_orient_desc": 1.0}  #
 def main(summary, out, images_per_step=256, steps=7):
     d = {}
     for line in open(summary):
-        m = re.match(r"(\S+)\s+(FETCH_SIZE|WRITE_SIZE)\s+launches\s+(\d+)\s+per-launch\s+([\d.]+) KB", line)
+        m = re.match(r"(.+?)\s+(FETCH_SIZE|WRITE_SIZE)\s+launches\s+(\d+)\s+per-launch\s+([\d.]+) KB", line)
         if not m:
             continue
         k = m.group(1).split("<")[0]
