@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="one front end, every step fully drained before the next")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight (front ends used round-robin)")
     ap.add_argument("--stats", default="", help="write per-stage timings to this file")
     args = ap.parse_args()
 
@@ -136,7 +137,7 @@ def main():
     # two front ends used alternately: while one batch drains (last descriptors, matching, result copies) the
     # next batch's pyramid / FAST / octree already run (ft_stereo_frontend_submit / _wait)
     fes = [orb.StereoFrontend(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, B, intr["mbf"], intr["mb"])
-           for _ in range(1 if args.sync_steps else 2)]
+           for _ in range(1 if args.sync_steps else max(1, args.in_flight))]
     fe = fes[0]
 
     # synthetic stream, resident in HBM before the timed region (seeds are per rank: one stream per GPU)
@@ -158,11 +159,13 @@ def main():
             for _ in range(steps):
                 fe.process_raw(ptrsL, ptrsR, B, True, w)
             return
+        F = len(fes)
         for k in range(steps):
-            fes[k & 1].submit_raw(ptrsL, ptrsR, B, True, w)
-            if k > 0:
-                fes[(k - 1) & 1].wait()
-        fes[(steps - 1) & 1].wait()
+            if k >= F:
+                fes[k % F].wait()  # the batch submitted F steps ago
+            fes[k % F].submit_raw(ptrsL, ptrsR, B, True, w)
+        for k in range(max(steps - F, 0), steps):
+            fes[k % F].wait()
 
     run(max(args.warmup, 1))
     ctx.reset_stats()
