@@ -412,3 +412,51 @@ def test_fisheye_stereo_with_triangulation(ctx):
     assert (g["depth"][g["matches"] < 0] == -1).all()
     e = orb.fisheye_stereo(ctx, sc.KB8_CAM, sc.KB8_CAM, S["Rlr"], S["tlr"], dL[:0], kL[:0], dR, kR, ls2)
     assert e["n"] == 0
+
+
+def test_full_size_batch_properties(ctx):
+    """BASELINE.json's full configuration (1280x720 stereo, nFeatures 2000, 128 pairs per batch, two batches in flight):
+    too large for the oracle in a test, so it is checked through properties - repeated pairs give identical results
+    wherever they sit in the batch and in whichever front end, a sample of pairs equals the oracle bit for bit,
+    every depth is mbf / disparity, keypoints respect the border and the per-level quotas."""
+    import ctypes as C
+    w, h, nf, B, D = 1280, 720, 2000, 128, 8
+    intr = synth.intrinsics(w, h)
+    fes = [orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"]) for _ in range(2)]
+    pairs = [synth.make_stereo_pair(w, h, seed=900 + i) for i in range(D)]
+    dev = [(ctx.to_device(p[0]), ctx.to_device(p[1])) for p in pairs]
+    pL = (C.c_void_p * B)(*[dev[b % D][0].ptr for b in range(B)])
+    pR = (C.c_void_p * B)(*[dev[b % D][1].ptr for b in range(B)])
+    fes[0].submit_raw(pL, pR, B, True, w)
+    fes[1].submit_raw(pL, pR, B, True, w)
+    fes[0].wait()
+    fes[1].wait()
+    quotas = fes[0].left.features_per_level()
+    sf, _ = ob.scale_factors(1.2, 8)
+
+    def res(fe, b):
+        n = int(fe._nL[b])
+        return fe._kL[b, :n], fe._dL[b, :n], fe._ur[b, :n], fe._dp[b, :n], int(fe._nm[b])
+    for b in range(B):
+        k0, d0, u0, z0, m0 = res(fes[0], b % D)
+        for fe in fes:
+            k, d, u, z, m = res(fe, b)
+            assert np.array_equal(k, k0) and np.array_equal(d, d0) and np.array_equal(u, u0) and np.array_equal(z, z0) and m == m0
+    for b in range(D):
+        k, d, u, z, m = res(fes[0], b)
+        assert 0.9 * nf <= len(k) <= nf + 24
+        lv = k["octave"]
+        assert (np.diff(lv) >= 0).all() and all((lv == l).sum() <= max(quotas[l] + 3, 8) for l in range(8))
+        xl, yl = k["x"] / sf[lv], k["y"] / sf[lv]
+        assert (xl >= 18.99).all() and (yl >= 18.99).all()
+        ok = z > 0
+        assert ok.sum() == m and m > 100
+        assert np.allclose(z[ok], intr["mbf"] / (k["x"][ok] - u[ok]), rtol=1e-5)
+        assert (u[~ok] == -1).all() and d.any(axis=1).all()
+    for b in (0, 5):  # the oracle on two of the pairs
+        oL, oR = ob.Extractor(nf), ob.Extractor(nf)
+        kL, dL, _ = oL.extract(pairs[b][0])
+        kR, dR, _ = oR.extract(pairs[b][1])
+        o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+        k, d, u, z, m = res(fes[1], b + 2 * D)
+        assert np.array_equal(k, kL) and np.array_equal(d, dL) and np.array_equal(u, o["uright"]) and np.array_equal(z, o["depth"])
