@@ -81,13 +81,13 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ------------------------------------------------------------------------------------------------
 // One WAVE per 64 x 8 output tile (no workgroup barrier, like k_fast_cells): the source footprint of the
 // tile (rows sy(first)..sy(last)+1, columns sx(first)..sx(last)+1) is staged in LDS with aligned dword
-// loads, then every lane produces the 8 outputs of its column from 2x2 taps read from LDS.
+// loads, then every lane produces a 4 x 4 block of outputs from 2x2 taps read from LDS and stores four dwords.
 #define PD_TW 64
 #define PD_TH 16
 // A wave's life is a chain of memory round trips, so the chain is kept short: the source footprint of the tile is
 // bounded arithmetically (fixed-point scale with a two-pixel margin instead of reading the first and last tap),
-// and the taps the outputs need - one per lane in x, eight wave-uniform ones in y - are requested together with
-// the footprint, before anything waits.
+// and the taps the outputs need - four in x and four in y per lane - are requested together with the footprint,
+// before anything waits.
 __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint8_t *const *l0, int l0pitch,
                                                  uint8_t *pyr, const FtTap *taps, int alignedLoads, int ldsPitch,
                                                  unsigned sxQ16, unsigned syQ16) {
@@ -233,8 +233,8 @@ __device__ __forceinline__ int fast_score(const int d[16]) {
     return max(best, -worst) - 1;
 }
 
-// One WAVE per (cell, image): no workgroup barrier anywhere, so the ~29 cells resident on a CU hide
-// each other's load and LDS latency (the kernel is occupancy bound: LDS per wave is kept near 5.5 KB).
+// One WAVE per (cell, image): no workgroup barrier anywhere, so the ~20 cells resident on a CU hide each other's
+// load and LDS latency (LDS per wave is kept near 6 KB); measured VALU bound.
 // TP = LDS pitch of the tile and of the score plane; TP > 0 makes every ring / neighbour offset an
 // instruction immediate, TP == 0 is the any-size fallback.
 // LDS carve (bytes): tile th*tp | score (ph+2)*tp | candidate ring FC_CAND u16 | corner list FC_CORN u16 ;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     wave_lds_sync();
     // ---- NMS (strictly greater than the 8 neighbours, cv::FAST), cell-level threshold fallback
     // (ORBextractor.cc:1157-1177: if any survivor reaches iniThFAST only those are emitted, otherwise every
-    // minThFAST survivor is) and ordered emission.  The corner list is in row-major order; a cell with more
+    // minThFAST survivor is) and emission.  The corner list is in row-major order in the ORDERED variant; a cell with more
     // than FC_CORN corners scans the score plane instead (same order).
     const bool useList = ncorn <= FC_CORN;
     const int nItems = useList ? ncorn : npx;
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ordered compaction: one workgroup per (level, image).  Exclusive scan of the cell counts in cell
+// Compaction in cell order: one workgroup per (level, image).  Exclusive scan of the cell counts in cell
 // order, then a coalesced gather into the dense list (which lives in host-mapped pinned memory so
 // the host octree can read it after a single stream sync).
 // ------------------------------------------------------------------------------------------------
