@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
     L.ft_fisheye_match.argtypes = [vp, vp, i, vp, i, vp, vp, vp]
     L.ft_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LocalPoints), f, f, vp, ip] + [vp] * 10
     L.ft_search_last_frame.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LastPoints), vp, f, i, i, i, vp, ip] + [vp] * 4
+    L.ft_features_in_area.argtypes = [vp, C.POINTER(FrameView), i, vp, vp, vp, vp, vp, vp, vp, i, vp]
     L.ft_fisheye_stereo.argtypes = [vp, C.POINTER(FisheyeRig), vp, vp, i, vp, vp, i, vp, i, vp, vp, vp, ip]
     L.ft_is_in_frustum.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FramePose), C.POINTER(MapPoints), f, f,
                                    C.POINTER(FrustumResult), ip]

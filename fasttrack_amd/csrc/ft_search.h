@@ -70,6 +70,9 @@ struct FtFrustumOut {
 };
 
 int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v);
+int ft_launch_features_in_area(hipStream_t st, const FtDevFrame &F, int nq, const float *qx, const float *qy, const float *qr,
+                               const int *qmin, const int *qmax, const uint8_t *qright, const int *offsets,
+                               unsigned *outKeys, int *outCount);
 int ft_launch_frustum(hipStream_t st, const FtDevFrame &F, const FtFrustumPose &T, const FtDevMapPoints &P,
                       float viewingCosLimit, float logScaleFactor, int farPoints, float thFar, const FtFrustumOut &O);
 int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,

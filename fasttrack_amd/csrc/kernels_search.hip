@@ -90,6 +90,40 @@ __device__ __forceinline__ bool in_area(const FtDevFrame &F, const ft_keypoint &
     return fabsf(dx) < r && fabsf(dy) < r;
 }
 
+// Frame::GetFeaturesInArea (src/Frame.cc:681-747) for a batch of queries: one wave per query, lanes stride over the
+// keypoints of the requested camera; hits are appended as (cell x, cell y, index) keys whose ascending order is the
+// order of the reference's nested cell loops (the host sorts the few hits of a query).
+__global__ __launch_bounds__(256) void k_features_in_area(FtDevFrame F, int nq, const float *qx, const float *qy, const float *qr,
+                                                          const int *qmin, const int *qmax, const uint8_t *qright,
+                                                          const int *offsets, unsigned *outKeys, int *outCount) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    const float x = qx[q], y = qy[q], r = qr[q];
+    const int minLevel = qmin[q], maxLevel = qmax[q];
+    const bool right = qright && qright[q];
+    const int n = F.Nleft == -1 ? F.N : (right ? F.N - F.Nleft : F.Nleft);
+    const ft_keypoint *keys = (F.Nleft != -1 && right) ? F.keysR : F.keys;
+    const Window w = cell_window(F, x, y, r);
+    int count = 0;
+    if (!w.empty) {
+        for (int base = 0; base < n; base += 64) {
+            const int idx = base + lane;
+            bool hit = false;
+            int cx = 0, cy = 0;
+            if (idx < n) hit = in_area(F, keys[idx], w, x, y, r, minLevel, maxLevel, cx, cy);
+            const unsigned long long b = __ballot(hit);
+            if (hit) {
+                // first pass (offsets == null) only counts; the second writes every hit at the query's offset
+                const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
+                if (offsets) outKeys[(size_t)offsets[q] + pos] = ((unsigned)cx << 26) | ((unsigned)cy << 20) | (unsigned)idx;
+            }
+            count += __popcll(b);
+        }
+    }
+    if (lane == 0 && !offsets) outCount[q] = count;
+}
+
 // two smallest keys of the wave (k0 < k1)
 __device__ __forceinline__ void wave_two_min(unsigned long long &k0, unsigned long long &k1) {
     const unsigned long long m0 = wave_min_u64(k0);
@@ -462,6 +496,16 @@ int ft_launch_frustum(hipStream_t st, const FtDevFrame &F, const FtFrustumPose &
     if (P.M <= 0) return FT_OK;
     hipLaunchKernelGGL(k_frustum, dim3((P.M + 255) / 256), dim3(256), 0, st, F, T, P, viewingCosLimit, logScaleFactor, farPoints,
                        thFar, O);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_features_in_area(hipStream_t st, const FtDevFrame &F, int nq, const float *qx, const float *qy, const float *qr,
+                               const int *qmin, const int *qmax, const uint8_t *qright, const int *offsets,
+                               unsigned *outKeys, int *outCount) {
+    if (nq <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_features_in_area, dim3((nq + 3) / 4), dim3(256), 0, st, F, nq, qx, qy, qr, qmin, qmax, qright, offsets,
+                       outKeys, outCount);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

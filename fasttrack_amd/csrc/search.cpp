@@ -546,6 +546,95 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     return FT_OK;
 }
 
+int ft_features_in_area(ft_context *ctx, const ft_frame_view *F, int nq, const float *x, const float *y, const float *r,
+                        const int *min_level, const int *max_level, const uint8_t *right, int *indices, int capacity,
+                        int *counts) {
+    FT_REQUIRE(ctx && counts && nq >= 0 && capacity >= 0, "ft_features_in_area: bad argument");
+    FT_REQUIRE(nq == 0 || (x && y && r && min_level && max_level), "ft_features_in_area: null query arrays");
+    FT_REQUIRE(capacity == 0 || indices, "ft_features_in_area: null index array");
+    FT_REQUIRE(nq < (1 << 22), "ft_features_in_area: too many queries");
+    int rc = checkFrame(F);
+    if (rc != FT_OK) return rc;
+    FT_REQUIRE(F->N < (1 << 20), "ft_features_in_area: frame too large for the hit keys");
+    if (nq == 0) return FT_OK;
+    rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    Arena a;
+    FrameLayout FL;
+    layoutFrame(F, a, FL);
+    const size_t Q = (size_t)nq;
+    const size_t oX = a.take(4 * Q), oY = a.take(4 * Q), oR = a.take(4 * Q), oMin = a.take(4 * Q), oMax = a.take(4 * Q),
+                 oRight = a.take(Q);
+    const size_t inputBytes = a.off;
+    const size_t oCount = a.take(4 * Q), oOff = a.take(4 * Q);
+    const size_t fixedBytes = a.off;
+    rc = ensureScratch(ctx, fixedBytes, fixedBytes);
+    if (rc != FT_OK) return rc;
+    uint8_t *pin = (uint8_t *)ctx->scratchPin, *dev = (uint8_t *)ctx->scratchDev;
+    stageFrame(F, FL, pin);
+    memcpy(pin + oX, x, 4 * Q);
+    memcpy(pin + oY, y, 4 * Q);
+    memcpy(pin + oR, r, 4 * Q);
+    memcpy(pin + oMin, min_level, 4 * Q);
+    memcpy(pin + oMax, max_level, 4 * Q);
+    if (right) memcpy(pin + oRight, right, Q);
+    hipStream_t st = ctx->stream;
+    FT_HIP(hipMemcpyAsync(dev, pin, inputBytes, hipMemcpyHostToDevice, st));
+    FtDevFrame DF = devFrame(F, FL, dev);
+    auto launch = [&](const int *offsets, unsigned *keys) {
+        return ft_launch_features_in_area(st, DF, nq, (const float *)(dev + oX), (const float *)(dev + oY),
+                                          (const float *)(dev + oR), (const int *)(dev + oMin), (const int *)(dev + oMax),
+                                          right ? dev + oRight : nullptr, offsets, keys, (int *)(dev + oCount));
+    };
+    // pass 1 counts the hits of every query, pass 2 writes them at the query's offset (no capacity inside)
+    rc = launch(nullptr, nullptr);
+    if (rc != FT_OK) return rc;
+    std::vector<int> hCount(nq), hOff(nq);
+    FT_HIP(hipMemcpyAsync(hCount.data(), dev + oCount, 4 * Q, hipMemcpyDeviceToHost, st));
+    FT_HIP(hipStreamSynchronize(st));
+    size_t totalHits = 0;
+    for (int q = 0; q < nq; q++) {
+        hOff[q] = (int)totalHits;
+        totalHits += (size_t)hCount[q];
+        counts[q] = hCount[q];
+    }
+    if (totalHits == 0) return FT_OK;
+    FT_REQUIRE(totalHits < (1u << 30), "ft_features_in_area: too many hits");
+    const size_t oKeys = a.take(4 * totalHits);
+    // growing the scratch buffer reallocates it: the frame and the queries are staged again in that case
+    const void *devBefore = ctx->scratchDev;
+    rc = ensureScratch(ctx, a.off, std::max(fixedBytes, 4 * totalHits));
+    if (rc != FT_OK) return rc;
+    pin = (uint8_t *)ctx->scratchPin;
+    dev = (uint8_t *)ctx->scratchDev;
+    if (ctx->scratchDev != devBefore) {
+        stageFrame(F, FL, pin);
+        memcpy(pin + oX, x, 4 * Q);
+        memcpy(pin + oY, y, 4 * Q);
+        memcpy(pin + oR, r, 4 * Q);
+        memcpy(pin + oMin, min_level, 4 * Q);
+        memcpy(pin + oMax, max_level, 4 * Q);
+        if (right) memcpy(pin + oRight, right, Q);
+        FT_HIP(hipMemcpyAsync(dev, pin, inputBytes, hipMemcpyHostToDevice, st));
+        FT_HIP(hipStreamSynchronize(st));
+        DF = devFrame(F, FL, dev);
+    }
+    FT_HIP(hipMemcpyAsync(dev + oOff, hOff.data(), 4 * Q, hipMemcpyHostToDevice, st));
+    rc = launch((const int *)(dev + oOff), (unsigned *)(dev + oKeys));
+    if (rc != FT_OK) return rc;
+    unsigned *hKeys = (unsigned *)pin;
+    FT_HIP(hipMemcpyAsync(hKeys, dev + oKeys, 4 * totalHits, hipMemcpyDeviceToHost, st));
+    FT_HIP(hipStreamSynchronize(st));
+    for (int q = 0; q < nq; q++) {
+        unsigned *k = hKeys + hOff[q];
+        std::sort(k, k + hCount[q]);  // (cell column, cell row, index): the order of the nested loops of Frame.cc:718-744
+        const int m = std::min(hCount[q], capacity);
+        for (int i = 0; i < m; i++) indices[(size_t)q * capacity + i] = (int)(k[i] & 0xfffffu);
+    }
+    return FT_OK;
+}
+
 int ft_is_in_frustum(ft_context *ctx, const ft_frame_view *F, const ft_frame_pose *pose, const ft_map_points *P,
                      float viewing_cos_limit, float log_scale_factor, const ft_frustum_result *out, int *n_to_match) {
     FT_REQUIRE(ctx && F && pose, "ft_is_in_frustum: null argument");

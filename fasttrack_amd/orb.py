@@ -569,3 +569,16 @@ def fisheye_stereo(ctx: Context, cam1, cam2, Rlr, tlr, descL, keysL, descR, keys
     check(lib().ft_fisheye_stereo(ctx._h, C.byref(rig), ptr(descL), ptr(keysL), nL, ptr(descR), ptr(keysR), nR, ptr(ls2),
                                   len(ls2), ptr(m), ptr(d), ptr(p), C.byref(n)))
     return dict(matches=m[:nL], depth=d[:nL], p3d=p[:nL], n=n.value)
+
+
+def features_in_area(ctx: Context, F: "FrameView", x, y, r, min_level, max_level, right=None, capacity=512):
+    """Frame::GetFeaturesInArea for arrays of queries (ft_features_in_area) -> list of index arrays"""
+    x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32); r = np.ascontiguousarray(r, np.float32)
+    lo = np.ascontiguousarray(min_level, np.int32); hi = np.ascontiguousarray(max_level, np.int32)
+    rt = None if right is None else np.ascontiguousarray(right, np.uint8)
+    nq = len(x)
+    idx = np.zeros((max(nq, 1), capacity), np.int32)
+    cnt = np.zeros(max(nq, 1), np.int32)
+    check(lib().ft_features_in_area(ctx._h, C.byref(F.c), nq, ptr(x), ptr(y), ptr(r), ptr(lo), ptr(hi), ptr(rt), ptr(idx),
+                                    capacity, ptr(cnt)))
+    return [idx[q, :min(cnt[q], capacity)].copy() for q in range(nq)], cnt[:nq]

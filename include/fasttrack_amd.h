@@ -234,6 +234,15 @@ typedef struct ft_frame_view {
     int nlevels;
 } ft_frame_view;
 
+/* Frame::GetFeaturesInArea (src/Frame.cc:681-747) for nq queries at once, with the 64x48 grid of
+ * Frame::AssignFeaturesToGrid / PosInGrid (:409-440, :749-759) evaluated on the device.  Query i = (x[i], y[i], r[i],
+ * min_level[i], max_level[i], right[i]) (right may be NULL: left camera).  indices receives, per query, the keypoint
+ * indices in the reference's order (cell column, cell row, then insertion order) at indices[i * capacity ...];
+ * counts[i] = number of hits; when it exceeds capacity the first `capacity` hits in that order are stored. */
+FT_API int ft_features_in_area(ft_context *ctx, const ft_frame_view *F, int nq, const float *x, const float *y,
+                               const float *r, const int *min_level, const int *max_level, const uint8_t *right,
+                               int *indices, int capacity, int *counts);
+
 /* SoA arrays of the local map points, exactly what SearchLocalPointsKernel::launch builds
  * (src/Kernels/SearchLocalPointsKernel.cu:369-390) plus Observations(). */
 typedef struct ft_local_points {

@@ -460,3 +460,35 @@ def test_full_size_batch_properties(ctx):
         o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
         k, d, u, z, m = res(fes[1], b + 2 * D)
         assert np.array_equal(k, kL) and np.array_equal(d, dL) and np.array_equal(u, o["uright"]) and np.array_equal(z, o["depth"])
+
+
+def test_features_in_area(ctx):
+    """Frame::GetFeaturesInArea with the grid evaluated on the device: same indices in the same order as the oracle's
+    64x48 grid walk, for both cameras of a two-camera frame, with and without level limits, at the image borders."""
+    w, h = 512, 512
+    fr = sc.fisheye_frame_scenario(w, h, 1500, 10)
+    sf, _ = ob.scale_factors(1.2, 8)
+    kw = dict(keys=fr["kL"], keys_right=fr["kR"], descriptors=np.concatenate([fr["dL"], fr["dR"]]),
+              bounds=sc.frame_bounds(w, h), left_to_right=fr["l2r"], right_to_left=fr["r2l"])
+    oF, gF = ob.FrameView(scale_factors_=sf, **kw), orb.FrameView(scale_factors=sf, **kw)
+    rng = np.random.default_rng(8)
+    nq = 400
+    x = rng.uniform(-30, w + 30, nq).astype(np.float32)
+    y = rng.uniform(-30, h + 30, nq).astype(np.float32)
+    r = rng.choice([1.0, 7.5, 15.0, 40.0, 120.0], nq).astype(np.float32)
+    lo = rng.integers(-1, 5, nq).astype(np.int32)
+    hi = np.where(rng.random(nq) < 0.3, -1, lo + rng.integers(0, 4, nq)).astype(np.int32)
+    right = (rng.random(nq) < 0.4).astype(np.uint8)
+    got, cnt = orb.features_in_area(ctx, gF, x, y, r, lo, hi, right, capacity=2048)
+    total = 0
+    for q in range(nq):
+        o = ob.features_in_area(oF, float(x[q]), float(y[q]), float(r[q]), int(lo[q]), int(hi[q]), bool(right[q]))
+        assert cnt[q] == len(o) and np.array_equal(got[q], o), q
+        total += len(o)
+    assert total > 5000
+    # rectified frame (Nleft == -1) and a capacity smaller than the hit count
+    fr2 = sc.oracle_stereo_frame(752, 480, 1200, 12)
+    oF2, gF2 = _frame_views(fr2, sf, 752, 480)
+    got, cnt = orb.features_in_area(ctx, gF2, [376.0], [240.0], [200.0], [-1], [-1], None, capacity=16)
+    o = ob.features_in_area(oF2, 376.0, 240.0, 200.0, -1, -1, False)
+    assert cnt[0] == len(o) > 16 and np.array_equal(got[0], o[:16])
