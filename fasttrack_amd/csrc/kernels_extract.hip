@@ -84,6 +84,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // loads, then every lane produces a 4 x 4 block of outputs from 2x2 taps read from LDS and stores four dwords.
 #define PD_TW 64
 #define PD_TH 16
+#define PD_NLOAD 9  // footprint dwords per lane in flight at once
 // A wave's life is a chain of memory round trips, so the chain is kept short: the source footprint of the tile is
 // bounded arithmetically (fixed-point scale with a two-pixel margin instead of reading the first and last tap),
 // and the taps the outputs need - four in x and four in y per lane - are requested together with the footprint,
@@ -129,9 +130,21 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
         const int nd = (sxb - sxa + 1 + ax + 3) >> 2;  // dwords per row; over-read stays inside the aligned row pitch
         const uint8_t *src = S + (size_t)sya * spitch + (sxa - ax);
         const unsigned ndMagic = div_magic_of((unsigned)nd);
-        for (int i = lane; i < nd * rows; i += 64) {
-            const int y = div_by(i, ndMagic), x = i - y * nd;
-            *(unsigned *)(smem + y * ldsPitch + 4 * x) = *(const unsigned *)(src + (size_t)y * spitch + 4 * x);
+        // all loads of the footprint are issued before the first LDS store (PD_NLOAD x 64 dwords cover the usual
+        // footprint; a larger one takes further rounds)
+        for (int i0 = 0; i0 < nd * rows; i0 += 64 * PD_NLOAD) {
+            unsigned v[PD_NLOAD];
+            int off[PD_NLOAD];
+#pragma unroll
+            for (int k = 0; k < PD_NLOAD; k++) {
+                const int i = i0 + 64 * k + lane;
+                const int y = div_by(min(i, nd * rows - 1), ndMagic), x = min(i, nd * rows - 1) - y * nd;
+                off[k] = i < nd * rows ? y * ldsPitch + 4 * x : -1;
+                v[k] = *(const unsigned *)(src + (size_t)y * spitch + 4 * x);
+            }
+#pragma unroll
+            for (int k = 0; k < PD_NLOAD; k++)
+                if (off[k] >= 0) *(unsigned *)(smem + off[k]) = v[k];
         }
     } else {
         const int cw = sxb - sxa + 1;
@@ -310,9 +323,20 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         const int nd = (tw + ax + 3) >> 2;
         const unsigned ndMagic = div_magic_of((unsigned)nd);
         const uint8_t *src = img + (size_t)iniY * pitch + (iniX - ax);
-        for (int i = lane; i < nd * th; i += 64) {
-            const int y = div_by(i, ndMagic), x = i - y * nd;
-            *(unsigned *)(tile + y * tp + 4 * x) = *(const unsigned *)(src + (size_t)y * pitch + 4 * x);
+        // every load of the tile is issued before the first LDS store (9 x 64 dwords cover a 48-pitch tile)
+        for (int i0 = 0; i0 < nd * th; i0 += 64 * 9) {
+            unsigned v[9];
+            int off[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int i = i0 + 64 * k + lane, ic = min(i, nd * th - 1);
+                const int y = div_by(ic, ndMagic), x = ic - y * nd;
+                off[k] = i < nd * th ? y * tp + 4 * x : -1;
+                v[k] = *(const unsigned *)(src + (size_t)y * pitch + 4 * x);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++)
+                if (off[k] >= 0) *(unsigned *)(tile + off[k]) = v[k];
         }
     } else {
         const unsigned twMagic = div_magic_of((unsigned)tw);
