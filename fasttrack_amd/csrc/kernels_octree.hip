@@ -74,6 +74,92 @@ __host__ __device__ inline OctLds oct_lds_layout(int cap) {
 
 // std::sort(a, a + n, compareNodes) of libstdc++ with one wave: the steps of octree_paths.h
 // std_sort_replay_steps (checked against libstdc++ on the CPU), each of them lane-parallel.
+// The introsort partitions of a range of at most 64 elements with the elements held in registers (lane i = element
+// f + i): median-of-three and the pivot come from v_readlane, the candidate sets of the closed-form partition are two
+// ballots, the k-th candidate from the left meets the k-th from the right through two 64-entry tables in LDS, and the
+// swaps are one ds_bpermute per dword; the range stack lives in the lanes of one register.  Only the final state goes
+// back to LDS.  Same steps as ss_partition_pairs (octree_paths.h), i.e. the same array as libstdc++'s loop.
+__device__ void wave_sort_window(SortElem *a, int f, int l, int depth0, uint8_t *tabA, uint8_t *tabB, int lane) {
+    const int len = l - f;
+    unsigned key = 0xffffffffu, val = 0;
+    if (lane < len) {
+        const SortElem e = a[f + lane];
+        key = e.key;
+        val = e.val;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull, above = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    unsigned frames = 0;  // lane s holds frame s: lo | hi << 8 | depth << 16
+    int sp = 0;
+    if (lane == 0) frames = (unsigned)(0 | (len << 8) | (depth0 << 16));
+    sp = 1;
+    while (sp > 0) {
+        const unsigned fr = __builtin_amdgcn_readlane(frames, --sp);
+        int lo = (int)(fr & 0xffu), hi = (int)((fr >> 8) & 0xffu), depth = (int)(fr >> 16);
+        while (hi - lo > 16) {
+            if (depth == 0) {  // heap sort at the depth limit: literal replay on one lane through LDS
+                if (lane < len) a[f + lane] = SortElem{key, val};
+                wave_lds_sync();
+                if (lane == 0) ft::op::ss_heap_sort(a + f + lo, a + f + hi);
+                wave_lds_sync();
+                if (lane < len) {
+                    const SortElem e = a[f + lane];
+                    key = e.key;
+                    val = e.val;
+                }
+                break;
+            }
+            --depth;
+            // __move_median_to_first(first, first + 1, mid, last - 1)
+            const int ia = lo + 1, ib = lo + (hi - lo) / 2, ic = hi - 1;
+            const unsigned ka = __builtin_amdgcn_readlane(key, ia), kb = __builtin_amdgcn_readlane(key, ib),
+                           kc = __builtin_amdgcn_readlane(key, ic);
+            int pick;
+            if (ka < kb) pick = (kb < kc) ? ib : (ka < kc) ? ic : ia;
+            else pick = (ka < kc) ? ia : (kb < kc) ? ic : ib;
+            const unsigned pv = (pick == ia) ? ka : (pick == ib) ? kb : kc;
+            {  // swap(first, pick)
+                const unsigned k0 = __builtin_amdgcn_readlane(key, lo), v0 = __builtin_amdgcn_readlane(val, lo);
+                const unsigned k1 = pv, v1 = __builtin_amdgcn_readlane(val, pick);
+                if (lane == lo) { key = k1; val = v1; }
+                if (lane == pick) { key = k0; val = v0; }
+            }
+            // __unguarded_partition(first + 1, last, first) in closed form
+            const bool in = lane > lo && lane < hi;
+            const bool isA = in && !(key < pv), isB = in && !(pv < key);
+            const unsigned long long mA = __ballot(isA), mB = __ballot(isB);
+            const int nA = __popcll(mA), nB = __popcll(mB);
+            const int ra = __popcll(mA & below), rb = __popcll(mB & above);
+            if (isA) tabA[ra] = (uint8_t)lane;  // k-th candidate from the left
+            if (isB) tabB[rb] = (uint8_t)lane;  // k-th candidate from the right
+            wave_lds_sync();
+            int partner = lane;
+            bool swA = false;
+            if (isA && ra < nB) {
+                const int pb = tabB[ra];
+                if (lane < pb) { partner = pb; swA = true; }
+            }
+            if (!swA && isB && rb < nA) {
+                const int pa = tabA[rb];
+                if (pa < lane) partner = pa;
+            }
+            const int K = __popcll(__ballot(swA));
+            const int bK = K ? (int)tabB[K - 1] : hi;
+            const int aK = K < nA ? (int)tabA[K] : 0x7fffffff;
+            const int cut = aK < bK ? aK : bK;
+            key = (unsigned)__shfl((int)key, partner);
+            val = (unsigned)__shfl((int)val, partner);
+            wave_lds_sync();  // the tables are read before the next partition rewrites them
+            if (sp < 64) {
+                if (lane == sp) frames = (unsigned)(cut | (hi << 8) | (depth << 16));
+                sp++;
+            }
+            hi = cut;
+        }
+    }
+    if (lane < len) a[f + lane] = SortElem{key, val};
+    wave_lds_sync();
+}
+
 __device__ void wave_std_sort(SortElem *a, int n, SortFrame *stack, uint16_t *posA, uint16_t *posB, SortElem *tmp, int lane) {
     if (n <= 1) return;
     int lg = 0;
@@ -88,6 +174,10 @@ __device__ void wave_std_sort(SortElem *a, int n, SortFrame *stack, uint16_t *po
         int f = fr.f, l = fr.l, depth = fr.depth;
         wave_lds_sync();  // the frame is read before a later push overwrites the slot
         while (l - f > 16) {
+            if (l - f <= 64) {  // the rest of this range's partitions run in registers
+                wave_sort_window(a, f, l, depth, (uint8_t *)posA, (uint8_t *)posB, lane);
+                break;
+            }
             if (depth == 0) {
                 if (lane == 0) ft::op::ss_heap_sort(a + f, a + l);
                 wave_lds_sync();
@@ -156,9 +246,19 @@ __device__ void wave_std_sort(SortElem *a, int n, SortFrame *stack, uint16_t *po
     // __final_insertion_sort as a windowed stable rank
     for (int i = lane; i < n; i += 64) {
         const SortElem e = a[i];
+        // the 32 neighbouring keys are requested together (clamped indices; out-of-range neighbours do not count)
+        uint32_t kl[16], kr[16];
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            kl[d] = a[max(i - 1 - d, 0)].key;
+            kr[d] = a[min(i + 1 + d, n - 1)].key;
+        }
         int pos = i;
-        for (int j = max(i - 16, 0); j < i; j++) pos -= a[j].key > e.key;
-        for (int j = i + 1; j <= min(i + 16, n - 1); j++) pos += a[j].key < e.key;
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            pos -= (i - 1 - d >= 0) && kl[d] > e.key;
+            pos += (i + 1 + d <= n - 1) && kr[d] < e.key;
+        }
         tmp[pos] = e;
     }
     wave_lds_sync();
