@@ -203,40 +203,40 @@ def main():
                      "stereo.host_tail_sync", "stereo.submit.total", "stereo.device_octree_fallbacks"):
             m, n = ctx.get_stat(name)
             host[name] = (m / n) if n else None
-        # the batch is processed in sub-batches (software pipeline), so bytes per launch = algorithmic
-        # bytes of the whole timed region / number of launches in it
-        total_bytes = float(args.steps) * 2.0 * B * sumP
-        roof = None
-        traffic = None
-        try:  # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]["k_fast_cells"]
-            imgs = args.steps * 2.0 * B / launches if launches else 0
-            if args.workload == "stereo_1280x720_nf2000" and abs(imgs - tj["images_per_launch"]) < 0.5:
-                traffic = tj["traffic_bytes_per_launch"]
+        # Roofline leg.  Algorithmic bytes per kernel: FAST + NMS reads every pyramid pixel once (sum P_l per
+        # image); the 7 pyramid launches of a sub-batch read P - P7 and write P - P0 per image; orientation + descriptor
+        # read a 43x43 patch and write 60 B per keypoint.  The batch is processed in sub-batches, so bytes per launch =
+        # algorithmic bytes of the whole timed region / launches in it; durations are HIP events on the launching stream.
+        # `roofline` is the kernel with the largest summed duration in this run, the others follow in
+        # roofline_other_kernels.  HBM-side traffic per launch comes from the committed PMC passes (FETCH_SIZE /
+        # WRITE_SIZE cannot be read live) and is reported when this run's launch shape equals the profiled one.
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
         except Exception:
+            tj = {}
+
+        def leg(stat, kernel, total_bytes, per_group=1):
+            m, n = ctx.get_stat(stat)
+            if not n:
+                return None
+            achieved = total_bytes / (m / 1e3) / 1e9
             traffic = None
-        if launches:
-            achieved = total_bytes / (ms / 1e3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            t = tj.get(kernel)
+            imgs = args.steps * 2.0 * B / n
+            if t and args.workload == "stereo_1280x720_nf2000" and abs(imgs - t["images_per_launch"] * per_group) < 0.5:
+                traffic = t["traffic_bytes_per_launch"] * per_group
+            return {"bound": "hbm", "kernel": kernel + (" (%d launches per sub-batch, timed as a group)" % per_group if per_group > 1 else ""),
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic,
                     "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                       "calibrated by tools/hbm_calib.sh)" if traffic else None,
-                    "bytes_per_launch": total_bytes / launches,
-                    "avg_launch_ms": ms / launches, "launches_timed": launches}
-        # the other two large kernels, same accounting: the 7 pyramid launches of a sub-batch read
-        # P - P7 and write P - P0 per image; orientation + descriptor read 1849 B and write 60 B per keypoint
-        also = []
-        m, n = ctx.get_stat("kernel.pyr_down(all levels)")
-        if n:
-            b_ = float(args.steps) * 2.0 * B * ((sumP - P[-1]) + (sumP - P[0]))
-            also.append({"kernel": "k_pyr_down (7 launches per sub-batch, timed as a group)", "bound": "hbm",
-                         "achieved": b_ / (m / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": b_ / (m / 1e3) / 1e9 / HBM_PEAK_GBS, "avg_group_ms": m / n})
-        m, n = ctx.get_stat("kernel.orient_desc")
-        if n:
-            b_ = float(kps) * args.steps * (43 * 43 + 60)
-            also.append({"kernel": "k_orient_desc", "bound": "hbm", "achieved": b_ / (m / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": b_ / (m / 1e3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": m / n})
+                    "bytes_per_launch": total_bytes / n, "avg_launch_ms": m / n, "launches_timed": n, "total_ms": m}
+        legs = [leg("kernel.fast_cells", "k_fast_cells", float(args.steps) * 2.0 * B * sumP),
+                leg("kernel.pyr_down(all levels)", "k_pyr_down", float(args.steps) * 2.0 * B * ((sumP - P[-1]) + (sumP - P[0])), 7),
+                leg("kernel.orient_desc", "k_orient_desc", float(kps) * args.steps * (43 * 43 + 60))]
+        legs = sorted([x for x in legs if x], key=lambda x: -x["total_ms"])
+        roof = legs[0] if legs else None
+        also = legs[1:]
         R_pair = 2 * (3 * sumP - P[-1])  # read bytes per stereo pair, unfused accounting
         out = {
             "metric": "frames/sec extract+match", "value": fps, "unit": "frames/s", "n_gpus": world,
