@@ -241,3 +241,30 @@ def test_two_host_threads_two_extractors(ctx):
                 assert np.array_equal(rk, gk) and np.array_equal(rd, gd) and rm == gm
         del exR
     ctx2.close()
+
+
+def test_random_configurations_bit_exact(ctx):
+    """seeded sweep over image sizes, feature counts, pyramid depths, scale factors and FAST thresholds (cells of every
+    width class: fixed-pitch 48 / 64 and the any-size fallback; levels with a single cell row; quotas above and below the
+    candidate count): keypoints and descriptors equal the oracle's"""
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for trial in range(24):
+        w = int(rng.integers(70, 1000))
+        h = int(rng.integers(70, 760))
+        nf = int(rng.choice([150, 500, 1000, 2500, 4000]))
+        nlevels = int(rng.integers(2, 11))
+        sfac = float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0]))
+        ini, mn = (20, 7) if trial % 3 else (int(rng.integers(12, 40)), int(rng.integers(3, 12)))
+        if min(w, h) / (sfac ** (nlevels - 1)) < 40:  # the last level must still hold a 35-px cell inside its borders
+            nlevels = max(2, int(np.log(min(w, h) / 40.0) / np.log(sfac)) + 1)
+        img = synth.make_image(w, h, seed=300 + trial, density=float(rng.choice([0.3, 1.0, 2.5])))
+        ex = orb.ORBextractor(ctx, nf, sfac, nlevels, ini, mn, w, h)
+        oex = ob.Extractor(nf, sfac, nlevels, ini, mn)
+        gk, gd, gm = ex(img)
+        ok, od, om = oex.extract(img)
+        _check_same(gk, gd, ok, od)
+        assert gm == om
+        checked += len(ok)
+        del ex
+    assert checked > 5000
