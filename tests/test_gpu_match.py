@@ -492,3 +492,27 @@ def test_features_in_area(ctx):
     got, cnt = orb.features_in_area(ctx, gF2, [376.0], [240.0], [200.0], [-1], [-1], None, capacity=16)
     o = ob.features_in_area(oF2, 376.0, 240.0, 200.0, -1, -1, False)
     assert cnt[0] == len(o) > 16 and np.array_equal(got[0], o[:16])
+
+
+def test_stereo_frontend_random_configurations(ctx):
+    """seeded sweep of the fused front end over image sizes, feature counts, batch sizes and baselines: keypoints,
+    descriptors, mvuRight, mvDepth and the match count equal extract(L), extract(R), ComputeStereoMatches of the oracle"""
+    rng = np.random.default_rng(77)
+    for trial in range(8):
+        w, h = int(rng.integers(200, 900)), int(rng.integers(160, 620))
+        nf = int(rng.choice([300, 1000, 2000]))
+        B = int(rng.integers(1, 4))
+        intr = synth.intrinsics(w, h)
+        mbf = float(intr["mbf"] * rng.choice([0.5, 1.0, 2.0]))
+        fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, mbf, intr["mb"])
+        pairs = [synth.make_stereo_pair(w, h, 500 + 10 * trial + b) for b in range(B)]
+        outs = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
+        for (imL, imR), out in zip(pairs, outs):
+            oL, oR = ob.Extractor(nf), ob.Extractor(nf)
+            kL, dL, _ = oL.extract(imL)
+            kR, dR, _ = oR.extract(imR)
+            o = ob.stereo_match(oL, oR, kL, kR, dL, dR, mbf, intr["mb"])
+            assert np.array_equal(out["keysL"], kL) and np.array_equal(out["keysR"], kR), (trial, w, h)
+            assert np.array_equal(out["descL"], dL) and np.array_equal(out["descR"], dR)
+            assert out["n"] == o["n"] and np.array_equal(out["uright"], o["uright"]) and np.array_equal(out["depth"], o["depth"])
+        fe.close()
