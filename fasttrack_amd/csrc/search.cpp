@@ -152,6 +152,77 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, int *resA,
     return FT_OK;
 }
 
+// Replays the writes of SearchByProjection(Frame, points) in map point order (ORBmatcher.cc:134-148 left,
+// :203-214 right): res holds per point the keypoints written as (primary left, side left, primary right, side right).
+int replayLocalWrites(const int *res, int M, const int *observations, int *holder, int *assign) {
+    int nm = 0;
+    for (int i = 0; i < M; i++) {
+        const int obs = observations[i];
+        const int order[4] = {res[4 * i], res[4 * i + 1], res[4 * i + 3], res[4 * i + 2]};  // primL sideL sideR primR
+        for (int k = 0; k < 4; k++) {
+            const int kp = order[k];
+            if (kp < 0) continue;
+            holder[kp] = obs;
+            assign[kp] = i;
+            nm++;
+        }
+    }
+    return nm;
+}
+
+// Replays the writes of SearchByProjection(CurrentFrame, LastFrame) in last-frame order with the rotation histogram
+// of ORBmatcher.cc:1880-1896, 1942-1957, 1966-1987 and ComputeThreeMaxima (:2210-2251).  curAngle(i) = angle of
+// keypoint i of the current frame (left keypoints, then right).
+template <typename AngleFn>
+int replayLastFrameWrites(const int *res, int M, const ft_last_points *L, AngleFn curAngle, bool checkOrientation, int *holder,
+                          int *assign) {
+    int nm = 0;
+    std::vector<int> rotHist[FT_HISTO_LENGTH];
+    const float factor = 1.0f / FT_HISTO_LENGTH;
+    for (int i = 0; i < M; i++) {
+        const int w2[2] = {res[4 * i], res[4 * i + 2]};
+        for (int k = 0; k < 2; k++) {
+            const int kp = w2[k];
+            if (kp < 0) continue;
+            holder[kp] = L->observations[i];
+            assign[kp] = i;
+            nm++;
+            if (checkOrientation) {
+                float rot = L->angle[i] - curAngle(kp);
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == FT_HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < FT_HISTO_LENGTH) rotHist[bin].push_back(kp);  // the reference asserts
+            }
+        }
+    }
+    if (checkOrientation) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < FT_HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) {
+                max3 = max2; max2 = max1; max1 = sz;
+                ind3 = ind2; ind2 = ind1; ind1 = i;
+            } else if (sz > max2) {
+                max3 = max2; max2 = sz;
+                ind3 = ind2; ind2 = i;
+            } else if (sz > max3) {
+                max3 = sz; ind3 = i;
+            }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < FT_HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int kp : rotHist[i]) {
+                    assign[kp] = -1;
+                    holder[kp] = -1;
+                    nm--;
+                }
+    }
+    return nm;
+}
+
 // frame constants of a view (no arrays)
 FtDevFrame devFrameConstants(const ft_frame_view *F) {
     FtDevFrame D;
@@ -395,19 +466,7 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     FT_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < 10; k++)
         if (outs[k]) memcpy(outs[k], hRaw + (size_t)k * M, 4 * (size_t)M);
-    // replay the writes in map point order (ORBmatcher.cc:134-148 left, :203-214 right)
-    int nm = 0;
-    for (int i = 0; i < M; i++) {
-        const int obs = P->observations[i];
-        const int order[4] = {hRes[4 * i], hRes[4 * i + 1], hRes[4 * i + 3], hRes[4 * i + 2]};  // primL sideL sideR primR
-        for (int k = 0; k < 4; k++) {
-            const int kp = order[k];
-            if (kp < 0) continue;
-            F->holder_obs[kp] = obs;
-            assign[kp] = i;
-            nm++;
-        }
-    }
+    const int nm = replayLocalWrites(hRes, M, P->observations, F->holder_obs, assign);
     if (n_matches) *n_matches = nm;
     ctx->addStat("search_local_points.total", tAll.ms());
     ctx->addStat("search_local_points.passes", passes);
@@ -489,57 +548,12 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     FT_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < 4; k++)
         if (outs[k]) memcpy(outs[k], hRaw + (size_t)k * M, 4 * (size_t)M);
-    // replay in last-frame order; rotation histogram as in ORBmatcher.cc:1880-1896, 1942-1957, 1966-1987
-    int nm = 0;
-    std::vector<int> rotHist[FT_HISTO_LENGTH];
-    const float factor = 1.0f / FT_HISTO_LENGTH;
     auto curAngle = [&](int idx) -> float {
         return (Cur->Nleft == -1) ? Cur->keys[idx].angle
                : (idx < Cur->Nleft) ? Cur->keys[idx].angle
                                     : Cur->keys_right[idx - Cur->Nleft].angle;
     };
-    for (int i = 0; i < M; i++) {
-        const int w2[2] = {hRes[4 * i], hRes[4 * i + 2]};
-        for (int k = 0; k < 2; k++) {
-            const int kp = w2[k];
-            if (kp < 0) continue;
-            Cur->holder_obs[kp] = L->observations[i];
-            assign[kp] = i;
-            nm++;
-            if (check_orientation) {
-                float rot = L->angle[i] - curAngle(kp);
-                if (rot < 0.0) rot += 360.0f;
-                int bin = (int)std::round(rot * factor);
-                if (bin == FT_HISTO_LENGTH) bin = 0;
-                if (bin >= 0 && bin < FT_HISTO_LENGTH) rotHist[bin].push_back(kp);  // the reference asserts
-            }
-        }
-    }
-    if (check_orientation) {
-        // ComputeThreeMaxima, ORBmatcher.cc:2210-2251
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < FT_HISTO_LENGTH; i++) {
-            const int s = (int)rotHist[i].size();
-            if (s > max1) {
-                max3 = max2; max2 = max1; max1 = s;
-                ind3 = ind2; ind2 = ind1; ind1 = i;
-            } else if (s > max2) {
-                max3 = max2; max2 = s;
-                ind3 = ind2; ind2 = i;
-            } else if (s > max3) {
-                max3 = s; ind3 = i;
-            }
-        }
-        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
-        for (int i = 0; i < FT_HISTO_LENGTH; i++)
-            if (i != ind1 && i != ind2 && i != ind3)
-                for (int kp : rotHist[i]) {
-                    assign[kp] = -1;
-                    Cur->holder_obs[kp] = -1;
-                    nm--;
-                }
-    }
+    const int nm = replayLastFrameWrites(hRes, M, L, curAngle, check_orientation != 0, Cur->holder_obs, assign);
     if (n_matches) *n_matches = nm;
     ctx->addStat("search_last_frame.total", tAll.ms());
     ctx->addStat("search_last_frame.passes", passes);
@@ -837,50 +851,8 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     int *hRes = (int *)pin;
     FT_HIP(hipMemcpyAsync(hRes, resFinal, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
     FT_HIP(hipStreamSynchronize(st));
-    int nm = 0;
-    std::vector<int> rotHist[FT_HISTO_LENGTH];
-    const float factor = 1.0f / FT_HISTO_LENGTH;
-    for (int i = 0; i < M; i++) {
-        const int w2[2] = {hRes[4 * i], hRes[4 * i + 2]};
-        for (int k = 0; k < 2; k++) {
-            const int kp = w2[k];
-            if (kp < 0) continue;
-            tf->holder[kp] = L->observations[i];
-            assign[kp] = i;
-            nm++;
-            if (check_orientation) {
-                float rot = L->angle[i] - tf->angles[kp];
-                if (rot < 0.0) rot += 360.0f;
-                int bin = (int)std::round(rot * factor);
-                if (bin == FT_HISTO_LENGTH) bin = 0;
-                if (bin >= 0 && bin < FT_HISTO_LENGTH) rotHist[bin].push_back(kp);
-            }
-        }
-    }
-    if (check_orientation) {
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < FT_HISTO_LENGTH; i++) {
-            const int sz = (int)rotHist[i].size();
-            if (sz > max1) {
-                max3 = max2; max2 = max1; max1 = sz;
-                ind3 = ind2; ind2 = ind1; ind1 = i;
-            } else if (sz > max2) {
-                max3 = max2; max2 = sz;
-                ind3 = ind2; ind2 = i;
-            } else if (sz > max3) {
-                max3 = sz; ind3 = i;
-            }
-        }
-        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
-        for (int i = 0; i < FT_HISTO_LENGTH; i++)
-            if (i != ind1 && i != ind2 && i != ind3)
-                for (int kp : rotHist[i]) {
-                    assign[kp] = -1;
-                    tf->holder[kp] = -1;
-                    nm--;
-                }
-    }
+    const int nm = replayLastFrameWrites(hRes, M, L, [&](int idx) { return tf->angles[idx]; }, check_orientation != 0,
+                                         tf->holder.data(), assign);
     // the occupancy the next search sees
     memcpy(pin, tf->holder.data(), sizeof(int) * N);
     FT_HIP(hipMemcpyAsync(tf->d_holder, pin, sizeof(int) * N, hipMemcpyHostToDevice, st));
@@ -956,17 +928,7 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
         FT_HIP(hipMemcpyAsync(hRes, resFinal, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
         rc = downloadFrustum(st, M, FL, fInputEnd, fOutEnd, dev, pin, frustum, n_to_match);
         if (rc != FT_OK) return rc;
-        for (int i = 0; i < M; i++) {
-            const int obs = P->observations[i];
-            const int order[4] = {hRes[4 * i], hRes[4 * i + 1], hRes[4 * i + 3], hRes[4 * i + 2]};  // primL sideL sideR primR
-            for (int k = 0; k < 4; k++) {
-                const int kp = order[k];
-                if (kp < 0) continue;
-                tf->holder[kp] = obs;
-                assign[kp] = i;
-                nm++;
-            }
-        }
+        nm = replayLocalWrites(hRes, M, P->observations, tf->holder.data(), assign);
         memcpy(pin, tf->holder.data(), sizeof(int) * N);
         FT_HIP(hipMemcpyAsync(tf->d_holder, pin, sizeof(int) * N, hipMemcpyHostToDevice, st));
         FT_HIP(hipStreamSynchronize(st));
