@@ -576,11 +576,8 @@ size_t ft_octree_smem_bytes(int poolCap) { return (size_t)oct_lds_layout(poolCap
 
 int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a) {
     const size_t smem = ft_octree_smem_bytes(a.poolCap);
-    static bool attrSet = false;
-    if (!attrSet && smem > 64 * 1024) {
+    if (smem > 64 * 1024)  // large quotas: raise the dynamic LDS limit (per device, so not cached in a static)
         FT_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attrSet = true;
-    }
     for (int rep = ft_debug_repeat("octree"); rep > 0; rep--)
     hipLaunchKernelGGL(k_octree, dim3(g.nlevels, batch), dim3(OCT_THREADS), smem, st, g, a);
     FT_HIP(hipGetLastError());
