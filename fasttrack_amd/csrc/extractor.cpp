@@ -168,6 +168,8 @@ void freeAll(ft_extractor *ex) {
         if (ex->evB[i]) hipEventDestroy(ex->evB[i]);
         if (ex->evO[i]) hipEventDestroy(ex->evO[i]);
     }
+    if (ex->evJoin) hipEventDestroy(ex->evJoin);
+    if (ex->graphExec) hipGraphExecDestroy(ex->graphExec);
     for (int i = 0; i < FT_OCT_STREAMS; i++)
         if (ex->streamO[i]) {
             hipStreamSynchronize(ex->streamO[i]);
@@ -488,6 +490,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         se = hipEventCreateWithFlags(&ex->evA[i], hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&ex->evB[i], hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&ex->evO[i], hipEventDisableTiming);
+        if (se == hipSuccess && i == 0) se = hipEventCreateWithFlags(&ex->evJoin, hipEventDisableTiming);
     }
     if (se != hipSuccess) {
         freeAll(ex);
@@ -691,11 +694,106 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
         return FT_ERR_EMPTY;
     }
     FtTimer tAll;
-    int rc = ft_extract_prepare(ex, images, batch, on_device, width, height, stride);
+    int rc = ft_set_device(ex->ctx);
     if (rc != FT_OK) return rc;
     const int S = ft_pipeline_depth(batch, ex->deviceOctree);
     const int sb = (batch + S - 1) / S;
-    for (int pass = 0; pass < 2; pass++) {
+    // everything a batch needs with the device octree, enqueued without a host synchronisation (capture != 0: ex->stream is
+    // being captured into a graph; the octree / stage-B streams fork from it through events and are joined back)
+    auto enqueueDevice = [&](int capture) -> int {
+        int r = ft_extract_prepare(ex, images, batch, on_device, width, height, stride);
+        if (r != FT_OK) return r;
+        for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
+            const int nb = std::min(sb, batch - b0);
+            r = ft_extract_launch_a(ex, b0, nb, nullptr);
+            if (r == FT_OK) r = ft_extract_launch_octree(ex, s, b0, nb, ex->evA[s]);
+            if (r != FT_OK) return r;
+        }
+        for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
+            const int nb = std::min(sb, batch - b0);
+            FT_HIP(hipStreamWaitEvent(ex->streamB, ex->evA[s], 0));
+            r = ft_extract_launch_b(ex, b0, nb, ex->streamB);
+            if (r == FT_OK) r = ft_extract_download(ex, b0, nb, ex->streamB);
+            if (r != FT_OK) return r;
+        }
+        r = ft_extract_finish_counts(ex, batch, ex->streamB);
+        if (r != FT_OK) return r;
+        if (capture) {
+            FT_HIP(hipEventRecord(ex->evJoin, ex->streamB));
+            FT_HIP(hipStreamWaitEvent(ex->stream, ex->evJoin, 0));
+        }
+        return FT_OK;
+    };
+    bool done = false;
+    const bool devWanted = ex->deviceOctree;
+    static const bool graphsOn = !(getenv("FT_GRAPH") && getenv("FT_GRAPH")[0] == '0');
+    if (graphsOn && !ex->graphDisabled && ex->deviceOctree && !ex->ctx->kernelTiming && batch >= 1 && batch <= 8 &&
+        batch <= ex->maxBatch && width == ex->width && height == ex->height && stride >= width) {
+        bool ok = true;
+        for (int b = 0; b < batch; b++)
+            if (!images[b]) ok = false;
+        if (ok) {
+            ft_extractor::GraphKey key;
+            key.batch = batch; key.onDevice = on_device; key.width = width; key.height = height; key.stride = stride;
+            key.aligned = 1;
+            if (on_device) {
+                if (stride & 3) key.aligned = 0;
+                for (int b = 0; b < batch; b++)
+                    if ((uintptr_t)images[b] & 3) key.aligned = 0;
+            } else {
+                key.hostImages.assign(images, images + batch);
+            }
+            bool launched = false;
+            if (ex->graphExec && key == ex->graphKey) {
+                if (on_device)
+                    for (int b = 0; b < batch; b++) ex->h_l0[b] = images[b];
+                ex->lastBatch = batch;
+                FT_HIP(hipGraphLaunch(ex->graphExec, ex->stream));
+                launched = true;
+            } else {
+                if (ex->graphExec) {
+                    hipGraphExecDestroy(ex->graphExec);
+                    ex->graphExec = nullptr;
+                }
+                hipGraph_t graph = nullptr;
+                hipError_t ce = hipStreamBeginCapture(ex->stream, hipStreamCaptureModeThreadLocal);
+                if (ce == hipSuccess) {
+                    rc = enqueueDevice(1);
+                    ce = hipStreamEndCapture(ex->stream, &graph);
+                    if (rc == FT_OK && ce == hipSuccess && graph) ce = hipGraphInstantiate(&ex->graphExec, graph, nullptr, nullptr, 0);
+                    if (graph) hipGraphDestroy(graph);
+                }
+                if (rc != FT_OK || ce != hipSuccess || !ex->graphExec) {
+                    (void)hipGetLastError();  // capture is an optimisation: plain enqueueing from now on
+                    ex->graphDisabled = true;
+                    ex->graphExec = nullptr;
+                    ex->ctx->addStat("extract.graph_capture_failed", 0);
+                    rc = FT_OK;
+                } else {
+                    ex->graphKey = key;
+                    ex->ctx->addStat("extract.graph_captures", 0);
+                    FT_HIP(hipGraphLaunch(ex->graphExec, ex->stream));
+                    launched = true;
+                }
+            }
+            if (launched) {
+                ex->ctx->addStat("extract.device_octree_batches", 0);
+                FT_HIP(hipStreamSynchronize(ex->stream));
+                done = !ex->h_overflow[0];  // an overflow is redone below with the host octree
+                if (!done) {  // redo with the host octree below
+                    ex->h_overflow[0] = 0;
+                    FT_HIP(hipMemsetAsync(ex->d_overflow, 0, sizeof(int), ex->stream));
+                    ex->ctx->addStat("extract.device_octree_fallbacks", 1);
+                    ex->deviceOctree = false;
+                }
+            }
+        }
+    }
+    if (!done) {
+        rc = ft_extract_prepare(ex, images, batch, on_device, width, height, stride);
+        if (rc != FT_OK) return rc;
+    }
+    for (int pass = done ? 2 : 0; pass < 2; pass++) {
         // pass 1 only when the device octree met a level beyond its limits: same batch, host octree
         if (pass == 1) {
             if (!(ex->deviceOctree && ex->h_overflow[0])) break;
@@ -740,6 +838,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
         if (!dev) ex->ctx->addStat("extract.octree(host)", tOct);
         if (pass == 1) ex->deviceOctree = true;
     }
+    ex->deviceOctree = devWanted;
     rc = assembleOutputs(ex, batch, lap0, lap1, keypoints, descriptors, capacity, n_keypoints, n_mono);
     ex->ctx->addStat("extract.total", tAll.ms());
     return rc;

@@ -105,6 +105,19 @@ struct ft_extractor {
     // so that the wide stage-A kernels of the following sub-batches are not queued behind it
     hipStream_t streamO[FT_OCT_STREAMS] = {};
     hipEvent_t evO[FT_PIPE_MAX] = {};
+    // latency mode of ft_extract / ft_extract_batch: a small batch with a fixed call shape is captured once as a HIP
+    // graph (see ft_stereo_frontend::GraphKey); the key is everything baked into the nodes
+    struct GraphKey {
+        int batch = 0, onDevice = 0, width = 0, height = 0, stride = 0, aligned = 0;
+        std::vector<const uint8_t *> hostImages;
+        bool operator==(const GraphKey &o) const {
+            return batch == o.batch && onDevice == o.onDevice && width == o.width && height == o.height && stride == o.stride &&
+                   aligned == o.aligned && hostImages == o.hostImages;
+        }
+    } graphKey;
+    hipGraphExec_t graphExec = nullptr;
+    bool graphDisabled = false;
+    hipEvent_t evJoin = nullptr;
     // device buffers
     uint8_t *d_pyr = nullptr;
     FtTap *d_taps = nullptr;
@@ -153,8 +166,27 @@ struct ft_stereo_frontend {
     int *d_sad = nullptr, *d_nMatches = nullptr, *h_nMatches = nullptr;
     int *d_order = nullptr, *d_rowStart = nullptr;  // right keypoints bucketed by row (k_stereo_rowsort)
     hipEvent_t evR = nullptr;
+    // Latency mode: a small batch with a fixed call shape (same sizes, same result arrays, same kind of input) is
+    // captured once as a HIP graph - ~45 enqueue calls on seven streams become one launch.  graphKey holds everything
+    // that is baked into the captured nodes.
+    struct GraphKey {
+        int batch = 0, onDevice = 0, width = 0, height = 0, stride = 0, capacity = 0, alignedL = 0, alignedR = 0;
+        const void *out[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        std::vector<const uint8_t *> hostImages;  // baked source pointers of the H2D copies (host input only)
+        bool operator==(const GraphKey &o) const {
+            if (batch != o.batch || onDevice != o.onDevice || width != o.width || height != o.height || stride != o.stride ||
+                capacity != o.capacity || alignedL != o.alignedL || alignedR != o.alignedR || hostImages != o.hostImages)
+                return false;
+            for (int i = 0; i < 6; i++)
+                if (out[i] != o.out[i]) return false;
+            return true;
+        }
+    } graphKey;
+    hipGraphExec_t graphExec = nullptr;
+    bool graphDisabled = false;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     struct Pending {  // batch enqueued by ft_stereo_frontend_submit, finished by ft_stereo_frontend_wait
-        bool active = false, direct = false;
+        bool active = false, direct = false, graph = false;
         int batch = 0, capacity = 0;
         std::vector<const uint8_t *> imagesL, imagesR;  // kept for the host-octree fallback
         int onDevice = 0, width = 0, height = 0, stride = 0;

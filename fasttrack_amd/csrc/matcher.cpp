@@ -137,6 +137,8 @@ int ft_stereo_frontend_create(ft_context *ctx, int nfeatures, float scale_factor
     if (e == hipSuccess) e = hipHostMalloc((void **)&fe->h_depth, sizeof(float) * n, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&fe->h_nMatches, sizeof(int) * max_batch, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&fe->evR, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&fe->evFork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&fe->evJoin, hipEventDisableTiming);
     if (e != hipSuccess) {
         ft_stereo_frontend_destroy(fe);
         return ft_hip_fail(e, "stereo frontend allocation", __FILE__, __LINE__);
@@ -160,6 +162,9 @@ int ft_stereo_frontend_destroy(ft_stereo_frontend *fe) {
     hipHostFree(fe->h_depth);
     hipHostFree(fe->h_nMatches);
     if (fe->evR) hipEventDestroy(fe->evR);
+    if (fe->evFork) hipEventDestroy(fe->evFork);
+    if (fe->evJoin) hipEventDestroy(fe->evJoin);
+    if (fe->graphExec) hipGraphExecDestroy(fe->graphExec);
     delete fe;
     return FT_OK;
 }
@@ -167,19 +172,32 @@ int ft_stereo_frontend_destroy(ft_stereo_frontend *fe) {
 ft_extractor *ft_stereo_frontend_left(ft_stereo_frontend *fe) { return fe ? fe->exL : nullptr; }
 ft_extractor *ft_stereo_frontend_right(ft_stereo_frontend *fe) { return fe ? fe->exR : nullptr; }
 
-int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imagesL, const uint8_t *const *imagesR,
-                              int batch, int on_device, int width, int height, int stride, ft_keypoint *keysL,
-                              uint8_t *descL, int *nL, ft_keypoint *keysR, uint8_t *descR, int *nR, int capacity,
-                              float *uright, float *depth, int *n_matches) {
-    FT_REQUIRE(fe, "null front end");
-    FT_REQUIRE(!fe->pending.active, "stereo front end: a submitted batch has not been waited for");
-    if (!imagesL || !imagesR || width <= 0 || height <= 0) {
-        ft_set_error("stereo front end: empty image");
-        return FT_ERR_EMPTY;
+// result arrays in pinned host memory (ft_host_malloc) are filled by the D2H copies directly
+static bool isPinnedHost(const void *p) {
+    if (!p) return true;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
     }
+    return at.type == hipMemoryTypeHost;
+}
+
+#define FT_GRAPH_MAX_BATCH 8
+
+// enqueues one batch on the front end's streams.  capture != 0: L->stream is being captured into a graph - the other
+// streams are forked from it first and joined back at the end, and nothing here may synchronise.
+static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL, const uint8_t *const *imagesR, int batch,
+                           int on_device, int width, int height, int stride, ft_keypoint *keysL, uint8_t *descL, int *nL,
+                           ft_keypoint *keysR, uint8_t *descR, int *nR, int capacity, float *uright, float *depth,
+                           int *n_matches, bool direct, int capture) {
     ft_extractor *L = fe->exL, *R = fe->exR;
     const FtGeom &g = L->geom;
     FtTimer tAll;
+    if (capture) {  // fork: everything the right camera enqueues hangs off the captured stream
+        FT_HIP(hipEventRecord(fe->evFork, L->stream));
+        FT_HIP(hipStreamWaitEvent(R->stream, fe->evFork, 0));
+    }
     int rc = ft_extract_prepare(L, imagesL, batch, on_device, width, height, stride);
     if (rc != FT_OK) return rc;
     rc = ft_extract_prepare(R, imagesR, batch, on_device, width, height, stride);
@@ -206,21 +224,9 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     const bool tm = fe->ctx->kernelTiming;
     hipStream_t st = L->streamB;
     double tOct = 0, tWait = 0, tLaunch = 0;
-    // result arrays in pinned host memory (ft_host_malloc) are filled by the D2H copies directly; pageable
-    // ones go through the library's pinned staging buffers and a host memcpy
-    auto pinned = [](const void *p) {
-        if (!p) return true;
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        return at.type == hipMemoryTypeHost;
-    };
+    // pageable result arrays go through the library's pinned staging buffers and a host memcpy in _wait
     // (with the device octree the per-image counts are unknown until the end: whole rows are copied, which the
     // caller's arrays must be able to hold)
-    const bool direct = pinned(keysL) && pinned(descL) && pinned(keysR) && pinned(descR) && pinned(uright) &&
-                        pinned(depth) && (!dev || capacity >= g.maxKp);
     const size_t kp = sizeof(ft_keypoint);
     auto d2h = [&](void *user, void *staging, const void *dev, size_t elem, int b0, int nb, int maxN) -> hipError_t {
         // rows of `elem`-byte records: device/staging stride maxKp, user stride capacity
@@ -316,10 +322,106 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     rc = ft_extract_finish_counts(L, batch, st);
     if (rc == FT_OK) rc = ft_extract_finish_counts(R, batch, st);
     if (rc != FT_OK) return rc;
+    if (capture) {  // join: the stage-B stream of the left camera is the tail of everything
+        FT_HIP(hipEventRecord(fe->evJoin, st));
+        FT_HIP(hipStreamWaitEvent(L->stream, fe->evJoin, 0));
+    }
     if (!dev) fe->ctx->addStat("stereo.octree(host,both)", tOct);
     fe->ctx->addStat("stereo.host_wait_stageA", tWait);
     fe->ctx->addStat("stereo.host_launch_stageB", tLaunch);
     fe->ctx->addStat("stereo.submit.total", tAll.ms());
+    return FT_OK;
+}
+
+int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imagesL, const uint8_t *const *imagesR,
+                              int batch, int on_device, int width, int height, int stride, ft_keypoint *keysL,
+                              uint8_t *descL, int *nL, ft_keypoint *keysR, uint8_t *descR, int *nR, int capacity,
+                              float *uright, float *depth, int *n_matches) {
+    FT_REQUIRE(fe, "null front end");
+    FT_REQUIRE(!fe->pending.active, "stereo front end: a submitted batch has not been waited for");
+    if (!imagesL || !imagesR || width <= 0 || height <= 0) {
+        ft_set_error("stereo front end: empty image");
+        return FT_ERR_EMPTY;
+    }
+    ft_extractor *L = fe->exL, *R = fe->exR;
+    const FtGeom &g = L->geom;
+    int rc = ft_set_device(fe->ctx);
+    if (rc != FT_OK) return rc;
+    const bool dev = L->deviceOctree && R->deviceOctree;
+    const bool direct = isPinnedHost(keysL) && isPinnedHost(descL) && isPinnedHost(keysR) && isPinnedHost(descR) &&
+                        isPinnedHost(uright) && isPinnedHost(depth) && (!dev || capacity >= g.maxKp);
+    // ---- latency mode: small batches with a fixed call shape run as one captured graph ----
+    static const bool graphsOn = !(getenv("FT_GRAPH") && getenv("FT_GRAPH")[0] == '0');
+    bool useGraph = graphsOn && !fe->graphDisabled && dev && direct && !fe->ctx->kernelTiming && batch >= 1 &&
+                    batch <= FT_GRAPH_MAX_BATCH && batch <= L->maxBatch && width == L->width && height == L->height &&
+                    stride >= width;
+    bool launched = false;
+    if (useGraph) {
+        for (int b = 0; b < batch; b++)
+            if (!imagesL[b] || !imagesR[b]) useGraph = false;
+    }
+    if (useGraph) {
+        ft_stereo_frontend::GraphKey key;
+        key.batch = batch; key.onDevice = on_device; key.width = width; key.height = height; key.stride = stride;
+        key.capacity = capacity;
+        key.alignedL = key.alignedR = 1;
+        if (on_device) {
+            if (stride & 3) key.alignedL = key.alignedR = 0;
+            for (int b = 0; b < batch; b++) {
+                if ((uintptr_t)imagesL[b] & 3) key.alignedL = 0;
+                if ((uintptr_t)imagesR[b] & 3) key.alignedR = 0;
+            }
+        } else {
+            key.hostImages.assign(imagesL, imagesL + batch);
+            key.hostImages.insert(key.hostImages.end(), imagesR, imagesR + batch);
+        }
+        const void *outs[6] = {keysL, descL, keysR, descR, uright, depth};
+        for (int i = 0; i < 6; i++) key.out[i] = outs[i];
+        if (fe->graphExec && key == fe->graphKey) {
+            // replay: only the level-0 pointer tables change (device input); host input is re-read by the baked copies
+            if (on_device)
+                for (int b = 0; b < batch; b++) {
+                    L->h_l0[b] = imagesL[b];
+                    R->h_l0[b] = imagesR[b];
+                }
+            L->lastBatch = R->lastBatch = batch;
+            FtTimer tG;
+            FT_HIP(hipGraphLaunch(fe->graphExec, L->stream));
+            fe->ctx->addStat("stereo.graph_launch", tG.ms());
+            launched = true;
+        } else {
+            if (fe->graphExec) {
+                hipGraphExecDestroy(fe->graphExec);
+                fe->graphExec = nullptr;
+            }
+            hipGraph_t graph = nullptr;
+            hipError_t ce = hipStreamBeginCapture(L->stream, hipStreamCaptureModeThreadLocal);
+            if (ce == hipSuccess) {
+                rc = frontendEnqueue(fe, imagesL, imagesR, batch, on_device, width, height, stride, keysL, descL, nL, keysR,
+                                     descR, nR, capacity, uright, depth, n_matches, direct, 1);
+                ce = hipStreamEndCapture(L->stream, &graph);
+                if (rc == FT_OK && ce == hipSuccess && graph) ce = hipGraphInstantiate(&fe->graphExec, graph, nullptr, nullptr, 0);
+                if (graph) hipGraphDestroy(graph);
+            }
+            if (rc != FT_OK || ce != hipSuccess || !fe->graphExec) {
+                // capture is an optimisation: fall back to plain enqueueing for good
+                (void)hipGetLastError();
+                fe->graphDisabled = true;
+                fe->graphExec = nullptr;
+                fe->ctx->addStat("stereo.graph_capture_failed", 0);
+            } else {
+                fe->graphKey = key;
+                fe->ctx->addStat("stereo.graph_captures", 0);
+                FT_HIP(hipGraphLaunch(fe->graphExec, L->stream));
+                launched = true;
+            }
+        }
+    }
+    if (!launched) {
+        rc = frontendEnqueue(fe, imagesL, imagesR, batch, on_device, width, height, stride, keysL, descL, nL, keysR, descR,
+                             nR, capacity, uright, depth, n_matches, direct, 0);
+        if (rc != FT_OK) return rc;
+    }
     // everything is enqueued; ft_stereo_frontend_wait drains the streams and finishes the outputs
     auto &P = fe->pending;
     P.imagesL.assign(imagesL, imagesL + batch);
@@ -329,6 +431,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     P.height = height;
     P.stride = stride;
     P.active = true;
+    P.graph = launched;
     P.batch = batch;
     P.capacity = capacity;
     P.direct = direct;
@@ -348,6 +451,7 @@ int ft_stereo_frontend_wait(ft_stereo_frontend *fe) {
     const FtGeom &g = L->geom;
     FtTimer tTail;
     P.active = false;
+    if (P.graph) FT_HIP(hipStreamSynchronize(L->stream));  // a captured batch completes on the stream it was launched on
     FT_HIP(hipStreamSynchronize(L->streamB));
     FT_HIP(hipStreamSynchronize(R->streamB));
     fe->ctx->addStat("stereo.host_tail_sync", tTail.ms());

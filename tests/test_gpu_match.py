@@ -516,3 +516,43 @@ def test_stereo_frontend_random_configurations(ctx):
             assert np.array_equal(out["descL"], dL) and np.array_equal(out["descR"], dR)
             assert out["n"] == o["n"] and np.array_equal(out["uright"], o["uright"]) and np.array_equal(out["depth"], o["depth"])
         fe.close()
+
+
+def test_stereo_frontend_graph_replay(ctx):
+    """latency mode: a small batch with a fixed call shape is captured once as a HIP graph and replayed; frames that
+    are resident in HBM change between replays through the level-0 pointer table, results always equal the oracle's"""
+    import ctypes as C
+    w, h, nf, B = 752, 480, 1200, 2
+    intr = synth.intrinsics(w, h)
+    fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
+
+    def calls(name):
+        try:
+            return ctx.get_stat(name)[1]
+        except Exception:
+            return 0
+    c0, l0 = calls("stereo.graph_captures"), calls("stereo.graph_launch")
+    frames = [[synth.make_stereo_pair(w, h, 700 + 10 * k + b) for b in range(B)] for k in range(3)]
+    dev = [[(ctx.to_device(p[0]), ctx.to_device(p[1])) for p in fr] for fr in frames]
+    for k in range(3):
+        pL = (C.c_void_p * B)(*[d[0].ptr for d in dev[k]])
+        pR = (C.c_void_p * B)(*[d[1].ptr for d in dev[k]])
+        fe.process_raw(pL, pR, B, True, w)
+        for b in range(B):
+            oL, oR = ob.Extractor(nf), ob.Extractor(nf)
+            kL, dL, _ = oL.extract(frames[k][b][0])
+            kR, dR, _ = oR.extract(frames[k][b][1])
+            o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+            n = int(fe._nL[b])
+            assert np.array_equal(fe._kL[b, :n], kL) and np.array_equal(fe._dL[b, :n], dL), (k, b)
+            assert np.array_equal(fe._ur[b, :n], o["uright"]) and int(fe._nm[b]) == o["n"]
+    if calls("stereo.graph_capture_failed") == 0:
+        assert calls("stereo.graph_captures") == c0 + 1, "the call shape did not change: one capture"
+        assert calls("stereo.graph_launch") == l0 + 2, "the second and third frame replay the graph"
+    # a different batch size is a different graph
+    pL = (C.c_void_p * 1)(dev[0][0][0].ptr)
+    pR = (C.c_void_p * 1)(dev[0][0][1].ptr)
+    fe.process_raw(pL, pR, 1, True, w)
+    oL = ob.Extractor(nf)
+    kL, dL, _ = oL.extract(frames[0][0][0])
+    assert np.array_equal(fe._kL[0, :int(fe._nL[0])], kL)
