@@ -177,6 +177,7 @@ void freeAll(ft_extractor *ex) {
         }
     if (ex->streamB) hipStreamDestroy(ex->streamB);
     hipFree(ex->d_pyr);
+    if (ex->h_stage) hipHostFree(ex->h_stage);
     hipFree(ex->d_taps);
     hipFree(ex->d_cellTab);
     hipFree(ex->d_cellCount);
@@ -243,6 +244,12 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
         uint8_t *slot0 = ex->d_pyr + (size_t)b * g.pyrPerSlot + g.lv[0].off;
         if (on_device) {
             ex->h_l0[b] = images[b];
+        } else if (ex->stageHost) {
+            // graph path: the frame is copied into pinned staging by the host, the (captured) upload reads from there
+            ex->h_l0[b] = slot0;
+            uint8_t *stg = ex->h_stage + (size_t)b * width * height;
+            for (int y = 0; y < height; y++) memcpy(stg + (size_t)y * width, images[b] + (size_t)y * stride, width);
+            FT_HIP(hipMemcpy2DAsync(slot0, g.lv[0].pitch, stg, width, width, height, hipMemcpyHostToDevice, ex->stream));
         } else {
             ex->h_l0[b] = slot0;
             FT_HIP(hipMemcpy2DAsync(slot0, g.lv[0].pitch, images[b], stride, width, height, hipMemcpyHostToDevice,
@@ -262,6 +269,20 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
     FT_HIP(hipMemcpyAsync((void *)ex->d_l0, (const void *)ex->h_l0, sizeof(uint8_t *) * batch, hipMemcpyHostToDevice,
                           ex->stream));
     return FT_OK;
+}
+
+// graph path with host frames: pinned staging for up to 8 slots (allocated once)
+int ft_extract_ensure_stage(ft_extractor *ex) {
+    if (ex->h_stage) return FT_OK;
+    FT_HIP(hipHostMalloc((void **)&ex->h_stage, (size_t)8 * ex->width * ex->height, hipHostMallocDefault));
+    return FT_OK;
+}
+// replay of a captured batch with host frames: refresh the staging copies the captured uploads read
+void ft_extract_restage(ft_extractor *ex, const uint8_t *const *images, int batch, int width, int height, int stride) {
+    for (int b = 0; b < batch; b++) {
+        uint8_t *stg = ex->h_stage + (size_t)b * width * height;
+        for (int y = 0; y < height; y++) memcpy(stg + (size_t)y * width, images[b] + (size_t)y * stride, width);
+    }
 }
 
 // stage A of slots [b0, b0+nb): pyramid + FAST + ordered compaction on ex->stream; `done` is recorded after it
@@ -740,13 +761,17 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
                 if (stride & 3) key.aligned = 0;
                 for (int b = 0; b < batch; b++)
                     if ((uintptr_t)images[b] & 3) key.aligned = 0;
-            } else {
-                key.hostImages.assign(images, images + batch);
+            } else if (ft_extract_ensure_stage(ex) != FT_OK) {
+                ok = false;
+                (void)hipGetLastError();
             }
             bool launched = false;
-            if (ex->graphExec && key == ex->graphKey) {
+            if (!ok) {
+            } else if (ex->graphExec && key == ex->graphKey) {
                 if (on_device)
                     for (int b = 0; b < batch; b++) ex->h_l0[b] = images[b];
+                else
+                    ft_extract_restage(ex, images, batch, width, height, stride);
                 ex->lastBatch = batch;
                 FT_HIP(hipGraphLaunch(ex->graphExec, ex->stream));
                 launched = true;
@@ -756,6 +781,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
                     ex->graphExec = nullptr;
                 }
                 hipGraph_t graph = nullptr;
+                ex->stageHost = !on_device;
                 hipError_t ce = hipStreamBeginCapture(ex->stream, hipStreamCaptureModeThreadLocal);
                 if (ce == hipSuccess) {
                     rc = enqueueDevice(1);
@@ -769,7 +795,9 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
                     ex->graphExec = nullptr;
                     ex->ctx->addStat("extract.graph_capture_failed", 0);
                     rc = FT_OK;
+                    ex->stageHost = false;
                 } else {
+                    ex->stageHost = false;
                     ex->graphKey = key;
                     ex->ctx->addStat("extract.graph_captures", 0);
                     FT_HIP(hipGraphLaunch(ex->graphExec, ex->stream));

@@ -109,10 +109,9 @@ struct ft_extractor {
     // graph (see ft_stereo_frontend::GraphKey); the key is everything baked into the nodes
     struct GraphKey {
         int batch = 0, onDevice = 0, width = 0, height = 0, stride = 0, aligned = 0;
-        std::vector<const uint8_t *> hostImages;
         bool operator==(const GraphKey &o) const {
             return batch == o.batch && onDevice == o.onDevice && width == o.width && height == o.height && stride == o.stride &&
-                   aligned == o.aligned && hostImages == o.hostImages;
+                   aligned == o.aligned;
         }
     } graphKey;
     hipGraphExec_t graphExec = nullptr;
@@ -126,6 +125,8 @@ struct ft_extractor {
     uint32_t *d_stage = nullptr;
     const uint8_t **d_l0 = nullptr;
     const uint8_t **h_l0 = nullptr;  // pinned
+    uint8_t *h_stage = nullptr;      // pinned staging of host frames for the graph path (up to 8 slots, allocated on first use)
+    bool stageHost = false;          // ft_extract_prepare: host frames go through h_stage (their pointers may change between replays)
     float *d_sf = nullptr;           // scale factors on device [nlevels] then inverse [nlevels]
     // host-mapped pinned buffers written by the device
     uint32_t *h_cand = nullptr, *d_cand = nullptr;
@@ -172,10 +173,9 @@ struct ft_stereo_frontend {
     struct GraphKey {
         int batch = 0, onDevice = 0, width = 0, height = 0, stride = 0, capacity = 0, alignedL = 0, alignedR = 0;
         const void *out[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        std::vector<const uint8_t *> hostImages;  // baked source pointers of the H2D copies (host input only)
         bool operator==(const GraphKey &o) const {
             if (batch != o.batch || onDevice != o.onDevice || width != o.width || height != o.height || stride != o.stride ||
-                capacity != o.capacity || alignedL != o.alignedL || alignedR != o.alignedR || hostImages != o.hostImages)
+                capacity != o.capacity || alignedL != o.alignedL || alignedR != o.alignedR)
                 return false;
             for (int i = 0; i < 6; i++)
                 if (out[i] != o.out[i]) return false;
@@ -205,6 +205,8 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
                        int stride);
 // per sub-batch of slots [b0, b0+nb): see extractor.cpp
 int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done);
+int ft_extract_ensure_stage(ft_extractor *ex);
+void ft_extract_restage(ft_extractor *ex, const uint8_t *const *images, int batch, int width, int height, int stride);
 int ft_extract_octree(ft_extractor *ex, int b0, int nb);
 int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb);
 int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent_t done);  // device octree, own streams

@@ -371,20 +371,27 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
                 if ((uintptr_t)imagesL[b] & 3) key.alignedL = 0;
                 if ((uintptr_t)imagesR[b] & 3) key.alignedR = 0;
             }
-        } else {
-            key.hostImages.assign(imagesL, imagesL + batch);
-            key.hostImages.insert(key.hostImages.end(), imagesR, imagesR + batch);
+        } else if (ft_extract_ensure_stage(L) != FT_OK || ft_extract_ensure_stage(R) != FT_OK) {
+            (void)hipGetLastError();
+            useGraph = false;
         }
         const void *outs[6] = {keysL, descL, keysR, descR, uright, depth};
         for (int i = 0; i < 6; i++) key.out[i] = outs[i];
-        if (fe->graphExec && key == fe->graphKey) {
-            // replay: only the level-0 pointer tables change (device input); host input is re-read by the baked copies
-            if (on_device)
+        if (!useGraph) {
+        } else if (fe->graphExec && key == fe->graphKey) {
+            // replay: device frames change through the level-0 pointer tables, host frames through the pinned staging
+            // the captured uploads read
+            if (on_device) {
                 for (int b = 0; b < batch; b++) {
                     L->h_l0[b] = imagesL[b];
                     R->h_l0[b] = imagesR[b];
                 }
+            } else {
+                ft_extract_restage(L, imagesL, batch, width, height, stride);
+                ft_extract_restage(R, imagesR, batch, width, height, stride);
+            }
             L->lastBatch = R->lastBatch = batch;
+            fe->ctx->addStat("stereo.device_octree_batches", 0);
             FtTimer tG;
             FT_HIP(hipGraphLaunch(fe->graphExec, L->stream));
             fe->ctx->addStat("stereo.graph_launch", tG.ms());
@@ -395,6 +402,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
                 fe->graphExec = nullptr;
             }
             hipGraph_t graph = nullptr;
+            L->stageHost = R->stageHost = !on_device;
             hipError_t ce = hipStreamBeginCapture(L->stream, hipStreamCaptureModeThreadLocal);
             if (ce == hipSuccess) {
                 rc = frontendEnqueue(fe, imagesL, imagesR, batch, on_device, width, height, stride, keysL, descL, nL, keysR,
@@ -403,6 +411,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
                 if (rc == FT_OK && ce == hipSuccess && graph) ce = hipGraphInstantiate(&fe->graphExec, graph, nullptr, nullptr, 0);
                 if (graph) hipGraphDestroy(graph);
             }
+            L->stageHost = R->stageHost = false;
             if (rc != FT_OK || ce != hipSuccess || !fe->graphExec) {
                 // capture is an optimisation: fall back to plain enqueueing for good
                 (void)hipGetLastError();

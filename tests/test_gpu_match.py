@@ -549,6 +549,16 @@ def test_stereo_frontend_graph_replay(ctx):
     if calls("stereo.graph_capture_failed") == 0:
         assert calls("stereo.graph_captures") == c0 + 1, "the call shape did not change: one capture"
         assert calls("stereo.graph_launch") == l0 + 2, "the second and third frame replay the graph"
+    # host frames: every call brings new arrays (new pointers); they reach the captured uploads through pinned staging
+    c1, l1 = calls("stereo.graph_captures"), calls("stereo.graph_launch")
+    for k in range(3):
+        outs = fe.process([p[0].copy() for p in frames[k]], [p[1].copy() for p in frames[k]])
+        for b in range(B):
+            oL = ob.Extractor(nf)
+            kL, dL, _ = oL.extract(frames[k][b][0])
+            assert np.array_equal(outs[b]["keysL"], kL) and np.array_equal(outs[b]["descL"], dL), (k, b)
+    if calls("stereo.graph_capture_failed") == 0:
+        assert calls("stereo.graph_captures") == c1 + 1 and calls("stereo.graph_launch") == l1 + 2
     # a different batch size is a different graph
     pL = (C.c_void_p * 1)(dev[0][0][0].ptr)
     pR = (C.c_void_p * 1)(dev[0][0][1].ptr)
