@@ -226,3 +226,25 @@ int ft_debug_repeat(const char *name) {
     }
     return 1;
 }
+
+// grow-only device / pinned scratch of the matchers (callers hold ctx->matchMutex)
+int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes) {
+    if (devBytes > ctx->scratchDevBytes) {
+        if (ctx->scratchDev) hipFree(ctx->scratchDev);
+        ctx->scratchDev = nullptr;
+        ctx->scratchDevBytes = 0;
+        const size_t want = devBytes + devBytes / 2;
+        FT_HIP(hipMalloc(&ctx->scratchDev, want));
+        ctx->scratchDevBytes = want;
+    }
+    if (pinBytes > ctx->scratchPinBytes) {
+        if (ctx->scratchPin) hipHostFree(ctx->scratchPin);
+        ctx->scratchPin = nullptr;
+        ctx->scratchPinBytes = 0;
+        const size_t want = pinBytes + pinBytes / 2;
+        FT_HIP(hipHostMalloc(&ctx->scratchPin, want, hipHostMallocDefault));
+        ctx->scratchPinBytes = want;
+    }
+    return FT_OK;
+}
+

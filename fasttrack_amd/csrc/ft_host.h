@@ -198,6 +198,7 @@ struct ft_stereo_frontend {
 };
 
 int ft_set_device(const ft_context *ctx);
+int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes);  // grow-only matcher scratch (hold matchMutex)
 int ft_usable_cpus();
 int ft_pipeline_depth(int batch, bool deviceOctree);
 // validation, level-0 pointers / uploads of a whole batch (async on ex->stream)

@@ -528,25 +528,25 @@ int ft_fisheye_match(ft_context *ctx, const uint8_t *descL, int nL, const uint8_
     if (nL == 0) return FT_OK;
     int rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
-    uint8_t *dL = nullptr, *dR = nullptr;
-    int *dOut = nullptr;
-    hipError_t e = hipMalloc((void **)&dL, (size_t)32 * nL);
-    if (e == hipSuccess) e = hipMalloc((void **)&dR, (size_t)32 * std::max(nR, 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&dOut, sizeof(int) * 3 * nL);
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    // layout in the context's grow-only scratch: descL | descR | matches, best, second
+    const size_t oL = 0, oR = (((size_t)32 * nL) + 63) & ~(size_t)63, oOut = oR + ((((size_t)32 * std::max(nR, 1)) + 63) & ~(size_t)63);
+    const size_t total = oOut + sizeof(int) * 3 * (size_t)nL;
+    rc = ft_ensure_scratch(ctx, total, sizeof(int) * 3 * (size_t)nL);
+    if (rc != FT_OK) return rc;
+    uint8_t *dev = (uint8_t *)ctx->scratchDev;
+    int *dOut = (int *)(dev + oOut), *hOut = (int *)ctx->scratchPin;
     hipStream_t st = ctx->stream;
-    if (e == hipSuccess) e = hipMemcpyAsync(dL, descL, (size_t)32 * nL, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && nR > 0) e = hipMemcpyAsync(dR, descR, (size_t)32 * nR, hipMemcpyHostToDevice, st);
-    rc = FT_OK;
-    if (e == hipSuccess) rc = ft_launch_fisheye(st, dL, nL, dR, nR, dOut, dOut + nL, dOut + 2 * nL);
-    if (e == hipSuccess && rc == FT_OK) e = hipMemcpyAsync(matches, dOut, sizeof(int) * nL, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && rc == FT_OK && best) e = hipMemcpyAsync(best, dOut + nL, sizeof(int) * nL, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && rc == FT_OK && second) e = hipMemcpyAsync(second, dOut + 2 * nL, sizeof(int) * nL, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(dL);
-    hipFree(dR);
-    hipFree(dOut);
-    if (e != hipSuccess) return ft_hip_fail(e, "ft_fisheye_match", __FILE__, __LINE__);
-    return rc;
+    FT_HIP(hipMemcpyAsync(dev + oL, descL, (size_t)32 * nL, hipMemcpyHostToDevice, st));
+    if (nR > 0) FT_HIP(hipMemcpyAsync(dev + oR, descR, (size_t)32 * nR, hipMemcpyHostToDevice, st));
+    rc = ft_launch_fisheye(st, dev + oL, nL, dev + oR, nR, dOut, dOut + nL, dOut + 2 * (size_t)nL);
+    if (rc != FT_OK) return rc;
+    FT_HIP(hipMemcpyAsync(hOut, dOut, sizeof(int) * 3 * (size_t)nL, hipMemcpyDeviceToHost, st));
+    FT_HIP(hipStreamSynchronize(st));
+    memcpy(matches, hOut, sizeof(int) * nL);
+    if (best) memcpy(best, hOut + nL, sizeof(int) * nL);
+    if (second) memcpy(second, hOut + 2 * (size_t)nL, sizeof(int) * nL);
+    return FT_OK;
 }
 
 int ft_fisheye_stereo(ft_context *ctx, const ft_fisheye_rig *rig, const uint8_t *descL, const ft_keypoint *keysL, int nL,
@@ -570,37 +570,40 @@ int ft_fisheye_stereo(ft_context *ctx, const ft_fisheye_rig *rig, const uint8_t 
     memcpy(G.Rlr, rig->Rlr, sizeof G.Rlr);
     memcpy(G.tlr, rig->tlr, sizeof G.tlr);
     for (int i = 0; i < nlevels; i++) G.sigma2[i] = level_sigma2[i];
-    uint8_t *dL = nullptr, *dR = nullptr;
-    ft_keypoint *kL = nullptr, *kR = nullptr;
-    int *dM = nullptr;
-    float *dOut = nullptr;
-    hipStream_t st = ctx->stream;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
     const size_t nRa = (size_t)std::max(nR, 1);
-    hipError_t e = hipMalloc((void **)&dL, (size_t)32 * nL);
-    if (e == hipSuccess) e = hipMalloc((void **)&dR, 32 * nRa);
-    if (e == hipSuccess) e = hipMalloc((void **)&kL, sizeof(ft_keypoint) * nL);
-    if (e == hipSuccess) e = hipMalloc((void **)&kR, sizeof(ft_keypoint) * nRa);
-    if (e == hipSuccess) e = hipMalloc((void **)&dM, sizeof(int) * (3 * (size_t)nL + 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&dOut, sizeof(float) * 4 * (size_t)nL);
-    if (e == hipSuccess) e = hipMemcpyAsync(dL, descL, (size_t)32 * nL, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(kL, keysL, sizeof(ft_keypoint) * nL, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && nR > 0) e = hipMemcpyAsync(dR, descR, (size_t)32 * nR, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && nR > 0) e = hipMemcpyAsync(kR, keysR, sizeof(ft_keypoint) * nR, hipMemcpyHostToDevice, st);
-    int *dCount = dM + 3 * (size_t)nL;
-    if (e == hipSuccess) e = hipMemsetAsync(dCount, 0, sizeof(int), st);
-    rc = FT_OK;
-    if (e == hipSuccess) rc = ft_launch_fisheye(st, dL, nL, dR, nR, dM, dM + nL, dM + 2 * (size_t)nL);
-    if (e == hipSuccess && rc == FT_OK) rc = ft_launch_fisheye_triangulate(st, G, kL, nL, kR, dM, dOut, dOut + nL, dCount);
-    int hCount = 0;
-    if (e == hipSuccess && rc == FT_OK) e = hipMemcpyAsync(matches, dM, sizeof(int) * nL, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && rc == FT_OK) e = hipMemcpyAsync(depth, dOut, sizeof(float) * nL, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && rc == FT_OK) e = hipMemcpyAsync(p3d, dOut + nL, sizeof(float) * 3 * (size_t)nL, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && rc == FT_OK) e = hipMemcpyAsync(&hCount, dCount, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(dL); hipFree(dR); hipFree(kL); hipFree(kR); hipFree(dM); hipFree(dOut);
-    if (e != hipSuccess) return ft_hip_fail(e, "ft_fisheye_stereo", __FILE__, __LINE__);
-    if (n_matches) *n_matches = hCount;
-    return rc;
+    const size_t oDL = 0, oDR = up((size_t)32 * nL), oKL = oDR + up(32 * nRa), oKR = oKL + up(sizeof(ft_keypoint) * nL),
+                 oOut = oKR + up(sizeof(ft_keypoint) * nRa);
+    // outputs: matches | best | second | count(+pad) | depth | p3d
+    const size_t outInts = 3 * (size_t)nL + 16, outBytes = sizeof(int) * outInts + sizeof(float) * 4 * (size_t)nL;
+    rc = ft_ensure_scratch(ctx, oOut + outBytes, outBytes);
+    if (rc != FT_OK) return rc;
+    uint8_t *dev = (uint8_t *)ctx->scratchDev, *pin = (uint8_t *)ctx->scratchPin;
+    int *dM = (int *)(dev + oOut), *dCount = dM + 3 * (size_t)nL;
+    float *dOut = (float *)(dM + outInts);
+    hipStream_t st = ctx->stream;
+    FT_HIP(hipMemcpyAsync(dev + oDL, descL, (size_t)32 * nL, hipMemcpyHostToDevice, st));
+    FT_HIP(hipMemcpyAsync(dev + oKL, keysL, sizeof(ft_keypoint) * nL, hipMemcpyHostToDevice, st));
+    if (nR > 0) {
+        FT_HIP(hipMemcpyAsync(dev + oDR, descR, (size_t)32 * nR, hipMemcpyHostToDevice, st));
+        FT_HIP(hipMemcpyAsync(dev + oKR, keysR, sizeof(ft_keypoint) * nR, hipMemcpyHostToDevice, st));
+    }
+    FT_HIP(hipMemsetAsync(dCount, 0, sizeof(int), st));
+    rc = ft_launch_fisheye(st, dev + oDL, nL, dev + oDR, nR, dM, dM + nL, dM + 2 * (size_t)nL);
+    if (rc == FT_OK)
+        rc = ft_launch_fisheye_triangulate(st, G, (const ft_keypoint *)(dev + oKL), nL, (const ft_keypoint *)(dev + oKR), dM, dOut,
+                                           dOut + nL, dCount);
+    if (rc != FT_OK) return rc;
+    FT_HIP(hipMemcpyAsync(pin, dev + oOut, outBytes, hipMemcpyDeviceToHost, st));
+    FT_HIP(hipStreamSynchronize(st));
+    const int *hM = (const int *)pin;
+    const float *hOut = (const float *)(hM + outInts);
+    memcpy(matches, hM, sizeof(int) * nL);
+    memcpy(depth, hOut, sizeof(float) * nL);
+    memcpy(p3d, hOut + nL, sizeof(float) * 3 * (size_t)nL);
+    if (n_matches) *n_matches = hM[3 * (size_t)nL];
+    return FT_OK;
 }
 
 int ft_descriptor_distance(ft_context *ctx, const uint8_t *a, const uint8_t *b, int n, int *dist) {
@@ -608,23 +611,20 @@ int ft_descriptor_distance(ft_context *ctx, const uint8_t *a, const uint8_t *b, 
     if (n == 0) return FT_OK;
     int rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
-    uint8_t *dA = nullptr, *dB = nullptr;
-    int *dD = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    const size_t oA = 0, oB = (((size_t)32 * n) + 63) & ~(size_t)63, oD = 2 * oB;
+    rc = ft_ensure_scratch(ctx, oD + sizeof(int) * (size_t)n, sizeof(int) * (size_t)n);
+    if (rc != FT_OK) return rc;
+    uint8_t *dev = (uint8_t *)ctx->scratchDev;
     hipStream_t st = ctx->stream;
-    hipError_t e = hipMalloc((void **)&dA, (size_t)32 * n);
-    if (e == hipSuccess) e = hipMalloc((void **)&dB, (size_t)32 * n);
-    if (e == hipSuccess) e = hipMalloc((void **)&dD, sizeof(int) * n);
-    if (e == hipSuccess) e = hipMemcpyAsync(dA, a, (size_t)32 * n, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(dB, b, (size_t)32 * n, hipMemcpyHostToDevice, st);
-    rc = FT_OK;
-    if (e == hipSuccess) rc = ft_launch_hamming_pairs(st, dA, dB, n, dD);
-    if (e == hipSuccess && rc == FT_OK) e = hipMemcpyAsync(dist, dD, sizeof(int) * n, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(dA);
-    hipFree(dB);
-    hipFree(dD);
-    if (e != hipSuccess) return ft_hip_fail(e, "ft_descriptor_distance", __FILE__, __LINE__);
-    return rc;
+    FT_HIP(hipMemcpyAsync(dev + oA, a, (size_t)32 * n, hipMemcpyHostToDevice, st));
+    FT_HIP(hipMemcpyAsync(dev + oB, b, (size_t)32 * n, hipMemcpyHostToDevice, st));
+    rc = ft_launch_hamming_pairs(st, dev + oA, dev + oB, n, (int *)(dev + oD));
+    if (rc != FT_OK) return rc;
+    FT_HIP(hipMemcpyAsync(ctx->scratchPin, dev + oD, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+    FT_HIP(hipStreamSynchronize(st));
+    memcpy(dist, ctx->scratchPin, sizeof(int) * (size_t)n);
+    return FT_OK;
 }
 
 }  // extern "C"

@@ -30,26 +30,6 @@ struct Arena {
     }
 };
 
-int ensureScratch(ft_context *ctx, size_t devBytes, size_t pinBytes) {
-    if (devBytes > ctx->scratchDevBytes) {
-        if (ctx->scratchDev) hipFree(ctx->scratchDev);
-        ctx->scratchDev = nullptr;
-        ctx->scratchDevBytes = 0;
-        const size_t want = devBytes + devBytes / 2;
-        FT_HIP(hipMalloc(&ctx->scratchDev, want));
-        ctx->scratchDevBytes = want;
-    }
-    if (pinBytes > ctx->scratchPinBytes) {
-        if (ctx->scratchPin) hipHostFree(ctx->scratchPin);
-        ctx->scratchPin = nullptr;
-        ctx->scratchPinBytes = 0;
-        const size_t want = pinBytes + pinBytes / 2;
-        FT_HIP(hipHostMalloc(&ctx->scratchPin, want, hipHostMallocDefault));
-        ctx->scratchPinBytes = want;
-    }
-    return FT_OK;
-}
-
 struct FrameLayout {
     size_t keys, keysR, desc, uright, holder, l2r, r2l;
     int nLeftKeys, nRightKeys;
@@ -417,7 +397,7 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     const size_t oRaw = a.take(40 * (size_t)M);
     const size_t total = a.off;
     const size_t outBytes = 16 * (size_t)M + 40 * (size_t)M + 64;
-    rc = ensureScratch(ctx, total, std::max(inputBytes, outBytes));
+    rc = ft_ensure_scratch(ctx, total, std::max(inputBytes, outBytes));
     if (rc != FT_OK) return rc;
     uint8_t *pin = (uint8_t *)ctx->scratchPin, *dev = (uint8_t *)ctx->scratchDev;
     stageFrame(F, FL, pin);
@@ -509,7 +489,7 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     const size_t oRaw = a.take(16 * (size_t)M);
     const size_t total = a.off;
     const size_t outBytes = 32 * (size_t)M + 64;
-    rc = ensureScratch(ctx, total, std::max(inputBytes, outBytes));
+    rc = ft_ensure_scratch(ctx, total, std::max(inputBytes, outBytes));
     if (rc != FT_OK) return rc;
     uint8_t *pin = (uint8_t *)ctx->scratchPin, *dev = (uint8_t *)ctx->scratchDev;
     stageFrame(Cur, FL, pin);
@@ -583,7 +563,7 @@ int ft_features_in_area(ft_context *ctx, const ft_frame_view *F, int nq, const f
     const size_t inputBytes = a.off;
     const size_t oCount = a.take(4 * Q), oOff = a.take(4 * Q);
     const size_t fixedBytes = a.off;
-    rc = ensureScratch(ctx, fixedBytes, fixedBytes);
+    rc = ft_ensure_scratch(ctx, fixedBytes, fixedBytes);
     if (rc != FT_OK) return rc;
     uint8_t *pin = (uint8_t *)ctx->scratchPin, *dev = (uint8_t *)ctx->scratchDev;
     stageFrame(F, FL, pin);
@@ -618,7 +598,7 @@ int ft_features_in_area(ft_context *ctx, const ft_frame_view *F, int nq, const f
     const size_t oKeys = a.take(4 * totalHits);
     // growing the scratch buffer reallocates it: the frame and the queries are staged again in that case
     const void *devBefore = ctx->scratchDev;
-    rc = ensureScratch(ctx, a.off, std::max(fixedBytes, 4 * totalHits));
+    rc = ft_ensure_scratch(ctx, a.off, std::max(fixedBytes, 4 * totalHits));
     if (rc != FT_OK) return rc;
     pin = (uint8_t *)ctx->scratchPin;
     dev = (uint8_t *)ctx->scratchDev;
@@ -666,7 +646,7 @@ int ft_is_in_frustum(ft_context *ctx, const ft_frame_view *F, const ft_frame_pos
     FrustumLayout L;
     size_t inputEnd = 0;
     layoutFrustum(P->M, P->skip != nullptr, a, L, &inputEnd);
-    rc = ensureScratch(ctx, a.off, a.off);
+    rc = ft_ensure_scratch(ctx, a.off, a.off);
     if (rc != FT_OK) return rc;
     uint8_t *pin = (uint8_t *)ctx->scratchPin, *dev = (uint8_t *)ctx->scratchDev;
     stageFrustum(P, L, pin);
