@@ -5,6 +5,7 @@
 //   k_compact      cell-row-major ordered candidate list          (ORBextractor.cc:1186-1198)
 //   k_orient_desc  IC_Angle + 7x7 fixed-point blur + rBRIEF       (ORBextractor.cc:39-108,1456-1462, A.2/A.4/A.6/A.7)
 #include "ft_internal.h"
+#include "sincos_poly.h"
 
 namespace {
 
@@ -58,6 +59,41 @@ __constant__ FtPatternF c_patternF = ft_make_pattern_f();
 // d == 1 makes the magic wrap to 0, so it is special-cased.
 __device__ __forceinline__ unsigned div_magic_of(unsigned d) { return d > 1 ? 0xffffffffu / d + 1u : 0u; }
 __device__ __forceinline__ int div_by(int i, unsigned magic) { return magic ? (int)__umulhi((unsigned)i, magic) : i; }
+
+// Image rows are read through explicit global-address-space loads: a level's base pointer is either loaded from the
+// frame-pointer array or derived from a kernel argument, which leaves the compiler with a generic pointer and
+// flat_load - and a flat load counts on the LDS counter as well, so every LDS wait would also wait for image loads.
+template <class T>
+__device__ __forceinline__ T gload(const void *p) {
+    return *(const __attribute__((address_space(1))) T *)p;
+}
+
+// Sum of an int over the 64 lanes, returned wave-uniform: four DPP adds (lane pairs, quads, half rows, rows of 16) and
+// one v_readlane per row, instead of six shuffles through the LDS crossbar with their address arithmetic.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+// Low 32 bits of the product of two operands that fit 24 bits, as ONE full-rate instruction.  (__mul24 is dissolved
+// into a plain multiply once the optimiser has proven the operand ranges, and instruction selection then falls back
+// to the quarter-rate 32-bit v_mul_lo_u32 whenever it cannot re-derive them.)
+__device__ __forceinline__ int vmul24(int a, int b) {
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// a * b + c with 24-bit a, b: one full-rate instruction (b wave-uniform)
+__device__ __forceinline__ int vmad24(int a, int bUniform, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(bUniform), "v"(c));
+    return r;
+}
 
 __device__ __forceinline__ const uint8_t *level_ptr(const FtGeom &g, int level, int slot, const uint8_t *const *l0,
                                                     int l0pitch, const uint8_t *pyr, int &pitch) {
@@ -129,18 +165,31 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
         ax = sxa & 3;
         const int nd = (sxb - sxa + 1 + ax + 3) >> 2;  // dwords per row; over-read stays inside the aligned row pitch
         const uint8_t *src = S + (size_t)sya * spitch + (sxa - ax);
-        const unsigned ndMagic = div_magic_of((unsigned)nd);
         // all loads of the footprint are issued before the first LDS store (PD_NLOAD x 64 dwords cover the usual
-        // footprint; a larger one takes further rounds)
-        for (int i0 = 0; i0 < nd * rows; i0 += 64 * PD_NLOAD) {
+        // footprint; a larger one takes further rounds).  Element i = lane + 64 j of the (rows x nd) footprint is
+        // walked incrementally - 64 elements further is dy rows and dx dwords further, one more row on wrap-around -
+        // so a load costs a few full-rate adds instead of a division and 64-bit address arithmetic.
+        const int n = nd * rows;
+        const unsigned ndMagic = div_magic_of((unsigned)nd);
+        const int dy = div_by(64, ndMagic), dx = 64 - dy * nd;
+        int x = lane - div_by(lane, ndMagic) * nd;
+        unsigned gOff = (unsigned)(div_by(lane, ndMagic) * spitch + 4 * x);
+        int lOff = div_by(lane, ndMagic) * ldsPitch + 4 * x;
+        const unsigned gStep = (unsigned)(dy * spitch + 4 * dx), gStepW = gStep + (unsigned)(spitch - 4 * nd);
+        const int lStep = dy * ldsPitch + 4 * dx, lStepW = lStep + ldsPitch - 4 * nd;
+        for (int i0 = 0; i0 < n; i0 += 64 * PD_NLOAD) {
             unsigned v[PD_NLOAD];
             int off[PD_NLOAD];
 #pragma unroll
             for (int k = 0; k < PD_NLOAD; k++) {
-                const int i = i0 + 64 * k + lane;
-                const int y = div_by(min(i, nd * rows - 1), ndMagic), x = min(i, nd * rows - 1) - y * nd;
-                off[k] = i < nd * rows ? y * ldsPitch + 4 * x : -1;
-                v[k] = *(const unsigned *)(src + (size_t)y * spitch + 4 * x);
+                const bool ok = i0 + 64 * k + lane < n;
+                off[k] = ok ? lOff : -1;
+                v[k] = ok ? gload<unsigned>(src + gOff) : 0u;
+                x += dx;
+                const bool wrap = x >= nd;
+                x -= wrap ? nd : 0;
+                gOff += wrap ? gStepW : gStep;
+                lOff += wrap ? lStepW : lStep;
             }
 #pragma unroll
             for (int k = 0; k < PD_NLOAD; k++)
@@ -152,7 +201,7 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
         const uint8_t *src = S + (size_t)sya * spitch + sxa;
         for (int i = lane; i < cw * rows; i += 64) {
             const int y = div_by(i, cwMagic), x = i - y * cw;
-            smem[y * ldsPitch + x] = src[(size_t)y * spitch + x];
+            smem[y * ldsPitch + x] = gload<uint8_t>(src + (size_t)y * spitch + x);
         }
     }
     wave_lds_sync();
@@ -170,7 +219,7 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int dxk = min(bx + k, dx1);
-                const uint8_t *r0 = T + (2 * dy - sya) * ldsPitch + (2 * dxk - sxa), *r1 = r0 + ldsPitch;
+                const uint8_t *r0 = T + __mul24(2 * dy - sya, ldsPitch) + (2 * dxk - sxa), *r1 = r0 + ldsPitch;
                 pk |= (unsigned)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2) << (8 * k);
             }
             *(unsigned *)(outBase + (size_t)dy * D.pitch) = pk;
@@ -188,13 +237,14 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
         const int dy = by + j;
         if (dy > dy1) break;
         const int sy0 = min(max((int)yt[j].s, 0), sh - 1) - sya, sy1 = min(max((int)yt[j].s + 1, 0), sh - 1) - sya;
-        const uint8_t *r0 = T + sy0 * ldsPitch, *r1 = T + sy1 * ldsPitch;
+        const uint8_t *r0 = T + __mul24(sy0, ldsPitch), *r1 = T + __mul24(sy1, ldsPitch);
         unsigned pk = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int h0 = r0[cx0[k]] * xt[k].a0 + r0[cx1[k]] * xt[k].a1;
             const int h1 = r1[cx0[k]] * xt[k].a0 + r1[cx1[k]] * xt[k].a1;
-            pk |= (unsigned)((((yt[j].a0 * (h0 >> 4)) >> 16) + ((yt[j].a1 * (h1 >> 4)) >> 16) + 2) >> 2) << (8 * k);
+            // weights <= 2^11 and h >> 4 < 2^15: 24-bit multiplies (full rate; the 32-bit v_mul_lo is quarter rate)
+            pk |= (unsigned)(((vmul24((int)yt[j].a0, h0 >> 4) >> 16) + (vmul24((int)yt[j].a1, h1 >> 4) >> 16) + 2) >> 2) << (8 * k);
         }
         *(unsigned *)(outBase + (size_t)dy * D.pitch) = pk;
     }
@@ -321,29 +371,49 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     if (alignedLoads) {
         ax = iniX & 3;
         const int nd = (tw + ax + 3) >> 2;
-        const unsigned ndMagic = div_magic_of((unsigned)nd);
         const uint8_t *src = img + (size_t)iniY * pitch + (iniX - ax);
-        // every load of the tile is issued before the first LDS store (9 x 64 dwords cover a 48-pitch tile)
-        for (int i0 = 0; i0 < nd * th; i0 += 64 * 9) {
-            unsigned v[9];
-            int off[9];
+        if constexpr (TP != 0) {
+            // fixed (row, dword) per lane: TP/4 dwords span a tile row, 64 / (TP/4) rows per trip, so a trip is one load
+            // at a scalar row base plus a constant lane offset and one LDS store at an immediate - no per-load
+            // division or 64-bit arithmetic.  Nine trips are in flight before the first LDS store.
+            constexpr int DW = TP / 4, RPT = 64 / DW;
+            const int rr = lane / DW, cc = lane - rr * DW;
+            const bool laneOn = rr < RPT && cc < nd;
+            const unsigned laneOff = (unsigned)(rr * pitch + 4 * cc);
+            unsigned *tileLane = (unsigned *)tile + rr * DW + cc;
+            for (int r0 = 0; r0 < th; r0 += 9 * RPT) {
+                unsigned v[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const int i = i0 + 64 * k + lane, ic = min(i, nd * th - 1);
-                const int y = div_by(ic, ndMagic), x = ic - y * nd;
-                off[k] = i < nd * th ? y * tp + 4 * x : -1;
-                v[k] = *(const unsigned *)(src + (size_t)y * pitch + 4 * x);
+                for (int k = 0; k < 9; k++)
+                    v[k] = (laneOn && r0 + k * RPT + rr < th) ? gload<unsigned>(src + (size_t)(r0 + k * RPT) * pitch + laneOff) : 0u;
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if (laneOn && r0 + k * RPT + rr < th) tileLane[(r0 + k * RPT) * DW] = v[k];
             }
+        } else {
+            const unsigned ndMagic = div_magic_of((unsigned)nd);
+            // every load of the tile is issued before the first LDS store
+            for (int i0 = 0; i0 < nd * th; i0 += 64 * 9) {
+                unsigned v[9];
+                int off[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++)
-                if (off[k] >= 0) *(unsigned *)(tile + off[k]) = v[k];
+                for (int k = 0; k < 9; k++) {
+                    const int i = i0 + 64 * k + lane, ic = min(i, nd * th - 1);
+                    const int y = div_by(ic, ndMagic), x = ic - y * nd;
+                    off[k] = i < nd * th ? y * tp + 4 * x : -1;
+                    v[k] = gload<unsigned>(src + (size_t)y * pitch + 4 * x);
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if (off[k] >= 0) *(unsigned *)(tile + off[k]) = v[k];
+            }
         }
     } else {
         const unsigned twMagic = div_magic_of((unsigned)tw);
         const uint8_t *src = img + (size_t)iniY * pitch + iniX;
         for (int i = lane; i < tw * th; i += 64) {
             const int y = div_by(i, twMagic), x = i - y * tw;
-            tile[y * tp + x] = src[(size_t)y * pitch + x];
+            tile[y * tp + x] = gload<uint8_t>(src + (size_t)y * pitch + x);
         }
     }
     for (int i = lane; i < (tp * (ph + 2)) >> 2; i += 64) ((unsigned *)score)[i] = 0;
@@ -355,6 +425,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     // candidate ring.  B (whenever the ring fills, and at the end): score = largest threshold at which
     // the pixel is still a corner (cornerScore<16>); corner at minThFAST <=> score >= minThFAST.
     int nc = 0, ncorn = 0;
+    // A pixel of the tested region travels through the candidate ring and the corner list as a 16-bit code: with a
+    // fixed pitch (pw < 64) that is (y << 6 | x), packed and unpacked with a shift and a mask; the any-size variant
+    // keeps the linear index y * pw + x and pays a division per unpack.
+    auto pixCode = [&](int y, int x) -> int { return TP > 0 ? ((y << 6) | x) : y * pw + x; };
+    auto pixY = [&](int code) -> int { return TP > 0 ? code >> 6 : div_by(code, pwMagic); };
+    auto pixX = [&](int code, int y) -> int { return TP > 0 ? (code & 63) : code - y * pw; };
     // phase B over the buffered candidates: score, corner list (row-major), ring reset
     auto flushB = [&]() {
         wave_lds_sync();
@@ -364,7 +440,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             int ci2 = 0;
             if (j < nc) {
                 ci2 = cand[j];
-                const int y = div_by(ci2, pwMagic), x = ci2 - y * pw;
+                const int y = pixY(ci2), x = pixX(ci2, y);
                 const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
                 const int v = cpx[0];
                 int d[16];
@@ -436,7 +512,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
                     const bool pass = min(m01[k], min(m2, m3)) > (unsigned)minTh;
                     const unsigned long long b = __ballot(pass);
                     if (!b) continue;  // wave-uniform
-                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)((y0h + y + k) * pw + cx);
+                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)pixCode(y0h + y + k, cx);
                     nc += __popcll(b);
                 }
             }
@@ -460,7 +536,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
                     const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
                     const bool pass = min(m01r, min(m2, m3)) > (unsigned)minTh;
                     const unsigned long long b = __ballot(pass);
-                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)(yy * pw + xx);
+                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)pixCode(yy, xx);
                     nc += __popcll(b);
                 }
                 if (nc > FC_CAND - 64) flushB();  // wave-uniform
@@ -513,7 +589,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
                     const bool pass = min(m01[k], min(m2, m3)) > (unsigned)minTh;
                     const unsigned long long b = __ballot(pass);
                     if (!b) continue;  // wave-uniform
-                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)((y + k) * pw + lane);
+                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)pixCode(y + k, lane);
                     nc += __popcll(b);
                 }
             }
@@ -566,8 +642,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     const bool useList = ncorn <= FC_CORN;
     const int nItems = useList ? ncorn : npx;
     auto nms = [&](int item, int &pix) -> int {
-        pix = useList ? (int)corn[item] : item;
-        const int y = div_by(pix, pwMagic), x = pix - y * pw;
+        int y, x;
+        if (useList) {
+            pix = (int)corn[item];
+            y = pixY(pix), x = pixX(pix, y);
+        } else {  // score-plane scan: item is the linear index of the pixel
+            y = div_by(item, pwMagic), x = item - y * pw;
+            pix = pixCode(y, x);
+        }
         const uint8_t *s = score + (y + 1) * tp + (x + 1);
         const int v = s[0];
         const bool keep = v > 0 && v > s[-1] && v > s[1] && v > s[-tp - 1] && v > s[-tp] && v > s[-tp + 1] &&
@@ -580,7 +662,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         const bool f = fl >= need;
         const unsigned long long b = __ballot(f);
         if (f) {
-            const int y = div_by(pix, pwMagic), x = pix - y * pw;
+            const int y = pixY(pix), x = pixX(pix, y);
             const int pos = run + __popcll(b & ((1ull << lane) - 1ull));
             // keypoint (x+3, y+3) in the cell sub-image, shifted by (j*wCell, i*hCell): ORBextractor.cc:1196-1197
             if (pos < L.cellCap)
@@ -728,7 +810,10 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
                                                                const int *selCount, FtOctArgs lay, int *nSel,
                                                                ft_keypoint *keysOut, uint8_t *descOut, FtSlotGrid sg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index is uniform by construction; as a scalar it makes the keypoint lookup below (level search, entry
+    // address, level geometry, image pointer, row addressing) SALU work instead of 64 identical VALU lanes
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int slot, blk;
     if (!ft_slot_block(sg, slot, blk)) return;
     const int k = blk * OD_WAVES + wave;
@@ -764,10 +849,13 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
         const unsigned laneOff = (unsigned)(rr * pitch + 4 * cc);
         unsigned *rawLane = (unsigned *)raw + rr * 12 + cc;
         if (lane < 60) {
+            unsigned v[9];  // all nine row groups requested before the first LDS store
 #pragma unroll
-            for (int it = 0; it < 9; it++) {
-                if (it < 8 || rr < 3) rawLane[it * 60] = *(const unsigned *)(src + (size_t)(it * 5) * pitch + laneOff);
-            }
+            for (int it = 0; it < 9; it++)
+                v[it] = (it < 8 || rr < 3) ? gload<unsigned>(src + (laneOff + (unsigned)(it * 5 * pitch))) : 0u;  // scalar base + 32-bit lane offset
+#pragma unroll
+            for (int it = 0; it < 9; it++)
+                if (it < 8 || rr < 3) rawLane[it * 60] = v[it];
         }
     } else {
         // BORDER_REFLECT_101 of the blur at the level's edges (keypoints are >= 19 px inside, the
@@ -776,7 +864,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
         for (int i = lane; i < OD_P * OD_P; i += 64) {
             const int r = i / OD_P, c = i - r * OD_P;
             const int gy = reflect101(py0 + r, h), gx = reflect101(px0 + c, w);
-            raw[r * OD_PP + c] = img[(size_t)gy * pitch + gx];
+            raw[r * OD_PP + c] = gload<uint8_t>(img + (size_t)gy * pitch + gx);
         }
     }
     wave_lds_sync();
@@ -797,14 +885,11 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
             const unsigned dw = __builtin_amdgcn_udot4(D, c_mom.W[av * 8 + jd], 0u, false);
             const unsigned dm = __builtin_amdgcn_udot4(D, c_mom.M[av * 8 + jd], 0u, false);
             m10 += (int)dw - 16 * (int)dm;
-            m01 += v * (int)dm;
+            m01 += __mul24(v, (int)dm);  // |v| <= 16, dm <= 4 * 255 * 15
             v += 8;
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            m10 += __shfl_xor(m10, o);
-            m01 += __shfl_xor(m01, o);
-        }
+        m10 = wave_sum_i32(m10);
+        m01 = wave_sum_i32(m01);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // horizontal 7-tap pass on the packed bytes: a task = (row, aligned group of 4 raw byte positions);
@@ -831,8 +916,8 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
                 unsigned h3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1,
                                                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
                 uint2 pk;
-                pk.x = h0 | (h1 << 16);
-                pk.y = h2 | (h3 << 16);
+                pk.x = __builtin_amdgcn_perm(h1, h0, 0x05040100u);  // h0 | h1 << 16 (both < 2^16) in one instruction
+                pk.y = __builtin_amdgcn_perm(h3, h2, 0x05040100u);
                 *(uint2 *)(hbLane + it * 6 * OD_HP) = pk;
             }
         }
@@ -842,27 +927,36 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = __fmul_rn(angle, factorPI);
     double sd, cd;
-    sincos((double)ar, &sd, &cd);
+    ft_sincos_0_2pi((double)ar, sd, cd);
     const float ca = (float)cd, sb = (float)sd;
     // vertical 7-tap pass only where the pattern samples (512 of the 1369 window positions): the blurred
     // pixel at offset (r, c) from the keypoint is (sum_s k[s] * hb[18 + r + s][ax + 18 + c] + 2^15) >> 16
-    const unsigned short *hcol = hb + ax + 18;
-    auto blurred = [&](int r, int c) -> int {
-        const unsigned short *p = hcol + (18 + r) * OD_HP + c;
-        const unsigned v = 18u * ((unsigned)p[0] + p[6 * OD_HP]) + 34u * ((unsigned)p[OD_HP] + p[5 * OD_HP]) +
-                           48u * ((unsigned)p[2 * OD_HP] + p[4 * OD_HP]) + 56u * (unsigned)p[3 * OD_HP];
-        return (int)((v + 32768u) >> 16);
+    // LDS byte offset of hb[18 + r][ax + 18 + c] = r * 80 + (2 c + hbase): one shift-add and one 24-bit multiply-add;
+    // the seven taps are immediates from there, combined with 24-bit multiply-adds (sums stay below 2^24)
+    const int hbase = (int)((const uint8_t *)(hb + 18 * OD_HP + ax + 18) - smem);
+    auto blurred = [&](int r, int c) -> unsigned {
+        const unsigned short *p = (const unsigned short *)(smem + vmad24(r, 2 * OD_HP, (c << 1) + hbase));
+        unsigned v;
+        asm("v_mad_u32_u24 %0, %1, 18, %2" : "=v"(v) : "v"((unsigned)p[0] + p[6 * OD_HP]), "s"(32768u));
+        asm("v_mad_u32_u24 %0, %1, 34, %2" : "=v"(v) : "v"((unsigned)p[OD_HP] + p[5 * OD_HP]), "v"(v));
+        asm("v_mad_u32_u24 %0, %1, 48, %2" : "=v"(v) : "v"((unsigned)p[2 * OD_HP] + p[4 * OD_HP]), "v"(v));
+        asm("v_mad_u32_u24 %0, %1, 56, %2" : "=v"(v) : "v"((unsigned)p[3 * OD_HP]), "v"(v));
+        return v >> 16;
     };
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f scPair = {sb, ca}, csPair = {ca, sb};
     unsigned long long words[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int p = q * 64 + lane;  // pair index: byte p/8, bit p%8
         const float4 pt = c_patternF.p[p];
-        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
+        // (x, y) pairs times (sin, cos) and (cos, sin) pairs: packed fp32 multiplies, every product rounded on its own
+        const v2f p0 = {pt.x, pt.y}, p1 = {pt.z, pt.w};
+        const v2f a0 = p0 * scPair, b0 = p0 * csPair, a1 = p1 * scPair, b1 = p1 * csPair;
+        const int r0 = __float2int_rn(__fadd_rn(a0.x, a0.y));  // x0 sin + y0 cos
+        const int c0 = __float2int_rn(__fsub_rn(b0.x, b0.y));  // x0 cos - y0 sin
+        const int r1 = __float2int_rn(__fadd_rn(a1.x, a1.y));
+        const int c1 = __float2int_rn(__fsub_rn(b1.x, b1.y));
         words[q] = __ballot(blurred(r0, c0) < blurred(r1, c1));
     }
     if (lane == 0) {
