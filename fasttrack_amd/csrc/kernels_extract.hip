@@ -6,6 +6,7 @@
 //   k_orient_desc  IC_Angle + 7x7 fixed-point blur + rBRIEF       (ORBextractor.cc:39-108,1456-1462, A.2/A.4/A.6/A.7)
 #include "ft_internal.h"
 #include "sincos_poly.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -59,41 +60,6 @@ __constant__ FtPatternF c_patternF = ft_make_pattern_f();
 // d == 1 makes the magic wrap to 0, so it is special-cased.
 __device__ __forceinline__ unsigned div_magic_of(unsigned d) { return d > 1 ? 0xffffffffu / d + 1u : 0u; }
 __device__ __forceinline__ int div_by(int i, unsigned magic) { return magic ? (int)__umulhi((unsigned)i, magic) : i; }
-
-// Image rows are read through explicit global-address-space loads: a level's base pointer is either loaded from the
-// frame-pointer array or derived from a kernel argument, which leaves the compiler with a generic pointer and
-// flat_load - and a flat load counts on the LDS counter as well, so every LDS wait would also wait for image loads.
-template <class T>
-__device__ __forceinline__ T gload(const void *p) {
-    return *(const __attribute__((address_space(1))) T *)p;
-}
-
-// Sum of an int over the 64 lanes, returned wave-uniform: four DPP adds (lane pairs, quads, half rows, rows of 16) and
-// one v_readlane per row, instead of six shuffles through the LDS crossbar with their address arithmetic.
-__device__ __forceinline__ int wave_sum_i32(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
-           __builtin_amdgcn_readlane(v, 48);
-}
-
-// Low 32 bits of the product of two operands that fit 24 bits, as ONE full-rate instruction.  (__mul24 is dissolved
-// into a plain multiply once the optimiser has proven the operand ranges, and instruction selection then falls back
-// to the quarter-rate 32-bit v_mul_lo_u32 whenever it cannot re-derive them.)
-__device__ __forceinline__ int vmul24(int a, int b) {
-    int r;
-    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// a * b + c with 24-bit a, b: one full-rate instruction (b wave-uniform)
-__device__ __forceinline__ int vmad24(int a, int bUniform, int c) {
-    int r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(bUniform), "v"(c));
-    return r;
-}
 
 __device__ __forceinline__ const uint8_t *level_ptr(const FtGeom &g, int level, int slot, const uint8_t *const *l0,
                                                     int l0pitch, const uint8_t *pyr, int &pitch) {
@@ -813,7 +779,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is uniform by construction; as a scalar it makes the keypoint lookup below (level search, entry
     // address, level geometry, image pointer, row addressing) SALU work instead of 64 identical VALU lanes
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_index();
     int slot, blk;
     if (!ft_slot_block(sg, slot, blk)) return;
     const int k = blk * OD_WAVES + wave;

@@ -6,6 +6,7 @@
 //   k_fisheye_2nn    BFMatcher knnMatch(k=2)+ratio (src/Frame.cc:1231-1255)
 //   k_hamming_pairs  ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2256-2272)
 #include "ft_internal.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -23,22 +24,11 @@ __device__ __forceinline__ int hamming256(const unsigned long long a[4], const u
     return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
 }
 
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
 // One wave per left keypoint.
 __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *const *l0L, const uint8_t *const *l0R,
                                                       int l0pitchL, int l0pitchR, const uint8_t *pyrL,
                                                       const uint8_t *pyrR, FtStereoArgs a, FtSlotGrid sg) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_index();  // scalar: the left keypoint's data become SALU / s_load work
     int slot, blk;
     if (!ft_slot_block(sg, slot, blk)) return;
     const int iL = blk * 4 + wave;
@@ -117,15 +107,15 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
             // 11x11 left patch: each lane owns pixels lane and lane+64 (< 121)
             const int p0 = lane, p1 = lane + 64;
             const int r0 = p0 / 11, c0 = p0 - r0 * 11, r1 = p1 / 11, c1 = p1 - r1 * 11;
-            const int a0 = imL[(size_t)(yl0 + r0) * pitchL + xl0 + c0];
-            const int a1 = p1 < 121 ? imL[(size_t)(yl0 + r1) * pitchL + xl0 + c1] : 0;
+            const int a0 = gload<uint8_t>(imL + (size_t)(yl0 + r0) * pitchL + xl0 + c0);
+            const int a1 = p1 < 121 ? gload<uint8_t>(imL + (size_t)(yl0 + r1) * pitchL + xl0 + c1) : 0;
             int bestS = 0x7fffffff, bestinc = 0;
             float dists[11];
 #pragma unroll
             for (int s = 0; s < 11; s++) {
                 const int xr = xr00 + s;
-                int d = abs(a0 - (int)imR[(size_t)(yl0 + r0) * pitchR + xr + c0]);
-                if (p1 < 121) d += abs(a1 - (int)imR[(size_t)(yl0 + r1) * pitchR + xr + c1]);
+                int d = abs(a0 - (int)gload<uint8_t>(imR + (size_t)(yl0 + r0) * pitchR + xr + c0));
+                if (p1 < 121) d += abs(a1 - (int)gload<uint8_t>(imR + (size_t)(yl0 + r1) * pitchR + xr + c1));
                 d = wave_sum_i32(d);
                 dists[s] = (float)d;
                 if (d < bestS) {
@@ -280,7 +270,7 @@ __global__ __launch_bounds__(64) void k_stereo_median(FtStereoArgs a) {
 // (distance, index) keys of the wave are the reference's (best, second) with earlier index first.
 __global__ __launch_bounds__(256) void k_fisheye_2nn(const uint8_t *descL, int nL, const uint8_t *descR, int nR,
                                                      int *matches, int *bestOut, int *secondOut) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_index();
     const int i = blockIdx.x * 4 + wave;
     if (i >= nL) return;
     unsigned long long q[4];

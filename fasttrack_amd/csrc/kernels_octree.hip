@@ -301,9 +301,11 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     const OctLds o = oct_lds_layout(cap);
     unsigned long long *keys = (unsigned long long *)(smem + o.keys);  // code << 32 | index
     const uint32_t *codes = (const uint32_t *)keys;                     // codes[2 * i + 1] = code << 4 | response >> 4
-    uint32_t *lohiB[2] = {(uint32_t *)(smem + o.lohi[0]), (uint32_t *)(smem + o.lohi[1])};
-    uint32_t *x01B[2] = {(uint32_t *)(smem + o.x01[0]), (uint32_t *)(smem + o.x01[1])};
-    uint8_t *depB[2] = {smem + o.dep[0], smem + o.dep[1]};
+    // the two copies of the node list are addressed as smem + offset (never through an array of pointers: that loses
+    // the LDS address space and turns every node access into a flat instruction)
+    auto lohiOf = [&](int b) -> uint32_t * { return (uint32_t *)(smem + (b ? o.lohi[1] : o.lohi[0])); };
+    auto x01Of = [&](int b) -> uint32_t * { return (uint32_t *)(smem + (b ? o.x01[1] : o.x01[0])); };
+    auto depOf = [&](int b) -> uint8_t * { return smem + (b ? o.dep[1] : o.dep[0]); };
     SortElem *vSize = (SortElem *)(smem + o.vSize);
     SortElem *vPrev = (SortElem *)(smem + o.vPrev);
     uint16_t *ord = (uint16_t *)(smem + o.ord);
@@ -386,9 +388,9 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
             const int pos = start + m + __popcll(bal & ((1ull << lane) - 1));
             int x0, x1;
             ft::op::root_bounds(R, s, x0, x1);
-            lohiB[0][pos] = (uint32_t)lo | ((uint32_t)hi << 16);
-            x01B[0][pos] = (uint32_t)x0 | ((uint32_t)x1 << 16);
-            depB[0][pos] = 0;
+            lohiOf(0)[pos] = (uint32_t)lo | ((uint32_t)hi << 16);
+            x01Of(0)[pos] = (uint32_t)x0 | ((uint32_t)x1 << 16);
+            depOf(0)[pos] = 0;
         }
         m += __popcll(bal);
     }
@@ -396,10 +398,10 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     int nV = 0;
     // splits the nodes ord[0..nOrd) of the current list in that order (with useStop: until the list holds N)
     auto split_round = [&](int nOrd, bool useStop) {
-        const uint32_t *cl = lohiB[curB], *cx = x01B[curB];
-        const uint8_t *cd = depB[curB];
-        uint32_t *nl = lohiB[curB ^ 1], *nx = x01B[curB ^ 1];
-        uint8_t *ndp = depB[curB ^ 1];
+        const uint32_t *cl = lohiOf(curB), *cx = x01Of(curB);
+        const uint8_t *cd = depOf(curB);
+        uint32_t *nl = lohiOf(curB ^ 1), *nx = x01Of(curB ^ 1);
+        uint8_t *ndp = depOf(curB ^ 1);
         // pass A: boundaries, child counts, prefixes, stop
         int carryP = 0, carryQ = 0, cum = m, nproc = nOrd;
         for (int r0 = 0; r0 < nOrd; r0 += 64) {
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
         // breadth-first pass (:719-797): every node with more than one key is split, in list order
         int nOrd = 0;
         {
-            const uint32_t *cl = lohiB[curB];
+            const uint32_t *cl = lohiOf(curB);
             for (int t0 = start; t0 < start + m; t0 += 64) {
                 const int t = t0 + lane;
                 bool big = false;
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     tick();  // 2: rounds
     // ---- 4. per retained node: largest response, earliest original index on ties ----
     const int kept = min(m, a.levelMax[level]);
-    const uint32_t *cl = lohiB[curB];
+    const uint32_t *cl = lohiOf(curB);
     FtSelKp *out = a.sel + (size_t)slot * g.maxKp + a.selOff[level];
     for (int t = lane; t < kept; t += 64) {
         const unsigned lh = cl[start + t];

@@ -16,22 +16,12 @@
 // after at most i+1 passes and the iteration stops when a pass changes nothing - the unique fixed
 // point is the sequential result.
 #include "ft_search.h"
+#include "wave_ops.h"
 
 namespace {
 
 __device__ __forceinline__ int hamming256(const unsigned long long a[4], const unsigned long long *b) {
     return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
-}
-
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o);
-        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o);
-        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
-        v = w < v ? w : v;
-    }
-    return v;
 }
 
 #define KEY_NONE 0xffffffffffffffffull
@@ -96,7 +86,7 @@ __device__ __forceinline__ bool in_area(const FtDevFrame &F, const ft_keypoint &
 __global__ __launch_bounds__(256) void k_features_in_area(FtDevFrame F, int nq, const float *qx, const float *qy, const float *qr,
                                                           const int *qmin, const int *qmax, const uint8_t *qright,
                                                           const int *offsets, unsigned *outKeys, int *outCount) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_index();
     const int q = blockIdx.x * 4 + wave;
     if (q >= nq) return;
     const float x = qx[q], y = qy[q], r = qr[q];
@@ -135,7 +125,7 @@ __device__ __forceinline__ void wave_two_min(unsigned long long &k0, unsigned lo
 
 __global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPoints P, FtClaims C, float th,
                                                       float nnRatio, int *res, FtLocalRaw raw) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_index();
     const int i = blockIdx.x * 4 + wave;
     if (i >= P.M) return;
     int primL = -1, sideL = -1, primR = -1, sideR = -1;
@@ -277,7 +267,7 @@ __device__ __forceinline__ void transform34(const float *T, const float x[3], fl
 
 __global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoints Lp, FtClaims C, FtPose Tcw, float th,
                                                      int bForward, int bBackward, int *res, FtLastRaw raw) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_index();
     const int i = blockIdx.x * 4 + wave;
     if (i >= Lp.N) return;
     int primL = -1, primR = -1;
