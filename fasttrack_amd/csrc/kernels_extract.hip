@@ -93,7 +93,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // before anything waits.
 __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint8_t *const *l0, int l0pitch,
                                                  uint8_t *pyr, const FtTap *taps, int alignedLoads, int ldsPitch,
-                                                 unsigned sxQ16, unsigned syQ16) {
+                                                 int rowsAlloc, unsigned sxQ16, unsigned syQ16) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
     const int slot = blockIdx.z;
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
         // walked incrementally - 64 elements further is dy rows and dx dwords further, one more row on wrap-around -
         // so a load costs a few full-rate adds instead of a division and 64-bit address arithmetic.
         const int n = nd * rows;
+        const int spare = ldsPitch * rowsAlloc;  // one dword behind the tile (see the launcher)
         const unsigned ndMagic = div_magic_of((unsigned)nd);
         const int dy = div_by(64, ndMagic), dx = 64 - dy * nd;
         int x = lane - div_by(lane, ndMagic) * nd;
@@ -148,9 +149,11 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
             int off[PD_NLOAD];
 #pragma unroll
             for (int k = 0; k < PD_NLOAD; k++) {
+                // lanes past the footprint re-read its first dword and park it in the spare dword behind the tile:
+                // selects instead of exec-mask branches around every load and store
                 const bool ok = i0 + 64 * k + lane < n;
-                off[k] = ok ? lOff : -1;
-                v[k] = ok ? gload<unsigned>(src + gOff) : 0u;
+                off[k] = ok ? lOff : spare;
+                v[k] = gload<unsigned>(src + (ok ? gOff : 0u));
                 x += dx;
                 const bool wrap = x >= nd;
                 x -= wrap ? nd : 0;
@@ -158,8 +161,7 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
                 lOff += wrap ? lStepW : lStep;
             }
 #pragma unroll
-            for (int k = 0; k < PD_NLOAD; k++)
-                if (off[k] >= 0) *(unsigned *)(smem + off[k]) = v[k];
+            for (int k = 0; k < PD_NLOAD; k++) *(unsigned *)(smem + off[k]) = v[k];
         }
     } else {
         const int cw = sxb - sxa + 1;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
     wave_lds_sync();
     const uint8_t *T = smem + ax;  // source pixel (sx, sy) at T[(sy - sya) * ldsPitch + (sx - sxa)]
     if (bx > dx1 || by > dy1) return;
-    uint8_t *outBase = pyr + (size_t)slot * g.pyrPerSlot + D.off + bx;
+    // uniform level base + 32-bit lane offset (row * pitch + column): scalar-base stores, no 64-bit lane arithmetic
+    uint8_t *outLevel = pyr + (size_t)slot * g.pyrPerSlot + D.off;
     // the row pitch of a level is a multiple of 64 B, so the dword store may run past the last column of the level
     // (into the row's padding) but never into the next row
     if (D.area2x) {
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
                 const uint8_t *r0 = T + __mul24(2 * dy - sya, ldsPitch) + (2 * dxk - sxa), *r1 = r0 + ldsPitch;
                 pk |= (unsigned)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2) << (8 * k);
             }
-            *(unsigned *)(outBase + (size_t)dy * D.pitch) = pk;
+            gstore<unsigned>(outLevel + (unsigned)vmad24(dy, D.pitch, bx), pk);
         }
         return;
     }
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
             // weights <= 2^11 and h >> 4 < 2^15: 24-bit multiplies (full rate; the 32-bit v_mul_lo is quarter rate)
             pk |= (unsigned)(((vmul24((int)yt[j].a0, h0 >> 4) >> 16) + (vmul24((int)yt[j].a1, h1 >> 4) >> 16) + 2) >> 2) << (8 * k);
         }
-        *(unsigned *)(outBase + (size_t)dy * D.pitch) = pk;
+        gstore<unsigned>(outLevel + (unsigned)vmad24(dy, D.pitch, bx), pk);
     }
 }
 
@@ -339,22 +342,22 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         const int nd = (tw + ax + 3) >> 2;
         const uint8_t *src = img + (size_t)iniY * pitch + (iniX - ax);
         if constexpr (TP != 0) {
-            // fixed (row, dword) per lane: TP/4 dwords span a tile row, 64 / (TP/4) rows per trip, so a trip is one load
-            // at a scalar row base plus a constant lane offset and one LDS store at an immediate - no per-load
-            // division or 64-bit arithmetic.  Nine trips are in flight before the first LDS store.
+            // fixed (row, dword) per lane: TP/4 dwords span a tile row, 64 / (TP/4) rows per trip.  Rows and dwords beyond
+            // the tile are clamped to its last row / dword instead of being masked: such a lane loads and stores the
+            // same element as the lane that owns it, so the whole copy is branch-free - no per-load division, no 64-bit
+            // arithmetic, no exec-mask bookkeeping.  Nine trips are in flight before the first LDS store.
             constexpr int DW = TP / 4, RPT = 64 / DW;
-            const int rr = lane / DW, cc = lane - rr * DW;
-            const bool laneOn = rr < RPT && cc < nd;
-            const unsigned laneOff = (unsigned)(rr * pitch + 4 * cc);
-            unsigned *tileLane = (unsigned *)tile + rr * DW + cc;
+            const int rr = lane / DW, cc4 = 4 * min(lane - rr * DW, nd - 1);
             for (int r0 = 0; r0 < th; r0 += 9 * RPT) {
                 unsigned v[9];
+                int row[9];
 #pragma unroll
-                for (int k = 0; k < 9; k++)
-                    v[k] = (laneOn && r0 + k * RPT + rr < th) ? gload<unsigned>(src + (size_t)(r0 + k * RPT) * pitch + laneOff) : 0u;
+                for (int k = 0; k < 9; k++) {
+                    row[k] = min(r0 + k * RPT + rr, th - 1);
+                    v[k] = gload<unsigned>(src + (unsigned)vmad24(row[k], pitch, cc4));
+                }
 #pragma unroll
-                for (int k = 0; k < 9; k++)
-                    if (laneOn && r0 + k * RPT + rr < th) tileLane[(r0 + k * RPT) * DW] = v[k];
+                for (int k = 0; k < 9; k++) *(unsigned *)(tile + vmad24(row[k], TP, cc4)) = v[k];
             }
         } else {
             const unsigned ndMagic = div_magic_of((unsigned)nd);
@@ -980,8 +983,8 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
         const unsigned sxQ16 = (unsigned)(((unsigned long long)P.w << 16) / (unsigned)D.w) + 1u;
         const unsigned syQ16 = (unsigned)(((unsigned long long)P.h << 16) / (unsigned)D.h) + 1u;
         dim3 grid((D.w + PD_TW - 1) / PD_TW, (D.h + PD_TH - 1) / PD_TH, batch), block(64, 1, 1);
-        hipLaunchKernelGGL(k_pyr_down, grid, block, (size_t)ldsPitch * rowsN, st, g, level, l0, l0pitch, pyr, taps,
-                           alignedLoads, ldsPitch, sxQ16, syQ16);
+        hipLaunchKernelGGL(k_pyr_down, grid, block, (size_t)ldsPitch * rowsN + 4, st, g, level, l0, l0pitch, pyr, taps,
+                           alignedLoads, ldsPitch, rowsN, sxQ16, syQ16);
     }
     FT_HIP(hipGetLastError());
     return FT_OK;

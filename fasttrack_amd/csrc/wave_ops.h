@@ -12,6 +12,11 @@ __device__ __forceinline__ T gload(const void *p) {
     return *(const __attribute__((address_space(1))) T *)p;
 }
 
+template <class T>
+__device__ __forceinline__ void gstore(void *p, T v) {
+    *(__attribute__((address_space(1))) T *)p = v;
+}
+
 // The wave index of a thread, as a scalar: it is uniform by construction, which the compiler cannot see (it derives
 // from threadIdx); with it everything a one-item-per-wave kernel looks up for its item becomes SALU work and scalar
 // loads instead of 64 identical VALU lanes.
