@@ -241,27 +241,29 @@ __device__ __forceinline__ bool has_arc9(unsigned m) {
     F(9, -1, -3) F(10, -2, -2) F(11, -3, -1) F(12, -3, 0) F(13, -3, 1) F(14, -2, 2) F(15, -1, 3)
 
 __device__ __forceinline__ int fast_score(const int d[16]) {
-    // score = max over the 16 arcs of 9 of min(d) (either polarity) - 1  == cornerScore<16> for corners
-    int mn2[16], mx2[16];
+    // score = max over the 16 arcs of 9 of min(d) (either polarity) - 1  == cornerScore<16> for corners.
+    // Arc minima from runs of three: min9[k] = min3(min3[k], min3[k+3], min3[k+6]) - v_min3 / v_max3 make every line
+    // below one instruction per element (64 for both polarities, plus 16 for the two final reductions).
+    int mn3[16], mx3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        mn2[k] = min(d[k], d[(k + 1) & 15]);
-        mx2[k] = max(d[k], d[(k + 1) & 15]);
+        mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
     }
-    int mn4[16], mx4[16];
+    int mn9[16], mx9[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        mn4[k] = min(mn2[k], mn2[(k + 2) & 15]);
-        mx4[k] = max(mx2[k], mx2[(k + 2) & 15]);
+        mn9[k] = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
+        mx9[k] = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
     }
-    int best = -256, worst = 256;
+    int best = max(max(mn9[0], mn9[1]), mn9[2]), worst = min(min(mx9[0], mx9[1]), mx9[2]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-        best = max(best, mn9);
-        worst = min(worst, mx9);
+    for (int k = 3; k < 15; k += 2) {
+        best = max(max(best, mn9[k]), mn9[k + 1]);
+        worst = min(min(worst, mx9[k]), mx9[k + 1]);
     }
+    best = max(best, mn9[15]);
+    worst = min(worst, mx9[15]);
     return max(best, -worst) - 1;
 }
 
