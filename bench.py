@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="stereo_1280x720_nf2000", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=128, help="stereo pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="stereo pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

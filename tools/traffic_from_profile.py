@@ -25,7 +25,7 @@ def main(summary, out, images_per_step=256, steps=7):
         e["traffic_bytes_per_launch"] = (e.get("fetch_kb", 0) * f + e.get("write_kb", 0)) * 1024
     for k, e in d.items():  # images one launch covers (bench under the profiler: `steps` passes over the batch)
         e["images_per_launch"] = images_per_step * steps / e["launches"] if e["launches"] else None
-    json.dump({"source": summary, "note": "per launch; default bench (128 pairs of 1280x720 per step, %d steps profiled)" % steps,
+    json.dump({"source": summary, "note": "per launch; default bench (%d pairs of 1280x720 per step, %d steps profiled)" % (images_per_step // 2, steps),
                "kernels": d}, open(out, "w"), indent=1)
     print(json.dumps(d.get("k_fast_cells"), indent=1))
 
