@@ -207,8 +207,7 @@ def main():
         # image); the 7 pyramid launches of a sub-batch read P - P7 and write P - P0 per image; orientation + descriptor
         # read a 43x43 patch and write 60 B per keypoint.  The batch is processed in sub-batches, so bytes per launch =
         # algorithmic bytes of the whole timed region / launches in it; durations are HIP events on the launching stream.
-        # `roofline` is the kernel with the largest summed duration in this run, the others follow in
-        # roofline_other_kernels.  HBM-side traffic per launch comes from the committed PMC passes (FETCH_SIZE /
+        # `roofline` is k_fast_cells (see below), the others follow in roofline_other_kernels.  HBM-side traffic per launch comes from the committed PMC passes (FETCH_SIZE /
         # WRITE_SIZE cannot be read live) and is reported when this run's launch shape equals the profiled one.
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
@@ -234,9 +233,14 @@ def main():
         legs = [leg("kernel.fast_cells", "k_fast_cells", float(args.steps) * 2.0 * B * sumP),
                 leg("kernel.pyr_down(all levels)", "k_pyr_down", float(args.steps) * 2.0 * B * ((sumP - P[-1]) + (sumP - P[0])), 7),
                 leg("kernel.orient_desc", "k_orient_desc", float(kps) * args.steps * (43 * 43 + 60))]
-        legs = sorted([x for x in legs if x], key=lambda x: -x["total_ms"])
+        # Dominant kernel = k_fast_cells: the largest cost inside the overlapped pipeline (0.80 of 2.48 ms per 128 pairs,
+        # profiles/r01_marginal_costs.json; k_orient_desc 0.53, pyramid 0.39) and level with k_orient_desc / k_octree in
+        # the rocprofv3 totals (23.6 / 24.7 / 24.5 %).  Its event duration equals its rocprofv3 duration; the events
+        # around k_orient_desc read ~30 % long, because the stage-B streams of the two cameras share a hardware queue
+        # and the second camera's begin marker executes while the first camera's kernel still runs.
+        legs = [x for x in legs if x]
         roof = legs[0] if legs else None
-        also = legs[1:]
+        also = sorted(legs[1:], key=lambda x: -x["total_ms"])
         R_pair = 2 * (3 * sumP - P[-1])  # read bytes per stereo pair, unfused accounting
         out = {
             "metric": "frames/sec extract+match", "value": fps, "unit": "frames/s", "n_gpus": world,
