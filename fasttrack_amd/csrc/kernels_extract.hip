@@ -292,7 +292,7 @@ __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int 
     return ((t > f ? t : f) + 15) & ~15;
 }
 __host__ __device__ __forceinline__ int fc_score_bytes(int wCell, int hCell, int TP) { return (((hCell + 2) * fc_pitch(wCell, TP)) + 15) & ~15; }
-__host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + FC_CORN); }
+__host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + FC_CORN) + 16; }  // + the spare entry
 
 // ORDERED = false (device octree, which ranks candidates by their coordinates): the rejection pass is free to
 // visit the pixels in any order and uses all 64 lanes (see below); ORDERED = true delivers every cell's
@@ -435,6 +435,17 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         wave_lds_sync();
         };
 #define FT_AD(ox, oy) __builtin_amdgcn_sad_u8(v, (unsigned)cpx[(oy)*tp + (ox)], 0u)
+    // Appends the lanes of a row whose compass pairs pass to the candidate ring, in lane order, without a branch: the
+    // other lanes store to the spare entry behind the lists.  (The two diagonal pairs used to be tested first; on
+    // textured images that cost more instructions per row than the few candidates it removed cost in phase B, where
+    // a partly filled round of 64 is as expensive as a full one.)
+    auto pushRow = [&](bool pass, int code, int n) -> int {
+        const unsigned long long b = __ballot(pass);
+        const int pos = pass ? n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))
+                             : FC_CAND + FC_CORN;
+        cand[pos] = (unsigned short)code;
+        return n + __popcll(b);
+    };
     if constexpr (TP > 0 && !ORDERED) {
         // Two half-cells side by side: lanes 0-31 walk the rows of the upper half, lanes 32-63 the rows of the lower
         // half, 32 columns each (a 36-pixel-wide cell fills 56 % of a 64-lane row, two 32-wide halves fill it); the
@@ -470,22 +481,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             dA = dSv[FC_ROWS - 3]; dB = dSv[FC_ROWS - 2]; dC = dSv[FC_ROWS - 1];
             pA = pv[FC_ROWS]; pB = pv[FC_ROWS + 1]; pC = pv[FC_ROWS + 2];
             if (__any(mAny > (unsigned)minTh)) {
-                unsigned long long rowAny[FC_ROWS];
 #pragma unroll
-                for (int k = 0; k < FC_ROWS; k++) rowAny[k] = __ballot(m01[k] > (unsigned)minTh);
-#pragma unroll
-                for (int k = 0; k < FC_ROWS; k++) {
-                    if (!rowAny[k]) continue;  // wave-uniform
-                    const unsigned v = pv[k];
-                    const uint8_t *cpx = r + (k + 3) * TP;
-                    const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
-                    const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
-                    const bool pass = min(m01[k], min(m2, m3)) > (unsigned)minTh;
-                    const unsigned long long b = __ballot(pass);
-                    if (!b) continue;  // wave-uniform
-                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)pixCode(y0h + y + k, cx);
-                    nc += __popcll(b);
-                }
+                for (int k = 0; k < FC_ROWS; k++) nc = pushRow(m01[k] > (unsigned)minTh, pixCode(y0h + y + k, cx), nc);
             }
             if (nc > FC_CAND - FC_ROWS * 64) flushB();  // wave-uniform
         }
@@ -502,14 +499,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
                 const unsigned m0 = max(FT_AD(0, 3), FT_AD(0, -3));
                 const unsigned m1 = max(FT_AD(3, 0), FT_AD(-3, 0));
                 const unsigned m01r = i < nRem ? min(m0, m1) : 0u;
-                if (__any(m01r > (unsigned)minTh)) {
-                    const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
-                    const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
-                    const bool pass = min(m01r, min(m2, m3)) > (unsigned)minTh;
-                    const unsigned long long b = __ballot(pass);
-                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)pixCode(yy, xx);
-                    nc += __popcll(b);
-                }
+                if (__any(m01r > (unsigned)minTh)) nc = pushRow(m01r > (unsigned)minTh, pixCode(yy, xx), nc);
                 if (nc > FC_CAND - 64) flushB();  // wave-uniform
             }
         }
@@ -546,23 +536,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             dA = dSv[FC_ROWS - 3]; dB = dSv[FC_ROWS - 2]; dC = dSv[FC_ROWS - 1];
             pA = pv[FC_ROWS]; pB = pv[FC_ROWS + 1]; pC = pv[FC_ROWS + 2];
             if (__any(mAny > (unsigned)minTh)) {
-                // rows without a survivor of the compass test skip the diagonal test, rows without a candidate the append
-                unsigned long long rowAny[FC_ROWS];
 #pragma unroll
-                for (int k = 0; k < FC_ROWS; k++) rowAny[k] = __ballot(m01[k] > (unsigned)minTh);
-#pragma unroll
-                for (int k = 0; k < FC_ROWS; k++) {
-                    if (!rowAny[k]) continue;  // wave-uniform
-                    const unsigned v = pv[k];
-                    const uint8_t *cpx = r + (k + 3) * TP;
-                    const unsigned m2 = max(FT_AD(2, 2), FT_AD(-2, -2));
-                    const unsigned m3 = max(FT_AD(2, -2), FT_AD(-2, 2));
-                    const bool pass = min(m01[k], min(m2, m3)) > (unsigned)minTh;
-                    const unsigned long long b = __ballot(pass);
-                    if (!b) continue;  // wave-uniform
-                    if (pass) cand[nc + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)pixCode(y + k, lane);
-                    nc += __popcll(b);
-                }
+                for (int k = 0; k < FC_ROWS; k++) nc = pushRow(m01[k] > (unsigned)minTh, pixCode(y + k, lane), nc);
             }
             if (nc > FC_CAND - FC_ROWS * 64 || y + FC_ROWS >= ph) flushB();  // wave-uniform
         }
