@@ -391,9 +391,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     wave_lds_sync();
     const uint8_t *t0 = tile + ax;  // pixel (x, y) of the cell sub-image at t0[y * tp + x]
     // ---- phase A / B rounds.  A: high-speed rejection (OpenCV's opposite-pair test without the
-    // polarity): a 9-arc contains one pixel of every opposite pair, so min over the four even pairs of
+    // polarity): a 9-arc contains one pixel of every opposite pair, so for the two compass pairs (k = 0, 4)
     // max(|d_k|, |d_k+8|) must exceed the threshold; survivors are appended in row-major order to the
-    // candidate ring.  B (whenever the ring fills, and at the end): score = largest threshold at which
+    // candidate ring (the any-size variant also tests the two diagonal pairs).  B (whenever the ring fills, and at the end): score = largest threshold at which
     // the pixel is still a corner (cornerScore<16>); corner at minThFAST <=> score >= minThFAST.
     int nc = 0, ncorn = 0;
     // A pixel of the tested region travels through the candidate ring and the corner list as a 16-bit code: with a
