@@ -236,7 +236,10 @@ class Extractor:
     def extract(self, img: np.ndarray, lap=(0, 0)):
         """returns (keypoints[KP_DTYPE], descriptors[n,32], n_mono)"""
         img = np.ascontiguousarray(img, np.uint8)
-        cap = self.nfeatures + 64
+        # DistributeOctTree overshoots its per-level quota: a breadth-first pass splits every node of the list before
+        # the size is checked (ORBextractor.cc:719-797), so a level may return up to four times its quota (or its
+        # initial nodes); orc_extract never writes past `cap` and returns the full count
+        cap = 4 * self.nfeatures + 128 * self.nlevels
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         nm = C.c_int(0)
