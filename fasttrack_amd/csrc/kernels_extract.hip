@@ -240,15 +240,17 @@ __device__ __forceinline__ bool has_arc9(unsigned m) {
     F(0, 0, 3) F(1, 1, 3) F(2, 2, 2) F(3, 3, 1) F(4, 3, 0) F(5, 3, -1) F(6, 2, -2) F(7, 1, -3) F(8, 0, -3)    \
     F(9, -1, -3) F(10, -2, -2) F(11, -3, -1) F(12, -3, 0) F(13, -3, 1) F(14, -2, 2) F(15, -1, 3)
 
-__device__ __forceinline__ int fast_score(const int d[16]) {
-    // score = max over the 16 arcs of 9 of min(d) (either polarity) - 1  == cornerScore<16> for corners.
-    // Arc minima from runs of three: min9[k] = min3(min3[k], min3[k+3], min3[k+6]) - v_min3 / v_max3 make every line
-    // below one instruction per element (64 for both polarities, plus 16 for the two final reductions).
+__device__ __forceinline__ int fast_score(int v, const int p[16]) {
+    // score = max over the 16 arcs of 9 of min(v - p_i) (either polarity) - 1  == cornerScore<16> for corners.
+    // min over an arc of (v - p_i) = v - max over the arc of p_i, so the arc extrema are taken on the ring pixels
+    // themselves and v enters once at the end: score = max(v - min_k max9_k(p), max_k min9_k(p) - v) - 1.
+    // Arc extrema from runs of three: ext9[k] = ext3(ext3[k], ext3[k+3], ext3[k+6]) - v_min3 / v_max3 make every line
+    // below one instruction per element (64 in all, plus 16 for the two final reductions).
     int mn3[16], mx3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-        mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        mn3[k] = min(min(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
+        mx3[k] = max(max(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
     }
     int mn9[16], mx9[16];
 #pragma unroll
@@ -256,15 +258,15 @@ __device__ __forceinline__ int fast_score(const int d[16]) {
         mn9[k] = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
         mx9[k] = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
     }
-    int best = max(max(mn9[0], mn9[1]), mn9[2]), worst = min(min(mx9[0], mx9[1]), mx9[2]);
+    int darkest = max(max(mn9[0], mn9[1]), mn9[2]), brightest = min(min(mx9[0], mx9[1]), mx9[2]);
 #pragma unroll
     for (int k = 3; k < 15; k += 2) {
-        best = max(max(best, mn9[k]), mn9[k + 1]);
-        worst = min(min(worst, mx9[k]), mx9[k + 1]);
+        darkest = max(max(darkest, mn9[k]), mn9[k + 1]);
+        brightest = min(min(brightest, mx9[k]), mx9[k + 1]);
     }
-    best = max(best, mn9[15]);
-    worst = min(worst, mx9[15]);
-    return max(best, -worst) - 1;
+    darkest = max(darkest, mn9[15]);      // max over arcs of the arc's darkest pixel
+    brightest = min(brightest, mx9[15]);  // min over arcs of the arc's brightest pixel
+    return max(v - brightest, darkest - v) - 1;
 }
 
 // One WAVE per (cell, image): no workgroup barrier anywhere, so the ~20 cells resident on a CU hide each other's
@@ -387,7 +389,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             tile[y * tp + x] = gload<uint8_t>(src + (size_t)y * pitch + x);
         }
     }
-    for (int i = lane; i < (tp * (ph + 2)) >> 2; i += 64) ((unsigned *)score)[i] = 0;
+    // the whole score plane (a multiple of 16 bytes, 16-byte aligned) is cleared with 16-byte stores: two per lane
+    for (int i = lane; i < fc_score_bytes(L.wCell, L.hCell, TP) >> 4; i += 64) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
     wave_lds_sync();
     const uint8_t *t0 = tile + ax;  // pixel (x, y) of the cell sub-image at t0[y * tp + x]
     // ---- phase A / B rounds.  A: high-speed rejection (OpenCV's opposite-pair test without the
@@ -414,11 +417,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
                 const int y = pixY(ci2), x = pixX(ci2, y);
                 const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
                 const int v = cpx[0];
-                int d[16];
-#define FT_LD(k, ox, oy) d[k] = v - (int)cpx[(oy)*tp + (ox)];
+                int ringPx[16];
+#define FT_LD(k, ox, oy) ringPx[k] = (int)cpx[(oy)*tp + (ox)];
                 FT_RING(FT_LD)
 #undef FT_LD
-                const int sc = fast_score(d);
+                const int sc = fast_score(v, ringPx);
                 if (sc >= minTh) {
                     score[(y + 1) * tp + (x + 1)] = (uint8_t)sc;
                     isCorner = true;
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     // a partly filled round of 64 is as expensive as a full one.)
     auto pushRow = [&](bool pass, int code, int n) -> int {
         const unsigned long long b = __ballot(pass);
-        const int pos = pass ? n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))
+        const int pos = pass ? (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, (unsigned)n))
                              : FC_CAND + FC_CORN;
         cand[pos] = (unsigned short)code;
         return n + __popcll(b);
