@@ -58,7 +58,19 @@ __constant__ FtPatternF c_patternF = ft_make_pattern_f();
 
 // i / d for small operands with a precomputed magic = floor(2^32 / d) + 1 (exact for i < 2^32 / d);
 // d == 1 makes the magic wrap to 0, so it is special-cased.
-__device__ __forceinline__ unsigned div_magic_of(unsigned d) { return d > 1 ? 0xffffffffu / d + 1u : 0u; }
+__host__ __device__ constexpr unsigned div_magic_of(unsigned d) { return d > 1 ? 0xffffffffu / d + 1u : 0u; }
+// The divisors that occur per wave (dwords per footprint row, columns behind the 32-column halves of a cell) are
+// small: their magics come from a constant table (one scalar load) instead of a ~25-instruction integer division.
+struct FtDivMagicTab {
+    unsigned m[128];
+};
+constexpr FtDivMagicTab ft_make_div_magic_tab() {
+    FtDivMagicTab t{};
+    for (unsigned d = 0; d < 128; d++) t.m[d] = d ? div_magic_of(d) : 0u;
+    return t;
+}
+__constant__ FtDivMagicTab c_divMagic = ft_make_div_magic_tab();
+__device__ __forceinline__ unsigned div_magic_small(unsigned d) { return d < 128u ? c_divMagic.m[d] : div_magic_of(d); }
 __device__ __forceinline__ int div_by(int i, unsigned magic) { return magic ? (int)__umulhi((unsigned)i, magic) : i; }
 
 __device__ __forceinline__ const uint8_t *level_ptr(const FtGeom &g, int level, int slot, const uint8_t *const *l0,
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
         // so a load costs a few full-rate adds instead of a division and 64-bit address arithmetic.
         const int n = nd * rows;
         const int spare = ldsPitch * rowsAlloc;  // one dword behind the tile (see the launcher)
-        const unsigned ndMagic = div_magic_of((unsigned)nd);
+        const unsigned ndMagic = div_magic_small((unsigned)nd);
         const int dy = div_by(64, ndMagic), dx = 64 - dy * nd;
         int x = lane - div_by(lane, ndMagic) * nd;
         unsigned gOff = (unsigned)(div_by(lane, ndMagic) * spitch + 4 * x);
@@ -331,7 +343,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     const int pw = tw - 6, ph = th - 6;  // tested region
     const int npx = pw * ph;
     const int tp = TP ? TP : fc_pitch(L.wCell, 0);
-    const unsigned pwMagic = div_magic_of((unsigned)pw);
+    // division by the row length: only the any-size variant unpacks pixel codes with it (the fixed-pitch variants
+    // need it on the rare score-plane scan alone and compute it there)
+    const unsigned pwMagic = TP ? 0u : div_magic_of((unsigned)pw);
     uint8_t *tile = smem;
     uint8_t *score = tile + fc_tile_bytes(L.wCell, L.hCell, TP);
     unsigned short *cand = (unsigned short *)(score + fc_score_bytes(L.wCell, L.hCell, TP));
@@ -492,7 +506,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         // columns 32 .. pw-1 (four of them for a 36-pixel cell), every row, in linear order
         const int wRem = pw - wMain, nRem = wRem * ph;
         if (wRem > 0) {
-            const unsigned remMagic = div_magic_of((unsigned)wRem);
+            const unsigned remMagic = div_magic_small((unsigned)wRem);
             for (int base = 0; base < nRem; base += 64) {
                 const int i = base + lane;
                 const int ii = min(i, nRem - 1);
@@ -596,7 +610,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             pix = (int)corn[item];
             y = pixY(pix), x = pixX(pix, y);
         } else {  // score-plane scan: item is the linear index of the pixel
-            y = div_by(item, pwMagic), x = item - y * pw;
+            const unsigned mg = TP ? div_magic_of((unsigned)pw) : pwMagic;
+            y = div_by(item, mg), x = item - y * pw;
             pix = pixCode(y, x);
         }
         const uint8_t *s = score + (y + 1) * tp + (x + 1);
