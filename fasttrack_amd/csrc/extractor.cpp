@@ -197,6 +197,7 @@ void freeAll(ft_extractor *ex) {
     hipFree(ex->d_stDesc);
     hipFree(ex->d_stOut);
     hipFree(ex->d_stInt);
+    hipFree(ex->d_stSorted);
     hipHostFree((void *)ex->h_l0);
     hipHostFree(ex->h_cand);
     hipHostFree(ex->h_candCount);

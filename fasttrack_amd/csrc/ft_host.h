@@ -148,7 +148,8 @@ struct ft_extractor {
     ft_keypoint *d_stKeys = nullptr;  // [2 * maxKp] left then right
     uint8_t *d_stDesc = nullptr;      // [2 * maxKp * 32]
     float *d_stOut = nullptr;         // [2 * maxKp] uright then depth
-    int *d_stInt = nullptr;           // [2 * stCap + 4] sad, hamming idx, then nL nR nMatches
+    int *d_stInt = nullptr;           // [2 * stCap + 4] sad, hamming idx, then nL nR nMatches, then the row starts
+    FtSortedR *d_stSorted = nullptr;  // [stCap] right keypoints in row-bucket order
     int stCap = 0;
     FtEventTimer evt;
     // state of the last call (consumed by the stereo matcher)
@@ -165,7 +166,8 @@ struct ft_stereo_frontend {
     int capacity = 0;
     float *d_uright = nullptr, *d_depth = nullptr, *h_uright = nullptr, *h_depth = nullptr;
     int *d_sad = nullptr, *d_nMatches = nullptr, *h_nMatches = nullptr;
-    int *d_order = nullptr, *d_rowStart = nullptr;  // right keypoints bucketed by row (k_stereo_rowsort)
+    FtSortedR *d_sorted = nullptr;  // right keypoints bucketed by row (k_stereo_rowsort)
+    int *d_rowStart = nullptr;
     hipEvent_t evR = nullptr;
     // Latency mode: a small batch with a fixed call shape (same sizes, same result arrays, same kind of input) is
     // captured once as a HIP graph - ~45 enqueue calls on seven streams become one launch.  graphKey holds everything

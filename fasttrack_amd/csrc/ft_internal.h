@@ -146,6 +146,13 @@ size_t ft_octree_smem_bytes(int poolCap);
 size_t ft_fast_smem_bytes(const FtGeom &g);
 
 // ---- kernel launchers (kernels_match.hip) ---------------------------------------------------
+// A right keypoint as k_stereo_rowsort lays it down in row-bucket order: everything the left keypoint's scan needs in
+// one 48-byte entry, so the scan is one coalesced read instead of the chain index -> keypoint -> descriptor.
+struct __attribute__((aligned(16))) FtSortedR {
+    float x, y;
+    int octave, idx;  // idx = position in the caller's right keypoint array
+    unsigned long long desc[4];
+};
 struct FtStereoArgs {
     const ft_keypoint *keysL, *keysR;  // device
     const uint8_t *descL, *descR;      // device, n x 32
@@ -158,7 +165,7 @@ struct FtStereoArgs {
     int *nMatches;                     // device [batch]
     int applyMedianCut;
     int *rowStart;                     // device [batch * rowStride]: right keypoints bucketed by (int)y
-    int *order;                        // device [batch * capacity]: right keypoint indices in bucket order
+    FtSortedR *sorted;                 // device [batch * capacity]: right keypoints in bucket order
     int rowStride;                     // >= level-0 height + 2
 };
 struct FtFisheyeRig {

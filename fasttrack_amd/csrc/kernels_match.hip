@@ -32,12 +32,14 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
     int slot, blk;
     if (!ft_slot_block(sg, slot, blk)) return;
     const int iL = blk * 4 + wave;
+    const size_t base = (size_t)slot * a.capacity;
+    // the keypoint is requested together with the count that decides whether it exists (the arrays hold `capacity`
+    // entries per image, so the read is in bounds either way): one memory round trip instead of two
+    const ft_keypoint kpL = a.keysL[base + min(iL, a.capacity - 1)];
     const int nL = a.nL[slot];
     if (iL >= nL) return;
-    const size_t base = (size_t)slot * a.capacity;
     float outU = -1.0f, outD = -1.0f;
     int outSad = -1, outHam = -1;
-    const ft_keypoint kpL = a.keysL[base + iL];
     const int levelL = kpL.octave;
     const float vL = kpL.y, uL = kpL.x;
     const int nRows = g.lv[0].h;
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
         dL[0] = p[0]; dL[1] = p[1]; dL[2] = p[2]; dL[3] = p[3];
     }
     unsigned best = 0xffffffffu;  // (dist << 16) | iR
+    float bestX = 0.f;            // x of this lane's best right keypoint
     if (row >= 0 && row < nRows && !(maxU < 0)) {
         // right keypoints are bucketed by (int)y (k_stereo_rowsort); the band of keypoint iR covers `row` only
         // if |y_R - row| < r + 1 with r = 2 * sf[octave] <= 2 * max scale factor, so scanning the buckets
@@ -61,10 +64,9 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
         const int reach = (int)ceilf(2.0f * g.sf[g.nlevels - 1]) + 1;
         const int *rs = a.rowStart + (size_t)slot * a.rowStride;
         const int t0 = rs[max(row - reach, 0)], t1 = rs[min(row + reach + 1, nRows)];
-        const int *ord = a.order + base;
+        const FtSortedR *srt = a.sorted + base;
         for (int t = t0 + lane; t < t1; t += 64) {
-            const int iR = ord[t];
-            const ft_keypoint kpR = a.keysR[base + iR];
+            const FtSortedR kpR = srt[t];  // consecutive lanes read consecutive 48-byte entries
             // row band of the right keypoint (Frame.cc:852-862): rows floor(y-r) .. ceil(y+r), r = 2*sf[octave]
             const float r = __fmul_rn(2.0f, g.sf[kpR.octave]);
             const int maxr = (int)ceilf(__fadd_rn(kpR.y, r));
@@ -73,19 +75,26 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
             if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
             const float uR = kpR.x;
             if (uR >= minU && uR <= maxU) {
-                const int dist = hamming256(dL, (const unsigned long long *)(a.descR + (base + iR) * 32));
-                best = min(best, ((unsigned)dist << 16) | (unsigned)iR);
+                const int dist = hamming256(dL, kpR.desc);
+                const unsigned key = ((unsigned)dist << 16) | (unsigned)kpR.idx;
+                if (key < best) {
+                    best = key;
+                    bestX = uR;
+                }
             }
         }
     }
+    const unsigned myBest = best;
     best = wave_min_u32(best);
+    // x of the winner travels with it: the lane that holds the minimum (keys are unique: they contain the index)
+    const unsigned long long winner = __ballot(myBest == best);
+    const float uR0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bestX), (int)__ffsll((long long)winner) - 1));
     const int bestDist = (int)(best >> 16);
     const int thOrbDist = (FT_TH_HIGH + FT_TH_LOW) / 2;
     // bestDist starts at TH_HIGH in the reference, so only dist < TH_HIGH ever registers; < thOrbDist is stricter
     if (best != 0xffffffffu && bestDist < thOrbDist) {
         const int bestIdxR = (int)(best & 0xffffu);
         outHam = bestIdxR;
-        const float uR0 = a.keysR[base + bestIdxR].x;
         const float scaleFactor = g.invsf[levelL];
         const float scaleduL = roundf(__fmul_rn(kpL.x, scaleFactor));
         const float scaledvL = roundf(__fmul_rn(kpL.y, scaleFactor));
@@ -107,15 +116,26 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
             // 11x11 left patch: each lane owns pixels lane and lane+64 (< 121)
             const int p0 = lane, p1 = lane + 64;
             const int r0 = p0 / 11, c0 = p0 - r0 * 11, r1 = p1 / 11, c1 = p1 - r1 * 11;
-            const int a0 = gload<uint8_t>(imL + (size_t)(yl0 + r0) * pitchL + xl0 + c0);
-            const int a1 = p1 < 121 ? gload<uint8_t>(imL + (size_t)(yl0 + r1) * pitchL + xl0 + c1) : 0;
+            // every load of the SAD search is issued before the first reduction: the left patch and, per lane, the 11
+            // consecutive right-image bytes its two pixels slide over (a wave used to pay the memory latency 11 times)
+            const uint8_t *pl0 = imL + (size_t)(yl0 + r0) * pitchL + xl0 + c0;
+            const uint8_t *pl1 = imL + (size_t)(yl0 + min(r1, 10)) * pitchL + xl0 + c1;
+            const uint8_t *pr0 = imR + (size_t)(yl0 + r0) * pitchR + xr00 + c0;
+            const uint8_t *pr1 = imR + (size_t)(yl0 + min(r1, 10)) * pitchR + xr00 + c1;
+            const int a0 = gload<uint8_t>(pl0);
+            const int a1 = gload<uint8_t>(pl1);
+            int b0[11], b1[11];
+#pragma unroll
+            for (int s = 0; s < 11; s++) {
+                b0[s] = gload<uint8_t>(pr0 + s);
+                b1[s] = gload<uint8_t>(pr1 + s);
+            }
             int bestS = 0x7fffffff, bestinc = 0;
             float dists[11];
 #pragma unroll
             for (int s = 0; s < 11; s++) {
-                const int xr = xr00 + s;
-                int d = abs(a0 - (int)gload<uint8_t>(imR + (size_t)(yl0 + r0) * pitchR + xr + c0));
-                if (p1 < 121) d += abs(a1 - (int)gload<uint8_t>(imR + (size_t)(yl0 + r1) * pitchR + xr + c1));
+                int d = abs(a0 - b0[s]);
+                if (p1 < 121) d += abs(a1 - b1[s]);
                 d = wave_sum_i32(d);
                 dists[s] = (float)d;
                 if (d < bestS) {
@@ -200,10 +220,20 @@ __global__ __launch_bounds__(256) void k_stereo_rowsort(FtGeom g, FtStereoArgs a
     }
     if (tid == 255) rs[H] = run;  // the last thread's chunk ends at H
     __syncthreads();
-    int *ord = a.order + base;
+    FtSortedR *srt = a.sorted + base;
     for (int i = tid; i < nR; i += 256) {
-        const int y = (int)a.keysR[base + i].y;
-        if (y >= 0 && y < H) ord[atomicAdd(&sh[y], 1)] = i;
+        const ft_keypoint kp = a.keysR[base + i];
+        const int y = (int)kp.y;
+        if (y >= 0 && y < H) {
+            FtSortedR e;
+            e.x = kp.x;
+            e.y = kp.y;
+            e.octave = kp.octave;
+            e.idx = i;
+            const unsigned long long *d = (const unsigned long long *)(a.descR + (base + i) * 32);
+            e.desc[0] = d[0]; e.desc[1] = d[1]; e.desc[2] = d[2]; e.desc[3] = d[3];
+            srt[atomicAdd(&sh[y], 1)] = e;
+        }
     }
 }
 

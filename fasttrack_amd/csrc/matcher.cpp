@@ -46,6 +46,8 @@ int ft_stereo_match(ft_extractor *exL, ft_extractor *exR, int slot, const ft_key
         hipFree(exL->d_stDesc);
         hipFree(exL->d_stOut);
         hipFree(exL->d_stInt);
+        hipFree(exL->d_stSorted);
+        exL->d_stSorted = nullptr;
         exL->d_stKeys = nullptr;
         exL->d_stDesc = nullptr;
         exL->d_stOut = nullptr;
@@ -53,7 +55,8 @@ int ft_stereo_match(ft_extractor *exL, ft_extractor *exR, int slot, const ft_key
         FT_HIP(hipMalloc((void **)&exL->d_stKeys, sizeof(ft_keypoint) * 2 * need));
         FT_HIP(hipMalloc((void **)&exL->d_stDesc, (size_t)64 * need));
         FT_HIP(hipMalloc((void **)&exL->d_stOut, sizeof(float) * 2 * need));
-        FT_HIP(hipMalloc((void **)&exL->d_stInt, sizeof(int) * (3 * (size_t)need + 8 + exL->height + 2)));
+        FT_HIP(hipMalloc((void **)&exL->d_stInt, sizeof(int) * (2 * (size_t)need + 8 + exL->height + 2)));
+        FT_HIP(hipMalloc((void **)&exL->d_stSorted, sizeof(FtSortedR) * (size_t)need));
         exL->stCap = need;
     }
     const int C = exL->stCap;
@@ -86,8 +89,8 @@ int ft_stereo_match(ft_extractor *exL, ft_extractor *exR, int slot, const ft_key
     a.hamIdx = exL->d_stInt + C;
     a.nMatches = d_hdr + 2;
     a.applyMedianCut = apply_median_cut;
-    a.order = exL->d_stInt + 2 * C + 4;
-    a.rowStart = a.order + C;
+    a.sorted = exL->d_stSorted;
+    a.rowStart = exL->d_stInt + 2 * C + 4;
     a.rowStride = exL->height + 2;
     rc = ft_launch_stereo_rowsort(st, g, 1, a);
     if (rc != FT_OK) return rc;
@@ -131,7 +134,7 @@ int ft_stereo_frontend_create(ft_context *ctx, int nfeatures, float scale_factor
     if (e == hipSuccess) e = hipMalloc((void **)&fe->d_depth, sizeof(float) * n);
     if (e == hipSuccess) e = hipMalloc((void **)&fe->d_sad, sizeof(int) * n);
     if (e == hipSuccess) e = hipMalloc((void **)&fe->d_nMatches, sizeof(int) * max_batch);
-    if (e == hipSuccess) e = hipMalloc((void **)&fe->d_order, sizeof(int) * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&fe->d_sorted, sizeof(FtSortedR) * n);
     if (e == hipSuccess) e = hipMalloc((void **)&fe->d_rowStart, sizeof(int) * (size_t)max_batch * (image_height + 2));
     if (e == hipSuccess) e = hipHostMalloc((void **)&fe->h_uright, sizeof(float) * n, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&fe->h_depth, sizeof(float) * n, hipHostMallocDefault);
@@ -156,7 +159,7 @@ int ft_stereo_frontend_destroy(ft_stereo_frontend *fe) {
     hipFree(fe->d_depth);
     hipFree(fe->d_sad);
     hipFree(fe->d_nMatches);
-    hipFree(fe->d_order);
+    hipFree(fe->d_sorted);
     hipFree(fe->d_rowStart);
     hipHostFree(fe->h_uright);
     hipHostFree(fe->h_depth);
@@ -283,7 +286,7 @@ static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL
         a.applyMedianCut = 1;
         a.rowStride = L->height + 2;
         a.rowStart = fe->d_rowStart + (size_t)b0 * a.rowStride;
-        a.order = fe->d_order + o;
+        a.sorted = fe->d_sorted + o;
         L->evt.begin(tm, "kernel.stereo_rowsort", st);
         rc = ft_launch_stereo_rowsort(st, g, nb, a);
         L->evt.end(tm, st);
