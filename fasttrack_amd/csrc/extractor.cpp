@@ -527,7 +527,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     FT_TRY(devAlloc(&ex->d_l0, B));
     FT_TRY(devAlloc(&ex->d_sel, B * g.maxKp));
     FT_TRY(devAlloc(&ex->d_nSel, B));
-    FT_TRY(devAlloc(&ex->d_selCount, B * g.nlevels));
+    FT_TRY(devAlloc(&ex->d_selCount, B * g.nlevels + FT_MAX_LEVELS));  // k_orient_desc reads FT_MAX_LEVELS counts per image at once
     FT_TRY(devAlloc(&ex->d_overflow, 1));
     FT_TRY(pinAlloc(&ex->h_selCount, B * g.nlevels));
     FT_TRY(pinAlloc(&ex->h_overflow, 1));

@@ -783,9 +783,15 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     const int k = blk * OD_WAVES + wave;
     // the octree leaves its result per level; keypoint k of the image (level order) is entry k - prefix of
     // the level that contains it
+    // All level counts of the image are requested at once (scalar loads of FT_MAX_LEVELS consecutive ints; the array is
+    // padded by that much) instead of one dependent scalar round trip per level.
     int selLevel = -1, prefix = 0, total = 0;
-    for (int l = 0; l < g.nlevels; l++) {
-        const int c = selCount[slot * g.nlevels + l];
+    int cnt[FT_MAX_LEVELS];
+#pragma unroll
+    for (int l = 0; l < FT_MAX_LEVELS; l++) cnt[l] = selCount[slot * g.nlevels + l];
+#pragma unroll
+    for (int l = 0; l < FT_MAX_LEVELS; l++) {
+        const int c = l < g.nlevels ? cnt[l] : 0;
         if (selLevel < 0 && k < total + c) {
             selLevel = l;
             prefix = total;
