@@ -217,15 +217,16 @@ void freeAll(ft_extractor *ex) {
 int ft_pipeline_depth(int batch, bool deviceOctree) {
     // Host octree: sub-batches of ~16 images keep every launch large enough to fill the 256 CUs while the host
     // octree of one sub-batch hides behind the kernels of the next.  Device octree: nothing waits for the host,
-    // and fewer, wider launches win (measured on MI355X, 128 pairs of 1280x720: depth 8 22.8k fps, depth 2
-    // 31.0k, depth 1 30.6k) - sub-batches of ~64 images only keep thin kernels (octree, copies) of one
-    // sub-batch under the wide kernels of the next.  FT_PIPELINE_DEPTH overrides (1 = no pipelining).
+    // and fewer, wider launches win (measured on MI355X, 256 pairs of 1280x720: depth 8 46.9k fps, depth 4
+    // 54.3k, depth 3 56.2k, depth 2 57.5k, depth 1 57.9k; 512 pairs: depth 4 58.0k, depth 2 58.5k) - sub-batches
+    // of ~128 images only keep thin kernels (octree, copies) of one sub-batch under the wide kernels of the
+    // next.  FT_PIPELINE_DEPTH overrides (1 = no pipelining).
     static const int envDepth = [] {
         const char *e = getenv("FT_PIPELINE_DEPTH");
         return e ? std::max(1, std::min(FT_PIPE_MAX, atoi(e))) : 0;
     }();
     if (envDepth) return std::max(1, std::min(envDepth, batch));
-    return std::max(1, std::min(FT_PIPE_MAX, batch / (deviceOctree ? 64 : 16)));
+    return std::max(1, std::min(FT_PIPE_MAX, batch / (deviceOctree ? 128 : 16)));
 }
 
 int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
