@@ -274,7 +274,9 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     const int lane = tid & 63;
     // a thin kernel that runs next to wide ones: its single critical wave per level should win the issue arbitration
     __builtin_amdgcn_s_setprio(3);
-    const int level = blockIdx.x, slot = blockIdx.y;
+    // workgroups are dispatched in the order of their linear index: image fastest, so the level-0 workgroups of all
+    // images (the long ones: most candidates, largest quota) start first and the short high levels fill in behind
+    const int slot = blockIdx.x, level = blockIdx.y;
     const FtLevelGeom &L = g.lv[level];
     const int n = a.candCount[slot * g.nlevels + level];
     const int N = a.quota[level];
@@ -581,7 +583,7 @@ int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs
     if (smem > 64 * 1024)  // large quotas: raise the dynamic LDS limit (per device, so not cached in a static)
         FT_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     for (int rep = ft_debug_repeat("octree"); rep > 0; rep--)
-    hipLaunchKernelGGL(k_octree, dim3(g.nlevels, batch), dim3(OCT_THREADS), smem, st, g, a);
+    hipLaunchKernelGGL(k_octree, dim3(batch, g.nlevels), dim3(OCT_THREADS), smem, st, g, a);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
