@@ -111,8 +111,8 @@ def cpu_baseline(w, h, nf, pairs, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="stereo_1280x720_nf2000", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256, help="stereo pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
