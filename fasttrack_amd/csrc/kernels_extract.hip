@@ -867,7 +867,14 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     // raw[r][b + t] for raw byte positions b in [0, 40) (16 bit, <= 255 * 256); output column c of the
     // blurred window is b = ax + c.
     {
-        const unsigned K0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K1 = 48u | (34u << 8) | (18u << 16);
+        // the shifted windows of outputs 1 .. 3 are expressed through shifted WEIGHTS on the three aligned dwords (ten
+        // v_dot4 with constant weight vectors) instead of byte-aligning the data first (six v_alignbyte + eight v_dot4)
+#define FT_W4(a, b, c, d) ((unsigned)(a) | ((unsigned)(b) << 8) | ((unsigned)(c) << 16) | ((unsigned)(d) << 24))
+        const unsigned W0a = FT_W4(18, 34, 48, 56), W0b = FT_W4(48, 34, 18, 0);
+        const unsigned W1a = FT_W4(0, 18, 34, 48), W1b = FT_W4(56, 48, 34, 18);
+        const unsigned W2a = FT_W4(0, 0, 18, 34), W2b = FT_W4(48, 56, 48, 34), W2c = FT_W4(18, 0, 0, 0);
+        const unsigned W3a = FT_W4(0, 0, 0, 18), W3b = FT_W4(34, 48, 56, 48), W3c = FT_W4(34, 18, 0, 0);
+#undef FT_W4
         // six rows per step on lanes 0-59, (row, group) fixed per lane: every LDS offset of a step is an immediate
         const int rr = (lane * 13) >> 7, gq = lane - rr * 10;  // lane / 10 for lane < 64
         const unsigned *rwLane = (const unsigned *)(raw + rr * OD_PP) + gq;
@@ -878,13 +885,10 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
                 if (it == 7 && rr > 0) break;  // rows 42 .. 47: only row 42 exists
                 const unsigned *rw = rwLane + it * (6 * OD_PP / 4);
                 const unsigned d0 = rw[0], d1 = rw[1], d2 = rw[2];
-                unsigned h0 = __builtin_amdgcn_udot4(d1, K1, __builtin_amdgcn_udot4(d0, K0, 0u, false), false);
-                unsigned h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1,
-                                                     __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false), false);
-                unsigned h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1,
-                                                     __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false), false);
-                unsigned h3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1,
-                                                     __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
+                unsigned h0 = __builtin_amdgcn_udot4(d1, W0b, __builtin_amdgcn_udot4(d0, W0a, 0u, false), false);
+                unsigned h1 = __builtin_amdgcn_udot4(d1, W1b, __builtin_amdgcn_udot4(d0, W1a, 0u, false), false);
+                unsigned h2 = __builtin_amdgcn_udot4(d2, W2c, __builtin_amdgcn_udot4(d1, W2b, __builtin_amdgcn_udot4(d0, W2a, 0u, false), false), false);
+                unsigned h3 = __builtin_amdgcn_udot4(d2, W3c, __builtin_amdgcn_udot4(d1, W3b, __builtin_amdgcn_udot4(d0, W3a, 0u, false), false), false);
                 uint2 pk;
                 pk.x = __builtin_amdgcn_perm(h1, h0, 0x05040100u);  // h0 | h1 << 16 (both < 2^16) in one instruction
                 pk.y = __builtin_amdgcn_perm(h3, h2, 0x05040100u);
