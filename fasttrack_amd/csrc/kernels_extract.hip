@@ -105,12 +105,17 @@ __device__ __forceinline__ void wave_lds_sync() {
 // before anything waits.
 __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint8_t *const *l0, int l0pitch,
                                                  uint8_t *pyr, const FtTap *taps, int alignedLoads, int ldsPitch,
-                                                 int rowsAlloc, unsigned sxQ16, unsigned syQ16) {
+                                                 int rowsAlloc, unsigned sxQ16, unsigned syQ16, FtSlotGrid sg, int tilesX,
+                                                 unsigned txMagic) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
-    const int slot = blockIdx.z;
+    // all tiles of an image on one XCD (ft_slot_grid): neighbouring tiles share source lines (footprint margins, 64-B
+    // lines), which then come from that XCD's L2 instead of being fetched once per XCD
+    int slot, tile;
+    if (!ft_slot_block(sg, slot, tile)) return;
+    const int tileY = div_by(tile, txMagic), tileX = tile - tileY * tilesX;
     const FtLevelGeom &D = g.lv[level];
-    const int dx0 = blockIdx.x * PD_TW, dy0 = blockIdx.y * PD_TH;
+    const int dx0 = tileX * PD_TW, dy0 = tileY * PD_TH;
     const int dx1 = min(dx0 + PD_TW, D.w) - 1, dy1 = min(dy0 + PD_TH, D.h) - 1;  // last output col / row
     int spitch;
     const uint8_t *S = level_ptr(g, level - 1, slot, l0, l0pitch, pyr, spitch);
@@ -987,9 +992,11 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
         // scale = source size / destination size in 16.16, rounded up (the error stays far below one pixel)
         const unsigned sxQ16 = (unsigned)(((unsigned long long)P.w << 16) / (unsigned)D.w) + 1u;
         const unsigned syQ16 = (unsigned)(((unsigned long long)P.h << 16) / (unsigned)D.h) + 1u;
-        dim3 grid((D.w + PD_TW - 1) / PD_TW, (D.h + PD_TH - 1) / PD_TH, batch), block(64, 1, 1);
+        const int tilesX = (D.w + PD_TW - 1) / PD_TW, tilesY = (D.h + PD_TH - 1) / PD_TH;
+        dim3 grid, block(64, 1, 1);
+        const FtSlotGrid sg = ft_slot_grid(tilesX * tilesY, batch, grid);
         hipLaunchKernelGGL(k_pyr_down, grid, block, (size_t)ldsPitch * rowsN + 4, st, g, level, l0, l0pitch, pyr, taps,
-                           alignedLoads, ldsPitch, rowsN, sxQ16, syQ16);
+                           alignedLoads, ldsPitch, rowsN, sxQ16, syQ16, sg, tilesX, div_magic_of((unsigned)tilesX));
     }
     FT_HIP(hipGetLastError());
     return FT_OK;
