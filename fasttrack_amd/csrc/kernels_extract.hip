@@ -319,17 +319,19 @@ __host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + 
 template <int TP, bool ORDERED>
 __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
                                                    int iniTh, int minTh, int alignedLoads, int *cellCount,
-                                                   uint32_t *stage, const uint32_t *cellTab) {
+                                                   uint32_t *stage, const uint32_t *cellTab, FtSlotGrid sg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
-    const int slot = blockIdx.y;
+    int slot = blockIdx.y, cellSg = 0;
+    if (sg.xcdMap && !ft_slot_block(sg, slot, cellSg)) return;
     const uint8_t *img0 = l0[slot];  // level 0 is the caller's frame; requested before anything depends on the level
-    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed placement, used for speed only).  Runs of
-    // FC_XCD_RUN consecutive cells are dealt round-robin to the XCDs, so horizontally neighbouring cells,
-    // whose tiles overlap by 6 px and share 64-B lines, hit the same private L2 instead of fetching the
-    // lines once per XCD, while every XCD still gets the same mix of levels.
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed placement, used for speed only).  Launches of eight
+    // or more images put all cells of an image on one XCD (ft_slot_grid, above): neighbouring cells - their tiles
+    // overlap by 6 px in both directions and share 64-B lines - hit the same private L2, which also still holds what
+    // the pyramid kernel wrote for that image.  Smaller launches deal runs of FC_XCD_RUN consecutive cells round-robin
+    // to the XCDs, so that at least horizontal neighbours share an L2 while all XCDs stay busy on the few images.
     const int j = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
-    const int cell = ((j / FC_XCD_RUN) * 8 + xcd) * FC_XCD_RUN + (j % FC_XCD_RUN);
+    const int cell = sg.xcdMap ? cellSg : ((j / FC_XCD_RUN) * 8 + xcd) * FC_XCD_RUN + (j % FC_XCD_RUN);
     if (cell >= g.totalCells) return;
     // (level, cell row, cell column) of the cell from a table built with the extractor: no search, no division
     const uint32_t ct = cellTab[cell];
@@ -1010,14 +1012,18 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
     dim3 grid(((g.totalCells + runBlock - 1) / runBlock) * runBlock, batch, 1), block(64, 1, 1);
     const size_t smem = ft_fast_smem_bytes(g);
     const int TP = fast_tile_pitch(g);
-    typedef void (*FastFn)(FtGeom, const uint8_t *const *, int, const uint8_t *, int, int, int, int *, uint32_t *, const uint32_t *);
+    typedef void (*FastFn)(FtGeom, const uint8_t *const *, int, const uint8_t *, int, int, int, int *, uint32_t *, const uint32_t *,
+                           FtSlotGrid);
+    FtSlotGrid sg;
+    sg.blocksPerSlot = 0; sg.batch = batch; sg.xcdMap = 0; sg.magic = 0;
+    if (batch >= 8) sg = ft_slot_grid(g.totalCells, batch, grid);  // image -> XCD; smaller launches keep the cell-run mapping
     const FastFn fn = TP == 48 ? (ordered ? k_fast_cells<48, true> : k_fast_cells<48, false>)
                       : TP == 64 ? (ordered ? k_fast_cells<64, true> : k_fast_cells<64, false>)
                                  : k_fast_cells<0, true>;  // any-size cells: the linear pass is ordered anyway
     if (smem > 64 * 1024)  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
         FT_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
-        hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab);
+        hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab, sg);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
