@@ -111,10 +111,10 @@ def cpu_baseline(w, h, nf, pairs, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="stereo_1280x720_nf2000", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=256, help="stereo pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="stereo pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -233,8 +233,8 @@ def main():
         legs = [leg("kernel.fast_cells", "k_fast_cells", float(args.steps) * 2.0 * B * sumP),
                 leg("kernel.pyr_down(all levels)", "k_pyr_down", float(args.steps) * 2.0 * B * ((sumP - P[-1]) + (sumP - P[0])), 7),
                 leg("kernel.orient_desc", "k_orient_desc", float(kps) * args.steps * (43 * 43 + 60))]
-        # Dominant kernel = k_fast_cells: the largest cost inside the overlapped pipeline (0.68 of 2.08 ms per 128 pairs,
-        # profiles/r01_marginal_costs.json; k_orient_desc 0.52, pyramid 0.35).  It fills the chip while it runs, so its
+        # Dominant kernel = k_fast_cells: the largest cost inside the overlapped pipeline (0.69 of 1.97 ms per 128 pairs,
+        # profiles/r01_marginal_costs.json; k_orient_desc 0.48, pyramid 0.36).  It fills the chip while it runs, so its
         # event duration is its own and equals its rocprofv3 duration; the durations of k_orient_desc and the thin
         # k_octree (events and rocprofv3 alike) include the stage-A kernels of the next sub-batch they run beside.
         legs = [x for x in legs if x]

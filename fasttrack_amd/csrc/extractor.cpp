@@ -219,14 +219,16 @@ int ft_pipeline_depth(int batch, bool deviceOctree) {
     // octree of one sub-batch hides behind the kernels of the next.  Device octree: nothing waits for the host,
     // and fewer, wider launches win (measured on MI355X, 256 pairs of 1280x720: depth 8 46.9k fps, depth 4
     // 54.3k, depth 3 56.2k, depth 2 57.5k, depth 1 57.9k; 512 pairs: depth 4 58.0k, depth 2 58.5k) - sub-batches
-    // of ~128 images only keep thin kernels (octree, copies) of one sub-batch under the wide kernels of the
-    // next.  FT_PIPELINE_DEPTH overrides (1 = no pipelining).
+    // only keep thin kernels (octree, copies) of one sub-batch under the wide kernels of the next; with all
+    // kernels placing an image on one XCD the best shape is two sub-batches whatever the batch (512 pairs per
+    // step: 65.0k, 384: 64.2k, 256: 63.7k, 768: 63.7k, 1024: 62.9k).  FT_PIPELINE_DEPTH overrides (1 = no pipelining).
     static const int envDepth = [] {
         const char *e = getenv("FT_PIPELINE_DEPTH");
         return e ? std::max(1, std::min(FT_PIPE_MAX, atoi(e))) : 0;
     }();
     if (envDepth) return std::max(1, std::min(envDepth, batch));
-    return std::max(1, std::min(FT_PIPE_MAX, batch / (deviceOctree ? 128 : 16)));
+    if (deviceOctree) return batch >= 256 ? 2 : 1;  // two sub-batches: 512 pairs 65.0k fps (3: 61.4k, 4: 60.1k, 1: 62.6k)
+    return std::max(1, std::min(FT_PIPE_MAX, batch / 16));
 }
 
 int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
