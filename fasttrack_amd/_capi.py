@@ -151,6 +151,12 @@ def lib() -> C.CDLL:
                                                    C.POINTER(FrustumResult), ip, vp, ip]
     L.ft_tracked_frame_holder_obs.argtypes = [vp, vp]
     L.ft_descriptor_distance.argtypes = [vp, vp, vp, i, vp]
+    L.ft_stereo_frontend_device_descriptors.argtypes = [vp, i, i, C.POINTER(vp), ip]
+    L.ft_vocabulary_create.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, C.POINTER(vp)]
+    L.ft_vocabulary_load_text.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    L.ft_vocabulary_destroy.argtypes = [vp]
+    L.ft_vocabulary_info.argtypes = [vp, ip, ip, ip, ip]
+    L.ft_bow_transform.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, vp, i, ip, vp, vp, vp, i, ip]
     L.ft_octree_distribute.argtypes = [vp, i, i, i, i, i, i, vp, i, ip]
     L.ft_level_geometry.argtypes = [i, i, i, f, i, vp, vp, vp, vp, vp, vp, vp]
     _lib = L

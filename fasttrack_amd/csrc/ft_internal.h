@@ -113,6 +113,19 @@ struct FtOctArgs {
     unsigned long long *prof;  // FT_OCT_PROFILE=1: per-level phase times of slot 0 (wall_clock64 ticks), else null
 };
 
+// vocabulary tree on the device (kernels_bow.hip): children of node i are childList[childStart[i] .. childStart[i+1])
+// in ascending node id; a node without children is a word
+struct FtBowTree {
+    const int *childStart;      // [nNodes + 1]
+    const unsigned *childList;  // [nNodes - 1]
+    const uint8_t *desc;        // [nNodes * 32]
+    const unsigned *wordId;     // [nNodes] (valid for leaves)
+    const double *weight;       // [nNodes]
+    int nNodes;
+};
+int ft_launch_bow_walk(hipStream_t st, const FtBowTree &t, const uint8_t *desc, int n, int nidLevel, unsigned *wordOut,
+                       unsigned *nodeOut, double *weightOut);
+
 void ft_set_error(const std::string &msg);
 // Profiling aid: FT_DEBUG_REPEAT=<name>[,<name>...] makes the launcher of that kernel (pyr, fast, compact, octree,
 // orient, rowsort, stereo, median) enqueue it twice.  Every kernel is idempotent, so results do not change; the

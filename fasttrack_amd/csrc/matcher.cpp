@@ -609,6 +609,15 @@ int ft_fisheye_stereo(ft_context *ctx, const ft_fisheye_rig *rig, const uint8_t 
     return FT_OK;
 }
 
+int ft_stereo_frontend_device_descriptors(ft_stereo_frontend *fe, int slot, int right, const uint8_t **dptr, int *n) {
+    FT_REQUIRE(fe && dptr && n, "ft_stereo_frontend_device_descriptors: null argument");
+    ft_extractor *ex = right ? fe->exR : fe->exL;
+    FT_REQUIRE(slot >= 0 && slot < ex->lastBatch, "ft_stereo_frontend_device_descriptors: slot holds no result");
+    *dptr = ex->d_desc + (size_t)slot * ex->geom.maxKp * 32;
+    *n = ex->h_nSel[slot];
+    return FT_OK;
+}
+
 int ft_descriptor_distance(ft_context *ctx, const uint8_t *a, const uint8_t *b, int n, int *dist) {
     FT_REQUIRE(ctx && n >= 0 && (n == 0 || (a && b && dist)), "ft_descriptor_distance: bad argument");
     if (n == 0) return FT_OK;

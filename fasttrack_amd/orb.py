@@ -362,6 +362,57 @@ class KernelController:
         return d[:n]
 
 
+class Vocabulary:
+    """ORBVocabulary (DBoW2 TemplatedVocabulary<FORB>) with the tree walk of Frame::ComputeBoW on the device.
+    Build from arrays (node 0 = root, see ft_vocabulary_create) or from ORB-SLAM3's ORBvoc.txt text format."""
+
+    def __init__(self, ctx: Context, k=None, L=None, scoring=0, weighting=0, parent=None, is_leaf=None, descriptors=None,
+                 weights=None, path=None):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        if path is not None:
+            check(lib().ft_vocabulary_load_text(ctx._h, str(path).encode(), C.byref(self._h)))
+        else:
+            parent = np.ascontiguousarray(parent, np.int32)
+            is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+            descriptors = np.ascontiguousarray(descriptors, np.uint8)
+            weights = np.ascontiguousarray(weights, np.float64)
+            check(lib().ft_vocabulary_create(ctx._h, k, L, scoring, weighting, len(parent), ptr(parent), ptr(is_leaf),
+                                             ptr(descriptors), ptr(weights), C.byref(self._h)))
+        k_, L_, nn, nw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().ft_vocabulary_info(self._h, C.byref(k_), C.byref(L_), C.byref(nn), C.byref(nw)))
+        self.k, self.L, self.n_nodes, self.n_words = k_.value, L_.value, nn.value, nw.value
+
+    def close(self):
+        if self._h:
+            lib().ft_vocabulary_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def transform(self, descriptors, levelsup=4, device_ptr=None, n=None):
+        """Frame::ComputeBoW: -> dict(word, node, weight per feature; bow_ids, bow_values (BowVector);
+        fv_nodes, fv_offsets, fv_features (FeatureVector, CSR)).  device_ptr / n: descriptors already in HBM."""
+        if device_ptr is None:
+            d = np.ascontiguousarray(descriptors, np.uint8)
+            n = len(d)
+            src, on_dev = ptr(d), 0
+        else:
+            src, on_dev = C.c_void_p(device_ptr), 1
+        m = max(n, 1)
+        word = np.zeros(m, np.uint32); node = np.zeros(m, np.uint32); w = np.zeros(m, np.float64)
+        bi = np.zeros(m, np.uint32); bv = np.zeros(m, np.float64); nb = C.c_int(0)
+        fn = np.zeros(m, np.uint32); fo = np.zeros(m + 1, np.int32); ff = np.zeros(m, np.uint32); nf = C.c_int(0)
+        check(lib().ft_bow_transform(self._h, src, n, on_dev, levelsup, ptr(word), ptr(node), ptr(w), ptr(bi), ptr(bv), m,
+                                     C.byref(nb), ptr(fn), ptr(fo), ptr(ff), m, C.byref(nf)))
+        return dict(word=word[:n], node=node[:n], weight=w[:n], bow_ids=bi[:nb.value], bow_values=bv[:nb.value],
+                    fv_nodes=fn[:nf.value], fv_offsets=fo[:nf.value + 1], fv_features=ff[:fo[nf.value]])
+
+
 class StereoFrontend:
     """Fused extract(left) + extract(right) + ComputeStereoMatches for batches of rectified pairs."""
 
@@ -387,6 +438,12 @@ class StereoFrontend:
         self._ur = alloc((B, cap), np.float32)
         self._dp = alloc((B, cap), np.float32)
         self._nm = np.zeros(B, np.int32)
+
+    def device_descriptors(self, slot, right=False):
+        """device pointer of the descriptors of pair `slot` of the last batch (see ft_stereo_frontend_device_descriptors)"""
+        p, n = C.c_void_p(), C.c_int()
+        check(lib().ft_stereo_frontend_device_descriptors(self._h, slot, 1 if right else 0, C.byref(p), C.byref(n)))
+        return p.value
 
     def close(self):
         if getattr(self, "_h", None) and self.ctx._h:

@@ -109,3 +109,43 @@ def make_noise(width: int, height: int, seed: int) -> np.ndarray:
     """Uniform random bytes: worst case for candidate counts (dense FAST responses)."""
     rng = np.random.default_rng(seed)
     return rng.integers(0, 256, (height, width), dtype=np.uint8)
+
+
+def make_vocabulary(k: int, L: int, seed: int, flip_bits: int = 40, stop_fraction: float = 0.02, ragged: bool = False):
+    """Synthetic DBoW2-style vocabulary tree: node 0 = root, every inner node has k children whose 256-bit centres are
+    the parent's with `flip_bits` random bits flipped (so walks are decided by real Hamming contests, ties included);
+    leaves carry idf-like weights, a few of them 0 (stopped words).  ragged=True ends some branches one level early.
+    Returns dict(k, L, parent, is_leaf, descriptors (n x 32 u8), weights) with nodes in breadth-first order - the
+    order ORBvoc.txt lists them in."""
+    rng = np.random.default_rng(seed)
+    parent, leaf, desc, weight, depth = [0], [0], [np.zeros(32, np.uint8)], [0.0], [0]
+    frontier = [0]
+    root_centre = rng.integers(0, 256, 32, dtype=np.uint8)
+    for level in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            base = root_centre if p == 0 else desc[p]
+            for _ in range(k):
+                bits = np.unpackbits(base).copy()
+                flip = rng.choice(256, size=max(1, flip_bits // level), replace=False)
+                bits[flip] ^= 1
+                nid = len(parent)
+                parent.append(p); desc.append(np.packbits(bits)); depth.append(level)
+                is_leaf = level == L or (ragged and level == L - 1 and rng.random() < 0.15)
+                leaf.append(1 if is_leaf else 0)
+                weight.append(0.0 if not is_leaf else (0.0 if rng.random() < stop_fraction else float(rng.uniform(0.5, 12.0))))
+                if not is_leaf:
+                    nxt.append(nid)
+        frontier = nxt
+    return dict(k=k, L=L, parent=np.array(parent, np.int32), is_leaf=np.array(leaf, np.uint8),
+                descriptors=np.stack(desc).astype(np.uint8), weights=np.array(weight, np.float64))
+
+
+def write_vocabulary_text(voc: dict, path: str, scoring: int = 0, weighting: int = 0) -> None:
+    """The text format of ORB-SLAM3's vocabulary (TemplatedVocabulary::saveToTextFile): header "k L  scoring weighting",
+    one line per node: parent is_leaf 32 descriptor bytes weight."""
+    with open(path, "w") as f:
+        f.write("%d %d  %d %d\n" % (voc["k"], voc["L"], scoring, weighting))
+        for i in range(1, len(voc["parent"])):
+            f.write("%d %d %s %r\n" % (voc["parent"][i], voc["is_leaf"][i], " ".join(str(int(b)) for b in voc["descriptors"][i]),
+                                        float(voc["weights"][i])))

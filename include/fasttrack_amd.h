@@ -180,6 +180,10 @@ FT_API int ft_stereo_frontend_process(ft_stereo_frontend *fe, const uint8_t *con
                                       int height, int stride, ft_keypoint *keysL, uint8_t *descL, int *nL,
                                       ft_keypoint *keysR, uint8_t *descR, int *nR, int capacity, float *uright,
                                       float *depth, int *n_matches);
+/* the descriptors of pair `slot` of the batch processed last, where the front end left them in HBM (n x 32 bytes in
+ * the order of the host results; valid until the front end processes another batch): input of ft_bow_transform
+ * (Frame::ComputeBoW) without a copy */
+FT_API int ft_stereo_frontend_device_descriptors(ft_stereo_frontend *fe, int slot, int right, const uint8_t **dptr, int *n);
 
 /* ------------------------------------------------------------------------------------------------
  * Fisheye stereo matching (matching part).
@@ -366,6 +370,42 @@ FT_API int ft_tracked_frame_holder_obs(ft_tracked_frame *tf, int *holder_obs);
 /* ORBmatcher::DescriptorDistance for n pairs on the device (src/ORBmatcher.cc:2256-2272,
  * device copy src/Kernels/CudaUtils.cu:42-56).  a, b: n x 32 host bytes; dist: n ints. */
 FT_API int ft_descriptor_distance(ft_context *ctx, const uint8_t *a, const uint8_t *b, int n, int *dist);
+
+/* ----------------------------------------------------------------------------------------------
+ * Frame::ComputeBoW (src/Frame.cc:762-769): DBoW2's
+ * TemplatedVocabulary<FORB::TDescriptor, FORB>::transform(features, BowVector&, FeatureVector&, levelsup)
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1194) with the tree walk of every descriptor
+ * (:1208-1253, FORB::distance Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101) on the device.
+ *
+ * A vocabulary is the k-ary tree of ORBvoc.txt: node 0 is the root, node i > 0 has parent[i] < i ... (any order of
+ * the file is accepted), the children of a node are visited in ascending node id (the order loadFromTextFile
+ * appends them, :1369-1420), leaves are the words, numbered in ascending node id.  scoring / weighting use the
+ * reference's enum values (BowVector.h:39-56: weighting 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring 0 L1_NORM,
+ * 1 L2_NORM, 2 CHI_SQUARE, 3 KL, 4 BHATTACHARYYA, 5 DOT_PRODUCT).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ft_vocabulary ft_vocabulary;
+/* n_nodes includes the root (entry 0 of every array is ignored except is_leaf); descriptors: n_nodes x 32 bytes */
+FT_API int ft_vocabulary_create(ft_context *ctx, int k, int L, int scoring, int weighting, int n_nodes,
+                                const int *parent, const uint8_t *is_leaf, const uint8_t *descriptors,
+                                const double *weights, ft_vocabulary **out);
+/* the text format ORB-SLAM3 ships (TemplatedVocabulary::loadFromTextFile, :1338-1423): "k L scoring weighting", then
+ * one line per node: parent is_leaf d0 .. d31 weight */
+FT_API int ft_vocabulary_load_text(ft_context *ctx, const char *path, ft_vocabulary **out);
+FT_API int ft_vocabulary_destroy(ft_vocabulary *voc);
+FT_API int ft_vocabulary_info(const ft_vocabulary *voc, int *k, int *L, int *n_nodes, int *n_words);
+/* transform of the n descriptors of one frame (host n x 32 bytes, or a device pointer with on_device != 0, e.g. the
+ * descriptors a stereo front end left in HBM).
+ * Per feature (each may be NULL): word_ids, node_ids (the ancestor at level L - levelsup, 0 = root if that level is
+ * <= 0; the leaf itself if the walk ends above that level), weights (the word's weight; 0 = stopped word).
+ * BowVector: bow_ids ascending with bow_values (after the weighting and the normalisation the scoring asks for),
+ * n_bow entries (bow_capacity >= n is always enough).
+ * FeatureVector in CSR form: fv_nodes ascending, the feature indices of node j (ascending, as push_back leaves them)
+ * are fv_features[fv_offsets[j] .. fv_offsets[j + 1]), n_fv nodes (fv_nodes / fv_offsets hold fv_capacity and
+ * fv_capacity + 1 entries, fv_features n). */
+FT_API int ft_bow_transform(ft_vocabulary *voc, const uint8_t *descriptors, int n, int on_device, int levelsup,
+                            unsigned *word_ids, unsigned *node_ids, double *weights, unsigned *bow_ids,
+                            double *bow_values, int bow_capacity, int *n_bow, unsigned *fv_nodes, int *fv_offsets,
+                            unsigned *fv_features, int fv_capacity, int *n_fv);
 
 #ifdef __cplusplus
 }

@@ -483,3 +483,49 @@ def fisheye_stereo(rig: FisheyeRig, descL, keysL, descR, keysR, level_sigma2):
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     n = lib().orc_fisheye_stereo(C.byref(rig), _p(descL), _p(keysL), nL, _p(descR), _p(keysR), nR, _p(ls2), _p(m), _p(d), _p(p))
     return dict(matches=m[:nL], depth=d[:nL], p3d=p[:nL], n=n)
+
+
+class Vocabulary:
+    """DBoW2 ORBVocabulary (oracle): build from arrays (node 0 = root) or from the ORBvoc.txt text format."""
+
+    def __init__(self, k=None, L=None, scoring=0, weighting=0, parent=None, is_leaf=None, descriptors=None, weights=None,
+                 path=None):
+        L_ = lib()
+        L_.orc_vocabulary_create.restype = C.c_void_p
+        L_.orc_vocabulary_create.argtypes = [C.c_int] * 5 + [C.c_void_p] * 4
+        L_.orc_vocabulary_load_text.restype = C.c_void_p
+        L_.orc_vocabulary_load_text.argtypes = [C.c_char_p]
+        L_.orc_vocabulary_destroy.argtypes = [C.c_void_p]
+        L_.orc_vocabulary_nodes.argtypes = [C.c_void_p]
+        L_.orc_vocabulary_words.argtypes = [C.c_void_p]
+        L_.orc_bow_transform.restype = None
+        L_.orc_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10
+        if path is not None:
+            self._h = L_.orc_vocabulary_load_text(str(path).encode())
+            if not self._h:
+                raise ValueError("not a vocabulary text file: %s" % path)
+        else:
+            parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+            descriptors = np.ascontiguousarray(descriptors, np.uint8); weights = np.ascontiguousarray(weights, np.float64)
+            self._h = L_.orc_vocabulary_create(k, L, scoring, weighting, len(parent), _p(parent), _p(is_leaf),
+                                               _p(descriptors), _p(weights))
+        self.n_nodes = L_.orc_vocabulary_nodes(self._h)
+        self.n_words = L_.orc_vocabulary_words(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_vocabulary_destroy(self._h)
+            self._h = None
+
+    def transform(self, descriptors, levelsup=4):
+        """-> dict(word, node, weight per feature; bow_ids, bow_values; fv_nodes, fv_offsets, fv_features)"""
+        d = np.ascontiguousarray(descriptors, np.uint8)
+        n = len(d)
+        m = max(n, 1)
+        word = np.zeros(m, np.uint32); node = np.zeros(m, np.uint32); w = np.zeros(m, np.float64)
+        bi = np.zeros(m, np.uint32); bv = np.zeros(m, np.float64); nb = C.c_int(0)
+        fn = np.zeros(m, np.uint32); fo = np.zeros(m + 1, np.int32); ff = np.zeros(m, np.uint32); nf = C.c_int(0)
+        lib().orc_bow_transform(self._h, _p(d), n, levelsup, _p(word), _p(node), _p(w), _p(bi), _p(bv),
+                                C.addressof(nb), _p(fn), _p(fo), _p(ff), C.addressof(nf))
+        return dict(word=word[:n], node=node[:n], weight=w[:n], bow_ids=bi[:nb.value], bow_values=bv[:nb.value],
+                    fv_nodes=fn[:nf.value], fv_offsets=fo[:nf.value + 1], fv_features=ff[:fo[nf.value]])

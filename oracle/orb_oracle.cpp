@@ -1491,3 +1491,201 @@ int orc_fisheye_stereo(const orc_fisheye_rig *rig, const uint8_t *descL, const o
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Frame::ComputeBoW (src/Frame.cc:762-769) = mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4):
+// DBoW2's TemplatedVocabulary restated with the same containers (std::map, std::vector) and loops.
+// ------------------------------------------------------------------------------------------------
+#include <fstream>
+#include <map>
+#include <sstream>
+
+struct orc_vocabulary {
+    struct Node {  // TemplatedVocabulary.h:297-330
+        double weight = 0;
+        std::vector<unsigned> children;
+        unsigned parent = 0;
+        uint8_t descriptor[32] = {0};
+        unsigned word_id = 0;
+        bool isLeaf() const { return children.empty(); }
+    };
+    int k = 0, L = 0, scoring = 0, weighting = 0;
+    std::vector<Node> nodes;
+    int nWords = 0;
+};
+
+namespace {
+
+// FORB::distance (FORB.cpp:81-101): the parallel bit count over eight 32-bit words
+int forb_distance(const uint8_t *a, const uint8_t *b) {
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        unsigned int v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+// TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (:1208-1253)
+void voc_transform_one(const orc_vocabulary *voc, const uint8_t *feature, unsigned &word_id, double &weight, unsigned &nid,
+                       int levelsup) {
+    const int nid_level = voc->L - levelsup;
+    nid = 0;  // root when nid_level <= 0 (:1218); the reference leaves it unset if the walk ends above nid_level
+    unsigned final_id = 0;
+    int current_level = 0;
+    do {
+        ++current_level;
+        const std::vector<unsigned> &nodes = voc->nodes[final_id].children;
+        final_id = nodes[0];
+        double best_d = forb_distance(feature, voc->nodes[final_id].descriptor);
+        for (size_t j = 1; j < nodes.size(); j++) {
+            const unsigned id = nodes[j];
+            const double d = forb_distance(feature, voc->nodes[id].descriptor);
+            if (d < best_d) {
+                best_d = d;
+                final_id = id;
+            }
+        }
+        if (current_level == nid_level) nid = final_id;
+    } while (!voc->nodes[final_id].isLeaf());
+    if (nid_level > current_level) nid = final_id;  // defined here as the leaf (fasttrack_amd.h: ft_bow_transform)
+    word_id = voc->nodes[final_id].word_id;
+    weight = voc->nodes[final_id].weight;
+}
+
+}  // namespace
+
+extern "C" {
+
+orc_vocabulary *orc_vocabulary_create(int k, int L, int scoring, int weighting, int n_nodes, const int *parent,
+                                      const uint8_t *is_leaf, const uint8_t *descriptors, const double *weights) {
+    orc_vocabulary *v = new orc_vocabulary;
+    v->k = k;
+    v->L = L;
+    v->scoring = scoring;
+    v->weighting = weighting;
+    v->nodes.resize(n_nodes);
+    for (int nid = 1; nid < n_nodes; nid++) {  // the body of loadFromTextFile's loop (:1384-1419)
+        v->nodes[nid].parent = (unsigned)parent[nid];
+        v->nodes[parent[nid]].children.push_back((unsigned)nid);
+        memcpy(v->nodes[nid].descriptor, descriptors + (size_t)32 * nid, 32);
+        v->nodes[nid].weight = weights[nid];
+        if (is_leaf[nid]) v->nodes[nid].word_id = (unsigned)v->nWords++;
+    }
+    return v;
+}
+
+orc_vocabulary *orc_vocabulary_load_text(const char *path) {
+    std::ifstream f(path);
+    if (!f.good()) return nullptr;
+    std::string s;
+    std::getline(f, s);
+    std::stringstream ss;
+    ss << s;
+    int k = -1, L = -1, n1 = -1, n2 = -1;
+    ss >> k;
+    ss >> L;
+    ss >> n1;
+    ss >> n2;
+    if (k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) return nullptr;  // :1359
+    std::vector<int> parent(1, 0);
+    std::vector<uint8_t> leaf(1, 0), desc(32, 0);
+    std::vector<double> weight(1, 0.0);
+    while (!f.eof()) {
+        std::string snode;
+        std::getline(f, snode);
+        if (snode.find_first_not_of(" \t\r\n") == std::string::npos) continue;  // (a trailing empty line: see bow.cpp)
+        std::stringstream ssnode;
+        ssnode << snode;
+        int pid = 0, nIsLeaf = 0;
+        ssnode >> pid;
+        ssnode >> nIsLeaf;
+        const size_t at = desc.size();
+        desc.resize(at + 32, 0);
+        for (int iD = 0; iD < 32; iD++) {  // FORB::fromString (FORB.cpp:120-135)
+            int n = 0;
+            ssnode >> n;
+            if (!ssnode.fail()) desc[at + iD] = (unsigned char)n;
+        }
+        double w = 0.0;
+        ssnode >> w;
+        parent.push_back(pid);
+        leaf.push_back(nIsLeaf > 0 ? 1 : 0);
+        weight.push_back(w);
+    }
+    return orc_vocabulary_create(k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data());
+}
+
+void orc_vocabulary_destroy(orc_vocabulary *v) { delete v; }
+int orc_vocabulary_nodes(const orc_vocabulary *v) { return (int)v->nodes.size(); }
+int orc_vocabulary_words(const orc_vocabulary *v) { return v->nWords; }
+
+void orc_bow_transform(const orc_vocabulary *voc, const uint8_t *descriptors, int n, int levelsup, unsigned *word_ids,
+                       unsigned *node_ids, double *weights, unsigned *bow_ids, double *bow_values, int *n_bow,
+                       unsigned *fv_nodes, int *fv_offsets, unsigned *fv_features, int *n_fv) {
+    std::map<unsigned, double> v;                 // BowVector
+    std::map<unsigned, std::vector<unsigned>> fv;  // FeatureVector
+    if (voc->nodes.size() > 1) {                  // !empty() (:1134)
+        const bool must = voc->scoring != 5;      // mustNormalize: all but DotProductScoring (ScoringObject.h:73-89)
+        const bool l2 = voc->scoring == 1;
+        const bool tf = voc->weighting == 0 || voc->weighting == 1;  // TF_IDF || TF (:1145)
+        for (int i_feature = 0; i_feature < n; i_feature++) {
+            unsigned id, nid;
+            double w;
+            voc_transform_one(voc, descriptors + (size_t)32 * i_feature, id, w, nid, levelsup);
+            if (word_ids) word_ids[i_feature] = id;
+            if (node_ids) node_ids[i_feature] = nid;
+            if (weights) weights[i_feature] = w;
+            if (w > 0) {  // not stopped
+                if (tf) {  // BowVector::addWeight (BowVector.cpp:32-44)
+                    auto vit = v.lower_bound(id);
+                    if (vit != v.end() && !(v.key_comp()(id, vit->first))) vit->second += w;
+                    else v.insert(vit, std::make_pair(id, w));
+                } else {  // BowVector::addIfNotExist (:48-56)
+                    auto vit = v.lower_bound(id);
+                    if (vit == v.end() || (v.key_comp()(id, vit->first))) v.insert(vit, std::make_pair(id, w));
+                }
+                fv[nid].push_back((unsigned)i_feature);  // FeatureVector::addFeature (FeatureVector.cpp:31-45)
+            }
+        }
+        if (tf && !v.empty() && !must) {  // :1164-1170
+            const double nd = v.size();
+            for (auto vit = v.begin(); vit != v.end(); vit++) vit->second /= nd;
+        }
+        if (must) {  // BowVector::normalize (BowVector.cpp:60-85)
+            double norm = 0.0;
+            if (!l2) {
+                for (auto it = v.begin(); it != v.end(); ++it) norm += fabs(it->second);
+            } else {
+                for (auto it = v.begin(); it != v.end(); ++it) norm += it->second * it->second;
+                norm = sqrt(norm);
+            }
+            if (norm > 0.0)
+                for (auto it = v.begin(); it != v.end(); ++it) it->second /= norm;
+        }
+    }
+    int m = 0;
+    for (auto it = v.begin(); it != v.end(); ++it, ++m) {
+        if (bow_ids) bow_ids[m] = it->first;
+        if (bow_values) bow_values[m] = it->second;
+    }
+    if (n_bow) *n_bow = m;
+    int j = 0, off = 0;
+    for (auto it = fv.begin(); it != fv.end(); ++it, ++j) {
+        if (fv_nodes) fv_nodes[j] = it->first;
+        if (fv_offsets) fv_offsets[j] = off;
+        for (unsigned f : it->second) {
+            if (fv_features) fv_features[off] = f;
+            off++;
+        }
+    }
+    if (fv_offsets) fv_offsets[j] = off;
+    if (n_fv) *n_fv = j;
+}
+
+}  // extern "C"

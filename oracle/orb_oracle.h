@@ -198,6 +198,24 @@ int orc_is_in_frustum(const orc_frame *F, const orc_frame_pose *T, const orc_map
                       float *view_cos, float *view_cos_r, float *proj_x, float *proj_y, float *proj_xr,
                       float *proj_yr, float *depth, float *depth_r);
 
+/* ---- Frame::ComputeBoW (src/Frame.cc:762-769): DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>
+ *      (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) restated: loadFromTextFile :1338-1423, transform of a frame
+ *      :1127-1194, of one feature :1208-1253, FORB::distance FORB.cpp:81-101, BowVector.cpp:32-85,
+ *      FeatureVector.cpp:31-45 ---- */
+typedef struct orc_vocabulary orc_vocabulary;
+/* node 0 is the root; children are appended in ascending node id, words numbered in node order */
+orc_vocabulary *orc_vocabulary_create(int k, int L, int scoring, int weighting, int n_nodes, const int *parent,
+                                      const uint8_t *is_leaf, const uint8_t *descriptors, const double *weights);
+orc_vocabulary *orc_vocabulary_load_text(const char *path);
+void orc_vocabulary_destroy(orc_vocabulary *v);
+int orc_vocabulary_nodes(const orc_vocabulary *v);
+int orc_vocabulary_words(const orc_vocabulary *v);
+/* per feature: word_ids, node_ids, weights (each may be NULL); BowVector as (ids, values) in map order, returns its
+ * size in *n_bow; FeatureVector in CSR form (fv_nodes, fv_offsets[n_fv + 1], fv_features[n]) */
+void orc_bow_transform(const orc_vocabulary *v, const uint8_t *descriptors, int n, int levelsup, unsigned *word_ids,
+                       unsigned *node_ids, double *weights, unsigned *bow_ids, double *bow_values, int *n_bow,
+                       unsigned *fv_nodes, int *fv_offsets, unsigned *fv_features, int *n_fv);
+
 #ifdef __cplusplus
 }
 #endif
