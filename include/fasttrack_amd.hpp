@@ -13,6 +13,7 @@
 #pragma once
 
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -298,6 +299,39 @@ public:
 private:
     ft_tracked_frame *h_ = nullptr;
     int N_ = 0;
+};
+
+// ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) for Frame::ComputeBoW: same call as
+// mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4) (src/Frame.cc:762-769), with the tree walk on the
+// device.  BowVector / FeatureVector are the std::map types of DBoW2 (BowVector.h:59, FeatureVector.h:24).
+class ORBVocabulary {
+public:
+    typedef std::map<unsigned, double> BowVector;
+    typedef std::map<unsigned, std::vector<unsigned>> FeatureVector;
+    ORBVocabulary(Context &ctx, const std::string &textFile) { check(ft_vocabulary_load_text(ctx.handle(), textFile.c_str(), &h_)); }
+    ~ORBVocabulary() { ft_vocabulary_destroy(h_); }
+    ORBVocabulary(const ORBVocabulary &) = delete;
+    ORBVocabulary &operator=(const ORBVocabulary &) = delete;
+    // descriptors: N x 32 bytes (cv::Mat mDescriptors is continuous); onDevice: a pointer into HBM, e.g. from
+    // ft_stereo_frontend_device_descriptors
+    void transform(const uint8_t *descriptors, int N, BowVector &v, FeatureVector &fv, int levelsup, bool onDevice = false) {
+        v.clear();
+        fv.clear();
+        if (N <= 0) return;
+        std::vector<unsigned> ids(N), nodes(N), feats(N);
+        std::vector<double> vals(N);
+        std::vector<int> offs(N + 1);
+        int nb = 0, nf = 0;
+        check(ft_bow_transform(h_, descriptors, N, onDevice ? 1 : 0, levelsup, nullptr, nullptr, nullptr, ids.data(), vals.data(), N,
+                               &nb, nodes.data(), offs.data(), feats.data(), N, &nf));
+        for (int j = 0; j < nb; j++) v.emplace_hint(v.end(), ids[j], vals[j]);
+        for (int j = 0; j < nf; j++)
+            fv.emplace_hint(fv.end(), nodes[j], std::vector<unsigned>(feats.begin() + offs[j], feats.begin() + offs[j + 1]));
+    }
+    ft_vocabulary *handle() { return h_; }
+
+private:
+    ft_vocabulary *h_ = nullptr;
 };
 
 }  // namespace fasttrack
