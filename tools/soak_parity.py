@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Long randomized parity run on an MI355X (not part of the test suite): extractor and fused stereo front end against
-the oracle over many random configurations.  usage: tools/soak_parity.py [--trials N] [--seed S] [--unaligned]
+the oracle over many random configurations (every fifth trial also Frame::ComputeBoW on a random vocabulary).
+usage: tools/soak_parity.py [--trials N] [--seed S]
 
 Every trial draws image size, feature count, pyramid depth, scale factor, FAST thresholds and texture density,
 runs the HIP path through the C ABI and compares keypoints (all fields, angles bit-exactly), descriptors and - for
@@ -63,6 +64,20 @@ def main():
             err = same_keys(gk, gd, ok, od) or (None if gm == om else "mono count")
             kps += len(ok)
             del ex
+            if err is None and trial % 5 == 0 and len(ok) > 0:  # Frame::ComputeBoW on this frame's descriptors
+                k, Lv = int(rng.integers(1, 21)), int(rng.integers(1, 5))
+                if k ** Lv > 20000:
+                    Lv = max(1, int(np.log(20000) / np.log(max(k, 2))))
+                voc = synth.make_vocabulary(k, Lv, seed=int(rng.integers(1 << 30)), ragged=bool(rng.integers(2)),
+                                            flip_bits=int(rng.choice([4, 40, 128])))
+                sc, wt = int(rng.integers(0, 6)), int(rng.integers(0, 4))
+                va = (voc["parent"], voc["is_leaf"], voc["descriptors"], voc["weights"])
+                gv, ov = orb.Vocabulary(ctx, k, Lv, sc, wt, *va), ob.Vocabulary(k, Lv, sc, wt, *va)
+                lu = int(rng.integers(0, Lv + 2))
+                a, b = gv.transform(od, lu), ov.transform(od, lu)
+                if not all(np.array_equal(a[key], b[key]) for key in a):
+                    err = "bow transform k=%d L=%d scoring=%d weighting=%d levelsup=%d" % (k, Lv, sc, wt, lu)
+                gv.close()
             if err is None and trial % args.frontend_every == 0 and nlevels >= 2:
                 B = int(rng.integers(1, 4))
                 intr = synth.intrinsics(w, h)
