@@ -181,6 +181,22 @@ struct FtStereoArgs {
     FtSortedR *sorted;                 // device [batch * capacity]: right keypoints in bucket order
     int rowStride;                     // >= level-0 height + 2
 };
+// Result delivery of a small batch (latency mode): one kernel writes everything the host needs - keypoints and
+// descriptors of both cameras, mvuRight, mvDepth and the counters - straight into pinned host memory, instead of
+// eleven small copies through the DMA queue (each a few microseconds of work behind ~10 us of latency).
+struct FtDeliverArgs {
+    const ft_keypoint *keysL, *keysR;  // device, rows of srcStride records per image
+    const uint8_t *descL, *descR;
+    const float *uright, *depth;
+    const int *nL, *nR, *nMatches;      // device [batch]
+    const int *overflowL, *overflowR;   // device flags of the two extractors
+    ft_keypoint *oKeysL, *oKeysR;       // pinned host (any of the row destinations may be null), rows of dstStride records
+    uint8_t *oDescL, *oDescR;
+    float *oUright, *oDepth;
+    int *oNL, *oNR, *oNMatches, *oOverflowL, *oOverflowR;
+    int srcStride, dstStride;
+};
+int ft_launch_deliver(hipStream_t st, int batch, const FtDeliverArgs &a);
 struct FtFisheyeRig {
     float cam1[8], cam2[8], precision, Rlr[9], tlr[3];
     float sigma2[FT_MAX_LEVELS];

@@ -522,6 +522,45 @@ __global__ __launch_bounds__(64) void k_fisheye_triangulate(FtFisheyeRig rig, co
 
 }  // namespace
 
+namespace {
+// grid (DL_BLOCKS, batch): the blocks of an image share the rows of its six result arrays dword by dword (every record
+// size is a multiple of four bytes); the stores go over the host link, the counters with them
+#define DL_BLOCKS 24
+__global__ __launch_bounds__(256) void k_deliver(FtDeliverArgs a) {
+    const int slot = blockIdx.y;
+    const int nl = a.nL[slot], nr = a.nR[slot];
+    const int t = blockIdx.x * 256 + threadIdx.x, T = DL_BLOCKS * 256;
+    auto rows = [&](const void *src, void *dst, int recBytes, int n) {
+        if (!dst || n <= 0) return;
+        const unsigned *s = (const unsigned *)((const uint8_t *)src + (size_t)slot * a.srcStride * recBytes);
+        unsigned *d = (unsigned *)((uint8_t *)dst + (size_t)slot * a.dstStride * recBytes);
+        const int words = n * (recBytes >> 2);
+        for (int i = t; i < words; i += T) d[i] = s[i];
+    };
+    rows(a.keysL, a.oKeysL, (int)sizeof(ft_keypoint), nl);
+    rows(a.descL, a.oDescL, 32, nl);
+    rows(a.uright, a.oUright, 4, nl);
+    rows(a.depth, a.oDepth, 4, nl);
+    rows(a.keysR, a.oKeysR, (int)sizeof(ft_keypoint), nr);
+    rows(a.descR, a.oDescR, 32, nr);
+    if (t == 0) {
+        a.oNL[slot] = nl;
+        a.oNR[slot] = nr;
+        a.oNMatches[slot] = a.nMatches[slot];
+        if (slot == 0) {
+            *a.oOverflowL = *a.overflowL;
+            *a.oOverflowR = *a.overflowR;
+        }
+    }
+}
+}  // namespace
+
+int ft_launch_deliver(hipStream_t st, int batch, const FtDeliverArgs &a) {
+    hipLaunchKernelGGL(k_deliver, dim3(DL_BLOCKS, batch), dim3(256), 0, st, a);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
 int ft_launch_stereo_match(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0L,
                            const uint8_t *const *l0R, int l0pitchL, int l0pitchR, const uint8_t *pyrL,
                            const uint8_t *pyrR, const FtStereoArgs &a) {

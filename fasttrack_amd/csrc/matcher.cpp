@@ -226,6 +226,10 @@ static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL
     }
     const bool tm = fe->ctx->kernelTiming;
     hipStream_t st = L->streamB;
+    // latency mode: the results of a small batch are written to pinned host memory by one kernel (FtDeliverArgs); large
+    // batches keep the DMA copies, which cost no compute units
+    static const bool deliverOn = !(getenv("FT_DELIVER_KERNEL") && atoi(getenv("FT_DELIVER_KERNEL")) == 0);
+    const bool deliver = deliverOn && dev && batch <= FT_GRAPH_MAX_BATCH;
     double tOct = 0, tWait = 0, tLaunch = 0;
     // pageable result arrays go through the library's pinned staging buffers and a host memcpy in _wait
     // (with the device octree the per-image counts are unknown until the end: whole rows are copied, which the
@@ -309,6 +313,7 @@ static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL
             ft_set_error("stereo front end: output capacity too small (use ft_extractor_max_keypoints)");
             return FT_ERR_CAPACITY;
         }
+        if (deliver) continue;  // one kernel at the end delivers everything
         if (maxNL > 0) {
             FT_HIP(d2h(keysL, L->h_keys, L->d_keys, kp, b0, nb, maxNL));
             FT_HIP(d2h(descL, L->h_desc, L->d_desc, 32, b0, nb, maxNL));
@@ -322,9 +327,39 @@ static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL
         FT_HIP(hipMemcpyAsync(fe->h_nMatches + b0, fe->d_nMatches + b0, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
         tLaunch += tL.ms();
     }
-    rc = ft_extract_finish_counts(L, batch, st);
-    if (rc == FT_OK) rc = ft_extract_finish_counts(R, batch, st);
-    if (rc != FT_OK) return rc;
+    if (deliver) {
+        FtDeliverArgs d;
+        d.keysL = L->d_keys;
+        d.keysR = R->d_keys;
+        d.descL = L->d_desc;
+        d.descR = R->d_desc;
+        d.uright = fe->d_uright;
+        d.depth = fe->d_depth;
+        d.nL = L->d_nSel;
+        d.nR = R->d_nSel;
+        d.nMatches = fe->d_nMatches;
+        d.overflowL = L->d_overflow;
+        d.overflowR = R->d_overflow;
+        d.oKeysL = direct ? keysL : L->h_keys;
+        d.oKeysR = direct ? keysR : R->h_keys;
+        d.oDescL = direct ? descL : L->h_desc;
+        d.oDescR = direct ? descR : R->h_desc;
+        d.oUright = direct ? uright : fe->h_uright;
+        d.oDepth = direct ? depth : fe->h_depth;
+        d.oNL = L->h_nSel;
+        d.oNR = R->h_nSel;
+        d.oNMatches = fe->h_nMatches;
+        d.oOverflowL = L->h_overflow;
+        d.oOverflowR = R->h_overflow;
+        d.srcStride = g.maxKp;
+        d.dstStride = direct ? capacity : g.maxKp;
+        rc = ft_launch_deliver(st, batch, d);
+        if (rc != FT_OK) return rc;
+    } else {
+        rc = ft_extract_finish_counts(L, batch, st);
+        if (rc == FT_OK) rc = ft_extract_finish_counts(R, batch, st);
+        if (rc != FT_OK) return rc;
+    }
     if (capture) {  // join: the stage-B stream of the left camera is the tail of everything
         FT_HIP(hipEventRecord(fe->evJoin, st));
         FT_HIP(hipStreamWaitEvent(L->stream, fe->evJoin, 0));
