@@ -725,6 +725,8 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
     const int sb = (batch + S - 1) / S;
     // everything a batch needs with the device octree, enqueued without a host synchronisation (capture != 0: ex->stream is
     // being captured into a graph; the octree / stage-B streams fork from it through events and are joined back)
+    static const bool deliverOn = !(getenv("FT_DELIVER_KERNEL") && atoi(getenv("FT_DELIVER_KERNEL")) == 0);
+    const bool deliver = deliverOn && batch <= 8;  // (FtDeliverArgs, ft_internal.h)
     auto enqueueDevice = [&](int capture) -> int {
         int r = ft_extract_prepare(ex, images, batch, on_device, width, height, stride);
         if (r != FT_OK) return r;
@@ -738,10 +740,25 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
             const int nb = std::min(sb, batch - b0);
             FT_HIP(hipStreamWaitEvent(ex->streamB, ex->evA[s], 0));
             r = ft_extract_launch_b(ex, b0, nb, ex->streamB);
-            if (r == FT_OK) r = ft_extract_download(ex, b0, nb, ex->streamB);
+            if (r == FT_OK && !deliver) r = ft_extract_download(ex, b0, nb, ex->streamB);
             if (r != FT_OK) return r;
         }
-        r = ft_extract_finish_counts(ex, batch, ex->streamB);
+        if (deliver) {  // latency mode: one kernel writes keypoints, descriptors and counters to the pinned staging
+            FtDeliverArgs d;
+            memset(&d, 0, sizeof d);
+            d.keysL = ex->d_keys;
+            d.descL = ex->d_desc;
+            d.nL = ex->d_nSel;
+            d.overflowL = ex->d_overflow;
+            d.oKeysL = ex->h_keys;
+            d.oDescL = ex->h_desc;
+            d.oNL = ex->h_nSel;
+            d.oOverflowL = ex->h_overflow;
+            d.srcStride = d.dstStride = ex->geom.maxKp;
+            r = ft_launch_deliver(ex->streamB, batch, d);
+        } else {
+            r = ft_extract_finish_counts(ex, batch, ex->streamB);
+        }
         if (r != FT_OK) return r;
         if (capture) {
             FT_HIP(hipEventRecord(ex->evJoin, ex->streamB));

@@ -528,7 +528,7 @@ namespace {
 #define DL_BLOCKS 24
 __global__ __launch_bounds__(256) void k_deliver(FtDeliverArgs a) {
     const int slot = blockIdx.y;
-    const int nl = a.nL[slot], nr = a.nR[slot];
+    const int nl = a.nL[slot], nr = a.nR ? a.nR[slot] : 0;  // one camera only: the right-hand pointers are null
     const int t = blockIdx.x * 256 + threadIdx.x, T = DL_BLOCKS * 256;
     auto rows = [&](const void *src, void *dst, int recBytes, int n) {
         if (!dst || n <= 0) return;
@@ -545,11 +545,11 @@ __global__ __launch_bounds__(256) void k_deliver(FtDeliverArgs a) {
     rows(a.descR, a.oDescR, 32, nr);
     if (t == 0) {
         a.oNL[slot] = nl;
-        a.oNR[slot] = nr;
-        a.oNMatches[slot] = a.nMatches[slot];
+        if (a.oNR) a.oNR[slot] = nr;
+        if (a.oNMatches) a.oNMatches[slot] = a.nMatches[slot];
         if (slot == 0) {
             *a.oOverflowL = *a.overflowL;
-            *a.oOverflowR = *a.overflowR;
+            if (a.oOverflowR) *a.oOverflowR = *a.overflowR;
         }
     }
 }
