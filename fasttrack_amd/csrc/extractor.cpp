@@ -240,6 +240,26 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
     int rc = ft_set_device(ex->ctx);
     if (rc != FT_OK) return rc;
     const FtGeom &g = ex->geom;
+    static const bool uploadKernel = !(getenv("FT_UPLOAD_KERNEL") && atoi(getenv("FT_UPLOAD_KERNEL")) == 0);
+    if (!on_device && ex->stageHost && uploadKernel) {
+        // graph path (latency mode): the host copies the frames into pinned staging, one (captured) kernel moves them
+        // into the slot pyramids and writes the level-0 pointer table (ft_launch_upload)
+        for (int b = 0; b < batch; b++) {
+            if (!images[b]) {
+                ft_set_error("extract: empty image");
+                return FT_ERR_EMPTY;
+            }
+            uint8_t *stg = ex->h_stage + (size_t)b * width * height;
+            for (int y = 0; y < height; y++) memcpy(stg + (size_t)y * width, images[b] + (size_t)y * stride, width);
+            ex->h_l0[b] = ex->d_pyr + (size_t)b * g.pyrPerSlot + g.lv[0].off;
+        }
+        ex->l0External = false;
+        ex->l0Aligned = true;
+        ex->l0pitch = g.lv[0].pitch;
+        ex->lastBatch = batch;
+        return ft_launch_upload(ex->stream, batch, ex->h_stage, width, height, ex->d_pyr + g.lv[0].off, g.lv[0].pitch,
+                                g.pyrPerSlot, ex->d_l0);
+    }
     for (int b = 0; b < batch; b++) {
         if (!images[b]) {
             ft_set_error("extract: empty image");

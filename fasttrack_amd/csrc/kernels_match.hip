@@ -555,6 +555,37 @@ __global__ __launch_bounds__(256) void k_deliver(FtDeliverArgs a) {
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void k_upload(const uint8_t *stage, int width, int height, uint8_t *slot0, int pitch,
+                                                size_t slotBytes, const uint8_t **l0Table) {
+    const int slot = blockIdx.y;
+    const uint8_t *src = stage + (size_t)slot * width * height;
+    uint8_t *dst = slot0 + (size_t)slot * slotBytes;
+    const int t = blockIdx.x * 256 + threadIdx.x, T = gridDim.x * 256;
+    if ((width & 3) == 0) {  // dword columns (the slot pitch is a multiple of 64 bytes)
+        const int wq = width >> 2, n = wq * height;
+        for (int i = t; i < n; i += T) {
+            const int y = i / wq, x = i - y * wq;
+            ((unsigned *)(dst + (size_t)y * pitch))[x] = ((const unsigned *)(src + (size_t)y * width))[x];
+        }
+    } else {
+        const int n = width * height;
+        for (int i = t; i < n; i += T) {
+            const int y = i / width, x = i - y * width;
+            dst[(size_t)y * pitch + x] = src[(size_t)y * width + x];
+        }
+    }
+    if (t == 0) l0Table[slot] = dst;
+}
+}  // namespace
+
+int ft_launch_upload(hipStream_t st, int batch, const uint8_t *stage, int width, int height, uint8_t *slot0, int pitch,
+                     size_t slotBytes, const uint8_t **l0Table) {
+    hipLaunchKernelGGL(k_upload, dim3(48, batch), dim3(256), 0, st, stage, width, height, slot0, pitch, slotBytes, l0Table);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
 int ft_launch_deliver(hipStream_t st, int batch, const FtDeliverArgs &a) {
     hipLaunchKernelGGL(k_deliver, dim3(DL_BLOCKS, batch), dim3(256), 0, st, a);
     FT_HIP(hipGetLastError());
