@@ -36,8 +36,14 @@ struct FtDevLastPoints {
 
 // writer lists of the previous pass: head[kp] -> slot s (= 4*point + write kind), next[s]
 struct FtClaims {
-    const int *head, *next;
-    const int *obs;  // Observations() per map point
+    const int *head, *next;  // writer lists of the previous pass
+    const int *obs;          // Observations() per map point
+    // housekeeping of the claim iteration, done by the search kernel itself so that a pass is two launches:
+    int *headNext;           // the list heads this pass's k_build_claims will fill: reset to -1 here
+    int nKp;
+    int *changedCur;         // this pass's "something changed" flag: reset to 0 here
+    const int *changedPrev;  // the previous pass's flag (null for the first pass of a burst): 0 = fixed point reached,
+                             // this pass would reproduce its input and returns at once
 };
 
 struct FtPose {
@@ -79,5 +85,5 @@ int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocal
                            float nnRatio, int *res, const FtLocalRaw &raw);
 int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
                           const FtPose &Tcw, float th, int forward, int backward, int *res, const FtLastRaw &raw);
-int ft_launch_build_claims(hipStream_t st, const int *res, const int *prevRes, int nPoints, int nKp, int *head,
-                           int *next, int *changed);
+int ft_launch_build_claims(hipStream_t st, const int *res, const int *prevRes, int nPoints, int *head, int *next,
+                           int *changed, const int *changedPrev);

@@ -43,6 +43,15 @@ __device__ __forceinline__ bool is_locked(const FtDevFrame &F, const FtClaims &C
     return best >= 0 ? C.obs[best] > 0 : F.holderObs[kp] > 0;
 }
 
+// start of a claim-iteration pass (see FtClaims): false = the iteration has converged, nothing to do
+__device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) {
+    if (C.changedPrev && *C.changedPrev == 0) return false;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+    for (int k = t; k < C.nKp; k += T) C.headNext[k] = -1;
+    if (t == 0) *C.changedCur = 0;
+    return true;
+}
+
 struct Window {
     int minCX, maxCX, minCY, maxCY;
     bool empty;
@@ -125,6 +134,7 @@ __device__ __forceinline__ void wave_two_min(unsigned long long &k0, unsigned lo
 
 __global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPoints P, FtClaims C, float th,
                                                       float nnRatio, int *res, FtLocalRaw raw) {
+    if (!claims_begin_pass(C)) return;
     const int lane = threadIdx.x & 63, wave = wave_index();
     const int i = blockIdx.x * 4 + wave;
     if (i >= P.M) return;
@@ -267,6 +277,7 @@ __device__ __forceinline__ void transform34(const float *T, const float x[3], fl
 
 __global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoints Lp, FtClaims C, FtPose Tcw, float th,
                                                      int bForward, int bBackward, int *res, FtLastRaw raw) {
+    if (!claims_begin_pass(C)) return;
     const int lane = threadIdx.x & 63, wave = wave_index();
     const int i = blockIdx.x * 4 + wave;
     if (i >= Lp.N) return;
@@ -457,8 +468,12 @@ __global__ __launch_bounds__(256) void k_frustum(FtDevFrame F, FtFrustumPose T, 
 // rebuild the per-keypoint writer lists from this pass's results and flag any change against the
 // previous pass
 __global__ __launch_bounds__(256) void k_build_claims(const int *res, const int *prevRes, int n4, int *head, int *next,
-                                                      int *changed) {
+                                                      int *changed, const int *changedPrev) {
     const int s = blockIdx.x * 256 + threadIdx.x;
+    if (changedPrev && *changedPrev == 0) {  // converged before this pass (its search kernel did not run either)
+        if (s == 0) *changed = 0;
+        return;
+    }
     if (s >= n4) return;
     const int kp = res[s];
     if (kp != prevRes[s]) atomicOr(changed, 1);
@@ -516,14 +531,13 @@ int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPo
     return FT_OK;
 }
 
-int ft_launch_build_claims(hipStream_t st, const int *res, const int *prevRes, int nPoints, int nKp, int *head,
-                           int *next, int *changed) {
-    int rc = ft_launch_fill_i32(st, head, nKp, -1);
-    if (rc != FT_OK) return rc;
-    rc = ft_launch_fill_i32(st, changed, 1, 0);
-    if (rc != FT_OK) return rc;
+// head / changed have been reset by the search kernel of this pass (claims_begin_pass)
+int ft_launch_build_claims(hipStream_t st, const int *res, const int *prevRes, int nPoints, int *head, int *next,
+                           int *changed, const int *changedPrev) {
     const int n4 = 4 * nPoints;
-    if (n4 > 0) hipLaunchKernelGGL(k_build_claims, dim3((n4 + 255) / 256), dim3(256), 0, st, res, prevRes, n4, head, next, changed);
+    if (n4 > 0)
+        hipLaunchKernelGGL(k_build_claims, dim3((n4 + 255) / 256), dim3(256), 0, st, res, prevRes, n4, head, next, changed,
+                           changedPrev);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

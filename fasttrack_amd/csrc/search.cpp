@@ -95,27 +95,41 @@ FtDevFrame devFrame(const ft_frame_view *F, const FrameLayout &L, uint8_t *dev) 
 }
 
 // runs `search` passes until a pass changes nothing; leaves the final results in resFinal (device).
-// Passes are enqueued in bursts of FT_PASS_BURST without waiting in between: a pass after the fixed point
-// reproduces its input, so running a few too many costs microseconds of GPU time while every avoided
-// round trip (4-byte D2H + stream sync) costs tens.  `changed` holds one flag per pass of a burst.
-#define FT_PASS_BURST 3
+// A pass is two launches: the search kernel - which also resets the list heads and the flag its k_build_claims will
+// write (claims_begin_pass) - and k_build_claims.  Passes are enqueued in bursts of FT_PASS_BURST without waiting in
+// between; every kernel of a pass first looks at the previous pass's `changed` flag and returns at once when the
+// fixed point has been reached (such a pass would reproduce its input), so the surplus passes of a burst cost two
+// empty launches each while every avoided round trip (D2H of the flags + stream sync) costs ~100 us.
+// `changed` holds one flag per pass of a burst; the caller's claims struct C is set up per pass (search reads it).
+#define FT_PASS_BURST 6
 template <typename SearchFn>
-int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, int *resA, int *resB, int *head, int *next,
-               int *changed, SearchFn search, int **resFinal, int *passes) {
-    int rc = ft_launch_fill_i32(st, head, nKp, -1);
+int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, int *resA, int *resB, int *headA, int *headB,
+               int *next, int *changed, FtClaims &C, SearchFn search, int **resFinal, int *passes) {
+    *resFinal = resA;
+    *passes = 0;
+    if (nPoints <= 0) return FT_OK;
+    int rc = ft_launch_fill_i32(st, headA, nKp, -1);  // no claims before the first pass
     if (rc != FT_OK) return rc;
     rc = ft_launch_fill_i32(st, resB, 4 * nPoints, -2);
     if (rc != FT_OK) return rc;
     int *cur = resA, *prev = resB;
+    int *headRead = headA, *headWrite = headB;
     int pass = 0;
     const int maxPasses = 2 * nPoints + 4 + FT_PASS_BURST;
+    C.next = next;
+    C.nKp = nKp;
     for (;;) {
         for (int b = 0; b < FT_PASS_BURST; b++) {
+            C.head = headRead;
+            C.headNext = headWrite;
+            C.changedCur = changed + b;
+            C.changedPrev = b > 0 ? changed + b - 1 : nullptr;
             rc = search(cur);
             if (rc != FT_OK) return rc;
-            rc = ft_launch_build_claims(st, cur, prev, nPoints, nKp, head, next, changed + b);
+            rc = ft_launch_build_claims(st, cur, prev, nPoints, headWrite, next, changed + b, C.changedPrev);
             if (rc != FT_OK) return rc;
             std::swap(cur, prev);
+            std::swap(headRead, headWrite);
             pass++;
         }
         int h[FT_PASS_BURST];
@@ -392,7 +406,7 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
                  oPyr = a.take(4 * (size_t)M);
     const size_t oDesc = a.take(32 * (size_t)M), oObs = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(4 * (size_t)N),
+    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(8 * (size_t)std::max(N, 1)),
                  oNext = a.take(16 * (size_t)M), oChanged = a.take(64);
     const size_t oRaw = a.take(40 * (size_t)M);
     const size_t total = a.off;
@@ -435,8 +449,8 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     raw.bestIdx = rawBase + 4 * M; raw.bestDistR = rawBase + 5 * M; raw.bestDist2R = rawBase + 6 * M;
     raw.bestLevelR = rawBase + 7 * M; raw.bestLevel2R = rawBase + 8 * M; raw.bestIdxR = rawBase + 9 * M;
     int *resFinal = nullptr, passes = 0;
-    rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oNext),
-                    (int *)(dev + oChanged),
+    rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
+                    (int *)(dev + oNext), (int *)(dev + oChanged), C,
                     [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); }, &resFinal,
                     &passes);
     if (rc != FT_OK) return rc;
@@ -484,7 +498,7 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     const size_t oValid = a.take(M), oPos = a.take(12 * (size_t)M), oDesc = a.take(32 * (size_t)M),
                  oObs = a.take(4 * (size_t)M), oOct = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(4 * (size_t)N),
+    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(8 * (size_t)std::max(N, 1)),
                  oNext = a.take(16 * (size_t)M), oChanged = a.take(64);
     const size_t oRaw = a.take(16 * (size_t)M);
     const size_t total = a.off;
@@ -517,8 +531,8 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     FtLastRaw raw;
     raw.bestDist = rawBase; raw.bestIdx = rawBase + M; raw.bestDistR = rawBase + 2 * M; raw.bestIdxR = rawBase + 3 * M;
     int *resFinal = nullptr, passes = 0;
-    rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oNext),
-                    (int *)(dev + oChanged),
+    rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
+                    (int *)(dev + oNext), (int *)(dev + oChanged), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
                     &resFinal, &passes);
     if (rc != FT_OK) return rc;
@@ -797,7 +811,7 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     const size_t oValid = a.take(M), oPos = a.take(12 * (size_t)M), oDesc = a.take(32 * (size_t)M),
                  oObs = a.take(4 * (size_t)M), oOct = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(4 * (size_t)N),
+    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(8 * (size_t)std::max(N, 1)),
                  oNext = a.take(16 * (size_t)M), oChanged = a.take(64);
     FT_REQUIRE(a.off <= tf->workBytes, "tracked frame work arena too small");
     uint8_t *pin = tf->h_work, *dev = tf->d_work;
@@ -823,8 +837,8 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     FtLastRaw raw = {nullptr, nullptr, nullptr, nullptr};
     int *resFinal = nullptr, passes = 0;
     const FtDevFrame DF = tf->DF;
-    rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oNext),
-                    (int *)(dev + oChanged),
+    rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
+                    (int *)(dev + oNext), (int *)(dev + oChanged), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
                     &resFinal, &passes);
     if (rc != FT_OK) return rc;
@@ -867,7 +881,7 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
     layoutFrustum(M, P->skip != nullptr, a, FL, &fInputEnd);
     const size_t fOutEnd = a.off;
     const size_t oDesc = a.take(32 * (size_t)M), oObs = a.take(4 * (size_t)M);
-    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(4 * (size_t)std::max(N, 1)),
+    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(8 * (size_t)std::max(N, 1)),
                  oNext = a.take(16 * (size_t)M), oChanged = a.take(64);
     FT_REQUIRE(a.off <= tf->workBytes, "tracked frame work arena too small");
     uint8_t *pin = tf->h_work, *dev = tf->d_work;
@@ -899,8 +913,8 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
         FtLocalRaw raw;
         memset(&raw, 0, sizeof raw);
         int *resFinal = nullptr;
-        rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oNext),
-                        (int *)(dev + oChanged),
+        rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
+                        (int *)(dev + oNext), (int *)(dev + oChanged), C,
                         [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); }, &resFinal,
                         &passes);
         if (rc != FT_OK) return rc;
