@@ -102,12 +102,20 @@ FtDevFrame devFrame(const ft_frame_view *F, const FrameLayout &L, uint8_t *dev) 
 // empty launches each while every avoided round trip (D2H of the flags + stream sync) costs ~100 us.
 // `changed` holds one flag per pass of a burst; the caller's claims struct C is set up per pass (search reads it).
 #define FT_PASS_BURST 6
-template <typename SearchFn>
+// `download(res)` enqueues the device-to-host copies of whatever the caller needs from the pass results `res`; it runs
+// behind every burst, in front of the one stream synchronisation that also brings the flags - the results are on the
+// host when fixedPoint returns.
+template <typename SearchFn, typename DownloadFn>
 int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, int *resA, int *resB, int *headA, int *headB,
-               int *next, int *changed, FtClaims &C, SearchFn search, int **resFinal, int *passes) {
+               int *next, int *changed, FtClaims &C, SearchFn search, DownloadFn download, int **resFinal, int *passes) {
     *resFinal = resA;
     *passes = 0;
-    if (nPoints <= 0) return FT_OK;
+    if (nPoints <= 0) {
+        int rc0 = download(resA);
+        if (rc0 != FT_OK) return rc0;
+        FT_HIP(hipStreamSynchronize(st));
+        return FT_OK;
+    }
     int rc = ft_launch_fill_i32(st, headA, nKp, -1);  // no claims before the first pass
     if (rc != FT_OK) return rc;
     rc = ft_launch_fill_i32(st, resB, 4 * nPoints, -2);
@@ -132,6 +140,8 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, int *resA,
             std::swap(headRead, headWrite);
             pass++;
         }
+        rc = download(prev);  // `prev` holds the results of the last pass
+        if (rc != FT_OK) return rc;
         int h[FT_PASS_BURST];
         FT_HIP(hipMemcpyAsync(h, changed, sizeof h, hipMemcpyDeviceToHost, st));
         FT_HIP(hipStreamSynchronize(st));
@@ -321,13 +331,19 @@ FtFrustumOut devFrustumOut(const FrustumLayout &L, uint8_t *dev) {
 }
 
 // D2H of the frustum fields the caller asked for (one contiguous copy of the output block, then scatter)
+void unpackFrustum(int M, const FrustumLayout &L, size_t outBegin, uint8_t *pin, const ft_frustum_result *R, int *n_to_match);
 int downloadFrustum(hipStream_t st, int M, const FrustumLayout &L, size_t outBegin, size_t outEnd, uint8_t *dev, uint8_t *pin,
                     const ft_frustum_result *R, int *n_to_match) {
     FT_HIP(hipMemcpyAsync(pin, dev + outBegin, outEnd - outBegin, hipMemcpyDeviceToHost, st));
     FT_HIP(hipStreamSynchronize(st));
+    unpackFrustum(M, L, outBegin, pin, R, n_to_match);
+    return FT_OK;
+}
+// the frustum fields of the output block [outBegin, ...) that sits at the start of `pin`
+void unpackFrustum(int M, const FrustumLayout &L, size_t outBegin, uint8_t *pin, const ft_frustum_result *R, int *n_to_match) {
     auto at = [&](size_t off) { return pin + (off - outBegin); };
     if (n_to_match) *n_to_match = *(const int *)at(L.count);
-    if (!R || !M) return FT_OK;
+    if (!R || !M) return;
     const size_t m = (size_t)M;
     if (R->in_view) memcpy(R->in_view, at(L.inV), m);
     if (R->in_view_r) memcpy(R->in_view_r, at(L.inVR), m);
@@ -341,7 +357,6 @@ int downloadFrustum(hipStream_t st, int M, const FrustumLayout &L, size_t outBeg
     if (R->proj_yr) memcpy(R->proj_yr, at(L.pyr), 4 * m);
     if (R->depth) memcpy(R->depth, at(L.dep), 4 * m);
     if (R->depth_r) memcpy(R->depth_r, at(L.depR), 4 * m);
-    return FT_OK;
 }
 
 }  // namespace
@@ -358,6 +373,7 @@ struct ft_tracked_frame {
     float *d_uright = nullptr;
     int *d_holder = nullptr, *d_l2r = nullptr, *d_r2l = nullptr;
     uint8_t *d_work = nullptr, *h_work = nullptr;  // per-call arena (points, passes, outputs) and its pinned mirror
+    int *h_holderUp = nullptr;                       // pinned source of the holder_obs uploads (see uploadHolder)
     size_t workBytes = 0;
     // current frame
     bool loaded = false;
@@ -365,6 +381,18 @@ struct ft_tracked_frame {
     std::vector<float> angles;  // angle of keypoint i (left then right)
     std::vector<int> holder;
 };
+
+// holder_obs of the resident frame to the device, without a synchronisation: the pinned source belongs to the frame and is
+// rewritten only by the next search on it, which is ordered behind this copy on the stream and synchronises the stream
+// (fixedPoint) before the host gets here again
+static int uploadHolder(ft_tracked_frame *tf, hipStream_t st) {
+    const size_t bytes = sizeof(int) * tf->holder.size();
+    if (!bytes) return FT_OK;
+    memcpy(tf->h_holderUp, tf->holder.data(), bytes);
+    FT_HIP(hipMemcpyAsync(tf->d_holder, tf->h_holderUp, bytes, hipMemcpyHostToDevice, st));
+    return FT_OK;
+}
+
 
 extern "C" {
 
@@ -451,13 +479,15 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     int *resFinal = nullptr, passes = 0;
     rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
                     (int *)(dev + oNext), (int *)(dev + oChanged), C,
-                    [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); }, &resFinal,
-                    &passes);
+                    [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); },
+                    [&](int *res) -> int {
+                        FT_HIP(hipMemcpyAsync(pin, res, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
+                        FT_HIP(hipMemcpyAsync(pin + 16 * (size_t)M + 64, rawBase, 40 * (size_t)M, hipMemcpyDeviceToHost, st));
+                        return FT_OK;
+                    },
+                    &resFinal, &passes);
     if (rc != FT_OK) return rc;
     int *hRes = (int *)pin, *hRaw = (int *)(pin + 16 * (size_t)M + 64);
-    FT_HIP(hipMemcpyAsync(hRes, resFinal, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
-    FT_HIP(hipMemcpyAsync(hRaw, rawBase, 40 * (size_t)M, hipMemcpyDeviceToHost, st));
-    FT_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < 10; k++)
         if (outs[k]) memcpy(outs[k], hRaw + (size_t)k * M, 4 * (size_t)M);
     const int nm = replayLocalWrites(hRes, M, P->observations, F->holder_obs, assign);
@@ -534,12 +564,14 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
                     (int *)(dev + oNext), (int *)(dev + oChanged), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
+                    [&](int *res) -> int {
+                        FT_HIP(hipMemcpyAsync(pin, res, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
+                        FT_HIP(hipMemcpyAsync(pin + 16 * (size_t)M + 64, rawBase, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
+                        return FT_OK;
+                    },
                     &resFinal, &passes);
     if (rc != FT_OK) return rc;
     int *hRes = (int *)pin, *hRaw = (int *)(pin + 16 * (size_t)M + 64);
-    FT_HIP(hipMemcpyAsync(hRes, resFinal, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
-    FT_HIP(hipMemcpyAsync(hRaw, rawBase, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
-    FT_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < 4; k++)
         if (outs[k]) memcpy(outs[k], hRaw + (size_t)k * M, 4 * (size_t)M);
     auto curAngle = [&](int idx) -> float {
@@ -696,6 +728,7 @@ int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, 
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_r2l, sizeof(int) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_work, tf->workBytes);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_work, tf->workBytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_holderUp, sizeof(int) * K, hipHostMallocDefault);
     if (e != hipSuccess) {
         ft_tracked_frame_destroy(tf);
         return ft_hip_fail(e, "ft_tracked_frame_create", __FILE__, __LINE__);
@@ -711,6 +744,7 @@ int ft_tracked_frame_destroy(ft_tracked_frame *tf) {
     hipFree(tf->d_keys); hipFree(tf->d_keysR); hipFree(tf->d_desc); hipFree(tf->d_uright);
     hipFree(tf->d_holder); hipFree(tf->d_l2r); hipFree(tf->d_r2l); hipFree(tf->d_work);
     if (tf->h_work) hipHostFree(tf->h_work);
+    if (tf->h_holderUp) hipHostFree(tf->h_holderUp);
     delete tf;
     return FT_OK;
 }
@@ -840,17 +874,19 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
                     (int *)(dev + oNext), (int *)(dev + oChanged), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
+                    [&](int *res) -> int {
+                        FT_HIP(hipMemcpyAsync(pin, res, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
+                        return FT_OK;
+                    },
                     &resFinal, &passes);
     if (rc != FT_OK) return rc;
     int *hRes = (int *)pin;
-    FT_HIP(hipMemcpyAsync(hRes, resFinal, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
-    FT_HIP(hipStreamSynchronize(st));
     const int nm = replayLastFrameWrites(hRes, M, L, [&](int idx) { return tf->angles[idx]; }, check_orientation != 0,
                                          tf->holder.data(), assign);
-    // the occupancy the next search sees
-    memcpy(pin, tf->holder.data(), sizeof(int) * N);
-    FT_HIP(hipMemcpyAsync(tf->d_holder, pin, sizeof(int) * N, hipMemcpyHostToDevice, st));
-    FT_HIP(hipStreamSynchronize(st));
+    // the occupancy the next search sees: uploaded from a pinned buffer of the frame's own, so that nothing has to wait
+    // for the copy (the next call on this frame is ordered behind it on the stream and synchronises before it returns)
+    rc = uploadHolder(tf, st);
+    if (rc != FT_OK) return rc;
     if (n_matches) *n_matches = nm;
     ctx->addStat("tracked.search_last_frame.total", tAll.ms());
     ctx->addStat("tracked.search_last_frame.passes", passes);
@@ -915,17 +951,19 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
         int *resFinal = nullptr;
         rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
                         (int *)(dev + oNext), (int *)(dev + oChanged), C,
-                        [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); }, &resFinal,
-                        &passes);
+                        [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); },
+                        [&](int *res) -> int {  // pass results and the frustum fields travel behind the same burst
+                            FT_HIP(hipMemcpyAsync(pin + fOutEnd, res, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
+                            FT_HIP(hipMemcpyAsync(pin, dev + fInputEnd, fOutEnd - fInputEnd, hipMemcpyDeviceToHost, st));
+                            return FT_OK;
+                        },
+                        &resFinal, &passes);
         if (rc != FT_OK) return rc;
         int *hRes = (int *)(pin + fOutEnd);
-        FT_HIP(hipMemcpyAsync(hRes, resFinal, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
-        rc = downloadFrustum(st, M, FL, fInputEnd, fOutEnd, dev, pin, frustum, n_to_match);
-        if (rc != FT_OK) return rc;
+        unpackFrustum(M, FL, fInputEnd, pin, frustum, n_to_match);
         nm = replayLocalWrites(hRes, M, P->observations, tf->holder.data(), assign);
-        memcpy(pin, tf->holder.data(), sizeof(int) * N);
-        FT_HIP(hipMemcpyAsync(tf->d_holder, pin, sizeof(int) * N, hipMemcpyHostToDevice, st));
-        FT_HIP(hipStreamSynchronize(st));
+        rc = uploadHolder(tf, st);
+        if (rc != FT_OK) return rc;
     } else {
         rc = downloadFrustum(st, M, FL, fInputEnd, fOutEnd, dev, pin, frustum, n_to_match);
         if (rc != FT_OK) return rc;
