@@ -2,8 +2,8 @@
 search over the last frame's points followed by the local-map step (isInFrustum + SearchByProjection).
   separate : ft_search_last_frame, ft_is_in_frustum, ft_search_local_points - every call marshals its arrays
              (what the reference does per kernel, CudaFrame::setMemory)
-  resident : ft_tracked_frame_* - frame uploaded once (or bound to the stereo front end's buffers), frustum fields
-             stay on the device
+  resident : ft_tracked_frame_* - frame uploaded once, frustum fields stay on the device
+  bound    : the same with the frame bound to the buffers the stereo front end left in HBM (no upload at all)
   oracle   : the CPU restatement on one host core
 usage: python tools/bench_tracking.py [reps]"""
 import json
@@ -59,6 +59,19 @@ def resident():
     return tf.track_local_map(pose, pts, 0.5, LOG_SF, 3.0)["n"]
 
 
+# the frame as the stereo front end leaves it in HBM: bound, not uploaded (the flow of a SLAM front end)
+fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, 1, fr["intr"]["mbf"], fr["intr"]["mb"])
+fe.process([fr["L"]], [fr["R"]])  # the same pair the oracle frame was extracted from: identical keypoints in HBM
+tfb = orb.TrackedFrame(ctx, max_keypoints=fe.capacity, max_points=4096)
+
+
+def bound():
+    F = orb.FrameView(scale_factors=sf, **kw)
+    tfb.bind_stereo(fe, 0, F)
+    tfb.search_last_frame(last, Tcw_last, 15.0)
+    return tfb.track_local_map(pose, pts, 0.5, LOG_SF, 3.0)["n"]
+
+
 def oracle():
     F = ob.FrameView(scale_factors_=sf, **kw)
     ob.search_last_frame(F, last, Tcw_last, 15.0, False, False, True)
@@ -66,10 +79,10 @@ def oracle():
     return ob.search_local_points(F, sc.local_points_from_frustum(f, pts), 3.0)["n"]
 
 
-assert separate() == resident() == oracle()
+assert separate() == resident() == bound() == oracle()
 out = {"frame": [w, h], "keypoints": int(len(fr["kL"])), "last_frame_points": int(len(last["valid"])),
        "local_map_points": int(len(pts["world_pos"])),
-       "ms_per_frame": {"separate_calls": timeit(separate, reps), "resident_frame": timeit(resident, reps),
+       "ms_per_frame": {"separate_calls": timeit(separate, reps), "resident_frame": timeit(resident, reps), "bound_to_front_end": timeit(bound, reps),
                         "oracle_1_core": timeit(oracle, max(3, reps // 5))},
        "frustum_only_ms": timeit(lambda: orb.is_in_frustum(ctx, orb.FrameView(scale_factors=sf, **kw), pose, pts, 0.5, LOG_SF), reps),
        "frustum_only_oracle_ms": timeit(lambda: ob.is_in_frustum(ob.FrameView(scale_factors_=sf, **kw), ob.make_pose(Rcw, tcw), pts, 0.5, LOG_SF), reps),
