@@ -298,7 +298,8 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
 // graph path with host frames: pinned staging for up to 8 slots (allocated once)
 int ft_extract_ensure_stage(ft_extractor *ex) {
     if (ex->h_stage) return FT_OK;
-    FT_HIP(hipHostMalloc((void **)&ex->h_stage, (size_t)8 * ex->width * ex->height, hipHostMallocDefault));
+    // (up to 8 frames per camera; a paired stereo batch brings both cameras through one extractor)
+    FT_HIP(hipHostMalloc((void **)&ex->h_stage, (size_t)std::min(ex->maxBatch, 16) * ex->width * ex->height, hipHostMallocDefault));
     return FT_OK;
 }
 // replay of a captured batch with host frames: refresh the staging copies the captured uploads read

@@ -166,6 +166,12 @@ struct ft_stereo_frontend {
     int capacity = 0;
     float *d_uright = nullptr, *d_depth = nullptr, *h_uright = nullptr, *h_depth = nullptr;
     int *d_sad = nullptr, *d_nMatches = nullptr, *h_nMatches = nullptr;
+    // Latency front ends (max_batch <= 8): the left extractor is created with room for 2 x max_batch images and a small
+    // batch runs PAIRED - left frames in its slots [0, B), right frames in [B, 2B) - so that every kernel of the
+    // extraction is launched once for both cameras (half the launches; the two cameras no longer queue behind each other
+    // in the graph's launch order).  The right extractor then only lends its pinned host buffers to the results.
+    int maxBatch = 0;
+    bool pairedCapable = false, lastPaired = false;
     FtSortedR *d_sorted = nullptr;  // right keypoints bucketed by row (k_stereo_rowsort)
     int *d_rowStart = nullptr;
     hipEvent_t evR = nullptr;
@@ -173,11 +179,11 @@ struct ft_stereo_frontend {
     // captured once as a HIP graph - ~45 enqueue calls on seven streams become one launch.  graphKey holds everything
     // that is baked into the captured nodes.
     struct GraphKey {
-        int batch = 0, onDevice = 0, width = 0, height = 0, stride = 0, capacity = 0, alignedL = 0, alignedR = 0;
+        int batch = 0, onDevice = 0, width = 0, height = 0, stride = 0, capacity = 0, alignedL = 0, alignedR = 0, paired = 0;
         const void *out[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         bool operator==(const GraphKey &o) const {
             if (batch != o.batch || onDevice != o.onDevice || width != o.width || height != o.height || stride != o.stride ||
-                capacity != o.capacity || alignedL != o.alignedL || alignedR != o.alignedR)
+                capacity != o.capacity || alignedL != o.alignedL || alignedR != o.alignedR || paired != o.paired)
                 return false;
             for (int i = 0; i < 6; i++)
                 if (out[i] != o.out[i]) return false;

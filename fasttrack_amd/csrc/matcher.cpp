@@ -6,6 +6,8 @@
 
 #include "ft_host.h"
 
+#define FT_GRAPH_MAX_BATCH 8  // latency mode: batches up to this size are captured as graphs / run paired
+
 #define FT_REQUIRE(cond, msg)               \
     do {                                    \
         if (!(cond)) {                      \
@@ -119,8 +121,11 @@ int ft_stereo_frontend_create(ft_context *ctx, int nfeatures, float scale_factor
     fe->ctx = ctx;
     fe->mbf = mbf;
     fe->mb = mb;
+    fe->maxBatch = max_batch;
+    static const bool pairedOn = !(getenv("FT_PAIRED") && atoi(getenv("FT_PAIRED")) == 0);
+    fe->pairedCapable = pairedOn && max_batch >= 1 && max_batch <= FT_GRAPH_MAX_BATCH;
     int rc = ft_extractor_create(ctx, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, image_width,
-                                 image_height, max_batch, &fe->exL);
+                                 image_height, fe->pairedCapable ? 2 * max_batch : max_batch, &fe->exL);
     if (rc == FT_OK)
         rc = ft_extractor_create(ctx, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, image_width,
                                  image_height, max_batch, &fe->exR);
@@ -186,17 +191,92 @@ static bool isPinnedHost(const void *p) {
     return at.type == hipMemoryTypeHost;
 }
 
-#define FT_GRAPH_MAX_BATCH 8
 
 // enqueues one batch on the front end's streams.  capture != 0: L->stream is being captured into a graph - the other
 // streams are forked from it first and joined back at the end, and nothing here may synchronise.
 static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL, const uint8_t *const *imagesR, int batch,
                            int on_device, int width, int height, int stride, ft_keypoint *keysL, uint8_t *descL, int *nL,
                            ft_keypoint *keysR, uint8_t *descR, int *nR, int capacity, float *uright, float *depth,
-                           int *n_matches, bool direct, int capture) {
+                           int *n_matches, bool direct, int capture, bool paired) {
     ft_extractor *L = fe->exL, *R = fe->exR;
     const FtGeom &g = L->geom;
     FtTimer tAll;
+    fe->lastPaired = paired;
+    if (paired) {
+        // both cameras through the left extractor: slots [0, B) left, [B, 2B) right; one launch per kernel
+        const int B = batch;
+        std::vector<const uint8_t *> imgs(imagesL, imagesL + B);
+        imgs.insert(imgs.end(), imagesR, imagesR + B);
+        int rc = ft_extract_prepare(L, imgs.data(), 2 * B, on_device, width, height, stride);
+        if (rc != FT_OK) return rc;
+        fe->ctx->addStat("stereo.device_octree_batches", 0);
+        rc = ft_extract_launch_a(L, 0, 2 * B, nullptr);
+        if (rc == FT_OK) rc = ft_extract_launch_octree(L, 0, 0, 2 * B, L->evA[0]);
+        if (rc != FT_OK) return rc;
+        hipStream_t st = L->streamB;
+        FT_HIP(hipStreamWaitEvent(st, L->evA[0], 0));
+        rc = ft_extract_launch_b(L, 0, 2 * B, st);
+        if (rc != FT_OK) return rc;
+        const size_t oR = (size_t)B * g.maxKp;  // the right camera's half of the left extractor's arrays
+        FtStereoArgs a;
+        a.keysL = L->d_keys;
+        a.keysR = L->d_keys + oR;
+        a.descL = L->d_desc;
+        a.descR = L->d_desc + oR * 32;
+        a.nL = L->d_nSel;
+        a.nR = L->d_nSel + B;
+        a.capacity = g.maxKp;
+        a.mbf = fe->mbf;
+        a.mb = fe->mb;
+        a.uright = fe->d_uright;
+        a.depth = fe->d_depth;
+        a.sad = fe->d_sad;
+        a.hamIdx = nullptr;
+        a.nMatches = fe->d_nMatches;
+        a.applyMedianCut = 1;
+        a.rowStride = L->height + 2;
+        a.rowStart = fe->d_rowStart;
+        a.sorted = fe->d_sorted;
+        rc = ft_launch_stereo_rowsort(st, g, B, a);
+        if (rc == FT_OK)
+            rc = ft_launch_stereo_match(st, g, B, L->d_l0, L->d_l0 + B, L->l0pitch, L->l0pitch, L->d_pyr,
+                                        L->d_pyr + (size_t)B * g.pyrPerSlot, a);
+        if (rc == FT_OK) rc = ft_launch_stereo_median(st, B, a);
+        if (rc != FT_OK) return rc;
+        FtDeliverArgs d;
+        d.keysL = a.keysL;
+        d.keysR = a.keysR;
+        d.descL = a.descL;
+        d.descR = a.descR;
+        d.uright = fe->d_uright;
+        d.depth = fe->d_depth;
+        d.nL = a.nL;
+        d.nR = a.nR;
+        d.nMatches = fe->d_nMatches;
+        d.overflowL = d.overflowR = L->d_overflow;
+        d.oKeysL = direct ? keysL : L->h_keys;
+        d.oKeysR = direct ? keysR : R->h_keys;  // the right extractor lends its pinned staging and counters
+        d.oDescL = direct ? descL : L->h_desc;
+        d.oDescR = direct ? descR : R->h_desc;
+        d.oUright = direct ? uright : fe->h_uright;
+        d.oDepth = direct ? depth : fe->h_depth;
+        d.oNL = L->h_nSel;
+        d.oNR = R->h_nSel;
+        d.oNMatches = fe->h_nMatches;
+        d.oOverflowL = L->h_overflow;
+        d.oOverflowR = R->h_overflow;
+        d.srcStride = g.maxKp;
+        d.dstStride = direct ? capacity : g.maxKp;
+        rc = ft_launch_deliver(st, B, d);
+        if (rc != FT_OK) return rc;
+        R->lastBatch = B;
+        if (capture) {
+            FT_HIP(hipEventRecord(fe->evJoin, st));
+            FT_HIP(hipStreamWaitEvent(L->stream, fe->evJoin, 0));
+        }
+        fe->ctx->addStat("stereo.submit.total", tAll.ms());
+        return FT_OK;
+    }
     if (capture) {  // fork: everything the right camera enqueues hangs off the captured stream
         FT_HIP(hipEventRecord(fe->evFork, L->stream));
         FT_HIP(hipStreamWaitEvent(R->stream, fe->evFork, 0));
@@ -385,13 +465,15 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     const FtGeom &g = L->geom;
     int rc = ft_set_device(fe->ctx);
     if (rc != FT_OK) return rc;
+    FT_REQUIRE(batch >= 1 && batch <= fe->maxBatch, "stereo front end: batch outside [1, max_batch]");
     const bool dev = L->deviceOctree && R->deviceOctree;
+    const bool paired = fe->pairedCapable && dev && batch <= FT_GRAPH_MAX_BATCH && 2 * batch <= L->maxBatch;
     const bool direct = isPinnedHost(keysL) && isPinnedHost(descL) && isPinnedHost(keysR) && isPinnedHost(descR) &&
                         isPinnedHost(uright) && isPinnedHost(depth) && (!dev || capacity >= g.maxKp);
     // ---- latency mode: small batches with a fixed call shape run as one captured graph ----
     static const bool graphsOn = !(getenv("FT_GRAPH") && getenv("FT_GRAPH")[0] == '0');
     bool useGraph = graphsOn && !fe->graphDisabled && dev && direct && !fe->ctx->kernelTiming && batch >= 1 &&
-                    batch <= FT_GRAPH_MAX_BATCH && batch <= L->maxBatch && width == L->width && height == L->height &&
+                    batch <= FT_GRAPH_MAX_BATCH && batch <= fe->maxBatch && width == L->width && height == L->height &&
                     stride >= width;
     bool launched = false;
     if (useGraph) {
@@ -402,6 +484,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
         ft_stereo_frontend::GraphKey key;
         key.batch = batch; key.onDevice = on_device; key.width = width; key.height = height; key.stride = stride;
         key.capacity = capacity;
+        key.paired = paired ? 1 : 0;
         key.alignedL = key.alignedR = 1;
         if (on_device) {
             if (stride & 3) key.alignedL = key.alignedR = 0;
@@ -409,6 +492,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
                 if ((uintptr_t)imagesL[b] & 3) key.alignedL = 0;
                 if ((uintptr_t)imagesR[b] & 3) key.alignedR = 0;
             }
+            if (paired) key.alignedL = key.alignedR = key.alignedL & key.alignedR;  // one launch reads both cameras
         } else if (ft_extract_ensure_stage(L) != FT_OK || ft_extract_ensure_stage(R) != FT_OK) {
             (void)hipGetLastError();
             useGraph = false;
@@ -419,16 +503,29 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
         } else if (fe->graphExec && key == fe->graphKey) {
             // replay: device frames change through the level-0 pointer tables, host frames through the pinned staging
             // the captured uploads read
-            if (on_device) {
-                for (int b = 0; b < batch; b++) {
-                    L->h_l0[b] = imagesL[b];
-                    R->h_l0[b] = imagesR[b];
-                }
+            if (paired) {
+                std::vector<const uint8_t *> imgs(imagesL, imagesL + batch);
+                imgs.insert(imgs.end(), imagesR, imagesR + batch);
+                if (on_device)
+                    for (int b = 0; b < 2 * batch; b++) L->h_l0[b] = imgs[b];
+                else
+                    ft_extract_restage(L, imgs.data(), 2 * batch, width, height, stride);
+                L->lastBatch = 2 * batch;
+                R->lastBatch = batch;
+                fe->lastPaired = true;
             } else {
-                ft_extract_restage(L, imagesL, batch, width, height, stride);
-                ft_extract_restage(R, imagesR, batch, width, height, stride);
+                if (on_device) {
+                    for (int b = 0; b < batch; b++) {
+                        L->h_l0[b] = imagesL[b];
+                        R->h_l0[b] = imagesR[b];
+                    }
+                } else {
+                    ft_extract_restage(L, imagesL, batch, width, height, stride);
+                    ft_extract_restage(R, imagesR, batch, width, height, stride);
+                }
+                L->lastBatch = R->lastBatch = batch;
+                fe->lastPaired = false;
             }
-            L->lastBatch = R->lastBatch = batch;
             fe->ctx->addStat("stereo.device_octree_batches", 0);
             FtTimer tG;
             FT_HIP(hipGraphLaunch(fe->graphExec, L->stream));
@@ -444,7 +541,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
             hipError_t ce = hipStreamBeginCapture(L->stream, hipStreamCaptureModeThreadLocal);
             if (ce == hipSuccess) {
                 rc = frontendEnqueue(fe, imagesL, imagesR, batch, on_device, width, height, stride, keysL, descL, nL, keysR,
-                                     descR, nR, capacity, uright, depth, n_matches, direct, 1);
+                                     descR, nR, capacity, uright, depth, n_matches, direct, 1, paired);
                 ce = hipStreamEndCapture(L->stream, &graph);
                 if (rc == FT_OK && ce == hipSuccess && graph) ce = hipGraphInstantiate(&fe->graphExec, graph, nullptr, nullptr, 0);
                 if (graph) hipGraphDestroy(graph);
@@ -466,7 +563,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     }
     if (!launched) {
         rc = frontendEnqueue(fe, imagesL, imagesR, batch, on_device, width, height, stride, keysL, descL, nL, keysR, descR,
-                             nR, capacity, uright, depth, n_matches, direct, 0);
+                             nR, capacity, uright, depth, n_matches, direct, 0, paired);
         if (rc != FT_OK) return rc;
     }
     // everything is enqueued; ft_stereo_frontend_wait drains the streams and finishes the outputs
@@ -647,8 +744,10 @@ int ft_fisheye_stereo(ft_context *ctx, const ft_fisheye_rig *rig, const uint8_t 
 int ft_stereo_frontend_device_descriptors(ft_stereo_frontend *fe, int slot, int right, const uint8_t **dptr, int *n) {
     FT_REQUIRE(fe && dptr && n, "ft_stereo_frontend_device_descriptors: null argument");
     ft_extractor *ex = right ? fe->exR : fe->exL;
-    FT_REQUIRE(slot >= 0 && slot < ex->lastBatch, "ft_stereo_frontend_device_descriptors: slot holds no result");
-    *dptr = ex->d_desc + (size_t)slot * ex->geom.maxKp * 32;
+    FT_REQUIRE(slot >= 0 && slot < fe->exR->lastBatch, "ft_stereo_frontend_device_descriptors: slot holds no result");
+    // a paired batch keeps the right camera's results in the upper half of the left extractor's arrays
+    const int devSlot = (right && fe->lastPaired) ? fe->exR->lastBatch + slot : slot;
+    *dptr = (fe->lastPaired ? fe->exL : ex)->d_desc + (size_t)devSlot * ex->geom.maxKp * 32;
     *n = ex->h_nSel[slot];
     return FT_OK;
 }

@@ -791,7 +791,7 @@ int ft_tracked_frame_bind_stereo(ft_tracked_frame *tf, ft_stereo_frontend *fe, i
     FT_REQUIRE(tf->ctx == fe->ctx, "tracked frame and front end belong to different contexts");
     FT_REQUIRE(!fe->pending.active, "ft_tracked_frame_bind_stereo: the front end has a submitted batch that was not waited for");
     ft_extractor *L = fe->exL;
-    FT_REQUIRE(slot >= 0 && slot < L->maxBatch, "ft_tracked_frame_bind_stereo: slot out of range");
+    FT_REQUIRE(slot >= 0 && slot < fe->maxBatch, "ft_tracked_frame_bind_stereo: slot out of range");
     const int N = L->h_nSel[slot];
     FT_REQUIRE(meta->Nleft == -1, "ft_tracked_frame_bind_stereo: the stereo front end produces rectified frames (Nleft == -1)");
     FT_REQUIRE(meta->N == N, "ft_tracked_frame_bind_stereo: meta->N differs from the keypoint count of the slot");
