@@ -1,4 +1,4 @@
-"""Oracle vs the committed golden vectors (tests/golden/*.npz, made by tools/make_golden_vectors.py) - CPU only.
+"""Oracle vs the committed golden vectors (tests/golden/*.npz, made by tests/tools/make_golden_vectors.py) - CPU only.
 The vectors were produced by this oracle: they pin it against drift, they do not pin it to OpenCV
 (parity unpinned, see oracle/orb_oracle.h)."""
 import os

@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fasttrack_amd import orb, synth  # noqa: E402
 from oracle import binding as ob  # noqa: E402
 

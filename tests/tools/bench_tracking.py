@@ -5,13 +5,13 @@ search over the last frame's points followed by the local-map step (isInFrustum 
   resident : ft_tracked_frame_* - frame uploaded once, frustum fields stay on the device
   bound    : the same with the frame bound to the buffers the stereo front end left in HBM (no upload at all)
   oracle   : the CPU restatement on one host core
-usage: python tools/bench_tracking.py [reps]"""
+usage: python tests/tools/bench_tracking.py [reps]"""
 import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 from fasttrack_amd import orb

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long randomized parity run on an MI355X (not part of the test suite): extractor and fused stereo front end against
 the oracle over many random configurations (every fifth trial also Frame::ComputeBoW on a random vocabulary).
-usage: tools/soak_parity.py [--trials N] [--seed S]
+usage: tests/tools/soak_parity.py [--trials N] [--seed S]
 
 Every trial draws image size, feature count, pyramid depth, scale factor, FAST thresholds and texture density,
 runs the HIP path through the C ABI and compares keypoints (all fields, angles bit-exactly), descriptors and - for
@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fasttrack_amd import orb, synth  # noqa: E402
 from oracle import binding as ob  # noqa: E402
 
