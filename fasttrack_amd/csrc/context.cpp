@@ -227,6 +227,16 @@ int ft_debug_repeat(const char *name) {
     return 1;
 }
 
+bool ft_is_pinned_host(const void *p) {
+    if (!p) return true;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
 // grow-only device / pinned scratch of the matchers (callers hold ctx->matchMutex)
 int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes) {
     if (devBytes > ctx->scratchDevBytes) {

@@ -178,6 +178,7 @@ void freeAll(ft_extractor *ex) {
     if (ex->streamB) hipStreamDestroy(ex->streamB);
     hipFree(ex->d_pyr);
     if (ex->h_stage) hipHostFree(ex->h_stage);
+    if (ex->h_srcTab) hipHostFree(ex->h_srcTab);
     hipFree(ex->d_taps);
     hipFree(ex->d_cellTab);
     hipFree(ex->d_cellCount);
@@ -249,15 +250,14 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
                 ft_set_error("extract: empty image");
                 return FT_ERR_EMPTY;
             }
-            uint8_t *stg = ex->h_stage + (size_t)b * width * height;
-            for (int y = 0; y < height; y++) memcpy(stg + (size_t)y * width, images[b] + (size_t)y * stride, width);
             ex->h_l0[b] = ex->d_pyr + (size_t)b * g.pyrPerSlot + g.lv[0].off;
         }
+        ft_extract_restage(ex, images, batch, width, height, stride);
         ex->l0External = false;
         ex->l0Aligned = true;
         ex->l0pitch = g.lv[0].pitch;
         ex->lastBatch = batch;
-        return ft_launch_upload(ex->stream, batch, ex->h_stage, width, height, ex->d_pyr + g.lv[0].off, g.lv[0].pitch,
+        return ft_launch_upload(ex->stream, batch, ex->h_srcTab, width, height, ex->d_pyr + g.lv[0].off, g.lv[0].pitch,
                                 g.pyrPerSlot, ex->d_l0);
     }
     for (int b = 0; b < batch; b++) {
@@ -298,15 +298,24 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
 // graph path with host frames: pinned staging for up to 8 slots (allocated once)
 int ft_extract_ensure_stage(ft_extractor *ex) {
     if (ex->h_stage) return FT_OK;
+    FT_HIP(hipHostMalloc((void **)&ex->h_srcTab, sizeof(FtSrcEntry) * 16, hipHostMallocDefault));
     // (up to 8 frames per camera; a paired stereo batch brings both cameras through one extractor)
     FT_HIP(hipHostMalloc((void **)&ex->h_stage, (size_t)std::min(ex->maxBatch, 16) * ex->width * ex->height, hipHostMallocDefault));
     return FT_OK;
 }
 // replay of a captured batch with host frames: refresh the staging copies the captured uploads read
 void ft_extract_restage(ft_extractor *ex, const uint8_t *const *images, int batch, int width, int height, int stride) {
+    static const bool uploadKernel = !(getenv("FT_UPLOAD_KERNEL") && atoi(getenv("FT_UPLOAD_KERNEL")) == 0);
     for (int b = 0; b < batch; b++) {
+        if (uploadKernel && ft_is_pinned_host(images[b])) {  // the upload kernel reads the caller's pinned frame in place
+            ex->h_srcTab[b].ptr = images[b];
+            ex->h_srcTab[b].stride = stride;
+            continue;
+        }
         uint8_t *stg = ex->h_stage + (size_t)b * width * height;
         for (int y = 0; y < height; y++) memcpy(stg + (size_t)y * width, images[b] + (size_t)y * stride, width);
+        ex->h_srcTab[b].ptr = stg;
+        ex->h_srcTab[b].stride = width;
     }
 }
 

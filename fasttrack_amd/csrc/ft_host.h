@@ -125,7 +125,8 @@ struct ft_extractor {
     uint32_t *d_stage = nullptr;
     const uint8_t **d_l0 = nullptr;
     const uint8_t **h_l0 = nullptr;  // pinned
-    uint8_t *h_stage = nullptr;      // pinned staging of host frames for the graph path (up to 8 slots, allocated on first use)
+    uint8_t *h_stage = nullptr;      // pinned staging of host frames for the graph path (up to 16 slots, allocated on first use)
+    FtSrcEntry *h_srcTab = nullptr;  // pinned: where k_upload finds each frame (the caller's pinned memory or h_stage)
     bool stageHost = false;          // ft_extract_prepare: host frames go through h_stage (their pointers may change between replays)
     float *d_sf = nullptr;           // scale factors on device [nlevels] then inverse [nlevels]
     // host-mapped pinned buffers written by the device
@@ -206,6 +207,7 @@ struct ft_stereo_frontend {
 };
 
 int ft_set_device(const ft_context *ctx);
+bool ft_is_pinned_host(const void *p);  // null counts as pinned (nothing to copy)
 int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes);  // grow-only matcher scratch (hold matchMutex)
 int ft_usable_cpus();
 int ft_pipeline_depth(int batch, bool deviceOctree);

@@ -197,10 +197,17 @@ struct FtDeliverArgs {
     int srcStride, dstStride;
 };
 int ft_launch_deliver(hipStream_t st, int batch, const FtDeliverArgs &a);
-// Frame upload of a small batch (latency mode): one kernel reads the frames from pinned host staging (w x h bytes
-// each, dense) and writes them as level 0 of the slot pyramids (row pitch `pitch`, `slotBytes` apart), and fills
+// Frame upload of a small batch (latency mode): one kernel reads the frames from pinned host memory
+// and writes them as level 0 of the slot pyramids (row pitch `pitch`, `slotBytes` apart), and fills
 // the level-0 pointer table - instead of one DMA copy per frame plus one for the table.
-int ft_launch_upload(hipStream_t st, int batch, const uint8_t *stage, int width, int height, uint8_t *slot0, int pitch,
+// Each frame is described by an entry of a table in pinned host memory that the kernel reads when it runs (so a captured
+// launch follows the frames of every replay): a frame the caller keeps in pinned memory is read where it is, any other
+// frame from the library's pinned staging copy.
+struct FtSrcEntry {
+    const uint8_t *ptr;
+    long long stride;
+};
+int ft_launch_upload(hipStream_t st, int batch, const FtSrcEntry *srcTab, int width, int height, uint8_t *slot0, int pitch,
                      size_t slotBytes, const uint8_t **l0Table);
 struct FtFisheyeRig {
     float cam1[8], cam2[8], precision, Rlr[9], tlr[3];

@@ -556,32 +556,34 @@ __global__ __launch_bounds__(256) void k_deliver(FtDeliverArgs a) {
 }  // namespace
 
 namespace {
-__global__ __launch_bounds__(256) void k_upload(const uint8_t *stage, int width, int height, uint8_t *slot0, int pitch,
+__global__ __launch_bounds__(256) void k_upload(const FtSrcEntry *srcTab, int width, int height, uint8_t *slot0, int pitch,
                                                 size_t slotBytes, const uint8_t **l0Table) {
     const int slot = blockIdx.y;
-    const uint8_t *src = stage + (size_t)slot * width * height;
+    const FtSrcEntry e = srcTab[slot];  // (pinned host memory, written by the host just before the launch or replay)
+    const uint8_t *src = e.ptr;
+    const size_t sstride = (size_t)e.stride;
     uint8_t *dst = slot0 + (size_t)slot * slotBytes;
     const int t = blockIdx.x * 256 + threadIdx.x, T = gridDim.x * 256;
-    if ((width & 3) == 0) {  // dword columns (the slot pitch is a multiple of 64 bytes)
+    if ((width & 3) == 0 && (((uintptr_t)src | sstride) & 3) == 0) {  // dword columns (the slot pitch is a multiple of 64 bytes)
         const int wq = width >> 2, n = wq * height;
         for (int i = t; i < n; i += T) {
             const int y = i / wq, x = i - y * wq;
-            ((unsigned *)(dst + (size_t)y * pitch))[x] = ((const unsigned *)(src + (size_t)y * width))[x];
+            ((unsigned *)(dst + (size_t)y * pitch))[x] = ((const unsigned *)(src + (size_t)y * sstride))[x];
         }
     } else {
         const int n = width * height;
         for (int i = t; i < n; i += T) {
             const int y = i / width, x = i - y * width;
-            dst[(size_t)y * pitch + x] = src[(size_t)y * width + x];
+            dst[(size_t)y * pitch + x] = src[(size_t)y * sstride + x];
         }
     }
     if (t == 0) l0Table[slot] = dst;
 }
 }  // namespace
 
-int ft_launch_upload(hipStream_t st, int batch, const uint8_t *stage, int width, int height, uint8_t *slot0, int pitch,
+int ft_launch_upload(hipStream_t st, int batch, const FtSrcEntry *srcTab, int width, int height, uint8_t *slot0, int pitch,
                      size_t slotBytes, const uint8_t **l0Table) {
-    hipLaunchKernelGGL(k_upload, dim3(48, batch), dim3(256), 0, st, stage, width, height, slot0, pitch, slotBytes, l0Table);
+    hipLaunchKernelGGL(k_upload, dim3(48, batch), dim3(256), 0, st, srcTab, width, height, slot0, pitch, slotBytes, l0Table);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -181,15 +181,7 @@ ft_extractor *ft_stereo_frontend_left(ft_stereo_frontend *fe) { return fe ? fe->
 ft_extractor *ft_stereo_frontend_right(ft_stereo_frontend *fe) { return fe ? fe->exR : nullptr; }
 
 // result arrays in pinned host memory (ft_host_malloc) are filled by the D2H copies directly
-static bool isPinnedHost(const void *p) {
-    if (!p) return true;
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return at.type == hipMemoryTypeHost;
-}
+static bool isPinnedHost(const void *p) { return ft_is_pinned_host(p); }
 
 
 // enqueues one batch on the front end's streams.  capture != 0: L->stream is being captured into a graph - the other

@@ -560,6 +560,36 @@ def test_stereo_frontend_graph_replay(ctx):
             assert np.array_equal(outs[b]["keysL"], kL) and np.array_equal(outs[b]["descL"], dL), (k, b)
     if calls("stereo.graph_capture_failed") == 0:
         assert calls("stereo.graph_captures") == c1 + 1 and calls("stereo.graph_launch") == l1 + 2
+    # frames the caller keeps in pinned memory are read where they are (dense, and as views into a wider pinned buffer:
+    # stride > width, rows starting at odd addresses), mixed with a pageable frame in the same call
+    wide = ctx.pinned_array((h, w + 13), np.uint8)
+    dense = ctx.pinned_array((h, w), np.uint8)
+    for k in range(2):
+        (L0, R0), (L1, R1) = frames[k][0], frames[k][1]
+        wide[:, 5:5 + w] = L0
+        dense[:] = R1
+        # (a call has one stride: both frames are views of wider pinned buffers)
+        fe1 = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, 1, intr["mbf"], intr["mb"])
+        Rw = ctx.pinned_array((h, w + 13), np.uint8)
+        Rw[:, 5:5 + w] = R1
+        pl1, pr1 = (C.c_void_p * 1)(wide.ctypes.data + 5), (C.c_void_p * 1)(Rw.ctypes.data + 5)
+        fe1.process_raw(pl1, pr1, 1, False, w + 13)
+        oL, oR = ob.Extractor(nf), ob.Extractor(nf)
+        kL, dL, _ = oL.extract(L0)
+        kR, dR, _ = oR.extract(R1)
+        o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+        n = int(fe1._nL[0])
+        assert np.array_equal(fe1._kL[0, :n], kL) and np.array_equal(fe1._dL[0, :n], dL)
+        assert np.array_equal(fe1._kR[0, :int(fe1._nR[0])], kR) and np.array_equal(fe1._ur[0, :n], o["uright"])
+        # pinned and pageable frames in one call (dense rows)
+        fe.process_raw((C.c_void_p * 2)(dense.ctypes.data, L1.ctypes.data), (C.c_void_p * 2)(R0.ctypes.data, dense.ctypes.data),
+                       2, False, w)
+        oA = ob.Extractor(nf)
+        kA, dA, _ = oA.extract(R1)  # `dense` holds R1: left frame of pair 0 and right frame of pair 1
+        assert np.array_equal(fe._kL[0, :int(fe._nL[0])], kA) and np.array_equal(fe._kR[1, :int(fe._nR[1])], kA)
+        kB, dB, _ = ob.Extractor(nf).extract(L1)
+        assert np.array_equal(fe._kL[1, :int(fe._nL[1])], kB) and np.array_equal(fe._dL[1, :int(fe._nL[1])], dB)
+        fe1.close()
     # a different batch size is a different graph
     pL = (C.c_void_p * 1)(dev[0][0][0].ptr)
     pR = (C.c_void_p * 1)(dev[0][0][1].ptr)

@@ -29,6 +29,11 @@ for (w, h, nf) in [(752, 480, 1200), (1280, 720, 2000)]:
             fn()
             t.append(time.perf_counter() - t0)
         return 1e3 * float(np.median(t))
+    # the same frames in pinned host memory (ft_host_malloc): the upload kernel reads them where they are
+    Lp, Rp = ctx.pinned_array(L.shape, np.uint8), ctx.pinned_array(R.shape, np.uint8)
+    Lp[:], Rp[:] = L, R
     out[f"{w}x{h}_nf{nf}"] = {"extract_one_image_ms": timeit(lambda: ex(L)),
-                              "stereo_pair_extract_and_match_ms": timeit(lambda: fe.process([L], [R]))}
+                              "stereo_pair_extract_and_match_ms": timeit(lambda: fe.process([L], [R])),
+                              "extract_one_image_pinned_frame_ms": timeit(lambda: ex(Lp)),
+                              "stereo_pair_pinned_frames_ms": timeit(lambda: fe.process([Lp], [Rp]))}
 print(json.dumps(out))
