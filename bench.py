@@ -10,9 +10,18 @@ nFeatures 2000, 8 levels, scale 1.2, FAST 20/7.  One process per GPU; streams ar
 GPUs run N shards with no collective on the data path (weak scaling); torch.distributed (gloo) is
 used only for the barrier and the max-over-ranks time.
 
+`python bench.py --gpus N` without a torch.distributed.run environment starts the N ranks itself (a child
+`python -m torch.distributed.run`, started before this process touches the GPU; never an exec); under the
+launcher `--gpus` must equal WORLD_SIZE.
+
+Inputs: every pair of a step is a DISTINCT frame (`distinct_pairs == batch_pairs_per_gpu` by default), so
+level 0 streams from HBM: `--scenes` seeded synthetic scenes, each presented at distinct cyclic (dx, dy)
+shifts - the same shift for the left and the right image, which keeps the pair rectified.
+
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   roofline      dominant kernel (FAST cells): algorithmic bytes per launch / HIP-event duration vs 8 TB/s
   cpu_baseline  the oracle (restated CPU path of the reference) timed on this box's host cores
+  host_in       the same workload with the frames in pinned host memory (H2D inside the timed region)
 """
 import argparse
 import json
@@ -25,7 +34,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from fasttrack_amd import orb, shard, synth  # noqa: E402
+from fasttrack_amd import shard, synth  # noqa: E402  (orb - the HIP library - is imported in main(), after the launcher decision)
 
 WORKLOADS = {
     # name: (width, height, nfeatures, BASELINE.json config it mirrors)
@@ -35,6 +44,7 @@ WORKLOADS = {
 }
 NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_JSON = "r02_traffic.json"
 
 
 def usable_cpus():
@@ -108,6 +118,41 @@ def cpu_baseline(w, h, nf, pairs, budget_s=12.0):
                       f"matcher single-threaded): {ref_fps:.2f} frames/s over {n_ref} pairs"}
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` outside a launcher: start N ranks as a child job (this process has not touched the GPU
+    and does not exec), relay its output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def make_stream(ctx, w, h, rank, D, scenes, density=1.0):
+    """D distinct stereo pairs of this rank's stream in pinned host memory: `scenes` seeded scenes (synth.make_stereo_pair),
+    scene s of variant k shifted cyclically by (53 k mod w, 29 k mod h) px in BOTH images (rectification and disparities
+    are kept; the wrap-around seam is one more edge).  Returns (hostL, hostR) of shape (D, h, w) and the seeded scenes."""
+    S = max(1, min(scenes, D))
+    base = [synth.make_stereo_pair(w, h, seed=s, density=density) for s in shard.stream_seeds(rank, S)]
+    hostL, hostR = ctx.pinned_array((D, h, w), np.uint8), ctx.pinned_array((D, h, w), np.uint8)
+    for d in range(D):
+        L, R = base[d % S]
+        k = d // S
+        dx, dy = (53 * k) % w, (29 * k) % h
+        if k == 0:
+            hostL[d], hostR[d] = L, R
+        else:
+            hostL[d] = np.roll(L, (dy, dx), (0, 1))
+            hostR[d] = np.roll(R, (dy, dx), (0, 1))
+    return hostL, hostR, base
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,15 +160,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="stereo_1280x720_nf2000", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=512, help="stereo pairs per step per GPU")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct frames cycled through the batch (0 = the batch size)")
+    ap.add_argument("--scenes", type=int, default=16, help="seeded synthetic scenes behind the distinct frames")
+    ap.add_argument("--density", type=float, default=1.0, help="object density of the synthetic scenes (synth.py)")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-in", action="store_true", help="skip the second timed region with frames in pinned host memory")
     ap.add_argument("--sync-steps", action="store_true", help="one front end, every step fully drained before the next")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight (front ends used round-robin)")
     ap.add_argument("--stats", default="", help="write per-stage timings to this file")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank, local_rank, world = shard.env()
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: a run must not pass as a {args.gpus}-GPU result")
+    from fasttrack_amd import orb  # the HIP library: loaded by the ranks only
     # plumbing only: CPU tensors over gloo; the data path has no exchange step
     dist = shard.init(rank, world)
 
@@ -140,79 +193,102 @@ def main():
            for _ in range(1 if args.sync_steps else max(1, args.in_flight))]
     fe = fes[0]
 
-    # synthetic stream, resident in HBM before the timed region (seeds are per rank: one stream per GPU)
-    D = max(1, min(args.distinct, B))
-    pairs = [synth.make_stereo_pair(w, h, seed=s) for s in shard.stream_seeds(rank, D)]
-    devL = [ctx.to_device(p[0]) for p in pairs]
-    devR = [ctx.to_device(p[1]) for p in pairs]
+    # synthetic stream (seeds are per rank: one stream per GPU): D distinct pairs in pinned host memory and, for the
+    # headline number, resident in HBM before the timed region
+    D = max(1, min(args.distinct or B, B))
+    hostL, hostR, pairs = make_stream(ctx, w, h, rank, D, args.scenes, args.density)
+    devL, devR = ctx.to_device(hostL), ctx.to_device(hostR)
     import ctypes as C
-    ptrsL = (C.c_void_p * B)(*[devL[b % D].ptr for b in range(B)])
-    ptrsR = (C.c_void_p * B)(*[devR[b % D].ptr for b in range(B)])
+    fb = w * h
+    ptrsL = (C.c_void_p * B)(*[devL.ptr.value + (b % D) * fb for b in range(B)])
+    ptrsR = (C.c_void_p * B)(*[devR.ptr.value + (b % D) * fb for b in range(B)])
+    hptrsL = (C.c_void_p * B)(*[hostL.ctypes.data + (b % D) * fb for b in range(B)])
+    hptrsR = (C.c_void_p * B)(*[hostR.ctypes.data + (b % D) * fb for b in range(B)])
 
     def barrier():
         ctx.synchronize()  # hipDeviceSynchronize on this rank's device (the library owns its HIP runtime)
         shard.barrier(dist)
 
-    def run(steps):
+    def run(steps, pL, pR, on_device):
         """`steps` passes over the batch; every pass is complete (results in host arrays) on return"""
         if len(fes) == 1:
             for _ in range(steps):
-                fe.process_raw(ptrsL, ptrsR, B, True, w)
+                fe.process_raw(pL, pR, B, on_device, w)
             return
         F = len(fes)
         for k in range(steps):
             if k >= F:
                 fes[k % F].wait()  # the batch submitted F steps ago
-            fes[k % F].submit_raw(ptrsL, ptrsR, B, True, w)
+            fes[k % F].submit_raw(pL, pR, B, on_device, w)
         for k in range(max(steps - F, 0), steps):
             fes[k % F].wait()
 
-    run(max(args.warmup, 1))
+    def timed(steps, pL, pR, on_device):
+        barrier()
+        t0 = time.perf_counter()
+        run(steps, pL, pR, on_device)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        barrier()
+        return dt
+
+    run(max(args.warmup, 1), ptrsL, ptrsR, True)
     ctx.reset_stats()
     ctx.set_kernel_timing(True)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    ctx.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    kps = int(fe._nL[:B].sum() + fe._nR[:B].sum())
+    elapsed_rank = timed(args.steps, ptrsL, ptrsR, True)
+    ctx.set_kernel_timing(False)
+    kps_rank = int(fe._nL[:B].sum() + fe._nR[:B].sum())  # keypoints of one pass over this rank's batch
     matches = int(fe._nm[:B].sum())
 
-    elapsed = shard.reduce_max(dist, elapsed)
-    kps, matches = [int(v) for v in shard.reduce_sum(dist, [kps, matches])]
+    elapsed = shard.reduce_max(dist, elapsed_rank)
+    kps, matches = [int(v) for v in shard.reduce_sum(dist, [kps_rank, matches])]
+    rank_fps = shard.gather_floats(dist, B * args.steps / elapsed_rank, world)
 
     if args.stats:
         ctx.save_stats(args.stats + (f".rank{rank}" if world > 1 else ""))
+    # statistics of the headline region (rank 0's kernels), read before the host-in region runs
+    kern = {}
+    for name in ("kernel.pyr_down(all levels)", "kernel.fast_cells", "kernel.compact", "kernel.octree", "kernel.orient_desc",
+                 "kernel.stereo_rowsort", "kernel.stereo_match", "kernel.stereo_median"):
+        m, n = ctx.get_stat(name)
+        kern[name] = {"ms_per_launch": (m / n) if n else None, "launches": n}
+    host = {}
+    for name in ("stereo.octree(host,both)", "stereo.host_wait_stageA", "stereo.host_launch_stageB",
+                 "stereo.host_tail_sync", "stereo.submit.total", "stereo.device_octree_fallbacks"):
+        m, n = ctx.get_stat(name)
+        host[name] = (m / n) if n else None
+    fallbacks = ctx.get_stat("stereo.device_octree_fallbacks")[1]
+
+    # ---- host-in: the same workload with every frame handed over in pinned host memory, as the reference's call sites
+    # do (cv::Mat, src/Frame.cc:442-449; the reference uploads per call, src/ORBextractor.cc:1522-1541): the H2D copies
+    # of all 2 B frames of a step are inside the timed region.  Never the headline value.
+    host_in = None
+    if not args.no_host_in:
+        hsteps = max(2, min(args.steps, 12))
+        run(2, hptrsL, hptrsR, False)
+        dt_h = shard.reduce_max(dist, timed(hsteps, hptrsL, hptrsR, False))
+        host_in = {"value": B * hsteps * world / dt_h, "unit": "frames/s", "steps": hsteps, "ms_per_step": 1e3 * dt_h / hsteps,
+                   "h2d_bytes_per_step_per_gpu": 2 * B * fb, "h2d_GBps_per_gpu": 2 * B * fb * hsteps / dt_h / 1e9,
+                   "note": "frames in pinned host memory (ft_host_malloc), uploaded inside the timed region; results to host as in the headline"}
 
     if rank == 0:
         frames = B * args.steps * world
         fps = frames / elapsed
         P = level_pixels(w, h)
         sumP = sum(P)
-        # dominant kernel: k_fast_cells.  Algorithmic bytes (SURVEY 8d): FAST + NMS reads every pyramid
-        # pixel once = sum(P_l) bytes per image; one launch covers B images (one launch per camera).
-        ms, launches = ctx.get_stat("kernel.fast_cells")
-        kern = {}
-        for name in ("kernel.pyr_down(all levels)", "kernel.fast_cells", "kernel.compact", "kernel.octree", "kernel.orient_desc",
-                     "kernel.stereo_rowsort", "kernel.stereo_match", "kernel.stereo_median"):
-            m, n = ctx.get_stat(name)
-            kern[name] = {"ms_per_launch": (m / n) if n else None, "launches": n}
-        host = {}
-        for name in ("stereo.octree(host,both)", "stereo.host_wait_stageA", "stereo.host_launch_stageB",
-                     "stereo.host_tail_sync", "stereo.submit.total", "stereo.device_octree_fallbacks"):
-            m, n = ctx.get_stat(name)
-            host[name] = (m / n) if n else None
         # Roofline leg.  Algorithmic bytes per kernel (SURVEY 8d): FAST + NMS reads every pyramid pixel once (sum P_l per
         # image); the 7 pyramid launches of a sub-batch read P - P7 and write P - P0 per image; orientation + descriptor
         # read a 43x43 patch and write 60 B per keypoint.  The batch is processed in sub-batches, so bytes per launch =
-        # algorithmic bytes of the whole timed region / launches in it; durations are HIP events on the launching stream.
-        # `roofline` is k_fast_cells (see below), the others follow in roofline_other_kernels.  HBM-side traffic per launch comes from the committed PMC passes (FETCH_SIZE /
-        # WRITE_SIZE cannot be read live) and is reported when this run's launch shape equals the profiled one.
+        # algorithmic bytes of rank 0's timed region / its launches; durations are HIP events on the launching stream.
+        # `roofline` is k_fast_cells (see below), the others follow in roofline_other_kernels.  HBM-side traffic per launch
+        # comes from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live; FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes) and is reported when this run's launch shape equals the profiled one.
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))
         except Exception:
             tj = {}
+        tk = tj.get("kernels", {})
+        same_inputs = tj.get("distinct_pairs") == D and tj.get("batch_pairs") == B and tj.get("workload") == args.workload
 
         def leg(stat, kernel, total_bytes, per_group=1):
             m, n = ctx.get_stat(stat)
@@ -220,23 +296,25 @@ def main():
                 return None
             achieved = total_bytes / (m / 1e3) / 1e9
             traffic = None
-            t = tj.get(kernel)
+            t = tk.get(kernel)
             imgs = args.steps * 2.0 * B / n
-            if t and args.workload == "stereo_1280x720_nf2000" and abs(imgs - t["images_per_launch"] * per_group) < 0.5:
+            if t and same_inputs and abs(imgs - t["images_per_launch"] * per_group) < 0.5:
                 traffic = t["traffic_bytes_per_launch"] * per_group
             return {"bound": "hbm", "kernel": kernel + (" (%d launches per sub-batch, timed as a group)" % per_group if per_group > 1 else ""),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic,
-                    "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                                      "calibrated by tools/hbm_calib.sh)" if traffic else None,
+                    "traffic_over_algorithmic": (traffic / (total_bytes / n)) if traffic else None,
+                    "traffic_source": f"profiles/{TRAFFIC_JSON} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes, "
+                                      "same workload and launch shape)" if traffic else None,
+                    "valu_issue_frac": (t or {}).get("valu_issue_frac"),
                     "bytes_per_launch": total_bytes / n, "avg_launch_ms": m / n, "launches_timed": n, "total_ms": m}
         legs = [leg("kernel.fast_cells", "k_fast_cells", float(args.steps) * 2.0 * B * sumP),
                 leg("kernel.pyr_down(all levels)", "k_pyr_down", float(args.steps) * 2.0 * B * ((sumP - P[-1]) + (sumP - P[0])), 7),
-                leg("kernel.orient_desc", "k_orient_desc", float(kps) * args.steps * (43 * 43 + 60))]
-        # Dominant kernel = k_fast_cells: the largest cost inside the overlapped pipeline (0.69 of 1.97 ms per 128 pairs,
-        # profiles/r01_marginal_costs.json; k_orient_desc 0.48, pyramid 0.36).  It fills the chip while it runs, so its
-        # event duration is its own and equals its rocprofv3 duration; the durations of k_orient_desc and the thin
-        # k_octree (events and rocprofv3 alike) include the stage-A kernels of the next sub-batch they run beside.
+                leg("kernel.orient_desc", "k_orient_desc", float(kps_rank) * args.steps * (43 * 43 + 60))]
+        # Dominant kernel = k_fast_cells: the largest cost inside the overlapped pipeline (profiles/*_marginal_costs.json).
+        # It fills the chip while it runs, so its event duration is its own and equals its rocprofv3 duration; the
+        # durations of k_orient_desc and the thin k_octree (events and rocprofv3 alike) include the stage-A kernels of
+        # the next sub-batch they run beside.
         legs = [x for x in legs if x]
         roof = legs[0] if legs else None
         also = sorted(legs[1:], key=lambda x: -x["total_ms"])
@@ -248,15 +326,21 @@ def main():
             "config": {"workload": args.workload, "note": cfg_note, "frame": "one rectified stereo pair",
                        "image": [w, h], "nfeatures": nf, "nlevels": NLEVELS, "scale_factor": SCALE,
                        "fast_thresholds": [INI_TH, MIN_TH], "batch_pairs_per_gpu": B, "distinct_pairs": D,
+                       "scenes": min(args.scenes, D), "scene_density": args.density,
+                       "inputs": "resident in HBM before the timed region (host_in: pinned host memory, uploaded inside it)",
                        "batches_in_flight": len(fes),
                        "parallelism": f"{world} independent stream(s), one per GPU, no collective",
                        "host_threads_per_gpu": ctx.host_threads, "device": ctx.device_name},
+            "per_rank_frames_per_s": rank_fps,
             "keypoints_per_s": kps * args.steps / elapsed,
+            "keypoints_per_frame": kps / (B * world),
             "stereo_matches_per_frame": matches / (B * world),
-            "pipeline_hbm_read_frac": fps * R_pair / (HBM_PEAK_GBS * 1e9),
+            "device_octree_fallbacks": fallbacks,
+            "pipeline_hbm_read_frac": fps / world * R_pair / (HBM_PEAK_GBS * 1e9),
             "kernels": kern, "host_ms_per_step": host,
             "roofline": roof,
             "roofline_other_kernels": also,
+            "host_in": host_in,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h, nf, pairs)

@@ -237,6 +237,25 @@ bool ft_is_pinned_host(const void *p) {
     return at.type == hipMemoryTypeHost;
 }
 
+// A frame the device may read in place: first AND last byte lie in the same pinned / registered host allocation.
+// (A frame that starts inside a pinned region and runs past it - wrong stride or height, a view at the tail of a
+// registered range - would be a device access to unpinned memory: a fatal GPU fault, not an error code.)
+bool ft_is_pinned_host_range(const void *p, size_t bytes) {
+    if (!p || bytes == 0) return false;
+    if (!ft_is_pinned_host(p)) return false;
+    const uint8_t *last = (const uint8_t *)p + (bytes - 1);
+    if (!ft_is_pinned_host(last)) return false;
+    void *b0 = nullptr, *b1 = nullptr;
+    size_t s0 = 0, s1 = 0;
+    if (hipMemGetAddressRange((hipDeviceptr_t *)&b0, &s0, (hipDeviceptr_t)p) != hipSuccess ||
+        hipMemGetAddressRange((hipDeviceptr_t *)&b1, &s1, (hipDeviceptr_t)last) != hipSuccess) {
+        (void)hipGetLastError();
+        // the runtime cannot name the allocation (e.g. hipHostRegister'ed ranges on some stacks): be conservative
+        return false;
+    }
+    return b0 == b1;
+}
+
 // grow-only device / pinned scratch of the matchers (callers hold ctx->matchMutex)
 int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes) {
     if (devBytes > ctx->scratchDevBytes) {

@@ -297,17 +297,18 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
 
 // graph path with host frames: pinned staging for up to 8 slots (allocated once)
 int ft_extract_ensure_stage(ft_extractor *ex) {
-    if (ex->h_stage) return FT_OK;
-    FT_HIP(hipHostMalloc((void **)&ex->h_srcTab, sizeof(FtSrcEntry) * 16, hipHostMallocDefault));
+    if (!ex->h_srcTab) FT_HIP(hipHostMalloc((void **)&ex->h_srcTab, sizeof(FtSrcEntry) * 16, hipHostMallocDefault));
     // (up to 8 frames per camera; a paired stereo batch brings both cameras through one extractor)
-    FT_HIP(hipHostMalloc((void **)&ex->h_stage, (size_t)std::min(ex->maxBatch, 16) * ex->width * ex->height, hipHostMallocDefault));
+    if (!ex->h_stage)
+        FT_HIP(hipHostMalloc((void **)&ex->h_stage, (size_t)std::min(ex->maxBatch, 16) * ex->width * ex->height, hipHostMallocDefault));
     return FT_OK;
 }
 // replay of a captured batch with host frames: refresh the staging copies the captured uploads read
 void ft_extract_restage(ft_extractor *ex, const uint8_t *const *images, int batch, int width, int height, int stride) {
     static const bool uploadKernel = !(getenv("FT_UPLOAD_KERNEL") && atoi(getenv("FT_UPLOAD_KERNEL")) == 0);
     for (int b = 0; b < batch; b++) {
-        if (uploadKernel && ft_is_pinned_host(images[b])) {  // the upload kernel reads the caller's pinned frame in place
+        // the upload kernel reads the caller's pinned frame in place - only when its whole extent is pinned
+        if (uploadKernel && ft_is_pinned_host_range(images[b], (size_t)(height - 1) * stride + width)) {
             ex->h_srcTab[b].ptr = images[b];
             ex->h_srcTab[b].stride = stride;
             continue;

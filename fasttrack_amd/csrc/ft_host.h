@@ -208,6 +208,7 @@ struct ft_stereo_frontend {
 
 int ft_set_device(const ft_context *ctx);
 bool ft_is_pinned_host(const void *p);  // null counts as pinned (nothing to copy)
+bool ft_is_pinned_host_range(const void *p, size_t bytes);  // [p, p + bytes) inside ONE pinned host allocation
 int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes);  // grow-only matcher scratch (hold matchMutex)
 int ft_usable_cpus();
 int ft_pipeline_depth(int batch, bool deviceOctree);

@@ -477,7 +477,8 @@ class StereoFrontend:
         B = len(imagesL)
         pL, keepL = _image_ptrs(imagesL, on_device)
         pR, keepR = _image_ptrs(imagesR, on_device)
-        self.process_raw(pL, pR, B, on_device, stride or self.width)
+        # host frames were made dense by _image_ptrs: their row stride is the width whatever the caller's view had
+        self.process_raw(pL, pR, B, on_device, (stride or self.width) if on_device else self.width)
         out = []
         for b in range(B):
             nl, nr = int(self._nL[b]), int(self._nR[b])

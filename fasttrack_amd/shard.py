@@ -52,6 +52,17 @@ def reduce_sum(dist, values):
     return [float(v) for v in t]
 
 
+def gather_floats(dist, value: float, world: int):
+    """one float per rank, in rank order (bench.py: per-rank frames/s)"""
+    if dist is None:
+        return [float(value)]
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(o[0]) for o in out]
+
+
 def gather_ints(dist, values, world: int):
     """all_gather of a small int list (tests: stream disjointness)."""
     if dist is None:

@@ -168,7 +168,11 @@ FT_API ft_extractor *ft_stereo_frontend_right(ft_stereo_frontend *fe);
  * octree of the last sub-batch is done and its kernels are queued), wait drains the device and finishes
  * the outputs.  With two front ends used alternately the drain of one batch overlaps with the next batch:
  *   submit(fe[k & 1], batch k);  wait(fe[(k - 1) & 1]);
- * Output arrays of a submitted batch must stay untouched until its wait returns. */
+ * Output arrays of a submitted batch must stay untouched until its wait returns.
+ * INPUT FRAMES of a submitted batch must stay valid AND UNCHANGED until its wait returns, whatever memory they live
+ * in: frames resident in HBM (on_device) and frames in pinned host memory (ft_host_malloc / hipHostMalloc /
+ * hipHostRegister) are read in place by the device after submit has returned; only pageable host frames are copied
+ * before submit returns.  A camera ring buffer must therefore not recycle a slot between submit and wait. */
 FT_API int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imagesL,
                                      const uint8_t *const *imagesR, int batch, int on_device, int width, int height,
                                      int stride, ft_keypoint *keysL, uint8_t *descL, int *nL, ft_keypoint *keysR,

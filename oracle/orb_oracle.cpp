@@ -1,6 +1,6 @@
 /*
  * orb_oracle.cpp - CPU restatement of the reference's CPU branch (see orb_oracle.h for the role and
- * the "parity unpinned" caveat).  Build: oracle/Makefile (g++ -O2 -ffp-contract=off, no fast-math).
+ * the "parity unpinned" caveat).  Build: oracle/Makefile (g++ -O3 -ffp-contract=off, no fast-math).
  *
  * File:line citations are relative to /root/reference.
  */

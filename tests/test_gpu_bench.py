@@ -1,0 +1,44 @@
+"""bench.py on the GPU box: the N>1 launch path through the real library (two ranks folded onto the one device
+of the box with FT_BENCH_DEVICE_MOD=1), the contract fields of the JSON line, and the host-in leg."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=900):
+    env = dict(os.environ, **(env_extra or {}))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_folded_onto_one_device():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16", "--workload", "stereo_640x480_nf1000",
+              "--no-cpu-baseline"], {"FT_BENCH_DEVICE_MOD": "1"})
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 3
+    assert len(r["per_rank_frames_per_s"]) == 2 and min(r["per_rank_frames_per_s"]) > 0
+    # whole-job value = frames of both ranks / max-over-ranks time: never above the sum of the per-rank rates
+    assert r["value"] <= sum(r["per_rank_frames_per_s"]) * 1.0001
+    assert r["config"]["distinct_pairs"] == r["config"]["batch_pairs_per_gpu"] == 16
+    assert r["host_in"]["value"] > 0 and r["cpu_baseline"] is None
+    assert r["device_octree_fallbacks"] == 0
+
+
+def test_bench_single_rank_line_has_the_contract_fields():
+    r = _run(["--steps", "3", "--warmup", "1", "--batch", "32", "--workload", "stereo_752x480_nf1200", "--no-cpu-baseline"])
+    assert r["n_gpus"] == 1 and r["metric"] == "frames/sec extract+match" and r["unit"] == "frames/s"
+    assert r["dtype"] == "u8" and r["vs_baseline"] is None and r["higher_is_better"] is True
+    roof = r["roofline"]
+    assert roof["bound"] == "hbm" and roof["kernel"] == "k_fast_cells" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    assert r["config"]["distinct_pairs"] == 32
+    assert 0 < r["host_in"]["value"] <= r["value"] * 1.05   # uploading inside the timed region cannot be faster

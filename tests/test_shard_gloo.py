@@ -35,3 +35,44 @@ def test_single_process_path_needs_no_process_group():
     assert shard.init(0, 1) is None
     assert shard.reduce_max(None, 1.5) == 1.5 and shard.reduce_sum(None, [1, 2]) == [1.0, 2.0]
     assert shard.stream_seeds(3, 2) == [3000, 3001]
+
+
+def test_gather_floats_single_process():
+    from fasttrack_amd import shard
+    assert shard.gather_floats(None, 2.5, 1) == [2.5]
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    """`bench.py --gpus 8` inside a 1-rank launcher environment must fail instead of printing n_gpus: 1"""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert "--gpus 8 but WORLD_SIZE is 1" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_gpus_n_starts_n_ranks(tmp_path, monkeypatch):
+    """without a launcher environment `--gpus N` starts N ranks through torch.distributed.run (here: the command
+    line it builds, with the child replaced by a recorder - there is no GPU in this container)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    import pytest
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                   # the child's exit code is relayed
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -48,7 +48,10 @@ int main() {
     write_b32<<<4096, 256>>>((unsigned *)buf, bytes / 4);
     write_b8<<<4096, 256>>>(buf, bytes / 4);
     hipDeviceSynchronize();
-    printf("expected_KB read_b32 %zu read_b128 %zu read_rows48 %zu (48 of every 1280 B; whole 64-B lines touched: %zu) write_b32 %zu write_b8 %zu\n",
-           bytes / 1024, bytes / 1024, bytes / 1280 * 48 / 1024, bytes / 1280 * 64 / 1024, bytes / 1024, bytes / 4 / 1024);
+    // 1280 = 10 x 128: every row's 48-byte segment starts a 128-byte line, so a row touches one 64-B line and one 128-B line
+    printf("expected_KB read_b32 %zu read_b128 %zu read_rows48 %zu (48 of every 1280 B; whole 64-B lines touched: %zu; whole 128-B "
+           "lines touched: %zu) write_b32 %zu write_b8 %zu\n",
+           bytes / 1024, bytes / 1024, bytes / 1280 * 48 / 1024, bytes / 1280 * 64 / 1024, bytes / 1280 * 128 / 1024, bytes / 1024,
+           bytes / 4 / 1024);
     return 0;
 }

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 output directory written by tools/profile_bench.sh (rocpd sqlite output):
-per-kernel launch count / average / total time from the kernel trace, and per-launch FETCH_SIZE /
-WRITE_SIZE (KB as rocprofv3 reports them; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly half
-of a wide coalesced stream, other widths uncalibrated)."""
+per-kernel launch count / average / total time from the kernel trace, per-launch FETCH_SIZE / WRITE_SIZE
+(KB as rocprofv3 reports them; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts 128-B requests at 64 B,
+so it is DOUBLED before it is compared with bytes - tools/traffic_from_profile.py does that) and the SQ
+instruction counters per wave and per launch."""
 import glob
 import os
 import sqlite3
@@ -32,6 +33,25 @@ def main(root):
             print(f"== {which}: per-launch counter value (KB as reported by rocprofv3)")
             for n, cn, c, a in rows:
                 print(f"{short(n):48s} {cn:12s} launches {c:6d}  per-launch {a:14.1f} KB")
+    for f in glob.glob(os.path.join(root, "pmc_sq", "**", "*.db"), recursive=True):
+        db = sqlite3.connect(f)
+        rows = db.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                          "group by kernel_name, counter_name").fetchall()
+        d = {}
+        for n, c, k, v in rows:
+            e = d.setdefault(short(n), {})
+            e[c] = v
+            e["launches"] = k
+        print("== pmc_sq: SQ counters, averages per launch (cycle counters are quad-cycles summed over waves)")
+        for n, c in sorted(d.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
+            if n.startswith("__amd"):
+                continue
+            w = c.get("SQ_WAVES", 1) or 1
+            wc = max(c.get("SQ_WAVE_CYCLES", 1), 1)
+            print(f"{n:48s} SQ launches {c['launches']:6d} waves {w:11.0f} valu_per_launch {c.get('SQ_INSTS_VALU', 0):14.0f} "
+                  f"valu/wave {c.get('SQ_INSTS_VALU', 0)/w:8.1f} salu/wave {c.get('SQ_INSTS_SALU', 0)/w:8.1f} lds/wave {c.get('SQ_INSTS_LDS', 0)/w:7.1f} "
+                  f"cyc/wave {4*c.get('SQ_WAVE_CYCLES', 0)/w:9.0f} wait_any% {100*c.get('SQ_WAIT_ANY', 0)/wc:5.1f} "
+                  f"active% {100*c.get('SQ_ACTIVE_INST_ANY', 0)/wc:5.1f} wait_inst% {100*c.get('SQ_WAIT_INST_ANY', 0)/wc:5.1f}")
 
 
 if __name__ == "__main__":

@@ -1,34 +1,60 @@
 #!/usr/bin/env python3
 """profiles/<tag>_rocprof_summary.txt -> profiles/<tag>_traffic.json: per-launch HBM-side bytes of every kernel
-from the FETCH_SIZE / WRITE_SIZE passes, with the gfx950 corrections measured by tools/hbm_calib.sh
-(profiles/r01_hbm_calibration_expected.txt): FETCH_SIZE is halved for coalesced streams, exact for the
-row-segment tile loads k_fast_cells / k_pyr_down / k_orient_desc issue; WRITE_SIZE is exact."""
+from the FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts
+128-byte read requests at 64 bytes each, so it is DOUBLED for every kernel (tools/hbm_calib.sh confirms it for the
+access patterns of this repo: a coalesced dword / 16-byte stream and the 48-byte row segments of the tile loads both
+read back as half of the 128-byte requests they touch); WRITE_SIZE is exact.  Also records, per kernel, the average
+rocprofv3 duration and the VALU issue fraction = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x duration x 2.4 GHz).
+
+usage: traffic_from_profile.py <summary.txt> <out.json> --workload W --batch B --distinct D --steps S"""
+import argparse
 import json
 import re
-import sys
 
-FETCH_FACTOR = {"k_fast_cells": 1.0, "k_pyr_down": 1.0, "k_orient_desc": 1.0}  # row-segment tile loads
+FETCH_FACTOR = 2.0
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
-def main(summary, out, images_per_step=256, steps=7):
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("summary")
+    ap.add_argument("out")
+    ap.add_argument("--workload", default="stereo_1280x720_nf2000")
+    ap.add_argument("--batch", type=int, default=512, help="pairs per step")
+    ap.add_argument("--distinct", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=7, help="passes over the batch the profiled run made (warmup + steps)")
+    a = ap.parse_args()
     d = {}
-    for line in open(summary):
+    for line in open(a.summary):
         m = re.match(r"(.+?)\s+(FETCH_SIZE|WRITE_SIZE)\s+launches\s+(\d+)\s+per-launch\s+([\d.]+) KB", line)
-        if not m:
+        if m:
+            e = d.setdefault(m.group(1).split("<")[0], {})
+            e["launches"] = int(m.group(3))
+            e["fetch_kb_raw" if m.group(2) == "FETCH_SIZE" else "write_kb"] = float(m.group(4))
             continue
-        k = m.group(1).split("<")[0]
-        e = d.setdefault(k, {"launches": int(m.group(3))})
-        e["fetch_kb" if m.group(2) == "FETCH_SIZE" else "write_kb"] = float(m.group(4))
+        m = re.match(r"(\S+)\s+SQ launches\s+(\d+)\s+waves\s+([\d.]+)\s+valu_per_launch\s+([\d.]+)\s+valu/wave\s+([\d.]+)\s+salu/wave\s+([\d.]+)\s+lds/wave\s+([\d.]+)", line)
+        if m:
+            e = d.setdefault(m.group(1).split("<")[0], {})
+            e.update(waves_per_launch=float(m.group(3)), valu_per_launch=float(m.group(4)), valu_per_wave=float(m.group(5)),
+                     salu_per_wave=float(m.group(6)), lds_per_wave=float(m.group(7)))
+            continue
+        m = re.match(r"(\S+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(\d+)\s+(\d+)\s*$", line)
+        if m and not line.startswith("kernel"):
+            e = d.setdefault(m.group(1).split("<")[0], {})
+            e.update(trace_launches=int(m.group(2)), avg_us=float(m.group(3)), pct_of_kernel_time=float(m.group(5)))
+    images_per_step = 2 * a.batch
     for k, e in d.items():
-        f = FETCH_FACTOR.get(k, 2.0)
-        e["fetch_factor"] = f
-        e["traffic_bytes_per_launch"] = (e.get("fetch_kb", 0) * f + e.get("write_kb", 0)) * 1024
-    for k, e in d.items():  # images one launch covers (bench under the profiler: `steps` passes over the batch)
-        e["images_per_launch"] = images_per_step * steps / e["launches"] if e["launches"] else None
-    json.dump({"source": summary, "note": "per launch; default bench (%d pairs of 1280x720 per step, %d steps profiled)" % (images_per_step // 2, steps),
-               "kernels": d}, open(out, "w"), indent=1)
+        if "launches" in e:
+            e["fetch_factor"] = FETCH_FACTOR
+            e["traffic_bytes_per_launch"] = (e.get("fetch_kb_raw", 0) * FETCH_FACTOR + e.get("write_kb", 0)) * 1024
+            e["images_per_launch"] = images_per_step * a.steps / e["launches"] if e["launches"] else None
+        if "valu_per_launch" in e and e.get("avg_us"):
+            e["valu_issue_frac"] = e["valu_per_launch"] * 4 / (SIMDS * e["avg_us"] * 1e-6 * CLOCK_HZ)
+    json.dump({"source": a.summary, "workload": a.workload, "batch_pairs": a.batch, "distinct_pairs": a.distinct,
+               "note": "per launch; bench of %d pairs per step, %d passes profiled; FETCH_SIZE doubled (128-B requests counted at 64 B)"
+                       % (a.batch, a.steps), "kernels": d}, open(a.out, "w"), indent=1)
     print(json.dumps(d.get("k_fast_cells"), indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], *(int(a) for a in sys.argv[3:5]))
+    main()
