@@ -32,13 +32,13 @@ def main():
             e["launches"] = int(m.group(3))
             e["fetch_kb_raw" if m.group(2) == "FETCH_SIZE" else "write_kb"] = float(m.group(4))
             continue
-        m = re.match(r"(\S+)\s+SQ launches\s+(\d+)\s+waves\s+([\d.]+)\s+valu_per_launch\s+([\d.]+)\s+valu/wave\s+([\d.]+)\s+salu/wave\s+([\d.]+)\s+lds/wave\s+([\d.]+)", line)
+        m = re.match(r"(.+?)\s+SQ launches\s+(\d+)\s+waves\s+([\d.]+)\s+valu_per_launch\s+([\d.]+)\s+valu/wave\s+([\d.]+)\s+salu/wave\s+([\d.]+)\s+lds/wave\s+([\d.]+)", line)
         if m:
             e = d.setdefault(m.group(1).split("<")[0], {})
             e.update(waves_per_launch=float(m.group(3)), valu_per_launch=float(m.group(4)), valu_per_wave=float(m.group(5)),
                      salu_per_wave=float(m.group(6)), lds_per_wave=float(m.group(7)))
             continue
-        m = re.match(r"(\S+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(\d+)\s+(\d+)\s*$", line)
+        m = re.match(r"(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(\d+)\s+(\d+)\s*$", line)
         if m and not line.startswith("kernel"):
             e = d.setdefault(m.group(1).split("<")[0], {})
             e.update(trace_launches=int(m.group(2)), avg_us=float(m.group(3)), pct_of_kernel_time=float(m.group(5)))
