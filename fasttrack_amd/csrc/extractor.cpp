@@ -966,6 +966,29 @@ int ft_extractor_download_level(ft_extractor *ex, int slot, int level, uint8_t *
     return FT_OK;
 }
 
+int ft_extractor_download_blurred_level(ft_extractor *ex, int slot, int level, uint8_t *dst, int dst_stride) {
+    FT_REQUIRE(dst, "null destination");
+    const uint8_t *src = nullptr;
+    int pitch = 0;
+    int rc = ft_extractor_device_level(ex, slot, level, &src, &pitch);
+    if (rc != FT_OK) return rc;
+    rc = ft_set_device(ex->ctx);
+    if (rc != FT_OK) return rc;
+    const FtLevelGeom &v = ex->geom.lv[level];
+    FT_REQUIRE(dst_stride >= v.w, "destination stride smaller than the level width");
+    FT_HIP(hipStreamSynchronize(ex->stream));
+    FT_HIP(hipStreamSynchronize(ex->streamB));
+    uint8_t *tmp = nullptr;
+    FT_HIP(hipMalloc((void **)&tmp, (size_t)v.w * v.h));
+    rc = ft_launch_blur_level(ex->stream, src, pitch, v.w, v.h, tmp, v.w);
+    hipError_t e = rc == FT_OK ? hipStreamSynchronize(ex->stream) : hipSuccess;
+    if (rc == FT_OK && e == hipSuccess) e = hipMemcpy2D(dst, dst_stride, tmp, v.w, v.w, v.h, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    if (rc != FT_OK) return rc;
+    FT_HIP(e);
+    return FT_OK;
+}
+
 int ft_extractor_download_candidates(ft_extractor *ex, int slot, int level, int *xys, int capacity, int *n) {
     FT_REQUIRE(ex && n, "null argument");
     FT_REQUIRE(slot >= 0 && slot < ex->lastBatch, "slot holds no image");

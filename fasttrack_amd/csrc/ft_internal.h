@@ -155,6 +155,8 @@ int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint
                           const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *selCount,
                           const FtOctArgs &layout, int *nSel, ft_keypoint *keys, uint8_t *desc);
 int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a);
+// test tap: 7x7 Gaussian of a whole level through k_orient_desc's blur routines (dst on the device)
+int ft_launch_blur_level(hipStream_t st, const uint8_t *img, int pitch, int w, int h, uint8_t *dst, int dstPitch);
 size_t ft_octree_smem_bytes(int poolCap);
 size_t ft_fast_smem_bytes(const FtGeom &g);
 

@@ -753,6 +753,50 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return i;
 }
 
+// The 7x7 sigma-2 Gaussian of cv::GaussianBlur (8-bit fixed point, taps {18,34,48,56,48,34,18}) as the
+// two routines k_orient_desc applies on the fly; k_blur_level (a test tap) runs the same two routines over a whole level.
+// Horizontal: four consecutive outputs h[j] = sum_t k[t] * byte[j + t] (j = 0..3, t = 0..6) from three aligned dwords
+// holding bytes 0..11.  The shifted windows of outputs 1 .. 3 are expressed through shifted WEIGHTS on the aligned
+// dwords (ten v_dot4 with constant weight vectors) instead of byte-aligning the data first.
+__device__ __forceinline__ void od_hblur4(unsigned d0, unsigned d1, unsigned d2, unsigned &h0, unsigned &h1, unsigned &h2, unsigned &h3) {
+#define FT_W4(a, b, c, d) ((unsigned)(a) | ((unsigned)(b) << 8) | ((unsigned)(c) << 16) | ((unsigned)(d) << 24))
+    const unsigned W0a = FT_W4(18, 34, 48, 56), W0b = FT_W4(48, 34, 18, 0);
+    const unsigned W1a = FT_W4(0, 18, 34, 48), W1b = FT_W4(56, 48, 34, 18);
+    const unsigned W2a = FT_W4(0, 0, 18, 34), W2b = FT_W4(48, 56, 48, 34), W2c = FT_W4(18, 0, 0, 0);
+    const unsigned W3a = FT_W4(0, 0, 0, 18), W3b = FT_W4(34, 48, 56, 48), W3c = FT_W4(34, 18, 0, 0);
+#undef FT_W4
+    h0 = __builtin_amdgcn_udot4(d1, W0b, __builtin_amdgcn_udot4(d0, W0a, 0u, false), false);
+    h1 = __builtin_amdgcn_udot4(d1, W1b, __builtin_amdgcn_udot4(d0, W1a, 0u, false), false);
+    h2 = __builtin_amdgcn_udot4(d2, W2c, __builtin_amdgcn_udot4(d1, W2b, __builtin_amdgcn_udot4(d0, W2a, 0u, false), false), false);
+    h3 = __builtin_amdgcn_udot4(d2, W3c, __builtin_amdgcn_udot4(d1, W3b, __builtin_amdgcn_udot4(d0, W3a, 0u, false), false), false);
+}
+// Vertical: blurred pixel = (sum_s k[s] * h[s] + 2^15) >> 16 from the seven horizontally blurred values of its column
+// (each <= 255 * 256; the sums stay below 2^24, so 24-bit multiply-adds are exact)
+__device__ __forceinline__ unsigned od_vblur7(unsigned p0, unsigned p1, unsigned p2, unsigned p3, unsigned p4, unsigned p5, unsigned p6) {
+    unsigned v;
+    asm("v_mad_u32_u24 %0, %1, 18, %2" : "=v"(v) : "v"(p0 + p6), "s"(32768u));
+    asm("v_mad_u32_u24 %0, %1, 34, %2" : "=v"(v) : "v"(p1 + p5), "v"(v));
+    asm("v_mad_u32_u24 %0, %1, 48, %2" : "=v"(v) : "v"(p2 + p4), "v"(v));
+    asm("v_mad_u32_u24 %0, %1, 56, %2" : "=v"(v) : "v"(p3), "v"(v));
+    return v >> 16;
+}
+
+// Test tap (a7, GaussianBlur directly): the blurred image of one pyramid level, BORDER_REFLECT_101, computed with
+// od_hblur4 / od_vblur7.  One thread per aligned group of four output pixels; speed is irrelevant here.
+__global__ void k_blur_level(const uint8_t *img, int pitch, int w, int h, uint8_t *dst, int dstPitch) {
+    const int gx = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    if (gx >= w || y >= h) return;
+    unsigned hb[7][4];
+    for (int s = 0; s < 7; s++) {
+        const uint8_t *row = img + (size_t)reflect101(y + s - 3, h) * pitch;
+        unsigned d[3] = {0u, 0u, 0u};
+        for (int b = 0; b < 12; b++) d[b >> 2] |= (unsigned)row[reflect101(gx - 3 + b, w)] << (8 * (b & 3));
+        od_hblur4(d[0], d[1], d[2], hb[s][0], hb[s][1], hb[s][2], hb[s][3]);
+    }
+    for (int j = 0; j < 4 && gx + j < w; j++)
+        dst[(size_t)y * dstPitch + gx + j] = (uint8_t)od_vblur7(hb[0][j], hb[1][j], hb[2][j], hb[3][j], hb[4][j], hb[5][j], hb[6][j]);
+}
+
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2; every operation rounded separately (no FMA contraction)
     const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
@@ -874,14 +918,6 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     // raw[r][b + t] for raw byte positions b in [0, 40) (16 bit, <= 255 * 256); output column c of the
     // blurred window is b = ax + c.
     {
-        // the shifted windows of outputs 1 .. 3 are expressed through shifted WEIGHTS on the three aligned dwords (ten
-        // v_dot4 with constant weight vectors) instead of byte-aligning the data first (six v_alignbyte + eight v_dot4)
-#define FT_W4(a, b, c, d) ((unsigned)(a) | ((unsigned)(b) << 8) | ((unsigned)(c) << 16) | ((unsigned)(d) << 24))
-        const unsigned W0a = FT_W4(18, 34, 48, 56), W0b = FT_W4(48, 34, 18, 0);
-        const unsigned W1a = FT_W4(0, 18, 34, 48), W1b = FT_W4(56, 48, 34, 18);
-        const unsigned W2a = FT_W4(0, 0, 18, 34), W2b = FT_W4(48, 56, 48, 34), W2c = FT_W4(18, 0, 0, 0);
-        const unsigned W3a = FT_W4(0, 0, 0, 18), W3b = FT_W4(34, 48, 56, 48), W3c = FT_W4(34, 18, 0, 0);
-#undef FT_W4
         // six rows per step on lanes 0-59, (row, group) fixed per lane: every LDS offset of a step is an immediate
         const int rr = (lane * 13) >> 7, gq = lane - rr * 10;  // lane / 10 for lane < 64
         const unsigned *rwLane = (const unsigned *)(raw + rr * OD_PP) + gq;
@@ -892,10 +928,8 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
                 if (it == 7 && rr > 0) break;  // rows 42 .. 47: only row 42 exists
                 const unsigned *rw = rwLane + it * (6 * OD_PP / 4);
                 const unsigned d0 = rw[0], d1 = rw[1], d2 = rw[2];
-                unsigned h0 = __builtin_amdgcn_udot4(d1, W0b, __builtin_amdgcn_udot4(d0, W0a, 0u, false), false);
-                unsigned h1 = __builtin_amdgcn_udot4(d1, W1b, __builtin_amdgcn_udot4(d0, W1a, 0u, false), false);
-                unsigned h2 = __builtin_amdgcn_udot4(d2, W2c, __builtin_amdgcn_udot4(d1, W2b, __builtin_amdgcn_udot4(d0, W2a, 0u, false), false), false);
-                unsigned h3 = __builtin_amdgcn_udot4(d2, W3c, __builtin_amdgcn_udot4(d1, W3b, __builtin_amdgcn_udot4(d0, W3a, 0u, false), false), false);
+                unsigned h0, h1, h2, h3;
+                od_hblur4(d0, d1, d2, h0, h1, h2, h3);
                 uint2 pk;
                 pk.x = __builtin_amdgcn_perm(h1, h0, 0x05040100u);  // h0 | h1 << 16 (both < 2^16) in one instruction
                 pk.y = __builtin_amdgcn_perm(h3, h2, 0x05040100u);
@@ -917,12 +951,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     const int hbase = (int)((const uint8_t *)(hb + 18 * OD_HP + ax + 18) - smem);
     auto blurred = [&](int r, int c) -> unsigned {
         const unsigned short *p = (const unsigned short *)(smem + vmad24(r, 2 * OD_HP, (c << 1) + hbase));
-        unsigned v;
-        asm("v_mad_u32_u24 %0, %1, 18, %2" : "=v"(v) : "v"((unsigned)p[0] + p[6 * OD_HP]), "s"(32768u));
-        asm("v_mad_u32_u24 %0, %1, 34, %2" : "=v"(v) : "v"((unsigned)p[OD_HP] + p[5 * OD_HP]), "v"(v));
-        asm("v_mad_u32_u24 %0, %1, 48, %2" : "=v"(v) : "v"((unsigned)p[2 * OD_HP] + p[4 * OD_HP]), "v"(v));
-        asm("v_mad_u32_u24 %0, %1, 56, %2" : "=v"(v) : "v"((unsigned)p[3 * OD_HP]), "v"(v));
-        return v >> 16;
+        return od_vblur7(p[0], p[OD_HP], p[2 * OD_HP], p[3 * OD_HP], p[4 * OD_HP], p[5 * OD_HP], p[6 * OD_HP]);
     };
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f scPair = {sb, ca}, csPair = {ca, sb};
@@ -1036,6 +1065,13 @@ int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cel
     for (int rep = ft_debug_repeat("compact"); rep > 0; rep--)
     hipLaunchKernelGGL(k_compact, grid2, block, (size_t)(maxCells + 1) * sizeof(int), st, g, cellCount, stage, cand,
                        candCount);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_blur_level(hipStream_t st, const uint8_t *img, int pitch, int w, int h, uint8_t *dst, int dstPitch) {
+    dim3 grid(((w + 3) / 4 + 63) / 64, h, 1), block(64, 1, 1);
+    hipLaunchKernelGGL(k_blur_level, grid, block, 0, st, img, pitch, w, h, dst, dstPitch);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -6,6 +6,7 @@
 //   k_fisheye_2nn    BFMatcher knnMatch(k=2)+ratio (src/Frame.cc:1231-1255)
 //   k_hamming_pairs  ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2256-2272)
 #include "ft_internal.h"
+#include "kb8_math.h"
 #include "wave_ops.h"
 
 namespace {
@@ -363,7 +364,7 @@ __device__ void kb8_unproject(const float *cam, float precision, float px, float
             theta = __fsub_rn(theta, fix);
             if (fabsf(fix) < precision) break;
         }
-        scale = __fdiv_rn(tanf(theta), theta_d);
+        scale = __fdiv_rn(ft_tan_f(theta), theta_d);
     }
     r[0] = __fmul_rn(pwx, scale);
     r[1] = __fmul_rn(pwy, scale);
@@ -372,14 +373,14 @@ __device__ void kb8_unproject(const float *cam, float precision, float px, float
 
 __device__ void kb8_project(const float *cam, const float p[3], float uv[2]) {
     const float x2y2 = __fadd_rn(__fmul_rn(p[0], p[0]), __fmul_rn(p[1], p[1]));
-    const float theta = atan2f(sqrtf(x2y2), p[2]);
-    const float psi = atan2f(p[1], p[0]);
+    const float theta = ft_atan2_f(sqrtf(x2y2), p[2]);
+    const float psi = ft_atan2_f(p[1], p[0]);
     const float t2 = __fmul_rn(theta, theta), t3 = __fmul_rn(theta, t2), t5 = __fmul_rn(t3, t2), t7 = __fmul_rn(t5, t2),
                 t9 = __fmul_rn(t7, t2);
     const float r = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(theta, __fmul_rn(cam[4], t3)), __fmul_rn(cam[5], t5)), __fmul_rn(cam[6], t7)),
                               __fmul_rn(cam[7], t9));
-    uv[0] = __fadd_rn(__fmul_rn(__fmul_rn(cam[0], r), cosf(psi)), cam[2]);
-    uv[1] = __fadd_rn(__fmul_rn(__fmul_rn(cam[1], r), sinf(psi)), cam[3]);
+    uv[0] = __fadd_rn(__fmul_rn(__fmul_rn(cam[0], r), ft_cos_f(psi)), cam[2]);
+    uv[1] = __fadd_rn(__fmul_rn(__fmul_rn(cam[1], r), ft_sin_f(psi)), cam[3]);
 }
 
 // right singular vector of the smallest singular value of a 4x4 matrix: one-sided (Hestenes) Jacobi in double

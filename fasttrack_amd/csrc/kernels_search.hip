@@ -15,6 +15,7 @@
 // against the writes of the previous pass (per-keypoint linked lists of writers); point i is final
 // after at most i+1 passes and the iteration stops when a pass changes nothing - the unique fixed
 // point is the sequential result.
+#include "kb8_math.h"
 #include "ft_search.h"
 #include "wave_ops.h"
 
@@ -252,8 +253,8 @@ __device__ __forceinline__ void project_cam(const FtDevFrame &F, const float p[3
         uv[1] = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[1], p[1]), p[2]), F.cam[3]);
     } else {
         const float x2y2 = __fadd_rn(__fmul_rn(p[0], p[0]), __fmul_rn(p[1], p[1]));
-        const float theta = atan2f(sqrtf(x2y2), p[2]);
-        const float psi = atan2f(p[1], p[0]);
+        const float theta = ft_atan2_f(sqrtf(x2y2), p[2]);
+        const float psi = ft_atan2_f(p[1], p[0]);
         const float t2 = __fmul_rn(theta, theta);
         const float t3 = __fmul_rn(theta, t2);
         const float t5 = __fmul_rn(t3, t2);
@@ -262,8 +263,8 @@ __device__ __forceinline__ void project_cam(const FtDevFrame &F, const float p[3
         const float r = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(theta, __fmul_rn(F.cam[4], t3)), __fmul_rn(F.cam[5], t5)),
                                             __fmul_rn(F.cam[6], t7)),
                                   __fmul_rn(F.cam[7], t9));
-        uv[0] = __fadd_rn(__fmul_rn(__fmul_rn(F.cam[0], r), cosf(psi)), F.cam[2]);
-        uv[1] = __fadd_rn(__fmul_rn(__fmul_rn(F.cam[1], r), sinf(psi)), F.cam[3]);
+        uv[0] = __fadd_rn(__fmul_rn(__fmul_rn(F.cam[0], r), ft_cos_f(psi)), F.cam[2]);
+        uv[1] = __fadd_rn(__fmul_rn(__fmul_rn(F.cam[1], r), ft_sin_f(psi)), F.cam[3]);
     }
 }
 

@@ -222,6 +222,13 @@ class ORBextractor:
         check(lib().ft_extractor_download_level(self._h, slot, level, ptr(out), w))
         return out
 
+    def blurred_level(self, level, slot=0) -> np.ndarray:
+        """the level after GaussianBlur(7x7, 2, 2, BORDER_REFLECT_101), through the descriptor kernel's blur routines"""
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        check(lib().ft_extractor_download_blurred_level(self._h, slot, level, ptr(out), w))
+        return out
+
     def candidates(self, level, slot=0) -> np.ndarray:
         n = C.c_int()
         check(lib().ft_extractor_download_candidates(self._h, slot, level, None, 0, C.byref(n)))

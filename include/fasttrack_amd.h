@@ -120,6 +120,10 @@ FT_API int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int 
 
 /* mvImagePyramid[level] of slot `slot` copied to host (tight or strided rows) */
 FT_API int ft_extractor_download_level(ft_extractor *ex, int slot, int level, uint8_t *dst, int dst_stride);
+/* stage tap for parity tests: level `level` of slot `slot` after cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101)
+ * (ORBextractor.cc:1456-1457), computed by the blur routines the descriptor kernel applies on the fly (the path itself
+ * never materialises a blurred level) */
+FT_API int ft_extractor_download_blurred_level(ft_extractor *ex, int slot, int level, uint8_t *dst, int dst_stride);
 /* GetGPUPyramid(): device pointer + pitch of one level of one slot */
 FT_API int ft_extractor_device_level(ft_extractor *ex, int slot, int level, const uint8_t **dptr, int *pitch);
 /* stage taps for parity tests: FAST candidates handed to the octree, in the CPU's emission order,

@@ -192,6 +192,11 @@ def gaussian_blur7(src: np.ndarray) -> np.ndarray:
     return dst
 
 
+def fast_atan2(y: float, x: float) -> float:
+    """cv::fastAtan2 (degrees)"""
+    return float(lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
 def gaussian_kernel7():
     a = np.zeros(7, np.int32)
     lib().orc_gaussian_kernel7_fixed(_p(a))

@@ -58,6 +58,38 @@ def test_extract_bit_exact(ctx, w, h, nf):
         ok, od, om = oex.extract(img)
         _check_same(gk, gd, ok, od)
         assert gm == om
+
+
+@pytest.mark.parametrize("w,h,nf,lap", [
+    (752, 480, 1000, (0, 1000)),   # BASELINE configs[0]: EuRoC monocular call shape, Frame::ExtractORB(0, im, 0, 1000) (src/Frame.cc:335)
+    (752, 480, 5000, (0, 1000)),   # mpIniORBextractor = 5 * nFeatures (src/Tracking.cc:632)
+    (1280, 720, 10000, (0, 0)),    # 5 * 2000 at the bench size
+])
+def test_extract_monocular_call_shape_and_ini_extractor(ctx, w, h, nf, lap):
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
+    oex = ob.Extractor(nf)
+    for seed, dens in ((3, 1.0), (4, 3.0)):
+        img = synth.make_image(w, h, seed=seed, density=dens)
+        gk, gd, gm = ex(img, lapping_area=lap)
+        ok, od, om = oex.extract(img, lap=lap)
+        _check_same(gk, gd, ok, od)
+        assert gm == om
+        if lap == (0, 1000):
+            assert gm == 0 and len(gk) > 0.6 * min(nf, 3000)  # every keypoint has x in [0, 1000]: all filled from the back
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (752, 480), (161, 123)])
+def test_gaussian_blur_of_whole_levels_bit_exact(ctx, w, h):
+    """a7 directly: every pyramid level blurred by the descriptor kernel's own blur routines (od_hblur4 / od_vblur7,
+    BORDER_REFLECT_101) equals the oracle's cv::GaussianBlur(7x7, sigma 2) restatement, pixel for pixel"""
+    ex = orb.ORBextractor(ctx, 500, 1.2, 8, 20, 7, w, h)
+    oex = ob.Extractor(500)
+    for img in (synth.make_image(w, h, seed=21), synth.make_noise(w, h, seed=22)):
+        ex(img)
+        oex.extract(img)
+        for level in range(8):
+            src = ex.image_pyramid_level(level)
+            assert np.array_equal(ex.blurred_level(level), ob.gaussian_blur7(src)), f"blur of level {level}"
         assert len(gk) >= nf * 0.9
 
 

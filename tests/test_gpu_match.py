@@ -295,8 +295,9 @@ def test_is_in_frustum_pinhole_bit_exact(ctx):
 
 def test_is_in_frustum_two_cameras_kb8(ctx):
     """fisheye stereo (Nleft != -1): both cameras through isInFrustumChecks, right camera pose composed from Trl / Tlr.
-    KannalaBrandt8 uses atan2f/cosf/sinf (libm on the host, OCML on the device): flags and levels must agree away
-    from decision boundaries, floats within 1e-3 px / 1e-6."""
+    KannalaBrandt8 uses atan2f/cosf/sinf (libm on the host; evaluated in double and narrowed on the device,
+    kb8_math.h): flags and levels must agree away from decision boundaries, projections within 1e-4 px
+    (north_star's tolerance for floats)."""
     w, h = 512, 512
     fr = sc.fisheye_frame_scenario(w, h, 1500, 10)
     sf, _ = ob.scale_factors(1.2, 8)
@@ -317,7 +318,7 @@ def test_is_in_frustum_two_cameras_kb8(ctx):
     for k in ("level", "level_r"):
         assert np.array_equal(g[k][same], o[k][same]), k
     for k in ("proj_x", "proj_y", "proj_xr", "proj_yr"):
-        assert np.allclose(g[k][same], o[k][same], rtol=0, atol=1e-3), k
+        assert np.allclose(g[k][same], o[k][same], rtol=0, atol=1e-4), k
     for k in ("view_cos", "view_cos_r", "depth", "depth_r"):
         assert np.array_equal(g[k][same], o[k][same]), k  # no transcendental on these paths
 
@@ -405,7 +406,7 @@ def test_fisheye_stereo_with_triangulation(ctx):
     g = orb.fisheye_stereo(ctx, sc.KB8_CAM, sc.KB8_CAM, S["Rlr"], S["tlr"], dL, kL, dR, kR, ls2)
     assert o["n"] > 1000
     same = g["matches"] == o["matches"]
-    assert same.mean() > 0.998 and abs(g["n"] - o["n"]) <= (~same).sum()
+    assert same.mean() > 0.999 and abs(g["n"] - o["n"]) <= (~same).sum()
     both = same & (o["matches"] >= 0)
     assert np.allclose(g["depth"][both], o["depth"][both], rtol=1e-4, atol=0)
     assert np.allclose(g["p3d"][both], o["p3d"][both], rtol=1e-4, atol=1e-5)
