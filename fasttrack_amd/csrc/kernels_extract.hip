@@ -4,6 +4,8 @@
 //   k_fast_cells   per-cell cv::FAST-9/16 + NMS + threshold fallback (ORBextractor.cc:1136-1199, A.3)
 //   k_compact      cell-row-major ordered candidate list          (ORBextractor.cc:1186-1198)
 //   k_orient_desc  IC_Angle + 7x7 fixed-point blur + rBRIEF       (ORBextractor.cc:39-108,1456-1462, A.2/A.4/A.6/A.7)
+#include <vector>
+
 #include "ft_internal.h"
 #include "sincos_poly.h"
 #include "wave_ops.h"
@@ -233,6 +235,150 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
             pk |= (unsigned)(((vmul24((int)yt[j].a0, h0 >> 4) >> 16) + (vmul24((int)yt[j].a1, h1 >> 4) >> 16) + 2) >> 2) << (8 * k);
         }
         gstore<unsigned>(outLevel + (unsigned)vmad24(dy, D.pitch, bx), pk);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pyramid, row-streaming form (the default): one WAVE per strip of 128 output columns x PR_RB output rows.
+// A lane owns two adjacent output columns for the whole strip: their taps (source column, weights) live in registers,
+// the eight source bytes that hold both columns' two taps are ONE aligned 8-byte load per source row, and the
+// horizontal interpolation of a column is one v_perm (two bytes -> a pair of u16) + one v_dot2_u32_u16.  The wave
+// walks the source rows of its strip once, top to bottom: cv::resize needs rows sy and sy + 1 for an output row and
+// sy advances by one or two, so the horizontally interpolated row is kept in registers and serves as the lower row of
+// one output row and the upper row of the next (1.2 instead of 2 interpolations per output row at scale 1.2).  No LDS,
+// no workgroup barrier; row taps are wave-uniform (one lane holds the taps of one output row, v_readlane hands them
+// out); the next source row is requested before the current one is used.  Per output pixel ~9 VALU instructions
+// instead of ~32 in the tile kernel above, whose arithmetic it repeats bit for bit.
+// ------------------------------------------------------------------------------------------------
+#define PR_COLS 128
+#define PR_RB 32
+typedef unsigned short ft_us2 __attribute__((ext_vector_type(2)));
+typedef unsigned ft_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned udot2_u16(unsigned a, unsigned b) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ft_us2, a), __builtin_bit_cast(ft_us2, b), 0u, false);
+}
+// b (wave-uniform, < 2^24) * a (< 2^24) [+ c]: full-rate 24-bit multiplies with the uniform factor as scalar operand
+__device__ __forceinline__ unsigned umul24_su(unsigned bUniform, unsigned a) {
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(bUniform), "v"(a));
+    return r;
+}
+__device__ __forceinline__ unsigned umad24_su(unsigned bUniform, unsigned a, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(bUniform), "v"(a), "v"(c));
+    return r;
+}
+template <bool AREA>
+__global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint8_t *const *l0, int l0pitch, uint8_t *pyr,
+                                                 const FtTap *taps, FtSlotGrid sg, int stripsX, unsigned sxMagic,
+                                                 int readableEnd) {
+    const int lane = threadIdx.x;
+    int slot, tile;
+    if (!ft_slot_block(sg, slot, tile)) return;
+    const int ty = div_by(tile, sxMagic), tx = tile - ty * stripsX;
+    const FtLevelGeom &D = g.lv[level];
+    int spitch;
+    const uint8_t *S = level_ptr(g, level - 1, slot, l0, l0pitch, pyr, spitch);
+    const int sw = g.lv[level - 1].w, sh = g.lv[level - 1].h;
+    const int dx = tx * PR_COLS + 2 * lane;  // first of this lane's two output columns
+    const int j0 = ty * PR_RB, nrows = min(PR_RB, D.h - j0);
+    // row taps: lane r holds (sy | b0 << 16, b1) of output row j0 + r
+    unsigned rowW0 = 0, rowW1 = 0;
+    if constexpr (!AREA) {
+        const ft_u2 t = gload<ft_u2>(taps + D.ytab + j0 + min(lane, nrows - 1));
+        rowW0 = t.x;
+        rowW1 = t.y;
+    }
+    // column taps; columns beyond the level repeat its last column (their stores are masked)
+    const int dxa = min(dx, D.w - 1), dxb = min(dx + 1, D.w - 1);
+    int sxa, sxb, cxa, cxb;
+    unsigned wa, wb;
+    if constexpr (AREA) {
+        sxa = 2 * dxa; sxb = 2 * dxb; cxa = sxa + 1; cxb = sxb + 1;
+        wa = wb = 0x00010001u;  // s0 + s1
+    } else {
+        const ft_u2 ta = gload<ft_u2>(taps + D.xtab + dxa), tb = gload<ft_u2>(taps + D.xtab + dxb);
+        sxa = (int)(short)(ta.x & 0xffffu); sxb = (int)(short)(tb.x & 0xffffu);
+        cxa = min(sxa + 1, sw - 1); cxb = min(sxb + 1, sw - 1);
+        wa = (ta.x >> 16) | (ta.y << 16);  // a0 | a1 << 16
+        wb = (tb.x >> 16) | (tb.y << 16);
+    }
+    // the 8-byte window [base, base + 8) of a source row that holds all four taps of the lane (the launcher has checked
+    // that it does); it never reaches past the readable end of a row
+    const int base = min(sxa & ~3, readableEnd - 8);
+    const unsigned selA = (unsigned)(sxa - base) | 0x0c00u | ((unsigned)(cxa - base) << 16) | 0x0c000000u;
+    const unsigned selB = (unsigned)(sxb - base) | 0x0c00u | ((unsigned)(cxb - base) << 16) | 0x0c000000u;
+    auto rowTap = [&](int r, int &sy0, int &sy1, unsigned &b0, unsigned &b1) {
+        if constexpr (AREA) {
+            sy0 = 2 * (j0 + r); sy1 = sy0 + 1; b0 = b1 = 0;
+        } else {
+            const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)rowW0, r), w1 = (unsigned)__builtin_amdgcn_readlane((int)rowW1, r);
+            const int sy = (int)(short)(w0 & 0xffffu);
+            sy0 = min(max(sy, 0), sh - 1); sy1 = min(max(sy + 1, 0), sh - 1);
+            b0 = w0 >> 16; b1 = w1 & 0xffffu;
+        }
+    };
+    int jr = 0, sy0, sy1;
+    unsigned b0, b1;
+    rowTap(0, sy0, sy1, b0, b1);
+    int lastSy0, rLast;
+    unsigned bx0, bx1;
+    rowTap(nrows - 1, lastSy0, rLast, bx0, bx1);
+    int r = sy0;
+    // wave-uniform row pointers + 32-bit lane offsets: scalar-base loads and stores, no 64-bit lane arithmetic
+    const uint8_t *srcRow = S + (size_t)r * spitch;
+    uint8_t *dstRow = pyr + (size_t)slot * g.pyrPerSlot + D.off + (size_t)j0 * D.pitch;
+    const unsigned laneSrc = (unsigned)base, laneDst = (unsigned)dx;
+    const bool store2 = dx + 1 < D.w, store1 = dx < D.w;
+    const unsigned round2 = 0x20000u;
+    // PR_PF source rows are in flight ahead of the one being used (a ring of registers, the loop unrolled over it): a
+    // wave's life is a chain of dependent row loads, and a store counts on the same counter as a load, so with one row
+    // in flight every wait would also wait for the stores just issued
+    const uint8_t *pfRow = srcRow;  // row min(r + k, rLast) for the next prefetch
+    int pfIdx = r;
+    auto prefetch = [&]() -> ft_u2 {
+        unsigned offS = laneSrc;
+        // (the empty asm keeps the zero-extension of the lane offset inside this block, where instruction selection
+        // can fold it into the scalar-base addressing mode)
+        asm volatile("" : "+v"(offS));
+        const ft_u2 v = gload<ft_u2>(pfRow + offS);
+        if (pfIdx < rLast) { pfRow += spitch; pfIdx++; }  // wave-uniform
+        return v;
+    };
+    ft_u2 q0 = prefetch(), q1 = prefetch(), q2 = prefetch(), q3 = prefetch();
+    unsigned hpA = 0, hpB = 0, hcA = 0, hcB = 0;
+    auto step = [&](const ft_u2 cur) {
+        hpA = hcA; hpB = hcB;
+        hcA = udot2_u16(__builtin_amdgcn_perm(cur.y, cur.x, selA), wa);
+        hcB = udot2_u16(__builtin_amdgcn_perm(cur.y, cur.x, selB), wb);
+        if constexpr (!AREA) { hcA >>= 4; hcB >>= 4; }
+        while (jr < nrows && sy1 == r) {  // wave-uniform
+            // both taps on one source row happens only where cv::resize clamps the rows (top and bottom edge): monotonic,
+            // so the upper-row registers may simply be overwritten
+            if (sy0 == r) { hpA = hcA; hpB = hcB; }
+            unsigned oA, oB;
+            if constexpr (AREA) {
+                oA = (hpA + hcA + 2u) >> 2; oB = (hpB + hcB + 2u) >> 2;
+            } else {
+                // ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2; the + 2 rides in the first product
+                oA = ((umad24_su(b0, hpA, round2) >> 16) + (umul24_su(b1, hcA) >> 16)) >> 2;
+                oB = ((umad24_su(b0, hpB, round2) >> 16) + (umul24_su(b1, hcB) >> 16)) >> 2;
+            }
+            unsigned offD = laneDst;
+            asm volatile("" : "+v"(offD));
+            if (store2) gstore<unsigned short>(dstRow + offD, (unsigned short)(oA | (oB << 8)));
+            else if (store1) gstore<uint8_t>(dstRow + offD, (uint8_t)oA);
+            dstRow += D.pitch;
+            jr++;
+            if (jr < nrows) rowTap(jr, sy0, sy1, b0, b1);
+        }
+        r++;
+    };
+    while (r <= rLast) {
+        { const ft_u2 c = q0; q0 = prefetch(); step(c); if (r > rLast) break; }
+        { const ft_u2 c = q1; q1 = prefetch(); step(c); if (r > rLast) break; }
+        { const ft_u2 c = q2; q2 = prefetch(); step(c); if (r > rLast) break; }
+        { const ft_u2 c = q3; q3 = prefetch(); step(c); }
     }
 }
 
@@ -1011,11 +1157,36 @@ size_t ft_fast_smem_bytes(const FtGeom &g) {
     return mx;
 }
 
+// the row-streaming kernel needs every lane's four taps inside one aligned 8-byte window of a source row
+static bool pyr_rows_fits(const FtGeom &g, int level, const std::vector<FtTap> *hostTaps) {
+    (void)hostTaps;
+    const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
+    // the window starts at sx(dx) & ~3 (<= 3 bytes before the first tap), sx(dx + 1) <= sx(dx) + ceil(scale), and the
+    // second tap of column dx + 1 is one further: 3 + ceil(scale) + 1 <= 7 holds for every scale <= 3
+    return (double)P.w / (double)D.w < 2.5 && P.w >= 8;
+}
+
 int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                       uint8_t *pyr, const FtTap *taps, int alignedLoads) {
+    static const bool rowsOn = !(getenv("FT_PYR_ROWS") && atoi(getenv("FT_PYR_ROWS")) == 0);
     for (int rep = ft_debug_repeat("pyr"); rep > 0; rep--)
     for (int level = 1; level < g.nlevels; level++) {
         const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
+        if (rowsOn && alignedLoads && pyr_rows_fits(g, level, nullptr)) {
+            const int stripsX = (D.w + PR_COLS - 1) / PR_COLS, stripsY = (D.h + PR_RB - 1) / PR_RB;
+            dim3 grid, block(64, 1, 1);
+            const FtSlotGrid sg = ft_slot_grid(stripsX * stripsY, batch, grid);
+            // bytes of a source row that may be read: the whole pitch of a slot level, the width rounded up to a dword
+            // (inside the 4-byte aligned stride) of a caller's frame
+            const int readableEnd = level == 1 ? std::min((P.w + 3) & ~3, l0pitch) : P.pitch;
+            if (D.area2x)
+                hipLaunchKernelGGL(k_pyr_rows<true>, grid, block, 0, st, g, level, l0, l0pitch, pyr, taps, sg, stripsX,
+                                   div_magic_of((unsigned)stripsX), readableEnd);
+            else
+                hipLaunchKernelGGL(k_pyr_rows<false>, grid, block, 0, st, g, level, l0, l0pitch, pyr, taps, sg, stripsX,
+                                   div_magic_of((unsigned)stripsX), readableEnd);
+            continue;
+        }
         // LDS footprint of a 64 x 8 output tile: ceil(tile * scale) + the second tap + the margin of the
         // arithmetic footprint bound + alignment slack
         const int cols = (int)((long long)PD_TW * P.w / D.w) + 8, rowsN = (int)((long long)PD_TH * P.h / D.h) + 8;
