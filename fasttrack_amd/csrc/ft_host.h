@@ -122,6 +122,9 @@ struct ft_extractor {
     FtTap *d_taps = nullptr;
     uint32_t *d_cellTab = nullptr;  // per FAST cell: level | cell row << 8 | cell column << 20
     int *d_cellCount = nullptr;
+    uint32_t *d_stripTab = nullptr;  // per FAST strip: level | strip row << 8 | strip column << 20
+    int *d_cellCount2 = nullptr;     // [maxBatch][totalCells][2]: strong / weak survivors per cell (strips form), zero between launches
+    bool fastStrips = false;
     uint32_t *d_stage = nullptr;
     const uint8_t **d_l0 = nullptr;
     const uint8_t **h_l0 = nullptr;  // pinned

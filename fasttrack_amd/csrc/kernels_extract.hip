@@ -824,6 +824,289 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// FAST-9/16 over strips (device octree; the default).  cv::FAST is called per ~35-px cell by the reference, but the
+// cells' tested regions tile the rectangle [19, w-19) x [19, h-19) of a level exactly, a pixel's score does not depend
+// on its cell, and the cell only enters (a) non-maximum suppression - a neighbour in another cell counts as 0 - and
+// (b) the threshold fallback - a cell emits its survivors with score >= iniThFAST if it has any, else all of them
+// (ORBextractor.cc:1157-1177).  So one WAVE takes a strip of up to 62 x sH pixels of that rectangle that
+// ignores the cell grid, plus a one-pixel halo whose scores its NMS needs: lane = column (64 columns: every row fills the
+// wave, where a 36-px cell filled 56 %), rows top to bottom.
+//   A  rejection on the compass pairs, six rows per trip as three PAIRS of rows (y, y + 3) packed in the halves of a
+//      register (v_sad_u8 / v_sad_hi_u8 produce the halves, v_pk_max_u16 / v_pk_min_u16 combine them): the vertical
+//      difference |p(y) - p(y+3)| is the south difference of row y and the north difference of row y + 3, so the north
+//      pair is an alignbit of the previous and the current south pair; ~5 VALU instructions per row of 64 pixels;
+//   B  cornerScore of the buffered candidates in FULL rounds of 64 (the remainder stays in the ring until the end);
+//   C  NMS of the corners against the score plane with the cell borders applied as masks, then every survivor is filed
+//      under its cell: an atomic counter pair per cell hands out staging slots - strong survivors (score >= iniThFAST)
+//      from the front, the others from the back - and k_compact_strips applies (b).
+// The order inside a cell's staging is arbitrary: k_octree ranks candidates by their coordinates.
+// ------------------------------------------------------------------------------------------------
+#define FS_TP 80                 // LDS pitch of the tile: 62 + 2 halo + 6 ring + 3 alignment, in dwords
+#define FS_ROWS 6                // rows per trip of phase A (three pairs)
+#define FS_CAND 640              // candidate ring (u16 codes): a trip adds up to 384, full rounds leave < 64
+#define FS_CORN 256              // corner list; a strip with more corners scans its score plane
+typedef unsigned short fs_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(fs_us2, a), __builtin_bit_cast(fs_us2, b)));
+}
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(fs_us2, a), __builtin_bit_cast(fs_us2, b)));
+}
+__host__ __device__ __forceinline__ int fs_tile_rows(int sH) { return ((sH + 2 + FS_ROWS - 1) / FS_ROWS) * FS_ROWS + 6; }
+__host__ __device__ __forceinline__ int fs_tile_bytes(int sH) { return (fs_tile_rows(sH) * FS_TP + 15) & ~15; }
+__host__ __device__ __forceinline__ int fs_score_bytes(int sH) { return ((sH + 2) * 64 + 64 + 15) & ~15; }  // + a row of slack for the reads of the last rows' neighbours
+__host__ __device__ __forceinline__ int fs_list_bytes() { return 2 * (FS_CAND + FS_CORN) + 16; }
+
+__global__ __launch_bounds__(64) void k_fast_strips(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr, int iniTh,
+                                                    int minTh, int *cellCount2, uint32_t *stage, const uint32_t *stripTab,
+                                                    FtSlotGrid sg, int maxSH) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x;
+    int slot, strip;
+    if (!ft_slot_block(sg, slot, strip)) return;
+    if (strip >= g.totalStrips) return;
+    const uint8_t *img0 = l0[slot];
+    const uint32_t stt = stripTab[strip];
+    const int level = (int)(stt & 0xffu), sy = (int)((stt >> 8) & 0xfffu), sx = (int)(stt >> 20);
+    const FtLevelGeom &L = g.lv[level];
+    const int E = FT_EDGE_THRESHOLD;
+    // interior [X0, X1) x [Y0, Y1) of the strip; scored region = interior + 1 (clipped to the tested rectangle by `act`
+    // and the row bounds below); lane <-> column X0 - 1 + lane, scored row yy <-> row Y0 - 1 + yy
+    const int X0 = E + sx * L.sW, X1 = min(X0 + L.sW, L.w - E);
+    const int Y0 = E + sy * L.sH, Y1 = min(Y0 + L.sH, L.h - E);
+    const int CH = Y1 - Y0 + 2;                                  // scored rows
+    const int yyMin = Y0 - 1 < E ? 1 : 0, yyMax = Y1 + 1 > L.h - E ? CH - 1 : CH;  // rows of the tested rectangle
+    const int xl = X0 - 1 + lane;
+    const bool act = xl >= E && xl < L.w - E && xl <= X1;
+    const unsigned long long actMask = __builtin_amdgcn_ballot_w64(act);
+    uint8_t *tile = smem;
+    uint8_t *score = tile + fs_tile_bytes(maxSH);
+    unsigned short *cand = (unsigned short *)(score + fs_score_bytes(maxSH));
+    unsigned short *corn = cand + FS_CAND;
+    const int pitch = level ? L.pitch : l0pitch;
+    const uint8_t *img = level ? pyr + (size_t)slot * g.pyrPerSlot + L.off : img0;
+    // ---- stage the tile: columns [X0 - 4, X1 + 4), rows [Y0 - 4, Y1 + 4): aligned dword rows, fixed (row, dword) per lane,
+    // rows and dwords beyond the tile clamped onto its last row / dword (duplicates instead of masks); three rows per trip
+    const int tx0 = X0 - 4, ax = tx0 & 3;
+    {
+        const int tw = X1 + 4 - tx0, th = Y1 + 4 - (Y0 - 4);
+        const int nd = (tw + ax + 3) >> 2;  // <= 20
+        const uint8_t *src = img + (size_t)(Y0 - 4) * pitch + (tx0 - ax);
+        constexpr int DW = FS_TP / 4, RPT = 3;  // 20 dwords per row, 3 rows per trip (lanes 60 .. 63 duplicate)
+        const int rr = min(lane / DW, RPT - 1), cc4 = 4 * min(lane - (lane / DW) * DW, nd - 1);
+        for (int r0 = 0; r0 < th; r0 += 8 * RPT) {
+            unsigned v[8];
+            int row[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                row[k] = min(r0 + k * RPT + rr, th - 1);
+                v[k] = gload<unsigned>(src + (unsigned)vmad24(row[k], pitch, cc4));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) *(unsigned *)(tile + vmad24(row[k], FS_TP, cc4)) = v[k];
+        }
+    }
+    for (int i = lane; i < fs_score_bytes(maxSH) >> 4; i += 64) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
+    wave_lds_sync();
+    // pixel (column of lane, scored row yy) at col[(yy + 3) * FS_TP]
+    const uint8_t *t0 = tile + ax + 3;  // (column X0 - 1, tile row 0)
+    const uint8_t *col = t0 + lane;
+    int nc = 0, ncorn = 0;
+    // phase B over the buffered candidates: full rounds of 64 (all of them when `final`), the rest moves to the front
+    auto flushB = [&](bool final) {
+        wave_lds_sync();
+        const int rounds = final ? (nc + 63) >> 6 : nc >> 6;
+        for (int jb = 0; jb < rounds * 64; jb += 64) {
+            const int j = jb + lane;
+            bool isCorner = false;
+            int code = 0;
+            if (j < nc) {
+                code = cand[j];
+                // top-left corner of the pixel's 7 x 7 ring window: every ring offset is a non-negative immediate
+                const uint8_t *win = t0 - 3 + vmad24(code >> 6, FS_TP, code & 63);
+                const int v = win[3 * FS_TP + 3];
+                int ringPx[16];
+#define FT_LD(k, ox, oy) ringPx[k] = (int)win[((oy) + 3) * FS_TP + (ox) + 3];
+                FT_RING(FT_LD)
+#undef FT_LD
+                const int sc = fast_score(v, ringPx);
+                if (sc >= minTh) {
+                    score[code] = (uint8_t)sc;
+                    isCorner = true;
+                }
+            }
+            const unsigned long long cb = __ballot(isCorner);
+            if (isCorner) {
+                const int pos = ncorn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cb, 0u));
+                if (pos < FS_CORN) corn[pos] = (unsigned short)code;
+            }
+            ncorn += __popcll(cb);
+        }
+        const int rem = nc - rounds * 64;
+        if (rem > 0) {  // wave-uniform; rem < 64
+            const unsigned short keep = cand[rounds * 64 + min(lane, rem - 1)];
+            wave_lds_sync();
+            if (lane < rem) cand[lane] = keep;
+        }
+        nc = max(rem, 0);
+        wave_lds_sync();
+    };
+    // ---- phase A
+    {
+        const unsigned th = (unsigned)minTh;
+        unsigned pA = col[3 * FS_TP], pB = col[4 * FS_TP], pC = col[5 * FS_TP];  // scored rows 0, 1, 2
+        // "previous south pairs": their high halves are the north differences |p(yy) - p(yy - 3)| of rows 0 .. 2
+        unsigned prev[3];
+        prev[0] = __builtin_amdgcn_sad_hi_u8(pA, (unsigned)col[0], 0u);
+        prev[1] = __builtin_amdgcn_sad_hi_u8(pB, (unsigned)col[FS_TP], 0u);
+        prev[2] = __builtin_amdgcn_sad_hi_u8(pC, (unsigned)col[2 * FS_TP], 0u);
+        for (int yy = 0; yy < CH; yy += FS_ROWS) {
+            const uint8_t *r = col + yy * FS_TP;
+            unsigned pv[9], M[3];
+            pv[0] = pA; pv[1] = pB; pv[2] = pC;
+#pragma unroll
+            for (int k = 0; k < 6; k++) pv[k + 3] = r[(k + 6) * FS_TP];  // scored rows yy + 3 .. yy + 8
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                // rows yy + k (low half) and yy + k + 3 (high half)
+                const unsigned ps = __builtin_amdgcn_sad_hi_u8(pv[k + 3], pv[k + 6], __builtin_amdgcn_sad_u8(pv[k], pv[k + 3], 0u));
+                const unsigned pn = __builtin_amdgcn_alignbit(ps, prev[k], 16);
+                const unsigned pe = __builtin_amdgcn_sad_hi_u8(pv[k + 3], (unsigned)r[(k + 6) * FS_TP + 3],
+                                                               __builtin_amdgcn_sad_u8(pv[k], (unsigned)r[(k + 3) * FS_TP + 3], 0u));
+                const unsigned pw = __builtin_amdgcn_sad_hi_u8(pv[k + 3], (unsigned)r[(k + 6) * FS_TP - 3],
+                                                               __builtin_amdgcn_sad_u8(pv[k], (unsigned)r[(k + 3) * FS_TP - 3], 0u));
+                M[k] = pk_min_u16(pk_max_u16(pn, ps), pk_max_u16(pe, pw));
+                prev[k] = ps;
+            }
+            pA = pv[6]; pB = pv[7]; pC = pv[8];
+            // candidates of a row = lanes whose pixel passes, in the tested rectangle, appended in lane order.  All six
+            // row masks are formed first (one v_cmp each; lane and row validity are scalar masks), so a trip without
+            // candidates costs nothing more, and rows without any are skipped on the scalar side
+            unsigned mrow[6];
+            unsigned long long bal[6], any = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                mrow[k] = k < 3 ? (M[k] & 0xffffu) : (M[k - 3] >> 16);
+                const unsigned long long rowMask = 0ull - (unsigned long long)((unsigned)(yy + k - yyMin) < (unsigned)(yyMax - yyMin));
+                bal[k] = __builtin_amdgcn_ballot_w64(mrow[k] > th) & actMask & rowMask;
+                any |= bal[k];
+            }
+            if (any) {  // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    if (bal[k]) {  // wave-uniform; implies a valid row
+                        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[k], (unsigned)nc));
+                        if (mrow[k] > th && act) cand[pos] = (unsigned short)(((yy + k) << 6) | lane);
+                        nc += __popcll(bal[k]);
+                    }
+                }
+            }
+            if (nc > FS_CAND - FS_ROWS * 64) flushB(false);  // wave-uniform
+        }
+        flushB(true);
+    }
+    // ---- phase C: NMS (strictly greater than the 8 neighbours; a neighbour in another cell counts as 0) and filing of the
+    // survivors of the strip's interior under their cells
+    const unsigned wMagic = div_magic_small((unsigned)L.wCell), hMagic = div_magic_small((unsigned)L.hCell);
+    const bool useList = ncorn <= FS_CORN;
+    const int nItems = useList ? ncorn : CH * 64;
+    int *cnt2 = cellCount2 + (size_t)slot * g.totalCells * 2;
+    uint32_t *stg = stage + (size_t)slot * g.stagePerSlot + L.stageBase;
+    for (int base = 0; base < nItems; base += 64) {
+        const int it = base + lane;
+        if (it >= nItems) continue;
+        const int code = useList ? (int)corn[it] : it;
+        const int yy = code >> 6, xx = code & 63;
+        const uint8_t *sp = score + code;
+        const int v = sp[0];
+        // interior only: the halo belongs to the neighbouring strips
+        if (v == 0 || xx < 1 || xx > X1 - X0 || yy < 1 || yy > Y1 - Y0) continue;
+        const int ux = X0 - 1 + xx - E, uy = Y0 - 1 + yy - E;  // coordinates in the tested rectangle
+        const int cj = div_by(ux, wMagic), ci = div_by(uy, hMagic);
+        const int rx = ux - cj * L.wCell, ry = uy - ci * L.hCell;
+        const bool vl = rx > 0, vr = rx < L.wCell - 1, vu = ry > 0, vd = ry < L.hCell - 1;
+        const int nl = vl ? (int)sp[-1] : 0, nr = vr ? (int)sp[1] : 0;
+        const int nu = vu ? (int)sp[-64] : 0, nd = vd ? (int)sp[64] : 0;
+        const int nul = (vu && vl) ? (int)sp[-65] : 0, nur = (vu && vr) ? (int)sp[-63] : 0;
+        const int ndl = (vd && vl) ? (int)sp[63] : 0, ndr = (vd && vr) ? (int)sp[65] : 0;
+        const bool keep = v > nl && v > nr && v > nu && v > nd && v > nul && v > nur && v > ndl && v > ndr;
+        if (!keep) continue;
+        const int cell = ci * L.nCols + cj;
+        const int weak = v >= iniTh ? 0 : 1;
+        const int k = atomicAdd(cnt2 + 2 * (L.cellBase + cell) + weak, 1);
+        const int pos = weak ? L.cellCap - 1 - k : k;
+        // keypoint relative to (minBorderX, minBorderY) = (16, 16): ORBextractor.cc:1196-1197
+        if (pos >= 0 && pos < L.cellCap) stg[(size_t)cell * L.cellCap + pos] = ft_pack_cand(ux + 3, uy + 3, v);
+    }
+}
+
+// Compaction of the strips form: per cell the strong survivors if there are any, else the weak ones (the cell's
+// iniThFAST / minThFAST fallback); the counters are zeroed for the next launch.
+__global__ __launch_bounds__(256) void k_compact_strips(FtGeom g, int *cellCount2, const uint32_t *stage, uint32_t *cand,
+                                                        int *candCount) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int *offs = (int *)smem;  // nCells + 1
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int level = blockIdx.x, slot = blockIdx.y;
+    const FtLevelGeom &L = g.lv[level];
+    const int nCells = L.nCols * L.nRows;
+    int *cnt = cellCount2 + ((size_t)slot * g.totalCells + L.cellBase) * 2;
+    const int per = (nCells + 255) / 256;
+    const int c0 = tid * per, c1 = min(c0 + per, nCells);
+    auto count = [&](int c) -> int {
+        const int hi = min(cnt[2 * c], L.cellCap), lo = min(cnt[2 * c + 1], L.cellCap);
+        return hi > 0 ? hi : lo;
+    };
+    int local = 0;
+    for (int c = c0; c < c1; c++) local += count(c);
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) wbase += wsum[w];
+        total += wsum[w];
+    }
+    int run = wbase + incl - local;
+    for (int c = c0; c < c1; c++) {
+        // the sign of the offset records which end of the cell's staging holds the list: strong from the front (+),
+        // weak from the back (stored as ~offset)
+        const int hi = cnt[2 * c];
+        offs[c] = hi > 0 ? run : ~run;
+        run += count(c);
+    }
+    if (tid == 0) offs[nCells] = total;
+    __syncthreads();
+    total = min(total, L.candCap);
+    const uint32_t *st = stage + (size_t)slot * g.stagePerSlot + L.stageBase;
+    uint32_t *dst = cand + (size_t)slot * g.candPerSlot + L.candBase;
+    auto offAt = [&](int c) -> int { const int o = offs[c]; return o < 0 ? ~o : o; };
+    for (int o = tid; o < total; o += 256) {
+        int lo = 0, hi = nCells;  // last cell whose offset is <= o
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (offAt(mid) <= o) lo = mid;
+            else hi = mid;
+        }
+        const int e = o - offAt(lo);
+        dst[o] = st[(size_t)lo * L.cellCap + (offs[lo] < 0 ? L.cellCap - 1 - e : e)];
+    }
+    if (tid == 0) candCount[slot * g.nlevels + level] = total;
+    __syncthreads();
+    for (int c = c0; c < c1; c++) {
+        cnt[2 * c] = 0;
+        cnt[2 * c + 1] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Compaction in cell order: one workgroup per (level, image).  Exclusive scan of the cell counts in cell
 // order, then a coalesced gather into the dense list (which lives in host-mapped pinned memory so
 // the host octree can read it after a single stream sync).
@@ -1224,6 +1507,41 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
         FT_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
         hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab, sg);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+size_t ft_fast_strips_smem_bytes(const FtGeom &g) {
+    int maxSH = 1;
+    for (int l = 0; l < g.nlevels; l++) maxSH = std::max(maxSH, g.lv[l].sH);
+    return (size_t)fs_tile_bytes(maxSH) + fs_score_bytes(maxSH) + fs_list_bytes();
+}
+
+int ft_launch_fast_strips(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
+                          const uint8_t *pyr, int iniTh, int minTh, int *cellCount2, uint32_t *stage,
+                          const uint32_t *stripTab) {
+    if (g.totalStrips == 0) return FT_OK;
+    int maxSH = 1;
+    for (int l = 0; l < g.nlevels; l++) maxSH = std::max(maxSH, g.lv[l].sH);
+    const size_t smem = ft_fast_strips_smem_bytes(g);
+    dim3 grid, block(64, 1, 1);
+    const FtSlotGrid sg = ft_slot_grid(g.totalStrips, batch, grid);
+    if (smem > 64 * 1024)
+        FT_HIP(hipFuncSetAttribute((const void *)k_fast_strips, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(k_fast_strips, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, cellCount2, stage, stripTab, sg,
+                       maxSH);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_compact_strips(hipStream_t st, const FtGeom &g, int batch, int *cellCount2, const uint32_t *stage,
+                             uint32_t *cand, int *candCount) {
+    int maxCells = 0;
+    for (int l = 0; l < g.nlevels; l++) maxCells = std::max(maxCells, g.lv[l].nCols * g.lv[l].nRows);
+    dim3 grid2(g.nlevels, batch, 1), block(256, 1, 1);
+    // (idempotent under FT_DEBUG_REPEAT only together with the FAST kernel: the counters are consumed here)
+    hipLaunchKernelGGL(k_compact_strips, grid2, block, (size_t)(maxCells + 1) * sizeof(int), st, g, cellCount2, stage, cand,
+                       candCount);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -93,6 +93,28 @@ def test_gaussian_blur_of_whole_levels_bit_exact(ctx, w, h):
             assert np.array_equal(ex.blurred_level(level), ob.gaussian_blur7(src)), f"blur of level {level}"
 
 
+@pytest.mark.parametrize("w,h,nf,rows", [(752, 480, 1200, 32), (1280, 720, 2000, 16), (333, 257, 500, 64), (97, 83, 200, 8)])
+def test_fast_strips_variant_bit_exact(ctx, w, h, nf, rows, monkeypatch):
+    """k_fast_strips (opt-in, FT_FAST_STRIPS=1 at creation): FAST over 62-column strips that ignore the cell grid, cell borders
+    applied as NMS masks, the per-cell threshold fallback in the compaction - same candidates, same keypoints"""
+    monkeypatch.setenv("FT_FAST_STRIPS", "1")
+    monkeypatch.setenv("FT_STRIP_ROWS", str(rows))
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8 if min(w, h) > 200 else 3, 20, 7, w, h, max_batch=3)
+    monkeypatch.delenv("FT_FAST_STRIPS")
+    monkeypatch.delenv("FT_STRIP_ROWS")
+    oex = ob.Extractor(nf, 1.2, ex.nlevels)
+    imgs = [synth.make_image(w, h, seed=31), synth.make_noise(w, h, seed=32), synth.make_image(w, h, seed=33, density=3.0)]
+    res = ex.extract_batch(imgs)
+    for b, img in enumerate(imgs):
+        ok, od, om = oex.extract(img)
+        _check_same(res[b][0], res[b][1], ok, od)
+    ex(imgs[0])
+    oex.extract(imgs[0])
+    for level in range(ex.nlevels):
+        gc, oc = ex.candidates(level), oex.candidates(level)
+        assert gc.shape == oc.shape and np.array_equal(gc, oc), f"FAST candidates level {level}"
+
+
 def test_lapping_area_partition(ctx):
     """fisheye / monocular callers pass a lapping area: keypoints inside fill from the back (ORBextractor.cc:1476-1485)"""
     w, h, nf = 512, 512, 2000
