@@ -134,12 +134,15 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def make_stream(ctx, w, h, rank, D, scenes, density=1.0):
+def make_stream(ctx, w, h, rank, D, scenes, density=1.0, mosaic=0):
     """D distinct stereo pairs of this rank's stream in pinned host memory: `scenes` seeded scenes (synth.make_stereo_pair),
     scene s of variant k shifted cyclically by (53 k mod w, 29 k mod h) px in BOTH images (rectification and disparities
     are kept; the wrap-around seam is one more edge).  Returns (hostL, hostR) of shape (D, h, w) and the seeded scenes."""
     S = max(1, min(scenes, D))
-    base = [synth.make_stereo_pair(w, h, seed=s, density=density) for s in shard.stream_seeds(rank, S)]
+    if mosaic:
+        base = [synth.make_mosaic_pair(w, h, seed=s, block=mosaic) for s in shard.stream_seeds(rank, S)]
+    else:
+        base = [synth.make_stereo_pair(w, h, seed=s, density=density) for s in shard.stream_seeds(rank, S)]
     hostL, hostR = ctx.pinned_array((D, h, w), np.uint8), ctx.pinned_array((D, h, w), np.uint8)
     for d in range(D):
         L, R = base[d % S]
@@ -163,6 +166,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=0, help="distinct frames cycled through the batch (0 = the batch size)")
     ap.add_argument("--scenes", type=int, default=16, help="seeded synthetic scenes behind the distinct frames")
     ap.add_argument("--density", type=float, default=1.0, help="object density of the synthetic scenes (synth.py)")
+    ap.add_argument("--mosaic", type=int, default=0, metavar="BLOCK",
+                    help="dense-corner scenes instead (synth.make_mosaic_pair with tiles of BLOCK px: 8 gives > 8 k FAST "
+                         "candidates at level 0 of a 1280x720 frame)")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-in", action="store_true", help="skip the second timed region with frames in pinned host memory")
@@ -196,7 +202,7 @@ def main():
     # synthetic stream (seeds are per rank: one stream per GPU): D distinct pairs in pinned host memory and, for the
     # headline number, resident in HBM before the timed region
     D = max(1, min(args.distinct or B, B))
-    hostL, hostR, pairs = make_stream(ctx, w, h, rank, D, args.scenes, args.density)
+    hostL, hostR, pairs = make_stream(ctx, w, h, rank, D, args.scenes, args.density, args.mosaic)
     devL, devR = ctx.to_device(hostL), ctx.to_device(hostR)
     import ctypes as C
     fb = w * h
@@ -327,6 +333,7 @@ def main():
                        "image": [w, h], "nfeatures": nf, "nlevels": NLEVELS, "scale_factor": SCALE,
                        "fast_thresholds": [INI_TH, MIN_TH], "batch_pairs_per_gpu": B, "distinct_pairs": D,
                        "scenes": min(args.scenes, D), "scene_density": args.density,
+                       "scene_kind": f"mosaic of {args.mosaic}-px tiles" if args.mosaic else "objects on a smooth background",
                        "inputs": "resident in HBM before the timed region (host_in: pinned host memory, uploaded inside it)",
                        "batches_in_flight": len(fes),
                        "parallelism": f"{world} independent stream(s), one per GPU, no collective",

@@ -203,6 +203,10 @@ void freeAll(ft_extractor *ex) {
     hipFree(ex->d_nSel);
     hipFree(ex->d_selCount);
     hipFree(ex->d_overflow);
+    hipFree(ex->d_ovSlot);
+    hipFree(ex->d_bigCount);
+    hipHostFree(ex->h_bigStat);
+    hipFree(ex->d_bigList);
     hipFree(ex->d_candDev);
     hipFree(ex->d_candCountDev);
     hipHostFree(ex->h_selCount);
@@ -399,6 +403,10 @@ int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent
     a.sel = ex->d_sel + (size_t)b0 * g.maxKp;
     a.selCount = ex->d_selCount + (size_t)b0 * g.nlevels;
     a.overflow = ex->d_overflow;
+    a.ovSlot = ex->d_ovSlot + b0;
+    // second tier (levels with more than FT_OCT_MAXN candidates): small batches always get a workgroup per level, large
+    // ones the grid the previous batches asked for (0 while the frames do not need it)
+    a.bigCap = a.bigN ? (ex->lastBatch <= 16 ? nb * g.nlevels : std::min(ex->bigGrid, nb * g.nlevels)) : 0;
     const bool tm = ex->ctx->kernelTiming;
     ex->evt.begin(tm, "kernel.octree", so);
     int rc = ft_launch_octree(so, g, nb, a);
@@ -454,6 +462,66 @@ int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb) {
 
 int ft_extract_octree(ft_extractor *ex, int b0, int nb) { return ft_extract_octree_multi(&ex, 1, b0, nb); }
 
+// After a large batch has drained: size the second-tier octree kernel of the following batches by what this one asked for
+// (levels with more than FT_OCT_MAXN candidates per launch), and retire it after a run of batches without demand.
+void ft_extract_update_big_grid(ft_extractor *ex) {
+    if (!ex->octLayout.bigN || ex->lastBatch <= 16) return;
+    const int want = ex->h_bigStat[0];
+    ex->h_bigStat[0] = 0;
+    if (want > 0) {
+        ex->bigIdle = 0;
+        const int need = std::max(FT_OCT_BIGMIN, ((want + want / 4 + 63) / 64) * 64);
+        if (need > ex->bigGrid) ex->bigGrid = std::min(need, ex->maxBatch * ex->nlevels);
+    } else if (ex->bigGrid > 0 && ++ex->bigIdle >= 16) {
+        ex->bigGrid = 0;
+    }
+}
+
+// Which slots of the last device-octree batch need the host octree (a level beyond the kernels' limits).  Called after
+// the batch has drained and the summary flag was seen; clears the device flags.
+int ft_extract_overflow_slots(ft_extractor *ex, int batch, std::vector<int> &slots) {
+    std::vector<int> f(batch, 0);
+    FT_HIP(hipMemcpy(f.data(), ex->d_ovSlot, sizeof(int) * batch, hipMemcpyDeviceToHost));
+    for (int b = 0; b < batch; b++)
+        if (f[b]) slots.push_back(b);
+    FT_HIP(hipMemset(ex->d_ovSlot, 0, sizeof(int) * batch));
+    FT_HIP(hipMemset(ex->d_overflow, 0, sizeof(int)));
+    ex->h_overflow[0] = 0;
+    return FT_OK;
+}
+
+// Redo the octree of ONE slot on the host, in place: its candidate lists come back from the device (in the order the
+// device stage delivered them; they are put into the reference's emission order - cell row, cell column, row-major inside
+// the cell - which the host octree's result depends on), the selection goes up again and orientation + descriptors of
+// that slot are enqueued on `st`.  The other slots of the batch keep their device results.
+int ft_extract_repair_slot(ft_extractor *ex, int slot, hipStream_t st) {
+    const FtGeom &g = ex->geom;
+    const int L = g.nlevels;
+    FT_HIP(hipMemcpy(ex->h_candCount + (size_t)slot * L, ex->d_candCountDev + (size_t)slot * L, sizeof(int) * L, hipMemcpyDeviceToHost));
+    for (int l = 0; l < L; l++) {
+        const FtLevelGeom &v = g.lv[l];
+        const int n = std::min(ex->h_candCount[(size_t)slot * L + l], v.candCap);
+        if (n <= 0) continue;
+        uint32_t *c = ex->h_cand + (size_t)slot * g.candPerSlot + v.candBase;
+        FT_HIP(hipMemcpy(c, ex->d_candDev + (size_t)slot * g.candPerSlot + v.candBase, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+        auto rank = [&](uint32_t q) -> uint64_t {
+            const int x = (int)(q & 0xfffu) - 3, y = (int)((q >> 12) & 0xfffu) - 3;
+            const int cj = std::min(x / std::max(v.wCell, 1), std::max(v.nCols - 1, 0));
+            const int ci = std::min(y / std::max(v.hCell, 1), std::max(v.nRows - 1, 0));
+            return ((uint64_t)ci << 48) | ((uint64_t)cj << 32) | ((uint64_t)y << 16) | (uint64_t)x;
+        };
+        std::sort(c, c + n, [&](uint32_t a, uint32_t b) { return rank(a) < rank(b); });
+    }
+    int rc = ft_extract_octree(ex, slot, 1);
+    if (rc != FT_OK) return rc;
+    const bool dev = ex->deviceOctree;
+    ex->deviceOctree = false;  // stage B uploads the host selection of the slot
+    rc = ft_extract_launch_b(ex, slot, 1, st);
+    ex->deviceOctree = dev;
+    ex->ctx->addStat("extract.host_octree_repairs", 0);
+    return rc;
+}
+
 static int rangeMaxN(const ft_extractor *ex, int b0, int nb) {
     if (ex->deviceOctree) return ex->geom.maxKp;  // totals are not known on the host yet: copy whole rows
     int maxN = 0;
@@ -487,6 +555,10 @@ int ft_extract_finish_counts(ft_extractor *ex, int batch, hipStream_t st) {
     if (!ex->deviceOctree) return FT_OK;
     FT_HIP(hipMemcpyAsync(ex->h_nSel, ex->d_nSel, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
     FT_HIP(hipMemcpyAsync(ex->h_overflow, ex->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (ex->octLayout.bigN) {  // demand for the second-tier octree kernel during this batch (ft_extract_update_big_grid)
+        FT_HIP(hipMemcpyAsync(ex->h_bigStat, ex->d_bigCount + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+        FT_HIP(hipMemsetAsync(ex->d_bigCount + 1, 0, sizeof(int), st));
+    }
     return FT_OK;
 }
 
@@ -602,6 +674,11 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     FT_TRY(devAlloc(&ex->d_nSel, B));
     FT_TRY(devAlloc(&ex->d_selCount, B * g.nlevels + FT_MAX_LEVELS));  // k_orient_desc reads FT_MAX_LEVELS counts per image at once
     FT_TRY(devAlloc(&ex->d_overflow, 1));
+    FT_TRY(devAlloc(&ex->d_ovSlot, B));
+    FT_TRY(devAlloc(&ex->d_bigCount, 2));
+    FT_TRY(pinAlloc(&ex->h_bigStat, 1));
+    ex->h_bigStat[0] = 0;
+    FT_TRY(devAlloc(&ex->d_bigList, B * g.nlevels));
     FT_TRY(pinAlloc(&ex->h_selCount, B * g.nlevels));
     FT_TRY(pinAlloc(&ex->h_overflow, 1));
     FT_TRY(devAlloc(&ex->d_keys, B * g.maxKp));
@@ -671,8 +748,13 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         o.poolCap = need + 16;
         // FT_DEVICE_OCTREE=0 keeps the octree on the host (also the path when a quota exceeds the kernel's limit)
         const char *e = getenv("FT_DEVICE_OCTREE");
-        ex->deviceOctree = !(e && e[0] == '0') && maxQ <= FT_OCT_MAXQ && o.poolCap < 60000;
-        if (ex->deviceOctree && ft_octree_smem_bytes(o.poolCap) > 160 * 1024) ex->deviceOctree = false;
+        // the node pools must fit a CU's LDS beside FT_OCT_MAXN keys (per-level quotas up to ~1900); u16 node indices
+        (void)maxQ;
+        ex->deviceOctree = !(e && e[0] == '0') && o.poolCap < 30000 && ft_octree_smem_bytes(o.poolCap) <= 160 * 1024;
+        o.bigCap = 0;
+        o.bigN = ex->deviceOctree && !(getenv("FT_OCT_BIG") && atoi(getenv("FT_OCT_BIG")) == 0) ? ft_octree_big_keys(o.poolCap) : 0;
+        o.bigCount = ex->d_bigCount;
+        o.bigList = ex->d_bigList;
         if (ex->deviceOctree) {
             if (getenv("FT_OCT_PROFILE")) {
                 FT_TRY(devAlloc(&o.prof, (size_t)FT_MAX_LEVELS * 8));
@@ -681,6 +763,8 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
             FT_TRY(devAlloc(&ex->d_candDev, B * g.candPerSlot));
             FT_TRY(devAlloc(&ex->d_candCountDev, B * g.nlevels));
             hipError_t me = hipMemset(ex->d_overflow, 0, sizeof(int));
+            if (me == hipSuccess) me = hipMemset(ex->d_ovSlot, 0, sizeof(int) * B);
+            if (me == hipSuccess) me = hipMemset(ex->d_bigCount, 0, 2 * sizeof(int));
             if (me != hipSuccess) {
                 freeAll(ex);
                 delete ex;
@@ -843,6 +927,21 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
         }
         return FT_OK;
     };
+    // images with a level beyond the device octree's limits (seen after the batch has drained): each is redone with the
+    // host octree in place, the rest of the batch keeps its device results
+    auto repairOverflow = [&]() -> int {
+        std::vector<int> slots;
+        int r = ft_extract_overflow_slots(ex, batch, slots);
+        if (r != FT_OK) return r;
+        for (int b : slots) {
+            ex->ctx->addStat("extract.device_octree_fallbacks", 1);
+            r = ft_extract_repair_slot(ex, b, ex->streamB);
+            if (r == FT_OK) r = ft_extract_download(ex, b, 1, ex->streamB);
+            if (r != FT_OK) return r;
+        }
+        FT_HIP(hipStreamSynchronize(ex->streamB));
+        return FT_OK;
+    };
     bool done = false;
     const bool devWanted = ex->deviceOctree;
     static const bool graphsOn = !(getenv("FT_GRAPH") && getenv("FT_GRAPH")[0] == '0');
@@ -905,13 +1004,11 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
             if (launched) {
                 ex->ctx->addStat("extract.device_octree_batches", 0);
                 FT_HIP(hipStreamSynchronize(ex->stream));
-                done = !ex->h_overflow[0];  // an overflow is redone below with the host octree
-                if (!done) {  // redo with the host octree below
-                    ex->h_overflow[0] = 0;
-                    FT_HIP(hipMemsetAsync(ex->d_overflow, 0, sizeof(int), ex->stream));
-                    ex->ctx->addStat("extract.device_octree_fallbacks", 1);
-                    ex->deviceOctree = false;
+                if (ex->h_overflow[0]) {  // some image met a level beyond the device octree's limits: that image is repaired
+                    rc = repairOverflow();
+                    if (rc != FT_OK) return rc;
                 }
+                done = true;
             }
         }
     }
@@ -919,15 +1016,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
         rc = ft_extract_prepare(ex, images, batch, on_device, width, height, stride);
         if (rc != FT_OK) return rc;
     }
-    for (int pass = done ? 2 : 0; pass < 2; pass++) {
-        // pass 1 only when the device octree met a level beyond its limits: same batch, host octree
-        if (pass == 1) {
-            if (!(ex->deviceOctree && ex->h_overflow[0])) break;
-            ex->h_overflow[0] = 0;
-            FT_HIP(hipMemsetAsync(ex->d_overflow, 0, sizeof(int), ex->stream));
-            ex->deviceOctree = false;
-            ex->ctx->addStat("extract.device_octree_fallbacks", 1);
-        }
+    if (!done) {
         const bool dev = ex->deviceOctree;
         if (dev) ex->ctx->addStat("extract.device_octree_batches", 0);
         for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
@@ -962,7 +1051,11 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
         FT_HIP(hipStreamSynchronize(ex->stream));
         ex->evt.resolve(ex->ctx);
         if (!dev) ex->ctx->addStat("extract.octree(host)", tOct);
-        if (pass == 1) ex->deviceOctree = true;
+        if (dev) ft_extract_update_big_grid(ex);
+        if (dev && ex->h_overflow[0]) {
+            rc = repairOverflow();
+            if (rc != FT_OK) return rc;
+        }
     }
     ex->deviceOctree = devWanted;
     rc = assembleOutputs(ex, batch, lap0, lap1, keypoints, descriptors, capacity, n_keypoints, n_mono);

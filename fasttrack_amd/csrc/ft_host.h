@@ -141,6 +141,11 @@ struct ft_extractor {
     int *d_candCountDev = nullptr;
     int *d_selCount = nullptr, *h_selCount = nullptr;  // [maxBatch * nlevels]
     int *d_overflow = nullptr, *h_overflow = nullptr;
+    int *d_ovSlot = nullptr;         // [maxBatch] which slots overflowed (read only after the summary flag was seen)
+    int *d_bigCount = nullptr;       // second-tier octree kernel: [0] entries of the running launch, [1] maximum since last read
+    int *h_bigStat = nullptr;        // pinned copy of d_bigCount[1]
+    unsigned *d_bigList = nullptr;   // [maxBatch * nlevels] (slot, level) pairs with more than FT_OCT_MAXN candidates
+    int bigGrid = 0, bigIdle = 0;    // grid of k_octree_big for large batches: 0 until a batch asks for it, sized by demand
     FtOctArgs octLayout{};
     // selected keypoints host -> device
     FtSelKp *h_sel = nullptr, *d_sel = nullptr;
@@ -223,6 +228,9 @@ int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done);
 int ft_extract_ensure_stage(ft_extractor *ex);
 void ft_extract_restage(ft_extractor *ex, const uint8_t *const *images, int batch, int width, int height, int stride);
 int ft_extract_octree(ft_extractor *ex, int b0, int nb);
+int ft_extract_overflow_slots(ft_extractor *ex, int batch, std::vector<int> &slots);
+void ft_extract_update_big_grid(ft_extractor *ex);
+int ft_extract_repair_slot(ft_extractor *ex, int slot, hipStream_t st);
 int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb);
 int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent_t done);  // device octree, own streams
 int ft_extract_launch_b(ft_extractor *ex, int b0, int nb, hipStream_t st);

@@ -102,16 +102,23 @@ struct FtTap {
     short s, a0, a1, pad;
 };
 
-// device octree (kernels_octree.hip): limits of the one-wave-per-level kernel; beyond them the batch is
-// redone with the host octree
-#define FT_OCT_MAXN 4096  // candidates of one level of one image (sorted in LDS)
-#define FT_OCT_MAXQ 1024  // per-level quota (node pool in LDS)
+// device octree (kernels_octree.hip): a level with up to FT_OCT_MAXN candidates is sorted in the LDS layout of the
+// main kernel, one with up to bigN (16384 when the node pools leave room, see ft_octree_big_keys) by the second-tier
+// kernel that runs behind it; an image with a level beyond that is redone with the host octree (that image only).
+// The per-level quota is bounded by the LDS the node pools need (ft_octree_smem_bytes <= 160 KB).
+#define FT_OCT_MAXN 4096
+#define FT_OCT_BIGMIN 64   // smallest grid of the second-tier kernel once a stream of frames needs it
 struct FtOctArgs {
     const uint32_t *cand;   // device dense candidate lists [slot * candPerSlot + candBase]
     const int *candCount;   // device [slot * nlevels + level]
     FtSelKp *sel;           // device [slot * maxKp + selOff[level] + i]
     int *selCount;          // device [slot * nlevels + level]
-    int *overflow;          // device flag
+    int *overflow;          // device flag: some image of the launch needs the host octree
+    int *ovSlot;            // device [batch]: which ones
+    int *bigCount;          // second tier: [0] listed (slot, level) pairs of this launch, [1] maximum since the host last looked;
+                            // the list, its capacity (= grid of k_octree_big), keys per workgroup
+    unsigned *bigList;
+    int bigCap, bigN;
     int quota[FT_MAX_LEVELS], levelMax[FT_MAX_LEVELS], selOff[FT_MAX_LEVELS];
     int poolCap, keyBytes;
     unsigned long long *prof;  // FT_OCT_PROFILE=1: per-level phase times of slot 0 (wall_clock64 ticks), else null
@@ -173,6 +180,7 @@ int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs
 // test tap: 7x7 Gaussian of a whole level through k_orient_desc's blur routines (dst on the device)
 int ft_launch_blur_level(hipStream_t st, const uint8_t *img, int pitch, int w, int h, uint8_t *dst, int dstPitch);
 size_t ft_octree_smem_bytes(int poolCap);
+int ft_octree_big_keys(int poolCap);
 size_t ft_fast_smem_bytes(const FtGeom &g);
 
 // ---- kernel launchers (kernels_match.hip) ---------------------------------------------------

@@ -47,7 +47,7 @@ struct OctLds {
     int keys, lohi[2], x01[2], dep[2], vSize, vPrev, ord, bq, pq, mark, stack, total;
 };
 
-__host__ __device__ inline OctLds oct_lds_layout(int cap) {
+__host__ __device__ inline OctLds oct_lds_layout(int cap, int maxN) {
     OctLds o;
     int p = 0;
     auto take = [&](int bytes) {
@@ -55,7 +55,7 @@ __host__ __device__ inline OctLds oct_lds_layout(int cap) {
         p += (bytes + 15) & ~15;
         return at;
     };
-    o.keys = take(FT_OCT_MAXN * 8);
+    o.keys = take(maxN * 8);
     for (int i = 0; i < 2; i++) {
         o.lohi[i] = take(2 * cap * 4);
         o.x01[i] = take(2 * cap * 4);
@@ -268,15 +268,11 @@ __device__ void wave_std_sort(SortElem *a, int n, SortFrame *stack, uint16_t *po
 
 constexpr int OCT_THREADS = 512;  // codes + key sort use the whole block, the rounds only its first wave
 
-__global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// one (level, image) with at most maxN candidates (maxN: the key capacity of the LDS layout of this launch)
+__device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, const int slot, const int level, const int maxN,
+                                          uint8_t *smem) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    // a thin kernel that runs next to wide ones: its single critical wave per level should win the issue arbitration
-    __builtin_amdgcn_s_setprio(3);
-    // workgroups are dispatched in the order of their linear index: image fastest, so the level-0 workgroups of all
-    // images (the long ones: most candidates, largest quota) start first and the short high levels fill in behind
-    const int slot = blockIdx.x, level = blockIdx.y;
     const FtLevelGeom &L = g.lv[level];
     const int n = a.candCount[slot * g.nlevels + level];
     const int N = a.quota[level];
@@ -291,16 +287,32 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     const int minB = FT_EDGE_THRESHOLD - 3;
     const Roots R = ft::op::make_roots(minB, L.maxBX, minB, L.maxBY);
     const bool keyFits = L.nCols <= 128 && L.nRows <= 128 && L.wCell <= 128 && L.hCell <= 128 && R.nIni <= 15;
-    if (n > FT_OCT_MAXN || N > FT_OCT_MAXQ || !keyFits) {
+    if (n > maxN && n <= a.bigN && keyFits && maxN < a.bigN) {
+        // more candidates than this launch sorts in LDS: the level goes on the list of k_octree_big, which runs behind this
+        // kernel with room for bigN keys per workgroup
+        if (tid == 0) {
+            const int idx = atomicAdd(a.bigCount, 1);
+            atomicMax(a.bigCount + 1, idx + 1);  // the host sizes the second tier of the following batches by this
+            if (idx < a.bigCap) a.bigList[idx] = (unsigned)slot | ((unsigned)level << 16);
+            else {
+                *cntOut = 0;
+                atomicOr(a.overflow, 1);
+                a.ovSlot[slot] = 1;
+            }
+        }
+        return;
+    }
+    if (n > maxN || !keyFits) {  // beyond the device formulation: this image is redone with the host octree
         if (tid == 0) {
             *cntOut = 0;
             atomicOr(a.overflow, 1);
+            a.ovSlot[slot] = 1;
         }
         return;
     }
     const uint32_t *cand = a.cand + (size_t)slot * g.candPerSlot + L.candBase;
     const int cap = a.poolCap;
-    const OctLds o = oct_lds_layout(cap);
+    const OctLds o = oct_lds_layout(cap, maxN);
     unsigned long long *keys = (unsigned long long *)(smem + o.keys);  // code << 32 | index
     const uint32_t *codes = (const uint32_t *)keys;                     // codes[2 * i + 1] = code << 4 | response >> 4
     // the two copies of the node list are addressed as smem + offset (never through an array of pointers: that loses
@@ -574,16 +586,48 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     if (lane == 0) *cntOut = kept;
 }
 
+__global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // a thin kernel that runs next to wide ones: its single critical wave per level should win the issue arbitration
+    __builtin_amdgcn_s_setprio(3);
+    // workgroups are dispatched in the order of their linear index: image fastest, so the level-0 workgroups of all
+    // images (the long ones: most candidates, largest quota) start first and the short high levels fill in behind
+    oct_level(g, a, blockIdx.x, blockIdx.y, FT_OCT_MAXN, smem);
+}
+
+// The levels k_octree left on the list (more than FT_OCT_MAXN candidates): one workgroup per entry with an LDS layout
+// for a.bigN keys (up to the whole 160 KB of a CU).  A workgroup that needs a CU's whole LDS waits for a CU to drain even
+// if it has nothing to do, so the kernel is only launched while the stream of frames needs it, with a grid the host sizes
+// from the demand of the previous batches (ft_extractor::bigGrid); small batches always get one workgroup per level.
+__global__ __launch_bounds__(OCT_THREADS) void k_octree_big(FtGeom g, FtOctArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int cnt = min(*a.bigCount, a.bigCap);
+    if ((int)blockIdx.x >= cnt) return;
+    const unsigned e = a.bigList[blockIdx.x];
+    oct_level(g, a, (int)(e & 0xffffu), (int)(e >> 16), a.bigN, smem);
+}
+
 }  // namespace
 
-size_t ft_octree_smem_bytes(int poolCap) { return (size_t)oct_lds_layout(poolCap).total; }
+size_t ft_octree_smem_bytes(int poolCap) { return (size_t)oct_lds_layout(poolCap, FT_OCT_MAXN).total; }
+// key capacity of the second-tier kernel: the largest power of two (the sort is bitonic) whose layout fits one CU's LDS
+int ft_octree_big_keys(int poolCap) {
+    for (int n = 16384; n > FT_OCT_MAXN; n >>= 1)
+        if ((size_t)oct_lds_layout(poolCap, n).total <= 160 * 1024) return n;
+    return 0;
+}
 
 int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a) {
     const size_t smem = ft_octree_smem_bytes(a.poolCap);
     if (smem > 64 * 1024)  // large quotas: raise the dynamic LDS limit (per device, so not cached in a static)
         FT_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    for (int rep = ft_debug_repeat("octree"); rep > 0; rep--)
-    hipLaunchKernelGGL(k_octree, dim3(batch, g.nlevels), dim3(OCT_THREADS), smem, st, g, a);
+    const size_t smemBig = a.bigN ? (size_t)oct_lds_layout(a.poolCap, a.bigN).total : 0;
+    if (a.bigN) FT_HIP(hipFuncSetAttribute((const void *)k_octree_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemBig));
+    for (int rep = ft_debug_repeat("octree"); rep > 0; rep--) {
+        if (a.bigN) FT_HIP(hipMemsetAsync(a.bigCount, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_octree, dim3(batch, g.nlevels), dim3(OCT_THREADS), smem, st, g, a);
+        if (a.bigN && a.bigCap > 0) hipLaunchKernelGGL(k_octree_big, dim3(a.bigCap), dim3(OCT_THREADS), smemBig, st, g, a);
+    }
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -184,6 +184,93 @@ ft_extractor *ft_stereo_frontend_right(ft_stereo_frontend *fe) { return fe ? fe-
 static bool isPinnedHost(const void *p) { return ft_is_pinned_host(p); }
 
 
+// Matching and result copies of the slots [b0, b0 + nb) once their descriptors are enqueued on the stage-B streams of the
+// two extractors: row sort, stereo match, median cut on the left stage-B stream, then (unless one kernel delivers the whole
+// batch at the end) the D2H copies of the rows.  Also the tail of the per-image host-octree repair.
+static int frontendMatchAndDeliver(ft_stereo_frontend *fe, int s, int b0, int nb, bool dev, bool deliver, bool direct,
+                                   ft_keypoint *keysL, uint8_t *descL, ft_keypoint *keysR, uint8_t *descR, int capacity,
+                                   float *uright, float *depth) {
+    ft_extractor *L = fe->exL, *R = fe->exR;
+    const FtGeom &g = L->geom;
+    const bool tm = fe->ctx->kernelTiming;
+    hipStream_t st = L->streamB;
+    int rc;
+    // pageable result arrays go through the library's pinned staging buffers and a host memcpy in _wait
+    // (with the device octree the per-image counts are unknown until the end: whole rows are copied, which the
+    // caller's arrays must be able to hold)
+    const size_t kp = sizeof(ft_keypoint);
+    auto d2h = [&](void *user, void *staging, const void *dev, size_t elem, int b0, int nb, int maxN) -> hipError_t {
+        // rows of `elem`-byte records: device/staging stride maxKp, user stride capacity
+        const size_t o = (size_t)b0 * g.maxKp * elem;
+        if (direct) {
+            if (!user) return hipSuccess;
+            return hipMemcpy2DAsync((uint8_t *)user + (size_t)b0 * capacity * elem, elem * capacity, (const uint8_t *)dev + o,
+                                    elem * g.maxKp, elem * maxN, nb, hipMemcpyDeviceToHost, st);
+        }
+        return hipMemcpy2DAsync((uint8_t *)staging + o, elem * g.maxKp, (const uint8_t *)dev + o, elem * g.maxKp, elem * maxN,
+                                nb, hipMemcpyDeviceToHost, st);
+    };
+    FT_HIP(hipEventRecord(R->evB[s], R->streamB));
+    FT_HIP(hipStreamWaitEvent(st, R->evB[s], 0));
+    // keypoints stay on the device between extraction and matching: pinhole stereo passes the lapping
+    // area (0,0) (src/Frame.cc:127), no keypoint has x == 0, so mono order == extraction order.
+    const size_t o = (size_t)b0 * g.maxKp;
+    FtStereoArgs a;
+    a.keysL = L->d_keys + o;
+    a.keysR = R->d_keys + o;
+    a.descL = L->d_desc + o * 32;
+    a.descR = R->d_desc + o * 32;
+    a.nL = L->d_nSel + b0;
+    a.nR = R->d_nSel + b0;
+    a.capacity = g.maxKp;
+    a.mbf = fe->mbf;
+    a.mb = fe->mb;
+    a.uright = fe->d_uright + o;
+    a.depth = fe->d_depth + o;
+    a.sad = fe->d_sad + o;
+    a.hamIdx = nullptr;
+    a.nMatches = fe->d_nMatches + b0;
+    a.applyMedianCut = 1;
+    a.rowStride = L->height + 2;
+    a.rowStart = fe->d_rowStart + (size_t)b0 * a.rowStride;
+    a.sorted = fe->d_sorted + o;
+    L->evt.begin(tm, "kernel.stereo_rowsort", st);
+    rc = ft_launch_stereo_rowsort(st, g, nb, a);
+    L->evt.end(tm, st);
+    if (rc != FT_OK) return rc;
+    L->evt.begin(tm, "kernel.stereo_match", st);
+    rc = ft_launch_stereo_match(st, g, nb, L->d_l0 + b0, R->d_l0 + b0, L->l0pitch, R->l0pitch,
+                                L->d_pyr + (size_t)b0 * g.pyrPerSlot, R->d_pyr + (size_t)b0 * g.pyrPerSlot, a);
+    L->evt.end(tm, st);
+    if (rc != FT_OK) return rc;
+    L->evt.begin(tm, "kernel.stereo_median", st);
+    rc = ft_launch_stereo_median(st, nb, a);
+    L->evt.end(tm, st);
+    if (rc != FT_OK) return rc;
+    int maxNL = 0, maxNR = 0;
+    for (int b = b0; b < b0 + nb; b++) {
+        maxNL = std::max(maxNL, dev ? g.maxKp : L->h_nSel[b]);
+        maxNR = std::max(maxNR, dev ? g.maxKp : R->h_nSel[b]);
+    }
+    if (!dev && (maxNL > capacity || maxNR > capacity)) {
+        ft_set_error("stereo front end: output capacity too small (use ft_extractor_max_keypoints)");
+        return FT_ERR_CAPACITY;
+    }
+    if (deliver) return FT_OK;  // one kernel at the end delivers everything
+    if (maxNL > 0) {
+        FT_HIP(d2h(keysL, L->h_keys, L->d_keys, kp, b0, nb, maxNL));
+        FT_HIP(d2h(descL, L->h_desc, L->d_desc, 32, b0, nb, maxNL));
+        FT_HIP(d2h(uright, fe->h_uright, fe->d_uright, 4, b0, nb, maxNL));
+        FT_HIP(d2h(depth, fe->h_depth, fe->d_depth, 4, b0, nb, maxNL));
+    }
+    if (maxNR > 0) {
+        FT_HIP(d2h(keysR, R->h_keys, R->d_keys, kp, b0, nb, maxNR));
+        FT_HIP(d2h(descR, R->h_desc, R->d_desc, 32, b0, nb, maxNR));
+    }
+    FT_HIP(hipMemcpyAsync(fe->h_nMatches + b0, fe->d_nMatches + b0, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+    return FT_OK;
+}
+
 // enqueues one batch on the front end's streams.  capture != 0: L->stream is being captured into a graph - the other
 // streams are forked from it first and joined back at the end, and nothing here may synchronise.
 static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL, const uint8_t *const *imagesR, int batch,
@@ -296,28 +383,12 @@ static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL
         if (rc == FT_OK && dev) rc = ft_extract_launch_octree(R, s, b0, nb, R->evA[s]);
         if (rc != FT_OK) return rc;
     }
-    const bool tm = fe->ctx->kernelTiming;
     hipStream_t st = L->streamB;
     // latency mode: the results of a small batch are written to pinned host memory by one kernel (FtDeliverArgs); large
     // batches keep the DMA copies, which cost no compute units
     static const bool deliverOn = !(getenv("FT_DELIVER_KERNEL") && atoi(getenv("FT_DELIVER_KERNEL")) == 0);
     const bool deliver = deliverOn && dev && batch <= FT_GRAPH_MAX_BATCH;
     double tOct = 0, tWait = 0, tLaunch = 0;
-    // pageable result arrays go through the library's pinned staging buffers and a host memcpy in _wait
-    // (with the device octree the per-image counts are unknown until the end: whole rows are copied, which the
-    // caller's arrays must be able to hold)
-    const size_t kp = sizeof(ft_keypoint);
-    auto d2h = [&](void *user, void *staging, const void *dev, size_t elem, int b0, int nb, int maxN) -> hipError_t {
-        // rows of `elem`-byte records: device/staging stride maxKp, user stride capacity
-        const size_t o = (size_t)b0 * g.maxKp * elem;
-        if (direct) {
-            if (!user) return hipSuccess;
-            return hipMemcpy2DAsync((uint8_t *)user + (size_t)b0 * capacity * elem, elem * capacity, (const uint8_t *)dev + o,
-                                    elem * g.maxKp, elem * maxN, nb, hipMemcpyDeviceToHost, st);
-        }
-        return hipMemcpy2DAsync((uint8_t *)staging + o, elem * g.maxKp, (const uint8_t *)dev + o, elem * g.maxKp, elem * maxN,
-                                nb, hipMemcpyDeviceToHost, st);
-    };
     for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
         const int nb = std::min(sb, batch - b0);
         if (dev) {
@@ -339,64 +410,8 @@ static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL
         if (rc != FT_OK) return rc;
         rc = ft_extract_launch_b(R, b0, nb, R->streamB);
         if (rc != FT_OK) return rc;
-        FT_HIP(hipEventRecord(R->evB[s], R->streamB));
-        FT_HIP(hipStreamWaitEvent(st, R->evB[s], 0));
-        // keypoints stay on the device between extraction and matching: pinhole stereo passes the lapping
-        // area (0,0) (src/Frame.cc:127), no keypoint has x == 0, so mono order == extraction order.
-        const size_t o = (size_t)b0 * g.maxKp;
-        FtStereoArgs a;
-        a.keysL = L->d_keys + o;
-        a.keysR = R->d_keys + o;
-        a.descL = L->d_desc + o * 32;
-        a.descR = R->d_desc + o * 32;
-        a.nL = L->d_nSel + b0;
-        a.nR = R->d_nSel + b0;
-        a.capacity = g.maxKp;
-        a.mbf = fe->mbf;
-        a.mb = fe->mb;
-        a.uright = fe->d_uright + o;
-        a.depth = fe->d_depth + o;
-        a.sad = fe->d_sad + o;
-        a.hamIdx = nullptr;
-        a.nMatches = fe->d_nMatches + b0;
-        a.applyMedianCut = 1;
-        a.rowStride = L->height + 2;
-        a.rowStart = fe->d_rowStart + (size_t)b0 * a.rowStride;
-        a.sorted = fe->d_sorted + o;
-        L->evt.begin(tm, "kernel.stereo_rowsort", st);
-        rc = ft_launch_stereo_rowsort(st, g, nb, a);
-        L->evt.end(tm, st);
+        rc = frontendMatchAndDeliver(fe, s, b0, nb, dev, deliver, direct, keysL, descL, keysR, descR, capacity, uright, depth);
         if (rc != FT_OK) return rc;
-        L->evt.begin(tm, "kernel.stereo_match", st);
-        rc = ft_launch_stereo_match(st, g, nb, L->d_l0 + b0, R->d_l0 + b0, L->l0pitch, R->l0pitch,
-                                    L->d_pyr + (size_t)b0 * g.pyrPerSlot, R->d_pyr + (size_t)b0 * g.pyrPerSlot, a);
-        L->evt.end(tm, st);
-        if (rc != FT_OK) return rc;
-        L->evt.begin(tm, "kernel.stereo_median", st);
-        rc = ft_launch_stereo_median(st, nb, a);
-        L->evt.end(tm, st);
-        if (rc != FT_OK) return rc;
-        int maxNL = 0, maxNR = 0;
-        for (int b = b0; b < b0 + nb; b++) {
-            maxNL = std::max(maxNL, dev ? g.maxKp : L->h_nSel[b]);
-            maxNR = std::max(maxNR, dev ? g.maxKp : R->h_nSel[b]);
-        }
-        if (!dev && (maxNL > capacity || maxNR > capacity)) {
-            ft_set_error("stereo front end: output capacity too small (use ft_extractor_max_keypoints)");
-            return FT_ERR_CAPACITY;
-        }
-        if (deliver) continue;  // one kernel at the end delivers everything
-        if (maxNL > 0) {
-            FT_HIP(d2h(keysL, L->h_keys, L->d_keys, kp, b0, nb, maxNL));
-            FT_HIP(d2h(descL, L->h_desc, L->d_desc, 32, b0, nb, maxNL));
-            FT_HIP(d2h(uright, fe->h_uright, fe->d_uright, 4, b0, nb, maxNL));
-            FT_HIP(d2h(depth, fe->h_depth, fe->d_depth, 4, b0, nb, maxNL));
-        }
-        if (maxNR > 0) {
-            FT_HIP(d2h(keysR, R->h_keys, R->d_keys, kp, b0, nb, maxNR));
-            FT_HIP(d2h(descR, R->h_desc, R->d_desc, 32, b0, nb, maxNR));
-        }
-        FT_HIP(hipMemcpyAsync(fe->h_nMatches + b0, fe->d_nMatches + b0, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
         tLaunch += tL.ms();
     }
     if (deliver) {
@@ -593,22 +608,55 @@ int ft_stereo_frontend_wait(ft_stereo_frontend *fe) {
     fe->ctx->addStat("stereo.host_tail_sync", tTail.ms());
     L->evt.resolve(fe->ctx);
     R->evt.resolve(fe->ctx);
+    if (L->deviceOctree) ft_extract_update_big_grid(L);
+    if (R->deviceOctree) ft_extract_update_big_grid(R);
     if ((L->deviceOctree && L->h_overflow[0]) || (R->deviceOctree && R->h_overflow[0])) {
-        // a level exceeded the device octree's limits (FT_OCT_MAXN candidates): redo this batch with the host
-        // octree.  Same inputs, same outputs, only slower.
-        fe->ctx->addStat("stereo.device_octree_fallbacks", 1);
-        L->h_overflow[0] = R->h_overflow[0] = 0;
-        FT_HIP(hipMemset(L->d_overflow, 0, sizeof(int)));
-        FT_HIP(hipMemset(R->d_overflow, 0, sizeof(int)));
-        const bool dl = L->deviceOctree, dr = R->deviceOctree;
-        L->deviceOctree = R->deviceOctree = false;
-        std::vector<const uint8_t *> il = P.imagesL, ir = P.imagesR;
-        rc = ft_stereo_frontend_submit(fe, il.data(), ir.data(), P.batch, P.onDevice, P.width, P.height, P.stride, P.keysL,
-                                       P.descL, P.nL, P.keysR, P.descR, P.nR, P.capacity, P.uright, P.depth, P.nMatches);
-        if (rc == FT_OK) rc = ft_stereo_frontend_wait(fe);
-        L->deviceOctree = dl;
-        R->deviceOctree = dr;
-        return rc;
+        // a level of some image exceeded the device octree's limits (more than 16 384 candidates, or more than
+        // FT_OCT_BIGCAP levels of the launch beyond 4 096)
+        if (P.graph || fe->lastPaired) {
+            // latency mode (at most 8 pairs, possibly both cameras in one extractor): the whole small batch is redone with
+            // the host octree.  Same inputs, same outputs, only slower.
+            fe->ctx->addStat("stereo.device_octree_fallbacks", 1);
+            L->h_overflow[0] = R->h_overflow[0] = 0;
+            FT_HIP(hipMemset(L->d_overflow, 0, sizeof(int)));
+            FT_HIP(hipMemset(R->d_overflow, 0, sizeof(int)));
+            FT_HIP(hipMemset(L->d_ovSlot, 0, sizeof(int) * L->maxBatch));
+            FT_HIP(hipMemset(R->d_ovSlot, 0, sizeof(int) * R->maxBatch));
+            const bool dl = L->deviceOctree, dr = R->deviceOctree;
+            L->deviceOctree = R->deviceOctree = false;
+            std::vector<const uint8_t *> il = P.imagesL, ir = P.imagesR;
+            rc = ft_stereo_frontend_submit(fe, il.data(), ir.data(), P.batch, P.onDevice, P.width, P.height, P.stride, P.keysL,
+                                           P.descL, P.nL, P.keysR, P.descR, P.nR, P.capacity, P.uright, P.depth, P.nMatches);
+            if (rc == FT_OK) rc = ft_stereo_frontend_wait(fe);
+            L->deviceOctree = dl;
+            R->deviceOctree = dr;
+            return rc;
+        }
+        // throughput mode: only the pairs concerned are redone, in place - host octree of the camera(s) that overflowed,
+        // descriptors, matching and result copies of that pair; every other pair keeps its device results
+        std::vector<int> sl, sr;
+        rc = ft_extract_overflow_slots(L, P.batch, sl);
+        if (rc == FT_OK) rc = ft_extract_overflow_slots(R, P.batch, sr);
+        if (rc != FT_OK) return rc;
+        std::vector<char> bad(P.batch, 0);
+        for (int b : sl) bad[b] |= 1;
+        for (int b : sr) bad[b] |= 2;
+        for (int b = 0; b < P.batch; b++) {
+            if (!bad[b]) continue;
+            fe->ctx->addStat("stereo.device_octree_fallbacks", 1);
+            if (bad[b] & 1) rc = ft_extract_repair_slot(L, b, L->streamB);
+            if (rc == FT_OK && (bad[b] & 2)) rc = ft_extract_repair_slot(R, b, R->streamB);
+            if (rc == FT_OK)
+                rc = frontendMatchAndDeliver(fe, 0, b, 1, true, false, P.direct, P.keysL, P.descL, P.keysR, P.descR, P.capacity,
+                                             P.uright, P.depth);
+            if (rc != FT_OK) return rc;
+            FT_HIP(hipStreamSynchronize(L->streamB));  // evB[0] is reused by the next repaired pair
+            // the device totals of the repaired images (orientation kernel) are the host octree's
+            FT_HIP(hipMemcpy(L->h_nSel + b, L->d_nSel + b, sizeof(int), hipMemcpyDeviceToHost));
+            FT_HIP(hipMemcpy(R->h_nSel + b, R->d_nSel + b, sizeof(int), hipMemcpyDeviceToHost));
+        }
+        L->evt.resolve(fe->ctx);
+        R->evt.resolve(fe->ctx);
     }
     const size_t kp = sizeof(ft_keypoint);
     const int capacity = P.capacity;

@@ -100,6 +100,22 @@ def make_stereo_pair(width: int, height: int, seed: int, density: float = 1.0):
     return np.ascontiguousarray(left), np.ascontiguousarray(right)
 
 
+def make_mosaic_pair(width: int, height: int, seed: int, block: int = 8, disparity: int = 12):
+    """Dense-corner stereo pair: a mosaic of block x block tiles with random grey levels from four well separated values
+    (every tile corner where the levels differ is a FAST corner: ~(w / block) * (h / block) of them at level 0 - the
+    5-30 k candidates per image SURVEY a4 expects from real frames, where the object scenes give ~3 k) + noise of +-3;
+    the right image is the same fronto-parallel plane `disparity` px closer to the left edge."""
+    rng = np.random.default_rng(seed)
+    levels = np.array([35.0, 95.0, 160.0, 220.0], np.float32)
+    gw = (width + disparity) // block + 2
+    grid = rng.choice(levels, size=(height // block + 2, gw))
+    plane = np.kron(grid, np.ones((block, block), np.float32))
+    oy, ox = int(rng.integers(0, block)), int(rng.integers(0, block))
+    left = plane[oy:oy + height, ox:ox + width]
+    right = plane[oy:oy + height, ox + disparity:ox + disparity + width]
+    return np.ascontiguousarray(_finish(rng, left)), np.ascontiguousarray(_finish(rng, right))
+
+
 def make_flat(width: int, height: int, value: int = 128) -> np.ndarray:
     """Featureless frame: exercises the empty-cell / zero-keypoint paths."""
     return np.full((height, width), value, np.uint8)

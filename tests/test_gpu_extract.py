@@ -265,6 +265,23 @@ def test_device_octree_overflow_falls_back_to_host(ctx):
     _check_same(res[1][0], res[1][1], ok, od)
 
 
+def test_device_octree_second_tier(ctx):
+    """levels with more than FT_OCT_MAXN = 4 096 and at most 16 384 candidates are distributed by k_octree_big (LDS layout
+    for 16 384 keys): dense frames stay on the device, the result equals the oracle's"""
+    w, h, nf = 1280, 720, 2000
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=2)
+    oex = ob.Extractor(nf)
+    dense = synth.make_mosaic_pair(w, h, seed=5, block=12)
+    f0 = _calls(ctx, "extract.device_octree_fallbacks")
+    res = ex.extract_batch([dense[0], dense[1]])
+    for img, (gk, gd, gm) in zip(dense, res):
+        ok, od, om = oex.extract(img)
+        counts = [len(oex.candidates(l)) for l in range(8)]
+        assert max(counts) > 4096 and max(counts) <= 16384, counts
+        _check_same(gk, gd, ok, od)
+    assert _calls(ctx, "extract.device_octree_fallbacks") == f0, "a dense frame fell back to the host octree"
+
+
 def test_two_host_threads_two_extractors(ctx):
     """Frame's constructor runs the left and the right extractor on two host threads (src/Frame.cc:127-130): two
     extractors of one context called concurrently (ctypes releases the GIL) give the single-threaded results, and a

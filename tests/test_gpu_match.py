@@ -156,6 +156,55 @@ def test_stereo_frontend_device_octree_overflow(ctx):
     assert calls("stereo.device_octree_batches") == b0 + 2
 
 
+def test_dense_frames_stay_on_the_device_and_overflows_are_repaired_per_pair(ctx):
+    """Throughput mode (more than 16 pairs per batch).  Levels with 4 096 .. 16 384 candidates go to the second-tier octree
+    kernel, whose grid the host sizes from the previous batch: the first dense batch finds it absent and is repaired pair
+    by pair with the host octree, the second one stays on the device.  A pair with a level beyond 16 384 candidates is
+    always repaired - that pair only.  Every output equals the oracle's."""
+    w, h, nf, B = 752, 480, 1200, 18
+    intr = synth.intrinsics(w, h)
+    fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
+
+    def calls(name):
+        try:
+            return ctx.get_stat(name)[1]
+        except Exception:
+            return 0
+
+    def check(pairs, outs, which):
+        for b in which:
+            (imL, imR), out = pairs[b], outs[b]
+            oL, oR = ob.Extractor(nf), ob.Extractor(nf)
+            kL, dL, _ = oL.extract(imL)
+            kR, dR, _ = oR.extract(imR)
+            o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+            assert np.array_equal(out["keysL"], kL) and np.array_equal(out["keysR"], kR), b
+            assert np.array_equal(out["descL"], dL) and np.array_equal(out["descR"], dR), b
+            assert out["n"] == o["n"] and np.array_equal(out["uright"], o["uright"]) and np.array_equal(out["depth"], o["depth"]), b
+    dense = [synth.make_mosaic_pair(w, h, seed=60 + i, block=8) for i in range(3)]
+    oex = ob.Extractor(nf)
+    oex.extract(dense[0][0])
+    top = max(len(oex.candidates(l)) for l in range(8))
+    assert 4096 < top <= 16384, f"test input should need the second tier only ({top})"
+    calm = [synth.make_stereo_pair(w, h, 70 + i) for i in range(3)]
+    batch1 = [dense[i % 3] if i % 2 == 0 else calm[i % 3] for i in range(B)]  # 9 dense pairs among 18
+    f0 = calls("stereo.device_octree_fallbacks")
+    outs = fe.process([p[0] for p in batch1], [p[1] for p in batch1])
+    assert calls("stereo.device_octree_fallbacks") == f0 + 9, "first dense batch: the dense pairs, and only they, are repaired"
+    check(batch1, outs, [0, 1, 2, 17])
+    outs = fe.process([p[0] for p in batch1], [p[1] for p in batch1])
+    assert calls("stereo.device_octree_fallbacks") == f0 + 9, "second dense batch stays on the device"
+    check(batch1, outs, [0, 3, 4, 16])
+    # a frame beyond the second tier (pure noise: tens of thousands of candidates at level 0) among dense and calm ones
+    noisy = (synth.make_noise(w, h, seed=8), synth.make_noise(w, h, seed=9))
+    batch2 = list(batch1)
+    batch2[5] = noisy
+    batch2[11] = (calm[0][0], noisy[1])  # only the right camera overflows
+    outs = fe.process([p[0] for p in batch2], [p[1] for p in batch2])
+    assert calls("stereo.device_octree_fallbacks") == f0 + 11
+    check(batch2, outs, [4, 5, 6, 11])
+
+
 def test_fisheye_match(ctx):
     rng = np.random.default_rng(2)
     fr = sc.oracle_stereo_frame(512, 512, 2000, 6)
