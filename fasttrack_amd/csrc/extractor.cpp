@@ -490,35 +490,75 @@ int ft_extract_overflow_slots(ft_extractor *ex, int batch, std::vector<int> &slo
     return FT_OK;
 }
 
-// Redo the octree of ONE slot on the host, in place: its candidate lists come back from the device (in the order the
-// device stage delivered them; they are put into the reference's emission order - cell row, cell column, row-major inside
-// the cell - which the host octree's result depends on), the selection goes up again and orientation + descriptors of
-// that slot are enqueued on `st`.  The other slots of the batch keep their device results.
-int ft_extract_repair_slot(ft_extractor *ex, int slot, hipStream_t st) {
-    const FtGeom &g = ex->geom;
+// Redo the octree of single slots on the host, in place (jobs = (extractor, slot) pairs; the extractors share geometry and
+// context): the candidate lists of those slots come back from the device - in the order the device stage delivered them;
+// they are put into the reference's emission order (cell row, cell column, row-major inside the cell), which the host
+// octree's result depends on - and all (job, level) trees run as one parallel job.  ft_extract_repair_launch then uploads
+// a slot's selection and enqueues its orientation + descriptors.  The other slots keep their device results.
+int ft_extract_repair_prepare(const std::vector<std::pair<ft_extractor *, int>> &jobs) {
+    if (jobs.empty()) return FT_OK;
+    ft_extractor *e0 = jobs[0].first;
+    const FtGeom &g = e0->geom;
     const int L = g.nlevels;
-    FT_HIP(hipMemcpy(ex->h_candCount + (size_t)slot * L, ex->d_candCountDev + (size_t)slot * L, sizeof(int) * L, hipMemcpyDeviceToHost));
-    for (int l = 0; l < L; l++) {
-        const FtLevelGeom &v = g.lv[l];
-        const int n = std::min(ex->h_candCount[(size_t)slot * L + l], v.candCap);
-        if (n <= 0) continue;
-        uint32_t *c = ex->h_cand + (size_t)slot * g.candPerSlot + v.candBase;
-        FT_HIP(hipMemcpy(c, ex->d_candDev + (size_t)slot * g.candPerSlot + v.candBase, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    for (auto &j : jobs) {
+        ft_extractor *ex = j.first;
+        const int slot = j.second;
+        FT_HIP(hipMemcpy(ex->h_candCount + (size_t)slot * L, ex->d_candCountDev + (size_t)slot * L, sizeof(int) * L, hipMemcpyDeviceToHost));
+        for (int l = 0; l < L; l++) {
+            const FtLevelGeom &v = g.lv[l];
+            int &n = ex->h_candCount[(size_t)slot * L + l];
+            n = std::min(n, v.candCap);
+            if (n > 0)
+                FT_HIP(hipMemcpyAsync(ex->h_cand + (size_t)slot * g.candPerSlot + v.candBase,
+                                      ex->d_candDev + (size_t)slot * g.candPerSlot + v.candBase, sizeof(uint32_t) * n,
+                                      hipMemcpyDeviceToHost, ex->streamB));
+        }
+    }
+    for (auto &j : jobs) FT_HIP(hipStreamSynchronize(j.first->streamB));
+    auto task = [&](int t, int) {
+        static thread_local ft::OctreeWorkspace ws;
+        static thread_local std::vector<int> keep;
+        ft_extractor *ex = jobs[t / L].first;
+        const int slot = jobs[t / L].second, level = t % L;
+        const FtLevelGeom &v = g.lv[level];
+        const int n = ex->h_candCount[(size_t)slot * L + level];
+        uint32_t *cand = ex->h_cand + (size_t)slot * g.candPerSlot + v.candBase;
         auto rank = [&](uint32_t q) -> uint64_t {
             const int x = (int)(q & 0xfffu) - 3, y = (int)((q >> 12) & 0xfffu) - 3;
             const int cj = std::min(x / std::max(v.wCell, 1), std::max(v.nCols - 1, 0));
             const int ci = std::min(y / std::max(v.hCell, 1), std::max(v.nRows - 1, 0));
             return ((uint64_t)ci << 48) | ((uint64_t)cj << 32) | ((uint64_t)y << 16) | (uint64_t)x;
         };
-        std::sort(c, c + n, [&](uint32_t a, uint32_t b) { return rank(a) < rank(b); });
+        std::sort(cand, cand + std::max(n, 0), [&](uint32_t a, uint32_t b) { return rank(a) < rank(b); });
+        keep.clear();
+        const int minB = FT_EDGE_THRESHOLD - 3;
+        int k = ft::distribute_octree(cand, n, minB, v.maxBX, minB, v.maxBY, ex->quota[level], ws, keep);
+        k = std::min(k, ex->levelMax[level]);
+        FtSelKp *dst = ex->h_sel + (size_t)slot * g.maxKp + ex->levelOff[level];
+        for (int i = 0; i < k; i++) {
+            const uint32_t c = cand[keep[i]];
+            dst[i].x = (short)((c & 0xfffu) + minB);  // ORBextractor.cc:1211-1217: add the border offset back
+            dst[i].y = (short)(((c >> 12) & 0xfffu) + minB);
+            dst[i].level = (short)level;
+            dst[i].response = (short)(c >> 24);
+        }
+        ex->h_selCount[(size_t)slot * L + level] = k;
+    };
+    e0->ctx->pool->parallel_for((int)jobs.size() * L, task);
+    for (auto &j : jobs) {
+        int n = 0;
+        for (int l = 0; l < L; l++) n += j.first->h_selCount[(size_t)j.second * L + l];
+        j.first->h_nSel[j.second] = n;
+        j.first->ctx->addStat("extract.host_octree_repairs", 0);
     }
-    int rc = ft_extract_octree(ex, slot, 1);
-    if (rc != FT_OK) return rc;
+    return FT_OK;
+}
+
+int ft_extract_repair_launch(ft_extractor *ex, int slot, hipStream_t st) {
     const bool dev = ex->deviceOctree;
     ex->deviceOctree = false;  // stage B uploads the host selection of the slot
-    rc = ft_extract_launch_b(ex, slot, 1, st);
+    const int rc = ft_extract_launch_b(ex, slot, 1, st);
     ex->deviceOctree = dev;
-    ex->ctx->addStat("extract.host_octree_repairs", 0);
     return rc;
 }
 
@@ -933,9 +973,13 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
         std::vector<int> slots;
         int r = ft_extract_overflow_slots(ex, batch, slots);
         if (r != FT_OK) return r;
+        std::vector<std::pair<ft_extractor *, int>> jobs;
+        for (int b : slots) jobs.emplace_back(ex, b);
+        r = ft_extract_repair_prepare(jobs);
+        if (r != FT_OK) return r;
         for (int b : slots) {
             ex->ctx->addStat("extract.device_octree_fallbacks", 1);
-            r = ft_extract_repair_slot(ex, b, ex->streamB);
+            r = ft_extract_repair_launch(ex, b, ex->streamB);
             if (r == FT_OK) r = ft_extract_download(ex, b, 1, ex->streamB);
             if (r != FT_OK) return r;
         }

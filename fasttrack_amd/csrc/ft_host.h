@@ -230,7 +230,8 @@ void ft_extract_restage(ft_extractor *ex, const uint8_t *const *images, int batc
 int ft_extract_octree(ft_extractor *ex, int b0, int nb);
 int ft_extract_overflow_slots(ft_extractor *ex, int batch, std::vector<int> &slots);
 void ft_extract_update_big_grid(ft_extractor *ex);
-int ft_extract_repair_slot(ft_extractor *ex, int slot, hipStream_t st);
+int ft_extract_repair_prepare(const std::vector<std::pair<ft_extractor *, int>> &jobs);
+int ft_extract_repair_launch(ft_extractor *ex, int slot, hipStream_t st);
 int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb);
 int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent_t done);  // device octree, own streams
 int ft_extract_launch_b(ft_extractor *ex, int b0, int nb, hipStream_t st);

@@ -613,10 +613,23 @@ int ft_stereo_frontend_wait(ft_stereo_frontend *fe) {
     if ((L->deviceOctree && L->h_overflow[0]) || (R->deviceOctree && R->h_overflow[0])) {
         // a level of some image exceeded the device octree's limits (more than 16 384 candidates, or more than
         // FT_OCT_BIGCAP levels of the launch beyond 4 096)
-        if (P.graph || fe->lastPaired) {
-            // latency mode (at most 8 pairs, possibly both cameras in one extractor): the whole small batch is redone with
-            // the host octree.  Same inputs, same outputs, only slower.
+        std::vector<int> sl, sr;
+        std::vector<char> bad(P.batch, 0);
+        int nBad = 0;
+        if (!(P.graph || fe->lastPaired)) {
+            rc = ft_extract_overflow_slots(L, P.batch, sl);
+            if (rc == FT_OK) rc = ft_extract_overflow_slots(R, P.batch, sr);
+            if (rc != FT_OK) return rc;
+            for (int b : sl) bad[b] |= 1;
+            for (int b : sr) bad[b] |= 2;
+            for (int b = 0; b < P.batch; b++) nBad += bad[b] ? 1 : 0;
+        }
+        if (P.graph || fe->lastPaired || 4 * nBad > P.batch) {
+            // latency mode (at most 8 pairs, possibly both cameras in one extractor), or most of the batch is beyond the
+            // device octree: the whole batch is redone with the host-octree pipeline (sub-batches of 16 pairs, the host
+            // octree of one overlapping with the kernels of the next).  Same inputs, same outputs, only slower.
             fe->ctx->addStat("stereo.device_octree_fallbacks", 1);
+            for (int k = 1; k < nBad; k++) fe->ctx->addStat("stereo.device_octree_fallbacks", 1);
             L->h_overflow[0] = R->h_overflow[0] = 0;
             FT_HIP(hipMemset(L->d_overflow, 0, sizeof(int)));
             FT_HIP(hipMemset(R->d_overflow, 0, sizeof(int)));
@@ -632,29 +645,26 @@ int ft_stereo_frontend_wait(ft_stereo_frontend *fe) {
             R->deviceOctree = dr;
             return rc;
         }
-        // throughput mode: only the pairs concerned are redone, in place - host octree of the camera(s) that overflowed,
-        // descriptors, matching and result copies of that pair; every other pair keeps its device results
-        std::vector<int> sl, sr;
-        rc = ft_extract_overflow_slots(L, P.batch, sl);
-        if (rc == FT_OK) rc = ft_extract_overflow_slots(R, P.batch, sr);
+        // throughput mode, a few pairs concerned: only they are redone, in place - host octree of the camera(s) that
+        // overflowed (all of them as one parallel job), then descriptors, matching and result copies of each such pair;
+        // every other pair keeps its device results
+        std::vector<std::pair<ft_extractor *, int>> jobs;
+        for (int b : sl) jobs.emplace_back(L, b);
+        for (int b : sr) jobs.emplace_back(R, b);
+        rc = ft_extract_repair_prepare(jobs);
         if (rc != FT_OK) return rc;
-        std::vector<char> bad(P.batch, 0);
-        for (int b : sl) bad[b] |= 1;
-        for (int b : sr) bad[b] |= 2;
         for (int b = 0; b < P.batch; b++) {
             if (!bad[b]) continue;
             fe->ctx->addStat("stereo.device_octree_fallbacks", 1);
-            if (bad[b] & 1) rc = ft_extract_repair_slot(L, b, L->streamB);
-            if (rc == FT_OK && (bad[b] & 2)) rc = ft_extract_repair_slot(R, b, R->streamB);
+            if (bad[b] & 1) rc = ft_extract_repair_launch(L, b, L->streamB);
+            if (rc == FT_OK && (bad[b] & 2)) rc = ft_extract_repair_launch(R, b, R->streamB);
             if (rc == FT_OK)
                 rc = frontendMatchAndDeliver(fe, 0, b, 1, true, false, P.direct, P.keysL, P.descL, P.keysR, P.descR, P.capacity,
                                              P.uright, P.depth);
             if (rc != FT_OK) return rc;
-            FT_HIP(hipStreamSynchronize(L->streamB));  // evB[0] is reused by the next repaired pair
-            // the device totals of the repaired images (orientation kernel) are the host octree's
-            FT_HIP(hipMemcpy(L->h_nSel + b, L->d_nSel + b, sizeof(int), hipMemcpyDeviceToHost));
-            FT_HIP(hipMemcpy(R->h_nSel + b, R->d_nSel + b, sizeof(int), hipMemcpyDeviceToHost));
         }
+        FT_HIP(hipStreamSynchronize(L->streamB));
+        FT_HIP(hipStreamSynchronize(R->streamB));
         L->evt.resolve(fe->ctx);
         R->evt.resolve(fe->ctx);
     }
