@@ -16,7 +16,14 @@ struct FtDevFrame {
     float Trl[12];
     float sf[FT_MAX_LEVELS];
     int nlevels;
+    // Frame::mGrid as CSR (k_build_grid; AssignFeaturesToGrid src/Frame.cc:409-440): the keypoints of cell (cx, cy) are
+    // gridIdx[gridStart[cx * 48 + cy] .. gridStart[cx * 48 + cy + 1]), each entry = keypoint index | cy << 24, so a
+    // window's column cx is ONE contiguous range; [0] left camera (or the only one), [1] right camera.  Null = no grid:
+    // the searches then scan every keypoint.
+    const int *gridStart[2];
+    const int *gridIdx[2];
 };
+#define FT_GRID_CELLS (FT_GRID_COLS * FT_GRID_ROWS)
 
 struct FtDevLocalPoints {
     int M;
@@ -34,16 +41,22 @@ struct FtDevLastPoints {
     const int *octave;
 };
 
-// writer lists of the previous pass: head[kp] -> slot s (= 4*point + write kind), next[s]
+// The claim iteration (Jacobi passes over the sequential claiming of SearchByProjection): a pass reads the writer lists
+// the previous pass built - head[kp] -> slot s (= 4 * point + write kind), next[s] - and builds the lists of the next
+// pass while it runs, so a pass is ONE launch.  The list heads rotate through three arrays (read / write / clear), next
+// and the results through two.  Flags: -1 = "this pass changed nothing", 0 = "changed" (one memset with 0xff prepares
+// heads and flags of a call); a pass returns at once when the previous pass's flag says the fixed point was reached.
 struct FtClaims {
     const int *head, *next;  // writer lists of the previous pass
     const int *obs;          // Observations() per map point
-    // housekeeping of the claim iteration, done by the search kernel itself so that a pass is two launches:
-    int *headNext;           // the list heads this pass's k_build_claims will fill: reset to -1 here
+    int firstPass;           // no lists yet: the pre-call holders decide, and every result counts as changed
+    int *headWrite, *nextWrite;  // lists this pass builds for the next one
+    int *headClear;          // the heads the next pass will write: reset to -1 here
     int nKp;
-    int *changedCur;         // this pass's "something changed" flag: reset to 0 here
-    const int *changedPrev;  // the previous pass's flag (null for the first pass of a burst): 0 = fixed point reached,
-                             // this pass would reproduce its input and returns at once
+    const int *resPrev;      // results of the previous pass
+    int *flagCur;            // this pass's flag (atomicAnd 0 on a change)
+    const int *flagPrev;     // the previous pass's flag (null for the first pass of a burst)
+    int *flagReset;          // the flag of the same position in the other burst parity: reset to -1 here
 };
 
 struct FtPose {
@@ -76,6 +89,9 @@ struct FtFrustumOut {
 };
 
 int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v);
+// one kernel copies up to three device blocks (sizes rounded up to dwords) into pinned host memory
+int ft_launch_deliver_blocks(hipStream_t st, void *d0, const void *s0, size_t bytes0, void *d1, const void *s1, size_t bytes1,
+                             void *d2, const void *s2, size_t bytes2);
 int ft_launch_features_in_area(hipStream_t st, const FtDevFrame &F, int nq, const float *qx, const float *qy, const float *qr,
                                const int *qmin, const int *qmax, const uint8_t *qright, const int *offsets,
                                unsigned *outKeys, int *outCount);
@@ -85,5 +101,4 @@ int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocal
                            float nnRatio, int *res, const FtLocalRaw &raw);
 int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
                           const FtPose &Tcw, float th, int forward, int backward, int *res, const FtLastRaw &raw);
-int ft_launch_build_claims(hipStream_t st, const int *res, const int *prevRes, int nPoints, int *head, int *next,
-                           int *changed, const int *changedPrev);
+int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridIdxL, int *gridStartR, int *gridIdxR);

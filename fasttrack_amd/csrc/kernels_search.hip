@@ -15,6 +15,8 @@
 // against the writes of the previous pass (per-keypoint linked lists of writers); point i is final
 // after at most i+1 passes and the iteration stops when a pass changes nothing - the unique fixed
 // point is the sequential result.
+#include <algorithm>
+
 #include "kb8_math.h"
 #include "ft_search.h"
 #include "wave_ops.h"
@@ -37,20 +39,36 @@ __device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(k & 
 // previous pass, else the pre-call holder
 __device__ __forceinline__ bool is_locked(const FtDevFrame &F, const FtClaims &C, int kp, int i) {
     int best = -1;
-    for (int s = C.head[kp]; s >= 0; s = C.next[s]) {
-        const int j = s >> 2;
-        if (j < i && j > best) best = j;
-    }
+    if (!C.firstPass)
+        for (int s = C.head[kp]; s >= 0; s = C.next[s]) {
+            const int j = s >> 2;
+            if (j < i && j > best) best = j;
+        }
     return best >= 0 ? C.obs[best] > 0 : F.holderObs[kp] > 0;
 }
 
 // start of a claim-iteration pass (see FtClaims): false = the iteration has converged, nothing to do
 __device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) {
-    if (C.changedPrev && *C.changedPrev == 0) return false;
+    if (C.flagPrev && *C.flagPrev == -1) return false;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
-    for (int k = t; k < C.nKp; k += T) C.headNext[k] = -1;
-    if (t == 0) *C.changedCur = 0;
+    for (int k = t; k < C.nKp; k += T) C.headClear[k] = -1;
+    if (t == 0) {
+        *C.flagReset = -1;
+        if (C.firstPass) *C.flagCur = 0;  // the first pass always "changes" its input
+    }
     return true;
+}
+
+// end of a point's turn in a pass: lane k files write kind k of point i - the result, the "changed" flag against the
+// previous pass, and the entry in the writer lists the NEXT pass will read (so a pass is one launch)
+__device__ __forceinline__ void claims_file(const FtClaims &C, int *res, int i, int lane, const int r4[4]) {
+    if (lane < 4) {
+        const int kp = lane == 0 ? r4[0] : lane == 1 ? r4[1] : lane == 2 ? r4[2] : r4[3];
+        const int s = 4 * i + lane;
+        if (!C.firstPass && kp != C.resPrev[s]) atomicAnd(C.flagCur, 0);
+        res[s] = kp;
+        if (kp >= 0) C.nextWrite[s] = atomicExch(&C.headWrite[kp], s);
+    }
 }
 
 struct Window {
@@ -133,12 +151,124 @@ __device__ __forceinline__ void wave_two_min(unsigned long long &k0, unsigned lo
     k1 = m1;
 }
 
-__global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPoints P, FtClaims C, float th,
-                                                      float nnRatio, int *res, FtLocalRaw raw) {
-    if (!claims_begin_pass(C)) return;
-    const int lane = threadIdx.x & 63, wave = wave_index();
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= P.M) return;
+// level band and box test of GetFeaturesInArea for a keypoint whose cell is already known to lie in the window
+__device__ __forceinline__ bool in_box(const ft_keypoint &kp, float x, float y, float r, int minLevel, int maxLevel) {
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    if (checkLevels) {
+        if (kp.octave < minLevel) return false;
+        if (maxLevel >= 0 && kp.octave > maxLevel) return false;
+    }
+    const float dx = __fsub_rn(kp.x, x), dy = __fsub_rn(kp.y, y);
+    return fabsf(dx) < r && fabsf(dy) < r;
+}
+
+// The keypoints of camera `cam` whose grid cell lies in window w, handed to fn(idx, cx, cy) lane-parallel.  With the
+// frame's CSR grid (k_build_grid) a column of cells is one contiguous range of entries - a map point looks at the
+// keypoints of its window only, as Frame::GetFeaturesInArea does; without it every keypoint's cell is computed and tested.
+template <class Fn>
+__device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const ft_keypoint *keys, int n, const Window &w, int lane,
+                                           Fn fn) {
+    if (F.gridStart[cam]) {
+        // The window's columns of cells are contiguous ranges of grid entries.  One lane per column fetches its range, a
+        // wave scan lays the ranges end to end, and the lanes then take the window's entries 64 at a time: the usual
+        // window (a few dozen keypoints in up to ~12 columns) is ONE round of dependent loads instead of one per column.
+        const int *gs = F.gridStart[cam], *gi = F.gridIdx[cam];
+        for (int c0 = w.minCX; c0 <= w.maxCX; c0 += 64) {
+            const int ncols = min(64, w.maxCX - c0 + 1);
+            int b = 0, cnt = 0;
+            if (lane < ncols) {
+                const int *col = gs + (c0 + lane) * FT_GRID_ROWS;
+                b = col[w.minCY];
+                cnt = col[w.maxCY + 1] - b;
+            }
+            int incl = cnt;  // inclusive scan over the lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(incl, d);
+                if (lane >= d) incl += y;
+            }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            for (int t0 = 0; t0 < total; t0 += 64) {
+                const int t = t0 + lane;
+                int colIdx = 0;  // the column entry t falls into: the number of columns that end at or before t
+                for (int c = 0; c < ncols - 1; c++) colIdx += t >= __builtin_amdgcn_readlane(incl, c) ? 1 : 0;
+                const int cb = __shfl(b, colIdx), cEnd = __shfl(incl, colIdx), cCnt = __shfl(cnt, colIdx);
+                if (t < total) {
+                    const int v = gi[cb + (t - (cEnd - cCnt))];
+                    fn(v & 0xffffff, c0 + colIdx, v >> 24);
+                }
+            }
+        }
+        return;
+    }
+    for (int idx = lane; idx < n; idx += 64) {
+        const ft_keypoint kp = keys[idx];
+        const int cx = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.mnMinX), F.invW));
+        const int cy = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.mnMinY), F.invH));
+        if (cx < 0 || cx >= FT_GRID_COLS || cy < 0 || cy >= FT_GRID_ROWS) continue;  // never entered the grid
+        if (cx < w.minCX || cx > w.maxCX || cy < w.minCY || cy > w.maxCY) continue;
+        fn(idx, cx, cy);
+    }
+}
+
+// Frame::AssignFeaturesToGrid (src/Frame.cc:409-440) as CSR: block 0 the left camera (or the only one), block 1 the
+// right camera of a two-camera frame.  Counting sort by cell cx * 48 + cy in LDS; the order inside a cell is free (the
+// searches order candidates by (distance, cx, cy, index) keys).
+__global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, int *idxL, int *startR, int *idxR) {
+    __shared__ int cnt[FT_GRID_CELLS + 1];
+    __shared__ int wsum[4];
+    const int cam = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = cam == 0 ? (F.Nleft == -1 ? F.N : F.Nleft) : (F.Nleft == -1 ? 0 : F.N - F.Nleft);
+    const ft_keypoint *keys = cam == 0 ? F.keys : F.keysR;
+    int *start = cam == 0 ? startL : startR, *out = cam == 0 ? idxL : idxR;
+    if (!start) return;
+    for (int c = tid; c <= FT_GRID_CELLS; c += 256) cnt[c] = 0;
+    __syncthreads();
+    auto cellOf = [&](int i) -> int {
+        const ft_keypoint kp = keys[i];
+        const int cx = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.mnMinX), F.invW));
+        const int cy = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.mnMinY), F.invH));
+        if (cx < 0 || cx >= FT_GRID_COLS || cy < 0 || cy >= FT_GRID_ROWS) return -1;
+        return cx * FT_GRID_ROWS + cy;
+    };
+    for (int i = tid; i < n; i += 256) {
+        const int c = cellOf(i);
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the 3072 counts: 12 consecutive cells per thread
+    constexpr int PER = FT_GRID_CELLS / 256;
+    int local = 0;
+    for (int k = 0; k < PER; k++) local += cnt[tid * PER + k];
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    for (int k = 0; k < PER; k++) {
+        const int c = tid * PER + k, v = cnt[c];
+        start[c] = run;
+        cnt[c] = run;  // becomes the fill cursor of the cell
+        run += v;
+    }
+    if (tid == 0) start[FT_GRID_CELLS] = total;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int c = cellOf(i);
+        if (c >= 0) out[atomicAdd(&cnt[c], 1)] = i | ((c % FT_GRID_ROWS) << 24);
+    }
+}
+
+// ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) for map point i by one wave (src/ORBmatcher.cc:49-225):
+// r = (primary left, side left, primary right, side right) keypoints it writes; raw outputs as the reference kernel's
+__device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
+                                            float nnRatio, int i, int lane, int r4[4], const FtLocalRaw &raw) {
     int primL = -1, sideL = -1, primR = -1, sideR = -1;
     int bd = 256, bd2 = 256, bl = -1, bl2 = -1, bi = -1;
     int bdr = 256, bd2r = 256, blr = -1, bl2r = -1, bir = -1;
@@ -159,20 +289,19 @@ __global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPo
             const Window w = cell_window(F, x, y, rad);
             unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
             if (!w.empty) {
-                for (int idx = lane; idx < nLeft; idx += 64) {
+                for_window(F, 0, F.keys, nLeft, w, lane, [&](int idx, int cx, int cy) {
                     const ft_keypoint kp = F.keys[idx];
-                    int cx, cy;
-                    if (!in_area(F, kp, w, x, y, rad, level - 1, level, cx, cy)) continue;
-                    if (is_locked(F, C, idx, i)) continue;
+                    if (!in_box(kp, x, y, rad, level - 1, level)) return;
+                    if (is_locked(F, C, idx, i)) return;
                     if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
                         const float er = fabsf(__fsub_rn(P.projXR[i], F.uright[idx]));
-                        if (er > rad) continue;
+                        if (er > rad) return;
                     }
                     const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
                     const unsigned long long key = make_key(dist, cx, cy, idx);
                     if (key < k0) { k1 = k0; k0 = key; }
                     else if (key < k1) k1 = key;
-                }
+                });
             }
             wave_two_min(k0, k1);
             if (k0 != KEY_NONE) {
@@ -203,19 +332,18 @@ __global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPo
                 const int nRight = F.N - F.Nleft;
                 unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
                 if (!w.empty) {
-                    for (int idx = lane; idx < nRight; idx += 64) {
+                    for_window(F, 1, F.keysR, nRight, w, lane, [&](int idx, int cx, int cy) {
                         const ft_keypoint kp = F.keysR[idx];
-                        int cx, cy;
-                        if (!in_area(F, kp, w, x, y, rad, level - 1, level, cx, cy)) continue;
+                        if (!in_box(kp, x, y, rad, level - 1, level)) return;
                         const int g = idx + F.Nleft;
                         // this point's own left-block side write precedes its right-block search
                         const bool locked = (g == sideL) ? (C.obs[i] > 0) : is_locked(F, C, g, i);
-                        if (locked) continue;
+                        if (locked) return;
                         const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)g * 32));
                         const unsigned long long key = make_key(dist, cx, cy, idx);
                         if (key < k0) { k1 = k0; k0 = key; }
                         else if (key < k1) k1 = key;
-                    }
+                    });
                 }
                 wave_two_min(k0, k1);
                 if (k0 != KEY_NONE) {
@@ -234,16 +362,22 @@ __global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPo
             }
         }
     }
-    if (lane == 0) {
-        res[4 * i] = primL;
-        res[4 * i + 1] = sideL;
-        res[4 * i + 2] = primR;
-        res[4 * i + 3] = sideR;
-        if (raw.bestDist) {  // the reference kernel's raw outputs are optional (the resident-frame path skips them)
-            raw.bestDist[i] = bd; raw.bestDist2[i] = bd2; raw.bestLevel[i] = bl; raw.bestLevel2[i] = bl2; raw.bestIdx[i] = bi;
-            raw.bestDistR[i] = bdr; raw.bestDist2R[i] = bd2r; raw.bestLevelR[i] = blr; raw.bestLevel2R[i] = bl2r; raw.bestIdxR[i] = bir;
-        }
+    r4[0] = primL; r4[1] = sideL; r4[2] = primR; r4[3] = sideR;
+    if (lane == 0 && raw.bestDist) {  // the reference kernel's raw outputs are optional (the resident-frame path skips them)
+        raw.bestDist[i] = bd; raw.bestDist2[i] = bd2; raw.bestLevel[i] = bl; raw.bestLevel2[i] = bl2; raw.bestIdx[i] = bi;
+        raw.bestDistR[i] = bdr; raw.bestDist2R[i] = bd2r; raw.bestLevelR[i] = blr; raw.bestLevel2R[i] = bl2r; raw.bestIdxR[i] = bir;
     }
+}
+
+__global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPoints P, FtClaims C, float th,
+                                                      float nnRatio, int *res, FtLocalRaw raw) {
+    if (!claims_begin_pass(C)) return;
+    const int lane = threadIdx.x & 63, wave = wave_index();
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= P.M) return;
+    int r4[4];
+    local_point(F, P, C, th, nnRatio, i, lane, r4, raw);
+    claims_file(C, res, i, lane, r4);
 }
 
 // camera models: src/CameraModels/Pinhole.cpp:43-49, KannalaBrandt8.cpp:67-84
@@ -276,12 +410,10 @@ __device__ __forceinline__ void transform34(const float *T, const float x[3], fl
                          T[4 * r + 3]);
 }
 
-__global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoints Lp, FtClaims C, FtPose Tcw, float th,
-                                                     int bForward, int bBackward, int *res, FtLastRaw raw) {
-    if (!claims_begin_pass(C)) return;
-    const int lane = threadIdx.x & 63, wave = wave_index();
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= Lp.N) return;
+// ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) for last-frame point i by one wave (src/ORBmatcher.cc:
+// 1775-1960): r = (left keypoint written, -1, right keypoint written, -1)
+__device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastPoints &Lp, const FtClaims &C, const FtPose &Tcw,
+                                           float th, int bForward, int bBackward, int i, int lane, int r4[4], const FtLastRaw &raw) {
     int primL = -1, primR = -1;
     int bd = 256, bi = -1, bdr = 256, bir = -1;
     if (Lp.valid[i]) {
@@ -313,21 +445,20 @@ __global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoin
             unsigned long long k0 = KEY_NONE;
             int anyCand = 0;
             if (!w.empty) {
-                for (int idx = lane; idx < nLeft; idx += 64) {
+                for_window(F, 0, F.keys, nLeft, w, lane, [&](int idx, int cx, int cy) {
                     const ft_keypoint kp = F.keys[idx];
-                    int cx, cy;
-                    if (!in_area(F, kp, w, uv[0], uv[1], radius, minLevel, maxLevel, cx, cy)) continue;
+                    if (!in_box(kp, uv[0], uv[1], radius, minLevel, maxLevel)) return;
                     anyCand = 1;
-                    if (is_locked(F, C, idx, i)) continue;
+                    if (is_locked(F, C, idx, i)) return;
                     if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
                         const float ur = __fsub_rn(uv[0], __fmul_rn(F.mbf, invzc));
                         const float er = fabsf(__fsub_rn(ur, F.uright[idx]));
-                        if (er > radius) continue;
+                        if (er > radius) return;
                     }
                     const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
                     const unsigned long long key = make_key(dist, cx, cy, idx);
                     k0 = key < k0 ? key : k0;
-                }
+                });
             }
             anyCand = __any(anyCand);
             k0 = wave_min_u64(k0);
@@ -346,15 +477,14 @@ __global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoin
                     const int nRight = F.N - F.Nleft;
                     unsigned long long kr = KEY_NONE;
                     if (!wr.empty) {
-                        for (int idx = lane; idx < nRight; idx += 64) {
+                        for_window(F, 1, F.keysR, nRight, wr, lane, [&](int idx, int cx, int cy) {
                             const ft_keypoint kp = F.keysR[idx];
-                            int cx, cy;
-                            if (!in_area(F, kp, wr, uvr[0], uvr[1], radius, minLevel, maxLevel, cx, cy)) continue;
-                            if (is_locked(F, C, idx + F.Nleft, i)) continue;
+                            if (!in_box(kp, uvr[0], uvr[1], radius, minLevel, maxLevel)) return;
+                            if (is_locked(F, C, idx + F.Nleft, i)) return;
                             const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)(idx + F.Nleft) * 32));
                             const unsigned long long key = make_key(dist, cx, cy, idx);
                             kr = key < kr ? key : kr;
-                        }
+                        });
                     }
                     kr = wave_min_u64(kr);
                     if (kr != KEY_NONE) {
@@ -366,15 +496,21 @@ __global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoin
             }
         }
     }
-    if (lane == 0) {
-        res[4 * i] = primL;
-        res[4 * i + 1] = -1;
-        res[4 * i + 2] = primR;
-        res[4 * i + 3] = -1;
-        if (raw.bestDist) {
-            raw.bestDist[i] = bd; raw.bestIdx[i] = bi; raw.bestDistR[i] = bdr; raw.bestIdxR[i] = bir;
-        }
+    r4[0] = primL; r4[1] = -1; r4[2] = primR; r4[3] = -1;
+    if (lane == 0 && raw.bestDist) {
+        raw.bestDist[i] = bd; raw.bestIdx[i] = bi; raw.bestDistR[i] = bdr; raw.bestIdxR[i] = bir;
     }
+}
+
+__global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoints Lp, FtClaims C, FtPose Tcw, float th,
+                                                     int bForward, int bBackward, int *res, FtLastRaw raw) {
+    if (!claims_begin_pass(C)) return;
+    const int lane = threadIdx.x & 63, wave = wave_index();
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= Lp.N) return;
+    int r4[4];
+    last_point(F, Lp, C, Tcw, th, bForward, bBackward, i, lane, r4, raw);
+    claims_file(C, res, i, lane, r4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -466,19 +602,22 @@ __global__ __launch_bounds__(256) void k_frustum(FtDevFrame F, FtFrustumPose T, 
     if (inView || inViewR) atomicAdd(O.count, 1);
 }
 
-// rebuild the per-keypoint writer lists from this pass's results and flag any change against the
-// previous pass
-__global__ __launch_bounds__(256) void k_build_claims(const int *res, const int *prevRes, int n4, int *head, int *next,
-                                                      int *changed, const int *changedPrev) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (changedPrev && *changedPrev == 0) {  // converged before this pass (its search kernel did not run either)
-        if (s == 0) *changed = 0;
-        return;
+// Result delivery of a search: up to three device blocks (dword granularity) written straight into pinned host memory by
+// one kernel - pass results, raw outputs / frustum fields, and the pass flags - instead of one DMA copy each (a small copy
+// is a few microseconds of work behind tens of microseconds of queueing).
+struct FtBlocks {
+    void *dst[3];
+    const void *src[3];
+    int words[3];
+};
+__global__ __launch_bounds__(256) void k_deliver_blocks(FtBlocks b) {
+    const int t = blockIdx.x * 256 + threadIdx.x, T = gridDim.x * 256;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        unsigned *d = (unsigned *)b.dst[k];
+        const unsigned *s = (const unsigned *)b.src[k];
+        for (int i = t; i < b.words[k]; i += T) d[i] = s[i];
     }
-    if (s >= n4) return;
-    const int kp = res[s];
-    if (kp != prevRes[s]) atomicOr(changed, 1);
-    if (kp >= 0) next[s] = atomicExch(&head[kp], s);
 }
 
 __global__ __launch_bounds__(256) void k_fill_i32(int *p, int n, int v) {
@@ -487,6 +626,19 @@ __global__ __launch_bounds__(256) void k_fill_i32(int *p, int n, int v) {
 }
 
 }  // namespace
+
+int ft_launch_deliver_blocks(hipStream_t st, void *d0, const void *s0, size_t bytes0, void *d1, const void *s1, size_t bytes1,
+                             void *d2, const void *s2, size_t bytes2) {
+    FtBlocks b;
+    b.dst[0] = d0; b.src[0] = s0; b.words[0] = (int)((bytes0 + 3) / 4);
+    b.dst[1] = d1; b.src[1] = s1; b.words[1] = (int)((bytes1 + 3) / 4);
+    b.dst[2] = d2; b.src[2] = s2; b.words[2] = (int)((bytes2 + 3) / 4);
+    const int total = b.words[0] + b.words[1] + b.words[2];
+    if (total <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_deliver_blocks, dim3(std::max(1, std::min(64, (total + 1023) / 1024))), dim3(256), 0, st, b);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
 
 int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v) {
     if (n <= 0) return FT_OK;
@@ -516,6 +668,12 @@ int ft_launch_features_in_area(hipStream_t st, const FtDevFrame &F, int nq, cons
     return FT_OK;
 }
 
+int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridIdxL, int *gridStartR, int *gridIdxR) {
+    hipLaunchKernelGGL(k_build_grid, dim3(gridStartR ? 2 : 1), dim3(256), 0, st, F, gridStartL, gridIdxL, gridStartR, gridIdxR);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
 int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
                            float nnRatio, int *res, const FtLocalRaw &raw) {
     if (P.M <= 0) return FT_OK;
@@ -528,17 +686,6 @@ int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPo
                           const FtPose &Tcw, float th, int forward, int backward, int *res, const FtLastRaw &raw) {
     if (L.N <= 0) return FT_OK;
     hipLaunchKernelGGL(k_search_last, dim3((L.N + 3) / 4), dim3(256), 0, st, F, L, C, Tcw, th, forward, backward, res, raw);
-    FT_HIP(hipGetLastError());
-    return FT_OK;
-}
-
-// head / changed have been reset by the search kernel of this pass (claims_begin_pass)
-int ft_launch_build_claims(hipStream_t st, const int *res, const int *prevRes, int nPoints, int *head, int *next,
-                           int *changed, const int *changedPrev) {
-    const int n4 = 4 * nPoints;
-    if (n4 > 0)
-        hipLaunchKernelGGL(k_build_claims, dim3((n4 + 255) / 256), dim3(256), 0, st, res, prevRes, n4, head, next, changed,
-                           changedPrev);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

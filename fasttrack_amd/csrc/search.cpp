@@ -94,65 +94,117 @@ FtDevFrame devFrame(const ft_frame_view *F, const FrameLayout &L, uint8_t *dev) 
     return D;
 }
 
-// runs `search` passes until a pass changes nothing; leaves the final results in resFinal (device).
-// A pass is two launches: the search kernel - which also resets the list heads and the flag its k_build_claims will
-// write (claims_begin_pass) - and k_build_claims.  Passes are enqueued in bursts of FT_PASS_BURST without waiting in
-// between; every kernel of a pass first looks at the previous pass's `changed` flag and returns at once when the
-// fixed point has been reached (such a pass would reproduce its input), so the surplus passes of a burst cost two
-// empty launches each while every avoided round trip (D2H of the flags + stream sync) costs ~100 us.
-// `changed` holds one flag per pass of a burst; the caller's claims struct C is set up per pass (search reads it).
+// Runs `search` passes until a pass changes nothing; the final results are on the host (through `download`) when it returns.
+// A pass is ONE launch: the search kernel files every point's writes in the writer lists the next pass reads (three rotating
+// head arrays: read / write / clear) and flags any change against the previous pass's results.  Passes are enqueued in
+// bursts of FT_PASS_BURST without waiting in between; a pass first looks at the previous pass's flag and returns at once
+// when the fixed point has been reached (it would reproduce its input), so the surplus passes of a burst cost an empty
+// launch each while every avoided round trip (D2H of the flags + stream sync) costs ~100 us.  One memset (0xff: list heads
+// = -1, flags = "unchanged") prepares a call.
 #define FT_PASS_BURST 6
-// `download(res)` enqueues the device-to-host copies of whatever the caller needs from the pass results `res`; it runs
-// behind every burst, in front of the one stream synchronisation that also brings the flags - the results are on the
-// host when fixedPoint returns.
+// device buffers of the claim iteration: res 2 x 4 nPoints ints, head 3 x nKp directly followed by 16 flag ints (two burst
+// parities x FT_PASS_BURST), next 2 x 4 nPoints
+struct PassBufs {
+    int *res, *head, *next;
+    const int *obs;
+};
+// `download(res, flags, nFlagBytes)` enqueues ONE delivery kernel that writes the pass results `res`, whatever else the
+// caller needs and the burst's flags into pinned host memory (hostFlags); it runs behind every burst, in front of the one
+// stream synchronisation.
 template <typename SearchFn, typename DownloadFn>
-int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, int *resA, int *resB, int *headA, int *headB,
-               int *next, int *changed, FtClaims &C, SearchFn search, DownloadFn download, int **resFinal, int *passes) {
-    *resFinal = resA;
+int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const PassBufs &B, FtClaims &C, SearchFn search,
+               DownloadFn download, const int *hostFlags, int **resFinal, int *passes) {
+    (void)ctx;
+    *resFinal = B.res;
     *passes = 0;
     if (nPoints <= 0) {
-        int rc0 = download(resA);
+        int rc0 = download(B.res, nullptr, 0);
         if (rc0 != FT_OK) return rc0;
         FT_HIP(hipStreamSynchronize(st));
         return FT_OK;
     }
-    int rc = ft_launch_fill_i32(st, headA, nKp, -1);  // no claims before the first pass
-    if (rc != FT_OK) return rc;
-    rc = ft_launch_fill_i32(st, resB, 4 * nPoints, -2);
-    if (rc != FT_OK) return rc;
-    int *cur = resA, *prev = resB;
-    int *headRead = headA, *headWrite = headB;
-    int pass = 0;
+    const size_t K = (size_t)std::max(nKp, 1);
+    int *flags = B.head + 3 * K;
+    {   // list heads = -1, flags = "unchanged" (-1)
+        const int rcf = ft_launch_fill_i32(st, B.head, (int)(3 * K + 16), -1);
+        if (rcf != FT_OK) return rcf;
+    }
+    int pass = 0, burst = 0;
     const int maxPasses = 2 * nPoints + 4 + FT_PASS_BURST;
-    C.next = next;
+    C.obs = B.obs;
     C.nKp = nKp;
-    for (;;) {
-        for (int b = 0; b < FT_PASS_BURST; b++) {
-            C.head = headRead;
-            C.headNext = headWrite;
-            C.changedCur = changed + b;
-            C.changedPrev = b > 0 ? changed + b - 1 : nullptr;
-            rc = search(cur);
+    int *last = B.res;
+    for (;; burst++) {
+        int *fl = flags + 8 * (burst & 1), *flOther = flags + 8 * ((burst + 1) & 1);
+        for (int b = 0; b < FT_PASS_BURST; b++, pass++) {
+            C.firstPass = pass == 0;
+            C.head = B.head + (size_t)(pass % 3) * K;
+            C.headWrite = B.head + (size_t)((pass + 1) % 3) * K;
+            C.headClear = B.head + (size_t)((pass + 2) % 3) * K;
+            C.next = B.next + (size_t)((pass + 1) & 1) * 4 * nPoints;
+            C.nextWrite = B.next + (size_t)(pass & 1) * 4 * nPoints;
+            C.resPrev = B.res + (size_t)((pass + 1) & 1) * 4 * nPoints;
+            C.flagCur = fl + b;
+            C.flagPrev = b > 0 ? fl + b - 1 : nullptr;
+            C.flagReset = flOther + b;
+            last = B.res + (size_t)(pass & 1) * 4 * nPoints;
+            const int rc = search(last);
             if (rc != FT_OK) return rc;
-            rc = ft_launch_build_claims(st, cur, prev, nPoints, headWrite, next, changed + b, C.changedPrev);
-            if (rc != FT_OK) return rc;
-            std::swap(cur, prev);
-            std::swap(headRead, headWrite);
-            pass++;
         }
-        rc = download(prev);  // `prev` holds the results of the last pass
+        // after a converged burst both result buffers hold the fixed point (the last pass that ran reproduced its input)
+        int rc = download(last, fl, sizeof(int) * FT_PASS_BURST);
         if (rc != FT_OK) return rc;
-        int h[FT_PASS_BURST];
-        FT_HIP(hipMemcpyAsync(h, changed, sizeof h, hipMemcpyDeviceToHost, st));
         FT_HIP(hipStreamSynchronize(st));
-        if (!h[FT_PASS_BURST - 1]) break;  // the last pass of the burst changed nothing: `prev` is the fixed point
+        const int *h = hostFlags;
+        if (h[FT_PASS_BURST - 1] == -1) {  // the last pass of the burst changed nothing (or did not have to run)
+            int ran = 0;
+            while (ran < FT_PASS_BURST && h[ran] != -1) ran++;
+            pass = pass - FT_PASS_BURST + std::min(ran + 1, FT_PASS_BURST);
+            break;
+        }
         if (pass >= maxPasses) {
             ft_set_error("projection search: claim resolution did not converge");
             return FT_ERR_HIP;
         }
     }
-    *resFinal = prev;
+    *resFinal = last;
     *passes = pass;
+    return FT_OK;
+}
+
+// arena space of the claim iteration for M points on a frame of N keypoints
+struct PassLayout {
+    size_t res, head, next;
+};
+PassLayout layoutPasses(Arena &a, int M, int N) {
+    PassLayout L;
+    L.res = a.take(32 * (size_t)M);
+    L.head = a.take(12 * (size_t)std::max(N, 1) + 64);
+    L.next = a.take(32 * (size_t)M);
+    return L;
+}
+PassBufs passBufs(const PassLayout &L, uint8_t *dev, const int *obs) {
+    PassBufs B;
+    B.res = (int *)(dev + L.res);
+    B.head = (int *)(dev + L.head);
+    B.next = (int *)(dev + L.next);
+    B.obs = obs;
+    return B;
+}
+// Frame::mGrid of a frame staged in the arena: CSR arrays behind the frame's own, built by one small launch
+size_t layoutGrid(Arena &a, int N) { return a.take(sizeof(int) * (2 * (size_t)(FT_GRID_CELLS + 1) + (size_t)std::max(N, 1))); }
+int buildGrid(hipStream_t st, FtDevFrame &DF, int *grid) {
+    static const bool gridOn = !(getenv("FT_SEARCH_GRID") && atoi(getenv("FT_SEARCH_GRID")) == 0);
+    if (!gridOn) return FT_OK;
+    const int nL = DF.Nleft == -1 ? DF.N : DF.Nleft;
+    int *startL = grid, *startR = grid + (FT_GRID_CELLS + 1), *idx = grid + 2 * (FT_GRID_CELLS + 1);
+    const bool two = DF.Nleft != -1;
+    const int rc = ft_launch_build_grid(st, DF, startL, idx, two ? startR : nullptr, two ? idx + nL : nullptr);
+    if (rc != FT_OK) return rc;
+    DF.gridStart[0] = startL;
+    DF.gridIdx[0] = idx;
+    DF.gridStart[1] = two ? startR : nullptr;
+    DF.gridIdx[1] = two ? idx + nL : nullptr;
     return FT_OK;
 }
 
@@ -372,6 +424,7 @@ struct ft_tracked_frame {
     uint8_t *d_desc = nullptr;
     float *d_uright = nullptr;
     int *d_holder = nullptr, *d_l2r = nullptr, *d_r2l = nullptr;
+    int *d_grid = nullptr;                         // Frame::mGrid as CSR (both cameras), built when a frame is loaded
     uint8_t *d_work = nullptr, *h_work = nullptr;  // per-call arena (points, passes, outputs) and its pinned mirror
     int *h_holderUp = nullptr;                       // pinned source of the holder_obs uploads (see uploadHolder)
     size_t workBytes = 0;
@@ -434,8 +487,8 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
                  oPyr = a.take(4 * (size_t)M);
     const size_t oDesc = a.take(32 * (size_t)M), oObs = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(8 * (size_t)std::max(N, 1)),
-                 oNext = a.take(16 * (size_t)M), oChanged = a.take(64);
+    const PassLayout PL = layoutPasses(a, M, N);
+    const size_t oGrid = layoutGrid(a, N);
     const size_t oRaw = a.take(40 * (size_t)M);
     const size_t total = a.off;
     const size_t outBytes = 16 * (size_t)M + 40 * (size_t)M + 64;
@@ -458,7 +511,9 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     memcpy(pin + oObs, P->observations, 4 * (size_t)M);
     hipStream_t st = ctx->stream;
     FT_HIP(hipMemcpyAsync(dev, pin, inputBytes, hipMemcpyHostToDevice, st));
-    const FtDevFrame DF = devFrame(F, FL, dev);
+    FtDevFrame DF = devFrame(F, FL, dev);
+    rc = buildGrid(st, DF, (int *)(dev + oGrid));
+    if (rc != FT_OK) return rc;
     FtDevLocalPoints DP;
     DP.M = M;
     DP.skip = dev + oSkip; DP.inView = dev + oIn; DP.inViewR = dev + oInR;
@@ -468,8 +523,6 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     DP.projXR = (const float *)(dev + oPxr); DP.projYR = (const float *)(dev + oPyr);
     DP.desc = dev + oDesc;
     FtClaims C;
-    C.head = (const int *)(dev + oHead);
-    C.next = (const int *)(dev + oNext);
     C.obs = (const int *)(dev + oObs);
     int *rawBase = (int *)(dev + oRaw);
     FtLocalRaw raw;
@@ -477,15 +530,13 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     raw.bestIdx = rawBase + 4 * M; raw.bestDistR = rawBase + 5 * M; raw.bestDist2R = rawBase + 6 * M;
     raw.bestLevelR = rawBase + 7 * M; raw.bestLevel2R = rawBase + 8 * M; raw.bestIdxR = rawBase + 9 * M;
     int *resFinal = nullptr, passes = 0;
-    rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
-                    (int *)(dev + oNext), (int *)(dev + oChanged), C,
+    rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs), C,
                     [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); },
-                    [&](int *res) -> int {
-                        FT_HIP(hipMemcpyAsync(pin, res, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
-                        FT_HIP(hipMemcpyAsync(pin + 16 * (size_t)M + 64, rawBase, 40 * (size_t)M, hipMemcpyDeviceToHost, st));
-                        return FT_OK;
+                    [&](int *res, const int *fl, size_t flBytes) -> int {
+                        return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M + 64, rawBase, 40 * (size_t)M,
+                                                        pin + 16 * (size_t)M, fl, flBytes);
                     },
-                    &resFinal, &passes);
+                    (const int *)(pin + 16 * (size_t)M), &resFinal, &passes);
     if (rc != FT_OK) return rc;
     int *hRes = (int *)pin, *hRaw = (int *)(pin + 16 * (size_t)M + 64);
     for (int k = 0; k < 10; k++)
@@ -528,8 +579,8 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     const size_t oValid = a.take(M), oPos = a.take(12 * (size_t)M), oDesc = a.take(32 * (size_t)M),
                  oObs = a.take(4 * (size_t)M), oOct = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(8 * (size_t)std::max(N, 1)),
-                 oNext = a.take(16 * (size_t)M), oChanged = a.take(64);
+    const PassLayout PL = layoutPasses(a, M, N);
+    const size_t oGrid = layoutGrid(a, N);
     const size_t oRaw = a.take(16 * (size_t)M);
     const size_t total = a.off;
     const size_t outBytes = 32 * (size_t)M + 64;
@@ -544,7 +595,9 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     memcpy(pin + oOct, L->octave, 4 * (size_t)M);
     hipStream_t st = ctx->stream;
     FT_HIP(hipMemcpyAsync(dev, pin, inputBytes, hipMemcpyHostToDevice, st));
-    const FtDevFrame DF = devFrame(Cur, FL, dev);
+    FtDevFrame DF = devFrame(Cur, FL, dev);
+    rc = buildGrid(st, DF, (int *)(dev + oGrid));
+    if (rc != FT_OK) return rc;
     FtDevLastPoints DL;
     DL.N = M;
     DL.valid = dev + oValid;
@@ -552,8 +605,6 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     DL.desc = dev + oDesc;
     DL.octave = (const int *)(dev + oOct);
     FtClaims C;
-    C.head = (const int *)(dev + oHead);
-    C.next = (const int *)(dev + oNext);
     C.obs = (const int *)(dev + oObs);
     FtPose pose;
     memcpy(pose.m, Tcw, sizeof pose.m);
@@ -561,15 +612,13 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     FtLastRaw raw;
     raw.bestDist = rawBase; raw.bestIdx = rawBase + M; raw.bestDistR = rawBase + 2 * M; raw.bestIdxR = rawBase + 3 * M;
     int *resFinal = nullptr, passes = 0;
-    rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
-                    (int *)(dev + oNext), (int *)(dev + oChanged), C,
+    rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
-                    [&](int *res) -> int {
-                        FT_HIP(hipMemcpyAsync(pin, res, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
-                        FT_HIP(hipMemcpyAsync(pin + 16 * (size_t)M + 64, rawBase, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
-                        return FT_OK;
+                    [&](int *res, const int *fl, size_t flBytes) -> int {
+                        return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M + 64, rawBase, 16 * (size_t)M,
+                                                        pin + 16 * (size_t)M, fl, flBytes);
                     },
-                    &resFinal, &passes);
+                    (const int *)(pin + 16 * (size_t)M), &resFinal, &passes);
     if (rc != FT_OK) return rc;
     int *hRes = (int *)pin, *hRaw = (int *)(pin + 16 * (size_t)M + 64);
     for (int k = 0; k < 4; k++)
@@ -718,7 +767,7 @@ int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, 
     tf->maxPts = max_points;
     const size_t K = (size_t)max_keypoints, M = (size_t)max_points;
     // arena of one call: map points (<= 72 B) + frustum outputs (<= 48 B) + passes / raw outputs (<= 104 B) per point
-    tf->workBytes = 256 * M + 8 * K + 4096;
+    tf->workBytes = 320 * M + 16 * K + 8192;
     hipError_t e = hipMalloc((void **)&tf->d_keys, sizeof(ft_keypoint) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_keysR, sizeof(ft_keypoint) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_desc, 32 * K);
@@ -727,6 +776,7 @@ int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, 
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_l2r, sizeof(int) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_r2l, sizeof(int) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_work, tf->workBytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&tf->d_grid, sizeof(int) * (2 * (size_t)(FT_GRID_CELLS + 1) + K));
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_work, tf->workBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_holderUp, sizeof(int) * K, hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -742,7 +792,7 @@ int ft_tracked_frame_destroy(ft_tracked_frame *tf) {
     ft_set_device(tf->ctx);
     hipStreamSynchronize(tf->ctx->stream);
     hipFree(tf->d_keys); hipFree(tf->d_keysR); hipFree(tf->d_desc); hipFree(tf->d_uright);
-    hipFree(tf->d_holder); hipFree(tf->d_l2r); hipFree(tf->d_r2l); hipFree(tf->d_work);
+    hipFree(tf->d_holder); hipFree(tf->d_l2r); hipFree(tf->d_r2l); hipFree(tf->d_work); hipFree(tf->d_grid);
     if (tf->h_work) hipHostFree(tf->h_work);
     if (tf->h_holderUp) hipHostFree(tf->h_holderUp);
     delete tf;
@@ -769,7 +819,6 @@ int ft_tracked_frame_upload(ft_tracked_frame *tf, const ft_frame_view *F) {
         if (nR) FT_HIP(hipMemcpyAsync(tf->d_r2l, F->right_to_left, sizeof(int) * nR, hipMemcpyHostToDevice, st));
     }
     if (F->N) FT_HIP(hipMemcpyAsync(tf->d_holder, F->holder_obs, sizeof(int) * F->N, hipMemcpyHostToDevice, st));
-    FT_HIP(hipStreamSynchronize(st));
     tf->DF = devFrameConstants(F);
     tf->DF.keys = tf->d_keys;
     tf->DF.keysR = tf->d_keysR;
@@ -778,6 +827,9 @@ int ft_tracked_frame_upload(ft_tracked_frame *tf, const ft_frame_view *F) {
     tf->DF.holderObs = tf->d_holder;
     tf->DF.l2r = F->Nleft != -1 ? tf->d_l2r : nullptr;
     tf->DF.r2l = F->Nleft != -1 ? tf->d_r2l : nullptr;
+    rc = buildGrid(st, tf->DF, tf->d_grid);  // the grid of the frame, once: both searches look up their windows in it
+    if (rc != FT_OK) return rc;
+    FT_HIP(hipStreamSynchronize(st));
     tf->angles.resize(F->N);
     for (int i = 0; i < nL; i++) tf->angles[i] = F->keys[i].angle;
     for (int i = 0; i < nR; i++) tf->angles[nL + i] = F->keys_right[i].angle;
@@ -814,6 +866,8 @@ int ft_tracked_frame_bind_stereo(ft_tracked_frame *tf, ft_stereo_frontend *fe, i
     tf->angles.resize(N);
     for (int i = 0; i < N; i++) tf->angles[i] = meta->keys[i].angle;
     if (N) FT_HIP(hipMemcpy(tf->d_holder, tf->holder.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+    rc = buildGrid(tf->ctx->stream, tf->DF, tf->d_grid);  // ordered in front of the searches on the context stream
+    if (rc != FT_OK) return rc;
     tf->loaded = true;
     return FT_OK;
 }
@@ -845,8 +899,7 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     const size_t oValid = a.take(M), oPos = a.take(12 * (size_t)M), oDesc = a.take(32 * (size_t)M),
                  oObs = a.take(4 * (size_t)M), oOct = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(8 * (size_t)std::max(N, 1)),
-                 oNext = a.take(16 * (size_t)M), oChanged = a.take(64);
+    const PassLayout PL = layoutPasses(a, M, N);
     FT_REQUIRE(a.off <= tf->workBytes, "tracked frame work arena too small");
     uint8_t *pin = tf->h_work, *dev = tf->d_work;
     memcpy(pin + oValid, L->valid, M);
@@ -863,22 +916,18 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     DL.desc = dev + oDesc;
     DL.octave = (const int *)(dev + oOct);
     FtClaims C;
-    C.head = (const int *)(dev + oHead);
-    C.next = (const int *)(dev + oNext);
     C.obs = (const int *)(dev + oObs);
     FtPose pose;
     memcpy(pose.m, Tcw, sizeof pose.m);
     FtLastRaw raw = {nullptr, nullptr, nullptr, nullptr};
     int *resFinal = nullptr, passes = 0;
     const FtDevFrame DF = tf->DF;
-    rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
-                    (int *)(dev + oNext), (int *)(dev + oChanged), C,
+    rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
-                    [&](int *res) -> int {
-                        FT_HIP(hipMemcpyAsync(pin, res, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
-                        return FT_OK;
+                    [&](int *res, const int *fl, size_t flBytes) -> int {
+                        return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M, fl, flBytes, nullptr, nullptr, 0);
                     },
-                    &resFinal, &passes);
+                    (const int *)(pin + 16 * (size_t)M), &resFinal, &passes);
     if (rc != FT_OK) return rc;
     int *hRes = (int *)pin;
     const int nm = replayLastFrameWrites(hRes, M, L, [&](int idx) { return tf->angles[idx]; }, check_orientation != 0,
@@ -917,8 +966,7 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
     layoutFrustum(M, P->skip != nullptr, a, FL, &fInputEnd);
     const size_t fOutEnd = a.off;
     const size_t oDesc = a.take(32 * (size_t)M), oObs = a.take(4 * (size_t)M);
-    const size_t oResA = a.take(16 * (size_t)M), oResB = a.take(16 * (size_t)M), oHead = a.take(8 * (size_t)std::max(N, 1)),
-                 oNext = a.take(16 * (size_t)M), oChanged = a.take(64);
+    const PassLayout PL = layoutPasses(a, M, N);
     FT_REQUIRE(a.off <= tf->workBytes, "tracked frame work arena too small");
     uint8_t *pin = tf->h_work, *dev = tf->d_work;
     stageFrustum(P, FL, pin);
@@ -943,21 +991,17 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
         DP.projX = FO.projX; DP.projY = FO.projY; DP.projXR = FO.projXR; DP.projYR = FO.projYR;
         DP.desc = dev + oDesc;
         FtClaims C;
-        C.head = (const int *)(dev + oHead);
-        C.next = (const int *)(dev + oNext);
         C.obs = (const int *)(dev + oObs);
         FtLocalRaw raw;
         memset(&raw, 0, sizeof raw);
         int *resFinal = nullptr;
-        rc = fixedPoint(ctx, st, M, N, (int *)(dev + oResA), (int *)(dev + oResB), (int *)(dev + oHead), (int *)(dev + oHead) + std::max(N, 1),
-                        (int *)(dev + oNext), (int *)(dev + oChanged), C,
+        rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs), C,
                         [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); },
-                        [&](int *res) -> int {  // pass results and the frustum fields travel behind the same burst
-                            FT_HIP(hipMemcpyAsync(pin + fOutEnd, res, 16 * (size_t)M, hipMemcpyDeviceToHost, st));
-                            FT_HIP(hipMemcpyAsync(pin, dev + fInputEnd, fOutEnd - fInputEnd, hipMemcpyDeviceToHost, st));
-                            return FT_OK;
+                        [&](int *res, const int *fl, size_t flBytes) -> int {  // pass results, frustum fields and flags: one kernel
+                            return ft_launch_deliver_blocks(st, pin + fOutEnd, res, 16 * (size_t)M, pin, dev + fInputEnd, fOutEnd - fInputEnd,
+                                                            pin + fOutEnd + 16 * (size_t)M, fl, flBytes);
                         },
-                        &resFinal, &passes);
+                        (const int *)(pin + fOutEnd + 16 * (size_t)M), &resFinal, &passes);
         if (rc != FT_OK) return rc;
         int *hRes = (int *)(pin + fOutEnd);
         unpackFrustum(M, FL, fInputEnd, pin, frustum, n_to_match);
