@@ -279,13 +279,29 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
         return ft_launch_upload(ex->stream, batch, ex->h_srcTab, width, height, ex->d_pyr + g.lv[0].off, g.lv[0].pitch,
                                 g.pyrPerSlot, ex->d_l0);
     }
+    // host frames laid out at a constant distance from each other (a camera ring buffer, a decoded clip): the whole batch
+    // goes up as ONE strided copy - rows of the copy = frames - instead of one DMA operation per frame
+    bool oneCopy = false;
+    if (!on_device && !ex->stageHost && batch >= 4 && stride == width && g.lv[0].pitch == width) {
+        oneCopy = images[0] != nullptr;
+        const ptrdiff_t delta = oneCopy && images[1] ? images[1] - images[0] : 0;
+        if (delta < (ptrdiff_t)width * height) oneCopy = false;
+        for (int b = 1; b < batch && oneCopy; b++)
+            if (!images[b] || images[b] - images[b - 1] != delta) oneCopy = false;
+        if (oneCopy) {
+            FT_HIP(hipMemcpy2DAsync(ex->d_pyr + g.lv[0].off, g.pyrPerSlot, images[0], (size_t)delta, (size_t)width * height, batch,
+                                    hipMemcpyHostToDevice, ex->stream));
+        }
+    }
     for (int b = 0; b < batch; b++) {
         if (!images[b]) {
             ft_set_error("extract: empty image");
             return FT_ERR_EMPTY;
         }
         uint8_t *slot0 = ex->d_pyr + (size_t)b * g.pyrPerSlot + g.lv[0].off;
-        if (on_device) {
+        if (oneCopy) {
+            ex->h_l0[b] = slot0;
+        } else if (on_device) {
             ex->h_l0[b] = images[b];
         } else if (ex->stageHost) {
             // graph path: the frame is copied into pinned staging by the host, the (captured) upload reads from there

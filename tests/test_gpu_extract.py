@@ -115,6 +115,24 @@ def test_fast_strips_variant_bit_exact(ctx, w, h, nf, rows, monkeypatch):
         assert gc.shape == oc.shape and np.array_equal(gc, oc), f"FAST candidates level {level}"
 
 
+def test_equally_spaced_host_frames_go_up_as_one_copy(ctx):
+    """host frames at a constant distance (a ring buffer / clip in one allocation, stride == width == slot pitch): the batch is
+    uploaded by one strided copy; same results as the oracle, also with a gap between the frames and for a 3-frame batch
+    (below the one-copy threshold)"""
+    w, h, nf = 640, 480, 800
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=6)
+    oex = ob.Extractor(nf)
+    clip = np.zeros((6, h + 7, w), np.uint8)  # 7 spare rows between the frames
+    for b in range(6):
+        clip[b, :h] = synth.make_image(w, h, seed=80 + b)
+    for frames in ([clip[b, :h] for b in range(6)], [clip[b, :h] for b in range(3)]):
+        assert all(f.flags["C_CONTIGUOUS"] for f in frames)
+        res = ex.extract_batch(frames)
+        for f, (gk, gd, gm) in zip(frames, res):
+            ok, od, om = oex.extract(f)
+            _check_same(gk, gd, ok, od)
+
+
 def test_lapping_area_partition(ctx):
     """fisheye / monocular callers pass a lapping area: keypoints inside fill from the back (ORBextractor.cc:1476-1485)"""
     w, h, nf = 512, 512, 2000
