@@ -420,9 +420,9 @@ int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent
     a.selCount = ex->d_selCount + (size_t)b0 * g.nlevels;
     a.overflow = ex->d_overflow;
     a.ovSlot = ex->d_ovSlot + b0;
-    // second tier (levels with more than FT_OCT_MAXN candidates): small batches always get a workgroup per level, large
-    // ones the grid the previous batches asked for (0 while the frames do not need it)
-    a.bigCap = a.bigN ? (ex->lastBatch <= 16 ? nb * g.nlevels : std::min(ex->bigGrid, nb * g.nlevels)) : 0;
+    // second tier (levels with more than FT_OCT_MAXN candidates): the grid the previous batches asked for (0 while the
+    // frames do not need it: a workgroup that wants a CU's whole LDS is not free even when it has nothing to do)
+    a.bigCap = a.bigN ? std::min(ex->bigGrid, nb * g.nlevels) : 0;
     const bool tm = ex->ctx->kernelTiming;
     ex->evt.begin(tm, "kernel.octree", so);
     int rc = ft_launch_octree(so, g, nb, a);
@@ -481,7 +481,13 @@ int ft_extract_octree(ft_extractor *ex, int b0, int nb) { return ft_extract_octr
 // After a large batch has drained: size the second-tier octree kernel of the following batches by what this one asked for
 // (levels with more than FT_OCT_MAXN candidates per launch), and retire it after a run of batches without demand.
 void ft_extract_update_big_grid(ft_extractor *ex) {
-    if (!ex->octLayout.bigN || ex->lastBatch <= 16) return;
+    if (!ex->octLayout.bigN) return;
+    if (ex->lastBatch <= 16) {
+        // latency mode (results delivered by one kernel, no demand counter on the host): an overflow of a frame switches the
+        // second tier on for the frames that follow (the captured graph is re-captured: its key holds the grid)
+        if (ex->h_overflow[0] && ex->bigGrid == 0) ex->bigGrid = ex->maxBatch * ex->nlevels;
+        return;
+    }
     const int want = ex->h_bigStat[0];
     ex->h_bigStat[0] = 0;
     if (want > 0) {
@@ -1014,6 +1020,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
             ft_extractor::GraphKey key;
             key.batch = batch; key.onDevice = on_device; key.width = width; key.height = height; key.stride = stride;
             key.aligned = 1;
+            key.bigGrid = ex->bigGrid;
             if (on_device) {
                 if (stride & 3) key.aligned = 0;
                 for (int b = 0; b < batch; b++)
@@ -1064,6 +1071,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
             if (launched) {
                 ex->ctx->addStat("extract.device_octree_batches", 0);
                 FT_HIP(hipStreamSynchronize(ex->stream));
+                ft_extract_update_big_grid(ex);
                 if (ex->h_overflow[0]) {  // some image met a level beyond the device octree's limits: that image is repaired
                     rc = repairOverflow();
                     if (rc != FT_OK) return rc;

@@ -108,10 +108,10 @@ struct ft_extractor {
     // latency mode of ft_extract / ft_extract_batch: a small batch with a fixed call shape is captured once as a HIP
     // graph (see ft_stereo_frontend::GraphKey); the key is everything baked into the nodes
     struct GraphKey {
-        int batch = 0, onDevice = 0, width = 0, height = 0, stride = 0, aligned = 0;
+        int batch = 0, onDevice = 0, width = 0, height = 0, stride = 0, aligned = 0, bigGrid = 0;
         bool operator==(const GraphKey &o) const {
             return batch == o.batch && onDevice == o.onDevice && width == o.width && height == o.height && stride == o.stride &&
-                   aligned == o.aligned;
+                   aligned == o.aligned && bigGrid == o.bigGrid;
         }
     } graphKey;
     hipGraphExec_t graphExec = nullptr;
@@ -189,10 +189,12 @@ struct ft_stereo_frontend {
     // that is baked into the captured nodes.
     struct GraphKey {
         int batch = 0, onDevice = 0, width = 0, height = 0, stride = 0, capacity = 0, alignedL = 0, alignedR = 0, paired = 0;
+        int bigGridL = 0, bigGridR = 0;
         const void *out[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         bool operator==(const GraphKey &o) const {
             if (batch != o.batch || onDevice != o.onDevice || width != o.width || height != o.height || stride != o.stride ||
-                capacity != o.capacity || alignedL != o.alignedL || alignedR != o.alignedR || paired != o.paired)
+                capacity != o.capacity || alignedL != o.alignedL || alignedR != o.alignedR || paired != o.paired ||
+                bigGridL != o.bigGridL || bigGridR != o.bigGridR)
                 return false;
             for (int i = 0; i < 6; i++)
                 if (out[i] != o.out[i]) return false;

@@ -389,6 +389,13 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
 // compacted in row-major order with ballot/popcount prefix sums (no atomics: the octree's result
 // depends on candidate order).
 // ------------------------------------------------------------------------------------------------
+typedef unsigned short fs_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(fs_us2, a), __builtin_bit_cast(fs_us2, b)));
+}
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(fs_us2, a), __builtin_bit_cast(fs_us2, b)));
+}
 __device__ __forceinline__ bool has_arc9(unsigned m) {
     unsigned d = m | (m << 16);
     unsigned a = d & (d >> 1);
@@ -582,10 +589,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             if (j < nc) {
                 ci2 = cand[j];
                 const int y = pixY(ci2), x = pixX(ci2, y);
-                const uint8_t *cpx = t0 + (y + 3) * tp + (x + 3);
-                const int v = cpx[0];
+                // top-left corner of the pixel's 7 x 7 ring window: with a fixed pitch every ring offset is a non-negative
+                // immediate of the LDS read (a negative one costs an address add of its own)
+                const uint8_t *win = t0 + y * tp + x;
+                const int v = win[3 * tp + 3];
                 int ringPx[16];
-#define FT_LD(k, ox, oy) ringPx[k] = (int)cpx[(oy)*tp + (ox)];
+#define FT_LD(k, ox, oy) ringPx[k] = (int)win[((oy) + 3) * tp + (ox) + 3];
                 FT_RING(FT_LD)
 #undef FT_LD
                 const int sc = fast_score(v, ringPx);
@@ -624,37 +633,67 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         const int half = lane >> 5, cx = lane & 31;
         const int hRows = (ph + 1) >> 1;          // rows of the upper half; the lower half has ph - hRows
         const int y0h = half * hRows;              // first row of this lane's half
-        const int nRowsH = half ? ph - hRows : hRows;
         const int wMain = min(pw, 32);
         const bool actC = cx < wMain;
+        const unsigned long long actMask = __builtin_amdgcn_ballot_w64(actC);
         const uint8_t *col = t0 + min(cx, wMain - 1) + 3 + y0h * TP;  // (x + 3, tile row y0h)
+        const int codeBase = (y0h << 6) | cx;
         unsigned pA = col[3 * TP], pB = col[4 * TP], pC = col[5 * TP];
-        unsigned dA = __builtin_amdgcn_sad_u8(pA, (unsigned)col[0], 0u);
-        unsigned dB = __builtin_amdgcn_sad_u8(pB, (unsigned)col[TP], 0u);
-        unsigned dC = __builtin_amdgcn_sad_u8(pC, (unsigned)col[2 * TP], 0u);
-        for (int y = 0; y < hRows; y += FC_ROWS) {
+        // Rows travel in PAIRS (y, y + 1) packed in the halves of a register: v_sad_u8 / v_sad_hi_u8 produce the halves,
+        // v_pk_max_u16 / v_pk_min_u16 combine them.  The vertical difference |p(y) - p(y + 3)| is the south difference of
+        // row y and the north difference of row y + 3, so a north pair is an alignbit of two earlier south pairs.
+        // History: hist0 = [., dS(y - 3)], hist1 = [dS(y - 2), dS(y - 1)].
+        unsigned hist0 = __builtin_amdgcn_sad_hi_u8(pA, (unsigned)col[0], 0u);
+        unsigned hist1 = __builtin_amdgcn_sad_hi_u8(pC, (unsigned)col[2 * TP], __builtin_amdgcn_sad_u8(pB, (unsigned)col[TP], 0u));
+        const unsigned th = (unsigned)minTh;
+        for (int y = 0; y < hRows; y += 4) {
             const uint8_t *r = col + y * TP;
-            unsigned pv[FC_ROWS + 3], m01[FC_ROWS], dSv[FC_ROWS], mAny = 0;
+            unsigned pv[7];
             pv[0] = pA; pv[1] = pB; pv[2] = pC;
 #pragma unroll
-            for (int k = 0; k < FC_ROWS; k++) pv[k + 3] = r[(k + 6) * TP];
+            for (int k = 0; k < 4; k++) pv[k + 3] = r[(k + 6) * TP];
+            const unsigned ps0 = __builtin_amdgcn_sad_hi_u8(pv[1], pv[4], __builtin_amdgcn_sad_u8(pv[0], pv[3], 0u));
+            const unsigned ps1 = __builtin_amdgcn_sad_hi_u8(pv[3], pv[6], __builtin_amdgcn_sad_u8(pv[2], pv[5], 0u));
+            const unsigned pn0 = __builtin_amdgcn_alignbit(hist1, hist0, 16);  // [dS(y - 3), dS(y - 2)]
+            const unsigned pn1 = __builtin_amdgcn_alignbit(ps0, hist1, 16);    // [dS(y - 1), dS(y)]
+            const unsigned pe0 = __builtin_amdgcn_sad_hi_u8(pv[1], (unsigned)r[4 * TP + 3], __builtin_amdgcn_sad_u8(pv[0], (unsigned)r[3 * TP + 3], 0u));
+            const unsigned pw0 = __builtin_amdgcn_sad_hi_u8(pv[1], (unsigned)r[4 * TP - 3], __builtin_amdgcn_sad_u8(pv[0], (unsigned)r[3 * TP - 3], 0u));
+            const unsigned pe1 = __builtin_amdgcn_sad_hi_u8(pv[3], (unsigned)r[6 * TP + 3], __builtin_amdgcn_sad_u8(pv[2], (unsigned)r[5 * TP + 3], 0u));
+            const unsigned pw1 = __builtin_amdgcn_sad_hi_u8(pv[3], (unsigned)r[6 * TP - 3], __builtin_amdgcn_sad_u8(pv[2], (unsigned)r[5 * TP - 3], 0u));
+            const unsigned M0 = pk_min_u16(pk_max_u16(pn0, ps0), pk_max_u16(pe0, pw0));
+            const unsigned M1 = pk_min_u16(pk_max_u16(pn1, ps1), pk_max_u16(pe1, pw1));
+            hist0 = ps0; hist1 = ps1;
+            pA = pv[4]; pB = pv[5]; pC = pv[6];
+            // a row's candidates = lanes that pass, in an active column, in a row of their half: the last two are scalar
+            // masks, so all four row masks cost one v_cmp each and a trip without candidates nothing more
+            unsigned mrow[4];
+            unsigned long long bal[4], any = 0;
+            mrow[0] = M0 & 0xffffu; mrow[1] = M0 >> 16; mrow[2] = M1 & 0xffffu; mrow[3] = M1 >> 16;
+            if (y + 4 <= ph - hRows) {  // wave-uniform: every row of the trip exists in both halves (all trips but the last)
 #pragma unroll
-            for (int k = 0; k < FC_ROWS; k++) {
-                const unsigned v = pv[k];
-                const uint8_t *cpx = r + (k + 3) * TP;
-                const unsigned dS = dSv[k] = __builtin_amdgcn_sad_u8(v, pv[k + 3], 0u);
-                const unsigned dN = k == 0 ? dA : k == 1 ? dB : k == 2 ? dC : dSv[k >= 3 ? k - 3 : 0];
-                const unsigned m1 = max(FT_AD(3, 0), FT_AD(-3, 0));
-                m01[k] = (actC && y + k < nRowsH) ? min(max(dN, dS), m1) : 0u;
-                mAny = max(mAny, m01[k]);
-            }
-            dA = dSv[FC_ROWS - 3]; dB = dSv[FC_ROWS - 2]; dC = dSv[FC_ROWS - 1];
-            pA = pv[FC_ROWS]; pB = pv[FC_ROWS + 1]; pC = pv[FC_ROWS + 2];
-            if (__any(mAny > (unsigned)minTh)) {
+                for (int k = 0; k < 4; k++) {
+                    bal[k] = __builtin_amdgcn_ballot_w64(mrow[k] > th) & actMask;
+                    any |= bal[k];
+                }
+            } else {
 #pragma unroll
-                for (int k = 0; k < FC_ROWS; k++) nc = pushRow(m01[k] > (unsigned)minTh, pixCode(y0h + y + k, cx), nc);
+                for (int k = 0; k < 4; k++) {
+                    const unsigned long long rowMask = (y + k < hRows ? 0x00000000ffffffffull : 0ull) | (y + k < ph - hRows ? 0xffffffff00000000ull : 0ull);
+                    bal[k] = __builtin_amdgcn_ballot_w64(mrow[k] > th) & actMask & rowMask;
+                    any |= bal[k];
+                }
             }
-            if (nc > FC_CAND - FC_ROWS * 64) flushB();  // wave-uniform
+            if (any) {  // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (bal[k]) {  // wave-uniform
+                        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[k], (unsigned)nc));
+                        if (__builtin_amdgcn_inverse_ballot_w64(bal[k])) cand[pos] = (unsigned short)(codeBase + ((y + k) << 6));
+                        nc += __popcll(bal[k]);
+                    }
+                }
+            }
+            if (nc > FC_CAND - 4 * 64) flushB();  // wave-uniform
         }
         // columns 32 .. pw-1 (four of them for a 36-pixel cell), every row, in linear order
         const int wRem = pw - wMain, nRem = wRem * ph;
@@ -845,13 +884,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
 #define FS_ROWS 6                // rows per trip of phase A (three pairs)
 #define FS_CAND 640              // candidate ring (u16 codes): a trip adds up to 384, full rounds leave < 64
 #define FS_CORN 256              // corner list; a strip with more corners scans its score plane
-typedef unsigned short fs_us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(fs_us2, a), __builtin_bit_cast(fs_us2, b)));
-}
-__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(fs_us2, a), __builtin_bit_cast(fs_us2, b)));
-}
 __host__ __device__ __forceinline__ int fs_tile_rows(int sH) { return ((sH + 2 + FS_ROWS - 1) / FS_ROWS) * FS_ROWS + 6; }
 __host__ __device__ __forceinline__ int fs_tile_bytes(int sH) { return (fs_tile_rows(sH) * FS_TP + 15) & ~15; }
 __host__ __device__ __forceinline__ int fs_score_bytes(int sH) { return ((sH + 2) * 64 + 64 + 15) & ~15; }  // + a row of slack for the reads of the last rows' neighbours
@@ -996,7 +1028,7 @@ __global__ __launch_bounds__(64) void k_fast_strips(FtGeom g, const uint8_t *con
                 for (int k = 0; k < 6; k++) {
                     if (bal[k]) {  // wave-uniform; implies a valid row
                         const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[k], (unsigned)nc));
-                        if (mrow[k] > th && act) cand[pos] = (unsigned short)(((yy + k) << 6) | lane);
+                        if (__builtin_amdgcn_inverse_ballot_w64(bal[k])) cand[pos] = (unsigned short)(((yy + k) << 6) | lane);
                         nc += __popcll(bal[k]);
                     }
                 }
@@ -1455,7 +1487,9 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
     for (int rep = ft_debug_repeat("pyr"); rep > 0; rep--)
     for (int level = 1; level < g.nlevels; level++) {
         const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
-        if (rowsOn && alignedLoads && pyr_rows_fits(g, level, nullptr)) {
+        // a launch of a few images is latency bound: the tile kernel's many short waves finish a level sooner than the
+        // row-streaming kernel's few long ones (752x480 frame: 0.19 against 0.23 ms); wide launches take the streaming kernel
+        if (rowsOn && batch >= 8 && alignedLoads && pyr_rows_fits(g, level, nullptr)) {
             const int stripsX = (D.w + PR_COLS - 1) / PR_COLS, stripsY = (D.h + PR_RB - 1) / PR_RB;
             dim3 grid, block(64, 1, 1);
             const FtSlotGrid sg = ft_slot_grid(stripsX * stripsY, batch, grid);

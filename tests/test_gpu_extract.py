@@ -285,19 +285,27 @@ def test_device_octree_overflow_falls_back_to_host(ctx):
 
 def test_device_octree_second_tier(ctx):
     """levels with more than FT_OCT_MAXN = 4 096 and at most 16 384 candidates are distributed by k_octree_big (LDS layout
-    for 16 384 keys): dense frames stay on the device, the result equals the oracle's"""
+    for 16 384 keys), which is launched once a frame has asked for it: the first dense frame is repaired with the host
+    octree, the following ones stay on the device; every result equals the oracle's"""
     w, h, nf = 1280, 720, 2000
     ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=2)
     oex = ob.Extractor(nf)
     dense = synth.make_mosaic_pair(w, h, seed=5, block=12)
-    f0 = _calls(ctx, "extract.device_octree_fallbacks")
-    res = ex.extract_batch([dense[0], dense[1]])
-    for img, (gk, gd, gm) in zip(dense, res):
+    expect = []
+    for img in dense:
         ok, od, om = oex.extract(img)
         counts = [len(oex.candidates(l)) for l in range(8)]
         assert max(counts) > 4096 and max(counts) <= 16384, counts
-        _check_same(gk, gd, ok, od)
-    assert _calls(ctx, "extract.device_octree_fallbacks") == f0, "a dense frame fell back to the host octree"
+        expect.append((ok, od))
+    f0 = _calls(ctx, "extract.device_octree_fallbacks")
+    for k in range(3):
+        res = ex.extract_batch([dense[0], dense[1]])
+        for (gk, gd, gm), (ok, od) in zip(res, expect):
+            _check_same(gk, gd, ok, od)
+        if k == 0:
+            f1 = _calls(ctx, "extract.device_octree_fallbacks")
+            assert f1 == f0 + 2, "the first dense batch is repaired image by image"
+    assert _calls(ctx, "extract.device_octree_fallbacks") == f1, "a later dense frame fell back to the host octree"
 
 
 def test_two_host_threads_two_extractors(ctx):
