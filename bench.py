@@ -134,16 +134,17 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def make_stream(ctx, w, h, rank, D, scenes, density=1.0, mosaic=0):
+def make_stream(alloc, w, h, rank, D, scenes, density=1.0, mosaic=0):
     """D distinct stereo pairs of this rank's stream in pinned host memory: `scenes` seeded scenes (synth.make_stereo_pair),
     scene s of variant k shifted cyclically by (53 k mod w, 29 k mod h) px in BOTH images (rectification and disparities
-    are kept; the wrap-around seam is one more edge).  Returns (hostL, hostR) of shape (D, h, w) and the seeded scenes."""
+    are kept; the wrap-around seam is one more edge).  alloc(shape, dtype) provides the (pinned) arrays.  Returns (hostL,
+    hostR) of shape (D, h, w) and the seeded scenes."""
     S = max(1, min(scenes, D))
     if mosaic:
         base = [synth.make_mosaic_pair(w, h, seed=s, block=mosaic) for s in shard.stream_seeds(rank, S)]
     else:
         base = [synth.make_stereo_pair(w, h, seed=s, density=density) for s in shard.stream_seeds(rank, S)]
-    hostL, hostR = ctx.pinned_array((D, h, w), np.uint8), ctx.pinned_array((D, h, w), np.uint8)
+    hostL, hostR = alloc((D, h, w), np.uint8), alloc((D, h, w), np.uint8)
     for d in range(D):
         L, R = base[d % S]
         k = d // S
@@ -202,7 +203,7 @@ def main():
     # synthetic stream (seeds are per rank: one stream per GPU): D distinct pairs in pinned host memory and, for the
     # headline number, resident in HBM before the timed region
     D = max(1, min(args.distinct or B, B))
-    hostL, hostR, pairs = make_stream(ctx, w, h, rank, D, args.scenes, args.density, args.mosaic)
+    hostL, hostR, pairs = make_stream(ctx.pinned_array, w, h, rank, D, args.scenes, args.density, args.mosaic)
     devL, devR = ctx.to_device(hostL), ctx.to_device(hostR)
     import ctypes as C
     fb = w * h

@@ -355,9 +355,25 @@ void ft_extract_restage(ft_extractor *ex, const uint8_t *const *images, int batc
     }
 }
 
+// The host-mapped pinned candidate lists the host octree reads (2.7 MB per 1280x720 slot: 1.4 GB for 512 slots) exist only
+// once the host octree is used - an extractor that stays on the device octree never allocates them.
+int ft_extract_ensure_host_cand(ft_extractor *ex) {
+    if (ex->h_cand) return FT_OK;
+    const size_t n = std::max<size_t>((size_t)ex->maxBatch * ex->geom.candPerSlot, 1);
+    FT_HIP(hipHostMalloc((void **)&ex->h_cand, n * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    void *dp = nullptr;
+    FT_HIP(hipHostGetDevicePointer(&dp, ex->h_cand, 0));
+    ex->d_cand = (uint32_t *)dp;
+    return FT_OK;
+}
+
 // stage A of slots [b0, b0+nb): pyramid + FAST + ordered compaction on ex->stream; `done` is recorded after it
 int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done) {
     const FtGeom &g = ex->geom;
+    if (!ex->deviceOctree) {
+        const int rce = ft_extract_ensure_host_cand(ex);
+        if (rce != FT_OK) return rce;
+    }
     const bool tm = ex->ctx->kernelTiming;
     const int al = ex->l0Aligned ? 1 : 0;
     const uint8_t *const *l0 = ex->d_l0 + b0;
@@ -525,6 +541,8 @@ int ft_extract_repair_prepare(const std::vector<std::pair<ft_extractor *, int>> 
     for (auto &j : jobs) {
         ft_extractor *ex = j.first;
         const int slot = j.second;
+        const int rce = ft_extract_ensure_host_cand(ex);
+        if (rce != FT_OK) return rce;
         FT_HIP(hipMemcpy(ex->h_candCount + (size_t)slot * L, ex->d_candCountDev + (size_t)slot * L, sizeof(int) * L, hipMemcpyDeviceToHost));
         for (int l = 0; l < L; l++) {
             const FtLevelGeom &v = g.lv[l];
@@ -746,7 +764,6 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     FT_TRY(devAlloc(&ex->d_keys, B * g.maxKp));
     FT_TRY(devAlloc(&ex->d_desc, B * g.maxKp * 32));
     FT_TRY(pinAlloc(&ex->h_l0, B));
-    FT_TRY(pinAlloc(&ex->h_cand, B * g.candPerSlot, hipHostMallocMapped | hipHostMallocCoherent));
     FT_TRY(pinAlloc(&ex->h_candCount, B * g.nlevels, hipHostMallocMapped | hipHostMallocCoherent));
     FT_TRY(pinAlloc(&ex->h_sel, B * g.maxKp));
     FT_TRY(pinAlloc(&ex->h_nSel, B));
@@ -754,12 +771,8 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     FT_TRY(pinAlloc(&ex->h_desc, B * g.maxKp * 32));
     {
         void *dp = nullptr;
-        hipError_t e = hipHostGetDevicePointer(&dp, ex->h_cand, 0);
-        if (e == hipSuccess) {
-            ex->d_cand = (uint32_t *)dp;
-            e = hipHostGetDevicePointer(&dp, ex->h_candCount, 0);
-            ex->d_candCount = (int *)dp;
-        }
+        hipError_t e = hipHostGetDevicePointer(&dp, ex->h_candCount, 0);
+        ex->d_candCount = (int *)dp;
         if (e != hipSuccess) {
             freeAll(ex);
             delete ex;
@@ -1205,7 +1218,7 @@ int ft_extractor_download_candidates(ft_extractor *ex, int slot, int level, int 
     FT_HIP(hipStreamSynchronize(ex->stream));
     const FtGeom &g = ex->geom;
     std::vector<uint32_t> tmp;
-    const uint32_t *c = ex->h_cand + (size_t)slot * g.candPerSlot + g.lv[level].candBase;
+    const uint32_t *c = ex->h_cand ? ex->h_cand + (size_t)slot * g.candPerSlot + g.lv[level].candBase : nullptr;
     int cnt = ex->h_candCount[slot * g.nlevels + level];
     if (ex->deviceOctree) {  // the lists never left the device
         FT_HIP(hipStreamSynchronize(ex->streamB));

@@ -228,6 +228,7 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
 // per sub-batch of slots [b0, b0+nb): see extractor.cpp
 int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done);
 int ft_extract_ensure_stage(ft_extractor *ex);
+int ft_extract_ensure_host_cand(ft_extractor *ex);
 void ft_extract_restage(ft_extractor *ex, const uint8_t *const *images, int batch, int width, int height, int stride);
 int ft_extract_octree(ft_extractor *ex, int b0, int nb);
 int ft_extract_overflow_slots(ft_extractor *ex, int batch, std::vector<int> &slots);
