@@ -52,9 +52,15 @@ def main():
         if min(w, h) / (sfac ** (nlevels - 1)) < 40:
             nlevels = max(1, int(np.log(min(w, h) / 40.0) / np.log(sfac)) + 1)
         dens = float(rng.choice([0.0, 0.1, 0.3, 1.0, 2.5, 6.0]))
-        cfg = dict(w=w, h=h, nf=nf, nlevels=nlevels, sfac=sfac, ini=ini, mn=mn, dens=dens, trial=trial)
+        strips = rng.random() < 0.25  # the strips form of FAST (read when the extractor is created)
+        mosaic = int(rng.choice([0, 0, 0, 6, 9, 14]))  # dense mosaics: levels of 4 k .. 30 k candidates (second octree tier / repair)
+        cfg = dict(w=w, h=h, nf=nf, nlevels=nlevels, sfac=sfac, ini=ini, mn=mn, dens=dens, trial=trial, strips=strips, mosaic=mosaic)
+        os.environ["FT_FAST_STRIPS"] = "1" if strips else "0"
+        os.environ["FT_STRIP_ROWS"] = str(int(rng.choice([8, 16, 32, 48])))
         try:
             img = synth.make_image(w, h, seed=int(rng.integers(1 << 30)), density=dens)
+            if mosaic:
+                img = synth.make_mosaic_pair(w, h, int(rng.integers(1 << 30)), block=mosaic)[0]
             if rng.random() < 0.15:  # noise: many weak corners, dense candidate lists
                 img = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
             ex = orb.ORBextractor(ctx, nf, sfac, nlevels, ini, mn, w, h)
@@ -79,11 +85,17 @@ def main():
                     err = "bow transform k=%d L=%d scoring=%d weighting=%d levelsup=%d" % (k, Lv, sc, wt, lu)
                 gv.close()
             if err is None and trial % args.frontend_every == 0 and nlevels >= 2:
-                B = int(rng.integers(1, 4))
+                # latency mode (1-3 pairs, captured graph, both cameras in one launch) or, for small frames now and then,
+                # throughput mode (more than 16 pairs: per-pair repair, second-tier grid sized from the previous batch)
+                big = w * h < 400 * 300 and rng.random() < 0.5
+                B = int(rng.integers(17, 22)) if big else int(rng.integers(1, 4))
                 intr = synth.intrinsics(w, h)
                 fe = orb.StereoFrontend(ctx, nf, sfac, nlevels, ini, mn, w, h, B, intr["mbf"], intr["mb"])
-                pairs = [synth.make_stereo_pair(w, h, int(rng.integers(1 << 30))) for _ in range(B)]
+                pairs = [synth.make_mosaic_pair(w, h, int(rng.integers(1 << 30)), block=mosaic) if mosaic and rng.random() < 0.5
+                         else synth.make_stereo_pair(w, h, int(rng.integers(1 << 30))) for _ in range(B)]
                 outs = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
+                if big:  # a second batch: the one that runs with the second tier switched on
+                    outs = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
                 for (imL, imR), out in zip(pairs, outs):
                     oL, oR = ob.Extractor(nf, sfac, nlevels, ini, mn), ob.Extractor(nf, sfac, nlevels, ini, mn)
                     kL, dL, _ = oL.extract(imL)
