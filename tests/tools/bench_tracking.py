@@ -80,10 +80,27 @@ def oracle():
 
 
 assert separate() == resident() == bound() == oracle()
+
+
+def library_ms(fn, names, n):
+    """time inside the C++ entry points only (the library's own per-call timers), without the Python marshalling"""
+    fn()
+    ctx.reset_stats()
+    for _ in range(n):
+        fn()
+    tot = 0.0
+    for name in names:
+        ms, calls = ctx.get_stat(name)
+        tot += ms / max(calls, 1)
+    return tot
+
 out = {"frame": [w, h], "keypoints": int(len(fr["kL"])), "last_frame_points": int(len(last["valid"])),
        "local_map_points": int(len(pts["world_pos"])),
        "ms_per_frame": {"separate_calls": timeit(separate, reps), "resident_frame": timeit(resident, reps), "bound_to_front_end": timeit(bound, reps),
                         "oracle_1_core": timeit(oracle, max(3, reps // 5))},
+       "ms_per_frame_inside_the_library": {
+           "resident_frame (search_last_frame + track_local_map)": library_ms(resident, ["tracked.search_last_frame.total", "tracked.track_local_map.total"], reps),
+           "bound_to_front_end": library_ms(bound, ["tracked.search_last_frame.total", "tracked.track_local_map.total"], reps)},
        "frustum_only_ms": timeit(lambda: orb.is_in_frustum(ctx, orb.FrameView(scale_factors=sf, **kw), pose, pts, 0.5, LOG_SF), reps),
        "frustum_only_oracle_ms": timeit(lambda: ob.is_in_frustum(ob.FrameView(scale_factors_=sf, **kw), ob.make_pose(Rcw, tcw), pts, 0.5, LOG_SF), reps),
        "note": "median wall time per frame including the Python marshalling of the calls"}
