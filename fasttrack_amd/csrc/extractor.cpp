@@ -439,6 +439,9 @@ int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent
     // second tier (levels with more than FT_OCT_MAXN candidates): the grid the previous batches asked for (0 while the
     // frames do not need it: a workgroup that wants a CU's whole LDS is not free even when it has nothing to do)
     a.bigCap = a.bigN ? std::min(ex->bigGrid, nb * g.nlevels) : 0;
+    // one list and one counter pair per octree stream: the launches of two sub-batches run side by side
+    a.bigCount = ex->d_bigCount + 2 * (sub % FT_OCT_STREAMS);
+    a.bigList = ex->d_bigList + (size_t)(sub % FT_OCT_STREAMS) * ex->maxBatch * g.nlevels;
     const bool tm = ex->ctx->kernelTiming;
     ex->evt.begin(tm, "kernel.octree", so);
     int rc = ft_launch_octree(so, g, nb, a);
@@ -504,8 +507,11 @@ void ft_extract_update_big_grid(ft_extractor *ex) {
         if (ex->h_overflow[0] && ex->bigGrid == 0) ex->bigGrid = ex->maxBatch * ex->nlevels;
         return;
     }
-    const int want = ex->h_bigStat[0];
-    ex->h_bigStat[0] = 0;
+    int want = 0;  // the octree streams keep a list each (launches on different streams run side by side)
+    for (int k = 0; k < FT_OCT_STREAMS; k++) {
+        want = std::max(want, ex->h_bigStat[k]);
+        ex->h_bigStat[k] = 0;
+    }
     if (want > 0) {
         ex->bigIdle = 0;
         const int need = std::max(FT_OCT_BIGMIN, ((want + want / 4 + 63) / 64) * 64);
@@ -636,8 +642,10 @@ int ft_extract_finish_counts(ft_extractor *ex, int batch, hipStream_t st) {
     FT_HIP(hipMemcpyAsync(ex->h_nSel, ex->d_nSel, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
     FT_HIP(hipMemcpyAsync(ex->h_overflow, ex->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
     if (ex->octLayout.bigN) {  // demand for the second-tier octree kernel during this batch (ft_extract_update_big_grid)
-        FT_HIP(hipMemcpyAsync(ex->h_bigStat, ex->d_bigCount + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-        FT_HIP(hipMemsetAsync(ex->d_bigCount + 1, 0, sizeof(int), st));
+        for (int k = 0; k < FT_OCT_STREAMS; k++) {
+            FT_HIP(hipMemcpyAsync(ex->h_bigStat + k, ex->d_bigCount + 2 * k + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+            FT_HIP(hipMemsetAsync(ex->d_bigCount + 2 * k + 1, 0, sizeof(int), st));
+        }
     }
     return FT_OK;
 }
@@ -755,10 +763,10 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     FT_TRY(devAlloc(&ex->d_selCount, B * g.nlevels + FT_MAX_LEVELS));  // k_orient_desc reads FT_MAX_LEVELS counts per image at once
     FT_TRY(devAlloc(&ex->d_overflow, 1));
     FT_TRY(devAlloc(&ex->d_ovSlot, B));
-    FT_TRY(devAlloc(&ex->d_bigCount, 2));
-    FT_TRY(pinAlloc(&ex->h_bigStat, 1));
-    ex->h_bigStat[0] = 0;
-    FT_TRY(devAlloc(&ex->d_bigList, B * g.nlevels));
+    FT_TRY(devAlloc(&ex->d_bigCount, 2 * FT_OCT_STREAMS));
+    FT_TRY(pinAlloc(&ex->h_bigStat, FT_OCT_STREAMS));
+    for (int k = 0; k < FT_OCT_STREAMS; k++) ex->h_bigStat[k] = 0;
+    FT_TRY(devAlloc(&ex->d_bigList, (size_t)FT_OCT_STREAMS * B * g.nlevels));
     FT_TRY(pinAlloc(&ex->h_selCount, B * g.nlevels));
     FT_TRY(pinAlloc(&ex->h_overflow, 1));
     FT_TRY(devAlloc(&ex->d_keys, B * g.maxKp));
@@ -839,7 +847,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
             FT_TRY(devAlloc(&ex->d_candCountDev, B * g.nlevels));
             hipError_t me = hipMemset(ex->d_overflow, 0, sizeof(int));
             if (me == hipSuccess) me = hipMemset(ex->d_ovSlot, 0, sizeof(int) * B);
-            if (me == hipSuccess) me = hipMemset(ex->d_bigCount, 0, 2 * sizeof(int));
+            if (me == hipSuccess) me = hipMemset(ex->d_bigCount, 0, 2 * FT_OCT_STREAMS * sizeof(int));
             if (me != hipSuccess) {
                 freeAll(ex);
                 delete ex;

@@ -142,9 +142,9 @@ struct ft_extractor {
     int *d_selCount = nullptr, *h_selCount = nullptr;  // [maxBatch * nlevels]
     int *d_overflow = nullptr, *h_overflow = nullptr;
     int *d_ovSlot = nullptr;         // [maxBatch] which slots overflowed (read only after the summary flag was seen)
-    int *d_bigCount = nullptr;       // second-tier octree kernel: [0] entries of the running launch, [1] maximum since last read
-    int *h_bigStat = nullptr;        // pinned copy of d_bigCount[1]
-    unsigned *d_bigList = nullptr;   // [maxBatch * nlevels] (slot, level) pairs with more than FT_OCT_MAXN candidates
+    int *d_bigCount = nullptr;       // second-tier octree kernel, per octree stream: [0] entries of the running launch, [1] maximum since last read
+    int *h_bigStat = nullptr;        // pinned copies of the maxima
+    unsigned *d_bigList = nullptr;   // per octree stream [maxBatch * nlevels] (slot, level) pairs with more than FT_OCT_MAXN candidates
     int bigGrid = 0, bigIdle = 0;    // grid of k_octree_big for large batches: 0 until a batch asks for it, sized by demand
     FtOctArgs octLayout{};
     // selected keypoints host -> device

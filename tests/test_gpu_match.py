@@ -205,6 +205,46 @@ def test_dense_frames_stay_on_the_device_and_overflows_are_repaired_per_pair(ctx
     check(batch2, outs, [4, 5, 6, 11])
 
 
+def test_dense_frames_in_concurrent_sub_batches(ctx):
+    """256 pairs per batch = two sub-batches whose octree kernels run side by side on the two octree streams, every pair with
+    levels beyond 4 096 candidates: the second-tier lists are per stream.  The first batch finds the second tier switched off
+    and goes through the host-octree pipeline as a whole; the second runs on the device and must reproduce it slot for slot;
+    the four distinct pairs are checked against the oracle."""
+    w, h, nf, B = 640, 480, 1000, 256
+    intr = synth.intrinsics(w, h)
+    fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
+    dense = [synth.make_mosaic_pair(w, h, seed=160 + i, block=6) for i in range(4)]
+    oex = ob.Extractor(nf)
+    oex.extract(dense[0][0])
+    top = max(len(oex.candidates(l)) for l in range(8))
+    assert 4096 < top <= 16384, top
+    pairs = [dense[b % 4] for b in range(B)]
+
+    def calls(name):
+        try:
+            return ctx.get_stat(name)[1]
+        except Exception:
+            return 0
+    f0 = calls("stereo.device_octree_fallbacks")
+    first = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
+    assert calls("stereo.device_octree_fallbacks") == f0 + B
+    second = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
+    assert calls("stereo.device_octree_fallbacks") == f0 + B, "the second dense batch stays on the device"
+    for b in range(B):
+        for k in ("keysL", "keysR", "descL", "descR", "uright", "depth"):
+            assert np.array_equal(first[b][k], second[b][k]), (b, k)
+        assert first[b]["n"] == second[b]["n"]
+    for b in range(4):
+        oL, oR = ob.Extractor(nf), ob.Extractor(nf)
+        kL, dL, _ = oL.extract(pairs[b][0])
+        kR, dR, _ = oR.extract(pairs[b][1])
+        o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+        out = second[b]
+        assert np.array_equal(out["keysL"], kL) and np.array_equal(out["keysR"], kR)
+        assert np.array_equal(out["descL"], dL) and np.array_equal(out["descR"], dR)
+        assert out["n"] == o["n"] and np.array_equal(out["uright"], o["uright"]) and np.array_equal(out["depth"], o["depth"])
+
+
 def test_fisheye_match(ctx):
     rng = np.random.default_rng(2)
     fr = sc.oracle_stereo_frame(512, 512, 2000, 6)
