@@ -4,8 +4,6 @@
 //   k_fast_cells   per-cell cv::FAST-9/16 + NMS + threshold fallback (ORBextractor.cc:1136-1199, A.3)
 //   k_compact      cell-row-major ordered candidate list          (ORBextractor.cc:1186-1198)
 //   k_orient_desc  IC_Angle + 7x7 fixed-point blur + rBRIEF       (ORBextractor.cc:39-108,1456-1462, A.2/A.4/A.6/A.7)
-#include <vector>
-
 #include "ft_internal.h"
 #include "sincos_poly.h"
 #include "wave_ops.h"
@@ -1473,8 +1471,7 @@ size_t ft_fast_smem_bytes(const FtGeom &g) {
 }
 
 // the row-streaming kernel needs every lane's four taps inside one aligned 8-byte window of a source row
-static bool pyr_rows_fits(const FtGeom &g, int level, const std::vector<FtTap> *hostTaps) {
-    (void)hostTaps;
+static bool pyr_rows_fits(const FtGeom &g, int level) {
     const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
     // the window starts at sx(dx) & ~3 (<= 3 bytes before the first tap), sx(dx + 1) <= sx(dx) + ceil(scale), and the
     // second tap of column dx + 1 is one further: 3 + ceil(scale) + 1 <= 7 holds for every scale <= 3
@@ -1489,7 +1486,7 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
         const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
         // a launch of a few images is latency bound: the tile kernel's many short waves finish a level sooner than the
         // row-streaming kernel's few long ones (752x480 frame: 0.19 against 0.23 ms); wide launches take the streaming kernel
-        if (rowsOn && batch >= 8 && alignedLoads && pyr_rows_fits(g, level, nullptr)) {
+        if (rowsOn && batch >= 8 && alignedLoads && pyr_rows_fits(g, level)) {
             const int stripsX = (D.w + PR_COLS - 1) / PR_COLS, stripsY = (D.h + PR_RB - 1) / PR_RB;
             dim3 grid, block(64, 1, 1);
             const FtSlotGrid sg = ft_slot_grid(stripsX * stripsY, batch, grid);

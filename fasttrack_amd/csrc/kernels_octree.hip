@@ -12,9 +12,10 @@
 //      literally on lane 0 (octree_paths.h std_sort_replay).
 //   4. per retained node the first-maximum response pick, one lane per node.
 //
-// The result - retained candidates AND their order - equals the host octree (octree.cpp), which stays as the
-// path for inputs beyond this kernel's limits (more than FT_OCT_MAXN candidates in one level or a quota
-// above FT_OCT_MAXQ): the kernel then raises `overflow` and the host re-runs that batch.
+// The result - retained candidates AND their order - equals the host octree (octree.cpp).  Two tiers: k_octree sorts up to
+// FT_OCT_MAXN = 4 096 candidates of a level in LDS; a level with more goes on a list for k_octree_big (the same code with
+// an LDS layout for up to 16 384 keys).  A level beyond that - or a listed one the second tier has no workgroup for - raises
+// the image's overflow flag, and the host redoes that image with the host octree (extractor.cpp ft_extract_repair_*).
 #include "ft_internal.h"
 #include "octree_paths.h"
 
