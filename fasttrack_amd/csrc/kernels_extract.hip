@@ -1201,8 +1201,12 @@ __global__ __launch_bounds__(256) void k_compact(FtGeom g, const int *cellCount,
 #define OD_P (2 * OD_R + 1)     // 43
 #define OD_PP 48                // raw pitch: 12 dwords cover the 43 bytes at any 4-byte phase
 #define OD_HP 40                // pitch (u16) of the horizontally blurred rows: raw byte positions 0..39
+#ifndef OD_LAYOUT
+#define OD_LAYOUT 1             // 0: horizontally blurred rows row-major (seven scattered u16 reads per sample); 1: column-major
+#endif                          // (the seven values of a sample are consecutive: two ds_read2_b32 + three v_alignbit)
+#define OD_RP 44                // column-major layout: u16 slots per column (43 rows + 1: dword-aligned columns)
 #define OD_RAW_BYTES (OD_P * OD_PP)                  // 2064
-#define OD_HB_BYTES (OD_P * OD_HP * 2)               // 3440
+#define OD_HB_BYTES (OD_LAYOUT ? OD_HP * OD_RP * 2 + 16 : OD_P * OD_HP * 2)  // 3536 / 3440
 #define OD_WAVE_BYTES ((OD_RAW_BYTES + OD_HB_BYTES + 15) & ~15)
 #define OD_WAVES 4
 
@@ -1240,6 +1244,22 @@ __device__ __forceinline__ unsigned od_vblur7(unsigned p0, unsigned p1, unsigned
     return v >> 16;
 }
 
+// The same sum from the column-major layout, where the seven values of a column are consecutive u16: four dwords that
+// hold them (starting at the dword that holds the first one; sh = 16 if the first value is that dword's high half, else 0)
+// -> three v_alignbit + one shift put the pairs (t0,t1) (t2,t3) (t4,t5) (t6,-) into place, four v_dot2_u32_u16 weigh them.
+typedef unsigned short od_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned od_dot2(unsigned a, unsigned w, unsigned acc) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(od_us2, a), __builtin_bit_cast(od_us2, w), acc, false);
+}
+__device__ __forceinline__ unsigned od_vblur7_pairs(unsigned e0, unsigned e1, unsigned e2, unsigned e3) {
+    const unsigned W01 = 18u | (34u << 16), W23 = 48u | (56u << 16), W45 = 48u | (34u << 16), W6 = 18u;
+    return od_dot2(e3, W6, od_dot2(e2, W45, od_dot2(e1, W23, od_dot2(e0, W01, 32768u)))) >> 16;
+}
+__device__ __forceinline__ unsigned od_vblur7_dwords(unsigned d0, unsigned d1, unsigned d2, unsigned d3, unsigned sh) {
+    return od_vblur7_pairs(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                           __builtin_amdgcn_alignbit(d3, d2, sh), d3 >> sh);
+}
+
 // Test tap (a7, GaussianBlur directly): the blurred image of one pyramid level, BORDER_REFLECT_101, computed with
 // od_hblur4 / od_vblur7.  One thread per aligned group of four output pixels; speed is irrelevant here.
 __global__ void k_blur_level(const uint8_t *img, int pitch, int w, int h, uint8_t *dst, int dstPitch) {
@@ -1252,8 +1272,18 @@ __global__ void k_blur_level(const uint8_t *img, int pitch, int w, int h, uint8_
         for (int b = 0; b < 12; b++) d[b >> 2] |= (unsigned)row[reflect101(gx - 3 + b, w)] << (8 * (b & 3));
         od_hblur4(d[0], d[1], d[2], hb[s][0], hb[s][1], hb[s][2], hb[s][3]);
     }
-    for (int j = 0; j < 4 && gx + j < w; j++)
+    for (int j = 0; j < 4 && gx + j < w; j++) {
+#if OD_LAYOUT
+        // the column as k_orient_desc keeps it: consecutive u16, once starting in a low half and once in a high half
+        const unsigned t[8] = {hb[0][j], hb[1][j], hb[2][j], hb[3][j], hb[4][j], hb[5][j], hb[6][j], 0u};
+        unsigned v;
+        if ((gx + j + y) & 1) v = od_vblur7_dwords(t[0] << 16, t[1] | (t[2] << 16), t[3] | (t[4] << 16), t[5] | (t[6] << 16), 16u);
+        else v = od_vblur7_dwords(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6], 0u);
+        dst[(size_t)y * dstPitch + gx + j] = (uint8_t)v;
+#else
         dst[(size_t)y * dstPitch + gx + j] = (uint8_t)od_vblur7(hb[0][j], hb[1][j], hb[2][j], hb[3][j], hb[4][j], hb[5][j], hb[6][j]);
+#endif
+    }
 }
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -1293,20 +1323,24 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     const int k = blk * OD_WAVES + wave;
     // the octree leaves its result per level; keypoint k of the image (level order) is entry k - prefix of
     // the level that contains it
-    // All level counts of the image are requested at once (scalar loads of FT_MAX_LEVELS consecutive ints; the array is
-    // padded by that much) instead of one dependent scalar round trip per level.
+    // Lane l holds the count of level l (one vector load), a DPP scan over the row of 16 lanes turns the counts into
+    // inclusive prefixes, and the level of keypoint k is the first lane whose prefix exceeds k (one ballot): a dozen
+    // instructions where the scalar unit used to walk the FT_MAX_LEVELS levels one by one (150 scalar instructions per wave -
+    // and the CU's four SIMDs share one scalar unit).
     int selLevel = -1, prefix = 0, total = 0;
-    int cnt[FT_MAX_LEVELS];
-#pragma unroll
-    for (int l = 0; l < FT_MAX_LEVELS; l++) cnt[l] = selCount[slot * g.nlevels + l];
-#pragma unroll
-    for (int l = 0; l < FT_MAX_LEVELS; l++) {
-        const int c = l < g.nlevels ? cnt[l] : 0;
-        if (selLevel < 0 && k < total + c) {
-            selLevel = l;
-            prefix = total;
+    {
+        const int c = lane < g.nlevels ? selCount[slot * g.nlevels + lane] : 0;
+        int incl = c;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);  // row_shr:1 (lanes shifted in from outside the row read 0)
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);  // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);  // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr:8
+        total = __builtin_amdgcn_readlane(incl, 15);
+        const unsigned below = (unsigned)__builtin_amdgcn_ballot_w64(k < incl) & 0xffffu;
+        if (below) {
+            selLevel = __builtin_ctz(below);
+            prefix = __builtin_amdgcn_readlane(incl - c, selLevel);
         }
-        total += c;
     }
     if (k == 0 && lane == 0) nSel[slot] = total;
     if (selLevel < 0) return;  // k >= total; waves are independent: no workgroup barrier below
@@ -1377,6 +1411,28 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     // raw[r][b + t] for raw byte positions b in [0, 40) (16 bit, <= 255 * 256); output column c of the
     // blurred window is b = ax + c.
     {
+#if OD_LAYOUT
+        // column-major output (hbT[column][row], OD_RP u16 slots per column): a lane takes a PAIR of rows (2P, 2P + 1) of its
+        // group of four columns and stores the two values of a column as one dword; six row pairs per step on lanes 0-59
+        const int rr = (lane * 13) >> 7, gq = lane - rr * 10;  // lane / 10 for lane < 64
+        const unsigned *rwLane = (const unsigned *)(raw + 2 * rr * OD_PP) + gq;
+        unsigned *hbLane = (unsigned *)hb + 4 * gq * (OD_RP / 2) + rr;
+        if (lane < 60) {
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                if (it == 3 && rr > 3) break;  // row pairs 22, 23 do not exist (rows 0 .. 42; row 43 is a dummy)
+                const unsigned *rw = rwLane + it * (12 * OD_PP / 4);
+                unsigned a0, a1, a2, a3, b0, b1, b2, b3;
+                od_hblur4(rw[0], rw[1], rw[2], a0, a1, a2, a3);
+                od_hblur4(rw[OD_PP / 4], rw[OD_PP / 4 + 1], rw[OD_PP / 4 + 2], b0, b1, b2, b3);
+                unsigned *o = hbLane + it * 6;
+                o[0] = __builtin_amdgcn_perm(b0, a0, 0x05040100u);  // a | b << 16 (both < 2^16)
+                o[OD_RP / 2] = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
+                o[2 * (OD_RP / 2)] = __builtin_amdgcn_perm(b2, a2, 0x05040100u);
+                o[3 * (OD_RP / 2)] = __builtin_amdgcn_perm(b3, a3, 0x05040100u);
+            }
+        }
+#else
         // six rows per step on lanes 0-59, (row, group) fixed per lane: every LDS offset of a step is an immediate
         const int rr = (lane * 13) >> 7, gq = lane - rr * 10;  // lane / 10 for lane < 64
         const unsigned *rwLane = (const unsigned *)(raw + rr * OD_PP) + gq;
@@ -1395,6 +1451,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
                 *(uint2 *)(hbLane + it * 6 * OD_HP) = pk;
             }
         }
+#endif
     }
     wave_lds_sync();
     // computeOrbDescriptor: angle in radians as float, cos/sin in double then narrowed
@@ -1407,11 +1464,22 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     // pixel at offset (r, c) from the keypoint is (sum_s k[s] * hb[18 + r + s][ax + 18 + c] + 2^15) >> 16
     // LDS byte offset of hb[18 + r][ax + 18 + c] = r * 80 + (2 c + hbase): one shift-add and one 24-bit multiply-add;
     // the seven taps are immediates from there, combined with 24-bit multiply-adds (sums stay below 2^24)
+#if OD_LAYOUT
+    // column-major: the seven values of a sample are consecutive u16 of column ax + 18 + c starting at row 18 + r: byte
+    // offset 2 * ((ax + 18 + c) * OD_RP + 18 + r) in the wave's hbT
+    const int hbase = (int)((const uint8_t *)hb - smem) + 2 * ((ax + 18) * OD_RP + 18);
+    auto blurred = [&](int r, int c) -> unsigned {
+        const int byteIdx = vmad24(c, 2 * OD_RP, (r << 1) + hbase);
+        const unsigned *p = (const unsigned *)(smem + (byteIdx & ~3));
+        return od_vblur7_dwords(p[0], p[1], p[2], p[3], (unsigned)(byteIdx & 2) << 3);
+    };
+#else
     const int hbase = (int)((const uint8_t *)(hb + 18 * OD_HP + ax + 18) - smem);
     auto blurred = [&](int r, int c) -> unsigned {
         const unsigned short *p = (const unsigned short *)(smem + vmad24(r, 2 * OD_HP, (c << 1) + hbase));
         return od_vblur7(p[0], p[OD_HP], p[2 * OD_HP], p[3 * OD_HP], p[4 * OD_HP], p[5 * OD_HP], p[6 * OD_HP]);
     };
+#endif
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f scPair = {sb, ca}, csPair = {ca, sb};
     unsigned long long words[4];
