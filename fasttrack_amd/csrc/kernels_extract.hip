@@ -464,13 +464,15 @@ __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int 
 __host__ __device__ __forceinline__ int fc_score_bytes(int wCell, int hCell, int TP) { return (((hCell + 2) * fc_pitch(wCell, TP)) + 15) & ~15; }
 __host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + FC_CORN) + 16; }  // + the spare entry
 
+// dbg (FT_FAST_DBG, a timing probe - results are wrong with it): 1 replaces the score network by a three-pixel hash, 2 stops in
+// front of NMS / emission, 4 right behind the staging of the tile; tools/fast_probe.py times the kernel with each of them.
 // ORDERED = false (device octree, which ranks candidates by their coordinates): the rejection pass is free to
 // visit the pixels in any order and uses all 64 lanes (see below); ORDERED = true delivers every cell's
 // candidates row-major, as the host octree expects them.
 template <int TP, bool ORDERED>
 __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
                                                    int iniTh, int minTh, int alignedLoads, int *cellCount,
-                                                   uint32_t *stage, const uint32_t *cellTab, FtSlotGrid sg) {
+                                                   uint32_t *stage, const uint32_t *cellTab, FtSlotGrid sg, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
     int slot = blockIdx.y, cellSg = 0;
@@ -564,6 +566,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     // the whole score plane (a multiple of 16 bytes, 16-byte aligned) is cleared with 16-byte stores: two per lane
     for (int i = lane; i < fc_score_bytes(L.wCell, L.hCell, TP) >> 4; i += 64) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
     wave_lds_sync();
+    if (dbg & 4) {
+        if (lane == 0) *cnt = (int)tile[lane] & 0;
+        return;
+    }
     const uint8_t *t0 = tile + ax;  // pixel (x, y) of the cell sub-image at t0[y * tp + x]
     // ---- phase A / B rounds.  A: high-speed rejection (OpenCV's opposite-pair test without the
     // polarity): a 9-arc contains one pixel of every opposite pair, so for the two compass pairs (k = 0, 4)
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
 #define FT_LD(k, ox, oy) ringPx[k] = (int)win[((oy) + 3) * tp + (ox) + 3];
                 FT_RING(FT_LD)
 #undef FT_LD
-                const int sc = fast_score(v, ringPx);
+                const int sc = (dbg & 1) ? ((v + ringPx[0] + ringPx[5] + ringPx[11]) & 31) : fast_score(v, ringPx);
                 if (sc >= minTh) {
                     score[(y + 1) * tp + (x + 1)] = (uint8_t)sc;
                     isCorner = true;
@@ -792,6 +798,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     // (ORBextractor.cc:1157-1177: if any survivor reaches iniThFAST only those are emitted, otherwise every
     // minThFAST survivor is) and emission.  The corner list is in row-major order in the ORDERED variant; a cell with more
     // than FC_CORN corners scans the score plane instead (same order).
+    if (dbg & 2) {
+        if (lane == 0) *cnt = 0;
+        return;
+    }
     const bool useList = ncorn <= FC_CORN;
     const int nItems = useList ? ncorn : npx;
     auto nms = [&](int item, int &pix) -> int {
@@ -1595,7 +1605,8 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
     const size_t smem = ft_fast_smem_bytes(g);
     const int TP = fast_tile_pitch(g);
     typedef void (*FastFn)(FtGeom, const uint8_t *const *, int, const uint8_t *, int, int, int, int *, uint32_t *, const uint32_t *,
-                           FtSlotGrid);
+                           FtSlotGrid, int);
+    static const int dbg = getenv("FT_FAST_DBG") ? atoi(getenv("FT_FAST_DBG")) : 0;
     FtSlotGrid sg;
     sg.blocksPerSlot = 0; sg.batch = batch; sg.xcdMap = 0; sg.magic = 0;
     if (batch >= 8) sg = ft_slot_grid(g.totalCells, batch, grid);  // image -> XCD; smaller launches keep the cell-run mapping
@@ -1605,7 +1616,7 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
     if (smem > 64 * 1024)  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
         FT_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
-        hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab, sg);
+        hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab, sg, dbg);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
