@@ -273,7 +273,10 @@ def main():
     if not args.no_host_in:
         hsteps = max(2, min(args.steps, 12))
         run(2, hptrsL, hptrsR, False)
+        ctx.reset_stats()
         dt_h = shard.reduce_max(dist, timed(hsteps, hptrsL, hptrsR, False))
+        if args.stats:
+            ctx.save_stats(args.stats + ".host_in" + (f".rank{rank}" if world > 1 else ""))
         host_in = {"value": B * hsteps * world / dt_h, "unit": "frames/s", "steps": hsteps, "ms_per_step": 1e3 * dt_h / hsteps,
                    "h2d_bytes_per_step_per_gpu": 2 * B * fb, "h2d_GBps_per_gpu": 2 * B * fb * hsteps / dt_h / 1e9,
                    "note": "frames in pinned host memory (ft_host_malloc), uploaded inside the timed region; results to host as in the headline"}
@@ -299,9 +302,11 @@ def main():
                        not args.mosaic and args.density == 1.0)  # the profiled scenes are the default ones
 
         def leg(stat, kernel, total_bytes, per_group=1):
-            m, n = ctx.get_stat(stat)
+            k = kern[stat]  # read before the host-in region reset the statistics
+            n = k["launches"]
             if not n:
                 return None
+            m = k["ms_per_launch"] * n
             achieved = total_bytes / (m / 1e3) / 1e9
             traffic = None
             t = tk.get(kernel)

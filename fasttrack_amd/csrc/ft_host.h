@@ -204,6 +204,7 @@ struct ft_stereo_frontend {
     hipGraphExec_t graphExec = nullptr;
     bool graphDisabled = false;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipEvent_t evDone[2] = {nullptr, nullptr};  // end of the submitted batch on the two stage-B streams
     struct Pending {  // batch enqueued by ft_stereo_frontend_submit, finished by ft_stereo_frontend_wait
         bool active = false, direct = false, graph = false;
         int batch = 0, capacity = 0;

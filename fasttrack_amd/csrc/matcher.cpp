@@ -147,6 +147,7 @@ int ft_stereo_frontend_create(ft_context *ctx, int nfeatures, float scale_factor
     if (e == hipSuccess) e = hipEventCreateWithFlags(&fe->evR, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&fe->evFork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&fe->evJoin, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&fe->evDone[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         ft_stereo_frontend_destroy(fe);
         return ft_hip_fail(e, "stereo frontend allocation", __FILE__, __LINE__);
@@ -172,6 +173,8 @@ int ft_stereo_frontend_destroy(ft_stereo_frontend *fe) {
     if (fe->evR) hipEventDestroy(fe->evR);
     if (fe->evFork) hipEventDestroy(fe->evFork);
     if (fe->evJoin) hipEventDestroy(fe->evJoin);
+    for (int i = 0; i < 2; i++)
+        if (fe->evDone[i]) hipEventDestroy(fe->evDone[i]);
     if (fe->graphExec) hipGraphExecDestroy(fe->graphExec);
     delete fe;
     return FT_OK;
@@ -574,8 +577,14 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
         rc = frontendEnqueue(fe, imagesL, imagesR, batch, on_device, width, height, stride, keysL, descL, nL, keysR, descR,
                              nR, capacity, uright, depth, n_matches, direct, 0, paired);
         if (rc != FT_OK) return rc;
+        // the end of this batch, marked NOW: ft_stereo_frontend_wait waits for these events and not for the streams - a
+        // stream synchronisation enqueues its marker at the time of the call, behind whatever another front end has put
+        // into the same hardware queue since (the runtime multiplexes all streams onto a few in-order queues), so waiting
+        // for batch k-1 returned only when batch k was nearly through and the upload of batch k+1 started that late
+        FT_HIP(hipEventRecord(fe->evDone[0], L->streamB));
+        FT_HIP(hipEventRecord(fe->evDone[1], R->streamB));
     }
-    // everything is enqueued; ft_stereo_frontend_wait drains the streams and finishes the outputs
+    // everything is enqueued; ft_stereo_frontend_wait waits for the end of the batch and finishes the outputs
     auto &P = fe->pending;
     P.imagesL.assign(imagesL, imagesL + batch);
     P.imagesR.assign(imagesR, imagesR + batch);
@@ -604,9 +613,14 @@ int ft_stereo_frontend_wait(ft_stereo_frontend *fe) {
     const FtGeom &g = L->geom;
     FtTimer tTail;
     P.active = false;
-    if (P.graph) FT_HIP(hipStreamSynchronize(L->stream));  // a captured batch completes on the stream it was launched on
-    FT_HIP(hipStreamSynchronize(L->streamB));
-    FT_HIP(hipStreamSynchronize(R->streamB));
+    if (P.graph) {
+        FT_HIP(hipStreamSynchronize(L->stream));  // a captured batch completes on the stream it was launched on
+        FT_HIP(hipStreamSynchronize(L->streamB));
+        FT_HIP(hipStreamSynchronize(R->streamB));
+    } else {
+        FT_HIP(hipEventSynchronize(fe->evDone[0]));
+        FT_HIP(hipEventSynchronize(fe->evDone[1]));
+    }
     fe->ctx->addStat("stereo.host_tail_sync", tTail.ms());
     L->evt.resolve(fe->ctx);
     R->evt.resolve(fe->ctx);
