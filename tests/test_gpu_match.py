@@ -127,6 +127,49 @@ def test_stereo_frontend_submit_wait_two_in_flight(ctx):
             assert np.array_equal(gk, kL) and np.array_equal(gd, dL) and np.array_equal(gu, o["uright"]) and gn == o["n"]
 
 
+@pytest.mark.parametrize("B", [4, 12])  # latency mode (captured graph, upload kernel) and one strided copy per batch
+def test_stereo_frontend_submit_wait_pinned_ring(ctx, B):
+    """The input-frame contract of submit / wait (include/fasttrack_amd.h): frames in pinned host memory are read in place
+    after submit returns, so a camera ring buffer may recycle a slot once wait() has returned for the batch that used it -
+    and not before.  Two front ends in flight over a ring of two slots, every slot overwritten right after its wait()."""
+    import ctypes as C
+    w, h, nf = 752, 480, 1200
+    intr = synth.intrinsics(w, h)
+    fes = [orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"]) for _ in range(2)]
+    batches = [[synth.make_stereo_pair(w, h, 170 + 10 * k + b) for b in range(B)] for k in range(4)]
+    ring = [(ctx.pinned_array((B, h, w), np.uint8), ctx.pinned_array((B, h, w), np.uint8)) for _ in range(2)]
+    ptrs = [((C.c_void_p * B)(*[r[0].ctypes.data + b * w * h for b in range(B)]),
+             (C.c_void_p * B)(*[r[1].ctypes.data + b * w * h for b in range(B)])) for r in ring]
+
+    def fill(slot, k):
+        for b in range(B):
+            ring[slot][0][b], ring[slot][1][b] = batches[k][b]
+
+    def results(f):
+        return [(f._kL[b, :f._nL[b]].copy(), f._dL[b, :f._nL[b]].copy(), f._ur[b, :f._nL[b]].copy(), int(f._nm[b])) for b in range(B)]
+
+    got = {}
+    for k in range(4):
+        s = k & 1
+        if k >= 2:
+            fes[s].wait()          # batch k - 2 is complete: its results are final ...
+            got[k - 2] = results(fes[s])
+        fill(s, k)                 # ... and its slot may be overwritten
+        fes[s].submit_raw(ptrs[s][0], ptrs[s][1], B, False, w)
+    for k in (2, 3):
+        fes[k & 1].wait()
+        got[k] = results(fes[k & 1])
+        ring[k & 1][0][:] = 0      # overwriting after wait() changes nothing that was delivered
+    for k in range(4):
+        for b in range(B):
+            oL, oR = ob.Extractor(nf), ob.Extractor(nf)
+            kL, dL, _ = oL.extract(batches[k][b][0])
+            kR, dR, _ = oR.extract(batches[k][b][1])
+            o = ob.stereo_match(oL, oR, kL, kR, dL, dR, intr["mbf"], intr["mb"])
+            gk, gd, gu, gn = got[k][b]
+            assert np.array_equal(gk, kL) and np.array_equal(gd, dL) and np.array_equal(gu, o["uright"]) and gn == o["n"]
+
+
 def test_stereo_frontend_device_octree_overflow(ctx):
     """a pair whose level-0 candidates exceed what k_octree sorts in LDS: wait() re-submits the batch with the
     host octree; the outputs still equal the oracle's, and the following batch runs on the device again"""
