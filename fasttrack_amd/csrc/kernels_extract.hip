@@ -639,7 +639,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         const int y0h = half * hRows;              // first row of this lane's half
         const int wMain = min(pw, 32);
         const bool actC = cx < wMain;
-        const unsigned long long actMask = __builtin_amdgcn_ballot_w64(actC);
         const uint8_t *col = t0 + min(cx, wMain - 1) + 3 + y0h * TP;  // (x + 3, tile row y0h)
         const int codeBase = (y0h << 6) | cx;
         unsigned pA = col[3 * TP], pB = col[4 * TP], pC = col[5 * TP];
@@ -650,7 +649,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         unsigned hist0 = __builtin_amdgcn_sad_hi_u8(pA, (unsigned)col[0], 0u);
         unsigned hist1 = __builtin_amdgcn_sad_hi_u8(pC, (unsigned)col[2 * TP], __builtin_amdgcn_sad_u8(pB, (unsigned)col[TP], 0u));
         const unsigned th = (unsigned)minTh;
-        for (int y = 0; y < hRows; y += 4) {
+        const int rowsHalf = half ? ph - hRows : hRows;
+        // blocks of at most 28 rows (seven trips): a lane's verdicts of a block fit one 32-bit mask
+        for (int yb = 0; yb < hRows; yb += 28) {
+        const int yEnd = min(yb + 28, hRows);
+        unsigned cmask = 0;
+        for (int y = yb; y < yEnd; y += 4) {
             const uint8_t *r = col + y * TP;
             unsigned pv[7];
             pv[0] = pA; pv[1] = pB; pv[2] = pC;
@@ -668,36 +672,64 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             const unsigned M1 = pk_min_u16(pk_max_u16(pn1, ps1), pk_max_u16(pe1, pw1));
             hist0 = ps0; hist1 = ps1;
             pA = pv[4]; pB = pv[5]; pC = pv[6];
-            // a row's candidates = lanes that pass, in an active column, in a row of their half: the last two are scalar
-            // masks, so all four row masks cost one v_cmp each and a trip without candidates nothing more
-            unsigned mrow[4];
-            unsigned long long bal[4], any = 0;
-            mrow[0] = M0 & 0xffffu; mrow[1] = M0 >> 16; mrow[2] = M1 & 0xffffu; mrow[3] = M1 >> 16;
-            if (y + 4 <= ph - hRows) {  // wave-uniform: every row of the trip exists in both halves (all trips but the last)
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    bal[k] = __builtin_amdgcn_ballot_w64(mrow[k] > th) & actMask;
-                    any |= bal[k];
+            // Every lane files the verdicts of its column in a bit mask of its own: the compare of a half of M against the
+            // threshold lands in vcc and v_addc shifts it into the mask (mask = 2 * mask + vcc) - two vector instructions per row
+            // and no scalar work at all, where a ballot per row with its popcount, position arithmetic and exec juggling cost
+            // a dozen scalar instructions for every row that holds a candidate.
+            asm("v_cmp_gt_u32_sdwa vcc, %1, %2 src0_sel:WORD_0 src1_sel:DWORD\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                "v_cmp_gt_u32_sdwa vcc, %1, %2 src0_sel:WORD_1 src1_sel:DWORD\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                "v_cmp_gt_u32_sdwa vcc, %3, %2 src0_sel:WORD_0 src1_sel:DWORD\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                "v_cmp_gt_u32_sdwa vcc, %3, %2 src0_sel:WORD_1 src1_sel:DWORD\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                : "+v"(cmask)
+                : "v"(M0), "v"(th), "v"(M1)
+                : "vcc");
+        }
+        {
+            // row yb + r of a half sits at bit T - 1 - r (T = rows walked in the block, a multiple of four); rows the half does
+            // not have and columns beyond the cell are masked out here, once
+            const int T = (yEnd - yb + 3) & ~3;
+            const int cnt = min(max(rowsHalf - yb, 0), T);
+            const unsigned valid = actC ? (((1u << cnt) - 1u) << (T - cnt)) : 0u;
+            cmask &= valid;
+            const int codeTop = codeBase + ((yb + T - 1) << 6);
+            // Emission.  The lanes' candidate counts are scanned once (six DPP adds), which gives every lane the ring slot of
+            // its first candidate; then every lane writes its own candidates one after the other, lowest bit first - as many
+            // rounds as the fullest column holds candidates, each round five vector instructions, a write and the loop test
+            // (a ballot + popcount + position per round, as the rows used to cost, is what this avoids).
+            int incl = __popc(cmask);
+            const int own = incl;
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);  // row_shr:1
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);  // row_shr:2
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);  // row_shr:4
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr:8
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, true);  // row_bcast:15 into rows 1 and 3
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, true);  // row_bcast:31 into rows 2 and 3
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            // (every step leaves room for one more round of 64 in the ring: the appends of the remaining columns rely on it)
+            if (nc + total > FC_CAND - 64) flushB();  // wave-uniform; leaves nc = 0
+            if (total <= FC_CAND - 64) {
+                unsigned short *slot = cand + (nc + incl - own);
+                while (__builtin_amdgcn_ballot_w64(cmask != 0u)) {  // wave-uniform
+                    if (cmask) *slot = (unsigned short)(codeTop - (__builtin_ctz(cmask) << 6));
+                    cmask &= cmask - 1u;
+                    slot++;
                 }
+                nc += total;
             } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const unsigned long long rowMask = (y + k < hRows ? 0x00000000ffffffffull : 0ull) | (y + k < ph - hRows ? 0xffffffff00000000ull : 0ull);
-                    bal[k] = __builtin_amdgcn_ballot_w64(mrow[k] > th) & actMask & rowMask;
-                    any |= bal[k];
+                // more candidates in one block than the ring holds (dense texture): a round per candidate rank with a flush
+                // whenever the ring fills
+                for (;;) {
+                    const unsigned long long b = __builtin_amdgcn_ballot_w64(cmask != 0u);
+                    if (!b) break;  // wave-uniform
+                    const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, (unsigned)nc));
+                    const int bit = __builtin_ctz(cmask | 0x80000000u);
+                    if (__builtin_amdgcn_inverse_ballot_w64(b)) cand[pos] = (unsigned short)(codeTop - (bit << 6));
+                    cmask &= cmask - 1u;
+                    nc += __popcll(b);
+                    if (nc > FC_CAND - 64) flushB();  // wave-uniform
                 }
             }
-            if (any) {  // wave-uniform
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (bal[k]) {  // wave-uniform
-                        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[k], (unsigned)nc));
-                        if (__builtin_amdgcn_inverse_ballot_w64(bal[k])) cand[pos] = (unsigned short)(codeBase + ((y + k) << 6));
-                        nc += __popcll(bal[k]);
-                    }
-                }
-            }
-            if (nc > FC_CAND - 4 * 64) flushB();  // wave-uniform
+        }
         }
         // columns 32 .. pw-1 (four of them for a 36-pixel cell), every row, in linear order
         const int wRem = pw - wMain, nRem = wRem * ph;
