@@ -526,6 +526,20 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             // arithmetic, no exec-mask bookkeeping.  Nine trips are in flight before the first LDS store.
             constexpr int DW = TP / 4, RPT = 64 / DW;
             const int rr = lane / DW, cc4 = 4 * min(lane - rr * DW, nd - 1);
+            if (th > 8 * RPT && th <= 9 * RPT) {  // wave-uniform
+                // the usual cell (41 - 45 tile rows at TP 48): the first eight row groups exist for every lane, so their
+                // rows need no clamp - a load is one address add, its LDS store an immediate offset; only the ninth is clamped
+                const unsigned goff = (unsigned)vmad24(rr, pitch, cc4);
+                unsigned *tl = (unsigned *)(tile + vmad24(rr, TP, cc4));
+                const int row8 = min(8 * RPT + rr, th - 1);
+                unsigned v[9];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = gload<unsigned>(src + (goff + (unsigned)(k * RPT * pitch)));
+                v[8] = gload<unsigned>(src + (unsigned)vmad24(row8, pitch, cc4));
+#pragma unroll
+                for (int k = 0; k < 8; k++) tl[k * RPT * (TP / 4)] = v[k];
+                *(unsigned *)(tile + vmad24(row8, TP, cc4)) = v[8];
+            } else
             for (int r0 = 0; r0 < th; r0 += 9 * RPT) {
                 unsigned v[9];
                 int row[9];
@@ -586,37 +600,33 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     // phase B over the buffered candidates: score, corner list (row-major), ring reset
     auto flushB = [&]() {
         wave_lds_sync();
-            for (int jb = 0; jb < nc; jb += 64) {
+        // Branch-free rounds: a lane beyond the last candidate repeats the last one (same score, same store) and is kept out
+        // of the corner list by its flag; a candidate that is no corner stores 0 over the 0 the plane already holds; a lane
+        // with nothing for the corner list writes the spare entry behind the lists.
+        for (int jb = 0; jb < nc; jb += 64) {
             const int j = jb + lane;
-            bool isCorner = false;
-            int ci2 = 0;
-            if (j < nc) {
-                ci2 = cand[j];
-                const int y = pixY(ci2), x = pixX(ci2, y);
-                // top-left corner of the pixel's 7 x 7 ring window: with a fixed pitch every ring offset is a non-negative
-                // immediate of the LDS read (a negative one costs an address add of its own)
-                const uint8_t *win = t0 + y * tp + x;
-                const int v = win[3 * tp + 3];
-                int ringPx[16];
+            const int ci2 = cand[min(j, nc - 1)];
+            const int y = pixY(ci2), x = pixX(ci2, y);
+            // top-left corner of the pixel's 7 x 7 ring window: with a fixed pitch every ring offset is a non-negative
+            // immediate of the LDS read (a negative one costs an address add of its own)
+            const uint8_t *win = t0 + y * tp + x;
+            const int v = win[3 * tp + 3];
+            int ringPx[16];
 #define FT_LD(k, ox, oy) ringPx[k] = (int)win[((oy) + 3) * tp + (ox) + 3];
-                FT_RING(FT_LD)
+            FT_RING(FT_LD)
 #undef FT_LD
-                const int sc = (dbg & 1) ? ((v + ringPx[0] + ringPx[5] + ringPx[11]) & 31) : fast_score(v, ringPx);
-                if (sc >= minTh) {
-                    score[(y + 1) * tp + (x + 1)] = (uint8_t)sc;
-                    isCorner = true;
-                }
-            }
-            const unsigned long long cb = __ballot(isCorner);
-            if (isCorner) {
-                const int pos = ncorn + __popcll(cb & ((1ull << lane) - 1ull));
-                if (pos < FC_CORN) corn[pos] = (unsigned short)ci2;
-            }
+            const int sc = (dbg & 1) ? ((v + ringPx[0] + ringPx[5] + ringPx[11]) & 31) : fast_score(v, ringPx);
+            const bool corner = sc >= minTh;
+            score[(y + 1) * tp + (x + 1)] = (uint8_t)(corner ? sc : 0);
+            const bool isCorner = corner && j < nc;
+            const unsigned long long cb = __builtin_amdgcn_ballot_w64(isCorner);
+            const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cb, (unsigned)ncorn));
+            corn[isCorner && pos < FC_CORN ? pos : FC_CORN] = (unsigned short)ci2;  // corn + FC_CORN = the spare entry
             ncorn += __popcll(cb);
         }
         nc = 0;
         wave_lds_sync();
-        };
+    };
 #define FT_AD(ox, oy) __builtin_amdgcn_sad_u8(v, (unsigned)cpx[(oy)*tp + (ox)], 0u)
     // Appends the lanes of a row whose compass pairs pass to the candidate ring, in lane order, without a branch: the
     // other lanes store to the spare entry behind the lists.  (The two diagonal pairs used to be tested first; on
@@ -710,7 +720,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             if (total <= FC_CAND - 64) {
                 unsigned short *slot = cand + (nc + incl - own);
                 while (__builtin_amdgcn_ballot_w64(cmask != 0u)) {  // wave-uniform
-                    if (cmask) *slot = (unsigned short)(codeTop - (__builtin_ctz(cmask) << 6));
+                    // a lane whose mask is empty writes the spare entry behind the lists: no exec juggling in the loop
+                    *(cmask ? slot : cand + (FC_CAND + FC_CORN)) = (unsigned short)(codeTop - (__builtin_ctz(cmask | 0x80000000u) << 6));
                     cmask &= cmask - 1u;
                     slot++;
                 }
@@ -846,24 +857,26 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             y = div_by(item, mg), x = item - y * pw;
             pix = pixCode(y, x);
         }
-        const uint8_t *s = score + (y + 1) * tp + (x + 1);
-        const int v = s[0];
-        const bool keep = v > 0 && v > s[-1] && v > s[1] && v > s[-tp - 1] && v > s[-tp] && v > s[-tp + 1] &&
-                          v > s[tp - 1] && v > s[tp] && v > s[tp + 1];
-        return keep ? (v >= iniTh ? 2 : 1) : 0;
+        // top-left neighbour of the pixel: every offset below is a non-negative immediate with a fixed pitch
+        const uint8_t *s = score + y * tp + x;
+        const unsigned v = s[tp + 1];
+        // strictly greater than all eight neighbours <=> greater than their maximum (three v_max3 and a v_max, no
+        // short-circuit branches); the maximum is >= 0, so a kept pixel has a score
+        const unsigned m = max(max(max(max((unsigned)s[0], (unsigned)s[1]), (unsigned)s[2]),
+                                   max(max((unsigned)s[tp], (unsigned)s[tp + 2]), (unsigned)s[2 * tp])),
+                               max((unsigned)s[2 * tp + 1], (unsigned)s[2 * tp + 2]));
+        return v > m ? (v >= (unsigned)iniTh ? 2 : 1) : 0;
     };
     uint32_t *out = stage + (size_t)slot * g.stagePerSlot + L.stageBase + (size_t)c * L.cellCap;
     int run = 0;
     auto emit = [&](int fl, int pix, int need) {
         const bool f = fl >= need;
-        const unsigned long long b = __ballot(f);
-        if (f) {
-            const int y = pixY(pix), x = pixX(pix, y);
-            const int pos = run + __popcll(b & ((1ull << lane) - 1ull));
-            // keypoint (x+3, y+3) in the cell sub-image, shifted by (j*wCell, i*hCell): ORBextractor.cc:1196-1197
-            if (pos < L.cellCap)
-                out[pos] = ft_pack_cand(x + 3 + cj * L.wCell, y + 3 + ci * L.hCell, score[(y + 1) * tp + (x + 1)]);
-        }
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(f);
+        const int y = pixY(pix), x = pixX(pix, y);
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, (unsigned)run));
+        // keypoint (x+3, y+3) in the cell sub-image, shifted by (j*wCell, i*hCell): ORBextractor.cc:1196-1197
+        const uint32_t packed = ft_pack_cand(x + 3 + cj * L.wCell, y + 3 + ci * L.hCell, score[(y + 1) * tp + (x + 1)]);
+        if (f && pos < L.cellCap) out[pos] = packed;
         run += __popcll(b);
     };
     if (nItems <= 64 * FC_NMS_REG) {
@@ -874,7 +887,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
             fl[q] = 0;
             px[q] = 0;
             if (q * 64 < nItems) {  // wave-uniform
-                if (q * 64 + lane < nItems) fl[q] = nms(q * 64 + lane, px[q]);
+                // lanes beyond the list look at its last entry and drop the verdict (no divergent branch)
+                const int f = nms(min(q * 64 + lane, nItems - 1), px[q]);
+                fl[q] = q * 64 + lane < nItems ? f : 0;
                 anyHi |= __any(fl[q] == 2);
             }
         }
