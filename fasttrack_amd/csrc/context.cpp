@@ -59,6 +59,34 @@ int ft_set_device(const ft_context *ctx) {
     return FT_OK;
 }
 
+int ft_context_upload_stream(ft_context *ctx, hipStream_t *out) {
+    std::lock_guard<std::mutex> lk(ctx->laneMutex);
+    if (!ctx->uploadStream) FT_HIP(hipStreamCreateWithFlags(&ctx->uploadStream, hipStreamNonBlocking));
+    *out = ctx->uploadStream;
+    return FT_OK;
+}
+
+// the streams of the next extractor (see ft_host.h); out[FT_LANE_STREAMS]
+int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, hipStream_t *out, bool *owned) {
+    std::lock_guard<std::mutex> lk(ctx->laneMutex);
+    if (wantPrivate || ctx->laneMap.empty()) {
+        for (int i = 0; i < FT_LANE_STREAMS; i++) out[i] = nullptr;
+        for (int i = 0; i < FT_LANE_STREAMS; i++) FT_HIP(hipStreamCreateWithFlags(&out[i], hipStreamNonBlocking));
+        *owned = true;
+        return FT_OK;
+    }
+    const size_t sets = ctx->laneMap.size() / FT_LANE_STREAMS;
+    const size_t set = (size_t)(ctx->nextLaneSet++) % sets;
+    for (int i = 0; i < FT_LANE_STREAMS; i++) {
+        const size_t lane = (size_t)ctx->laneMap[set * FT_LANE_STREAMS + i];
+        if (ctx->lanes.size() <= lane) ctx->lanes.resize(lane + 1, nullptr);
+        if (!ctx->lanes[lane]) FT_HIP(hipStreamCreateWithFlags(&ctx->lanes[lane], hipStreamNonBlocking));
+        out[i] = ctx->lanes[lane];
+    }
+    *owned = false;
+    return FT_OK;
+}
+
 extern "C" {
 
 const char *ft_version(void) { return "fasttrack_amd 0.1 (gfx950)"; }
@@ -77,6 +105,15 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
         return FT_ERR_INVALID;
     }
     *out = nullptr;
+    // The HIP runtime multiplexes the streams of a process onto GPU_MAX_HW_QUEUES in-order hardware queues (4 unless the
+    // variable says otherwise), handed out as the streams are first used; streams that share a queue run one kernel at a time,
+    // whatever their events say.  With four queues the stage-A streams of both cameras and both front ends of a
+    // double-buffered caller shared ONE queue (66.4 k frames/s on the default bench); which streams share what is worth more
+    // than any kernel change of this round (49 k - 71 k over GPU_MAX_HW_QUEUES = 5 .. 16 with private streams).  So the
+    // library decides it itself: the wide extractors run on "lanes" of the context (ft_host.h) - eight streams, one upload
+    // stream, the matchers' stream - and the runtime is asked for a queue per stream.  The runtime reads the variable when it
+    // initialises, i.e. at the first HIP call of the process: set it here unless the user has.
+    setenv("GPU_MAX_HW_QUEUES", "10", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) {
@@ -96,6 +133,20 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
     if (host_threads <= 0) host_threads = ft_usable_cpus();
     if (host_threads < 1) host_threads = 1;
     ctx->pool = new ft::ThreadPool(host_threads - 1);
+    // FT_LANE_MAP="a b o0 o1  a b o0 o1 ..." : lane of (stage A, stage B, octree 0, octree 1) for the 1st, 2nd, ... extractor
+    // created on the context (the list wraps around); FT_LANE_MAP=own gives every extractor four streams of its own
+    ctx->laneMap = {1, 2, 3, 4, 5, 1, 3, 1, 5, 4, 3, 2, 1, 1, 7, 6};
+    if (const char *lm = getenv("FT_LANE_MAP")) {
+        ctx->laneMap.clear();
+        for (const char *p = lm; *p;) {
+            char *end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            if (v >= 0 && v < 64) ctx->laneMap.push_back((int)v);
+            p = end;
+        }
+        ctx->laneMap.resize(ctx->laneMap.size() / FT_LANE_STREAMS * FT_LANE_STREAMS);
+    }
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete ctx->pool;
@@ -109,6 +160,15 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
 int ft_context_destroy(ft_context *ctx) {
     if (!ctx) return FT_OK;
     hipSetDevice(ctx->device);
+    for (hipStream_t s : ctx->lanes)
+        if (s) {
+            hipStreamSynchronize(s);
+            hipStreamDestroy(s);
+        }
+    if (ctx->uploadStream) {
+        hipStreamSynchronize(ctx->uploadStream);
+        hipStreamDestroy(ctx->uploadStream);
+    }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->scratchDev) hipFree(ctx->scratchDev);
     if (ctx->scratchPin) hipHostFree(ctx->scratchPin);

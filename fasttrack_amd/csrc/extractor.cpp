@@ -182,13 +182,17 @@ void freeAll(ft_extractor *ex) {
         if (ex->evO[i]) hipEventDestroy(ex->evO[i]);
     }
     if (ex->evJoin) hipEventDestroy(ex->evJoin);
+    if (ex->evUp) hipEventDestroy(ex->evUp);
     if (ex->graphExec) hipGraphExecDestroy(ex->graphExec);
     for (int i = 0; i < FT_OCT_STREAMS; i++)
         if (ex->streamO[i]) {
             hipStreamSynchronize(ex->streamO[i]);
-            hipStreamDestroy(ex->streamO[i]);
+            if (ex->ownStreams) hipStreamDestroy(ex->streamO[i]);
         }
-    if (ex->streamB) hipStreamDestroy(ex->streamB);
+    if (ex->streamB) {
+        hipStreamSynchronize(ex->streamB);
+        if (ex->ownStreams) hipStreamDestroy(ex->streamB);
+    }
     hipFree(ex->d_pyr);
     if (ex->h_stage) hipHostFree(ex->h_stage);
     if (ex->h_srcTab) hipHostFree(ex->h_srcTab);
@@ -225,7 +229,10 @@ void freeAll(ft_extractor *ex) {
     hipHostFree(ex->h_nSel);
     hipHostFree(ex->h_keys);
     hipHostFree(ex->h_desc);
-    if (ex->stream) hipStreamDestroy(ex->stream);
+    if (ex->stream) {
+        hipStreamSynchronize(ex->stream);
+        if (ex->ownStreams) hipStreamDestroy(ex->stream);
+    }
 }
 
 }  // namespace
@@ -281,6 +288,15 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
     }
     // host frames laid out at a constant distance from each other (a camera ring buffer, a decoded clip): the whole batch
     // goes up as ONE strided copy - rows of the copy = frames - instead of one DMA operation per frame
+    // Uploads of host frames outside a captured graph go through the context's upload stream, which carries nothing but
+    // copies: the extractors' own streams are lanes they share with other extractors (ft_host.h), and a 0.5 GB copy in front
+    // of another front end's kernels would hold those up.  (The previous batch of this extractor is complete - the caller has
+    // waited for it - so nothing still reads the slots the copies overwrite.)
+    hipStream_t us = ex->stream;
+    if (!on_device && !ex->stageHost) {
+        rc = ft_context_upload_stream(ex->ctx, &us);
+        if (rc != FT_OK) return rc;
+    }
     bool oneCopy = false;
     if (!on_device && !ex->stageHost && batch >= 4 && stride == width && g.lv[0].pitch == width) {
         oneCopy = images[0] != nullptr;
@@ -290,7 +306,7 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
             if (!images[b] || images[b] - images[b - 1] != delta) oneCopy = false;
         if (oneCopy) {
             FT_HIP(hipMemcpy2DAsync(ex->d_pyr + g.lv[0].off, g.pyrPerSlot, images[0], (size_t)delta, (size_t)width * height, batch,
-                                    hipMemcpyHostToDevice, ex->stream));
+                                    hipMemcpyHostToDevice, us));
         }
     }
     for (int b = 0; b < batch; b++) {
@@ -311,9 +327,12 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
             FT_HIP(hipMemcpy2DAsync(slot0, g.lv[0].pitch, stg, width, width, height, hipMemcpyHostToDevice, ex->stream));
         } else {
             ex->h_l0[b] = slot0;
-            FT_HIP(hipMemcpy2DAsync(slot0, g.lv[0].pitch, images[b], stride, width, height, hipMemcpyHostToDevice,
-                                    ex->stream));
+            FT_HIP(hipMemcpy2DAsync(slot0, g.lv[0].pitch, images[b], stride, width, height, hipMemcpyHostToDevice, us));
         }
+    }
+    if (us != ex->stream) {
+        FT_HIP(hipEventRecord(ex->evUp, us));
+        FT_HIP(hipStreamWaitEvent(ex->stream, ex->evUp, 0));
     }
     ex->l0External = on_device != 0;
     // dword tile loads need 4-byte aligned rows; the slot pyramids always are, caller frames may not be
@@ -736,14 +755,21 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
             return rc;       \
         }                    \
     } while (0)
-    hipError_t se = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
-    if (se == hipSuccess) se = hipStreamCreateWithFlags(&ex->streamB, hipStreamNonBlocking);
-    for (int i = 0; i < FT_OCT_STREAMS && se == hipSuccess; i++) se = hipStreamCreateWithFlags(&ex->streamO[i], hipStreamNonBlocking);
+    {
+        hipStream_t lanes[FT_LANE_STREAMS];
+        // latency-mode extractors (graph capture) own their streams; wide ones run on the context's lanes
+        FT_TRY(ft_context_take_lanes(ctx, max_batch <= 16, lanes, &ex->ownStreams));
+        ex->stream = lanes[0];
+        ex->streamB = lanes[1];
+        for (int i = 0; i < FT_OCT_STREAMS; i++) ex->streamO[i] = lanes[2 + i];
+    }
+    hipError_t se = hipSuccess;
     for (int i = 0; i < FT_PIPE_MAX && se == hipSuccess; i++) {
         se = hipEventCreateWithFlags(&ex->evA[i], hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&ex->evB[i], hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&ex->evO[i], hipEventDisableTiming);
         if (se == hipSuccess && i == 0) se = hipEventCreateWithFlags(&ex->evJoin, hipEventDisableTiming);
+        if (se == hipSuccess && i == 0) se = hipEventCreateWithFlags(&ex->evUp, hipEventDisableTiming);
     }
     if (se != hipSuccess) {
         freeAll(ex);
@@ -1032,7 +1058,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
     bool done = false;
     const bool devWanted = ex->deviceOctree;
     static const bool graphsOn = !(getenv("FT_GRAPH") && getenv("FT_GRAPH")[0] == '0');
-    if (graphsOn && !ex->graphDisabled && ex->deviceOctree && !ex->ctx->kernelTiming && batch >= 1 && batch <= 8 &&
+    if (graphsOn && !ex->graphDisabled && ex->ownStreams && ex->deviceOctree && !ex->ctx->kernelTiming && batch >= 1 && batch <= 8 &&
         batch <= ex->maxBatch && width == ex->width && height == ex->height && stride >= width) {
         bool ok = true;
         for (int b = 0; b < batch; b++)

@@ -12,18 +12,32 @@
 #include "thread_pool.h"
 
 #define FT_PIPE_MAX 8
-// Streams per extractor: stage A, stage B and FT_OCT_STREAMS octree streams = 4, the number of hardware queues the
-// runtime multiplexes streams onto (round-robin in creation order).  With exactly four, every extractor's stage-A
-// streams share one hardware queue, the stage-B streams another and the octree streams the remaining two, so a long,
-// thin k_octree never sits in front of a wide kernel of another stream (measured on MI355X, default bench: 1 octree
-// stream 32.3 k frames/s, 2: 37.4 k, 4: 35.5 k).  Placement is the runtime's business: a different one only costs speed.
+// Streams of an extractor: stage A, stage B and FT_OCT_STREAMS octree streams (a long, thin k_octree never sits in front
+// of a wide kernel of the same stream; measured on MI355X, default bench: 1 octree stream 32.3 k frames/s, 2: 37.4 k,
+// 4: 35.5 k).  The streams belong to the CONTEXT, which keeps FT_LANE_SETS sets of them ("lanes") and hands the sets to
+// the extractors in turn: the left and the right extractor of a stereo front end get different sets, the second front end
+// of a double-buffered caller gets the same two again.  Why: the runtime multiplexes streams onto a few in-order hardware
+// queues in an order of its own (least used queue at first use), and which streams end up sharing a queue decides the
+// throughput - with 16 private streams the default bench ran 49 k to 71 k frames/s depending on GPU_MAX_HW_QUEUES (5 .. 16).
+// Which stream goes to which lane is a table (ft_context::laneMap, FT_LANE_MAP) found by a search on the default bench
+// (tools/lane_search.py: random maps 45 - 66 k frames/s, hill climbing from the best 73.4 k).  Extractors for small batches
+// (latency mode) keep streams of their own: their batches are captured as HIP graphs, and a stream under capture cannot be
+// shared with another host thread.
 #define FT_OCT_STREAMS 2
+#define FT_LANE_STREAMS (2 + FT_OCT_STREAMS)
 
 struct ft_context {
     int device = 0;
     std::string deviceName;
     ft::ThreadPool *pool = nullptr;
     hipStream_t stream = nullptr;  // context-level stream for the stand-alone matchers
+    // lanes[set * FT_LANE_STREAMS + {0: stage A, 1: stage B, 2..: octree}], created on demand; laneSets = 0: every extractor
+    // creates (and owns) its streams
+    std::mutex laneMutex;
+    std::vector<hipStream_t> lanes;
+    hipStream_t uploadStream = nullptr;  // host frames of whole batches go up here (copies only)
+    std::vector<int> laneMap;  // [extractor k mod sets][role] -> lane; empty: private streams
+    int nextLaneSet = 0;
     // grow-only scratch of the stand-alone matchers (one call at a time per context)
     std::mutex matchMutex;
     void *scratchDev = nullptr, *scratchPin = nullptr;
@@ -104,6 +118,7 @@ struct ft_extractor {
     // the device octree is a long, narrow kernel (one wave per level and image): it runs on its own streams
     // so that the wide stage-A kernels of the following sub-batches are not queued behind it
     hipStream_t streamO[FT_OCT_STREAMS] = {};
+    bool ownStreams = false;  // false: the streams are lanes of the context
     hipEvent_t evO[FT_PIPE_MAX] = {};
     // latency mode of ft_extract / ft_extract_batch: a small batch with a fixed call shape is captured once as a HIP
     // graph (see ft_stereo_frontend::GraphKey); the key is everything baked into the nodes
@@ -117,6 +132,7 @@ struct ft_extractor {
     hipGraphExec_t graphExec = nullptr;
     bool graphDisabled = false;
     hipEvent_t evJoin = nullptr;
+    hipEvent_t evUp = nullptr;  // the batch of host frames has arrived (recorded on the upload stream of the context)
     // device buffers
     uint8_t *d_pyr = nullptr;
     FtTap *d_taps = nullptr;
@@ -218,6 +234,8 @@ struct ft_stereo_frontend {
 };
 
 int ft_set_device(const ft_context *ctx);
+int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, hipStream_t *out, bool *owned);  // out[FT_LANE_STREAMS]
+int ft_context_upload_stream(ft_context *ctx, hipStream_t *out);  // the copy-only stream of the context (created on demand)
 bool ft_is_pinned_host(const void *p);  // null counts as pinned (nothing to copy)
 bool ft_is_pinned_host_range(const void *p, size_t bytes);  // [p, p + bytes) inside ONE pinned host allocation
 int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes);  // grow-only matcher scratch (hold matchMutex)

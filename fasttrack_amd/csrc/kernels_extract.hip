@@ -280,12 +280,15 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
     const int sw = g.lv[level - 1].w, sh = g.lv[level - 1].h;
     const int dx = tx * PR_COLS + 2 * lane;  // first of this lane's two output columns
     const int j0 = ty * PR_RB, nrows = min(PR_RB, D.h - j0);
-    // row taps: lane r holds (sy | b0 << 16, b1) of output row j0 + r
+    // row taps: lane r holds the two source rows (clamped to the level, packed sy0 | sy1 << 16) and the two weights
+    // (b0 | b1 << 16) of output row j0 + r - unpacked and clamped once here, by the vector unit for all rows at a time;
+    // the loop below reads a row's pair with two v_readlane and four scalar instructions
     unsigned rowW0 = 0, rowW1 = 0;
     if constexpr (!AREA) {
         const ft_u2 t = gload<ft_u2>(taps + D.ytab + j0 + min(lane, nrows - 1));
-        rowW0 = t.x;
-        rowW1 = t.y;
+        const int sy = (int)(short)(t.x & 0xffffu);
+        rowW0 = (unsigned)min(max(sy, 0), sh - 1) | ((unsigned)min(max(sy + 1, 0), sh - 1) << 16);
+        rowW1 = (t.x >> 16) | (t.y << 16);
     }
     // column taps; columns beyond the level repeat its last column (their stores are masked)
     const int dxa = min(dx, D.w - 1), dxb = min(dx + 1, D.w - 1);
@@ -311,9 +314,8 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
             sy0 = 2 * (j0 + r); sy1 = sy0 + 1; b0 = b1 = 0;
         } else {
             const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)rowW0, r), w1 = (unsigned)__builtin_amdgcn_readlane((int)rowW1, r);
-            const int sy = (int)(short)(w0 & 0xffffu);
-            sy0 = min(max(sy, 0), sh - 1); sy1 = min(max(sy + 1, 0), sh - 1);
-            b0 = w0 >> 16; b1 = w1 & 0xffffu;
+            sy0 = (int)(w0 & 0xffffu); sy1 = (int)(w0 >> 16);
+            b0 = w1 & 0xffffu; b1 = w1 >> 16;
         }
     };
     int jr = 0, sy0, sy1;
@@ -331,53 +333,74 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
     const unsigned round2 = 0x20000u;
     // PR_PF source rows are in flight ahead of the one being used (a ring of registers, the loop unrolled over it): a
     // wave's life is a chain of dependent row loads, and a store counts on the same counter as a load, so with one row
-    // in flight every wait would also wait for the stores just issued
-    const uint8_t *pfRow = srcRow;  // row min(r + k, rLast) for the next prefetch
-    int pfIdx = r;
-    auto prefetch = [&]() -> ft_u2 {
-        unsigned offS = laneSrc;
-        // (the empty asm keeps the zero-extension of the lane offset inside this block, where instruction selection
-        // can fold it into the scalar-base addressing mode)
-        asm volatile("" : "+v"(offS));
-        const ft_u2 v = gload<ft_u2>(pfRow + offS);
-        if (pfIdx < rLast) { pfRow += spitch; pfIdx++; }  // wave-uniform
-        return v;
-    };
-    ft_u2 q0 = prefetch(), q1 = prefetch(), q2 = prefetch(), q3 = prefetch();
-    unsigned hpA = 0, hpB = 0, hcA = 0, hcB = 0;
-    auto step = [&](const ft_u2 cur) {
-        hpA = hcA; hpB = hcB;
-        hcA = udot2_u16(__builtin_amdgcn_perm(cur.y, cur.x, selA), wa);
-        hcB = udot2_u16(__builtin_amdgcn_perm(cur.y, cur.x, selB), wb);
-        if constexpr (!AREA) { hcA >>= 4; hcB >>= 4; }
-        while (jr < nrows && sy1 == r) {  // wave-uniform
-            // both taps on one source row happens only where cv::resize clamps the rows (top and bottom edge): monotonic,
-            // so the upper-row registers may simply be overwritten
-            if (sy0 == r) { hpA = hcA; hpB = hcB; }
-            unsigned oA, oB;
-            if constexpr (AREA) {
-                oA = (hpA + hcA + 2u) >> 2; oB = (hpB + hcB + 2u) >> 2;
-            } else {
-                // ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2; the + 2 rides in the first product
-                oA = ((umad24_su(b0, hpA, round2) >> 16) + (umul24_su(b1, hcA) >> 16)) >> 2;
-                oB = ((umad24_su(b0, hpB, round2) >> 16) + (umul24_su(b1, hcB) >> 16)) >> 2;
+    // in flight every wait would also wait for the stores just issued.
+    // The loop exists twice: for strips inside the level, where every lane stores its two columns (no exec masks in the
+    // loop), and for the last strip of a row of strips.
+    auto run = [&](auto edgeTag) {
+        constexpr bool EDGE = decltype(edgeTag)::value;
+        const uint8_t *pfRow = srcRow;  // row min(r + k, rLast) for the next prefetch
+        int pfLeft = rLast - r;         // rows the prefetch pointer may still advance
+        auto prefetch = [&]() -> ft_u2 {
+            unsigned offS = laneSrc;
+            // (the empty asm keeps the zero-extension of the lane offset inside this block, where instruction selection
+            // can fold it into the scalar-base addressing mode)
+            asm volatile("" : "+v"(offS));
+            const ft_u2 v = gload<ft_u2>(pfRow + offS);
+            pfRow += pfLeft > 0 ? spitch : 0;  // wave-uniform
+            pfLeft--;
+            return v;
+        };
+        ft_u2 q0 = prefetch(), q1 = prefetch(), q2 = prefetch(), q3 = prefetch();
+        unsigned hpA = 0, hpB = 0, hcA = 0, hcB = 0;
+        // a source row is used up by its two horizontal interpolations; the next row of the ring is requested into the same
+        // registers right behind them (requested before, it would need registers of its own and the ring would have to be
+        // copied around at the end of every trip - behind a wait for all of its loads)
+        auto take = [&](ft_u2 &q) {
+            hpA = hcA; hpB = hcB;
+            hcA = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selA), wa);
+            hcB = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selB), wb);
+            if constexpr (!AREA) { hcA >>= 4; hcB >>= 4; }
+            q = prefetch();
+        };
+        auto step = [&]() {
+            while (sy1 == r) {  // wave-uniform; sy1 = -1 once every output row is written
+                // both taps on one source row happens only where cv::resize clamps the rows (top and bottom edge): monotonic,
+                // so the upper-row registers may simply be overwritten
+                if (sy0 == r) { hpA = hcA; hpB = hcB; }
+                unsigned oA, oB;
+                if constexpr (AREA) {
+                    oA = (hpA + hcA + 2u) >> 2; oB = (hpB + hcB + 2u) >> 2;
+                } else {
+                    // ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2; the + 2 rides in the first product
+                    oA = ((umad24_su(b0, hpA, round2) >> 16) + (umul24_su(b1, hcA) >> 16)) >> 2;
+                    oB = ((umad24_su(b0, hpB, round2) >> 16) + (umul24_su(b1, hcB) >> 16)) >> 2;
+                }
+                unsigned offD = laneDst;
+                asm volatile("" : "+v"(offD));
+                if constexpr (!EDGE) {
+                    gstore<unsigned short>(dstRow + offD, (unsigned short)(oA | (oB << 8)));
+                } else {
+                    if (store2) gstore<unsigned short>(dstRow + offD, (unsigned short)(oA | (oB << 8)));
+                    else if (store1) gstore<uint8_t>(dstRow + offD, (uint8_t)oA);
+                }
+                dstRow += D.pitch;
+                jr++;
+                rowTap(min(jr, nrows - 1), sy0, sy1, b0, b1);
+                if (jr >= nrows) sy1 = -1;
             }
-            unsigned offD = laneDst;
-            asm volatile("" : "+v"(offD));
-            if (store2) gstore<unsigned short>(dstRow + offD, (unsigned short)(oA | (oB << 8)));
-            else if (store1) gstore<uint8_t>(dstRow + offD, (uint8_t)oA);
-            dstRow += D.pitch;
-            jr++;
-            if (jr < nrows) rowTap(jr, sy0, sy1, b0, b1);
+            r++;
+        };
+        // whole trips of four: the up to three steps behind the last source row see the last row again (the prefetch
+        // pointer stops there) and write nothing, since every output row is done by then (sy1 = -1)
+        for (int left = rLast - r + 1; left > 0; left -= 4) {
+            take(q0); step();
+            take(q1); step();
+            take(q2); step();
+            take(q3); step();
         }
-        r++;
     };
-    while (r <= rLast) {
-        { const ft_u2 c = q0; q0 = prefetch(); step(c); if (r > rLast) break; }
-        { const ft_u2 c = q1; q1 = prefetch(); step(c); if (r > rLast) break; }
-        { const ft_u2 c = q2; q2 = prefetch(); step(c); if (r > rLast) break; }
-        { const ft_u2 c = q3; q3 = prefetch(); step(c); }
-    }
+    if (tx * PR_COLS + PR_COLS <= D.w) run(std::false_type{});  // wave-uniform
+    else run(std::true_type{});
 }
 
 // ------------------------------------------------------------------------------------------------

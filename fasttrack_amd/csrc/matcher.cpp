@@ -482,7 +482,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
                         isPinnedHost(uright) && isPinnedHost(depth) && (!dev || capacity >= g.maxKp);
     // ---- latency mode: small batches with a fixed call shape run as one captured graph ----
     static const bool graphsOn = !(getenv("FT_GRAPH") && getenv("FT_GRAPH")[0] == '0');
-    bool useGraph = graphsOn && !fe->graphDisabled && dev && direct && !fe->ctx->kernelTiming && batch >= 1 &&
+    bool useGraph = graphsOn && !fe->graphDisabled && L->ownStreams && R->ownStreams && dev && direct && !fe->ctx->kernelTiming && batch >= 1 &&
                     batch <= FT_GRAPH_MAX_BATCH && batch <= fe->maxBatch && width == L->width && height == L->height &&
                     stride >= width;
     bool launched = false;

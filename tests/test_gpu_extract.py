@@ -358,6 +358,36 @@ def test_two_host_threads_two_extractors(ctx):
     ctx2.close()
 
 
+def test_host_threads_on_shared_lanes(ctx):
+    """Wide extractors (max_batch > 16) do not own their streams: they run on the context's lanes, which several extractors
+    share (ft_host.h).  Four of them - as many as the lane table has rows - driven by four host threads at once, with host
+    frames (the shared upload stream) and with resident ones, give the single-threaded results."""
+    import threading
+    w, h, nf, B = 640, 480, 1000, 24
+    imgs = [synth.make_image(w, h, seed=300 + i) for i in range(B)]
+    exs = [orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=32) for _ in range(4)]
+    ref = exs[0].extract_batch(imgs)
+    dev = [ctx.to_device(im) for im in imgs]
+    got, err = {}, []
+
+    def work(k):
+        try:
+            for it in range(3):
+                if (k + it) & 1:
+                    got[k] = exs[k].extract_batch(dev, on_device=True, width=w, height=h, stride=w)
+                else:
+                    got[k] = exs[k].extract_batch(imgs)
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not err, err
+    for k in range(4):
+        for (rk, rd, rm), (gk, gd, gm) in zip(ref, got[k]):
+            assert np.array_equal(rk, gk) and np.array_equal(rd, gd) and rm == gm
+
+
 def test_random_configurations_bit_exact(ctx):
     """seeded sweep over image sizes, feature counts, pyramid depths, scale factors and FAST thresholds (cells of every
     width class: fixed-pitch 48 / 64 and the any-size fallback; levels with a single cell row; quotas above and below the
