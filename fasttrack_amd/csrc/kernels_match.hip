@@ -123,25 +123,40 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
             const uint8_t *pl1 = imL + (size_t)(yl0 + min(r1, 10)) * pitchL + xl0 + c1;
             const uint8_t *pr0 = imR + (size_t)(yl0 + r0) * pitchR + xr00 + c0;
             const uint8_t *pr1 = imR + (size_t)(yl0 + min(r1, 10)) * pitchR + xr00 + c1;
-            const int a0 = gload<uint8_t>(pl0);
-            const int a1 = gload<uint8_t>(pl1);
-            int b0[11], b1[11];
+            // the lanes whose second pixel does not exist (p1 >= 121) carry 0 on both sides
+            const bool two = p1 < 121;
+            const unsigned a0 = gload<uint8_t>(pl0);
+            const unsigned a1r = gload<uint8_t>(pl1);
+            unsigned b0[11], b1[11];
 #pragma unroll
             for (int s = 0; s < 11; s++) {
                 b0[s] = gload<uint8_t>(pr0 + s);
                 b1[s] = gload<uint8_t>(pr1 + s);
             }
+            const unsigned a1 = two ? a1r : 0u;
+#pragma unroll
+            for (int s = 0; s < 11; s++) b1[s] = two ? b1[s] : 0u;
+            // two shifts per register: v_sad_u8 adds |a - b| to the low half, v_sad_hi_u8 to the high half (a lane's two
+            // pixels give at most 510, a wave's sum at most 121 * 255 < 2^16), so six wave sums serve the eleven shifts
             int bestS = 0x7fffffff, bestinc = 0;
             float dists[11];
 #pragma unroll
-            for (int s = 0; s < 11; s++) {
-                int d = abs(a0 - b0[s]);
-                if (p1 < 121) d += abs(a1 - b1[s]);
-                d = wave_sum_i32(d);
-                dists[s] = (float)d;
-                if (d < bestS) {
-                    bestS = d;
+            for (int s = 0; s < 11; s += 2) {
+                unsigned d = __builtin_amdgcn_sad_u8(a1, b1[s], __builtin_amdgcn_sad_u8(a0, b0[s], 0u));
+                if (s + 1 < 11) d = __builtin_amdgcn_sad_hi_u8(a1, b1[s + 1], __builtin_amdgcn_sad_hi_u8(a0, b0[s + 1], d));
+                const unsigned sum = (unsigned)wave_sum_i32((int)d);
+                const int dLo = (int)(sum & 0xffffu), dHi = (int)(sum >> 16);
+                dists[s] = (float)dLo;
+                if (dLo < bestS) {
+                    bestS = dLo;
                     bestinc = s - Ls;
+                }
+                if (s + 1 < 11) {
+                    dists[s + 1] = (float)dHi;
+                    if (dHi < bestS) {
+                        bestS = dHi;
+                        bestinc = s + 1 - Ls;
+                    }
                 }
             }
             if (!(bestinc == -Ls || bestinc == Ls)) {
