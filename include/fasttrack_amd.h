@@ -55,7 +55,10 @@ FT_API const char *ft_version(void);
 FT_API const char *ft_last_error(void);
 FT_API int ft_device_count(void); /* number of HIP devices, 0 if none (never fails) */
 /* host_threads: workers for the host-side octree stage (0 = the CPUs this process may use:
- * hardware threads capped by affinity and by a cgroup CPU quota) */
+ * hardware threads capped by affinity and by a cgroup CPU quota).
+ * Side effect: sets GPU_MAX_HW_QUEUES=10 in the process environment unless the variable is already set (the HIP
+ * runtime reads it at the first HIP call of the process): extractors for batches of more than 16 frames run on eight
+ * streams of the context and are fastest when each of those has a hardware queue of its own. */
 FT_API int ft_context_create(int device, int host_threads, ft_context **out);
 FT_API int ft_context_destroy(ft_context *ctx);
 FT_API int ft_context_synchronize(ft_context *ctx);
