@@ -106,6 +106,8 @@ int buildGeometry(ft_extractor *ex, std::vector<FtTap> &taps) {
         v.nRows = nRows;
         v.cellBase = cellBase;
         v.cellCap = ((v.wCell + 1) / 2) * ((v.hCell + 1) / 2);  // strict 3x3 maxima cannot be adjacent
+        FT_REQUIRE(v.cellCap < 65536 && v.wCell + 6 < 256 && v.hCell + 6 < 256, "FAST cell too large for the cell records");
+        g.fastLv[l] = (unsigned)v.pitch | ((unsigned)v.cellCap << 16);
         v.stageBase = stageBase;
         v.candBase = candBase;
         v.candCap = nCols * nRows * v.cellCap;
@@ -814,17 +816,31 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         }
     }
     {
-        std::vector<uint32_t> cellTab(std::max(g.totalCells, 1), 0u);
-        for (int l = 0; l < nlevels; l++)
-            for (int ci = 0; ci < g.lv[l].nRows; ci++)
-                for (int cj = 0; cj < g.lv[l].nCols; cj++)
-                    cellTab[g.lv[l].cellBase + ci * g.lv[l].nCols + cj] = (uint32_t)l | ((uint32_t)ci << 8) | ((uint32_t)cj << 20);
+        std::vector<FtCellRec> cellTab(std::max(g.totalCells, 1), FtCellRec{0, 0, 0, 0});
+        for (int l = 0; l < nlevels; l++) {
+            const FtLevelGeom &v = g.lv[l];
+            for (int ci = 0; ci < v.nRows; ci++)
+                for (int cj = 0; cj < v.nCols; cj++) {
+                    // ORBextractor.cc:1138-1152: the cell's sub-image [iniX, maxX) x [iniY, maxY) and the skip rules;
+                    // cv::FAST finds nothing in a sub-image under 7 px
+                    const int iniX = 16 + cj * v.wCell, iniY = 16 + ci * v.hCell;
+                    const int maxX = std::min(iniX + v.wCell + 6, v.maxBX), maxY = std::min(iniY + v.hCell + 6, v.maxBY);
+                    int tw = maxX - iniX, th = maxY - iniY;
+                    if (iniX >= v.maxBX - 6 || iniY >= v.maxBY - 3 || tw < 7 || th < 7) tw = th = 0;
+                    const int c = ci * v.nCols + cj;
+                    FtCellRec &r = cellTab[v.cellBase + c];
+                    r.origin = (uint32_t)iniX | ((uint32_t)iniY << 16);
+                    r.shape = (uint32_t)tw | ((uint32_t)th << 8) | ((uint32_t)l << 16);
+                    r.srcOff = (uint32_t)(v.off + iniY * v.pitch + iniX);
+                    r.outOff = (uint32_t)(v.stageBase + c * v.cellCap);
+                }
+        }
         std::vector<uint32_t> stripTab(std::max(g.totalStrips, 1), 0u);
         for (int l = 0; l < nlevels; l++)
             for (int sy = 0; sy < g.lv[l].sNY; sy++)
                 for (int sx = 0; sx < g.lv[l].sNX; sx++)
                     stripTab[g.lv[l].stripBase + sy * g.lv[l].sNX + sx] = (uint32_t)l | ((uint32_t)sy << 8) | ((uint32_t)sx << 20);
-        hipError_t e = hipMemcpy(ex->d_cellTab, cellTab.data(), cellTab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpy(ex->d_cellTab, cellTab.data(), cellTab.size() * sizeof(FtCellRec), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(ex->d_stripTab, stripTab.data(), stripTab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(ex->d_cellCount2, 0, sizeof(int) * std::max<size_t>(B * g.totalCells * 2, 1));
         if (e == hipSuccess) e = hipMemcpy(ex->d_taps, taps.data(), taps.size() * sizeof(FtTap), hipMemcpyHostToDevice);

@@ -136,7 +136,7 @@ struct ft_extractor {
     // device buffers
     uint8_t *d_pyr = nullptr;
     FtTap *d_taps = nullptr;
-    uint32_t *d_cellTab = nullptr;  // per FAST cell: level | cell row << 8 | cell column << 20
+    FtCellRec *d_cellTab = nullptr;  // per FAST cell: origin, tile shape, level, source and staging offsets
     int *d_cellCount = nullptr;
     uint32_t *d_stripTab = nullptr;  // per FAST strip: level | strip row << 8 | strip column << 20
     int *d_cellCount2 = nullptr;     // [maxBatch][totalCells][2]: strong / weak survivors per cell (strips form), zero between launches

@@ -47,7 +47,17 @@ struct FtGeom {
     int totalStrips;   // FAST strips of all levels
     float sf[FT_MAX_LEVELS];     // mvScaleFactor
     float invsf[FT_MAX_LEVELS];  // mvInvScaleFactor
+    unsigned fastLv[FT_MAX_LEVELS];  // k_fast_cells: row pitch | cellCap << 16 of the level (one scalar load)
     FtLevelGeom lv[FT_MAX_LEVELS];
+};
+
+// k_fast_cells: everything a wave needs to know about its cell, built with the extractor (one 16-byte scalar load where the
+// kernel used to derive it from the level geometry with ~70 scalar instructions and a dozen dependent scalar loads)
+struct FtCellRec {
+    uint32_t origin;  // iniX | iniY << 16: top-left corner of the cell's sub-image (ORBextractor.cc:1138-1147)
+    uint32_t shape;   // tile width | tile height << 8 | level << 16; width 0 = the reference skips the cell (:1141,1150)
+    uint32_t srcOff;  // byte offset of pixel (iniX, iniY) in the slot's pyramid buffer (levels >= 1)
+    uint32_t outOff;  // entry offset of the cell's staging slot in the slot's staging buffer
 };
 
 // candidate / keypoint packing: x | y << 12 | score << 24 (x, y < 4096; score <= 254)
@@ -157,7 +167,7 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
                       uint8_t *pyr, const FtTap *taps, int alignedLoads);
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
-                         uint32_t *stage, int ordered, const uint32_t *cellTab);
+                         uint32_t *stage, int ordered, const FtCellRec *cellTab);
 int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cellCount, const uint32_t *stage,
                       uint32_t *cand, int *candCount);
 // strips form (device octree): FAST over 62-column strips that ignore the cell grid; every NMS survivor is filed under

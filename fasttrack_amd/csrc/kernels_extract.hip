@@ -495,7 +495,8 @@ __host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + 
 template <int TP, bool ORDERED>
 __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
                                                    int iniTh, int minTh, int alignedLoads, int *cellCount,
-                                                   uint32_t *stage, const uint32_t *cellTab, FtSlotGrid sg, int dbg) {
+                                                   uint32_t *stage, const FtCellRec *cellTab, FtSlotGrid sg, int dbg, int tileBytes,
+                                                   int scoreBytesMax) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
     int slot = blockIdx.y, cellSg = 0;
@@ -509,39 +510,41 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
     const int j = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
     const int cell = sg.xcdMap ? cellSg : ((j / FC_XCD_RUN) * 8 + xcd) * FC_XCD_RUN + (j % FC_XCD_RUN);
     if (cell >= g.totalCells) return;
-    // (level, cell row, cell column) of the cell from a table built with the extractor: no search, no division
-    const uint32_t ct = cellTab[cell];
-    const int level = (int)(ct & 0xffu), ci = (int)((ct >> 8) & 0xfffu), cj = (int)(ct >> 20);
-    const FtLevelGeom &L = g.lv[level];
-    const int c = cell - L.cellBase;
-    const int iniX = 16 + cj * L.wCell, iniY = 16 + ci * L.hCell;
-    const int maxX = min(iniX + L.wCell + 6, L.maxBX), maxY = min(iniY + L.hCell + 6, L.maxBY);
+    // the cell's record, built with the extractor: origin, tile size, level, source and staging offsets in one scalar load
+    const FtCellRec rec = cellTab[cell];
+    const int iniX = (int)(rec.origin & 0xffffu), iniY = (int)(rec.origin >> 16);
+    const int tw = (int)(rec.shape & 0xffu), th = (int)((rec.shape >> 8) & 0xffu), level = (int)((rec.shape >> 16) & 0xffu);
     int *cnt = cellCount + (size_t)slot * g.totalCells + cell;
-    const int tw = maxX - iniX, th = maxY - iniY;
-    // ORBextractor.cc:1141,1150 skip rules; cv::FAST finds nothing in a sub-image under 7 px
-    if (iniX >= L.maxBX - 6 || iniY >= L.maxBY - 3 || tw < 7 || th < 7) {
+    // ORBextractor.cc:1141,1150 skip rules; cv::FAST finds nothing in a sub-image under 7 px (the record says so)
+    if (tw == 0) {
         if (lane == 0) *cnt = 0;
         return;
     }
+    const unsigned lv = g.fastLv[level];
+    const int cellCap = (int)(lv >> 16);
     const int pw = tw - 6, ph = th - 6;  // tested region
     const int npx = pw * ph;
-    const int tp = TP ? TP : fc_pitch(L.wCell, 0);
+    // the any-size variant derives its LDS pitch from the level's cell width; the fixed-pitch variants carve the LDS by the
+    // launch-wide maxima (the launcher sizes the allocation by them anyway)
+    const int tp = TP ? TP : fc_pitch(g.lv[level].wCell, 0);
     // division by the row length: only the any-size variant unpacks pixel codes with it (the fixed-pitch variants
     // need it on the rare score-plane scan alone and compute it there)
     const unsigned pwMagic = TP ? 0u : div_magic_of((unsigned)pw);
     uint8_t *tile = smem;
-    uint8_t *score = tile + fc_tile_bytes(L.wCell, L.hCell, TP);
-    unsigned short *cand = (unsigned short *)(score + fc_score_bytes(L.wCell, L.hCell, TP));
+    uint8_t *score = tile + (TP ? tileBytes : fc_tile_bytes(g.lv[level].wCell, g.lv[level].hCell, 0));
+    const int scoreBytes = TP ? ((ph + 2) * TP + 15) & ~15 : fc_score_bytes(g.lv[level].wCell, g.lv[level].hCell, 0);
+    unsigned short *cand = (unsigned short *)(score + (TP ? scoreBytesMax : scoreBytes));
     unsigned short *corn = cand + FC_CAND;
     uint8_t *surv = tile;
-    const int pitch = level ? L.pitch : l0pitch;
-    const uint8_t *img = level ? pyr + (size_t)slot * g.pyrPerSlot + L.off : img0;
+    const int pitch = level ? (int)(lv & 0xffffu) : l0pitch;
+    // pixel (iniX, iniY) of the level
+    const uint8_t *org = level ? pyr + ((size_t)slot * g.pyrPerSlot + rec.srcOff) : img0 + ((size_t)iniY * l0pitch + iniX);
     // ---- stage the tile: aligned dword rows when the level allows it (coalesced 4-byte lanes) ----
     int ax = 0;
     if (alignedLoads) {
         ax = iniX & 3;
         const int nd = (tw + ax + 3) >> 2;
-        const uint8_t *src = img + (size_t)iniY * pitch + (iniX - ax);
+        const uint8_t *src = org - ax;
         if constexpr (TP != 0) {
             // fixed (row, dword) per lane: TP/4 dwords span a tile row, 64 / (TP/4) rows per trip.  Rows and dwords beyond
             // the tile are clamped to its last row / dword instead of being masked: such a lane loads and stores the
@@ -594,14 +597,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         }
     } else {
         const unsigned twMagic = div_magic_of((unsigned)tw);
-        const uint8_t *src = img + (size_t)iniY * pitch + iniX;
+        const uint8_t *src = org;
         for (int i = lane; i < tw * th; i += 64) {
             const int y = div_by(i, twMagic), x = i - y * tw;
             tile[y * tp + x] = gload<uint8_t>(src + (size_t)y * pitch + x);
         }
     }
     // the whole score plane (a multiple of 16 bytes, 16-byte aligned) is cleared with 16-byte stores: two per lane
-    for (int i = lane; i < fc_score_bytes(L.wCell, L.hCell, TP) >> 4; i += 64) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < scoreBytes >> 4; i += 64) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
     wave_lds_sync();
     if (dbg & 4) {
         if (lane == 0) *cnt = (int)tile[lane] & 0;
@@ -890,7 +893,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
                                max((unsigned)s[2 * tp + 1], (unsigned)s[2 * tp + 2]));
         return v > m ? (v >= (unsigned)iniTh ? 2 : 1) : 0;
     };
-    uint32_t *out = stage + (size_t)slot * g.stagePerSlot + L.stageBase + (size_t)c * L.cellCap;
+    uint32_t *out = stage + ((size_t)slot * g.stagePerSlot + rec.outOff);
     int run = 0;
     auto emit = [&](int fl, int pix, int need) {
         const bool f = fl >= need;
@@ -898,8 +901,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         const int y = pixY(pix), x = pixX(pix, y);
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, (unsigned)run));
         // keypoint (x+3, y+3) in the cell sub-image, shifted by (j*wCell, i*hCell): ORBextractor.cc:1196-1197
-        const uint32_t packed = ft_pack_cand(x + 3 + cj * L.wCell, y + 3 + ci * L.hCell, score[(y + 1) * tp + (x + 1)]);
-        if (f && pos < L.cellCap) out[pos] = packed;
+        const uint32_t packed = ft_pack_cand(x + (iniX - 13), y + (iniY - 13), score[(y + 1) * tp + (x + 1)]);
+        if (f && pos < cellCap) out[pos] = packed;
         run += __popcll(b);
     };
     if (nItems <= 64 * FC_NMS_REG) {
@@ -937,7 +940,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         }
     }
     (void)surv;
-    if (lane == 0) *cnt = min(run, L.cellCap);
+    if (lane == 0) *cnt = min(run, cellCap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1609,13 +1612,17 @@ static int fast_tile_pitch(const FtGeom &g) {
 
 size_t ft_fast_smem_bytes(const FtGeom &g) {
     const int TP = fast_tile_pitch(g);
-    size_t mx = 0;
+    // the fixed-pitch variants carve tile | score plane | lists at the largest tile and the largest score plane of any
+    // level; the any-size variant at the sizes of the cell's own level
+    size_t mxTile = 0, mxScore = 0, mxSum = 0;
     for (int l = 0; l < g.nlevels; l++) {
         const FtLevelGeom &L = g.lv[l];
-        mx = std::max(mx, (size_t)fc_tile_bytes(L.wCell, L.hCell, TP) + fc_score_bytes(L.wCell, L.hCell, TP) +
-                              fc_list_bytes());
+        const size_t t = (size_t)fc_tile_bytes(L.wCell, L.hCell, TP), sc = (size_t)fc_score_bytes(L.wCell, L.hCell, TP);
+        mxTile = std::max(mxTile, t);
+        mxScore = std::max(mxScore, sc);
+        mxSum = std::max(mxSum, t + sc);
     }
-    return mx;
+    return (TP ? mxTile + mxScore : mxSum) + fc_list_bytes();
 }
 
 // the row-streaming kernel needs every lane's four taps inside one aligned 8-byte window of a source row
@@ -1668,14 +1675,20 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
 
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
-                         uint32_t *stage, int ordered, const uint32_t *cellTab) {
+                         uint32_t *stage, int ordered, const FtCellRec *cellTab) {
     if (g.totalCells == 0) return FT_OK;  // every level is too small for a 35-px cell: no candidates
     const int runBlock = 8 * FC_XCD_RUN;  // grid padded to whole rounds of the XCD mapping
     dim3 grid(((g.totalCells + runBlock - 1) / runBlock) * runBlock, batch, 1), block(64, 1, 1);
     const size_t smem = ft_fast_smem_bytes(g);
     const int TP = fast_tile_pitch(g);
-    typedef void (*FastFn)(FtGeom, const uint8_t *const *, int, const uint8_t *, int, int, int, int *, uint32_t *, const uint32_t *,
-                           FtSlotGrid, int);
+    // LDS carve of the fixed-pitch variants: the largest tile and score plane of any level (the allocation is sized by them)
+    int tileBytes = 0, scoreBytes = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        tileBytes = std::max(tileBytes, fc_tile_bytes(g.lv[l].wCell, g.lv[l].hCell, TP));
+        scoreBytes = std::max(scoreBytes, fc_score_bytes(g.lv[l].wCell, g.lv[l].hCell, TP));
+    }
+    typedef void (*FastFn)(FtGeom, const uint8_t *const *, int, const uint8_t *, int, int, int, int *, uint32_t *, const FtCellRec *,
+                           FtSlotGrid, int, int, int);
     static const int dbg = getenv("FT_FAST_DBG") ? atoi(getenv("FT_FAST_DBG")) : 0;
     FtSlotGrid sg;
     sg.blocksPerSlot = 0; sg.batch = batch; sg.xcdMap = 0; sg.magic = 0;
@@ -1686,7 +1699,8 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
     if (smem > 64 * 1024)  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
         FT_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
-        hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab, sg, dbg);
+        hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab, sg, dbg,
+                           tileBytes, scoreBytes);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
