@@ -17,6 +17,6 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
   -d $OUT/pmc_sq -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/bench_sq.log 2>&1
 python3 $REPO/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
-tail -1 $OUT/bench_trace.log > $OUT/bench_line_under_profiler.json
+grep -a '^{"metric"' $OUT/bench_trace.log | tail -1 > $OUT/bench_line_under_profiler.json
 # keep only what is needed (the merge back is capped at 64 MiB)
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
