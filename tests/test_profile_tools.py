@@ -19,7 +19,7 @@ def test_traffic_json_follows_from_the_rocprof_summary(tmp_path):
     assert abs(f["traffic_bytes_per_launch"] - (2 * f["fetch_kb_raw"] + f["write_kb"]) * 1024) < 1
     # FAST + NMS reads every pyramid pixel once: 256 images x 2 853 088 px; the memory side sees about that, not a third of it
     assert 0.9 < f["traffic_bytes_per_launch"] / (256 * 2853088) < 1.15
-    assert 0.5 < f["valu_issue_frac"] < 1.0 and f["valu_per_wave"] > 500 and f["salu_per_wave"] > 300
+    assert 0.5 < f["valu_issue_frac"] < 1.0 and f["valu_per_wave"] > 500 and f["salu_per_wave"] > 100
 
 
 def test_bench_line_reports_the_committed_traffic():
