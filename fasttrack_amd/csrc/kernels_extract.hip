@@ -366,7 +366,10 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
             while (sy1 == r) {  // wave-uniform; sy1 = -1 once every output row is written
                 // both taps on one source row happens only where cv::resize clamps the rows (top and bottom edge): monotonic,
                 // so the upper-row registers may simply be overwritten
-                if (sy0 == r) { hpA = hcA; hpB = hcB; }
+                if (__builtin_expect(sy0 == r, 0)) {  // wave-uniform and rare: a branch, not two selects per row
+                    hpA = hcA; hpB = hcB;
+                    asm volatile("" : "+v"(hpA), "+v"(hpB));
+                }
                 unsigned oA, oB;
                 if constexpr (AREA) {
                     oA = (hpA + hcA + 2u) >> 2; oB = (hpB + hcB + 2u) >> 2;
