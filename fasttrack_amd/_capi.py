@@ -90,6 +90,10 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(or `make -C fasttrack_amd/csrc`).  fasttrack_amd has no CPU fallback.")
+    # Application-side choice, made before the first HIP call of the process (the HIP runtime reads the variable once, when
+    # it initialises): a hardware queue per lane of the context, which selects the library's eight-lane table
+    # (include/fasttrack_amd.h, ft_context_create).  The library itself never touches the environment.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "10")
     mode = os.RTLD_LOCAL | os.RTLD_NOW | getattr(os, "RTLD_DEEPBIND", 0)
     L = C.CDLL(LIB_PATH, mode=mode)
     vp, i, f = C.c_void_p, C.c_int, C.c_float
@@ -102,6 +106,7 @@ def lib() -> C.CDLL:
     L.ft_context_synchronize.argtypes = [vp]
     L.ft_context_device_name.argtypes = [vp, C.c_char_p, i]
     L.ft_context_host_threads.argtypes = [vp]
+    L.ft_context_hw_queues.argtypes = [vp]
     L.ft_context_save_stats.argtypes = [vp, C.c_char_p]
     L.ft_context_set_kernel_timing.argtypes = [vp, i]
     L.ft_context_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]
@@ -125,6 +130,7 @@ def lib() -> C.CDLL:
     L.ft_extractor_download_level.argtypes = [vp, i, i, vp, i]
     L.ft_extractor_device_level.argtypes = [vp, i, i, C.POINTER(vp), ip]
     L.ft_extractor_download_candidates.argtypes = [vp, i, i, vp, i, ip]
+    L.ft_extractor_octree_on_device.argtypes = [vp, i, vp, i, i, vp, i, ip, ip]
     L.ft_stereo_match.argtypes = [vp, vp, i, vp, i, vp, i, vp, vp, f, f, i, vp, vp, vp, ip]
     L.ft_stereo_frontend_create.argtypes = [vp, i, f, i, i, i, i, i, i, f, f, C.POINTER(vp)]
     L.ft_stereo_frontend_destroy.argtypes = [vp]

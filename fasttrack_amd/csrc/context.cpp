@@ -71,7 +71,16 @@ int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, hipStream_t *out, b
     std::lock_guard<std::mutex> lk(ctx->laneMutex);
     if (wantPrivate || ctx->laneMap.empty()) {
         for (int i = 0; i < FT_LANE_STREAMS; i++) out[i] = nullptr;
-        for (int i = 0; i < FT_LANE_STREAMS; i++) FT_HIP(hipStreamCreateWithFlags(&out[i], hipStreamNonBlocking));
+        for (int i = 0; i < FT_LANE_STREAMS; i++) {
+            const hipError_t e = hipStreamCreateWithFlags(&out[i], hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                for (int k = 0; k < i; k++) {
+                    hipStreamDestroy(out[k]);
+                    out[k] = nullptr;
+                }
+                return ft_hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+            }
+        }
         *owned = true;
         return FT_OK;
     }
@@ -85,6 +94,53 @@ int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, hipStream_t *out, b
     }
     *owned = false;
     return FT_OK;
+}
+
+// hardware queues the HIP runtime multiplexes this process's streams onto: GPU_MAX_HW_QUEUES as the process environment
+// holds it (the runtime reads it once, when it initialises), 4 when it is unset
+int ft_hw_queues_hint() {
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 4;
+}
+
+// "own" (private streams: empty map) or whole sets of four lane numbers in [0, 64); anything else is an error, not a
+// silently different table
+bool ft_parse_lane_map(const char *text, std::vector<int> &map, std::string &err) {
+    std::vector<int> m;
+    const char *p = text;
+    while (*p == ' ' || *p == '\t' || *p == ',') p++;
+    if (strncmp(p, "own", 3) == 0) {
+        p += 3;
+        while (*p == ' ' || *p == '\t') p++;
+        if (*p) {
+            err = "unexpected text after \"own\"";
+            return false;
+        }
+        map.clear();
+        return true;
+    }
+    while (*p) {
+        char *end = nullptr;
+        const long v = strtol(p, &end, 10);
+        if (end == p) {
+            err = std::string("not a number: \"") + p + "\"";
+            return false;
+        }
+        if (v < 0 || v >= 64) {
+            err = "lane " + std::to_string(v) + " outside [0, 64)";
+            return false;
+        }
+        m.push_back((int)v);
+        p = end;
+        while (*p == ' ' || *p == '\t' || *p == ',') p++;
+    }
+    if (m.empty() || m.size() % FT_LANE_STREAMS != 0) {
+        err = std::to_string(m.size()) + " entries: need whole sets of (stage A, stage B, octree 0, octree 1)";
+        return false;
+    }
+    map = m;
+    return true;
 }
 
 extern "C" {
@@ -107,13 +163,24 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
     *out = nullptr;
     // The HIP runtime multiplexes the streams of a process onto GPU_MAX_HW_QUEUES in-order hardware queues (4 unless the
     // variable says otherwise), handed out as the streams are first used; streams that share a queue run one kernel at a time,
-    // whatever their events say.  With four queues the stage-A streams of both cameras and both front ends of a
-    // double-buffered caller shared ONE queue (66.4 k frames/s on the default bench); which streams share what is worth more
-    // than any kernel change of this round (49 k - 71 k over GPU_MAX_HW_QUEUES = 5 .. 16 with private streams).  So the
-    // library decides it itself: the wide extractors run on "lanes" of the context (ft_host.h) - eight streams, one upload
-    // stream, the matchers' stream - and the runtime is asked for a queue per stream.  The runtime reads the variable when it
-    // initialises, i.e. at the first HIP call of the process: set it here unless the user has.
-    setenv("GPU_MAX_HW_QUEUES", "10", 0);
+    // whatever their events say, and which streams share what is worth +-20 % of the throughput (49 k - 71 k frames/s over
+    // GPU_MAX_HW_QUEUES = 5 .. 16 with private streams).  So the wide extractors run on "lanes" of the context (ft_host.h), by a
+    // table made for the number of queues the process HAS: the runtime reads the variable when it initialises - at the first
+    // HIP call of the process, which need not be ours - so the library does not touch the environment (round 2 did: a
+    // setenv that came too late whenever the caller, a device probe or another HIP user had initialised the runtime, and a
+    // write to process-wide state from library code).  The application sets GPU_MAX_HW_QUEUES (10 serves the eight-lane
+    // table: a queue per lane, the upload stream and the matchers' stream) before its first HIP call - bench.py and the
+    // Python driver do - and ft_context_hw_queues() / the "context.hw_queues" statistic say which table is in use.
+    std::vector<int> userMap;
+    const char *lm = getenv("FT_LANE_MAP");
+    const bool haveUserMap = lm != nullptr;
+    if (haveUserMap) {  // checked before anything else: a typo must not pass as a different table
+        std::string err;
+        if (!ft_parse_lane_map(lm, userMap, err)) {
+            ft_set_error("FT_LANE_MAP: " + err);
+            return FT_ERR_INVALID;
+        }
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) {
@@ -135,18 +202,13 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
     ctx->pool = new ft::ThreadPool(host_threads - 1);
     // FT_LANE_MAP="a b o0 o1  a b o0 o1 ..." : lane of (stage A, stage B, octree 0, octree 1) for the 1st, 2nd, ... extractor
     // created on the context (the list wraps around); FT_LANE_MAP=own gives every extractor four streams of its own
-    ctx->laneMap = {1, 2, 3, 4, 5, 1, 3, 1, 5, 4, 3, 2, 1, 1, 7, 6};
-    if (const char *lm = getenv("FT_LANE_MAP")) {
-        ctx->laneMap.clear();
-        for (const char *p = lm; *p;) {
-            char *end = nullptr;
-            const long v = strtol(p, &end, 10);
-            if (end == p) break;
-            if (v >= 0 && v < 64) ctx->laneMap.push_back((int)v);
-            p = end;
-        }
-        ctx->laneMap.resize(ctx->laneMap.size() / FT_LANE_STREAMS * FT_LANE_STREAMS);
-    }
+    ctx->hwQueues = ft_hw_queues_hint();
+    if (ctx->hwQueues >= 8) ctx->laneMap = {1, 2, 3, 4, 5, 1, 3, 1, 5, 4, 3, 2, 1, 1, 7, 6};  // searched with 10 queues (tools/lane_search.py)
+    else ctx->laneMap.clear();  // the runtime's default of four queues: private streams, placed by the runtime (66 k frames/s on the headline
+                                // workload; a lane per stage shared by the cameras and front ends - {0,1,2,3} for everyone - ran 55 k)
+    if (haveUserMap) ctx->laneMap = userMap;
+    ctx->addStat("context.hw_queues", 0.0);
+    ctx->stats["context.hw_queues"].second = ctx->hwQueues;
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete ctx->pool;
@@ -159,6 +221,12 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
 
 int ft_context_destroy(ft_context *ctx) {
     if (!ctx) return FT_OK;
+    if (ctx->liveObjects.load() > 0) {
+        // extractors / front ends of this context still hold its lane streams: destroying those under them would leave
+        // their own destructors synchronising dead handles
+        ft_set_error("ft_context_destroy: extractors, front ends or tracked frames of this context are still alive - destroy them first");
+        return FT_ERR_INVALID;
+    }
     hipSetDevice(ctx->device);
     for (hipStream_t s : ctx->lanes)
         if (s) {
@@ -191,6 +259,8 @@ int ft_context_device_name(ft_context *ctx, char *buf, int len) {
 }
 
 int ft_context_host_threads(const ft_context *ctx) { return ctx ? ctx->pool->size() : 0; }
+
+int ft_context_hw_queues(const ft_context *ctx) { return ctx ? ctx->hwQueues : 0; }
 
 int ft_context_save_stats(ft_context *ctx, const char *path) {
     if (!ctx || !path) return FT_ERR_INVALID;

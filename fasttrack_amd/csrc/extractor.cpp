@@ -212,7 +212,9 @@ void freeAll(ft_extractor *ex) {
     hipFree(ex->d_ovSlot);
     hipFree(ex->d_bigCount);
     hipHostFree(ex->h_bigStat);
+    hipHostFree(ex->h_histStat);
     hipFree(ex->d_bigList);
+    hipFree(ex->d_sortList);
     hipFree(ex->d_candDev);
     hipFree(ex->d_candCountDev);
     hipHostFree(ex->h_selCount);
@@ -457,12 +459,20 @@ int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent
     a.selCount = ex->d_selCount + (size_t)b0 * g.nlevels;
     a.overflow = ex->d_overflow;
     a.ovSlot = ex->d_ovSlot + b0;
-    // second tier (levels with more than FT_OCT_MAXN candidates): the grid the previous batches asked for (0 while the
-    // frames do not need it: a workgroup that wants a CU's whole LDS is not free even when it has nothing to do)
-    a.bigCap = a.bigN ? std::min(ex->bigGrid, nb * g.nlevels) : 0;
-    // one list and one counter pair per octree stream: the launches of two sub-batches run side by side
-    a.bigCount = ex->d_bigCount + 2 * (sub % FT_OCT_STREAMS);
+    // Levels with more than FT_OCT_MAXN candidates.  Large batches always launch the histogram tier, with a list for every
+    // level of the launch and a grid sized by what the previous batches asked for (FT_OCT_HISTMIN workgroups while they asked
+    // for nothing: its workgroups walk the list, so a first dense batch is slow on the device instead of repaired on the
+    // host); small (latency-mode) batches only since a frame needed it (a kernel node more in the captured graph).  The
+    // sorted big tier wants a CU's whole LDS per workgroup and is not free even when idle: the grid the previous batches'
+    // give-ups asked for.
+    const bool histNow = ex->histEnabled && (nb > 16 || ex->lastBatch > 16 || ex->histOn);
+    a.histCap = histNow ? nb * g.nlevels : 0;
+    a.histGrid = ex->lastBatch > 16 ? std::min(ex->histGrid, nb * g.nlevels) : nb * g.nlevels;
+    a.sortCap = a.bigN ? std::min(ex->bigGrid, nb * g.nlevels) : 0;
+    // one set of lists and counters per octree stream: the launches of two sub-batches run side by side
+    a.bigCount = ex->d_bigCount + 4 * (sub % FT_OCT_STREAMS);
     a.bigList = ex->d_bigList + (size_t)(sub % FT_OCT_STREAMS) * ex->maxBatch * g.nlevels;
+    a.sortList = ex->d_sortList + (size_t)(sub % FT_OCT_STREAMS) * ex->maxBatch * g.nlevels;
     const bool tm = ex->ctx->kernelTiming;
     ex->evt.begin(tm, "kernel.octree", so);
     int rc = ft_launch_octree(so, g, nb, a);
@@ -518,21 +528,33 @@ int ft_extract_octree_multi(ft_extractor *const *exs, int nex, int b0, int nb) {
 
 int ft_extract_octree(ft_extractor *ex, int b0, int nb) { return ft_extract_octree_multi(&ex, 1, b0, nb); }
 
-// After a large batch has drained: size the second-tier octree kernel of the following batches by what this one asked for
-// (levels with more than FT_OCT_MAXN candidates per launch), and retire it after a run of batches without demand.
+// After a batch has drained: size the sorted big tier (k_octree_big) of the following batches by what the histogram tier
+// handed on in this one, and retire it after a run of batches without demand.
 void ft_extract_update_big_grid(ft_extractor *ex) {
-    if (!ex->octLayout.bigN) return;
+    if (!ex->octLayout.bigN && !ex->histEnabled) return;
     if (ex->lastBatch <= 16) {
         // latency mode (results delivered by one kernel, no demand counter on the host): an overflow of a frame switches the
-        // second tier on for the frames that follow (the captured graph is re-captured: its key holds the grid)
-        if (ex->h_overflow[0] && ex->bigGrid == 0) ex->bigGrid = ex->maxBatch * ex->nlevels;
+        // histogram tier on for the frames that follow, one more the sorted big tier (the captured graph is re-captured: its
+        // key holds both)
+        if (ex->h_overflow[0]) {
+            if (ex->histEnabled && !ex->histOn) ex->histOn = true;
+            else if (ex->octLayout.bigN && ex->bigGrid == 0) ex->bigGrid = ex->maxBatch * ex->nlevels;
+        }
         return;
     }
-    int want = 0;  // the octree streams keep a list each (launches on different streams run side by side)
+    int want = 0, wantHist = 0;  // the octree streams keep a list each (launches on different streams run side by side)
     for (int k = 0; k < FT_OCT_STREAMS; k++) {
         want = std::max(want, ex->h_bigStat[k]);
-        ex->h_bigStat[k] = 0;
+        wantHist = std::max(wantHist, ex->h_histStat[k]);
+        ex->h_bigStat[k] = ex->h_histStat[k] = 0;
     }
+    if (wantHist > 0) {  // a workgroup per listed level up to FT_OCT_HISTMAX (beyond that they walk the list)
+        ex->histIdle = 0;
+        ex->histGrid = std::max(ex->histGrid, std::min(FT_OCT_HISTMAX, ((wantHist + 63) / 64) * 64));
+    } else if (ex->histGrid > FT_OCT_HISTMIN && ++ex->histIdle >= 16) {
+        ex->histGrid = FT_OCT_HISTMIN;
+    }
+    if (!ex->octLayout.bigN) return;
     if (want > 0) {
         ex->bigIdle = 0;
         const int need = std::max(FT_OCT_BIGMIN, ((want + want / 4 + 63) / 64) * 64);
@@ -662,10 +684,11 @@ int ft_extract_finish_counts(ft_extractor *ex, int batch, hipStream_t st) {
     if (!ex->deviceOctree) return FT_OK;
     FT_HIP(hipMemcpyAsync(ex->h_nSel, ex->d_nSel, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
     FT_HIP(hipMemcpyAsync(ex->h_overflow, ex->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (ex->octLayout.bigN) {  // demand for the second-tier octree kernel during this batch (ft_extract_update_big_grid)
+    if (ex->octLayout.bigN || ex->histEnabled) {  // demand for the tiers behind k_octree during this batch (ft_extract_update_big_grid)
         for (int k = 0; k < FT_OCT_STREAMS; k++) {
-            FT_HIP(hipMemcpyAsync(ex->h_bigStat + k, ex->d_bigCount + 2 * k + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-            FT_HIP(hipMemsetAsync(ex->d_bigCount + 2 * k + 1, 0, sizeof(int), st));
+            FT_HIP(hipMemcpyAsync(ex->h_histStat + k, ex->d_bigCount + 4 * k + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+            FT_HIP(hipMemcpyAsync(ex->h_bigStat + k, ex->d_bigCount + 4 * k + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+            FT_HIP(hipMemsetAsync(ex->d_bigCount + 4 * k + 2, 0, 2 * sizeof(int), st));
         }
     }
     return FT_OK;
@@ -791,10 +814,12 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     FT_TRY(devAlloc(&ex->d_selCount, B * g.nlevels + FT_MAX_LEVELS));  // k_orient_desc reads FT_MAX_LEVELS counts per image at once
     FT_TRY(devAlloc(&ex->d_overflow, 1));
     FT_TRY(devAlloc(&ex->d_ovSlot, B));
-    FT_TRY(devAlloc(&ex->d_bigCount, 2 * FT_OCT_STREAMS));
+    FT_TRY(devAlloc(&ex->d_bigCount, 4 * FT_OCT_STREAMS));
     FT_TRY(pinAlloc(&ex->h_bigStat, FT_OCT_STREAMS));
-    for (int k = 0; k < FT_OCT_STREAMS; k++) ex->h_bigStat[k] = 0;
+    FT_TRY(pinAlloc(&ex->h_histStat, FT_OCT_STREAMS));
+    for (int k = 0; k < FT_OCT_STREAMS; k++) ex->h_bigStat[k] = ex->h_histStat[k] = 0;
     FT_TRY(devAlloc(&ex->d_bigList, (size_t)FT_OCT_STREAMS * B * g.nlevels));
+    FT_TRY(devAlloc(&ex->d_sortList, (size_t)FT_OCT_STREAMS * B * g.nlevels));
     FT_TRY(pinAlloc(&ex->h_selCount, B * g.nlevels));
     FT_TRY(pinAlloc(&ex->h_overflow, 1));
     FT_TRY(devAlloc(&ex->d_keys, B * g.maxKp));
@@ -876,10 +901,13 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         // the node pools must fit a CU's LDS beside FT_OCT_MAXN keys (per-level quotas up to ~1900); u16 node indices
         (void)maxQ;
         ex->deviceOctree = !(e && e[0] == '0') && o.poolCap < 30000 && ft_octree_smem_bytes(o.poolCap) <= 160 * 1024;
-        o.bigCap = 0;
+        o.histCap = o.sortCap = 0;
+        ex->histEnabled = ex->deviceOctree && !(getenv("FT_OCT_HIST") && atoi(getenv("FT_OCT_HIST")) == 0) &&
+                          ft_octree_hist_smem_bytes(o.poolCap) <= 160 * 1024;
         o.bigN = ex->deviceOctree && !(getenv("FT_OCT_BIG") && atoi(getenv("FT_OCT_BIG")) == 0) ? ft_octree_big_keys(o.poolCap) : 0;
         o.bigCount = ex->d_bigCount;
         o.bigList = ex->d_bigList;
+        o.sortList = ex->d_sortList;
         if (ex->deviceOctree) {
             if (getenv("FT_OCT_PROFILE")) {
                 FT_TRY(devAlloc(&o.prof, (size_t)FT_MAX_LEVELS * 8));
@@ -889,7 +917,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
             FT_TRY(devAlloc(&ex->d_candCountDev, B * g.nlevels));
             hipError_t me = hipMemset(ex->d_overflow, 0, sizeof(int));
             if (me == hipSuccess) me = hipMemset(ex->d_ovSlot, 0, sizeof(int) * B);
-            if (me == hipSuccess) me = hipMemset(ex->d_bigCount, 0, 2 * FT_OCT_STREAMS * sizeof(int));
+            if (me == hipSuccess) me = hipMemset(ex->d_bigCount, 0, 4 * FT_OCT_STREAMS * sizeof(int));
             if (me != hipSuccess) {
                 freeAll(ex);
                 delete ex;
@@ -898,6 +926,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         }
     }
 #undef FT_TRY
+    ctx->liveObjects++;
     *out = ex;
     return FT_OK;
 }
@@ -915,11 +944,21 @@ int ft_octree_distribute(const int *xys, int n, int minX, int maxX, int minY, in
     }
     ft::OctreeWorkspace ws;
     std::vector<int> keep;
-    // FT_OCTREE_PATHS=1 / 2 route this host entry point through the path-code formulations the device kernel
-    // is built from (1: node list replay, 2: round formulation), so they can be checked without a GPU
+    // FT_OCTREE_PATHS=1 / 2 / 3 route this host entry point through the path-code formulations the device kernels
+    // are built from (1: node list replay, 2: round formulation over sorted keys, 3: over a histogram), so they can be
+    // checked without a GPU
     static const int usePaths = getenv("FT_OCTREE_PATHS") ? atoi(getenv("FT_OCTREE_PATHS")) : 0;
     int k;
-    if (usePaths == 2 && n < 65535) k = ft::distribute_octree_rounds(packed.data(), n, minX, maxX, minY, maxY, N, keep);
+    if (usePaths == 3 && n < 65535) {
+        // 3: the histogram formulation of k_octree_hist (FT_OCTREE_HIST_BINS bins, default 8192); a level it gives up on
+        // goes to the sorted rounds, as on the device.  FT_OCTREE_HIST_STRICT=1 reports the give-up instead.
+        static const int bins = getenv("FT_OCTREE_HIST_BINS") ? atoi(getenv("FT_OCTREE_HIST_BINS")) : FT_OCT_HIST_BINS;
+        k = ft::distribute_octree_hist(packed.data(), n, minX, maxX, minY, maxY, N, bins, keep);
+        if (k == -2 && !(getenv("FT_OCTREE_HIST_STRICT") && atoi(getenv("FT_OCTREE_HIST_STRICT")))) {
+            keep.clear();
+            k = ft::distribute_octree_rounds(packed.data(), n, minX, maxX, minY, maxY, N, keep);
+        }
+    } else if (usePaths == 2 && n < 65535) k = ft::distribute_octree_rounds(packed.data(), n, minX, maxX, minY, maxY, N, keep);
     else if (usePaths == 1 && n < 65535) k = ft::distribute_octree_paths(packed.data(), n, minX, maxX, minY, maxY, N, keep);
     else k = ft::distribute_octree(packed.data(), n, minX, maxX, minY, maxY, N, ws, keep);
     if (k < 0) {
@@ -963,6 +1002,7 @@ int ft_level_geometry(int width, int height, int nfeatures, float scale_factor, 
 int ft_extractor_destroy(ft_extractor *ex) {
     if (!ex) return FT_OK;
     freeAll(ex);
+    ex->ctx->liveObjects--;
     delete ex;
     return FT_OK;
 }
@@ -1083,7 +1123,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
             ft_extractor::GraphKey key;
             key.batch = batch; key.onDevice = on_device; key.width = width; key.height = height; key.stride = stride;
             key.aligned = 1;
-            key.bigGrid = ex->bigGrid;
+            key.bigGrid = ex->bigGrid + (ex->histOn ? (1 << 24) : 0);
             if (on_device) {
                 if (stride & 3) key.aligned = 0;
                 for (int b = 0; b < batch; b++)
@@ -1295,6 +1335,74 @@ int ft_extractor_download_candidates(ft_extractor *ex, int slot, int level, int 
             xys[3 * i + 1] = (int)((c[i] >> 12) & 0xfffu);
             xys[3 * i + 2] = (int)(c[i] >> 24);
         }
+    }
+    return FT_OK;
+}
+
+// Test tap: the device octree of ONE level on caller-provided candidates (slot 0 of the extractor).  tiers: bit 0 is always
+// on (k_octree), bit 1 allows the histogram tier, bit 2 the sorted big tier.  *tier = the tier that produced the result
+// (1, 2, 3) or 0 when the level was left to the host (overflow flag raised; *n_out = 0).
+int ft_extractor_octree_on_device(ft_extractor *ex, int level, const int *xys, int n, int tiers, int *out_xys, int capacity,
+                                  int *n_out, int *tier) {
+    FT_REQUIRE(ex && xys && n_out && tier && n >= 0, "null argument");
+    FT_REQUIRE(level >= 0 && level < ex->nlevels, "level out of range");
+    FT_REQUIRE(ex->deviceOctree, "the extractor keeps the octree on the host");
+    const FtGeom &g = ex->geom;
+    FT_REQUIRE(n <= g.lv[level].candCap, "more candidates than the level's list holds");
+    int rc = ft_set_device(ex->ctx);
+    if (rc != FT_OK) return rc;
+    std::vector<uint32_t> packed(std::max(n, 1));
+    for (int i = 0; i < n; i++) {
+        FT_REQUIRE(xys[3 * i] >= 3 && xys[3 * i] < 4096 && xys[3 * i + 1] >= 3 && xys[3 * i + 1] < 4096 && xys[3 * i + 2] >= 1 &&
+                       xys[3 * i + 2] < 256,
+                   "candidate out of range");
+        packed[i] = ft_pack_cand(xys[3 * i], xys[3 * i + 1], xys[3 * i + 2]);
+    }
+    hipStream_t so = ex->streamO[0];
+    FT_HIP(hipStreamSynchronize(ex->stream));
+    FT_HIP(hipStreamSynchronize(so));
+    std::vector<int> counts(g.nlevels, 0);
+    counts[level] = n;
+    FT_HIP(hipMemcpy(ex->d_candCountDev, counts.data(), sizeof(int) * g.nlevels, hipMemcpyHostToDevice));
+    if (n) FT_HIP(hipMemcpy(ex->d_candDev + g.lv[level].candBase, packed.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    FT_HIP(hipMemset(ex->d_bigCount, 0, 4 * sizeof(int)));
+    FtOctArgs a = ex->octLayout;
+    a.cand = ex->d_candDev;
+    a.candCount = ex->d_candCountDev;
+    a.sel = ex->d_sel;
+    a.selCount = ex->d_selCount;
+    a.overflow = ex->d_overflow;
+    a.ovSlot = ex->d_ovSlot;
+    a.histCap = (tiers & 2) && ex->histEnabled ? g.nlevels : 0;
+    a.histGrid = g.nlevels;
+    a.sortCap = (tiers & 4) && a.bigN ? g.nlevels : 0;
+    a.bigCount = ex->d_bigCount;
+    a.bigList = ex->d_bigList;
+    a.sortList = ex->d_sortList;
+    rc = ft_launch_octree(so, g, 1, a);
+    if (rc != FT_OK) return rc;
+    FT_HIP(hipStreamSynchronize(so));
+    int cnt[4] = {0, 0, 0, 0}, ov = 0, k = 0;
+    FT_HIP(hipMemcpy(cnt, ex->d_bigCount, sizeof cnt, hipMemcpyDeviceToHost));
+    FT_HIP(hipMemcpy(&ov, ex->d_overflow, sizeof(int), hipMemcpyDeviceToHost));
+    FT_HIP(hipMemcpy(&k, ex->d_selCount + level, sizeof(int), hipMemcpyDeviceToHost));
+    FT_HIP(hipMemset(ex->d_overflow, 0, sizeof(int)));
+    FT_HIP(hipMemset(ex->d_ovSlot, 0, sizeof(int)));
+    FT_HIP(hipMemset(ex->d_bigCount, 0, 4 * sizeof(int)));
+    *tier = ov ? 0 : cnt[1] > 0 ? 3 : cnt[0] > 0 ? 2 : 1;
+    if (ov) k = 0;
+    *n_out = k;
+    if (k > capacity) {
+        ft_set_error("ft_extractor_octree_on_device: capacity too small");
+        return FT_ERR_CAPACITY;
+    }
+    std::vector<FtSelKp> sel(std::max(k, 1));
+    if (k) FT_HIP(hipMemcpy(sel.data(), ex->d_sel + ex->levelOff[level], sizeof(FtSelKp) * k, hipMemcpyDeviceToHost));
+    const int minB = FT_EDGE_THRESHOLD - 3;
+    for (int i = 0; i < k && out_xys; i++) {
+        out_xys[3 * i] = sel[i].x - minB;
+        out_xys[3 * i + 1] = sel[i].y - minB;
+        out_xys[3 * i + 2] = sel[i].response;
     }
     return FT_OK;
 }

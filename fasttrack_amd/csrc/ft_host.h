@@ -1,6 +1,7 @@
 // Host-side object definitions behind the opaque C handles.
 #pragma once
 
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -38,6 +39,8 @@ struct ft_context {
     hipStream_t uploadStream = nullptr;  // host frames of whole batches go up here (copies only)
     std::vector<int> laneMap;  // [extractor k mod sets][role] -> lane; empty: private streams
     int nextLaneSet = 0;
+    int hwQueues = 4;                   // GPU_MAX_HW_QUEUES of the process environment when the context was created (4 = unset)
+    std::atomic<int> liveObjects{0};    // extractors (incl. those of front ends) alive on this context: they hold its lanes
     // grow-only scratch of the stand-alone matchers (one call at a time per context)
     std::mutex matchMutex;
     void *scratchDev = nullptr, *scratchPin = nullptr;
@@ -158,10 +161,16 @@ struct ft_extractor {
     int *d_selCount = nullptr, *h_selCount = nullptr;  // [maxBatch * nlevels]
     int *d_overflow = nullptr, *h_overflow = nullptr;
     int *d_ovSlot = nullptr;         // [maxBatch] which slots overflowed (read only after the summary flag was seen)
-    int *d_bigCount = nullptr;       // second-tier octree kernel, per octree stream: [0] entries of the running launch, [1] maximum since last read
-    int *h_bigStat = nullptr;        // pinned copies of the maxima
-    unsigned *d_bigList = nullptr;   // per octree stream [maxBatch * nlevels] (slot, level) pairs with more than FT_OCT_MAXN candidates
-    int bigGrid = 0, bigIdle = 0;    // grid of k_octree_big for large batches: 0 until a batch asks for it, sized by demand
+    int *d_bigCount = nullptr;       // octree tiers beyond FT_OCT_MAXN candidates, per octree stream: FtOctArgs::bigCount (4 ints)
+    int *h_bigStat = nullptr;        // pinned copies of the sorted big tier's demand ([3])
+    unsigned *d_bigList = nullptr;   // per octree stream [maxBatch * nlevels] (slot, level) pairs for the histogram tier
+    unsigned *d_sortList = nullptr;  // ... and the pairs that tier handed on to k_octree_big
+    bool histEnabled = false;        // k_octree_hist available (FT_OCT_HIST=0 switches it off)
+    bool histOn = false;             // latency mode: launched since a frame overflowed the first tier (large batches: always)
+    int histGrid = FT_OCT_HISTMIN;   // workgroups of k_octree_hist for large batches: by the demand of the previous ones
+    int histIdle = 0;
+    int *h_histStat = nullptr;       // pinned copies of the histogram tier's demand ([1])
+    int bigGrid = 0, bigIdle = 0;    // grid of k_octree_big: 0 until the histogram tier hands levels on, sized by that demand
     FtOctArgs octLayout{};
     // selected keypoints host -> device
     FtSelKp *h_sel = nullptr, *d_sel = nullptr;
@@ -240,6 +249,8 @@ bool ft_is_pinned_host(const void *p);  // null counts as pinned (nothing to cop
 bool ft_is_pinned_host_range(const void *p, size_t bytes);  // [p, p + bytes) inside ONE pinned host allocation
 int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes);  // grow-only matcher scratch (hold matchMutex)
 int ft_usable_cpus();
+int ft_hw_queues_hint();
+bool ft_parse_lane_map(const char *text, std::vector<int> &map, std::string &err);
 int ft_pipeline_depth(int batch, bool deviceOctree);
 // validation, level-0 pointers / uploads of a whole batch (async on ex->stream)
 int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width, int height,

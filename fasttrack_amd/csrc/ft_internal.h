@@ -117,7 +117,10 @@ struct FtTap {
 // kernel that runs behind it; an image with a level beyond that is redone with the host octree (that image only).
 // The per-level quota is bounded by the LDS the node pools need (ft_octree_smem_bytes <= 160 KB).
 #define FT_OCT_MAXN 4096
-#define FT_OCT_BIGMIN 64   // smallest grid of the second-tier kernel once a stream of frames needs it
+#define FT_OCT_HIST_BINS 8192  // bins of the histogram tier (k_octree_hist): nodes of depth D, nIni * 4^D <= this
+#define FT_OCT_HISTMIN 16      // workgroups of the histogram tier while no batch has asked for more (each walks the list)
+#define FT_OCT_HISTMAX 512     // ... and at most (two or three fit a CU)
+#define FT_OCT_BIGMIN 64   // smallest grid of the sorted big tier (k_octree_big) once a stream of frames needs it
 struct FtOctArgs {
     const uint32_t *cand;   // device dense candidate lists [slot * candPerSlot + candBase]
     const int *candCount;   // device [slot * nlevels + level]
@@ -125,10 +128,14 @@ struct FtOctArgs {
     int *selCount;          // device [slot * nlevels + level]
     int *overflow;          // device flag: some image of the launch needs the host octree
     int *ovSlot;            // device [batch]: which ones
-    int *bigCount;          // second tier: [0] listed (slot, level) pairs of this launch, [1] maximum since the host last looked;
-                            // the list, its capacity (= grid of k_octree_big), keys per workgroup
-    unsigned *bigList;
-    int bigCap, bigN;
+    // Levels with more than FT_OCT_MAXN candidates.  bigCount (per octree stream): [0] (slot, level) pairs listed for the
+    // histogram tier by the running launch, [1] pairs that tier handed on to the sorted big tier, [2] / [3] the maxima of
+    // [0] / [1] since the host last looked.  histCap / sortCap: capacity of the lists = grids of
+    // k_octree_big (0 = tier not launched; k_octree_hist walks its list with histGrid workgroups); bigN: keys per
+    // workgroup of k_octree_big.
+    int *bigCount;
+    unsigned *bigList, *sortList;
+    int histCap, histGrid, sortCap, bigN;  // histGrid: workgroups of k_octree_hist (they walk the list)
     int quota[FT_MAX_LEVELS], levelMax[FT_MAX_LEVELS], selOff[FT_MAX_LEVELS];
     int poolCap, keyBytes;
     unsigned long long *prof;  // FT_OCT_PROFILE=1: per-level phase times of slot 0 (wall_clock64 ticks), else null
@@ -190,6 +197,7 @@ int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs
 // test tap: 7x7 Gaussian of a whole level through k_orient_desc's blur routines (dst on the device)
 int ft_launch_blur_level(hipStream_t st, const uint8_t *img, int pitch, int w, int h, uint8_t *dst, int dstPitch);
 size_t ft_octree_smem_bytes(int poolCap);
+size_t ft_octree_hist_smem_bytes(int poolCap);
 int ft_octree_big_keys(int poolCap);
 size_t ft_fast_smem_bytes(const FtGeom &g);
 

@@ -463,6 +463,48 @@ __device__ __forceinline__ int fast_score(int v, const int p[16]) {
     return max(v - brightest, darkest - v) - 1;
 }
 
+// cornerScore of TWO candidates per lane: their ring pixels travel in the halves of a register, and the arc extrema are
+// taken with v_pk_minimum3_f16 / v_pk_maximum3_f16 (gfx950) - three operands AND two halves per instruction, half the
+// instructions of the v_min3_u32 / v_max3_u32 network above per candidate.  The bit patterns 0x0000 .. 0x00ff are f16
+// denormals n * 2^-24, which order like the integers they are; tools/pkmin3_probe.hip checks on the hardware that neither
+// instruction flushes or canonicalises them (all 2 x 16.7 M operand triples, both halves).  v = the two centre pixels.
+__device__ __forceinline__ unsigned pk_min3_h(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_max3_h(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+typedef short fs_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned fast_score2(unsigned v, const unsigned p[16]) {
+    unsigned mn3[16], mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn3[k] = pk_min3_h(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+        mx3[k] = pk_max3_h(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+    }
+    unsigned mn9[16], mx9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn9[k] = pk_min3_h(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
+        mx9[k] = pk_max3_h(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
+    }
+    unsigned darkest = pk_max3_h(mn9[0], mn9[1], mn9[2]), brightest = pk_min3_h(mx9[0], mx9[1], mx9[2]);
+#pragma unroll
+    for (int k = 3; k < 15; k += 2) {
+        darkest = pk_max3_h(darkest, mn9[k], mn9[k + 1]);
+        brightest = pk_min3_h(brightest, mx9[k], mx9[k + 1]);
+    }
+    const fs_s2 dk = __builtin_bit_cast(fs_s2, pk_max3_h(darkest, mn9[15], mn9[15]));
+    const fs_s2 br = __builtin_bit_cast(fs_s2, pk_min3_h(brightest, mx9[15], mx9[15]));
+    const fs_s2 vv = __builtin_bit_cast(fs_s2, v);
+    const fs_s2 sc = __builtin_elementwise_max(vv - br, dk - vv) - (fs_s2)(1);
+    return __builtin_bit_cast(unsigned, sc);
+}
+
 // One WAVE per (cell, image): no workgroup barrier anywhere, so the ~20 cells resident on a CU hide each other's
 // load and LDS latency (LDS per wave is kept near 6 KB); measured VALU bound.
 // TP = LDS pitch of the tile and of the score plane; TP > 0 makes every ring / neighbour offset an
@@ -632,7 +674,36 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         // Branch-free rounds: a lane beyond the last candidate repeats the last one (same score, same store) and is kept out
         // of the corner list by its flag; a candidate that is no corner stores 0 over the 0 the plane already holds; a lane
         // with nothing for the corner list writes the spare entry behind the lists.
-        for (int jb = 0; jb < nc; jb += 64) {
+        int jb = 0;
+        if constexpr (TP > 0) {
+            // rounds of 128: two candidates per lane through the packed network (fast_score2); the corner list takes the
+            // first 64 of a round before the second 64, so its order is the ring's
+            for (; nc - jb > 64 && !(dbg & 1); jb += 128) {
+                const int jA = jb + lane, jB = jb + 64 + lane;
+                const int cA = cand[jA], cB = cand[min(jB, nc - 1)];
+                const int yA = pixY(cA), xA = pixX(cA, yA), yB = pixY(cB), xB = pixX(cB, yB);
+                const uint8_t *wA = t0 + yA * tp + xA, *wB = t0 + yB * tp + xB;
+                const unsigned v2 = (unsigned)wA[3 * tp + 3] | ((unsigned)wB[3 * tp + 3] << 16);
+                unsigned ring2[16];
+#define FT_LD2(k, ox, oy) ring2[k] = (unsigned)wA[((oy) + 3) * tp + (ox) + 3] | ((unsigned)wB[((oy) + 3) * tp + (ox) + 3] << 16);
+                FT_RING(FT_LD2)
+#undef FT_LD2
+                const unsigned sc2 = fast_score2(v2, ring2);
+                const int scA = (int)(short)(sc2 & 0xffffu), scB = (int)(short)(sc2 >> 16);
+                const bool cornA = scA >= minTh, cornB = scB >= minTh;
+                score[(yA + 1) * tp + (xA + 1)] = (uint8_t)(cornA ? scA : 0);
+                score[(yB + 1) * tp + (xB + 1)] = (uint8_t)(cornB ? scB : 0);
+                const bool isB = cornB && jB < nc;
+                const unsigned long long ba = __builtin_amdgcn_ballot_w64(cornA), bb = __builtin_amdgcn_ballot_w64(isB);
+                const int posA = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ba >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ba, (unsigned)ncorn));
+                ncorn += __popcll(ba);
+                const int posB = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bb, (unsigned)ncorn));
+                ncorn += __popcll(bb);
+                corn[cornA && posA < FC_CORN ? posA : FC_CORN] = (unsigned short)cA;  // corn + FC_CORN = the spare entry
+                corn[isB && posB < FC_CORN ? posB : FC_CORN] = (unsigned short)cB;
+            }
+        }
+        for (; jb < nc; jb += 64) {
             const int j = jb + lane;
             const int ci2 = cand[min(j, nc - 1)];
             const int y = pixY(ci2), x = pixX(ci2, y);

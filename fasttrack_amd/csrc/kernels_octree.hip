@@ -12,10 +12,20 @@
 //      literally on lane 0 (octree_paths.h std_sort_replay).
 //   4. per retained node the first-maximum response pick, one lane per node.
 //
-// The result - retained candidates AND their order - equals the host octree (octree.cpp).  Two tiers: k_octree sorts up to
-// FT_OCT_MAXN = 4 096 candidates of a level in LDS; a level with more goes on a list for k_octree_big (the same code with
-// an LDS layout for up to 16 384 keys).  A level beyond that - or a listed one the second tier has no workgroup for - raises
-// the image's overflow flag, and the host redoes that image with the host octree (extractor.cpp ft_extract_repair_*).
+// The result - retained candidates AND their order - equals the host octree (octree.cpp).  Three tiers:
+//   k_octree       sorts up to FT_OCT_MAXN = 4 096 candidates of a level in LDS (the formulation above);
+//   k_octree_hist  a level with more goes on a list for the HISTOGRAM formulation (octree.cpp HistKeys is its host
+//                  statement): nothing is sorted - the candidates are counted per tree node of depth D (nIni * 4^D <=
+//                  FT_OCT_HIST_BINS bins in code order, LDS atomics by the whole workgroup), the exclusive prefix sums of
+//                  the bins are the positions the sorted array would have, so a node's child boundaries are three table
+//                  look-ups instead of three binary searches, and the pick is one more pass over the candidates (bin ->
+//                  final node -> LDS atomic maximum of (response, -emission rank)).  Any number of candidates up to
+//                  65 535 per level, 16 KB of bins instead of 8 bytes per key: two or three workgroups per CU where the
+//                  sorted second tier took a whole CU for a 512-thread bitonic sort of 16 384 keys;
+//   k_octree_big   a level whose tree grows deeper than D somewhere (the quota is spent on a few dense clusters) is
+//                  handed on to the sorted formulation with an LDS layout for up to 16 384 keys.
+// A level beyond all that - or a listed one the next tier has no workgroup for - raises the image's overflow flag, and
+// the host redoes that image with the host octree (extractor.cpp ft_extract_repair_*).
 #include "ft_internal.h"
 #include "octree_paths.h"
 
@@ -43,12 +53,13 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
     return x - v;
 }
 
-// LDS layout of one wave's workspace (offsets in bytes from the dynamic LDS base)
+// LDS layout of one workgroup's workspace (offsets in bytes from the dynamic LDS base)
 struct OctLds {
-    int keys, lohi[2], x01[2], dep[2], vSize, vPrev, ord, bq, pq, mark, stack, total;
+    int keys, lohi[2], x01[2], dep[2], pre[2], vSize, vPrev, ord, bq, pq, mark, stack, best, misc, total;
 };
 
-__host__ __device__ inline OctLds oct_lds_layout(int cap, int maxN) {
+// keyBytes: the sorted tiers hold 8 bytes per key, the histogram tier two bytes per bin (+ the end entry)
+__host__ __device__ inline OctLds oct_lds_layout(int cap, int keyBytes, bool hist) {
     OctLds o;
     int p = 0;
     auto take = [&](int bytes) {
@@ -56,11 +67,12 @@ __host__ __device__ inline OctLds oct_lds_layout(int cap, int maxN) {
         p += (bytes + 15) & ~15;
         return at;
     };
-    o.keys = take(maxN * 8);
+    o.keys = take(keyBytes);
     for (int i = 0; i < 2; i++) {
         o.lohi[i] = take(2 * cap * 4);
         o.x01[i] = take(2 * cap * 4);
         o.dep[i] = take(2 * cap);
+        o.pre[i] = hist ? take(2 * cap * 4) : 0;  // code prefix of a node (the sorted tiers read it from the node's first key)
     }
     o.vSize = take(cap * 8);
     o.vPrev = take(cap * 8);
@@ -69,9 +81,12 @@ __host__ __device__ inline OctLds oct_lds_layout(int cap, int maxN) {
     o.pq = take(cap * 4);  // exclusive prefixes: children | children with more than one key << 16
     o.mark = take(2 * cap);
     o.stack = take(64 * sizeof(SortFrame));
+    o.best = hist ? take(2 * cap * 8) : 0;  // per final node: (response, -emission rank) maximum
+    o.misc = take(64);                      // hand-over between the round wave and the workgroup; scan carries
     o.total = p;
     return o;
 }
+__host__ __device__ inline int oct_hist_key_bytes() { return 2 * FT_OCT_HIST_BINS + 16; }
 
 // std::sort(a, a + n, compareNodes) of libstdc++ with one wave: the steps of octree_paths.h
 // std_sort_replay_steps (checked against libstdc++ on the CPU), each of them lane-parallel.
@@ -267,10 +282,16 @@ __device__ void wave_std_sort(SortElem *a, int n, SortFrame *stack, uint16_t *po
     wave_lds_sync();
 }
 
-constexpr int OCT_THREADS = 512;  // codes + key sort use the whole block, the rounds only its first wave
+constexpr int OCT_THREADS = 512;  // codes + key sort / histogram / pick use the whole block, the rounds only its first wave
 
-// one (level, image) with at most maxN candidates (maxN: the key capacity of the LDS layout of this launch)
-__device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, const int slot, const int level, const int maxN,
+// hand-over words in OctLds::misc (ints)
+enum { OM_START = 0, OM_M = 1, OM_CURB = 2, OM_GAVEUP = 3, OM_WAVESUM = 4 /* .. +8 */ };
+
+// one (level, image).  Sorted tiers (HIST = false): at most maxN candidates (the key capacity of the LDS layout of this
+// launch).  Histogram tier (HIST = true): any number up to 65 535.  Returns false when the histogram tier gave up on the
+// level (a node deeper than its table would have to be split); nothing has been written then.
+template <bool HIST>
+__device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, const int slot, const int level, const int maxN,
                                           uint8_t *smem) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -280,7 +301,7 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
     int *cntOut = a.selCount + slot * g.nlevels + level;
     if (n <= 0) {
         if (tid == 0) *cntOut = 0;
-        return;
+        return true;
     }
     const unsigned wMagic = L.wCell > 1 ? 0xffffffffu / (unsigned)L.wCell + 1u : 0u;
     const unsigned hMagic = L.hCell > 1 ? 0xffffffffu / (unsigned)L.hCell + 1u : 0u;
@@ -288,39 +309,62 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
     const int minB = FT_EDGE_THRESHOLD - 3;
     const Roots R = ft::op::make_roots(minB, L.maxBX, minB, L.maxBY);
     const bool keyFits = L.nCols <= 128 && L.nRows <= 128 && L.wCell <= 128 && L.hCell <= 128 && R.nIni <= 15;
-    if (n > maxN && n <= a.bigN && keyFits && maxN < a.bigN) {
-        // more candidates than this launch sorts in LDS: the level goes on the list of k_octree_big, which runs behind this
-        // kernel with room for bigN keys per workgroup
-        if (tid == 0) {
-            const int idx = atomicAdd(a.bigCount, 1);
-            atomicMax(a.bigCount + 1, idx + 1);  // the host sizes the second tier of the following batches by this
-            if (idx < a.bigCap) a.bigList[idx] = (unsigned)slot | ((unsigned)level << 16);
-            else {
-                *cntOut = 0;
-                atomicOr(a.overflow, 1);
-                a.ovSlot[slot] = 1;
-            }
-        }
-        return;
-    }
-    if (n > maxN || !keyFits) {  // beyond the device formulation: this image is redone with the host octree
+    auto fail = [&]() {  // beyond the device formulation: this image is redone with the host octree
         if (tid == 0) {
             *cntOut = 0;
             atomicOr(a.overflow, 1);
             a.ovSlot[slot] = 1;
         }
-        return;
+    };
+    // files the level under the next tier (count at cnt[0], demand since the host last looked at cnt[2]); false = no room
+    auto hand_on = [&](int *cnt, unsigned *list, int cap) -> bool {
+        const int idx = atomicAdd(cnt, 1);
+        atomicMax(cnt + 2, idx + 1);
+        if (idx >= cap) return false;
+        list[idx] = (unsigned)slot | ((unsigned)level << 16);
+        return true;
+    };
+    if constexpr (!HIST) {
+        if (n > maxN && keyFits && (a.histCap > 0 || maxN < a.bigN)) {
+            // more candidates than this launch sorts in LDS: the level goes on the list of the histogram tier (or, with that
+            // tier switched off, of k_octree_big while it has room for the keys), which runs behind this kernel
+            if (tid == 0) {
+                bool ok;
+                if (a.histCap > 0 && n <= 65535) ok = hand_on(a.bigCount, a.bigList, a.histCap);
+                else if (n <= a.bigN) ok = hand_on(a.bigCount + 1, a.sortList, a.sortCap);
+                else ok = false;
+                if (!ok) {
+                    *cntOut = 0;
+                    atomicOr(a.overflow, 1);
+                    a.ovSlot[slot] = 1;
+                }
+            }
+            return true;
+        }
+        if (n > maxN || !keyFits) {
+            fail();
+            return true;
+        }
+    } else {
+        if (n > 65535 || !keyFits) {
+            fail();
+            return true;
+        }
     }
     const uint32_t *cand = a.cand + (size_t)slot * g.candPerSlot + L.candBase;
     const int cap = a.poolCap;
-    const OctLds o = oct_lds_layout(cap, maxN);
-    unsigned long long *keys = (unsigned long long *)(smem + o.keys);  // code << 32 | index
+    const OctLds o = oct_lds_layout(cap, HIST ? oct_hist_key_bytes() : maxN * 8, HIST);
+    unsigned long long *keys = (unsigned long long *)(smem + o.keys);  // sorted tiers: code << 36 | response << 28 | rank
     const uint32_t *codes = (const uint32_t *)keys;                     // codes[2 * i + 1] = code << 4 | response >> 4
+    uint32_t *bins32 = (uint32_t *)(smem + o.keys);                     // histogram tier: two 16-bit counters per dword,
+    uint16_t *bins = (uint16_t *)(smem + o.keys);                       // then bins[b] = candidates in bins below b
+    int *misc = (int *)(smem + o.misc);
     // the two copies of the node list are addressed as smem + offset (never through an array of pointers: that loses
     // the LDS address space and turns every node access into a flat instruction)
     auto lohiOf = [&](int b) -> uint32_t * { return (uint32_t *)(smem + (b ? o.lohi[1] : o.lohi[0])); };
     auto x01Of = [&](int b) -> uint32_t * { return (uint32_t *)(smem + (b ? o.x01[1] : o.x01[0])); };
     auto depOf = [&](int b) -> uint8_t * { return smem + (b ? o.dep[1] : o.dep[0]); };
+    auto preOf = [&](int b) -> uint32_t * { return (uint32_t *)(smem + (b ? o.pre[1] : o.pre[0])); };
     SortElem *vSize = (SortElem *)(smem + o.vSize);
     SortElem *vPrev = (SortElem *)(smem + o.vPrev);
     uint16_t *ord = (uint16_t *)(smem + o.ord);
@@ -328,6 +372,10 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
     uint32_t *pq = (uint32_t *)(smem + o.pq);
     uint8_t *mark = smem + o.mark;
     SortFrame *stack = (SortFrame *)(smem + o.stack);
+    // histogram tier: depth of the table and its size
+    const int D = HIST ? ft::op::hist_depth(R.nIni, FT_OCT_HIST_BINS) : 0;
+    const int nBins = HIST ? R.nIni << (2 * D) : 0;
+    const int perThread = HIST ? (nBins + OCT_THREADS - 1) / OCT_THREADS : 0;
 
     const bool prof = a.prof && slot == 0;
     unsigned long long tPrev = prof ? wall_clock64() : 0;
@@ -339,47 +387,84 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
         profIdx++;
         tPrev = t;
     };
-    // ---- 1. path codes ----
-    int nPad = 64;
-    while (nPad < n) nPad <<= 1;
-    for (int i = tid; i < nPad; i += OCT_THREADS) {
-        unsigned long long k = ~0ull;
-        if (i < n) {
-            const uint32_t c = cand[i];
-            // key = path code << 36 | response << 28 | emission rank.  Codes are unique (a depth-12 path identifies
-            // the pixel), so the low 36 bits never decide the order; they carry what the pick at the end needs: the
-            // response and the candidate's rank in the reference's emission order - cell row, cell column, then
-            // row-major inside the cell (ORBextractor.cc:1136-1199) - which is a function of its coordinates, so the
-            // order in which the FAST stage delivers the candidates does not matter.
-            const int x = (int)(c & 0xfffu), y = (int)((c >> 12) & 0xfffu);
-            const int cj = min(wMagic ? (int)__umulhi((unsigned)(x - 3), wMagic) : x - 3, L.nCols - 1);
-            const int ci = min(hMagic ? (int)__umulhi((unsigned)(y - 3), hMagic) : y - 3, L.nRows - 1);
-            const unsigned ekey = ((unsigned)ci << 21) | ((unsigned)cj << 14) | ((unsigned)(y - 3 - ci * L.hCell) << 7) |
-                                  (unsigned)(x - 3 - cj * L.wCell);
-            k = ((unsigned long long)ft::op::path_code(R, x, y) << 36) | ((unsigned long long)(c >> 24) << 28) | ekey;
-        }
-        keys[i] = k;
-    }
-    __syncthreads();
-    tick();  // 0: codes
-    // ---- 2. bitonic sort (keys are unique, so the order equals a stable sort by code) ----
-    for (int k = 2; k <= nPad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (nPad >> 1); t += OCT_THREADS) {
-                const int i = ((t / j) * (j << 1)) + (t % j);  // j is a power of two: shifts / masks
-                const int l = i + j;
-                const unsigned long long x = keys[i], y = keys[l];
-                const bool up = (i & k) == 0;
-                if ((x > y) == up) {
-                    keys[i] = y;
-                    keys[l] = x;
-                }
+    // emission rank of a candidate - cell row, cell column, then row-major inside the cell (ORBextractor.cc:1136-1199) - a
+    // function of its coordinates, so the order in which the FAST stage delivers the candidates does not matter
+    auto emission_key = [&](int x, int y) -> unsigned {
+        const int cj = min(wMagic ? (int)__umulhi((unsigned)(x - 3), wMagic) : x - 3, L.nCols - 1);
+        const int ci = min(hMagic ? (int)__umulhi((unsigned)(y - 3), hMagic) : y - 3, L.nRows - 1);
+        return ((unsigned)ci << 21) | ((unsigned)cj << 14) | ((unsigned)(y - 3 - ci * L.hCell) << 7) | (unsigned)(x - 3 - cj * L.wCell);
+    };
+    if constexpr (!HIST) {
+        // ---- 1. path codes ----
+        int nPad = 64;
+        while (nPad < n) nPad <<= 1;
+        for (int i = tid; i < nPad; i += OCT_THREADS) {
+            unsigned long long k = ~0ull;
+            if (i < n) {
+                const uint32_t c = cand[i];
+                // key = path code << 36 | response << 28 | emission rank.  Codes are unique (a depth-12 path identifies
+                // the pixel), so the low 36 bits never decide the order; they carry what the pick at the end needs: the
+                // response and the candidate's rank in the reference's emission order.
+                const int x = (int)(c & 0xfffu), y = (int)((c >> 12) & 0xfffu);
+                k = ((unsigned long long)ft::op::path_code(R, x, y) << 36) | ((unsigned long long)(c >> 24) << 28) | emission_key(x, y);
             }
+            keys[i] = k;
+        }
+        __syncthreads();
+        tick();  // 0: codes
+        // ---- 2. bitonic sort (keys are unique, so the order equals a stable sort by code) ----
+        for (int k = 2; k <= nPad; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (nPad >> 1); t += OCT_THREADS) {
+                    const int i = ((t / j) * (j << 1)) + (t % j);  // j is a power of two: shifts / masks
+                    const int l = i + j;
+                    const unsigned long long x = keys[i], y = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) {
+                        keys[i] = y;
+                        keys[l] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        tick();  // 1: sort
+        if (tid >= 64) return true;  // the rest is one wave: no block barrier below this line
+    } else {
+        // ---- 1. histogram over the nodes of depth D: bins in code order ----
+        for (int i = tid; i <= (nBins >> 1); i += OCT_THREADS) bins32[i] = 0;
+        if (tid == 0) misc[OM_GAVEUP] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += OCT_THREADS) {
+            const uint32_t c = cand[i];
+            const unsigned b = ft::op::path_prefix(R, (int)(c & 0xfffu), (int)((c >> 12) & 0xfffu), D);
+            atomicAdd(&bins32[b >> 1], 1u << ((b & 1u) * 16u));  // a half never carries: n <= 65 535
+        }
+        __syncthreads();
+        tick();  // 0: histogram
+        // ---- 2. exclusive prefix sums in place: bins[b] = position of the bin's first key in the (virtual) sorted array ----
+        {
+            const int b0 = min(tid * perThread, nBins), b1 = min(b0 + perThread, nBins);
+            int sum = 0;
+            for (int b = b0; b < b1; b++) sum += bins[b];
+            int tot;
+            int ex = wave_excl_scan(sum, lane, tot);
+            if (lane == 63) misc[OM_WAVESUM + (tid >> 6)] = tot;
+            __syncthreads();
+            for (int w = 0; w < (tid >> 6); w++) ex += misc[OM_WAVESUM + w];
+            for (int b = b0; b < b1; b++) {
+                const int c = bins[b];
+                bins[b] = (uint16_t)ex;
+                ex += c;
+            }
+            if (tid == OCT_THREADS - 1) bins[nBins] = (uint16_t)n;
             __syncthreads();
         }
+        tick();  // 1: scan
     }
-    tick();  // 1: sort
-    if (tid >= 64) return;  // the rest is one wave: no block barrier below this line
+    int curB = 0, start = cap, m = 0;
+    bool gaveUp = false;
+    if (tid < 64) {
     auto lower_bound = [&](int lo, int hi, uint32_t target) {
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -389,13 +474,17 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
         return lo;
     };
     // ---- 3. rounds ----
-    int curB = 0, start = cap, m = 0;
     for (int s0 = 0; s0 < R.nIni; s0 += 64) {  // root nodes (:672-705), empty ones dropped
         const int s = s0 + lane;
         int lo = 0, hi = 0;
         if (s < R.nIni) {
-            lo = lower_bound(0, n, (uint32_t)s << (2 * kMaxDepth));
-            hi = lower_bound(lo, n, (uint32_t)(s + 1) << (2 * kMaxDepth));
+            if constexpr (HIST) {
+                lo = bins[s << (2 * D)];
+                hi = bins[(s + 1) << (2 * D)];
+            } else {
+                lo = lower_bound(0, n, (uint32_t)s << (2 * kMaxDepth));
+                hi = lower_bound(lo, n, (uint32_t)(s + 1) << (2 * kMaxDepth));
+            }
         }
         const bool has = hi > lo;
         const unsigned long long bal = __ballot(has);
@@ -406,6 +495,7 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
             lohiOf(0)[pos] = (uint32_t)lo | ((uint32_t)hi << 16);
             x01Of(0)[pos] = (uint32_t)x0 | ((uint32_t)x1 << 16);
             depOf(0)[pos] = 0;
+            if constexpr (HIST) preOf(0)[pos] = (uint32_t)s;
         }
         m += __popcll(bal);
     }
@@ -413,21 +503,32 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
     int nV = 0;
     // splits the nodes ord[0..nOrd) of the current list in that order (with useStop: until the list holds N)
     auto split_round = [&](int nOrd, bool useStop) {
-        const uint32_t *cl = lohiOf(curB), *cx = x01Of(curB);
+        const uint32_t *cl = lohiOf(curB), *cx = x01Of(curB), *cp = preOf(curB);
         const uint8_t *cd = depOf(curB);
-        uint32_t *nl = lohiOf(curB ^ 1), *nx = x01Of(curB ^ 1);
+        uint32_t *nl = lohiOf(curB ^ 1), *nx = x01Of(curB ^ 1), *np = preOf(curB ^ 1);
         uint8_t *ndp = depOf(curB ^ 1);
         // pass A: boundaries, child counts, prefixes, stop
         int carryP = 0, carryQ = 0, cum = m, nproc = nOrd;
         for (int r0 = 0; r0 < nOrd; r0 += 64) {
             const int r = r0 + lane;
             int nch = 0, nbig = 0;
+            bool deep = false;
             if (r < nOrd) {
                 const int t = ord[r];
                 const uint32_t lh = cl[t];
                 const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16), d = cd[t];
                 int b1 = hi, b2 = hi, b3 = hi;
-                if (d < kMaxDepth) {
+                if constexpr (HIST) {
+                    if (d < D) {  // the children's first bins
+                        const int sh = 2 * (D - 1 - d);
+                        const uint32_t p4 = cp[t] << 2;
+                        b1 = bins[(p4 | 1u) << sh];
+                        b2 = bins[(p4 | 2u) << sh];
+                        b3 = bins[(p4 | 3u) << sh];
+                    } else {
+                        deep = true;  // the table ends at depth D
+                    }
+                } else if (d < kMaxDepth) {
                     const int shift = 2 * (kMaxDepth - 1 - d);
                     const uint32_t prefix = codes[2 * lo + 1] >> (shift + 2 + 4);
                     b1 = lower_bound(lo, hi, ((prefix << 2) | 1u) << shift);
@@ -439,6 +540,12 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
                 bq[4 * r + 2] = (uint16_t)b3;
                 nch = (b1 > lo) + (b2 > b1) + (b3 > b2) + (hi > b3);
                 nbig = (b1 - lo > 1) + (b2 - b1 > 1) + (b3 - b2 > 1) + (hi - b3 > 1);
+            }
+            if constexpr (HIST) {
+                if (__any(deep)) {  // wave-uniform
+                    gaveUp = true;
+                    return;
+                }
             }
             int totP, totQ;
             const int exP = wave_excl_scan(nch, lane, totP);
@@ -476,6 +583,8 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
             const int mx = x0 + ((x1 - x0 + 1) >> 1);
             const int b[5] = {(int)(lh & 0xffffu), bq[4 * r], bq[4 * r + 1], bq[4 * r + 2], (int)(lh >> 16)};
             const uint32_t pp = pq[r];
+            uint32_t p4 = 0;
+            if constexpr (HIST) p4 = cp[t] << 2;
             int k = (int)(pp & 0xffffu), kb = (int)(pp >> 16);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -486,6 +595,7 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
                 nl[pos] = (uint32_t)b[c] | ((uint32_t)b[c + 1] << 16);
                 nx[pos] = (uint32_t)cx0 | ((uint32_t)cx1 << 16);
                 ndp[pos] = (uint8_t)(d + 1);
+                if constexpr (HIST) np[pos] = p4 | (uint32_t)c;
                 if (cnt > 1) {
                     SortElem e;
                     e.key = ((uint32_t)cnt << 16) | (uint32_t)cx0;
@@ -507,6 +617,7 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
                 nl[pos] = cl[t];
                 nx[pos] = cx[t];
                 ndp[pos] = cd[t];
+                if constexpr (HIST) np[pos] = cp[t];
             }
             u += __popcll(bal);
         }
@@ -537,6 +648,7 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
             wave_lds_sync();
         }
         split_round(nOrd, false);
+        if (gaveUp) break;
         if (m >= N || m == prevSize) {
             finish = true;
         } else if (m + 3 * nV > N) {
@@ -556,35 +668,113 @@ __device__ __forceinline__ void oct_level(const FtGeom &g, const FtOctArgs &a, c
                 for (int r = lane; r < nPrev; r += 64) ord[r] = (uint16_t)vPrev[nPrev - 1 - r].val;
                 wave_lds_sync();
                 split_round(nPrev, true);
+                if (gaveUp) break;
                 if (m >= N || m == prevSize) finish = true;
             }
+            if (gaveUp) break;
         }
     }
+    if constexpr (HIST) {
+        if (lane == 0) {
+            misc[OM_START] = start;
+            misc[OM_M] = m;
+            misc[OM_CURB] = curB;
+            misc[OM_GAVEUP] = gaveUp ? 1 : 0;
+        }
+    }
+    }  // tid < 64
     tick();  // 2: rounds
-    // ---- 4. per retained node: largest response, earliest original index on ties ----
-    const int kept = min(m, a.levelMax[level]);
-    const uint32_t *cl = lohiOf(curB);
     FtSelKp *out = a.sel + (size_t)slot * g.maxKp + a.selOff[level];
-    for (int t = lane; t < kept; t += 64) {
-        const unsigned lh = cl[start + t];
-        const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
-        // maximise (response, -emission rank): the first maximum in emission order (:863-881)
-        const unsigned long long low = (1ull << 36) - 1, inv = (1ull << 28) - 1;
-        unsigned long long best = (keys[lo] & low) ^ inv;
-        for (int k = lo + 1; k < hi; k++) best = max(best, (keys[k] & low) ^ inv);
+    const unsigned long long low = (1ull << 36) - 1, inv = (1ull << 28) - 1;
+    auto write_out = [&](int t, unsigned long long best) {  // best = (response << 28 | rank) ^ inv: the first maximum in emission order
         const unsigned ek = (unsigned)(~best) & (unsigned)inv;
         const int bx = (int)((ek >> 14) & 127u) * L.wCell + (int)(ek & 127u) + 3;
         const int by = (int)((ek >> 21) & 127u) * L.hCell + (int)((ek >> 7) & 127u) + 3;
-        const unsigned bestC = ft_pack_cand(bx, by, (int)(best >> 28));
         FtSelKp s;
-        s.x = (short)((bestC & 0xfffu) + minB);  // ORBextractor.cc:1211-1217: add the border offset back
-        s.y = (short)(((bestC >> 12) & 0xfffu) + minB);
+        s.x = (short)(bx + minB);  // ORBextractor.cc:1211-1217: add the border offset back
+        s.y = (short)(by + minB);
         s.level = (short)level;
-        s.response = (short)(bestC >> 24);
+        s.response = (short)(best >> 28);
         out[t] = s;
+    };
+    if constexpr (!HIST) {
+        // ---- 4. per retained node: largest response, earliest emission rank on ties (:863-881) ----
+        const int kept = min(m, a.levelMax[level]);
+        const uint32_t *cl = lohiOf(curB);
+        for (int t = lane; t < kept; t += 64) {
+            const unsigned lh = cl[start + t];
+            const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
+            unsigned long long best = (keys[lo] & low) ^ inv;
+            for (int k = lo + 1; k < hi; k++) best = max(best, (keys[k] & low) ^ inv);
+            write_out(t, best);
+        }
+        tick();  // 3: pick
+        if (lane == 0) *cntOut = kept;
+        return true;
+    } else {
+        __syncthreads();
+        if (misc[OM_GAVEUP]) return false;  // uniform
+        start = misc[OM_START];
+        m = misc[OM_M];
+        curB = misc[OM_CURB];
+        const int kept = min(m, a.levelMax[level]);
+        // ---- 4. bin -> final node.  Every node marks the first bin of its subtree with its list position + 1; a bin belongs to
+        // the last mark at or below it (the final nodes tile the code space except where there are no candidates).  The table
+        // of bin starts is not needed any more: the owners take its place.
+        unsigned long long *best = (unsigned long long *)(smem + o.best);
+        __syncthreads();  // every thread has read the hand-over words (the scan below reuses them)
+        for (int b = tid; b < nBins; b += OCT_THREADS) bins[b] = 0;
+        for (int t = tid; t < kept; t += OCT_THREADS) best[t] = 0;
+        __syncthreads();
+        {
+            const uint32_t *cp = preOf(curB);
+            const uint8_t *cd = depOf(curB);
+            for (int t = tid; t < m; t += OCT_THREADS) bins[cp[start + t] << (2 * (D - (int)cd[start + t]))] = (uint16_t)(t + 1);
+        }
+        __syncthreads();
+        {
+            const int b0 = min(tid * perThread, nBins), b1 = min(b0 + perThread, nBins);
+            int last = 0;
+            for (int b = b0; b < b1; b++) {
+                const int v = bins[b];
+                last = v ? v : last;
+            }
+            // the last mark of the threads below: inside the wave by ballot, across the waves through LDS
+            const unsigned long long has = __ballot(last != 0);
+            const unsigned long long below = has & ((1ull << lane) - 1ull);
+            const int src = below ? 63 - __clzll((long long)below) : 0;
+            const int fromWave = __shfl(last, src);
+            const int waveLast = __shfl(last, has ? 63 - __clzll((long long)has) : 0);
+            if (lane == 0) misc[OM_WAVESUM + (tid >> 6)] = has ? waveLast : 0;
+            __syncthreads();
+            int carry = 0;
+            for (int w = 0; w < (tid >> 6); w++) {
+                const int v = misc[OM_WAVESUM + w];
+                carry = v ? v : carry;
+            }
+            if (below) carry = fromWave;
+            for (int b = b0; b < b1; b++) {
+                const int v = bins[b];
+                carry = v ? v : carry;
+                bins[b] = (uint16_t)carry;
+            }
+        }
+        __syncthreads();
+        tick();  // 3: owners
+        // ---- 5. pick: one pass over the candidates, LDS atomic maximum per final node ----
+        for (int i = tid; i < n; i += OCT_THREADS) {
+            const uint32_t c = cand[i];
+            const int x = (int)(c & 0xfffu), y = (int)((c >> 12) & 0xfffu);
+            const int t1 = bins[ft::op::path_prefix(R, x, y, D)];
+            if (t1 >= 1 && t1 <= kept)
+                atomicMax(&best[t1 - 1], ((((unsigned long long)(c >> 24)) << 28) | (unsigned long long)emission_key(x, y)) ^ inv);
+        }
+        __syncthreads();
+        for (int t = tid; t < kept; t += OCT_THREADS) write_out(t, best[t]);
+        tick();  // 4: pick
+        if (tid == 0) *cntOut = kept;
+        return true;
     }
-    tick();  // 3: pick
-    if (lane == 0) *cntOut = kept;
 }
 
 __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
@@ -593,28 +783,64 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     __builtin_amdgcn_s_setprio(3);
     // workgroups are dispatched in the order of their linear index: image fastest, so the level-0 workgroups of all
     // images (the long ones: most candidates, largest quota) start first and the short high levels fill in behind
-    oct_level(g, a, blockIdx.x, blockIdx.y, FT_OCT_MAXN, smem);
+    oct_level<false>(g, a, blockIdx.x, blockIdx.y, FT_OCT_MAXN, smem);
 }
 
-// The levels k_octree left on the list (more than FT_OCT_MAXN candidates): one workgroup per entry with an LDS layout
-// for a.bigN keys (up to the whole 160 KB of a CU).  A workgroup that needs a CU's whole LDS waits for a CU to drain even
-// if it has nothing to do, so the kernel is only launched while the stream of frames needs it, with a grid the host sizes
-// from the demand of the previous batches (ft_extractor::bigGrid); small batches always get one workgroup per level.
+// The levels k_octree left on the list (more than FT_OCT_MAXN candidates): histogram formulation.  The workgroups walk the
+// list (entry blockIdx.x, + gridDim.x, ...): the grid is sized by the demand of the previous batches, not by the worst case
+// (a grid of one workgroup per level of the launch cost the headline workload 5 % although none of them had an entry: 2 048
+// workgroups of 58 KB LDS still have to be placed).  A level the formulation gives up on is handed on to k_octree_big (or
+// flagged for the host when that tier has no room).
+__global__ __launch_bounds__(OCT_THREADS) void k_octree_hist(FtGeom g, FtOctArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int cnt = min(a.bigCount[0], a.histCap);
+    if ((int)blockIdx.x >= cnt) return;
+    __builtin_amdgcn_s_setprio(3);
+    for (int ei = (int)blockIdx.x; ei < cnt; ei += (int)gridDim.x) {
+        const unsigned e = a.bigList[ei];
+        const int slot = (int)(e & 0xffffu), level = (int)(e >> 16);
+        const bool done = oct_level<true>(g, a, slot, level, 0, smem);
+        if (!done && threadIdx.x == 0) {
+            const int n = a.candCount[slot * g.nlevels + level];
+            bool ok = false;
+            if (n <= a.bigN) {
+                const int idx = atomicAdd(a.bigCount + 1, 1);
+                atomicMax(a.bigCount + 3, idx + 1);  // the host sizes the third tier of the following batches by this
+                if (idx < a.sortCap) {
+                    a.sortList[idx] = e;
+                    ok = true;
+                }
+            }
+            if (!ok) {
+                a.selCount[slot * g.nlevels + level] = 0;
+                atomicOr(a.overflow, 1);
+                a.ovSlot[slot] = 1;
+            }
+        }
+        __syncthreads();  // the next level reuses the LDS
+    }
+}
+
+// The levels the histogram tier gave up on: the sorted formulation with an LDS layout for a.bigN keys (up to the whole
+// 160 KB of a CU).  A workgroup that needs a CU's whole LDS waits for a CU to drain even if it has nothing to do, so the
+// kernel is only launched while the stream of frames needs it, with a grid the host sizes from the demand of the previous
+// batches (ft_extractor::bigGrid).
 __global__ __launch_bounds__(OCT_THREADS) void k_octree_big(FtGeom g, FtOctArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int cnt = min(*a.bigCount, a.bigCap);
+    const int cnt = min(a.bigCount[1], a.sortCap);
     if ((int)blockIdx.x >= cnt) return;
-    const unsigned e = a.bigList[blockIdx.x];
-    oct_level(g, a, (int)(e & 0xffffu), (int)(e >> 16), a.bigN, smem);
+    const unsigned e = a.sortList[blockIdx.x];
+    oct_level<false>(g, a, (int)(e & 0xffffu), (int)(e >> 16), a.bigN, smem);
 }
 
 }  // namespace
 
-size_t ft_octree_smem_bytes(int poolCap) { return (size_t)oct_lds_layout(poolCap, FT_OCT_MAXN).total; }
-// key capacity of the second-tier kernel: the largest power of two (the sort is bitonic) whose layout fits one CU's LDS
+size_t ft_octree_smem_bytes(int poolCap) { return (size_t)oct_lds_layout(poolCap, FT_OCT_MAXN * 8, false).total; }
+size_t ft_octree_hist_smem_bytes(int poolCap) { return (size_t)oct_lds_layout(poolCap, oct_hist_key_bytes(), true).total; }
+// key capacity of the sorted big tier: the largest power of two (the sort is bitonic) whose layout fits one CU's LDS
 int ft_octree_big_keys(int poolCap) {
     for (int n = 16384; n > FT_OCT_MAXN; n >>= 1)
-        if ((size_t)oct_lds_layout(poolCap, n).total <= 160 * 1024) return n;
+        if ((size_t)oct_lds_layout(poolCap, n * 8, false).total <= 160 * 1024) return n;
     return 0;
 }
 
@@ -622,12 +848,18 @@ int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs
     const size_t smem = ft_octree_smem_bytes(a.poolCap);
     if (smem > 64 * 1024)  // large quotas: raise the dynamic LDS limit (per device, so not cached in a static)
         FT_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    const size_t smemBig = a.bigN ? (size_t)oct_lds_layout(a.poolCap, a.bigN).total : 0;
-    if (a.bigN) FT_HIP(hipFuncSetAttribute((const void *)k_octree_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemBig));
+    const size_t smemHist = a.histCap > 0 ? ft_octree_hist_smem_bytes(a.poolCap) : 0;
+    if (smemHist > 64 * 1024)
+        FT_HIP(hipFuncSetAttribute((const void *)k_octree_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemHist));
+    const size_t smemBig = a.bigN ? (size_t)oct_lds_layout(a.poolCap, a.bigN * 8, false).total : 0;
+    if (a.bigN && a.sortCap > 0)
+        FT_HIP(hipFuncSetAttribute((const void *)k_octree_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemBig));
     for (int rep = ft_debug_repeat("octree"); rep > 0; rep--) {
-        if (a.bigN) FT_HIP(hipMemsetAsync(a.bigCount, 0, sizeof(int), st));
+        // the list counters of the launch ([2] and [3], the demand, are the host's to reset)
+        if (a.bigN || a.histCap > 0) FT_HIP(hipMemsetAsync(a.bigCount, 0, 2 * sizeof(int), st));
         hipLaunchKernelGGL(k_octree, dim3(batch, g.nlevels), dim3(OCT_THREADS), smem, st, g, a);
-        if (a.bigN && a.bigCap > 0) hipLaunchKernelGGL(k_octree_big, dim3(a.bigCap), dim3(OCT_THREADS), smemBig, st, g, a);
+        if (a.histCap > 0) hipLaunchKernelGGL(k_octree_hist, dim3(std::min(a.histCap, std::max(a.histGrid, 1))), dim3(OCT_THREADS), smemHist, st, g, a);
+        if (a.bigN && a.sortCap > 0) hipLaunchKernelGGL(k_octree_big, dim3(a.sortCap), dim3(OCT_THREADS), smemBig, st, g, a);
     }
     FT_HIP(hipGetLastError());
     return FT_OK;

@@ -495,8 +495,8 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
         key.batch = batch; key.onDevice = on_device; key.width = width; key.height = height; key.stride = stride;
         key.capacity = capacity;
         key.paired = paired ? 1 : 0;
-        key.bigGridL = L->bigGrid;
-        key.bigGridR = R->bigGrid;
+        key.bigGridL = L->bigGrid + (L->histOn ? (1 << 24) : 0);
+        key.bigGridR = R->bigGrid + (R->histOn ? (1 << 24) : 0);
         key.alignedL = key.alignedR = 1;
         if (on_device) {
             if (stride & 3) key.alignedL = key.alignedR = 0;

@@ -251,26 +251,113 @@ int distribute_octree_paths(const uint32_t *cand, int n, int minX, int maxX, int
     return k;
 }
 
-// Single-thread host statement of the ROUND formulation the device kernel executes (kernels_octree.hip):
+// Single-thread host statement of the ROUND formulation the device kernels execute (kernels_octree.hip):
 // the node list is an array, and a whole pass of the reference - every node of a breadth-first pass, or
 // the first `nproc` nodes of the size-sorted careful pass - is split at once.  The list after a pass is
 //   [children of the last processed node, n4..n1] ... [children of the first processed node, n4..n1]
 //   followed by the nodes that were not split, in their old order
 // (std::list::push_front of every child + erase of the parent, ORBextractor.cc:741-789 / :808-848), so
 // every position is a prefix sum.  Only the careful pass's std::sort stays sequential (replayed literally).
-int distribute_octree_rounds(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
-                             std::vector<int> &out) {
-    if (n <= 0) return 0;
-    if (n > 65535) return -1;
-    const op::Roots R = op::make_roots(minX, maxX, minY, maxY);
-    std::vector<uint64_t> keys(n);
-    for (int i = 0; i < n; i++)
-        keys[i] = ((uint64_t)op::path_code(R, (int)(cand[i] & 0xfffu), (int)((cand[i] >> 12) & 0xfffu)) << 32) | (uint32_t)i;
-    std::sort(keys.begin(), keys.end());
-    auto codeAt = [&](int i) -> uint32_t { return (uint32_t)(keys[i] >> 32); };
-    struct RNode {
-        int lo, hi, x0, x1, depth;
-    };
+//
+// Where a node's keys lie is the business of a policy:
+//   SortedKeys (k_octree, k_octree_big): the keys are sorted by path code, a node owns a contiguous range and its
+//       children's boundaries are three binary searches;
+//   HistKeys (k_octree_hist): nothing is sorted.  The candidates are COUNTED per node of depth D (a histogram over
+//       the code prefixes of depth D, nIni * 4^D bins in code order); the exclusive prefix sums of the bins are the
+//       positions the sorted array would have, so the boundaries of a node of depth < D are table look-ups, and the
+//       pick at the end is one more pass over the candidates (bin -> final node -> maximum of (response, -rank)).
+//       A node of depth D that would have to be split is beyond the table: the policy gives up (-2) and the level
+//       goes to the sorted formulation.
+namespace {
+
+struct RNode {
+    int lo, hi, x0, x1, depth;
+    uint32_t pre;  // code prefix of the node: root, then one quadrant digit per depth
+};
+
+struct SortedKeys {
+    const uint32_t *cand;
+    int n;
+    op::Roots R;
+    std::vector<uint64_t> keys;
+    SortedKeys(const uint32_t *c, int n_, const op::Roots &r) : cand(c), n(n_), R(r), keys(n_) {
+        for (int i = 0; i < n; i++)
+            keys[i] = ((uint64_t)op::path_code(R, (int)(cand[i] & 0xfffu), (int)((cand[i] >> 12) & 0xfffu)) << 32) | (uint32_t)i;
+        std::sort(keys.begin(), keys.end());
+    }
+    uint32_t codeAt(int i) const { return (uint32_t)(keys[i] >> 32); }
+    void rootRange(int s, int &lo, int &hi) const {
+        auto at = [&](int i) { return codeAt(i); };
+        lo = op::lower_bound_code(at, 0, n, (uint32_t)s << (2 * op::kMaxDepth));
+        hi = op::lower_bound_code(at, lo, n, (uint32_t)(s + 1) << (2 * op::kMaxDepth));
+    }
+    bool children(const RNode &nd, int b[5]) const {
+        b[0] = nd.lo;
+        b[1] = b[2] = b[3] = b[4] = nd.hi;
+        if (nd.depth < op::kMaxDepth) {
+            auto at = [&](int i) { return codeAt(i); };
+            const int shift = 2 * (op::kMaxDepth - 1 - nd.depth);
+            for (int k = 1; k < 4; k++) b[k] = op::lower_bound_code(at, b[k - 1], nd.hi, ((nd.pre << 2) | (uint32_t)k) << shift);
+        }
+        return true;
+    }
+    void pick(const RNode *nodes, int m, std::vector<int> &out) const {
+        for (int t = 0; t < m; t++) {
+            int best = (int)(uint32_t)keys[nodes[t].lo];
+            for (int k = nodes[t].lo + 1; k < nodes[t].hi; k++) {
+                const int i = (int)(uint32_t)keys[k];
+                const unsigned r = cand[i] >> 24, rb = cand[best] >> 24;
+                if (r > rb || (r == rb && i < best)) best = i;
+            }
+            out.push_back(best);
+        }
+    }
+};
+
+struct HistKeys {
+    const uint32_t *cand;
+    int n, D;
+    op::Roots R;
+    std::vector<int> start;  // [nBins + 1]: candidates in bins below b
+    HistKeys(const uint32_t *c, int n_, const op::Roots &r, int maxBins) : cand(c), n(n_), D(op::hist_depth(r.nIni, maxBins)), R(r) {
+        const int nBins = r.nIni << (2 * D);
+        start.assign(nBins + 1, 0);
+        for (int i = 0; i < n; i++) start[op::path_prefix(R, (int)(cand[i] & 0xfffu), (int)((cand[i] >> 12) & 0xfffu), D) + 1]++;
+        for (int b = 0; b < nBins; b++) start[b + 1] += start[b];
+    }
+    void rootRange(int s, int &lo, int &hi) const {
+        lo = start[(size_t)s << (2 * D)];
+        hi = start[(size_t)(s + 1) << (2 * D)];
+    }
+    bool children(const RNode &nd, int b[5]) const {
+        if (nd.depth >= D) return false;  // the table ends here
+        const int sh = 2 * (D - 1 - nd.depth);
+        b[0] = nd.lo;
+        for (int k = 1; k < 4; k++) b[k] = start[(size_t)((nd.pre << 2) | (uint32_t)k) << sh];
+        b[4] = nd.hi;
+        return true;
+    }
+    void pick(const RNode *nodes, int m, std::vector<int> &out) const {
+        // bin -> final node: every node marks its first bin, a bin belongs to the last mark at or below it (the final
+        // nodes tile the code space except for regions without candidates)
+        const int nBins = R.nIni << (2 * D);
+        std::vector<int> owner(nBins, -1), best(m, -1);
+        for (int t = 0; t < m; t++) owner[(size_t)nodes[t].pre << (2 * (D - nodes[t].depth))] = t;
+        for (int b = 1; b < nBins; b++)
+            if (owner[b] < 0) owner[b] = owner[b - 1];
+        for (int i = 0; i < n; i++) {
+            const int t = owner[op::path_prefix(R, (int)(cand[i] & 0xfffu), (int)((cand[i] >> 12) & 0xfffu), D)];
+            if (t < 0) continue;
+            // first maximum in emission order = largest response, smallest index (the caller's order IS the emission order here)
+            if (best[t] < 0 || (cand[i] >> 24) > (cand[best[t]] >> 24)) best[t] = i;
+        }
+        for (int t = 0; t < m; t++) out.push_back(best[t]);
+    }
+};
+
+// returns the number of retained nodes, -2 when the policy gave up
+template <class Keys>
+int rounds_impl(const Keys &K, const op::Roots &R, int N, std::vector<int> &out) {
     const int cap = std::max(N + 3, 4 * R.nIni) + 16;
     std::vector<RNode> bufA(2 * cap), bufB(2 * cap);
     RNode *cur = bufA.data(), *nxt = bufB.data();
@@ -279,25 +366,25 @@ int distribute_octree_rounds(const uint32_t *cand, int n, int minX, int maxX, in
     std::vector<uint8_t> mark(2 * cap);
     int start = cap, m = 0;
     for (int s = 0; s < R.nIni; s++) {
-        const int lo = op::lower_bound_code(codeAt, 0, n, (uint32_t)s << (2 * op::kMaxDepth));
-        const int hi = op::lower_bound_code(codeAt, lo, n, (uint32_t)(s + 1) << (2 * op::kMaxDepth));
+        int lo, hi;
+        K.rootRange(s, lo, hi);
         if (hi == lo) continue;
         int x0, x1;
         op::root_bounds(R, s, x0, x1);
-        cur[start + m++] = RNode{lo, hi, x0, x1, 0};
+        cur[start + m++] = RNode{lo, hi, x0, x1, 0, (uint32_t)s};
     }
     int nV = 0;
+    bool gaveUp = false;
     // splits ord[0..nOrd) (absolute positions in cur) in that order; with useStop the pass ends after the
     // split that brings the list to N nodes
     auto split_round = [&](int nOrd, bool useStop) {
         int cum = m, nproc = nOrd, p = 0, q = 0;
         for (int r = 0; r < nOrd; r++) {
             const RNode nd = cur[ord[r]];
-            int b[5] = {nd.lo, nd.hi, nd.hi, nd.hi, nd.hi};
-            if (nd.depth < op::kMaxDepth) {
-                const int shift = 2 * (op::kMaxDepth - 1 - nd.depth);
-                const uint32_t prefix = codeAt(nd.lo) >> (shift + 2);
-                for (int k = 1; k < 4; k++) b[k] = op::lower_bound_code(codeAt, b[k - 1], nd.hi, ((prefix << 2) | (uint32_t)k) << shift);
+            int b[5];
+            if (!K.children(nd, b)) {
+                gaveUp = true;
+                return;
             }
             b1[r] = b[1]; b2[r] = b[2]; b3[r] = b[3];
             int nch = 0, nbig = 0;
@@ -325,7 +412,7 @@ int distribute_octree_rounds(const uint32_t *cand, int n, int minX, int maxX, in
                 const int cnt = b[c + 1] - b[c];
                 if (cnt == 0) continue;
                 const int pos = cap - 1 - (P[r] + k);
-                nxt[pos] = RNode{b[c], b[c + 1], (c & 1) ? mx : nd.x0, (c & 1) ? nd.x1 : mx, nd.depth + 1};
+                nxt[pos] = RNode{b[c], b[c + 1], (c & 1) ? mx : nd.x0, (c & 1) ? nd.x1 : mx, nd.depth + 1, (nd.pre << 2) | (uint32_t)c};
                 if (cnt > 1) {
                     vSize[Q[r] + kb].key = ((uint32_t)cnt << 16) | (uint32_t)nxt[pos].x0;
                     vSize[Q[r] + kb].val = (uint32_t)pos;
@@ -349,6 +436,7 @@ int distribute_octree_rounds(const uint32_t *cand, int n, int minX, int maxX, in
         for (int t = start; t < start + m; t++)
             if (cur[t].hi - cur[t].lo > 1) ord[nOrd++] = t;
         split_round(nOrd, false);
+        if (gaveUp) return -2;
         if (m >= N || m == prevSize) {
             finish = true;
         } else if (m + 3 * nV > N) {
@@ -359,20 +447,32 @@ int distribute_octree_rounds(const uint32_t *cand, int n, int minX, int maxX, in
                 op::std_sort_replay(vPrev.data(), vPrev.data() + nPrev);
                 for (int r = 0; r < nPrev; r++) ord[r] = (int)vPrev[nPrev - 1 - r].val;
                 split_round(nPrev, true);
+                if (gaveUp) return -2;
                 if (m >= N || m == prevSize) finish = true;
             }
         }
     }
-    for (int t = start; t < start + m; t++) {
-        int best = (int)(uint32_t)keys[cur[t].lo];
-        for (int k = cur[t].lo + 1; k < cur[t].hi; k++) {
-            const int i = (int)(uint32_t)keys[k];
-            const unsigned r = cand[i] >> 24, rb = cand[best] >> 24;
-            if (r > rb || (r == rb && i < best)) best = i;
-        }
-        out.push_back(best);
-    }
+    K.pick(cur + start, m, out);
     return m;
+}
+
+}  // namespace
+
+int distribute_octree_rounds(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
+                             std::vector<int> &out) {
+    if (n <= 0) return 0;
+    if (n > 65535) return -1;
+    const op::Roots R = op::make_roots(minX, maxX, minY, maxY);
+    return rounds_impl(SortedKeys(cand, n, R), R, N, out);
+}
+
+int distribute_octree_hist(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N, int maxBins,
+                           std::vector<int> &out) {
+    if (n <= 0) return 0;
+    if (n > 65535) return -1;
+    const op::Roots R = op::make_roots(minX, maxX, minY, maxY);
+    if (R.nIni > maxBins) return -2;
+    return rounds_impl(HistKeys(cand, n, R, maxBins), R, N, out);
 }
 
 }  // namespace ft

@@ -48,6 +48,11 @@ int distribute_octree_paths(const uint32_t *cand, int n, int minX, int maxX, int
 int distribute_octree_rounds(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N,
                              std::vector<int> &out);
 
+// the round formulation over a HISTOGRAM of the candidates instead of sorted keys (what k_octree_hist executes, see
+// octree.cpp): -2 when a node deeper than the histogram (nIni * 4^D <= maxBins bins) would have to be split
+int distribute_octree_hist(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N, int maxBins,
+                           std::vector<int> &out);
+
 // upper bound of what distribute_octree can return for a level (used to size output buffers)
 int octree_max_result(int minX, int maxX, int minY, int maxY, int N);
 

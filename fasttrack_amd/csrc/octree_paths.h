@@ -285,6 +285,32 @@ OP_HD inline uint32_t path_code(const Roots &r, int x, int y) {
     return code;
 }
 
+// The first D digits of the path code: root << 2D | q_1 << 2(D-1) | ... | q_D, i.e. the index of the candidate's node of
+// depth D in code order (path_code(...) >> 2 * (kMaxDepth - D)).  The histogram formulation (k_octree_hist) counts the
+// candidates per such node instead of sorting them.
+OP_HD inline uint32_t path_prefix(const Roots &r, int x, int y, int D) {
+    int s = (int)((float)x / r.hX);
+    if (s >= r.nIni) s = r.nIni - 1;
+    int x0, x1, y0 = 0, y1 = r.H;
+    root_bounds(r, s, x0, x1);
+    uint32_t code = (uint32_t)s;
+    for (int d = 0; d < D; d++) {
+        const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+        const int q = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
+        if (q & 1) x0 = mx; else x1 = mx;
+        if (q & 2) y0 = my; else y1 = my;
+        code = (code << 2) | (uint32_t)q;
+    }
+    return code;
+}
+
+// depth of the histogram: the deepest D whose nIni * 4^D nodes fit maxBins (0 when not even the roots do)
+OP_HD inline int hist_depth(int nIni, int maxBins) {
+    int D = 0;
+    while (D < kMaxDepth && ((long long)nIni << (2 * (D + 1))) <= (long long)maxBins) D++;
+    return D;
+}
+
 // ---- tree replay over sorted codes ----------------------------------------------------------------------
 struct Node {
     uint16_t x0, y0, x1, y1;

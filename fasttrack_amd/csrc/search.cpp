@@ -417,6 +417,7 @@ void unpackFrustum(int M, const FrustumLayout &L, size_t outBegin, uint8_t *pin,
 // arrays in HBM; the scalar part of the frame, the host copy of the keypoints (angles for the rotation histogram)
 // and the authoritative holder_obs live on the host and are cheap (a few KB per frame).
 struct ft_tracked_frame {
+    bool counted = false;  // registered with the context (ft_context::liveObjects)
     ft_context *ctx = nullptr;
     int maxKp = 0, maxPts = 0;
     // owned device storage
@@ -783,6 +784,8 @@ int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, 
         ft_tracked_frame_destroy(tf);
         return ft_hip_fail(e, "ft_tracked_frame_create", __FILE__, __LINE__);
     }
+    tf->counted = true;
+    ctx->liveObjects++;
     *out = tf;
     return FT_OK;
 }
@@ -795,6 +798,7 @@ int ft_tracked_frame_destroy(ft_tracked_frame *tf) {
     hipFree(tf->d_holder); hipFree(tf->d_l2r); hipFree(tf->d_r2l); hipFree(tf->d_work); hipFree(tf->d_grid);
     if (tf->h_work) hipHostFree(tf->h_work);
     if (tf->h_holderUp) hipHostFree(tf->h_holderUp);
+    if (tf->counted) tf->ctx->liveObjects--;
     delete tf;
     return FT_OK;
 }

@@ -54,6 +54,11 @@ class Context:
     def host_threads(self) -> int:
         return lib().ft_context_host_threads(self._h)
 
+    @property
+    def hw_queues(self) -> int:
+        """GPU_MAX_HW_QUEUES the context was created under (4 = unset): which lane table the wide extractors use"""
+        return lib().ft_context_hw_queues(self._h)
+
     def set_kernel_timing(self, enabled: bool):
         check(lib().ft_context_set_kernel_timing(self._h, int(enabled)))
 
@@ -235,6 +240,15 @@ class ORBextractor:
         out = np.zeros((max(n.value, 1), 3), np.int32)
         check(lib().ft_extractor_download_candidates(self._h, slot, level, ptr(out), n.value, C.byref(n)))
         return out[:n.value]
+
+    def octree_on_device(self, level, xys, tiers=7):
+        """test tap: the device formulation of DistributeOctTree of one level on the given (x, y, score) candidates;
+        returns (retained (x, y, score) rows in the reference's result order, tier that produced them; 0 = left to the host)"""
+        xys = np.ascontiguousarray(xys, np.int32).reshape(-1, 3)
+        out = np.zeros((len(xys) + 64, 3), np.int32)
+        n, tier = C.c_int(), C.c_int()
+        check(lib().ft_extractor_octree_on_device(self._h, level, ptr(xys), len(xys), tiers, ptr(out), len(out), C.byref(n), C.byref(tier)))
+        return out[:n.value].copy(), tier.value
 
 
 class FrameView:

@@ -56,13 +56,19 @@ FT_API const char *ft_last_error(void);
 FT_API int ft_device_count(void); /* number of HIP devices, 0 if none (never fails) */
 /* host_threads: workers for the host-side octree stage (0 = the CPUs this process may use:
  * hardware threads capped by affinity and by a cgroup CPU quota).
- * Side effect: sets GPU_MAX_HW_QUEUES=10 in the process environment unless the variable is already set (the HIP
- * runtime reads it at the first HIP call of the process): extractors for batches of more than 16 frames run on eight
- * streams of the context and are fastest when each of those has a hardware queue of its own. */
+ * No side effects on the process environment.  Extractors for batches of more than 16 frames run on streams of the context
+ * ("lanes") by a table made for the number of hardware queues the HIP runtime gives the process: GPU_MAX_HW_QUEUES, which
+ * the runtime reads ONCE, at the first HIP call of the process.  An application that wants the eight-lane table (+10 % on
+ * the headline workload over the four queues of the runtime's default) sets GPU_MAX_HW_QUEUES=10 before its first HIP call
+ * (INTEGRATION.md section 6); ft_context_hw_queues() reports what the context was created under (4 = variable unset).
+ * FT_LANE_MAP ("own" or whole sets of four lane numbers) overrides the table; a malformed value is FT_ERR_INVALID.
+ * ft_context_destroy refuses (FT_ERR_INVALID) while extractors, front ends or tracked frames of the context are alive:
+ * they run on its streams. */
 FT_API int ft_context_create(int device, int host_threads, ft_context **out);
 FT_API int ft_context_destroy(ft_context *ctx);
 FT_API int ft_context_synchronize(ft_context *ctx);
 FT_API int ft_context_device_name(ft_context *ctx, char *buf, int len);
+FT_API int ft_context_hw_queues(const ft_context *ctx);
 FT_API int ft_context_host_threads(const ft_context *ctx);
 /* per-stage wall/GPU timings of the calls made so far; the reference's REGISTER_STATS analogue
  * (include/Kernels/CudaUtils.h:14, src/Stats.cc:31-60).  Writes "<name>: <ms>" lines. */
@@ -133,6 +139,15 @@ FT_API int ft_extractor_device_level(ft_extractor *ex, int slot, int level, cons
  * as (x, y, score) triples relative to the level's (minBorderX, minBorderY) (ORBextractor.cc:1196-1198) */
 FT_API int ft_extractor_download_candidates(ft_extractor *ex, int slot, int level, int *xys, int capacity,
                                             int *n);
+
+/* stage tap for parity tests: the DEVICE formulation of DistributeOctTree (ORBextractor.cc:660-884) of one level on
+ * caller-provided candidates ((x, y, score) triples relative to the level's (minBorderX, minBorderY), any order: the
+ * kernels rank them by the reference's emission order themselves).  tiers: bit 1 allows the histogram tier
+ * (k_octree_hist), bit 2 the sorted big tier (k_octree_big); *tier = the tier that produced the result (1, 2, 3), 0 = the
+ * level is beyond the allowed tiers (the pipeline would repair the image with the host octree).  out_xys: the retained
+ * candidates in the reference's result order. */
+FT_API int ft_extractor_octree_on_device(ft_extractor *ex, int level, const int *xys, int n, int tiers, int *out_xys,
+                                         int capacity, int *n_out, int *tier);
 
 /* Host-only stages, callable without a GPU (they never touch pixels):
  * ft_octree_distribute = ORBextractor::DistributeOctTree (ORBextractor.cc:660-884), the serial stage

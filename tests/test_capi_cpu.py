@@ -139,14 +139,16 @@ def test_sincos_polynomial_equals_libm_on_every_float(tmp_path):
     assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
 def test_path_code_octree_equals_oracle(mode):
     """The path-code formulations the device kernel is built from (octree_paths.h; 1 = node-list replay over
-    sorted path codes, 2 = the round formulation k_octree executes: array list + prefix sums), executed
+    sorted path codes, 2 = the round formulation k_octree executes: array list + prefix sums, 3 = the same rounds over a
+    histogram of the candidates per tree node instead of sorted keys, as k_octree_hist runs them - with up to 20 000
+    candidates and clustered sets; a level that formulation gives up on goes to the sorted rounds, as on the device), executed
     single-threaded on the host through ft_octree_distribute with FT_OCTREE_PATHS=<mode>, equal the oracle -
     in a fresh process because the switch is read once."""
     code = r'''
-import numpy as np, ctypes as C, sys
+import numpy as np, ctypes as C, sys, os
 sys.path.insert(0, %r)
 from fasttrack_amd import _capi
 from oracle import binding as ob
@@ -156,15 +158,49 @@ def octree(xys, a, b, c, d, N):
     assert L.ft_octree_distribute(_capi.ptr(xys), len(xys), a, b, c, d, N, _capi.ptr(out), len(out), C.byref(n)) == 0
     return out[:n.value].copy()
 rng = np.random.default_rng(5)
+MODE = os.environ["FT_OCTREE_PATHS"]
 for trial in range(300):
     W, H = int(rng.integers(40, 1300)), int(rng.integers(40, 720))
     if trial %% 7 == 0: W, H = int(rng.integers(300, 2000)), int(rng.integers(20, 60))  # many root nodes
-    n, N = int(rng.integers(1, 5000)), int(rng.integers(1, 500))
-    pts = np.unique(np.stack([rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)], 1), axis=0); rng.shuffle(pts)
+    n, N = int(rng.integers(1, 20000 if MODE == "3" else 5000)), int(rng.integers(1, 500))
+    if MODE == "3" and trial %% 3 == 0:
+        cx, cy = rng.integers(3, W - 3), rng.integers(3, H - 3)
+        pts = np.stack([np.clip(rng.normal(cx, W / 16, n), 3, W - 4).astype(int), np.clip(rng.normal(cy, H / 16, n), 3, H - 4).astype(int)], 1)
+    else:
+        pts = np.stack([rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)], 1)
+    pts = np.unique(pts, axis=0); rng.shuffle(pts)
     xys = np.concatenate([pts, rng.integers(7, 12, (len(pts), 1))], 1).astype(np.int32)
     assert np.array_equal(ob.distribute_octree(xys, 16, 16 + W, 16, 16 + H, N), octree(xys, 16, 16 + W, 16, 16 + H, N)), trial
 print("ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FT_OCTREE_PATHS=mode)
     out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_malformed_lane_map_is_an_error_not_a_different_table():
+    """FT_LANE_MAP is checked before anything else in ft_context_create: a typo, an out-of-range lane or an incomplete set is
+    FT_ERR_INVALID with a message (round 2 dropped the offending entries silently and ran on a shifted table); a well-formed
+    value gets as far as the device probe."""
+    code = r'''
+import os, sys, ctypes as C
+sys.path.insert(0, %r)
+from fasttrack_amd import _capi
+L = _capi.lib()
+h = C.c_void_p()
+for bad in ("1 2 x 4", "1 2 3", "1 2 3 99", "own 1", ""):
+    os.environ["FT_LANE_MAP"] = bad
+    assert L.ft_context_create(0, 0, C.byref(h)) == _capi.FT_ERR_INVALID, bad
+    assert b"FT_LANE_MAP" in L.ft_last_error(), bad
+for good in ("own", "0 1 2 3", "1,2,3,4, 5 1 3 1"):
+    os.environ["FT_LANE_MAP"] = good
+    rc = L.ft_context_create(0, 0, C.byref(h))
+    assert rc in (0, _capi.FT_ERR_NO_DEVICE), (good, rc)
+    if rc == 0: L.ft_context_destroy(h)
+assert os.environ.get("GPU_MAX_HW_QUEUES") == "10"  # exported by the Python driver, not by the library
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

@@ -302,9 +302,9 @@ def test_device_octree_overflow_falls_back_to_host(ctx):
 
 
 def test_device_octree_second_tier(ctx):
-    """levels with more than FT_OCT_MAXN = 4 096 and at most 16 384 candidates are distributed by k_octree_big (LDS layout
-    for 16 384 keys), which is launched once a frame has asked for it: the first dense frame is repaired with the host
-    octree, the following ones stay on the device; every result equals the oracle's"""
+    """latency mode (small batches): levels with more than FT_OCT_MAXN = 4 096 candidates are distributed by the histogram
+    tier (k_octree_hist), which joins the captured graph once a frame has asked for it: the first dense frame is repaired
+    with the host octree, the following ones stay on the device; every result equals the oracle's"""
     w, h, nf = 1280, 720, 2000
     ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=2)
     oex = ob.Extractor(nf)
@@ -324,6 +324,90 @@ def test_device_octree_second_tier(ctx):
             f1 = _calls(ctx, "extract.device_octree_fallbacks")
             assert f1 == f0 + 2, "the first dense batch is repaired image by image"
     assert _calls(ctx, "extract.device_octree_fallbacks") == f1, "a later dense frame fell back to the host octree"
+
+
+def _emission_order(pts, wCell, hCell, nCols, nRows):
+    """cell row, cell column, then row-major inside the cell (ORBextractor.cc:1136-1199); pts relative to the border"""
+    x, y = pts[:, 0] - 3, pts[:, 1] - 3
+    cj, ci = np.minimum(x // wCell, nCols - 1), np.minimum(y // hCell, nRows - 1)
+    return np.lexsort((x, y, cj, ci))
+
+
+@pytest.mark.parametrize("w,h,nf", [(1280, 720, 2000), (752, 480, 1200), (640, 480, 1000), (1920, 400, 3000)])
+def test_device_octree_tiers_on_directed_candidates(ctx, w, h, nf):
+    """The three device formulations of DistributeOctTree (ORBextractor.cc:660-884) on candidate sets made for them, through
+    the test tap: k_octree (sorted keys, <= 4 096), k_octree_hist (histogram over the tree nodes of depth D, any count), and
+    k_octree_big (sorted, <= 16 384) for the levels whose tree outgrows the histogram - uniform and clustered sets, ties in
+    the responses, counts beyond 16 384 - all equal to the oracle in content and order."""
+    import ctypes as C
+    from fasttrack_amd import _capi
+    L = 8
+    lw, lh, quota, nc, nr, wc, hc = [np.zeros(L, np.int32) for _ in range(7)]
+    assert _capi.lib().ft_level_geometry(w, h, nf, 1.2, L, *[_capi.ptr(a) for a in (lw, lh, quota, nc, nr, wc, hc)]) == 0
+    ex = orb.ORBextractor(ctx, nf, 1.2, L, 20, 7, w, h, max_batch=1)
+    rng = np.random.default_rng(w + nf)
+    tiers_seen = set()
+    for trial in range(36):
+        level = int(rng.integers(0, 3)) if trial % 4 else int(rng.integers(0, L))
+        W, H = int(lw[level]) - 32, int(lh[level]) - 32  # maxBorder - minBorder (border 16)
+        kind = trial % 6
+        n = int(rng.integers(4200, 14000)) if kind < 4 else int(rng.integers(17000, 30000)) if kind == 4 else int(rng.integers(50, 4000))
+        n = min(n, (W - 6) * (H - 6) // 5)
+        if kind in (1, 3):  # a few dense clusters: the tree goes deep where the candidates are
+            k = int(rng.integers(1, 5))
+            cx, cy = rng.integers(3, W - 3, k), rng.integers(3, H - 3, k)
+            sel = rng.integers(0, k, n)
+            sd = (W / 40 if kind == 1 else W / 12)
+            pts = np.stack([np.clip(rng.normal(cx[sel], sd), 3, W - 4), np.clip(rng.normal(cy[sel], sd * H / W), 3, H - 4)], 1).astype(np.int64)
+        else:
+            pts = np.stack([rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)], 1)
+        pts = np.unique(pts, axis=0)
+        pts = pts[_emission_order(pts, int(wc[level]), int(hc[level]), int(nc[level]), int(nr[level]))]
+        resp = rng.integers(7, 12 if trial % 2 else 200, (len(pts), 1))  # narrow range: many ties for the first-maximum rule
+        xys = np.concatenate([pts, resp], 1).astype(np.int32)
+        want = xys[ob.distribute_octree(xys, 16, 16 + W, 16, 16 + H, int(quota[level]))]
+        shuffled = xys[rng.permutation(len(xys))]  # the device ranks the candidates by their coordinates
+        got, tier = ex.octree_on_device(level, shuffled, tiers=7)
+        if tier == 0:  # the histogram gave up and the level has more keys than the sorted big tier holds: left to the host
+            assert kind in (1, 3) and len(xys) > 4096 and len(got) == 0, (trial, level, len(xys), kind)
+            continue
+        assert tier in (1, 2, 3), (trial, level, len(xys), tier)
+        assert np.array_equal(got, want), (trial, level, len(xys), tier)
+        tiers_seen.add(tier)
+        if tier == 2 and len(xys) <= 16384:  # the sorted big tier on the same level (it holds 8 192 keys when the quotas are large)
+            got3, t3 = ex.octree_on_device(level, shuffled, tiers=5)
+            assert t3 in (0, 3) and (t3 == 3 or len(xys) > 8192), (trial, level, len(xys), t3)
+            if t3 == 3:
+                assert np.array_equal(got3, want), (trial, level, len(xys))
+                tiers_seen.add(3)
+        if tier != 1:  # and with neither: left to the host, nothing half-written
+            got0, t0 = ex.octree_on_device(level, shuffled, tiers=1)
+            assert t0 == 0 and len(got0) == 0
+    assert {1, 2, 3} <= tiers_seen, tiers_seen
+    ex.close()
+
+
+def test_device_octree_histogram_gives_up_to_sorted_tier(ctx):
+    """a level whose quota is spent inside one small cluster: the tree grows deeper than the histogram's table, k_octree_hist
+    gives up and hands the level to k_octree_big; with that tier not allowed the level is left to the host"""
+    w, h, nf = 1280, 720, 2000
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=1)
+    W, H = w - 32, h - 32
+    rng = np.random.default_rng(11)
+    ys, xs = np.mgrid[200:290, 300:390]  # 8 100 candidates in a 90 x 90 px block
+    pts = np.stack([xs.ravel(), ys.ravel()], 1)
+    quota = ex.features_per_level()[0]
+    lw, lh, q, nc, nr, wc, hc = [np.zeros(8, np.int32) for _ in range(7)]
+    from fasttrack_amd import _capi
+    assert _capi.lib().ft_level_geometry(w, h, nf, 1.2, 8, *[_capi.ptr(a) for a in (lw, lh, q, nc, nr, wc, hc)]) == 0
+    pts = pts[_emission_order(pts, int(wc[0]), int(hc[0]), int(nc[0]), int(nr[0]))]
+    xys = np.concatenate([pts, rng.integers(7, 40, (len(pts), 1))], 1).astype(np.int32)
+    want = xys[ob.distribute_octree(xys, 16, 16 + W, 16, 16 + H, int(quota))]
+    got, tier = ex.octree_on_device(0, xys, tiers=7)
+    assert tier == 3 and np.array_equal(got, want)
+    got, tier = ex.octree_on_device(0, xys, tiers=3)
+    assert tier == 0 and len(got) == 0
+    ex.close()
 
 
 def test_two_host_threads_two_extractors(ctx):

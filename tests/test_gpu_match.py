@@ -199,13 +199,18 @@ def test_stereo_frontend_device_octree_overflow(ctx):
     assert calls("stereo.device_octree_batches") == b0 + 2
 
 
-def test_dense_frames_stay_on_the_device_and_overflows_are_repaired_per_pair(ctx):
-    """Throughput mode (more than 16 pairs per batch).  Levels with 4 096 .. 16 384 candidates go to the second-tier octree
-    kernel, whose grid the host sizes from the previous batch: the first dense batch finds it absent and is repaired pair
-    by pair with the host octree, the second one stays on the device.  A pair with a level beyond 16 384 candidates is
-    always repaired - that pair only.  Every output equals the oracle's."""
+@pytest.mark.parametrize("hist", [True, False])
+def test_dense_frames_stay_on_the_device_and_overflows_are_repaired_per_pair(ctx, hist, monkeypatch):
+    """Throughput mode (more than 16 pairs per batch).  Levels with more than 4 096 candidates go to the histogram tier of the
+    device octree (k_octree_hist, any count up to 65 535): dense and pure-noise frames stay on the device from the first batch
+    on.  With that tier switched off (FT_OCT_HIST=0, read when the front end is created) levels up to 16 384 candidates go to
+    the sorted big tier, whose grid the host sizes from the previous batch: the first dense batch finds it absent and is
+    repaired pair by pair with the host octree, the second one stays on the device, and a pair with a level beyond 16 384
+    candidates is always repaired - that pair only.  Every output equals the oracle's."""
     w, h, nf, B = 752, 480, 1200, 18
     intr = synth.intrinsics(w, h)
+    if not hist:
+        monkeypatch.setenv("FT_OCT_HIST", "0")
     fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
 
     def calls(name):
@@ -233,10 +238,11 @@ def test_dense_frames_stay_on_the_device_and_overflows_are_repaired_per_pair(ctx
     batch1 = [dense[i % 3] if i % 2 == 0 else calm[i % 3] for i in range(B)]  # 9 dense pairs among 18
     f0 = calls("stereo.device_octree_fallbacks")
     outs = fe.process([p[0] for p in batch1], [p[1] for p in batch1])
-    assert calls("stereo.device_octree_fallbacks") == f0 + 9, "first dense batch: the dense pairs, and only they, are repaired"
+    r1 = 0 if hist else 9
+    assert calls("stereo.device_octree_fallbacks") == f0 + r1, "first dense batch: on the device / the dense pairs, and only they, are repaired"
     check(batch1, outs, [0, 1, 2, 17])
     outs = fe.process([p[0] for p in batch1], [p[1] for p in batch1])
-    assert calls("stereo.device_octree_fallbacks") == f0 + 9, "second dense batch stays on the device"
+    assert calls("stereo.device_octree_fallbacks") == f0 + r1, "second dense batch stays on the device"
     check(batch1, outs, [0, 3, 4, 16])
     # a frame beyond the second tier (pure noise: tens of thousands of candidates at level 0) among dense and calm ones
     noisy = (synth.make_noise(w, h, seed=8), synth.make_noise(w, h, seed=9))
@@ -244,17 +250,22 @@ def test_dense_frames_stay_on_the_device_and_overflows_are_repaired_per_pair(ctx
     batch2[5] = noisy
     batch2[11] = (calm[0][0], noisy[1])  # only the right camera overflows
     outs = fe.process([p[0] for p in batch2], [p[1] for p in batch2])
-    assert calls("stereo.device_octree_fallbacks") == f0 + 11
+    assert calls("stereo.device_octree_fallbacks") == f0 + (0 if hist else 11)
     check(batch2, outs, [4, 5, 6, 11])
+    fe.close()
 
 
-def test_dense_frames_in_concurrent_sub_batches(ctx):
+@pytest.mark.parametrize("hist", [True, False])
+def test_dense_frames_in_concurrent_sub_batches(ctx, hist, monkeypatch):
     """256 pairs per batch = two sub-batches whose octree kernels run side by side on the two octree streams, every pair with
-    levels beyond 4 096 candidates: the second-tier lists are per stream.  The first batch finds the second tier switched off
-    and goes through the host-octree pipeline as a whole; the second runs on the device and must reproduce it slot for slot;
-    the four distinct pairs are checked against the oracle."""
+    levels beyond 4 096 candidates: the lists of the tiers behind k_octree are per stream.  Both batches run on the device
+    (histogram tier) and must agree slot for slot.  With that tier switched off the first batch finds the sorted big tier
+    absent and goes through the host-octree pipeline as a whole; the second runs on the device and must reproduce it.  The four
+    distinct pairs are checked against the oracle."""
     w, h, nf, B = 640, 480, 1000, 256
     intr = synth.intrinsics(w, h)
+    if not hist:
+        monkeypatch.setenv("FT_OCT_HIST", "0")
     fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
     dense = [synth.make_mosaic_pair(w, h, seed=160 + i, block=6) for i in range(4)]
     oex = ob.Extractor(nf)
@@ -270,9 +281,10 @@ def test_dense_frames_in_concurrent_sub_batches(ctx):
             return 0
     f0 = calls("stereo.device_octree_fallbacks")
     first = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
-    assert calls("stereo.device_octree_fallbacks") == f0 + B
+    r1 = 0 if hist else B
+    assert calls("stereo.device_octree_fallbacks") == f0 + r1
     second = fe.process([p[0] for p in pairs], [p[1] for p in pairs])
-    assert calls("stereo.device_octree_fallbacks") == f0 + B, "the second dense batch stays on the device"
+    assert calls("stereo.device_octree_fallbacks") == f0 + r1, "the second dense batch stays on the device"
     for b in range(B):
         for k in ("keysL", "keysR", "descL", "descR", "uright", "depth"):
             assert np.array_equal(first[b][k], second[b][k]), (b, k)
