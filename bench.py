@@ -20,8 +20,13 @@ shifts - the same shift for the left and the right image, which keeps the pair r
 
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   roofline      dominant kernel (FAST cells): algorithmic bytes per launch / HIP-event duration vs 8 TB/s
-  cpu_baseline  the oracle (restated CPU path of the reference) timed on this box's host cores
+  cpu_baseline  the oracle (restated CPU path of the reference) timed on this box's host cores (rank 0, after the last barrier)
   host_in       the same workload with the frames in pinned host memory (H2D inside the timed region)
+  workloads     (N = 1) the other workloads BASELINE.json's north_star names, a few steps each after the headline region:
+                stereo_752x480_nf1200 (configs[2]), tracking_512x512_nf2000 (configs[3]: fisheye extraction with the YAML's
+                lapping area + both SearchByProjection searches per frame, latency mode), dense_1280x720_nf2000 (mosaic
+                frames with ~10 k FAST survivors at level 0, SURVEY a4's range) and planes_1280x720_nf2000 (60 % of the
+                left keypoints find a stereo partner) - each with its own cpu_baseline sample
 """
 import argparse
 import json
@@ -134,7 +139,7 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def make_stream(alloc, w, h, rank, D, scenes, density=1.0, mosaic=0):
+def make_stream(alloc, w, h, rank, D, scenes, density=1.0, mosaic=0, planes=False):
     """D distinct stereo pairs of this rank's stream in pinned host memory: `scenes` seeded scenes (synth.make_stereo_pair),
     scene s of variant k shifted cyclically by (53 k mod w, 29 k mod h) px in BOTH images (rectification and disparities
     are kept; the wrap-around seam is one more edge).  alloc(shape, dtype) provides the (pinned) arrays.  Returns (hostL,
@@ -142,6 +147,8 @@ def make_stream(alloc, w, h, rank, D, scenes, density=1.0, mosaic=0):
     S = max(1, min(scenes, D))
     if mosaic:
         base = [synth.make_mosaic_pair(w, h, seed=s, block=mosaic) for s in shard.stream_seeds(rank, S)]
+    elif planes:
+        base = [synth.make_planes_pair(w, h, seed=s, density=density) for s in shard.stream_seeds(rank, S)]
     else:
         base = [synth.make_stereo_pair(w, h, seed=s, density=density) for s in shard.stream_seeds(rank, S)]
     hostL, hostR = alloc((D, h, w), np.uint8), alloc((D, h, w), np.uint8)
@@ -157,6 +164,203 @@ def make_stream(alloc, w, h, rank, D, scenes, density=1.0, mosaic=0):
     return hostL, hostR, base
 
 
+def stereo_leg(orb, ctx, name, w, h, nf, B, steps, warmup, mosaic=0, planes=False, scenes=8, cpu_budget_s=4.0, cpu=True):
+    """One of the extra stereo workloads: the headline pipeline (two front ends used alternately, frames resident in HBM,
+    results to host arrays) on another shape or scene kind, a few steps; buffers are released afterwards."""
+    import ctypes as C
+    intr = synth.intrinsics(w, h)
+    fes = [orb.StereoFrontend(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, B, intr["mbf"], intr["mb"]) for _ in range(2)]
+    hostL, hostR, pairs = make_stream(lambda shape, dt: np.empty(shape, dt), w, h, 0, B, scenes, 1.0, mosaic, planes)
+    devL, devR = ctx.to_device(hostL), ctx.to_device(hostR)
+    fb = w * h
+    pL = (C.c_void_p * B)(*[devL.ptr.value + b * fb for b in range(B)])
+    pR = (C.c_void_p * B)(*[devR.ptr.value + b * fb for b in range(B)])
+
+    def run(n):
+        for k in range(n):
+            if k >= 2:
+                fes[k % 2].wait()
+            fes[k % 2].submit_raw(pL, pR, B, True, w)
+        for k in range(max(n - 2, 0), n):
+            fes[k % 2].wait()
+    f0 = ctx.get_stat("stereo.device_octree_fallbacks")[1]
+    run(max(warmup, 2))  # (the first dense batches size the octree's histogram tier)
+    f1 = ctx.get_stat("stereo.device_octree_fallbacks")[1]
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    fe = fes[(steps - 1) % 2]
+    kps = int(fe._nL[:B].sum() + fe._nR[:B].sum())
+    nL = int(fe._nL[:B].sum())
+    matches = int(fe._nm[:B].sum())
+    out = {"value": B * steps / dt, "unit": "frames/s", "metric": "frames/sec extract+match", "steps": steps, "warmup": max(warmup, 2),
+           "ms_per_step": 1e3 * dt / steps, "batch_pairs": B, "distinct_pairs": B, "image": [w, h], "nfeatures": nf,
+           "scene_kind": f"mosaic of {mosaic}-px tiles" if mosaic else "object scene on fronto-parallel planes" if planes else "objects on a smooth background",
+           "inputs": "resident in HBM before the timed region", "keypoints_per_s": kps * steps / dt, "keypoints_per_frame": kps / B,
+           "stereo_matches_per_frame": matches / B, "stereo_match_fraction": matches / max(nL, 1),
+           "device_octree_fallbacks": ctx.get_stat("stereo.device_octree_fallbacks")[1] - f1,
+           "device_octree_fallbacks_during_warmup": f1 - f0,
+           "pipeline_hbm_read_frac": (B * steps / dt) * 2 * (3 * sum(level_pixels(w, h)) - level_pixels(w, h)[-1]) / (HBM_PEAK_GBS * 1e9)}
+    for f in fes:
+        f.close()
+    devL.free()
+    devR.free()
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline(w, h, nf, pairs, budget_s=cpu_budget_s)
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=True):
+    """BASELINE.json configs[3] (TUM-VI stereo-inertial fisheye, 512x512, nFeatures 2000, Examples/Stereo-Inertial/TUM-VI.yaml:
+    45-53,86): per frame, as a SLAM front end calls it - one frame at a time, host images in, host results out -
+      extraction of the left and the right image with the YAML's lapping areas [0, 511]  (ORBextractor::operator(), Frame.cc:1144)
+      left <-> right descriptor matching of the lapping subsets                            (ComputeStereoFishEyeMatches, Frame.cc:1231-1271)
+      SearchByProjection(CurrentFrame, LastFrame, th)                                       (ORBmatcher.cc:1775-1990; th 7 for stereo, 15 otherwise, Tracking.cc:2941-2946)
+      isInFrustum + SearchByProjection(CurrentFrame, local map points, th)                  (Frame.cc:536-610, ORBmatcher.cc:49-225)
+    on a two-camera KannalaBrandt8 frame resident in HBM (ft_tracked_frame_*), M local map points and one last-frame point
+    per left keypoint, for th in {7, 15}.  Reported: frames/s, map points/s (points handed to the two searches) and Hamming
+    compares/s (keypoints returned by GetFeaturesInArea for the searched points' windows, both cameras, counted once outside
+    the timed region through ft_features_in_area with the searches' own radii and level ranges)."""
+    from fasttrack_amd import scenarios as sc
+    w, h, nf, D = 512, 512, 2000, 8
+    lap = (0, 511)
+    cam = list(sc.KB8_CAM)
+    intr = dict(fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+    Trl = np.concatenate([np.eye(3), [[-0.101], [0.0], [0.0]]], 1).astype(np.float32)  # x_r = x_l + trl: 10.1 cm baseline (TUM-VI)
+    TLR = (0.101, 0.0, 0.0)
+    LOG_SF = float(np.float32(np.log(np.float32(SCALE))))
+    exL = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=1)
+    exR = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=1)
+    sf = np.asarray(exL.GetScaleFactors(), np.float32)
+    pairs = [synth.make_planes_pair(w, h, seed=7000 + i) for i in range(D)]
+    tf = orb.TrackedFrame(ctx, max_keypoints=2 * exL.max_keypoints + 64, max_points=max(M, exL.max_keypoints) + 64)
+
+    def extract(i):
+        kL, dL, _ = exL(pairs[i][0], lap)
+        kR, dR, _ = exR(pairs[i][1], lap)
+        m = orb.KernelController.launchFisheyeStereoMatchKernel(ctx, dL, dR)
+        l2r = np.ascontiguousarray(m["matches"], np.int32)
+        r2l = np.full(len(kR), -1, np.int32)
+        ok = l2r >= 0
+        r2l[l2r[ok]] = np.nonzero(ok)[0].astype(np.int32)
+        F = orb.FrameView(keys=kL, keys_right=kR, descriptors=np.concatenate([dL, dR]), scale_factors=sf, bounds=sc.frame_bounds(w, h),
+                          left_to_right=l2r, right_to_left=r2l, cam_model=1, cam=cam, Trl=Trl)
+        return kL, dL, kR, dR, F
+    # per distinct frame: the last frame's points and the local map, built from the frame's own keypoints (SURVEY 8d)
+    scen = []
+    for i in range(D):
+        kL, dL, kR, dR, F = extract(i)
+        depth = np.zeros(len(kL), np.float32)
+        last, Tcw_last = sc.last_frame_scenario(kL, dL, None, depth, intr, w, h, seed=40 + i)
+        pts, Rcw, tcw = sc.map_points_scenario(kL, dL, depth, intr, NLEVELS, sf, 90 + i, M=M)
+        scen.append((last, Tcw_last, pts, Rcw, tcw))
+
+    def frame(i, th):
+        kL, dL, kR, dR, F = extract(i)
+        last, Tcw_last, pts, Rcw, tcw = scen[i]
+        tf.upload(F)
+        a = tf.search_last_frame(last, Tcw_last, th)
+        b = tf.track_local_map(orb.make_pose(Rcw, tcw, TLR), pts, 0.5, LOG_SF, th)
+        return len(kL), len(kR), a, b, F
+    out = {"metric": "frames/sec extract + SearchByProjection (last frame, local map)", "unit": "frames/s", "image": [w, h], "nfeatures": nf,
+           "camera": "KannalaBrandt8 stereo rig, lapping areas [0, 511]", "local_map_points": M, "mode": "one frame at a time (latency mode), host images in, host results out",
+           "scene_kind": "object scene on fronto-parallel planes", "distinct_frames": D, "by_th": {}}
+    for th in (7.0, 15.0):
+        for k in range(warmup):
+            frame(k % D, th)
+        ctx.synchronize()
+        npts = ncmp = nmatch = 0
+        t0 = time.perf_counter()
+        for k in range(frames):
+            nl, nr, a, b, F = frame(k % D, th)
+            npts += len(scen[k % D][0]["valid"]) + M
+            nmatch += a["n"] + b["n"]
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        # Hamming compares of one pass over the distinct frames, counted outside the timed region
+        for i in range(D):
+            nl, nr, a, b, F = frame(i, th)
+            ncmp += count_compares(orb, ctx, F, sf, scen[i], b, th, cam, Trl)
+        out["by_th"][str(int(th))] = {"value": frames / dt, "ms_per_frame": 1e3 * dt / frames, "map_points_per_s": npts / dt,
+                                      "hamming_compares_per_frame": ncmp / D, "hamming_compares_per_s": ncmp / D * frames / dt,
+                                      "matches_per_frame": nmatch / frames}
+    out["value"] = out["by_th"]["7"]["value"]
+    out["keypoints_per_frame"] = nl + nr
+    if cpu:
+        out["cpu_baseline"] = tracking_cpu_baseline(pairs, scen, cam, Trl, sf, lap, w, h, nf, LOG_SF, cpu_budget_s)
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    tf.close()
+    exL.close()
+    exR.close()
+    return out
+
+
+def count_compares(orb, ctx, F, sf, scen, b, th, cam, Trl):
+    """DescriptorDistance calls of the two searches of one frame = keypoints GetFeaturesInArea returns for every searched point:
+    last frame (ORBmatcher.cc:1830-1846, 1905-1915: radius th * sf[octave], levels [octave - 1, octave + 1], left and right
+    camera; projections recomputed here in float64) and local map (ORBmatcher.cc:76-90, 150-160: radius RadiusByViewingCos *
+    th * sf[predicted level], levels [level - 1, level], from the frustum fields the search itself used)."""
+    from fasttrack_amd import scenarios as sc
+    last, Tcw_last, pts, Rcw, tcw = scen
+    nlevels = len(sf)
+    T = np.asarray(Tcw_last, np.float64).reshape(3, 4)
+    Pc = np.asarray(last["world_pos"], np.float64) @ T[:, :3].T + T[:, 3]
+    Pr = Pc @ np.asarray(Trl, np.float64)[:, :3].T + np.asarray(Trl, np.float64)[:, 3]
+    octv = np.asarray(last["octave"])
+    qs = []
+    for P, right in ((Pc, None), (Pr, 1)):
+        ok = (np.asarray(last["valid"]) > 0) & (P[:, 2] > 0)
+        uv = sc.kb8_project64(cam, P[ok])
+        qs.append((uv[:, 0], uv[:, 1], np.float32(th) * sf[octv[ok]], octv[ok] - 1, octv[ok] + 1, None if right is None else np.ones(int(ok.sum()), np.uint8)))
+    for side in ("", "_r"):
+        inv = b["in_view" + side] > 0
+        lv = np.clip(b["level" + side], 0, nlevels - 1)
+        r = np.where(b["view_cos" + side] > np.float32(0.998), 2.5, 4.0).astype(np.float32) * np.float32(th)
+        px, py = (b["proj_x"], b["proj_y"]) if side == "" else (b["proj_xr"], b["proj_yr"])
+        qs.append((px[inv], py[inv], (r * sf[lv])[inv], lv[inv] - 1, lv[inv], None if side == "" else np.ones(int(inv.sum()), np.uint8)))
+    total = 0
+    for x, y, rad, lo, hi, right in qs:
+        if len(x) == 0:
+            continue
+        _, cnt = orb.features_in_area(ctx, F, np.asarray(x, np.float32), np.asarray(y, np.float32), np.asarray(rad, np.float32),
+                                      np.asarray(lo, np.int32), np.asarray(hi, np.int32), right, capacity=8)
+        total += int(np.asarray(cnt).sum())
+    return total
+
+
+def tracking_cpu_baseline(pairs, scen, cam, Trl, sf, lap, w, h, nf, LOG_SF, budget_s):
+    """the oracle on ONE host core (the reference's tracking thread runs these stages one after the other; its two
+    extraction threads are the only parallelism, Frame.cc:127-130): same frames, same sequence, th = 7"""
+    from oracle import binding as ob
+    from fasttrack_amd import scenarios as sc
+    exL, exR = ob.Extractor(nf, SCALE, NLEVELS, INI_TH, MIN_TH), ob.Extractor(nf, SCALE, NLEVELS, INI_TH, MIN_TH)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        i = n % len(pairs)
+        kL, dL, _ = exL.extract(pairs[i][0], lap)
+        kR, dR, _ = exR.extract(pairs[i][1], lap)
+        l2r = ob.fisheye_match(dL, dR)["matches"].astype(np.int32)
+        r2l = np.full(len(kR), -1, np.int32)
+        ok = l2r >= 0
+        r2l[l2r[ok]] = np.nonzero(ok)[0].astype(np.int32)
+        F = ob.FrameView(keys=kL, keys_right=kR, descriptors=np.concatenate([dL, dR]), scale_factors_=sf, bounds=sc.frame_bounds(w, h),
+                         left_to_right=l2r, right_to_left=r2l, cam_model=1, cam=cam, Trl=Trl)
+        last, Tcw_last, pts, Rcw, tcw = scen[i]
+        ob.search_last_frame(F, last, Tcw_last, 7.0, False, False, True)
+        fr = ob.is_in_frustum(F, ob.make_pose(Rcw, tcw, (0.101, 0.0, 0.0)), pts, 0.5, LOG_SF)
+        ob.search_local_points(F, sc.local_points_from_frustum(fr, pts), 7.0)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 256:
+            break
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} synthetic 512x512 fisheye pairs (nFeatures {nf}): oracle extract L + R with lapping areas, fisheye match, "
+                      f"SearchByProjection(last frame) + isInFrustum + SearchByProjection(local map, {len(scen[0][2]['world_pos'])} points), th 7, one thread, {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,6 +371,12 @@ def main():
     ap.add_argument("--distinct", type=int, default=0, help="distinct frames cycled through the batch (0 = the batch size)")
     ap.add_argument("--scenes", type=int, default=16, help="seeded synthetic scenes behind the distinct frames")
     ap.add_argument("--density", type=float, default=1.0, help="object density of the synthetic scenes (synth.py)")
+    ap.add_argument("--scene", default="objects", choices=["objects", "planes"],
+                    help="objects: every object at a disparity of its own (keypoints on occlusion edges, ~10 %% of the left keypoints "
+                         "match); planes: the same scene on fronto-parallel planes (synth.make_planes_pair: ~60 %% match)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the extra workloads (752x480, tracking 512x512, dense, planes)")
+    ap.add_argument("--workload-batch", type=int, default=512, help="pairs per step of the extra stereo workloads")
+    ap.add_argument("--workload-frames", type=int, default=48, help="frames per threshold of the tracking workload")
     ap.add_argument("--mosaic", type=int, default=0, metavar="BLOCK",
                     help="dense-corner scenes instead (synth.make_mosaic_pair with tiles of BLOCK px: 8 gives > 8 k FAST "
                          "candidates at level 0 of a 1280x720 frame)")
@@ -203,7 +413,7 @@ def main():
     # synthetic stream (seeds are per rank: one stream per GPU): D distinct pairs in pinned host memory and, for the
     # headline number, resident in HBM before the timed region
     D = max(1, min(args.distinct or B, B))
-    hostL, hostR, pairs = make_stream(ctx.pinned_array, w, h, rank, D, args.scenes, args.density, args.mosaic)
+    hostL, hostR, pairs = make_stream(ctx.pinned_array, w, h, rank, D, args.scenes, args.density, args.mosaic, args.scene == "planes")
     devL, devR = ctx.to_device(hostL), ctx.to_device(hostR)
     import ctypes as C
     fb = w * h
@@ -248,7 +458,7 @@ def main():
     matches = int(fe._nm[:B].sum())
 
     elapsed = shard.reduce_max(dist, elapsed_rank)
-    kps, matches = [int(v) for v in shard.reduce_sum(dist, [kps_rank, matches])]
+    kps, matches, kpsL = [int(v) for v in shard.reduce_sum(dist, [kps_rank, matches, int(fe._nL[:B].sum())])]
     rank_fps = shard.gather_floats(dist, B * args.steps / elapsed_rank, world)
 
     if args.stats:
@@ -299,7 +509,7 @@ def main():
             tj = {}
         tk = tj.get("kernels", {})
         same_inputs = (tj.get("distinct_pairs") == D and tj.get("batch_pairs") == B and tj.get("workload") == args.workload and
-                       not args.mosaic and args.density == 1.0)  # the profiled scenes are the default ones
+                       not args.mosaic and args.density == 1.0 and args.scene == "objects")  # the profiled scenes are the default ones
 
         def leg(stat, kernel, total_bytes, per_group=1):
             k = kern[stat]  # read before the host-in region reset the statistics
@@ -336,7 +546,7 @@ def main():
             mc = json.load(open(os.path.join(ROOT, "profiles", "r02_marginal_costs.json")))
         except Exception:
             mc = {}
-        if roof and mc.get("workload") == args.workload and mc.get("batch_pairs") == B and not args.mosaic:
+        if roof and mc.get("workload") == args.workload and mc.get("batch_pairs") == B and not args.mosaic and args.scene == "objects":
             ms = mc["marginal_ms_per_step"]["k_fast_cells"] / (roof["launches_timed"] / args.steps)
             ach = roof["bytes_per_launch"] / (ms / 1e3) / 1e9
             roof["at_marginal_cost"] = {"ms_per_launch": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
@@ -351,7 +561,7 @@ def main():
                        "image": [w, h], "nfeatures": nf, "nlevels": NLEVELS, "scale_factor": SCALE,
                        "fast_thresholds": [INI_TH, MIN_TH], "batch_pairs_per_gpu": B, "distinct_pairs": D,
                        "scenes": min(args.scenes, D), "scene_density": args.density,
-                       "scene_kind": f"mosaic of {args.mosaic}-px tiles" if args.mosaic else "objects on a smooth background",
+                       "scene_kind": f"mosaic of {args.mosaic}-px tiles" if args.mosaic else "object scene on fronto-parallel planes" if args.scene == "planes" else "objects on a smooth background",
                        "inputs": "resident in HBM before the timed region (host_in: pinned host memory, uploaded inside it)",
                        "batches_in_flight": len(fes),
                        "parallelism": f"{world} independent stream(s), one per GPU, no collective",
@@ -360,6 +570,7 @@ def main():
             "keypoints_per_s": kps * args.steps / elapsed,
             "keypoints_per_frame": kps / (B * world),
             "stereo_matches_per_frame": matches / (B * world),
+            "stereo_match_fraction": matches / max(kpsL, 1),
             "device_octree_fallbacks": fallbacks,
             "pipeline_hbm_read_frac": fps / world * R_pair / (HBM_PEAK_GBS * 1e9),
             "kernels": kern, "host_ms_per_step": host,
@@ -367,9 +578,27 @@ def main():
             "roofline_other_kernels": also,
             "host_in": host_in,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        # The other workloads north_star names (N = 1 only: they are this box's numbers, not part of the scaling curve).  The
+        # headline's buffers are released first; every leg builds and releases its own.
+        out["workloads"] = None
+        if world == 1 and not args.no_workloads:
+            for f in fes:
+                f.close()
+            devL.free()
+            devR.free()
+            cpu = not args.no_cpu_baseline
+            wl = {}
+            WB = args.workload_batch
+            wl["stereo_752x480_nf1200"] = stereo_leg(orb, ctx, "stereo_752x480_nf1200", 752, 480, 1200, WB, 16, 3, cpu=cpu)
+            wl["tracking_512x512_nf2000"] = tracking_leg(orb, ctx, frames=args.workload_frames, cpu=cpu)
+            wl["dense_1280x720_nf2000"] = stereo_leg(orb, ctx, "dense", 1280, 720, 2000, WB, 8, 3, mosaic=10, cpu=cpu, cpu_budget_s=3.0)
+            wl["planes_1280x720_nf2000"] = stereo_leg(orb, ctx, "planes", 1280, 720, 2000, WB, 8, 3, planes=True, cpu=cpu, cpu_budget_s=3.0)
+            out["workloads"] = wl
+        if not args.no_cpu_baseline:  # rank 0, after the last barrier: the other ranks are done and the host cores are free
             out["cpu_baseline"] = cpu_baseline(w, h, nf, pairs)
-            out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
+            out["gpu_over_cpu_per_gpu"] = fps / world / out["cpu_baseline"]["value"]
+            if world == 1:
+                out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

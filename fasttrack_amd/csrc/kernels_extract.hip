@@ -532,7 +532,7 @@ __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int 
 __host__ __device__ __forceinline__ int fc_score_bytes(int wCell, int hCell, int TP) { return (((hCell + 2) * fc_pitch(wCell, TP)) + 15) & ~15; }
 __host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + FC_CORN) + 16; }  // + the spare entry
 
-// dbg (FT_FAST_DBG, a timing probe - results are wrong with it): 1 replaces the score network by a three-pixel hash, 2 stops in
+// dbg (FT_FAST_DBG, a timing probe - results are wrong with 1, 2, 4; 8 only switches the paired score rounds off): 1 replaces the score network by a three-pixel hash, 2 stops in
 // front of NMS / emission, 4 right behind the staging of the tile; tools/fast_probe.py times the kernel with each of them.
 // ORDERED = false (device octree, which ranks candidates by their coordinates): the rejection pass is free to
 // visit the pixels in any order and uses all 64 lanes (see below); ORDERED = true delivers every cell's
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
         if constexpr (TP > 0) {
             // rounds of 128: two candidates per lane through the packed network (fast_score2); the corner list takes the
             // first 64 of a round before the second 64, so its order is the ring's
-            for (; nc - jb > 64 && !(dbg & 1); jb += 128) {
+            for (; nc - jb > 64 && !(dbg & 9); jb += 128) {  // dbg 8: A/B switch, rounds of 64 only
                 const int jA = jb + lane, jB = jb + 64 + lane;
                 const int cA = cand[jA], cB = cand[min(jB, nc - 1)];
                 const int yA = pixY(cA), xA = pixX(cA, yA), yB = pixY(cB), xB = pixX(cB, yB);

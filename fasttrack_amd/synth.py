@@ -116,6 +116,30 @@ def make_mosaic_pair(width: int, height: int, seed: int, block: int = 8, dispari
     return np.ascontiguousarray(_finish(rng, left)), np.ascontiguousarray(_finish(rng, right))
 
 
+def make_planes_pair(width: int, height: int, seed: int, density: float = 1.0, planes: int = 3):
+    """Rectified pair with the stereo statistics of an indoor sequence: the object scene of make_image painted on `planes`
+    fronto-parallel surfaces (horizontal bands of the image, each at one disparity in [4, 0.12 fx] px) instead of on
+    occluding objects at a disparity each.  Inside a band both cameras see the same texture, so most left keypoints have
+    their partner in the right image (make_stereo_pair: ~10 %, because its keypoints sit on occlusion edges whose two
+    sides move differently) and the SAD / parabola half of Frame::ComputeStereoMatches (Frame.cc:921-987) is loaded as
+    on EuRoC-like frames (30-45 % and more)."""
+    rng = np.random.default_rng(seed)
+    fx = float(intrinsics(width, height)["fx"])
+    dmax = max(5, int(0.12 * fx))
+    wide = width + dmax + 1
+    bg = _background(rng, wide, height)
+    objs = _objects(rng, wide, height, fx, density)
+    base = _render(bg, objs, 0.0)
+    disp = np.sort(rng.integers(4, dmax + 1, planes))[::-1]  # nearer planes (larger disparity) at the bottom, like a floor
+    edges = np.linspace(0, height, planes + 1).astype(int)
+    left = base[:, :width].copy()
+    right = np.empty_like(left)
+    for i in range(planes):
+        d = int(disp[planes - 1 - i])
+        right[edges[i]:edges[i + 1]] = base[edges[i]:edges[i + 1], d:d + width]
+    return np.ascontiguousarray(_finish(rng, left)), np.ascontiguousarray(_finish(rng, right))
+
+
 def make_flat(width: int, height: int, value: int = 128) -> np.ndarray:
     """Featureless frame: exercises the empty-cell / zero-keypoint paths."""
     return np.full((height, width), value, np.uint8)

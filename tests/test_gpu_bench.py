@@ -24,6 +24,7 @@ def _run(args, env_extra=None, timeout=900):
 def test_bench_two_ranks_folded_onto_one_device():
     r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16", "--workload", "stereo_640x480_nf1000",
               "--no-cpu-baseline"], {"FT_BENCH_DEVICE_MOD": "1"})
+    assert r["workloads"] is None  # N = 1 only
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 3
     assert len(r["per_rank_frames_per_s"]) == 2 and min(r["per_rank_frames_per_s"]) > 0
     # whole-job value = frames of both ranks / max-over-ranks time: never above the sum of the per-rank rates
@@ -34,7 +35,8 @@ def test_bench_two_ranks_folded_onto_one_device():
 
 
 def test_bench_single_rank_line_has_the_contract_fields():
-    r = _run(["--steps", "3", "--warmup", "1", "--batch", "32", "--workload", "stereo_752x480_nf1200", "--no-cpu-baseline"])
+    r = _run(["--steps", "3", "--warmup", "1", "--batch", "32", "--workload", "stereo_752x480_nf1200", "--no-cpu-baseline",
+              "--workload-batch", "20", "--workload-frames", "6"])
     assert r["n_gpus"] == 1 and r["metric"] == "frames/sec extract+match" and r["unit"] == "frames/s"
     assert r["dtype"] == "u8" and r["vs_baseline"] is None and r["higher_is_better"] is True
     roof = r["roofline"]
@@ -42,3 +44,14 @@ def test_bench_single_rank_line_has_the_contract_fields():
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     assert r["config"]["distinct_pairs"] == 32
     assert 0 < r["host_in"]["value"] <= r["value"] * 1.05   # uploading inside the timed region cannot be faster
+    # the other north_star workloads ride on the same line (N = 1): 752x480 stereo, configs[3] tracking, dense and planes scenes
+    wl = r["workloads"]
+    assert set(wl) == {"stereo_752x480_nf1200", "tracking_512x512_nf2000", "dense_1280x720_nf2000", "planes_1280x720_nf2000"}
+    for k in ("stereo_752x480_nf1200", "dense_1280x720_nf2000", "planes_1280x720_nf2000"):
+        assert wl[k]["value"] > 0 and wl[k]["device_octree_fallbacks"] == 0 and wl[k]["keypoints_per_frame"] > 1000, k
+    assert wl["planes_1280x720_nf2000"]["stereo_match_fraction"] > 0.3 > r["stereo_match_fraction"] > 0
+    t = wl["tracking_512x512_nf2000"]
+    assert set(t["by_th"]) == {"7", "15"} and t["value"] == t["by_th"]["7"]["value"] > 0
+    for th in ("7", "15"):
+        assert t["by_th"][th]["map_points_per_s"] > 0 and t["by_th"][th]["hamming_compares_per_frame"] > 1000 and t["by_th"][th]["matches_per_frame"] > 50
+    assert t["by_th"]["15"]["hamming_compares_per_frame"] > t["by_th"]["7"]["hamming_compares_per_frame"]  # wider windows

@@ -359,6 +359,8 @@ def test_device_octree_tiers_on_directed_candidates(ctx, w, h, nf):
             sel = rng.integers(0, k, n)
             sd = (W / 40 if kind == 1 else W / 12)
             pts = np.stack([np.clip(rng.normal(cx[sel], sd), 3, W - 4), np.clip(rng.normal(cy[sel], sd * H / W), 3, H - 4)], 1).astype(np.int64)
+            # + a sparse background: it keeps the node list growing pass after pass, so the tree really goes deep
+            pts = np.concatenate([pts, np.stack([rng.integers(3, W - 3, 120), rng.integers(3, H - 3, 120)], 1)])
         else:
             pts = np.stack([rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)], 1)
         pts = np.unique(pts, axis=0)
@@ -388,14 +390,17 @@ def test_device_octree_tiers_on_directed_candidates(ctx, w, h, nf):
 
 
 def test_device_octree_histogram_gives_up_to_sorted_tier(ctx):
-    """a level whose quota is spent inside one small cluster: the tree grows deeper than the histogram's table, k_octree_hist
-    gives up and hands the level to k_octree_big; with that tier not allowed the level is left to the host"""
+    """a level whose quota is spent inside one small cluster (a sparse background keeps the list growing pass after pass -
+    a cluster alone ends the reference's loop early through `lNodes.size() == prevSize`, ORBextractor.cc:797): the tree grows
+    deeper than the histogram's table, k_octree_hist gives up and hands the level to k_octree_big; with that tier not allowed
+    the level is left to the host"""
     w, h, nf = 1280, 720, 2000
     ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=1)
     W, H = w - 32, h - 32
     rng = np.random.default_rng(11)
     ys, xs = np.mgrid[200:290, 300:390]  # 8 100 candidates in a 90 x 90 px block
-    pts = np.stack([xs.ravel(), ys.ravel()], 1)
+    bg = np.stack([rng.integers(3, W - 3, 150), rng.integers(3, H - 3, 150)], 1)
+    pts = np.unique(np.concatenate([np.stack([xs.ravel(), ys.ravel()], 1), bg]), axis=0)
     quota = ex.features_per_level()[0]
     lw, lh, q, nc, nr, wc, hc = [np.zeros(8, np.int32) for _ in range(7)]
     from fasttrack_amd import _capi

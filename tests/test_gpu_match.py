@@ -560,13 +560,14 @@ def test_fisheye_stereo_with_triangulation(ctx):
 
 
 def test_full_size_batch_properties(ctx):
-    """BASELINE.json's full configuration (1280x720 stereo, nFeatures 2000, 256 pairs per batch = two sub-batches of
-    the device-octree pipeline, two batches in flight):
+    """BASELINE.json's full configuration in bench.py's own launch shape (1280x720 stereo, nFeatures 2000, 512 pairs per
+    batch = two sub-batches of 256 pairs of the device-octree pipeline, i.e. 256 images per kernel launch and camera, two
+    batches in flight):
     too large for the oracle in a test, so it is checked through properties - repeated pairs give identical results
     wherever they sit in the batch and in whichever front end, a sample of pairs equals the oracle bit for bit,
     every depth is mbf / disparity, keypoints respect the border and the per-level quotas."""
     import ctypes as C
-    w, h, nf, B, D = 1280, 720, 2000, 256, 8
+    w, h, nf, B, D = 1280, 720, 2000, 512, 8
     intr = synth.intrinsics(w, h)
     fes = [orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"]) for _ in range(2)]
     pairs = [synth.make_stereo_pair(w, h, seed=900 + i) for i in range(D)]

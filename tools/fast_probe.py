@@ -7,7 +7,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from fasttrack_amd import orb, synth
 ctx = orb.Context(0)
 w, h, B = 1280, 720, 256
-base = [synth.make_image(w, h, seed=s) for s in range(8)]
+mosaic = int(os.environ.get("FP_MOSAIC", "0"))  # dense-corner frames instead (bench.py --mosaic)
+base = [synth.make_mosaic_pair(w, h, seed=s, block=mosaic)[0] if mosaic else synth.make_image(w, h, seed=s) for s in range(8)]
 arr = np.stack([np.roll(base[b % 8], (29 * (b // 8), 53 * (b // 8)), (0, 1)) for b in range(B)])
 dev = ctx.to_device(arr)
 ex = orb.ORBextractor(ctx, 2000, 1.2, 8, 20, 7, w, h, max_batch=B)
@@ -19,4 +20,4 @@ for _ in range(5): ex.extract_batch(imgs, on_device=True, width=w, height=h, str
 out = {}
 for k in ("kernel.pyr_down(all levels)", "kernel.fast_cells", "kernel.compact", "kernel.octree", "kernel.orient_desc"):
     ms, n = ctx.get_stat(k); out[k] = round(ms / max(n, 1), 4)
-print(os.environ.get("FT_FAST_DBG", "0"), out)
+print(os.environ.get("FT_FAST_DBG", "0"), "mosaic", mosaic, out)
