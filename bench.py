@@ -402,7 +402,25 @@ def main():
     host_threads = args.host_threads or max(1, usable_cpus() // max(world, 1))
     # one device per rank; FT_BENCH_DEVICE_MOD=<n> folds the ranks onto n devices (plumbing check on a smaller box)
     ndev_mod = int(os.environ.get("FT_BENCH_DEVICE_MOD", "0"))
-    ctx = orb.Context(local_rank % ndev_mod if ndev_mod > 0 else local_rank, host_threads)
+    device = local_rank % ndev_mod if ndev_mod > 0 else local_rank
+    # host threads next to the GPU: the rank pins itself to the NUMA node its device hangs off (ranks that share a node share
+    # its CPUs evenly) before the context creates its thread pool; FT_BENCH_NUMA=0 leaves the affinity alone
+    numa = {"node": -1, "cpus": None}
+    if world > 1 and os.environ.get("FT_BENCH_NUMA", "1") != "0":
+        import ctypes as _C
+        from fasttrack_amd import _capi
+        ndev = max(_capi.lib().ft_device_count(), 1)
+        nodes = []
+        for d in range(ndev):
+            buf = _C.create_string_buffer(64)
+            nodes.append(shard.numa_node_of_pci(buf.value.decode()) if _capi.lib().ft_device_pci_bus_id(d, buf, 64) == 0 else -1)
+        numa["node"] = nodes[device] if device < len(nodes) else -1
+        peers = [r for r in range(world) if nodes[(r % ndev_mod if ndev_mod > 0 else r) % ndev] == numa["node"]]
+        cpus = shard.pin_to_numa_node(numa["node"], len(peers), peers.index(local_rank) if local_rank in peers else 0)
+        numa["cpus"] = len(cpus) if cpus else None
+        if cpus and not args.host_threads:
+            host_threads = max(1, min(host_threads, len(cpus)))
+    ctx = orb.Context(device, host_threads)
     intr = synth.intrinsics(w, h)
     # two front ends used alternately: while one batch drains (last descriptors, matching, result copies) the
     # next batch's pyramid / FAST / octree already run (ft_stereo_frontend_submit / _wait)
@@ -565,7 +583,8 @@ def main():
                        "inputs": "resident in HBM before the timed region (host_in: pinned host memory, uploaded inside it)",
                        "batches_in_flight": len(fes),
                        "parallelism": f"{world} independent stream(s), one per GPU, no collective",
-                       "host_threads_per_gpu": ctx.host_threads, "device": ctx.device_name},
+                       "host_threads_per_gpu": ctx.host_threads, "device": ctx.device_name, "hw_queues": ctx.hw_queues,
+                       "numa_node_of_rank0": numa["node"], "cpus_pinned_rank0": numa["cpus"]},
             "per_rank_frames_per_s": rank_fps,
             "keypoints_per_s": kps * args.steps / elapsed,
             "keypoints_per_frame": kps / (B * world),

@@ -12,7 +12,8 @@ import re
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libfasttrack_amd.so")
+# FT_LIB: another build of the library (A/B measurements of compile-time variants, tools/ab_build.sh); never set in tests
+LIB_PATH = os.environ.get("FT_LIB") or os.path.join(_PKG, "libfasttrack_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "fasttrack_amd.h")
 
 FT_OK, FT_ERR_INVALID, FT_ERR_NO_DEVICE, FT_ERR_HIP, FT_ERR_CAPACITY, FT_ERR_EMPTY = 0, -1, -2, -3, -4, -5
@@ -101,6 +102,7 @@ def lib() -> C.CDLL:
     L.ft_version.restype = C.c_char_p
     L.ft_last_error.restype = C.c_char_p
     L.ft_device_count.restype = i
+    L.ft_device_pci_bus_id.argtypes = [i, C.c_char_p, i]
     L.ft_context_create.argtypes = [i, i, C.POINTER(vp)]
     L.ft_context_destroy.argtypes = [vp]
     L.ft_context_synchronize.argtypes = [vp]

@@ -155,6 +155,17 @@ int ft_device_count(void) {
     return n;
 }
 
+// "0000:c1:00.0" of a HIP device: the key to /sys/bus/pci/devices/<id>/numa_node, by which a rank pins its host
+// threads next to its GPU before it creates the context (fasttrack_amd/shard.py)
+int ft_device_pci_bus_id(int device, char *buf, int len) {
+    if (!buf || len < 16) {
+        ft_set_error("ft_device_pci_bus_id: buffer too small");
+        return FT_ERR_INVALID;
+    }
+    FT_HIP(hipDeviceGetPCIBusId(buf, len, device));
+    return FT_OK;
+}
+
 int ft_context_create(int device, int host_threads, ft_context **out) {
     if (!out) {
         ft_set_error("ft_context_create: out is null");
@@ -197,6 +208,11 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
     ft_context *ctx = new ft_context();
     ctx->device = device;
     ctx->deviceName = std::string(prop.name[0] ? prop.name : "AMD GPU") + " (" + prop.gcnArchName + ")";
+    {
+        int mp = 0;
+        if (hipDeviceGetAttribute(&mp, hipDeviceAttributeMaxPitch, device) == hipSuccess && mp > 0) ctx->maxPitch = (size_t)mp;
+        else (void)hipGetLastError();
+    }
     if (host_threads <= 0) host_threads = ft_usable_cpus();
     if (host_threads < 1) host_threads = 1;
     ctx->pool = new ft::ThreadPool(host_threads - 1);

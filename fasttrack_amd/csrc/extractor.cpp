@@ -3,6 +3,7 @@
 // the reference's CPU branch does (float arithmetic, cvRound = half-to-even); pixels are only ever
 // touched by the HIP kernels in kernels_extract.hip.  Compiled with -ffp-contract=off.
 #include <algorithm>
+#include <map>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -215,6 +216,7 @@ void freeAll(ft_extractor *ex) {
     hipHostFree(ex->h_histStat);
     hipFree(ex->d_bigList);
     hipFree(ex->d_sortList);
+    if (ex->h_repCand) hipHostFree(ex->h_repCand);
     hipFree(ex->d_candDev);
     hipFree(ex->d_candCountDev);
     hipHostFree(ex->h_selCount);
@@ -308,9 +310,16 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
         if (delta < (ptrdiff_t)width * height) oneCopy = false;
         for (int b = 1; b < batch && oneCopy; b++)
             if (!images[b] || images[b] - images[b - 1] != delta) oneCopy = false;
+        // the distance between frames is the copy's source pitch: beyond what the device takes as a pitch (or when the
+        // runtime refuses the copy for any other reason) the frames go up one by one, as frames at irregular distances do
+        if (oneCopy && ex->ctx->maxPitch > 0 && (size_t)delta > ex->ctx->maxPitch) oneCopy = false;
         if (oneCopy) {
-            FT_HIP(hipMemcpy2DAsync(ex->d_pyr + g.lv[0].off, g.pyrPerSlot, images[0], (size_t)delta, (size_t)width * height, batch,
-                                    hipMemcpyHostToDevice, us));
+            const hipError_t ce = hipMemcpy2DAsync(ex->d_pyr + g.lv[0].off, g.pyrPerSlot, images[0], (size_t)delta, (size_t)width * height,
+                                                   batch, hipMemcpyHostToDevice, us);
+            if (ce != hipSuccess) {
+                (void)hipGetLastError();
+                oneCopy = false;
+            }
         }
     }
     for (int b = 0; b < batch; b++) {
@@ -459,15 +468,18 @@ int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent
     a.selCount = ex->d_selCount + (size_t)b0 * g.nlevels;
     a.overflow = ex->d_overflow;
     a.ovSlot = ex->d_ovSlot + b0;
-    // Levels with more than FT_OCT_MAXN candidates.  Large batches always launch the histogram tier, with a list for every
-    // level of the launch and a grid sized by what the previous batches asked for (FT_OCT_HISTMIN workgroups while they asked
-    // for nothing: its workgroups walk the list, so a first dense batch is slow on the device instead of repaired on the
-    // host); small (latency-mode) batches only since a frame needed it (a kernel node more in the captured graph).  The
-    // sorted big tier wants a CU's whole LDS per workgroup and is not free even when idle: the grid the previous batches'
-    // give-ups asked for.
-    const bool histNow = ex->histEnabled && (nb > 16 || ex->lastBatch > 16 || ex->histOn);
+    // Levels with more than FT_OCT_MAXN candidates go to the histogram tier.  A kernel more behind k_octree costs the
+    // headline workload 1.2 % even when its 16 workgroups find nothing to do (A/B, 3 x 96 steps: 74.1 against 75.0 k frames/s:
+    // one more launch in the chain of the octree lane), so the tier follows the demand: launched for the first batches of an
+    // extractor and while the frames ask for it, with a grid sized by what the previous batches listed (its workgroups walk
+    // the list), retired after FT_OCT_HIST_RETIRE batches without a listed level.  A dense frame that arrives while it is
+    // retired is repaired on the host - that frame only, once - and brings the tier back for the next batch (the demand is
+    // counted either way).  Small (latency-mode) batches: since a frame needed it (a kernel node more in the captured graph).
+    const bool large = nb > 16 || ex->lastBatch > 16;
+    const bool histNow = ex->histEnabled && (large ? ex->histGrid > 0 : ex->histOn);
     a.histCap = histNow ? nb * g.nlevels : 0;
-    a.histGrid = ex->lastBatch > 16 ? std::min(ex->histGrid, nb * g.nlevels) : nb * g.nlevels;
+    a.histGrid = large ? std::min(ex->histGrid, nb * g.nlevels) : nb * g.nlevels;
+    a.histWanted = ex->histEnabled && !histNow ? 1 : 0;
     a.sortCap = a.bigN ? std::min(ex->bigGrid, nb * g.nlevels) : 0;
     // one set of lists and counters per octree stream: the launches of two sub-batches run side by side
     a.bigCount = ex->d_bigCount + 4 * (sub % FT_OCT_STREAMS);
@@ -550,9 +562,9 @@ void ft_extract_update_big_grid(ft_extractor *ex) {
     }
     if (wantHist > 0) {  // a workgroup per listed level up to FT_OCT_HISTMAX (beyond that they walk the list)
         ex->histIdle = 0;
-        ex->histGrid = std::max(ex->histGrid, std::min(FT_OCT_HISTMAX, ((wantHist + 63) / 64) * 64));
-    } else if (ex->histGrid > FT_OCT_HISTMIN && ++ex->histIdle >= 16) {
-        ex->histGrid = FT_OCT_HISTMIN;
+        ex->histGrid = std::max(std::max(ex->histGrid, FT_OCT_HISTMIN), std::min(FT_OCT_HISTMAX, ((wantHist + 63) / 64) * 64));
+    } else if (ex->histGrid > 0 && ++ex->histIdle >= FT_OCT_HIST_RETIRE) {
+        ex->histGrid = 0;  // retired until a frame asks for it again
     }
     if (!ex->octLayout.bigN) return;
     if (want > 0) {
@@ -587,18 +599,37 @@ int ft_extract_repair_prepare(const std::vector<std::pair<ft_extractor *, int>> 
     ft_extractor *e0 = jobs[0].first;
     const FtGeom &g = e0->geom;
     const int L = g.nlevels;
-    for (auto &j : jobs) {
-        ft_extractor *ex = j.first;
-        const int slot = j.second;
-        const int rce = ft_extract_ensure_host_cand(ex);
-        if (rce != FT_OK) return rce;
-        FT_HIP(hipMemcpy(ex->h_candCount + (size_t)slot * L, ex->d_candCountDev + (size_t)slot * L, sizeof(int) * L, hipMemcpyDeviceToHost));
+    // The candidate lists of the slots under repair come back into a pinned buffer of the extractor that holds just those
+    // slots (grow-only, indexed by job) - not into the host-octree pipeline's array for ALL slots (max_batch x candPerSlot:
+    // 1.4 GB of pinned memory for 512 slots, whose allocation in the middle of the pipeline stalled the other front end's
+    // batch and turned a recoverable overflow into a hard error when it failed).
+    std::vector<int> jobIdx(jobs.size());
+    {
+        std::map<ft_extractor *, int> perEx;
+        for (size_t j = 0; j < jobs.size(); j++) jobIdx[j] = perEx[jobs[j].first]++;
+        for (auto &kv : perEx) {
+            ft_extractor *ex = kv.first;
+            if (kv.second > ex->repCap) {
+                if (ex->h_repCand) hipHostFree(ex->h_repCand);
+                ex->h_repCand = nullptr;
+                ex->repCap = 0;
+                const int want = std::min(ex->maxBatch, std::max(kv.second + kv.second / 2, 4));
+                FT_HIP(hipHostMalloc((void **)&ex->h_repCand, (size_t)want * g.candPerSlot * sizeof(uint32_t), hipHostMallocDefault));
+                ex->repCap = want;
+            }
+        }
+    }
+    std::vector<int> counts(jobs.size() * L, 0);
+    for (size_t j = 0; j < jobs.size(); j++) {
+        ft_extractor *ex = jobs[j].first;
+        const int slot = jobs[j].second;
+        FT_HIP(hipMemcpy(counts.data() + j * L, ex->d_candCountDev + (size_t)slot * L, sizeof(int) * L, hipMemcpyDeviceToHost));
         for (int l = 0; l < L; l++) {
             const FtLevelGeom &v = g.lv[l];
-            int &n = ex->h_candCount[(size_t)slot * L + l];
-            n = std::min(n, v.candCap);
+            int &n = counts[j * L + l];
+            n = std::max(0, std::min(n, v.candCap));
             if (n > 0)
-                FT_HIP(hipMemcpyAsync(ex->h_cand + (size_t)slot * g.candPerSlot + v.candBase,
+                FT_HIP(hipMemcpyAsync(ex->h_repCand + (size_t)jobIdx[j] * g.candPerSlot + v.candBase,
                                       ex->d_candDev + (size_t)slot * g.candPerSlot + v.candBase, sizeof(uint32_t) * n,
                                       hipMemcpyDeviceToHost, ex->streamB));
         }
@@ -607,18 +638,19 @@ int ft_extract_repair_prepare(const std::vector<std::pair<ft_extractor *, int>> 
     auto task = [&](int t, int) {
         static thread_local ft::OctreeWorkspace ws;
         static thread_local std::vector<int> keep;
-        ft_extractor *ex = jobs[t / L].first;
-        const int slot = jobs[t / L].second, level = t % L;
+        const int j = t / L, level = t % L;
+        ft_extractor *ex = jobs[j].first;
+        const int slot = jobs[j].second;
         const FtLevelGeom &v = g.lv[level];
-        const int n = ex->h_candCount[(size_t)slot * L + level];
-        uint32_t *cand = ex->h_cand + (size_t)slot * g.candPerSlot + v.candBase;
+        const int n = counts[(size_t)j * L + level];
+        uint32_t *cand = ex->h_repCand + (size_t)jobIdx[j] * g.candPerSlot + v.candBase;
         auto rank = [&](uint32_t q) -> uint64_t {
             const int x = (int)(q & 0xfffu) - 3, y = (int)((q >> 12) & 0xfffu) - 3;
             const int cj = std::min(x / std::max(v.wCell, 1), std::max(v.nCols - 1, 0));
             const int ci = std::min(y / std::max(v.hCell, 1), std::max(v.nRows - 1, 0));
             return ((uint64_t)ci << 48) | ((uint64_t)cj << 32) | ((uint64_t)y << 16) | (uint64_t)x;
         };
-        std::sort(cand, cand + std::max(n, 0), [&](uint32_t a, uint32_t b) { return rank(a) < rank(b); });
+        std::sort(cand, cand + n, [&](uint32_t a, uint32_t b) { return rank(a) < rank(b); });
         keep.clear();
         const int minB = FT_EDGE_THRESHOLD - 3;
         int k = ft::distribute_octree(cand, n, minB, v.maxBX, minB, v.maxBY, ex->quota[level], ws, keep);
@@ -901,7 +933,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         // the node pools must fit a CU's LDS beside FT_OCT_MAXN keys (per-level quotas up to ~1900); u16 node indices
         (void)maxQ;
         ex->deviceOctree = !(e && e[0] == '0') && o.poolCap < 30000 && ft_octree_smem_bytes(o.poolCap) <= 160 * 1024;
-        o.histCap = o.sortCap = 0;
+        o.histCap = o.sortCap = o.histGrid = o.histWanted = 0;
         ex->histEnabled = ex->deviceOctree && !(getenv("FT_OCT_HIST") && atoi(getenv("FT_OCT_HIST")) == 0) &&
                           ft_octree_hist_smem_bytes(o.poolCap) <= 160 * 1024;
         o.bigN = ex->deviceOctree && !(getenv("FT_OCT_BIG") && atoi(getenv("FT_OCT_BIG")) == 0) ? ft_octree_big_keys(o.poolCap) : 0;
@@ -1375,6 +1407,7 @@ int ft_extractor_octree_on_device(ft_extractor *ex, int level, const int *xys, i
     a.ovSlot = ex->d_ovSlot;
     a.histCap = (tiers & 2) && ex->histEnabled ? g.nlevels : 0;
     a.histGrid = g.nlevels;
+    a.histWanted = 0;
     a.sortCap = (tiers & 4) && a.bigN ? g.nlevels : 0;
     a.bigCount = ex->d_bigCount;
     a.bigList = ex->d_bigList;

@@ -39,6 +39,7 @@ struct ft_context {
     hipStream_t uploadStream = nullptr;  // host frames of whole batches go up here (copies only)
     std::vector<int> laneMap;  // [extractor k mod sets][role] -> lane; empty: private streams
     int nextLaneSet = 0;
+    size_t maxPitch = 0;                // hipDeviceAttributeMaxPitch (0 = unknown): bound of the one-copy upload's source pitch
     int hwQueues = 4;                   // GPU_MAX_HW_QUEUES of the process environment when the context was created (4 = unset)
     std::atomic<int> liveObjects{0};    // extractors (incl. those of front ends) alive on this context: they hold its lanes
     // grow-only scratch of the stand-alone matchers (one call at a time per context)
@@ -165,6 +166,8 @@ struct ft_extractor {
     int *h_bigStat = nullptr;        // pinned copies of the sorted big tier's demand ([3])
     unsigned *d_bigList = nullptr;   // per octree stream [maxBatch * nlevels] (slot, level) pairs for the histogram tier
     unsigned *d_sortList = nullptr;  // ... and the pairs that tier handed on to k_octree_big
+    uint32_t *h_repCand = nullptr;   // pinned candidate lists of the slots under per-image repair (repCap slots, grow-only)
+    int repCap = 0;
     bool histEnabled = false;        // k_octree_hist available (FT_OCT_HIST=0 switches it off)
     bool histOn = false;             // latency mode: launched since a frame overflowed the first tier (large batches: always)
     int histGrid = FT_OCT_HISTMIN;   // workgroups of k_octree_hist for large batches: by the demand of the previous ones

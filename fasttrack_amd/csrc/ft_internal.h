@@ -119,6 +119,7 @@ struct FtTap {
 #define FT_OCT_MAXN 4096
 #define FT_OCT_HIST_BINS 8192  // bins of the histogram tier (k_octree_hist): nodes of depth D, nIni * 4^D <= this
 #define FT_OCT_HISTMIN 16      // workgroups of the histogram tier while no batch has asked for more (each walks the list)
+#define FT_OCT_HIST_RETIRE 2   // batches without a listed level after which the histogram tier is not launched any more
 #define FT_OCT_HISTMAX 512     // ... and at most (two or three fit a CU)
 #define FT_OCT_BIGMIN 64   // smallest grid of the sorted big tier (k_octree_big) once a stream of frames needs it
 struct FtOctArgs {
@@ -136,6 +137,7 @@ struct FtOctArgs {
     int *bigCount;
     unsigned *bigList, *sortList;
     int histCap, histGrid, sortCap, bigN;  // histGrid: workgroups of k_octree_hist (they walk the list)
+    int histWanted;                        // the histogram tier exists but is not launched now: count its demand all the same
     int quota[FT_MAX_LEVELS], levelMax[FT_MAX_LEVELS], selOff[FT_MAX_LEVELS];
     int poolCap, keyBytes;
     unsigned long long *prof;  // FT_OCT_PROFILE=1: per-level phase times of slot 0 (wall_clock64 ticks), else null

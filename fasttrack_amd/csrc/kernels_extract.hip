@@ -683,8 +683,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *cons
                 const int cA = cand[jA], cB = cand[min(jB, nc - 1)];
                 const int yA = pixY(cA), xA = pixX(cA, yA), yB = pixY(cB), xB = pixX(cB, yB);
                 const uint8_t *wA = t0 + yA * tp + xA, *wB = t0 + yB * tp + xB;
-                const unsigned v2 = (unsigned)wA[3 * tp + 3] | ((unsigned)wB[3 * tp + 3] << 16);
+                unsigned v2;
                 unsigned ring2[16];
+                // (Tried, round 3: the 7 x 7 window as seven unaligned ds_read_b64 / _b32 per candidate + v_perm_b32 - 14 LDS
+                // instructions per round instead of 34 - is correct and TWICE as slow, 0.63 against 0.34 ms per launch of 128
+                // frames: unaligned LDS accesses are replayed.  ds_read_u8 + ds_read_u8_d16_hi into one register, to save the 17
+                // packing instructions: gfx950 runs with SRAM ECC, where a d16 load writes the whole register - wrong results.)
+                v2 = (unsigned)wA[3 * tp + 3] | ((unsigned)wB[3 * tp + 3] << 16);
 #define FT_LD2(k, ox, oy) ring2[k] = (unsigned)wA[((oy) + 3) * tp + (ox) + 3] | ((unsigned)wB[((oy) + 3) * tp + (ox) + 3] << 16);
                 FT_RING(FT_LD2)
 #undef FT_LD2
@@ -1366,6 +1371,9 @@ __global__ __launch_bounds__(256) void k_compact(FtGeom g, const int *cellCount,
 #define OD_HB_BYTES (OD_LAYOUT ? OD_HP * OD_RP * 2 + 16 : OD_P * OD_HP * 2)  // 3536 / 3440
 #define OD_WAVE_BYTES ((OD_RAW_BYTES + OD_HB_BYTES + 15) & ~15)
 #define OD_WAVES 4
+#ifndef OD_KPW
+#define OD_KPW 2                // keypoints per wave: loads of all of them in flight before the first is processed
+#endif
 
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (i < 0) i = -i;
@@ -1477,56 +1485,84 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     const int wave = wave_index();
     int slot, blk;
     if (!ft_slot_block(sg, slot, blk)) return;
-    const int k = blk * OD_WAVES + wave;
+    // OD_KPW keypoints per wave, one after the other through the same LDS buffers - with the LOADS of all of them issued up
+    // front: level lookup, selection entries, image pointers and the nine patch dwords per lane of every keypoint are
+    // requested before the first one is processed, so the dependent chain selCount -> sel entry -> image pointer -> patch
+    // (three to four memory round trips) is paid once per OD_KPW keypoints and the later patches arrive behind the
+    // arithmetic of the earlier ones (SQ counters of round 2: the waves of this kernel waited 42 % of their time, 26 % active).
+    // Only the loaded dwords are kept (9 registers per extra keypoint) - no tables are hoisted across keypoints, which is what
+    // cost the four-keypoints-per-wave variant of round 2 its occupancy.
+    const int kFirst = (blk * OD_WAVES + wave) * OD_KPW;
     // the octree leaves its result per level; keypoint k of the image (level order) is entry k - prefix of
     // the level that contains it
     // Lane l holds the count of level l (one vector load), a DPP scan over the row of 16 lanes turns the counts into
     // inclusive prefixes, and the level of keypoint k is the first lane whose prefix exceeds k (one ballot): a dozen
     // instructions where the scalar unit used to walk the FT_MAX_LEVELS levels one by one (150 scalar instructions per wave -
     // and the CU's four SIMDs share one scalar unit).
-    int selLevel = -1, prefix = 0, total = 0;
-    {
-        const int c = lane < g.nlevels ? selCount[slot * g.nlevels + lane] : 0;
-        int incl = c;
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);  // row_shr:1 (lanes shifted in from outside the row read 0)
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);  // row_shr:2
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);  // row_shr:4
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr:8
-        total = __builtin_amdgcn_readlane(incl, 15);
-        const unsigned below = (unsigned)__builtin_amdgcn_ballot_w64(k < incl) & 0xffffu;
-        if (below) {
-            selLevel = __builtin_ctz(below);
-            prefix = __builtin_amdgcn_readlane(incl - c, selLevel);
-        }
-    }
-    if (k == 0 && lane == 0) nSel[slot] = total;
-    if (selLevel < 0) return;  // k >= total; waves are independent: no workgroup barrier below
+    int total = 0;
+    const int cnt = lane < g.nlevels ? selCount[slot * g.nlevels + lane] : 0;
+    int incl = cnt;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);  // row_shr:1 (lanes shifted in from outside the row read 0)
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);  // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);  // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr:8
+    total = __builtin_amdgcn_readlane(incl, 15);
+    if (kFirst == 0 && lane == 0) nSel[slot] = total;
+    if (kFirst >= total) return;  // waves are independent: no workgroup barrier below
+    const int nKp = min(OD_KPW, total - kFirst);
     uint8_t *raw = smem + (size_t)wave * OD_WAVE_BYTES;
     unsigned short *hb = (unsigned short *)(raw + OD_RAW_BYTES);
-    const FtSelKp s = sel[(size_t)slot * g.maxKp + lay.selOff[selLevel] + (k - prefix)];
+    // per keypoint of the wave: the selection entry and what the patch load needs (all wave-uniform)
+    FtSelKp sk[OD_KPW];
+    const uint8_t *imgK[OD_KPW];
+    int pitchK[OD_KPW];
+    bool interiorK[OD_KPW];
+    unsigned pv[OD_KPW][9];
+    const int rrL = (lane * 43) >> 9, ccL = lane - rrL * 12;  // lane / 12 for lane < 64
+#pragma unroll
+    for (int q = 0; q < OD_KPW; q++) {
+        const int kk = min(kFirst + q, total - 1);  // (a keypoint beyond the last repeats it; its loads are harmless, it is not processed)
+        const unsigned below = (unsigned)__builtin_amdgcn_ballot_w64(kk < incl) & 0xffffu;
+        const int selLevel = __builtin_ctz(below | 0x8000u);
+        const int prefix = __builtin_amdgcn_readlane(incl - cnt, selLevel);
+        sk[q] = sel[(size_t)slot * g.maxKp + lay.selOff[selLevel] + (kk - prefix)];
+    }
+#pragma unroll
+    for (int q = 0; q < OD_KPW; q++) {
+        const int level = sk[q].level;
+        imgK[q] = level_ptr(g, level, slot, l0, l0pitch, pyr, pitchK[q]);
+        const int px0 = sk[q].x - OD_R, py0 = sk[q].y - OD_R;
+        const int axq = px0 & 3;
+        interiorK[q] = alignedLoads && px0 >= 0 && py0 >= 0 && py0 + OD_P <= g.lv[level].h && (px0 - axq) + OD_PP <= g.lv[level].w;
+        if (interiorK[q] && lane < 60) {
+            // 43 rows x 12 aligned dwords: coalesced 4-byte lanes, pixel (r, c) lands at raw[r*48 + ax + c].  Five rows
+            // per step on lanes 0-59 with a fixed (row, dword) per lane, so a step is one load and one LDS store with
+            // immediate offsets; all nine row groups are requested before the first LDS store
+            const uint8_t *src = imgK[q] + (size_t)py0 * pitchK[q] + (px0 - axq);
+            const unsigned laneOff = (unsigned)(rrL * pitchK[q] + 4 * ccL);
+#pragma unroll
+            for (int it = 0; it < 9; it++)
+                pv[q][it] = (it < 8 || rrL < 3) ? gload<unsigned>(src + (laneOff + (unsigned)(it * 5 * pitchK[q]))) : 0u;  // scalar base + 32-bit lane offset
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < OD_KPW; q++) {
+    if (q >= nKp) break;  // wave-uniform
+    const int k = kFirst + q;
+    const FtSelKp s = sk[q];
     const int cx = s.x, cy = s.y, level = s.level, response = s.response;
-    int pitch;
-    const uint8_t *img = level_ptr(g, level, slot, l0, l0pitch, pyr, pitch);
+    const int pitch = pitchK[q];
+    const uint8_t *img = imgK[q];
     const int w = g.lv[level].w, h = g.lv[level].h;
     const int px0 = cx - OD_R, py0 = cy - OD_R;
     int ax = px0 & 3;
-    const bool interior = alignedLoads && px0 >= 0 && py0 >= 0 && py0 + OD_P <= h && (px0 - ax) + OD_PP <= w;
-    if (interior) {
-        // 43 rows x 12 aligned dwords: coalesced 4-byte lanes, pixel (r, c) lands at raw[r*48 + ax + c].  Five rows
-        // per step on lanes 0-59 with a fixed (row, dword) per lane, so a step is one load and one LDS store with
-        // immediate offsets.
-        const uint8_t *src = img + (size_t)py0 * pitch + (px0 - ax);
-        const int rr = (lane * 43) >> 9, cc = lane - rr * 12;  // lane / 12 for lane < 64
-        const unsigned laneOff = (unsigned)(rr * pitch + 4 * cc);
-        unsigned *rawLane = (unsigned *)raw + rr * 12 + cc;
+    if (q > 0) wave_lds_sync();  // the previous keypoint's reads of the buffers are done
+    if (interiorK[q]) {
+        unsigned *rawLane = (unsigned *)raw + rrL * 12 + ccL;
         if (lane < 60) {
-            unsigned v[9];  // all nine row groups requested before the first LDS store
 #pragma unroll
             for (int it = 0; it < 9; it++)
-                v[it] = (it < 8 || rr < 3) ? gload<unsigned>(src + (laneOff + (unsigned)(it * 5 * pitch))) : 0u;  // scalar base + 32-bit lane offset
-#pragma unroll
-            for (int it = 0; it < 9; it++)
-                if (it < 8 || rr < 3) rawLane[it * 60] = v[it];
+                if (it < 8 || rrL < 3) rawLane[it * 60] = pv[q][it];
         }
     } else {
         // BORDER_REFLECT_101 of the blur at the level's edges (keypoints are >= 19 px inside, the
@@ -1672,6 +1708,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
         d[2] = words[2];
         d[3] = words[3];
     }
+    }  // keypoints of the wave
 }
 
 }  // namespace
@@ -1837,7 +1874,7 @@ int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint
                           const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *selCount,
                           const FtOctArgs &layout, int *nSel, ft_keypoint *keys, uint8_t *desc) {
     dim3 grid, block(64 * OD_WAVES, 1, 1);
-    const FtSlotGrid sg = ft_slot_grid((g.maxKp + OD_WAVES - 1) / OD_WAVES, batch, grid);
+    const FtSlotGrid sg = ft_slot_grid((g.maxKp + OD_WAVES * OD_KPW - 1) / (OD_WAVES * OD_KPW), batch, grid);
     const size_t smem = OD_WAVES * (size_t)OD_WAVE_BYTES;
     for (int rep = ft_debug_repeat("orient"); rep > 0; rep--)
     hipLaunchKernelGGL(k_orient_desc, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, selCount, layout,

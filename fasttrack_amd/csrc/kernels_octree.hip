@@ -325,12 +325,14 @@ __device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, c
         return true;
     };
     if constexpr (!HIST) {
-        if (n > maxN && keyFits && (a.histCap > 0 || maxN < a.bigN)) {
+        if (n > maxN && keyFits && (a.histCap > 0 || a.histWanted || maxN < a.bigN)) {
             // more candidates than this launch sorts in LDS: the level goes on the list of the histogram tier (or, with that
             // tier switched off, of k_octree_big while it has room for the keys), which runs behind this kernel
             if (tid == 0) {
                 bool ok;
-                if (a.histCap > 0 && n <= 65535) ok = hand_on(a.bigCount, a.bigList, a.histCap);
+                // (with the histogram tier retired for lack of demand - histCap 0, histWanted set - the level still counts as
+                // demand, so that the host brings the tier back for the next batch; this one is repaired on the host)
+                if ((a.histCap > 0 || a.histWanted) && n <= 65535) ok = hand_on(a.bigCount, a.bigList, a.histCap);
                 else if (n <= a.bigN) ok = hand_on(a.bigCount + 1, a.sortList, a.sortCap);
                 else ok = false;
                 if (!ok) {

@@ -24,6 +24,48 @@ def init(rank: int, world: int):
     return dist
 
 
+def parse_cpulist(text: str):
+    """'0-63,128-191' -> sorted list of CPU numbers (the format of /sys/devices/system/node/node*/cpulist)"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return sorted(set(cpus))
+
+
+def numa_node_of_pci(bus_id: str, sysfs: str = "/sys") -> int:
+    """NUMA node of a PCI device, -1 when the platform does not say"""
+    try:
+        return int(open(os.path.join(sysfs, "bus/pci/devices", bus_id.lower(), "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def pin_to_numa_node(node: int, world: int = 1, slot: int = 0, sysfs: str = "/sys"):
+    """Restricts this process (and the threads it starts later: the library's host pool) to the CPUs of `node` that its
+    current affinity allows; with several ranks on one node (`world` of them, this one the `slot`-th) every rank takes an
+    equal share of those CPUs.  Returns the CPUs chosen, or None when nothing was changed (node unknown, no CPU of the node
+    allowed, platform without sched_setaffinity).  On an 8 x MI355X box the GPUs hang off two sockets: a rank whose threads
+    marshal frames on the other socket pays the inter-socket hop for every upload."""
+    if node < 0 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cpus = parse_cpulist(open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")).read())
+    except OSError:
+        return None
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+    if not allowed:
+        return None
+    if world > 1:
+        share = max(1, len(allowed) // world)
+        mine = allowed[slot * share:(slot + 1) * share] if slot < world - 1 else allowed[slot * share:]
+        allowed = mine or allowed
+    os.sched_setaffinity(0, allowed)
+    return allowed
+
+
 def stream_seeds(rank: int, n: int):
     """Seeds of the synthetic frames of this rank's stream: disjoint across ranks."""
     return [1000 * rank + i for i in range(n)]

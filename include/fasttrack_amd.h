@@ -54,6 +54,10 @@ typedef struct ft_context ft_context;
 FT_API const char *ft_version(void);
 FT_API const char *ft_last_error(void);
 FT_API int ft_device_count(void); /* number of HIP devices, 0 if none (never fails) */
+/* PCI bus id ("0000:c1:00.0") of a device: /sys/bus/pci/devices/<id>/numa_node names the host memory node next to it, so a
+ * process that serves one GPU (reference: one KernelController per process, src/Kernels/KernelController.cu:24-29) can pin
+ * its host threads there before it creates the context */
+FT_API int ft_device_pci_bus_id(int device, char *buf, int len);
 /* host_threads: workers for the host-side octree stage (0 = the CPUs this process may use:
  * hardware threads capped by affinity and by a cgroup CPU quota).
  * No side effects on the process environment.  Extractors for batches of more than 16 frames run on streams of the context
@@ -119,6 +123,13 @@ FT_API int ft_extractor_level_size(const ft_extractor *ex, int level, int *width
 FT_API int ft_extract(ft_extractor *ex, const uint8_t *image, int width, int height, int stride, int lap0,
                       int lap1, ft_keypoint *keypoints, uint8_t *descriptors, int capacity, int *n_keypoints,
                       int *n_mono);
+
+/* Modes of an extractor / front end, fixed by max_batch at creation: max_batch <= 16 = LATENCY mode - private streams, and a
+ * batch of at most 8 frames with a fixed call shape is captured once as a HIP graph and replayed (statistics
+ * "extract.graph_launch" / "stereo.graph_launch" count the replays); max_batch > 16 = THROUGHPUT mode - the streams are lanes
+ * of the context shared with the other wide extractors, which a capture cannot use, so such an object never takes the graph
+ * path, whatever the size of the batch it is handed (FT_LANE_MAP=own gives wide extractors private streams and the graph path
+ * back).  A caller that alternates between single frames and large batches creates one object for each. */
 
 /* The same for `batch` <= max_batch images of identical size.  images[b] is a host pointer
  * (on_device = 0) or a device pointer on this context's device (on_device = 1, frames already in HBM).

@@ -34,6 +34,18 @@ def test_bench_two_ranks_folded_onto_one_device():
     assert r["device_octree_fallbacks"] == 0
 
 
+def test_bench_eight_ranks_folded_onto_one_device():
+    """the shape of the driver's 8-GPU run on the one device of the box: eight processes, eight contexts with their lane
+    tables and thread pools (cpus / 8 each), gloo rendezvous, NUMA pinning of every rank, the cpu_baseline leg on rank 0
+    after the last barrier - so that the first real 8-GPU run does not die on ports, pinned-memory limits or queue counts"""
+    r = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "24", "--workload", "stereo_752x480_nf1200", "--no-host-in"],
+             {"FT_BENCH_DEVICE_MOD": "1"}, timeout=1500)
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak" and len(r["per_rank_frames_per_s"]) == 8 and min(r["per_rank_frames_per_s"]) > 0
+    assert r["value"] <= sum(r["per_rank_frames_per_s"]) * 1.0001 and r["device_octree_fallbacks"] == 0
+    assert r["workloads"] is None and r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["kind"] == "port"
+    assert r["config"]["host_threads_per_gpu"] >= 1 and r["config"]["hw_queues"] == 10
+
+
 def test_bench_single_rank_line_has_the_contract_fields():
     r = _run(["--steps", "3", "--warmup", "1", "--batch", "32", "--workload", "stereo_752x480_nf1200", "--no-cpu-baseline",
               "--workload-batch", "20", "--workload-frames", "6"])

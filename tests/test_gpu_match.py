@@ -252,6 +252,20 @@ def test_dense_frames_stay_on_the_device_and_overflows_are_repaired_per_pair(ctx
     outs = fe.process([p[0] for p in batch2], [p[1] for p in batch2])
     assert calls("stereo.device_octree_fallbacks") == f0 + (0 if hist else 11)
     check(batch2, outs, [4, 5, 6, 11])
+    if hist:
+        # the tier follows the demand: after a few calm batches it is not launched any more (a kernel less in the octree
+        # lane), the dense batch that arrives then is repaired pair by pair - once - and the next one is back on the device
+        calm_batch = [calm[i % 3] for i in range(B)]
+        for _ in range(3):
+            fe.process([p[0] for p in calm_batch], [p[1] for p in calm_batch])
+        f1 = calls("stereo.device_octree_fallbacks")
+        assert f1 == f0
+        outs = fe.process([p[0] for p in batch1], [p[1] for p in batch1])
+        assert calls("stereo.device_octree_fallbacks") == f1 + 9, "dense pairs of the first batch after the tier was retired: repaired"
+        check(batch1, outs, [0, 1, 2])
+        outs = fe.process([p[0] for p in batch1], [p[1] for p in batch1])
+        assert calls("stereo.device_octree_fallbacks") == f1 + 9, "the tier is back"
+        check(batch1, outs, [2, 16])
     fe.close()
 
 

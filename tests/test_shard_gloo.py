@@ -76,3 +76,28 @@ def test_bench_gpus_n_starts_n_ranks(tmp_path, monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_numa_pinning_helpers(tmp_path):
+    """shard.pin_to_numa_node on a fake sysfs tree: the CPUs of the device's node, shared evenly by the ranks of that node,
+    intersected with the affinity the process already has; unknown nodes change nothing"""
+    from fasttrack_amd import shard
+    assert shard.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    have = sorted(os.sched_getaffinity(0))
+    sysfs = tmp_path / "sys"
+    (sysfs / "bus/pci/devices/0000:c1:00.0").mkdir(parents=True)
+    (sysfs / "bus/pci/devices/0000:c1:00.0/numa_node").write_text("1\n")
+    (sysfs / "devices/system/node/node1").mkdir(parents=True)
+    (sysfs / "devices/system/node/node1/cpulist").write_text(f"{have[0]}-{have[-1]}\n")
+    assert shard.numa_node_of_pci("0000:C1:00.0", str(sysfs)) == 1 and shard.numa_node_of_pci("0000:00:00.0", str(sysfs)) == -1
+    try:
+        assert shard.pin_to_numa_node(-1, sysfs=str(sysfs)) is None and shard.pin_to_numa_node(7, sysfs=str(sysfs)) is None
+        assert sorted(os.sched_getaffinity(0)) == have
+        if len(have) >= 4:
+            a = shard.pin_to_numa_node(1, world=2, slot=0, sysfs=str(sysfs))
+            assert a == have[:len(have) // 2] and sorted(os.sched_getaffinity(0)) == a
+            os.sched_setaffinity(0, have)
+            b = shard.pin_to_numa_node(1, world=2, slot=1, sysfs=str(sysfs))
+            assert b == have[len(have) // 2:] and not set(a) & set(b)
+    finally:
+        os.sched_setaffinity(0, have)

@@ -10,12 +10,13 @@ seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 rng = random.Random(seed)
 STEPS = os.environ.get("LS_STEPS", "64")
+EXTRA = os.environ.get("LS_BENCH_ARGS", "").split()  # e.g. "--workload stereo_752x480_nf1200" or "--mosaic 10"
 
 
 def run(m):
     env = dict(os.environ, FT_LANE_MAP=m, GPU_MAX_HW_QUEUES=str(lanes + 2))
     try:
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-host-in", "--steps", STEPS],
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-host-in", "--no-workloads", "--steps", STEPS] + EXTRA,
                              env=env, capture_output=True, text=True, timeout=120).stdout
         return json.loads(out.strip().splitlines()[-1])["value"]
     except Exception:  # noqa: BLE001
