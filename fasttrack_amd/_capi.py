@@ -109,6 +109,7 @@ def lib() -> C.CDLL:
     L.ft_context_device_name.argtypes = [vp, C.c_char_p, i]
     L.ft_context_host_threads.argtypes = [vp]
     L.ft_context_hw_queues.argtypes = [vp]
+    L.ft_context_set_lane_map.argtypes = [vp, vp, i]
     L.ft_context_save_stats.argtypes = [vp, C.c_char_p]
     L.ft_context_set_kernel_timing.argtypes = [vp, i]
     L.ft_context_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]

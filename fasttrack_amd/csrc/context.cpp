@@ -67,9 +67,12 @@ int ft_context_upload_stream(ft_context *ctx, hipStream_t *out) {
 }
 
 // the streams of the next extractor (see ft_host.h); out[FT_LANE_STREAMS]
-int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, hipStream_t *out, bool *owned) {
+int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, int width, int height, hipStream_t *out, bool *owned) {
     std::lock_guard<std::mutex> lk(ctx->laneMutex);
-    if (wantPrivate || ctx->laneMap.empty()) {
+    // which table: the user's (FT_LANE_MAP / ft_context_set_lane_map) for every shape, else the one searched for frames of
+    // this size class (ft_host.h)
+    const std::vector<int> &laneMap = ctx->userLaneMap || (size_t)width * height >= FT_LANE_SMALL_PIXELS ? ctx->laneMap : ctx->laneMapSmall;
+    if (wantPrivate || laneMap.empty()) {
         for (int i = 0; i < FT_LANE_STREAMS; i++) out[i] = nullptr;
         for (int i = 0; i < FT_LANE_STREAMS; i++) {
             const hipError_t e = hipStreamCreateWithFlags(&out[i], hipStreamNonBlocking);
@@ -84,10 +87,10 @@ int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, hipStream_t *out, b
         *owned = true;
         return FT_OK;
     }
-    const size_t sets = ctx->laneMap.size() / FT_LANE_STREAMS;
+    const size_t sets = laneMap.size() / FT_LANE_STREAMS;
     const size_t set = (size_t)(ctx->nextLaneSet++) % sets;
     for (int i = 0; i < FT_LANE_STREAMS; i++) {
-        const size_t lane = (size_t)ctx->laneMap[set * FT_LANE_STREAMS + i];
+        const size_t lane = (size_t)laneMap[set * FT_LANE_STREAMS + i];
         if (ctx->lanes.size() <= lane) ctx->lanes.resize(lane + 1, nullptr);
         if (!ctx->lanes[lane]) FT_HIP(hipStreamCreateWithFlags(&ctx->lanes[lane], hipStreamNonBlocking));
         out[i] = ctx->lanes[lane];
@@ -219,10 +222,16 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
     // FT_LANE_MAP="a b o0 o1  a b o0 o1 ..." : lane of (stage A, stage B, octree 0, octree 1) for the 1st, 2nd, ... extractor
     // created on the context (the list wraps around); FT_LANE_MAP=own gives every extractor four streams of its own
     ctx->hwQueues = ft_hw_queues_hint();
-    if (ctx->hwQueues >= 8) ctx->laneMap = {1, 2, 3, 4, 5, 1, 3, 1, 5, 4, 3, 2, 1, 1, 7, 6};  // searched with 10 queues (tools/lane_search.py)
-    else ctx->laneMap.clear();  // the runtime's default of four queues: private streams, placed by the runtime (66 k frames/s on the headline
+    if (ctx->hwQueues >= 8) {
+        // searched with 10 queues (tools/lane_search.py): on 1280x720 / 512 pairs, and on 752x480 / 512 pairs for the small class
+        ctx->laneMap = {1, 2, 3, 4, 5, 1, 3, 1, 5, 4, 3, 2, 1, 1, 7, 6};
+        ctx->laneMapSmall = FT_LANE_MAP_SMALL;
+    } else ctx->laneMap.clear();  // the runtime's default of four queues: private streams, placed by the runtime (66 k frames/s on the headline
                                 // workload; a lane per stage shared by the cameras and front ends - {0,1,2,3} for everyone - ran 55 k)
-    if (haveUserMap) ctx->laneMap = userMap;
+    if (haveUserMap) {
+        ctx->laneMap = userMap;
+        ctx->userLaneMap = true;
+    }
     ctx->addStat("context.hw_queues", 0.0);
     ctx->stats["context.hw_queues"].second = ctx->hwQueues;
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -277,6 +286,24 @@ int ft_context_device_name(ft_context *ctx, char *buf, int len) {
 int ft_context_host_threads(const ft_context *ctx) { return ctx ? ctx->pool->size() : 0; }
 
 int ft_context_hw_queues(const ft_context *ctx) { return ctx ? ctx->hwQueues : 0; }
+
+int ft_context_set_lane_map(ft_context *ctx, const int *map, int n) {
+    if (!ctx || n < 0 || (n > 0 && !map)) return FT_ERR_INVALID;
+    if (n % FT_LANE_STREAMS != 0) {
+        ft_set_error("ft_context_set_lane_map: need whole sets of (stage A, stage B, octree 0, octree 1)");
+        return FT_ERR_INVALID;
+    }
+    for (int i = 0; i < n; i++)
+        if (map[i] < 0 || map[i] >= 64) {
+            ft_set_error("ft_context_set_lane_map: lane outside [0, 64)");
+            return FT_ERR_INVALID;
+        }
+    std::lock_guard<std::mutex> lk(ctx->laneMutex);
+    ctx->laneMap.assign(map, map + n);  // n == 0: private streams for every extractor
+    ctx->userLaneMap = true;
+    ctx->nextLaneSet = 0;
+    return FT_OK;
+}
 
 int ft_context_save_stats(ft_context *ctx, const char *path) {
     if (!ctx || !path) return FT_ERR_INVALID;

@@ -815,7 +815,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     {
         hipStream_t lanes[FT_LANE_STREAMS];
         // latency-mode extractors (graph capture) own their streams; wide ones run on the context's lanes
-        FT_TRY(ft_context_take_lanes(ctx, max_batch <= 16, lanes, &ex->ownStreams));
+        FT_TRY(ft_context_take_lanes(ctx, max_batch <= 16, image_width, image_height, lanes, &ex->ownStreams));
         ex->stream = lanes[0];
         ex->streamB = lanes[1];
         for (int i = 0; i < FT_OCT_STREAMS; i++) ex->streamO[i] = lanes[2 + i];

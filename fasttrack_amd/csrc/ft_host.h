@@ -24,6 +24,11 @@
 // (tools/lane_search.py: random maps 45 - 66 k frames/s, hill climbing from the best 73.4 k).  Extractors for small batches
 // (latency mode) keep streams of their own: their batches are captured as HIP graphs, and a stream under capture cannot be
 // shared with another host thread.
+// Size classes of the shipped tables: frames of fewer pixels than this take laneMapSmall.  (What the frames CONTAIN - dense
+// texture, host-in uploads - also shifts the balance, but is not known when an extractor is created: an application that
+// knows its stream searches a table on it with tools/lane_search.py and sets it with ft_context_set_lane_map / FT_LANE_MAP.)
+#define FT_LANE_SMALL_PIXELS ((size_t)600 * 1000)
+#define FT_LANE_MAP_SMALL {1, 2, 3, 4, 1, 1, 3, 1, 5, 4, 3, 2, 1, 1, 7, 6}  // 752x480: 151.6 k frames/s against 147.6 k with the 1280x720 table
 #define FT_OCT_STREAMS 2
 #define FT_LANE_STREAMS (2 + FT_OCT_STREAMS)
 
@@ -38,6 +43,8 @@ struct ft_context {
     std::vector<hipStream_t> lanes;
     hipStream_t uploadStream = nullptr;  // host frames of whole batches go up here (copies only)
     std::vector<int> laneMap;  // [extractor k mod sets][role] -> lane; empty: private streams
+    std::vector<int> laneMapSmall;  // the same for frames below FT_LANE_SMALL_PIXELS (a table of its own: other kernel balance)
+    bool userLaneMap = false;       // laneMap came from FT_LANE_MAP / ft_context_set_lane_map: it serves every shape
     int nextLaneSet = 0;
     size_t maxPitch = 0;                // hipDeviceAttributeMaxPitch (0 = unknown): bound of the one-copy upload's source pitch
     int hwQueues = 4;                   // GPU_MAX_HW_QUEUES of the process environment when the context was created (4 = unset)
@@ -246,7 +253,7 @@ struct ft_stereo_frontend {
 };
 
 int ft_set_device(const ft_context *ctx);
-int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, hipStream_t *out, bool *owned);  // out[FT_LANE_STREAMS]
+int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, int width, int height, hipStream_t *out, bool *owned);  // out[FT_LANE_STREAMS]
 int ft_context_upload_stream(ft_context *ctx, hipStream_t *out);  // the copy-only stream of the context (created on demand)
 bool ft_is_pinned_host(const void *p);  // null counts as pinned (nothing to copy)
 bool ft_is_pinned_host_range(const void *p, size_t bytes);  // [p, p + bytes) inside ONE pinned host allocation

@@ -73,6 +73,10 @@ FT_API int ft_context_destroy(ft_context *ctx);
 FT_API int ft_context_synchronize(ft_context *ctx);
 FT_API int ft_context_device_name(ft_context *ctx, char *buf, int len);
 FT_API int ft_context_hw_queues(const ft_context *ctx);
+/* The lane table of the extractors created on the context from now on: n = 4 * sets entries, (stage A, stage B, octree 0,
+ * octree 1) lane numbers in [0, 64) for the 1st, 2nd, ... extractor (wrapping around); n = 0: private streams for every
+ * extractor.  What FT_LANE_MAP does through the environment; tools/lane_search.py finds a table for a given stream of frames. */
+FT_API int ft_context_set_lane_map(ft_context *ctx, const int *map, int n);
 FT_API int ft_context_host_threads(const ft_context *ctx);
 /* per-stage wall/GPU timings of the calls made so far; the reference's REGISTER_STATS analogue
  * (include/Kernels/CudaUtils.h:14, src/Stats.cc:31-60).  Writes "<name>: <ms>" lines. */
