@@ -232,22 +232,35 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
     Trl = np.concatenate([np.eye(3), [[-0.101], [0.0], [0.0]]], 1).astype(np.float32)  # x_r = x_l + trl: 10.1 cm baseline (TUM-VI)
     TLR = (0.101, 0.0, 0.0)
     LOG_SF = float(np.float32(np.log(np.float32(SCALE))))
-    exL = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=1)
-    exR = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=1)
+    ex2 = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=2)
+    exL = ex2
     sf = np.asarray(exL.GetScaleFactors(), np.float32)
     pairs = [synth.make_planes_pair(w, h, seed=7000 + i) for i in range(D)]
     tf = orb.TrackedFrame(ctx, max_keypoints=2 * exL.max_keypoints + 64, max_points=max(M, exL.max_keypoints) + 64)
 
+    part = {"extract_left_right": 0.0, "fisheye_match": 0.0, "frame_marshalling(python)": 0.0, "upload": 0.0,
+            "search_last_frame": 0.0, "track_local_map": 0.0}
+
+    def clock(name, t0):
+        t1 = time.perf_counter()
+        part[name] += t1 - t0
+        return t1
+
     def extract(i):
-        kL, dL, _ = exL(pairs[i][0], lap)
-        kR, dR, _ = exR(pairs[i][1], lap)
+        t = time.perf_counter()
+        # both cameras in ONE call (a batch of two through the captured graph), as Frame's two extraction threads overlap them
+        # in the reference (Frame.cc:1144-1147); the lapping areas of the two cameras are the same in TUM-VI.yaml
+        (kL, dL, _), (kR, dR, _) = ex2.extract_batch([pairs[i][0], pairs[i][1]], lap)
+        t = clock("extract_left_right", t)
         m = orb.KernelController.launchFisheyeStereoMatchKernel(ctx, dL, dR)
+        t = clock("fisheye_match", t)
         l2r = np.ascontiguousarray(m["matches"], np.int32)
         r2l = np.full(len(kR), -1, np.int32)
         ok = l2r >= 0
         r2l[l2r[ok]] = np.nonzero(ok)[0].astype(np.int32)
         F = orb.FrameView(keys=kL, keys_right=kR, descriptors=np.concatenate([dL, dR]), scale_factors=sf, bounds=sc.frame_bounds(w, h),
                           left_to_right=l2r, right_to_left=r2l, cam_model=1, cam=cam, Trl=Trl)
+        clock("frame_marshalling(python)", t)
         return kL, dL, kR, dR, F
     # per distinct frame: the last frame's points and the local map, built from the frame's own keypoints
     scen = []
@@ -261,9 +274,13 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
     def frame(i, th):
         kL, dL, kR, dR, F = extract(i)
         last, Tcw_last, pts, Rcw, tcw = scen[i]
+        t = time.perf_counter()
         tf.upload(F)
+        t = clock("upload", t)
         a = tf.search_last_frame(last, Tcw_last, th)
+        t = clock("search_last_frame", t)
         b = tf.track_local_map(orb.make_pose(Rcw, tcw, TLR), pts, 0.5, LOG_SF, th)
+        clock("track_local_map", t)
         return len(kL), len(kR), a, b, F
     out = {"metric": "frames/sec extract + SearchByProjection (last frame, local map)", "unit": "frames/s", "image": [w, h], "nfeatures": nf,
            "camera": "KannalaBrandt8 stereo rig, lapping areas [0, 511]", "local_map_points": M, "mode": "one frame at a time (latency mode), host images in, host results out",
@@ -273,6 +290,8 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
             frame(k % D, th)
         ctx.synchronize()
         npts = ncmp = nmatch = 0
+        for k_ in part:
+            part[k_] = 0.0
         t0 = time.perf_counter()
         for k in range(frames):
             nl, nr, a, b, F = frame(k % D, th)
@@ -280,21 +299,21 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
             nmatch += a["n"] + b["n"]
         ctx.synchronize()
         dt = time.perf_counter() - t0
+        parts_ms = {k_: 1e3 * v_ / frames for k_, v_ in part.items()}
         # Hamming compares of one pass over the distinct frames, counted outside the timed region
         for i in range(D):
             nl, nr, a, b, F = frame(i, th)
             ncmp += count_compares(orb, ctx, F, sf, scen[i], b, th, cam, Trl)
         out["by_th"][str(int(th))] = {"value": frames / dt, "ms_per_frame": 1e3 * dt / frames, "map_points_per_s": npts / dt,
                                       "hamming_compares_per_frame": ncmp / D, "hamming_compares_per_s": ncmp / D * frames / dt,
-                                      "matches_per_frame": nmatch / frames}
+                                      "matches_per_frame": nmatch / frames, "ms_per_frame_by_part": parts_ms}
     out["value"] = out["by_th"]["7"]["value"]
     out["keypoints_per_frame"] = nl + nr
     if cpu:
         out["cpu_baseline"] = tracking_cpu_baseline(pairs, scen, cam, Trl, sf, lap, w, h, nf, LOG_SF, cpu_budget_s)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     tf.close()
-    exL.close()
-    exR.close()
+    ex2.close()
     return out
 
 
@@ -444,19 +463,33 @@ def main():
         ctx.synchronize()  # hipDeviceSynchronize on this rank's device (the library owns its HIP runtime)
         shard.barrier(dist)
 
+    done_at = []  # completion time of every step of the last run() (results of the step in host arrays)
+
     def run(steps, pL, pR, on_device):
         """`steps` passes over the batch; every pass is complete (results in host arrays) on return"""
+        del done_at[:]
         if len(fes) == 1:
             for _ in range(steps):
                 fe.process_raw(pL, pR, B, on_device, w)
+                done_at.append(time.perf_counter())
             return
         F = len(fes)
         for k in range(steps):
             if k >= F:
                 fes[k % F].wait()  # the batch submitted F steps ago
+                done_at.append(time.perf_counter())
             fes[k % F].submit_raw(pL, pR, B, on_device, w)
         for k in range(max(steps - F, 0), steps):
             fes[k % F].wait()
+            done_at.append(time.perf_counter())
+
+    def steady_rate():
+        """frames/s between the completions of the steps in the middle of the timed region: without the fill of the pipeline at
+        its start (nothing completes for the first ~1.5 steps) and the drain at its end - what a stream of batches sees"""
+        if len(done_at) < 6:
+            return None
+        a_, b_ = len(done_at) // 4, len(done_at) - 1 - len(done_at) // 8
+        return B * (b_ - a_) / (done_at[b_] - done_at[a_])
 
     def timed(steps, pL, pR, on_device):
         barrier()
@@ -471,6 +504,7 @@ def main():
     ctx.reset_stats()
     ctx.set_kernel_timing(True)
     elapsed_rank = timed(args.steps, ptrsL, ptrsR, True)
+    steady_rank = steady_rate()
     ctx.set_kernel_timing(False)
     kps_rank = int(fe._nL[:B].sum() + fe._nR[:B].sum())  # keypoints of one pass over this rank's batch
     matches = int(fe._nm[:B].sum())
@@ -478,6 +512,7 @@ def main():
     elapsed = shard.reduce_max(dist, elapsed_rank)
     kps, matches, kpsL = [int(v) for v in shard.reduce_sum(dist, [kps_rank, matches, int(fe._nL[:B].sum())])]
     rank_fps = shard.gather_floats(dist, B * args.steps / elapsed_rank, world)
+    rank_steady = shard.gather_floats(dist, steady_rank or 0.0, world)
 
     if args.stats:
         ctx.save_stats(args.stats + (f".rank{rank}" if world > 1 else ""))
@@ -586,6 +621,9 @@ def main():
                        "host_threads_per_gpu": ctx.host_threads, "device": ctx.device_name, "hw_queues": ctx.hw_queues,
                        "numa_node_of_rank0": numa["node"], "cpus_pinned_rank0": numa["cpus"]},
             "per_rank_frames_per_s": rank_fps,
+            # beside `value` (the contract: all frames / the whole timed region, fill and drain of the pipeline included): the
+            # rate between step completions in the middle of the region, summed over the ranks
+            "steady_state_frames_per_s": sum(rank_steady) if all(rank_steady) else None,
             "keypoints_per_s": kps * args.steps / elapsed,
             "keypoints_per_frame": kps / (B * world),
             "stereo_matches_per_frame": matches / (B * world),

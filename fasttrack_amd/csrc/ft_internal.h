@@ -120,7 +120,9 @@ struct FtTap {
 #define FT_OCT_HIST_BINS 8192  // bins of the histogram tier (k_octree_hist): nodes of depth D, nIni * 4^D <= this
 #define FT_OCT_HISTMIN 16      // workgroups of the histogram tier while no batch has asked for more (each walks the list)
 #define FT_OCT_HIST_RETIRE 2   // batches without a listed level after which the histogram tier is not launched any more
+#ifndef FT_OCT_HISTMAX
 #define FT_OCT_HISTMAX 512     // ... and at most (two or three fit a CU)
+#endif
 #define FT_OCT_BIGMIN 64   // smallest grid of the sorted big tier (k_octree_big) once a stream of frames needs it
 struct FtOctArgs {
     const uint32_t *cand;   // device dense candidate lists [slot * candPerSlot + candBase]

@@ -1371,8 +1371,8 @@ __global__ __launch_bounds__(256) void k_compact(FtGeom g, const int *cellCount,
 #define OD_HB_BYTES (OD_LAYOUT ? OD_HP * OD_RP * 2 + 16 : OD_P * OD_HP * 2)  // 3536 / 3440
 #define OD_WAVE_BYTES ((OD_RAW_BYTES + OD_HB_BYTES + 15) & ~15)
 #define OD_WAVES 4
-#ifndef OD_KPW
-#define OD_KPW 2                // keypoints per wave: loads of all of them in flight before the first is processed
+#ifndef OD_KPW_WIDE
+#define OD_KPW_WIDE 2           // keypoints per wave in launches of 8+ images: loads of all of them in flight before the first is processed
 #endif
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -1474,6 +1474,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+template <int OD_KPW>
 __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const uint8_t *const *l0, int l0pitch,
                                                                const uint8_t *pyr, int alignedLoads, const FtSelKp *sel,
                                                                const int *selCount, FtOctArgs lay, int *nSel,
@@ -1874,11 +1875,20 @@ int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint
                           const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *selCount,
                           const FtOctArgs &layout, int *nSel, ft_keypoint *keys, uint8_t *desc) {
     dim3 grid, block(64 * OD_WAVES, 1, 1);
-    const FtSlotGrid sg = ft_slot_grid((g.maxKp + OD_WAVES * OD_KPW - 1) / (OD_WAVES * OD_KPW), batch, grid);
+    // Launches that fill the chip (8+ images) give a wave several keypoints, which hides the load chains behind arithmetic;
+    // a frame or two at a time (latency mode) leaves SIMDs idle as it is, and a wave that works through two keypoints one
+    // after the other only doubles the time to the last result (stereo pair 752x480: 0.284 against 0.244 ms): one each.
+    const int kpw = batch >= 8 ? OD_KPW_WIDE : 1;
+    const FtSlotGrid sg = ft_slot_grid((g.maxKp + OD_WAVES * kpw - 1) / (OD_WAVES * kpw), batch, grid);
     const size_t smem = OD_WAVES * (size_t)OD_WAVE_BYTES;
-    for (int rep = ft_debug_repeat("orient"); rep > 0; rep--)
-    hipLaunchKernelGGL(k_orient_desc, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, selCount, layout,
-                       nSel, keys, desc, sg);
+    for (int rep = ft_debug_repeat("orient"); rep > 0; rep--) {
+        if (kpw == 1)
+            hipLaunchKernelGGL(k_orient_desc<1>, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, selCount, layout,
+                               nSel, keys, desc, sg);
+        else
+            hipLaunchKernelGGL(k_orient_desc<OD_KPW_WIDE>, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, selCount,
+                               layout, nSel, keys, desc, sg);
+    }
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
