@@ -49,7 +49,7 @@ WORKLOADS = {
 }
 NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_JSON = "r02_traffic.json"
+TRAFFIC_JSON = "r03_traffic.json"
 
 
 def usable_cpus():
@@ -176,13 +176,18 @@ def stereo_leg(orb, ctx, name, w, h, nf, B, steps, warmup, mosaic=0, planes=Fals
     pL = (C.c_void_p * B)(*[devL.ptr.value + b * fb for b in range(B)])
     pR = (C.c_void_p * B)(*[devR.ptr.value + b * fb for b in range(B)])
 
+    done_at = []
+
     def run(n):
+        del done_at[:]
         for k in range(n):
             if k >= 2:
                 fes[k % 2].wait()
+                done_at.append(time.perf_counter())
             fes[k % 2].submit_raw(pL, pR, B, True, w)
         for k in range(max(n - 2, 0), n):
             fes[k % 2].wait()
+            done_at.append(time.perf_counter())
     f0 = ctx.get_stat("stereo.device_octree_fallbacks")[1]
     run(max(warmup, 2))  # (the first dense batches size the octree's histogram tier)
     f1 = ctx.get_stat("stereo.device_octree_fallbacks")[1]
@@ -195,7 +200,9 @@ def stereo_leg(orb, ctx, name, w, h, nf, B, steps, warmup, mosaic=0, planes=Fals
     kps = int(fe._nL[:B].sum() + fe._nR[:B].sum())
     nL = int(fe._nL[:B].sum())
     matches = int(fe._nm[:B].sum())
+    a_, b_ = len(done_at) // 4, len(done_at) - 1 - len(done_at) // 8
     out = {"value": B * steps / dt, "unit": "frames/s", "metric": "frames/sec extract+match", "steps": steps, "warmup": max(warmup, 2),
+           "steady_state_frames_per_s": B * (b_ - a_) / (done_at[b_] - done_at[a_]) if b_ > a_ else None,
            "ms_per_step": 1e3 * dt / steps, "batch_pairs": B, "distinct_pairs": B, "image": [w, h], "nfeatures": nf,
            "scene_kind": f"mosaic of {mosaic}-px tiles" if mosaic else "object scene on fronto-parallel planes" if planes else "objects on a smooth background",
            "inputs": "resident in HBM before the timed region", "keypoints_per_s": kps * steps / dt, "keypoints_per_frame": kps / B,
@@ -290,6 +297,7 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
             frame(k % D, th)
         ctx.synchronize()
         npts = ncmp = nmatch = 0
+        ctx.reset_stats()
         for k_ in part:
             part[k_] = 0.0
         t0 = time.perf_counter()
@@ -300,13 +308,20 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
         ctx.synchronize()
         dt = time.perf_counter() - t0
         parts_ms = {k_: 1e3 * v_ / frames for k_, v_ in part.items()}
+        # passes of the exact in-call claiming (one launch per pass, as many as the longest chain of map points
+        # that take a keypoint from one another) and the time inside the two C entry points
+        lib_stats = {}
+        for nm_ in ("tracked.search_last_frame.passes", "tracked.track_local_map.passes", "tracked.search_last_frame.total",
+                    "tracked.track_local_map.total"):
+            tot_, n_ = ctx.get_stat(nm_)
+            lib_stats[nm_ + ("_per_call" if nm_.endswith("passes") else "_ms_per_call")] = tot_ / n_ if n_ else None
         # Hamming compares of one pass over the distinct frames, counted outside the timed region
         for i in range(D):
             nl, nr, a, b, F = frame(i, th)
             ncmp += count_compares(orb, ctx, F, sf, scen[i], b, th, cam, Trl)
         out["by_th"][str(int(th))] = {"value": frames / dt, "ms_per_frame": 1e3 * dt / frames, "map_points_per_s": npts / dt,
                                       "hamming_compares_per_frame": ncmp / D, "hamming_compares_per_s": ncmp / D * frames / dt,
-                                      "matches_per_frame": nmatch / frames, "ms_per_frame_by_part": parts_ms}
+                                      "matches_per_frame": nmatch / frames, "ms_per_frame_by_part": parts_ms, "inside_the_library": lib_stats}
     out["value"] = out["by_th"]["7"]["value"]
     out["keypoints_per_frame"] = nl + nr
     if cpu:
@@ -596,14 +611,14 @@ def main():
         legs = [x for x in legs if x]
         roof = legs[0] if legs else None
         try:
-            mc = json.load(open(os.path.join(ROOT, "profiles", "r02_marginal_costs.json")))
+            mc = json.load(open(os.path.join(ROOT, "profiles", "r03_marginal_costs.json")))
         except Exception:
             mc = {}
         if roof and mc.get("workload") == args.workload and mc.get("batch_pairs") == B and not args.mosaic and args.scene == "objects":
             ms = mc["marginal_ms_per_step"]["k_fast_cells"] / (roof["launches_timed"] / args.steps)
             ach = roof["bytes_per_launch"] / (ms / 1e3) / 1e9
             roof["at_marginal_cost"] = {"ms_per_launch": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-                                        "source": "profiles/r02_marginal_costs.json (tools/marginal_costs.py: FT_DEBUG_REPEAT=fast, same workload)"}
+                                        "source": "profiles/r03_marginal_costs.json (tools/marginal_costs.py: FT_DEBUG_REPEAT=fast, same workload)"}
         also = sorted(legs[1:], key=lambda x: -x["total_ms"])
         R_pair = 2 * (3 * sumP - P[-1])  # read bytes per stereo pair, unfused accounting
         out = {
@@ -646,10 +661,10 @@ def main():
             cpu = not args.no_cpu_baseline
             wl = {}
             WB = args.workload_batch
-            wl["stereo_752x480_nf1200"] = stereo_leg(orb, ctx, "stereo_752x480_nf1200", 752, 480, 1200, WB, 16, 3, cpu=cpu)
+            wl["stereo_752x480_nf1200"] = stereo_leg(orb, ctx, "stereo_752x480_nf1200", 752, 480, 1200, WB, 48, 5, cpu=cpu)
             wl["tracking_512x512_nf2000"] = tracking_leg(orb, ctx, frames=args.workload_frames, cpu=cpu)
-            wl["dense_1280x720_nf2000"] = stereo_leg(orb, ctx, "dense", 1280, 720, 2000, WB, 8, 3, mosaic=10, cpu=cpu, cpu_budget_s=3.0)
-            wl["planes_1280x720_nf2000"] = stereo_leg(orb, ctx, "planes", 1280, 720, 2000, WB, 8, 3, planes=True, cpu=cpu, cpu_budget_s=3.0)
+            wl["dense_1280x720_nf2000"] = stereo_leg(orb, ctx, "dense", 1280, 720, 2000, WB, 16, 4, mosaic=10, cpu=cpu, cpu_budget_s=3.0)
+            wl["planes_1280x720_nf2000"] = stereo_leg(orb, ctx, "planes", 1280, 720, 2000, WB, 16, 4, planes=True, cpu=cpu, cpu_budget_s=3.0)
             out["workloads"] = wl
         if not args.no_cpu_baseline:  # rank 0, after the last barrier: the other ranks are done and the host cores are free
             out["cpu_baseline"] = cpu_baseline(w, h, nf, pairs)
