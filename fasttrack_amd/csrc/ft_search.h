@@ -57,7 +57,20 @@ struct FtClaims {
     int *flagCur;            // this pass's flag (atomicAnd 0 on a change)
     const int *flagPrev;     // the previous pass's flag (null for the first pass of a burst)
     int *flagReset;          // the flag of the same position in the other burst parity: reset to -1 here
+    // Candidate cache (may be null).  What does NOT change from pass to pass - which keypoints of a point's window pass the
+    // level band, the box and the uright test, and their Hamming distances - is computed once: the first pass that reaches a
+    // (point, camera) window files the (distance, cell x, cell y, index) keys of all its candidates here, and every later
+    // pass only walks those keys against the new lock state (a round of 64 keys = one coalesced load + the lock look-ups)
+    // instead of walking the grid, the keypoints and the descriptors again.  A pass of the iteration is as long as its
+    // slowest wave, and a window scan is a chain of ~5 dependent loads per 64 entries: 85 us per pass at th 15, whatever
+    // the number of points.  Per (point, camera) FT_CACHE_CAP + 1 64-bit words: [0] = ~0 "not built" | number of
+    // candidates (more than FT_CACHE_CAP: not cached, scan again) | any keypoint in the box << 32, then the keys, unordered.
+    unsigned long long *cache;
 };
+#ifndef FT_CACHE_CAP
+#define FT_CACHE_CAP 511
+#endif
+#define FT_CACHE_WORDS (2 * (FT_CACHE_CAP + 1))  // per point: left and right camera
 
 struct FtPose {
     float m[12];
@@ -89,6 +102,8 @@ struct FtFrustumOut {
 };
 
 int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v);
+// p[i * strideWords] = v for i < n (64-bit words): the meta words of the candidate cache
+int ft_launch_fill_stride_u64(hipStream_t st, unsigned long long *p, int n, int strideWords, unsigned long long v);
 // one kernel copies up to three device blocks (sizes rounded up to dwords) into pinned host memory
 int ft_launch_deliver_blocks(hipStream_t st, void *d0, const void *s0, size_t bytes0, void *d1, const void *s1, size_t bytes1,
                              void *d2, const void *s2, size_t bytes2);

@@ -151,6 +151,46 @@ __device__ __forceinline__ void wave_two_min(unsigned long long &k0, unsigned lo
     k1 = m1;
 }
 
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- candidate cache of the claim iteration (FtClaims::cache) ----
+// One LDS counter per wave hands out the positions while a window is scanned (the candidates turn up in divergent code).
+struct CacheBuild {
+    unsigned long long *slot;  // null: no cache
+    int *counter;              // LDS, this wave's
+    bool build;                // wave-uniform: this scan files its candidates
+};
+__device__ __forceinline__ void cache_begin(CacheBuild &B, int lane) {
+    if (B.build) {
+        if (lane == 0) *B.counter = 0;
+        wave_lds_sync();
+    }
+}
+__device__ __forceinline__ void cache_append(const CacheBuild &B, unsigned long long key) {
+    const int pos = atomicAdd(B.counter, 1);
+    if (pos < FT_CACHE_CAP) B.slot[1 + pos] = key;
+}
+__device__ __forceinline__ void cache_end(const CacheBuild &B, int lane, bool anyInBox) {
+    if (B.build) {
+        wave_lds_sync();
+        if (lane == 0) B.slot[0] = (unsigned long long)(unsigned)*B.counter | ((unsigned long long)(anyInBox ? 1 : 0) << 32);
+    }
+}
+// 0 = not built yet, 1 = usable (count = candidates filed), 2 = built but too many candidates: scan the window again
+__device__ __forceinline__ int cache_state(const unsigned long long *slot, int &count, bool &anyInBox) {
+    count = 0;
+    anyInBox = false;
+    if (!slot) return 2;
+    const unsigned long long meta = slot[0];
+    if (meta == KEY_NONE) return 0;
+    count = (int)(unsigned)meta;
+    anyInBox = (meta >> 32) != 0;
+    return count <= FT_CACHE_CAP ? 1 : 2;
+}
+
 // level band and box test of GetFeaturesInArea for a keypoint whose cell is already known to lie in the window
 __device__ __forceinline__ bool in_box(const ft_keypoint &kp, float x, float y, float r, int minLevel, int maxLevel) {
     const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
@@ -268,7 +308,7 @@ __global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, i
 // ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) for map point i by one wave (src/ORBmatcher.cc:49-225):
 // r = (primary left, side left, primary right, side right) keypoints it writes; raw outputs as the reference kernel's
 __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
-                                            float nnRatio, int i, int lane, int r4[4], const FtLocalRaw &raw) {
+                                            float nnRatio, int i, int lane, int r4[4], const FtLocalRaw &raw, int *ldsCounter) {
     int primL = -1, sideL = -1, primR = -1, sideR = -1;
     int bd = 256, bd2 = 256, bl = -1, bl2 = -1, bi = -1;
     int bdr = 256, bd2r = 256, blr = -1, bl2r = -1, bir = -1;
@@ -288,20 +328,41 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
             const float x = P.projX[i], y = P.projY[i];
             const Window w = cell_window(F, x, y, rad);
             unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
-            if (!w.empty) {
-                for_window(F, 0, F.keys, nLeft, w, lane, [&](int idx, int cx, int cy) {
-                    const ft_keypoint kp = F.keys[idx];
-                    if (!in_box(kp, x, y, rad, level - 1, level)) return;
-                    if (is_locked(F, C, idx, i)) return;
-                    if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
-                        const float er = fabsf(__fsub_rn(P.projXR[i], F.uright[idx]));
-                        if (er > rad) return;
-                    }
-                    const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
-                    const unsigned long long key = make_key(dist, cx, cy, idx);
+            CacheBuild cb;
+            cb.slot = C.cache ? C.cache + (size_t)i * FT_CACHE_WORDS : nullptr;
+            cb.counter = ldsCounter;
+            int nCached;
+            bool anyBox;
+            const int cs = cache_state(cb.slot, nCached, anyBox);
+            cb.build = cs == 0;
+            if (cs == 1) {
+                for (int t = lane; t < nCached; t += 64) {
+                    const unsigned long long key = cb.slot[1 + t];
+                    if (is_locked(F, C, key_idx(key), i)) continue;
                     if (key < k0) { k1 = k0; k0 = key; }
                     else if (key < k1) k1 = key;
-                });
+                }
+            } else {
+                cache_begin(cb, lane);
+                if (!w.empty) {
+                    for_window(F, 0, F.keys, nLeft, w, lane, [&](int idx, int cx, int cy) {
+                        const ft_keypoint kp = F.keys[idx];
+                        if (!in_box(kp, x, y, rad, level - 1, level)) return;
+                        const bool locked = is_locked(F, C, idx, i);
+                        if (locked && !cb.build) return;
+                        if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
+                            const float er = fabsf(__fsub_rn(P.projXR[i], F.uright[idx]));
+                            if (er > rad) return;
+                        }
+                        const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
+                        const unsigned long long key = make_key(dist, cx, cy, idx);
+                        if (cb.build) cache_append(cb, key);
+                        if (locked) return;
+                        if (key < k0) { k1 = k0; k0 = key; }
+                        else if (key < k1) k1 = key;
+                    });
+                }
+                cache_end(cb, lane, false);
             }
             wave_two_min(k0, k1);
             if (k0 != KEY_NONE) {
@@ -331,19 +392,42 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 const Window w = cell_window(F, x, y, rad);
                 const int nRight = F.N - F.Nleft;
                 unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
-                if (!w.empty) {
-                    for_window(F, 1, F.keysR, nRight, w, lane, [&](int idx, int cx, int cy) {
-                        const ft_keypoint kp = F.keysR[idx];
-                        if (!in_box(kp, x, y, rad, level - 1, level)) return;
-                        const int g = idx + F.Nleft;
-                        // this point's own left-block side write precedes its right-block search
-                        const bool locked = (g == sideL) ? (C.obs[i] > 0) : is_locked(F, C, g, i);
-                        if (locked) return;
-                        const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)g * 32));
-                        const unsigned long long key = make_key(dist, cx, cy, idx);
+                // this point's own left-block side write precedes its right-block search
+                auto lockedR = [&](int g) -> bool { return (g == sideL) ? (C.obs[i] > 0) : is_locked(F, C, g, i); };
+                // (the right block is not reached in every pass - skipRight depends on the locks - so its candidates are filed by
+                // the first pass that gets here)
+                CacheBuild cb;
+                cb.slot = C.cache ? C.cache + (size_t)i * FT_CACHE_WORDS + (FT_CACHE_CAP + 1) : nullptr;
+                cb.counter = ldsCounter;
+                int nCached;
+                bool anyBox;
+                const int cs = cache_state(cb.slot, nCached, anyBox);
+                cb.build = cs == 0;
+                if (cs == 1) {
+                    for (int t = lane; t < nCached; t += 64) {
+                        const unsigned long long key = cb.slot[1 + t];
+                        if (lockedR(key_idx(key) + F.Nleft)) continue;
                         if (key < k0) { k1 = k0; k0 = key; }
                         else if (key < k1) k1 = key;
-                    });
+                    }
+                } else {
+                    cache_begin(cb, lane);
+                    if (!w.empty) {
+                        for_window(F, 1, F.keysR, nRight, w, lane, [&](int idx, int cx, int cy) {
+                            const ft_keypoint kp = F.keysR[idx];
+                            if (!in_box(kp, x, y, rad, level - 1, level)) return;
+                            const int g = idx + F.Nleft;
+                            const bool locked = lockedR(g);
+                            if (locked && !cb.build) return;
+                            const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)g * 32));
+                            const unsigned long long key = make_key(dist, cx, cy, idx);
+                            if (cb.build) cache_append(cb, key);
+                            if (locked) return;
+                            if (key < k0) { k1 = k0; k0 = key; }
+                            else if (key < k1) k1 = key;
+                        });
+                    }
+                    cache_end(cb, lane, false);
                 }
                 wave_two_min(k0, k1);
                 if (k0 != KEY_NONE) {
@@ -375,8 +459,9 @@ __global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPo
     const int lane = threadIdx.x & 63, wave = wave_index();
     const int i = blockIdx.x * 4 + wave;
     if (i >= P.M) return;
+    __shared__ int cacheCounter[4];
     int r4[4];
-    local_point(F, P, C, th, nnRatio, i, lane, r4, raw);
+    local_point(F, P, C, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
     claims_file(C, res, i, lane, r4);
 }
 
@@ -413,7 +498,8 @@ __device__ __forceinline__ void transform34(const float *T, const float x[3], fl
 // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) for last-frame point i by one wave (src/ORBmatcher.cc:
 // 1775-1960): r = (left keypoint written, -1, right keypoint written, -1)
 __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastPoints &Lp, const FtClaims &C, const FtPose &Tcw,
-                                           float th, int bForward, int bBackward, int i, int lane, int r4[4], const FtLastRaw &raw) {
+                                           float th, int bForward, int bBackward, int i, int lane, int r4[4], const FtLastRaw &raw,
+                                           int *ldsCounter) {
     int primL = -1, primR = -1;
     int bd = 256, bi = -1, bdr = 256, bir = -1;
     if (Lp.valid[i]) {
@@ -444,23 +530,44 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
             const Window w = cell_window(F, uv[0], uv[1], radius);
             unsigned long long k0 = KEY_NONE;
             int anyCand = 0;
-            if (!w.empty) {
-                for_window(F, 0, F.keys, nLeft, w, lane, [&](int idx, int cx, int cy) {
-                    const ft_keypoint kp = F.keys[idx];
-                    if (!in_box(kp, uv[0], uv[1], radius, minLevel, maxLevel)) return;
-                    anyCand = 1;
-                    if (is_locked(F, C, idx, i)) return;
-                    if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
-                        const float ur = __fsub_rn(uv[0], __fmul_rn(F.mbf, invzc));
-                        const float er = fabsf(__fsub_rn(ur, F.uright[idx]));
-                        if (er > radius) return;
-                    }
-                    const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
-                    const unsigned long long key = make_key(dist, cx, cy, idx);
+            CacheBuild cb;
+            cb.slot = C.cache ? C.cache + (size_t)i * FT_CACHE_WORDS : nullptr;
+            cb.counter = ldsCounter;
+            int nCached;
+            bool anyBox;
+            const int cs = cache_state(cb.slot, nCached, anyBox);
+            cb.build = cs == 0;
+            if (cs == 1) {
+                anyCand = anyBox ? 1 : 0;
+                for (int t = lane; t < nCached; t += 64) {
+                    const unsigned long long key = cb.slot[1 + t];
+                    if (is_locked(F, C, key_idx(key), i)) continue;
                     k0 = key < k0 ? key : k0;
-                });
+                }
+            } else {
+                cache_begin(cb, lane);
+                if (!w.empty) {
+                    for_window(F, 0, F.keys, nLeft, w, lane, [&](int idx, int cx, int cy) {
+                        const ft_keypoint kp = F.keys[idx];
+                        if (!in_box(kp, uv[0], uv[1], radius, minLevel, maxLevel)) return;
+                        anyCand = 1;
+                        const bool locked = is_locked(F, C, idx, i);
+                        if (locked && !cb.build) return;
+                        if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
+                            const float ur = __fsub_rn(uv[0], __fmul_rn(F.mbf, invzc));
+                            const float er = fabsf(__fsub_rn(ur, F.uright[idx]));
+                            if (er > radius) return;
+                        }
+                        const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
+                        const unsigned long long key = make_key(dist, cx, cy, idx);
+                        if (cb.build) cache_append(cb, key);
+                        if (locked) return;
+                        k0 = key < k0 ? key : k0;
+                    });
+                }
+                anyCand = __any(anyCand);
+                cache_end(cb, lane, anyCand != 0);
             }
-            anyCand = __any(anyCand);
             k0 = wave_min_u64(k0);
             // `if(vIndices2.empty()) continue;` (ORBmatcher.cc:1836) also skips the right-camera block
             if (anyCand) {
@@ -476,15 +583,35 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                     const Window wr = cell_window(F, uvr[0], uvr[1], radius);
                     const int nRight = F.N - F.Nleft;
                     unsigned long long kr = KEY_NONE;
-                    if (!wr.empty) {
-                        for_window(F, 1, F.keysR, nRight, wr, lane, [&](int idx, int cx, int cy) {
-                            const ft_keypoint kp = F.keysR[idx];
-                            if (!in_box(kp, uvr[0], uvr[1], radius, minLevel, maxLevel)) return;
-                            if (is_locked(F, C, idx + F.Nleft, i)) return;
-                            const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)(idx + F.Nleft) * 32));
-                            const unsigned long long key = make_key(dist, cx, cy, idx);
+                    CacheBuild cbr;
+                    cbr.slot = C.cache ? C.cache + (size_t)i * FT_CACHE_WORDS + (FT_CACHE_CAP + 1) : nullptr;
+                    cbr.counter = ldsCounter;
+                    int nCachedR;
+                    bool anyBoxR;
+                    const int csr = cache_state(cbr.slot, nCachedR, anyBoxR);
+                    cbr.build = csr == 0;
+                    if (csr == 1) {
+                        for (int t = lane; t < nCachedR; t += 64) {
+                            const unsigned long long key = cbr.slot[1 + t];
+                            if (is_locked(F, C, key_idx(key) + F.Nleft, i)) continue;
                             kr = key < kr ? key : kr;
-                        });
+                        }
+                    } else {
+                        cache_begin(cbr, lane);
+                        if (!wr.empty) {
+                            for_window(F, 1, F.keysR, nRight, wr, lane, [&](int idx, int cx, int cy) {
+                                const ft_keypoint kp = F.keysR[idx];
+                                if (!in_box(kp, uvr[0], uvr[1], radius, minLevel, maxLevel)) return;
+                                const bool locked = is_locked(F, C, idx + F.Nleft, i);
+                                if (locked && !cbr.build) return;
+                                const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)(idx + F.Nleft) * 32));
+                                const unsigned long long key = make_key(dist, cx, cy, idx);
+                                if (cbr.build) cache_append(cbr, key);
+                                if (locked) return;
+                                kr = key < kr ? key : kr;
+                            });
+                        }
+                        cache_end(cbr, lane, false);
                     }
                     kr = wave_min_u64(kr);
                     if (kr != KEY_NONE) {
@@ -508,8 +635,9 @@ __global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoin
     const int lane = threadIdx.x & 63, wave = wave_index();
     const int i = blockIdx.x * 4 + wave;
     if (i >= Lp.N) return;
+    __shared__ int cacheCounter[4];
     int r4[4];
-    last_point(F, Lp, C, Tcw, th, bForward, bBackward, i, lane, r4, raw);
+    last_point(F, Lp, C, Tcw, th, bForward, bBackward, i, lane, r4, raw, &cacheCounter[wave]);
     claims_file(C, res, i, lane, r4);
 }
 
@@ -620,6 +748,11 @@ __global__ __launch_bounds__(256) void k_deliver_blocks(FtBlocks b) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_fill_stride_u64(unsigned long long *p, int n, int strideWords, unsigned long long v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[(size_t)i * strideWords] = v;
+}
+
 __global__ __launch_bounds__(256) void k_fill_i32(int *p, int n, int v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
@@ -636,6 +769,13 @@ int ft_launch_deliver_blocks(hipStream_t st, void *d0, const void *s0, size_t by
     const int total = b.words[0] + b.words[1] + b.words[2];
     if (total <= 0) return FT_OK;
     hipLaunchKernelGGL(k_deliver_blocks, dim3(std::max(1, std::min(64, (total + 1023) / 1024))), dim3(256), 0, st, b);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_fill_stride_u64(hipStream_t st, unsigned long long *p, int n, int strideWords, unsigned long long v) {
+    if (n <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_fill_stride_u64, dim3((n + 255) / 256), dim3(256), 0, st, p, n, strideWords, v);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -107,6 +107,7 @@ FtDevFrame devFrame(const ft_frame_view *F, const FrameLayout &L, uint8_t *dev) 
 struct PassBufs {
     int *res, *head, *next;
     const int *obs;
+    unsigned long long *cache;  // FT_CACHE_WORDS per point, or null (FT_SEARCH_CACHE=0)
 };
 // `download(res, flags, nFlagBytes)` enqueues ONE delivery kernel that writes the pass results `res`, whatever else the
 // caller needs and the burst's flags into pinned host memory (hostFlags); it runs behind every burst, in front of the one
@@ -128,7 +129,13 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
     {   // list heads = -1, flags = "unchanged" (-1)
         const int rcf = ft_launch_fill_i32(st, B.head, (int)(3 * K + 16), -1);
         if (rcf != FT_OK) return rcf;
+        // candidate cache: ~0 in a slot's first word = "not built yet"
+        if (B.cache) {
+            const int rcc = ft_launch_fill_stride_u64(st, B.cache, 2 * nPoints, FT_CACHE_CAP + 1, ~0ull);
+            if (rcc != FT_OK) return rcc;
+        }
     }
+    C.cache = B.cache;
     int pass = 0, burst = 0;
     const int maxPasses = 2 * nPoints + 4 + FT_PASS_BURST;
     C.obs = B.obs;
@@ -174,21 +181,33 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
 
 // arena space of the claim iteration for M points on a frame of N keypoints
 struct PassLayout {
-    size_t res, head, next;
+    size_t res, head, next, cache;
+    bool haveCache;
 };
-PassLayout layoutPasses(Arena &a, int M, int N) {
+bool searchCacheOn() {
+    static const bool on = !(getenv("FT_SEARCH_CACHE") && atoi(getenv("FT_SEARCH_CACHE")) == 0);
+    return on;
+}
+size_t searchCacheBytes(int M) { return 8 * (size_t)FT_CACHE_WORDS * (size_t)std::max(M, 1); }
+// cacheInArena: the candidate cache (device only, 8 KB per point) lives at the end of the arena - the stand-alone searches,
+// whose arena sizes the context's device scratch; a tracked frame owns a cache buffer of its own, so that its pinned mirror
+// of the arena stays small
+PassLayout layoutPasses(Arena &a, int M, int N, bool cacheInArena) {
     PassLayout L;
     L.res = a.take(32 * (size_t)M);
     L.head = a.take(12 * (size_t)std::max(N, 1) + 64);
     L.next = a.take(32 * (size_t)M);
+    L.haveCache = cacheInArena && searchCacheOn();
+    L.cache = L.haveCache ? a.take(searchCacheBytes(M)) : 0;
     return L;
 }
-PassBufs passBufs(const PassLayout &L, uint8_t *dev, const int *obs) {
+PassBufs passBufs(const PassLayout &L, uint8_t *dev, const int *obs, unsigned long long *ownCache = nullptr) {
     PassBufs B;
     B.res = (int *)(dev + L.res);
     B.head = (int *)(dev + L.head);
     B.next = (int *)(dev + L.next);
     B.obs = obs;
+    B.cache = L.haveCache ? (unsigned long long *)(dev + L.cache) : ownCache;
     return B;
 }
 // Frame::mGrid of a frame staged in the arena: CSR arrays behind the frame's own, built by one small launch
@@ -417,6 +436,7 @@ void unpackFrustum(int M, const FrustumLayout &L, size_t outBegin, uint8_t *pin,
 // arrays in HBM; the scalar part of the frame, the host copy of the keypoints (angles for the rotation histogram)
 // and the authoritative holder_obs live on the host and are cheap (a few KB per frame).
 struct ft_tracked_frame {
+    unsigned long long *d_cache = nullptr;  // candidate cache of the claim iteration (FtClaims::cache), maxPts points
     bool counted = false;  // registered with the context (ft_context::liveObjects)
     ft_context *ctx = nullptr;
     int maxKp = 0, maxPts = 0;
@@ -488,7 +508,7 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
                  oPyr = a.take(4 * (size_t)M);
     const size_t oDesc = a.take(32 * (size_t)M), oObs = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const PassLayout PL = layoutPasses(a, M, N);
+    const PassLayout PL = layoutPasses(a, M, N, true);
     const size_t oGrid = layoutGrid(a, N);
     const size_t oRaw = a.take(40 * (size_t)M);
     const size_t total = a.off;
@@ -580,7 +600,7 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     const size_t oValid = a.take(M), oPos = a.take(12 * (size_t)M), oDesc = a.take(32 * (size_t)M),
                  oObs = a.take(4 * (size_t)M), oOct = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const PassLayout PL = layoutPasses(a, M, N);
+    const PassLayout PL = layoutPasses(a, M, N, true);
     const size_t oGrid = layoutGrid(a, N);
     const size_t oRaw = a.take(16 * (size_t)M);
     const size_t total = a.off;
@@ -778,6 +798,7 @@ int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, 
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_r2l, sizeof(int) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_work, tf->workBytes);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_grid, sizeof(int) * (2 * (size_t)(FT_GRID_CELLS + 1) + K));
+    if (e == hipSuccess && searchCacheOn()) e = hipMalloc((void **)&tf->d_cache, searchCacheBytes(max_points));
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_work, tf->workBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_holderUp, sizeof(int) * K, hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -796,6 +817,7 @@ int ft_tracked_frame_destroy(ft_tracked_frame *tf) {
     hipStreamSynchronize(tf->ctx->stream);
     hipFree(tf->d_keys); hipFree(tf->d_keysR); hipFree(tf->d_desc); hipFree(tf->d_uright);
     hipFree(tf->d_holder); hipFree(tf->d_l2r); hipFree(tf->d_r2l); hipFree(tf->d_work); hipFree(tf->d_grid);
+    if (tf->d_cache) hipFree(tf->d_cache);
     if (tf->h_work) hipHostFree(tf->h_work);
     if (tf->h_holderUp) hipHostFree(tf->h_holderUp);
     if (tf->counted) tf->ctx->liveObjects--;
@@ -903,7 +925,7 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     const size_t oValid = a.take(M), oPos = a.take(12 * (size_t)M), oDesc = a.take(32 * (size_t)M),
                  oObs = a.take(4 * (size_t)M), oOct = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const PassLayout PL = layoutPasses(a, M, N);
+    const PassLayout PL = layoutPasses(a, M, N, false);
     FT_REQUIRE(a.off <= tf->workBytes, "tracked frame work arena too small");
     uint8_t *pin = tf->h_work, *dev = tf->d_work;
     memcpy(pin + oValid, L->valid, M);
@@ -926,7 +948,7 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     FtLastRaw raw = {nullptr, nullptr, nullptr, nullptr};
     int *resFinal = nullptr, passes = 0;
     const FtDevFrame DF = tf->DF;
-    rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs), C,
+    rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs, tf->d_cache), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
                     [&](int *res, const int *fl, size_t flBytes) -> int {
                         return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M, fl, flBytes, nullptr, nullptr, 0);
@@ -970,7 +992,7 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
     layoutFrustum(M, P->skip != nullptr, a, FL, &fInputEnd);
     const size_t fOutEnd = a.off;
     const size_t oDesc = a.take(32 * (size_t)M), oObs = a.take(4 * (size_t)M);
-    const PassLayout PL = layoutPasses(a, M, N);
+    const PassLayout PL = layoutPasses(a, M, N, false);
     FT_REQUIRE(a.off <= tf->workBytes, "tracked frame work arena too small");
     uint8_t *pin = tf->h_work, *dev = tf->d_work;
     stageFrustum(P, FL, pin);
@@ -999,7 +1021,7 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
         FtLocalRaw raw;
         memset(&raw, 0, sizeof raw);
         int *resFinal = nullptr;
-        rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs), C,
+        rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs, tf->d_cache), C,
                         [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); },
                         [&](int *res, const int *fl, size_t flBytes) -> int {  // pass results, frustum fields and flags: one kernel
                             return ft_launch_deliver_blocks(st, pin + fOutEnd, res, 16 * (size_t)M, pin, dev + fInputEnd, fOutEnd - fInputEnd,

@@ -338,8 +338,10 @@ def _frame_views(fr, sf, w, h, uright=None, holder=None):
     return ob.FrameView(scale_factors_=sf, **args), orb.FrameView(scale_factors=sf, **args)
 
 
-@pytest.mark.parametrize("th,dense", [(1.0, False), (3.0, False), (7.0, True), (15.0, True)])
+@pytest.mark.parametrize("th,dense", [(1.0, False), (3.0, False), (7.0, True), (15.0, True), (60.0, True)])
 def test_search_local_points_mono_stereo(ctx, th, dense):
+    """(th 60: windows with more candidates than the claim iteration's candidate cache holds per point - those points scan
+    their window again in every pass, the others walk their cached keys)"""
     w, h, nf = 752, 480, 1200
     fr = sc.oracle_stereo_frame(w, h, nf, 12)
     sf, _ = ob.scale_factors(1.2, 8)
@@ -376,7 +378,8 @@ def test_search_local_points_two_cameras(ctx):
         assert np.array_equal(g[k], o[k]), k
 
 
-@pytest.mark.parametrize("th,fwd,bwd,ori", [(7.0, False, False, True), (15.0, True, False, True), (15.0, False, True, False)])
+@pytest.mark.parametrize("th,fwd,bwd,ori", [(7.0, False, False, True), (15.0, True, False, True), (15.0, False, True, False),
+                                           (90.0, False, True, True)])
 def test_search_last_frame_pinhole(ctx, th, fwd, bwd, ori):
     w, h, nf = 752, 480, 1200
     fr = sc.oracle_stereo_frame(w, h, nf, 14)
@@ -757,3 +760,47 @@ def test_stereo_frontend_graph_replay(ctx):
     oL = ob.Extractor(nf)
     kL, dL, _ = oL.extract(frames[0][0][0])
     assert np.array_equal(fe._kL[0, :int(fe._nL[0])], kL)
+
+
+def test_candidate_cache_changes_nothing(ctx):
+    """the claim iteration with and without its candidate cache (FT_SEARCH_CACHE=0, read once per process): the resident-frame
+    tracking sequence on a two-camera KB8 frame at th 7 and 15 gives identical assignments and frustum fields"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+from fasttrack_amd import orb, scenarios as sc, synth
+ctx = orb.Context(0)
+w, h, nf = 512, 512, 2000
+ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=2)
+L, R = synth.make_planes_pair(w, h, seed=77)
+(kL, dL, _), (kR, dR, _) = ex.extract_batch([L, R], (0, 511))
+m = orb.KernelController.launchFisheyeStereoMatchKernel(ctx, dL, dR)["matches"].astype(np.int32)
+r2l = np.full(len(kR), -1, np.int32); ok = m >= 0; r2l[m[ok]] = np.nonzero(ok)[0]
+sf = np.asarray(ex.GetScaleFactors(), np.float32)
+cam = list(sc.KB8_CAM); intr = dict(fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+Trl = np.concatenate([np.eye(3), [[-0.101], [0.0], [0.0]]], 1).astype(np.float32)
+F = orb.FrameView(keys=kL, keys_right=kR, descriptors=np.concatenate([dL, dR]), scale_factors=sf, bounds=sc.frame_bounds(w, h),
+                  left_to_right=m, right_to_left=r2l, cam_model=1, cam=cam, Trl=Trl)
+depth = np.zeros(len(kL), np.float32)
+last, Tcw = sc.last_frame_scenario(kL, dL, None, depth, intr, w, h, seed=3)
+pts, Rcw, tcw = sc.map_points_scenario(kL, dL, depth, intr, 8, sf, 4, M=2000)
+tf = orb.TrackedFrame(ctx, 2 * ex.max_keypoints + 64, 4096)
+hs = hashlib.sha256()
+for th in (7.0, 15.0):
+    tf.upload(F)
+    a = tf.search_last_frame(last, Tcw, th)
+    b = tf.track_local_map(orb.make_pose(Rcw, tcw, (0.101, 0.0, 0.0)), pts, 0.5, float(np.float32(np.log(np.float32(1.2)))), th)
+    assert a["n"] > 100 and b["n"] > 100
+    for x in (a["assign"], b["assign"], b["level"], b["proj_x"], tf.holder_obs()):
+        hs.update(np.ascontiguousarray(x).tobytes())
+print("HASH", hs.hexdigest(), ctx.get_stat("tracked.track_local_map.passes")[0])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for cache in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, FT_SEARCH_CACHE=cache))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][-1])
+    assert outs[0] == outs[1], outs
