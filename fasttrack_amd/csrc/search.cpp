@@ -101,7 +101,18 @@ FtDevFrame devFrame(const ft_frame_view *F, const FrameLayout &L, uint8_t *dev) 
 // when the fixed point has been reached (it would reproduce its input), so the surplus passes of a burst cost an empty
 // launch each while every avoided round trip (D2H of the flags + stream sync) costs ~100 us.  One memset (0xff: list heads
 // = -1, flags = "unchanged") prepares a call.
-#define FT_PASS_BURST 6
+#define FT_PASS_BURST_MAX 14  // flag slots per burst parity (16) and the 64-byte flag window of the pinned result area bound it
+// passes per burst: with the candidate cache a pass is ~12 us and an early-exit pass ~5 us, a round trip to the host ~40 us,
+// and a search needs 9 - 13 passes - one burst of 12 mostly does it (FT_PASS_BURST=<n> to experiment)
+static int passBurst() {
+    static const int n = [] {
+        const char *e = getenv("FT_PASS_BURST");
+        const int v = e ? atoi(e) : 12;
+        return std::min(std::max(v, 2), FT_PASS_BURST_MAX);
+    }();
+    return n;
+}
+#define FT_PASS_BURST (passBurst())
 // device buffers of the claim iteration: res 2 x 4 nPoints ints, head 3 x nKp directly followed by 16 flag ints (two burst
 // parities x FT_PASS_BURST), next 2 x 4 nPoints
 struct PassBufs {
@@ -127,7 +138,7 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
     const size_t K = (size_t)std::max(nKp, 1);
     int *flags = B.head + 3 * K;
     {   // list heads = -1, flags = "unchanged" (-1)
-        const int rcf = ft_launch_fill_i32(st, B.head, (int)(3 * K + 16), -1);
+        const int rcf = ft_launch_fill_i32(st, B.head, (int)(3 * K + 32), -1);
         if (rcf != FT_OK) return rcf;
         // candidate cache: ~0 in a slot's first word = "not built yet"
         if (B.cache) {
@@ -142,7 +153,7 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
     C.nKp = nKp;
     int *last = B.res;
     for (;; burst++) {
-        int *fl = flags + 8 * (burst & 1), *flOther = flags + 8 * ((burst + 1) & 1);
+        int *fl = flags + 16 * (burst & 1), *flOther = flags + 16 * ((burst + 1) & 1);
         for (int b = 0; b < FT_PASS_BURST; b++, pass++) {
             C.firstPass = pass == 0;
             C.head = B.head + (size_t)(pass % 3) * K;
@@ -195,7 +206,7 @@ size_t searchCacheBytes(int M) { return 8 * (size_t)FT_CACHE_WORDS * (size_t)std
 PassLayout layoutPasses(Arena &a, int M, int N, bool cacheInArena) {
     PassLayout L;
     L.res = a.take(32 * (size_t)M);
-    L.head = a.take(12 * (size_t)std::max(N, 1) + 64);
+    L.head = a.take(12 * (size_t)std::max(N, 1) + 128);
     L.next = a.take(32 * (size_t)M);
     L.haveCache = cacheInArena && searchCacheOn();
     L.cache = L.haveCache ? a.take(searchCacheBytes(M)) : 0;
