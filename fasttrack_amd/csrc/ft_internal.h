@@ -121,7 +121,7 @@ struct FtTap {
 #define FT_OCT_HISTMIN 16      // workgroups of the histogram tier while no batch has asked for more (each walks the list)
 #define FT_OCT_HIST_RETIRE 2   // batches without a listed level after which the histogram tier is not launched any more
 #ifndef FT_OCT_HISTMAX
-#define FT_OCT_HISTMAX 512     // ... and at most (two or three fit a CU)
+#define FT_OCT_HISTMAX 768     // ... and at most (three fit a CU)
 #endif
 #define FT_OCT_BIGMIN 64   // smallest grid of the sorted big tier (k_octree_big) once a stream of frames needs it
 struct FtOctArgs {
