@@ -189,7 +189,13 @@ def stereo_leg(orb, ctx, name, w, h, nf, B, steps, warmup, mosaic=0, planes=Fals
             fes[k % 2].wait()
             done_at.append(time.perf_counter())
     f0 = ctx.get_stat("stereo.device_octree_fallbacks")[1]
-    run(max(warmup, 2))  # (the first dense batches size the octree's histogram tier)
+    # warm-up: at least `warmup` steps (the first dense batches size the octree's histogram tier) AND at least 0.4 s - a leg
+    # starts behind CPU-side work (scene generation, the previous leg's CPU baseline), and a leg of 0.2 s measured on a GPU that
+    # is still ramping its clocks up read 20 % low (122 k against 154 k frames/s for the 752x480 leg in two otherwise equal runs)
+    run(max(warmup, 2))
+    tw0 = time.perf_counter()
+    while time.perf_counter() - tw0 < 0.4:
+        run(4)
     f1 = ctx.get_stat("stereo.device_octree_fallbacks")[1]
     ctx.synchronize()
     t0 = time.perf_counter()
@@ -293,8 +299,11 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
            "camera": "KannalaBrandt8 stereo rig, lapping areas [0, 511]", "local_map_points": M, "mode": "one frame at a time (latency mode), host images in, host results out",
            "scene_kind": "object scene on fronto-parallel planes", "distinct_frames": D, "by_th": {}}
     for th in (7.0, 15.0):
-        for k in range(warmup):
+        tw0 = time.perf_counter()
+        k = 0
+        while k < warmup or time.perf_counter() - tw0 < 0.3:  # (clocks: see stereo_leg)
             frame(k % D, th)
+            k += 1
         ctx.synchronize()
         npts = ncmp = nmatch = 0
         ctx.reset_stats()
