@@ -480,6 +480,9 @@ int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent
     a.histCap = histNow ? nb * g.nlevels : 0;
     a.histGrid = large ? std::min(ex->histGrid, nb * g.nlevels) : nb * g.nlevels;
     a.histWanted = ex->histEnabled && !histNow ? 1 : 0;
+    // launches of a frame or two: the histogram formulation for every level (no sort: the last level is done sooner)
+    a.histFirst = ex->histEnabled && (ex->histFirstMode == 2 || (ex->histFirstMode == 1 && !large)) ? 1 : 0;
+    if (a.histFirst) a.histCap = a.histGrid = a.histWanted = 0;  // no list: a workgroup per (level, image)
     a.sortCap = a.bigN ? std::min(ex->bigGrid, nb * g.nlevels) : 0;
     // one set of lists and counters per octree stream: the launches of two sub-batches run side by side
     a.bigCount = ex->d_bigCount + 4 * (sub % FT_OCT_STREAMS);
@@ -549,7 +552,7 @@ void ft_extract_update_big_grid(ft_extractor *ex) {
         // histogram tier on for the frames that follow, one more the sorted big tier (the captured graph is re-captured: its
         // key holds both)
         if (ex->h_overflow[0]) {
-            if (ex->histEnabled && !ex->histOn) ex->histOn = true;
+            if (ex->histEnabled && ex->histFirstMode == 0 && !ex->histOn) ex->histOn = true;
             else if (ex->octLayout.bigN && ex->bigGrid == 0) ex->bigGrid = ex->maxBatch * ex->nlevels;
         }
         return;
@@ -933,9 +936,10 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         // the node pools must fit a CU's LDS beside FT_OCT_MAXN keys (per-level quotas up to ~1900); u16 node indices
         (void)maxQ;
         ex->deviceOctree = !(e && e[0] == '0') && o.poolCap < 30000 && ft_octree_smem_bytes(o.poolCap) <= 160 * 1024;
-        o.histCap = o.sortCap = o.histGrid = o.histWanted = 0;
+        o.histCap = o.sortCap = o.histGrid = o.histWanted = o.histFirst = 0;
         ex->histEnabled = ex->deviceOctree && !(getenv("FT_OCT_HIST") && atoi(getenv("FT_OCT_HIST")) == 0) &&
                           ft_octree_hist_smem_bytes(o.poolCap) <= 160 * 1024;
+        ex->histFirstMode = getenv("FT_OCT_HIST_FIRST") ? atoi(getenv("FT_OCT_HIST_FIRST")) : 1;
         o.bigN = ex->deviceOctree && !(getenv("FT_OCT_BIG") && atoi(getenv("FT_OCT_BIG")) == 0) ? ft_octree_big_keys(o.poolCap) : 0;
         o.bigCount = ex->d_bigCount;
         o.bigList = ex->d_bigList;
@@ -1408,6 +1412,7 @@ int ft_extractor_octree_on_device(ft_extractor *ex, int level, const int *xys, i
     a.histCap = (tiers & 2) && ex->histEnabled ? g.nlevels : 0;
     a.histGrid = g.nlevels;
     a.histWanted = 0;
+    a.histFirst = (tiers & 8) && ex->histEnabled ? 1 : 0;  // bit 3: the histogram formulation for every level, as latency-mode launches run it
     a.sortCap = (tiers & 4) && a.bigN ? g.nlevels : 0;
     a.bigCount = ex->d_bigCount;
     a.bigList = ex->d_bigList;
@@ -1422,7 +1427,7 @@ int ft_extractor_octree_on_device(ft_extractor *ex, int level, const int *xys, i
     FT_HIP(hipMemset(ex->d_overflow, 0, sizeof(int)));
     FT_HIP(hipMemset(ex->d_ovSlot, 0, sizeof(int)));
     FT_HIP(hipMemset(ex->d_bigCount, 0, 4 * sizeof(int)));
-    *tier = ov ? 0 : cnt[1] > 0 ? 3 : cnt[0] > 0 ? 2 : 1;
+    *tier = ov ? 0 : cnt[1] > 0 ? 3 : (cnt[0] > 0 || a.histFirst) ? 2 : 1;
     if (ov) k = 0;
     *n_out = k;
     if (k > capacity) {

@@ -176,6 +176,7 @@ struct ft_extractor {
     uint32_t *h_repCand = nullptr;   // pinned candidate lists of the slots under per-image repair (repCap slots, grow-only)
     int repCap = 0;
     bool histEnabled = false;        // k_octree_hist available (FT_OCT_HIST=0 switches it off)
+    int histFirstMode = 1;           // FT_OCT_HIST_FIRST: 0 never, 1 (default) in latency-mode launches, 2 always
     bool histOn = false;             // latency mode: launched since a frame overflowed the first tier (large batches: always)
     int histGrid = FT_OCT_HISTMIN;   // workgroups of k_octree_hist for large batches: by the demand of the previous ones
     int histIdle = 0;

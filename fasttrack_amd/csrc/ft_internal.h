@@ -140,6 +140,7 @@ struct FtOctArgs {
     unsigned *bigList, *sortList;
     int histCap, histGrid, sortCap, bigN;  // histGrid: workgroups of k_octree_hist (they walk the list)
     int histWanted;                        // the histogram tier exists but is not launched now: count its demand all the same
+    int histFirst;                         // the histogram formulation runs every level (k_octree_hist_all); give-ups -> k_octree_big
     int quota[FT_MAX_LEVELS], levelMax[FT_MAX_LEVELS], selOff[FT_MAX_LEVELS];
     int poolCap, keyBytes;
     unsigned long long *prof;  // FT_OCT_PROFILE=1: per-level phase times of slot 0 (wall_clock64 ticks), else null

@@ -826,6 +826,50 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree_hist(FtGeom g, FtOctArgs
     }
 }
 
+// Launches of a frame or two (latency mode; FtOctArgs::histFirst): one workgroup per (level, image) picks the formulation
+// by the level's numbers.  Plenty of candidates for the quota (n >= 1.5 N) -> the histogram formulation: without the 512-
+// thread bitonic sort (29 of the 102 us of a 1280x720 level 0) and with table look-ups instead of binary searches in the
+// rounds the level - and with it the frame - is done sooner (extraction of a 1280x720 frame 0.269 -> 0.239 ms).  Fewer
+// candidates than that and the tree is split until every node holds one key, far below the histogram's depth (measured on
+// the test frames: every level with n < 1.3 N gives up, none above) -> the sorted formulation at once; it also takes over,
+// in the same workgroup, a level the histogram gave up on after all (nothing has been written by then).  Only a level with
+// more than FT_OCT_MAXN candidates AND a tree deeper than the table leaves the kernel: to k_octree_big, or to the host.
+// (Launches that fill the chip keep the sorted tier first and the histogram tier behind it: there the two formulations
+// cost the same)
+__global__ __launch_bounds__(OCT_THREADS) void k_octree_auto(FtGeom g, FtOctArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __builtin_amdgcn_s_setprio(3);
+    const int slot = (int)blockIdx.x, level = (int)blockIdx.y;
+    const int n = a.candCount[slot * g.nlevels + level];
+    const int N = a.quota[level];
+    bool done = false;
+    if (2 * n >= 3 * N || n > FT_OCT_MAXN) done = oct_level<true>(g, a, slot, level, 0, smem);  // wave- and block-uniform
+    if (done) return;
+    if (n <= FT_OCT_MAXN) {
+        __syncthreads();  // the histogram formulation's LDS is dead
+        FtOctArgs b = a;
+        b.histCap = 0;  // (n <= FT_OCT_MAXN: the sorted formulation never lists the level)
+        oct_level<false>(g, b, slot, level, FT_OCT_MAXN, smem);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        bool ok = false;
+        if (n <= a.bigN) {
+            const int idx = atomicAdd(a.bigCount + 1, 1);
+            atomicMax(a.bigCount + 3, idx + 1);  // the host sizes the sorted big tier of the following frames by this
+            if (idx < a.sortCap) {
+                a.sortList[idx] = (unsigned)slot | ((unsigned)level << 16);
+                ok = true;
+            }
+        }
+        if (!ok) {
+            a.selCount[slot * g.nlevels + level] = 0;
+            atomicOr(a.overflow, 1);
+            a.ovSlot[slot] = 1;
+        }
+    }
+}
+
 // The levels the histogram tier gave up on: the sorted formulation with an LDS layout for a.bigN keys (up to the whole
 // 160 KB of a CU).  A workgroup that needs a CU's whole LDS waits for a CU to drain even if it has nothing to do, so the
 // kernel is only launched while the stream of frames needs it, with a grid the host sizes from the demand of the previous
@@ -859,6 +903,18 @@ int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs
     const size_t smemBig = a.bigN ? (size_t)oct_lds_layout(a.poolCap, a.bigN * 8, false).total : 0;
     if (a.bigN && a.sortCap > 0)
         FT_HIP(hipFuncSetAttribute((const void *)k_octree_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemBig));
+    if (a.histFirst) {
+        const size_t smemAll = std::max(ft_octree_hist_smem_bytes(a.poolCap), smem);
+        if (smemAll > 64 * 1024)
+            FT_HIP(hipFuncSetAttribute((const void *)k_octree_auto, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemAll));
+        for (int rep = ft_debug_repeat("octree"); rep > 0; rep--) {
+            if (a.bigN) FT_HIP(hipMemsetAsync(a.bigCount, 0, 2 * sizeof(int), st));
+            hipLaunchKernelGGL(k_octree_auto, dim3(batch, g.nlevels), dim3(OCT_THREADS), smemAll, st, g, a);
+            if (a.bigN && a.sortCap > 0) hipLaunchKernelGGL(k_octree_big, dim3(a.sortCap), dim3(OCT_THREADS), smemBig, st, g, a);
+        }
+        FT_HIP(hipGetLastError());
+        return FT_OK;
+    }
     for (int rep = ft_debug_repeat("octree"); rep > 0; rep--) {
         // the list counters of the launch ([2] and [3], the demand, are the host's to reset)
         if (a.bigN || a.histCap > 0) FT_HIP(hipMemsetAsync(a.bigCount, 0, 2 * sizeof(int), st));

@@ -158,7 +158,8 @@ FT_API int ft_extractor_download_candidates(ft_extractor *ex, int slot, int leve
 /* stage tap for parity tests: the DEVICE formulation of DistributeOctTree (ORBextractor.cc:660-884) of one level on
  * caller-provided candidates ((x, y, score) triples relative to the level's (minBorderX, minBorderY), any order: the
  * kernels rank them by the reference's emission order themselves).  tiers: bit 1 allows the histogram tier
- * (k_octree_hist), bit 2 the sorted big tier (k_octree_big); *tier = the tier that produced the result (1, 2, 3), 0 = the
+ * (k_octree_hist), bit 2 the sorted big tier (k_octree_big), bit 3 selects the kernel of latency-mode launches
+ * (k_octree_auto: reported as tier 2); *tier = the tier that produced the result (1, 2, 3), 0 = the
  * level is beyond the allowed tiers (the pipeline would repair the image with the host octree).  out_xys: the retained
  * candidates in the reference's result order. */
 FT_API int ft_extractor_octree_on_device(ft_extractor *ex, int level, const int *xys, int n, int tiers, int *out_xys,
