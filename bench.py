@@ -629,6 +629,23 @@ def main():
             roof["at_marginal_cost"] = {"ms_per_launch": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                                         "source": "profiles/r03_marginal_costs.json (tools/marginal_costs.py: FT_DEBUG_REPEAT=fast, same workload)"}
         also = sorted(legs[1:], key=lambda x: -x["total_ms"])
+        # The ceiling this integer / bitwise path really works against: vector-instruction issue.  Wave-level vector
+        # instructions of the timed region (per-launch counts of the committed SQ pass x this run's launches) x 4 cycles each
+        # on a 16-lane SIMD / (1 024 SIMDs x 2.4 GHz x elapsed).  Reported when the run's inputs equal the profiled ones.
+        valu_frac = None
+        if same_inputs:
+            pairs_ = (("kernel.fast_cells", "k_fast_cells"), ("kernel.orient_desc", "k_orient_desc"), ("kernel.pyr_down(all levels)", "k_pyr_rows"),
+                      ("kernel.octree", "k_octree"), ("kernel.stereo_match", "k_stereo_match"))
+            tot_valu = 0.0
+            for stat, kname in pairs_:
+                t = tk.get(kname)
+                n = kern[stat]["launches"]
+                if not t or not n or "valu_per_launch" not in t:
+                    tot_valu = None
+                    break
+                tot_valu += t["valu_per_launch"] * n * (7 if kname == "k_pyr_rows" else 1)  # the pyramid stat groups 7 launches
+            if tot_valu:
+                valu_frac = tot_valu * 4.0 / (1024 * 2.4e9 * elapsed_rank)
         R_pair = 2 * (3 * sumP - P[-1])  # read bytes per stereo pair, unfused accounting
         out = {
             "metric": "frames/sec extract+match", "value": fps, "unit": "frames/s", "n_gpus": world,
@@ -654,6 +671,7 @@ def main():
             "stereo_match_fraction": matches / max(kpsL, 1),
             "device_octree_fallbacks": fallbacks,
             "pipeline_hbm_read_frac": fps / world * R_pair / (HBM_PEAK_GBS * 1e9),
+            "pipeline_valu_issue_frac": valu_frac,
             "kernels": kern, "host_ms_per_step": host,
             "roofline": roof,
             "roofline_other_kernels": also,
