@@ -1366,7 +1366,9 @@ __global__ __launch_bounds__(256) void k_compact(FtGeom g, const int *cellCount,
 #ifndef OD_LAYOUT
 #define OD_LAYOUT 1             // 0: horizontally blurred rows row-major (seven scattered u16 reads per sample); 1: column-major
 #endif                          // (the seven values of a sample are consecutive: two ds_read2_b32 + three v_alignbit)
+#ifndef OD_RP
 #define OD_RP 44                // column-major layout: u16 slots per column (43 rows + 1: dword-aligned columns)
+#endif
 #define OD_RAW_BYTES (OD_P * OD_PP)                  // 2064
 #define OD_HB_BYTES (OD_LAYOUT ? OD_HP * OD_RP * 2 + 16 : OD_P * OD_HP * 2)  // 3536 / 3440
 #define OD_WAVE_BYTES ((OD_RAW_BYTES + OD_HB_BYTES + 15) & ~15)
