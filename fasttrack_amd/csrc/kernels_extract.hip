@@ -511,7 +511,9 @@ __device__ __forceinline__ unsigned fast_score2(unsigned v, const unsigned p[16]
 // instruction immediate, TP == 0 is the any-size fallback.
 // LDS carve (bytes): tile th*tp | score (ph+2)*tp | candidate ring FC_CAND u16 | corner list FC_CORN u16 ;
 // the survivor flags reuse the tile once the scores are final.
+#ifndef FC_CAND
 #define FC_CAND 512   // candidates buffered between the rejection test and the score pass
+#endif
 #ifndef FC_XCD_RUN
 #define FC_XCD_RUN 8
 #endif
@@ -522,7 +524,12 @@ __device__ __forceinline__ unsigned fast_score2(unsigned v, const unsigned p[16]
 #define FC_ROWS 4     // rows per trip of the column-mapped rejection pass (>= 3)
 #endif
 #define FC_NMS_REG 2  // corner-list chunks (64 corners each) whose NMS flags stay in registers
+#ifndef FC_CORN
 #define FC_CORN 256   // corners kept for NMS / emission; a cell with more falls back to scanning the plane
+#endif
+#ifndef FC_WAVES_PER_EU
+#define FC_WAVES_PER_EU 1
+#endif
 __host__ __device__ __forceinline__ int fc_pitch(int wCell, int TP) { return TP ? TP : ((wCell + 12) & ~3); }
 __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int TP) {
     // the flags of the slow path need one byte per tested pixel
@@ -538,7 +545,7 @@ __host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + 
 // visit the pixels in any order and uses all 64 lanes (see below); ORDERED = true delivers every cell's
 // candidates row-major, as the host octree expects them.
 template <int TP, bool ORDERED>
-__global__ __launch_bounds__(64) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
+__global__ __launch_bounds__(64, FC_WAVES_PER_EU) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
                                                    int iniTh, int minTh, int alignedLoads, int *cellCount,
                                                    uint32_t *stage, const FtCellRec *cellTab, FtSlotGrid sg, int dbg, int tileBytes,
                                                    int scoreBytesMax) {
@@ -1812,6 +1819,12 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
                                  : k_fast_cells<0, true>;  // any-size cells: the linear pass is ordered anyway
     if (smem > 64 * 1024)  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
         FT_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    static const bool occDbg = getenv("FT_DEBUG_OCC") != nullptr;  // resident workgroups per CU as the runtime computes them
+    if (occDbg) {
+        int nb = 0;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fn, 64, smem);
+        fprintf(stderr, "[ft] k_fast_cells<%d,%d>: %zu B of LDS per wave, %d waves per CU\n", TP, ordered, smem, nb);
+    }
     for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
         hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab, sg, dbg,
                            tileBytes, scoreBytes);
@@ -1883,6 +1896,13 @@ int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint
     const int kpw = batch >= 8 ? OD_KPW_WIDE : 1;
     const FtSlotGrid sg = ft_slot_grid((g.maxKp + OD_WAVES * kpw - 1) / (OD_WAVES * kpw), batch, grid);
     const size_t smem = OD_WAVES * (size_t)OD_WAVE_BYTES;
+    static const bool occDbg = getenv("FT_DEBUG_OCC") != nullptr;
+    if (occDbg) {
+        int nb = 0;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kpw == 1 ? (const void *)k_orient_desc<1> : (const void *)k_orient_desc<OD_KPW_WIDE>,
+                                                     64 * OD_WAVES, smem);
+        fprintf(stderr, "[ft] k_orient_desc<%d>: %zu B of LDS per workgroup, %d workgroups per CU\n", kpw, smem, nb);
+    }
     for (int rep = ft_debug_repeat("orient"); rep > 0; rep--) {
         if (kpw == 1)
             hipLaunchKernelGGL(k_orient_desc<1>, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, selCount, layout,
