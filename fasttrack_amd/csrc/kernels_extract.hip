@@ -250,6 +250,9 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
 // ------------------------------------------------------------------------------------------------
 #define PR_COLS 128
 #define PR_RB 32
+#ifndef PR_PF
+#define PR_PF 4       // source rows in flight ahead of the one being used
+#endif
 typedef unsigned short ft_us2 __attribute__((ext_vector_type(2)));
 typedef unsigned ft_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned udot2_u16(unsigned a, unsigned b) {
@@ -350,7 +353,9 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
             pfLeft--;
             return v;
         };
-        ft_u2 q0 = prefetch(), q1 = prefetch(), q2 = prefetch(), q3 = prefetch();
+        ft_u2 q[PR_PF];
+#pragma unroll
+        for (int k = 0; k < PR_PF; k++) q[k] = prefetch();
         unsigned hpA = 0, hpB = 0, hcA = 0, hcB = 0;
         // a source row is used up by its two horizontal interpolations; the next row of the ring is requested into the same
         // registers right behind them (requested before, it would need registers of its own and the ring would have to be
@@ -393,13 +398,14 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
             }
             r++;
         };
-        // whole trips of four: the up to three steps behind the last source row see the last row again (the prefetch
-        // pointer stops there) and write nothing, since every output row is done by then (sy1 = -1)
-        for (int left = rLast - r + 1; left > 0; left -= 4) {
-            take(q0); step();
-            take(q1); step();
-            take(q2); step();
-            take(q3); step();
+        // whole trips of PR_PF: the steps behind the last source row see the last row again (the prefetch pointer stops
+        // there) and write nothing, since every output row is done by then (sy1 = -1)
+        for (int left = rLast - r + 1; left > 0; left -= PR_PF) {
+#pragma unroll
+            for (int k = 0; k < PR_PF; k++) {
+                take(q[k]);
+                step();
+            }
         }
     };
     if (tx * PR_COLS + PR_COLS <= D.w) run(std::false_type{});  // wave-uniform
