@@ -216,6 +216,7 @@ void freeAll(ft_extractor *ex) {
     hipHostFree(ex->h_histStat);
     hipFree(ex->d_bigList);
     hipFree(ex->d_sortList);
+    hipFree(ex->d_octLow);
     if (ex->h_repCand) hipHostFree(ex->h_repCand);
     hipFree(ex->d_candDev);
     hipFree(ex->d_candCountDev);
@@ -468,6 +469,7 @@ int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent
     a.selCount = ex->d_selCount + (size_t)b0 * g.nlevels;
     a.overflow = ex->d_overflow;
     a.ovSlot = ex->d_ovSlot + b0;
+    a.low = ex->d_octLow ? ex->d_octLow + (size_t)b0 * g.nlevels * FT_OCT_MAXN : nullptr;
     // Levels with more than FT_OCT_MAXN candidates go to the histogram tier.  A kernel more behind k_octree costs the
     // headline workload 1.2 % even when its 16 workgroups find nothing to do (A/B, 3 x 96 steps: 74.1 against 75.0 k frames/s:
     // one more launch in the chain of the octree lane), so the tier follows the demand: launched for the first batches of an
@@ -944,6 +946,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         o.bigCount = ex->d_bigCount;
         o.bigList = ex->d_bigList;
         o.sortList = ex->d_sortList;
+        o.low = nullptr;  // set per launch (ft_extract_launch_octree)
         if (ex->deviceOctree) {
             if (getenv("FT_OCT_PROFILE")) {
                 FT_TRY(devAlloc(&o.prof, (size_t)FT_MAX_LEVELS * 8));
@@ -951,6 +954,10 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
             }
             FT_TRY(devAlloc(&ex->d_candDev, B * g.candPerSlot));
             FT_TRY(devAlloc(&ex->d_candCountDev, B * g.nlevels));
+            // FT_OCT_COMPACT=0: the first sorted tier in the plain LDS layout (64 instead of 49 KB per workgroup)
+            if (!(getenv("FT_OCT_COMPACT") && atoi(getenv("FT_OCT_COMPACT")) == 0) &&
+                ft_octree_smem_bytes(o.poolCap, true) < ft_octree_smem_bytes(o.poolCap, false))
+                FT_TRY(devAlloc(&ex->d_octLow, B * g.nlevels * (size_t)FT_OCT_MAXN));
             hipError_t me = hipMemset(ex->d_overflow, 0, sizeof(int));
             if (me == hipSuccess) me = hipMemset(ex->d_ovSlot, 0, sizeof(int) * B);
             if (me == hipSuccess) me = hipMemset(ex->d_bigCount, 0, 4 * FT_OCT_STREAMS * sizeof(int));
@@ -1414,6 +1421,7 @@ int ft_extractor_octree_on_device(ft_extractor *ex, int level, const int *xys, i
     a.histWanted = 0;
     a.histFirst = (tiers & 8) && ex->histEnabled ? 1 : 0;  // bit 3: the histogram formulation for every level, as latency-mode launches run it
     a.sortCap = (tiers & 4) && a.bigN ? g.nlevels : 0;
+    a.low = ex->d_octLow;
     a.bigCount = ex->d_bigCount;
     a.bigList = ex->d_bigList;
     a.sortList = ex->d_sortList;

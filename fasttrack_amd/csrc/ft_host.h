@@ -173,6 +173,7 @@ struct ft_extractor {
     int *h_bigStat = nullptr;        // pinned copies of the sorted big tier's demand ([3])
     unsigned *d_bigList = nullptr;   // per octree stream [maxBatch * nlevels] (slot, level) pairs for the histogram tier
     unsigned *d_sortList = nullptr;  // ... and the pairs that tier handed on to k_octree_big
+    uint32_t *d_octLow = nullptr;    // low key dwords of the first sorted tier while its rounds run (FtOctArgs::low)
     uint32_t *h_repCand = nullptr;   // pinned candidate lists of the slots under per-image repair (repCap slots, grow-only)
     int repCap = 0;
     bool histEnabled = false;        // k_octree_hist available (FT_OCT_HIST=0 switches it off)

@@ -138,6 +138,9 @@ struct FtOctArgs {
     // workgroup of k_octree_big.
     int *bigCount;
     unsigned *bigList, *sortList;
+    // first sorted tier, compact LDS layout (kernels_octree.hip oct_lds_layout): FT_OCT_MAXN dwords of scratch per (image,
+    // level) of the launch, [(slot * nlevels + level) * FT_OCT_MAXN]; null = the plain layout
+    uint32_t *low;
     int histCap, histGrid, sortCap, bigN;  // histGrid: workgroups of k_octree_hist (they walk the list)
     int histWanted;                        // the histogram tier exists but is not launched now: count its demand all the same
     int histFirst;                         // the histogram formulation runs every level (k_octree_hist_all); give-ups -> k_octree_big
@@ -201,7 +204,7 @@ int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint
 int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a);
 // test tap: 7x7 Gaussian of a whole level through k_orient_desc's blur routines (dst on the device)
 int ft_launch_blur_level(hipStream_t st, const uint8_t *img, int pitch, int w, int h, uint8_t *dst, int dstPitch);
-size_t ft_octree_smem_bytes(int poolCap);
+size_t ft_octree_smem_bytes(int poolCap, bool compact = false);
 size_t ft_octree_hist_smem_bytes(int poolCap);
 int ft_octree_big_keys(int poolCap);
 size_t ft_fast_smem_bytes(const FtGeom &g);

@@ -56,10 +56,18 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
 // LDS layout of one workgroup's workspace (offsets in bytes from the dynamic LDS base)
 struct OctLds {
     int keys, lohi[2], x01[2], dep[2], pre[2], vSize, vPrev, ord, bq, pq, mark, stack, best, misc, total;
+    int low;  // compact layout only (else 0): the low key dwords during the pick, in the upper half of the key array
 };
 
-// keyBytes: the sorted tiers hold 8 bytes per key, the histogram tier two bytes per bin (+ the end entry)
-__host__ __device__ inline OctLds oct_lds_layout(int cap, int keyBytes, bool hist) {
+// keyBytes: the sorted tiers hold 8 bytes per key, the histogram tier two bytes per bin (+ the end entry).
+// compact (first sorted tier): the rounds need the keys' high dwords alone (the path codes), so behind the sort the
+// workgroup packs those into the lower half of the key array, parks the low dwords (response, emission rank: the pick's
+// business) in global memory, and the arrays only the rounds use - vSize .. mark - live in the upper half; the pick brings
+// the low dwords back over them.  49 instead of 64 KB per workgroup at the headline's quotas: THREE workgroups per CU, and a
+// quarter less LDS withheld from the kernels that share the CUs while one wave per workgroup walks the rounds (the
+// footprint is what the tier costs the pipeline: FT_OCT_SMEM_PAD).  Falls back to the plain layout
+// when the round arrays do not fit half the key array (quotas beyond ~500 per level).
+__host__ __device__ inline OctLds oct_lds_layout(int cap, int keyBytes, bool hist, bool compact = false) {
     OctLds o;
     int p = 0;
     auto take = [&](int bytes) {
@@ -67,19 +75,30 @@ __host__ __device__ inline OctLds oct_lds_layout(int cap, int keyBytes, bool his
         p += (bytes + 15) & ~15;
         return at;
     };
+    auto round_arrays = [&]() {
+        o.vSize = take(cap * 8);
+        o.vPrev = take(cap * 8);
+        o.ord = take(cap * 2);
+        o.bq = take(cap * 8);  // b1, b2, b3 of a processed node (u16 x 3, one pad)
+        o.pq = take(cap * 4);  // exclusive prefixes: children | children with more than one key << 16
+        o.mark = take(2 * cap);
+    };
     o.keys = take(keyBytes);
+    o.low = 0;
+    if (compact && !hist) {
+        const int half = (keyBytes / 2 + 15) & ~15, end = p;
+        p = o.keys + half;
+        round_arrays();
+        if (p <= end) o.low = o.keys + half;
+        p = end;
+    }
     for (int i = 0; i < 2; i++) {
         o.lohi[i] = take(2 * cap * 4);
         o.x01[i] = take(2 * cap * 4);
         o.dep[i] = take(2 * cap);
         o.pre[i] = hist ? take(2 * cap * 4) : 0;  // code prefix of a node (the sorted tiers read it from the node's first key)
     }
-    o.vSize = take(cap * 8);
-    o.vPrev = take(cap * 8);
-    o.ord = take(cap * 2);
-    o.bq = take(cap * 8);  // b1, b2, b3 of a processed node (u16 x 3, one pad)
-    o.pq = take(cap * 4);  // exclusive prefixes: children | children with more than one key << 16
-    o.mark = take(2 * cap);
+    if (!o.low) round_arrays();
     o.stack = take(64 * sizeof(SortFrame));
     // per final node (at most levelMax <= N + 3 < cap of them): the (response, -emission rank) maximum.  Needed only after the
     // rounds, so it takes the place of vSize (cap * 8 bytes, used by the rounds alone): 51 KB instead of 58 - THREE workgroups
@@ -295,7 +314,7 @@ enum { OM_START = 0, OM_M = 1, OM_CURB = 2, OM_GAVEUP = 3, OM_WAVESUM = 4 /* .. 
 // level (a node deeper than its table would have to be split); nothing has been written then.
 template <bool HIST>
 __device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, const int slot, const int level, const int maxN,
-                                          uint8_t *smem) {
+                                          uint8_t *smem, uint32_t *lowG = nullptr) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const FtLevelGeom &L = g.lv[level];
@@ -358,9 +377,14 @@ __device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, c
     }
     const uint32_t *cand = a.cand + (size_t)slot * g.candPerSlot + L.candBase;
     const int cap = a.poolCap;
-    const OctLds o = oct_lds_layout(cap, HIST ? oct_hist_key_bytes() : maxN * 8, HIST);
+    // lowG (first sorted tier): maxN dwords of global scratch of this (level, image) - the compact layout, if it fits
+    const OctLds o = oct_lds_layout(cap, HIST ? oct_hist_key_bytes() : maxN * 8, HIST, lowG != nullptr);
+    const bool compact = !HIST && o.low != 0;
     unsigned long long *keys = (unsigned long long *)(smem + o.keys);  // sorted tiers: code << 36 | response << 28 | rank
-    const uint32_t *codes = (const uint32_t *)keys;                     // codes[2 * i + 1] = code << 4 | response >> 4
+    // the high dword of key i = code << 4 | response >> 4: every second dword of the key array, or (compact layout, behind
+    // the sort) dword i of its lower half
+    const uint32_t *codes = (const uint32_t *)keys + (compact ? 0 : 1);
+    const int codeShift = compact ? 0 : 1;
     uint32_t *bins32 = (uint32_t *)(smem + o.keys);                     // histogram tier: two 16-bit counters per dword,
     uint16_t *bins = (uint16_t *)(smem + o.keys);                       // then bins[b] = candidates in bins below b
     int *misc = (int *)(smem + o.misc);
@@ -434,6 +458,29 @@ __device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, c
             }
         }
         tick();  // 1: sort
+        if (compact) {
+            // high dwords to the lower half of the key array, low dwords to global memory: eight keys per thread and trip
+            // are read before the first one is overwritten (chunk c's packed dwords land on keys of chunks <= c / 2)
+            uint32_t *packed = (uint32_t *)keys;
+            for (int base = 0; base < n; base += 8 * OCT_THREADS) {
+                unsigned long long kk[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int i = base + j * OCT_THREADS + tid;
+                    kk[j] = i < n ? keys[i] : 0ull;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int i = base + j * OCT_THREADS + tid;
+                    if (i < n) {
+                        packed[i] = (uint32_t)(kk[j] >> 32);
+                        lowG[i] = (uint32_t)kk[j];
+                    }
+                }
+                __syncthreads();  // (also: the stores to lowG are done - the pick's wave reads them back)
+            }
+        }
         if (tid >= 64) return true;  // the rest is one wave: no block barrier below this line
     } else {
         // ---- 1. histogram over the nodes of depth D: bins in code order ----
@@ -473,7 +520,7 @@ __device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, c
     auto lower_bound = [&](int lo, int hi, uint32_t target) {
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (codes[2 * mid + 1] < (target << 4)) lo = mid + 1;
+            if (codes[mid << codeShift] < (target << 4)) lo = mid + 1;
             else hi = mid;
         }
         return lo;
@@ -535,7 +582,7 @@ __device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, c
                     }
                 } else if (d < kMaxDepth) {
                     const int shift = 2 * (kMaxDepth - 1 - d);
-                    const uint32_t prefix = codes[2 * lo + 1] >> (shift + 2 + 4);
+                    const uint32_t prefix = codes[lo << codeShift] >> (shift + 2 + 4);
                     b1 = lower_bound(lo, hi, ((prefix << 2) | 1u) << shift);
                     b2 = lower_bound(b1, hi, ((prefix << 2) | 2u) << shift);
                     b3 = lower_bound(b2, hi, ((prefix << 2) | 3u) << shift);
@@ -706,12 +753,41 @@ __device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, c
         // ---- 4. per retained node: largest response, earliest emission rank on ties (:863-881) ----
         const int kept = min(m, a.levelMax[level]);
         const uint32_t *cl = lohiOf(curB);
-        for (int t = lane; t < kept; t += 64) {
-            const unsigned lh = cl[start + t];
-            const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
-            unsigned long long best = (keys[lo] & low) ^ inv;
-            for (int k = lo + 1; k < hi; k++) best = max(best, (keys[k] & low) ^ inv);
-            write_out(t, best);
+        if (compact) {
+            // the low dwords come back from global memory into the upper half of the key array (the round arrays there are
+            // dead); agent-scope loads: other waves of the workgroup wrote them
+            uint32_t *lowL = (uint32_t *)(smem + o.low);
+            wave_lds_sync();
+            for (int base = 0; base < n; base += 8 * 64) {
+                uint32_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int i = base + j * 64 + lane;
+                    v[j] = i < n ? __hip_atomic_load(lowG + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int i = base + j * 64 + lane;
+                    if (i < n) lowL[i] = v[j];
+                }
+            }
+            wave_lds_sync();
+            for (int t = lane; t < kept; t += 64) {
+                const unsigned lh = cl[start + t];
+                const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
+                unsigned long long best = 0;
+                for (int k = lo; k < hi; k++)
+                    best = max(best, (((unsigned long long)(codes[k] & 0xfu) << 32) | lowL[k]) ^ inv);
+                write_out(t, best);
+            }
+        } else {
+            for (int t = lane; t < kept; t += 64) {
+                const unsigned lh = cl[start + t];
+                const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
+                unsigned long long best = (keys[lo] & low) ^ inv;
+                for (int k = lo + 1; k < hi; k++) best = max(best, (keys[k] & low) ^ inv);
+                write_out(t, best);
+            }
         }
         tick();  // 3: pick
         if (lane == 0) *cntOut = kept;
@@ -788,7 +864,8 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(FtGeom g, FtOctArgs a) {
     __builtin_amdgcn_s_setprio(3);
     // workgroups are dispatched in the order of their linear index: image fastest, so the level-0 workgroups of all
     // images (the long ones: most candidates, largest quota) start first and the short high levels fill in behind
-    oct_level<false>(g, a, blockIdx.x, blockIdx.y, FT_OCT_MAXN, smem);
+    oct_level<false>(g, a, blockIdx.x, blockIdx.y, FT_OCT_MAXN, smem,
+                     a.low ? a.low + ((size_t)blockIdx.x * g.nlevels + blockIdx.y) * FT_OCT_MAXN : nullptr);
 }
 
 // The levels k_octree left on the list (more than FT_OCT_MAXN candidates): histogram formulation.  The workgroups walk the
@@ -849,7 +926,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree_auto(FtGeom g, FtOctArgs
         __syncthreads();  // the histogram formulation's LDS is dead
         FtOctArgs b = a;
         b.histCap = 0;  // (n <= FT_OCT_MAXN: the sorted formulation never lists the level)
-        oct_level<false>(g, b, slot, level, FT_OCT_MAXN, smem);
+        oct_level<false>(g, b, slot, level, FT_OCT_MAXN, smem, a.low ? a.low + ((size_t)slot * g.nlevels + level) * FT_OCT_MAXN : nullptr);
         return;
     }
     if (threadIdx.x == 0) {
@@ -884,7 +961,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree_big(FtGeom g, FtOctArgs 
 
 }  // namespace
 
-size_t ft_octree_smem_bytes(int poolCap) { return (size_t)oct_lds_layout(poolCap, FT_OCT_MAXN * 8, false).total; }
+size_t ft_octree_smem_bytes(int poolCap, bool compact) { return (size_t)oct_lds_layout(poolCap, FT_OCT_MAXN * 8, false, compact).total; }
 size_t ft_octree_hist_smem_bytes(int poolCap) { return (size_t)oct_lds_layout(poolCap, oct_hist_key_bytes(), true).total; }
 // key capacity of the sorted big tier: the largest power of two (the sort is bitonic) whose layout fits one CU's LDS
 int ft_octree_big_keys(int poolCap) {
@@ -894,7 +971,11 @@ int ft_octree_big_keys(int poolCap) {
 }
 
 int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a) {
-    const size_t smem = ft_octree_smem_bytes(a.poolCap);
+    // FT_OCT_SMEM_PAD (a probe): extra bytes of LDS per workgroup of the sorted tier - what its footprint costs the kernels
+    // that share the CUs with it
+    static const size_t pad = getenv("FT_OCT_SMEM_PAD") ? (size_t)atoi(getenv("FT_OCT_SMEM_PAD")) : 0;
+    const size_t smem = ft_octree_smem_bytes(a.poolCap, a.low != nullptr) + pad;
+    if (getenv("FT_DEBUG_OCC")) fprintf(stderr, "[ft] k_octree: %zu B of LDS per workgroup (pool %d)\n", smem, a.poolCap);
     if (smem > 64 * 1024)  // large quotas: raise the dynamic LDS limit (per device, so not cached in a static)
         FT_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const size_t smemHist = a.histCap > 0 ? ft_octree_hist_smem_bytes(a.poolCap) : 0;
@@ -904,7 +985,7 @@ int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs
     if (a.bigN && a.sortCap > 0)
         FT_HIP(hipFuncSetAttribute((const void *)k_octree_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemBig));
     if (a.histFirst) {
-        const size_t smemAll = std::max(ft_octree_hist_smem_bytes(a.poolCap), smem);
+        const size_t smemAll = std::max(ft_octree_hist_smem_bytes(a.poolCap), smem);  // (a.low: the sorted fallback in the compact layout)
         if (smemAll > 64 * 1024)
             FT_HIP(hipFuncSetAttribute((const void *)k_octree_auto, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemAll));
         for (int rep = ft_debug_repeat("octree"); rep > 0; rep--) {
