@@ -305,6 +305,39 @@ __device__ void wave_std_sort(SortElem *a, int n, SortFrame *stack, uint16_t *po
 }
 
 constexpr int OCT_THREADS = 512;  // codes + key sort / histogram / pick use the whole block, the rounds only its first wave
+#ifndef OCT_SORT_STAGES
+#define OCT_SORT_STAGES 2  // bitonic stages per LDS round trip (2^S keys per thread)
+#endif
+static_assert(OCT_SORT_STAGES >= 1 && OCT_SORT_STAGES <= 4, "bitonic_pass is instantiated for 1 .. 4 stages");
+
+// S consecutive stages (partner distances 2^p .. 2^(p-S+1)) of the bitonic merge of size k over keys[0, nPad), by the whole
+// workgroup; ends with the block barrier
+template <int S>
+__device__ __forceinline__ void bitonic_pass(unsigned long long *keys, int nPad, int k, int p, int tid) {
+    constexpr int E = 1 << S;
+    const int q = p - S + 1;  // lowest distance bit
+    for (int t = tid; t < (nPad >> S); t += OCT_THREADS) {
+        const int i = ((t >> q) << (p + 1)) + (t & ((1 << q) - 1));  // bits q .. p of the index are zero
+        unsigned long long e[E];
+#pragma unroll
+        for (int r = 0; r < E; r++) e[r] = keys[i + (r << q)];
+        const bool up = (i & k) == 0;
+#pragma unroll
+        for (int d = E >> 1; d > 0; d >>= 1) {
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                if (r & d) continue;
+                const unsigned long long x = e[r], y = e[r | d];
+                const unsigned long long lo = x < y ? x : y, hi = x < y ? y : x;
+                e[r] = up ? lo : hi;
+                e[r | d] = up ? hi : lo;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < E; r++) keys[i + (r << q)] = e[r];
+    }
+    __syncthreads();
+}
 
 // hand-over words in OctLds::misc (ints)
 enum { OM_START = 0, OM_M = 1, OM_CURB = 2, OM_GAVEUP = 3, OM_WAVESUM = 4 /* .. +8 */ };
@@ -446,23 +479,21 @@ __device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, c
         // emits two integer divisions per pair, which was a third of the sort's time.  Ending the stages that stay inside
         // one wave's run of keys with a wave-level fence instead of the block barrier - 60 of the 66 stages of 2 048 keys -
         // gains nothing on top: A/B 75.63 against 75.71 k frames/s.)
+        // Up to OCT_SORT_STAGES stages per pass: a thread takes the 2^S keys whose indices differ in the bits of the S partner
+        // distances 2^p .. 2^(p-S+1), runs those compare-exchange stages on them in registers and writes them back.  S = 2:
+        // 36 passes (LDS round trip + block barrier each) instead of 66 for 2 048 keys, 16 instead of 23 us per level under
+        // load; S = 3 / 4 (26 / 21 passes, but a half / a quarter of the threads with work and longer strides): 20 / 26 us.
+        // The direction of a merge of size k depends on bit k of the index alone, which the keys of a thread share.
         {
-            const int half = nPad >> 1;
-            for (int k = 2; k <= nPad; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    const int sh = __builtin_ctz(j);
-                    for (int t = tid; t < half; t += OCT_THREADS) {
-                        const int i = ((t >> sh) << (sh + 1)) + (t & (j - 1));
-                        const int l = i + j;
-                        const unsigned long long x = keys[i], y = keys[l];
-                        const bool up = (i & k) == 0;
-                        if ((x > y) == up) {
-                            keys[i] = y;
-                            keys[l] = x;
-                        }
-                    }
-                    __syncthreads();
-                }
+            int m = 1;  // log2(k)
+            for (int k = 2; k <= nPad; k <<= 1, m++) {
+                int p = m - 1;  // the merge's stages: partner distances 2^p .. 2^0
+                const int first = m % OCT_SORT_STAGES;  // the odd stages first, in a smaller pass
+                if (first == 1) bitonic_pass<1>(keys, nPad, k, p, tid);
+                else if (first == 2) bitonic_pass<2>(keys, nPad, k, p, tid);
+                else if (first == 3) bitonic_pass<3>(keys, nPad, k, p, tid);
+                p -= first;
+                for (; p >= OCT_SORT_STAGES - 1; p -= OCT_SORT_STAGES) bitonic_pass<OCT_SORT_STAGES>(keys, nPad, k, p, tid);
             }
         }
         tick();  // 1: sort
