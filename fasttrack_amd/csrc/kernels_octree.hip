@@ -620,11 +620,25 @@ __device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, c
                         deep = true;  // the table ends at depth D
                     }
                 } else if (d < kMaxDepth) {
+                    // the first keys of children 1, 2, 3: three binary searches over [lo, hi), advanced together - one
+                    // LDS latency per step for all three instead of three dependent chains (b1 <= b2 <= b3 by the order
+                    // of the targets; searching each in the whole range finds the same positions)
                     const int shift = 2 * (kMaxDepth - 1 - d);
                     const uint32_t prefix = codes[lo << codeShift] >> (shift + 2 + 4);
-                    b1 = lower_bound(lo, hi, ((prefix << 2) | 1u) << shift);
-                    b2 = lower_bound(b1, hi, ((prefix << 2) | 2u) << shift);
-                    b3 = lower_bound(b2, hi, ((prefix << 2) | 3u) << shift);
+                    const uint32_t t1 = (((prefix << 2) | 1u) << shift) << 4, t2 = (((prefix << 2) | 2u) << shift) << 4,
+                                   t3 = (((prefix << 2) | 3u) << shift) << 4;
+                    int l1 = lo, h1 = hi, l2 = lo, h2 = hi, l3 = lo, h3 = hi;
+                    while (l1 < h1 || l2 < h2 || l3 < h3) {
+                        const int m1 = (l1 + h1) >> 1, m2 = (l2 + h2) >> 1, m3 = (l3 + h3) >> 1;
+                        const uint32_t c1 = codes[min(m1, hi - 1) << codeShift], c2 = codes[min(m2, hi - 1) << codeShift],
+                                       c3 = codes[min(m3, hi - 1) << codeShift];
+                        if (l1 < h1) { if (c1 < t1) l1 = m1 + 1; else h1 = m1; }
+                        if (l2 < h2) { if (c2 < t2) l2 = m2 + 1; else h2 = m2; }
+                        if (l3 < h3) { if (c3 < t3) l3 = m3 + 1; else h3 = m3; }
+                    }
+                    b1 = l1;
+                    b2 = l2;
+                    b3 = l3;
                 }
                 bq[4 * r] = (uint16_t)b1;
                 bq[4 * r + 1] = (uint16_t)b2;
