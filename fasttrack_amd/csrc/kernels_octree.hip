@@ -117,7 +117,7 @@ __host__ __device__ inline int oct_hist_key_bytes() { return 2 * FT_OCT_HIST_BIN
 // ballots, the k-th candidate from the left meets the k-th from the right through two 64-entry tables in LDS, and the
 // swaps are one ds_bpermute per dword; the range stack lives in the lanes of one register.  Only the final state goes
 // back to LDS.  Same steps as ss_partition_pairs (octree_paths.h), i.e. the same array as libstdc++'s loop.
-__device__ void wave_sort_window(SortElem *a, int f, int l, int depth0, uint8_t *tabA, uint8_t *tabB, int lane) {
+__device__ __forceinline__ void wave_sort_window(SortElem *a, int f, int l, int depth0, uint8_t *tabA, uint8_t *tabB, int lane) {
     const int len = l - f;
     unsigned key = 0xffffffffu, val = 0;
     if (lane < len) {
@@ -198,7 +198,7 @@ __device__ void wave_sort_window(SortElem *a, int f, int l, int depth0, uint8_t 
     wave_lds_sync();
 }
 
-__device__ void wave_std_sort(SortElem *a, int n, SortFrame *stack, uint16_t *posA, uint16_t *posB, SortElem *tmp, int lane) {
+__device__ __forceinline__ void wave_std_sort(SortElem *a, int n, SortFrame *stack, uint16_t *posA, uint16_t *posB, SortElem *tmp, int lane) {
     if (n <= 1) return;
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) lg++;
@@ -977,9 +977,9 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree_auto(FtGeom g, FtOctArgs
     if (done) return;
     if (n <= FT_OCT_MAXN) {
         __syncthreads();  // the histogram formulation's LDS is dead
-        FtOctArgs b = a;
-        b.histCap = 0;  // (n <= FT_OCT_MAXN: the sorted formulation never lists the level)
-        oct_level<false>(g, b, slot, level, FT_OCT_MAXN, smem, a.low ? a.low + ((size_t)slot * g.nlevels + level) * FT_OCT_MAXN : nullptr);
+        // (n <= FT_OCT_MAXN: the sorted formulation never lists the level, whatever the list capacities say.  No modified copy
+        // of the arguments: a 300-byte struct on the stack means scratch memory and flat accesses for the whole kernel)
+        oct_level<false>(g, a, slot, level, FT_OCT_MAXN, smem, a.low ? a.low + ((size_t)slot * g.nlevels + level) * FT_OCT_MAXN : nullptr);
         return;
     }
     if (threadIdx.x == 0) {
