@@ -143,6 +143,14 @@ __global__ __launch_bounds__(256) void k_features_in_area(FtDevFrame F, int nq, 
 }
 
 // two smallest keys of the wave (k0 < k1)
+// key joins the two smallest keys seen (k0 <= k1), as selects: written as `if (key < k0) { k1 = k0; k0 = key; } else if
+// (key < k1) k1 = key;` inside the window lambda the compiler selects between the ADDRESSES of k0 and k1 and keeps both in
+// scratch memory - a load and a store per candidate
+__device__ __forceinline__ void two_min_insert(unsigned long long &k0, unsigned long long &k1, unsigned long long key) {
+    const unsigned long long larger = key < k0 ? k0 : key;
+    k0 = key < k0 ? key : k0;
+    k1 = larger < k1 ? larger : k1;
+}
 __device__ __forceinline__ void wave_two_min(unsigned long long &k0, unsigned long long &k1) {
     const unsigned long long m0 = wave_min_u64(k0);
     const unsigned long long cand = (k0 == m0) ? k1 : k0;
@@ -339,8 +347,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 for (int t = lane; t < nCached; t += 64) {
                     const unsigned long long key = cb.slot[1 + t];
                     if (is_locked(F, C, key_idx(key), i)) continue;
-                    if (key < k0) { k1 = k0; k0 = key; }
-                    else if (key < k1) k1 = key;
+                    two_min_insert(k0, k1, key);
                 }
             } else {
                 cache_begin(cb, lane);
@@ -358,8 +365,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                         const unsigned long long key = make_key(dist, cx, cy, idx);
                         if (cb.build) cache_append(cb, key);
                         if (locked) return;
-                        if (key < k0) { k1 = k0; k0 = key; }
-                        else if (key < k1) k1 = key;
+                        two_min_insert(k0, k1, key);
                     });
                 }
                 cache_end(cb, lane, false);
@@ -407,8 +413,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                     for (int t = lane; t < nCached; t += 64) {
                         const unsigned long long key = cb.slot[1 + t];
                         if (lockedR(key_idx(key) + F.Nleft)) continue;
-                        if (key < k0) { k1 = k0; k0 = key; }
-                        else if (key < k1) k1 = key;
+                        two_min_insert(k0, k1, key);
                     }
                 } else {
                     cache_begin(cb, lane);
@@ -423,8 +428,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                             const unsigned long long key = make_key(dist, cx, cy, idx);
                             if (cb.build) cache_append(cb, key);
                             if (locked) return;
-                            if (key < k0) { k1 = k0; k0 = key; }
-                            else if (key < k1) k1 = key;
+                            two_min_insert(k0, k1, key);
                         });
                     }
                     cache_end(cb, lane, false);
