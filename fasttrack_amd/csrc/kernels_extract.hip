@@ -249,7 +249,9 @@ __global__ __launch_bounds__(64) void k_pyr_down(FtGeom g, int level, const uint
 // instead of ~32 in the tile kernel above, whose arithmetic it repeats bit for bit.
 // ------------------------------------------------------------------------------------------------
 #define PR_COLS 128
+#ifndef PR_RB
 #define PR_RB 32
+#endif
 #ifndef PR_PF
 #define PR_PF 4       // source rows in flight ahead of the one being used
 #endif

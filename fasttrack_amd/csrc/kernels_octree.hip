@@ -41,15 +41,19 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// exclusive prefix sum over the wave; total = sum of all lanes
+// exclusive prefix sum over the wave; total = sum of all lanes.  Six DPP adds (shifts inside the rows of 16 lanes, then the
+// row totals broadcast into the following rows) - as six __shfl_up it was six ds_bpermute round trips, and the rounds
+// scan twice per 64 nodes
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    (void)lane;
     int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    total = __shfl(x, 63);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1 (lanes shifted in from outside the row read 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true);  // row_bcast:31 into rows 2 and 3
+    total = __builtin_amdgcn_readlane(x, 63);
     return x - v;
 }
 
@@ -663,8 +667,8 @@ __device__ __forceinline__ bool oct_level(const FtGeom &g, const FtOctArgs &a, c
                 if (hit) {
                     const int f = __ffsll((long long)hit) - 1;
                     nproc = r0 + f + 1;
-                    carryP += __shfl(exP + nch, f);
-                    carryQ += __shfl(exQ + nbig, f);
+                    carryP += __builtin_amdgcn_readlane(exP + nch, f);  // (f is wave-uniform)
+                    carryQ += __builtin_amdgcn_readlane(exQ + nbig, f);
                     break;
                 }
             }
