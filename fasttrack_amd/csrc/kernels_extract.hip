@@ -294,6 +294,9 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
         const int sy = (int)(short)(t.x & 0xffffu);
         rowW0 = (unsigned)min(max(sy, 0), sh - 1) | ((unsigned)min(max(sy + 1, 0), sh - 1) << 16);
         rowW1 = (t.x >> 16) | (t.y << 16);
+        // the lane behind the last output row holds a row pair no source row ever matches: the loop below runs out of output
+        // rows by reading it, without a clamp and a test per row (nrows <= PR_RB < 64)
+        if (lane >= nrows) rowW0 = 0xffffffffu;
     }
     // column taps; columns beyond the level repeat its last column (their stores are masked)
     const int dxa = min(dx, D.w - 1), dxb = min(dx + 1, D.w - 1);
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
     const unsigned selB = (unsigned)(sxb - base) | 0x0c00u | ((unsigned)(cxb - base) << 16) | 0x0c000000u;
     auto rowTap = [&](int r, int &sy0, int &sy1, unsigned &b0, unsigned &b1) {
         if constexpr (AREA) {
-            sy0 = 2 * (j0 + r); sy1 = sy0 + 1; b0 = b1 = 0;
+            sy0 = 2 * (j0 + r); sy1 = r < nrows ? sy0 + 1 : -1; b0 = b1 = 0;
         } else {
             const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)rowW0, r), w1 = (unsigned)__builtin_amdgcn_readlane((int)rowW1, r);
             sy0 = (int)(w0 & 0xffffu); sy1 = (int)(w0 >> 16);
@@ -330,9 +333,14 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
     unsigned bx0, bx1;
     rowTap(nrows - 1, lastSy0, rLast, bx0, bx1);
     int r = sy0;
-    // wave-uniform row pointers + 32-bit lane offsets: scalar-base loads and stores, no 64-bit lane arithmetic
-    const uint8_t *srcRow = S + (size_t)r * spitch;
-    uint8_t *dstRow = pyr + (size_t)slot * g.pyrPerSlot + D.off + (size_t)j0 * D.pitch;
+    // Fixed wave-uniform bases + 32-bit offsets (row offset: scalar, lane offset: vector): scalar-base loads and stores, no
+    // 64-bit arithmetic in the loop.  The kernel issues MORE scalar than vector instructions per wave (833 against 721 in
+    // round 3's profile, and a SIMD issues one of each per slot at best), so the loop's bookkeeping is written for the
+    // scalar count: a row's offset is one multiply of its clamped index (pointer += select(pitch, 0) took five
+    // instructions), the destination advances by one 32-bit add, the row taps end in a sentinel.
+    const uint8_t *srcBase = S;
+    uint8_t *dstBase = pyr + (size_t)slot * g.pyrPerSlot + D.off + (size_t)j0 * D.pitch;
+    unsigned dOff = 0;
     const unsigned laneSrc = (unsigned)base, laneDst = (unsigned)dx;
     const bool store2 = dx + 1 < D.w, store1 = dx < D.w;
     const unsigned round2 = 0x20000u;
@@ -343,16 +351,14 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
     // loop), and for the last strip of a row of strips.
     auto run = [&](auto edgeTag) {
         constexpr bool EDGE = decltype(edgeTag)::value;
-        const uint8_t *pfRow = srcRow;  // row min(r + k, rLast) for the next prefetch
-        int pfLeft = rLast - r;         // rows the prefetch pointer may still advance
+        int pfIdx = r;  // the next row to request: min(pfIdx, rLast) (the ring runs up to PR_PF - 1 rows past the strip's last)
         auto prefetch = [&]() -> ft_u2 {
-            unsigned offS = laneSrc;
-            // (the empty asm keeps the zero-extension of the lane offset inside this block, where instruction selection
-            // can fold it into the scalar-base addressing mode)
+            unsigned offS = laneSrc + (unsigned)min(pfIdx, rLast) * (unsigned)spitch;
+            // (the empty asm keeps the zero-extension of the offset inside this block, where instruction selection can fold
+            // it into the scalar-base addressing mode)
             asm volatile("" : "+v"(offS));
-            const ft_u2 v = gload<ft_u2>(pfRow + offS);
-            pfRow += pfLeft > 0 ? spitch : 0;  // wave-uniform
-            pfLeft--;
+            const ft_u2 v = gload<ft_u2>(srcBase + offS);
+            pfIdx++;
             return v;
         };
         ft_u2 q[PR_PF];
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
             q = prefetch();
         };
         auto step = [&]() {
-            while (sy1 == r) {  // wave-uniform; sy1 = -1 once every output row is written
+            while (sy1 == r) {  // wave-uniform; behind the last output row sy1 matches no row
                 // both taps on one source row happens only where cv::resize clamps the rows (top and bottom edge): monotonic,
                 // so the upper-row registers may simply be overwritten
                 if (__builtin_expect(sy0 == r, 0)) {  // wave-uniform and rare: a branch, not two selects per row
@@ -385,18 +391,17 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
                     oA = ((umad24_su(b0, hpA, round2) >> 16) + (umul24_su(b1, hcA) >> 16)) >> 2;
                     oB = ((umad24_su(b0, hpB, round2) >> 16) + (umul24_su(b1, hcB) >> 16)) >> 2;
                 }
-                unsigned offD = laneDst;
+                unsigned offD = laneDst + dOff;
                 asm volatile("" : "+v"(offD));
                 if constexpr (!EDGE) {
-                    gstore<unsigned short>(dstRow + offD, (unsigned short)(oA | (oB << 8)));
+                    gstore<unsigned short>(dstBase + offD, (unsigned short)(oA | (oB << 8)));
                 } else {
-                    if (store2) gstore<unsigned short>(dstRow + offD, (unsigned short)(oA | (oB << 8)));
-                    else if (store1) gstore<uint8_t>(dstRow + offD, (uint8_t)oA);
+                    if (store2) gstore<unsigned short>(dstBase + offD, (unsigned short)(oA | (oB << 8)));
+                    else if (store1) gstore<uint8_t>(dstBase + offD, (uint8_t)oA);
                 }
-                dstRow += D.pitch;
+                dOff += (unsigned)D.pitch;
                 jr++;
-                rowTap(min(jr, nrows - 1), sy0, sy1, b0, b1);
-                if (jr >= nrows) sy1 = -1;
+                rowTap(jr, sy0, sy1, b0, b1);  // (row nrows: the sentinel)
             }
             r++;
         };
