@@ -1568,170 +1568,213 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
                 pv[q][it] = (it < 8 || rrL < 3) ? gload<unsigned>(src + (laneOff + (unsigned)(it * 5 * pitchK[q]))) : 0u;  // scalar base + 32-bit lane offset
         }
     }
+    // The keypoints of the wave go through the LDS buffers one after the other, but the wave-uniform arithmetic between the
+    // moments and the samples - fastAtan2, the angle in radians, sin / cos in double: a fifth of the kernel's vector
+    // instructions, all 64 lanes computing the same number - is done ONCE for both: keypoint 0's moments on lanes 0-31,
+    // keypoint 1's on lanes 32-63.  Order: raw 0 -> moments 0 -> hblur 0 | raw 1 (the raw buffer is free again) -> moments 1 |
+    // angles of both | samples 0 (hb 0) | hblur 1 -> samples 1.
+    int axK[OD_KPW], m10K[OD_KPW], m01K[OD_KPW];
+    auto stage = [&](const int q) {
+        const FtSelKp s = sk[q];
+        const int level = s.level;
+        const int pitch = pitchK[q];
+        const uint8_t *img = imgK[q];
+        const int w = g.lv[level].w, h = g.lv[level].h;
+        const int px0 = s.x - OD_R, py0 = s.y - OD_R;
+        int ax = px0 & 3;
+        if (interiorK[q]) {
+            unsigned *rawLane = (unsigned *)raw + rrL * 12 + ccL;
+            if (lane < 60) {
 #pragma unroll
-    for (int q = 0; q < OD_KPW; q++) {
-    if (q >= nKp) break;  // wave-uniform
-    const int k = kFirst + q;
-    const FtSelKp s = sk[q];
-    const int cx = s.x, cy = s.y, level = s.level, response = s.response;
-    const int pitch = pitchK[q];
-    const uint8_t *img = imgK[q];
-    const int w = g.lv[level].w, h = g.lv[level].h;
-    const int px0 = cx - OD_R, py0 = cy - OD_R;
-    int ax = px0 & 3;
-    if (q > 0) wave_lds_sync();  // the previous keypoint's reads of the buffers are done
-    if (interiorK[q]) {
-        unsigned *rawLane = (unsigned *)raw + rrL * 12 + ccL;
-        if (lane < 60) {
-#pragma unroll
-            for (int it = 0; it < 9; it++)
-                if (it < 8 || rrL < 3) rawLane[it * 60] = pv[q][it];
+                for (int it = 0; it < 9; it++)
+                    if (it < 8 || rrL < 3) rawLane[it * 60] = pv[q][it];
+            }
+        } else {
+            // BORDER_REFLECT_101 of the blur at the level's edges (keypoints are >= 19 px inside, the
+            // patch reaches 21) or unaligned caller frames
+            ax = 0;
+            for (int i = lane; i < OD_P * OD_P; i += 64) {
+                const int r = i / OD_P, c = i - r * OD_P;
+                const int gy = reflect101(py0 + r, h), gx = reflect101(px0 + c, w);
+                raw[r * OD_PP + c] = gload<uint8_t>(img + (size_t)gy * pitch + gx);
+            }
         }
-    } else {
-        // BORDER_REFLECT_101 of the blur at the level's edges (keypoints are >= 19 px inside, the
-        // patch reaches 21) or unaligned caller frames
-        ax = 0;
-        for (int i = lane; i < OD_P * OD_P; i += 64) {
-            const int r = i / OD_P, c = i - r * OD_P;
-            const int gy = reflect101(py0 + r, h), gx = reflect101(px0 + c, w);
-            raw[r * OD_PP + c] = gload<uint8_t>(img + (size_t)gy * pitch + gx);
-        }
-    }
-    wave_lds_sync();
-    // IC_Angle: integer moments over the 31-px disc, four pixels per v_dot4 (tables above): lane = (row of an
-    // 8-row group, dword of the row), four groups cover rows v = -15 .. 16 (row 16 has zero weights)
-    int m10 = 0, m01 = 0;
-    {
-        const int rsub = lane >> 3, jd = lane & 7;
-        const int sh = (ax + 6) & 3;
-        // dword j of row v starts at raw byte (v + 21) * 48 + ax + 6 + 4j
-        const unsigned *w = (const unsigned *)raw + (rsub + 6) * 12 + ((ax + 6) >> 2) + jd;
-        int v = rsub - 15;
-#pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const unsigned lo = w[it * 96], hi = w[it * 96 + 1];
-            const unsigned D = __builtin_amdgcn_alignbyte(hi, lo, sh);
-            const int av = v < 0 ? -v : v;
-            const unsigned dw = __builtin_amdgcn_udot4(D, c_mom.W[av * 8 + jd], 0u, false);
-            const unsigned dm = __builtin_amdgcn_udot4(D, c_mom.M[av * 8 + jd], 0u, false);
-            m10 += (int)dw - 16 * (int)dm;
-            m01 += __mul24(v, (int)dm);  // |v| <= 16, dm <= 4 * 255 * 15
-            v += 8;
-        }
-        m10 = wave_sum_i32(m10);
-        m01 = wave_sum_i32(m01);
-    }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // horizontal 7-tap pass on the packed bytes: a task = (row, aligned group of 4 raw byte positions);
-    // two v_dot4_u32_u8 per output on byte windows cut out with v_alignbyte.  hb[r][b] = sum_t k[t] *
-    // raw[r][b + t] for raw byte positions b in [0, 40) (16 bit, <= 255 * 256); output column c of the
-    // blurred window is b = ax + c.
-    {
-#if OD_LAYOUT
-        // column-major output (hbT[column][row], OD_RP u16 slots per column): a lane takes a PAIR of rows (2P, 2P + 1) of its
-        // group of four columns and stores the two values of a column as one dword; six row pairs per step on lanes 0-59
-        const int rr = (lane * 13) >> 7, gq = lane - rr * 10;  // lane / 10 for lane < 64
-        const unsigned *rwLane = (const unsigned *)(raw + 2 * rr * OD_PP) + gq;
-        unsigned *hbLane = (unsigned *)hb + 4 * gq * (OD_RP / 2) + rr;
-        if (lane < 60) {
+        axK[q] = ax;
+    };
+    auto moments = [&](const int q) {
+        const int ax = axK[q];
+        // IC_Angle: integer moments over the 31-px disc, four pixels per v_dot4 (tables above): lane = (row of an
+        // 8-row group, dword of the row), four groups cover rows v = -15 .. 16 (row 16 has zero weights)
+        int m10 = 0, m01 = 0;
+        {
+            const int rsub = lane >> 3, jd = lane & 7;
+            const int sh = (ax + 6) & 3;
+            // dword j of row v starts at raw byte (v + 21) * 48 + ax + 6 + 4j
+            const unsigned *w = (const unsigned *)raw + (rsub + 6) * 12 + ((ax + 6) >> 2) + jd;
+            int v = rsub - 15;
 #pragma unroll
             for (int it = 0; it < 4; it++) {
-                if (it == 3 && rr > 3) break;  // row pairs 22, 23 do not exist (rows 0 .. 42; row 43 is a dummy)
-                const unsigned *rw = rwLane + it * (12 * OD_PP / 4);
-                unsigned a0, a1, a2, a3, b0, b1, b2, b3;
-                od_hblur4(rw[0], rw[1], rw[2], a0, a1, a2, a3);
-                od_hblur4(rw[OD_PP / 4], rw[OD_PP / 4 + 1], rw[OD_PP / 4 + 2], b0, b1, b2, b3);
-                unsigned *o = hbLane + it * 6;
-                o[0] = __builtin_amdgcn_perm(b0, a0, 0x05040100u);  // a | b << 16 (both < 2^16)
-                o[OD_RP / 2] = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
-                o[2 * (OD_RP / 2)] = __builtin_amdgcn_perm(b2, a2, 0x05040100u);
-                o[3 * (OD_RP / 2)] = __builtin_amdgcn_perm(b3, a3, 0x05040100u);
+                const unsigned lo = w[it * 96], hi = w[it * 96 + 1];
+                const unsigned D = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                const int av = v < 0 ? -v : v;
+                const unsigned dw = __builtin_amdgcn_udot4(D, c_mom.W[av * 8 + jd], 0u, false);
+                const unsigned dm = __builtin_amdgcn_udot4(D, c_mom.M[av * 8 + jd], 0u, false);
+                m10 += (int)dw - 16 * (int)dm;
+                m01 += __mul24(v, (int)dm);  // |v| <= 16, dm <= 4 * 255 * 15
+                v += 8;
             }
+            m10 = wave_sum_i32(m10);
+            m01 = wave_sum_i32(m01);
         }
-#else
-        // six rows per step on lanes 0-59, (row, group) fixed per lane: every LDS offset of a step is an immediate
-        const int rr = (lane * 13) >> 7, gq = lane - rr * 10;  // lane / 10 for lane < 64
-        const unsigned *rwLane = (const unsigned *)(raw + rr * OD_PP) + gq;
-        unsigned short *hbLane = hb + rr * OD_HP + 4 * gq;
-        if (lane < 60) {
+        m10K[q] = m10;
+        m01K[q] = m01;
+    };
+    auto hblur = [&]() {
+        // horizontal 7-tap pass on the packed bytes: a task = (row, aligned group of 4 raw byte positions);
+        // two v_dot4_u32_u8 per output on byte windows cut out with v_alignbyte.  hb[r][b] = sum_t k[t] *
+        // raw[r][b + t] for raw byte positions b in [0, 40) (16 bit, <= 255 * 256); output column c of the
+        // blurred window is b = ax + c.
+        {
+#if OD_LAYOUT
+            // column-major output (hbT[column][row], OD_RP u16 slots per column): a lane takes a PAIR of rows (2P, 2P + 1) of its
+            // group of four columns and stores the two values of a column as one dword; six row pairs per step on lanes 0-59
+            const int rr = (lane * 13) >> 7, gq = lane - rr * 10;  // lane / 10 for lane < 64
+            const unsigned *rwLane = (const unsigned *)(raw + 2 * rr * OD_PP) + gq;
+            unsigned *hbLane = (unsigned *)hb + 4 * gq * (OD_RP / 2) + rr;
+            if (lane < 60) {
 #pragma unroll
-            for (int it = 0; it < 8; it++) {
-                if (it == 7 && rr > 0) break;  // rows 42 .. 47: only row 42 exists
-                const unsigned *rw = rwLane + it * (6 * OD_PP / 4);
-                const unsigned d0 = rw[0], d1 = rw[1], d2 = rw[2];
-                unsigned h0, h1, h2, h3;
-                od_hblur4(d0, d1, d2, h0, h1, h2, h3);
-                uint2 pk;
-                pk.x = __builtin_amdgcn_perm(h1, h0, 0x05040100u);  // h0 | h1 << 16 (both < 2^16) in one instruction
-                pk.y = __builtin_amdgcn_perm(h3, h2, 0x05040100u);
-                *(uint2 *)(hbLane + it * 6 * OD_HP) = pk;
+                for (int it = 0; it < 4; it++) {
+                    if (it == 3 && rr > 3) break;  // row pairs 22, 23 do not exist (rows 0 .. 42; row 43 is a dummy)
+                    const unsigned *rw = rwLane + it * (12 * OD_PP / 4);
+                    unsigned a0, a1, a2, a3, b0, b1, b2, b3;
+                    od_hblur4(rw[0], rw[1], rw[2], a0, a1, a2, a3);
+                    od_hblur4(rw[OD_PP / 4], rw[OD_PP / 4 + 1], rw[OD_PP / 4 + 2], b0, b1, b2, b3);
+                    unsigned *o = hbLane + it * 6;
+                    o[0] = __builtin_amdgcn_perm(b0, a0, 0x05040100u);  // a | b << 16 (both < 2^16)
+                    o[OD_RP / 2] = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
+                    o[2 * (OD_RP / 2)] = __builtin_amdgcn_perm(b2, a2, 0x05040100u);
+                    o[3 * (OD_RP / 2)] = __builtin_amdgcn_perm(b3, a3, 0x05040100u);
+                }
             }
-        }
+#else
+            // six rows per step on lanes 0-59, (row, group) fixed per lane: every LDS offset of a step is an immediate
+            const int rr = (lane * 13) >> 7, gq = lane - rr * 10;  // lane / 10 for lane < 64
+            const unsigned *rwLane = (const unsigned *)(raw + rr * OD_PP) + gq;
+            unsigned short *hbLane = hb + rr * OD_HP + 4 * gq;
+            if (lane < 60) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    if (it == 7 && rr > 0) break;  // rows 42 .. 47: only row 42 exists
+                    const unsigned *rw = rwLane + it * (6 * OD_PP / 4);
+                    const unsigned d0 = rw[0], d1 = rw[1], d2 = rw[2];
+                    unsigned h0, h1, h2, h3;
+                    od_hblur4(d0, d1, d2, h0, h1, h2, h3);
+                    uint2 pk;
+                    pk.x = __builtin_amdgcn_perm(h1, h0, 0x05040100u);  // h0 | h1 << 16 (both < 2^16) in one instruction
+                    pk.y = __builtin_amdgcn_perm(h3, h2, 0x05040100u);
+                    *(uint2 *)(hbLane + it * 6 * OD_HP) = pk;
+                }
+            }
 #endif
-    }
+        }
+    };
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    auto describe = [&](const int q, const float angle, const float ca, const float sb) {
+        const int ax = axK[q];
+        const int k = kFirst + q;
+        const FtSelKp s = sk[q];
+        const int cx = s.x, cy = s.y, level = s.level, response = s.response;
+        // vertical 7-tap pass only where the pattern samples (512 of the 1369 window positions): the blurred
+        // pixel at offset (r, c) from the keypoint is (sum_s k[s] * hb[18 + r + s][ax + 18 + c] + 2^15) >> 16
+        // LDS byte offset of hb[18 + r][ax + 18 + c] = r * 80 + (2 c + hbase): one shift-add and one 24-bit multiply-add;
+        // the seven taps are immediates from there, combined with 24-bit multiply-adds (sums stay below 2^24)
+#if OD_LAYOUT
+        // column-major: the seven values of a sample are consecutive u16 of column ax + 18 + c starting at row 18 + r: byte
+        // offset 2 * ((ax + 18 + c) * OD_RP + 18 + r) in the wave's hbT
+        const int hbase = (int)((const uint8_t *)hb - smem) + 2 * ((ax + 18) * OD_RP + 18);
+        auto blurred = [&](int r, int c) -> unsigned {
+            const int byteIdx = vmad24(c, 2 * OD_RP, (r << 1) + hbase);
+            const unsigned *p = (const unsigned *)(smem + (byteIdx & ~3));
+            return od_vblur7_dwords(p[0], p[1], p[2], p[3], (unsigned)(byteIdx & 2) << 3);
+        };
+#else
+        const int hbase = (int)((const uint8_t *)(hb + 18 * OD_HP + ax + 18) - smem);
+        auto blurred = [&](int r, int c) -> unsigned {
+            const unsigned short *p = (const unsigned short *)(smem + vmad24(r, 2 * OD_HP, (c << 1) + hbase));
+            return od_vblur7(p[0], p[OD_HP], p[2 * OD_HP], p[3 * OD_HP], p[4 * OD_HP], p[5 * OD_HP], p[6 * OD_HP]);
+        };
+#endif
+        const v2f scPair = {sb, ca}, csPair = {ca, sb};
+        unsigned long long words[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int p = q * 64 + lane;  // pair index: byte p/8, bit p%8
+            const float4 pt = c_patternF.p[p];
+            // (x, y) pairs times (sin, cos) and (cos, sin) pairs: packed fp32 multiplies, every product rounded on its own
+            const v2f p0 = {pt.x, pt.y}, p1 = {pt.z, pt.w};
+            const v2f a0 = p0 * scPair, b0 = p0 * csPair, a1 = p1 * scPair, b1 = p1 * csPair;
+            const int r0 = __float2int_rn(__fadd_rn(a0.x, a0.y));  // x0 sin + y0 cos
+            const int c0 = __float2int_rn(__fsub_rn(b0.x, b0.y));  // x0 cos - y0 sin
+            const int r1 = __float2int_rn(__fadd_rn(a1.x, a1.y));
+            const int c1 = __float2int_rn(__fsub_rn(b1.x, b1.y));
+            words[q] = __ballot(blurred(r0, c0) < blurred(r1, c1));
+        }
+        if (lane == 0) {
+            const size_t o = (size_t)slot * g.maxKp + k;
+            // ORBextractor.cc:1209-1221 (octave, size = int(PATCH_SIZE * sf)) and :1472-1475 (pt *= scale)
+            const float scale = g.sf[level];
+            ft_keypoint kp;
+            kp.x = level ? __fmul_rn((float)cx, scale) : (float)cx;
+            kp.y = level ? __fmul_rn((float)cy, scale) : (float)cy;
+            kp.size = (float)(int)__fmul_rn((float)FT_PATCH_SIZE, scale);
+            kp.angle = angle;
+            kp.response = (float)response;
+            kp.octave = level;
+            kp.class_id = -1;
+            keysOut[o] = kp;
+            unsigned long long *d = (unsigned long long *)(descOut + o * 32);
+            d[0] = words[0];
+            d[1] = words[1];
+            d[2] = words[2];
+            d[3] = words[3];
+        }
+    };
+    stage(0);
     wave_lds_sync();
+    moments(0);
+    hblur();
+    wave_lds_sync();  // hb 0 is complete, the raw buffer is free
+    if constexpr (OD_KPW > 1) {
+        if (nKp > 1) {  // wave-uniform
+            stage(1);
+            wave_lds_sync();
+            moments(1);
+        }
+    }
+    float mY = (float)m01K[0], mX = (float)m10K[0];
+    if constexpr (OD_KPW > 1) {
+        if (nKp > 1 && lane >= 32) {
+            mY = (float)m01K[1];
+            mX = (float)m10K[1];
+        }
+    }
+    const float angleL = fast_atan2_deg(mY, mX);
     // computeOrbDescriptor: angle in radians as float, cos/sin in double then narrowed
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    const float ar = __fmul_rn(angle, factorPI);
+    const float ar = __fmul_rn(angleL, factorPI);
     double sd, cd;
     ft_sincos_0_2pi((double)ar, sd, cd);
-    const float ca = (float)cd, sb = (float)sd;
-    // vertical 7-tap pass only where the pattern samples (512 of the 1369 window positions): the blurred
-    // pixel at offset (r, c) from the keypoint is (sum_s k[s] * hb[18 + r + s][ax + 18 + c] + 2^15) >> 16
-    // LDS byte offset of hb[18 + r][ax + 18 + c] = r * 80 + (2 c + hbase): one shift-add and one 24-bit multiply-add;
-    // the seven taps are immediates from there, combined with 24-bit multiply-adds (sums stay below 2^24)
-#if OD_LAYOUT
-    // column-major: the seven values of a sample are consecutive u16 of column ax + 18 + c starting at row 18 + r: byte
-    // offset 2 * ((ax + 18 + c) * OD_RP + 18 + r) in the wave's hbT
-    const int hbase = (int)((const uint8_t *)hb - smem) + 2 * ((ax + 18) * OD_RP + 18);
-    auto blurred = [&](int r, int c) -> unsigned {
-        const int byteIdx = vmad24(c, 2 * OD_RP, (r << 1) + hbase);
-        const unsigned *p = (const unsigned *)(smem + (byteIdx & ~3));
-        return od_vblur7_dwords(p[0], p[1], p[2], p[3], (unsigned)(byteIdx & 2) << 3);
-    };
-#else
-    const int hbase = (int)((const uint8_t *)(hb + 18 * OD_HP + ax + 18) - smem);
-    auto blurred = [&](int r, int c) -> unsigned {
-        const unsigned short *p = (const unsigned short *)(smem + vmad24(r, 2 * OD_HP, (c << 1) + hbase));
-        return od_vblur7(p[0], p[OD_HP], p[2 * OD_HP], p[3 * OD_HP], p[4 * OD_HP], p[5 * OD_HP], p[6 * OD_HP]);
-    };
-#endif
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const v2f scPair = {sb, ca}, csPair = {ca, sb};
-    unsigned long long words[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int p = q * 64 + lane;  // pair index: byte p/8, bit p%8
-        const float4 pt = c_patternF.p[p];
-        // (x, y) pairs times (sin, cos) and (cos, sin) pairs: packed fp32 multiplies, every product rounded on its own
-        const v2f p0 = {pt.x, pt.y}, p1 = {pt.z, pt.w};
-        const v2f a0 = p0 * scPair, b0 = p0 * csPair, a1 = p1 * scPair, b1 = p1 * csPair;
-        const int r0 = __float2int_rn(__fadd_rn(a0.x, a0.y));  // x0 sin + y0 cos
-        const int c0 = __float2int_rn(__fsub_rn(b0.x, b0.y));  // x0 cos - y0 sin
-        const int r1 = __float2int_rn(__fadd_rn(a1.x, a1.y));
-        const int c1 = __float2int_rn(__fsub_rn(b1.x, b1.y));
-        words[q] = __ballot(blurred(r0, c0) < blurred(r1, c1));
+    const float caL = (float)cd, sbL = (float)sd;
+    auto lane_value = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    describe(0, lane_value(angleL, 0), lane_value(caL, 0), lane_value(sbL, 0));
+    if constexpr (OD_KPW > 1) {
+        if (nKp > 1) {
+            wave_lds_sync();  // samples 0 have read hb
+            hblur();
+            wave_lds_sync();
+            describe(1, lane_value(angleL, 32), lane_value(caL, 32), lane_value(sbL, 32));
+        }
     }
-    if (lane == 0) {
-        const size_t o = (size_t)slot * g.maxKp + k;
-        // ORBextractor.cc:1209-1221 (octave, size = int(PATCH_SIZE * sf)) and :1472-1475 (pt *= scale)
-        const float scale = g.sf[level];
-        ft_keypoint kp;
-        kp.x = level ? __fmul_rn((float)cx, scale) : (float)cx;
-        kp.y = level ? __fmul_rn((float)cy, scale) : (float)cy;
-        kp.size = (float)(int)__fmul_rn((float)FT_PATCH_SIZE, scale);
-        kp.angle = angle;
-        kp.response = (float)response;
-        kp.octave = level;
-        kp.class_id = -1;
-        keysOut[o] = kp;
-        unsigned long long *d = (unsigned long long *)(descOut + o * 32);
-        d[0] = words[0];
-        d[1] = words[1];
-        d[2] = words[2];
-        d[3] = words[3];
-    }
-    }  // keypoints of the wave
 }
 
 }  // namespace
