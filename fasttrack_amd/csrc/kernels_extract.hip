@@ -1691,9 +1691,14 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
 #if OD_LAYOUT
         // column-major: the seven values of a sample are consecutive u16 of column ax + 18 + c starting at row 18 + r: byte
         // offset 2 * ((ax + 18 + c) * OD_RP + 18 + r) in the wave's hbT
-        const int hbase = (int)((const uint8_t *)hb - smem) + 2 * ((ax + 18) * OD_RP + 18);
-        auto blurred = [&](int r, int c) -> unsigned {
-            const int byteIdx = vmad24(c, 2 * OD_RP, (r << 1) + hbase);
+        // r and c arrive as the BIT PATTERNS of (offset + 1.5 * 2^23): adding that constant to a float rounds it to the
+        // nearest integer, ties to even - cvRound - and leaves 0x4B400000 + offset in the register (|offset| < 2^22), one
+        // instruction where v_rndne + v_cvt_i32 took two.  The constant parts come out in the wash: (r << 1) wraps to
+        // 2 * offset + 2 * 0x4B400000, the 24-bit multiply sees 0x400000 + c, and both surpluses are folded into hbase.
+        const int hbase = (int)((const uint8_t *)hb - smem) + 2 * ((ax + 18) * OD_RP + 18) -
+                          (int)(2u * 0x4B400000u + 0x400000u * (unsigned)(2 * OD_RP));
+        auto blurred = [&](unsigned rBits, unsigned cBits) -> unsigned {
+            const int byteIdx = vmad24((int)cBits, 2 * OD_RP, (int)((rBits << 1) + (unsigned)hbase));
             const unsigned *p = (const unsigned *)(smem + (byteIdx & ~3));
             return od_vblur7_dwords(p[0], p[1], p[2], p[3], (unsigned)(byteIdx & 2) << 3);
         };
@@ -1713,10 +1718,18 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
             // (x, y) pairs times (sin, cos) and (cos, sin) pairs: packed fp32 multiplies, every product rounded on its own
             const v2f p0 = {pt.x, pt.y}, p1 = {pt.z, pt.w};
             const v2f a0 = p0 * scPair, b0 = p0 * csPair, a1 = p1 * scPair, b1 = p1 * csPair;
+#if OD_LAYOUT
+            const float rnd = 12582912.f;  // 1.5 * 2^23
+            const unsigned r0 = __float_as_uint(__fadd_rn(__fadd_rn(a0.x, a0.y), rnd));  // cvRound(x0 sin + y0 cos), biased
+            const unsigned c0 = __float_as_uint(__fadd_rn(__fsub_rn(b0.x, b0.y), rnd));  // cvRound(x0 cos - y0 sin), biased
+            const unsigned r1 = __float_as_uint(__fadd_rn(__fadd_rn(a1.x, a1.y), rnd));
+            const unsigned c1 = __float_as_uint(__fadd_rn(__fsub_rn(b1.x, b1.y), rnd));
+#else
             const int r0 = __float2int_rn(__fadd_rn(a0.x, a0.y));  // x0 sin + y0 cos
             const int c0 = __float2int_rn(__fsub_rn(b0.x, b0.y));  // x0 cos - y0 sin
             const int r1 = __float2int_rn(__fadd_rn(a1.x, a1.y));
             const int c1 = __float2int_rn(__fsub_rn(b1.x, b1.y));
+#endif
             words[q] = __ballot(blurred(r0, c0) < blurred(r1, c1));
         }
         if (lane == 0) {
