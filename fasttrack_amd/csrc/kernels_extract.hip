@@ -1444,7 +1444,7 @@ __device__ __forceinline__ unsigned od_vblur7_pairs(unsigned e0, unsigned e1, un
 }
 __device__ __forceinline__ unsigned od_vblur7_dwords(unsigned d0, unsigned d1, unsigned d2, unsigned d3, unsigned sh) {
     return od_vblur7_pairs(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
-                           __builtin_amdgcn_alignbit(d3, d2, sh), d3 >> sh);
+                           __builtin_amdgcn_alignbit(d3, d2, sh), d3 >> (sh & 31u));  // (only the low five bits of sh count)
 }
 
 // Test tap (a7, GaussianBlur directly): the blurred image of one pyramid level, BORDER_REFLECT_101, computed with
@@ -1700,7 +1700,9 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
         auto blurred = [&](unsigned rBits, unsigned cBits) -> unsigned {
             const int byteIdx = vmad24((int)cBits, 2 * OD_RP, (int)((rBits << 1) + (unsigned)hbase));
             const unsigned *p = (const unsigned *)(smem + (byteIdx & ~3));
-            return od_vblur7_dwords(p[0], p[1], p[2], p[3], (unsigned)(byteIdx & 2) << 3);
+            // (bit shift of the window: 16 if the first value is a high half.  byteIdx is even, and both v_alignbit and the
+            // shift take the low five bits of their operand: byteIdx << 3 serves without masking bit 1 out first)
+            return od_vblur7_dwords(p[0], p[1], p[2], p[3], (unsigned)byteIdx << 3);
         };
 #else
         const int hbase = (int)((const uint8_t *)(hb + 18 * OD_HP + ax + 18) - smem);
