@@ -1695,11 +1695,14 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
         // nearest integer, ties to even - cvRound - and leaves 0x4B400000 + offset in the register (|offset| < 2^22), one
         // instruction where v_rndne + v_cvt_i32 took two.  The constant parts come out in the wash: (r << 1) wraps to
         // 2 * offset + 2 * 0x4B400000, the 24-bit multiply sees 0x400000 + c, and both surpluses are folded into hbase.
-        const int hbase = (int)((const uint8_t *)hb - smem) + 2 * ((ax + 18) * OD_RP + 18) -
-                          (int)(2u * 0x4B400000u + 0x400000u * (unsigned)(2 * OD_RP));
+        // (hbase carries the LDS address of hb itself, and the sample pointer is made from the integer: as smem + offset the
+        // compiler adds the base of the dynamic LDS - zero, but a symbol to it - to every sample's address)
+        typedef __attribute__((address_space(3))) const unsigned od_lds_u32;
+        const int hbase = (int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(uint8_t *)hb +
+                          2 * ((ax + 18) * OD_RP + 18) - (int)(2u * 0x4B400000u + 0x400000u * (unsigned)(2 * OD_RP));
         auto blurred = [&](unsigned rBits, unsigned cBits) -> unsigned {
             const int byteIdx = vmad24((int)cBits, 2 * OD_RP, (int)((rBits << 1) + (unsigned)hbase));
-            const unsigned *p = (const unsigned *)(smem + (byteIdx & ~3));
+            od_lds_u32 *p = (od_lds_u32 *)(uintptr_t)(unsigned)(byteIdx & ~3);
             // (bit shift of the window: 16 if the first value is a high half.  byteIdx is even, and both v_alignbit and the
             // shift take the low five bits of their operand: byteIdx << 3 serves without masking bit 1 out first)
             return od_vblur7_dwords(p[0], p[1], p[2], p[3], (unsigned)byteIdx << 3);
