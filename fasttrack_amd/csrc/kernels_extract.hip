@@ -1024,22 +1024,36 @@ __global__ __launch_bounds__(64, FC_WAVES_PER_EU) void k_fast_cells(FtGeom g, co
         for (int q = 0; q < FC_NMS_REG; q++)
             if (q * 64 < nItems) emit(fl[q], px[q], need);
     } else {
+        // more corners than the registers hold flags for (dense frames): the verdicts of the first pass wait in LDS - the
+        // tile is dead by now - for the threshold decision, instead of being computed twice (nine reads and a max tree each)
         int anyHi = 0;
         for (int base = 0; base < nItems; base += 64) {
             const int it = base + lane;
             int fl = 0, pix;
-            if (it < nItems) fl = nms(it, pix);
+            if (it < nItems) {
+                fl = nms(it, pix);
+                surv[it] = (uint8_t)fl;
+            }
             anyHi |= __any(fl == 2);
         }
+        wave_lds_sync();
         const int need = anyHi ? 2 : 1;
         for (int base = 0; base < nItems; base += 64) {
             const int it = base + lane;
             int fl = 0, pix = 0;
-            if (it < nItems) fl = nms(it, pix);
+            if (it < nItems) {
+                fl = surv[it];
+                if (useList) {
+                    pix = (int)corn[it];
+                } else {
+                    const unsigned mg = TP ? div_magic_of((unsigned)pw) : pwMagic;
+                    const int y = div_by(it, mg);
+                    pix = pixCode(y, it - y * pw);
+                }
+            }
             emit(fl, pix, need);
         }
     }
-    (void)surv;
     if (lane == 0) *cnt = min(run, cellCap);
 }
 
