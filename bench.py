@@ -628,6 +628,12 @@ def main():
             ach = roof["bytes_per_launch"] / (ms / 1e3) / 1e9
             roof["at_marginal_cost"] = {"ms_per_launch": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                                         "source": "profiles/r03_marginal_costs.json (tools/marginal_costs.py: FT_DEBUG_REPEAT=fast, same workload)"}
+            # the same for the vector-issue bound: the launch's vector instructions (committed SQ pass) x 4 cycles on a
+            # 16-lane SIMD / (1 024 SIMDs x 2.4 GHz x the launch's cost inside the pipeline) - ~1.0 says the kernel is priced
+            # at its instruction stream, which is what "the chip is full" means for it
+            tkf = tk.get("k_fast_cells") or {}
+            if same_inputs and tkf.get("valu_per_launch"):
+                roof["at_marginal_cost"]["valu_issue_frac"] = tkf["valu_per_launch"] * 4.0 / (1024 * 2.4e9 * ms / 1e3)
         also = sorted(legs[1:], key=lambda x: -x["total_ms"])
         # The ceiling this integer / bitwise path really works against: vector-instruction issue.  Wave-level vector
         # instructions of the timed region (per-launch counts of the committed SQ pass x this run's launches) x 4 cycles each
