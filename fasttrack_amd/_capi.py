@@ -166,6 +166,8 @@ def lib() -> C.CDLL:
     L.ft_vocabulary_destroy.argtypes = [vp]
     L.ft_vocabulary_info.argtypes = [vp, ip, ip, ip, ip]
     L.ft_bow_transform.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, vp, i, ip, vp, vp, vp, i, ip]
+    L.ft_selftest_libm.argtypes = [vp, i, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong),
+                                   C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint32)]
     L.ft_octree_distribute.argtypes = [vp, i, i, i, i, i, i, vp, i, ip]
     L.ft_level_geometry.argtypes = [i, i, i, f, i, vp, vp, vp, vp, vp, vp, vp]
     _lib = L

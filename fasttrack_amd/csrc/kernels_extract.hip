@@ -5,7 +5,7 @@
 //   k_compact      cell-row-major ordered candidate list          (ORBextractor.cc:1186-1198)
 //   k_orient_desc  IC_Angle + 7x7 fixed-point blur + rBRIEF       (ORBextractor.cc:39-108,1456-1462, A.2/A.4/A.6/A.7)
 #include "ft_internal.h"
-#include "sincos_poly.h"
+#include "libm_f32.h"
 #include "wave_ops.h"
 
 namespace {
@@ -1792,12 +1792,11 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
         }
     }
     const float angleL = fast_atan2_deg(mY, mX);
-    // computeOrbDescriptor: angle in radians as float, cos/sin in double then narrowed
+    // computeOrbDescriptor (ORBextractor.cc:72-74): angle in radians as float, then std::cos(float) / std::sin(float)
+    // = glibc's cosf / sinf, reproduced bit for bit (libm_f32.h)
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = __fmul_rn(angleL, factorPI);
-    double sd, cd;
-    ft_sincos_0_2pi((double)ar, sd, cd);
-    const float caL = (float)cd, sbL = (float)sd;
+    const float caL = ft_libm::cosf_glibc(ar), sbL = ft_libm::sinf_glibc(ar);
     auto lane_value = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     describe(0, lane_value(angleL, 0), lane_value(caL, 0), lane_value(sbL, 0));
     if constexpr (OD_KPW > 1) {

@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "kb8_math.h"
+#include "libm_f32.h"
 #include "ft_search.h"
 #include "wave_ops.h"
 
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoin
 // ------------------------------------------------------------------------------------------------
 // Frame::isInFrustum / isInFrustumChecks (src/Frame.cc:536-610, 1308-1382) with MapPoint::PredictScale
 // (src/MapPoint.cc:531-546): one thread per local map point.  Float expressions are evaluated in the
-// order the oracle states (no contraction); logf(ratio) is taken as the narrowed double logarithm.
+// order the oracle states (no contraction); log(ratio) binds to logf (MapPoint.cc:539), reproduced by libm_f32.h.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dot3(const float *a, const float *b) {
     return __fadd_rn(__fadd_rn(__fmul_rn(a[0], b[0]), __fmul_rn(a[1], b[1])), __fmul_rn(a[2], b[2]));
@@ -658,7 +659,7 @@ __device__ __forceinline__ float norm3(const float *a) { return sqrtf(dot3(a, a)
 
 __device__ __forceinline__ int predict_scale(float maxDistanceRaw, float dist, float logScaleFactor, int nLevels) {
     const float ratio = __fdiv_rn(maxDistanceRaw, dist);
-    const float lg = (float)log((double)ratio);
+    const float lg = ft_libm::logf_glibc(ratio);
     int nScale = (int)ceilf(__fdiv_rn(lg, logScaleFactor));
     if (nScale < 0) nScale = 0;
     else if (nScale >= nLevels) nScale = nLevels - 1;

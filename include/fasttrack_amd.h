@@ -413,6 +413,15 @@ FT_API int ft_tracked_frame_holder_obs(ft_tracked_frame *tf, int *holder_obs);
  * device copy src/Kernels/CudaUtils.cu:42-56).  a, b: n x 32 host bytes; dist: n ints. */
 FT_API int ft_descriptor_distance(ft_context *ctx, const uint8_t *a, const uint8_t *b, int n, int *dist);
 
+/* Host-libm self test.  The rBRIEF rotation (src/ORBextractor.cc:73-74: std::cos(float), std::sin(float)) and
+ * MapPoint::PredictScale (src/MapPoint.cc:539: std::log(float)) are evaluated by the reference with the HOST libm;
+ * the kernels reproduce glibc's cosf / sinf / logf bit for bit (fasttrack_amd/csrc/libm_f32.h).  This sweep evaluates
+ * func (0 cosf, 1 sinf, 2 logf) on the device for the float bit patterns first_bits, first_bits + stride, ... <= last_bits
+ * and compares with the cosf / sinf / logf of the calling process.  mismatches == 0 over [0, 0x40c90fdb] (cos, sin) and
+ * [1, 0x461c4000] (log, up to 1e4) means the device and this host's libm agree on every argument the path can produce. */
+FT_API int ft_selftest_libm(ft_context *ctx, int func, uint32_t first_bits, uint32_t last_bits, uint32_t stride,
+                            unsigned long long *checked, unsigned long long *mismatches, uint32_t *first_bad);
+
 /* ----------------------------------------------------------------------------------------------
  * Frame::ComputeBoW (src/Frame.cc:762-769): DBoW2's
  * TemplatedVocabulary<FORB::TDescriptor, FORB>::transform(features, BowVector&, FeatureVector&, levelsup)

@@ -389,12 +389,15 @@ float orc_ic_angle(const uint8_t *img, int stride, float x, float y) {
     return orc_fast_atan2((float)m_01, (float)m_10);
 }
 
-// computeOrbDescriptor - src/ORBextractor.cc:68-108.  cos/sin are evaluated in double and narrowed
-// (SURVEY A.7); which libm the reference binary binds to is unpinned.
+// computeOrbDescriptor - src/ORBextractor.cc:68-108.  `cos(angle)` / `sin(angle)` on a float under
+// `using namespace std` (:34) bind to std::cos(float) / std::sin(float) = libm's cosf / sinf (SURVEY A.7
+// misread this as the double routines).  The host libm is a third party the oracle calls, not restates:
+// glibc 2.35 here and on the GPU box; its float routines are not correctly rounded, so another libm may
+// differ in the last bit on a few per cent of angles.
 void orc_brief_descriptor(const uint8_t *img, int stride, float x, float y, float angle_deg, uint8_t *desc) {
     const float factorPI = (float)(M_PI / 180.f);
     float angle = (float)angle_deg * factorPI;
-    float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    float a = cosf(angle), b = sinf(angle);
     const uint8_t *center = img + (size_t)cvRoundF(y) * stride + cvRoundF(x);
     const signed char *pat = kOrcPattern31;
     auto value = [&](int idx) -> int {

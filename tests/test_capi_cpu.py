@@ -125,20 +125,6 @@ def test_std_sort_replay_matches_libstdcxx(tmp_path):
     assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout + out.stderr
 
 
-def test_sincos_polynomial_equals_libm_on_every_float(tmp_path):
-    """csrc/sincos_poly.h (the rotation of k_orient_desc) narrowed to float equals libm's cos/sin narrowed to float
-    for EVERY float in [0, 2 pi] (1.09e9 values, about 15 s with hardware FMA; a strided sweep without it)."""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = os.path.join(root, "tests", "cpp", "test_sincos.cpp")
-    exe = str(tmp_path / "tsc")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", src, "-o", exe])
-    out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=600)
-    if out.returncode < 0:  # no FMA unit on this host: software fma, strided
-        subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe])
-        out = subprocess.run([exe, "101"], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout + out.stderr
-
-
 @pytest.mark.parametrize("mode", ["1", "2", "3"])
 def test_path_code_octree_equals_oracle(mode):
     """The path-code formulations the device kernel is built from (octree_paths.h; 1 = node-list replay over

@@ -1,0 +1,36 @@
+"""-m gpu: the DEVICE evaluation of libm_f32.h (what k_orient_desc and k_frustum call) equals the GPU box's host libm
+on every float the path can produce - through the C ABI (ft_selftest_libm)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from fasttrack_amd import _capi, orb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("func,first,last", [(0, 0, 0x40C90FDC), (1, 0, 0x40C90FDC), (2, 1, 0x461C4000)],
+                         ids=["cosf[0,2pi]", "sinf[0,2pi]", "logf(0,1e4]"])
+def test_device_libm_equals_host_libm_exhaustively(func, first, last):
+    ctx = orb.Context(0)
+    L = _capi.lib()
+    checked, bad, first_bad = C.c_ulonglong(0), C.c_ulonglong(0), C.c_uint32(0)
+    _capi.check(L.ft_selftest_libm(ctx._h, func, first, last, 1, C.byref(checked), C.byref(bad), C.byref(first_bad)))
+    assert checked.value == last - first + 1
+    assert bad.value == 0, f"{bad.value} mismatches, first at bits 0x{first_bad.value:08x}"
+
+
+def test_device_libm_reproduces_the_glibc_vectors(golden_dir):
+    """the committed glibc 2.35 vectors (angles where cosf / sinf are not the correctly rounded values), one argument
+    at a time through the same entry point: a mismatch there names the GPU box's libm as a different one"""
+    import os
+    g = np.load(os.path.join(golden_dir, "libm_rotation_glibc235.npz"))
+    ctx = orb.Context(0)
+    L = _capi.lib()
+    rad = (g["angle_deg"] * np.float32(np.pi / np.float32(180.0))).astype(np.float32).view(np.uint32)
+    for func, args in ((0, rad), (1, rad), (2, g["ratio"].view(np.uint32)[:200])):
+        for b in args:
+            checked, bad = C.c_ulonglong(0), C.c_ulonglong(0)
+            _capi.check(L.ft_selftest_libm(ctx._h, func, int(b), int(b), 1, C.byref(checked), C.byref(bad), None))
+            assert checked.value == 1 and bad.value == 0, (func, hex(int(b)))

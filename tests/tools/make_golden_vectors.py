@@ -68,7 +68,43 @@ def search_case(name, w, h, nf, seed):
                         lf_n=la["n"], lf_best_dist=la["best_dist"], lf_best_idx=la["best_idx"])
 
 
+def libm_case(name, seed=1):
+    """The rBRIEF rotation binds to libm's cosf / sinf, PredictScale to logf (glibc 2.35 in this image).  48 angles at
+    which cosf / sinf (not correctly rounded) make computeOrbDescriptor sample a different pixel than the narrowed double
+    cos / sin would (found by tests/tools/find_libm_angles.cpp), with the descriptors the oracle computes there on a
+    seeded image, the cosf / sinf bits themselves, and logf on a sweep of PredictScale ratios."""
+    import ctypes
+    import subprocess
+    import tempfile
+    exe = os.path.join(tempfile.mkdtemp(), "fla")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off",
+                           os.path.join(ROOT, "tests", "tools", "find_libm_angles.cpp"), "-o", exe])
+    bits = [int(x, 16) for x in subprocess.run([exe, "48", str(seed)], capture_output=True, text=True, check=True).stdout.split()]
+    deg = np.array(bits, np.uint32).view(np.float32)
+    m = ctypes.CDLL("libm.so.6")
+    for f in (m.cosf, m.sinf, m.logf):
+        f.restype, f.argtypes = ctypes.c_float, [ctypes.c_float]
+    factor = np.float32(np.pi / np.float32(180.0))  # (float)(CV_PI / 180.f), ORBextractor.cc:68
+    rad = (deg * factor).astype(np.float32)
+    cs = np.array([m.cosf(float(r)) for r in rad], np.float32)
+    sn = np.array([m.sinf(float(r)) for r in rad], np.float32)
+    img = synth.make_image(96, 96, 11)
+    blurred = ob.gaussian_blur7(img)
+    L = ob.lib()
+    desc = np.zeros((len(deg), 32), np.uint8)
+    for i, d in enumerate(deg):
+        L.orc_brief_descriptor(blurred.ctypes.data, blurred.strides[0], ctypes.c_float(48.0), ctypes.c_float(47.0),
+                               ctypes.c_float(float(d)), desc[i].ctypes.data)
+    rng = np.random.default_rng(seed)
+    ratio = np.concatenate([np.float32(1.2) ** np.arange(-3, 12, dtype=np.float32),
+                            np.exp(rng.uniform(np.log(1e-3), np.log(1e4), 4000)).astype(np.float32)]).astype(np.float32)
+    lg = np.array([m.logf(float(r)) for r in ratio], np.float32)
+    np.savez_compressed(os.path.join(G, name), image=img, x=48.0, y=47.0, angle_deg=deg, cosf_bits=cs.view(np.uint32),
+                        sinf_bits=sn.view(np.uint32), descriptors=desc, ratio=ratio, logf_bits=lg.view(np.uint32))
+
+
 if __name__ == "__main__":
+    libm_case("libm_rotation_glibc235.npz")
     extract_case("extract_160x120_s1.npz", 160, 120, 300, 4, 1)
     extract_case("extract_320x240_s2_lap.npz", 320, 240, 500, 8, 2, lap=(100, 200))
     stereo_case("stereo_320x240_s3.npz", 320, 240, 500, 3)
