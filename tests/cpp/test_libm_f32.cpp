@@ -1,6 +1,6 @@
 // Host check of fasttrack_amd/csrc/libm_f32.h against the libm this process is linked with:
-//   * cosf_glibc / sinf_glibc == cosf / sinf for every float of [0, 6.2831860] (the rBRIEF rotation angle of
-//     /root/reference/src/ORBextractor.cc:72-74 is fastAtan2 degrees * (float)(pi/180)),
+//   * cosf_glibc / sinf_glibc == cosf / sinf for every float of [-6.2831860, 6.2831860] (the rBRIEF rotation angle of
+//     /root/reference/src/ORBextractor.cc:72-74 is fastAtan2 degrees * (float)(pi/180); KB8's psi is in [-pi, pi]),
 //   * logf_glibc == logf for every positive float up to 1e4 (PredictScale's ratio, /root/reference/src/MapPoint.cc:539)
 //     plus every float above it at a coarse stride.
 // Build with -DFT_LIBM_CONTRACT=1 (glibc's *_fma ifunc variant, the one an AVX2+FMA host runs) or =0 (the *_sse2
@@ -66,6 +66,12 @@ int main(int argc, char **argv) {
     float (*volatile hlog)(float) = logf;
     bad += sweep("cosf", 0, top, stride, threads, [](float x) { return ft_libm::cosf_glibc(x); }, [&](float x) { return hcos(x); });
     bad += sweep("sinf", 0, top, stride, threads, [](float x) { return ft_libm::sinf_glibc(x); }, [&](float x) { return hsin(x); });
+    // negative arguments: KannalaBrandt8::project takes cos / sin of psi = atan2f(y, x) in [-pi, pi]
+    // (/root/reference/src/CameraModels/KannalaBrandt8.cpp:74-75)
+    bad += sweep("cosf(neg)", 0x80000000u, 0x80000000u | top, stride, threads, [](float x) { return ft_libm::cosf_glibc(x); },
+                 [&](float x) { return hcos(x); });
+    bad += sweep("sinf(neg)", 0x80000000u, 0x80000000u | top, stride, threads, [](float x) { return ft_libm::sinf_glibc(x); },
+                 [&](float x) { return hsin(x); });
     // every positive float (subnormals included) up to 1e4, then the rest of the finite range at 64x the stride
     bad += sweep("logf(0,1e4]", 1, to_bits(1e4f), stride, threads, [](float x) { return ft_libm::logf_glibc(x); },
                  [&](float x) { return hlog(x); });

@@ -35,9 +35,9 @@ def test_device_restatement_equals_host_libm_on_every_float(tmp_path, contract):
     stride = "1" if (flags or not contract) else "101"
     out = subprocess.run([exe, stride, str(os.cpu_count() or 1)], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout + out.stderr
-    for fn in ("cosf", "sinf", "logf(0,1e4]", "logf(1e4,max]"):
+    for fn in ("cosf", "sinf", "cosf(neg)", "sinf(neg)", "logf(0,1e4]", "logf(1e4,max]"):
         assert f"{fn}: checked" in out.stdout
-    assert out.stdout.count("mismatches 0") == 4, out.stdout
+    assert out.stdout.count("mismatches 0") == 6, out.stdout
 
 
 def test_host_libm_and_oracle_reproduce_the_glibc_vectors(golden_dir):
