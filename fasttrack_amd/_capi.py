@@ -81,6 +81,14 @@ def declared_symbols() -> list[str]:
 _lib = None
 
 
+def _hip_runtime_mapped() -> bool:
+    try:
+        with open("/proc/self/maps") as f:
+            return "libamdhip64" in f.read()
+    except OSError:
+        return False
+
+
 def lib() -> C.CDLL:
     """Load the shared library (RTLD_LOCAL | RTLD_DEEPBIND so it binds to the system ROCm runtime even
     when another HIP runtime, e.g. the one bundled with PyTorch, is present in the process)."""
@@ -94,7 +102,18 @@ def lib() -> C.CDLL:
     # Application-side choice, made before the first HIP call of the process (the HIP runtime reads the variable once, when
     # it initialises): a hardware queue per lane of the context, which selects the library's eight-lane table
     # (include/fasttrack_amd.h, ft_context_create).  The library itself never touches the environment.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "10")
+    # If the HIP runtime is already mapped into the process (torch, a device probe) it may have initialised with four queues:
+    # exporting the variable now would make ft_context_hw_queues() report 10 while the runtime multiplexes onto 4 - the lanes
+    # of the shipped table would then share queues in an order nobody chose.  In that case the variable is left alone (the
+    # context takes private streams, the best four queues offer) and a warning says how to get the lanes.
+    if "GPU_MAX_HW_QUEUES" not in os.environ:
+        if _hip_runtime_mapped():
+            import warnings
+            warnings.warn("fasttrack_amd: a HIP runtime was loaded before the library and GPU_MAX_HW_QUEUES is unset - contexts "
+                          "will use private streams (about 10 % below the lane table on wide batches); export "
+                          "GPU_MAX_HW_QUEUES=10 before the first HIP call of the process", RuntimeWarning, stacklevel=2)
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = "10"
     mode = os.RTLD_LOCAL | os.RTLD_NOW | getattr(os, "RTLD_DEEPBIND", 0)
     L = C.CDLL(LIB_PATH, mode=mode)
     vp, i, f = C.c_void_p, C.c_int, C.c_float
@@ -110,6 +129,9 @@ def lib() -> C.CDLL:
     L.ft_context_host_threads.argtypes = [vp]
     L.ft_context_hw_queues.argtypes = [vp]
     L.ft_context_set_lane_map.argtypes = [vp, vp, i]
+    L.ft_context_set_option.argtypes = [vp, C.c_char_p, i]
+    L.ft_context_get_option.argtypes = [vp, C.c_char_p, ip]
+    L.ft_option_describe.argtypes = [i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), ip, C.POINTER(C.c_char_p)]
     L.ft_context_save_stats.argtypes = [vp, C.c_char_p]
     L.ft_context_set_kernel_timing.argtypes = [vp, i]
     L.ft_context_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]

@@ -102,9 +102,41 @@ int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, int width, int heig
 // hardware queues the HIP runtime multiplexes this process's streams onto: GPU_MAX_HW_QUEUES as the process environment
 // holds it (the runtime reads it once, when it initialises), 4 when it is unset
 int ft_hw_queues_hint() {
-    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    const char *e = ft_read_env("GPU_MAX_HW_QUEUES");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 4;
+}
+
+// ---- the environment is read HERE and nowhere else (ft_host.h, FT_TUNING_OPTIONS) ----------------------------------------
+const char *ft_read_env(const char *name) { return getenv(name); }
+const char *ft_debug_env(const char *name) { return strncmp(name, "FT_DEBUG_", 9) == 0 ? ft_read_env(name) : nullptr; }
+
+static const struct {
+    const char *name, *env, *doc;
+    int def;
+} kTuningTable[] = {
+#define FT_X(field, env, def, doc) {#field, env, doc, def},
+    FT_TUNING_OPTIONS(FT_X)
+#undef FT_X
+};
+static const int kTuningCount = (int)(sizeof kTuningTable / sizeof kTuningTable[0]);
+
+int *ft_tuning_field(ft_tuning &t, const char *name) {
+    if (!name) return nullptr;
+#define FT_X(field, env, def, doc) \
+    if (strcmp(name, #field) == 0 || strcmp(name, env) == 0) return &t.field;
+    FT_TUNING_OPTIONS(FT_X)
+#undef FT_X
+    return nullptr;
+}
+
+ft_tuning ft_tuning_from_env() {
+    ft_tuning t;
+    for (int i = 0; i < kTuningCount; i++) {
+        const char *e = ft_read_env(kTuningTable[i].env);
+        if (e && *e) *ft_tuning_field(t, kTuningTable[i].name) = atoi(e);
+    }
+    return t;
 }
 
 // "own" (private streams: empty map) or whole sets of four lane numbers in [0, 64); anything else is an error, not a
@@ -186,7 +218,9 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
     // table: a queue per lane, the upload stream and the matchers' stream) before its first HIP call - bench.py and the
     // Python driver do - and ft_context_hw_queues() / the "context.hw_queues" statistic say which table is in use.
     std::vector<int> userMap;
-    const char *lm = getenv("FT_LANE_MAP");
+    const char *lm = ft_read_env("FT_LANE_MAP");
+    // exported but empty (or blank) = unset: "FT_LANE_MAP= cmd" is how a shell neutralises a variable
+    if (lm && lm[strspn(lm, " \t")] == 0) lm = nullptr;
     const bool haveUserMap = lm != nullptr;
     if (haveUserMap) {  // checked before anything else: a typo must not pass as a different table
         std::string err;
@@ -221,8 +255,11 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
     ctx->pool = new ft::ThreadPool(host_threads - 1);
     // FT_LANE_MAP="a b o0 o1  a b o0 o1 ..." : lane of (stage A, stage B, octree 0, octree 1) for the 1st, 2nd, ... extractor
     // created on the context (the list wraps around); FT_LANE_MAP=own gives every extractor four streams of its own
+    ctx->tuning = ft_tuning_from_env();
     ctx->hwQueues = ft_hw_queues_hint();
-    if (ctx->hwQueues >= 8) {
+    // the shipped table was searched with 10 queues (a queue per lane, the upload stream, the matchers' stream): with fewer
+    // the lanes share queues in an order the runtime picks, which is what the table exists to avoid
+    if (ctx->hwQueues >= 10) {
         // searched with 10 queues (tools/lane_search.py): on 1280x720 / 512 pairs, and on 752x480 / 512 pairs for the small class
         // (climbed again at the end of round 3, when the octree tier had become short: two entries moved, +0.7 % on the
         // headline scenes, +1.1 % on dense ones)
@@ -234,8 +271,6 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
         ctx->laneMap = userMap;
         ctx->userLaneMap = true;
     }
-    ctx->addStat("context.hw_queues", 0.0);
-    ctx->stats["context.hw_queues"].second = ctx->hwQueues;
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete ctx->pool;
@@ -267,6 +302,7 @@ int ft_context_destroy(ft_context *ctx) {
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->scratchDev) hipFree(ctx->scratchDev);
     if (ctx->scratchPin) hipHostFree(ctx->scratchPin);
+    for (void *p : ctx->hostAllocs) hipHostFree(p);  // ft_host_malloc blocks the caller did not free: they go with the context
     delete ctx->pool;
     delete ctx;
     return FT_OK;
@@ -307,6 +343,35 @@ int ft_context_set_lane_map(ft_context *ctx, const int *map, int n) {
     return FT_OK;
 }
 
+int ft_context_set_option(ft_context *ctx, const char *name, int value) {
+    int *f = ctx ? ft_tuning_field(ctx->tuning, name) : nullptr;
+    if (!f) {
+        ft_set_error(std::string("ft_context_set_option: unknown option \"") + (name ? name : "(null)") + "\"");
+        return FT_ERR_INVALID;
+    }
+    *f = value;
+    return FT_OK;
+}
+
+int ft_context_get_option(const ft_context *ctx, const char *name, int *value) {
+    const int *f = ctx && value ? ft_tuning_field(const_cast<ft_context *>(ctx)->tuning, name) : nullptr;
+    if (!f) {
+        ft_set_error(std::string("ft_context_get_option: unknown option \"") + (name ? name : "(null)") + "\"");
+        return FT_ERR_INVALID;
+    }
+    *value = *f;
+    return FT_OK;
+}
+
+int ft_option_describe(int index, const char **name, const char **env, int *default_value, const char **doc) {
+    if (index < 0 || index >= kTuningCount) return FT_ERR_INVALID;
+    if (name) *name = kTuningTable[index].name;
+    if (env) *env = kTuningTable[index].env;
+    if (default_value) *default_value = kTuningTable[index].def;
+    if (doc) *doc = kTuningTable[index].doc;
+    return FT_OK;
+}
+
 int ft_context_save_stats(ft_context *ctx, const char *path) {
     if (!ctx || !path) return FT_ERR_INVALID;
     FILE *f = fopen(path, "w");
@@ -315,6 +380,7 @@ int ft_context_save_stats(ft_context *ctx, const char *path) {
         return FT_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(ctx->statsMutex);
+    fprintf(f, "context.hw_queues: %d (GPU_MAX_HW_QUEUES as the process environment held it when the context was created)\n", ctx->hwQueues);
     for (auto &kv : ctx->stats)
         fprintf(f, "%s: %.4f ms total, %ld calls, %.4f ms/call\n", kv.first.c_str(), kv.second.first, kv.second.second,
                 kv.second.second ? kv.second.first / kv.second.second : 0.0);
@@ -362,12 +428,19 @@ int ft_host_malloc(ft_context *ctx, size_t bytes, void **ptr) {
     if (!ctx || !ptr) return FT_ERR_INVALID;
     FT_HIP(hipSetDevice(ctx->device));
     FT_HIP(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lk(ctx->hostAllocMutex);
+    ctx->hostAllocs.push_back(*ptr);  // released by ft_host_free, or with the context
     return FT_OK;
 }
 
 int ft_host_free(ft_context *ctx, void *ptr) {
     if (!ctx) return FT_ERR_INVALID;
     FT_HIP(hipSetDevice(ctx->device));
+    {
+        std::lock_guard<std::mutex> lk(ctx->hostAllocMutex);
+        auto it = std::find(ctx->hostAllocs.begin(), ctx->hostAllocs.end(), ptr);
+        if (it != ctx->hostAllocs.end()) ctx->hostAllocs.erase(it);
+    }
     FT_HIP(hipHostFree(ptr));
     return FT_OK;
 }
@@ -389,7 +462,7 @@ int ft_memcpy_d2h(ft_context *ctx, void *dst, const void *src, size_t bytes) {
 }  // extern "C"
 
 int ft_debug_repeat(const char *name) {
-    static const char *env = getenv("FT_DEBUG_REPEAT");
+    static const char *env = ft_debug_env("FT_DEBUG_REPEAT");
     if (!env || !*env) return 1;
     const size_t n = strlen(name);
     for (const char *p = env; *p;) {

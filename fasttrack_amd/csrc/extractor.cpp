@@ -127,7 +127,7 @@ int buildGeometry(ft_extractor *ex, std::vector<FtTap> &taps) {
         // tested regions tile [19, w-19) x [19, h-19), ORBextractor.cc:1136-1158)
         v.stripBase = stripBase;
         if (nCols > 0) {
-            const int envRows = getenv("FT_STRIP_ROWS") ? std::max(8, std::min(120, atoi(getenv("FT_STRIP_ROWS")))) : 16;
+            const int envRows = std::max(8, std::min(120, ex->tune.strip_rows));
             const int tw = v.w - 2 * FT_EDGE_THRESHOLD, th = v.h - 2 * FT_EDGE_THRESHOLD;
             v.sNX = (tw + FT_STRIP_MAXW - 1) / FT_STRIP_MAXW;
             v.sW = (tw + v.sNX - 1) / v.sNX;
@@ -248,7 +248,7 @@ void freeAll(ft_extractor *ex) {
 // stages.  A batch is cut into sub-batches of consecutive slots so that the host octree of one
 // sub-batch overlaps with the kernels of the next (stage A on ex->stream, stage B on ex->streamB).
 // ------------------------------------------------------------------------------------------------
-int ft_pipeline_depth(int batch, bool deviceOctree) {
+int ft_pipeline_depth(const ft_tuning &t, int batch, bool deviceOctree) {
     // Host octree: sub-batches of ~16 images keep every launch large enough to fill the 256 CUs while the host
     // octree of one sub-batch hides behind the kernels of the next.  Device octree: nothing waits for the host,
     // and fewer, wider launches win (measured on MI355X, 256 pairs of 1280x720: depth 8 46.9k fps, depth 4
@@ -256,10 +256,7 @@ int ft_pipeline_depth(int batch, bool deviceOctree) {
     // only keep thin kernels (octree, copies) of one sub-batch under the wide kernels of the next; with all
     // kernels placing an image on one XCD the best shape is two sub-batches whatever the batch (512 pairs per
     // step: 65.0k, 384: 64.2k, 256: 63.7k, 768: 63.7k, 1024: 62.9k).  FT_PIPELINE_DEPTH overrides (1 = no pipelining).
-    static const int envDepth = [] {
-        const char *e = getenv("FT_PIPELINE_DEPTH");
-        return e ? std::max(1, std::min(FT_PIPE_MAX, atoi(e))) : 0;
-    }();
+    const int envDepth = t.pipeline_depth > 0 ? std::min(FT_PIPE_MAX, t.pipeline_depth) : 0;
     if (envDepth) return std::max(1, std::min(envDepth, batch));
     if (deviceOctree) return batch >= 256 ? 2 : 1;  // two sub-batches: 512 pairs 65.0k fps (3: 61.4k, 4: 60.1k, 1: 62.6k)
     return std::max(1, std::min(FT_PIPE_MAX, batch / 16));
@@ -274,7 +271,7 @@ int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch
     int rc = ft_set_device(ex->ctx);
     if (rc != FT_OK) return rc;
     const FtGeom &g = ex->geom;
-    static const bool uploadKernel = !(getenv("FT_UPLOAD_KERNEL") && atoi(getenv("FT_UPLOAD_KERNEL")) == 0);
+    const bool uploadKernel = ex->tune.upload_kernel != 0;
     if (!on_device && ex->stageHost && uploadKernel) {
         // graph path (latency mode): the host copies the frames into pinned staging, one (captured) kernel moves them
         // into the slot pyramids and writes the level-0 pointer table (ft_launch_upload)
@@ -373,7 +370,7 @@ int ft_extract_ensure_stage(ft_extractor *ex) {
 }
 // replay of a captured batch with host frames: refresh the staging copies the captured uploads read
 void ft_extract_restage(ft_extractor *ex, const uint8_t *const *images, int batch, int width, int height, int stride) {
-    static const bool uploadKernel = !(getenv("FT_UPLOAD_KERNEL") && atoi(getenv("FT_UPLOAD_KERNEL")) == 0);
+    const bool uploadKernel = ex->tune.upload_kernel != 0;
     for (int b = 0; b < batch; b++) {
         // the upload kernel reads the caller's pinned frame in place - only when its whole extent is pinned
         if (uploadKernel && ft_is_pinned_host_range(images[b], (size_t)(height - 1) * stride + width)) {
@@ -414,7 +411,7 @@ int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done) {
     int *cellCount = ex->d_cellCount + (size_t)b0 * g.totalCells;
     uint32_t *stage = ex->d_stage + (size_t)b0 * g.stagePerSlot;
     ex->evt.begin(tm, "kernel.pyr_down(all levels)", ex->stream);
-    int rc = ft_launch_pyramid(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->d_taps, al);
+    int rc = ft_launch_pyramid(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->d_taps, al, ex->tune.pyr_rows);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.fast_cells", ex->stream);
@@ -492,7 +489,7 @@ int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent
     a.sortList = ex->d_sortList + (size_t)(sub % FT_OCT_STREAMS) * ex->maxBatch * g.nlevels;
     const bool tm = ex->ctx->kernelTiming;
     ex->evt.begin(tm, "kernel.octree", so);
-    int rc = ft_launch_octree(so, g, nb, a);
+    int rc = ft_launch_octree(so, g, nb, a, ex->tune.oct_smem_pad);
     ex->evt.end(tm, so);
     if (rc != FT_OK) return rc;
     if (done) FT_HIP(hipEventRecord(done, so));
@@ -799,7 +796,8 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     ex->width = image_width;
     ex->height = image_height;
     ex->maxBatch = max_batch;
-    ex->fastStrips = getenv("FT_FAST_STRIPS") && atoi(getenv("FT_FAST_STRIPS")) != 0;
+    ex->tune = ctx->tuning;  // the extractor keeps the switches it was created under
+    ex->fastStrips = ex->tune.fast_strips != 0;
     std::vector<FtTap> taps;
     rc = buildGeometry(ex, taps);
     if (rc != FT_OK) {
@@ -934,28 +932,27 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         }
         o.poolCap = need + 16;
         // FT_DEVICE_OCTREE=0 keeps the octree on the host (also the path when a quota exceeds the kernel's limit)
-        const char *e = getenv("FT_DEVICE_OCTREE");
         // the node pools must fit a CU's LDS beside FT_OCT_MAXN keys (per-level quotas up to ~1900); u16 node indices
         (void)maxQ;
-        ex->deviceOctree = !(e && e[0] == '0') && o.poolCap < 30000 && ft_octree_smem_bytes(o.poolCap) <= 160 * 1024;
+        ex->deviceOctree = ex->tune.device_octree != 0 && o.poolCap < 30000 && ft_octree_smem_bytes(o.poolCap) <= 160 * 1024;
         o.histCap = o.sortCap = o.histGrid = o.histWanted = o.histFirst = 0;
-        ex->histEnabled = ex->deviceOctree && !(getenv("FT_OCT_HIST") && atoi(getenv("FT_OCT_HIST")) == 0) &&
+        ex->histEnabled = ex->deviceOctree && ex->tune.oct_hist != 0 &&
                           ft_octree_hist_smem_bytes(o.poolCap) <= 160 * 1024;
-        ex->histFirstMode = getenv("FT_OCT_HIST_FIRST") ? atoi(getenv("FT_OCT_HIST_FIRST")) : 1;
-        o.bigN = ex->deviceOctree && !(getenv("FT_OCT_BIG") && atoi(getenv("FT_OCT_BIG")) == 0) ? ft_octree_big_keys(o.poolCap) : 0;
+        ex->histFirstMode = ex->tune.oct_hist_first;
+        o.bigN = ex->deviceOctree && ex->tune.oct_big != 0 ? ft_octree_big_keys(o.poolCap) : 0;
         o.bigCount = ex->d_bigCount;
         o.bigList = ex->d_bigList;
         o.sortList = ex->d_sortList;
         o.low = nullptr;  // set per launch (ft_extract_launch_octree)
         if (ex->deviceOctree) {
-            if (getenv("FT_OCT_PROFILE")) {
+            if (ex->tune.oct_profile) {
                 FT_TRY(devAlloc(&o.prof, (size_t)FT_MAX_LEVELS * 8));
                 hipMemset(o.prof, 0, sizeof(unsigned long long) * FT_MAX_LEVELS * 8);
             }
             FT_TRY(devAlloc(&ex->d_candDev, B * g.candPerSlot));
             FT_TRY(devAlloc(&ex->d_candCountDev, B * g.nlevels));
             // FT_OCT_COMPACT=0: the first sorted tier in the plain LDS layout (64 instead of 49 KB per workgroup)
-            if (!(getenv("FT_OCT_COMPACT") && atoi(getenv("FT_OCT_COMPACT")) == 0) &&
+            if (ex->tune.oct_compact != 0 &&
                 ft_octree_smem_bytes(o.poolCap, true) < ft_octree_smem_bytes(o.poolCap, false))
                 FT_TRY(devAlloc(&ex->d_octLow, B * g.nlevels * (size_t)FT_OCT_MAXN));
             hipError_t me = hipMemset(ex->d_overflow, 0, sizeof(int));
@@ -990,14 +987,15 @@ int ft_octree_distribute(const int *xys, int n, int minX, int maxX, int minY, in
     // FT_OCTREE_PATHS=1 / 2 / 3 route this host entry point through the path-code formulations the device kernels
     // are built from (1: node list replay, 2: round formulation over sorted keys, 3: over a histogram), so they can be
     // checked without a GPU
-    static const int usePaths = getenv("FT_OCTREE_PATHS") ? atoi(getenv("FT_OCTREE_PATHS")) : 0;
+    const ft_tuning tune = ft_tuning_from_env();  // a host entry point without a context: the switches of this call
+    const int usePaths = tune.octree_paths;
     int k;
     if (usePaths == 3 && n < 65535) {
         // 3: the histogram formulation of k_octree_hist (FT_OCTREE_HIST_BINS bins, default 8192); a level it gives up on
         // goes to the sorted rounds, as on the device.  FT_OCTREE_HIST_STRICT=1 reports the give-up instead.
-        static const int bins = getenv("FT_OCTREE_HIST_BINS") ? atoi(getenv("FT_OCTREE_HIST_BINS")) : FT_OCT_HIST_BINS;
+        const int bins = tune.octree_hist_bins;
         k = ft::distribute_octree_hist(packed.data(), n, minX, maxX, minY, maxY, N, bins, keep);
-        if (k == -2 && !(getenv("FT_OCTREE_HIST_STRICT") && atoi(getenv("FT_OCTREE_HIST_STRICT")))) {
+        if (k == -2 && !tune.octree_hist_strict) {
             keep.clear();
             k = ft::distribute_octree_rounds(packed.data(), n, minX, maxX, minY, maxY, N, keep);
         }
@@ -1090,11 +1088,11 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
     FtTimer tAll;
     int rc = ft_set_device(ex->ctx);
     if (rc != FT_OK) return rc;
-    const int S = ft_pipeline_depth(batch, ex->deviceOctree);
+    const int S = ft_pipeline_depth(ex->tune, batch, ex->deviceOctree);
     const int sb = (batch + S - 1) / S;
     // everything a batch needs with the device octree, enqueued without a host synchronisation (capture != 0: ex->stream is
     // being captured into a graph; the octree / stage-B streams fork from it through events and are joined back)
-    static const bool deliverOn = !(getenv("FT_DELIVER_KERNEL") && atoi(getenv("FT_DELIVER_KERNEL")) == 0);
+    const bool deliverOn = ex->tune.deliver_kernel != 0;
     const bool deliver = deliverOn && batch <= 8;  // (FtDeliverArgs, ft_internal.h)
     auto enqueueDevice = [&](int capture) -> int {
         int r = ft_extract_prepare(ex, images, batch, on_device, width, height, stride);
@@ -1156,7 +1154,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
     };
     bool done = false;
     const bool devWanted = ex->deviceOctree;
-    static const bool graphsOn = !(getenv("FT_GRAPH") && getenv("FT_GRAPH")[0] == '0');
+    const bool graphsOn = ex->tune.graph != 0;
     if (graphsOn && !ex->graphDisabled && ex->ownStreams && ex->deviceOctree && !ex->ctx->kernelTiming && batch >= 1 && batch <= 8 &&
         batch <= ex->maxBatch && width == ex->width && height == ex->height && stride >= width) {
         bool ok = true;
@@ -1396,7 +1394,8 @@ int ft_extractor_octree_on_device(ft_extractor *ex, int level, const int *xys, i
     if (rc != FT_OK) return rc;
     std::vector<uint32_t> packed(std::max(n, 1));
     for (int i = 0; i < n; i++) {
-        FT_REQUIRE(xys[3 * i] >= 3 && xys[3 * i] < 4096 && xys[3 * i + 1] >= 3 && xys[3 * i + 1] < 4096 && xys[3 * i + 2] >= 1 &&
+        FT_REQUIRE(xys[3 * i] >= 3 && xys[3 * i] - 3 < g.lv[level].nCols * g.lv[level].wCell && xys[3 * i] < 4096 && xys[3 * i + 1] >= 3 &&
+                       xys[3 * i + 1] - 3 < g.lv[level].nRows * g.lv[level].hCell && xys[3 * i + 1] < 4096 && xys[3 * i + 2] >= 1 &&
                        xys[3 * i + 2] < 256,
                    "candidate out of range");
         packed[i] = ft_pack_cand(xys[3 * i], xys[3 * i + 1], xys[3 * i + 2]);

@@ -32,6 +32,47 @@
 #define FT_OCT_STREAMS 2
 #define FT_LANE_STREAMS (2 + FT_OCT_STREAMS)
 
+// ---- tuning options --------------------------------------------------------------------------------------------------
+// Every switch of the library that is not a debugging aid, in ONE table: name (as ft_context_set_option takes it), the
+// environment variable that sets its initial value, the default, and what it does.  ft_context_create reads the environment
+// ONCE into ft_context::tuning; ft_context_set_option changes the context's copy; extractors, front ends and tracked frames
+// take their switches from the context when they are CREATED (an option set later applies to objects created later; the
+// search switches are read per call).  Nothing else in the library reads FT_* variables except the FT_DEBUG_* aids
+// (ft_debug_env, context.cpp) and FT_LANE_MAP (a list, ft_context_create).
+#define FT_TUNING_OPTIONS(X)                                                                                                  \
+    X(pipeline_depth, "FT_PIPELINE_DEPTH", 0, "sub-batches a throughput batch is enqueued as (0 = automatic, 1 = no pipelining, <= 8)") \
+    X(device_octree, "FT_DEVICE_OCTREE", 1, "DistributeOctTree on the device (0 = host thread pool)")                        \
+    X(oct_hist, "FT_OCT_HIST", 1, "histogram tier of the device octree for levels above 4096 candidates")                    \
+    X(oct_hist_first, "FT_OCT_HIST_FIRST", 1, "histogram formulation for every level: 0 never, 1 latency-mode launches, 2 always") \
+    X(oct_big, "FT_OCT_BIG", 1, "sorted big tier of the device octree (up to 16384 keys per level)")                         \
+    X(oct_compact, "FT_OCT_COMPACT", 1, "first sorted tier in the compact LDS layout (49 instead of 64 KB per workgroup)")   \
+    X(oct_profile, "FT_OCT_PROFILE", 0, "per-level phase clocks of k_octree (slot 0) kept on the device")                    \
+    X(oct_smem_pad, "FT_OCT_SMEM_PAD", 0, "extra LDS bytes per k_octree workgroup (occupancy probe)")                        \
+    X(fast_strips, "FT_FAST_STRIPS", 0, "FAST over 62-column strips instead of one wave per cell")                           \
+    X(strip_rows, "FT_STRIP_ROWS", 16, "rows per strip of the strips form (8 .. 120)")                                       \
+    X(pyr_rows, "FT_PYR_ROWS", 1, "row-streaming pyramid kernel for launches of 8+ images (0 = tile kernel always)")         \
+    X(upload_kernel, "FT_UPLOAD_KERNEL", 1, "latency mode: frames go up through k_upload instead of DMA copies")             \
+    X(deliver_kernel, "FT_DELIVER_KERNEL", 1, "latency mode: one kernel writes all results into pinned host memory")         \
+    X(graph, "FT_GRAPH", 1, "latency mode: batches of <= 8 frames are captured and replayed as HIP graphs")                  \
+    X(paired, "FT_PAIRED", 1, "latency-mode stereo front ends run both cameras through one set of launches")                \
+    X(pass_burst, "FT_PASS_BURST", 12, "projection searches, multi-launch path: claim passes enqueued per host round trip (2 .. 14)") \
+    X(search_cache, "FT_SEARCH_CACHE", 1, "projection searches: later claim passes walk the cached candidate keys")          \
+    X(search_grid, "FT_SEARCH_GRID", 1, "projection searches: CSR grid of the frame built on the device")                    \
+    X(search_persistent, "FT_SEARCH_PERSISTENT", 1, "projection searches: all claim passes inside ONE launch (grid barrier) when the points fit the chip") \
+    X(octree_paths, "FT_OCTREE_PATHS", 0, "ft_octree_distribute (host entry): 1 / 2 / 3 = the path-code formulations of the device kernels") \
+    X(octree_hist_bins, "FT_OCTREE_HIST_BINS", FT_OCT_HIST_BINS, "ft_octree_distribute, formulation 3: histogram bins")      \
+    X(octree_hist_strict, "FT_OCTREE_HIST_STRICT", 0, "ft_octree_distribute, formulation 3: report a give-up instead of falling back")
+
+struct ft_tuning {
+#define FT_X(field, env, def, doc) int field = def;
+    FT_TUNING_OPTIONS(FT_X)
+#undef FT_X
+};
+ft_tuning ft_tuning_from_env();                                      // defaults overridden by the FT_* variables that are set
+int *ft_tuning_field(ft_tuning &t, const char *name);                // by option name or by environment name; null = unknown
+const char *ft_debug_env(const char *name);                          // FT_DEBUG_* aids: the one other place that reads the environment
+const char *ft_read_env(const char *name);                           // context.cpp only: the single getenv of the library
+
 struct ft_context {
     int device = 0;
     std::string deviceName;
@@ -53,7 +94,10 @@ struct ft_context {
     std::mutex matchMutex;
     void *scratchDev = nullptr, *scratchPin = nullptr;
     size_t scratchDevBytes = 0, scratchPinBytes = 0;
+    std::mutex hostAllocMutex;
+    std::vector<void *> hostAllocs;  // live ft_host_malloc blocks
     bool kernelTiming = false;  // ft_context_set_kernel_timing
+    ft_tuning tuning;           // FT_TUNING_OPTIONS: read from the environment by ft_context_create, changed by ft_context_set_option
     std::mutex statsMutex;
     std::map<std::string, std::pair<double, long>> stats;  // name -> (total ms, calls)
     void addStat(const char *name, double ms) {
@@ -116,6 +160,7 @@ struct FtTimer {
 
 struct ft_extractor {
     ft_context *ctx = nullptr;
+    ft_tuning tune;  // copy of ctx->tuning taken when the extractor was created
     int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, width = 0, height = 0, maxBatch = 0;
     float scaleFactor = 1.2f;
     std::vector<float> sf, invsf, sigma2, invsigma2;
@@ -263,7 +308,7 @@ int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes);  // gr
 int ft_usable_cpus();
 int ft_hw_queues_hint();
 bool ft_parse_lane_map(const char *text, std::vector<int> &map, std::string &err);
-int ft_pipeline_depth(int batch, bool deviceOctree);
+int ft_pipeline_depth(const ft_tuning &t, int batch, bool deviceOctree);
 // validation, level-0 pointers / uploads of a whole batch (async on ex->stream)
 int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width, int height,
                        int stride);

@@ -169,6 +169,7 @@ void ft_set_error(const std::string &msg);
 // per-launch event times nor the rocprof durations (both inflated by concurrency) show.
 int ft_debug_repeat(const char *name);
 int ft_hip_fail(hipError_t e, const char *what, const char *file, int line);
+const char *ft_debug_env(const char *name);  // FT_DEBUG_* aids only (context.cpp)
 
 #define FT_HIP(call)                                                              \
     do {                                                                          \
@@ -179,7 +180,7 @@ int ft_hip_fail(hipError_t e, const char *what, const char *file, int line);
 // ---- kernel launchers (kernels_extract.hip) -------------------------------------------------
 // l0: device array [batch] of level-0 pointers; pyr: base of the slot pyramids
 int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                      uint8_t *pyr, const FtTap *taps, int alignedLoads);
+                      uint8_t *pyr, const FtTap *taps, int alignedLoads, int rowsKernel);
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
                          uint32_t *stage, int ordered, const FtCellRec *cellTab);
@@ -201,7 +202,7 @@ size_t ft_fast_strips_smem_bytes(const FtGeom &g);
 int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                           const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *selCount,
                           const FtOctArgs &layout, int *nSel, ft_keypoint *keys, uint8_t *desc);
-int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a);
+int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a, int smemPad = 0);
 // test tap: 7x7 Gaussian of a whole level through k_orient_desc's blur routines (dst on the device)
 int ft_launch_blur_level(hipStream_t st, const uint8_t *img, int pitch, int w, int h, uint8_t *dst, int dstPitch);
 size_t ft_octree_smem_bytes(int poolCap, bool compact = false);

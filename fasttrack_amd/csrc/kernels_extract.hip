@@ -1843,8 +1843,8 @@ static bool pyr_rows_fits(const FtGeom &g, int level) {
 }
 
 int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                      uint8_t *pyr, const FtTap *taps, int alignedLoads) {
-    static const bool rowsOn = !(getenv("FT_PYR_ROWS") && atoi(getenv("FT_PYR_ROWS")) == 0);
+                      uint8_t *pyr, const FtTap *taps, int alignedLoads, int rowsKernel) {
+    const bool rowsOn = rowsKernel != 0;
     for (int rep = ft_debug_repeat("pyr"); rep > 0; rep--)
     for (int level = 1; level < g.nlevels; level++) {
         const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
@@ -1898,7 +1898,7 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
     }
     typedef void (*FastFn)(FtGeom, const uint8_t *const *, int, const uint8_t *, int, int, int, int *, uint32_t *, const FtCellRec *,
                            FtSlotGrid, int, int, int);
-    static const int dbg = getenv("FT_FAST_DBG") ? atoi(getenv("FT_FAST_DBG")) : 0;
+    static const int dbg = ft_debug_env("FT_DEBUG_FAST") ? atoi(ft_debug_env("FT_DEBUG_FAST")) : 0;
     FtSlotGrid sg;
     sg.blocksPerSlot = 0; sg.batch = batch; sg.xcdMap = 0; sg.magic = 0;
     if (batch >= 8) sg = ft_slot_grid(g.totalCells, batch, grid);  // image -> XCD; smaller launches keep the cell-run mapping
@@ -1907,7 +1907,7 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
                                  : k_fast_cells<0, true>;  // any-size cells: the linear pass is ordered anyway
     if (smem > 64 * 1024)  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
         FT_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    static const bool occDbg = getenv("FT_DEBUG_OCC") != nullptr;  // resident workgroups per CU as the runtime computes them
+    static const bool occDbg = ft_debug_env("FT_DEBUG_OCC") != nullptr;  // resident workgroups per CU as the runtime computes them
     if (occDbg) {
         int nb = 0;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fn, 64, smem);
@@ -1984,7 +1984,7 @@ int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint
     const int kpw = batch >= 8 ? OD_KPW_WIDE : 1;
     const FtSlotGrid sg = ft_slot_grid((g.maxKp + OD_WAVES * kpw - 1) / (OD_WAVES * kpw), batch, grid);
     const size_t smem = OD_WAVES * (size_t)OD_WAVE_BYTES;
-    static const bool occDbg = getenv("FT_DEBUG_OCC") != nullptr;
+    static const bool occDbg = ft_debug_env("FT_DEBUG_OCC") != nullptr;
     if (occDbg) {
         int nb = 0;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kpw == 1 ? (const void *)k_orient_desc<1> : (const void *)k_orient_desc<OD_KPW_WIDE>,

@@ -1027,12 +1027,11 @@ int ft_octree_big_keys(int poolCap) {
     return 0;
 }
 
-int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a) {
-    // FT_OCT_SMEM_PAD (a probe): extra bytes of LDS per workgroup of the sorted tier - what its footprint costs the kernels
-    // that share the CUs with it
-    static const size_t pad = getenv("FT_OCT_SMEM_PAD") ? (size_t)atoi(getenv("FT_OCT_SMEM_PAD")) : 0;
-    const size_t smem = ft_octree_smem_bytes(a.poolCap, a.low != nullptr) + pad;
-    if (getenv("FT_DEBUG_OCC")) fprintf(stderr, "[ft] k_octree: %zu B of LDS per workgroup (pool %d)\n", smem, a.poolCap);
+int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a, int smemPad) {
+    // smemPad (option oct_smem_pad, a probe): extra bytes of LDS per workgroup of the sorted tier - what its footprint costs
+    // the kernels that share the CUs with it
+    const size_t smem = ft_octree_smem_bytes(a.poolCap, a.low != nullptr) + (size_t)std::max(smemPad, 0);
+    if (ft_debug_env("FT_DEBUG_OCC")) fprintf(stderr, "[ft] k_octree: %zu B of LDS per workgroup (pool %d)\n", smem, a.poolCap);
     if (smem > 64 * 1024)  // large quotas: raise the dynamic LDS limit (per device, so not cached in a static)
         FT_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const size_t smemHist = a.histCap > 0 ? ft_octree_hist_smem_bytes(a.poolCap) : 0;
@@ -1055,7 +1054,7 @@ int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs
     }
     for (int rep = ft_debug_repeat("octree"); rep > 0; rep--) {
         // the list counters of the launch ([2] and [3], the demand, are the host's to reset)
-        if (a.bigN || a.histCap > 0) FT_HIP(hipMemsetAsync(a.bigCount, 0, 2 * sizeof(int), st));
+        if (a.bigN || a.histCap > 0 || a.histWanted) FT_HIP(hipMemsetAsync(a.bigCount, 0, 2 * sizeof(int), st));
         hipLaunchKernelGGL(k_octree, dim3(batch, g.nlevels), dim3(OCT_THREADS), smem, st, g, a);
         if (a.histCap > 0) hipLaunchKernelGGL(k_octree_hist, dim3(std::min(a.histCap, std::max(a.histGrid, 1))), dim3(OCT_THREADS), smemHist, st, g, a);
         if (a.bigN && a.sortCap > 0) hipLaunchKernelGGL(k_octree_big, dim3(a.sortCap), dim3(OCT_THREADS), smemBig, st, g, a);

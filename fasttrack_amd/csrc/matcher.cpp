@@ -122,7 +122,7 @@ int ft_stereo_frontend_create(ft_context *ctx, int nfeatures, float scale_factor
     fe->mbf = mbf;
     fe->mb = mb;
     fe->maxBatch = max_batch;
-    static const bool pairedOn = !(getenv("FT_PAIRED") && atoi(getenv("FT_PAIRED")) == 0);
+    const bool pairedOn = ctx->tuning.paired != 0;
     fe->pairedCapable = pairedOn && max_batch >= 1 && max_batch <= FT_GRAPH_MAX_BATCH;
     int rc = ft_extractor_create(ctx, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, image_width,
                                  image_height, fe->pairedCapable ? 2 * max_batch : max_batch, &fe->exL);
@@ -370,7 +370,7 @@ static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL
     // software pipeline over sub-batches: while the host distributes the keypoints of sub-batch s, the
     // GPU already runs pyramid + FAST of sub-batch s+1 (stage-A streams) and descriptors / matching of
     // sub-batch s-1 (stage-B streams)
-    const int S = ft_pipeline_depth(batch, L->deviceOctree && R->deviceOctree);
+    const int S = ft_pipeline_depth(L->tune, batch, L->deviceOctree && R->deviceOctree);
     const int sb = (batch + S - 1) / S;
     // device octree: candidates, selection and counts stay on the device, so the whole batch is enqueued
     // without a single host synchronisation; otherwise the host octree of sub-batch s runs between the stages
@@ -389,7 +389,7 @@ static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL
     hipStream_t st = L->streamB;
     // latency mode: the results of a small batch are written to pinned host memory by one kernel (FtDeliverArgs); large
     // batches keep the DMA copies, which cost no compute units
-    static const bool deliverOn = !(getenv("FT_DELIVER_KERNEL") && atoi(getenv("FT_DELIVER_KERNEL")) == 0);
+    const bool deliverOn = fe->exL->tune.deliver_kernel != 0;
     const bool deliver = deliverOn && dev && batch <= FT_GRAPH_MAX_BATCH;
     double tOct = 0, tWait = 0, tLaunch = 0;
     for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
@@ -481,7 +481,7 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     const bool direct = isPinnedHost(keysL) && isPinnedHost(descL) && isPinnedHost(keysR) && isPinnedHost(descR) &&
                         isPinnedHost(uright) && isPinnedHost(depth) && (!dev || capacity >= g.maxKp);
     // ---- latency mode: small batches with a fixed call shape run as one captured graph ----
-    static const bool graphsOn = !(getenv("FT_GRAPH") && getenv("FT_GRAPH")[0] == '0');
+    const bool graphsOn = fe->exL->tune.graph != 0;
     bool useGraph = graphsOn && !fe->graphDisabled && L->ownStreams && R->ownStreams && dev && direct && !fe->ctx->kernelTiming && batch >= 1 &&
                     batch <= FT_GRAPH_MAX_BATCH && batch <= fe->maxBatch && width == L->width && height == L->height &&
                     stride >= width;

@@ -104,15 +104,7 @@ FtDevFrame devFrame(const ft_frame_view *F, const FrameLayout &L, uint8_t *dev) 
 #define FT_PASS_BURST_MAX 14  // flag slots per burst parity (16) and the 64-byte flag window of the pinned result area bound it
 // passes per burst: with the candidate cache a pass is ~12 us and an early-exit pass ~5 us, a round trip to the host ~40 us,
 // and a search needs 9 - 13 passes - one burst of 12 mostly does it (FT_PASS_BURST=<n> to experiment)
-static int passBurst() {
-    static const int n = [] {
-        const char *e = getenv("FT_PASS_BURST");
-        const int v = e ? atoi(e) : 12;
-        return std::min(std::max(v, 2), FT_PASS_BURST_MAX);
-    }();
-    return n;
-}
-#define FT_PASS_BURST (passBurst())
+static int passBurst(const ft_context *ctx) { return std::min(std::max(ctx->tuning.pass_burst, 2), FT_PASS_BURST_MAX); }
 // device buffers of the claim iteration: res 2 x 4 nPoints ints, head 3 x nKp directly followed by 16 flag ints (two burst
 // parities x FT_PASS_BURST), next 2 x 4 nPoints
 struct PassBufs {
@@ -126,7 +118,7 @@ struct PassBufs {
 template <typename SearchFn, typename DownloadFn>
 int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const PassBufs &B, FtClaims &C, SearchFn search,
                DownloadFn download, const int *hostFlags, int **resFinal, int *passes) {
-    (void)ctx;
+    const int FT_PASS_BURST = passBurst(ctx);
     *resFinal = B.res;
     *passes = 0;
     if (nPoints <= 0) {
@@ -195,20 +187,17 @@ struct PassLayout {
     size_t res, head, next, cache;
     bool haveCache;
 };
-bool searchCacheOn() {
-    static const bool on = !(getenv("FT_SEARCH_CACHE") && atoi(getenv("FT_SEARCH_CACHE")) == 0);
-    return on;
-}
+bool searchCacheOn(const ft_context *ctx) { return ctx->tuning.search_cache != 0; }
 size_t searchCacheBytes(int M) { return 8 * (size_t)FT_CACHE_WORDS * (size_t)std::max(M, 1); }
 // cacheInArena: the candidate cache (device only, 8 KB per point) lives at the end of the arena - the stand-alone searches,
 // whose arena sizes the context's device scratch; a tracked frame owns a cache buffer of its own, so that its pinned mirror
 // of the arena stays small
-PassLayout layoutPasses(Arena &a, int M, int N, bool cacheInArena) {
+PassLayout layoutPasses(const ft_context *ctx, Arena &a, int M, int N, bool cacheInArena) {
     PassLayout L;
     L.res = a.take(32 * (size_t)M);
     L.head = a.take(12 * (size_t)std::max(N, 1) + 128);
     L.next = a.take(32 * (size_t)M);
-    L.haveCache = cacheInArena && searchCacheOn();
+    L.haveCache = cacheInArena && searchCacheOn(ctx);
     L.cache = L.haveCache ? a.take(searchCacheBytes(M)) : 0;
     return L;
 }
@@ -223,9 +212,8 @@ PassBufs passBufs(const PassLayout &L, uint8_t *dev, const int *obs, unsigned lo
 }
 // Frame::mGrid of a frame staged in the arena: CSR arrays behind the frame's own, built by one small launch
 size_t layoutGrid(Arena &a, int N) { return a.take(sizeof(int) * (2 * (size_t)(FT_GRID_CELLS + 1) + (size_t)std::max(N, 1))); }
-int buildGrid(hipStream_t st, FtDevFrame &DF, int *grid) {
-    static const bool gridOn = !(getenv("FT_SEARCH_GRID") && atoi(getenv("FT_SEARCH_GRID")) == 0);
-    if (!gridOn) return FT_OK;
+int buildGrid(const ft_context *ctx, hipStream_t st, FtDevFrame &DF, int *grid) {
+    if (!ctx->tuning.search_grid) return FT_OK;
     const int nL = DF.Nleft == -1 ? DF.N : DF.Nleft;
     int *startL = grid, *startR = grid + (FT_GRID_CELLS + 1), *idx = grid + 2 * (FT_GRID_CELLS + 1);
     const bool two = DF.Nleft != -1;
@@ -519,7 +507,7 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
                  oPyr = a.take(4 * (size_t)M);
     const size_t oDesc = a.take(32 * (size_t)M), oObs = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const PassLayout PL = layoutPasses(a, M, N, true);
+    const PassLayout PL = layoutPasses(ctx, a, M, N, true);
     const size_t oGrid = layoutGrid(a, N);
     const size_t oRaw = a.take(40 * (size_t)M);
     const size_t total = a.off;
@@ -544,7 +532,7 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     hipStream_t st = ctx->stream;
     FT_HIP(hipMemcpyAsync(dev, pin, inputBytes, hipMemcpyHostToDevice, st));
     FtDevFrame DF = devFrame(F, FL, dev);
-    rc = buildGrid(st, DF, (int *)(dev + oGrid));
+    rc = buildGrid(ctx, st, DF, (int *)(dev + oGrid));
     if (rc != FT_OK) return rc;
     FtDevLocalPoints DP;
     DP.M = M;
@@ -611,7 +599,7 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     const size_t oValid = a.take(M), oPos = a.take(12 * (size_t)M), oDesc = a.take(32 * (size_t)M),
                  oObs = a.take(4 * (size_t)M), oOct = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const PassLayout PL = layoutPasses(a, M, N, true);
+    const PassLayout PL = layoutPasses(ctx, a, M, N, true);
     const size_t oGrid = layoutGrid(a, N);
     const size_t oRaw = a.take(16 * (size_t)M);
     const size_t total = a.off;
@@ -628,7 +616,7 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     hipStream_t st = ctx->stream;
     FT_HIP(hipMemcpyAsync(dev, pin, inputBytes, hipMemcpyHostToDevice, st));
     FtDevFrame DF = devFrame(Cur, FL, dev);
-    rc = buildGrid(st, DF, (int *)(dev + oGrid));
+    rc = buildGrid(ctx, st, DF, (int *)(dev + oGrid));
     if (rc != FT_OK) return rc;
     FtDevLastPoints DL;
     DL.N = M;
@@ -809,7 +797,7 @@ int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, 
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_r2l, sizeof(int) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_work, tf->workBytes);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_grid, sizeof(int) * (2 * (size_t)(FT_GRID_CELLS + 1) + K));
-    if (e == hipSuccess && searchCacheOn()) e = hipMalloc((void **)&tf->d_cache, searchCacheBytes(max_points));
+    if (e == hipSuccess && searchCacheOn(ctx)) e = hipMalloc((void **)&tf->d_cache, searchCacheBytes(max_points));
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_work, tf->workBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_holderUp, sizeof(int) * K, hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -864,7 +852,7 @@ int ft_tracked_frame_upload(ft_tracked_frame *tf, const ft_frame_view *F) {
     tf->DF.holderObs = tf->d_holder;
     tf->DF.l2r = F->Nleft != -1 ? tf->d_l2r : nullptr;
     tf->DF.r2l = F->Nleft != -1 ? tf->d_r2l : nullptr;
-    rc = buildGrid(st, tf->DF, tf->d_grid);  // the grid of the frame, once: both searches look up their windows in it
+    rc = buildGrid(tf->ctx, st, tf->DF, tf->d_grid);  // the grid of the frame, once: both searches look up their windows in it
     if (rc != FT_OK) return rc;
     FT_HIP(hipStreamSynchronize(st));
     tf->angles.resize(F->N);
@@ -903,7 +891,7 @@ int ft_tracked_frame_bind_stereo(ft_tracked_frame *tf, ft_stereo_frontend *fe, i
     tf->angles.resize(N);
     for (int i = 0; i < N; i++) tf->angles[i] = meta->keys[i].angle;
     if (N) FT_HIP(hipMemcpy(tf->d_holder, tf->holder.data(), sizeof(int) * N, hipMemcpyHostToDevice));
-    rc = buildGrid(tf->ctx->stream, tf->DF, tf->d_grid);  // ordered in front of the searches on the context stream
+    rc = buildGrid(tf->ctx, tf->ctx->stream, tf->DF, tf->d_grid);  // ordered in front of the searches on the context stream
     if (rc != FT_OK) return rc;
     tf->loaded = true;
     return FT_OK;
@@ -936,7 +924,7 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     const size_t oValid = a.take(M), oPos = a.take(12 * (size_t)M), oDesc = a.take(32 * (size_t)M),
                  oObs = a.take(4 * (size_t)M), oOct = a.take(4 * (size_t)M);
     const size_t inputBytes = a.off;
-    const PassLayout PL = layoutPasses(a, M, N, false);
+    const PassLayout PL = layoutPasses(tf->ctx, a, M, N, false);
     FT_REQUIRE(a.off <= tf->workBytes, "tracked frame work arena too small");
     uint8_t *pin = tf->h_work, *dev = tf->d_work;
     memcpy(pin + oValid, L->valid, M);
@@ -1003,7 +991,7 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
     layoutFrustum(M, P->skip != nullptr, a, FL, &fInputEnd);
     const size_t fOutEnd = a.off;
     const size_t oDesc = a.take(32 * (size_t)M), oObs = a.take(4 * (size_t)M);
-    const PassLayout PL = layoutPasses(a, M, N, false);
+    const PassLayout PL = layoutPasses(tf->ctx, a, M, N, false);
     FT_REQUIRE(a.off <= tf->workBytes, "tracked frame work arena too small");
     uint8_t *pin = tf->h_work, *dev = tf->d_work;
     stageFrustum(P, FL, pin);

@@ -28,18 +28,57 @@ class Context:
         self.device = device
 
     def close(self):
+        """Destroys the context.  ft_context_destroy refuses (FT_ERR_INVALID) while extractors, front ends or tracked frames
+        of the context are alive: then NOTHING is released here - the handle and the pinned arrays those objects may still
+        write into stay valid - and the error is raised, so an early close() cannot leak the context silently."""
         if getattr(self, "_h", None):
-            for p in getattr(self, "_pinned", []):
-                lib().ft_host_free(self._h, p)
-            self._pinned = []
-            lib().ft_context_destroy(self._h)
+            check(lib().ft_context_destroy(self._h))  # destroys only when nothing lives on the context any more ...
             self._h = None
+            self._pinned = []  # ... and takes the pinned allocations of ft_host_malloc with it (context.cpp)
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+    # ---- tuning options (ft_context_set_option; the table is FT_TUNING_OPTIONS in csrc/ft_host.h) ----
+    def set_option(self, name: str, value: int):
+        check(lib().ft_context_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        check(lib().ft_context_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """context manager: `with ctx.options(device_octree=0): ex = ORBextractor(ctx, ...)` - objects created inside take the
+        switches, the previous values come back afterwards"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = {k: self.get_option(k) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+        return cm()
+
+    @staticmethod
+    def option_table():
+        """[(name, environment variable, default, description)] of every tuning option"""
+        out = []
+        i = 0
+        while True:
+            n, e, d, doc = C.c_char_p(), C.c_char_p(), C.c_int(), C.c_char_p()
+            if lib().ft_option_describe(i, C.byref(n), C.byref(e), C.byref(d), C.byref(doc)) != 0:
+                return out
+            out.append((n.value.decode(), e.value.decode(), d.value, doc.value.decode()))
+            i += 1
 
     def synchronize(self):
         check(lib().ft_context_synchronize(self._h))

@@ -77,6 +77,39 @@ FT_API int ft_context_hw_queues(const ft_context *ctx);
  * octree 1) lane numbers in [0, 64) for the 1st, 2nd, ... extractor (wrapping around); n = 0: private streams for every
  * extractor.  What FT_LANE_MAP does through the environment; tools/lane_search.py finds a table for a given stream of frames. */
 FT_API int ft_context_set_lane_map(ft_context *ctx, const int *map, int n);
+/* Tuning options.  Every switch of the library that is not a debugging aid is a named integer option of the CONTEXT.
+ * ft_context_create reads the initial values from the environment, once (variable = "FT_" + upper-case name):
+ *
+ *   name                 default  meaning
+ *   pipeline_depth       0        sub-batches a throughput batch is enqueued as (0 = automatic, 1 = no pipelining, <= 8)
+ *   device_octree        1        DistributeOctTree on the device (0 = host thread pool)
+ *   oct_hist             1        histogram tier of the device octree for levels above 4096 candidates
+ *   oct_hist_first       1        histogram formulation for every level: 0 never, 1 latency-mode launches, 2 always
+ *   oct_big              1        sorted big tier of the device octree (up to 16384 keys per level)
+ *   oct_compact          1        first sorted tier in the compact LDS layout (49 instead of 64 KB per workgroup)
+ *   oct_profile          0        per-level phase clocks of k_octree kept on the device
+ *   oct_smem_pad         0        extra LDS bytes per k_octree workgroup (occupancy probe)
+ *   fast_strips          0        FAST over 62-column strips instead of one wave per cell
+ *   strip_rows           16       rows per strip of the strips form (8 .. 120)
+ *   pyr_rows             1        row-streaming pyramid kernel for launches of 8+ images
+ *   upload_kernel        1        latency mode: frames go up through one kernel instead of DMA copies
+ *   deliver_kernel       1        latency mode: one kernel writes all results into pinned host memory
+ *   graph                1        latency mode: batches of <= 8 frames are captured and replayed as HIP graphs
+ *   paired               1        latency-mode stereo front ends run both cameras through one set of launches
+ *   pass_burst           12       projection searches, multi-launch path: claim passes per host round trip (2 .. 14)
+ *   search_cache         1        projection searches: later claim passes walk the cached candidate keys
+ *   search_grid          1        projection searches: CSR grid of the frame built on the device
+ *   search_persistent    1        projection searches: all claim passes inside one launch when the points fit the chip
+ *   octree_paths, octree_hist_bins, octree_hist_strict   host test entry ft_octree_distribute only (read per call from the environment)
+ *
+ * ft_context_set_option changes the context's value; extractors, front ends and tracked frames take the switches of their
+ * context when they are CREATED (the search_* and pass_burst options are read per call).  `name` is the option name or its
+ * environment spelling.  ft_option_describe enumerates the table (index 0, 1, ... until FT_ERR_INVALID).
+ * Only the FT_DEBUG_* aids (FT_DEBUG_REPEAT, FT_DEBUG_OCC, FT_DEBUG_FAST) and FT_LANE_MAP are read from the environment
+ * anywhere else; none of them changes results. */
+FT_API int ft_context_set_option(ft_context *ctx, const char *name, int value);
+FT_API int ft_context_get_option(const ft_context *ctx, const char *name, int *value);
+FT_API int ft_option_describe(int index, const char **name, const char **env, int *default_value, const char **doc);
 FT_API int ft_context_host_threads(const ft_context *ctx);
 /* per-stage wall/GPU timings of the calls made so far; the reference's REGISTER_STATS analogue
  * (include/Kernels/CudaUtils.h:14, src/Stats.cc:31-60).  Writes "<name>: <ms>" lines. */

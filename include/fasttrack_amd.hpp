@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <stdexcept>
+#include <cstdio>
 #include <string>
 #include <utility>
 #include <vector>
@@ -35,7 +36,19 @@ inline void check(int status) {
 class Context {
 public:
     explicit Context(int device = 0, int hostThreads = 0) { check(ft_context_create(device, hostThreads, &h_)); }
-    ~Context() { ft_context_destroy(h_); }
+    // ft_context_destroy refuses while extractors, front ends or tracked frames of the context are alive (they hold its
+    // streams): a destructor cannot throw, so that ordering mistake is reported on stderr instead of leaking silently.
+    // Declare the Context BEFORE the objects that use it (members are destroyed in reverse order).
+    ~Context() {
+        if (h_ && ft_context_destroy(h_) != FT_OK)
+            std::fprintf(stderr, "fasttrack_amd: context not destroyed (leaked): %s\n", ft_last_error());
+    }
+    void setOption(const char *name, int value) { check(ft_context_set_option(h_, name, value)); }
+    int getOption(const char *name) const {
+        int v = 0;
+        check(ft_context_get_option(h_, name, &v));
+        return v;
+    }
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     ft_context *handle() const { return h_; }

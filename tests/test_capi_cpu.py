@@ -174,11 +174,11 @@ sys.path.insert(0, %r)
 from fasttrack_amd import _capi
 L = _capi.lib()
 h = C.c_void_p()
-for bad in ("1 2 x 4", "1 2 3", "1 2 3 99", "own 1", ""):
+for bad in ("1 2 x 4", "1 2 3", "1 2 3 99", "own 1"):
     os.environ["FT_LANE_MAP"] = bad
     assert L.ft_context_create(0, 0, C.byref(h)) == _capi.FT_ERR_INVALID, bad
     assert b"FT_LANE_MAP" in L.ft_last_error(), bad
-for good in ("own", "0 1 2 3", "1,2,3,4, 5 1 3 1"):
+for good in ("own", "0 1 2 3", "1,2,3,4, 5 1 3 1", "", "  "):  # exported but empty = unset (how a shell neutralises a variable)
     os.environ["FT_LANE_MAP"] = good
     rc = L.ft_context_create(0, 0, C.byref(h))
     assert rc in (0, _capi.FT_ERR_NO_DEVICE), (good, rc)
@@ -190,3 +190,27 @@ print("ok")
     env.pop("GPU_MAX_HW_QUEUES", None)
     out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_option_table_matches_the_header_documentation():
+    """every tuning option of csrc/ft_host.h (FT_TUNING_OPTIONS, enumerated through ft_option_describe) is documented in
+    include/fasttrack_amd.h with its default; its environment spelling is FT_ + upper-case name; and the library has ONE
+    getenv (context.cpp)"""
+    import re
+    from fasttrack_amd import _capi, orb
+    table = orb.Context.option_table()
+    assert len(table) >= 20 and len({t[0] for t in table}) == len(table)
+    header = open(_capi.HEADER_PATH).read()
+    for name, env, default, doc in table:
+        assert env == "FT_" + name.upper() and doc
+        if name.startswith("octree_"):
+            assert name in header
+            continue
+        m = re.search(r"^ \*   %s\s+(-?\d+)\s" % re.escape(name), header, re.M)
+        assert m, f"option {name} is not documented in fasttrack_amd.h"
+        assert int(m.group(1)) == default, (name, default)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "fasttrack_amd", "csrc")
+    n = sum(len(re.findall(r"\bgetenv\s*\(", open(os.path.join(csrc, f)).read())) for f in os.listdir(csrc)
+            if f.endswith((".cpp", ".hip", ".h")))
+    assert n == 1, n

@@ -95,13 +95,10 @@ def test_gaussian_blur_of_whole_levels_bit_exact(ctx, w, h):
 
 @pytest.mark.parametrize("w,h,nf,rows", [(752, 480, 1200, 32), (1280, 720, 2000, 16), (333, 257, 500, 64), (97, 83, 200, 8)])
 def test_fast_strips_variant_bit_exact(ctx, w, h, nf, rows, monkeypatch):
-    """k_fast_strips (opt-in, FT_FAST_STRIPS=1 at creation): FAST over 62-column strips that ignore the cell grid, cell borders
+    """k_fast_strips (opt-in, option fast_strips=1 at creation): FAST over 62-column strips that ignore the cell grid, cell borders
     applied as NMS masks, the per-cell threshold fallback in the compaction - same candidates, same keypoints"""
-    monkeypatch.setenv("FT_FAST_STRIPS", "1")
-    monkeypatch.setenv("FT_STRIP_ROWS", str(rows))
-    ex = orb.ORBextractor(ctx, nf, 1.2, 8 if min(w, h) > 200 else 3, 20, 7, w, h, max_batch=3)
-    monkeypatch.delenv("FT_FAST_STRIPS")
-    monkeypatch.delenv("FT_STRIP_ROWS")
+    with ctx.options(fast_strips=1, strip_rows=rows):
+        ex = orb.ORBextractor(ctx, nf, 1.2, 8 if min(w, h) > 200 else 3, 20, 7, w, h, max_batch=3)
     oex = ob.Extractor(nf, 1.2, ex.nlevels)
     imgs = [synth.make_image(w, h, seed=31), synth.make_noise(w, h, seed=32), synth.make_image(w, h, seed=33, density=3.0)]
     res = ex.extract_batch(imgs)
@@ -256,17 +253,16 @@ def _calls(ctx, name):
 
 
 def test_device_octree_equals_host_octree(ctx, monkeypatch):
-    """k_octree (default) and the host octree (FT_DEVICE_OCTREE=0, read when the extractor is created) select
+    """k_octree (default) and the host octree (option device_octree=0, taken when the extractor is created) select
     the same keypoints in the same order - and both equal the oracle."""
     for (w, h, nf) in [(752, 480, 1200), (1280, 720, 2000), (320, 240, 500)]:
-        monkeypatch.setenv("FT_DEVICE_OCTREE", "0")
-        ex_host = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=3)
-        monkeypatch.delenv("FT_DEVICE_OCTREE")
+        with ctx.options(device_octree=0):
+            ex_host = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=3)
         ex_dev = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=3)
         imgs = [synth.make_image(w, h, seed=40 + i, density=d) for i, d in enumerate((1.0, 0.3, 2.0))]
         before = _calls(ctx, "extract.device_octree_batches"), _calls(ctx, "extract.device_octree_fallbacks")
         rh = ex_host.extract_batch(imgs)
-        assert _calls(ctx, "extract.device_octree_batches") == before[0], "FT_DEVICE_OCTREE=0 must keep the octree on the host"
+        assert _calls(ctx, "extract.device_octree_batches") == before[0], "device_octree=0 must keep the octree on the host"
         rd = ex_dev.extract_batch(imgs)
         assert _calls(ctx, "extract.device_octree_batches") == before[0] + 1, "the device octree did not run"
         assert _calls(ctx, "extract.device_octree_fallbacks") == before[1], "unexpected fallback to the host octree"

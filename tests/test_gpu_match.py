@@ -203,15 +203,14 @@ def test_stereo_frontend_device_octree_overflow(ctx):
 def test_dense_frames_stay_on_the_device_and_overflows_are_repaired_per_pair(ctx, hist, monkeypatch):
     """Throughput mode (more than 16 pairs per batch).  Levels with more than 4 096 candidates go to the histogram tier of the
     device octree (k_octree_hist, any count up to 65 535): dense and pure-noise frames stay on the device from the first batch
-    on.  With that tier switched off (FT_OCT_HIST=0, read when the front end is created) levels up to 16 384 candidates go to
+    on.  With that tier switched off (option oct_hist=0, taken when the front end is created) levels up to 16 384 candidates go to
     the sorted big tier, whose grid the host sizes from the previous batch: the first dense batch finds it absent and is
     repaired pair by pair with the host octree, the second one stays on the device, and a pair with a level beyond 16 384
     candidates is always repaired - that pair only.  Every output equals the oracle's."""
     w, h, nf, B = 752, 480, 1200, 18
     intr = synth.intrinsics(w, h)
-    if not hist:
-        monkeypatch.setenv("FT_OCT_HIST", "0")
-    fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
+    with ctx.options(oct_hist=int(hist)):
+        fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
 
     def calls(name):
         try:
@@ -278,9 +277,8 @@ def test_dense_frames_in_concurrent_sub_batches(ctx, hist, monkeypatch):
     distinct pairs are checked against the oracle."""
     w, h, nf, B = 640, 480, 1000, 256
     intr = synth.intrinsics(w, h)
-    if not hist:
-        monkeypatch.setenv("FT_OCT_HIST", "0")
-    fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
+    with ctx.options(oct_hist=int(hist)):
+        fe = orb.StereoFrontend(ctx, nf, 1.2, 8, 20, 7, w, h, B, intr["mbf"], intr["mb"])
     dense = [synth.make_mosaic_pair(w, h, seed=160 + i, block=6) for i in range(4)]
     oex = ob.Extractor(nf)
     oex.extract(dense[0][0])

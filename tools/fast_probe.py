@@ -1,7 +1,7 @@
 """What the time of k_fast_cells is made of (runs on the GPU box): the extractor on 256 resident 1280x720 frames (two launches of
-128) with the kernel's timing probe FT_FAST_DBG = 0 (the real kernel), 2 (no NMS / emission), 3 (also a three-pixel hash instead
+128) with the kernel's timing probe FT_DEBUG_FAST = 0 (the real kernel), 2 (no NMS / emission), 3 (also a three-pixel hash instead
 of the score network), 4 (staging of the tile only).  Prints the HIP-event time per launch of every extraction kernel.
-usage: for d in 0 2 3 4; do FT_FAST_DBG=$d python tools/fast_probe.py; done"""
+usage: for d in 0 2 3 4; do FT_DEBUG_FAST=$d python tools/fast_probe.py; done"""
 import sys, os, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from fasttrack_amd import orb, synth
@@ -20,4 +20,4 @@ for _ in range(5): ex.extract_batch(imgs, on_device=True, width=w, height=h, str
 out = {}
 for k in ("kernel.pyr_down(all levels)", "kernel.fast_cells", "kernel.compact", "kernel.octree", "kernel.orient_desc"):
     ms, n = ctx.get_stat(k); out[k] = round(ms / max(n, 1), 4)
-print(os.environ.get("FT_FAST_DBG", "0"), "mosaic", mosaic, out)
+print(os.environ.get("FT_DEBUG_FAST", "0"), "mosaic", mosaic, out)
