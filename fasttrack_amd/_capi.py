@@ -82,11 +82,17 @@ _lib = None
 
 
 def _hip_runtime_mapped() -> bool:
+    """Is the HIP runtime the library binds to (the system one next to hipcc, RTLD_DEEPBIND) already mapped into the process?
+    A DIFFERENT copy of the runtime - PyTorch bundles its own under torch/lib - does not count: each copy reads the
+    environment when IT initialises."""
     try:
         with open("/proc/self/maps") as f:
-            return "libamdhip64" in f.read()
+            mapped = {ln.split()[-1] for ln in f if "libamdhip64" in ln}
     except OSError:
         return False
+    ours = {os.path.realpath(os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", n))
+            for n in ("libamdhip64.so", "libamdhip64.so.7")}
+    return any(os.path.realpath(m) in ours for m in mapped)
 
 
 def lib() -> C.CDLL:

@@ -72,6 +72,15 @@ struct FtClaims {
 #endif
 #define FT_CACHE_WORDS (2 * (FT_CACHE_CAP + 1))  // per point: left and right camera
 
+// the claim iteration in one launch (k_search_*_persist): the rotating buffers of fixedPoint (search.cpp) and six sync words
+struct FtPersist {
+    int *res, *head, *next;  // 2 x 4 nPoints, 3 x K, 2 x 4 nPoints
+    int *sync;               // [0..3] flag ring, [4] status (passes run; < -16: not converged after -(status) - 16 passes;
+                             // -2: a grid barrier timed out), [5] arrival counter; all -1 when the launch starts
+    int K, nPoints, maxPasses;
+};
+#define FT_PERSIST_STATUS_TIMEOUT (-2)
+
 struct FtPose {
     float m[12];
 };
@@ -116,4 +125,9 @@ int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocal
                            float nnRatio, int *res, const FtLocalRaw &raw);
 int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
                           const FtPose &Tcw, float th, int forward, int backward, int *res, const FtLastRaw &raw);
+int ft_search_persist_capacity();  // points one persistent launch serves (one workgroup per CU)
+int ft_launch_search_local_persist(hipStream_t st, const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
+                                   float nnRatio, const FtPersist &S, const FtLocalRaw &raw);
+int ft_launch_search_last_persist(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
+                                  const FtPose &Tcw, float th, int forward, int backward, const FtPersist &S, const FtLastRaw &raw);
 int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridIdxL, int *gridStartR, int *gridIdxR);

@@ -36,12 +36,20 @@ __device__ __forceinline__ unsigned long long make_key(int dist, int cx, int cy,
 __device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 40); }
 __device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(k & 0xfffffffull); }
 
+// The words one pass of the claim iteration hands to the next - writer lists, results, flags - are written and read by
+// DIFFERENT workgroups, and in the persistent form (k_search_*_persist) inside ONE launch: every access to them is an
+// agent-scope relaxed atomic (sc1: stores write through, loads are served by the L2, never by a CU's L1, which no other
+// CU's store ever refreshes).  With that the hand-over between passes needs no cache maintenance, only "all stores of the
+// pass have landed" (s_waitcnt vmcnt(0) in every wave) in front of the grid barrier.
+__device__ __forceinline__ int shared_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void shared_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // F.mvpMapPoints[kp] && ->Observations() > 0 as seen by map point i: the last writer j < i of the
 // previous pass, else the pre-call holder
 __device__ __forceinline__ bool is_locked(const FtDevFrame &F, const FtClaims &C, int kp, int i) {
     int best = -1;
     if (!C.firstPass)
-        for (int s = C.head[kp]; s >= 0; s = C.next[s]) {
+        for (int s = shared_load(&C.head[kp]); s >= 0; s = shared_load(&C.next[s])) {
             const int j = s >> 2;
             if (j < i && j > best) best = j;
         }
@@ -50,12 +58,12 @@ __device__ __forceinline__ bool is_locked(const FtDevFrame &F, const FtClaims &C
 
 // start of a claim-iteration pass (see FtClaims): false = the iteration has converged, nothing to do
 __device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) {
-    if (C.flagPrev && *C.flagPrev == -1) return false;
+    if (C.flagPrev && shared_load(C.flagPrev) == -1) return false;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
-    for (int k = t; k < C.nKp; k += T) C.headClear[k] = -1;
+    for (int k = t; k < C.nKp; k += T) shared_store(&C.headClear[k], -1);
     if (t == 0) {
-        *C.flagReset = -1;
-        if (C.firstPass) *C.flagCur = 0;  // the first pass always "changes" its input
+        shared_store(C.flagReset, -1);
+        if (C.firstPass) shared_store(C.flagCur, 0);  // the first pass always "changes" its input
     }
     return true;
 }
@@ -66,9 +74,9 @@ __device__ __forceinline__ void claims_file(const FtClaims &C, int *res, int i, 
     if (lane < 4) {
         const int kp = lane == 0 ? r4[0] : lane == 1 ? r4[1] : lane == 2 ? r4[2] : r4[3];
         const int s = 4 * i + lane;
-        if (!C.firstPass && kp != C.resPrev[s]) atomicAnd(C.flagCur, 0);
-        res[s] = kp;
-        if (kp >= 0) C.nextWrite[s] = atomicExch(&C.headWrite[kp], s);
+        if (!C.firstPass && kp != shared_load(&C.resPrev[s])) atomicAnd(C.flagCur, 0);
+        shared_store(&res[s], kp);
+        if (kp >= 0) shared_store(&C.nextWrite[s], atomicExch(&C.headWrite[kp], s));
     }
 }
 
@@ -646,6 +654,98 @@ __global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoin
     claims_file(C, res, i, lane, r4);
 }
 
+// ---- the whole claim iteration in ONE launch ------------------------------------------------------------------------------
+// The multi-launch form pays a launch (and its ramp) per pass, an empty launch for every surplus pass of a burst and a host
+// round trip per burst - 9 to 13 passes per search, 12 us each where the pass itself is a handful of dependent L2 reads.
+// Here every point keeps its wave for the whole search: the grid is at most ONE workgroup per CU (8 or 16 waves = points per
+// workgroup, <= 256 workgroups, so every workgroup is resident and a grid barrier cannot wait for one that is not), passes
+// are separated by a counter barrier, and all workgroups leave together after the first pass that changed nothing.
+//   sync[0..3] ring of "changed" flags (-1 = unchanged; a pass resets the flag of the pass after next),
+//   sync[4] status: passes run, or FT_PERSIST_TIMEOUT when a barrier gave up (the host then runs the multi-launch form),
+//   sync[5] arrival counter, monotonic, starts at -1 (the call's fill writes -1 over heads, flags and these words).
+// The barrier: every wave drains its stores (the shared words are written through, see shared_store), the workgroup meets,
+// one lane arrives and polls the counter with relaxed loads and s_sleep, the workgroup meets again.  No fence: nothing the
+// passes exchange is ever read through an L1.  Spins are bounded by the 100 MHz wall clock.
+#define FT_PERSIST_TIMEOUT (-2)
+#define FT_PERSIST_TICKS 20000000ull  // 200 ms
+__device__ __forceinline__ bool persist_barrier(int *sync, int target) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int gaveUp;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        __hip_atomic_fetch_add(&sync[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        while (shared_load(&sync[5]) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0 && (wall_clock64() - t0 > FT_PERSIST_TICKS || shared_load(&sync[4]) == FT_PERSIST_TIMEOUT)) {
+                shared_store(&sync[4], FT_PERSIST_TIMEOUT);
+                ok = 0;
+                break;
+            }
+        }
+        gaveUp = !ok;
+    }
+    __syncthreads();
+    return !gaveUp;
+}
+
+// the per-pass view of the rotating buffers, exactly as fixedPoint (search.cpp) sets it up for a launch of its own
+__device__ __forceinline__ void persist_pass_view(FtClaims &C, const FtPersist &S, int pass, int *&res) {
+    const size_t K = (size_t)S.K, R = (size_t)4 * S.nPoints;
+    C.firstPass = pass == 0;
+    C.head = S.head + (size_t)(pass % 3) * K;
+    C.headWrite = S.head + (size_t)((pass + 1) % 3) * K;
+    C.headClear = S.head + (size_t)((pass + 2) % 3) * K;
+    C.next = S.next + (size_t)((pass + 1) & 1) * R;
+    C.nextWrite = S.next + (size_t)(pass & 1) * R;
+    C.resPrev = S.res + (size_t)((pass + 1) & 1) * R;
+    C.flagCur = S.sync + (pass & 3);
+    C.flagPrev = nullptr;
+    C.flagReset = S.sync + ((pass + 2) & 3);
+    res = S.res + (size_t)(pass & 1) * R;
+}
+
+template <class PointFn>
+__device__ __forceinline__ void persist_loop(FtClaims C, const FtPersist &S, int nPoints, PointFn point) {
+    const int lane = threadIdx.x & 63, wave = wave_index(), wpb = (int)(blockDim.x >> 6);
+    const int i = blockIdx.x * wpb + wave;
+    for (int pass = 0;; pass++) {
+        int *res;
+        persist_pass_view(C, S, pass, res);
+        claims_begin_pass(C);
+        if (i < nPoints) {
+            int r4[4];
+            point(C, i, lane, wave, r4);
+            claims_file(C, res, i, lane, r4);
+        }
+        if (!persist_barrier(S.sync, (int)gridDim.x * (pass + 1) - 1)) return;
+        const bool changed = shared_load(S.sync + (pass & 3)) == 0;
+        if (!changed || pass + 1 >= S.maxPasses) {
+            // converged: this pass reproduced its input, so BOTH result buffers hold the fixed point
+            if (blockIdx.x == 0 && threadIdx.x == 0) shared_store(&S.sync[4], changed ? -(pass + 1) - 16 : pass + 1);
+            return;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_search_local_persist(FtDevFrame F, FtDevLocalPoints P, FtClaims C, float th, float nnRatio,
+                                                               FtPersist S, FtLocalRaw raw) {
+    __shared__ int cacheCounter[16];
+    persist_loop(C, S, P.M, [&](const FtClaims &Cp, int i, int lane, int wave, int r4[4]) {
+        local_point(F, P, Cp, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
+    });
+}
+
+__global__ __launch_bounds__(1024) void k_search_last_persist(FtDevFrame F, FtDevLastPoints Lp, FtClaims C, FtPose Tcw, float th,
+                                                              int bForward, int bBackward, FtPersist S, FtLastRaw raw) {
+    __shared__ int cacheCounter[16];
+    persist_loop(C, S, Lp.N, [&](const FtClaims &Cp, int i, int lane, int wave, int r4[4]) {
+        last_point(F, Lp, Cp, Tcw, th, bForward, bBackward, i, lane, r4, raw, &cacheCounter[wave]);
+    });
+}
+
 // ------------------------------------------------------------------------------------------------
 // Frame::isInFrustum / isInFrustumChecks (src/Frame.cc:536-610, 1308-1382) with MapPoint::PredictScale
 // (src/MapPoint.cc:531-546): one thread per local map point.  Float expressions are evaluated in the
@@ -831,6 +931,32 @@ int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPo
                           const FtPose &Tcw, float th, int forward, int backward, int *res, const FtLastRaw &raw) {
     if (L.N <= 0) return FT_OK;
     hipLaunchKernelGGL(k_search_last, dim3((L.N + 3) / 4), dim3(256), 0, st, F, L, C, Tcw, th, forward, backward, res, raw);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+// One launch for the whole claim iteration (see k_search_*_persist).  The grid never exceeds one workgroup per CU.
+int ft_search_persist_capacity() { return 256 * 16; }
+static dim3 persist_grid(int n, int &threads) {
+    threads = n <= 256 * 8 ? 512 : 1024;  // as many CUs as the points allow, one workgroup each
+    const int wpb = threads / 64;
+    return dim3((n + wpb - 1) / wpb);
+}
+int ft_launch_search_local_persist(hipStream_t st, const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
+                                   float nnRatio, const FtPersist &S, const FtLocalRaw &raw) {
+    if (P.M <= 0 || P.M > ft_search_persist_capacity()) return FT_ERR_INVALID;
+    int threads;
+    const dim3 grid = persist_grid(P.M, threads);
+    hipLaunchKernelGGL(k_search_local_persist, grid, dim3(threads), 0, st, F, P, C, th, nnRatio, S, raw);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+int ft_launch_search_last_persist(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
+                                  const FtPose &Tcw, float th, int forward, int backward, const FtPersist &S, const FtLastRaw &raw) {
+    if (L.N <= 0 || L.N > ft_search_persist_capacity()) return FT_ERR_INVALID;
+    int threads;
+    const dim3 grid = persist_grid(L.N, threads);
+    hipLaunchKernelGGL(k_search_last_persist, grid, dim3(threads), 0, st, F, L, C, Tcw, th, forward, backward, S, raw);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

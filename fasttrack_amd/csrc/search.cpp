@@ -115,9 +115,31 @@ struct PassBufs {
 // `download(res, flags, nFlagBytes)` enqueues ONE delivery kernel that writes the pass results `res`, whatever else the
 // caller needs and the burst's flags into pinned host memory (hostFlags); it runs behind every burst, in front of the one
 // stream synchronisation.
-template <typename SearchFn, typename DownloadFn>
+//
+// Persistent form (option search_persistent, default): when the points fit one workgroup per CU, `persist(S)` enqueues ONE
+// launch that runs every pass with grid barriers in between (kernels_search.hip, k_search_*_persist) and leaves the number of
+// passes in sync word 4; one delivery, one synchronisation.  A launch whose barrier timed out (a workgroup that could not
+// become resident: another process holding the CUs) or that hit the pass bound reports that instead, and the call is redone
+// by the multi-launch form - results never depend on which form ran.  Persistent launches of one process on one device are
+// chained by an event, whatever streams they are on: two of them dispatching side by side could each hold CUs the other
+// needs for its last workgroups.
+static std::mutex g_persistMutex;
+static hipEvent_t g_persistDone[64] = {};
+static int chainPersistent(ft_context *ctx, hipStream_t st, bool before) {
+    std::lock_guard<std::mutex> lk(g_persistMutex);
+    const int d = ctx->device & 63;
+    if (before) {
+        if (g_persistDone[d]) FT_HIP(hipStreamWaitEvent(st, g_persistDone[d], 0));
+        return FT_OK;
+    }
+    if (!g_persistDone[d]) FT_HIP(hipEventCreateWithFlags(&g_persistDone[d], hipEventDisableTiming));
+    FT_HIP(hipEventRecord(g_persistDone[d], st));
+    return FT_OK;
+}
+
+template <typename SearchFn, typename PersistFn, typename DownloadFn>
 int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const PassBufs &B, FtClaims &C, SearchFn search,
-               DownloadFn download, const int *hostFlags, int **resFinal, int *passes) {
+               PersistFn persist, DownloadFn download, const int *hostFlags, int **resFinal, int *passes) {
     const int FT_PASS_BURST = passBurst(ctx);
     *resFinal = B.res;
     *passes = 0;
@@ -143,6 +165,33 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
     const int maxPasses = 2 * nPoints + 4 + FT_PASS_BURST;
     C.obs = B.obs;
     C.nKp = nKp;
+    if (ctx->tuning.search_persistent && nPoints <= ft_search_persist_capacity()) {
+        FtPersist S;
+        S.res = B.res;
+        S.head = B.head;
+        S.next = B.next;
+        S.sync = flags;
+        S.K = (int)K;
+        S.nPoints = nPoints;
+        S.maxPasses = std::min(maxPasses, 1 << 20);
+        int rc = chainPersistent(ctx, st, true);
+        if (rc == FT_OK) rc = persist(S);
+        if (rc == FT_OK) rc = chainPersistent(ctx, st, false);
+        if (rc == FT_OK) rc = download(B.res, flags, sizeof(int) * 8);
+        if (rc != FT_OK) return rc;
+        FT_HIP(hipStreamSynchronize(st));
+        const int status = hostFlags[4];
+        if (status > 0) {
+            *resFinal = B.res;
+            *passes = status;
+            ctx->addStat("search.persistent_launches", 0.0);
+            return FT_OK;
+        }
+        // timeout / pass bound: start over with launches of their own (the candidate cache keeps what was built)
+        ctx->addStat(status == FT_PERSIST_STATUS_TIMEOUT ? "search.persistent_timeouts" : "search.persistent_fallbacks", 0.0);
+        const int rcf = ft_launch_fill_i32(st, B.head, (int)(3 * K + 32), -1);
+        if (rcf != FT_OK) return rcf;
+    }
     int *last = B.res;
     for (;; burst++) {
         int *fl = flags + 16 * (burst & 1), *flOther = flags + 16 * ((burst + 1) & 1);
@@ -552,6 +601,7 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     int *resFinal = nullptr, passes = 0;
     rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs), C,
                     [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); },
+                    [&](const FtPersist &S) { return ft_launch_search_local_persist(st, DF, DP, C, th, nn_ratio, S, raw); },
                     [&](int *res, const int *fl, size_t flBytes) -> int {
                         return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M + 64, rawBase, 40 * (size_t)M,
                                                         pin + 16 * (size_t)M, fl, flBytes);
@@ -634,6 +684,7 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     int *resFinal = nullptr, passes = 0;
     rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
+                    [&](const FtPersist &S) { return ft_launch_search_last_persist(st, DF, DL, C, pose, th, forward, backward, S, raw); },
                     [&](int *res, const int *fl, size_t flBytes) -> int {
                         return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M + 64, rawBase, 16 * (size_t)M,
                                                         pin + 16 * (size_t)M, fl, flBytes);
@@ -949,6 +1000,7 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     const FtDevFrame DF = tf->DF;
     rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs, tf->d_cache), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
+                    [&](const FtPersist &S) { return ft_launch_search_last_persist(st, DF, DL, C, pose, th, forward, backward, S, raw); },
                     [&](int *res, const int *fl, size_t flBytes) -> int {
                         return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M, fl, flBytes, nullptr, nullptr, 0);
                     },
@@ -1022,6 +1074,7 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
         int *resFinal = nullptr;
         rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs, tf->d_cache), C,
                         [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); },
+                        [&](const FtPersist &S) { return ft_launch_search_local_persist(st, DF, DP, C, th, nn_ratio, S, raw); },
                         [&](int *res, const int *fl, size_t flBytes) -> int {  // pass results, frustum fields and flags: one kernel
                             return ft_launch_deliver_blocks(st, pin + fOutEnd, res, 16 * (size_t)M, pin, dev + fInputEnd, fOutEnd - fInputEnd,
                                                             pin + fOutEnd + 16 * (size_t)M, fl, flBytes);
