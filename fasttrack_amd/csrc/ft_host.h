@@ -58,7 +58,7 @@
     X(pass_burst, "FT_PASS_BURST", 12, "projection searches, multi-launch path: claim passes enqueued per host round trip (2 .. 14)") \
     X(search_cache, "FT_SEARCH_CACHE", 1, "projection searches: later claim passes walk the cached candidate keys")          \
     X(search_grid, "FT_SEARCH_GRID", 1, "projection searches: CSR grid of the frame built on the device")                    \
-    X(search_persistent, "FT_SEARCH_PERSISTENT", 1, "projection searches: all claim passes inside ONE launch (grid barrier) when the points fit the chip") \
+    X(search_persistent, "FT_SEARCH_PERSISTENT", 0, "projection searches: all claim passes inside ONE launch with grid barriers (measured slower than a launch per pass: EXPERIMENTS.md)") \
     X(octree_paths, "FT_OCTREE_PATHS", 0, "ft_octree_distribute (host entry): 1 / 2 / 3 = the path-code formulations of the device kernels") \
     X(octree_hist_bins, "FT_OCTREE_HIST_BINS", FT_OCT_HIST_BINS, "ft_octree_distribute, formulation 3: histogram bins")      \
     X(octree_hist_strict, "FT_OCTREE_HIST_STRICT", 0, "ft_octree_distribute, formulation 3: report a give-up instead of falling back")

@@ -52,6 +52,10 @@ struct FtClaims {
     int firstPass;           // no lists yet: the pre-call holders decide, and every result counts as changed
     int *headWrite, *nextWrite;  // lists this pass builds for the next one
     int *headClear;          // the heads the next pass will write: reset to -1 here
+    // the writer table (kernels_search.hip, FT_TAB_ENTRIES): 8 ints per keypoint, rotating like the heads; head / next
+    // only take the writers a record has no room for
+    const int *tab;
+    int *tabWrite, *tabClear;
     int nKp;
     const int *resPrev;      // results of the previous pass
     int *flagCur;            // this pass's flag (atomicAnd 0 on a change)
@@ -75,6 +79,7 @@ struct FtClaims {
 // the claim iteration in one launch (k_search_*_persist): the rotating buffers of fixedPoint (search.cpp) and six sync words
 struct FtPersist {
     int *res, *head, *next;  // 2 x 4 nPoints, 3 x K, 2 x 4 nPoints
+    int *tab;                // 3 x 8 K
     int *sync;               // [0..3] flag ring, [4] status (passes run; < -16: not converged after -(status) - 16 passes;
                              // -2: a grid barrier timed out), [5] arrival counter; all -1 when the launch starts
     int K, nPoints, maxPasses;

@@ -29,12 +29,18 @@ __device__ __forceinline__ int hamming256(const unsigned long long a[4], const u
 }
 
 #define KEY_NONE 0xffffffffffffffffull
-__device__ __forceinline__ unsigned long long make_key(int dist, int cx, int cy, int idx) {
-    return ((unsigned long long)dist << 40) | ((unsigned long long)cx << 34) | ((unsigned long long)cy << 28) |
-           (unsigned long long)idx;
+// Candidate key: (distance, cell x, cell y, index) in the high bits - ascending keys are the scan order of the CPU loop, see
+// the header - and below them what a later pass would otherwise have to fetch again through dependent loads: the keypoint's
+// octave and whether it was held before the call (mvpMapPoints[idx]->Observations() > 0).  The index is unique inside a
+// window, so the low bits never decide a comparison.
+__device__ __forceinline__ unsigned long long make_key(int dist, int cx, int cy, int idx, int octave, bool heldBefore) {
+    return ((unsigned long long)dist << 41) | ((unsigned long long)cx << 35) | ((unsigned long long)cy << 29) |
+           ((unsigned long long)idx << 5) | ((unsigned long long)octave << 1) | (heldBefore ? 1ull : 0ull);
 }
-__device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 40); }
-__device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(k & 0xfffffffull); }
+__device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 41); }
+__device__ __forceinline__ int key_idx(unsigned long long k) { return (int)((k >> 5) & 0xffffffull); }
+__device__ __forceinline__ int key_octave(unsigned long long k) { return (int)((k >> 1) & 15ull); }
+__device__ __forceinline__ bool key_held(unsigned long long k) { return (k & 1ull) != 0; }
 
 // The words one pass of the claim iteration hands to the next - writer lists, results, flags - are written and read by
 // DIFFERENT workgroups, and in the persistent form (k_search_*_persist) inside ONE launch: every access to them is an
@@ -44,16 +50,31 @@ __device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(k & 
 __device__ __forceinline__ int shared_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void shared_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// F.mvpMapPoints[kp] && ->Observations() > 0 as seen by map point i: the last writer j < i of the
-// previous pass, else the pre-call holder
-__device__ __forceinline__ bool is_locked(const FtDevFrame &F, const FtClaims &C, int kp, int i) {
+// Writer table of a pass: per keypoint a 32-byte record {last position handed out, 7 entries}, entry = (4 * point + write
+// kind) << 1 | (Observations() of the point > 0), -1 = empty; an eighth and later writer of one keypoint (never seen outside
+// directed tests) goes to the overflow lists head / next, which hold the same entries.  One 32-byte read tells a later
+// pass everything about a keypoint - where the linked lists of rounds 1-3 cost a dependent load per writer plus one for the
+// writer's Observations() (a later pass is nothing but a chain of such round trips, ~1 us each).
+#define FT_TAB_ENTRIES 7
+__device__ __forceinline__ unsigned long long shared_load64(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// F.mvpMapPoints[kp] && ->Observations() > 0 as seen by map point i: the last writer j < i of the previous pass decides,
+// else the pre-call holder (heldBefore)
+__device__ __forceinline__ bool is_locked(const FtClaims &C, int kp, int i, bool heldBefore) {
+    if (C.firstPass) return heldBefore;
+    const unsigned long long *rec = (const unsigned long long *)(C.tab + 8 * (size_t)kp);
+    const unsigned long long a = shared_load64(rec), b = shared_load64(rec + 1), c = shared_load64(rec + 2), d = shared_load64(rec + 3);
+    const int last = (int)(unsigned)a;
     int best = -1;
-    if (!C.firstPass)
-        for (int s = shared_load(&C.head[kp]); s >= 0; s = shared_load(&C.next[s])) {
-            const int j = s >> 2;
-            if (j < i && j > best) best = j;
-        }
-    return best >= 0 ? C.obs[best] > 0 : F.holderObs[kp] > 0;
+    auto take = [&](int e) {
+        if (e >= 0 && (e >> 3) < i && e > best) best = e;
+    };
+    take((int)(a >> 32)); take((int)(unsigned)b); take((int)(b >> 32)); take((int)(unsigned)c);
+    take((int)(c >> 32)); take((int)(unsigned)d); take((int)(d >> 32));
+    if (last >= FT_TAB_ENTRIES)
+        for (int e = shared_load(&C.head[kp]); e >= 0; e = shared_load(&C.next[e >> 1])) take(e);
+    return best >= 0 ? (best & 1) != 0 : heldBefore;
 }
 
 // start of a claim-iteration pass (see FtClaims): false = the iteration has converged, nothing to do
@@ -61,6 +82,8 @@ __device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) {
     if (C.flagPrev && shared_load(C.flagPrev) == -1) return false;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
     for (int k = t; k < C.nKp; k += T) shared_store(&C.headClear[k], -1);
+    unsigned long long *tc = (unsigned long long *)C.tabClear;
+    for (int k = t; k < 4 * C.nKp; k += T) __hip_atomic_store(&tc[k], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == 0) {
         shared_store(C.flagReset, -1);
         if (C.firstPass) shared_store(C.flagCur, 0);  // the first pass always "changes" its input
@@ -69,14 +92,21 @@ __device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) {
 }
 
 // end of a point's turn in a pass: lane k files write kind k of point i - the result, the "changed" flag against the
-// previous pass, and the entry in the writer lists the NEXT pass will read (so a pass is one launch)
+// previous pass, and the entry in the writer table the NEXT pass will read (so a pass is one launch)
 __device__ __forceinline__ void claims_file(const FtClaims &C, int *res, int i, int lane, const int r4[4]) {
     if (lane < 4) {
         const int kp = lane == 0 ? r4[0] : lane == 1 ? r4[1] : lane == 2 ? r4[2] : r4[3];
         const int s = 4 * i + lane;
-        if (!C.firstPass && kp != shared_load(&C.resPrev[s])) atomicAnd(C.flagCur, 0);
+        const int prev = C.firstPass ? 0 : shared_load(&C.resPrev[s]);
+        if (!C.firstPass && kp != prev) atomicAnd(C.flagCur, 0);
         shared_store(&res[s], kp);
-        if (kp >= 0) shared_store(&C.nextWrite[s], atomicExch(&C.headWrite[kp], s));
+        if (kp >= 0) {
+            const int e = (s << 1) | (C.obs[i] > 0 ? 1 : 0);
+            int *rec = C.tabWrite + 8 * (size_t)kp;
+            const int pos = atomicAdd(rec, 1) + 1;  // the record starts at -1
+            if (pos < FT_TAB_ENTRIES) shared_store(rec + 1 + pos, e);
+            else shared_store(&C.nextWrite[s], atomicExch(&C.headWrite[kp], e));
+        }
     }
 }
 
@@ -355,7 +385,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
             if (cs == 1) {
                 for (int t = lane; t < nCached; t += 64) {
                     const unsigned long long key = cb.slot[1 + t];
-                    if (is_locked(F, C, key_idx(key), i)) continue;
+                    if (is_locked(C, key_idx(key), i, key_held(key))) continue;
                     two_min_insert(k0, k1, key);
                 }
             } else {
@@ -364,14 +394,15 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                     for_window(F, 0, F.keys, nLeft, w, lane, [&](int idx, int cx, int cy) {
                         const ft_keypoint kp = F.keys[idx];
                         if (!in_box(kp, x, y, rad, level - 1, level)) return;
-                        const bool locked = is_locked(F, C, idx, i);
+                        const bool held = F.holderObs[idx] > 0;
+                        const bool locked = is_locked(C, idx, i, held);
                         if (locked && !cb.build) return;
                         if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
                             const float er = fabsf(__fsub_rn(P.projXR[i], F.uright[idx]));
                             if (er > rad) return;
                         }
                         const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
-                        const unsigned long long key = make_key(dist, cx, cy, idx);
+                        const unsigned long long key = make_key(dist, cx, cy, idx, kp.octave, held);
                         if (cb.build) cache_append(cb, key);
                         if (locked) return;
                         two_min_insert(k0, k1, key);
@@ -383,11 +414,11 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
             if (k0 != KEY_NONE) {
                 bd = key_dist(k0);
                 bi = key_idx(k0);
-                bl = F.keys[bi].octave;
+                bl = key_octave(k0);
             }
             if (k1 != KEY_NONE) {
                 bd2 = key_dist(k1);
-                bl2 = F.keys[key_idx(k1)].octave;
+                bl2 = key_octave(k1);
             }
             if (bd <= FT_TH_HIGH) {
                 if (bl == bl2 && (float)bd > __fmul_rn(nnRatio, (float)bd2)) {
@@ -408,7 +439,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 const int nRight = F.N - F.Nleft;
                 unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
                 // this point's own left-block side write precedes its right-block search
-                auto lockedR = [&](int g) -> bool { return (g == sideL) ? (C.obs[i] > 0) : is_locked(F, C, g, i); };
+                auto lockedR = [&](int g, bool held) -> bool { return (g == sideL) ? (C.obs[i] > 0) : is_locked(C, g, i, held); };
                 // (the right block is not reached in every pass - skipRight depends on the locks - so its candidates are filed by
                 // the first pass that gets here)
                 CacheBuild cb;
@@ -421,7 +452,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 if (cs == 1) {
                     for (int t = lane; t < nCached; t += 64) {
                         const unsigned long long key = cb.slot[1 + t];
-                        if (lockedR(key_idx(key) + F.Nleft)) continue;
+                        if (lockedR(key_idx(key) + F.Nleft, key_held(key))) continue;
                         two_min_insert(k0, k1, key);
                     }
                 } else {
@@ -431,10 +462,11 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                             const ft_keypoint kp = F.keysR[idx];
                             if (!in_box(kp, x, y, rad, level - 1, level)) return;
                             const int g = idx + F.Nleft;
-                            const bool locked = lockedR(g);
+                            const bool held = F.holderObs[g] > 0;
+                            const bool locked = lockedR(g, held);
                             if (locked && !cb.build) return;
                             const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)g * 32));
-                            const unsigned long long key = make_key(dist, cx, cy, idx);
+                            const unsigned long long key = make_key(dist, cx, cy, idx, kp.octave, held);
                             if (cb.build) cache_append(cb, key);
                             if (locked) return;
                             two_min_insert(k0, k1, key);
@@ -446,11 +478,11 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 if (k0 != KEY_NONE) {
                     bdr = key_dist(k0);
                     bir = key_idx(k0);
-                    blr = F.keysR[bir].octave;
+                    blr = key_octave(k0);
                 }
                 if (k1 != KEY_NONE) {
                     bd2r = key_dist(k1);
-                    bl2r = F.keysR[key_idx(k1)].octave;
+                    bl2r = key_octave(k1);
                 }
                 if (bdr <= FT_TH_HIGH && !(blr == bl2r && (float)bdr > __fmul_rn(nnRatio, (float)bd2r))) {
                     if (F.r2l[bir] != -1) sideR = F.r2l[bir];
@@ -554,7 +586,7 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                 anyCand = anyBox ? 1 : 0;
                 for (int t = lane; t < nCached; t += 64) {
                     const unsigned long long key = cb.slot[1 + t];
-                    if (is_locked(F, C, key_idx(key), i)) continue;
+                    if (is_locked(C, key_idx(key), i, key_held(key))) continue;
                     k0 = key < k0 ? key : k0;
                 }
             } else {
@@ -564,7 +596,8 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                         const ft_keypoint kp = F.keys[idx];
                         if (!in_box(kp, uv[0], uv[1], radius, minLevel, maxLevel)) return;
                         anyCand = 1;
-                        const bool locked = is_locked(F, C, idx, i);
+                        const bool held = F.holderObs[idx] > 0;
+                        const bool locked = is_locked(C, idx, i, held);
                         if (locked && !cb.build) return;
                         if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
                             const float ur = __fsub_rn(uv[0], __fmul_rn(F.mbf, invzc));
@@ -572,7 +605,7 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                             if (er > radius) return;
                         }
                         const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
-                        const unsigned long long key = make_key(dist, cx, cy, idx);
+                        const unsigned long long key = make_key(dist, cx, cy, idx, kp.octave, held);
                         if (cb.build) cache_append(cb, key);
                         if (locked) return;
                         k0 = key < k0 ? key : k0;
@@ -606,7 +639,7 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                     if (csr == 1) {
                         for (int t = lane; t < nCachedR; t += 64) {
                             const unsigned long long key = cbr.slot[1 + t];
-                            if (is_locked(F, C, key_idx(key) + F.Nleft, i)) continue;
+                            if (is_locked(C, key_idx(key) + F.Nleft, i, key_held(key))) continue;
                             kr = key < kr ? key : kr;
                         }
                     } else {
@@ -615,10 +648,11 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                             for_window(F, 1, F.keysR, nRight, wr, lane, [&](int idx, int cx, int cy) {
                                 const ft_keypoint kp = F.keysR[idx];
                                 if (!in_box(kp, uvr[0], uvr[1], radius, minLevel, maxLevel)) return;
-                                const bool locked = is_locked(F, C, idx + F.Nleft, i);
+                                const bool held = F.holderObs[idx + F.Nleft] > 0;
+                                const bool locked = is_locked(C, idx + F.Nleft, i, held);
                                 if (locked && !cbr.build) return;
                                 const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)(idx + F.Nleft) * 32));
-                                const unsigned long long key = make_key(dist, cx, cy, idx);
+                                const unsigned long long key = make_key(dist, cx, cy, idx, kp.octave, held);
                                 if (cbr.build) cache_append(cbr, key);
                                 if (locked) return;
                                 kr = key < kr ? key : kr;
@@ -678,8 +712,8 @@ __device__ __forceinline__ bool persist_barrier(int *sync, int target) {
         const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
         while (shared_load(&sync[5]) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0 && (wall_clock64() - t0 > FT_PERSIST_TICKS || shared_load(&sync[4]) == FT_PERSIST_TIMEOUT)) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 255u) == 0 && (wall_clock64() - t0 > FT_PERSIST_TICKS || shared_load(&sync[4]) == FT_PERSIST_TIMEOUT)) {
                 shared_store(&sync[4], FT_PERSIST_TIMEOUT);
                 ok = 0;
                 break;
@@ -698,6 +732,9 @@ __device__ __forceinline__ void persist_pass_view(FtClaims &C, const FtPersist &
     C.head = S.head + (size_t)(pass % 3) * K;
     C.headWrite = S.head + (size_t)((pass + 1) % 3) * K;
     C.headClear = S.head + (size_t)((pass + 2) % 3) * K;
+    C.tab = S.tab + (size_t)(pass % 3) * 8 * K;
+    C.tabWrite = S.tab + (size_t)((pass + 1) % 3) * 8 * K;
+    C.tabClear = S.tab + (size_t)((pass + 2) % 3) * 8 * K;
     C.next = S.next + (size_t)((pass + 1) & 1) * R;
     C.nextWrite = S.next + (size_t)(pass & 1) * R;
     C.resPrev = S.res + (size_t)((pass + 1) & 1) * R;
@@ -938,7 +975,7 @@ int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPo
 // One launch for the whole claim iteration (see k_search_*_persist).  The grid never exceeds one workgroup per CU.
 int ft_search_persist_capacity() { return 256 * 16; }
 static dim3 persist_grid(int n, int &threads) {
-    threads = n <= 256 * 8 ? 512 : 1024;  // as many CUs as the points allow, one workgroup each
+    threads = 1024;  // few arrivals per barrier: the counter serialises them
     const int wpb = threads / 64;
     return dim3((n + wpb - 1) / wpb);
 }

@@ -116,7 +116,8 @@ struct PassBufs {
 // caller needs and the burst's flags into pinned host memory (hostFlags); it runs behind every burst, in front of the one
 // stream synchronisation.
 //
-// Persistent form (option search_persistent, default): when the points fit one workgroup per CU, `persist(S)` enqueues ONE
+// Persistent form (option search_persistent; opt-in - measured 20 % SLOWER than the launches: a counter barrier over ~130
+// workgroups costs more than a launch boundary, and a pass is a handful of dependent L2 round trips either way): when the points fit one workgroup per CU, `persist(S)` enqueues ONE
 // launch that runs every pass with grid barriers in between (kernels_search.hip, k_search_*_persist) and leaves the number of
 // passes in sync word 4; one delivery, one synchronisation.  A launch whose barrier timed out (a workgroup that could not
 // become resident: another process holding the CUs) or that hit the pass bound reports that instead, and the call is redone
@@ -149,10 +150,11 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
         FT_HIP(hipStreamSynchronize(st));
         return FT_OK;
     }
-    const size_t K = (size_t)std::max(nKp, 1);
-    int *flags = B.head + 3 * K;
-    {   // list heads = -1, flags = "unchanged" (-1)
-        const int rcf = ft_launch_fill_i32(st, B.head, (int)(3 * K + 32), -1);
+    const size_t K = ((size_t)std::max(nKp, 1) + 7) & ~(size_t)7;  // = passK(nKp)
+    int *flags = B.head + 3 * K, *tab = flags + 32;  // (the table records are 32 bytes and 32-byte aligned: layoutPasses)
+    const int fillWords = (int)(3 * K + 32 + 24 * K);
+    {   // list heads = -1, flags = "unchanged" (-1), writer table empty (-1)
+        const int rcf = ft_launch_fill_i32(st, B.head, fillWords, -1);
         if (rcf != FT_OK) return rcf;
         // candidate cache: ~0 in a slot's first word = "not built yet"
         if (B.cache) {
@@ -170,6 +172,7 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
         S.res = B.res;
         S.head = B.head;
         S.next = B.next;
+        S.tab = tab;
         S.sync = flags;
         S.K = (int)K;
         S.nPoints = nPoints;
@@ -189,7 +192,7 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
         }
         // timeout / pass bound: start over with launches of their own (the candidate cache keeps what was built)
         ctx->addStat(status == FT_PERSIST_STATUS_TIMEOUT ? "search.persistent_timeouts" : "search.persistent_fallbacks", 0.0);
-        const int rcf = ft_launch_fill_i32(st, B.head, (int)(3 * K + 32), -1);
+        const int rcf = ft_launch_fill_i32(st, B.head, fillWords, -1);
         if (rcf != FT_OK) return rcf;
     }
     int *last = B.res;
@@ -200,6 +203,9 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
             C.head = B.head + (size_t)(pass % 3) * K;
             C.headWrite = B.head + (size_t)((pass + 1) % 3) * K;
             C.headClear = B.head + (size_t)((pass + 2) % 3) * K;
+            C.tab = tab + (size_t)(pass % 3) * 8 * K;
+            C.tabWrite = tab + (size_t)((pass + 1) % 3) * 8 * K;
+            C.tabClear = tab + (size_t)((pass + 2) % 3) * 8 * K;
             C.next = B.next + (size_t)((pass + 1) & 1) * 4 * nPoints;
             C.nextWrite = B.next + (size_t)(pass & 1) * 4 * nPoints;
             C.resPrev = B.res + (size_t)((pass + 1) & 1) * 4 * nPoints;
@@ -236,6 +242,8 @@ struct PassLayout {
     size_t res, head, next, cache;
     bool haveCache;
 };
+// keypoint count of the claim buffers: a multiple of 8, so that the 32-byte table records behind 3 K heads + 32 flags are aligned
+size_t passK(int N) { return ((size_t)std::max(N, 1) + 7) & ~(size_t)7; }
 bool searchCacheOn(const ft_context *ctx) { return ctx->tuning.search_cache != 0; }
 size_t searchCacheBytes(int M) { return 8 * (size_t)FT_CACHE_WORDS * (size_t)std::max(M, 1); }
 // cacheInArena: the candidate cache (device only, 8 KB per point) lives at the end of the arena - the stand-alone searches,
@@ -244,7 +252,7 @@ size_t searchCacheBytes(int M) { return 8 * (size_t)FT_CACHE_WORDS * (size_t)std
 PassLayout layoutPasses(const ft_context *ctx, Arena &a, int M, int N, bool cacheInArena) {
     PassLayout L;
     L.res = a.take(32 * (size_t)M);
-    L.head = a.take(12 * (size_t)std::max(N, 1) + 128);
+    L.head = a.take(4 * (3 * passK(N) + 32 + 24 * passK(N)));  // list heads, flags, writer table (fixedPoint)
     L.next = a.take(32 * (size_t)M);
     L.haveCache = cacheInArena && searchCacheOn(ctx);
     L.cache = L.haveCache ? a.take(searchCacheBytes(M)) : 0;
@@ -838,7 +846,7 @@ int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, 
     tf->maxPts = max_points;
     const size_t K = (size_t)max_keypoints, M = (size_t)max_points;
     // arena of one call: map points (<= 72 B) + frustum outputs (<= 48 B) + passes / raw outputs (<= 104 B) per point
-    tf->workBytes = 320 * M + 16 * K + 8192;
+    tf->workBytes = 320 * M + 112 * K + 16384;  // (108 K: list heads and writer table of the claim iteration)
     hipError_t e = hipMalloc((void **)&tf->d_keys, sizeof(ft_keypoint) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_keysR, sizeof(ft_keypoint) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_desc, 32 * K);

@@ -99,7 +99,7 @@ FT_API int ft_context_set_lane_map(ft_context *ctx, const int *map, int n);
  *   pass_burst           12       projection searches, multi-launch path: claim passes per host round trip (2 .. 14)
  *   search_cache         1        projection searches: later claim passes walk the cached candidate keys
  *   search_grid          1        projection searches: CSR grid of the frame built on the device
- *   search_persistent    1        projection searches: all claim passes inside one launch when the points fit the chip
+ *   search_persistent    0        projection searches: all claim passes inside one launch with grid barriers (opt-in: slower)
  *   octree_paths, octree_hist_bins, octree_hist_strict   host test entry ft_octree_distribute only (read per call from the environment)
  *
  * ft_context_set_option changes the context's value; extractors, front ends and tracked frames take the switches of their

@@ -26,14 +26,14 @@ def _calls(ctx, name):
 
 @pytest.fixture(params=[1, 0], ids=["one-launch", "launch-per-pass"])
 def search_form(ctx, request):
-    """the two forms of the claim iteration of the projection searches: every pass inside ONE persistent launch with grid
-    barriers (default), or a launch per pass driven by the host (points beyond one workgroup per CU, or option
-    search_persistent=0).  Read per call; the test asserts which one ran."""
+    """the two forms of the claim iteration of the projection searches: a launch per pass driven by the host (default), or
+    every pass inside ONE persistent launch with grid barriers (option search_persistent=1; correct, but measured slower:
+    a barrier costs more than a launch boundary).  Read per call; the test asserts which one ran."""
     ctx.set_option("search_persistent", request.param)
     before = [_calls(ctx, "search.persistent_" + k) for k in ("launches", "timeouts", "fallbacks")]
     yield request.param
     after = [_calls(ctx, "search.persistent_" + k) for k in ("launches", "timeouts", "fallbacks")]
-    ctx.set_option("search_persistent", 1)
+    ctx.set_option("search_persistent", 0)
     assert after[1] == before[1] and after[2] == before[2], "a persistent search timed out or hit its pass bound"
     assert (after[0] > before[0]) == bool(request.param), "the requested form of the claim iteration did not run"
 
