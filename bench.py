@@ -317,7 +317,7 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
         ctx.synchronize()
         dt = time.perf_counter() - t0
         parts_ms = {k_: 1e3 * v_ / frames for k_, v_ in part.items()}
-        # passes of the exact in-call claiming (one launch per pass, as many as the longest chain of map points
+        # passes of the exact in-call claiming (EXPERIMENTS 3.2: one launch per pass, as many as the longest chain of map points
         # that take a keypoint from one another) and the time inside the two C entry points
         lib_stats = {}
         for nm_ in ("tracked.search_last_frame.passes", "tracked.track_local_map.passes", "tracked.search_last_frame.total",

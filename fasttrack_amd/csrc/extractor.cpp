@@ -417,7 +417,7 @@ int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done) {
     ex->evt.begin(tm, "kernel.fast_cells", ex->stream);
     // the device octree ranks candidates by their coordinates: FAST need not deliver them in the reference's order, which
     // frees it from the cell grid altogether (k_fast_strips, opt-in: FT_FAST_STRIPS=1 when the extractor is created -
-    // 11 % fewer VALU instructions than the per-cell kernel but a larger LDS footprint, no faster on MI355X);
+    // 11 % fewer VALU instructions than the per-cell kernel but a larger LDS footprint, no faster on MI355X; EXPERIMENTS.md section 3.4);
     // the host octree gets the ordered per-cell kernel
     const bool strips = ex->fastStrips && ex->deviceOctree && al && g.totalStrips > 0;
     int *cellCount2 = ex->d_cellCount2 + (size_t)b0 * g.totalCells * 2;

@@ -519,7 +519,7 @@ __device__ __forceinline__ unsigned fast_score2(unsigned v, const unsigned p[16]
 }
 
 // One WAVE per (cell, image): no workgroup barrier anywhere, so the ~20 cells resident on a CU hide each other's
-// load and LDS latency (LDS per wave is kept near 6 KB); measured VALU bound.
+// load and LDS latency (LDS per wave is kept near 6 KB); measured VALU bound (EXPERIMENTS.md section 3).
 // TP = LDS pitch of the tile and of the score plane; TP > 0 makes every ring / neighbour offset an
 // instruction immediate, TP == 0 is the any-size fallback.
 // LDS carve (bytes): tile th*tp | score (ph+2)*tp | candidate ring FC_CAND u16 | corner list FC_CORN u16 ;

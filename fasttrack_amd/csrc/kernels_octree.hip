@@ -69,7 +69,7 @@ struct OctLds {
 // business) in global memory, and the arrays only the rounds use - vSize .. mark - live in the upper half; the pick brings
 // the low dwords back over them.  49 instead of 64 KB per workgroup at the headline's quotas: THREE workgroups per CU, and a
 // quarter less LDS withheld from the kernels that share the CUs while one wave per workgroup walks the rounds (the
-// footprint is what the tier costs the pipeline: FT_OCT_SMEM_PAD).  Falls back to the plain layout
+// footprint is what the tier costs the pipeline: option oct_smem_pad, EXPERIMENTS.md section 3.1).  Falls back to the plain layout
 // when the round arrays do not fit half the key array (quotas beyond ~500 per level).
 __host__ __device__ inline OctLds oct_lds_layout(int cap, int keyBytes, bool hist, bool compact = false) {
     OctLds o;
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree_hist(FtGeom g, FtOctArgs
 // in the same workgroup, a level the histogram gave up on after all (nothing has been written by then).  Only a level with
 // more than FT_OCT_MAXN candidates AND a tree deeper than the table leaves the kernel: to k_octree_big, or to the host.
 // (Launches that fill the chip keep the sorted tier first and the histogram tier behind it: there the two formulations
-// cost the same)
+// cost the same, EXPERIMENTS.md section 3.5.)
 __global__ __launch_bounds__(OCT_THREADS) void k_octree_auto(FtGeom g, FtOctArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __builtin_amdgcn_s_setprio(3);
