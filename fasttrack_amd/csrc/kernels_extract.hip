@@ -420,6 +420,192 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two pyramid levels per pass (round 4): level l from level l - 1 exactly as k_pyr_rows does it, and level l + 1 from the
+// rows of level l the wave has just produced - kept in LDS (33 rows x 128 bytes per wave), so level l is written to HBM but
+// not read back.  The pyramid is the one kernel of the pipeline that is priced by its bytes (EXPERIMENTS.md section 8 (5)):
+// of the 2.80 MB per 1280x720 image the seven launches read, 1.10 MB are the levels 1, 3 and 5 they wrote a moment before.
+//
+// Partition.  A strip of level l is 128 columns x 33 rows, strips STEP by 127 columns and 32 rows: neighbouring strips share
+// one column and one row, which both compute (the same value, stored twice).  An output pixel (dx2, dy2) of level l + 1 needs
+// the level-l columns sx2, sx2 + 1 and rows sy2, sy2 + 1 (clamped as cv::resize clamps them); it belongs to the strip with
+// c0 <= sx2 <= c0 + 126 and j0 <= clamp(sy2) <= j0 + 31, which holds all four taps.  sx2 and sy2 are monotone, so a strip's
+// share of level l + 1 is a rectangle [x2lo, x2hi) x [y2lo, y2hi) found by one vector load of taps and a ballot each.
+// Stage 2 repeats stage 1's arithmetic with LDS rows as its source: a lane owns two adjacent output columns,
+// the 8-byte window with their four taps is one ds_read2_b32, v_perm + v_dot2 interpolate, interpolated rows are reused.
+// ------------------------------------------------------------------------------------------------
+#define PR2_CSTEP 127
+#define PR2_RSTEP 32
+#define PR2_ROWS 33
+#define PR2_LDS_PITCH 128
+__global__ __launch_bounds__(64) void k_pyr_rows2(FtGeom g, int level, const uint8_t *const *l0, int l0pitch, uint8_t *pyr,
+                                                  const FtTap *taps, FtSlotGrid sg, int stripsX, unsigned sxMagic, int readableEnd) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[PR2_ROWS * PR2_LDS_PITCH];
+    const int lane = threadIdx.x;
+    int slot, tile;
+    if (!ft_slot_block(sg, slot, tile)) return;
+    const int ty = div_by(tile, sxMagic), tx = tile - ty * stripsX;
+    const FtLevelGeom &D = g.lv[level], &E = g.lv[level + 1];
+    int spitch;
+    const uint8_t *S = level_ptr(g, level - 1, slot, l0, l0pitch, pyr, spitch);
+    const int sw = g.lv[level - 1].w, sh = g.lv[level - 1].h;
+    const int c0 = tx * PR2_CSTEP, j0 = ty * PR2_RSTEP;
+    const int dx = c0 + 2 * lane;
+    const int nrows = min(PR2_ROWS, D.h - j0);
+    uint8_t *slotPyr = pyr + (size_t)slot * g.pyrPerSlot;
+    // ---- the strip's share of level l + 1 (requested first: the loads are behind stage 1 when stage 2 needs them) ----
+    // first index whose (clamped) tap reaches `bound`, searched in a 64-entry window around the arithmetic estimate
+    auto firstAtLeast = [&](int tab, int n, int srcN, int dstN, int bound, int clampHi) -> int {
+        if (bound <= 0) return 0;
+        const int est = (int)(((long long)bound * dstN) / srcN);  // ~ bound / scale; the boundary lies within a few entries of it
+        const int i = est - 32 + lane;
+        const int ic = min(max(i, 0), n - 1);
+        const int sTap = min(max((int)(short)(gload<unsigned>(taps + tab + ic) & 0xffffu), 0), clampHi);
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(i >= n || (i >= 0 && sTap >= bound));
+        return est - 32 + (b ? (int)__builtin_ctzll(b) : 64);
+    };
+    const int x2lo = firstAtLeast(E.xtab, E.w, D.w, E.w, c0, D.w - 1);
+    const int x2hi = min(firstAtLeast(E.xtab, E.w, D.w, E.w, c0 + PR2_CSTEP, D.w - 1), E.w);
+    const int y2lo = firstAtLeast(E.ytab, E.h, D.h, E.h, j0, D.h - 1);
+    const int y2hi = min(firstAtLeast(E.ytab, E.h, D.h, E.h, j0 + PR2_RSTEP, D.h - 1), E.h);
+    // ---- stage 2 set-up: [x2lo, x2hi) x [y2lo, y2hi) of level l + 1; its rows are produced INSIDE stage 1's loop, each as soon
+    // as the level-l rows it needs are in LDS, so its arithmetic runs in the shadow of stage 1's row loads instead of
+    // extending the wave's life (as a pass of its own behind stage 1 the fused kernel was 1.5 % slower than two launches) ----
+    const int n2rows = max(y2hi - y2lo, 0);
+    const bool have2 = n2rows > 0 && x2hi > x2lo;  // wave-uniform
+    const int x2a = x2lo & ~1;                     // pairs start at an even column: aligned 2-byte stores
+    const int ex = x2a + 2 * lane;                 // this lane's two columns: ex, ex + 1 (masked to [x2lo, x2hi))
+    unsigned row2W0 = 0xffffffffu, row2W1 = 0;
+    unsigned sel2A = 0, sel2B = 0, w2a = 0, w2b = 0;
+    int base2 = 0;
+    if (have2) {
+        const ft_u2 t = gload<ft_u2>(taps + E.ytab + y2lo + min(lane, n2rows - 1));
+        const int sy = (int)(short)(t.x & 0xffffu);
+        // rows relative to the strip: clamp(sy) - j0 in [0, 31], clamp(sy + 1) - j0 in [0, 32]
+        if (lane < n2rows) row2W0 = (unsigned)(min(max(sy, 0), D.h - 1) - j0) | ((unsigned)(min(max(sy + 1, 0), D.h - 1) - j0) << 16);
+        row2W1 = (t.x >> 16) | (t.y << 16);
+        const int exa = min(max(ex, x2lo), x2hi - 1), exb = min(max(ex + 1, x2lo), x2hi - 1);
+        const ft_u2 ua = gload<ft_u2>(taps + E.xtab + exa), ub = gload<ft_u2>(taps + E.xtab + exb);
+        const int s2a = (int)(short)(ua.x & 0xffffu) - c0, s2b = (int)(short)(ub.x & 0xffffu) - c0;  // LDS columns, in [0, 126]
+        const int lim = min(D.w - 1 - c0, PR2_LDS_PITCH - 1);
+        const int c2a = min(s2a + 1, lim), c2b = min(s2b + 1, lim);
+        w2a = (ua.x >> 16) | (ua.y << 16);
+        w2b = (ub.x >> 16) | (ub.y << 16);
+        base2 = min(s2a & ~3, PR2_LDS_PITCH - 8);
+        sel2A = (unsigned)(s2a - base2) | 0x0c00u | ((unsigned)(c2a - base2) << 16) | 0x0c000000u;
+        sel2B = (unsigned)(s2b - base2) | 0x0c00u | ((unsigned)(c2b - base2) << 16) | 0x0c000000u;
+    }
+    const bool st2 = have2 && ex >= x2lo && ex + 1 < x2hi, st1a = have2 && ex >= x2lo && ex < x2hi,
+               st1b = have2 && ex + 1 >= x2lo && ex + 1 < x2hi;
+    auto rowTap2 = [&](int r, int &sy0, int &sy1, unsigned &b0, unsigned &b1) {
+        const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)row2W0, r), w1 = (unsigned)__builtin_amdgcn_readlane((int)row2W1, r);
+        sy0 = (int)(w0 & 0xffffu); sy1 = (int)(w0 >> 16);
+        b0 = w1 & 0xffffu; b1 = w1 >> 16;
+    };
+    int jr2 = 0, t2y0, t2y1;
+    unsigned t2b0, t2b1;
+    rowTap2(0, t2y0, t2y1, t2b0, t2b1);  // (without a share of level l + 1: the sentinel, which matches no row)
+    uint8_t *dst2 = slotPyr + E.off + (size_t)y2lo * E.pitch + ex;
+    const unsigned *ldsRow2 = (const unsigned *)(lds + base2);
+    unsigned gpA = 0, gpB = 0, gcA = 0, gcB = 0;  // stage 2's interpolated rows: previous, current
+    // ---- stage 1: rows j0 .. j0 + nrows - 1 of level l, columns c0 .. c0 + 127 (k_pyr_rows<false>, strips stepping 127 x 32) ----
+    unsigned rowW0, rowW1;
+    {
+        const ft_u2 t = gload<ft_u2>(taps + D.ytab + j0 + min(lane, nrows - 1));
+        const int sy = (int)(short)(t.x & 0xffffu);
+        rowW0 = (unsigned)min(max(sy, 0), sh - 1) | ((unsigned)min(max(sy + 1, 0), sh - 1) << 16);
+        rowW1 = (t.x >> 16) | (t.y << 16);
+        if (lane >= nrows) rowW0 = 0xffffffffu;  // sentinel: matches no source row
+    }
+    const int dxa = min(dx, D.w - 1), dxb = min(dx + 1, D.w - 1);
+    const ft_u2 ta = gload<ft_u2>(taps + D.xtab + dxa), tb = gload<ft_u2>(taps + D.xtab + dxb);
+    const int sxa = (int)(short)(ta.x & 0xffffu), sxb = (int)(short)(tb.x & 0xffffu);
+    const int cxa = min(sxa + 1, sw - 1), cxb = min(sxb + 1, sw - 1);
+    const unsigned wa = (ta.x >> 16) | (ta.y << 16), wb = (tb.x >> 16) | (tb.y << 16);
+    const int base = min(sxa & ~3, readableEnd - 8);
+    const unsigned selA = (unsigned)(sxa - base) | 0x0c00u | ((unsigned)(cxa - base) << 16) | 0x0c000000u;
+    const unsigned selB = (unsigned)(sxb - base) | 0x0c00u | ((unsigned)(cxb - base) << 16) | 0x0c000000u;
+    const unsigned round2 = 0x20000u;
+    auto rowTap = [&](int r, int &sy0, int &sy1, unsigned &b0, unsigned &b1) {
+        const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)rowW0, r), w1 = (unsigned)__builtin_amdgcn_readlane((int)rowW1, r);
+        sy0 = (int)(w0 & 0xffffu); sy1 = (int)(w0 >> 16);
+        b0 = w1 & 0xffffu; b1 = w1 >> 16;
+    };
+    int jr = 0, sy0, sy1, lastSy0, rLast;
+    unsigned b0, b1, bx0, bx1;
+    rowTap(0, sy0, sy1, b0, b1);
+    rowTap(nrows - 1, lastSy0, rLast, bx0, bx1);
+    int r = sy0;
+    const uint8_t *srcBase = S;
+    uint8_t *dstBase = slotPyr + D.off + (size_t)j0 * D.pitch;
+    unsigned dOff = 0;
+    const unsigned laneSrc = (unsigned)base, laneDst = (unsigned)dx;
+    const bool store2 = dx + 1 < D.w, store1 = dx < D.w;
+    int pfIdx = r;
+    auto prefetch = [&]() -> ft_u2 {
+        unsigned offS = laneSrc + (unsigned)min(pfIdx, rLast) * (unsigned)spitch;
+        asm volatile("" : "+v"(offS));
+        const ft_u2 v = gload<ft_u2>(srcBase + offS);
+        pfIdx++;
+        return v;
+    };
+    ft_u2 q[PR_PF];
+#pragma unroll
+    for (int k = 0; k < PR_PF; k++) q[k] = prefetch();
+    unsigned hpA = 0, hpB = 0, hcA = 0, hcB = 0;
+    unsigned short *ldsLane = (unsigned short *)lds + lane;
+    for (int left = rLast - r + 1; left > 0; left -= PR_PF) {
+#pragma unroll
+        for (int k = 0; k < PR_PF; k++) {
+            hpA = hcA; hpB = hcB;
+            hcA = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selA), wa) >> 4;
+            hcB = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selB), wb) >> 4;
+            q[k] = prefetch();
+            while (sy1 == r) {  // wave-uniform; behind the last output row sy1 matches no row
+                if (__builtin_expect(sy0 == r, 0)) {
+                    hpA = hcA; hpB = hcB;
+                    asm volatile("" : "+v"(hpA), "+v"(hpB));
+                }
+                const unsigned oA = ((umad24_su(b0, hpA, round2) >> 16) + (umul24_su(b1, hcA) >> 16)) >> 2;
+                const unsigned oB = ((umad24_su(b0, hpB, round2) >> 16) + (umul24_su(b1, hcB) >> 16)) >> 2;
+                const unsigned short o2 = (unsigned short)(oA | (oB << 8));
+                unsigned offD = laneDst + dOff;
+                asm volatile("" : "+v"(offD));
+                if (store2) gstore<unsigned short>(dstBase + offD, o2);
+                else if (store1) gstore<uint8_t>(dstBase + offD, (uint8_t)oA);
+                // (columns beyond the level repeat its last column: stage 2's taps are clamped to it anyway)
+                ldsLane[jr * (PR2_LDS_PITCH / 2)] = o2;
+                dOff += (unsigned)D.pitch;
+                // ---- stage 2 takes level-l row jr of the strip from LDS (other lanes wrote its taps) ----
+                wave_lds_sync();
+                {
+                    const unsigned lo = ldsRow2[jr * (PR2_LDS_PITCH / 4)], hi = ldsRow2[jr * (PR2_LDS_PITCH / 4) + 1];
+                    gpA = gcA; gpB = gcB;
+                    gcA = udot2_u16(__builtin_amdgcn_perm(hi, lo, sel2A), w2a) >> 4;
+                    gcB = udot2_u16(__builtin_amdgcn_perm(hi, lo, sel2B), w2b) >> 4;
+                    while (t2y1 == jr) {  // wave-uniform
+                        if (__builtin_expect(t2y0 == jr, 0)) {
+                            gpA = gcA; gpB = gcB;
+                            asm volatile("" : "+v"(gpA), "+v"(gpB));
+                        }
+                        const unsigned pA = ((umad24_su(t2b0, gpA, round2) >> 16) + (umul24_su(t2b1, gcA) >> 16)) >> 2;
+                        const unsigned pB = ((umad24_su(t2b0, gpB, round2) >> 16) + (umul24_su(t2b1, gcB) >> 16)) >> 2;
+                        if (st2) gstore<unsigned short>(dst2, (unsigned short)(pA | (pB << 8)));
+                        else if (st1a) gstore<uint8_t>(dst2, (uint8_t)pA);
+                        else if (st1b) gstore<uint8_t>(dst2 + 1, (uint8_t)pB);
+                        dst2 += E.pitch;
+                        jr2++;
+                        rowTap2(jr2, t2y0, t2y1, t2b0, t2b1);
+                    }
+                }
+                jr++;
+                rowTap(jr, sy0, sy1, b0, b1);
+            }
+            r++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FAST-9/16 per cell.  One workgroup per (cell, image).  The cell's (wCell+6)x(hCell+6) uint8 tile is
 // staged in LDS; scores (largest threshold at which the pixel is still a corner) go to an LDS score
 // plane whose zero rim implements "a neighbour belonging to another cell counts as 0"; survivors are
@@ -553,7 +739,7 @@ __host__ __device__ __forceinline__ int fc_tile_bytes(int wCell, int hCell, int 
 __host__ __device__ __forceinline__ int fc_score_bytes(int wCell, int hCell, int TP) { return (((hCell + 2) * fc_pitch(wCell, TP)) + 15) & ~15; }
 __host__ __device__ __forceinline__ int fc_list_bytes() { return 2 * (FC_CAND + FC_CORN) + 16; }  // + the spare entry
 
-// dbg (FT_FAST_DBG, a timing probe - results are wrong with 1, 2, 4; 8 only switches the paired score rounds off): 1 replaces the score network by a three-pixel hash, 2 stops in
+// dbg (FT_DEBUG_FAST, a timing probe - results are wrong with 1, 2, 4, 16 (16 drops the candidates: phase A alone); 8 only switches the paired score rounds off): 1 replaces the score network by a three-pixel hash, 2 stops in
 // front of NMS / emission, 4 right behind the staging of the tile; tools/fast_probe.py times the kernel with each of them.
 // ORDERED = false (device octree, which ranks candidates by their coordinates): the rejection pass is free to
 // visit the pixels in any order and uses all 64 lanes (see below); ORDERED = true delivers every cell's
@@ -691,6 +877,10 @@ __global__ __launch_bounds__(64, FC_WAVES_PER_EU) void k_fast_cells(FtGeom g, co
     auto pixX = [&](int code, int y) -> int { return TP > 0 ? (code & 63) : code - y * pw; };
     // phase B over the buffered candidates: score, corner list (row-major), ring reset
     auto flushB = [&]() {
+        if (dbg & 16) {  // probe: phase A alone (the candidates are dropped)
+            nc = 0;
+            return;
+        }
         wave_lds_sync();
         // Branch-free rounds: a lane beyond the last candidate repeats the last one (same score, same store) and is kept out
         // of the corner list by its flag; a candidate that is no corner stores 0 over the 0 the plane already holds; a lane
@@ -1848,6 +2038,18 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
     for (int rep = ft_debug_repeat("pyr"); rep > 0; rep--)
     for (int level = 1; level < g.nlevels; level++) {
         const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
+        // two levels per pass (k_pyr_rows2): this level and the next one, when both take the row-streaming bilinear path
+        if (rowsKernel >= 2 && batch >= 8 && alignedLoads && level + 1 < g.nlevels && pyr_rows_fits(g, level) &&
+            pyr_rows_fits(g, level + 1) && !D.area2x && !g.lv[level + 1].area2x && D.w >= 16 && D.h >= 2) {
+            const int stripsX = (D.w + PR2_CSTEP - 1) / PR2_CSTEP, stripsY = (D.h + PR2_RSTEP - 1) / PR2_RSTEP;
+            dim3 grid, block(64, 1, 1);
+            const FtSlotGrid sg = ft_slot_grid(stripsX * stripsY, batch, grid);
+            const int readableEnd = level == 1 ? std::min((P.w + 3) & ~3, l0pitch) : P.pitch;
+            hipLaunchKernelGGL(k_pyr_rows2, grid, block, 0, st, g, level, l0, l0pitch, pyr, taps, sg, stripsX,
+                               div_magic_of((unsigned)stripsX), readableEnd);
+            level++;
+            continue;
+        }
         // a launch of a few images is latency bound: the tile kernel's many short waves finish a level sooner than the
         // row-streaming kernel's few long ones (752x480 frame: 0.19 against 0.23 ms); wide launches take the streaming kernel
         if (rowsOn && batch >= 8 && alignedLoads && pyr_rows_fits(g, level)) {

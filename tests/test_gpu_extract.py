@@ -132,12 +132,16 @@ def test_equally_spaced_host_frames_go_up_as_one_copy(ctx):
 
 @pytest.mark.parametrize("w,h,sf,levels", [(333, 257, 1.2, 8), (1000, 96, 1.2, 2), (641, 479, 1.5, 5), (512, 512, 2.0, 4),
                                             (97, 83, 1.1, 6), (1279, 717, 1.25, 8), (406, 302, 2.4, 3), (300, 200, 3.0, 2)])
-def test_row_streaming_pyramid_bit_exact(ctx, w, h, sf, levels):
-    """launches of 8+ images build the pyramid with k_pyr_rows (a lane owns two output columns, rows streamed top to bottom);
-    every level of the first and the last image equals the oracle's cv::resize chain - odd sizes, INTER_AREA at exactly 2.0,
-    other scale factors (3.0 takes the tile kernel: its taps do not fit the 8-byte window)"""
+@pytest.mark.parametrize("form", [2, 1], ids=["two-levels-per-pass", "one-level-per-pass"])
+def test_row_streaming_pyramid_bit_exact(ctx, w, h, sf, levels, form):
+    """launches of 8+ images build the pyramid with k_pyr_rows2 (two levels per pass: level l + 1 from the rows of level l the
+    wave keeps in LDS; strips overlapping by a column and a row) or k_pyr_rows (one level per pass; option pyr_rows = 1): a lane
+    owns two output columns, rows streamed top to bottom; every level of the first and the last image equals the oracle's
+    cv::resize chain - odd sizes, INTER_AREA at exactly 2.0, other scale factors (3.0 takes the tile kernel: its taps do not
+    fit the 8-byte window)"""
     nf = 300
-    ex = orb.ORBextractor(ctx, nf, sf, levels, 20, 7, w, h, max_batch=9)
+    with ctx.options(pyr_rows=form):
+        ex = orb.ORBextractor(ctx, nf, sf, levels, 20, 7, w, h, max_batch=9)
     oex = ob.Extractor(nf, sf, levels)
     imgs = [synth.make_image(w, h, seed=90 + b) for b in range(8)] + [synth.make_noise(w, h, seed=99)]
     res = ex.extract_batch(imgs)
