@@ -140,8 +140,13 @@ static int chainPersistent(ft_context *ctx, hipStream_t st, bool before) {
 
 template <typename SearchFn, typename PersistFn, typename DownloadFn>
 int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const PassBufs &B, FtClaims &C, SearchFn search,
-               PersistFn persist, DownloadFn download, const int *hostFlags, int **resFinal, int *passes) {
-    const int FT_PASS_BURST = passBurst(ctx);
+               PersistFn persist, DownloadFn download, const int *hostFlags, int **resFinal, int *passes, int *burstHint = nullptr) {
+    // Passes per burst.  Every surplus pass of a burst is an empty launch (4.5 us of dispatch for ~500 workgroups), every
+    // burst that falls short a host round trip (~40 us).  A caller that searches frame after frame (ft_tracked_frame) hands in
+    // the pass count of its previous search of the same kind: the first burst is that count + 1, later bursts are short.
+    // Without a hint: option pass_burst (12) for every burst.
+    const int burstMax = passBurst(ctx);
+    int FT_PASS_BURST = burstHint && *burstHint > 0 ? std::min(std::max(*burstHint + 1, 4), FT_PASS_BURST_MAX) : burstMax;
     *resFinal = B.res;
     *passes = 0;
     if (nPoints <= 0) {
@@ -164,7 +169,7 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
     }
     C.cache = B.cache;
     int pass = 0, burst = 0;
-    const int maxPasses = 2 * nPoints + 4 + FT_PASS_BURST;
+    const int maxPasses = 2 * nPoints + 4 + burstMax;
     C.obs = B.obs;
     C.nKp = nKp;
     if (ctx->tuning.search_persistent && nPoints <= ft_search_persist_capacity()) {
@@ -231,9 +236,11 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
             ft_set_error("projection search: claim resolution did not converge");
             return FT_ERR_HIP;
         }
+        if (burstHint) FT_PASS_BURST = 4;  // the hint fell short: short bursts from here
     }
     *resFinal = last;
     *passes = pass;
+    if (burstHint) *burstHint = pass;
     return FT_OK;
 }
 
@@ -510,6 +517,7 @@ struct ft_tracked_frame {
     FtDevFrame DF;
     std::vector<float> angles;  // angle of keypoint i (left then right)
     std::vector<int> holder;
+    int passesLast = 0, passesLocal = 0;  // claim passes of the previous search of each kind: the next one's burst size (fixedPoint)
 };
 
 // holder_obs of the resident frame to the device, without a synchronisation: the pinned source belongs to the frame and is
@@ -1012,7 +1020,7 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
                     [&](int *res, const int *fl, size_t flBytes) -> int {
                         return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M, fl, flBytes, nullptr, nullptr, 0);
                     },
-                    (const int *)(pin + 16 * (size_t)M), &resFinal, &passes);
+                    (const int *)(pin + 16 * (size_t)M), &resFinal, &passes, &tf->passesLast);
     if (rc != FT_OK) return rc;
     int *hRes = (int *)pin;
     const int nm = replayLastFrameWrites(hRes, M, L, [&](int idx) { return tf->angles[idx]; }, check_orientation != 0,
@@ -1087,7 +1095,7 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
                             return ft_launch_deliver_blocks(st, pin + fOutEnd, res, 16 * (size_t)M, pin, dev + fInputEnd, fOutEnd - fInputEnd,
                                                             pin + fOutEnd + 16 * (size_t)M, fl, flBytes);
                         },
-                        (const int *)(pin + fOutEnd + 16 * (size_t)M), &resFinal, &passes);
+                        (const int *)(pin + fOutEnd + 16 * (size_t)M), &resFinal, &passes, &tf->passesLocal);
         if (rc != FT_OK) return rc;
         int *hRes = (int *)(pin + fOutEnd);
         unpackFrustum(M, FL, fInputEnd, pin, frustum, n_to_match);
