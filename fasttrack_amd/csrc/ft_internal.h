@@ -232,6 +232,7 @@ struct FtStereoArgs {
     int *rowStart;                     // device [batch * rowStride]: right keypoints bucketed by (int)y
     FtSortedR *sorted;                 // device [batch * capacity]: right keypoints in bucket order
     int rowStride;                     // >= level-0 height + 2
+    int alignedLoads;                  // level-0 frames of both cameras are 4-byte aligned (base and stride): dword reads of image rows
 };
 // Result delivery of a small batch (latency mode): one kernel writes everything the host needs - keypoints and
 // descriptors of both cameras, mvuRight, mvDepth and the counters - straight into pinned host memory, instead of

@@ -114,6 +114,69 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
         ok = ok && yl0 >= 0 && yl0 + 2 * w + 1 <= lh && xl0 >= 0 && xl0 + 2 * w + 1 <= lw && xr00 >= 0 &&
              xr00 + 2 * (w + Ls) + 1 <= lw;
         if (ok) {
+            int bestS = 0x7fffffff, bestinc = 0;
+            float dists[11];
+            const int xl0a = xl0 & ~3, xr0a = xr00 & ~3;
+            // the aligned windows (16 bytes of a left row, 24 + 4 of a right row) stay inside the rows: wave-uniform
+            if (a.alignedLoads && xl0a + 16 <= lw && xr0a + 28 <= lw) {
+                // ---- SAD search on packed bytes (round 4).  The 11 x 11 left patch and the 11 x 21 right strip are fetched as
+                // aligned dwords - one load instruction per wave for each (44 and 66 dwords) where every lane used to issue 24
+                // byte loads - and parked in the wave's 476 bytes of LDS.  Then lane (shift group g = lane / 16, row r =
+                // lane % 16) takes row r at shift s = 4 k + g in round k = 0, 1, 2: the 11 bytes of the left row and of the
+                // shifted right row are three dwords each (v_alignbyte cuts them out, the twelfth byte is masked), three
+                // v_sad_u8 add up the row's absolute differences, four DPP adds inside the row of 16 lanes sum the 11 rows.
+                __shared__ unsigned sadBuf[4][44 + 77 + 3];
+                unsigned *ldsL = sadBuf[wave], *ldsR = ldsL + 44;  // right rows at a pitch of 7 dwords (the last one: padding)
+                {
+                    const int rl = lane >> 2, dl = lane & 3;  // lanes 0 .. 43
+                    const unsigned vL = gload<unsigned>(imL + (size_t)(yl0 + min(rl, 10)) * pitchL + xl0a + 4 * dl);
+                    const int rr0 = (lane * 43) >> 8, dr0 = lane - 6 * rr0;  // lane / 6 for lane < 64: rows 0 .. 10
+                    const unsigned vR0 = gload<unsigned>(imR + (size_t)(yl0 + rr0) * pitchR + xr0a + 4 * dr0);
+                    // dwords 64, 65 (row 10, dwords 4, 5) and the padding dword of every row: lanes 0 .. 12
+                    const int i1 = lane < 2 ? 64 + lane : 0;
+                    const unsigned vR1 = gload<unsigned>(imR + (size_t)(yl0 + (lane < 2 ? 10 : min(lane - 2, 10))) * pitchR + xr0a +
+                                                         (lane < 2 ? 4 * (4 + lane) : 24));
+                    if (lane < 44) ldsL[lane] = vL;
+                    ldsR[rr0 * 7 + dr0] = vR0;
+                    if (lane < 2) ldsR[10 * 7 + (i1 - 60)] = vR1;
+                    else if (lane < 13) ldsR[(lane - 2) * 7 + 6] = vR1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int g4 = lane >> 4, r = lane & 15, rc = min(r, 10);
+                const int offL = xl0 - xl0a, offR = xr00 - xr0a;
+                const unsigned l0d = ldsL[rc * 4], l1d = ldsL[rc * 4 + 1], l2d = ldsL[rc * 4 + 2], l3d = ldsL[rc * 4 + 3];
+                const unsigned Lw0 = __builtin_amdgcn_alignbyte(l1d, l0d, (unsigned)offL), Lw1 = __builtin_amdgcn_alignbyte(l2d, l1d, (unsigned)offL),
+                               Lw2 = __builtin_amdgcn_alignbyte(l3d, l2d, (unsigned)offL) & 0x00ffffffu;
+                unsigned sums[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int sft = min(4 * k + g4, 10);  // (shift 11 does not exist: the fourth group of the last round repeats shift 10)
+                    const int o = offR + sft;            // byte offset of the shifted row inside the aligned right row: 0 .. 13
+                    const unsigned *pr = ldsR + rc * 7 + (o >> 2);
+                    const unsigned r0 = pr[0], r1 = pr[1], r2 = pr[2], r3 = pr[3];
+                    const unsigned sh = (unsigned)(o & 3);
+                    const unsigned Rw0 = __builtin_amdgcn_alignbyte(r1, r0, sh), Rw1 = __builtin_amdgcn_alignbyte(r2, r1, sh),
+                                   Rw2 = __builtin_amdgcn_alignbyte(r3, r2, sh) & 0x00ffffffu;
+                    unsigned d = __builtin_amdgcn_sad_u8(Lw2, Rw2, __builtin_amdgcn_sad_u8(Lw1, Rw1, __builtin_amdgcn_sad_u8(Lw0, Rw0, 0u)));
+                    d = r < 11 ? d : 0u;
+                    // sum over the row of 16 lanes (every lane of the row ends up with it)
+                    d += (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                    d += (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+                    d += (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0x141, 0xF, 0xF, true);  // row_half_mirror
+                    d += (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0x140, 0xF, 0xF, true);  // row_mirror
+                    sums[k] = d;
+                }
+#pragma unroll
+                for (int sft = 0; sft < 11; sft++) {
+                    const int dS = __builtin_amdgcn_readlane((int)sums[sft >> 2], 16 * (sft & 3));
+                    dists[sft] = (float)dS;
+                    if (dS < bestS) {
+                        bestS = dS;
+                        bestinc = sft - Ls;
+                    }
+                }
+            } else {
             // 11x11 left patch: each lane owns pixels lane and lane+64 (< 121)
             const int p0 = lane, p1 = lane + 64;
             const int r0 = p0 / 11, c0 = p0 - r0 * 11, r1 = p1 / 11, c1 = p1 - r1 * 11;
@@ -138,8 +201,6 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
             for (int s = 0; s < 11; s++) b1[s] = two ? b1[s] : 0u;
             // two shifts per register: v_sad_u8 adds |a - b| to the low half, v_sad_hi_u8 to the high half (a lane's two
             // pixels give at most 510, a wave's sum at most 121 * 255 < 2^16), so six wave sums serve the eleven shifts
-            int bestS = 0x7fffffff, bestinc = 0;
-            float dists[11];
 #pragma unroll
             for (int s = 0; s < 11; s += 2) {
                 unsigned d = __builtin_amdgcn_sad_u8(a1, b1[s], __builtin_amdgcn_sad_u8(a0, b0[s], 0u));
@@ -158,6 +219,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
                         bestinc = s + 1 - Ls;
                     }
                 }
+            }
             }
             if (!(bestinc == -Ls || bestinc == Ls)) {
                 float dist1 = 0, dist2 = 0, dist3 = 0;

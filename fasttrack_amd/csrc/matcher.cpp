@@ -94,6 +94,7 @@ int ft_stereo_match(ft_extractor *exL, ft_extractor *exR, int slot, const ft_key
     a.sorted = exL->d_stSorted;
     a.rowStart = exL->d_stInt + 2 * C + 4;
     a.rowStride = exL->height + 2;
+    a.alignedLoads = exL->l0Aligned && exR->l0Aligned;
     rc = ft_launch_stereo_rowsort(st, g, 1, a);
     if (rc != FT_OK) return rc;
     rc = ft_launch_stereo_match(st, g, 1, exL->d_l0 + slot, exR->d_l0 + slot, exL->l0pitch, exR->l0pitch,
@@ -237,6 +238,7 @@ static int frontendMatchAndDeliver(ft_stereo_frontend *fe, int s, int b0, int nb
     a.rowStride = L->height + 2;
     a.rowStart = fe->d_rowStart + (size_t)b0 * a.rowStride;
     a.sorted = fe->d_sorted + o;
+    a.alignedLoads = L->l0Aligned && R->l0Aligned;
     L->evt.begin(tm, "kernel.stereo_rowsort", st);
     rc = ft_launch_stereo_rowsort(st, g, nb, a);
     L->evt.end(tm, st);
@@ -319,6 +321,7 @@ static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL
         a.rowStride = L->height + 2;
         a.rowStart = fe->d_rowStart;
         a.sorted = fe->d_sorted;
+        a.alignedLoads = L->l0Aligned;
         rc = ft_launch_stereo_rowsort(st, g, B, a);
         if (rc == FT_OK)
             rc = ft_launch_stereo_match(st, g, B, L->d_l0, L->d_l0 + B, L->l0pitch, L->l0pitch, L->d_pyr,
