@@ -22,6 +22,11 @@ struct FtDevFrame {
     // the searches then scan every keypoint.
     const int *gridStart[2];
     const int *gridIdx[2];
+    // the same entries as search records, in the order of gridIdx: {x, y, uright (or -1), index | octave << 24} and the
+    // 32-byte descriptor - what a window scan needs of a keypoint, as two contiguous reads per run of entries instead of
+    // the chain grid entry -> keypoint -> descriptor / uright
+    const float4 *gridRec[2];
+    const uint8_t *gridDesc[2];
 };
 #define FT_GRID_CELLS (FT_GRID_COLS * FT_GRID_ROWS)
 
@@ -135,4 +140,5 @@ int ft_launch_search_local_persist(hipStream_t st, const FtDevFrame &F, const Ft
                                    float nnRatio, const FtPersist &S, const FtLocalRaw &raw);
 int ft_launch_search_last_persist(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
                                   const FtPose &Tcw, float th, int forward, int backward, const FtPersist &S, const FtLastRaw &raw);
-int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridIdxL, int *gridStartR, int *gridIdxR);
+int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridIdxL, int *gridStartR, int *gridIdxR,
+                         float4 *recL, uint8_t *descL, float4 *recR, uint8_t *descR);

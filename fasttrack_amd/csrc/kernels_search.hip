@@ -238,8 +238,15 @@ __device__ __forceinline__ int cache_state(const unsigned long long *slot, int &
     return count <= FT_CACHE_CAP ? 1 : 2;
 }
 
+// A keypoint of a window as the scans see it: position, octave, uright, descriptor - from the search records of the grid
+// (one 16-byte and one 32-byte read at the entry's position) or, without a grid, from the frame's own arrays.
+struct WinEntry {
+    float x, y, uright;  // uright: < 0 = none (or a two-camera frame)
+    int idx, octave, cx, cy;
+    unsigned long long d[4];
+};
 // level band and box test of GetFeaturesInArea for a keypoint whose cell is already known to lie in the window
-__device__ __forceinline__ bool in_box(const ft_keypoint &kp, float x, float y, float r, int minLevel, int maxLevel) {
+__device__ __forceinline__ bool in_box(const WinEntry &kp, float x, float y, float r, int minLevel, int maxLevel) {
     const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
     if (checkLevels) {
         if (kp.octave < minLevel) return false;
@@ -249,7 +256,7 @@ __device__ __forceinline__ bool in_box(const ft_keypoint &kp, float x, float y, 
     return fabsf(dx) < r && fabsf(dy) < r;
 }
 
-// The keypoints of camera `cam` whose grid cell lies in window w, handed to fn(idx, cx, cy) lane-parallel.  With the
+// The keypoints of camera `cam` whose grid cell lies in window w, handed to fn(entry) lane-parallel.  With the
 // frame's CSR grid (k_build_grid) a column of cells is one contiguous range of entries - a map point looks at the
 // keypoints of its window only, as Frame::GetFeaturesInArea does; without it every keypoint's cell is computed and tested.
 template <class Fn>
@@ -258,8 +265,12 @@ __device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const f
     if (F.gridStart[cam]) {
         // The window's columns of cells are contiguous ranges of grid entries.  One lane per column fetches its range, a
         // wave scan lays the ranges end to end, and the lanes then take the window's entries 64 at a time: the usual
-        // window (a few dozen keypoints in up to ~12 columns) is ONE round of dependent loads instead of one per column.
-        const int *gs = F.gridStart[cam], *gi = F.gridIdx[cam];
+        // window (a few dozen keypoints in up to ~12 columns) is ONE round of loads, and a round is one memory round trip:
+        // record and descriptor of an entry sit at the entry's position (k_build_grid), so both are requested at once - and
+        // for TWO rounds at a time, a wide window being a chain of such trips otherwise.
+        const int *gs = F.gridStart[cam];
+        const float4 *rec = F.gridRec[cam];
+        const uint4 *gd = (const uint4 *)F.gridDesc[cam];
         for (int c0 = w.minCX; c0 <= w.maxCX; c0 += 64) {
             const int ncols = min(64, w.maxCX - c0 + 1);
             int b = 0, cnt = 0;
@@ -275,33 +286,69 @@ __device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const f
                 if (lane >= d) incl += y;
             }
             const int total = __builtin_amdgcn_readlane(incl, 63);
-            for (int t0 = 0; t0 < total; t0 += 64) {
-                const int t = t0 + lane;
-                int colIdx = 0;  // the column entry t falls into: the number of columns that end at or before t
+            auto locate = [&](int t, int &pos, int &colIdx) {
+                colIdx = 0;  // the column entry t falls into: the number of columns that end at or before t
                 for (int c = 0; c < ncols - 1; c++) colIdx += t >= __builtin_amdgcn_readlane(incl, c) ? 1 : 0;
                 const int cb = __shfl(b, colIdx), cEnd = __shfl(incl, colIdx), cCnt = __shfl(cnt, colIdx);
-                if (t < total) {
-                    const int v = gi[cb + (t - (cEnd - cCnt))];
-                    fn(v & 0xffffff, c0 + colIdx, v >> 24);
+                pos = cb + (t - (cEnd - cCnt));
+            };
+            auto hand = [&](const float4 &r, const uint4 &d0, const uint4 &d1, int colIdx) {
+                WinEntry e;
+                e.x = r.x; e.y = r.y; e.uright = r.z;
+                const int io = __float_as_int(r.w);
+                e.idx = io & 0xffffff;
+                e.octave = (io >> 24) & 15;
+                e.cx = c0 + colIdx;
+                e.cy = (int)roundf(__fmul_rn(__fsub_rn(r.y, F.mnMinY), F.invH));  // Frame::PosInGrid, as k_build_grid filed it
+                e.d[0] = (unsigned long long)d0.x | ((unsigned long long)d0.y << 32);
+                e.d[1] = (unsigned long long)d0.z | ((unsigned long long)d0.w << 32);
+                e.d[2] = (unsigned long long)d1.x | ((unsigned long long)d1.y << 32);
+                e.d[3] = (unsigned long long)d1.z | ((unsigned long long)d1.w << 32);
+                fn(e);
+            };
+            for (int t0 = 0; t0 < total; t0 += 128) {
+                const int tA = t0 + lane, tB = t0 + 64 + lane;
+                int posA, colA, posB = 0, colB = 0;
+                locate(min(tA, total - 1), posA, colA);
+                const bool second = t0 + 64 < total;  // wave-uniform
+                if (second) locate(min(tB, total - 1), posB, colB);
+                const float4 rA = rec[posA];
+                const uint4 a0 = gd[2 * (size_t)posA], a1 = gd[2 * (size_t)posA + 1];
+                float4 rB = rA;
+                uint4 b0 = a0, b1 = a1;
+                if (second) {
+                    rB = rec[posB];
+                    b0 = gd[2 * (size_t)posB];
+                    b1 = gd[2 * (size_t)posB + 1];
                 }
+                if (tA < total) hand(rA, a0, a1, colA);
+                if (second && tB < total) hand(rB, b0, b1, colB);
             }
         }
         return;
     }
+    const uint8_t *desc = F.desc + (cam == 0 ? 0 : (size_t)F.Nleft * 32);
     for (int idx = lane; idx < n; idx += 64) {
         const ft_keypoint kp = keys[idx];
         const int cx = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.mnMinX), F.invW));
         const int cy = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.mnMinY), F.invH));
         if (cx < 0 || cx >= FT_GRID_COLS || cy < 0 || cy >= FT_GRID_ROWS) continue;  // never entered the grid
         if (cx < w.minCX || cx > w.maxCX || cy < w.minCY || cy > w.maxCY) continue;
-        fn(idx, cx, cy);
+        WinEntry e;
+        e.x = kp.x; e.y = kp.y;
+        e.uright = (cam == 0 && F.Nleft == -1 && F.uright) ? F.uright[idx] : -1.0f;
+        e.idx = idx; e.octave = kp.octave; e.cx = cx; e.cy = cy;
+        const unsigned long long *dp = (const unsigned long long *)(desc + (size_t)idx * 32);
+        e.d[0] = dp[0]; e.d[1] = dp[1]; e.d[2] = dp[2]; e.d[3] = dp[3];
+        fn(e);
     }
 }
 
 // Frame::AssignFeaturesToGrid (src/Frame.cc:409-440) as CSR: block 0 the left camera (or the only one), block 1 the
 // right camera of a two-camera frame.  Counting sort by cell cx * 48 + cy in LDS; the order inside a cell is free (the
 // searches order candidates by (distance, cx, cy, index) keys).
-__global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, int *idxL, int *startR, int *idxR) {
+__global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, int *idxL, int *startR, int *idxR, float4 *recL,
+                                                    uint8_t *descL, float4 *recR, uint8_t *descR) {
     __shared__ int cnt[FT_GRID_CELLS + 1];
     __shared__ int wsum[4];
     const int cam = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -346,9 +393,22 @@ __global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, i
     }
     if (tid == 0) start[FT_GRID_CELLS] = total;
     __syncthreads();
+    float4 *rec = cam == 0 ? recL : recR;
+    uint8_t *gdesc = cam == 0 ? descL : descR;
+    const uint8_t *desc = F.desc + (cam == 0 ? 0 : (size_t)F.Nleft * 32);
     for (int i = tid; i < n; i += 256) {
         const int c = cellOf(i);
-        if (c >= 0) out[atomicAdd(&cnt[c], 1)] = i | ((c % FT_GRID_ROWS) << 24);
+        if (c >= 0) {
+            const int p = atomicAdd(&cnt[c], 1);
+            out[p] = i | ((c % FT_GRID_ROWS) << 24);
+            const ft_keypoint kp = keys[i];
+            const float ur = (cam == 0 && F.Nleft == -1 && F.uright) ? F.uright[i] : -1.0f;
+            rec[p] = make_float4(kp.x, kp.y, ur, __int_as_float(i | (kp.octave << 24)));
+            const uint4 *d = (const uint4 *)(desc + (size_t)i * 32);
+            uint4 *o = (uint4 *)(gdesc + (size_t)p * 32);
+            o[0] = d[0];
+            o[1] = d[1];
+        }
     }
 }
 
@@ -391,18 +451,19 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
             } else {
                 cache_begin(cb, lane);
                 if (!w.empty) {
-                    for_window(F, 0, F.keys, nLeft, w, lane, [&](int idx, int cx, int cy) {
-                        const ft_keypoint kp = F.keys[idx];
+                    const float pxr = (F.Nleft == -1 && F.uright) ? P.projXR[i] : 0.f;
+                    for_window(F, 0, F.keys, nLeft, w, lane, [&](const WinEntry &kp) {
                         if (!in_box(kp, x, y, rad, level - 1, level)) return;
+                        const int idx = kp.idx;
                         const bool held = F.holderObs[idx] > 0;
                         const bool locked = is_locked(C, idx, i, held);
                         if (locked && !cb.build) return;
-                        if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
-                            const float er = fabsf(__fsub_rn(P.projXR[i], F.uright[idx]));
+                        if (kp.uright > 0) {  // (mono-stereo frames only: the records of other frames hold -1)
+                            const float er = fabsf(__fsub_rn(pxr, kp.uright));
                             if (er > rad) return;
                         }
-                        const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
-                        const unsigned long long key = make_key(dist, cx, cy, idx, kp.octave, held);
+                        const int dist = hamming256(q, kp.d);
+                        const unsigned long long key = make_key(dist, kp.cx, kp.cy, idx, kp.octave, held);
                         if (cb.build) cache_append(cb, key);
                         if (locked) return;
                         two_min_insert(k0, k1, key);
@@ -458,15 +519,14 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 } else {
                     cache_begin(cb, lane);
                     if (!w.empty) {
-                        for_window(F, 1, F.keysR, nRight, w, lane, [&](int idx, int cx, int cy) {
-                            const ft_keypoint kp = F.keysR[idx];
+                        for_window(F, 1, F.keysR, nRight, w, lane, [&](const WinEntry &kp) {
                             if (!in_box(kp, x, y, rad, level - 1, level)) return;
-                            const int g = idx + F.Nleft;
+                            const int idx = kp.idx, g = idx + F.Nleft;
                             const bool held = F.holderObs[g] > 0;
                             const bool locked = lockedR(g, held);
                             if (locked && !cb.build) return;
-                            const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)g * 32));
-                            const unsigned long long key = make_key(dist, cx, cy, idx, kp.octave, held);
+                            const int dist = hamming256(q, kp.d);
+                            const unsigned long long key = make_key(dist, kp.cx, kp.cy, idx, kp.octave, held);
                             if (cb.build) cache_append(cb, key);
                             if (locked) return;
                             two_min_insert(k0, k1, key);
@@ -592,20 +652,20 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
             } else {
                 cache_begin(cb, lane);
                 if (!w.empty) {
-                    for_window(F, 0, F.keys, nLeft, w, lane, [&](int idx, int cx, int cy) {
-                        const ft_keypoint kp = F.keys[idx];
+                    for_window(F, 0, F.keys, nLeft, w, lane, [&](const WinEntry &kp) {
                         if (!in_box(kp, uv[0], uv[1], radius, minLevel, maxLevel)) return;
                         anyCand = 1;
+                        const int idx = kp.idx;
                         const bool held = F.holderObs[idx] > 0;
                         const bool locked = is_locked(C, idx, i, held);
                         if (locked && !cb.build) return;
-                        if (F.Nleft == -1 && F.uright && F.uright[idx] > 0) {
+                        if (kp.uright > 0) {
                             const float ur = __fsub_rn(uv[0], __fmul_rn(F.mbf, invzc));
-                            const float er = fabsf(__fsub_rn(ur, F.uright[idx]));
+                            const float er = fabsf(__fsub_rn(ur, kp.uright));
                             if (er > radius) return;
                         }
-                        const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)idx * 32));
-                        const unsigned long long key = make_key(dist, cx, cy, idx, kp.octave, held);
+                        const int dist = hamming256(q, kp.d);
+                        const unsigned long long key = make_key(dist, kp.cx, kp.cy, idx, kp.octave, held);
                         if (cb.build) cache_append(cb, key);
                         if (locked) return;
                         k0 = key < k0 ? key : k0;
@@ -645,14 +705,14 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                     } else {
                         cache_begin(cbr, lane);
                         if (!wr.empty) {
-                            for_window(F, 1, F.keysR, nRight, wr, lane, [&](int idx, int cx, int cy) {
-                                const ft_keypoint kp = F.keysR[idx];
+                            for_window(F, 1, F.keysR, nRight, wr, lane, [&](const WinEntry &kp) {
                                 if (!in_box(kp, uvr[0], uvr[1], radius, minLevel, maxLevel)) return;
+                                const int idx = kp.idx;
                                 const bool held = F.holderObs[idx + F.Nleft] > 0;
                                 const bool locked = is_locked(C, idx + F.Nleft, i, held);
                                 if (locked && !cbr.build) return;
-                                const int dist = hamming256(q, (const unsigned long long *)(F.desc + (size_t)(idx + F.Nleft) * 32));
-                                const unsigned long long key = make_key(dist, cx, cy, idx, kp.octave, held);
+                                const int dist = hamming256(q, kp.d);
+                                const unsigned long long key = make_key(dist, kp.cx, kp.cy, idx, kp.octave, held);
                                 if (cbr.build) cache_append(cbr, key);
                                 if (locked) return;
                                 kr = key < kr ? key : kr;
@@ -950,8 +1010,10 @@ int ft_launch_features_in_area(hipStream_t st, const FtDevFrame &F, int nq, cons
     return FT_OK;
 }
 
-int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridIdxL, int *gridStartR, int *gridIdxR) {
-    hipLaunchKernelGGL(k_build_grid, dim3(gridStartR ? 2 : 1), dim3(256), 0, st, F, gridStartL, gridIdxL, gridStartR, gridIdxR);
+int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridIdxL, int *gridStartR, int *gridIdxR,
+                         float4 *recL, uint8_t *descL, float4 *recR, uint8_t *descR) {
+    hipLaunchKernelGGL(k_build_grid, dim3(gridStartR ? 2 : 1), dim3(256), 0, st, F, gridStartL, gridIdxL, gridStartR, gridIdxR, recL,
+                       descL, recR, descR);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

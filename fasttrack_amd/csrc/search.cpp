@@ -275,18 +275,28 @@ PassBufs passBufs(const PassLayout &L, uint8_t *dev, const int *obs, unsigned lo
     return B;
 }
 // Frame::mGrid of a frame staged in the arena: CSR arrays behind the frame's own, built by one small launch
-size_t layoutGrid(Arena &a, int N) { return a.take(sizeof(int) * (2 * (size_t)(FT_GRID_CELLS + 1) + (size_t)std::max(N, 1))); }
+// CSR arrays (cell starts of both cameras, entries), then the entries again as 16-byte search records and 32-byte descriptors
+size_t gridIntBytes(int N) { return (sizeof(int) * (2 * (size_t)(FT_GRID_CELLS + 1) + (size_t)std::max(N, 1)) + 15) & ~(size_t)15; }
+size_t gridBytes(int N) { return gridIntBytes(N) + 48 * (size_t)std::max(N, 1); }
+size_t layoutGrid(Arena &a, int N) { return a.take(gridBytes(N)); }
 int buildGrid(const ft_context *ctx, hipStream_t st, FtDevFrame &DF, int *grid) {
     if (!ctx->tuning.search_grid) return FT_OK;
     const int nL = DF.Nleft == -1 ? DF.N : DF.Nleft;
     int *startL = grid, *startR = grid + (FT_GRID_CELLS + 1), *idx = grid + 2 * (FT_GRID_CELLS + 1);
     const bool two = DF.Nleft != -1;
-    const int rc = ft_launch_build_grid(st, DF, startL, idx, two ? startR : nullptr, two ? idx + nL : nullptr);
+    float4 *rec = (float4 *)((uint8_t *)grid + gridIntBytes(DF.N));
+    uint8_t *gdesc = (uint8_t *)(rec + std::max(DF.N, 1));
+    const int rc = ft_launch_build_grid(st, DF, startL, idx, two ? startR : nullptr, two ? idx + nL : nullptr, rec, gdesc,
+                                        two ? rec + nL : nullptr, two ? gdesc + (size_t)32 * nL : nullptr);
     if (rc != FT_OK) return rc;
     DF.gridStart[0] = startL;
     DF.gridIdx[0] = idx;
     DF.gridStart[1] = two ? startR : nullptr;
     DF.gridIdx[1] = two ? idx + nL : nullptr;
+    DF.gridRec[0] = rec;
+    DF.gridDesc[0] = gdesc;
+    DF.gridRec[1] = two ? rec + nL : nullptr;
+    DF.gridDesc[1] = two ? gdesc + (size_t)32 * nL : nullptr;
     return FT_OK;
 }
 
@@ -863,7 +873,7 @@ int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, 
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_l2r, sizeof(int) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_r2l, sizeof(int) * K);
     if (e == hipSuccess) e = hipMalloc((void **)&tf->d_work, tf->workBytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&tf->d_grid, sizeof(int) * (2 * (size_t)(FT_GRID_CELLS + 1) + K));
+    if (e == hipSuccess) e = hipMalloc((void **)&tf->d_grid, gridBytes((int)K));
     if (e == hipSuccess && searchCacheOn(ctx)) e = hipMalloc((void **)&tf->d_cache, searchCacheBytes(max_points));
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_work, tf->workBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_holderUp, sizeof(int) * K, hipHostMallocDefault);
