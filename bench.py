@@ -49,7 +49,7 @@ WORKLOADS = {
 }
 NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_JSON = "r03_traffic.json"
+TRAFFIC_JSON = "r04_traffic.json"
 
 
 def usable_cpus():
@@ -620,14 +620,14 @@ def main():
         legs = [x for x in legs if x]
         roof = legs[0] if legs else None
         try:
-            mc = json.load(open(os.path.join(ROOT, "profiles", "r03_marginal_costs.json")))
+            mc = json.load(open(os.path.join(ROOT, "profiles", "r04_marginal_costs.json")))
         except Exception:
             mc = {}
         if roof and mc.get("workload") == args.workload and mc.get("batch_pairs") == B and not args.mosaic and args.scene == "objects":
             ms = mc["marginal_ms_per_step"]["k_fast_cells"] / (roof["launches_timed"] / args.steps)
             ach = roof["bytes_per_launch"] / (ms / 1e3) / 1e9
             roof["at_marginal_cost"] = {"ms_per_launch": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-                                        "source": "profiles/r03_marginal_costs.json (tools/marginal_costs.py: FT_DEBUG_REPEAT=fast, same workload)"}
+                                        "source": "profiles/r04_marginal_costs.json (tools/marginal_costs.py: FT_DEBUG_REPEAT=fast, same workload)"}
             # the same for the vector-issue bound: the launch's vector instructions (committed SQ pass) x 4 cycles on a
             # 16-lane SIMD / (1 024 SIMDs x 2.4 GHz x the launch's cost inside the pipeline) - ~1.0 says the kernel is priced
             # at its instruction stream, which is what "the chip is full" means for it

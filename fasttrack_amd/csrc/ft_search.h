@@ -16,15 +16,14 @@ struct FtDevFrame {
     float Trl[12];
     float sf[FT_MAX_LEVELS];
     int nlevels;
-    // Frame::mGrid as CSR (k_build_grid; AssignFeaturesToGrid src/Frame.cc:409-440): the keypoints of cell (cx, cy) are
-    // gridIdx[gridStart[cx * 48 + cy] .. gridStart[cx * 48 + cy + 1]), each entry = keypoint index | cy << 24, so a
-    // window's column cx is ONE contiguous range; [0] left camera (or the only one), [1] right camera.  Null = no grid:
-    // the searches then scan every keypoint.
+    // Frame::mGrid as one CSR per octave (k_build_grid; AssignFeaturesToGrid src/Frame.cc:409-440): the keypoints of octave o
+    // in cell (cx, cy) are the entries gridStart[o * (FT_GRID_CELLS + 1) + cx * 48 + cy] .. [... + 1), so the part of a
+    // window's column cx that lies in the search's level band is ONE contiguous range per octave; [0] left camera (or the
+    // only one), [1] right camera.  Null = no grid: the searches then scan every keypoint.
     const int *gridStart[2];
-    const int *gridIdx[2];
-    // the same entries as search records, in the order of gridIdx: {x, y, uright (or -1), index | octave << 24} and the
-    // 32-byte descriptor - what a window scan needs of a keypoint, as two contiguous reads per run of entries instead of
-    // the chain grid entry -> keypoint -> descriptor / uright
+    // the entries as search records {x, y, uright (or -1), index | octave << 24} and 32-byte descriptors - what a window
+    // scan needs of a keypoint, as two contiguous reads per run of entries instead of the chain grid entry -> keypoint ->
+    // descriptor / uright
     const float4 *gridRec[2];
     const uint8_t *gridDesc[2];
 };
@@ -121,6 +120,8 @@ struct FtFrustumOut {
 };
 
 int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v);
+// p[0 .. n) = -1 and meta[i * strideWords] = ~0 for i < nMeta (meta may be null): the start of a claim iteration, one launch
+int ft_launch_fill_claims(hipStream_t st, int *p, int n, unsigned long long *meta, int nMeta, int strideWords);
 // p[i * strideWords] = v for i < n (64-bit words): the meta words of the candidate cache
 int ft_launch_fill_stride_u64(hipStream_t st, unsigned long long *p, int n, int strideWords, unsigned long long v);
 // one kernel copies up to three device blocks (sizes rounded up to dwords) into pinned host memory
@@ -140,5 +141,5 @@ int ft_launch_search_local_persist(hipStream_t st, const FtDevFrame &F, const Ft
                                    float nnRatio, const FtPersist &S, const FtLocalRaw &raw);
 int ft_launch_search_last_persist(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
                                   const FtPose &Tcw, float th, int forward, int backward, const FtPersist &S, const FtLastRaw &raw);
-int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridIdxL, int *gridStartR, int *gridIdxR,
-                         float4 *recL, uint8_t *descL, float4 *recR, uint8_t *descR);
+int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridStartR, float4 *recL, uint8_t *descL,
+                         float4 *recR, uint8_t *descR);

@@ -110,6 +110,8 @@ __device__ __forceinline__ void claims_file(const FtClaims &C, int *res, int i, 
     }
 }
 
+__device__ __forceinline__ unsigned div_magic_u(int d) { return d > 1 ? 0xffffffffu / (unsigned)d + 1u : 0u; }
+
 struct Window {
     int minCX, maxCX, minCY, maxCY;
     bool empty;
@@ -256,26 +258,38 @@ __device__ __forceinline__ bool in_box(const WinEntry &kp, float x, float y, flo
     return fabsf(dx) < r && fabsf(dy) < r;
 }
 
-// The keypoints of camera `cam` whose grid cell lies in window w, handed to fn(entry) lane-parallel.  With the
-// frame's CSR grid (k_build_grid) a column of cells is one contiguous range of entries - a map point looks at the
-// keypoints of its window only, as Frame::GetFeaturesInArea does; without it every keypoint's cell is computed and tested.
+// The keypoints of camera `cam` whose grid cell lies in window w and whose octave lies in the level band of the search,
+// handed to fn(entry) lane-parallel.  The frame's grid (k_build_grid) is a CSR PER OCTAVE: the keypoints of octave o in the
+// cells (cx, minCY .. maxCY) are one contiguous range of entries - a map point looks at the keypoints GetFeaturesInArea would
+// return for it (window AND level band: the band keeps 13 - 40 % of a window's keypoints, least where the windows are
+// largest), where a grid over all octaves made the first pass of a search read every keypoint of the window.  Without a grid
+// every keypoint's cell is computed and tested.
+// minLevel / maxLevel as Frame::GetFeaturesInArea takes them (src/Frame.cc:714-729): no check at all unless minLevel > 0 or
+// maxLevel >= 0; maxLevel < 0 = no upper bound.
 template <class Fn>
-__device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const ft_keypoint *keys, int n, const Window &w, int lane,
-                                           Fn fn) {
+__device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const ft_keypoint *keys, int n, const Window &w, int minLevel,
+                                           int maxLevel, int lane, Fn fn) {
     if (F.gridStart[cam]) {
-        // The window's columns of cells are contiguous ranges of grid entries.  One lane per column fetches its range, a
-        // wave scan lays the ranges end to end, and the lanes then take the window's entries 64 at a time: the usual
-        // window (a few dozen keypoints in up to ~12 columns) is ONE round of loads, and a round is one memory round trip:
-        // record and descriptor of an entry sit at the entry's position (k_build_grid), so both are requested at once - and
-        // for TWO rounds at a time, a wide window being a chain of such trips otherwise.
+        // One lane per (octave, column of cells) range, a wave scan lays the ranges end to end, and the lanes take the
+        // entries 64 at a time - two rounds per trip: record and descriptor of an entry sit at the entry's position, so a
+        // round is one memory round trip, and a wide window a chain of them.
+        const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+        const int lo = checkLevels ? min(max(minLevel, 0), F.nlevels - 1) : 0;  // (octaves beyond the table are filed under its last bucket)
+        const int hi = (checkLevels && maxLevel >= 0) ? min(maxLevel, F.nlevels - 1) : F.nlevels - 1;
+        const int ncolsW = w.maxCX - w.minCX + 1;
+        const int npairs = (hi - lo + 1) * ncolsW;  // (<= 0: an empty band)
         const int *gs = F.gridStart[cam];
         const float4 *rec = F.gridRec[cam];
         const uint4 *gd = (const uint4 *)F.gridDesc[cam];
-        for (int c0 = w.minCX; c0 <= w.maxCX; c0 += 64) {
-            const int ncols = min(64, w.maxCX - c0 + 1);
-            int b = 0, cnt = 0;
-            if (lane < ncols) {
-                const int *col = gs + (c0 + lane) * FT_GRID_ROWS;
+        const unsigned colMagic = div_magic_u(ncolsW);
+        for (int p0 = 0; p0 < npairs; p0 += 64) {
+            const int np = min(64, npairs - p0);
+            int b = 0, cnt = 0, myCol = 0;
+            if (lane < np) {
+                const int pidx = p0 + lane;
+                const int oi = colMagic ? (int)__umulhi((unsigned)pidx, colMagic) : pidx;
+                myCol = w.minCX + (pidx - oi * ncolsW);
+                const int *col = gs + (size_t)(lo + oi) * (FT_GRID_CELLS + 1) + myCol * FT_GRID_ROWS;
                 b = col[w.minCY];
                 cnt = col[w.maxCY + 1] - b;
             }
@@ -286,19 +300,20 @@ __device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const f
                 if (lane >= d) incl += y;
             }
             const int total = __builtin_amdgcn_readlane(incl, 63);
-            auto locate = [&](int t, int &pos, int &colIdx) {
-                colIdx = 0;  // the column entry t falls into: the number of columns that end at or before t
-                for (int c = 0; c < ncols - 1; c++) colIdx += t >= __builtin_amdgcn_readlane(incl, c) ? 1 : 0;
-                const int cb = __shfl(b, colIdx), cEnd = __shfl(incl, colIdx), cCnt = __shfl(cnt, colIdx);
+            auto locate = [&](int t, int &pos, int &cx) {
+                int r = 0;  // the range entry t falls into: the number of ranges that end at or before t
+                for (int c = 0; c < np - 1; c++) r += t >= __builtin_amdgcn_readlane(incl, c) ? 1 : 0;
+                const int cb = __shfl(b, r), cEnd = __shfl(incl, r), cCnt = __shfl(cnt, r);
+                cx = __shfl(myCol, r);
                 pos = cb + (t - (cEnd - cCnt));
             };
-            auto hand = [&](const float4 &r, const uint4 &d0, const uint4 &d1, int colIdx) {
+            auto hand = [&](const float4 &r, const uint4 &d0, const uint4 &d1, int cx) {
                 WinEntry e;
                 e.x = r.x; e.y = r.y; e.uright = r.z;
                 const int io = __float_as_int(r.w);
                 e.idx = io & 0xffffff;
-                e.octave = (io >> 24) & 15;
-                e.cx = c0 + colIdx;
+                e.octave = io >> 24;  // (signed: the keypoint's own octave, whatever bucket it was filed under)
+                e.cx = cx;
                 e.cy = (int)roundf(__fmul_rn(__fsub_rn(r.y, F.mnMinY), F.invH));  // Frame::PosInGrid, as k_build_grid filed it
                 e.d[0] = (unsigned long long)d0.x | ((unsigned long long)d0.y << 32);
                 e.d[1] = (unsigned long long)d0.z | ((unsigned long long)d0.w << 32);
@@ -308,10 +323,10 @@ __device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const f
             };
             for (int t0 = 0; t0 < total; t0 += 128) {
                 const int tA = t0 + lane, tB = t0 + 64 + lane;
-                int posA, colA, posB = 0, colB = 0;
-                locate(min(tA, total - 1), posA, colA);
+                int posA, cxA, posB = 0, cxB = 0;
+                locate(min(tA, total - 1), posA, cxA);
                 const bool second = t0 + 64 < total;  // wave-uniform
-                if (second) locate(min(tB, total - 1), posB, colB);
+                if (second) locate(min(tB, total - 1), posB, cxB);
                 const float4 rA = rec[posA];
                 const uint4 a0 = gd[2 * (size_t)posA], a1 = gd[2 * (size_t)posA + 1];
                 float4 rB = rA;
@@ -321,8 +336,8 @@ __device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const f
                     b0 = gd[2 * (size_t)posB];
                     b1 = gd[2 * (size_t)posB + 1];
                 }
-                if (tA < total) hand(rA, a0, a1, colA);
-                if (second && tB < total) hand(rB, b0, b1, colB);
+                if (tA < total) hand(rA, a0, a1, cxA);
+                if (second && tB < total) hand(rB, b0, b1, cxB);
             }
         }
         return;
@@ -344,31 +359,40 @@ __device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const f
     }
 }
 
-// Frame::AssignFeaturesToGrid (src/Frame.cc:409-440) as CSR: block 0 the left camera (or the only one), block 1 the
-// right camera of a two-camera frame.  Counting sort by cell cx * 48 + cy in LDS; the order inside a cell is free (the
-// searches order candidates by (distance, cx, cy, index) keys).
-__global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, int *idxL, int *startR, int *idxR, float4 *recL,
-                                                    uint8_t *descL, float4 *recR, uint8_t *descR) {
+// Frame::AssignFeaturesToGrid (src/Frame.cc:409-440) as one CSR per octave: workgroup (octave o, camera) counting-sorts the
+// camera's keypoints of octave o by cell cx * 48 + cy in LDS and files them behind the keypoints of the lower octaves (their
+// number is counted on the way).  An octave outside [0, nlevels) is filed under the nearest bucket; the searches test the
+// keypoint's own octave anyway.  The order inside a cell is free (the searches order candidates by (distance, cx, cy, index)
+// keys).  start: [nlevels][FT_GRID_CELLS + 1] absolute entry positions; rec / desc: the entries (ft_search.h).
+__global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, int *startR, float4 *recL, uint8_t *descL, float4 *recR,
+                                                    uint8_t *descR) {
     __shared__ int cnt[FT_GRID_CELLS + 1];
-    __shared__ int wsum[4];
-    const int cam = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int wsum[4], wbelow[4];
+    const int oct = blockIdx.x, cam = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = cam == 0 ? (F.Nleft == -1 ? F.N : F.Nleft) : (F.Nleft == -1 ? 0 : F.N - F.Nleft);
     const ft_keypoint *keys = cam == 0 ? F.keys : F.keysR;
-    int *start = cam == 0 ? startL : startR, *out = cam == 0 ? idxL : idxR;
+    int *start = (cam == 0 ? startL : startR);
     if (!start) return;
+    start += (size_t)oct * (FT_GRID_CELLS + 1);
     for (int c = tid; c <= FT_GRID_CELLS; c += 256) cnt[c] = 0;
     __syncthreads();
-    auto cellOf = [&](int i) -> int {
-        const ft_keypoint kp = keys[i];
+    auto cellOf = [&](const ft_keypoint &kp) -> int {
         const int cx = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.mnMinX), F.invW));
         const int cy = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.mnMinY), F.invH));
         if (cx < 0 || cx >= FT_GRID_COLS || cy < 0 || cy >= FT_GRID_ROWS) return -1;
         return cx * FT_GRID_ROWS + cy;
     };
+    int below = 0;  // keypoints of the grid in lower buckets
     for (int i = tid; i < n; i += 256) {
-        const int c = cellOf(i);
-        if (c >= 0) atomicAdd(&cnt[c], 1);
+        const ft_keypoint kp = keys[i];
+        const int c = cellOf(kp);
+        if (c < 0) continue;
+        const int bkt = min(max(kp.octave, 0), F.nlevels - 1);
+        if (bkt < oct) below++;
+        else if (bkt == oct) atomicAdd(&cnt[c], 1);
     }
+    below = wave_sum_i32(below);
+    if (lane == 0) wbelow[wave] = below;
     __syncthreads();
     // exclusive scan of the 3072 counts: 12 consecutive cells per thread
     constexpr int PER = FT_GRID_CELLS / 256;
@@ -382,7 +406,8 @@ __global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, i
     }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int run = incl - local;
+    const int base = wbelow[0] + wbelow[1] + wbelow[2] + wbelow[3];
+    int run = base + incl - local;
     for (int w = 0; w < wave; w++) run += wsum[w];
     const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     for (int k = 0; k < PER; k++) {
@@ -391,24 +416,22 @@ __global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, i
         cnt[c] = run;  // becomes the fill cursor of the cell
         run += v;
     }
-    if (tid == 0) start[FT_GRID_CELLS] = total;
+    if (tid == 0) start[FT_GRID_CELLS] = base + total;
     __syncthreads();
     float4 *rec = cam == 0 ? recL : recR;
     uint8_t *gdesc = cam == 0 ? descL : descR;
     const uint8_t *desc = F.desc + (cam == 0 ? 0 : (size_t)F.Nleft * 32);
     for (int i = tid; i < n; i += 256) {
-        const int c = cellOf(i);
-        if (c >= 0) {
-            const int p = atomicAdd(&cnt[c], 1);
-            out[p] = i | ((c % FT_GRID_ROWS) << 24);
-            const ft_keypoint kp = keys[i];
-            const float ur = (cam == 0 && F.Nleft == -1 && F.uright) ? F.uright[i] : -1.0f;
-            rec[p] = make_float4(kp.x, kp.y, ur, __int_as_float(i | (kp.octave << 24)));
-            const uint4 *d = (const uint4 *)(desc + (size_t)i * 32);
-            uint4 *o = (uint4 *)(gdesc + (size_t)p * 32);
-            o[0] = d[0];
-            o[1] = d[1];
-        }
+        const ft_keypoint kp = keys[i];
+        const int c = cellOf(kp);
+        if (c < 0 || min(max(kp.octave, 0), F.nlevels - 1) != oct) continue;
+        const int p = atomicAdd(&cnt[c], 1);
+        const float ur = (cam == 0 && F.Nleft == -1 && F.uright) ? F.uright[i] : -1.0f;
+        rec[p] = make_float4(kp.x, kp.y, ur, __int_as_float((i & 0xffffff) | (kp.octave << 24)));
+        const uint4 *d = (const uint4 *)(desc + (size_t)i * 32);
+        uint4 *o = (uint4 *)(gdesc + (size_t)p * 32);
+        o[0] = d[0];
+        o[1] = d[1];
     }
 }
 
@@ -452,7 +475,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 cache_begin(cb, lane);
                 if (!w.empty) {
                     const float pxr = (F.Nleft == -1 && F.uright) ? P.projXR[i] : 0.f;
-                    for_window(F, 0, F.keys, nLeft, w, lane, [&](const WinEntry &kp) {
+                    for_window(F, 0, F.keys, nLeft, w, level - 1, level, lane, [&](const WinEntry &kp) {
                         if (!in_box(kp, x, y, rad, level - 1, level)) return;
                         const int idx = kp.idx;
                         const bool held = F.holderObs[idx] > 0;
@@ -519,7 +542,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 } else {
                     cache_begin(cb, lane);
                     if (!w.empty) {
-                        for_window(F, 1, F.keysR, nRight, w, lane, [&](const WinEntry &kp) {
+                        for_window(F, 1, F.keysR, nRight, w, level - 1, level, lane, [&](const WinEntry &kp) {
                             if (!in_box(kp, x, y, rad, level - 1, level)) return;
                             const int idx = kp.idx, g = idx + F.Nleft;
                             const bool held = F.holderObs[g] > 0;
@@ -652,7 +675,7 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
             } else {
                 cache_begin(cb, lane);
                 if (!w.empty) {
-                    for_window(F, 0, F.keys, nLeft, w, lane, [&](const WinEntry &kp) {
+                    for_window(F, 0, F.keys, nLeft, w, minLevel, maxLevel, lane, [&](const WinEntry &kp) {
                         if (!in_box(kp, uv[0], uv[1], radius, minLevel, maxLevel)) return;
                         anyCand = 1;
                         const int idx = kp.idx;
@@ -705,7 +728,7 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                     } else {
                         cache_begin(cbr, lane);
                         if (!wr.empty) {
-                            for_window(F, 1, F.keysR, nRight, wr, lane, [&](const WinEntry &kp) {
+                            for_window(F, 1, F.keysR, nRight, wr, minLevel, maxLevel, lane, [&](const WinEntry &kp) {
                                 if (!in_box(kp, uvr[0], uvr[1], radius, minLevel, maxLevel)) return;
                                 const int idx = kp.idx;
                                 const bool held = F.holderObs[idx + F.Nleft] > 0;
@@ -955,6 +978,13 @@ __global__ __launch_bounds__(256) void k_fill_stride_u64(unsigned long long *p, 
     if (i < n) p[(size_t)i * strideWords] = v;
 }
 
+// start of a claim iteration: list heads, flags and writer table = -1, the cache's meta words = ~0 ("not built") - one launch
+__global__ __launch_bounds__(256) void k_fill_claims(int *p, int n, unsigned long long *meta, int nMeta, int strideWords) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = -1;
+    if (i < nMeta) meta[(size_t)i * strideWords] = ~0ull;
+}
+
 __global__ __launch_bounds__(256) void k_fill_i32(int *p, int n, int v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
@@ -978,6 +1008,14 @@ int ft_launch_deliver_blocks(hipStream_t st, void *d0, const void *s0, size_t by
 int ft_launch_fill_stride_u64(hipStream_t st, unsigned long long *p, int n, int strideWords, unsigned long long v) {
     if (n <= 0) return FT_OK;
     hipLaunchKernelGGL(k_fill_stride_u64, dim3((n + 255) / 256), dim3(256), 0, st, p, n, strideWords, v);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_fill_claims(hipStream_t st, int *p, int n, unsigned long long *meta, int nMeta, int strideWords) {
+    const int m = std::max(n, meta ? nMeta : 0);
+    if (m <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_fill_claims, dim3((m + 255) / 256), dim3(256), 0, st, p, n, meta, meta ? nMeta : 0, strideWords);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
@@ -1010,10 +1048,10 @@ int ft_launch_features_in_area(hipStream_t st, const FtDevFrame &F, int nq, cons
     return FT_OK;
 }
 
-int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridIdxL, int *gridStartR, int *gridIdxR,
-                         float4 *recL, uint8_t *descL, float4 *recR, uint8_t *descR) {
-    hipLaunchKernelGGL(k_build_grid, dim3(gridStartR ? 2 : 1), dim3(256), 0, st, F, gridStartL, gridIdxL, gridStartR, gridIdxR, recL,
-                       descL, recR, descR);
+int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridStartR, float4 *recL, uint8_t *descL,
+                         float4 *recR, uint8_t *descR) {
+    hipLaunchKernelGGL(k_build_grid, dim3(F.nlevels, gridStartR ? 2 : 1), dim3(256), 0, st, F, gridStartL, gridStartR, recL, descL, recR,
+                       descR);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -158,14 +158,9 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
     const size_t K = ((size_t)std::max(nKp, 1) + 7) & ~(size_t)7;  // = passK(nKp)
     int *flags = B.head + 3 * K, *tab = flags + 32;  // (the table records are 32 bytes and 32-byte aligned: layoutPasses)
     const int fillWords = (int)(3 * K + 32 + 24 * K);
-    {   // list heads = -1, flags = "unchanged" (-1), writer table empty (-1)
-        const int rcf = ft_launch_fill_i32(st, B.head, fillWords, -1);
+    {   // list heads = -1, flags = "unchanged" (-1), writer table empty (-1); candidate cache: ~0 in a slot's first word = "not built yet"
+        const int rcf = ft_launch_fill_claims(st, B.head, fillWords, B.cache, 2 * nPoints, FT_CACHE_CAP + 1);
         if (rcf != FT_OK) return rcf;
-        // candidate cache: ~0 in a slot's first word = "not built yet"
-        if (B.cache) {
-            const int rcc = ft_launch_fill_stride_u64(st, B.cache, 2 * nPoints, FT_CACHE_CAP + 1, ~0ull);
-            if (rcc != FT_OK) return rcc;
-        }
     }
     C.cache = B.cache;
     int pass = 0, burst = 0;
@@ -275,24 +270,23 @@ PassBufs passBufs(const PassLayout &L, uint8_t *dev, const int *obs, unsigned lo
     return B;
 }
 // Frame::mGrid of a frame staged in the arena: CSR arrays behind the frame's own, built by one small launch
-// CSR arrays (cell starts of both cameras, entries), then the entries again as 16-byte search records and 32-byte descriptors
-size_t gridIntBytes(int N) { return (sizeof(int) * (2 * (size_t)(FT_GRID_CELLS + 1) + (size_t)std::max(N, 1)) + 15) & ~(size_t)15; }
+// cell starts per octave of both cameras (FT_MAX_LEVELS x 3073 ints each), then the entries as 16-byte search records and
+// 32-byte descriptors
+size_t gridIntBytes(int) { return (sizeof(int) * 2 * (size_t)FT_MAX_LEVELS * (FT_GRID_CELLS + 1) + 15) & ~(size_t)15; }
 size_t gridBytes(int N) { return gridIntBytes(N) + 48 * (size_t)std::max(N, 1); }
 size_t layoutGrid(Arena &a, int N) { return a.take(gridBytes(N)); }
 int buildGrid(const ft_context *ctx, hipStream_t st, FtDevFrame &DF, int *grid) {
     if (!ctx->tuning.search_grid) return FT_OK;
     const int nL = DF.Nleft == -1 ? DF.N : DF.Nleft;
-    int *startL = grid, *startR = grid + (FT_GRID_CELLS + 1), *idx = grid + 2 * (FT_GRID_CELLS + 1);
+    int *startL = grid, *startR = grid + (size_t)FT_MAX_LEVELS * (FT_GRID_CELLS + 1);
     const bool two = DF.Nleft != -1;
     float4 *rec = (float4 *)((uint8_t *)grid + gridIntBytes(DF.N));
     uint8_t *gdesc = (uint8_t *)(rec + std::max(DF.N, 1));
-    const int rc = ft_launch_build_grid(st, DF, startL, idx, two ? startR : nullptr, two ? idx + nL : nullptr, rec, gdesc,
-                                        two ? rec + nL : nullptr, two ? gdesc + (size_t)32 * nL : nullptr);
+    const int rc = ft_launch_build_grid(st, DF, startL, two ? startR : nullptr, rec, gdesc, two ? rec + nL : nullptr,
+                                        two ? gdesc + (size_t)32 * nL : nullptr);
     if (rc != FT_OK) return rc;
     DF.gridStart[0] = startL;
-    DF.gridIdx[0] = idx;
     DF.gridStart[1] = two ? startR : nullptr;
-    DF.gridIdx[1] = two ? idx + nL : nullptr;
     DF.gridRec[0] = rec;
     DF.gridDesc[0] = gdesc;
     DF.gridRec[1] = two ? rec + nL : nullptr;
