@@ -1701,11 +1701,14 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+// FT_DEBUG_OD_PROFILE=1: where a wave of k_orient_desc spends its life - 100 MHz wall-clock stamps at the phase boundaries of
+// wave 0 of every 16th workgroup, summed here ([0] = sampled waves, [1 + p] = ticks of phase p); the launcher prints them
+__device__ unsigned long long g_odProf[16];
 template <int OD_KPW>
 __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const uint8_t *const *l0, int l0pitch,
                                                                const uint8_t *pyr, int alignedLoads, const FtSelKp *sel,
                                                                const int *selCount, FtOctArgs lay, int *nSel,
-                                                               ft_keypoint *keysOut, uint8_t *descOut, FtSlotGrid sg) {
+                                                               ft_keypoint *keysOut, uint8_t *descOut, FtSlotGrid sg, int prof) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is uniform by construction; as a scalar it makes the keypoint lookup below (level search, entry
@@ -1713,6 +1716,17 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     const int wave = wave_index();
     int slot, blk;
     if (!ft_slot_block(sg, slot, blk)) return;
+    const bool profW = prof && wave == 0 && (blockIdx.x & 15u) == 0;
+    unsigned long long tPrev = profW ? wall_clock64() : 0;
+    int profIdx = 0;
+    auto tick = [&]() {
+        if (!profW) return;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the phase's memory operations belong to it
+        const unsigned long long t = wall_clock64();
+        if (lane == 0) atomicAdd(&g_odProf[1 + profIdx], t - tPrev);
+        profIdx++;
+        tPrev = t;
+    };
     // OD_KPW keypoints per wave, one after the other through the same LDS buffers - with the LOADS of all of them issued up
     // front: level lookup, selection entries, image pointers and the nine patch dwords per lane of every keypoint are
     // requested before the first one is processed, so the dependent chain selCount -> sel entry -> image pointer -> patch
@@ -1962,11 +1976,15 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
             d[3] = words[3];
         }
     };
+    tick();  // 0: level lookup, selection entries, patch loads (all keypoints of the wave) have arrived
     stage(0);
     wave_lds_sync();
+    tick();  // 1: patch 0 staged in LDS
     moments(0);
+    tick();  // 2: moments 0
     hblur();
     wave_lds_sync();  // hb 0 is complete, the raw buffer is free
+    tick();  // 3: horizontal blur 0
     if constexpr (OD_KPW > 1) {
         if (nKp > 1) {  // wave-uniform
             stage(1);
@@ -1974,6 +1992,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
             moments(1);
         }
     }
+    tick();  // 4: patch 1 staged + moments 1
     float mY = (float)m01K[0], mX = (float)m10K[0];
     if constexpr (OD_KPW > 1) {
         if (nKp > 1 && lane >= 32) {
@@ -1988,15 +2007,20 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     const float ar = __fmul_rn(angleL, factorPI);
     const float caL = ft_libm::cosf_glibc(ar), sbL = ft_libm::sinf_glibc(ar);
     auto lane_value = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    tick();  // 5: angles of both keypoints
     describe(0, lane_value(angleL, 0), lane_value(caL, 0), lane_value(sbL, 0));
+    tick();  // 6: samples + stores of keypoint 0
     if constexpr (OD_KPW > 1) {
         if (nKp > 1) {
             wave_lds_sync();  // samples 0 have read hb
             hblur();
             wave_lds_sync();
+            tick();  // 7: horizontal blur 1
             describe(1, lane_value(angleL, 32), lane_value(caL, 32), lane_value(sbL, 32));
+            tick();  // 8: samples + stores of keypoint 1
         }
     }
+    if (profW && lane == 0) atomicAdd(&g_odProf[0], 1ull);
 }
 
 }  // namespace
@@ -2193,13 +2217,28 @@ int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint
                                                      64 * OD_WAVES, smem);
         fprintf(stderr, "[ft] k_orient_desc<%d>: %zu B of LDS per workgroup, %d workgroups per CU\n", kpw, smem, nb);
     }
+    static const int prof = ft_debug_env("FT_DEBUG_OD_PROFILE") ? 1 : 0;
     for (int rep = ft_debug_repeat("orient"); rep > 0; rep--) {
         if (kpw == 1)
             hipLaunchKernelGGL(k_orient_desc<1>, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, selCount, layout,
-                               nSel, keys, desc, sg);
+                               nSel, keys, desc, sg, 0);
         else
             hipLaunchKernelGGL(k_orient_desc<OD_KPW_WIDE>, grid, block, smem, st, g, l0, l0pitch, pyr, alignedLoads, sel, selCount,
-                               layout, nSel, keys, desc, sg);
+                               layout, nSel, keys, desc, sg, prof);
+    }
+    if (prof && kpw > 1) {
+        static int launches = 0;
+        if (++launches % 64 == 0) {  // (synchronises: a debugging aid)
+            unsigned long long h[16];
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_odProf), sizeof h) == hipSuccess && h[0]) {
+                static const char *names[9] = {"loads (level, selection, patches)", "stage 0", "moments 0", "hblur 0", "stage 1 + moments 1",
+                                               "angles", "samples 0 + stores", "hblur 1", "samples 1 + stores"};
+                double tot = 0;
+                for (int k = 0; k < 9; k++) tot += (double)h[1 + k];
+                fprintf(stderr, "[ft] k_orient_desc<2> wave life, %llu sampled waves, %.2f us per wave:\n", h[0], tot / h[0] / 100.0);
+                for (int k = 0; k < 9; k++) fprintf(stderr, "[ft]   %-36s %6.2f us  %5.1f %%\n", names[k], h[1 + k] / (double)h[0] / 100.0, 100.0 * h[1 + k] / tot);
+            }
+        }
     }
     FT_HIP(hipGetLastError());
     return FT_OK;
