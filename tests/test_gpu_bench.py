@@ -46,6 +46,16 @@ def test_bench_eight_ranks_folded_onto_one_device():
     assert r["config"]["host_threads_per_gpu"] >= 1 and r["config"]["hw_queues"] == 10
 
 
+def test_bench_four_ranks_folded_onto_one_device():
+    """the N = 4 point of the driver's scaling curve, folded: whole-job value over the slowest rank's time, per-rank rates, NUMA
+    fields, no data-path collective"""
+    r = _run(["--gpus", "4", "--steps", "3", "--warmup", "1", "--batch", "16", "--workload", "stereo_640x480_nf1000", "--no-host-in",
+              "--no-cpu-baseline"], {"FT_BENCH_DEVICE_MOD": "1"}, timeout=600)
+    assert r["n_gpus"] == 4 and r["scaling"] == "weak" and len(r["per_rank_frames_per_s"]) == 4 and min(r["per_rank_frames_per_s"]) > 0
+    assert r["value"] <= sum(r["per_rank_frames_per_s"]) * 1.0001 and r["device_octree_fallbacks"] == 0
+    assert "numa_node_of_rank0" in r["config"] and "no collective" in r["config"]["parallelism"]
+
+
 def test_bench_single_rank_line_has_the_contract_fields():
     r = _run(["--steps", "3", "--warmup", "1", "--batch", "32", "--workload", "stereo_752x480_nf1200", "--no-cpu-baseline",
               "--workload-batch", "20", "--workload-frames", "6"])
