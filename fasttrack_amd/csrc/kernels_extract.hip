@@ -722,7 +722,9 @@ __device__ __forceinline__ unsigned fast_score2(unsigned v, const unsigned p[16]
 #ifndef FC_ROWS
 #define FC_ROWS 4     // rows per trip of the column-mapped rejection pass (>= 3)
 #endif
+#ifndef FC_NMS_REG
 #define FC_NMS_REG 2  // corner-list chunks (64 corners each) whose NMS flags stay in registers
+#endif
 #ifndef FC_CORN
 #define FC_CORN 384   // corners kept for NMS / emission; a cell with more falls back to scanning the plane (256: the cells of
                       // dense frames, ~330 corners, all took the scan: dense scenes +2.4 % with 384, the headline +0.7 %; 448: -1 %)
