@@ -982,7 +982,7 @@ __global__ __launch_bounds__(64, FC_WAVES_PER_EU) void k_fast_cells(FtGeom g, co
         for (int yb = 0; yb < hRows; yb += 28) {
         const int yEnd = min(yb + 28, hRows);
         unsigned cmask = 0;
-        for (int y = yb; y < yEnd; y += 4) {
+        auto trip = [&](int y) {
             const uint8_t *r = col + y * TP;
             unsigned pv[7];
             pv[0] = pA; pv[1] = pB; pv[2] = pC;
@@ -1011,7 +1011,15 @@ __global__ __launch_bounds__(64, FC_WAVES_PER_EU) void k_fast_cells(FtGeom g, co
                 : "+v"(cmask)
                 : "v"(M0), "v"(th), "v"(M1)
                 : "vcc");
+        };
+        // two trips per iteration: the register rotation (pA / pB / pC, the two history pairs) between them is renaming
+        // instead of four moves per trip
+        int y = yb;
+        for (; y + 4 < yEnd; y += 8) {
+            trip(y);
+            trip(y + 4);
         }
+        if (y < yEnd) trip(y);
         {
             // row yb + r of a half sits at bit T - 1 - r (T = rows walked in the block, a multiple of four); rows the half does
             // not have and columns beyond the cell are masked out here, once
