@@ -581,13 +581,17 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
     }
 }
 
-__global__ __launch_bounds__(256) void k_search_local(FtDevFrame F, FtDevLocalPoints P, FtClaims C, float th,
+// waves (= points) per workgroup of the search kernels: a pass is short, and its fixed cost is the dispatch of its workgroups
+#ifndef FT_SEARCH_WPB
+#define FT_SEARCH_WPB 4
+#endif
+__global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_local(FtDevFrame F, FtDevLocalPoints P, FtClaims C, float th,
                                                       float nnRatio, int *res, FtLocalRaw raw) {
     if (!claims_begin_pass(C)) return;
     const int lane = threadIdx.x & 63, wave = wave_index();
-    const int i = blockIdx.x * 4 + wave;
+    const int i = blockIdx.x * FT_SEARCH_WPB + wave;
     if (i >= P.M) return;
-    __shared__ int cacheCounter[4];
+    __shared__ int cacheCounter[FT_SEARCH_WPB];
     int r4[4];
     local_point(F, P, C, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
     claims_file(C, res, i, lane, r4);
@@ -759,13 +763,13 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
     }
 }
 
-__global__ __launch_bounds__(256) void k_search_last(FtDevFrame F, FtDevLastPoints Lp, FtClaims C, FtPose Tcw, float th,
+__global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last(FtDevFrame F, FtDevLastPoints Lp, FtClaims C, FtPose Tcw, float th,
                                                      int bForward, int bBackward, int *res, FtLastRaw raw) {
     if (!claims_begin_pass(C)) return;
     const int lane = threadIdx.x & 63, wave = wave_index();
-    const int i = blockIdx.x * 4 + wave;
+    const int i = blockIdx.x * FT_SEARCH_WPB + wave;
     if (i >= Lp.N) return;
-    __shared__ int cacheCounter[4];
+    __shared__ int cacheCounter[FT_SEARCH_WPB];
     int r4[4];
     last_point(F, Lp, C, Tcw, th, bForward, bBackward, i, lane, r4, raw, &cacheCounter[wave]);
     claims_file(C, res, i, lane, r4);
@@ -1059,7 +1063,7 @@ int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, i
 int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
                            float nnRatio, int *res, const FtLocalRaw &raw) {
     if (P.M <= 0) return FT_OK;
-    hipLaunchKernelGGL(k_search_local, dim3((P.M + 3) / 4), dim3(256), 0, st, F, P, C, th, nnRatio, res, raw);
+    hipLaunchKernelGGL(k_search_local, dim3((P.M + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB), dim3(64 * FT_SEARCH_WPB), 0, st, F, P, C, th, nnRatio, res, raw);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
@@ -1067,7 +1071,7 @@ int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocal
 int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
                           const FtPose &Tcw, float th, int forward, int backward, int *res, const FtLastRaw &raw) {
     if (L.N <= 0) return FT_OK;
-    hipLaunchKernelGGL(k_search_last, dim3((L.N + 3) / 4), dim3(256), 0, st, F, L, C, Tcw, th, forward, backward, res, raw);
+    hipLaunchKernelGGL(k_search_last, dim3((L.N + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB), dim3(64 * FT_SEARCH_WPB), 0, st, F, L, C, Tcw, th, forward, backward, res, raw);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

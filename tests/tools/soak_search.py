@@ -73,6 +73,8 @@ def main():
             print(f"MISMATCH trial {trial} {tag}: {what}", flush=True)
 
     for t in range(args.trials):
+        # every third trial runs the claim iteration in its persistent one-launch form (option search_persistent; read per call)
+        ctx.set_option("search_persistent", 1 if t % 3 == 2 else 0)
         w, h = sizes[int(rng.integers(0, len(sizes)))]
         nf = int(rng.integers(300, 2001))
         seed = int(rng.integers(0, 1 << 30))
@@ -168,7 +170,14 @@ def main():
         matched += o1["n"] + o2["n"]
         if (t + 1) % 50 == 0:
             print(f"trial {t + 1}: {searches} searches, {matched} matches, {fails} mismatches, {time.time() - t0:.0f} s", flush=True)
-    print(f"{args.trials} trials, {searches} searches, {matched} matches, {fails} mismatches, {time.time() - t0:.0f} s")
+    def calls(name):
+        try:
+            return ctx.get_stat(name)[1]
+        except Exception:
+            return 0
+    print(f"{args.trials} trials, {searches} searches, {matched} matches, {fails} mismatches, {time.time() - t0:.0f} s; "
+          f"persistent launches {calls('search.persistent_launches')}, timeouts {calls('search.persistent_timeouts')}, "
+          f"fallbacks {calls('search.persistent_fallbacks')}")
     return 1 if fails else 0
 
 
