@@ -789,7 +789,6 @@ __global__ __launch_bounds__(64, FC_WAVES_PER_EU) void k_fast_cells(FtGeom g, co
     const int scoreBytes = TP ? ((ph + 2) * TP + 15) & ~15 : fc_score_bytes(g.lv[level].wCell, g.lv[level].hCell, 0);
     unsigned short *cand = (unsigned short *)(score + (TP ? scoreBytesMax : scoreBytes));
     unsigned short *corn = cand + FC_CAND;
-    uint8_t *surv = tile;
     const int pitch = level ? (int)(lv & 0xffffu) : l0pitch;
     // pixel (iniX, iniY) of the level
     const uint8_t *org = level ? pyr + ((size_t)slot * g.pyrPerSlot + rec.srcOff) : img0 + ((size_t)iniY * l0pitch + iniX);
@@ -1224,34 +1223,38 @@ __global__ __launch_bounds__(64, FC_WAVES_PER_EU) void k_fast_cells(FtGeom g, co
         for (int q = 0; q < FC_NMS_REG; q++)
             if (q * 64 < nItems) emit(fl[q], px[q], need);
     } else {
-        // more corners than the registers hold flags for (dense frames): the verdicts of the first pass wait in LDS - the
-        // tile is dead by now - for the threshold decision, instead of being computed twice (nine reads and a max tree each)
-        int anyHi = 0;
+        // More corners than the registers hold flags for (dense frames).  The threshold decision needs to know whether ANY
+        // survivor reaches iniThFAST before the first one is emitted; round 3 computed every verdict, parked it in LDS and walked
+        // the list a second time.  Now: a cell whose best corner is below iniThFAST cannot have such a survivor, and one whose
+        // best corner reaches it nearly always has (only ties between neighbouring maxima can take them all out) - so the
+        // decision is taken from the maximum score (one read per corner), the verdicts are computed and emitted in ONE walk,
+        // and the rare cell where the strong corners all fell to ties is walked again for the weak ones.
+        auto itemPix = [&](int it) -> int {
+            if (useList) return (int)corn[it];
+            const unsigned mg = TP ? div_magic_of((unsigned)pw) : pwMagic;
+            const int y = div_by(it, mg);
+            return pixCode(y, it - y * pw);
+        };
+        unsigned mx = 0;
         for (int base = 0; base < nItems; base += 64) {
-            const int it = base + lane;
-            int fl = 0, pix;
-            if (it < nItems) {
-                fl = nms(it, pix);
-                surv[it] = (uint8_t)fl;
-            }
-            anyHi |= __any(fl == 2);
+            const int pix = itemPix(min(base + lane, nItems - 1));
+            const int y = pixY(pix), x = pixX(pix, y);
+            mx = max(mx, (unsigned)score[(y + 1) * tp + (x + 1)]);
         }
-        wave_lds_sync();
-        const int need = anyHi ? 2 : 1;
-        for (int base = 0; base < nItems; base += 64) {
-            const int it = base + lane;
-            int fl = 0, pix = 0;
-            if (it < nItems) {
-                fl = surv[it];
-                if (useList) {
-                    pix = (int)corn[it];
-                } else {
-                    const unsigned mg = TP ? div_magic_of((unsigned)pw) : pwMagic;
-                    const int y = div_by(it, mg);
-                    pix = pixCode(y, it - y * pw);
-                }
+        int need = __any(mx >= (unsigned)iniTh) ? 2 : 1;
+        for (;;) {
+            int anyHi = 0;
+            run = 0;
+            for (int base = 0; base < nItems; base += 64) {
+                const int it = base + lane;
+                int pix = 0;
+                const int f = nms(min(it, nItems - 1), pix);
+                const int fl = it < nItems ? f : 0;
+                anyHi |= __any(fl == 2);
+                emit(fl, pix, need);
             }
-            emit(fl, pix, need);
+            if (need == 1 || anyHi) break;  // wave-uniform
+            need = 1;                       // every strong corner lost a tie: the cell emits its weak survivors
         }
     }
     if (lane == 0) *cnt = min(run, cellCap);
