@@ -121,7 +121,8 @@ FT_API int ft_context_reset_stats(ft_context *ctx);
 /* device memory helpers so that a caller (or bench.py) can keep frames resident in HBM */
 FT_API int ft_device_malloc(ft_context *ctx, size_t bytes, void **dptr);
 FT_API int ft_device_free(ft_context *ctx, void *dptr);
-/* pinned host memory: result arrays allocated here are filled by the device copies directly */
+/* pinned host memory: result arrays allocated here are filled by the device copies directly.  A block is released by
+ * ft_host_free, or with its context: ft_context_destroy frees what is still allocated (do not use such a block afterwards). */
 FT_API int ft_host_malloc(ft_context *ctx, size_t bytes, void **ptr);
 FT_API int ft_host_free(ft_context *ctx, void *ptr);
 FT_API int ft_memcpy_h2d(ft_context *ctx, void *dst, const void *src, size_t bytes);
