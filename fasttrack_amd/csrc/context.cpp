@@ -263,7 +263,7 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
         // searched with 10 queues (tools/lane_search.py): on 1280x720 / 512 pairs, and on 752x480 / 512 pairs for the small class
         // (climbed again at the end of round 3, when the octree tier had become short: two entries moved, +0.7 % on the
         // headline scenes, +1.1 % on dense ones)
-        ctx->laneMap = {1, 2, 7, 4, 5, 3, 3, 1, 1, 4, 3, 2, 1, 1, 4, 6};  // (round 4: two entries moved by another climb, +0.7 %; gpurun_out/r04_lanes)
+        ctx->laneMap = {1, 2, 7, 4, 5, 3, 3, 1, 1, 4, 3, 2, 1, 1, 4, 3};  // (round 4: three entries moved by two more climbs, +0.7 % and +0.5 %; profiles/r04_lane_search.txt)
         ctx->laneMapSmall = FT_LANE_MAP_SMALL;
     } else ctx->laneMap.clear();  // the runtime's default of four queues: private streams, placed by the runtime (66 k frames/s on the headline
                                 // workload; a lane per stage shared by the cameras and front ends - {0,1,2,3} for everyone - ran 55 k)
