@@ -515,6 +515,8 @@ struct ft_tracked_frame {
     int *d_grid = nullptr;                         // Frame::mGrid as CSR (both cameras), built when a frame is loaded
     uint8_t *d_work = nullptr, *h_work = nullptr;  // per-call arena (points, passes, outputs) and its pinned mirror
     int *h_holderUp = nullptr;                       // pinned source of the holder_obs uploads (see uploadHolder)
+    uint8_t *h_frameUp = nullptr;                    // pinned staging of ft_tracked_frame_upload (all arrays of a frame)
+    size_t frameUpBytes = 0;
     size_t workBytes = 0;
     // current frame
     bool loaded = false;
@@ -871,6 +873,8 @@ int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, 
     if (e == hipSuccess && searchCacheOn(ctx)) e = hipMalloc((void **)&tf->d_cache, searchCacheBytes(max_points));
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_work, tf->workBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_holderUp, sizeof(int) * K, hipHostMallocDefault);
+    tf->frameUpBytes = (2 * sizeof(ft_keypoint) + 32 + 4 * sizeof(int)) * K + 8 * 64;
+    if (e == hipSuccess) e = hipHostMalloc((void **)&tf->h_frameUp, tf->frameUpBytes, hipHostMallocDefault);
     if (e != hipSuccess) {
         ft_tracked_frame_destroy(tf);
         return ft_hip_fail(e, "ft_tracked_frame_create", __FILE__, __LINE__);
@@ -890,6 +894,7 @@ int ft_tracked_frame_destroy(ft_tracked_frame *tf) {
     if (tf->d_cache) hipFree(tf->d_cache);
     if (tf->h_work) hipHostFree(tf->h_work);
     if (tf->h_holderUp) hipHostFree(tf->h_holderUp);
+    if (tf->h_frameUp) hipHostFree(tf->h_frameUp);
     if (tf->counted) tf->ctx->liveObjects--;
     delete tf;
     return FT_OK;
@@ -905,16 +910,30 @@ int ft_tracked_frame_upload(ft_tracked_frame *tf, const ft_frame_view *F) {
     std::lock_guard<std::mutex> lk(tf->ctx->matchMutex);
     hipStream_t st = tf->ctx->stream;
     const int nL = F->Nleft == -1 ? F->N : F->Nleft, nR = F->Nleft == -1 ? 0 : F->N - F->Nleft;
-    // pageable sources: the copies are staged by the runtime and complete before the call returns
-    if (nL) FT_HIP(hipMemcpyAsync(tf->d_keys, F->keys, sizeof(ft_keypoint) * nL, hipMemcpyHostToDevice, st));
-    if (nR) FT_HIP(hipMemcpyAsync(tf->d_keysR, F->keys_right, sizeof(ft_keypoint) * nR, hipMemcpyHostToDevice, st));
-    if (F->N) FT_HIP(hipMemcpyAsync(tf->d_desc, F->descriptors, (size_t)32 * F->N, hipMemcpyHostToDevice, st));
-    if (F->uright && F->N) FT_HIP(hipMemcpyAsync(tf->d_uright, F->uright, sizeof(float) * F->N, hipMemcpyHostToDevice, st));
-    if (F->Nleft != -1) {
-        if (nL) FT_HIP(hipMemcpyAsync(tf->d_l2r, F->left_to_right, sizeof(int) * nL, hipMemcpyHostToDevice, st));
-        if (nR) FT_HIP(hipMemcpyAsync(tf->d_r2l, F->right_to_left, sizeof(int) * nR, hipMemcpyHostToDevice, st));
+    // The caller's arrays are pageable as a rule: handed to hipMemcpyAsync as they are, each of the seven copies is staged by
+    // the runtime and waited for (70 - 85 us per frame).  They are packed into the frame's own pinned buffer instead (one
+    // pass of host memcpy) and go up from there as plain asynchronous copies; nothing is waited for here - the searches that
+    // follow are ordered behind the copies on the stream, and the next upload waits for the stream before it repacks.
+    FT_HIP(hipStreamSynchronize(st));
+    {
+        Arena up;
+        auto put = [&](void *dst, const void *src, size_t bytes) -> int {
+            if (!bytes) return FT_OK;
+            const size_t o = up.take(bytes);
+            memcpy(tf->h_frameUp + o, src, bytes);
+            FT_HIP(hipMemcpyAsync(dst, tf->h_frameUp + o, bytes, hipMemcpyHostToDevice, st));
+            return FT_OK;
+        };
+        if ((rc = put(tf->d_keys, F->keys, sizeof(ft_keypoint) * nL)) != FT_OK) return rc;
+        if ((rc = put(tf->d_keysR, F->keys_right, sizeof(ft_keypoint) * nR)) != FT_OK) return rc;
+        if ((rc = put(tf->d_desc, F->descriptors, (size_t)32 * F->N)) != FT_OK) return rc;
+        if (F->uright && (rc = put(tf->d_uright, F->uright, sizeof(float) * F->N)) != FT_OK) return rc;
+        if (F->Nleft != -1) {
+            if ((rc = put(tf->d_l2r, F->left_to_right, sizeof(int) * nL)) != FT_OK) return rc;
+            if ((rc = put(tf->d_r2l, F->right_to_left, sizeof(int) * nR)) != FT_OK) return rc;
+        }
+        if ((rc = put(tf->d_holder, F->holder_obs, sizeof(int) * F->N)) != FT_OK) return rc;
     }
-    if (F->N) FT_HIP(hipMemcpyAsync(tf->d_holder, F->holder_obs, sizeof(int) * F->N, hipMemcpyHostToDevice, st));
     tf->DF = devFrameConstants(F);
     tf->DF.keys = tf->d_keys;
     tf->DF.keysR = tf->d_keysR;
@@ -925,7 +944,6 @@ int ft_tracked_frame_upload(ft_tracked_frame *tf, const ft_frame_view *F) {
     tf->DF.r2l = F->Nleft != -1 ? tf->d_r2l : nullptr;
     rc = buildGrid(tf->ctx, st, tf->DF, tf->d_grid);  // the grid of the frame, once: both searches look up their windows in it
     if (rc != FT_OK) return rc;
-    FT_HIP(hipStreamSynchronize(st));
     tf->angles.resize(F->N);
     for (int i = 0; i < nL; i++) tf->angles[i] = F->keys[i].angle;
     for (int i = 0; i < nR; i++) tf->angles[nL + i] = F->keys_right[i].angle;
