@@ -736,13 +736,24 @@ int ft_fisheye_match(ft_context *ctx, const uint8_t *descL, int nL, const uint8_
     // layout in the context's grow-only scratch: descL | descR | matches, best, second
     const size_t oL = 0, oR = (((size_t)32 * nL) + 63) & ~(size_t)63, oOut = oR + ((((size_t)32 * std::max(nR, 1)) + 63) & ~(size_t)63);
     const size_t total = oOut + sizeof(int) * 3 * (size_t)nL;
-    rc = ft_ensure_scratch(ctx, total, sizeof(int) * 3 * (size_t)nL);
+    rc = ft_ensure_scratch(ctx, total, total);
     if (rc != FT_OK) return rc;
-    uint8_t *dev = (uint8_t *)ctx->scratchDev;
-    int *dOut = (int *)(dev + oOut), *hOut = (int *)ctx->scratchPin;
+    uint8_t *dev = (uint8_t *)ctx->scratchDev, *pin = (uint8_t *)ctx->scratchPin;
+    int *dOut = (int *)(dev + oOut), *hOut = (int *)(pin + oOut);
     hipStream_t st = ctx->stream;
-    FT_HIP(hipMemcpyAsync(dev + oL, descL, (size_t)32 * nL, hipMemcpyHostToDevice, st));
-    if (nR > 0) FT_HIP(hipMemcpyAsync(dev + oR, descR, (size_t)32 * nR, hipMemcpyHostToDevice, st));
+    // pageable descriptors go up through the context's pinned scratch (one host memcpy each) instead of being staged and
+    // waited for by the runtime copy by copy; descriptors the caller keeps in pinned memory are read where they are
+    auto up = [&](size_t off, const uint8_t *src, size_t bytes) -> int {
+        const uint8_t *from = src;
+        if (!ft_is_pinned_host_range(src, bytes)) {
+            memcpy(pin + off, src, bytes);
+            from = pin + off;
+        }
+        FT_HIP(hipMemcpyAsync(dev + off, from, bytes, hipMemcpyHostToDevice, st));
+        return FT_OK;
+    };
+    if ((rc = up(oL, descL, (size_t)32 * nL)) != FT_OK) return rc;
+    if (nR > 0 && (rc = up(oR, descR, (size_t)32 * nR)) != FT_OK) return rc;
     rc = ft_launch_fisheye(st, dev + oL, nL, dev + oR, nR, dOut, dOut + nL, dOut + 2 * (size_t)nL);
     if (rc != FT_OK) return rc;
     FT_HIP(hipMemcpyAsync(hOut, dOut, sizeof(int) * 3 * (size_t)nL, hipMemcpyDeviceToHost, st));
