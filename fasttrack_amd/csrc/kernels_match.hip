@@ -129,13 +129,13 @@ __global__ __launch_bounds__(256) void k_stereo_match(FtGeom g, const uint8_t *c
                 unsigned *ldsL = sadBuf[wave], *ldsR = ldsL + 44;  // right rows at a pitch of 7 dwords (the last one: padding)
                 {
                     const int rl = lane >> 2, dl = lane & 3;  // lanes 0 .. 43
-                    const unsigned vL = gload<unsigned>(imL + (size_t)(yl0 + min(rl, 10)) * pitchL + xl0a + 4 * dl);
+                    const unsigned vL = gload<unsigned>(imL + (unsigned)((yl0 + min(rl, 10)) * pitchL + xl0a + 4 * dl));  // (scalar base + 32-bit lane offset)
                     const int rr0 = (lane * 43) >> 8, dr0 = lane - 6 * rr0;  // lane / 6 for lane < 64: rows 0 .. 10
-                    const unsigned vR0 = gload<unsigned>(imR + (size_t)(yl0 + rr0) * pitchR + xr0a + 4 * dr0);
+                    const unsigned vR0 = gload<unsigned>(imR + (unsigned)((yl0 + rr0) * pitchR + xr0a + 4 * dr0));
                     // dwords 64, 65 (row 10, dwords 4, 5) and the padding dword of every row: lanes 0 .. 12
                     const int i1 = lane < 2 ? 64 + lane : 0;
-                    const unsigned vR1 = gload<unsigned>(imR + (size_t)(yl0 + (lane < 2 ? 10 : min(lane - 2, 10))) * pitchR + xr0a +
-                                                         (lane < 2 ? 4 * (4 + lane) : 24));
+                    const unsigned vR1 = gload<unsigned>(imR + (unsigned)((yl0 + (lane < 2 ? 10 : min(lane - 2, 10))) * pitchR + xr0a +
+                                                                    (lane < 2 ? 4 * (4 + lane) : 24)));
                     if (lane < 44) ldsL[lane] = vL;
                     ldsR[rr0 * 7 + dr0] = vR0;
                     if (lane < 2) ldsR[10 * 7 + (i1 - 60)] = vR1;

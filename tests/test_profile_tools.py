@@ -8,11 +8,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_traffic_json_follows_from_the_rocprof_summary(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("tag", ["r02", "r04"])
+def test_traffic_json_follows_from_the_rocprof_summary(tmp_path, tag):
     out = tmp_path / "t.json"
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_from_profile.py"),
-                    os.path.join(ROOT, "profiles", "r02_rocprof_summary.txt"), str(out), "--steps", "7"], check=True, capture_output=True)
-    new, old = json.load(open(out)), json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+                    os.path.join(ROOT, "profiles", tag + "_rocprof_summary.txt"), str(out), "--steps", "7"], check=True, capture_output=True)
+    new, old = json.load(open(out)), json.load(open(os.path.join(ROOT, "profiles", tag + "_traffic.json")))
     assert new["kernels"] == old["kernels"] and new["batch_pairs"] == old["batch_pairs"] == 512 and old["distinct_pairs"] == 512
     f = new["kernels"]["k_fast_cells"]
     assert f["fetch_factor"] == 2.0 and f["images_per_launch"] == 256.0
@@ -22,9 +26,10 @@ def test_traffic_json_follows_from_the_rocprof_summary(tmp_path):
     assert 0.5 < f["valu_issue_frac"] < 1.0 and f["valu_per_wave"] > 500 and f["salu_per_wave"] > 100
 
 
-def test_bench_line_reports_the_committed_traffic():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_line.json")))
-    t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))["kernels"]["k_fast_cells"]
+@pytest.mark.parametrize("tag", ["r02", "r04"])
+def test_bench_line_reports_the_committed_traffic(tag):
+    d = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_line.json")))
+    t = json.load(open(os.path.join(ROOT, "profiles", tag + "_traffic.json")))["kernels"]["k_fast_cells"]
     r = d["roofline"]
     assert r["kernel"] == "k_fast_cells" and r["bound"] == "hbm" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
