@@ -2076,7 +2076,10 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
     for (int level = 1; level < g.nlevels; level++) {
         const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
         // two levels per pass (k_pyr_rows2): this level and the next one, when both take the row-streaming bilinear path
-        if (rowsKernel >= 2 && batch >= 8 && alignedLoads && level + 1 < g.nlevels && pyr_rows_fits(g, level) &&
+        // (rowsKernel 2: every pair of levels; 10 + k: pairs from level k upwards only - the small levels, whose launches do not
+        // fill the chip)
+        const int fuseFrom = rowsKernel >= 10 ? rowsKernel - 10 : (rowsKernel >= 2 ? 1 : FT_MAX_LEVELS);
+        if (level >= fuseFrom && batch >= 8 && alignedLoads && level + 1 < g.nlevels && pyr_rows_fits(g, level) &&
             pyr_rows_fits(g, level + 1) && !D.area2x && !g.lv[level + 1].area2x && D.w >= 16 && D.h >= 2) {
             const int stripsX = (D.w + PR2_CSTEP - 1) / PR2_CSTEP, stripsY = (D.h + PR2_RSTEP - 1) / PR2_RSTEP;
             dim3 grid, block(64, 1, 1);
