@@ -422,7 +422,9 @@ FT_API int ft_is_in_frustum(ft_context *ctx, const ft_frame_view *F, const ft_fr
 typedef struct ft_tracked_frame ft_tracked_frame;
 FT_API int ft_tracked_frame_create(ft_context *ctx, int max_keypoints, int max_points, ft_tracked_frame **out);
 FT_API int ft_tracked_frame_destroy(ft_tracked_frame *tf);
-/* copies keys / descriptors / uright / match tables / holder_obs of F to the device */
+/* copies keys / descriptors / uright / match tables / holder_obs of F to the device and builds its grid.  The arrays of F are
+ * read before the call returns (packed into pinned staging of the frame); the device copies and the grid are ordered in front of
+ * the searches that follow on the context's stream, the call itself does not wait for them. */
 FT_API int ft_tracked_frame_upload(ft_tracked_frame *tf, const ft_frame_view *F);
 /* pair `slot` of the batch the front end processed last (rectified stereo, Nleft == -1): keypoints, descriptors
  * and mvuRight are used where ft_stereo_frontend_* left them in HBM.  meta supplies the frame constants and
