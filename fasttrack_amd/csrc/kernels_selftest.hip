@@ -4,7 +4,9 @@
 // reference evaluates those on the host (/root/reference/src/ORBextractor.cc:73-74, src/MapPoint.cc:539).  Bit-exact
 // agreement with a reference binary therefore depends on the host libm being the glibc algorithm; a deployment on another
 // libc (musl, a vendor libm) can run this sweep once to find out.  The device evaluates the functions over a range of float
-// bit patterns, the host compares with its own cosf / sinf / logf.
+// bit patterns, the host compares with its own cosf / sinf / logf.  The same for atanf / atan2f of the KannalaBrandt8
+// projection (src/CameraModels/KannalaBrandt8.cpp:67-84); atan2f(y, x) sweeps y and pairs every y with one x derived from
+// its bits (pair_x: either sign, 2^-9 <= |x| < 2^7 - ray coordinates).
 #include <math.h>
 #include <string.h>
 
@@ -17,11 +19,24 @@
 
 namespace {
 
+__host__ __device__ inline float pair_x(uint32_t ybits) {
+    uint32_t h = ybits * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    const uint32_t bits = (h & 0x807fffffu) | ((118u + ((h >> 24) & 15u)) << 23);
+    return __builtin_bit_cast(float, bits);
+}
+
 __global__ __launch_bounds__(256) void k_libm_sweep(int func, uint32_t first, uint32_t stride, uint32_t n, float *out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const float x = __uint_as_float(first + i * stride);
-    out[i] = func == 0 ? ft_libm::cosf_glibc(x) : func == 1 ? ft_libm::sinf_glibc(x) : ft_libm::logf_glibc(x);
+    out[i] = func == 0   ? ft_libm::cosf_glibc(x)
+             : func == 1 ? ft_libm::sinf_glibc(x)
+             : func == 2 ? ft_libm::logf_glibc(x)
+             : func == 3 ? ft_libm::atanf_glibc(x)
+                         : ft_libm::atan2f_glibc(x, pair_x(first + i * stride));
 }
 
 float host_eval(int func, float x) {
@@ -29,14 +44,16 @@ float host_eval(int func, float x) {
     static float (*volatile fc)(float) = cosf;
     static float (*volatile fs)(float) = sinf;
     static float (*volatile fl)(float) = logf;
-    return func == 0 ? fc(x) : func == 1 ? fs(x) : fl(x);
+    static float (*volatile fa)(float) = atanf;
+    static float (*volatile fa2)(float, float) = atan2f;
+    return func == 0 ? fc(x) : func == 1 ? fs(x) : func == 2 ? fl(x) : func == 3 ? fa(x) : fa2(x, pair_x(__builtin_bit_cast(uint32_t, x)));
 }
 
 }  // namespace
 
 extern "C" FT_API int ft_selftest_libm(ft_context *ctx, int func, uint32_t first_bits, uint32_t last_bits, uint32_t stride,
                                        unsigned long long *checked, unsigned long long *mismatches, uint32_t *first_bad) {
-    if (!ctx || func < 0 || func > 2 || stride == 0 || last_bits < first_bits || !checked || !mismatches) {
+    if (!ctx || func < 0 || func > 4 || stride == 0 || last_bits < first_bits || !checked || !mismatches) {
         ft_set_error("ft_selftest_libm: bad arguments");
         return FT_ERR_INVALID;
     }

@@ -146,4 +146,117 @@ FT_LM_HD float logf_glibc(float x) {
     return (float)y;
 }
 
+
+// ---- atanf / atan2f --------------------------------------------------------------------------------------------------
+// glibc 2.35 still ships the fdlibm single-precision routines for these (sysdeps/ieee754/flt-32/s_atanf.c, e_atan2f.c; the
+// x86-64 multiarch directory has no FMA variant of them): sequences of float operations, each rounded on its own - so the
+// restatement below must not be contracted (host: -ffp-contract=off; device: the __f*_rn intrinsics) and its division must be
+// correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt).  Used by KannalaBrandt8::project
+// (/root/reference/src/CameraModels/KannalaBrandt8.cpp:67-84: theta = atan2f(sqrtf(x^2 + y^2), z), psi = atan2f(y, x)).
+// Checked against the host: tests/cpp/test_libm_f32.cpp (atanf on EVERY float, atan2f on the signs / special cases and 2^31
+// random pairs), and on the device through ft_selftest_libm.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FT_LM_MUL(a, b) __fmul_rn(a, b)
+#define FT_LM_ADD(a, b) __fadd_rn(a, b)
+#define FT_LM_SUB(a, b) __fsub_rn(a, b)
+#define FT_LM_DIV(a, b) __fdiv_rn(a, b)
+#else
+#define FT_LM_MUL(a, b) ((a) * (b))
+#define FT_LM_ADD(a, b) ((a) + (b))
+#define FT_LM_SUB(a, b) ((a) - (b))
+#define FT_LM_DIV(a, b) ((a) / (b))
+#endif
+
+FT_LM_HD float atanf_glibc(float x) {
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT[11] = {3.3333334327e-01f,  -2.0000000298e-01f, 1.4285714924e-01f,  -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                          6.6610731184e-02f,  -5.8335702866e-02f, 4.9768779427e-02f,  -3.6531571299e-02f, 1.6285819933e-02f};
+    const int32_t hx = (int32_t)f32_bits(x), ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {  // |x| >= 2^25
+        if (ix > 0x7f800000) return FT_LM_ADD(x, x);  // NaN
+        const float r = FT_LM_ADD(atanhi[3], atanlo[3]);
+        return hx > 0 ? r : -r;
+    }
+    if (ix < 0x3ee00000) {  // |x| < 0.4375
+        if (ix < 0x31000000) return x;  // |x| < 2^-29
+        id = -1;
+    } else {
+        x = __builtin_fabsf(x);
+        if (ix < 0x3f980000) {      // |x| < 1.1875
+            if (ix < 0x3f300000) {  // 7/16 <= |x| < 11/16
+                id = 0;
+                x = FT_LM_DIV(FT_LM_SUB(FT_LM_MUL(2.0f, x), 1.0f), FT_LM_ADD(2.0f, x));
+            } else {  // 11/16 <= |x| < 19/16
+                id = 1;
+                x = FT_LM_DIV(FT_LM_SUB(x, 1.0f), FT_LM_ADD(x, 1.0f));
+            }
+        } else {
+            if (ix < 0x401c0000) {  // |x| < 2.4375
+                id = 2;
+                x = FT_LM_DIV(FT_LM_SUB(x, 1.5f), FT_LM_ADD(1.0f, FT_LM_MUL(1.5f, x)));
+            } else {  // 2.4375 <= |x| < 2^25
+                id = 3;
+                x = FT_LM_DIV(-1.0f, x);
+            }
+        }
+    }
+    const float z = FT_LM_MUL(x, x), w = FT_LM_MUL(z, z);
+    // the sum of aT[i] z^(i+1) split into its odd and even terms
+    float s1 = FT_LM_ADD(aT[8], FT_LM_MUL(w, aT[10]));
+    s1 = FT_LM_ADD(aT[6], FT_LM_MUL(w, s1));
+    s1 = FT_LM_ADD(aT[4], FT_LM_MUL(w, s1));
+    s1 = FT_LM_ADD(aT[2], FT_LM_MUL(w, s1));
+    s1 = FT_LM_MUL(z, FT_LM_ADD(aT[0], FT_LM_MUL(w, s1)));
+    float s2 = FT_LM_ADD(aT[7], FT_LM_MUL(w, aT[9]));
+    s2 = FT_LM_ADD(aT[5], FT_LM_MUL(w, s2));
+    s2 = FT_LM_ADD(aT[3], FT_LM_MUL(w, s2));
+    s2 = FT_LM_MUL(w, FT_LM_ADD(aT[1], FT_LM_MUL(w, s2)));
+    if (id < 0) return FT_LM_SUB(x, FT_LM_MUL(x, FT_LM_ADD(s1, s2)));
+    const float zz = FT_LM_SUB(atanhi[id], FT_LM_SUB(FT_LM_SUB(FT_LM_MUL(x, FT_LM_ADD(s1, s2)), atanlo[id]), x));
+    return hx < 0 ? -zz : zz;
+}
+
+FT_LM_HD float atan2f_glibc(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)f32_bits(x), hy = (int32_t)f32_bits(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return FT_LM_ADD(x, y);  // NaN
+    if (hx == 0x3f800000) return atanf_glibc(y);                     // x = 1.0
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);               // 2 * sign(x) + sign(y)
+    if (iy == 0) {                                                   // y = 0
+        if (m < 2) return y;
+        return m == 2 ? FT_LM_ADD(pi, tiny) : FT_LM_SUB(-pi, tiny);
+    }
+    if (ix == 0) return hy < 0 ? FT_LM_SUB(-pi_o_2, tiny) : FT_LM_ADD(pi_o_2, tiny);  // x = 0
+    if (ix == 0x7f800000) {                                                             // x = +-inf
+        if (iy == 0x7f800000) {
+            switch (m) {
+                case 0: return FT_LM_ADD(pi_o_4, tiny);
+                case 1: return FT_LM_SUB(-pi_o_4, tiny);
+                case 2: return FT_LM_ADD(FT_LM_MUL(3.0f, pi_o_4), tiny);
+                default: return FT_LM_SUB(FT_LM_MUL(-3.0f, pi_o_4), tiny);
+            }
+        }
+        switch (m) {
+            case 0: return 0.0f;
+            case 1: return -0.0f;
+            case 2: return FT_LM_ADD(pi, tiny);
+            default: return FT_LM_SUB(-pi, tiny);
+        }
+    }
+    if (iy == 0x7f800000) return hy < 0 ? FT_LM_SUB(-pi_o_2, tiny) : FT_LM_ADD(pi_o_2, tiny);  // y = +-inf
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = FT_LM_ADD(pi_o_2, FT_LM_MUL(0.5f, pi_lo));  // |y / x| > 2^60
+    else if (hx < 0 && k < -60) z = 0.0f;                       // |y| / x < -2^60
+    else z = atanf_glibc(__builtin_fabsf(FT_LM_DIV(y, x)));
+    switch (m) {
+        case 0: return z;
+        case 1: return bits_f32(f32_bits(z) ^ 0x80000000u);
+        case 2: return FT_LM_SUB(pi, FT_LM_SUB(z, pi_lo));
+        default: return FT_LM_SUB(FT_LM_SUB(z, pi_lo), pi);
+    }
+}
+
 }  // namespace ft_libm

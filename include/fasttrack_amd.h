@@ -452,9 +452,11 @@ FT_API int ft_descriptor_distance(ft_context *ctx, const uint8_t *a, const uint8
 /* Host-libm self test.  The rBRIEF rotation (src/ORBextractor.cc:73-74: std::cos(float), std::sin(float)) and
  * MapPoint::PredictScale (src/MapPoint.cc:539: std::log(float)) are evaluated by the reference with the HOST libm;
  * the kernels reproduce glibc's cosf / sinf / logf bit for bit (fasttrack_amd/csrc/libm_f32.h).  This sweep evaluates
- * func (0 cosf, 1 sinf, 2 logf) on the device for the float bit patterns first_bits, first_bits + stride, ... <= last_bits
- * and compares with the cosf / sinf / logf of the calling process.  mismatches == 0 over [0, 0x40c90fdb] (cos, sin) and
- * [1, 0x461c4000] (log, up to 1e4) means the device and this host's libm agree on every argument the path can produce. */
+ * func (0 cosf, 1 sinf, 2 logf, 3 atanf, 4 atan2f) on the device for the float bit patterns first_bits, first_bits + stride,
+ * ... <= last_bits and compares with the same function of the calling process's libm.  mismatches == 0 over [0, 0x40c90fdb]
+ * (cos, sin) and [1, 0x461c4000] (log, up to 1e4) means the device and this host's libm agree on every argument the path can
+ * produce; atanf takes any range up to [0, 0xffffffff]; atan2f(y, x) sweeps y over the range and pairs each y with one x
+ * derived from its bits (either sign, 2^-9 <= |x| < 2^7): the KannalaBrandt8 projection of two-camera frames. */
 FT_API int ft_selftest_libm(ft_context *ctx, int func, uint32_t first_bits, uint32_t last_bits, uint32_t stride,
                             unsigned long long *checked, unsigned long long *mismatches, uint32_t *first_bad);
 

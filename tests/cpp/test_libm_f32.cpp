@@ -77,5 +77,63 @@ int main(int argc, char **argv) {
                  [&](float x) { return hlog(x); });
     bad += sweep("logf(1e4,max]", to_bits(1e4f), 0x7f7fffffu, stride * 64u, threads,
                  [](float x) { return ft_libm::logf_glibc(x); }, [&](float x) { return hlog(x); });
+    // atanf: every float (NaNs compare by kind); atan2f: the KB8 shapes and a dense random sample
+    float (*volatile hatan)(float) = atanf;
+    float (*volatile hatan2)(float, float) = atan2f;
+    {
+        std::atomic<unsigned long long> b{0}, c{0};
+        std::atomic<int> shown{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++)
+            pool.emplace_back([&, t] {
+                unsigned long long bb = 0, cc = 0;
+                for (uint64_t u = (uint64_t)t * stride; u <= 0xffffffffull; u += (uint64_t)stride * threads) {
+                    const float x = from_bits((uint32_t)u);
+                    const float m = ft_libm::atanf_glibc(x), h = hatan(x);
+                    if (to_bits(m) != to_bits(h) && !(m != m && h != h)) {
+                        bb++;
+                        if (shown.fetch_add(1) < 5) printf("  atanf(%.9g = 0x%08x): mine %.9g host %.9g\n", x, (uint32_t)u, m, h);
+                    }
+                    cc++;
+                }
+                b += bb;
+                c += cc;
+            });
+        for (auto &th : pool) th.join();
+        printf("atanf(all): checked %llu mismatches %llu\n", c.load(), b.load());
+        bad += b.load();
+    }
+    {
+        std::atomic<unsigned long long> b{0}, c{0};
+        std::atomic<int> shown{0};
+        std::vector<std::thread> pool;
+        const unsigned long long per = (1ull << 31) / stride / threads;
+        for (int t = 0; t < threads; t++)
+            pool.emplace_back([&, t] {
+                unsigned long long bb = 0, cc = 0;
+                uint64_t s = 0x9e3779b97f4a7c15ull * (t + 1);
+                auto next = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 32); };
+                for (unsigned long long i = 0; i < per; i++) {
+                    float y, x;
+                    switch (i & 3) {
+                        case 0: y = from_bits(next()); x = from_bits(next()); break;                          // any two floats
+                        case 1: y = (float)(int32_t)next() * 0x1p-20f; x = (float)(int32_t)next() * 0x1p-20f; break;  // |.| < 2048: image / ray coordinates
+                        case 2: y = std::fabs((float)(int32_t)next() * 0x1p-24f); x = (float)(int32_t)next() * 0x1p-22f; break;  // theta = atan2f(r >= 0, z)
+                        default: y = from_bits(next()); x = (i & 4) ? 1.0f : from_bits((next() & 0x80000000u) | (i & 8 ? 0x7f800000u : 0u)); break;  // x = 1, +-0, +-inf
+                    }
+                    const float m = ft_libm::atan2f_glibc(y, x), h = hatan2(y, x);
+                    if (to_bits(m) != to_bits(h) && !(m != m && h != h)) {
+                        bb++;
+                        if (shown.fetch_add(1) < 5) printf("  atan2f(%.9g, %.9g): mine %.9g host %.9g\n", y, x, m, h);
+                    }
+                    cc++;
+                }
+                b += bb;
+                c += cc;
+            });
+        for (auto &th : pool) th.join();
+        printf("atan2f(sample): checked %llu mismatches %llu\n", c.load(), b.load());
+        bad += b.load();
+    }
     return bad ? 1 : 0;
 }

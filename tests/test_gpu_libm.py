@@ -11,8 +11,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("func,first,last", [(0, 0, 0x40C90FDC), (1, 0, 0x40C90FDC), (0, 0x80000000, 0xC0C90FDC),
-                                             (1, 0x80000000, 0xC0C90FDC), (2, 1, 0x461C4000)],
-                         ids=["cosf[0,2pi]", "sinf[0,2pi]", "cosf[-2pi,0]", "sinf[-2pi,0]", "logf(0,1e4]"])
+                                             (1, 0x80000000, 0xC0C90FDC), (2, 1, 0x461C4000), (3, 0, 0xFFFFFFFF),
+                                             (4, 0x30000000, 0x4FFFFFFF), (4, 0xB0000000, 0xCFFFFFFF)],
+                         ids=["cosf[0,2pi]", "sinf[0,2pi]", "cosf[-2pi,0]", "sinf[-2pi,0]", "logf(0,1e4]", "atanf(all)",
+                              "atan2f(y>0)", "atan2f(y<0)"])
 def test_device_libm_equals_host_libm_exhaustively(func, first, last):
     ctx = orb.Context(0)
     L = _capi.lib()

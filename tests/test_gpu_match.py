@@ -415,8 +415,8 @@ def test_search_last_frame_pinhole(ctx, th, fwd, bwd, ori, search_form):
 
 
 def test_search_last_frame_two_cameras_kb8(ctx, search_form):
-    """fisheye stereo (config 4): KannalaBrandt8 projection, right-camera search through Trl.  Projection
-    uses libm atan2f/cosf/sinf on the host and OCML on the device: indices must agree, floats within 1e-4."""
+    """fisheye stereo (config 4): KannalaBrandt8 projection (atan2f / cosf / sinf as glibc evaluates them, libm_f32.h),
+    right-camera search through Trl: assignments, distances and indices equal the oracle's."""
     w, h, nf = 512, 512, 1500
     fr = sc.fisheye_frame_scenario(w, h, nf, 10)
     sf, _ = ob.scale_factors(1.2, 8)
@@ -475,9 +475,9 @@ def test_is_in_frustum_pinhole_bit_exact(ctx):
 
 def test_is_in_frustum_two_cameras_kb8(ctx):
     """fisheye stereo (Nleft != -1): both cameras through isInFrustumChecks, right camera pose composed from Trl / Tlr.
-    KannalaBrandt8 uses atan2f/cosf/sinf (libm on the host; evaluated in double and narrowed on the device,
-    kb8_math.h): flags and levels must agree away from decision boundaries, projections within 1e-4 px
-    (north_star's tolerance for floats)."""
+    KannalaBrandt8::project uses atan2f / cosf / sinf of the host libm; the device evaluates glibc's algorithms for the
+    three (libm_f32.h, checked against the host on every argument), so every flag, level and float equals the oracle's
+    bit for bit - as for the pinhole model."""
     w, h = 512, 512
     fr = sc.fisheye_frame_scenario(w, h, 1500, 10)
     sf, _ = ob.scale_factors(1.2, 8)
@@ -487,20 +487,18 @@ def test_is_in_frustum_two_cameras_kb8(ctx):
               bounds=sc.frame_bounds(w, h), left_to_right=fr["l2r"], right_to_left=fr["r2l"], cam_model=1, cam=cam, Trl=Trl)
     oF, gF = ob.FrameView(scale_factors_=sf, **kw), orb.FrameView(scale_factors=sf, **kw)
     intr = dict(fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
-    pts, Rcw, tcw = sc.map_points_scenario(fr["kL"], fr["dL"], np.zeros(len(fr["kL"]), np.float32), intr, 8, sf, 77)
     tlr = (0.1, 0.0, 0.0)
-    o = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, tlr), pts, 0.5, LOG_SF)
-    g = orb.is_in_frustum(ctx, gF, orb.make_pose(Rcw, tcw, tlr), pts, 0.5, LOG_SF)
-    assert o["in_view"].sum() > 200 and o["in_view_r"].sum() > 200 and (o["in_view"] != o["in_view_r"]).sum() > 5
-    same = (g["in_view"] == o["in_view"]) & (g["in_view_r"] == o["in_view_r"])
-    assert same.mean() > 0.999, "flags differ on more than boundary cases"
-    assert abs(g["n"] - o["n"]) <= (~same).sum()
-    for k in ("level", "level_r"):
-        assert np.array_equal(g[k][same], o[k][same]), k
-    for k in ("proj_x", "proj_y", "proj_xr", "proj_yr"):
-        assert np.allclose(g[k][same], o[k][same], rtol=0, atol=1e-4), k
-    for k in ("view_cos", "view_cos_r", "depth", "depth_r"):
-        assert np.array_equal(g[k][same], o[k][same]), k  # no transcendental on these paths
+    differ = 0
+    for seed in (77, 78, 79):
+        pts, Rcw, tcw = sc.map_points_scenario(fr["kL"], fr["dL"], np.zeros(len(fr["kL"]), np.float32), intr, 8, sf, seed)
+        o = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, tlr), pts, 0.5, LOG_SF)
+        g = orb.is_in_frustum(ctx, gF, orb.make_pose(Rcw, tcw, tlr), pts, 0.5, LOG_SF)
+        assert o["in_view"].sum() > 200 and o["in_view_r"].sum() > 200
+        differ += int((o["in_view"] != o["in_view_r"]).sum())
+        assert g["n"] == o["n"]
+        for k, _ in ob.FRUSTUM_FIELDS:
+            assert np.array_equal(g[k], o[k]), (seed, k)
+    assert differ > 5  # the two cameras do not see the same set
 
 
 def _oracle_tracking_sequence(oF, last, Tcw_last, pts, Rcw, tcw, th_last, th_local, far, th_far):

@@ -1,6 +1,8 @@
 """The host-libm seam of the path (CPU only): the reference evaluates the rBRIEF rotation with std::cos(float) /
 std::sin(float) (/root/reference/src/ORBextractor.cc:34,73-74) and PredictScale with std::log(float)
-(/root/reference/src/MapPoint.cc:539), i.e. glibc's cosf / sinf / logf, which are not correctly rounded.
+(/root/reference/src/MapPoint.cc:539), i.e. glibc's cosf / sinf / logf, which are not correctly rounded; KannalaBrandt8::
+project adds atan2f (/root/reference/src/CameraModels/KannalaBrandt8.cpp:67-84; atanf checked on all 2^32 floats, atan2f on
+2^31 pairs).
   * fasttrack_amd/csrc/libm_f32.h (what the kernels evaluate) equals this host's libm on EVERY float the path can
     produce (tests/cpp/test_libm_f32.cpp, exhaustive, both the FMA-contracted and the plain build of glibc's source);
   * this host's libm and the oracle reproduce tests/golden/libm_rotation_glibc235.npz: 48 angles at which cosf / sinf
@@ -35,9 +37,9 @@ def test_device_restatement_equals_host_libm_on_every_float(tmp_path, contract):
     stride = "1" if (flags or not contract) else "101"
     out = subprocess.run([exe, stride, str(os.cpu_count() or 1)], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout + out.stderr
-    for fn in ("cosf", "sinf", "cosf(neg)", "sinf(neg)", "logf(0,1e4]", "logf(1e4,max]"):
+    for fn in ("cosf", "sinf", "cosf(neg)", "sinf(neg)", "logf(0,1e4]", "logf(1e4,max]", "atanf(all)", "atan2f(sample)"):
         assert f"{fn}: checked" in out.stdout
-    assert out.stdout.count("mismatches 0") == 6, out.stdout
+    assert out.stdout.count("mismatches 0") == 8, out.stdout
 
 
 def test_host_libm_and_oracle_reproduce_the_glibc_vectors(golden_dir):
