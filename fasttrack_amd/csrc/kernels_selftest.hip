@@ -6,7 +6,8 @@
 // libc (musl, a vendor libm) can run this sweep once to find out.  The device evaluates the functions over a range of float
 // bit patterns, the host compares with its own cosf / sinf / logf.  The same for atanf / atan2f of the KannalaBrandt8
 // projection (src/CameraModels/KannalaBrandt8.cpp:67-84); atan2f(y, x) sweeps y and pairs every y with one x derived from
-// its bits (pair_x: either sign, 2^-9 <= |x| < 2^7 - ray coordinates).
+// its bits (pair_x: either sign, 2^-9 <= |x| < 2^7 - ray coordinates); tanf (KannalaBrandt8::unproject, :114-143) is restated
+// for |x| < 120.
 #include <math.h>
 #include <string.h>
 
@@ -28,6 +29,12 @@ __host__ __device__ inline float pair_x(uint32_t ybits) {
     return __builtin_bit_cast(float, bits);
 }
 
+__device__ inline float tan_or_nan(float x) {
+    bool exact;
+    const float t = ft_libm::tanf_glibc(x, &exact);
+    return exact ? t : __builtin_nanf("");  // outside the restated range: reported as a mismatch unless the host says NaN too
+}
+
 __global__ __launch_bounds__(256) void k_libm_sweep(int func, uint32_t first, uint32_t stride, uint32_t n, float *out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -36,7 +43,8 @@ __global__ __launch_bounds__(256) void k_libm_sweep(int func, uint32_t first, ui
              : func == 1 ? ft_libm::sinf_glibc(x)
              : func == 2 ? ft_libm::logf_glibc(x)
              : func == 3 ? ft_libm::atanf_glibc(x)
-                         : ft_libm::atan2f_glibc(x, pair_x(first + i * stride));
+             : func == 4 ? ft_libm::atan2f_glibc(x, pair_x(first + i * stride))
+                         : tan_or_nan(x);
 }
 
 float host_eval(int func, float x) {
@@ -46,14 +54,20 @@ float host_eval(int func, float x) {
     static float (*volatile fl)(float) = logf;
     static float (*volatile fa)(float) = atanf;
     static float (*volatile fa2)(float, float) = atan2f;
-    return func == 0 ? fc(x) : func == 1 ? fs(x) : func == 2 ? fl(x) : func == 3 ? fa(x) : fa2(x, pair_x(__builtin_bit_cast(uint32_t, x)));
+    static float (*volatile ft)(float) = tanf;
+    return func == 0   ? fc(x)
+           : func == 1 ? fs(x)
+           : func == 2 ? fl(x)
+           : func == 3 ? fa(x)
+           : func == 4 ? fa2(x, pair_x(__builtin_bit_cast(uint32_t, x)))
+                       : ft(x);
 }
 
 }  // namespace
 
 extern "C" FT_API int ft_selftest_libm(ft_context *ctx, int func, uint32_t first_bits, uint32_t last_bits, uint32_t stride,
                                        unsigned long long *checked, unsigned long long *mismatches, uint32_t *first_bad) {
-    if (!ctx || func < 0 || func > 4 || stride == 0 || last_bits < first_bits || !checked || !mismatches) {
+    if (!ctx || func < 0 || func > 5 || stride == 0 || last_bits < first_bits || !checked || !mismatches) {
         ft_set_error("ft_selftest_libm: bad arguments");
         return FT_ERR_INVALID;
     }

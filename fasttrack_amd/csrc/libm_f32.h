@@ -259,4 +259,92 @@ FT_LM_HD float atan2f_glibc(float y, float x) {
     }
 }
 
+// ---- tanf ------------------------------------------------------------------------------------------------------------
+// glibc 2.35 sysdeps/ieee754/flt-32/{s_tanf.c,k_tanf.c}: |x| <= pi/4 goes to fdlibm's float kernel directly, larger
+// arguments are first reduced in double by s_sincosf.h's reduce_fast (the disassembly of this image's libm.so.6 shows the
+// mulsd / subsd pair and the two constants) and handed to the kernel as a float head + tail.
+// KannalaBrandt8::unproject evaluates tanf(theta) with theta in [0, pi/2] (/root/reference/src/CameraModels/KannalaBrandt8.cpp:
+// 112-141: theta_d clamped to +-pi/2, then Newton steps on theta); |x| >= 120 (reduce_large) is not restated: *exact =
+// false tells the caller to take another route.
+FT_LM_HD float kernel_tanf(float x, float y, int iy) {
+    const uint32_t Tb[13] = {0x3eaaaaabu, 0x3e088889u, 0x3d5d0dd1u, 0x3cb327a4u, 0x3c11371fu, 0x3b6b6916u, 0x3abede48u,
+                             0x3a1a26c8u, 0x398137b9u, 0x38a3f445u, 0x3895c07au, 0xb79bae5fu, 0x37d95384u};
+    const float pio4 = bits_f32(0x3f490fdau), pio4lo = bits_f32(0x33222168u);
+    const int32_t hx = (int32_t)f32_bits(x), ix = hx & 0x7fffffff;
+    if (ix < 0x39000000) {  // |x| < 2^-13
+        if ((int)x == 0) {
+            if ((ix | (iy + 1)) == 0) return FT_LM_DIV(1.0f, __builtin_fabsf(x));
+            if (iy == 1) return x;
+            return FT_LM_DIV(-1.0f, x);
+        }
+    }
+    const float sgn = (float)(1 - ((hx >> 30) & 2));
+    if (ix >= 0x3f2ca140) {  // |x| >= 0.6744
+        if (hx < 0) {
+            x = -x;
+            y = -y;
+        }
+        const float z0 = FT_LM_SUB(pio4, x), w0 = FT_LM_SUB(pio4lo, y);
+        x = FT_LM_ADD(z0, w0);
+        y = 0.0f;
+        if (__builtin_fabsf(x) < 0x1p-13f) return FT_LM_MUL(FT_LM_MUL(sgn, (float)iy), FT_LM_SUB(1.0f, FT_LM_MUL((float)(2 * iy), x)));
+    }
+    float z = FT_LM_MUL(x, x), w = FT_LM_MUL(z, z);
+    // x^5 (T[1] + x^2 T[2] + ...) split into the terms of even and odd index
+    float r = FT_LM_ADD(bits_f32(Tb[9]), FT_LM_MUL(w, bits_f32(Tb[11])));
+    r = FT_LM_ADD(bits_f32(Tb[7]), FT_LM_MUL(w, r));
+    r = FT_LM_ADD(bits_f32(Tb[5]), FT_LM_MUL(w, r));
+    r = FT_LM_ADD(bits_f32(Tb[3]), FT_LM_MUL(w, r));
+    r = FT_LM_ADD(bits_f32(Tb[1]), FT_LM_MUL(w, r));
+    float v = FT_LM_ADD(bits_f32(Tb[10]), FT_LM_MUL(w, bits_f32(Tb[12])));
+    v = FT_LM_ADD(bits_f32(Tb[8]), FT_LM_MUL(w, v));
+    v = FT_LM_ADD(bits_f32(Tb[6]), FT_LM_MUL(w, v));
+    v = FT_LM_ADD(bits_f32(Tb[4]), FT_LM_MUL(w, v));
+    v = FT_LM_MUL(z, FT_LM_ADD(bits_f32(Tb[2]), FT_LM_MUL(w, v)));
+    float s = FT_LM_MUL(z, x);
+    r = FT_LM_ADD(y, FT_LM_MUL(z, FT_LM_ADD(FT_LM_MUL(s, FT_LM_ADD(r, v)), y)));
+    r = FT_LM_ADD(r, FT_LM_MUL(bits_f32(Tb[0]), s));
+    w = FT_LM_ADD(x, r);
+    if (ix >= 0x3f2ca140) {
+        v = (float)iy;
+        const float q = FT_LM_DIV(FT_LM_MUL(w, w), FT_LM_ADD(w, v));
+        return FT_LM_MUL(sgn, FT_LM_SUB(v, FT_LM_MUL(2.0f, FT_LM_SUB(x, FT_LM_SUB(q, r)))));
+    }
+    if (iy == 1) return w;
+    // -1 / (x + r), accurately
+    z = bits_f32(f32_bits(w) & 0xfffff000u);
+    v = FT_LM_SUB(r, FT_LM_SUB(z, x));  // z + v = r + x
+    const float a = FT_LM_DIV(-1.0f, w);
+    const float t = bits_f32(f32_bits(a) & 0xfffff000u);
+    s = FT_LM_ADD(1.0f, FT_LM_MUL(t, z));
+    return FT_LM_ADD(t, FT_LM_MUL(a, FT_LM_ADD(s, FT_LM_MUL(t, v))));
+}
+
+FT_LM_HD float tanf_glibc(float x, bool *exact) {
+    const int32_t hx = (int32_t)f32_bits(x), ix = hx & 0x7fffffff;
+    *exact = true;
+    if (ix <= 0x3f490fda) return kernel_tanf(x, 0.0f, 1);  // |x| <= pi/4
+    if (abstop12(x) >= abstop12(120.0f)) {                 // reduce_large (and inf / NaN): not restated
+        *exact = false;
+        return 0.0f;
+    }
+    // reduce_fast of s_sincosf.h in double - a plain multiply and subtract here: tanf has no FMA variant - then the reduced
+    // argument split into a float head and tail for the fdlibm kernel
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = __dmul_rn((double)x, 0x1.45F306DC9C883p+23);
+    const int n = (int)(((int32_t)r + 0x800000) >> 24);
+    const double xr = __dsub_rn((double)x, __dmul_rn((double)n, 0x1.921FB54442D18p0));
+    const float y0 = (float)xr;
+    const float y1 = (float)__dsub_rn(xr, (double)y0);
+#else
+    const double r = (double)x * 0x1.45F306DC9C883p+23;
+    const int n = (int)(((int32_t)r + 0x800000) >> 24);
+    const double nh = (double)n * 0x1.921FB54442D18p0;
+    const double xr = (double)x - nh;
+    const float y0 = (float)xr;
+    const float y1 = (float)(xr - (double)y0);
+#endif
+    return kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
+}
+
 }  // namespace ft_libm

@@ -279,7 +279,8 @@ FT_API int ft_fisheye_match(ft_context *ctx, const uint8_t *descL, int nL, const
  * matches[i] = index into the right subset or -1 (mvLeftToRightMatch), depth[i] = mvDepth or -1,
  * p3d[3i..3i+2] = mvStereo3Dpoints.  The null vector of the 4x4 triangulation system is computed by a one-sided
  * Jacobi SVD in double (the reference uses Eigen::JacobiSVD in float): depth / p3d agree with the reference to
- * its own rounding error, not bit for bit. */
+ * its own rounding error, not bit for bit.  Every other float step is the reference's operation for operation,
+ * including tanf / atan2f / cosf / sinf as the host's glibc evaluates them (ft_selftest_libm). */
 typedef struct ft_fisheye_rig {
     float cam1[8], cam2[8]; /* fx fy cx cy k1 k2 k3 k4 of mpCamera / mpCamera2 */
     float precision;        /* KannalaBrandt8::precision */
@@ -452,11 +453,12 @@ FT_API int ft_descriptor_distance(ft_context *ctx, const uint8_t *a, const uint8
 /* Host-libm self test.  The rBRIEF rotation (src/ORBextractor.cc:73-74: std::cos(float), std::sin(float)) and
  * MapPoint::PredictScale (src/MapPoint.cc:539: std::log(float)) are evaluated by the reference with the HOST libm;
  * the kernels reproduce glibc's cosf / sinf / logf bit for bit (fasttrack_amd/csrc/libm_f32.h).  This sweep evaluates
- * func (0 cosf, 1 sinf, 2 logf, 3 atanf, 4 atan2f) on the device for the float bit patterns first_bits, first_bits + stride,
+ * func (0 cosf, 1 sinf, 2 logf, 3 atanf, 4 atan2f, 5 tanf) on the device for the float bit patterns first_bits, first_bits + stride,
  * ... <= last_bits and compares with the same function of the calling process's libm.  mismatches == 0 over [0, 0x40c90fdb]
  * (cos, sin) and [1, 0x461c4000] (log, up to 1e4) means the device and this host's libm agree on every argument the path can
  * produce; atanf takes any range up to [0, 0xffffffff]; atan2f(y, x) sweeps y over the range and pairs each y with one x
- * derived from its bits (either sign, 2^-9 <= |x| < 2^7): the KannalaBrandt8 projection of two-camera frames. */
+ * derived from its bits (either sign, 2^-9 <= |x| < 2^7): the KannalaBrandt8 projection of two-camera frames; tanf (its
+ * unprojection) is reproduced for |x| < 120, i.e. bits [0, 0x42efffff] and [0x80000000, 0xc2efffff]. */
 FT_API int ft_selftest_libm(ft_context *ctx, int func, uint32_t first_bits, uint32_t last_bits, uint32_t stride,
                             unsigned long long *checked, unsigned long long *mismatches, uint32_t *first_bad);
 

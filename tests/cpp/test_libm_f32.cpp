@@ -135,5 +135,31 @@ int main(int argc, char **argv) {
         printf("atan2f(sample): checked %llu mismatches %llu\n", c.load(), b.load());
         bad += b.load();
     }
+    // tanf on every float of (-120, 120)
+    float (*volatile htan)(float) = tanf;
+    for (uint32_t sign : {0u, 0x80000000u}) {
+        std::atomic<unsigned long long> b{0}, c{0};
+        std::atomic<int> shown{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++)
+            pool.emplace_back([&, t] {
+                unsigned long long bb = 0, cc = 0;
+                for (uint64_t u = (uint64_t)t * stride; u < 0x42f00000ull; u += (uint64_t)stride * threads) {
+                    const float x = from_bits((uint32_t)u | sign);
+                    bool exact;
+                    const float m = ft_libm::tanf_glibc(x, &exact), h = htan(x);
+                    if (!exact || to_bits(m) != to_bits(h)) {
+                        bb++;
+                        if (shown.fetch_add(1) < 8) printf("  tanf(%.9g = 0x%08x): mine %.9g host %.9g\n", x, (uint32_t)u | sign, m, h);
+                    }
+                    cc++;
+                }
+                b += bb;
+                c += cc;
+            });
+        for (auto &th : pool) th.join();
+        printf("tanf(%s120): checked %llu mismatches %llu\n", sign ? "-" : "+", c.load(), b.load());
+        bad += b.load();
+    }
     return bad ? 1 : 0;
 }

@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("func,first,last", [(0, 0, 0x40C90FDC), (1, 0, 0x40C90FDC), (0, 0x80000000, 0xC0C90FDC),
                                              (1, 0x80000000, 0xC0C90FDC), (2, 1, 0x461C4000), (3, 0, 0xFFFFFFFF),
-                                             (4, 0x30000000, 0x4FFFFFFF), (4, 0xB0000000, 0xCFFFFFFF)],
+                                             (4, 0x30000000, 0x4FFFFFFF), (4, 0xB0000000, 0xCFFFFFFF),
+                                             (5, 0, 0x42EFFFFF), (5, 0x80000000, 0xC2EFFFFF)],
                          ids=["cosf[0,2pi]", "sinf[0,2pi]", "cosf[-2pi,0]", "sinf[-2pi,0]", "logf(0,1e4]", "atanf(all)",
-                              "atan2f(y>0)", "atan2f(y<0)"])
+                              "atan2f(y>0)", "atan2f(y<0)", "tanf[0,120)", "tanf(-120,0]"])
 def test_device_libm_equals_host_libm_exhaustively(func, first, last):
     ctx = orb.Context(0)
     L = _capi.lib()
@@ -37,3 +38,18 @@ def test_device_libm_reproduces_the_glibc_vectors(golden_dir):
             checked, bad = C.c_ulonglong(0), C.c_ulonglong(0)
             _capi.check(L.ft_selftest_libm(ctx._h, func, int(b), int(b), 1, C.byref(checked), C.byref(bad), None))
             assert checked.value == 1 and bad.value == 0, (func, hex(int(b)))
+
+
+def test_device_libm_reproduces_the_kb8_vectors(golden_dir):
+    """atan2f / atanf / tanf at arguments where glibc is not correctly rounded (tests/golden/libm_kb8_glibc235.npz; the x of
+    an atan2f vector is the one ft_selftest_libm pairs with its y)"""
+    import os
+    g = np.load(os.path.join(golden_dir, "libm_kb8_glibc235.npz"))
+    ctx = orb.Context(0)
+    L = _capi.lib()
+    for func, args in ((4, g["atan2_y"]), (5, g["tan_x"]), (3, g["atan_x"])):
+        for b in args.view(np.uint32):
+            checked, bad = C.c_ulonglong(0), C.c_ulonglong(0)
+            _capi.check(L.ft_selftest_libm(ctx._h, func, int(b), int(b), 1, C.byref(checked), C.byref(bad), None))
+            assert checked.value == 1 and bad.value == 0, (func, hex(int(b)))
+

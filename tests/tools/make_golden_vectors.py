@@ -103,8 +103,55 @@ def libm_case(name, seed=1):
                         sinf_bits=sn.view(np.uint32), descriptors=desc, ratio=ratio, logf_bits=lg.view(np.uint32))
 
 
+def pair_x(ybits):
+    """kernels_selftest.hip pair_x: the x that ft_selftest_libm(func 4) pairs with the y of these bits"""
+    h = (ybits.astype(np.uint64) * 0x9E3779B1) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x85EBCA77) & 0xFFFFFFFF
+    h ^= h >> 13
+    bits = (h & 0x807FFFFF) | ((118 + ((h >> 24) & 15)) << 23)
+    return bits.astype(np.uint32).view(np.float32)
+
+
+def kb8_libm_case(name, seed=2, n=256):
+    """KannalaBrandt8::project / unproject bind to libm's atan2f and tanf (fdlibm's float routines in glibc 2.35, within
+    1 ulp but not correctly rounded): n arguments each at which glibc's result is NOT the narrowed double value - the
+    arguments where evaluating in double on the device (rounds 2-3) gave a different float than the host."""
+    import ctypes
+    m = ctypes.CDLL("libm.so.6")
+    m.atan2f.restype, m.atan2f.argtypes = ctypes.c_float, [ctypes.c_float, ctypes.c_float]
+    m.tanf.restype, m.tanf.argtypes = ctypes.c_float, [ctypes.c_float]
+    m.atanf.restype, m.atanf.argtypes = ctypes.c_float, [ctypes.c_float]
+    rng = np.random.default_rng(seed)
+    ys, a2 = [], []
+    while len(ys) < n:
+        y = np.float32(rng.uniform(-4, 4))
+        x = pair_x(np.array([y], np.float32).view(np.uint32))[0]
+        r = np.float32(m.atan2f(float(y), float(x)))
+        if r != np.float32(np.arctan2(np.float64(y), np.float64(x))):
+            ys.append(y); a2.append(r)
+    ts, tn = [], []
+    while len(ts) < n:
+        t = np.float32(rng.uniform(0, np.pi / 2))
+        r = np.float32(m.tanf(float(t)))
+        if r != np.float32(np.tan(np.float64(t))):
+            ts.append(t); tn.append(r)
+    xs, at = [], []
+    while len(xs) < n:
+        x = np.float32(np.exp(rng.uniform(np.log(1e-3), np.log(1e3)))) * np.float32(rng.choice([-1, 1]))
+        r = np.float32(m.atanf(float(x)))
+        if r != np.float32(np.arctan(np.float64(x))):
+            xs.append(x); at.append(r)
+    ys = np.array(ys, np.float32)
+    np.savez_compressed(os.path.join(G, name), atan2_y=ys, atan2_x=pair_x(ys.view(np.uint32)),
+                        atan2f_bits=np.array(a2, np.float32).view(np.uint32), tan_x=np.array(ts, np.float32),
+                        tanf_bits=np.array(tn, np.float32).view(np.uint32), atan_x=np.array(xs, np.float32),
+                        atanf_bits=np.array(at, np.float32).view(np.uint32))
+
+
 if __name__ == "__main__":
     libm_case("libm_rotation_glibc235.npz")
+    kb8_libm_case("libm_kb8_glibc235.npz")
     extract_case("extract_160x120_s1.npz", 160, 120, 300, 4, 1)
     extract_case("extract_320x240_s2_lap.npz", 320, 240, 500, 8, 2, lap=(100, 200))
     stereo_case("stereo_320x240_s3.npz", 320, 240, 500, 3)
