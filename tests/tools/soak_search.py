@@ -7,7 +7,8 @@ A trial draws a frame (size, feature count, scene kind; every fourth one a two-c
 oracle, and then runs several searches on it, each with its own random point set, window factor, flags and occupancy of
 mvpMapPoints: the one-shot kernel-controller calls and the sequence on a resident frame (search last frame -> frustum ->
 local map, holder_obs carried over).  Assignments, every raw array, the frustum fields and the final occupancy must equal
-the oracle's.  Prints one line per failure and a summary; exit code 1 on any mismatch."""
+the oracle's.  The two-camera trials add the KannalaBrandt8 model: a last-frame search and isInFrustum projecting through it
+and the fisheye stereo triangulation on a random rig, every output compared for equality.  Prints one line per failure and a summary; exit code 1 on any mismatch."""
 import argparse
 import os
 import sys
@@ -65,6 +66,7 @@ def main():
     sf, _ = ob.scale_factors(1.2, 8)
     sizes = [(752, 480), (640, 480), (512, 512), (1280, 720), (376, 240)]
     fails, searches, matched, t0 = 0, 0, 0, time.time()
+    kb8_frustum_points = kb8_pairs = 0
 
     def check(tag, trial, what):
         nonlocal fails
@@ -101,6 +103,54 @@ def main():
                       (None if np.array_equal(gF.holder_obs, oF.holder_obs) else "holder_obs"))
                 searches += 1
                 matched += o["n"]
+            # --- KannalaBrandt8 on the same frame: SearchByProjection(last frame) and isInFrustum project through atan2f /
+            # cosf / sinf, the fisheye stereo triangulation unprojects through tanf - all equal to the oracle's bits ---
+            cam = list(sc.KB8_CAM)
+            cam[0] *= float(rng.uniform(0.8, 1.3)); cam[1] = cam[0] * float(rng.uniform(0.999, 1.001))
+            cam[2], cam[3] = w / 2 + float(rng.uniform(-8, 8)), h / 2 + float(rng.uniform(-8, 8))
+            Trl = np.concatenate([np.eye(3), [[-float(rng.uniform(0.05, 0.2))], [0.0], [0.0]]], 1).astype(np.float32)
+            kwk = dict(kw, cam_model=1, cam=cam, Trl=Trl)
+            N = len(fr["kL"])
+            z = rng.uniform(1.5, 9, N).astype(np.float32)
+            X = ((fr["kL"]["x"] - cam[2]) / cam[0] * z).astype(np.float32)
+            Y = ((fr["kL"]["y"] - cam[3]) / cam[1] * z).astype(np.float32)
+            last = dict(valid=(rng.random(N) < 0.8).astype(np.uint8), world_pos=np.stack([X, Y, z], 1),
+                        descriptors=fr["dL"].copy(), observations=rng.integers(0, 4, N).astype(np.int32),
+                        octave=fr["kL"]["octave"].astype(np.int32), angle=fr["kL"]["angle"].copy())
+            Tcw = sc.random_pose(rng, 0.02, 0.005)
+            th = float(rng.choice([7.0, 15.0]))
+            oF, gF = ob.FrameView(scale_factors_=sf, **kwk), orb.FrameView(scale_factors=sf, **kwk)
+            o = ob.search_last_frame(oF, last, Tcw, th, False, False, True)
+            g = orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, Tcw, th, False, False, True)
+            check(f"KB8 last th{th} [{desc}]", t, diff(g, o, ("best_dist", "best_idx", "best_dist_r", "best_idx_r")))
+            searches += 1
+            matched += o["n"]
+            intr = dict(fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+            pts, Rcw, tcw = sc.map_points_scenario(fr["kL"], fr["dL"], np.zeros(N, np.float32), intr, 8, sf, int(rng.integers(0, 1 << 30)))
+            tlr = (-float(Trl[0, 3]), 0.0, 0.0)
+            oF, gF = ob.FrameView(scale_factors_=sf, **kwk), orb.FrameView(scale_factors=sf, **kwk)
+            ofr = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, tlr), pts, 0.5, LOG_SF)
+            gfr = orb.is_in_frustum(ctx, gF, orb.make_pose(Rcw, tcw, tlr), pts, 0.5, LOG_SF)
+            bad = next((k for k, _ in ob.FRUSTUM_FIELDS if not np.array_equal(gfr[k], ofr[k])), None)
+            check(f"KB8 frustum [{desc}]", t, bad or (None if gfr["n"] == ofr["n"] else "n"))
+            kb8_frustum_points += len(pts["world_pos"])
+            S = sc.fisheye_rig_scenario(int(rng.integers(0, 1 << 30)), n=int(rng.integers(200, 2500)), noise=float(rng.uniform(0.1, 0.8)))
+            n = len(S["xy1"])
+            dL = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            perm = rng.permutation(n)
+            dR = dL[perm].copy()
+            flips = rng.integers(0, 256, (n, 6))
+            for k in range(6):
+                dR[np.arange(n), flips[:, k] // 8] ^= (1 << (flips[:, k] % 8)).astype(np.uint8)
+            kL = np.zeros(n, ob.KP_DTYPE); kR = np.zeros(n, ob.KP_DTYPE)
+            kL["x"], kL["y"], kL["octave"] = S["xy1"][:, 0], S["xy1"][:, 1], S["octave1"]
+            kR["x"], kR["y"], kR["octave"] = S["xy2"][perm, 0], S["xy2"][perm, 1], S["octave2"][perm]
+            ls2 = (sf ** 2).astype(np.float32)
+            o = ob.fisheye_stereo(ob.make_rig(sc.KB8_CAM, sc.KB8_CAM, S["Rlr"], S["tlr"]), dL, kL, dR, kR, ls2)
+            g = orb.fisheye_stereo(ctx, sc.KB8_CAM, sc.KB8_CAM, S["Rlr"], S["tlr"], dL, kL, dR, kR, ls2)
+            bad = next((k for k in ("matches", "depth", "p3d") if not np.array_equal(g[k], o[k])), None)
+            check(f"KB8 triangulation n{n} [{desc}]", t, bad or (None if g["n"] == o["n"] else "n"))
+            kb8_pairs += n
             continue
         kind = int(rng.integers(0, 3))
         fr = frame_of(rng, w, h, nf, kind, seed)
@@ -175,6 +225,7 @@ def main():
             return ctx.get_stat(name)[1]
         except Exception:
             return 0
+    print(f"KannalaBrandt8, all bit-exact comparisons: {kb8_frustum_points} frustum points, {kb8_pairs} triangulated pairs")
     print(f"{args.trials} trials, {searches} searches, {matched} matches, {fails} mismatches, {time.time() - t0:.0f} s; "
           f"persistent launches {calls('search.persistent_launches')}, timeouts {calls('search.persistent_timeouts')}, "
           f"fallbacks {calls('search.persistent_fallbacks')}")
