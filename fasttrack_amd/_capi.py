@@ -57,6 +57,12 @@ class FisheyeRig(C.Structure):
                 ("tlr", C.c_float * 3)]
 
 
+class BowSide(C.Structure):
+    """ft_bow_side: a DBoW2 FeatureVector in CSR form with the descriptors / angles it indexes"""
+    _fields_ = [("n", C.c_int), ("n_nodes", C.c_int), ("fv_nodes", C.c_void_p), ("fv_offsets", C.c_void_p),
+                ("fv_features", C.c_void_p), ("descriptors", C.c_void_p), ("angles", C.c_void_p)]
+
+
 class FramePose(C.Structure):
     _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("tlr", C.c_float * 3)]
 
@@ -194,6 +200,7 @@ def lib() -> C.CDLL:
     L.ft_vocabulary_destroy.argtypes = [vp]
     L.ft_vocabulary_info.argtypes = [vp, ip, ip, ip, ip]
     L.ft_bow_transform.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, vp, i, ip, vp, vp, vp, i, ip]
+    L.ft_search_by_bow.argtypes = [vp, C.POINTER(BowSide), vp, C.POINTER(BowSide), i, f, i, vp, ip]
     L.ft_selftest_libm.argtypes = [vp, i, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong),
                                    C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint32)]
     L.ft_octree_distribute.argtypes = [vp, i, i, i, i, i, i, vp, i, ip]

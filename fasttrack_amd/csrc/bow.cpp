@@ -298,3 +298,132 @@ int ft_bow_transform(ft_vocabulary *v, const uint8_t *descriptors, int n, int on
 }
 
 }  // extern "C"
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:322-524): the matching inside the common
+// nodes on the device (k_search_by_bow), the rotation-consistency filter (:489-521, ComputeThreeMaxima :2210-2251) here on the
+// downloaded assignments - the order inside a histogram bin does not matter to it, only the bins' sizes.
+namespace {
+int checkBowSide(const ft_bow_side *s, const char *who) {
+    auto bad = [&](const char *what) {
+        ft_set_error(std::string("ft_search_by_bow: ") + who + ": " + what);
+        return FT_ERR_INVALID;
+    };
+    if (s->n < 0 || s->n >= (1 << 20) || s->n_nodes < 0) return bad("count out of range");
+    if (s->n_nodes > 0 && (!s->fv_nodes || !s->fv_offsets)) return bad("null feature vector");
+    if (s->n > 0 && !s->descriptors) return bad("null descriptors");
+    if (s->n_nodes == 0) return FT_OK;
+    if (s->fv_offsets[0] != 0) return bad("fv_offsets[0] != 0");
+    for (int j = 0; j < s->n_nodes; j++) {
+        if (s->fv_offsets[j + 1] < s->fv_offsets[j]) return bad("fv_offsets not ascending");
+        if (j > 0 && s->fv_nodes[j] <= s->fv_nodes[j - 1]) return bad("fv_nodes not strictly ascending");
+    }
+    const int total = s->fv_offsets[s->n_nodes];
+    if (total > s->n) return bad("more feature-vector entries than features");
+    if (total > 0 && !s->fv_features) return bad("null fv_features");
+    for (int e = 0; e < total; e++)
+        if (s->fv_features[e] >= (unsigned)s->n) return bad("feature index out of range");
+    return FT_OK;
+}
+}  // namespace
+
+int ft_search_by_bow(ft_context *ctx, const ft_bow_side *kf, const uint8_t *kf_has_point, const ft_bow_side *frame, int frame_nleft,
+                     float nn_ratio, int check_orientation, int *matches, int *n_matches) {
+    FT_REQUIRE(ctx && kf && frame && matches, "ft_search_by_bow: null argument");
+    FT_REQUIRE(kf->n == 0 || kf_has_point, "ft_search_by_bow: null kf_has_point");
+    FT_REQUIRE(frame_nleft >= -1 && frame_nleft <= frame->n, "ft_search_by_bow: frame_nleft out of range");
+    int rc = checkBowSide(kf, "keyframe");
+    if (rc == FT_OK) rc = checkBowSide(frame, "frame");
+    if (rc != FT_OK) return rc;
+    FT_REQUIRE(!check_orientation || ((kf->n == 0 || kf->angles) && (frame->n == 0 || frame->angles)),
+               "ft_search_by_bow: check_orientation needs the keypoint angles of both sides");
+    if (n_matches) *n_matches = 0;
+    const int N = frame->n;
+    for (int i = 0; i < N; i++) matches[i] = -1;
+    if (N == 0 || kf->n == 0 || kf->n_nodes == 0 || frame->n_nodes == 0) return FT_OK;
+    rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    // one block of the context's scratch: per side nodes | offsets | features | descriptors, then has_point, then matches
+    auto up64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    struct Lay { size_t nodes, offsets, features, desc; };
+    size_t off = 0;
+    auto lay = [&](const ft_bow_side *s) {
+        Lay L;
+        L.nodes = off; off += up64(sizeof(unsigned) * (size_t)s->n_nodes);
+        L.offsets = off; off += up64(sizeof(int) * ((size_t)s->n_nodes + 1));
+        L.features = off; off += up64(sizeof(unsigned) * (size_t)std::max(s->fv_offsets[s->n_nodes], 1));
+        L.desc = off; off += up64((size_t)32 * s->n);
+        return L;
+    };
+    const Lay lk_ = lay(kf), lf = lay(frame);
+    const size_t oHas = off; off += up64((size_t)kf->n);
+    const size_t oMatches = off; off += up64(sizeof(int) * (size_t)N);
+    rc = ft_ensure_scratch(ctx, off, off);
+    if (rc != FT_OK) return rc;
+    uint8_t *dev = (uint8_t *)ctx->scratchDev, *pin = (uint8_t *)ctx->scratchPin;
+    hipStream_t st = ctx->stream;
+    auto fill = [&](const ft_bow_side *s, const Lay &L) {
+        memcpy(pin + L.nodes, s->fv_nodes, sizeof(unsigned) * (size_t)s->n_nodes);
+        memcpy(pin + L.offsets, s->fv_offsets, sizeof(int) * ((size_t)s->n_nodes + 1));
+        memcpy(pin + L.features, s->fv_features, sizeof(unsigned) * (size_t)s->fv_offsets[s->n_nodes]);
+        memcpy(pin + L.desc, s->descriptors, (size_t)32 * s->n);
+    };
+    fill(kf, lk_);
+    fill(frame, lf);
+    memcpy(pin + oHas, kf_has_point, (size_t)kf->n);
+    memset(pin + oMatches, 0xff, sizeof(int) * (size_t)N);
+    FT_HIP(hipMemcpyAsync(dev, pin, off, hipMemcpyHostToDevice, st));  // one copy: the block is contiguous
+    auto side = [&](const ft_bow_side *s, const Lay &L) {
+        FtBowSide D;
+        D.n = s->n;
+        D.nNodes = s->n_nodes;
+        D.nodes = (const unsigned *)(dev + L.nodes);
+        D.offsets = (const int *)(dev + L.offsets);
+        D.features = (const unsigned *)(dev + L.features);
+        D.desc = dev + L.desc;
+        return D;
+    };
+    rc = ft_launch_search_by_bow(st, side(kf, lk_), dev + oHas, side(frame, lf), frame_nleft, nn_ratio, (int *)(dev + oMatches));
+    if (rc != FT_OK) return rc;
+    FT_HIP(hipMemcpyAsync(pin + oMatches, dev + oMatches, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost, st));
+    FT_HIP(hipStreamSynchronize(st));
+    memcpy(matches, pin + oMatches, sizeof(int) * (size_t)N);
+    int nm = 0;
+    for (int i = 0; i < N; i++) nm += matches[i] >= 0;
+    if (check_orientation) {
+        std::vector<int> rotHist[FT_HISTO_LENGTH];
+        const float factor = 1.0f / FT_HISTO_LENGTH;
+        for (int i = 0; i < N; i++) {
+            if (matches[i] < 0) continue;
+            float rot = kf->angles[matches[i]] - frame->angles[i];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == FT_HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < FT_HISTO_LENGTH) rotHist[bin].push_back(i);  // the reference asserts
+        }
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < FT_HISTO_LENGTH; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) {
+                max3 = max2; max2 = max1; max1 = sz;
+                ind3 = ind2; ind2 = ind1; ind1 = i;
+            } else if (sz > max2) {
+                max3 = max2; max2 = sz;
+                ind3 = ind2; ind2 = i;
+            } else if (sz > max3) {
+                max3 = sz; ind3 = i;
+            }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < FT_HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) {
+                    matches[idx] = -1;
+                    nm--;
+                }
+    }
+    if (n_matches) *n_matches = nm;
+    return FT_OK;
+}
+

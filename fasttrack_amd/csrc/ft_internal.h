@@ -161,6 +161,16 @@ struct FtBowTree {
 };
 int ft_launch_bow_walk(hipStream_t st, const FtBowTree &t, const uint8_t *desc, int n, int nidLevel, unsigned *wordOut,
                        unsigned *nodeOut, double *weightOut);
+// one side of ORBmatcher::SearchByBoW on the device: a DBoW2 FeatureVector in CSR form and the descriptors it indexes
+struct FtBowSide {
+    int n, nNodes;
+    const unsigned *nodes;     // [nNodes] ascending
+    const int *offsets;        // [nNodes + 1]
+    const unsigned *features;  // [offsets[nNodes]]
+    const uint8_t *desc;       // [n * 32]
+};
+int ft_launch_search_by_bow(hipStream_t st, const FtBowSide &K, const uint8_t *kfHasPoint, const FtBowSide &F, int nleft,
+                            float nnRatio, int *matches);
 
 void ft_set_error(const std::string &msg);
 // Profiling aid: FT_DEBUG_REPEAT=<name>[,<name>...] makes the launcher of that kernel (pyr, fast, compact, octree,

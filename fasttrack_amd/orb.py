@@ -689,6 +689,39 @@ def fisheye_stereo(ctx: Context, cam1, cam2, Rlr, tlr, descL, keysL, descR, keys
     return dict(matches=m[:nL], depth=d[:nL], p3d=p[:nL], n=n.value)
 
 
+class BowSide:
+    """One side of ORBmatcher::SearchByBoW: the FeatureVector of Vocabulary.transform (fv_nodes, fv_offsets, fv_features),
+    the descriptors it indexes and the keypoint angles (for mbCheckOrientation).  Owns the arrays behind an ft_bow_side."""
+
+    def __init__(self, fv_nodes, fv_offsets, fv_features, descriptors, angles=None):
+        self.fv_nodes = np.ascontiguousarray(fv_nodes, np.uint32)
+        self.fv_offsets = np.ascontiguousarray(fv_offsets, np.int32)
+        self.fv_features = np.ascontiguousarray(fv_features, np.uint32)
+        self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
+        self.angles = None if angles is None else np.ascontiguousarray(angles, np.float32)
+        assert len(self.fv_offsets) == len(self.fv_nodes) + 1 or (len(self.fv_nodes) == 0 and len(self.fv_offsets) <= 1)
+        if len(self.fv_offsets) == 0:
+            self.fv_offsets = np.zeros(1, np.int32)
+        c = _capi.BowSide()
+        c.n, c.n_nodes = len(self.descriptors), len(self.fv_nodes)
+        c.fv_nodes, c.fv_offsets, c.fv_features = ptr(self.fv_nodes), ptr(self.fv_offsets), ptr(self.fv_features)
+        c.descriptors = ptr(self.descriptors)
+        c.angles = None if self.angles is None else ptr(self.angles)
+        self.c = c
+
+
+def search_by_bow(ctx: Context, kf: BowSide, kf_has_point, frame: BowSide, frame_nleft=-1, nn_ratio=0.7, check_orientation=True):
+    """ORBmatcher(nn_ratio, check_orientation).SearchByBoW(pKF, F, vpMapPointMatches) (ft_search_by_bow) ->
+    dict(matches[frame.n] = keyframe feature index or -1, n = nmatches)"""
+    has = np.ascontiguousarray(kf_has_point, np.uint8)
+    assert len(has) == kf.c.n
+    m = np.full(max(frame.c.n, 1), -1, np.int32)
+    n = C.c_int(0)
+    check(lib().ft_search_by_bow(ctx._h, C.byref(kf.c), ptr(has), C.byref(frame.c), int(frame_nleft), float(nn_ratio),
+                                 int(bool(check_orientation)), ptr(m), C.byref(n)))
+    return dict(matches=m[:frame.c.n], n=n.value)
+
+
 def features_in_area(ctx: Context, F: "FrameView", x, y, r, min_level, max_level, right=None, capacity=512):
     """Frame::GetFeaturesInArea for arrays of queries (ft_features_in_area) -> list of index arrays"""
     x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32); r = np.ascontiguousarray(r, np.float32)

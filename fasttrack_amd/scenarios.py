@@ -166,3 +166,51 @@ def fisheye_rig_scenario(seed, n=1500, noise=0.3):
     octave1, octave2 = rng.integers(0, 8, n), rng.integers(0, 8, n)
     return dict(Rlr=Rlr, tlr=tlr, xy1=xy1.astype(np.float32), xy2=xy2.astype(np.float32), Xl=Xl, wrong=wrong,
                 octave1=octave1, octave2=octave2)
+
+
+def bow_match_scenario(voc, transform, n_kf, n_f, seed, two_cam=False, levelsup=4):
+    """A keyframe and a frame for ORBmatcher::SearchByBoW.  voc: synth.make_vocabulary dict; transform(desc, levelsup) ->
+    dict with fv_nodes / fv_offsets / fv_features (either implementation's Vocabulary.transform).  Keyframe descriptors sit
+    near vocabulary centres; most frame descriptors are keyframe descriptors with 0 - 14 flipped bits (several copies of the
+    same one: equal distances, failed ratio tests, claims), some are 40 - 60 bits away (around TH_LOW), the rest random.
+    Angles follow one dominant rotation with outliers, so the rotation histogram removes some matches.
+    -> dict(kf=side, f=side, has_point, nleft) with side = dict(fv_*, descriptors, angles)"""
+    rng = np.random.default_rng(seed)
+    centres = voc["descriptors"][1:]
+
+    def near(base, lo, hi):
+        out = base.copy()
+        for i in range(len(out)):
+            nb = int(rng.integers(lo, hi + 1))
+            if nb:
+                bits = np.unpackbits(out[i])
+                bits[rng.choice(256, nb, replace=False)] ^= 1
+                out[i] = np.packbits(bits)
+        return out
+    dK = near(centres[rng.integers(0, len(centres), n_kf)], 0, 20)
+    src = rng.integers(0, max(n_kf, 1), n_f)
+    kind = rng.random(n_f)
+    if n_kf == 0:
+        dK = np.zeros((0, 32), np.uint8)
+    dF = np.zeros((n_f, 32), np.uint8)
+    if n_kf:
+        dF[kind < 0.7] = near(dK[src[kind < 0.7]], 0, 14)
+    mid = (kind >= 0.7) & (kind < 0.85)
+    if n_kf and mid.any():
+        dF[mid] = near(dK[src[mid]], 40, 60)
+    rnd = kind >= 0.85
+    dF[rnd] = rng.integers(0, 256, (int(rnd.sum()), 32), dtype=np.uint8)
+    dup = rng.random(n_f) < 0.1      # exact copies of another frame descriptor: ties in scan order
+    if n_f:
+        dF[dup] = dF[rng.integers(0, n_f, int(dup.sum()))]
+    aK = rng.uniform(0, 360, n_kf).astype(np.float32)
+    rot = np.float32(rng.uniform(0, 360))
+    aF = (aK[src] - rot + rng.normal(0, 4, n_f)).astype(np.float32) if n_kf else np.zeros(n_f, np.float32)
+    out_l = rng.random(n_f) < 0.2
+    aF[out_l] = rng.uniform(0, 360, int(out_l.sum()))
+    aF = np.mod(aF, np.float32(360)).astype(np.float32)
+    fk, ff = transform(dK, levelsup), transform(dF, levelsup)
+    side = lambda t, d, a: dict(fv_nodes=t["fv_nodes"], fv_offsets=t["fv_offsets"], fv_features=t["fv_features"], descriptors=d, angles=a)
+    return dict(kf=side(fk, dK, aK), f=side(ff, dF, aF), has_point=(rng.random(n_kf) < 0.8).astype(np.uint8),
+                nleft=(int(n_f * 0.55) if two_cam else -1))
+

@@ -498,6 +498,27 @@ FT_API int ft_bow_transform(ft_vocabulary *voc, const uint8_t *descriptors, int 
                             double *bow_values, int bow_capacity, int *n_bow, unsigned *fv_nodes, int *fv_offsets,
                             unsigned *fv_features, int fv_capacity, int *n_fv);
 
+/* ----------------------------------------------------------------------------------------------
+ * ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches)
+ * (src/ORBmatcher.cc:322-524; Tracking::TrackReferenceKeyFrame src/Tracking.cc:2732-2744 and Relocalization): the step
+ * that consumes the FeatureVectors of ft_bow_transform.  A side is its FeatureVector in that CSR form, its descriptors and,
+ * for the rotation-consistency filter (mbCheckOrientation), its keypoint angles.  kf_has_point[i] != 0 <=> the keyframe's
+ * i-th map point exists and is not bad (:345-351).  frame_nleft = Frame::Nleft (-1 = one camera; otherwise descriptors and
+ * angles of the right camera follow the left ones, :383-421 incl. the disabled ratio test of the right camera, :453).
+ * matches[i] (i < frame->n) = index of the keyframe feature whose map point vpMapPointMatches[i] receives, or -1;
+ * *n_matches = the function's return value.  TH_LOW = 50, HISTO_LENGTH = 30 as in the reference (:42-43). */
+typedef struct ft_bow_side {
+    int n;                       /* features (descriptors, angles) */
+    int n_nodes;                 /* FeatureVector entries */
+    const unsigned *fv_nodes;    /* [n_nodes] ascending */
+    const int *fv_offsets;       /* [n_nodes + 1] */
+    const unsigned *fv_features; /* [fv_offsets[n_nodes]] */
+    const uint8_t *descriptors;  /* n x 32 bytes, host */
+    const float *angles;         /* [n] cv::KeyPoint::angle; may be NULL without check_orientation */
+} ft_bow_side;
+FT_API int ft_search_by_bow(ft_context *ctx, const ft_bow_side *kf, const uint8_t *kf_has_point, const ft_bow_side *frame,
+                            int frame_nleft, float nn_ratio, int check_orientation, int *matches, int *n_matches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -347,4 +347,47 @@ private:
     ft_vocabulary *h_ = nullptr;
 };
 
+// ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) (src/ORBmatcher.cc:322-524) on the
+// std::map FeatureVectors of ORBVocabulary::transform.  kfHasPoint[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
+// kfAngles / fAngles = cv::KeyPoint::angle per feature (right-camera features after the left ones, as the reference indexes
+// them).  matches[i] = index into vpMapPointsKF or -1: `vpMapPointMatches[i] = matches[i] < 0 ? nullptr : vpMapPointsKF[matches[i]]`.
+// Returns nmatches.
+inline int SearchByBoW(Context &ctx, const ORBVocabulary::FeatureVector &kfFeatVec, const uint8_t *kfDescriptors, int kfN,
+                       const std::vector<uint8_t> &kfHasPoint, const float *kfAngles, const ORBVocabulary::FeatureVector &fFeatVec,
+                       const uint8_t *fDescriptors, int fN, const float *fAngles, int fNleft, float nnRatio, bool checkOrientation,
+                       std::vector<int> &matches) {
+    struct Csr {
+        std::vector<unsigned> nodes, feats;
+        std::vector<int> offs;
+    };
+    auto flatten = [](const ORBVocabulary::FeatureVector &fv) {
+        Csr c;
+        c.offs.push_back(0);
+        for (const auto &e : fv) {
+            c.nodes.push_back(e.first);
+            c.feats.insert(c.feats.end(), e.second.begin(), e.second.end());
+            c.offs.push_back((int)c.feats.size());
+        }
+        return c;
+    };
+    const Csr k = flatten(kfFeatVec), f = flatten(fFeatVec);
+    auto side = [](const Csr &c, int n, const uint8_t *d, const float *a) {
+        ft_bow_side s;
+        s.n = n;
+        s.n_nodes = (int)c.nodes.size();
+        s.fv_nodes = c.nodes.data();
+        s.fv_offsets = c.offs.data();
+        s.fv_features = c.feats.data();
+        s.descriptors = d;
+        s.angles = a;
+        return s;
+    };
+    const ft_bow_side K = side(k, kfN, kfDescriptors, kfAngles), F = side(f, fN, fDescriptors, fAngles);
+    matches.assign(fN > 0 ? fN : 1, -1);
+    int nm = 0;
+    check(ft_search_by_bow(ctx.handle(), &K, kfHasPoint.data(), &F, fNleft, nnRatio, checkOrientation ? 1 : 0, matches.data(), &nm));
+    matches.resize(fN > 0 ? fN : 0);
+    return nm;
+}
+
 }  // namespace fasttrack

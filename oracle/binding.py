@@ -534,3 +534,37 @@ class Vocabulary:
                                 C.addressof(nb), _p(fn), _p(fo), _p(ff), C.addressof(nf))
         return dict(word=word[:n], node=node[:n], weight=w[:n], bow_ids=bi[:nb.value], bow_values=bv[:nb.value],
                     fv_nodes=fn[:nf.value], fv_offsets=fo[:nf.value + 1], fv_features=ff[:fo[nf.value]])
+
+
+class BowSide(C.Structure):
+    """orc_bow_side (same layout as the product's ft_bow_side)"""
+    _fields_ = [("n", C.c_int), ("n_nodes", C.c_int), ("fv_nodes", C.c_void_p), ("fv_offsets", C.c_void_p),
+                ("fv_features", C.c_void_p), ("descriptors", C.c_void_p), ("angles", C.c_void_p)]
+
+
+def search_by_bow(kf, kf_has_point, frame, frame_nleft=-1, nn_ratio=0.7, check_orientation=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (orc_search_by_bow).  kf / frame: dicts with fv_nodes, fv_offsets,
+    fv_features (Vocabulary.transform), descriptors, angles -> dict(matches, n)"""
+    keep = []
+
+    def side(d):
+        s = BowSide()
+        arrs = [np.ascontiguousarray(d["fv_nodes"], np.uint32), np.ascontiguousarray(d["fv_offsets"], np.int32),
+                np.ascontiguousarray(d["fv_features"], np.uint32), np.ascontiguousarray(d["descriptors"], np.uint8),
+                np.ascontiguousarray(d["angles"], np.float32)]
+        if len(arrs[1]) == 0:
+            arrs[1] = np.zeros(1, np.int32)
+        keep.extend(arrs)
+        s.n, s.n_nodes = len(arrs[3]), len(arrs[0])
+        s.fv_nodes, s.fv_offsets, s.fv_features, s.descriptors, s.angles = [_p(a) for a in arrs]
+        return s
+    K, F = side(kf), side(frame)
+    has = np.ascontiguousarray(kf_has_point, np.uint8)
+    m = np.full(max(F.n, 1), -1, np.int32)
+    lib().orc_search_by_bow.restype = C.c_int
+    lib().orc_search_by_bow.argtypes = [C.POINTER(BowSide), C.c_void_p, C.POINTER(BowSide), C.c_int, C.c_float, C.c_int,
+                                        C.c_void_p]
+    n = lib().orc_search_by_bow(C.byref(K), _p(has), C.byref(F), int(frame_nleft), float(nn_ratio), int(bool(check_orientation)),
+                                _p(m))
+    return dict(matches=m[:F.n], n=n)
+

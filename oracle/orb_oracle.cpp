@@ -1691,4 +1691,82 @@ void orc_bow_transform(const orc_vocabulary *voc, const uint8_t *descriptors, in
     if (n_fv) *n_fv = j;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) - src/ORBmatcher.cc:322-524.
+// The two FeatureVectors are walked like the reference's std::map iterators (equal node: match the node's features;
+// otherwise lower_bound on the other side).  TH_LOW = 50 (:42), HISTO_LENGTH = 30 (:43).
+// ------------------------------------------------------------------------------------------------
+int orc_search_by_bow(const orc_bow_side *K, const uint8_t *kf_has_point, const orc_bow_side *F, int f_nleft, float nn_ratio,
+                      int check_orientation, int *matches) {
+    const int TH_LOW = 50;
+    for (int i = 0; i < F->n; i++) matches[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    auto pushRot = [&](int kfIdx, int fIdx) {
+        float rot = K->angles[kfIdx] - F->angles[fIdx];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(fIdx);
+    };
+    int a = 0, b = 0;
+    while (a < K->n_nodes && b < F->n_nodes) {
+        if (K->fv_nodes[a] == F->fv_nodes[b]) {
+            for (int ik = K->fv_offsets[a]; ik < K->fv_offsets[a + 1]; ik++) {
+                const int realIdxKF = (int)K->fv_features[ik];
+                if (!kf_has_point[realIdxKF]) continue;  // !pMP || pMP->isBad()
+                const uint8_t *dKF = K->descriptors + 32 * (size_t)realIdxKF;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+                for (int jf = F->fv_offsets[b]; jf < F->fv_offsets[b + 1]; jf++) {
+                    const int realIdxF = (int)F->fv_features[jf];
+                    if (matches[realIdxF] >= 0) continue;
+                    const int dist = orc_descriptor_distance(dKF, F->descriptors + 32 * (size_t)realIdxF);
+                    if (f_nleft == -1) {
+                        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                        else if (dist < bestDist2) bestDist2 = dist;
+                    } else {
+                        if (realIdxF < f_nleft && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                        else if (realIdxF < f_nleft && dist < bestDist2) bestDist2 = dist;
+                        if (realIdxF >= f_nleft && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+                        else if (realIdxF >= f_nleft && dist < bestDist2R) bestDist2R = dist;
+                    }
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if ((float)bestDist1 < nn_ratio * (float)bestDist2) {
+                        matches[bestIdxF] = realIdxKF;
+                        if (check_orientation) pushRot(realIdxKF, bestIdxF);
+                        nmatches++;
+                    }
+                    if (bestDist1R <= TH_LOW) {  // the ratio test of the right camera is disabled in the reference ("|| true", :460)
+                        matches[bestIdxFR] = realIdxKF;
+                        if (check_orientation) pushRot(realIdxKF, bestIdxFR);
+                        nmatches++;
+                    }
+                }
+            }
+            a++;
+            b++;
+        } else if (K->fv_nodes[a] < F->fv_nodes[b]) {
+            while (a < K->n_nodes && K->fv_nodes[a] < F->fv_nodes[b]) a++;  // lower_bound(Fit->first)
+        } else {
+            while (b < F->n_nodes && F->fv_nodes[b] < K->fv_nodes[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        orc_three_maxima(sizes, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) {
+                matches[idx] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 }  // extern "C"

@@ -216,6 +216,23 @@ void orc_bow_transform(const orc_vocabulary *v, const uint8_t *descriptors, int 
                        unsigned *node_ids, double *weights, unsigned *bow_ids, double *bow_values, int *n_bow,
                        unsigned *fv_nodes, int *fv_offsets, unsigned *fv_features, int *n_fv);
 
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) - src/ORBmatcher.cc:322-524 (TrackReferenceKeyFrame,
+ * Relocalization).  A side = its FeatureVector in the CSR form of orc_bow_transform, its descriptors and keypoint angles;
+ * kf has_point[i] != 0 <=> vpMapPointsKF[i] is a good map point; f_nleft = Frame::Nleft (-1: one camera; angles / descriptors
+ * of the right camera follow the left ones).  matches[i] = the keyframe feature whose map point vpMapPointMatches[i] holds,
+ * or -1.  Returns nmatches. */
+typedef struct orc_bow_side {
+    int n;                      /* features */
+    int n_nodes;                /* FeatureVector entries */
+    const unsigned *fv_nodes;   /* [n_nodes] ascending */
+    const int *fv_offsets;      /* [n_nodes + 1] */
+    const unsigned *fv_features; /* [fv_offsets[n_nodes]] */
+    const uint8_t *descriptors; /* n x 32 */
+    const float *angles;        /* [n] cv::KeyPoint::angle */
+} orc_bow_side;
+int orc_search_by_bow(const orc_bow_side *kf, const uint8_t *kf_has_point, const orc_bow_side *f, int f_nleft, float nn_ratio,
+                      int check_orientation, int *matches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,3 +101,59 @@ def test_edge_cases(ctx, tmp_path):
         orb.Vocabulary(ctx, path=os.path.join(tmp_path, "missing.txt"))
     for v in (gv, gz, g0):
         v.close()
+
+
+def _bow_side(d):
+    return orb.BowSide(d["fv_nodes"], d["fv_offsets"], d["fv_features"], d["descriptors"], d["angles"])
+
+
+@pytest.mark.parametrize("k,L,levelsup", [(10, 5, 3), (10, 4, 4), (3, 6, 2), (20, 2, 1), (6, 4, 0)])
+def test_search_by_bow_equals_oracle(ctx, k, L, levelsup):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&) on the FeatureVectors of the device transform: assignments and nmatches
+    equal the oracle's - one and two cameras, with and without the rotation histogram, several ratios; nodes from a few to
+    hundreds of features (levelsup 0 = one node per word, levelsup >= L = everything in the root's node)."""
+    from fasttrack_amd import scenarios as sc
+    voc = synth.make_vocabulary(k, L, seed=7 + k, ragged=(k == 3))
+    args = (voc["parent"], voc["is_leaf"], voc["descriptors"], voc["weights"])
+    gv, ov = orb.Vocabulary(ctx, k, L, 0, 0, *args), ob.Vocabulary(k, L, 0, 0, *args)
+    total = 0
+    for seed, (nk, nf) in enumerate([(1500, 2000), (2000, 700), (64, 65), (1, 1), (300, 3000)]):
+        for two_cam in (False, True):
+            S = sc.bow_match_scenario(voc, gv.transform, nk, nf, 10 * seed + two_cam, two_cam=two_cam, levelsup=levelsup)
+            O = sc.bow_match_scenario(voc, ov.transform, nk, nf, 10 * seed + two_cam, two_cam=two_cam, levelsup=levelsup)
+            assert np.array_equal(S["f"]["fv_features"], O["f"]["fv_features"])
+            for ratio, ori in [(0.7, True), (0.7, False), (0.9, True), (0.6, False)]:
+                o = ob.search_by_bow(O["kf"], O["has_point"], O["f"], O["nleft"], ratio, ori)
+                g = orb.search_by_bow(ctx, _bow_side(S["kf"]), S["has_point"], _bow_side(S["f"]), S["nleft"], ratio, ori)
+                assert g["n"] == o["n"] and np.array_equal(g["matches"], o["matches"]), (nk, nf, two_cam, ratio, ori)
+                total += o["n"]
+    assert total > 2000
+    gv.close()
+
+
+def test_search_by_bow_one_big_node_and_edge_cases(ctx):
+    """levelsup >= L puts every feature into node 0: one wave walks thousands of frame features per keyframe feature and the
+    claims of 2000 keyframe features in sequence; empty sides, no map points, bad arguments"""
+    from fasttrack_amd import scenarios as sc
+    voc = synth.make_vocabulary(4, 3, seed=2)
+    args = (voc["parent"], voc["is_leaf"], voc["descriptors"], voc["weights"])
+    gv, ov = orb.Vocabulary(ctx, 4, 3, 0, 0, *args), ob.Vocabulary(4, 3, 0, 0, *args)
+    S = sc.bow_match_scenario(voc, ov.transform, 700, 2500, 3, two_cam=True, levelsup=5)
+    assert len(S["f"]["fv_nodes"]) == 1
+    for ori in (False, True):
+        o = ob.search_by_bow(S["kf"], S["has_point"], S["f"], S["nleft"], 0.8, ori)
+        g = orb.search_by_bow(ctx, _bow_side(S["kf"]), S["has_point"], _bow_side(S["f"]), S["nleft"], 0.8, ori)
+        assert o["n"] > 300 and g["n"] == o["n"] and np.array_equal(g["matches"], o["matches"])
+    g = orb.search_by_bow(ctx, _bow_side(S["kf"]), np.zeros(700, np.uint8), _bow_side(S["f"]), -1)
+    assert g["n"] == 0 and (g["matches"] == -1).all()
+    for nk, nf in ((0, 40), (40, 0)):
+        E = sc.bow_match_scenario(voc, ov.transform, nk, nf, 1)
+        g = orb.search_by_bow(ctx, _bow_side(E["kf"]), E["has_point"], _bow_side(E["f"]), -1)
+        assert g["n"] == 0 and len(g["matches"]) == nf
+    bad = dict(S["f"]); bad["fv_features"] = S["f"]["fv_features"].copy(); bad["fv_features"][3] = 1 << 21
+    with pytest.raises(Exception):
+        orb.search_by_bow(ctx, _bow_side(S["kf"]), S["has_point"], _bow_side(bad), -1)
+    with pytest.raises(Exception):
+        orb.search_by_bow(ctx, _bow_side(S["kf"]), S["has_point"], _bow_side(S["f"]), 5000)
+    gv.close()
+

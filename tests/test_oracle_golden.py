@@ -57,3 +57,17 @@ def test_search_vectors(golden_dir):
     la = ob.search_last_frame(F2, last, g["lf_Tcw"], float(g["lf_th"]), False, False, True)
     assert la["n"] == int(g["lf_n"]) and np.array_equal(la["assign"], g["lf_assign"])
     assert np.array_equal(la["best_dist"], g["lf_best_dist"]) and np.array_equal(la["best_idx"], g["lf_best_idx"])
+
+
+def test_bow_match_vectors(golden_dir):
+    g = _load(golden_dir, "bow_match_s6.npz")
+    total = 0
+    for tag in ("mono", "two"):
+        kf = {k: g[f"{tag}_kf_{k}"] for k in ("fv_nodes", "fv_offsets", "fv_features", "descriptors", "angles")}
+        f = {k: g[f"{tag}_f_{k}"] for k in ("fv_nodes", "fv_offsets", "fv_features", "descriptors", "angles")}
+        for ori in (0, 1):
+            r = ob.search_by_bow(kf, g[f"{tag}_has_point"], f, int(g[f"{tag}_nleft"]), 0.7, bool(ori))
+            assert r["n"] == int(g[f"{tag}_n_ori{ori}"]) and np.array_equal(r["matches"], g[f"{tag}_matches_ori{ori}"])
+            total += r["n"]
+    assert total > 300
+

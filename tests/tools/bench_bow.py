@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Latency of Frame::ComputeBoW (ft_bow_transform) on a vocabulary of ORBvoc.txt's shape (k = 10, L = 6: 1.1 M nodes,
-10^6 words) for the descriptors of one frame, against the oracle (DBoW2's transform restated) on one host core."""
+10^6 words) for the descriptors of one frame, against the oracle (DBoW2's transform restated) on one host core - and of
+ORBmatcher::SearchByBoW (ft_search_by_bow) between two such frames (left / right image of a pair as keyframe / frame)."""
 import json
 import os
 import sys
@@ -43,6 +44,19 @@ def main():
             "device_ms_resident_descriptors": med(lambda: gv.transform(None, 4, device_ptr=dptr, n=len(d)), 50),
             "oracle_1_core_ms": med(lambda: ov.transform(d, 4), 10),
             "bow_entries": int(len(a["bow_ids"])), "feature_vector_nodes": int(len(a["fv_nodes"]))}
+        # SearchByBoW: the right image's features as the keyframe, the left image's as the frame
+        dR, kR, kL = o["descR"], o["keysR"], o["keysL"]
+        tR = gv.transform(dR, 4)
+        has = np.ones(len(dR), np.uint8)
+        gK = orb.BowSide(tR["fv_nodes"], tR["fv_offsets"], tR["fv_features"], dR, kR["angle"])
+        gF = orb.BowSide(a["fv_nodes"], a["fv_offsets"], a["fv_features"], d, kL["angle"])
+        oK = dict(tR, descriptors=dR, angles=kR["angle"]); oF = dict(a, descriptors=d, angles=kL["angle"])
+        g, oo = orb.search_by_bow(ctx, gK, has, gF), ob.search_by_bow(oK, has, oF)
+        assert g["n"] == oo["n"] and np.array_equal(g["matches"], oo["matches"])
+        out["n%d" % len(d)]["search_by_bow"] = {
+            "device_ms": med(lambda: orb.search_by_bow(ctx, gK, has, gF), 50),
+            "oracle_1_core_ms": med(lambda: ob.search_by_bow(oK, has, oF), 20), "matches": int(g["n"]),
+            "common_nodes": int(len(np.intersect1d(tR["fv_nodes"], a["fv_nodes"])))}
         fe.close()
     out["note"] = "median wall time per call including the Python marshalling"
     print(json.dumps(out))

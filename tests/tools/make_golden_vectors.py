@@ -68,6 +68,24 @@ def search_case(name, w, h, nf, seed):
                         lf_n=la["n"], lf_best_dist=la["best_dist"], lf_best_idx=la["best_idx"])
 
 
+def bow_match_case(name, seed=6):
+    """ORBmatcher::SearchByBoW on a seeded keyframe / frame pair (both FeatureVectors in CSR form, one- and two-camera
+    frames, with and without the rotation histogram): the oracle's assignments"""
+    voc = synth.make_vocabulary(8, 4, seed=seed)
+    ov = ob.Vocabulary(8, 4, 0, 0, voc["parent"], voc["is_leaf"], voc["descriptors"], voc["weights"])
+    out = {}
+    for tag, two in (("mono", False), ("two", True)):
+        S = sc.bow_match_scenario(voc, ov.transform, 400, 500, seed, two_cam=two, levelsup=2)
+        for side in ("kf", "f"):
+            for k, v in S[side].items():
+                out[f"{tag}_{side}_{k}"] = v
+        out[f"{tag}_has_point"], out[f"{tag}_nleft"] = S["has_point"], S["nleft"]
+        for ori in (0, 1):
+            r = ob.search_by_bow(S["kf"], S["has_point"], S["f"], S["nleft"], 0.7, bool(ori))
+            out[f"{tag}_matches_ori{ori}"], out[f"{tag}_n_ori{ori}"] = r["matches"], r["n"]
+    np.savez_compressed(os.path.join(G, name), **out)
+
+
 def libm_case(name, seed=1):
     """The rBRIEF rotation binds to libm's cosf / sinf, PredictScale to logf (glibc 2.35 in this image).  48 angles at
     which cosf / sinf (not correctly rounded) make computeOrbDescriptor sample a different pixel than the narrowed double
@@ -152,6 +170,7 @@ def kb8_libm_case(name, seed=2, n=256):
 if __name__ == "__main__":
     libm_case("libm_rotation_glibc235.npz")
     kb8_libm_case("libm_kb8_glibc235.npz")
+    bow_match_case("bow_match_s6.npz")
     extract_case("extract_160x120_s1.npz", 160, 120, 300, 4, 1)
     extract_case("extract_320x240_s2_lap.npz", 320, 240, 500, 8, 2, lap=(100, 200))
     stereo_case("stereo_320x240_s3.npz", 320, 240, 500, 3)
