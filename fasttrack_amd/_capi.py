@@ -57,6 +57,11 @@ class FisheyeRig(C.Structure):
                 ("tlr", C.c_float * 3)]
 
 
+class SE3(C.Structure):
+    """ft_se3: unit quaternion (x, y, z, w) and translation, as Sophus::SE3f holds a pose"""
+    _fields_ = [("q", C.c_float * 4), ("t", C.c_float * 3)]
+
+
 class BowSide(C.Structure):
     """ft_bow_side: a DBoW2 FeatureVector in CSR form with the descriptors / angles it indexes"""
     _fields_ = [("n", C.c_int), ("n_nodes", C.c_int), ("fv_nodes", C.c_void_p), ("fv_offsets", C.c_void_p),
@@ -190,6 +195,9 @@ def lib() -> C.CDLL:
     L.ft_tracked_frame_upload.argtypes = [vp, C.POINTER(FrameView)]
     L.ft_tracked_frame_bind_stereo.argtypes = [vp, vp, i, C.POINTER(FrameView)]
     L.ft_tracked_frame_search_last_frame.argtypes = [vp, C.POINTER(LastPoints), vp, f, i, i, i, vp, ip]
+    L.ft_tracked_frame_search_last_frame_se3.argtypes = [vp, C.POINTER(LastPoints), C.POINTER(SE3), C.POINTER(SE3), f, i, i, i, vp, ip]
+    L.ft_search_last_frame_se3.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LastPoints), C.POINTER(SE3), C.POINTER(SE3), f, i, i,
+                                           i, vp, ip] + [vp] * 4
     L.ft_tracked_frame_track_local_map.argtypes = [vp, C.POINTER(FramePose), C.POINTER(MapPoints), f, f, f, f, i, f,
                                                    C.POINTER(FrustumResult), ip, vp, ip]
     L.ft_tracked_frame_holder_obs.argtypes = [vp, vp]

@@ -14,6 +14,8 @@ struct FtDevFrame {
     int camModel;
     float cam[8];
     float Trl[12];
+    float TrlQ[4];  // trlQuat != 0: GetRelativePoseTrl() in the Sophus form (translation in Trl[3], [7], [11])
+    int trlQuat;
     float sf[FT_MAX_LEVELS];
     int nlevels;
     // Frame::mGrid as one CSR per octave (k_build_grid; AssignFeaturesToGrid src/Frame.cc:409-440): the keypoints of octave o
@@ -90,8 +92,12 @@ struct FtPersist {
 };
 #define FT_PERSIST_STATUS_TIMEOUT (-2)
 
+// a rigid transform: row-major 3x4 (y = R x + t), or - quat != 0 - as Sophus::SE3f holds and applies it: unit quaternion
+// q = (x, y, z, w), translation in m[3], m[7], m[11] (transform_pose, kernels_search.hip)
 struct FtPose {
     float m[12];
+    float q[4];
+    int quat;
 };
 
 struct FtLocalRaw {

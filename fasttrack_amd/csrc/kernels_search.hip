@@ -627,6 +627,28 @@ __device__ __forceinline__ void transform34(const float *T, const float x[3], fl
                          T[4 * r + 3]);
 }
 
+// Sophus::SE3f * point as the reference's CPU branch evaluates `Tcw * x3Dw` (src/ORBmatcher.cc:1805) and `GetRelativePoseTrl() *
+// x3Dc` (:1900): Thirdparty/Sophus/sophus/so3.hpp:358-367 - uv = q.vec().cross(p); uv += uv; p + q.w() * uv + q.vec().cross(uv) -
+// then + translation (se3.hpp:321-324); every product and sum rounded on its own, coefficient order as Eigen's cross()
+__device__ __forceinline__ void cross3_rn(const float a[3], const float b[3], float c[3]) {
+    c[0] = __fsub_rn(__fmul_rn(a[1], b[2]), __fmul_rn(a[2], b[1]));
+    c[1] = __fsub_rn(__fmul_rn(a[2], b[0]), __fmul_rn(a[0], b[2]));
+    c[2] = __fsub_rn(__fmul_rn(a[0], b[1]), __fmul_rn(a[1], b[0]));
+}
+__device__ __forceinline__ void transform_pose(const float *m, const float *q, int quat, const float x[3], float y[3]) {
+    if (!quat) {
+        transform34(m, x, y);
+        return;
+    }
+    float uv[3], c[3];
+    cross3_rn(q, x, uv);
+#pragma unroll
+    for (int i = 0; i < 3; i++) uv[i] = __fadd_rn(uv[i], uv[i]);
+    cross3_rn(q, uv, c);
+#pragma unroll
+    for (int i = 0; i < 3; i++) y[i] = __fadd_rn(__fadd_rn(__fadd_rn(x[i], __fmul_rn(q[3], uv[i])), c[i]), m[4 * i + 3]);
+}
+
 // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) for last-frame point i by one wave (src/ORBmatcher.cc:
 // 1775-1960): r = (left keypoint written, -1, right keypoint written, -1)
 __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastPoints &Lp, const FtClaims &C, const FtPose &Tcw,
@@ -637,7 +659,7 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
     if (Lp.valid[i]) {
         float xw[3] = {Lp.worldPos[3 * i], Lp.worldPos[3 * i + 1], Lp.worldPos[3 * i + 2]};
         float xc[3];
-        transform34(Tcw.m, xw, xc);
+        transform_pose(Tcw.m, Tcw.q, Tcw.quat, xw, xc);
         const float invzc = (float)(1.0 / (double)xc[2]);
         float uv[2];
         bool go = !(invzc < 0);
@@ -711,7 +733,7 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                 if (bd <= FT_TH_HIGH) primL = bi;
                 if (F.Nleft != -1) {
                     float xr[3], uvr[2];
-                    transform34(F.Trl, xc, xr);
+                    transform_pose(F.Trl, F.TrlQ, F.trlQuat, xc, xr);
                     project_cam(F, xr, uvr);
                     const Window wr = cell_window(F, uvr[0], uvr[1], radius);
                     const int nRight = F.N - F.Nleft;

@@ -640,10 +640,37 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     return FT_OK;
 }
 
-int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_points *L, const float *Tcw, float th,
-                         int forward, int backward, int check_orientation, int *assign, int *n_matches,
-                         int *best_dist, int *best_idx, int *best_dist_r, int *best_idx_r) {
-    FT_REQUIRE(ctx && L && Tcw && assign, "ft_search_last_frame: null argument");
+namespace {
+FtPose poseOfMatrix(const float *T) {
+    FtPose p;
+    memset(&p, 0, sizeof p);
+    memcpy(p.m, T, sizeof p.m);
+    return p;
+}
+int poseOfSe3(const ft_se3 *T, FtPose &p) {
+    memset(&p, 0, sizeof p);
+    const float n2 = T->q[0] * T->q[0] + T->q[1] * T->q[1] + T->q[2] * T->q[2] + T->q[3] * T->q[3];
+    if (!(n2 > 0.99f && n2 < 1.01f)) {
+        ft_set_error("ft_se3: q is not a unit quaternion (x, y, z, w)");
+        return FT_ERR_INVALID;
+    }
+    p.m[0] = p.m[5] = p.m[10] = 1.f;
+    p.m[3] = T->t[0]; p.m[7] = T->t[1]; p.m[11] = T->t[2];
+    memcpy(p.q, T->q, sizeof p.q);
+    p.quat = 1;
+    return FT_OK;
+}
+// the right camera's pose of a frame in the Sophus form, in place of the matrix of its view
+void setTrl(FtDevFrame &DF, const FtPose &trl) {
+    memcpy(DF.Trl, trl.m, sizeof DF.Trl);
+    memcpy(DF.TrlQ, trl.q, sizeof DF.TrlQ);
+    DF.trlQuat = trl.quat;
+}
+
+int searchLastFrame(ft_context *ctx, ft_frame_view *Cur, const ft_last_points *L, const FtPose &pose, const FtPose *trl, float th,
+                    int forward, int backward, int check_orientation, int *assign, int *n_matches, int *best_dist, int *best_idx,
+                    int *best_dist_r, int *best_idx_r) {
+    FT_REQUIRE(ctx && L && assign, "ft_search_last_frame: null argument");
     int rc = checkFrame(Cur);
     if (rc != FT_OK) return rc;
     const int M = L->N, N = Cur->N;
@@ -688,6 +715,7 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     hipStream_t st = ctx->stream;
     FT_HIP(hipMemcpyAsync(dev, pin, inputBytes, hipMemcpyHostToDevice, st));
     FtDevFrame DF = devFrame(Cur, FL, dev);
+    if (trl) setTrl(DF, *trl);
     rc = buildGrid(ctx, st, DF, (int *)(dev + oGrid));
     if (rc != FT_OK) return rc;
     FtDevLastPoints DL;
@@ -698,8 +726,6 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     DL.octave = (const int *)(dev + oOct);
     FtClaims C;
     C.obs = (const int *)(dev + oObs);
-    FtPose pose;
-    memcpy(pose.m, Tcw, sizeof pose.m);
     int *rawBase = (int *)(dev + oRaw);
     FtLastRaw raw;
     raw.bestDist = rawBase; raw.bestIdx = rawBase + M; raw.bestDistR = rawBase + 2 * M; raw.bestIdxR = rawBase + 3 * M;
@@ -726,6 +752,28 @@ int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_poin
     ctx->addStat("search_last_frame.total", tAll.ms());
     ctx->addStat("search_last_frame.passes", passes);
     return FT_OK;
+}
+}  // namespace
+
+int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_last_points *L, const float *Tcw, float th,
+                         int forward, int backward, int check_orientation, int *assign, int *n_matches,
+                         int *best_dist, int *best_idx, int *best_dist_r, int *best_idx_r) {
+    FT_REQUIRE(Tcw, "ft_search_last_frame: null pose");
+    return searchLastFrame(ctx, Cur, L, poseOfMatrix(Tcw), nullptr, th, forward, backward, check_orientation, assign, n_matches,
+                           best_dist, best_idx, best_dist_r, best_idx_r);
+}
+
+int ft_search_last_frame_se3(ft_context *ctx, ft_frame_view *Cur, const ft_last_points *L, const ft_se3 *Tcw, const ft_se3 *Trl,
+                             float th, int forward, int backward, int check_orientation, int *assign, int *n_matches,
+                             int *best_dist, int *best_idx, int *best_dist_r, int *best_idx_r) {
+    FT_REQUIRE(Tcw && Cur, "ft_search_last_frame_se3: null argument");
+    FT_REQUIRE(Trl || Cur->Nleft == -1, "ft_search_last_frame_se3: a two-camera frame needs Trl");
+    FtPose pose, trl;
+    int rc = poseOfSe3(Tcw, pose);
+    if (rc == FT_OK && Trl) rc = poseOfSe3(Trl, trl);
+    if (rc != FT_OK) return rc;
+    return searchLastFrame(ctx, Cur, L, pose, Trl ? &trl : nullptr, th, forward, backward, check_orientation, assign, n_matches,
+                           best_dist, best_idx, best_dist_r, best_idx_r);
 }
 
 int ft_features_in_area(ft_context *ctx, const ft_frame_view *F, int nq, const float *x, const float *y, const float *r,
@@ -992,9 +1040,10 @@ int ft_tracked_frame_holder_obs(ft_tracked_frame *tf, int *holder_obs) {
     return FT_OK;
 }
 
-int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_points *L, const float *Tcw, float th,
-                                       int forward, int backward, int check_orientation, int *assign, int *n_matches) {
-    FT_REQUIRE(tf && tf->loaded && L && Tcw && assign, "ft_tracked_frame_search_last_frame: null argument / no frame loaded");
+namespace {
+int trackedSearchLastFrame(ft_tracked_frame *tf, const ft_last_points *L, const FtPose &pose, const FtPose *trl, float th,
+                           int forward, int backward, int check_orientation, int *assign, int *n_matches) {
+    FT_REQUIRE(tf && tf->loaded && L && assign, "ft_tracked_frame_search_last_frame: null argument / no frame loaded");
     ft_context *ctx = tf->ctx;
     const int M = L->N, N = tf->DF.N;
     FT_REQUIRE(M >= 0 && M <= tf->maxPts, "last-frame point count beyond the frame's capacity");
@@ -1031,11 +1080,10 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     DL.octave = (const int *)(dev + oOct);
     FtClaims C;
     C.obs = (const int *)(dev + oObs);
-    FtPose pose;
-    memcpy(pose.m, Tcw, sizeof pose.m);
     FtLastRaw raw = {nullptr, nullptr, nullptr, nullptr};
     int *resFinal = nullptr, passes = 0;
-    const FtDevFrame DF = tf->DF;
+    FtDevFrame DF = tf->DF;
+    if (trl) setTrl(DF, *trl);
     rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs, tf->d_cache), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
                     [&](const FtPersist &S) { return ft_launch_search_last_persist(st, DF, DL, C, pose, th, forward, backward, S, raw); },
@@ -1055,6 +1103,24 @@ int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_point
     ctx->addStat("tracked.search_last_frame.total", tAll.ms());
     ctx->addStat("tracked.search_last_frame.passes", passes);
     return FT_OK;
+}
+}  // namespace
+
+int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_points *L, const float *Tcw, float th,
+                                       int forward, int backward, int check_orientation, int *assign, int *n_matches) {
+    FT_REQUIRE(Tcw, "ft_tracked_frame_search_last_frame: null pose");
+    return trackedSearchLastFrame(tf, L, poseOfMatrix(Tcw), nullptr, th, forward, backward, check_orientation, assign, n_matches);
+}
+
+int ft_tracked_frame_search_last_frame_se3(ft_tracked_frame *tf, const ft_last_points *L, const ft_se3 *Tcw, const ft_se3 *Trl,
+                                           float th, int forward, int backward, int check_orientation, int *assign, int *n_matches) {
+    FT_REQUIRE(tf && tf->loaded && Tcw, "ft_tracked_frame_search_last_frame_se3: null argument / no frame loaded");
+    FT_REQUIRE(Trl || tf->DF.Nleft == -1, "ft_tracked_frame_search_last_frame_se3: a two-camera frame needs Trl");
+    FtPose pose, trl;
+    int rc = poseOfSe3(Tcw, pose);
+    if (rc == FT_OK && Trl) rc = poseOfSe3(Trl, trl);
+    if (rc != FT_OK) return rc;
+    return trackedSearchLastFrame(tf, L, pose, Trl ? &trl : nullptr, th, forward, backward, check_orientation, assign, n_matches);
 }
 
 int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *pose, const ft_map_points *P,

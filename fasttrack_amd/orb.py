@@ -388,8 +388,9 @@ class KernelController:
 
     @staticmethod
     def launchPoseEstimationKernel(ctx: Context, Cur: FrameView, last: dict, Tcw, th, forward=False, backward=False,
-                                   check_orientation=True):
-        """KernelController.h:44-46 + the histogram loop of ORBmatcher.cc:2013-2081."""
+                                   check_orientation=True, Trl=None):
+        """KernelController.h:44-46 + the histogram loop of ORBmatcher.cc:2013-2081.  Tcw: 3x4 matrix, or an SE3 (then Trl, an
+        SE3 as well, is the right camera's pose of a two-camera frame): the CPU branch's Sophus arithmetic."""
         N = len(last["valid"])
         keep = {}
 
@@ -402,12 +403,17 @@ class KernelController:
         Lp.valid, Lp.world_pos = arr("valid", np.uint8), arr("world_pos", np.float32)
         Lp.descriptors, Lp.observations = arr("descriptors", np.uint8), arr("observations", np.int32)
         Lp.octave, Lp.angle = arr("octave", np.int32), arr("angle", np.float32)
-        T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(3, 4))
         assign = np.zeros(max(Cur.N, 1), np.int32)
         outs = [np.zeros(max(N, 1), np.int32) for _ in range(4)]
         nm = C.c_int()
-        check(lib().ft_search_last_frame(ctx._h, C.byref(Cur.c), C.byref(Lp), ptr(T), th, int(forward), int(backward),
-                                         int(check_orientation), ptr(assign), C.byref(nm), *[ptr(o) for o in outs]))
+        if isinstance(Tcw, SE3):  # the Sophus form the reference's CPU branch multiplies with (ft_search_last_frame_se3)
+            check(lib().ft_search_last_frame_se3(ctx._h, C.byref(Cur.c), C.byref(Lp), C.byref(Tcw.c), None if Trl is None else C.byref(Trl.c),
+                                                 th, int(forward), int(backward), int(check_orientation), ptr(assign), C.byref(nm),
+                                                 *[ptr(o) for o in outs]))
+        else:
+            T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(3, 4))
+            check(lib().ft_search_last_frame(ctx._h, C.byref(Cur.c), C.byref(Lp), ptr(T), th, int(forward), int(backward),
+                                             int(check_orientation), ptr(assign), C.byref(nm), *[ptr(o) for o in outs]))
         names = ["best_dist", "best_idx", "best_dist_r", "best_idx_r"]
         r = {k: o[:N] for k, o in zip(names, outs)}
         r["assign"], r["n"] = assign[:Cur.N], nm.value
@@ -637,7 +643,7 @@ class TrackedFrame:
         check(lib().ft_tracked_frame_holder_obs(self._h, ptr(out)))
         return out[:self.N]
 
-    def search_last_frame(self, last: dict, Tcw, th, forward=False, backward=False, check_orientation=True):
+    def search_last_frame(self, last: dict, Tcw, th, forward=False, backward=False, check_orientation=True, Trl=None):
         N = len(last["valid"])
         keep = {k: np.ascontiguousarray(last[k], dt) for k, dt in
                 (("valid", np.uint8), ("world_pos", np.float32), ("descriptors", np.uint8), ("observations", np.int32),
@@ -646,11 +652,16 @@ class TrackedFrame:
         Lp.N = N
         for k in keep:
             setattr(Lp, k, ptr(keep[k]))
-        T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(3, 4))
         assign = np.zeros(max(self.N, 1), np.int32)
         n = C.c_int()
-        check(lib().ft_tracked_frame_search_last_frame(self._h, C.byref(Lp), ptr(T), th, int(forward), int(backward),
-                                                       int(check_orientation), ptr(assign), C.byref(n)))
+        if isinstance(Tcw, SE3):
+            check(lib().ft_tracked_frame_search_last_frame_se3(self._h, C.byref(Lp), C.byref(Tcw.c), None if Trl is None else C.byref(Trl.c),
+                                                               th, int(forward), int(backward), int(check_orientation), ptr(assign),
+                                                               C.byref(n)))
+        else:
+            T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(3, 4))
+            check(lib().ft_tracked_frame_search_last_frame(self._h, C.byref(Lp), ptr(T), th, int(forward), int(backward),
+                                                           int(check_orientation), ptr(assign), C.byref(n)))
         return dict(assign=assign[:self.N], n=n.value)
 
     def track_local_map(self, pose, pts: dict, viewing_cos_limit, log_scale_factor, th, nn_ratio=0.8, far_points=False,
@@ -687,6 +698,17 @@ def fisheye_stereo(ctx: Context, cam1, cam2, Rlr, tlr, descL, keysL, descR, keys
     check(lib().ft_fisheye_stereo(ctx._h, C.byref(rig), ptr(descL), ptr(keysL), nL, ptr(descR), ptr(keysR), nR, ptr(ls2),
                                   len(ls2), ptr(m), ptr(d), ptr(p), C.byref(n)))
     return dict(matches=m[:nL], depth=d[:nL], p3d=p[:nL], n=n.value)
+
+
+class SE3:
+    """A pose as Sophus::SE3f holds it: unit quaternion (x, y, z, w = Eigen::Quaternionf::coeffs()) and translation"""
+
+    def __init__(self, q, t):
+        self.q = np.ascontiguousarray(q, np.float32).reshape(4)
+        self.t = np.ascontiguousarray(t, np.float32).reshape(3)
+        self.c = _capi.SE3()
+        self.c.q[:] = [float(v) for v in self.q]
+        self.c.t[:] = [float(v) for v in self.t]
 
 
 class BowSide:

@@ -23,6 +23,15 @@ def random_pose(rng, trans=0.05, rot=0.01):
 
 
 
+def random_se3(rng, trans=0.05, rot=0.01):
+    """the same kind of step as (q, t): unit quaternion x y z w (float32) and translation, as Sophus::SE3f holds a pose"""
+    w = rng.normal(0, rot, 3)
+    th = np.linalg.norm(w)
+    axis = w / th if th > 1e-12 else np.array([1.0, 0.0, 0.0])
+    q = np.concatenate([np.sin(th / 2) * axis, [np.cos(th / 2)]]).astype(np.float32)
+    return q, rng.normal(0, trans, 3).astype(np.float32)
+
+
 def local_points_scenario(keys, desc, sf, width, height, seed, M=1500, zero_obs_frac=0.15, uright=None,
                           mbf=40.0, dense=False):
     """Local map points built from a frame's own keypoints: projections jittered around keypoints,

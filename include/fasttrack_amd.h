@@ -371,6 +371,23 @@ FT_API int ft_search_last_frame(ft_context *ctx, ft_frame_view *Cur, const ft_la
                                 int *n_matches, int *best_dist, int *best_idx, int *best_dist_r,
                                 int *best_idx_r);
 
+/* The same search with the poses in the form the reference's CPU branch multiplies with.  CurrentFrame.GetPose() and
+ * GetRelativePoseTrl() are Sophus::SE3f: a unit quaternion and a translation, applied to a point as
+ * Thirdparty/Sophus/sophus/so3.hpp:358-367 + se3.hpp:321-324 do (uv = 2 (q.vec x p); p + w uv + q.vec x uv; + t) - NOT as a
+ * matrix product; the two differ in the last bits of the projected point, i.e. in whether a keypoint that sits within ~1e-4 px
+ * of a search window's edge is a candidate.  ft_search_last_frame (3x4 matrices, y = R x + t) is the form the reference's GPU
+ * boundary takes (Eigen::Matrix4f transform_matrix, include/Kernels/KernelController.h:44-46); this one reproduces
+ * `Tcw * x3Dw` (src/ORBmatcher.cc:1805) and `GetRelativePoseTrl() * x3Dc` (:1900) of the CPU branch operation for operation.
+ * q = Eigen::Quaternionf::coeffs() = (x, y, z, w) of so3().unit_quaternion(); Trl may be NULL when Cur->Nleft == -1 (Cur->Trl is
+ * not read by this call). */
+typedef struct ft_se3 {
+    float q[4];
+    float t[3];
+} ft_se3;
+FT_API int ft_search_last_frame_se3(ft_context *ctx, ft_frame_view *Cur, const ft_last_points *L, const ft_se3 *Tcw,
+                                    const ft_se3 *Trl, float th, int forward, int backward, int check_orientation, int *assign,
+                                    int *n_matches, int *best_dist, int *best_idx, int *best_dist_r, int *best_idx_r);
+
 /* ------------------------------------------------------------------------------------------------
  * Frustum test + scale prediction for the local map points: Frame::isInFrustum /
  * isInFrustumChecks (src/Frame.cc:536-610, 1308-1382) with MapPoint::PredictScale (src/MapPoint.cc:531-546),
@@ -436,6 +453,10 @@ FT_API int ft_tracked_frame_bind_stereo(ft_tracked_frame *tf, ft_stereo_frontend
 FT_API int ft_tracked_frame_search_last_frame(ft_tracked_frame *tf, const ft_last_points *L, const float *Tcw, float th,
                                               int forward, int backward, int check_orientation, int *assign,
                                               int *n_matches);
+/* the Sophus form of the poses (see ft_search_last_frame_se3) on the resident frame */
+FT_API int ft_tracked_frame_search_last_frame_se3(ft_tracked_frame *tf, const ft_last_points *L, const ft_se3 *Tcw,
+                                                  const ft_se3 *Trl, float th, int forward, int backward,
+                                                  int check_orientation, int *assign, int *n_matches);
 /* Tracking::SearchLocalPoints on the resident frame: isInFrustum (viewing_cos_limit, log_scale_factor) for all
  * points, then SearchByProjection(F, points, th, far_points, th_far_points) on the device-resident results.
  * frustum (may be NULL) receives the isInFrustum fields; assign / n_matches as in ft_search_local_points. */

@@ -225,7 +225,34 @@ struct KernelController {
         assign.resize(CurrentFrame.N);
         return nm;
     }
+    // The same with the poses as the CPU branch multiplies with them (Sophus::SE3f: `Tcw * x3Dw`, ORBmatcher.cc:1805, is a
+    // quaternion rotation): Tcw = se3Of(CurrentFrame.GetPose()), Trl = se3Of(CurrentFrame.GetRelativePoseTrl()) or nullptr for
+    // one camera.  Bit-for-bit the CPU branch; the matrix overload above is the reference's GPU boundary.
+    static int launchPoseEstimationKernel(Context &ctx, ft_frame_view &CurrentFrame, const ft_last_points &LastFrame,
+                                          float th, bool bForward, bool bBackward, const ft_se3 &Tcw, const ft_se3 *Trl,
+                                          bool mbCheckOrientation, std::vector<int> &assign, int *h_bestDist,
+                                          int *h_bestIdx2, int *h_bestDistR, int *h_bestIdxR2) {
+        assign.assign(CurrentFrame.N > 0 ? CurrentFrame.N : 1, -1);
+        int nm = 0;
+        check(ft_search_last_frame_se3(ctx.handle(), &CurrentFrame, &LastFrame, &Tcw, Trl, th, bForward ? 1 : 0, bBackward ? 1 : 0,
+                                       mbCheckOrientation ? 1 : 0, assign.data(), &nm, h_bestDist, h_bestIdx2, h_bestDistR,
+                                       h_bestIdxR2));
+        assign.resize(CurrentFrame.N);
+        return nm;
+    }
 };
+
+// ft_se3 of a Sophus::SE3f (or anything with unit_quaternion().coeffs() = x y z w and translation()): the pose form of the
+// CPU branch's point transforms
+template <class SE3f>
+inline ft_se3 se3Of(const SE3f &T) {
+    ft_se3 r;
+    const auto q = T.unit_quaternion().coeffs();
+    const auto t = T.translation();
+    for (int i = 0; i < 4; i++) r.q[i] = q[i];
+    for (int i = 0; i < 3; i++) r.t[i] = t[i];
+    return r;
+}
 
 // Frame::isInFrustum for all local map points (src/Frame.cc:536-610, 1308-1382; the loop of
 // src/Tracking.cc:3503-3522).  The vectors receive the MapPoint tracking fields; returns nToMatch.
@@ -285,6 +312,15 @@ public:
         int nm = 0;
         check(ft_tracked_frame_search_last_frame(h_, &LastFrame, Tcw, th, bForward, bBackward, mbCheckOrientation,
                                                  assign.data(), &nm));
+        assign.resize(N_);
+        return nm;
+    }
+    int SearchByProjection(const ft_last_points &LastFrame, const ft_se3 &Tcw, const ft_se3 *Trl, float th, bool bForward,
+                           bool bBackward, bool mbCheckOrientation, std::vector<int> &assign) {
+        assign.assign(N_ > 0 ? N_ : 1, -1);
+        int nm = 0;
+        check(ft_tracked_frame_search_last_frame_se3(h_, &LastFrame, &Tcw, Trl, th, bForward, bBackward, mbCheckOrientation,
+                                                     assign.data(), &nm));
         assign.resize(N_);
         return nm;
     }

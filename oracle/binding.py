@@ -395,8 +395,37 @@ def search_local_points(F: FrameView, pts: dict, th: float, nn_ratio: float = 0.
     return r
 
 
-def search_last_frame(Cur: FrameView, last: dict, Tcw, th, forward=False, backward=False, check_orientation=True):
-    """last: dict(valid, world_pos[N,3], descriptors, observations, octave, angle)."""
+class SE3:
+    """A rigid transform as Sophus::SE3f holds it: unit quaternion (x, y, z, w) and translation, float32"""
+
+    def __init__(self, q, t):
+        self.q = np.ascontiguousarray(q, np.float32).reshape(4)
+        self.t = np.ascontiguousarray(t, np.float32).reshape(3)
+
+    def apply(self, p):
+        """Sophus::SE3f * point through the oracle (orc_se3_transform)"""
+        p = np.ascontiguousarray(p, np.float32).reshape(3)
+        y = np.zeros(3, np.float32)
+        lib().orc_se3_transform.restype = None
+        lib().orc_se3_transform.argtypes = [C.c_void_p] * 4
+        lib().orc_se3_transform(_p(self.q), _p(self.t), _p(p), _p(y))
+        return y
+
+    def matrix(self):
+        """the 3x4 float32 matrix Eigen::Quaternionf::toRotationMatrix gives (for callers of the matrix form)"""
+        x, y, z, w = [np.float32(v) for v in self.q]
+        tx, ty, tz = np.float32(2) * x, np.float32(2) * y, np.float32(2) * z
+        twx, twy, twz, txx, txy, txz, tyy, tyz, tzz = tx * w, ty * w, tz * w, tx * x, ty * x, tz * x, ty * y, tz * y, tz * z
+        one = np.float32(1)
+        R = np.array([[one - (tyy + tzz), txy - twz, txz + twy], [txy + twz, one - (txx + tzz), tyz - twx],
+                      [txz - twy, tyz + twx, one - (txx + tyy)]], np.float32)
+        return np.concatenate([R, self.t.reshape(3, 1)], 1).astype(np.float32)
+
+
+def search_last_frame(Cur: FrameView, last: dict, Tcw, th, forward=False, backward=False, check_orientation=True, Trl=None):
+    """last: dict(valid, world_pos[N,3], descriptors, observations, octave, angle).  Tcw: a 3x4 matrix (y = R x + t, the
+    reference's GPU boundary) or an SE3 (quaternion form, what the CPU branch evaluates; then Trl - an SE3 - replaces Cur's
+    matrix for the right camera)."""
     N = len(last["valid"])
     keep = {}
 
@@ -409,11 +438,19 @@ def search_last_frame(Cur: FrameView, last: dict, Tcw, th, forward=False, backwa
     Lp.valid, Lp.world_pos = arr("valid", np.uint8), arr("world_pos", np.float32)
     Lp.descriptors, Lp.observations = arr("descriptors", np.uint8), arr("observations", np.int32)
     Lp.octave, Lp.angle = arr("octave", np.int32), arr("angle", np.float32)
-    T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(3, 4))
     assign = np.zeros(max(Cur.N, 1), np.int32)
     outs = [np.zeros(max(N, 1), np.int32) for _ in range(4)]
-    n = lib().orc_search_last_frame(C.byref(Cur.c), C.byref(Lp), _p(T), th, int(forward), int(backward),
-                                    int(check_orientation), _p(assign), *[_p(o) for o in outs])
+    if isinstance(Tcw, SE3):  # the Sophus form of the CPU branch; Trl likewise
+        lib().orc_search_last_frame_se3.restype = C.c_int
+        lib().orc_search_last_frame_se3.argtypes = [C.POINTER(Frame), C.POINTER(LastPoints)] + [C.c_void_p] * 4 + \
+            [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+        n = lib().orc_search_last_frame_se3(C.byref(Cur.c), C.byref(Lp), _p(Tcw.q), _p(Tcw.t), None if Trl is None else _p(Trl.q),
+                                            None if Trl is None else _p(Trl.t), th, int(forward), int(backward),
+                                            int(check_orientation), _p(assign), *[_p(o) for o in outs])
+    else:
+        T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(3, 4))
+        n = lib().orc_search_last_frame(C.byref(Cur.c), C.byref(Lp), _p(T), th, int(forward), int(backward),
+                                        int(check_orientation), _p(assign), *[_p(o) for o in outs])
     names = ["best_dist", "best_idx", "best_dist_r", "best_idx_r"]
     r = {k: o[:N] for k, o in zip(names, outs)}
     r["assign"] = assign[:Cur.N]

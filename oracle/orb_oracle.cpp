@@ -1127,9 +1127,32 @@ static void transform34(const float *T, const float x[3], float y[3]) {
 // src/ORBmatcher.cc:1775-1990.  bForward/bBackward (:1794-1795) are inputs, as in the reference's
 // own launchPoseEstimationKernel boundary (include/Kernels/KernelController.h:44-46).
 // ------------------------------------------------------------------------------------------------
-int orc_search_last_frame(orc_frame *Cur, const orc_last_points *Lp, const float *Tcw, float th, int bForward,
-                          int bBackward, int check_orientation, int *assign, int *o_bd, int *o_bi, int *o_bdr,
-                          int *o_bir) {
+// Sophus::SE3f * point as the CPU branch evaluates `Tcw * x3Dw` (src/ORBmatcher.cc:1805) and `GetRelativePoseTrl() * x3Dc`
+// (:1900): Sophus::SE3Base::operator*(point) = so3() * p + translation() (Thirdparty/Sophus/sophus/se3.hpp:321-324) with
+// SO3Base::operator*(point) (so3.hpp:358-367): uv = q.vec().cross(p); uv += uv; return p + q.w() * uv + q.vec().cross(uv).
+// Eigen's cross() (Eigen/src/Geometry/OrthoMethods.h) returns the evaluated vector (a1 b2 - a2 b1, a2 b0 - a0 b2,
+// a0 b1 - a1 b0); the sum is coefficient-wise (p + w uv) + cross.  q = (x, y, z, w) = Eigen::Quaternionf::coeffs().
+static void cross3(const float a[3], const float b[3], float c[3]) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+void orc_se3_transform(const float q[4], const float t[3], const float p[3], float y[3]) {
+    float uv[3], c[3];
+    cross3(q, p, uv);
+    for (int i = 0; i < 3; i++) uv[i] = uv[i] + uv[i];
+    cross3(q, uv, c);
+    for (int i = 0; i < 3; i++) {
+        const float r = (p[i] + q[3] * uv[i]) + c[i];
+        y[i] = r + t[i];
+    }
+}
+
+extern "C++" {
+template <class TcwFn, class TrlFn>
+static int searchLastFrameImpl(orc_frame *Cur, const orc_last_points *Lp, TcwFn applyTcw, TrlFn applyTrl, float th, int bForward,
+                               int bBackward, int check_orientation, int *assign, int *o_bd, int *o_bi, int *o_bdr,
+                               int *o_bir) {
     OrcGrid *g = new OrcGrid();
     buildGrid(Cur, *g);
     for (int i = 0; i < Cur->N; i++) assign[i] = -1;
@@ -1144,7 +1167,7 @@ int orc_search_last_frame(orc_frame *Cur, const orc_last_points *Lp, const float
         if (o_bdr) { o_bdr[i] = 256; o_bir[i] = -1; }
         if (!Lp->valid[i]) continue;
         float x3Dc[3];
-        transform34(Tcw, Lp->world_pos + 3 * i, x3Dc);
+        applyTcw(Lp->world_pos + 3 * i, x3Dc);
         const float invzc = 1.0 / x3Dc[2];
         if (invzc < 0) continue;
         float uv[2];
@@ -1185,7 +1208,7 @@ int orc_search_last_frame(orc_frame *Cur, const orc_last_points *Lp, const float
         }
         if (Cur->Nleft != -1) {
             float x3Dr[3];
-            transform34(Cur->Trl, x3Dc, x3Dr);
+            applyTrl(x3Dc, x3Dr);
             float uvr[2];
             projectCam(Cur, x3Dr, uvr);
             float radiusR = th * Cur->scale_factors[nLastOctave];
@@ -1229,6 +1252,27 @@ int orc_search_last_frame(orc_frame *Cur, const orc_last_points *Lp, const float
     }
     delete g;
     return nmatches;
+}
+}  // extern "C++"
+
+// the pose as a row-major 3x4 matrix, y = R x + t (the form the reference's GPU boundary takes: Eigen::Matrix4f
+// transform_matrix, include/Kernels/KernelController.h:44-46)
+int orc_search_last_frame(orc_frame *Cur, const orc_last_points *Lp, const float *Tcw, float th, int bForward,
+                          int bBackward, int check_orientation, int *assign, int *o_bd, int *o_bi, int *o_bdr,
+                          int *o_bir) {
+    return searchLastFrameImpl(
+        Cur, Lp, [&](const float *x, float *y) { transform34(Tcw, x, y); }, [&](const float *x, float *y) { transform34(Cur->Trl, x, y); },
+        th, bForward, bBackward, check_orientation, assign, o_bd, o_bi, o_bdr, o_bir);
+}
+
+// the poses as Sophus::SE3f holds and applies them - what the CPU branch computes (q = x y z w; trl may be NULL for one camera)
+int orc_search_last_frame_se3(orc_frame *Cur, const orc_last_points *Lp, const float *q_tcw, const float *t_tcw, const float *q_trl,
+                              const float *t_trl, float th, int bForward, int bBackward, int check_orientation, int *assign,
+                              int *o_bd, int *o_bi, int *o_bdr, int *o_bir) {
+    return searchLastFrameImpl(
+        Cur, Lp, [&](const float *x, float *y) { orc_se3_transform(q_tcw, t_tcw, x, y); },
+        [&](const float *x, float *y) { orc_se3_transform(q_trl, t_trl, x, y); }, th, bForward, bBackward, check_orientation, assign,
+        o_bd, o_bi, o_bdr, o_bir);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -151,6 +151,13 @@ typedef struct orc_last_points {
 int orc_search_last_frame(orc_frame *Cur, const orc_last_points *L, const float *Tcw, float th, int forward,
                           int backward, int check_orientation, int *assign, int *best_dist, int *best_idx,
                           int *best_dist_r, int *best_idx_r);
+/* the same search with the poses as Sophus::SE3f holds them (unit quaternion x y z w + translation) and applies them to a point
+ * (Thirdparty/Sophus/sophus/so3.hpp:358-367, se3.hpp:321-324): what the CPU branch evaluates at src/ORBmatcher.cc:1805 / :1900.
+ * q_trl / t_trl: GetRelativePoseTrl(), may be NULL when Cur->Nleft == -1. */
+int orc_search_last_frame_se3(orc_frame *Cur, const orc_last_points *L, const float *q_tcw, const float *t_tcw, const float *q_trl,
+                              const float *t_trl, float th, int forward, int backward, int check_orientation, int *assign,
+                              int *best_dist, int *best_idx, int *best_dist_r, int *best_idx_r);
+void orc_se3_transform(const float q[4], const float t[3], const float p[3], float y[3]);
 void orc_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3);
 
 /* ---- Frame::ComputeStereoFishEyeMatches complete (src/Frame.cc:1231-1271): 2-NN + ratio test, then

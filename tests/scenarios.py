@@ -3,7 +3,8 @@ import numpy as np
 
 from fasttrack_amd import synth
 from fasttrack_amd.scenarios import (KB8_CAM, bow_match_scenario, fisheye_rig_scenario, frame_bounds, kb8_project64, last_frame_scenario,  # noqa: F401
-                                     local_points_from_frustum, local_points_scenario, map_points_scenario, random_pose)
+                                     local_points_from_frustum, local_points_scenario, map_points_scenario, random_pose,
+                                     random_se3)
 from oracle import binding as ob
 
 KP = ob.KP_DTYPE

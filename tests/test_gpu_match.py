@@ -445,6 +445,64 @@ def test_search_last_frame_two_cameras_kb8(ctx, search_form):
         assert np.array_equal(g[k], o[k]), k
 
 
+@pytest.mark.parametrize("th,fwd,bwd,ori", [(7.0, False, False, True), (15.0, True, False, False), (30.0, False, True, True)])
+def test_search_last_frame_sophus_pose_form(ctx, th, fwd, bwd, ori, search_form):
+    """the poses as Sophus::SE3f holds and applies them (ft_search_last_frame_se3): `Tcw * x3Dw` of the CPU branch
+    (src/ORBmatcher.cc:1805) is a quaternion rotation, not a matrix product - device and oracle evaluate the same operations,
+    one-shot and on a resident frame"""
+    w, h, nf = 752, 480, 1200
+    fr = sc.oracle_stereo_frame(w, h, nf, 15)
+    sf, _ = ob.scale_factors(1.2, 8)
+    sm = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], fr["intr"]["mbf"], fr["intr"]["mb"])
+    last, _ = sc.last_frame_scenario(fr["kL"], fr["dL"], sm["uright"], sm["depth"], fr["intr"], w, h, seed=3)
+    q, t = sc.random_se3(np.random.default_rng(int(th)), 0.03, 0.006)
+    oF, gF = _frame_views(fr, sf, w, h, uright=sm["uright"])
+    o = ob.search_last_frame(oF, last, ob.SE3(q, t), th, fwd, bwd, ori)
+    g = orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, orb.SE3(q, t), th, fwd, bwd, ori)
+    assert o["n"] > 100
+    assert g["n"] == o["n"] and np.array_equal(g["assign"], o["assign"])
+    assert np.array_equal(g["best_dist"], o["best_dist"]) and np.array_equal(g["best_idx"], o["best_idx"])
+    assert np.array_equal(gF.holder_obs, oF.holder_obs)
+    _, gF2 = _frame_views(fr, sf, w, h, uright=sm["uright"])
+    tf = orb.TrackedFrame(ctx, max_keypoints=4096, max_points=4096)
+    tf.upload(gF2)
+    g2 = tf.search_last_frame(last, orb.SE3(q, t), th, fwd, bwd, ori)
+    assert g2["n"] == o["n"] and np.array_equal(g2["assign"], o["assign"])
+    tf.close()
+    with pytest.raises(Exception):
+        orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, orb.SE3([0.5, 0, 0, 0.5], t), th)  # not a unit quaternion
+
+
+def test_search_last_frame_sophus_pose_form_two_cameras_kb8(ctx, search_form):
+    """two-camera KB8 frame: Tcw and GetRelativePoseTrl() both in the Sophus form"""
+    w, h, nf = 512, 512, 1500
+    fr = sc.fisheye_frame_scenario(w, h, nf, 11)
+    sf, _ = ob.scale_factors(1.2, 8)
+    cam = list(sc.KB8_CAM)
+    rng = np.random.default_rng(2)
+    N = len(fr["kL"])
+    z = rng.uniform(2, 8, N).astype(np.float32)
+    X = ((fr["kL"]["x"] - cam[2]) / cam[0] * z).astype(np.float32)
+    Y = ((fr["kL"]["y"] - cam[3]) / cam[1] * z).astype(np.float32)
+    last = dict(valid=(rng.random(N) < 0.8).astype(np.uint8), world_pos=np.stack([X, Y, z], 1),
+                descriptors=fr["dL"].copy(), observations=rng.integers(0, 4, N).astype(np.int32),
+                octave=fr["kL"]["octave"].astype(np.int32), angle=fr["kL"]["angle"].copy())
+    q, t = sc.random_se3(rng, 0.02, 0.005)
+    qr, _ = sc.random_se3(rng, 0.0, 0.01)
+    tr = np.array([-0.1, 0.001, 0.002], np.float32)
+    kw = dict(keys=fr["kL"], keys_right=fr["kR"], descriptors=np.concatenate([fr["dL"], fr["dR"]]),
+              bounds=sc.frame_bounds(w, h), left_to_right=fr["l2r"], right_to_left=fr["r2l"], cam_model=1, cam=cam)
+    oF, gF = ob.FrameView(scale_factors_=sf, **kw), orb.FrameView(scale_factors=sf, **kw)
+    o = ob.search_last_frame(oF, last, ob.SE3(q, t), 15.0, False, False, True, Trl=ob.SE3(qr, tr))
+    g = orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, orb.SE3(q, t), 15.0, False, False, True, Trl=orb.SE3(qr, tr))
+    assert o["n"] > 30 and (o["best_idx_r"] >= 0).sum() > 30
+    assert g["n"] == o["n"] and np.array_equal(g["assign"], o["assign"])
+    for k in ("best_dist", "best_idx", "best_dist_r", "best_idx_r"):
+        assert np.array_equal(g[k], o[k]), k
+    with pytest.raises(Exception):
+        orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, orb.SE3(q, t), 15.0)  # two cameras need Trl
+
+
 LOG_SF = float(np.float32(np.log(np.float32(1.2))))  # Frame::mfLogScaleFactor = log(mfScaleFactor) stored as float
 
 

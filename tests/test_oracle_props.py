@@ -286,3 +286,51 @@ def test_kb8_triangulate_recovers_points():
     assert ok[S["wrong"]].mean() < 0.1
     neg = set(np.unique(code[~ok]).tolist())
     assert neg >= {-1.0, -4.0} and len(neg) >= 3, neg
+
+
+def test_se3_transform_is_the_sophus_formula():
+    """orc_se3_transform = Sophus::SE3f * point (/root/reference/Thirdparty/Sophus/sophus/so3.hpp:358-367, se3.hpp:321-324):
+    every product and sum in float32, in the order uv = q.vec x p; uv += uv; (p + w uv) + q.vec x uv; + t - stated here with
+    numpy float32 scalars; it is NOT the matrix product (last bits differ) but within a few ulp of it"""
+    from tests import scenarios as sc
+    f = np.float32
+    rng = np.random.default_rng(5)
+    differ = 0
+    for _ in range(300):
+        q, t = sc.random_se3(rng, 0.3, 0.4)
+        T = ob.SE3(q, t)
+        p = rng.normal(0, 3, 3).astype(f)
+        x, y, z, w = [f(v) for v in q]
+
+        def cross(a, b):
+            return [f(f(a[1] * b[2]) - f(a[2] * b[1])), f(f(a[2] * b[0]) - f(a[0] * b[2])), f(f(a[0] * b[1]) - f(a[1] * b[0]))]
+        uv = cross([x, y, z], p)
+        uv = [f(u + u) for u in uv]
+        c = cross([x, y, z], uv)
+        want = np.array([f(f(f(p[i] + f(w * uv[i])) + c[i]) + t[i]) for i in range(3)], f)
+        got = T.apply(p)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        M = T.matrix()
+        mat = np.array([f(f(f(f(M[i, 0] * p[0]) + f(M[i, 1] * p[1])) + f(M[i, 2] * p[2])) + M[i, 3]) for i in range(3)], f)
+        assert np.allclose(got, mat, rtol=0, atol=2e-6 * (1 + np.abs(p).max()))
+        differ += int(not np.array_equal(got, mat))
+    assert differ > 50   # the two forms are different float computations
+
+
+def test_search_last_frame_se3_form_agrees_with_matrix_form_up_to_boundaries():
+    """the Sophus form of the poses (what the CPU branch multiplies with) against the matrix form on the same scene: the
+    projections differ in the last bits, so the two searches agree except where a keypoint sits on a window's edge"""
+    from tests import scenarios as sc
+    w, h = 640, 480
+    fr = sc.oracle_stereo_frame(w, h, 1000, 8)
+    sf = ob.scale_factors(1.2, 8)[0]
+    sm = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], fr["intr"]["mbf"], fr["intr"]["mb"])
+    last, _ = sc.last_frame_scenario(fr["kL"], fr["dL"], sm["uright"], sm["depth"], fr["intr"], w, h, seed=2)
+    q, t = sc.random_se3(np.random.default_rng(3), 0.02, 0.004)
+    T = ob.SE3(q, t)
+    args = dict(keys=fr["kL"], descriptors=fr["dL"], scale_factors_=sf, bounds=sc.frame_bounds(w, h), mbf=fr["intr"]["mbf"],
+                mb=fr["intr"]["mb"], uright=sm["uright"], cam=[fr["intr"][k] for k in ("fx", "fy", "cx", "cy")])
+    a = ob.search_last_frame(ob.FrameView(**args), last, T, 15.0)
+    b = ob.search_last_frame(ob.FrameView(**args), last, T.matrix(), 15.0)
+    assert a["n"] > 100 and abs(a["n"] - b["n"]) <= 3 and (a["assign"] != b["assign"]).mean() < 0.01
+

@@ -66,7 +66,7 @@ def main():
     sf, _ = ob.scale_factors(1.2, 8)
     sizes = [(752, 480), (640, 480), (512, 512), (1280, 720), (376, 240)]
     fails, searches, matched, t0 = 0, 0, 0, time.time()
-    kb8_frustum_points = kb8_pairs = 0
+    kb8_frustum_points = kb8_pairs = se3_searches = 0
 
     def check(tag, trial, what):
         nonlocal fails
@@ -120,8 +120,16 @@ def main():
             Tcw = sc.random_pose(rng, 0.02, 0.005)
             th = float(rng.choice([7.0, 15.0]))
             oF, gF = ob.FrameView(scale_factors_=sf, **kwk), orb.FrameView(scale_factors=sf, **kwk)
-            o = ob.search_last_frame(oF, last, Tcw, th, False, False, True)
-            g = orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, Tcw, th, False, False, True)
+            if t % 8 == 7:  # both poses in the Sophus form
+                q, tt = sc.random_se3(rng, 0.02, 0.005)
+                qr, _ = sc.random_se3(rng, 0.0, 0.01)
+                o = ob.search_last_frame(oF, last, ob.SE3(q, tt), th, False, False, True, Trl=ob.SE3(qr, Trl[:, 3]))
+                g = orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, orb.SE3(q, tt), th, False, False, True,
+                                                                    Trl=orb.SE3(qr, Trl[:, 3]))
+                se3_searches += 1
+            else:
+                o = ob.search_last_frame(oF, last, Tcw, th, False, False, True)
+                g = orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, Tcw, th, False, False, True)
             check(f"KB8 last th{th} [{desc}]", t, diff(g, o, ("best_dist", "best_idx", "best_dist_r", "best_idx_r")))
             searches += 1
             matched += o["n"]
@@ -182,9 +190,15 @@ def main():
         ori = bool(rng.random() < 0.8)
         last, Tcw = sc.last_frame_scenario(fr["kL"], fr["dL"], sm["uright"], sm["depth"], fr["intr"], w, h, seed=int(rng.integers(0, 1 << 30)))
         oF, gF = views(fr, sf, w, h, sm["uright"], None)
-        o = ob.search_last_frame(oF, last, Tcw, th, fwd, bwd, ori)
-        g = orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, Tcw, th, fwd, bwd, ori)
-        check(f"last th{th} fwd{int(fwd)} bwd{int(bwd)} ori{int(ori)} [{desc}]", t, diff(g, o, ("best_dist", "best_idx")) or
+        if t % 2:  # every other trial hands the pose over as Sophus::SE3f holds it (the CPU branch's quaternion arithmetic)
+            q, tt = sc.random_se3(rng, 0.03, 0.006)
+            oT, gT = ob.SE3(q, tt), orb.SE3(q, tt)
+            se3_searches += 1
+        else:
+            oT = gT = Tcw
+        o = ob.search_last_frame(oF, last, oT, th, fwd, bwd, ori)
+        g = orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, gT, th, fwd, bwd, ori)
+        check(f"last th{th} fwd{int(fwd)} bwd{int(bwd)} ori{int(ori)} se3{t % 2} [{desc}]", t, diff(g, o, ("best_dist", "best_idx")) or
               (None if np.array_equal(gF.holder_obs, oF.holder_obs) else "holder_obs"))
         searches += 1
         matched += o["n"]
@@ -225,7 +239,8 @@ def main():
             return ctx.get_stat(name)[1]
         except Exception:
             return 0
-    print(f"KannalaBrandt8, all bit-exact comparisons: {kb8_frustum_points} frustum points, {kb8_pairs} triangulated pairs")
+    print(f"KannalaBrandt8, all bit-exact comparisons: {kb8_frustum_points} frustum points, {kb8_pairs} triangulated pairs; "
+          f"{se3_searches} last-frame searches with Sophus-form poses")
     print(f"{args.trials} trials, {searches} searches, {matched} matches, {fails} mismatches, {time.time() - t0:.0f} s; "
           f"persistent launches {calls('search.persistent_launches')}, timeouts {calls('search.persistent_timeouts')}, "
           f"fallbacks {calls('search.persistent_fallbacks')}")
