@@ -419,8 +419,9 @@ __global__ __launch_bounds__(256) void k_hamming_pairs(const uint8_t *a, const u
 // ratio test: one thread per left keypoint.  Float steps follow the reference's order without contraction; the
 // null vector of the 4x4 system comes from a one-sided Jacobi SVD in double (see fasttrack_amd.h).
 // ------------------------------------------------------------------------------------------------
+// Eigen's association of a three-term sum: e0 + (e1 + e2) (redux_novec_unroller; the oracle's note at orc_is_in_frustum)
 __device__ __forceinline__ float fdot3(const float *a, const float *b) {
-    return __fadd_rn(__fadd_rn(__fmul_rn(a[0], b[0]), __fmul_rn(a[1], b[1])), __fmul_rn(a[2], b[2]));
+    return __fadd_rn(__fmul_rn(a[0], b[0]), __fadd_rn(__fmul_rn(a[1], b[1]), __fmul_rn(a[2], b[2])));
 }
 __device__ __forceinline__ float fnorm3(const float *a) { return sqrtf(fdot3(a, a)); }
 

@@ -897,8 +897,10 @@ __global__ __launch_bounds__(1024) void k_search_last_persist(FtDevFrame F, FtDe
 // (src/MapPoint.cc:531-546): one thread per local map point.  Float expressions are evaluated in the
 // order the oracle states (no contraction); log(ratio) binds to logf (MapPoint.cc:539), reproduced by libm_f32.h.
 // ------------------------------------------------------------------------------------------------
+// Eigen's sum of three terms (dot, squaredNorm, a coefficient of a small matrix product): redux_novec_unroller splits the
+// range in halves, e0 + (e1 + e2) (see the oracle's note at orc_is_in_frustum)
 __device__ __forceinline__ float dot3(const float *a, const float *b) {
-    return __fadd_rn(__fadd_rn(__fmul_rn(a[0], b[0]), __fmul_rn(a[1], b[1])), __fmul_rn(a[2], b[2]));
+    return __fadd_rn(__fmul_rn(a[0], b[0]), __fadd_rn(__fmul_rn(a[1], b[1]), __fmul_rn(a[2], b[2])));
 }
 // sqrtf is correctly rounded here (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn maps to the native approximation
 __device__ __forceinline__ float norm3(const float *a) { return sqrtf(dot3(a, a)); }

@@ -382,18 +382,19 @@ FtDevFrame devFrameConstants(const ft_frame_view *F) {
     return D;
 }
 
-// camera poses of isInFrustumChecks (Frame.cc:1312-1325); compiled without contraction, evaluated left to right
+// camera poses of isInFrustumChecks (Frame.cc:1312-1325); compiled without contraction, sums associated as Eigen does
 FtFrustumPose frustumPose(const ft_frame_view *F, const ft_frame_pose *T) {
     FtFrustumPose P;
     memcpy(P.R[0], T->Rcw, sizeof P.R[0]);
     memcpy(P.t[0], T->tcw, sizeof P.t[0]);
     memcpy(P.twc[0], T->Ow, sizeof P.twc[0]);
     const float *Trl = F->Trl;
+    auto sum3 = [](float e0, float e1, float e2) { return e0 + (e1 + e2); };  // Eigen's association (redux_novec_unroller)
     for (int i = 0; i < 3; i++) {
         for (int j = 0; j < 3; j++)
-            P.R[1][3 * i + j] = (Trl[4 * i] * T->Rcw[j] + Trl[4 * i + 1] * T->Rcw[3 + j]) + Trl[4 * i + 2] * T->Rcw[6 + j];
-        P.t[1][i] = ((Trl[4 * i] * T->tcw[0] + Trl[4 * i + 1] * T->tcw[1]) + Trl[4 * i + 2] * T->tcw[2]) + Trl[4 * i + 3];
-        P.twc[1][i] = ((T->Rcw[i] * T->tlr[0] + T->Rcw[3 + i] * T->tlr[1]) + T->Rcw[6 + i] * T->tlr[2]) + T->Ow[i];
+            P.R[1][3 * i + j] = sum3(Trl[4 * i] * T->Rcw[j], Trl[4 * i + 1] * T->Rcw[3 + j], Trl[4 * i + 2] * T->Rcw[6 + j]);
+        P.t[1][i] = sum3(Trl[4 * i] * T->tcw[0], Trl[4 * i + 1] * T->tcw[1], Trl[4 * i + 2] * T->tcw[2]) + Trl[4 * i + 3];
+        P.twc[1][i] = sum3(T->Rcw[i] * T->tlr[0], T->Rcw[3 + i] * T->tlr[1], T->Rcw[6 + i] * T->tlr[2]) + T->Ow[i];
     }
     return P;
 }

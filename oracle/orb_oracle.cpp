@@ -1277,13 +1277,17 @@ int orc_search_last_frame_se3(orc_frame *Cur, const orc_last_points *Lp, const f
 
 // ------------------------------------------------------------------------------------------------
 // Frame::isInFrustum (src/Frame.cc:536-610), Frame::isInFrustumChecks (:1308-1382),
-// MapPoint::PredictScale (src/MapPoint.cc:531-546).  Eigen fixed-size float expressions are evaluated
-// left to right without contraction: (a0*b0 + a1*b1) + a2*b2, norm = sqrt((x*x + y*y) + z*z).
-// `log(ratio)` binds to logf (float argument, `using namespace std` reaches MapPoint.cc through
+// MapPoint::PredictScale (src/MapPoint.cc:531-546).  Eigen evaluates the sums of its fixed-size float expressions -
+// dot(), squaredNorm() and every coefficient of a small matrix product, which is `(lhs.row(i).transpose().cwiseProduct(
+// rhs.col(j))).sum()` (Eigen/src/Core/ProductEvaluators.h) - through redux_novec_unroller (Eigen/src/Core/Redux.h), which
+// splits a range of Length terms at Length / 2: three terms associate as e0 + (e1 + e2), NOT left to right.  (Eigen is a
+// third party absent from this image: restated from its published source, 3.3 / 3.4; tests/tools/eigen_order_probe.cpp
+// prints the association a real Eigen uses.)  No contraction.  `log(ratio)` binds to logf (float argument, `using namespace std` reaches MapPoint.cc through
 // include/Kernels/KernelController.h:11), `ceil` to ceilf.
 // ------------------------------------------------------------------------------------------------
-static inline float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
-static inline float norm3(const float *a) { return sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); }
+static inline float sum3(float e0, float e1, float e2) { return e0 + (e1 + e2); }
+static inline float dot3(const float *a, const float *b) { return sum3(a[0] * b[0], a[1] * b[1], a[2] * b[2]); }
+static inline float norm3(const float *a) { return sqrtf(dot3(a, a)); }
 
 static int predictScale(float maxDistanceRaw, float currentDist, float logScaleFactor, int nLevels) {
     const float ratio = maxDistanceRaw / currentDist;
@@ -1303,10 +1307,10 @@ int orc_is_in_frustum(const orc_frame *F, const orc_frame_pose *T, const orc_map
         const float *Trl = F->Trl;
         for (int i = 0; i < 3; i++) {
             for (int j = 0; j < 3; j++)
-                Rr[3 * i + j] = (Trl[4 * i] * T->Rcw[j] + Trl[4 * i + 1] * T->Rcw[3 + j]) + Trl[4 * i + 2] * T->Rcw[6 + j];
-            tr[i] = ((Trl[4 * i] * T->tcw[0] + Trl[4 * i + 1] * T->tcw[1]) + Trl[4 * i + 2] * T->tcw[2]) + Trl[4 * i + 3];
+                Rr[3 * i + j] = sum3(Trl[4 * i] * T->Rcw[j], Trl[4 * i + 1] * T->Rcw[3 + j], Trl[4 * i + 2] * T->Rcw[6 + j]);
+            tr[i] = sum3(Trl[4 * i] * T->tcw[0], Trl[4 * i + 1] * T->tcw[1], Trl[4 * i + 2] * T->tcw[2]) + Trl[4 * i + 3];
             // mRwc = mRcw^T
-            twcR[i] = ((T->Rcw[i] * T->tlr[0] + T->Rcw[3 + i] * T->tlr[1]) + T->Rcw[6 + i] * T->tlr[2]) + T->Ow[i];
+            twcR[i] = sum3(T->Rcw[i] * T->tlr[0], T->Rcw[3 + i] * T->tlr[1], T->Rcw[6 + i] * T->tlr[2]) + T->Ow[i];
         }
     }
     int nToMatch = 0;
