@@ -1097,7 +1097,11 @@ void orc_three_maxima(const int *histo, int L, int *ind1, int *ind2, int *ind3) 
     else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
 }
 
-// camera projection - src/CameraModels/Pinhole.cpp:43-49, KannalaBrandt8.cpp:67-84
+// camera projection - src/CameraModels/Pinhole.cpp:43-49, KannalaBrandt8.cpp:67-84.  `cos(psi)` / `sin(psi)` there are unqualified
+// calls with a float argument in a file without a using-directive: they bind to cosf / sinf because the translation unit reaches
+// <math.h> (KannalaBrandt8.h -> GeometricCamera.h -> Converter.h -> Thirdparty/g2o/g2o/types/types_six_dof_expmap.h ->
+// core/base_vertex.h:32 -> stuff/macros.h:104), whose libstdc++ wrapper (GCC >= 6) pulls the std:: float overloads into the global
+// namespace.  (With only <cmath> they would be ::cos(double): a double product narrowed at the store.)
 static void projectCam(const orc_frame *F, const float p[3], float uv[2]) {
     if (F->cam_model == 0) {
         uv[0] = F->cam[0] * p[0] / p[2] + F->cam[2];
