@@ -1098,10 +1098,13 @@ void orc_three_maxima(const int *histo, int L, int *ind1, int *ind2, int *ind3) 
 }
 
 // camera projection - src/CameraModels/Pinhole.cpp:43-49, KannalaBrandt8.cpp:67-84.  `cos(psi)` / `sin(psi)` there are unqualified
-// calls with a float argument in a file without a using-directive: they bind to cosf / sinf because the translation unit reaches
-// <math.h> (KannalaBrandt8.h -> GeometricCamera.h -> Converter.h -> Thirdparty/g2o/g2o/types/types_six_dof_expmap.h ->
-// core/base_vertex.h:32 -> stuff/macros.h:104), whose libstdc++ wrapper (GCC >= 6) pulls the std:: float overloads into the global
-// namespace.  (With only <cmath> they would be ::cos(double): a double product narrowed at the store.)
+// calls with a float argument in a file WITHOUT a using-directive (none is reachable from KannalaBrandt8.h either): they are cosf /
+// sinf only if the translation unit has seen libstdc++'s <math.h> wrapper, which pulls the std:: float overloads into the global
+// namespace; with <cmath> alone they are ::cos(double) - a double product narrowed at the store (checked with this image's g++ 11).
+// The reference's own headers do not include <math.h> on that path for GCC (Thirdparty/g2o/g2o/stuff/macros.h:104 is its
+// "unknown compiler" branch); KannalaBrandt8.h -> TwoViewReconstruction.h:22 includes <opencv2/opencv.hpp>, and OpenCV's flann
+// headers (opencv2/flann/lsh_table.h) do include <math.h> - OpenCV is absent here, so this binding is part of "unpinned: OpenCV".
+// cosf / sinf it is, as in rounds 1-3.
 static void projectCam(const orc_frame *F, const float p[3], float uv[2]) {
     if (F->cam_model == 0) {
         uv[0] = F->cam[0] * p[0] / p[2] + F->cam[2];
