@@ -1289,8 +1289,8 @@ int orc_search_last_frame_se3(orc_frame *Cur, const orc_last_points *Lp, const f
 // rhs.col(j))).sum()` (Eigen/src/Core/ProductEvaluators.h) - through redux_novec_unroller (Eigen/src/Core/Redux.h), which
 // splits a range of Length terms at Length / 2: three terms associate as e0 + (e1 + e2), NOT left to right.  (Eigen is a
 // third party absent from this image: restated from its published source, 3.3 / 3.4; tests/tools/eigen_order_probe.cpp
-// prints the association a real Eigen uses.)  No contraction.  `log(ratio)` binds to logf (float argument, `using namespace std` reaches MapPoint.cc through
-// include/Kernels/KernelController.h:11), `ceil` to ceilf.
+// prints the association a real Eigen uses.)  No contraction.  `log(ratio)` binds to logf (float argument; a using-directive reaches MapPoint.cc through
+// MapPoint.h -> Frame.h:31 -> ORBVocabulary.h:24 -> Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:36), `ceil` to ceilf.
 // ------------------------------------------------------------------------------------------------
 static inline float sum3(float e0, float e1, float e2) { return e0 + (e1 + e2); }
 static inline float dot3(const float *a, const float *b) { return sum3(a[0] * b[0], a[1] * b[1], a[2] * b[2]); }
