@@ -1612,7 +1612,7 @@ __global__ __launch_bounds__(256) void k_compact(FtGeom g, const int *cellCount,
 #define OD_WAVE_BYTES ((OD_RAW_BYTES + OD_HB_BYTES + 15) & ~15)
 #define OD_WAVES 4
 #ifndef OD_KPW_WIDE
-#define OD_KPW_WIDE 2           // keypoints per wave in launches of 8+ images: loads of all of them in flight before the first is processed
+#define OD_KPW_WIDE 2           // keypoints per wave (1 .. 3) in launches of 8+ images: loads of all of them in flight before the first is processed
 #endif
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -1718,7 +1718,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // wave 0 of every 16th workgroup, summed here ([0] = sampled waves, [1 + p] = ticks of phase p); the launcher prints them
 __device__ unsigned long long g_odProf[16];
 template <int OD_KPW>
-__global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const uint8_t *const *l0, int l0pitch,
+__global__ __launch_bounds__(64 * OD_WAVES, OD_KPW > 2 ? 7 : 1) void k_orient_desc(FtGeom g, const uint8_t *const *l0, int l0pitch,
                                                                const uint8_t *pyr, int alignedLoads, const FtSelKp *sel,
                                                                const int *selCount, FtOctArgs lay, int *nSel,
                                                                ft_keypoint *keysOut, uint8_t *descOut, FtSlotGrid sg, int prof) {
@@ -2005,12 +2005,30 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
             moments(1);
         }
     }
-    tick();  // 4: patch 1 staged + moments 1
+    if constexpr (OD_KPW > 2) {
+        // a third keypoint: its moments are wanted before the shared angle arithmetic, and the one raw buffer still holds
+        // patch 1 - which is staged a second time further down (its nine dwords per lane are still in registers)
+        if (nKp > 2) {
+            wave_lds_sync();  // moments 1 have read the raw buffer
+            stage(2);
+            wave_lds_sync();
+            moments(2);
+        }
+    }
+    tick();  // 4: patches 1 (, 2) staged + their moments
+    // lane group of keypoint q for the shared angle arithmetic: halves for two keypoints, rows of 16 lanes for three
+    constexpr int GROUP = OD_KPW > 2 ? 16 : 32;
     float mY = (float)m01K[0], mX = (float)m10K[0];
     if constexpr (OD_KPW > 1) {
-        if (nKp > 1 && lane >= 32) {
+        if (nKp > 1 && lane >= GROUP) {
             mY = (float)m01K[1];
             mX = (float)m10K[1];
+        }
+    }
+    if constexpr (OD_KPW > 2) {
+        if (nKp > 2 && lane >= 2 * GROUP) {
+            mY = (float)m01K[2];
+            mX = (float)m10K[2];
         }
     }
     const float angleL = fast_atan2_deg(mY, mX);
@@ -2020,16 +2038,25 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
     const float ar = __fmul_rn(angleL, factorPI);
     const float caL = ft_libm::cosf_glibc(ar), sbL = ft_libm::sinf_glibc(ar);
     auto lane_value = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-    tick();  // 5: angles of both keypoints
+    tick();  // 5: angles of all keypoints of the wave
     describe(0, lane_value(angleL, 0), lane_value(caL, 0), lane_value(sbL, 0));
     tick();  // 6: samples + stores of keypoint 0
+    if constexpr (OD_KPW > 2) {
+        if (nKp > 2) {
+            wave_lds_sync();  // samples 0 have read hb; the raw buffer holds patch 2
+            hblur();
+            wave_lds_sync();
+            describe(2, lane_value(angleL, 2 * GROUP), lane_value(caL, 2 * GROUP), lane_value(sbL, 2 * GROUP));
+            stage(1);  // patch 1 again (hblur 2 is done with the raw buffer)
+        }
+    }
     if constexpr (OD_KPW > 1) {
         if (nKp > 1) {
-            wave_lds_sync();  // samples 0 have read hb
+            wave_lds_sync();  // the samples in front have read hb (and patch 1 is staged)
             hblur();
             wave_lds_sync();
             tick();  // 7: horizontal blur 1
-            describe(1, lane_value(angleL, 32), lane_value(caL, 32), lane_value(sbL, 32));
+            describe(1, lane_value(angleL, GROUP), lane_value(caL, GROUP), lane_value(sbL, GROUP));
             tick();  // 8: samples + stores of keypoint 1
         }
     }
