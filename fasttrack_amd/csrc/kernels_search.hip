@@ -229,6 +229,15 @@ __device__ __forceinline__ void cache_end(const CacheBuild &B, int lane, bool an
     }
 }
 // 0 = not built yet, 1 = usable (count = candidates filed), 2 = built but too many candidates: scan the window again
+// the same from a meta word that is already in a register (slot != null)
+__device__ __forceinline__ int cache_state_of(unsigned long long meta, int &count, bool &anyInBox) {
+    count = 0;
+    anyInBox = false;
+    if (meta == KEY_NONE) return 0;
+    count = (int)(unsigned)meta;
+    anyInBox = (meta >> 32) != 0;
+    return count <= FT_CACHE_CAP ? 1 : 2;
+}
 __device__ __forceinline__ int cache_state(const unsigned long long *slot, int &count, bool &anyInBox) {
     count = 0;
     anyInBox = false;
@@ -448,30 +457,40 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
         const unsigned long long *p = (const unsigned long long *)(P.desc + (size_t)i * 32);
         q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
     }
-    if (!P.skip[i]) {
+    // Everything a pass needs of the point that does not depend on another load is requested HERE, before the first use: the
+    // flags, both cache meta words and - speculatively - the first 64 cached keys of either camera.  A pass on cached
+    // candidates was a chain of five dependent round trips (skip -> in view -> meta -> keys -> lock records); now it is two.
+    unsigned long long *slotL = C.cache ? C.cache + (size_t)i * FT_CACHE_WORDS : nullptr;
+    unsigned long long *slotR = slotL ? slotL + (FT_CACHE_CAP + 1) : nullptr;
+    const bool twoCam = F.Nleft != -1;
+    const uint8_t skipV = P.skip[i], inViewV = P.inView[i], inViewRV = twoCam ? P.inViewR[i] : (uint8_t)0;
+    const int levelRV = twoCam ? P.levelR[i] : -1;
+    const unsigned long long metaL = slotL ? slotL[0] : KEY_NONE, metaR = (slotR && twoCam) ? slotR[0] : KEY_NONE;
+    const unsigned long long keyL0 = slotL ? slotL[1 + lane] : KEY_NONE, keyR0 = (slotR && twoCam) ? slotR[1 + lane] : KEY_NONE;
+    if (!skipV) {
         const int nLeft = F.Nleft == -1 ? F.N : F.Nleft;
-        if (P.inView[i]) {
-            const int level = P.level[i];
-            float r = ((double)P.viewCos[i] > 0.998) ? 2.5f : 4.0f;  // RadiusByViewingCos, ORBmatcher.cc:314-320
-            if ((double)th != 1.0) r = __fmul_rn(r, th);
-            const float rad = __fmul_rn(r, F.sf[level]);
-            const float x = P.projX[i], y = P.projY[i];
-            const Window w = cell_window(F, x, y, rad);
+        if (inViewV) {
             unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
             CacheBuild cb;
-            cb.slot = C.cache ? C.cache + (size_t)i * FT_CACHE_WORDS : nullptr;
+            cb.slot = slotL;
             cb.counter = ldsCounter;
             int nCached;
             bool anyBox;
-            const int cs = cache_state(cb.slot, nCached, anyBox);
+            const int cs = slotL ? cache_state_of(metaL, nCached, anyBox) : 2;
             cb.build = cs == 0;
             if (cs == 1) {
                 for (int t = lane; t < nCached; t += 64) {
-                    const unsigned long long key = cb.slot[1 + t];
+                    const unsigned long long key = t < 64 ? keyL0 : cb.slot[1 + t];
                     if (is_locked(C, key_idx(key), i, key_held(key))) continue;
                     two_min_insert(k0, k1, key);
                 }
             } else {
+                const int level = P.level[i];
+                float r = ((double)P.viewCos[i] > 0.998) ? 2.5f : 4.0f;  // RadiusByViewingCos, ORBmatcher.cc:314-320
+                if ((double)th != 1.0) r = __fmul_rn(r, th);
+                const float rad = __fmul_rn(r, F.sf[level]);
+                const float x = P.projX[i], y = P.projY[i];
+                const Window w = cell_window(F, x, y, rad);
                 cache_begin(cb, lane);
                 if (!w.empty) {
                     const float pxr = (F.Nleft == -1 && F.uright) ? P.projXR[i] : 0.f;
@@ -513,13 +532,9 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 }
             }
         }
-        if (F.Nleft != -1 && P.inViewR[i] && !skipRight) {
-            const int level = P.levelR[i];
+        if (twoCam && inViewRV && !skipRight) {
+            const int level = levelRV;
             if (level != -1) {
-                const float r = ((double)P.viewCosR[i] > 0.998) ? 2.5f : 4.0f;
-                const float rad = __fmul_rn(r, F.sf[level]);
-                const float x = P.projXR[i], y = P.projYR[i];
-                const Window w = cell_window(F, x, y, rad);
                 const int nRight = F.N - F.Nleft;
                 unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
                 // this point's own left-block side write precedes its right-block search
@@ -527,19 +542,23 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 // (the right block is not reached in every pass - skipRight depends on the locks - so its candidates are filed by
                 // the first pass that gets here)
                 CacheBuild cb;
-                cb.slot = C.cache ? C.cache + (size_t)i * FT_CACHE_WORDS + (FT_CACHE_CAP + 1) : nullptr;
+                cb.slot = slotR;
                 cb.counter = ldsCounter;
                 int nCached;
                 bool anyBox;
-                const int cs = cache_state(cb.slot, nCached, anyBox);
+                const int cs = slotR ? cache_state_of(metaR, nCached, anyBox) : 2;
                 cb.build = cs == 0;
                 if (cs == 1) {
                     for (int t = lane; t < nCached; t += 64) {
-                        const unsigned long long key = cb.slot[1 + t];
+                        const unsigned long long key = t < 64 ? keyR0 : cb.slot[1 + t];
                         if (lockedR(key_idx(key) + F.Nleft, key_held(key))) continue;
                         two_min_insert(k0, k1, key);
                     }
                 } else {
+                    const float r = ((double)P.viewCosR[i] > 0.998) ? 2.5f : 4.0f;
+                    const float rad = __fmul_rn(r, F.sf[level]);
+                    const float x = P.projXR[i], y = P.projYR[i];
+                    const Window w = cell_window(F, x, y, rad);
                     cache_begin(cb, lane);
                     if (!w.empty) {
                         for_window(F, 1, F.keysR, nRight, w, level - 1, level, lane, [&](const WinEntry &kp) {
@@ -656,7 +675,51 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                                            int *ldsCounter) {
     int primL = -1, primR = -1;
     int bd = 256, bi = -1, bdr = 256, bir = -1;
-    if (Lp.valid[i]) {
+    // Later passes of the claim iteration on a point whose candidates are cached need neither the pose transform nor the camera
+    // model (two atan2f, a cosf and a sinf for KannalaBrandt8 - evaluated by all 64 lanes, on the critical path of a pass that
+    // is otherwise a handful of dependent loads): the cached keys already hold everything that depends on the projection.
+    unsigned long long *slotL = C.cache ? C.cache + (size_t)i * FT_CACHE_WORDS : nullptr;
+    unsigned long long *slotR = slotL ? slotL + (FT_CACHE_CAP + 1) : nullptr;
+    // requested together, before the first use: validity, both meta words and (speculatively) the first 64 keys of either camera
+    const bool twoCam = F.Nleft != -1;
+    const uint8_t validV = Lp.valid[i];
+    const unsigned long long metaL = slotL ? slotL[0] : KEY_NONE, metaR = (slotR && twoCam) ? slotR[0] : KEY_NONE;
+    const unsigned long long keyL0 = slotL ? slotL[1 + lane] : KEY_NONE, keyR0 = (slotR && twoCam) ? slotR[1 + lane] : KEY_NONE;
+    bool fromCache = false;
+    int nCachedL = 0, nCachedR = 0;
+    bool anyBoxL = false, anyBoxR = false;
+    if (validV && slotL && cache_state_of(metaL, nCachedL, anyBoxL) == 1)
+        fromCache = !twoCam || !anyBoxL || cache_state_of(metaR, nCachedR, anyBoxR) == 1;
+    if (fromCache) {
+        unsigned long long k0 = KEY_NONE;
+        for (int t = lane; t < nCachedL; t += 64) {
+            const unsigned long long key = t < 64 ? keyL0 : slotL[1 + t];
+            if (is_locked(C, key_idx(key), i, key_held(key))) continue;
+            k0 = key < k0 ? key : k0;
+        }
+        k0 = wave_min_u64(k0);
+        if (anyBoxL) {
+            if (k0 != KEY_NONE) {
+                bd = key_dist(k0);
+                bi = key_idx(k0);
+            }
+            if (bd <= FT_TH_HIGH) primL = bi;
+            if (F.Nleft != -1) {
+                unsigned long long kr = KEY_NONE;
+                for (int t = lane; t < nCachedR; t += 64) {
+                    const unsigned long long key = t < 64 ? keyR0 : slotR[1 + t];
+                    if (is_locked(C, key_idx(key) + F.Nleft, i, key_held(key))) continue;
+                    kr = key < kr ? key : kr;
+                }
+                kr = wave_min_u64(kr);
+                if (kr != KEY_NONE) {
+                    bdr = key_dist(kr);
+                    bir = key_idx(kr);
+                }
+                if (bdr <= FT_TH_HIGH) primR = bir + F.Nleft;
+            }
+        }
+    } else if (validV) {
         float xw[3] = {Lp.worldPos[3 * i], Lp.worldPos[3 * i + 1], Lp.worldPos[3 * i + 2]};
         float xc[3];
         transform_pose(Tcw.m, Tcw.q, Tcw.quat, xw, xc);
@@ -668,6 +731,8 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
             if (uv[0] < F.mnMinX || uv[0] > F.mnMaxX) go = false;
             if (uv[1] < F.mnMinY || uv[1] > F.mnMaxY) go = false;
         }
+        // a point that does not project into the image: an empty cache entry spares the later passes the projection
+        if (!go && slotL && lane == 0 && metaL == KEY_NONE) slotL[0] = 0ull;
         if (go) {
             const int oct = Lp.octave[i];
             const float radius = __fmul_rn(th, F.sf[oct]);
