@@ -411,7 +411,15 @@ int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done) {
     int *cellCount = ex->d_cellCount + (size_t)b0 * g.totalCells;
     uint32_t *stage = ex->d_stage + (size_t)b0 * g.stagePerSlot;
     ex->evt.begin(tm, "kernel.pyr_down(all levels)", ex->stream);
-    int rc = ft_launch_pyramid(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->d_taps, al, ex->tune.pyr_rows);
+    int rc = FT_OK;
+    {
+        // the levels of a group of images back to back: a group small enough that an XCD's share of a level stays in its L2
+        // between the launch that writes it and the launch that reads it (option pyr_group)
+        const int group = ex->tune.pyr_group >= 8 ? ex->tune.pyr_group : nb;
+        for (int s0 = 0; s0 < nb && rc == FT_OK; s0 += group)
+            rc = ft_launch_pyramid(ex->stream, g, std::min(group, nb - s0), l0 + s0, ex->l0pitch, pyr + (size_t)s0 * g.pyrPerSlot,
+                                   ex->d_taps, al, ex->tune.pyr_rows);
+    }
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.fast_cells", ex->stream);

@@ -50,6 +50,7 @@
     X(oct_smem_pad, "FT_OCT_SMEM_PAD", 0, "extra LDS bytes per k_octree workgroup (occupancy probe)")                        \
     X(fast_strips, "FT_FAST_STRIPS", 0, "FAST over 62-column strips instead of one wave per cell")                           \
     X(strip_rows, "FT_STRIP_ROWS", 16, "rows per strip of the strips form (8 .. 120)")                                       \
+    X(pyr_group, "FT_PYR_GROUP", 0, "images per pyramid launch group (0 = the whole sub-batch per level; >= 8: the levels of a group of images back to back, so that a level is read from the L2 it was just written to)")         \
     X(pyr_rows, "FT_PYR_ROWS", 1, "pyramid of launches of 8+ images: 1 = one level per pass (k_pyr_rows), 2 = two levels per pass (k_pyr_rows2: fewer bytes, measured 1.5 % slower in the pipeline; 10 + k = only from level k upwards), 0 = tile kernel")         \
     X(upload_kernel, "FT_UPLOAD_KERNEL", 1, "latency mode: frames go up through k_upload instead of DMA copies")             \
     X(deliver_kernel, "FT_DELIVER_KERNEL", 1, "latency mode: one kernel writes all results into pinned host memory")         \

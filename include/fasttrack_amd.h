@@ -91,6 +91,7 @@ FT_API int ft_context_set_lane_map(ft_context *ctx, const int *map, int n);
  *   oct_smem_pad         0        extra LDS bytes per k_octree workgroup (occupancy probe)
  *   fast_strips          0        FAST over 62-column strips instead of one wave per cell
  *   strip_rows           16       rows per strip of the strips form (8 .. 120)
+ *   pyr_group            0        images per pyramid launch group (0 = the whole sub-batch per level)
  *   pyr_rows             1        pyramid of launches of 8+ images: 1 = one level per pass, 2 = two levels per pass, 0 = tile kernel
  *   upload_kernel        1        latency mode: frames go up through one kernel instead of DMA copies
  *   deliver_kernel       1        latency mode: one kernel writes all results into pinned host memory
