@@ -149,6 +149,7 @@ def lib() -> C.CDLL:
     L.ft_context_set_option.argtypes = [vp, C.c_char_p, i]
     L.ft_context_get_option.argtypes = [vp, C.c_char_p, ip]
     L.ft_option_describe.argtypes = [i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), ip, C.POINTER(C.c_char_p)]
+    L.ft_option_range.argtypes = [C.c_char_p, ip, ip]
     L.ft_context_save_stats.argtypes = [vp, C.c_char_p]
     L.ft_context_set_kernel_timing.argtypes = [vp, i]
     L.ft_context_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]
@@ -201,6 +202,15 @@ def lib() -> C.CDLL:
     L.ft_tracked_frame_track_local_map.argtypes = [vp, C.POINTER(FramePose), C.POINTER(MapPoints), f, f, f, f, i, f,
                                                    C.POINTER(FrustumResult), ip, vp, ip]
     L.ft_tracked_frame_holder_obs.argtypes = [vp, vp]
+    L.ft_tracked_batch_create.argtypes = [vp, i, i, i, C.POINTER(vp)]
+    L.ft_tracked_batch_destroy.argtypes = [vp]
+    L.ft_tracked_batch_upload.argtypes = [vp, i, C.POINTER(FrameView)]
+    L.ft_tracked_batch_search_last_frame.argtypes = [vp, i, C.POINTER(LastPoints), vp, f, vp, vp, i, C.POINTER(vp), vp]
+    L.ft_tracked_batch_search_last_frame_se3.argtypes = [vp, i, C.POINTER(LastPoints), C.POINTER(SE3), C.POINTER(SE3), f, vp, vp, i,
+                                                         C.POINTER(vp), vp]
+    L.ft_tracked_batch_track_local_map.argtypes = [vp, i, C.POINTER(FramePose), C.POINTER(MapPoints), f, f, f, f, i, f,
+                                                   C.POINTER(FrustumResult), vp, C.POINTER(vp), vp]
+    L.ft_tracked_batch_holder_obs.argtypes = [vp, i, vp]
     L.ft_descriptor_distance.argtypes = [vp, vp, vp, i, vp]
     L.ft_stereo_frontend_device_descriptors.argtypes = [vp, i, i, C.POINTER(vp), ip]
     L.ft_vocabulary_create.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, C.POINTER(vp)]

@@ -113,9 +113,9 @@ const char *ft_debug_env(const char *name) { return strncmp(name, "FT_DEBUG_", 9
 
 static const struct {
     const char *name, *env, *doc;
-    int def;
+    int def, lo, hi;
 } kTuningTable[] = {
-#define FT_X(field, env, def, doc) {#field, env, doc, def},
+#define FT_X(field, env, def, lo, hi, doc) {#field, env, doc, def, lo, hi},
     FT_TUNING_OPTIONS(FT_X)
 #undef FT_X
 };
@@ -123,20 +123,38 @@ static const int kTuningCount = (int)(sizeof kTuningTable / sizeof kTuningTable[
 
 int *ft_tuning_field(ft_tuning &t, const char *name) {
     if (!name) return nullptr;
-#define FT_X(field, env, def, doc) \
+#define FT_X(field, env, def, lo, hi, doc) \
     if (strcmp(name, #field) == 0 || strcmp(name, env) == 0) return &t.field;
     FT_TUNING_OPTIONS(FT_X)
 #undef FT_X
     return nullptr;
 }
 
-ft_tuning ft_tuning_from_env() {
-    ft_tuning t;
+// the range of option `name` (by option or environment name); false = unknown
+static bool tuningRange(const char *name, int &lo, int &hi) {
+    for (int i = 0; i < kTuningCount; i++)
+        if (strcmp(name, kTuningTable[i].name) == 0 || strcmp(name, kTuningTable[i].env) == 0) {
+            lo = kTuningTable[i].lo;
+            hi = kTuningTable[i].hi;
+            return true;
+        }
+    return false;
+}
+
+// a value outside an option's range is an error (FT_ERR_INVALID from ft_context_create), not a silently different setting
+bool ft_tuning_from_env(ft_tuning &t, std::string &err) {
     for (int i = 0; i < kTuningCount; i++) {
         const char *e = ft_read_env(kTuningTable[i].env);
-        if (e && *e) *ft_tuning_field(t, kTuningTable[i].name) = atoi(e);
+        if (!e || !*e) continue;
+        const int v = atoi(e);
+        if (v < kTuningTable[i].lo || v > kTuningTable[i].hi) {
+            err = std::string(kTuningTable[i].env) + "=" + e + " is outside [" + std::to_string(kTuningTable[i].lo) + ", " +
+                  std::to_string(kTuningTable[i].hi) + "]";
+            return false;
+        }
+        *ft_tuning_field(t, kTuningTable[i].name) = v;
     }
-    return t;
+    return true;
 }
 
 // "own" (private streams: empty map) or whole sets of four lane numbers in [0, 64); anything else is an error, not a
@@ -229,6 +247,14 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
             return FT_ERR_INVALID;
         }
     }
+    ft_tuning tuning;
+    {
+        std::string err;
+        if (!ft_tuning_from_env(tuning, err)) {
+            ft_set_error("ft_context_create: " + err);
+            return FT_ERR_INVALID;
+        }
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) {
@@ -255,7 +281,7 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
     ctx->pool = new ft::ThreadPool(host_threads - 1);
     // FT_LANE_MAP="a b o0 o1  a b o0 o1 ..." : lane of (stage A, stage B, octree 0, octree 1) for the 1st, 2nd, ... extractor
     // created on the context (the list wraps around); FT_LANE_MAP=own gives every extractor four streams of its own
-    ctx->tuning = ft_tuning_from_env();
+    ctx->tuning = tuning;
     ctx->hwQueues = ft_hw_queues_hint();
     // the shipped table was searched with 10 queues (a queue per lane, the upload stream, the matchers' stream): with fewer
     // the lanes share queues in an order the runtime picks, which is what the table exists to avoid
@@ -349,6 +375,14 @@ int ft_context_set_option(ft_context *ctx, const char *name, int value) {
         ft_set_error(std::string("ft_context_set_option: unknown option \"") + (name ? name : "(null)") + "\"");
         return FT_ERR_INVALID;
     }
+    int lo = 0, hi = 0;
+    if (!tuningRange(name, lo, hi) || value < lo || value > hi) {
+        ft_set_error(std::string("ft_context_set_option: ") + name + " = " + std::to_string(value) + " is outside [" +
+                     std::to_string(lo) + ", " + std::to_string(hi) + "]");
+        return FT_ERR_INVALID;
+    }
+    // the search_* and pass_burst options are read per call, under the same mutex
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
     *f = value;
     return FT_OK;
 }
@@ -360,6 +394,14 @@ int ft_context_get_option(const ft_context *ctx, const char *name, int *value) {
         return FT_ERR_INVALID;
     }
     *value = *f;
+    return FT_OK;
+}
+
+int ft_option_range(const char *name, int *min_value, int *max_value) {
+    int lo = 0, hi = 0;
+    if (!name || !tuningRange(name, lo, hi)) return FT_ERR_INVALID;
+    if (min_value) *min_value = lo;
+    if (max_value) *max_value = hi;
     return FT_OK;
 }
 

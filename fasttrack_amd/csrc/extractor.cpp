@@ -77,7 +77,7 @@ int buildGeometry(ft_extractor *ex, std::vector<FtTap> &taps) {
         }
         ex->quota[L - 1] = std::max(ex->nfeatures - sum, 0);
     }
-    int pyrOff = 0, cellBase = 0, stageBase = 0, candBase = 0, tapOff = 0, maxKp = 0, stripBase = 0;
+    int pyrOff = 0, cellBase = 0, stageBase = 0, candBase = 0, tapOff = 0, maxKp = 0;
     ex->levelMax.assign(L, 0);
     for (int l = 0; l < L; l++) {
         FtLevelGeom &v = g.lv[l];
@@ -123,23 +123,10 @@ int buildGeometry(ft_extractor *ex, std::vector<FtTap> &taps) {
             v.ytab = tapOff;
             tapOff += v.h;
         }
-        // FAST strips: balanced cut of the tested rectangle (every pixel of it belongs to exactly one cell: the cells'
-        // tested regions tile [19, w-19) x [19, h-19), ORBextractor.cc:1136-1158)
-        v.stripBase = stripBase;
-        if (nCols > 0) {
-            const int envRows = std::max(8, std::min(120, ex->tune.strip_rows));
-            const int tw = v.w - 2 * FT_EDGE_THRESHOLD, th = v.h - 2 * FT_EDGE_THRESHOLD;
-            v.sNX = (tw + FT_STRIP_MAXW - 1) / FT_STRIP_MAXW;
-            v.sW = (tw + v.sNX - 1) / v.sNX;
-            v.sNY = (th + envRows - 1) / envRows;
-            v.sH = (th + v.sNY - 1) / v.sNY;
-            stripBase += v.sNX * v.sNY;
-        }
         ex->levelMax[l] = ft::octree_max_result(minB, v.maxBX, minB, v.maxBY, ex->quota[l]);
         maxKp += ex->levelMax[l];
     }
     g.totalCells = cellBase;
-    g.totalStrips = stripBase;
     g.stagePerSlot = stageBase;
     g.candPerSlot = candBase;
     g.pyrPerSlot = pyrOff;
@@ -202,8 +189,6 @@ void freeAll(ft_extractor *ex) {
     hipFree(ex->d_taps);
     hipFree(ex->d_cellTab);
     hipFree(ex->d_cellCount);
-    hipFree(ex->d_stripTab);
-    hipFree(ex->d_cellCount2);
     hipFree(ex->d_stage);
     hipFree((void *)ex->d_l0);
     hipFree(ex->d_sel);
@@ -411,49 +396,21 @@ int ft_extract_launch_a(ft_extractor *ex, int b0, int nb, hipEvent_t done) {
     int *cellCount = ex->d_cellCount + (size_t)b0 * g.totalCells;
     uint32_t *stage = ex->d_stage + (size_t)b0 * g.stagePerSlot;
     ex->evt.begin(tm, "kernel.pyr_down(all levels)", ex->stream);
-    int rc = FT_OK;
-    {
-        // the levels of a group of images back to back: a group small enough that an XCD's share of a level stays in its L2
-        // between the launch that writes it and the launch that reads it (option pyr_group)
-        const int group = ex->tune.pyr_group >= 8 ? ex->tune.pyr_group : nb;
-        for (int s0 = 0; s0 < nb && rc == FT_OK; s0 += group)
-            rc = ft_launch_pyramid(ex->stream, g, std::min(group, nb - s0), l0 + s0, ex->l0pitch, pyr + (size_t)s0 * g.pyrPerSlot,
-                                   ex->d_taps, al, ex->tune.pyr_rows);
-    }
+    int rc = ft_launch_pyramid(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->d_taps, al, ex->tune.pyr_rows);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.fast_cells", ex->stream);
-    // the device octree ranks candidates by their coordinates: FAST need not deliver them in the reference's order, which
-    // frees it from the cell grid altogether (k_fast_strips, opt-in: FT_FAST_STRIPS=1 when the extractor is created -
-    // 11 % fewer VALU instructions than the per-cell kernel but a larger LDS footprint, no faster on MI355X; EXPERIMENTS.md section 3.4);
-    // the host octree gets the ordered per-cell kernel
-    const bool strips = ex->fastStrips && ex->deviceOctree && al && g.totalStrips > 0;
-    int *cellCount2 = ex->d_cellCount2 + (size_t)b0 * g.totalCells * 2;
-    if (strips) {
-        uint32_t *candScratch = (ex->deviceOctree ? ex->d_candDev : ex->d_cand) + (size_t)b0 * g.candPerSlot;
-        int *cntScratch = (ex->deviceOctree ? ex->d_candCountDev : ex->d_candCount) + (size_t)b0 * g.nlevels;
-        // FT_DEBUG_REPEAT=fast: the kernel files its survivors through counters that the compaction consumes, so the
-        // repeated launch gets a compaction of its own
-        for (int rep = ft_debug_repeat("fast"); rep > 1 && rc == FT_OK; rep--) {
-            rc = ft_launch_fast_strips(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->iniTh, ex->minTh, cellCount2, stage, ex->d_stripTab);
-            if (rc == FT_OK) rc = ft_launch_compact_strips(ex->stream, g, nb, cellCount2, stage, candScratch, cntScratch);
-        }
-        if (rc == FT_OK)
-            rc = ft_launch_fast_strips(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->iniTh, ex->minTh, cellCount2, stage, ex->d_stripTab);
-    } else
-        rc = ft_launch_fast_cells(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->iniTh, ex->minTh, al, cellCount, stage,
-                                  ex->deviceOctree ? 0 : 1, ex->d_cellTab);
+    // the device octree ranks candidates by their coordinates: FAST need not deliver them in the reference's order; the host
+    // octree gets the ordered per-cell kernel
+    rc = ft_launch_fast_cells(ex->stream, g, nb, l0, ex->l0pitch, pyr, ex->iniTh, ex->minTh, al, cellCount, stage,
+                              ex->deviceOctree ? 0 : 1, ex->d_cellTab);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     ex->evt.begin(tm, "kernel.compact", ex->stream);
     uint32_t *candDst = ex->deviceOctree ? ex->d_candDev : ex->d_cand;
     int *cntDst = ex->deviceOctree ? ex->d_candCountDev : ex->d_candCount;
-    if (strips)
-        rc = ft_launch_compact_strips(ex->stream, g, nb, cellCount2, stage, candDst + (size_t)b0 * g.candPerSlot,
-                                      cntDst + (size_t)b0 * g.nlevels);
-    else
-        rc = ft_launch_compact(ex->stream, g, nb, cellCount, stage, candDst + (size_t)b0 * g.candPerSlot,
-                               cntDst + (size_t)b0 * g.nlevels);
+    rc = ft_launch_compact(ex->stream, g, nb, cellCount, stage, candDst + (size_t)b0 * g.candPerSlot,
+                           cntDst + (size_t)b0 * g.nlevels);
     ex->evt.end(tm, ex->stream);
     if (rc != FT_OK) return rc;
     if (done) FT_HIP(hipEventRecord(done, ex->stream));
@@ -497,7 +454,7 @@ int ft_extract_launch_octree(ft_extractor *ex, int sub, int b0, int nb, hipEvent
     a.sortList = ex->d_sortList + (size_t)(sub % FT_OCT_STREAMS) * ex->maxBatch * g.nlevels;
     const bool tm = ex->ctx->kernelTiming;
     ex->evt.begin(tm, "kernel.octree", so);
-    int rc = ft_launch_octree(so, g, nb, a, ex->tune.oct_smem_pad);
+    int rc = ft_launch_octree(so, g, nb, a);
     ex->evt.end(tm, so);
     if (rc != FT_OK) return rc;
     if (done) FT_HIP(hipEventRecord(done, so));
@@ -805,7 +762,6 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     ex->height = image_height;
     ex->maxBatch = max_batch;
     ex->tune = ctx->tuning;  // the extractor keeps the switches it was created under
-    ex->fastStrips = ex->tune.fast_strips != 0;
     std::vector<FtTap> taps;
     rc = buildGeometry(ex, taps);
     if (rc != FT_OK) {
@@ -848,8 +804,6 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     FT_TRY(devAlloc(&ex->d_taps, taps.size()));
     FT_TRY(devAlloc(&ex->d_cellTab, (size_t)std::max(g.totalCells, 1)));
     FT_TRY(devAlloc(&ex->d_cellCount, B * g.totalCells));
-    FT_TRY(devAlloc(&ex->d_stripTab, (size_t)std::max(g.totalStrips, 1)));
-    FT_TRY(devAlloc(&ex->d_cellCount2, B * g.totalCells * 2));
     FT_TRY(devAlloc(&ex->d_stage, B * g.stagePerSlot));
     FT_TRY(devAlloc(&ex->d_l0, B));
     FT_TRY(devAlloc(&ex->d_sel, B * g.maxKp));
@@ -903,14 +857,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
                     r.outOff = (uint32_t)(v.stageBase + c * v.cellCap);
                 }
         }
-        std::vector<uint32_t> stripTab(std::max(g.totalStrips, 1), 0u);
-        for (int l = 0; l < nlevels; l++)
-            for (int sy = 0; sy < g.lv[l].sNY; sy++)
-                for (int sx = 0; sx < g.lv[l].sNX; sx++)
-                    stripTab[g.lv[l].stripBase + sy * g.lv[l].sNX + sx] = (uint32_t)l | ((uint32_t)sy << 8) | ((uint32_t)sx << 20);
         hipError_t e = hipMemcpy(ex->d_cellTab, cellTab.data(), cellTab.size() * sizeof(FtCellRec), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(ex->d_stripTab, stripTab.data(), stripTab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemset(ex->d_cellCount2, 0, sizeof(int) * std::max<size_t>(B * g.totalCells * 2, 1));
         if (e == hipSuccess) e = hipMemcpy(ex->d_taps, taps.data(), taps.size() * sizeof(FtTap), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(ex->d_nSel, 0, sizeof(int) * B);
         if (e != hipSuccess) {
@@ -953,15 +900,14 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
         o.sortList = ex->d_sortList;
         o.low = nullptr;  // set per launch (ft_extract_launch_octree)
         if (ex->deviceOctree) {
-            if (ex->tune.oct_profile) {
+            if (ft_debug_env("FT_DEBUG_OCT_PROFILE")) {  // per-level phase clocks of k_octree (slot 0) kept on the device
                 FT_TRY(devAlloc(&o.prof, (size_t)FT_MAX_LEVELS * 8));
                 hipMemset(o.prof, 0, sizeof(unsigned long long) * FT_MAX_LEVELS * 8);
             }
             FT_TRY(devAlloc(&ex->d_candDev, B * g.candPerSlot));
             FT_TRY(devAlloc(&ex->d_candCountDev, B * g.nlevels));
-            // FT_OCT_COMPACT=0: the first sorted tier in the plain LDS layout (64 instead of 49 KB per workgroup)
-            if (ex->tune.oct_compact != 0 &&
-                ft_octree_smem_bytes(o.poolCap, true) < ft_octree_smem_bytes(o.poolCap, false))
+            // the first sorted tier in the compact LDS layout (49 instead of 64 KB per workgroup) wherever it fits
+            if (ft_octree_smem_bytes(o.poolCap, true) < ft_octree_smem_bytes(o.poolCap, false))
                 FT_TRY(devAlloc(&ex->d_octLow, B * g.nlevels * (size_t)FT_OCT_MAXN));
             hipError_t me = hipMemset(ex->d_overflow, 0, sizeof(int));
             if (me == hipSuccess) me = hipMemset(ex->d_ovSlot, 0, sizeof(int) * B);
@@ -992,18 +938,21 @@ int ft_octree_distribute(const int *xys, int n, int minX, int maxX, int minY, in
     }
     ft::OctreeWorkspace ws;
     std::vector<int> keep;
-    // FT_OCTREE_PATHS=1 / 2 / 3 route this host entry point through the path-code formulations the device kernels
+    // FT_DEBUG_OCTREE_PATHS=1 / 2 / 3 route this host entry point through the path-code formulations the device kernels
     // are built from (1: node list replay, 2: round formulation over sorted keys, 3: over a histogram), so they can be
     // checked without a GPU
-    const ft_tuning tune = ft_tuning_from_env();  // a host entry point without a context: the switches of this call
-    const int usePaths = tune.octree_paths;
+    auto dbgInt = [](const char *name, int def) {
+        const char *e = ft_debug_env(name);
+        return e && *e ? atoi(e) : def;
+    };
+    const int usePaths = dbgInt("FT_DEBUG_OCTREE_PATHS", 0);
     int k;
     if (usePaths == 3 && n < 65535) {
-        // 3: the histogram formulation of k_octree_hist (FT_OCTREE_HIST_BINS bins, default 8192); a level it gives up on
-        // goes to the sorted rounds, as on the device.  FT_OCTREE_HIST_STRICT=1 reports the give-up instead.
-        const int bins = tune.octree_hist_bins;
+        // 3: the histogram formulation of k_octree_hist (FT_DEBUG_OCTREE_HIST_BINS bins, default 8192); a level it gives up
+        // on goes to the sorted rounds, as on the device.  FT_DEBUG_OCTREE_HIST_STRICT=1 reports the give-up instead.
+        const int bins = dbgInt("FT_DEBUG_OCTREE_HIST_BINS", FT_OCT_HIST_BINS);
         k = ft::distribute_octree_hist(packed.data(), n, minX, maxX, minY, maxY, N, bins, keep);
-        if (k == -2 && !tune.octree_hist_strict) {
+        if (k == -2 && !dbgInt("FT_DEBUG_OCTREE_HIST_STRICT", 0)) {
             keep.clear();
             k = ft::distribute_octree_rounds(packed.data(), n, minX, maxX, minY, maxY, N, keep);
         }
@@ -1100,8 +1049,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
     const int sb = (batch + S - 1) / S;
     // everything a batch needs with the device octree, enqueued without a host synchronisation (capture != 0: ex->stream is
     // being captured into a graph; the octree / stage-B streams fork from it through events and are joined back)
-    const bool deliverOn = ex->tune.deliver_kernel != 0;
-    const bool deliver = deliverOn && batch <= 8;  // (FtDeliverArgs, ft_internal.h)
+    const bool deliver = batch <= 8;  // (FtDeliverArgs, ft_internal.h)
     auto enqueueDevice = [&](int capture) -> int {
         int r = ft_extract_prepare(ex, images, batch, on_device, width, height, stride);
         if (r != FT_OK) return r;

@@ -40,36 +40,25 @@
 // search switches are read per call).  Nothing else in the library reads FT_* variables except the FT_DEBUG_* aids
 // (ft_debug_env, context.cpp) and FT_LANE_MAP (a list, ft_context_create).
 #define FT_TUNING_OPTIONS(X)                                                                                                  \
-    X(pipeline_depth, "FT_PIPELINE_DEPTH", 0, "sub-batches a throughput batch is enqueued as (0 = automatic, 1 = no pipelining, <= 8)") \
-    X(device_octree, "FT_DEVICE_OCTREE", 1, "DistributeOctTree on the device (0 = host thread pool)")                        \
-    X(oct_hist, "FT_OCT_HIST", 1, "histogram tier of the device octree for levels above 4096 candidates")                    \
-    X(oct_hist_first, "FT_OCT_HIST_FIRST", 1, "histogram formulation for every level: 0 never, 1 latency-mode launches, 2 always") \
-    X(oct_big, "FT_OCT_BIG", 1, "sorted big tier of the device octree (up to 16384 keys per level)")                         \
-    X(oct_compact, "FT_OCT_COMPACT", 1, "first sorted tier in the compact LDS layout (49 instead of 64 KB per workgroup)")   \
-    X(oct_profile, "FT_OCT_PROFILE", 0, "per-level phase clocks of k_octree (slot 0) kept on the device")                    \
-    X(oct_smem_pad, "FT_OCT_SMEM_PAD", 0, "extra LDS bytes per k_octree workgroup (occupancy probe)")                        \
-    X(fast_strips, "FT_FAST_STRIPS", 0, "FAST over 62-column strips instead of one wave per cell")                           \
-    X(strip_rows, "FT_STRIP_ROWS", 16, "rows per strip of the strips form (8 .. 120)")                                       \
-    X(pyr_group, "FT_PYR_GROUP", 0, "images per pyramid launch group (0 = the whole sub-batch per level; >= 8: the levels of a group of images back to back, so that a level is read from the L2 it was just written to)")         \
-    X(pyr_rows, "FT_PYR_ROWS", 1, "pyramid of launches of 8+ images: 1 = one level per pass (k_pyr_rows), 2 = two levels per pass (k_pyr_rows2: fewer bytes, measured 1.5 % slower in the pipeline; 10 + k = only from level k upwards), 0 = tile kernel")         \
-    X(upload_kernel, "FT_UPLOAD_KERNEL", 1, "latency mode: frames go up through k_upload instead of DMA copies")             \
-    X(deliver_kernel, "FT_DELIVER_KERNEL", 1, "latency mode: one kernel writes all results into pinned host memory")         \
-    X(graph, "FT_GRAPH", 1, "latency mode: batches of <= 8 frames are captured and replayed as HIP graphs")                  \
-    X(paired, "FT_PAIRED", 1, "latency-mode stereo front ends run both cameras through one set of launches")                \
-    X(pass_burst, "FT_PASS_BURST", 12, "projection searches, multi-launch path: claim passes enqueued per host round trip (2 .. 14)") \
-    X(search_cache, "FT_SEARCH_CACHE", 1, "projection searches: later claim passes walk the cached candidate keys")          \
-    X(search_grid, "FT_SEARCH_GRID", 1, "projection searches: CSR grid of the frame built on the device")                    \
-    X(search_persistent, "FT_SEARCH_PERSISTENT", 0, "projection searches: all claim passes inside ONE launch with grid barriers (measured slower than a launch per pass: EXPERIMENTS.md)") \
-    X(octree_paths, "FT_OCTREE_PATHS", 0, "ft_octree_distribute (host entry): 1 / 2 / 3 = the path-code formulations of the device kernels") \
-    X(octree_hist_bins, "FT_OCTREE_HIST_BINS", FT_OCT_HIST_BINS, "ft_octree_distribute, formulation 3: histogram bins")      \
-    X(octree_hist_strict, "FT_OCTREE_HIST_STRICT", 0, "ft_octree_distribute, formulation 3: report a give-up instead of falling back")
+    X(pipeline_depth, "FT_PIPELINE_DEPTH", 0, 0, 8, "sub-batches a throughput batch is enqueued as (0 = automatic, 1 = no pipelining, <= 8)") \
+    X(device_octree, "FT_DEVICE_OCTREE", 1, 0, 1, "DistributeOctTree on the device (0 = host thread pool)")                  \
+    X(oct_hist, "FT_OCT_HIST", 1, 0, 1, "histogram tier of the device octree for levels above 4096 candidates")              \
+    X(oct_hist_first, "FT_OCT_HIST_FIRST", 1, 0, 2, "histogram formulation for every level: 0 never, 1 latency-mode launches, 2 always") \
+    X(oct_big, "FT_OCT_BIG", 1, 0, 1, "sorted big tier of the device octree (up to 16384 keys per level)")                   \
+    X(pyr_rows, "FT_PYR_ROWS", 1, 0, 1, "pyramid of launches of 8+ images: 1 = row-streaming kernel (k_pyr_rows), 0 = tile kernel (k_pyr_down)") \
+    X(upload_kernel, "FT_UPLOAD_KERNEL", 1, 0, 1, "latency mode: frames go up through k_upload instead of DMA copies")       \
+    X(graph, "FT_GRAPH", 1, 0, 1, "latency mode: batches of <= 8 frames are captured and replayed as HIP graphs")            \
+    X(paired, "FT_PAIRED", 1, 0, 1, "latency-mode stereo front ends run both cameras through one set of launches")           \
+    X(pass_burst, "FT_PASS_BURST", 12, 2, 14, "projection searches: claim passes enqueued per host round trip")              \
+    X(search_cache, "FT_SEARCH_CACHE", 1, 0, 1, "projection searches: later claim passes walk the cached candidate keys")    \
+    X(search_grid, "FT_SEARCH_GRID", 1, 0, 1, "projection searches: CSR grid of the frame built on the device")
 
 struct ft_tuning {
-#define FT_X(field, env, def, doc) int field = def;
+#define FT_X(field, env, def, lo, hi, doc) int field = def;
     FT_TUNING_OPTIONS(FT_X)
 #undef FT_X
 };
-ft_tuning ft_tuning_from_env();                                      // defaults overridden by the FT_* variables that are set
+bool ft_tuning_from_env(ft_tuning &t, std::string &err);             // defaults overridden by the FT_* variables that are set; false: a value out of range
 int *ft_tuning_field(ft_tuning &t, const char *name);                // by option name or by environment name; null = unknown
 const char *ft_debug_env(const char *name);                          // FT_DEBUG_* aids: the one other place that reads the environment
 const char *ft_read_env(const char *name);                           // context.cpp only: the single getenv of the library
@@ -195,9 +184,6 @@ struct ft_extractor {
     FtTap *d_taps = nullptr;
     FtCellRec *d_cellTab = nullptr;  // per FAST cell: origin, tile shape, level, source and staging offsets
     int *d_cellCount = nullptr;
-    uint32_t *d_stripTab = nullptr;  // per FAST strip: level | strip row << 8 | strip column << 20
-    int *d_cellCount2 = nullptr;     // [maxBatch][totalCells][2]: strong / weak survivors per cell (strips form), zero between launches
-    bool fastStrips = false;
     uint32_t *d_stage = nullptr;
     const uint8_t **d_l0 = nullptr;
     const uint8_t **h_l0 = nullptr;  // pinned

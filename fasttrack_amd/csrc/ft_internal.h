@@ -32,9 +32,6 @@ struct FtLevelGeom {
     int candCap;       // capacity of that list
     int xtab, ytab;    // offsets of the resize tables of this level (level >= 1)
     int area2x;        // level is an exact 2x decimation of the previous one (INTER_AREA path)
-    // FAST strips (k_fast_strips): the tested rectangle [19, w-19) x [19, h-19) cut into sNX x sNY strips whose
-    // interiors are sW x sH pixels (sW <= 62: with a one-pixel halo a row of a strip is one wave)
-    int sNX, sNY, sW, sH, stripBase;
 };
 
 struct FtGeom {
@@ -44,7 +41,6 @@ struct FtGeom {
     int candPerSlot;   // dense candidate entries per slot
     int pyrPerSlot;    // pyramid bytes per slot
     int maxKp;         // keypoint capacity per slot
-    int totalStrips;   // FAST strips of all levels
     float sf[FT_MAX_LEVELS];     // mvScaleFactor
     float invsf[FT_MAX_LEVELS];  // mvInvScaleFactor
     unsigned fastLv[FT_MAX_LEVELS];  // k_fast_cells: row pitch | cellCap << 16 of the level (one scalar load)
@@ -196,23 +192,12 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
                          uint32_t *stage, int ordered, const FtCellRec *cellTab);
 int ft_launch_compact(hipStream_t st, const FtGeom &g, int batch, const int *cellCount, const uint32_t *stage,
                       uint32_t *cand, int *candCount);
-// strips form (device octree): FAST over 62-column strips that ignore the cell grid; every NMS survivor is filed under
-// its cell with an atomic counter pair - cellCount2[slot][cell][0] strong survivors (score >= iniThFAST, from the front
-// of the cell's staging), [1] the others (from the back) - and the compaction applies the cell's threshold fallback and
-// zeroes the counters again
-int ft_launch_fast_strips(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                          const uint8_t *pyr, int iniTh, int minTh, int *cellCount2, uint32_t *stage,
-                          const uint32_t *stripTab);
-int ft_launch_compact_strips(hipStream_t st, const FtGeom &g, int batch, int *cellCount2, const uint32_t *stage,
-                             uint32_t *cand, int *candCount);
-size_t ft_fast_strips_smem_bytes(const FtGeom &g);
-#define FT_STRIP_MAXW 62
 // sel is laid out per level (slot * maxKp + selOff[level] + i) with per-level counts; the kernel packs the
 // results in level order (slot * maxKp + k) and stores the per-image total in nSel
 int ft_launch_orient_desc(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                           const uint8_t *pyr, int alignedLoads, const FtSelKp *sel, const int *selCount,
                           const FtOctArgs &layout, int *nSel, ft_keypoint *keys, uint8_t *desc);
-int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a, int smemPad = 0);
+int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a);
 // test tap: 7x7 Gaussian of a whole level through k_orient_desc's blur routines (dst on the device)
 int ft_launch_blur_level(hipStream_t st, const uint8_t *img, int pitch, int w, int h, uint8_t *dst, int dstPitch);
 size_t ft_octree_smem_bytes(int poolCap, bool compact = false);

@@ -67,6 +67,7 @@ struct FtClaims {
     int *flagCur;            // this pass's flag (atomicAnd 0 on a change)
     const int *flagPrev;     // the previous pass's flag (null for the first pass of a burst)
     int *flagReset;          // the flag of the same position in the other burst parity: reset to -1 here
+    int *flagStick = nullptr;  // batch form only: the 16 flag words of this burst (claims_begin_pass, kernels_search.hip)
     // Candidate cache (may be null).  What does NOT change from pass to pass - which keypoints of a point's window pass the
     // level band, the box and the uright test, and their Hamming distances - is computed once: the first pass that reaches a
     // (point, camera) window files the (distance, cell x, cell y, index) keys of all its candidates here, and every later
@@ -81,16 +82,6 @@ struct FtClaims {
 #define FT_CACHE_CAP 511
 #endif
 #define FT_CACHE_WORDS (2 * (FT_CACHE_CAP + 1))  // per point: left and right camera
-
-// the claim iteration in one launch (k_search_*_persist): the rotating buffers of fixedPoint (search.cpp) and six sync words
-struct FtPersist {
-    int *res, *head, *next;  // 2 x 4 nPoints, 3 x K, 2 x 4 nPoints
-    int *tab;                // 3 x 8 K
-    int *sync;               // [0..3] flag ring, [4] status (passes run; < -16: not converged after -(status) - 16 passes;
-                             // -2: a grid barrier timed out), [5] arrival counter; all -1 when the launch starts
-    int K, nPoints, maxPasses;
-};
-#define FT_PERSIST_STATUS_TIMEOUT (-2)
 
 // a rigid transform: row-major 3x4 (y = R x + t), or - quat != 0 - as Sophus::SE3f holds and applies it: unit quaternion
 // q = (x, y, z, w), translation in m[3], m[7], m[11] (transform_pose, kernels_search.hip)
@@ -125,6 +116,43 @@ struct FtFrustumOut {
     int *count;           // nToMatch (atomic; zeroed by the launcher)
 };
 
+// One frame of a batch of searches (ft_tracked_batch, search.cpp): what the batch kernels read of frame blockIdx.y, resident
+// in HBM.  Every pointer of a job points into the device arena of its batch (`arena` of the launchers below: the kernels
+// re-derive the pointers from it, see Rebase in kernels_search.hip).  The rotating buffers of the claim iteration are addressed by pass number (job_claims, kernels_search.hip):
+// res 2 x 4 nPoints | head 3 x K | next 2 x 4 nPoints | tab 3 x 8 K (K = keypoints rounded up to 8) | flags 32.
+struct FtBatchJob {
+    FtDevFrame F;
+    int *res, *head, *next, *tab, *flags;
+    const int *obs;             // Observations() per point of the running search
+    unsigned long long *cache;  // FT_CACHE_WORDS per point, or null
+    int K, nKp, nPoints;
+    // SearchByProjection(CurrentFrame, LastFrame)
+    FtDevLastPoints L;
+    FtPose Tcw;
+    int forward, backward;
+    // isInFrustum + SearchByProjection(Frame, local map points)
+    FtDevMapPoints MP;
+    FtFrustumPose T;
+    FtFrustumOut O;
+    FtDevLocalPoints P;
+};
+
+// a block of dwords delivered into pinned host memory by k_deliver_batch; src[parity of the last pass]
+struct FtDeliverRec {
+    void *dst;
+    const void *src[2];
+    int words;
+};
+int ft_launch_fill_claims_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxWords);
+int ft_launch_deliver_batch(hipStream_t st, const FtDeliverRec *recs, int nRecs, int maxWords, int parity);
+int ft_launch_build_grid_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxLevels, bool twoCam);
+int ft_launch_frustum_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxM, float viewingCosLimit, float logScaleFactor,
+                            int farPoints, float thFar);
+// one pass of the claim iteration of every frame; fCur / fPrev / fReset: positions in each frame's flag words (fPrev < 0: none)
+int ft_launch_search_last_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur, int fPrev,
+                                int fReset, float th);
+int ft_launch_search_local_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur, int fPrev,
+                                 int fReset, float th, float nnRatio);
 int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v);
 // p[0 .. n) = -1 and meta[i * strideWords] = ~0 for i < nMeta (meta may be null): the start of a claim iteration, one launch
 int ft_launch_fill_claims(hipStream_t st, int *p, int n, unsigned long long *meta, int nMeta, int strideWords);
@@ -142,10 +170,5 @@ int ft_launch_search_local(hipStream_t st, const FtDevFrame &F, const FtDevLocal
                            float nnRatio, int *res, const FtLocalRaw &raw);
 int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
                           const FtPose &Tcw, float th, int forward, int backward, int *res, const FtLastRaw &raw);
-int ft_search_persist_capacity();  // points one persistent launch serves (one workgroup per CU)
-int ft_launch_search_local_persist(hipStream_t st, const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
-                                   float nnRatio, const FtPersist &S, const FtLocalRaw &raw);
-int ft_launch_search_last_persist(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
-                                  const FtPose &Tcw, float th, int forward, int backward, const FtPersist &S, const FtLastRaw &raw);
 int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridStartR, float4 *recL, uint8_t *descL,
                          float4 *recR, uint8_t *descR);

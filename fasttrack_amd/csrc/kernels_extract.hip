@@ -420,192 +420,6 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two pyramid levels per pass (round 4): level l from level l - 1 exactly as k_pyr_rows does it, and level l + 1 from the
-// rows of level l the wave has just produced - kept in LDS (33 rows x 128 bytes per wave), so level l is written to HBM but
-// not read back.  The pyramid is the one kernel of the pipeline that is priced by its bytes (EXPERIMENTS.md section 8 (5)):
-// of the 2.80 MB per 1280x720 image the seven launches read, 1.10 MB are the levels 1, 3 and 5 they wrote a moment before.
-//
-// Partition.  A strip of level l is 128 columns x 33 rows, strips STEP by 127 columns and 32 rows: neighbouring strips share
-// one column and one row, which both compute (the same value, stored twice).  An output pixel (dx2, dy2) of level l + 1 needs
-// the level-l columns sx2, sx2 + 1 and rows sy2, sy2 + 1 (clamped as cv::resize clamps them); it belongs to the strip with
-// c0 <= sx2 <= c0 + 126 and j0 <= clamp(sy2) <= j0 + 31, which holds all four taps.  sx2 and sy2 are monotone, so a strip's
-// share of level l + 1 is a rectangle [x2lo, x2hi) x [y2lo, y2hi) found by one vector load of taps and a ballot each.
-// Stage 2 repeats stage 1's arithmetic with LDS rows as its source: a lane owns two adjacent output columns,
-// the 8-byte window with their four taps is one ds_read2_b32, v_perm + v_dot2 interpolate, interpolated rows are reused.
-// ------------------------------------------------------------------------------------------------
-#define PR2_CSTEP 127
-#define PR2_RSTEP 32
-#define PR2_ROWS 33
-#define PR2_LDS_PITCH 128
-__global__ __launch_bounds__(64) void k_pyr_rows2(FtGeom g, int level, const uint8_t *const *l0, int l0pitch, uint8_t *pyr,
-                                                  const FtTap *taps, FtSlotGrid sg, int stripsX, unsigned sxMagic, int readableEnd) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[PR2_ROWS * PR2_LDS_PITCH];
-    const int lane = threadIdx.x;
-    int slot, tile;
-    if (!ft_slot_block(sg, slot, tile)) return;
-    const int ty = div_by(tile, sxMagic), tx = tile - ty * stripsX;
-    const FtLevelGeom &D = g.lv[level], &E = g.lv[level + 1];
-    int spitch;
-    const uint8_t *S = level_ptr(g, level - 1, slot, l0, l0pitch, pyr, spitch);
-    const int sw = g.lv[level - 1].w, sh = g.lv[level - 1].h;
-    const int c0 = tx * PR2_CSTEP, j0 = ty * PR2_RSTEP;
-    const int dx = c0 + 2 * lane;
-    const int nrows = min(PR2_ROWS, D.h - j0);
-    uint8_t *slotPyr = pyr + (size_t)slot * g.pyrPerSlot;
-    // ---- the strip's share of level l + 1 (requested first: the loads are behind stage 1 when stage 2 needs them) ----
-    // first index whose (clamped) tap reaches `bound`, searched in a 64-entry window around the arithmetic estimate
-    auto firstAtLeast = [&](int tab, int n, int srcN, int dstN, int bound, int clampHi) -> int {
-        if (bound <= 0) return 0;
-        const int est = (int)(((long long)bound * dstN) / srcN);  // ~ bound / scale; the boundary lies within a few entries of it
-        const int i = est - 32 + lane;
-        const int ic = min(max(i, 0), n - 1);
-        const int sTap = min(max((int)(short)(gload<unsigned>(taps + tab + ic) & 0xffffu), 0), clampHi);
-        const unsigned long long b = __builtin_amdgcn_ballot_w64(i >= n || (i >= 0 && sTap >= bound));
-        return est - 32 + (b ? (int)__builtin_ctzll(b) : 64);
-    };
-    const int x2lo = firstAtLeast(E.xtab, E.w, D.w, E.w, c0, D.w - 1);
-    const int x2hi = min(firstAtLeast(E.xtab, E.w, D.w, E.w, c0 + PR2_CSTEP, D.w - 1), E.w);
-    const int y2lo = firstAtLeast(E.ytab, E.h, D.h, E.h, j0, D.h - 1);
-    const int y2hi = min(firstAtLeast(E.ytab, E.h, D.h, E.h, j0 + PR2_RSTEP, D.h - 1), E.h);
-    // ---- stage 2 set-up: [x2lo, x2hi) x [y2lo, y2hi) of level l + 1; its rows are produced INSIDE stage 1's loop, each as soon
-    // as the level-l rows it needs are in LDS, so its arithmetic runs in the shadow of stage 1's row loads instead of
-    // extending the wave's life (as a pass of its own behind stage 1 the fused kernel was 1.5 % slower than two launches) ----
-    const int n2rows = max(y2hi - y2lo, 0);
-    const bool have2 = n2rows > 0 && x2hi > x2lo;  // wave-uniform
-    const int x2a = x2lo & ~1;                     // pairs start at an even column: aligned 2-byte stores
-    const int ex = x2a + 2 * lane;                 // this lane's two columns: ex, ex + 1 (masked to [x2lo, x2hi))
-    unsigned row2W0 = 0xffffffffu, row2W1 = 0;
-    unsigned sel2A = 0, sel2B = 0, w2a = 0, w2b = 0;
-    int base2 = 0;
-    if (have2) {
-        const ft_u2 t = gload<ft_u2>(taps + E.ytab + y2lo + min(lane, n2rows - 1));
-        const int sy = (int)(short)(t.x & 0xffffu);
-        // rows relative to the strip: clamp(sy) - j0 in [0, 31], clamp(sy + 1) - j0 in [0, 32]
-        if (lane < n2rows) row2W0 = (unsigned)(min(max(sy, 0), D.h - 1) - j0) | ((unsigned)(min(max(sy + 1, 0), D.h - 1) - j0) << 16);
-        row2W1 = (t.x >> 16) | (t.y << 16);
-        const int exa = min(max(ex, x2lo), x2hi - 1), exb = min(max(ex + 1, x2lo), x2hi - 1);
-        const ft_u2 ua = gload<ft_u2>(taps + E.xtab + exa), ub = gload<ft_u2>(taps + E.xtab + exb);
-        const int s2a = (int)(short)(ua.x & 0xffffu) - c0, s2b = (int)(short)(ub.x & 0xffffu) - c0;  // LDS columns, in [0, 126]
-        const int lim = min(D.w - 1 - c0, PR2_LDS_PITCH - 1);
-        const int c2a = min(s2a + 1, lim), c2b = min(s2b + 1, lim);
-        w2a = (ua.x >> 16) | (ua.y << 16);
-        w2b = (ub.x >> 16) | (ub.y << 16);
-        base2 = min(s2a & ~3, PR2_LDS_PITCH - 8);
-        sel2A = (unsigned)(s2a - base2) | 0x0c00u | ((unsigned)(c2a - base2) << 16) | 0x0c000000u;
-        sel2B = (unsigned)(s2b - base2) | 0x0c00u | ((unsigned)(c2b - base2) << 16) | 0x0c000000u;
-    }
-    const bool st2 = have2 && ex >= x2lo && ex + 1 < x2hi, st1a = have2 && ex >= x2lo && ex < x2hi,
-               st1b = have2 && ex + 1 >= x2lo && ex + 1 < x2hi;
-    auto rowTap2 = [&](int r, int &sy0, int &sy1, unsigned &b0, unsigned &b1) {
-        const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)row2W0, r), w1 = (unsigned)__builtin_amdgcn_readlane((int)row2W1, r);
-        sy0 = (int)(w0 & 0xffffu); sy1 = (int)(w0 >> 16);
-        b0 = w1 & 0xffffu; b1 = w1 >> 16;
-    };
-    int jr2 = 0, t2y0, t2y1;
-    unsigned t2b0, t2b1;
-    rowTap2(0, t2y0, t2y1, t2b0, t2b1);  // (without a share of level l + 1: the sentinel, which matches no row)
-    uint8_t *dst2 = slotPyr + E.off + (size_t)y2lo * E.pitch + ex;
-    const unsigned *ldsRow2 = (const unsigned *)(lds + base2);
-    unsigned gpA = 0, gpB = 0, gcA = 0, gcB = 0;  // stage 2's interpolated rows: previous, current
-    // ---- stage 1: rows j0 .. j0 + nrows - 1 of level l, columns c0 .. c0 + 127 (k_pyr_rows<false>, strips stepping 127 x 32) ----
-    unsigned rowW0, rowW1;
-    {
-        const ft_u2 t = gload<ft_u2>(taps + D.ytab + j0 + min(lane, nrows - 1));
-        const int sy = (int)(short)(t.x & 0xffffu);
-        rowW0 = (unsigned)min(max(sy, 0), sh - 1) | ((unsigned)min(max(sy + 1, 0), sh - 1) << 16);
-        rowW1 = (t.x >> 16) | (t.y << 16);
-        if (lane >= nrows) rowW0 = 0xffffffffu;  // sentinel: matches no source row
-    }
-    const int dxa = min(dx, D.w - 1), dxb = min(dx + 1, D.w - 1);
-    const ft_u2 ta = gload<ft_u2>(taps + D.xtab + dxa), tb = gload<ft_u2>(taps + D.xtab + dxb);
-    const int sxa = (int)(short)(ta.x & 0xffffu), sxb = (int)(short)(tb.x & 0xffffu);
-    const int cxa = min(sxa + 1, sw - 1), cxb = min(sxb + 1, sw - 1);
-    const unsigned wa = (ta.x >> 16) | (ta.y << 16), wb = (tb.x >> 16) | (tb.y << 16);
-    const int base = min(sxa & ~3, readableEnd - 8);
-    const unsigned selA = (unsigned)(sxa - base) | 0x0c00u | ((unsigned)(cxa - base) << 16) | 0x0c000000u;
-    const unsigned selB = (unsigned)(sxb - base) | 0x0c00u | ((unsigned)(cxb - base) << 16) | 0x0c000000u;
-    const unsigned round2 = 0x20000u;
-    auto rowTap = [&](int r, int &sy0, int &sy1, unsigned &b0, unsigned &b1) {
-        const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)rowW0, r), w1 = (unsigned)__builtin_amdgcn_readlane((int)rowW1, r);
-        sy0 = (int)(w0 & 0xffffu); sy1 = (int)(w0 >> 16);
-        b0 = w1 & 0xffffu; b1 = w1 >> 16;
-    };
-    int jr = 0, sy0, sy1, lastSy0, rLast;
-    unsigned b0, b1, bx0, bx1;
-    rowTap(0, sy0, sy1, b0, b1);
-    rowTap(nrows - 1, lastSy0, rLast, bx0, bx1);
-    int r = sy0;
-    const uint8_t *srcBase = S;
-    uint8_t *dstBase = slotPyr + D.off + (size_t)j0 * D.pitch;
-    unsigned dOff = 0;
-    const unsigned laneSrc = (unsigned)base, laneDst = (unsigned)dx;
-    const bool store2 = dx + 1 < D.w, store1 = dx < D.w;
-    int pfIdx = r;
-    auto prefetch = [&]() -> ft_u2 {
-        unsigned offS = laneSrc + (unsigned)min(pfIdx, rLast) * (unsigned)spitch;
-        asm volatile("" : "+v"(offS));
-        const ft_u2 v = gload<ft_u2>(srcBase + offS);
-        pfIdx++;
-        return v;
-    };
-    ft_u2 q[PR_PF];
-#pragma unroll
-    for (int k = 0; k < PR_PF; k++) q[k] = prefetch();
-    unsigned hpA = 0, hpB = 0, hcA = 0, hcB = 0;
-    unsigned short *ldsLane = (unsigned short *)lds + lane;
-    for (int left = rLast - r + 1; left > 0; left -= PR_PF) {
-#pragma unroll
-        for (int k = 0; k < PR_PF; k++) {
-            hpA = hcA; hpB = hcB;
-            hcA = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selA), wa) >> 4;
-            hcB = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selB), wb) >> 4;
-            q[k] = prefetch();
-            while (sy1 == r) {  // wave-uniform; behind the last output row sy1 matches no row
-                if (__builtin_expect(sy0 == r, 0)) {
-                    hpA = hcA; hpB = hcB;
-                    asm volatile("" : "+v"(hpA), "+v"(hpB));
-                }
-                const unsigned oA = ((umad24_su(b0, hpA, round2) >> 16) + (umul24_su(b1, hcA) >> 16)) >> 2;
-                const unsigned oB = ((umad24_su(b0, hpB, round2) >> 16) + (umul24_su(b1, hcB) >> 16)) >> 2;
-                const unsigned short o2 = (unsigned short)(oA | (oB << 8));
-                unsigned offD = laneDst + dOff;
-                asm volatile("" : "+v"(offD));
-                if (store2) gstore<unsigned short>(dstBase + offD, o2);
-                else if (store1) gstore<uint8_t>(dstBase + offD, (uint8_t)oA);
-                // (columns beyond the level repeat its last column: stage 2's taps are clamped to it anyway)
-                ldsLane[jr * (PR2_LDS_PITCH / 2)] = o2;
-                dOff += (unsigned)D.pitch;
-                // ---- stage 2 takes level-l row jr of the strip from LDS (other lanes wrote its taps) ----
-                wave_lds_sync();
-                {
-                    const unsigned lo = ldsRow2[jr * (PR2_LDS_PITCH / 4)], hi = ldsRow2[jr * (PR2_LDS_PITCH / 4) + 1];
-                    gpA = gcA; gpB = gcB;
-                    gcA = udot2_u16(__builtin_amdgcn_perm(hi, lo, sel2A), w2a) >> 4;
-                    gcB = udot2_u16(__builtin_amdgcn_perm(hi, lo, sel2B), w2b) >> 4;
-                    while (t2y1 == jr) {  // wave-uniform
-                        if (__builtin_expect(t2y0 == jr, 0)) {
-                            gpA = gcA; gpB = gcB;
-                            asm volatile("" : "+v"(gpA), "+v"(gpB));
-                        }
-                        const unsigned pA = ((umad24_su(t2b0, gpA, round2) >> 16) + (umul24_su(t2b1, gcA) >> 16)) >> 2;
-                        const unsigned pB = ((umad24_su(t2b0, gpB, round2) >> 16) + (umul24_su(t2b1, gcB) >> 16)) >> 2;
-                        if (st2) gstore<unsigned short>(dst2, (unsigned short)(pA | (pB << 8)));
-                        else if (st1a) gstore<uint8_t>(dst2, (uint8_t)pA);
-                        else if (st1b) gstore<uint8_t>(dst2 + 1, (uint8_t)pB);
-                        dst2 += E.pitch;
-                        jr2++;
-                        rowTap2(jr2, t2y0, t2y1, t2b0, t2b1);
-                    }
-                }
-                jr++;
-                rowTap(jr, sy0, sy1, b0, b1);
-            }
-            r++;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // FAST-9/16 per cell.  One workgroup per (cell, image).  The cell's (wCell+6)x(hCell+6) uint8 tile is
 // staged in LDS; scores (largest threshold at which the pixel is still a corner) go to an LDS score
 // plane whose zero rim implements "a neighbour belonging to another cell counts as 0"; survivors are
@@ -1261,282 +1075,6 @@ __global__ __launch_bounds__(64, FC_WAVES_PER_EU) void k_fast_cells(FtGeom g, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST-9/16 over strips (device octree; the default).  cv::FAST is called per ~35-px cell by the reference, but the
-// cells' tested regions tile the rectangle [19, w-19) x [19, h-19) of a level exactly, a pixel's score does not depend
-// on its cell, and the cell only enters (a) non-maximum suppression - a neighbour in another cell counts as 0 - and
-// (b) the threshold fallback - a cell emits its survivors with score >= iniThFAST if it has any, else all of them
-// (ORBextractor.cc:1157-1177).  So one WAVE takes a strip of up to 62 x sH pixels of that rectangle that
-// ignores the cell grid, plus a one-pixel halo whose scores its NMS needs: lane = column (64 columns: every row fills the
-// wave, where a 36-px cell filled 56 %), rows top to bottom.
-//   A  rejection on the compass pairs, six rows per trip as three PAIRS of rows (y, y + 3) packed in the halves of a
-//      register (v_sad_u8 / v_sad_hi_u8 produce the halves, v_pk_max_u16 / v_pk_min_u16 combine them): the vertical
-//      difference |p(y) - p(y+3)| is the south difference of row y and the north difference of row y + 3, so the north
-//      pair is an alignbit of the previous and the current south pair; ~5 VALU instructions per row of 64 pixels;
-//   B  cornerScore of the buffered candidates in FULL rounds of 64 (the remainder stays in the ring until the end);
-//   C  NMS of the corners against the score plane with the cell borders applied as masks, then every survivor is filed
-//      under its cell: an atomic counter pair per cell hands out staging slots - strong survivors (score >= iniThFAST)
-//      from the front, the others from the back - and k_compact_strips applies (b).
-// The order inside a cell's staging is arbitrary: k_octree ranks candidates by their coordinates.
-// ------------------------------------------------------------------------------------------------
-#define FS_TP 80                 // LDS pitch of the tile: 62 + 2 halo + 6 ring + 3 alignment, in dwords
-#define FS_ROWS 6                // rows per trip of phase A (three pairs)
-#define FS_CAND 640              // candidate ring (u16 codes): a trip adds up to 384, full rounds leave < 64
-#define FS_CORN 256              // corner list; a strip with more corners scans its score plane
-__host__ __device__ __forceinline__ int fs_tile_rows(int sH) { return ((sH + 2 + FS_ROWS - 1) / FS_ROWS) * FS_ROWS + 6; }
-__host__ __device__ __forceinline__ int fs_tile_bytes(int sH) { return (fs_tile_rows(sH) * FS_TP + 15) & ~15; }
-__host__ __device__ __forceinline__ int fs_score_bytes(int sH) { return ((sH + 2) * 64 + 64 + 15) & ~15; }  // + a row of slack for the reads of the last rows' neighbours
-__host__ __device__ __forceinline__ int fs_list_bytes() { return 2 * (FS_CAND + FS_CORN) + 16; }
-
-__global__ __launch_bounds__(64) void k_fast_strips(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr, int iniTh,
-                                                    int minTh, int *cellCount2, uint32_t *stage, const uint32_t *stripTab,
-                                                    FtSlotGrid sg, int maxSH) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = threadIdx.x;
-    int slot, strip;
-    if (!ft_slot_block(sg, slot, strip)) return;
-    if (strip >= g.totalStrips) return;
-    const uint8_t *img0 = l0[slot];
-    const uint32_t stt = stripTab[strip];
-    const int level = (int)(stt & 0xffu), sy = (int)((stt >> 8) & 0xfffu), sx = (int)(stt >> 20);
-    const FtLevelGeom &L = g.lv[level];
-    const int E = FT_EDGE_THRESHOLD;
-    // interior [X0, X1) x [Y0, Y1) of the strip; scored region = interior + 1 (clipped to the tested rectangle by `act`
-    // and the row bounds below); lane <-> column X0 - 1 + lane, scored row yy <-> row Y0 - 1 + yy
-    const int X0 = E + sx * L.sW, X1 = min(X0 + L.sW, L.w - E);
-    const int Y0 = E + sy * L.sH, Y1 = min(Y0 + L.sH, L.h - E);
-    const int CH = Y1 - Y0 + 2;                                  // scored rows
-    const int yyMin = Y0 - 1 < E ? 1 : 0, yyMax = Y1 + 1 > L.h - E ? CH - 1 : CH;  // rows of the tested rectangle
-    const int xl = X0 - 1 + lane;
-    const bool act = xl >= E && xl < L.w - E && xl <= X1;
-    const unsigned long long actMask = __builtin_amdgcn_ballot_w64(act);
-    uint8_t *tile = smem;
-    uint8_t *score = tile + fs_tile_bytes(maxSH);
-    unsigned short *cand = (unsigned short *)(score + fs_score_bytes(maxSH));
-    unsigned short *corn = cand + FS_CAND;
-    const int pitch = level ? L.pitch : l0pitch;
-    const uint8_t *img = level ? pyr + (size_t)slot * g.pyrPerSlot + L.off : img0;
-    // ---- stage the tile: columns [X0 - 4, X1 + 4), rows [Y0 - 4, Y1 + 4): aligned dword rows, fixed (row, dword) per lane,
-    // rows and dwords beyond the tile clamped onto its last row / dword (duplicates instead of masks); three rows per trip
-    const int tx0 = X0 - 4, ax = tx0 & 3;
-    {
-        const int tw = X1 + 4 - tx0, th = Y1 + 4 - (Y0 - 4);
-        const int nd = (tw + ax + 3) >> 2;  // <= 20
-        const uint8_t *src = img + (size_t)(Y0 - 4) * pitch + (tx0 - ax);
-        constexpr int DW = FS_TP / 4, RPT = 3;  // 20 dwords per row, 3 rows per trip (lanes 60 .. 63 duplicate)
-        const int rr = min(lane / DW, RPT - 1), cc4 = 4 * min(lane - (lane / DW) * DW, nd - 1);
-        for (int r0 = 0; r0 < th; r0 += 8 * RPT) {
-            unsigned v[8];
-            int row[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                row[k] = min(r0 + k * RPT + rr, th - 1);
-                v[k] = gload<unsigned>(src + (unsigned)vmad24(row[k], pitch, cc4));
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) *(unsigned *)(tile + vmad24(row[k], FS_TP, cc4)) = v[k];
-        }
-    }
-    for (int i = lane; i < fs_score_bytes(maxSH) >> 4; i += 64) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
-    wave_lds_sync();
-    // pixel (column of lane, scored row yy) at col[(yy + 3) * FS_TP]
-    const uint8_t *t0 = tile + ax + 3;  // (column X0 - 1, tile row 0)
-    const uint8_t *col = t0 + lane;
-    int nc = 0, ncorn = 0;
-    // phase B over the buffered candidates: full rounds of 64 (all of them when `final`), the rest moves to the front
-    auto flushB = [&](bool final) {
-        wave_lds_sync();
-        const int rounds = final ? (nc + 63) >> 6 : nc >> 6;
-        for (int jb = 0; jb < rounds * 64; jb += 64) {
-            const int j = jb + lane;
-            bool isCorner = false;
-            int code = 0;
-            if (j < nc) {
-                code = cand[j];
-                // top-left corner of the pixel's 7 x 7 ring window: every ring offset is a non-negative immediate
-                const uint8_t *win = t0 - 3 + vmad24(code >> 6, FS_TP, code & 63);
-                const int v = win[3 * FS_TP + 3];
-                int ringPx[16];
-#define FT_LD(k, ox, oy) ringPx[k] = (int)win[((oy) + 3) * FS_TP + (ox) + 3];
-                FT_RING(FT_LD)
-#undef FT_LD
-                const int sc = fast_score(v, ringPx);
-                if (sc >= minTh) {
-                    score[code] = (uint8_t)sc;
-                    isCorner = true;
-                }
-            }
-            const unsigned long long cb = __ballot(isCorner);
-            if (isCorner) {
-                const int pos = ncorn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cb, 0u));
-                if (pos < FS_CORN) corn[pos] = (unsigned short)code;
-            }
-            ncorn += __popcll(cb);
-        }
-        const int rem = nc - rounds * 64;
-        if (rem > 0) {  // wave-uniform; rem < 64
-            const unsigned short keep = cand[rounds * 64 + min(lane, rem - 1)];
-            wave_lds_sync();
-            if (lane < rem) cand[lane] = keep;
-        }
-        nc = max(rem, 0);
-        wave_lds_sync();
-    };
-    // ---- phase A
-    {
-        const unsigned th = (unsigned)minTh;
-        unsigned pA = col[3 * FS_TP], pB = col[4 * FS_TP], pC = col[5 * FS_TP];  // scored rows 0, 1, 2
-        // "previous south pairs": their high halves are the north differences |p(yy) - p(yy - 3)| of rows 0 .. 2
-        unsigned prev[3];
-        prev[0] = __builtin_amdgcn_sad_hi_u8(pA, (unsigned)col[0], 0u);
-        prev[1] = __builtin_amdgcn_sad_hi_u8(pB, (unsigned)col[FS_TP], 0u);
-        prev[2] = __builtin_amdgcn_sad_hi_u8(pC, (unsigned)col[2 * FS_TP], 0u);
-        for (int yy = 0; yy < CH; yy += FS_ROWS) {
-            const uint8_t *r = col + yy * FS_TP;
-            unsigned pv[9], M[3];
-            pv[0] = pA; pv[1] = pB; pv[2] = pC;
-#pragma unroll
-            for (int k = 0; k < 6; k++) pv[k + 3] = r[(k + 6) * FS_TP];  // scored rows yy + 3 .. yy + 8
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                // rows yy + k (low half) and yy + k + 3 (high half)
-                const unsigned ps = __builtin_amdgcn_sad_hi_u8(pv[k + 3], pv[k + 6], __builtin_amdgcn_sad_u8(pv[k], pv[k + 3], 0u));
-                const unsigned pn = __builtin_amdgcn_alignbit(ps, prev[k], 16);
-                const unsigned pe = __builtin_amdgcn_sad_hi_u8(pv[k + 3], (unsigned)r[(k + 6) * FS_TP + 3],
-                                                               __builtin_amdgcn_sad_u8(pv[k], (unsigned)r[(k + 3) * FS_TP + 3], 0u));
-                const unsigned pw = __builtin_amdgcn_sad_hi_u8(pv[k + 3], (unsigned)r[(k + 6) * FS_TP - 3],
-                                                               __builtin_amdgcn_sad_u8(pv[k], (unsigned)r[(k + 3) * FS_TP - 3], 0u));
-                M[k] = pk_min_u16(pk_max_u16(pn, ps), pk_max_u16(pe, pw));
-                prev[k] = ps;
-            }
-            pA = pv[6]; pB = pv[7]; pC = pv[8];
-            // candidates of a row = lanes whose pixel passes, in the tested rectangle, appended in lane order.  All six
-            // row masks are formed first (one v_cmp each; lane and row validity are scalar masks), so a trip without
-            // candidates costs nothing more, and rows without any are skipped on the scalar side
-            unsigned mrow[6];
-            unsigned long long bal[6], any = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                mrow[k] = k < 3 ? (M[k] & 0xffffu) : (M[k - 3] >> 16);
-                const unsigned long long rowMask = 0ull - (unsigned long long)((unsigned)(yy + k - yyMin) < (unsigned)(yyMax - yyMin));
-                bal[k] = __builtin_amdgcn_ballot_w64(mrow[k] > th) & actMask & rowMask;
-                any |= bal[k];
-            }
-            if (any) {  // wave-uniform
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    if (bal[k]) {  // wave-uniform; implies a valid row
-                        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[k], (unsigned)nc));
-                        if (__builtin_amdgcn_inverse_ballot_w64(bal[k])) cand[pos] = (unsigned short)(((yy + k) << 6) | lane);
-                        nc += __popcll(bal[k]);
-                    }
-                }
-            }
-            if (nc > FS_CAND - FS_ROWS * 64) flushB(false);  // wave-uniform
-        }
-        flushB(true);
-    }
-    // ---- phase C: NMS (strictly greater than the 8 neighbours; a neighbour in another cell counts as 0) and filing of the
-    // survivors of the strip's interior under their cells
-    const unsigned wMagic = div_magic_small((unsigned)L.wCell), hMagic = div_magic_small((unsigned)L.hCell);
-    const bool useList = ncorn <= FS_CORN;
-    const int nItems = useList ? ncorn : CH * 64;
-    int *cnt2 = cellCount2 + (size_t)slot * g.totalCells * 2;
-    uint32_t *stg = stage + (size_t)slot * g.stagePerSlot + L.stageBase;
-    for (int base = 0; base < nItems; base += 64) {
-        const int it = base + lane;
-        if (it >= nItems) continue;
-        const int code = useList ? (int)corn[it] : it;
-        const int yy = code >> 6, xx = code & 63;
-        const uint8_t *sp = score + code;
-        const int v = sp[0];
-        // interior only: the halo belongs to the neighbouring strips
-        if (v == 0 || xx < 1 || xx > X1 - X0 || yy < 1 || yy > Y1 - Y0) continue;
-        const int ux = X0 - 1 + xx - E, uy = Y0 - 1 + yy - E;  // coordinates in the tested rectangle
-        const int cj = div_by(ux, wMagic), ci = div_by(uy, hMagic);
-        const int rx = ux - cj * L.wCell, ry = uy - ci * L.hCell;
-        const bool vl = rx > 0, vr = rx < L.wCell - 1, vu = ry > 0, vd = ry < L.hCell - 1;
-        const int nl = vl ? (int)sp[-1] : 0, nr = vr ? (int)sp[1] : 0;
-        const int nu = vu ? (int)sp[-64] : 0, nd = vd ? (int)sp[64] : 0;
-        const int nul = (vu && vl) ? (int)sp[-65] : 0, nur = (vu && vr) ? (int)sp[-63] : 0;
-        const int ndl = (vd && vl) ? (int)sp[63] : 0, ndr = (vd && vr) ? (int)sp[65] : 0;
-        const bool keep = v > nl && v > nr && v > nu && v > nd && v > nul && v > nur && v > ndl && v > ndr;
-        if (!keep) continue;
-        const int cell = ci * L.nCols + cj;
-        const int weak = v >= iniTh ? 0 : 1;
-        const int k = atomicAdd(cnt2 + 2 * (L.cellBase + cell) + weak, 1);
-        const int pos = weak ? L.cellCap - 1 - k : k;
-        // keypoint relative to (minBorderX, minBorderY) = (16, 16): ORBextractor.cc:1196-1197
-        if (pos >= 0 && pos < L.cellCap) stg[(size_t)cell * L.cellCap + pos] = ft_pack_cand(ux + 3, uy + 3, v);
-    }
-}
-
-// Compaction of the strips form: per cell the strong survivors if there are any, else the weak ones (the cell's
-// iniThFAST / minThFAST fallback); the counters are zeroed for the next launch.
-__global__ __launch_bounds__(256) void k_compact_strips(FtGeom g, int *cellCount2, const uint32_t *stage, uint32_t *cand,
-                                                        int *candCount) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int *offs = (int *)smem;  // nCells + 1
-    __shared__ int wsum[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int level = blockIdx.x, slot = blockIdx.y;
-    const FtLevelGeom &L = g.lv[level];
-    const int nCells = L.nCols * L.nRows;
-    int *cnt = cellCount2 + ((size_t)slot * g.totalCells + L.cellBase) * 2;
-    const int per = (nCells + 255) / 256;
-    const int c0 = tid * per, c1 = min(c0 + per, nCells);
-    auto count = [&](int c) -> int {
-        const int hi = min(cnt[2 * c], L.cellCap), lo = min(cnt[2 * c + 1], L.cellCap);
-        return hi > 0 ? hi : lo;
-    };
-    int local = 0;
-    for (int c = c0; c < c1; c++) local += count(c);
-    int incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if (w < wave) wbase += wsum[w];
-        total += wsum[w];
-    }
-    int run = wbase + incl - local;
-    for (int c = c0; c < c1; c++) {
-        // the sign of the offset records which end of the cell's staging holds the list: strong from the front (+),
-        // weak from the back (stored as ~offset)
-        const int hi = cnt[2 * c];
-        offs[c] = hi > 0 ? run : ~run;
-        run += count(c);
-    }
-    if (tid == 0) offs[nCells] = total;
-    __syncthreads();
-    total = min(total, L.candCap);
-    const uint32_t *st = stage + (size_t)slot * g.stagePerSlot + L.stageBase;
-    uint32_t *dst = cand + (size_t)slot * g.candPerSlot + L.candBase;
-    auto offAt = [&](int c) -> int { const int o = offs[c]; return o < 0 ? ~o : o; };
-    for (int o = tid; o < total; o += 256) {
-        int lo = 0, hi = nCells;  // last cell whose offset is <= o
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (offAt(mid) <= o) lo = mid;
-            else hi = mid;
-        }
-        const int e = o - offAt(lo);
-        dst[o] = st[(size_t)lo * L.cellCap + (offs[lo] < 0 ? L.cellCap - 1 - e : e)];
-    }
-    if (tid == 0) candCount[slot * g.nlevels + level] = total;
-    __syncthreads();
-    for (int c = c0; c < c1; c++) {
-        cnt[2 * c] = 0;
-        cnt[2 * c + 1] = 0;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Compaction in cell order: one workgroup per (level, image).  Exclusive scan of the cell counts in cell
 // order, then a coalesced gather into the dense list (which lives in host-mapped pinned memory so
 // the host octree can read it after a single stream sync).
@@ -1612,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_compact(FtGeom g, const int *cellCount,
 #define OD_WAVE_BYTES ((OD_RAW_BYTES + OD_HB_BYTES + 15) & ~15)
 #define OD_WAVES 4
 #ifndef OD_KPW_WIDE
-#define OD_KPW_WIDE 2           // keypoints per wave (1 .. 3) in launches of 8+ images: loads of all of them in flight before the first is processed
+#define OD_KPW_WIDE 2           // keypoints per wave (1 or 2) in launches of 8+ images: loads of all of them in flight before the first is processed
 #endif
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -1718,7 +1256,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // wave 0 of every 16th workgroup, summed here ([0] = sampled waves, [1 + p] = ticks of phase p); the launcher prints them
 __device__ unsigned long long g_odProf[16];
 template <int OD_KPW>
-__global__ __launch_bounds__(64 * OD_WAVES, OD_KPW > 2 ? 7 : 1) void k_orient_desc(FtGeom g, const uint8_t *const *l0, int l0pitch,
+__global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const uint8_t *const *l0, int l0pitch,
                                                                const uint8_t *pyr, int alignedLoads, const FtSelKp *sel,
                                                                const int *selCount, FtOctArgs lay, int *nSel,
                                                                ft_keypoint *keysOut, uint8_t *descOut, FtSlotGrid sg, int prof) {
@@ -2005,30 +1543,14 @@ __global__ __launch_bounds__(64 * OD_WAVES, OD_KPW > 2 ? 7 : 1) void k_orient_de
             moments(1);
         }
     }
-    if constexpr (OD_KPW > 2) {
-        // a third keypoint: its moments are wanted before the shared angle arithmetic, and the one raw buffer still holds
-        // patch 1 - which is staged a second time further down (its nine dwords per lane are still in registers)
-        if (nKp > 2) {
-            wave_lds_sync();  // moments 1 have read the raw buffer
-            stage(2);
-            wave_lds_sync();
-            moments(2);
-        }
-    }
-    tick();  // 4: patches 1 (, 2) staged + their moments
-    // lane group of keypoint q for the shared angle arithmetic: halves for two keypoints, rows of 16 lanes for three
-    constexpr int GROUP = OD_KPW > 2 ? 16 : 32;
+    tick();  // 4: patch 1 staged + its moments
+    // lane group of keypoint q for the shared angle arithmetic: the halves of the wave
+    constexpr int GROUP = 32;
     float mY = (float)m01K[0], mX = (float)m10K[0];
     if constexpr (OD_KPW > 1) {
         if (nKp > 1 && lane >= GROUP) {
             mY = (float)m01K[1];
             mX = (float)m10K[1];
-        }
-    }
-    if constexpr (OD_KPW > 2) {
-        if (nKp > 2 && lane >= 2 * GROUP) {
-            mY = (float)m01K[2];
-            mX = (float)m10K[2];
         }
     }
     const float angleL = fast_atan2_deg(mY, mX);
@@ -2041,15 +1563,6 @@ __global__ __launch_bounds__(64 * OD_WAVES, OD_KPW > 2 ? 7 : 1) void k_orient_de
     tick();  // 5: angles of all keypoints of the wave
     describe(0, lane_value(angleL, 0), lane_value(caL, 0), lane_value(sbL, 0));
     tick();  // 6: samples + stores of keypoint 0
-    if constexpr (OD_KPW > 2) {
-        if (nKp > 2) {
-            wave_lds_sync();  // samples 0 have read hb; the raw buffer holds patch 2
-            hblur();
-            wave_lds_sync();
-            describe(2, lane_value(angleL, 2 * GROUP), lane_value(caL, 2 * GROUP), lane_value(sbL, 2 * GROUP));
-            stage(1);  // patch 1 again (hblur 2 is done with the raw buffer)
-        }
-    }
     if constexpr (OD_KPW > 1) {
         if (nKp > 1) {
             wave_lds_sync();  // the samples in front have read hb (and patch 1 is staged)
@@ -2102,21 +1615,6 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
     for (int rep = ft_debug_repeat("pyr"); rep > 0; rep--)
     for (int level = 1; level < g.nlevels; level++) {
         const FtLevelGeom &D = g.lv[level], &P = g.lv[level - 1];
-        // two levels per pass (k_pyr_rows2): this level and the next one, when both take the row-streaming bilinear path
-        // (rowsKernel 2: every pair of levels; 10 + k: pairs from level k upwards only - the small levels, whose launches do not
-        // fill the chip)
-        const int fuseFrom = rowsKernel >= 10 ? rowsKernel - 10 : (rowsKernel >= 2 ? 1 : FT_MAX_LEVELS);
-        if (level >= fuseFrom && batch >= 8 && alignedLoads && level + 1 < g.nlevels && pyr_rows_fits(g, level) &&
-            pyr_rows_fits(g, level + 1) && !D.area2x && !g.lv[level + 1].area2x && D.w >= 16 && D.h >= 2) {
-            const int stripsX = (D.w + PR2_CSTEP - 1) / PR2_CSTEP, stripsY = (D.h + PR2_RSTEP - 1) / PR2_RSTEP;
-            dim3 grid, block(64, 1, 1);
-            const FtSlotGrid sg = ft_slot_grid(stripsX * stripsY, batch, grid);
-            const int readableEnd = level == 1 ? std::min((P.w + 3) & ~3, l0pitch) : P.pitch;
-            hipLaunchKernelGGL(k_pyr_rows2, grid, block, 0, st, g, level, l0, l0pitch, pyr, taps, sg, stripsX,
-                               div_magic_of((unsigned)stripsX), readableEnd);
-            level++;
-            continue;
-        }
         // a launch of a few images is latency bound: the tile kernel's many short waves finish a level sooner than the
         // row-streaming kernel's few long ones (752x480 frame: 0.19 against 0.23 ms); wide launches take the streaming kernel
         if (rowsOn && batch >= 8 && alignedLoads && pyr_rows_fits(g, level)) {
@@ -2185,41 +1683,6 @@ int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8
     for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
         hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab, sg, dbg,
                            tileBytes, scoreBytes);
-    FT_HIP(hipGetLastError());
-    return FT_OK;
-}
-
-size_t ft_fast_strips_smem_bytes(const FtGeom &g) {
-    int maxSH = 1;
-    for (int l = 0; l < g.nlevels; l++) maxSH = std::max(maxSH, g.lv[l].sH);
-    return (size_t)fs_tile_bytes(maxSH) + fs_score_bytes(maxSH) + fs_list_bytes();
-}
-
-int ft_launch_fast_strips(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
-                          const uint8_t *pyr, int iniTh, int minTh, int *cellCount2, uint32_t *stage,
-                          const uint32_t *stripTab) {
-    if (g.totalStrips == 0) return FT_OK;
-    int maxSH = 1;
-    for (int l = 0; l < g.nlevels; l++) maxSH = std::max(maxSH, g.lv[l].sH);
-    const size_t smem = ft_fast_strips_smem_bytes(g);
-    dim3 grid, block(64, 1, 1);
-    const FtSlotGrid sg = ft_slot_grid(g.totalStrips, batch, grid);
-    if (smem > 64 * 1024)
-        FT_HIP(hipFuncSetAttribute((const void *)k_fast_strips, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(k_fast_strips, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, cellCount2, stage, stripTab, sg,
-                       maxSH);
-    FT_HIP(hipGetLastError());
-    return FT_OK;
-}
-
-int ft_launch_compact_strips(hipStream_t st, const FtGeom &g, int batch, int *cellCount2, const uint32_t *stage,
-                             uint32_t *cand, int *candCount) {
-    int maxCells = 0;
-    for (int l = 0; l < g.nlevels; l++) maxCells = std::max(maxCells, g.lv[l].nCols * g.lv[l].nRows);
-    dim3 grid2(g.nlevels, batch, 1), block(256, 1, 1);
-    // (idempotent under FT_DEBUG_REPEAT only together with the FAST kernel: the counters are consumed here)
-    hipLaunchKernelGGL(k_compact_strips, grid2, block, (size_t)(maxCells + 1) * sizeof(int), st, g, cellCount2, stage, cand,
-                       candCount);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

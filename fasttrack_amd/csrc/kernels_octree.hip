@@ -1027,10 +1027,10 @@ int ft_octree_big_keys(int poolCap) {
     return 0;
 }
 
-int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a, int smemPad) {
+int ft_launch_octree(hipStream_t st, const FtGeom &g, int batch, const FtOctArgs &a) {
     // smemPad (option oct_smem_pad, a probe): extra bytes of LDS per workgroup of the sorted tier - what its footprint costs
     // the kernels that share the CUs with it
-    const size_t smem = ft_octree_smem_bytes(a.poolCap, a.low != nullptr) + (size_t)std::max(smemPad, 0);
+    const size_t smem = ft_octree_smem_bytes(a.poolCap, a.low != nullptr);
     if (ft_debug_env("FT_DEBUG_OCC")) fprintf(stderr, "[ft] k_octree: %zu B of LDS per workgroup (pool %d)\n", smem, a.poolCap);
     if (smem > 64 * 1024)  // large quotas: raise the dynamic LDS limit (per device, so not cached in a static)
         FT_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -28,14 +28,57 @@ __device__ __forceinline__ int hamming256(const unsigned long long a[4], const u
     return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
 }
 
+// The array pointers of a frame as the scans use them.  The kernels of ONE frame get the frame as a kernel argument and
+// its pointers are global pointers to the compiler; a pointer read from a record in memory (the job records of the batch
+// kernels, FtBatchJob) is a GENERIC pointer - flat_load: both wait counters, an aperture check per access - and neither
+// a cast through the global address space nor llvm.assume(!is_shared && !is_private) survives the optimiser.  What does:
+// re-deriving the pointer from a pointer that IS a kernel argument - the batch's device arena, with the arena's address
+// passed a second time as a plain integer, so that arena + (p - address) cannot be folded back into p.  Everything a job
+// record points to lies inside the arena of its batch (search.cpp).
+struct Rebase {
+    uint8_t *arena;
+    unsigned long long addr;  // (unsigned long long)arena
+    template <class T>
+    __device__ __forceinline__ T *operator()(T *p) const {
+        return p ? (T *)(arena + ((unsigned long long)p - addr)) : nullptr;
+    }
+};
+struct NoRebase {  // the pointers are kernel arguments already
+    template <class T>
+    __device__ __forceinline__ T *operator()(T *p) const {
+        return p;
+    }
+};
+struct FramePtrs {
+    const ft_keypoint *keys, *keysR;
+    const uint8_t *desc;
+    const float *uright;
+    const int *holderObs, *l2r, *r2l;
+    const int *gridStart[2];
+    const float4 *gridRec[2];
+    const uint8_t *gridDesc[2];
+};
+template <class RB>
+__device__ __forceinline__ FramePtrs frame_ptrs(const FtDevFrame &F, const RB &rb) {
+    FramePtrs Q;
+    Q.keys = rb(F.keys); Q.keysR = rb(F.keysR); Q.desc = rb(F.desc); Q.uright = rb(F.uright);
+    Q.holderObs = rb(F.holderObs); Q.l2r = rb(F.l2r); Q.r2l = rb(F.r2l);
+    Q.gridStart[0] = rb(F.gridStart[0]); Q.gridStart[1] = rb(F.gridStart[1]);
+    Q.gridRec[0] = rb(F.gridRec[0]); Q.gridRec[1] = rb(F.gridRec[1]);
+    Q.gridDesc[0] = rb(F.gridDesc[0]); Q.gridDesc[1] = rb(F.gridDesc[1]);
+    return Q;
+}
+#define FT_NO_REBASE (NoRebase{})
+
 #define KEY_NONE 0xffffffffffffffffull
 // Candidate key: (distance, cell x, cell y, index) in the high bits - ascending keys are the scan order of the CPU loop, see
 // the header - and below them what a later pass would otherwise have to fetch again through dependent loads: the keypoint's
-// octave and whether it was held before the call (mvpMapPoints[idx]->Observations() > 0).  The index is unique inside a
-// window, so the low bits never decide a comparison.
+// octave (four bits: checkFrame, search.cpp, admits octaves of [0, nlevels) only; masked here so that the keypoints of a
+// BOUND frame, which no host check sees, can never spill into the index) and whether it was held before the call
+// (mvpMapPoints[idx]->Observations() > 0).  The index is unique inside a window, so the low bits never decide a comparison.
 __device__ __forceinline__ unsigned long long make_key(int dist, int cx, int cy, int idx, int octave, bool heldBefore) {
     return ((unsigned long long)dist << 41) | ((unsigned long long)cx << 35) | ((unsigned long long)cy << 29) |
-           ((unsigned long long)idx << 5) | ((unsigned long long)octave << 1) | (heldBefore ? 1ull : 0ull);
+           ((unsigned long long)idx << 5) | ((unsigned long long)(octave & 15) << 1) | (heldBefore ? 1ull : 0ull);
 }
 __device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 41); }
 __device__ __forceinline__ int key_idx(unsigned long long k) { return (int)((k >> 5) & 0xffffffull); }
@@ -43,10 +86,8 @@ __device__ __forceinline__ int key_octave(unsigned long long k) { return (int)((
 __device__ __forceinline__ bool key_held(unsigned long long k) { return (k & 1ull) != 0; }
 
 // The words one pass of the claim iteration hands to the next - writer lists, results, flags - are written and read by
-// DIFFERENT workgroups, and in the persistent form (k_search_*_persist) inside ONE launch: every access to them is an
-// agent-scope relaxed atomic (sc1: stores write through, loads are served by the L2, never by a CU's L1, which no other
-// CU's store ever refreshes).  With that the hand-over between passes needs no cache maintenance, only "all stores of the
-// pass have landed" (s_waitcnt vmcnt(0) in every wave) in front of the grid barrier.
+// DIFFERENT workgroups of consecutive launches: every access to them is an agent-scope relaxed atomic (sc1: stores write
+// through, loads are served by the L2, never by a CU's L1, which no other CU's store ever refreshes).
 __device__ __forceinline__ int shared_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void shared_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -79,7 +120,13 @@ __device__ __forceinline__ bool is_locked(const FtClaims &C, int kp, int i, bool
 
 // start of a claim-iteration pass (see FtClaims): false = the iteration has converged, nothing to do
 __device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) {
-    if (C.flagPrev && shared_load(C.flagPrev) == -1) return false;
+    if (C.flagPrev && shared_load(C.flagPrev) == -1) {
+        // batch form, first pass of a later burst: the frame had converged before this burst began.  Its flag words of this
+        // burst's parity still hold what an earlier burst left there ("changed" for the passes it ran then): they all read
+        // "unchanged" from here on, so that every later pass of the burst returns here as well.
+        if (C.flagStick && blockIdx.x == 0 && threadIdx.x < 16) shared_store(C.flagStick + threadIdx.x, -1);
+        return false;
+    }
     const int t = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
     for (int k = t; k < C.nKp; k += T) shared_store(&C.headClear[k], -1);
     unsigned long long *tc = (unsigned long long *)C.tabClear;
@@ -276,9 +323,9 @@ __device__ __forceinline__ bool in_box(const WinEntry &kp, float x, float y, flo
 // minLevel / maxLevel as Frame::GetFeaturesInArea takes them (src/Frame.cc:714-729): no check at all unless minLevel > 0 or
 // maxLevel >= 0; maxLevel < 0 = no upper bound.
 template <class Fn>
-__device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const ft_keypoint *keys, int n, const Window &w, int minLevel,
-                                           int maxLevel, int lane, Fn fn) {
-    if (F.gridStart[cam]) {
+__device__ __forceinline__ void for_window(const FtDevFrame &F, const FramePtrs &Q, int cam, const ft_keypoint *keys, int n, const Window &w,
+                                           int minLevel, int maxLevel, int lane, Fn fn) {
+    if (Q.gridStart[cam]) {
         // One lane per (octave, column of cells) range, a wave scan lays the ranges end to end, and the lanes take the
         // entries 64 at a time - two rounds per trip: record and descriptor of an entry sit at the entry's position, so a
         // round is one memory round trip, and a wide window a chain of them.
@@ -287,9 +334,9 @@ __device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const f
         const int hi = (checkLevels && maxLevel >= 0) ? min(maxLevel, F.nlevels - 1) : F.nlevels - 1;
         const int ncolsW = w.maxCX - w.minCX + 1;
         const int npairs = (hi - lo + 1) * ncolsW;  // (<= 0: an empty band)
-        const int *gs = F.gridStart[cam];
-        const float4 *rec = F.gridRec[cam];
-        const uint4 *gd = (const uint4 *)F.gridDesc[cam];
+        const int *gs = Q.gridStart[cam];
+        const float4 *rec = Q.gridRec[cam];
+        const uint4 *gd = (const uint4 *)Q.gridDesc[cam];
         const unsigned colMagic = div_magic_u(ncolsW);
         for (int p0 = 0; p0 < npairs; p0 += 64) {
             const int np = min(64, npairs - p0);
@@ -351,7 +398,7 @@ __device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const f
         }
         return;
     }
-    const uint8_t *desc = F.desc + (cam == 0 ? 0 : (size_t)F.Nleft * 32);
+    const uint8_t *desc = Q.desc + (cam == 0 ? 0 : (size_t)F.Nleft * 32);
     for (int idx = lane; idx < n; idx += 64) {
         const ft_keypoint kp = keys[idx];
         const int cx = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.mnMinX), F.invW));
@@ -360,7 +407,7 @@ __device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const f
         if (cx < w.minCX || cx > w.maxCX || cy < w.minCY || cy > w.maxCY) continue;
         WinEntry e;
         e.x = kp.x; e.y = kp.y;
-        e.uright = (cam == 0 && F.Nleft == -1 && F.uright) ? F.uright[idx] : -1.0f;
+        e.uright = (cam == 0 && F.Nleft == -1 && Q.uright) ? Q.uright[idx] : -1.0f;
         e.idx = idx; e.octave = kp.octave; e.cx = cx; e.cy = cy;
         const unsigned long long *dp = (const unsigned long long *)(desc + (size_t)idx * 32);
         e.d[0] = dp[0]; e.d[1] = dp[1]; e.d[2] = dp[2]; e.d[3] = dp[3];
@@ -373,13 +420,13 @@ __device__ __forceinline__ void for_window(const FtDevFrame &F, int cam, const f
 // number is counted on the way).  An octave outside [0, nlevels) is filed under the nearest bucket; the searches test the
 // keypoint's own octave anyway.  The order inside a cell is free (the searches order candidates by (distance, cx, cy, index)
 // keys).  start: [nlevels][FT_GRID_CELLS + 1] absolute entry positions; rec / desc: the entries (ft_search.h).
-__global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, int *startR, float4 *recL, uint8_t *descL, float4 *recR,
-                                                    uint8_t *descR) {
+__device__ __forceinline__ void build_grid_body(const FtDevFrame &F, const FramePtrs &Q, int oct, int cam, int *startL, int *startR,
+                                                float4 *recL, uint8_t *descL, float4 *recR, uint8_t *descR) {
     __shared__ int cnt[FT_GRID_CELLS + 1];
     __shared__ int wsum[4], wbelow[4];
-    const int oct = blockIdx.x, cam = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = cam == 0 ? (F.Nleft == -1 ? F.N : F.Nleft) : (F.Nleft == -1 ? 0 : F.N - F.Nleft);
-    const ft_keypoint *keys = cam == 0 ? F.keys : F.keysR;
+    const ft_keypoint *keys = cam == 0 ? Q.keys : Q.keysR;
     int *start = (cam == 0 ? startL : startR);
     if (!start) return;
     start += (size_t)oct * (FT_GRID_CELLS + 1);
@@ -429,13 +476,13 @@ __global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, i
     __syncthreads();
     float4 *rec = cam == 0 ? recL : recR;
     uint8_t *gdesc = cam == 0 ? descL : descR;
-    const uint8_t *desc = F.desc + (cam == 0 ? 0 : (size_t)F.Nleft * 32);
+    const uint8_t *desc = Q.desc + (cam == 0 ? 0 : (size_t)F.Nleft * 32);
     for (int i = tid; i < n; i += 256) {
         const ft_keypoint kp = keys[i];
         const int c = cellOf(kp);
         if (c < 0 || min(max(kp.octave, 0), F.nlevels - 1) != oct) continue;
         const int p = atomicAdd(&cnt[c], 1);
-        const float ur = (cam == 0 && F.Nleft == -1 && F.uright) ? F.uright[i] : -1.0f;
+        const float ur = (cam == 0 && F.Nleft == -1 && Q.uright) ? Q.uright[i] : -1.0f;
         rec[p] = make_float4(kp.x, kp.y, ur, __int_as_float((i & 0xffffff) | (kp.octave << 24)));
         const uint4 *d = (const uint4 *)(desc + (size_t)i * 32);
         uint4 *o = (uint4 *)(gdesc + (size_t)p * 32);
@@ -443,10 +490,23 @@ __global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, i
         o[1] = d[1];
     }
 }
+__global__ __launch_bounds__(256) void k_build_grid(FtDevFrame F, int *startL, int *startR, float4 *recL, uint8_t *descL, float4 *recR,
+                                                    uint8_t *descR) {
+    build_grid_body(F, frame_ptrs(F, FT_NO_REBASE), blockIdx.x, blockIdx.y, startL, startR, recL, descL, recR, descR);
+}
+// the grids of the frames of a batch (ft_tracked_batch): blockIdx.z = frame; the arrays are those F.gridStart / gridRec /
+// gridDesc of the frame's job already point to
+__global__ __launch_bounds__(256) void k_build_grid_batch(const FtBatchJob *__restrict__ jobs, Rebase rb) {
+    const FtDevFrame &F = jobs[blockIdx.z].F;
+    if ((int)blockIdx.x >= F.nlevels || (blockIdx.y == 1 && F.Nleft == -1)) return;
+    const FramePtrs Q = frame_ptrs(F, rb);
+    build_grid_body(F, Q, blockIdx.x, blockIdx.y, (int *)Q.gridStart[0], (int *)Q.gridStart[1], (float4 *)Q.gridRec[0],
+                    (uint8_t *)Q.gridDesc[0], (float4 *)Q.gridRec[1], (uint8_t *)Q.gridDesc[1]);
+}
 
 // ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) for map point i by one wave (src/ORBmatcher.cc:49-225):
 // r = (primary left, side left, primary right, side right) keypoints it writes; raw outputs as the reference kernel's
-__device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
+__device__ __forceinline__ void local_point(const FtDevFrame &F, const FramePtrs &Q, const FtDevLocalPoints &P, const FtClaims &C, float th,
                                             float nnRatio, int i, int lane, int r4[4], const FtLocalRaw &raw, int *ldsCounter) {
     int primL = -1, sideL = -1, primR = -1, sideR = -1;
     int bd = 256, bd2 = 256, bl = -1, bl2 = -1, bi = -1;
@@ -493,11 +553,11 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                 const Window w = cell_window(F, x, y, rad);
                 cache_begin(cb, lane);
                 if (!w.empty) {
-                    const float pxr = (F.Nleft == -1 && F.uright) ? P.projXR[i] : 0.f;
-                    for_window(F, 0, F.keys, nLeft, w, level - 1, level, lane, [&](const WinEntry &kp) {
+                    const float pxr = (F.Nleft == -1 && Q.uright) ? P.projXR[i] : 0.f;
+                    for_window(F, Q, 0, Q.keys, nLeft, w, level - 1, level, lane, [&](const WinEntry &kp) {
                         if (!in_box(kp, x, y, rad, level - 1, level)) return;
                         const int idx = kp.idx;
-                        const bool held = F.holderObs[idx] > 0;
+                        const bool held = Q.holderObs[idx] > 0;
                         const bool locked = is_locked(C, idx, i, held);
                         if (locked && !cb.build) return;
                         if (kp.uright > 0) {  // (mono-stereo frames only: the records of other frames hold -1)
@@ -528,7 +588,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                     skipRight = true;  // the reference's `continue` also skips the right-camera block
                 } else {
                     primL = bi;
-                    if (F.Nleft != -1 && F.l2r[bi] != -1) sideL = F.l2r[bi] + F.Nleft;
+                    if (F.Nleft != -1 && Q.l2r[bi] != -1) sideL = Q.l2r[bi] + F.Nleft;
                 }
             }
         }
@@ -561,10 +621,10 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                     const Window w = cell_window(F, x, y, rad);
                     cache_begin(cb, lane);
                     if (!w.empty) {
-                        for_window(F, 1, F.keysR, nRight, w, level - 1, level, lane, [&](const WinEntry &kp) {
+                        for_window(F, Q, 1, Q.keysR, nRight, w, level - 1, level, lane, [&](const WinEntry &kp) {
                             if (!in_box(kp, x, y, rad, level - 1, level)) return;
                             const int idx = kp.idx, g = idx + F.Nleft;
-                            const bool held = F.holderObs[g] > 0;
+                            const bool held = Q.holderObs[g] > 0;
                             const bool locked = lockedR(g, held);
                             if (locked && !cb.build) return;
                             const int dist = hamming256(q, kp.d);
@@ -587,7 +647,7 @@ __device__ __forceinline__ void local_point(const FtDevFrame &F, const FtDevLoca
                     bl2r = key_octave(k1);
                 }
                 if (bdr <= FT_TH_HIGH && !(blr == bl2r && (float)bdr > __fmul_rn(nnRatio, (float)bd2r))) {
-                    if (F.r2l[bir] != -1) sideR = F.r2l[bir];
+                    if (Q.r2l[bir] != -1) sideR = Q.r2l[bir];
                     primR = bir + F.Nleft;
                 }
             }
@@ -612,7 +672,7 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_local(FtDevFrame 
     if (i >= P.M) return;
     __shared__ int cacheCounter[FT_SEARCH_WPB];
     int r4[4];
-    local_point(F, P, C, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
+    local_point(F, frame_ptrs(F, FT_NO_REBASE), P, C, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
     claims_file(C, res, i, lane, r4);
 }
 
@@ -670,7 +730,7 @@ __device__ __forceinline__ void transform_pose(const float *m, const float *q, i
 
 // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) for last-frame point i by one wave (src/ORBmatcher.cc:
 // 1775-1960): r = (left keypoint written, -1, right keypoint written, -1)
-__device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastPoints &Lp, const FtClaims &C, const FtPose &Tcw,
+__device__ __forceinline__ void last_point(const FtDevFrame &F, const FramePtrs &Q, const FtDevLastPoints &Lp, const FtClaims &C, const FtPose &Tcw,
                                            float th, int bForward, int bBackward, int i, int lane, int r4[4], const FtLastRaw &raw,
                                            int *ldsCounter) {
     int primL = -1, primR = -1;
@@ -766,11 +826,11 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
             } else {
                 cache_begin(cb, lane);
                 if (!w.empty) {
-                    for_window(F, 0, F.keys, nLeft, w, minLevel, maxLevel, lane, [&](const WinEntry &kp) {
+                    for_window(F, Q, 0, Q.keys, nLeft, w, minLevel, maxLevel, lane, [&](const WinEntry &kp) {
                         if (!in_box(kp, uv[0], uv[1], radius, minLevel, maxLevel)) return;
                         anyCand = 1;
                         const int idx = kp.idx;
-                        const bool held = F.holderObs[idx] > 0;
+                        const bool held = Q.holderObs[idx] > 0;
                         const bool locked = is_locked(C, idx, i, held);
                         if (locked && !cb.build) return;
                         if (kp.uright > 0) {
@@ -819,10 +879,10 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FtDevLastP
                     } else {
                         cache_begin(cbr, lane);
                         if (!wr.empty) {
-                            for_window(F, 1, F.keysR, nRight, wr, minLevel, maxLevel, lane, [&](const WinEntry &kp) {
+                            for_window(F, Q, 1, Q.keysR, nRight, wr, minLevel, maxLevel, lane, [&](const WinEntry &kp) {
                                 if (!in_box(kp, uvr[0], uvr[1], radius, minLevel, maxLevel)) return;
                                 const int idx = kp.idx;
-                                const bool held = F.holderObs[idx + F.Nleft] > 0;
+                                const bool held = Q.holderObs[idx + F.Nleft] > 0;
                                 const bool locked = is_locked(C, idx + F.Nleft, i, held);
                                 if (locked && !cbr.build) return;
                                 const int dist = hamming256(q, kp.d);
@@ -858,103 +918,83 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last(FtDevFrame F
     if (i >= Lp.N) return;
     __shared__ int cacheCounter[FT_SEARCH_WPB];
     int r4[4];
-    last_point(F, Lp, C, Tcw, th, bForward, bBackward, i, lane, r4, raw, &cacheCounter[wave]);
+    last_point(F, frame_ptrs(F, FT_NO_REBASE), Lp, C, Tcw, th, bForward, bBackward, i, lane, r4, raw, &cacheCounter[wave]);
     claims_file(C, res, i, lane, r4);
 }
 
-// ---- the whole claim iteration in ONE launch ------------------------------------------------------------------------------
-// The multi-launch form pays a launch (and its ramp) per pass, an empty launch for every surplus pass of a burst and a host
-// round trip per burst - 9 to 13 passes per search, 12 us each where the pass itself is a handful of dependent L2 reads.
-// Here every point keeps its wave for the whole search: the grid is at most ONE workgroup per CU (8 or 16 waves = points per
-// workgroup, <= 256 workgroups, so every workgroup is resident and a grid barrier cannot wait for one that is not), passes
-// are separated by a counter barrier, and all workgroups leave together after the first pass that changed nothing.
-//   sync[0..3] ring of "changed" flags (-1 = unchanged; a pass resets the flag of the pass after next),
-//   sync[4] status: passes run, or FT_PERSIST_TIMEOUT when a barrier gave up (the host then runs the multi-launch form),
-//   sync[5] arrival counter, monotonic, starts at -1 (the call's fill writes -1 over heads, flags and these words).
-// The barrier: every wave drains its stores (the shared words are written through, see shared_store), the workgroup meets,
-// one lane arrives and polls the counter with relaxed loads and s_sleep, the workgroup meets again.  No fence: nothing the
-// passes exchange is ever read through an L1.  Spins are bounded by the 100 MHz wall clock.
-#define FT_PERSIST_TIMEOUT (-2)
-#define FT_PERSIST_TICKS 20000000ull  // 200 ms
-__device__ __forceinline__ bool persist_barrier(int *sync, int target) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    __shared__ int gaveUp;
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        __hip_atomic_fetch_add(&sync[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = wall_clock64();
-        unsigned spins = 0;
-        while (shared_load(&sync[5]) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if ((++spins & 255u) == 0 && (wall_clock64() - t0 > FT_PERSIST_TICKS || shared_load(&sync[4]) == FT_PERSIST_TIMEOUT)) {
-                shared_store(&sync[4], FT_PERSIST_TIMEOUT);
-                ok = 0;
-                break;
-            }
-        }
-        gaveUp = !ok;
-    }
-    __syncthreads();
-    return !gaveUp;
-}
-
-// the per-pass view of the rotating buffers, exactly as fixedPoint (search.cpp) sets it up for a launch of its own
-__device__ __forceinline__ void persist_pass_view(FtClaims &C, const FtPersist &S, int pass, int *&res) {
-    const size_t K = (size_t)S.K, R = (size_t)4 * S.nPoints;
+// ---- B frames per launch (ft_tracked_batch) --------------------------------------------------------------------------------
+// One frame at a time leaves the chip idle by construction: a pass of the claim iteration is ~500 workgroups and a handful
+// of dependent L2 round trips, 9 - 13 passes per search, each a launch.  Here blockIdx.y is the FRAME: everything a pass
+// needs of a frame - the frame itself, its points, its rotating claim buffers - sits in a job record in HBM (read through
+// scalar loads: the address is uniform), the pass number selects the buffers exactly as fixedPoint (search.cpp) does for a
+// launch of its own, and every frame has its own convergence flags, so that the workgroups of a frame whose iteration has
+// reached its fixed point return at once while the other frames go on: the batch runs max-over-frames passes.
+__device__ __forceinline__ FtClaims job_claims(const FtBatchJob &J, const Rebase &rb, int pass, int fCur, int fPrev, int fReset, int *&res) {
+    const size_t K = (size_t)J.K, R = (size_t)4 * J.nPoints;
+    int *head = rb(J.head), *tab = rb(J.tab), *next = rb(J.next), *resB = rb(J.res), *flags = rb(J.flags);
+    FtClaims C;
     C.firstPass = pass == 0;
-    C.head = S.head + (size_t)(pass % 3) * K;
-    C.headWrite = S.head + (size_t)((pass + 1) % 3) * K;
-    C.headClear = S.head + (size_t)((pass + 2) % 3) * K;
-    C.tab = S.tab + (size_t)(pass % 3) * 8 * K;
-    C.tabWrite = S.tab + (size_t)((pass + 1) % 3) * 8 * K;
-    C.tabClear = S.tab + (size_t)((pass + 2) % 3) * 8 * K;
-    C.next = S.next + (size_t)((pass + 1) & 1) * R;
-    C.nextWrite = S.next + (size_t)(pass & 1) * R;
-    C.resPrev = S.res + (size_t)((pass + 1) & 1) * R;
-    C.flagCur = S.sync + (pass & 3);
-    C.flagPrev = nullptr;
-    C.flagReset = S.sync + ((pass + 2) & 3);
-    res = S.res + (size_t)(pass & 1) * R;
+    C.head = head + (size_t)(pass % 3) * K;
+    C.headWrite = head + (size_t)((pass + 1) % 3) * K;
+    C.headClear = head + (size_t)((pass + 2) % 3) * K;
+    C.tab = tab + (size_t)(pass % 3) * 8 * K;
+    C.tabWrite = tab + (size_t)((pass + 1) % 3) * 8 * K;
+    C.tabClear = tab + (size_t)((pass + 2) % 3) * 8 * K;
+    C.next = next + (size_t)((pass + 1) & 1) * R;
+    C.nextWrite = next + (size_t)(pass & 1) * R;
+    C.resPrev = resB + (size_t)((pass + 1) & 1) * R;
+    C.obs = rb(J.obs);
+    C.nKp = J.nKp;
+    C.flagCur = flags + fCur;
+    C.flagPrev = fPrev >= 0 ? flags + fPrev : nullptr;
+    C.flagReset = flags + fReset;
+    C.flagStick = (fPrev >= 0 && (fPrev >> 4) != (fCur >> 4)) ? flags + (fCur & ~15) : nullptr;
+    C.cache = rb(J.cache);
+    res = resB + (size_t)(pass & 1) * R;
+    return C;
 }
 
-template <class PointFn>
-__device__ __forceinline__ void persist_loop(FtClaims C, const FtPersist &S, int nPoints, PointFn point) {
-    const int lane = threadIdx.x & 63, wave = wave_index(), wpb = (int)(blockDim.x >> 6);
-    const int i = blockIdx.x * wpb + wave;
-    for (int pass = 0;; pass++) {
-        int *res;
-        persist_pass_view(C, S, pass, res);
-        claims_begin_pass(C);
-        if (i < nPoints) {
-            int r4[4];
-            point(C, i, lane, wave, r4);
-            claims_file(C, res, i, lane, r4);
-        }
-        if (!persist_barrier(S.sync, (int)gridDim.x * (pass + 1) - 1)) return;
-        const bool changed = shared_load(S.sync + (pass & 3)) == 0;
-        if (!changed || pass + 1 >= S.maxPasses) {
-            // converged: this pass reproduced its input, so BOTH result buffers hold the fixed point
-            if (blockIdx.x == 0 && threadIdx.x == 0) shared_store(&S.sync[4], changed ? -(pass + 1) - 16 : pass + 1);
-            return;
-        }
-    }
+__global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur,
+                                                                          int fPrev, int fReset, float th) {
+    const FtBatchJob &J = jobs[blockIdx.y];
+    if (J.nPoints <= 0) return;
+    int *res;
+    const FtClaims C = job_claims(J, rb, pass, fCur, fPrev, fReset, res);
+    if (!claims_begin_pass(C)) return;
+    const int lane = threadIdx.x & 63, wave = wave_index();
+    const int i = blockIdx.x * FT_SEARCH_WPB + wave;
+    if (i >= J.L.N) return;
+    __shared__ int cacheCounter[FT_SEARCH_WPB];
+    int r4[4];
+    const FtLastRaw raw = {nullptr, nullptr, nullptr, nullptr};
+    FtDevLastPoints L = J.L;
+    L.valid = rb(L.valid); L.worldPos = rb(L.worldPos); L.desc = rb(L.desc); L.octave = rb(L.octave);
+    last_point(J.F, frame_ptrs(J.F, rb), L, C, J.Tcw, th, J.forward, J.backward, i, lane, r4, raw, &cacheCounter[wave]);
+    claims_file(C, res, i, lane, r4);
 }
 
-__global__ __launch_bounds__(1024) void k_search_local_persist(FtDevFrame F, FtDevLocalPoints P, FtClaims C, float th, float nnRatio,
-                                                               FtPersist S, FtLocalRaw raw) {
-    __shared__ int cacheCounter[16];
-    persist_loop(C, S, P.M, [&](const FtClaims &Cp, int i, int lane, int wave, int r4[4]) {
-        local_point(F, P, Cp, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
-    });
-}
-
-__global__ __launch_bounds__(1024) void k_search_last_persist(FtDevFrame F, FtDevLastPoints Lp, FtClaims C, FtPose Tcw, float th,
-                                                              int bForward, int bBackward, FtPersist S, FtLastRaw raw) {
-    __shared__ int cacheCounter[16];
-    persist_loop(C, S, Lp.N, [&](const FtClaims &Cp, int i, int lane, int wave, int r4[4]) {
-        last_point(F, Lp, Cp, Tcw, th, bForward, bBackward, i, lane, r4, raw, &cacheCounter[wave]);
-    });
+__global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_local_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur,
+                                                                           int fPrev, int fReset, float th, float nnRatio) {
+    const FtBatchJob &J = jobs[blockIdx.y];
+    if (J.nPoints <= 0) return;
+    int *res;
+    const FtClaims C = job_claims(J, rb, pass, fCur, fPrev, fReset, res);
+    if (!claims_begin_pass(C)) return;
+    const int lane = threadIdx.x & 63, wave = wave_index();
+    const int i = blockIdx.x * FT_SEARCH_WPB + wave;
+    if (i >= J.P.M) return;
+    __shared__ int cacheCounter[FT_SEARCH_WPB];
+    int r4[4];
+    FtLocalRaw raw;
+    raw.bestDist = nullptr;
+    FtDevLocalPoints P = J.P;
+    P.skip = rb(P.skip); P.inView = rb(P.inView); P.inViewR = rb(P.inViewR);
+    P.level = rb(P.level); P.levelR = rb(P.levelR);
+    P.viewCos = rb(P.viewCos); P.viewCosR = rb(P.viewCosR);
+    P.projX = rb(P.projX); P.projY = rb(P.projY); P.projXR = rb(P.projXR); P.projYR = rb(P.projYR);
+    P.desc = rb(P.desc);
+    local_point(J.F, frame_ptrs(J.F, rb), P, C, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
+    claims_file(C, res, i, lane, r4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -979,9 +1019,8 @@ __device__ __forceinline__ int predict_scale(float maxDistanceRaw, float dist, f
     return nScale;
 }
 
-__global__ __launch_bounds__(256) void k_frustum(FtDevFrame F, FtFrustumPose T, FtDevMapPoints P, float viewingCosLimit,
-                                                 float logScaleFactor, int farPoints, float thFar, FtFrustumOut O) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void frustum_point(const FtDevFrame &F, const FtFrustumPose &T, const FtDevMapPoints &P, float viewingCosLimit,
+                                              float logScaleFactor, int farPoints, float thFar, const FtFrustumOut &O, int i) {
     if (i >= P.M) return;
     bool inView = false, inViewR = false;
     int level = -1, levelR = -1;
@@ -1047,6 +1086,23 @@ __global__ __launch_bounds__(256) void k_frustum(FtDevFrame F, FtFrustumPose T, 
         O.searchSkip[i] = (!inView && !inViewR) || (farPoints && depth > thFar) || (P.skip && P.skip[i]);
     if (inView || inViewR) atomicAdd(O.count, 1);
 }
+__global__ __launch_bounds__(256) void k_frustum(FtDevFrame F, FtFrustumPose T, FtDevMapPoints P, float viewingCosLimit,
+                                                 float logScaleFactor, int farPoints, float thFar, FtFrustumOut O) {
+    frustum_point(F, T, P, viewingCosLimit, logScaleFactor, farPoints, thFar, O, blockIdx.x * 256 + threadIdx.x);
+}
+// isInFrustum for the local map points of every frame of a batch: blockIdx.y = frame (the counts are zeroed by the launcher)
+__global__ __launch_bounds__(256) void k_frustum_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, float viewingCosLimit,
+                                                       float logScaleFactor, int farPoints, float thFar) {
+    const FtBatchJob &J = jobs[blockIdx.y];
+    FtDevMapPoints P = J.MP;
+    P.skip = rb(P.skip); P.worldPos = rb(P.worldPos); P.normal = rb(P.normal); P.maxDist = rb(P.maxDist); P.minDist = rb(P.minDist);
+    FtFrustumOut O = J.O;
+    O.inView = rb(O.inView); O.inViewR = rb(O.inViewR); O.level = rb(O.level); O.levelR = rb(O.levelR);
+    O.viewCos = rb(O.viewCos); O.viewCosR = rb(O.viewCosR); O.projX = rb(O.projX); O.projY = rb(O.projY);
+    O.projXR = rb(O.projXR); O.projYR = rb(O.projYR); O.depth = rb(O.depth); O.depthR = rb(O.depthR);
+    O.searchSkip = rb(O.searchSkip); O.count = rb(O.count);
+    frustum_point(J.F, J.T, P, viewingCosLimit, logScaleFactor, farPoints, thFar, O, blockIdx.x * 256 + threadIdx.x);
+}
 
 // Result delivery of a search: up to three device blocks (dword granularity) written straight into pinned host memory by
 // one kernel - pass results, raw outputs / frustum fields, and the pass flags - instead of one DMA copy each (a small copy
@@ -1081,6 +1137,33 @@ __global__ __launch_bounds__(256) void k_fill_claims(int *p, int n, unsigned lon
 __global__ __launch_bounds__(256) void k_fill_i32(int *p, int n, int v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
+}
+
+// start of the claim iteration of every frame of a batch (blockIdx.y = frame): list heads and writer table = -1 (27 K words
+// behind J.head: layoutBatch, search.cpp), the frame's 32 flag words = -1, the cache's meta words = ~0, the frustum count = 0
+__global__ __launch_bounds__(256) void k_fill_claims_batch(const FtBatchJob *__restrict__ jobs, Rebase rb) {
+    const FtBatchJob &J = jobs[blockIdx.y];
+    const int t = blockIdx.x * 256 + threadIdx.x, T = gridDim.x * 256;
+    int *count = rb(J.O.count);
+    if (t == 0 && count) *count = 0;
+    int *head = rb(J.head), *flags = rb(J.flags);
+    if (t < 32) flags[t] = -1;  // (also of a frame without points: "converged" is what the host reads there)
+    if (J.nPoints <= 0) return;
+    unsigned long long *cache = rb(J.cache);
+    const int words = 27 * J.K;
+    for (int i = t; i < words; i += T) head[i] = -1;
+    if (cache)
+        for (int i = t; i < 2 * J.nPoints; i += T) cache[(size_t)i * (FT_CACHE_CAP + 1)] = ~0ull;
+}
+
+// Result delivery of a batch: record r (blockIdx.y) = one block of dwords written into pinned host memory; src[parity] lets a
+// record follow the result buffer of the pass that ran last.
+__global__ __launch_bounds__(256) void k_deliver_batch(const FtDeliverRec *__restrict__ recs, int parity) {
+    const FtDeliverRec &R = recs[blockIdx.y];
+    unsigned *d = (unsigned *)R.dst;
+    const unsigned *s = (const unsigned *)R.src[parity];
+    const int t = blockIdx.x * 256 + threadIdx.x, T = gridDim.x * 256;
+    for (int i = t; i < R.words; i += T) d[i] = s[i];
 }
 
 }  // namespace
@@ -1165,28 +1248,55 @@ int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPo
     return FT_OK;
 }
 
-// One launch for the whole claim iteration (see k_search_*_persist).  The grid never exceeds one workgroup per CU.
-int ft_search_persist_capacity() { return 256 * 16; }
-static dim3 persist_grid(int n, int &threads) {
-    threads = 1024;  // few arrivals per barrier: the counter serialises them
-    const int wpb = threads / 64;
-    return dim3((n + wpb - 1) / wpb);
-}
-int ft_launch_search_local_persist(hipStream_t st, const FtDevFrame &F, const FtDevLocalPoints &P, const FtClaims &C, float th,
-                                   float nnRatio, const FtPersist &S, const FtLocalRaw &raw) {
-    if (P.M <= 0 || P.M > ft_search_persist_capacity()) return FT_ERR_INVALID;
-    int threads;
-    const dim3 grid = persist_grid(P.M, threads);
-    hipLaunchKernelGGL(k_search_local_persist, grid, dim3(threads), 0, st, F, P, C, th, nnRatio, S, raw);
+// ---- launches of a batch of frames (ft_tracked_batch, search.cpp) ----
+int ft_launch_fill_claims_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxWords);
+static Rebase rebase_of(void *arena) { return Rebase{(uint8_t *)arena, (unsigned long long)(uintptr_t)arena}; }
+
+int ft_launch_build_grid_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxLevels, bool twoCam) {
+    if (nFrames <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_build_grid_batch, dim3(maxLevels, twoCam ? 2 : 1, nFrames), dim3(256), 0, st, jobs, rebase_of(arena));
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
-int ft_launch_search_last_persist(hipStream_t st, const FtDevFrame &F, const FtDevLastPoints &L, const FtClaims &C,
-                                  const FtPose &Tcw, float th, int forward, int backward, const FtPersist &S, const FtLastRaw &raw) {
-    if (L.N <= 0 || L.N > ft_search_persist_capacity()) return FT_ERR_INVALID;
-    int threads;
-    const dim3 grid = persist_grid(L.N, threads);
-    hipLaunchKernelGGL(k_search_last_persist, grid, dim3(threads), 0, st, F, L, C, Tcw, th, forward, backward, S, raw);
+
+int ft_launch_frustum_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxM, float viewingCosLimit, float logScaleFactor,
+                            int farPoints, float thFar) {
+    if (nFrames <= 0 || maxM <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_frustum_batch, dim3((maxM + 255) / 256, nFrames), dim3(256), 0, st, jobs, rebase_of(arena), viewingCosLimit,
+                       logScaleFactor, farPoints, thFar);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_search_last_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur, int fPrev,
+                                int fReset, float th) {
+    if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_search_last_batch, dim3((maxPoints + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st,
+                       jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_search_local_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur, int fPrev,
+                                 int fReset, float th, float nnRatio) {
+    if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_search_local_batch, dim3((maxPoints + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB, nFrames), dim3(64 * FT_SEARCH_WPB), 0,
+                       st, jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th, nnRatio);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_fill_claims_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxWords) {
+    if (nFrames <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_fill_claims_batch, dim3(std::max(1, std::min(64, (maxWords + 1023) / 1024)), nFrames), dim3(256), 0, st, jobs,
+                       rebase_of(arena));
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_deliver_batch(hipStream_t st, const FtDeliverRec *recs, int nRecs, int maxWords, int parity) {
+    if (nRecs <= 0 || maxWords <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_deliver_batch, dim3(std::max(1, std::min(16, (maxWords + 1023) / 1024)), nRecs), dim3(256), 0, st, recs, parity);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -21,6 +21,7 @@
 // (log) with the host's cosf / sinf / logf; tests/test_libm_f32_cpu.py runs a strided version in the CPU suite and the
 // same sweep on the device against the GPU box's libm under -m gpu.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 #if defined(__HIPCC__)
 #define FT_LM_HD __host__ __device__ __forceinline__
@@ -83,11 +84,14 @@ FT_LM_HD float sinf_poly(double x, double x2, const SinCosPoly &p, int n) {
 
 FT_LM_HD uint32_t abstop12(float x) { return (f32_bits(x) >> 20) & 0x7ff; }
 
-// sinf (cosine = false) / cosf (cosine = true) of s_sinf.c / s_cosf.c for |y| < 120; larger arguments (the
-// reduce_large path) cannot occur: the callers pass an angle of [0, 2 pi].
+// sinf (cosine = false) / cosf (cosine = true) of s_sinf.c / s_cosf.c for |y| < 120.  Larger arguments (glibc's
+// reduce_large path) cannot occur on the path - the callers pass an angle of [0, 2 pi] or an atan2f result - and are not
+// restated: they, NaN and infinities take the double-precision routine narrowed once (NaN for NaN / Inf, as glibc returns;
+// the correctly rounded value except at double-rounding ties for finite arguments), never the polynomial outside its range.
 FT_LM_HD float sincosf_one(float y, bool cosine) {
     double x = (double)y;
     const uint32_t top = abstop12(y);
+    if (top >= abstop12(120.0f)) return cosine ? (float)cos(x) : (float)sin(x);
     if (top < abstop12(0x1.921FB6p-1f)) {  // pi / 4, compared on the top 12 bits as glibc does
         if (top < abstop12(0x1p-12f)) return cosine ? 1.0f : y;
         return sinf_poly(x, x * x, sincos_poly(false), cosine ? 1 : 0);

@@ -392,8 +392,7 @@ static int frontendEnqueue(ft_stereo_frontend *fe, const uint8_t *const *imagesL
     hipStream_t st = L->streamB;
     // latency mode: the results of a small batch are written to pinned host memory by one kernel (FtDeliverArgs); large
     // batches keep the DMA copies, which cost no compute units
-    const bool deliverOn = fe->exL->tune.deliver_kernel != 0;
-    const bool deliver = deliverOn && dev && batch <= FT_GRAPH_MAX_BATCH;
+    const bool deliver = dev && batch <= FT_GRAPH_MAX_BATCH;
     double tOct = 0, tWait = 0, tLaunch = 0;
     for (int s = 0, b0 = 0; b0 < batch; s++, b0 += sb) {
         const int nb = std::min(sb, batch - b0);

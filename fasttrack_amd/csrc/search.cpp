@@ -44,6 +44,11 @@ int checkFrame(const ft_frame_view *F) {
     FT_REQUIRE(F->Nleft == -1 || (F->left_to_right && F->right_to_left), "stereo match tables are null");
     FT_REQUIRE(F->scale_factors && F->nlevels >= 1 && F->nlevels <= FT_MAX_LEVELS, "scale factors missing");
     FT_REQUIRE(F->cam_model == 0 || F->cam_model == 1, "unknown camera model");
+    // the searches read a keypoint's octave back from four bits of a candidate key (make_key, kernels_search.hip)
+    const int nL = F->Nleft == -1 ? F->N : F->Nleft, nR = F->Nleft == -1 ? 0 : F->N - F->Nleft;
+    for (int i = 0; i < nL; i++) FT_REQUIRE(F->keys[i].octave >= 0 && F->keys[i].octave < F->nlevels, "keypoint octave outside [0, nlevels)");
+    for (int i = 0; i < nR; i++)
+        FT_REQUIRE(F->keys_right[i].octave >= 0 && F->keys_right[i].octave < F->nlevels, "right keypoint octave outside [0, nlevels)");
     return FT_OK;
 }
 
@@ -115,32 +120,9 @@ struct PassBufs {
 // `download(res, flags, nFlagBytes)` enqueues ONE delivery kernel that writes the pass results `res`, whatever else the
 // caller needs and the burst's flags into pinned host memory (hostFlags); it runs behind every burst, in front of the one
 // stream synchronisation.
-//
-// Persistent form (option search_persistent; opt-in - measured 20 % SLOWER than the launches: a counter barrier over ~130
-// workgroups costs more than a launch boundary, and a pass is a handful of dependent L2 round trips either way): when the points fit one workgroup per CU, `persist(S)` enqueues ONE
-// launch that runs every pass with grid barriers in between (kernels_search.hip, k_search_*_persist) and leaves the number of
-// passes in sync word 4; one delivery, one synchronisation.  A launch whose barrier timed out (a workgroup that could not
-// become resident: another process holding the CUs) or that hit the pass bound reports that instead, and the call is redone
-// by the multi-launch form - results never depend on which form ran.  Persistent launches of one process on one device are
-// chained by an event, whatever streams they are on: two of them dispatching side by side could each hold CUs the other
-// needs for its last workgroups.
-static std::mutex g_persistMutex;
-static hipEvent_t g_persistDone[64] = {};
-static int chainPersistent(ft_context *ctx, hipStream_t st, bool before) {
-    std::lock_guard<std::mutex> lk(g_persistMutex);
-    const int d = ctx->device & 63;
-    if (before) {
-        if (g_persistDone[d]) FT_HIP(hipStreamWaitEvent(st, g_persistDone[d], 0));
-        return FT_OK;
-    }
-    if (!g_persistDone[d]) FT_HIP(hipEventCreateWithFlags(&g_persistDone[d], hipEventDisableTiming));
-    FT_HIP(hipEventRecord(g_persistDone[d], st));
-    return FT_OK;
-}
-
-template <typename SearchFn, typename PersistFn, typename DownloadFn>
+template <typename SearchFn, typename DownloadFn>
 int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const PassBufs &B, FtClaims &C, SearchFn search,
-               PersistFn persist, DownloadFn download, const int *hostFlags, int **resFinal, int *passes, int *burstHint = nullptr) {
+               DownloadFn download, const int *hostFlags, int **resFinal, int *passes, int *burstHint = nullptr) {
     // Passes per burst.  Every surplus pass of a burst is an empty launch (4.5 us of dispatch for ~500 workgroups), every
     // burst that falls short a host round trip (~40 us).  A caller that searches frame after frame (ft_tracked_frame) hands in
     // the pass count of its previous search of the same kind: the first burst is that count + 1, later bursts are short.
@@ -167,34 +149,6 @@ int fixedPoint(ft_context *ctx, hipStream_t st, int nPoints, int nKp, const Pass
     const int maxPasses = 2 * nPoints + 4 + burstMax;
     C.obs = B.obs;
     C.nKp = nKp;
-    if (ctx->tuning.search_persistent && nPoints <= ft_search_persist_capacity()) {
-        FtPersist S;
-        S.res = B.res;
-        S.head = B.head;
-        S.next = B.next;
-        S.tab = tab;
-        S.sync = flags;
-        S.K = (int)K;
-        S.nPoints = nPoints;
-        S.maxPasses = std::min(maxPasses, 1 << 20);
-        int rc = chainPersistent(ctx, st, true);
-        if (rc == FT_OK) rc = persist(S);
-        if (rc == FT_OK) rc = chainPersistent(ctx, st, false);
-        if (rc == FT_OK) rc = download(B.res, flags, sizeof(int) * 8);
-        if (rc != FT_OK) return rc;
-        FT_HIP(hipStreamSynchronize(st));
-        const int status = hostFlags[4];
-        if (status > 0) {
-            *resFinal = B.res;
-            *passes = status;
-            ctx->addStat("search.persistent_launches", 0.0);
-            return FT_OK;
-        }
-        // timeout / pass bound: start over with launches of their own (the candidate cache keeps what was built)
-        ctx->addStat(status == FT_PERSIST_STATUS_TIMEOUT ? "search.persistent_timeouts" : "search.persistent_fallbacks", 0.0);
-        const int rcf = ft_launch_fill_i32(st, B.head, fillWords, -1);
-        if (rcf != FT_OK) return rcf;
-    }
     int *last = B.res;
     for (;; burst++) {
         int *fl = flags + 16 * (burst & 1), *flOther = flags + 16 * ((burst + 1) & 1);
@@ -624,7 +578,6 @@ int ft_search_local_points(ft_context *ctx, ft_frame_view *F, const ft_local_poi
     int *resFinal = nullptr, passes = 0;
     rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs), C,
                     [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); },
-                    [&](const FtPersist &S) { return ft_launch_search_local_persist(st, DF, DP, C, th, nn_ratio, S, raw); },
                     [&](int *res, const int *fl, size_t flBytes) -> int {
                         return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M + 64, rawBase, 40 * (size_t)M,
                                                         pin + 16 * (size_t)M, fl, flBytes);
@@ -733,7 +686,6 @@ int searchLastFrame(ft_context *ctx, ft_frame_view *Cur, const ft_last_points *L
     int *resFinal = nullptr, passes = 0;
     rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
-                    [&](const FtPersist &S) { return ft_launch_search_last_persist(st, DF, DL, C, pose, th, forward, backward, S, raw); },
                     [&](int *res, const int *fl, size_t flBytes) -> int {
                         return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M + 64, rawBase, 16 * (size_t)M,
                                                         pin + 16 * (size_t)M, fl, flBytes);
@@ -1087,7 +1039,6 @@ int trackedSearchLastFrame(ft_tracked_frame *tf, const ft_last_points *L, const 
     if (trl) setTrl(DF, *trl);
     rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs, tf->d_cache), C,
                     [&](int *res) { return ft_launch_search_last(st, DF, DL, C, pose, th, forward, backward, res, raw); },
-                    [&](const FtPersist &S) { return ft_launch_search_last_persist(st, DF, DL, C, pose, th, forward, backward, S, raw); },
                     [&](int *res, const int *fl, size_t flBytes) -> int {
                         return ft_launch_deliver_blocks(st, pin, res, 16 * (size_t)M, pin + 16 * (size_t)M, fl, flBytes, nullptr, nullptr, 0);
                     },
@@ -1179,7 +1130,6 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
         int *resFinal = nullptr;
         rc = fixedPoint(ctx, st, M, N, passBufs(PL, dev, C.obs, tf->d_cache), C,
                         [&](int *res) { return ft_launch_search_local(st, DF, DP, C, th, nn_ratio, res, raw); },
-                        [&](const FtPersist &S) { return ft_launch_search_local_persist(st, DF, DP, C, th, nn_ratio, S, raw); },
                         [&](int *res, const int *fl, size_t flBytes) -> int {  // pass results, frustum fields and flags: one kernel
                             return ft_launch_deliver_blocks(st, pin + fOutEnd, res, 16 * (size_t)M, pin, dev + fInputEnd, fOutEnd - fInputEnd,
                                                             pin + fOutEnd + 16 * (size_t)M, fl, flBytes);
@@ -1198,6 +1148,611 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
     if (n_matches) *n_matches = nm;
     ctx->addStat("tracked.track_local_map.total", tAll.ms());
     ctx->addStat("tracked.track_local_map.passes", passes);
+    return FT_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// B device-resident frames searched through ONE set of launches (ft_tracked_batch_*; SURVEY.md 7 step 7 "Batch API (B frames
+// per launch)").  One frame at a time is what the reference's tracking thread does (src/Tracking.cc:2911-2989, 3472-3555) and it
+// leaves a 256-CU chip idle by construction: ~45 launches of a few hundred workgroups per frame.  A batch holds B independent
+// frames - the camera streams of one time step, or any frames whose inputs the caller has - and runs every stage as one launch
+// over all of them: grid build (blockIdx.z = frame), isInFrustum, and each pass of the two searches' claim iteration
+// (blockIdx.y = frame, per-frame convergence flags; the batch runs max-over-frames passes).  Results per frame are those of
+// ft_tracked_frame_* on that frame, bit for bit.
+//
+// Memory: ONE device arena per batch (the kernels re-derive every pointer of a job record from it: Rebase, kernels_search.hip)
+//   work   | per call: job records, delivery records, the frames' point arrays (compact), frustum outputs
+//   frames | keypoints, descriptors, uright, match tables, holder_obs of the uploaded frames (compact)
+//   flags  | 32 words per frame;  counts | 1 word per frame (isInFrustum's nToMatch)
+//   grid   | Frame::mGrid as CSR, per frame;  claims | res, list heads + writer table, next, per frame;  cache | per frame
+// and two pinned buffers: the mirror of `work` + `frames` (inputs: one H2D copy per call) and the results.
+struct ft_tracked_batch {
+    ft_context *ctx = nullptr;
+    bool counted = false;
+    int maxFrames = 0, maxKp = 0, maxPts = 0;
+    uint8_t *d_arena = nullptr;
+    size_t arenaBytes = 0;
+    size_t oWork = 0, workBytes = 0, oFrames = 0, framesBytes = 0, oFlags = 0, oCounts = 0, oGrid = 0, gridStride = 0, oClaims = 0,
+           claimStride = 0, oCache = 0, cacheStride = 0;
+    uint8_t *h_in = nullptr;   // pinned mirror of [work | frames]
+    uint8_t *h_out = nullptr;  // pinned results
+    size_t outBytes = 0;
+    // the uploaded frames
+    int nFrames = 0;
+    std::vector<FtDevFrame> DF;
+    std::vector<size_t> holderOff;  // byte offset of frame f's holder_obs inside the frames region
+    size_t holderBegin = 0, holderEnd = 0;  // the holder_obs arrays of all frames are contiguous: one copy refreshes them
+    std::vector<std::vector<float>> angles;
+    std::vector<std::vector<int>> holder;
+    int passesLast = 0, passesLocal = 0;
+};
+
+namespace {
+
+size_t batchClaimBytes(int maxKp, int maxPts) {
+    const size_t K = passK(maxKp);
+    return ((32 * (size_t)maxPts + 63) & ~(size_t)63) * 2 + ((4 * 27 * K + 63) & ~(size_t)63);
+}
+// bytes of one frame's arrays in the frames region, upper bound
+size_t batchFrameBytes(int maxKp) {
+    const size_t K = (size_t)maxKp;
+    return (2 * sizeof(ft_keypoint) + 32 + 4 * 4) * K + 8 * 64;
+}
+// per call and frame: point inputs (<= 69 B), frustum outputs (<= 47 B) per point + alignment slack
+size_t batchWorkBytes(int maxPts) { return 128 * (size_t)maxPts + 24 * 64 + sizeof(FtBatchJob) + 4 * sizeof(FtDeliverRec); }
+size_t batchOutBytes(int maxPts) { return (16 + 47) * (size_t)maxPts + 20 * 64; }
+
+// the claim buffers of frame f for a search of nPoints points on nKp keypoints
+void batchClaims(const ft_tracked_batch *tb, int f, int nKp, int nPoints, FtBatchJob &J) {
+    uint8_t *c = tb->d_arena + tb->oClaims + (size_t)f * tb->claimStride;
+    const size_t resBytes = (32 * (size_t)tb->maxPts + 63) & ~(size_t)63;
+    J.res = (int *)c;
+    J.next = (int *)(c + resBytes);
+    J.head = (int *)(c + 2 * resBytes);
+    J.K = (int)passK(nKp);
+    J.tab = J.head + 3 * (size_t)J.K;
+    J.flags = (int *)(tb->d_arena + tb->oFlags) + 32 * (size_t)f;
+    J.cache = tb->oCache ? (unsigned long long *)(tb->d_arena + tb->oCache + (size_t)f * tb->cacheStride) : nullptr;
+    J.nKp = nKp;
+    J.nPoints = nPoints;
+}
+
+// The claim iteration of every frame of the batch (see fixedPoint): bursts of passes, one launch per pass for ALL frames, one
+// delivery + one synchronisation per burst.  launchPass(pass, fCur, fPrev, fReset); deliver(parity) writes every frame's
+// results of that parity and all flag words into tb->h_out (flags at hostFlags[32 f ...]).
+template <typename PassFn, typename DeliverFn>
+int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJobs, int n, int maxPoints, int maxK, PassFn launchPass,
+                    DeliverFn deliver, const int *hostFlags, int *parityFinal, int *passes, int *burstHint) {
+    ft_context *ctx = tb->ctx;
+    const int burstMax = passBurst(ctx);
+    int len = burstHint && *burstHint > 0 ? std::min(std::max(*burstHint + 1, 4), FT_PASS_BURST_MAX) : burstMax;
+    *parityFinal = 0;
+    *passes = 0;
+    int rc = ft_launch_fill_claims_batch(st, tb->d_arena, dJobs, n, 27 * maxK);
+    if (rc != FT_OK) return rc;
+    if (maxPoints <= 0) {
+        rc = deliver(0);
+        if (rc != FT_OK) return rc;
+        FT_HIP(hipStreamSynchronize(st));
+        return FT_OK;
+    }
+    const int maxPasses = 2 * maxPoints + 4 + burstMax;
+    int pass = 0, prevLen = 0, parity = 0;
+    for (int burst = 0;; burst++) {
+        const int base = 16 * (burst & 1), other = 16 * ((burst + 1) & 1);
+        for (int b = 0; b < len; b++, pass++) {
+            const int fPrev = b > 0 ? base + b - 1 : (burst > 0 ? other + prevLen - 1 : -1);
+            rc = launchPass(pass, base + b, fPrev, other + b);
+            if (rc != FT_OK) return rc;
+            parity = pass & 1;
+        }
+        rc = deliver(parity);
+        if (rc != FT_OK) return rc;
+        FT_HIP(hipStreamSynchronize(st));
+        bool all = true;
+        int ranMax = 0;
+        for (int f = 0; f < n; f++) {
+            const int *h = hostFlags + 32 * (size_t)f + base;
+            if (h[len - 1] != -1) all = false;
+            int ran = 0;
+            while (ran < len && h[ran] != -1) ran++;
+            ranMax = std::max(ranMax, std::min(ran + 1, len));
+        }
+        if (all) {
+            pass = pass - len + ranMax;
+            break;
+        }
+        if (pass >= maxPasses) {
+            ft_set_error("projection search (batch): claim resolution did not converge");
+            return FT_ERR_HIP;
+        }
+        prevLen = len;
+        if (burstHint) len = std::min(len, 4);  // the hint fell short: short bursts from here (never longer than the one before:
+                                                // the flag words beyond a burst's length are not reset by the next one)
+    }
+    *parityFinal = parity;
+    *passes = pass;
+    if (burstHint) *burstHint = pass;
+    return FT_OK;
+}
+
+int checkBatch(const ft_tracked_batch *tb, int n, const char *what) {
+    if (!tb) {
+        ft_set_error(std::string(what) + ": null batch");
+        return FT_ERR_INVALID;
+    }
+    if (n != tb->nFrames || n <= 0) {
+        ft_set_error(std::string(what) + ": n_frames differs from the number of frames uploaded");
+        return FT_ERR_INVALID;
+    }
+    return FT_OK;
+}
+
+// holder_obs of all frames to the device: the arrays are contiguous in the frames region, one copy from the pinned mirror
+int uploadBatchHolders(ft_tracked_batch *tb, hipStream_t st) {
+    for (int f = 0; f < tb->nFrames; f++)
+        if (!tb->holder[f].empty()) memcpy(tb->h_in + tb->workBytes + tb->holderOff[f], tb->holder[f].data(), sizeof(int) * tb->holder[f].size());
+    if (tb->holderEnd > tb->holderBegin)
+        FT_HIP(hipMemcpyAsync(tb->d_arena + tb->oFrames + tb->holderBegin, tb->h_in + tb->workBytes + tb->holderBegin,
+                              tb->holderEnd - tb->holderBegin, hipMemcpyHostToDevice, st));
+    return FT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, int max_points, ft_tracked_batch **out) {
+    FT_REQUIRE(ctx && out && max_frames > 0 && max_keypoints > 0 && max_points > 0, "ft_tracked_batch_create: bad argument");
+    FT_REQUIRE(max_frames <= 4096 && max_keypoints < (1 << 24) && max_points < (1 << 22), "ft_tracked_batch_create: capacity out of range");
+    int rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    ft_tracked_batch *tb = new ft_tracked_batch();
+    tb->ctx = ctx;
+    tb->maxFrames = max_frames;
+    tb->maxKp = max_keypoints;
+    tb->maxPts = max_points;
+    const size_t B = (size_t)max_frames;
+    Arena a;
+    tb->workBytes = (B * batchWorkBytes(max_points) + 4095) & ~(size_t)4095;
+    tb->oWork = a.take(tb->workBytes);
+    tb->framesBytes = (B * batchFrameBytes(max_keypoints) + 4095) & ~(size_t)4095;
+    tb->oFrames = a.take(tb->framesBytes);
+    tb->oFlags = a.take(B * 32 * sizeof(int));
+    tb->oCounts = a.take(B * sizeof(int));
+    tb->gridStride = (gridBytes(max_keypoints) + 255) & ~(size_t)255;
+    tb->oGrid = a.take(B * tb->gridStride);
+    tb->claimStride = (batchClaimBytes(max_keypoints, max_points) + 255) & ~(size_t)255;
+    tb->oClaims = a.take(B * tb->claimStride);
+    if (searchCacheOn(ctx)) {
+        tb->cacheStride = searchCacheBytes(max_points);
+        tb->oCache = a.take(B * tb->cacheStride);
+    }
+    tb->arenaBytes = a.off;
+    tb->outBytes = B * batchOutBytes(max_points) + B * 32 * sizeof(int) + 4096;
+    hipError_t e = hipMalloc((void **)&tb->d_arena, tb->arenaBytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_in, tb->workBytes + tb->framesBytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_out, tb->outBytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ft_tracked_batch_destroy(tb);
+        return ft_hip_fail(e, "ft_tracked_batch_create", __FILE__, __LINE__);
+    }
+    tb->counted = true;
+    ctx->liveObjects++;
+    *out = tb;
+    return FT_OK;
+}
+
+int ft_tracked_batch_destroy(ft_tracked_batch *tb) {
+    if (!tb) return FT_OK;
+    ft_set_device(tb->ctx);
+    hipStreamSynchronize(tb->ctx->stream);
+    if (tb->d_arena) hipFree(tb->d_arena);
+    if (tb->h_in) hipHostFree(tb->h_in);
+    if (tb->h_out) hipHostFree(tb->h_out);
+    if (tb->counted) tb->ctx->liveObjects--;
+    delete tb;
+    return FT_OK;
+}
+
+int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_frame_view *frames) {
+    FT_REQUIRE(tb && frames && n_frames > 0 && n_frames <= tb->maxFrames, "ft_tracked_batch_upload: bad argument");
+    int nlevelsMax = 1;
+    bool twoCam = false;
+    for (int f = 0; f < n_frames; f++) {
+        int rc = checkFrame(&frames[f]);
+        if (rc != FT_OK) return rc;
+        FT_REQUIRE(frames[f].N <= tb->maxKp, "ft_tracked_batch_upload: more keypoints than the batch was created for");
+        nlevelsMax = std::max(nlevelsMax, frames[f].nlevels);
+        twoCam = twoCam || frames[f].Nleft != -1;
+    }
+    ft_context *ctx = tb->ctx;
+    int rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    FtTimer tAll;
+    hipStream_t st = ctx->stream;
+    FT_HIP(hipStreamSynchronize(st));  // the pinned mirror is repacked: nothing of an earlier call may still read it
+    // layout of the frames region: the holder_obs arrays of all frames first (contiguous: refreshed after every search by one
+    // copy), then every frame's arrays
+    Arena a;
+    tb->holderOff.assign(n_frames, 0);
+    tb->holderBegin = a.off;
+    for (int f = 0; f < n_frames; f++) tb->holderOff[f] = a.take(sizeof(int) * std::max(frames[f].N, 1));
+    tb->holderEnd = a.off;
+    struct Lay {
+        size_t keys, keysR, desc, uright, l2r, r2l;
+    };
+    std::vector<Lay> lay(n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        const ft_frame_view &F = frames[f];
+        const int nL = F.Nleft == -1 ? F.N : F.Nleft, nR = F.Nleft == -1 ? 0 : F.N - F.Nleft;
+        lay[f].keys = a.take(sizeof(ft_keypoint) * std::max(nL, 1));
+        lay[f].keysR = a.take(sizeof(ft_keypoint) * std::max(nR, 1));
+        lay[f].desc = a.take((size_t)32 * std::max(F.N, 1));
+        lay[f].uright = a.take(sizeof(float) * std::max(F.N, 1));
+        lay[f].l2r = a.take(sizeof(int) * std::max(nL, 1));
+        lay[f].r2l = a.take(sizeof(int) * std::max(nR, 1));
+    }
+    FT_REQUIRE(a.off <= tb->framesBytes, "ft_tracked_batch_upload: frames region too small");
+    tb->nFrames = n_frames;
+    tb->DF.assign(n_frames, FtDevFrame());
+    tb->angles.resize(n_frames);
+    tb->holder.resize(n_frames);
+    uint8_t *pinF = tb->h_in + tb->workBytes, *devF = tb->d_arena + tb->oFrames;
+    FtBatchJob *hJobs = (FtBatchJob *)tb->h_in;
+    FT_REQUIRE((size_t)n_frames * sizeof(FtBatchJob) <= tb->workBytes, "ft_tracked_batch_upload: work region too small");
+    // the caller's arrays are pageable as a rule: packed into the pinned mirror by the context's host threads, one frame each
+    const std::function<void(int, int)> stage = [&](int f, int) {
+        const ft_frame_view &F = frames[f];
+        const int nL = F.Nleft == -1 ? F.N : F.Nleft, nR = F.Nleft == -1 ? 0 : F.N - F.Nleft;
+        if (nL) memcpy(pinF + lay[f].keys, F.keys, sizeof(ft_keypoint) * nL);
+        if (nR) memcpy(pinF + lay[f].keysR, F.keys_right, sizeof(ft_keypoint) * nR);
+        if (F.N) memcpy(pinF + lay[f].desc, F.descriptors, (size_t)32 * F.N);
+        if (F.uright && F.N) memcpy(pinF + lay[f].uright, F.uright, sizeof(float) * F.N);
+        if (F.Nleft != -1) {
+            if (nL) memcpy(pinF + lay[f].l2r, F.left_to_right, sizeof(int) * nL);
+            if (nR) memcpy(pinF + lay[f].r2l, F.right_to_left, sizeof(int) * nR);
+        }
+        if (F.N) memcpy(pinF + tb->holderOff[f], F.holder_obs, sizeof(int) * F.N);
+        FtDevFrame &D = tb->DF[f];
+        D = devFrameConstants(&F);
+        D.keys = (const ft_keypoint *)(devF + lay[f].keys);
+        D.keysR = (const ft_keypoint *)(devF + lay[f].keysR);
+        D.desc = devF + lay[f].desc;
+        D.uright = F.uright ? (const float *)(devF + lay[f].uright) : nullptr;
+        D.holderObs = (const int *)(devF + tb->holderOff[f]);
+        D.l2r = F.Nleft != -1 ? (const int *)(devF + lay[f].l2r) : nullptr;
+        D.r2l = F.Nleft != -1 ? (const int *)(devF + lay[f].r2l) : nullptr;
+        if (ctx->tuning.search_grid) {  // the arrays k_build_grid_batch fills (buildGrid's layout, per frame)
+            int *grid = (int *)(tb->d_arena + tb->oGrid + (size_t)f * tb->gridStride);
+            const bool two = D.Nleft != -1;
+            float4 *rec = (float4 *)((uint8_t *)grid + gridIntBytes(D.N));
+            uint8_t *gdesc = (uint8_t *)(rec + std::max(D.N, 1));
+            D.gridStart[0] = grid;
+            D.gridStart[1] = two ? grid + (size_t)FT_MAX_LEVELS * (FT_GRID_CELLS + 1) : nullptr;
+            D.gridRec[0] = rec;
+            D.gridDesc[0] = gdesc;
+            D.gridRec[1] = two ? rec + nL : nullptr;
+            D.gridDesc[1] = two ? gdesc + (size_t)32 * nL : nullptr;
+        }
+        memset(&hJobs[f], 0, sizeof(FtBatchJob));
+        hJobs[f].F = D;
+        tb->angles[f].resize(F.N);
+        for (int i = 0; i < nL; i++) tb->angles[f][i] = F.keys[i].angle;
+        for (int i = 0; i < nR; i++) tb->angles[f][nL + i] = F.keys_right[i].angle;
+        tb->holder[f].assign(F.holder_obs, F.holder_obs + F.N);
+    };
+    ctx->pool->parallel_for(n_frames, stage);
+    FT_HIP(hipMemcpyAsync(tb->d_arena + tb->oWork, tb->h_in, (size_t)n_frames * sizeof(FtBatchJob), hipMemcpyHostToDevice, st));
+    FT_HIP(hipMemcpyAsync(devF, pinF, a.off, hipMemcpyHostToDevice, st));
+    if (ctx->tuning.search_grid) {
+        rc = ft_launch_build_grid_batch(st, tb->d_arena, (const FtBatchJob *)(tb->d_arena + tb->oWork), n_frames, nlevelsMax, twoCam);
+        if (rc != FT_OK) return rc;
+    }
+    ctx->addStat("tracked_batch.upload.total", tAll.ms());
+    return FT_OK;
+}
+
+int ft_tracked_batch_holder_obs(ft_tracked_batch *tb, int frame, int *holder_obs) {
+    FT_REQUIRE(tb && frame >= 0 && frame < tb->nFrames && holder_obs, "ft_tracked_batch_holder_obs: bad argument");
+    const std::vector<int> &h = tb->holder[frame];
+    if (!h.empty()) memcpy(holder_obs, h.data(), sizeof(int) * h.size());
+    return FT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, const FtPose *poses, const FtPose *trls, float th,
+                         const int *forward, const int *backward, int check_orientation, int *const *assign, int *n_matches) {
+    int rc = checkBatch(tb, n, "ft_tracked_batch_search_last_frame");
+    if (rc != FT_OK) return rc;
+    FT_REQUIRE(L && assign, "ft_tracked_batch_search_last_frame: null argument");
+    ft_context *ctx = tb->ctx;
+    for (int f = 0; f < n; f++) {
+        const int M = L[f].N;
+        FT_REQUIRE(assign[f], "ft_tracked_batch_search_last_frame: null assign array");
+        FT_REQUIRE(M >= 0 && M <= tb->maxPts, "last-frame point count beyond the batch's capacity");
+        FT_REQUIRE(M == 0 || (L[f].valid && L[f].world_pos && L[f].descriptors && L[f].observations && L[f].octave && L[f].angle),
+                   "last-frame arrays are null");
+        for (int i = 0; i < M; i++)
+            FT_REQUIRE(!L[f].valid[i] || (L[f].octave[i] >= 0 && L[f].octave[i] < tb->DF[f].nlevels), "last-frame octave out of range");
+    }
+    rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    FtTimer tAll;
+    hipStream_t st = ctx->stream;
+    // layout of the call: job records | delivery records | per frame the point arrays
+    Arena a;
+    const size_t oJobs = a.take((size_t)n * sizeof(FtBatchJob));
+    const size_t oRecs = a.take((size_t)(n + 1) * sizeof(FtDeliverRec));
+    struct Lay {
+        size_t valid, pos, desc, obs, oct, out;
+    };
+    std::vector<Lay> lay(n);
+    Arena o;  // results in tb->h_out
+    const size_t oFlagsOut = o.take((size_t)n * 32 * sizeof(int));
+    int maxPoints = 0, maxK = 8;
+    for (int f = 0; f < n; f++) {
+        const size_t M = (size_t)std::max(L[f].N, 1);
+        lay[f].valid = a.take(M);
+        lay[f].pos = a.take(12 * M);
+        lay[f].desc = a.take(32 * M);
+        lay[f].obs = a.take(4 * M);
+        lay[f].oct = a.take(4 * M);
+        lay[f].out = o.take(16 * M);
+    }
+    FT_REQUIRE(a.off <= tb->workBytes && o.off <= tb->outBytes, "tracked batch work arena too small");
+    uint8_t *pin = tb->h_in, *dev = tb->d_arena + tb->oWork;
+    FtBatchJob *hJobs = (FtBatchJob *)(pin + oJobs);
+    FtDeliverRec *hRecs = (FtDeliverRec *)(pin + oRecs);
+    FT_HIP(hipStreamSynchronize(st));  // (the pinned mirror of the previous call)
+    const std::function<void(int, int)> stage = [&](int f, int) {
+        const ft_last_points &P = L[f];
+        const size_t M = (size_t)P.N;
+        const int N = tb->DF[f].N;
+        if (M) {
+            memcpy(pin + lay[f].valid, P.valid, M);
+            memcpy(pin + lay[f].pos, P.world_pos, 12 * M);
+            memcpy(pin + lay[f].desc, P.descriptors, 32 * M);
+            memcpy(pin + lay[f].obs, P.observations, 4 * M);
+            memcpy(pin + lay[f].oct, P.octave, 4 * M);
+        }
+        FtBatchJob &J = hJobs[f];
+        memset(&J, 0, sizeof J);
+        J.F = tb->DF[f];
+        if (trls) setTrl(J.F, trls[f]);
+        batchClaims(tb, f, N, N > 0 ? (int)M : 0, J);
+        J.obs = (const int *)(dev + lay[f].obs);
+        J.L.N = (int)M;
+        J.L.valid = dev + lay[f].valid;
+        J.L.worldPos = (const float *)(dev + lay[f].pos);
+        J.L.desc = dev + lay[f].desc;
+        J.L.octave = (const int *)(dev + lay[f].oct);
+        J.Tcw = poses[f];
+        J.forward = forward ? forward[f] : 0;
+        J.backward = backward ? backward[f] : 0;
+        FtDeliverRec &R = hRecs[f];
+        R.dst = tb->h_out + lay[f].out;
+        R.src[0] = J.res;
+        R.src[1] = J.res + 4 * (size_t)J.nPoints;
+        R.words = 4 * J.nPoints;
+        for (int i = 0; i < N; i++) assign[f][i] = -1;
+    };
+    ctx->pool->parallel_for(n, stage);
+    for (int f = 0; f < n; f++) {
+        maxPoints = std::max(maxPoints, hJobs[f].nPoints);
+        if (hJobs[f].nPoints > 0) maxK = std::max(maxK, hJobs[f].K);
+    }
+    hRecs[n].dst = tb->h_out + oFlagsOut;
+    hRecs[n].src[0] = hRecs[n].src[1] = tb->d_arena + tb->oFlags;
+    hRecs[n].words = 32 * n;
+    FT_HIP(hipMemcpyAsync(dev, pin, a.off, hipMemcpyHostToDevice, st));
+    const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
+    const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
+    int parity = 0, passes = 0;
+    rc = fixedPointBatch(
+        tb, st, dJobs, n, maxPoints, maxK,
+        [&](int pass, int fCur, int fPrev, int fReset) {
+            return ft_launch_search_last_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
+        },
+        [&](int par) { return ft_launch_deliver_batch(st, dRecs, n + 1, std::max(4 * maxPoints, 32 * n), par); },
+        (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLast);
+    if (rc != FT_OK) return rc;
+    const std::function<void(int, int)> replay = [&](int f, int) {
+        const int nm = hJobs[f].nPoints > 0
+                           ? replayLastFrameWrites((const int *)(tb->h_out + lay[f].out), L[f].N, &L[f], [&](int idx) { return tb->angles[f][idx]; },
+                                                   check_orientation != 0, tb->holder[f].data(), assign[f])
+                           : 0;
+        if (n_matches) n_matches[f] = nm;
+    };
+    ctx->pool->parallel_for(n, replay);
+    rc = uploadBatchHolders(tb, st);
+    if (rc != FT_OK) return rc;
+    ctx->addStat("tracked_batch.search_last_frame.total", tAll.ms());
+    ctx->addStat("tracked_batch.search_last_frame.passes", passes);
+    ctx->addStat("tracked_batch.search_last_frame.frames", n);
+    return FT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ft_tracked_batch_search_last_frame(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const float *Tcw, float th,
+                                       const int *forward, const int *backward, int check_orientation, int *const *assign,
+                                       int *n_matches) {
+    FT_REQUIRE(Tcw && n_frames > 0, "ft_tracked_batch_search_last_frame: null pose");
+    std::vector<FtPose> poses(n_frames);
+    for (int f = 0; f < n_frames; f++) poses[f] = poseOfMatrix(Tcw + 12 * (size_t)f);
+    return batchSearchLastFrame(tb, n_frames, L, poses.data(), nullptr, th, forward, backward, check_orientation, assign, n_matches);
+}
+
+int ft_tracked_batch_search_last_frame_se3(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const ft_se3 *Tcw,
+                                           const ft_se3 *Trl, float th, const int *forward, const int *backward,
+                                           int check_orientation, int *const *assign, int *n_matches) {
+    FT_REQUIRE(tb && Tcw && n_frames > 0 && n_frames == tb->nFrames, "ft_tracked_batch_search_last_frame_se3: bad argument");
+    std::vector<FtPose> poses(n_frames), trls(n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        FT_REQUIRE(Trl || tb->DF[f].Nleft == -1, "ft_tracked_batch_search_last_frame_se3: a two-camera frame needs Trl");
+        int rc = poseOfSe3(&Tcw[f], poses[f]);
+        if (rc == FT_OK && Trl) rc = poseOfSe3(&Trl[f], trls[f]);
+        if (rc != FT_OK) return rc;
+    }
+    return batchSearchLastFrame(tb, n_frames, L, poses.data(), Trl ? trls.data() : nullptr, th, forward, backward, check_orientation,
+                                assign, n_matches);
+}
+
+int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const ft_frame_pose *poses, const ft_map_points *P,
+                                     float viewing_cos_limit, float log_scale_factor, float th, float nn_ratio, int far_points,
+                                     float th_far_points, const ft_frustum_result *frustum, int *n_to_match, int *const *assign,
+                                     int *n_matches) {
+    int rc = checkBatch(tb, n_frames, "ft_tracked_batch_track_local_map");
+    if (rc != FT_OK) return rc;
+    FT_REQUIRE(poses && P && assign, "ft_tracked_batch_track_local_map: null argument");
+    const int n = n_frames;
+    for (int f = 0; f < n; f++) {
+        rc = checkMapPoints(&P[f], true);
+        if (rc != FT_OK) return rc;
+        FT_REQUIRE(P[f].M <= tb->maxPts, "map point count beyond the batch's capacity");
+        FT_REQUIRE(assign[f], "ft_tracked_batch_track_local_map: null assign array");
+    }
+    ft_context *ctx = tb->ctx;
+    rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    FtTimer tAll;
+    hipStream_t st = ctx->stream;
+    Arena a;
+    const size_t oJobs = a.take((size_t)n * sizeof(FtBatchJob));
+    const size_t oRecs = a.take((size_t)(2 * n + 2) * sizeof(FtDeliverRec));
+    struct Lay {
+        FrustumLayout FL;
+        size_t fIn0, fInEnd, fOutEnd, desc, obs, outRes, outFr;
+    };
+    std::vector<Lay> lay(n);
+    Arena o;
+    const size_t oFlagsOut = o.take((size_t)n * 32 * sizeof(int));
+    const size_t oCountsOut = o.take((size_t)n * sizeof(int));
+    // inputs of all frames first (one H2D copy), then the frustum outputs (device only)
+    for (int f = 0; f < n; f++) {
+        const size_t M = (size_t)std::max(P[f].M, 1);
+        lay[f].desc = a.take(32 * M);
+        lay[f].obs = a.take(4 * M);
+    }
+    // (FrustumLayout interleaves a frame's inputs and outputs: the copy covers both, the outputs' share is ~40 %)
+    for (int f = 0; f < n; f++) {
+        lay[f].fIn0 = a.off;
+        layoutFrustum(P[f].M, P[f].skip != nullptr, a, lay[f].FL, &lay[f].fInEnd);
+        lay[f].fOutEnd = a.off;
+        lay[f].outRes = o.take(16 * (size_t)std::max(P[f].M, 1));
+        lay[f].outFr = o.take(lay[f].fOutEnd - lay[f].fInEnd);
+    }
+    FT_REQUIRE(a.off <= tb->workBytes && o.off <= tb->outBytes, "tracked batch work arena too small");
+    uint8_t *pin = tb->h_in, *dev = tb->d_arena + tb->oWork;
+    FtBatchJob *hJobs = (FtBatchJob *)(pin + oJobs);
+    FtDeliverRec *hRecs = (FtDeliverRec *)(pin + oRecs);
+    FT_HIP(hipStreamSynchronize(st));
+    const std::function<void(int, int)> stage = [&](int f, int) {
+        const ft_map_points &Q = P[f];
+        const size_t M = (size_t)Q.M;
+        const int N = tb->DF[f].N;
+        stageFrustum(&Q, lay[f].FL, pin);
+        if (M) {
+            memcpy(pin + lay[f].desc, Q.descriptors, 32 * M);
+            memcpy(pin + lay[f].obs, Q.observations, 4 * M);
+        }
+        FtBatchJob &J = hJobs[f];
+        memset(&J, 0, sizeof J);
+        J.F = tb->DF[f];
+        batchClaims(tb, f, N, N > 0 ? (int)M : 0, J);
+        J.obs = (const int *)(dev + lay[f].obs);
+        J.MP = devMapPoints(&Q, lay[f].FL, dev);
+        J.T = frustumPose_fromDev(J.F, &poses[f]);
+        J.O = devFrustumOut(lay[f].FL, dev);
+        J.O.count = (int *)(tb->d_arena + tb->oCounts) + f;
+        J.P.M = (int)M;
+        J.P.skip = J.O.searchSkip; J.P.inView = J.O.inView; J.P.inViewR = J.O.inViewR;
+        J.P.level = J.O.level; J.P.levelR = J.O.levelR;
+        J.P.viewCos = J.O.viewCos; J.P.viewCosR = J.O.viewCosR;
+        J.P.projX = J.O.projX; J.P.projY = J.O.projY; J.P.projXR = J.O.projXR; J.P.projYR = J.O.projYR;
+        J.P.desc = dev + lay[f].desc;
+        FtDeliverRec &R = hRecs[2 * f];
+        R.dst = tb->h_out + lay[f].outRes;
+        R.src[0] = J.res;
+        R.src[1] = J.res + 4 * (size_t)J.nPoints;
+        R.words = 4 * J.nPoints;
+        FtDeliverRec &R2 = hRecs[2 * f + 1];
+        R2.dst = tb->h_out + lay[f].outFr;
+        R2.src[0] = R2.src[1] = dev + lay[f].fInEnd;
+        R2.words = M ? (int)((lay[f].fOutEnd - lay[f].fInEnd) / 4) : 0;
+        for (int i = 0; i < N; i++) assign[f][i] = -1;
+    };
+    ctx->pool->parallel_for(n, stage);
+    int maxPoints = 0, maxM = 0, maxK = 8, maxFrWords = 0;
+    for (int f = 0; f < n; f++) {
+        maxPoints = std::max(maxPoints, hJobs[f].nPoints);
+        maxM = std::max(maxM, P[f].M);
+        if (hJobs[f].nPoints > 0) maxK = std::max(maxK, hJobs[f].K);
+        maxFrWords = std::max(maxFrWords, hRecs[2 * f + 1].words);
+    }
+    hRecs[2 * n].dst = tb->h_out + oFlagsOut;
+    hRecs[2 * n].src[0] = hRecs[2 * n].src[1] = tb->d_arena + tb->oFlags;
+    hRecs[2 * n].words = 32 * n;
+    hRecs[2 * n + 1].dst = tb->h_out + oCountsOut;
+    hRecs[2 * n + 1].src[0] = hRecs[2 * n + 1].src[1] = tb->d_arena + tb->oCounts;
+    hRecs[2 * n + 1].words = n;
+    FT_HIP(hipMemcpyAsync(dev, pin, a.off, hipMemcpyHostToDevice, st));
+    const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
+    const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
+    int parity = 0, passes = 0;
+    bool frustumDone = false;
+    rc = fixedPointBatch(
+        tb, st, dJobs, n, maxPoints, maxK,
+        [&](int pass, int fCur, int fPrev, int fReset) {
+            if (!frustumDone) {  // behind the fill of the claim iteration (which zeroes the counts), in front of the first pass
+                frustumDone = true;
+                const int r = ft_launch_frustum_batch(st, tb->d_arena, dJobs, n, maxM, viewing_cos_limit, log_scale_factor, far_points,
+                                                      th_far_points);
+                if (r != FT_OK) return r;
+            }
+            return ft_launch_search_local_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
+        },
+        [&](int par) {
+            if (!frustumDone) {  // no frame has keypoints: the frustum fields are still the call's result
+                frustumDone = true;
+                const int r = ft_launch_frustum_batch(st, tb->d_arena, dJobs, n, maxM, viewing_cos_limit, log_scale_factor, far_points,
+                                                      th_far_points);
+                if (r != FT_OK) return r;
+            }
+            return ft_launch_deliver_batch(st, dRecs, 2 * n + 2, std::max(std::max(4 * maxPoints, maxFrWords), 32 * n), par);
+        },
+        (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLocal);
+    if (rc != FT_OK) return rc;
+    const int *hCounts = (const int *)(tb->h_out + oCountsOut);
+    const std::function<void(int, int)> replay = [&](int f, int) {
+        const int M = P[f].M;
+        int nToMatch = 0;
+        if (M > 0) {
+            // unpackFrustum reads the count through the layout; the batch keeps the counts of all frames in one block
+            unpackFrustum(M, lay[f].FL, lay[f].fInEnd, tb->h_out + lay[f].outFr, frustum ? &frustum[f] : nullptr, nullptr);
+            nToMatch = hCounts[f];
+        }
+        if (n_to_match) n_to_match[f] = nToMatch;
+        const int nm = hJobs[f].nPoints > 0 ? replayLocalWrites((const int *)(tb->h_out + lay[f].outRes), M, P[f].observations,
+                                                                 tb->holder[f].data(), assign[f])
+                                            : 0;
+        if (n_matches) n_matches[f] = nm;
+    };
+    ctx->pool->parallel_for(n, replay);
+    rc = uploadBatchHolders(tb, st);
+    if (rc != FT_OK) return rc;
+    ctx->addStat("tracked_batch.track_local_map.total", tAll.ms());
+    ctx->addStat("tracked_batch.track_local_map.passes", passes);
+    ctx->addStat("tracked_batch.track_local_map.frames", n);
     return FT_OK;
 }
 

@@ -80,6 +80,12 @@ class Context:
             out.append((n.value.decode(), e.value.decode(), d.value, doc.value.decode()))
             i += 1
 
+    @staticmethod
+    def option_range(name: str):
+        lo, hi = C.c_int(), C.c_int()
+        check(lib().ft_option_range(name.encode(), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
     def synchronize(self):
         check(lib().ft_context_synchronize(self._h))
 
@@ -677,6 +683,121 @@ class TrackedFrame:
         r = {k: v[:M] for k, v in outs.items()}
         r.update(assign=assign[:self.N], n=n.value, n_to_match=nt.value)
         return r
+
+
+class TrackedBatch:
+    """B device-resident frames searched through one set of launches (ft_tracked_batch_*): per frame the results of
+    TrackedFrame's calls.  The marshalled inputs of a call (ctypes arrays of ft_last_points / ft_map_points) can be prepared
+    once with prepare_last / prepare_local and handed in again, so that a benchmark loop does not time Python."""
+
+    def __init__(self, ctx: Context, max_frames: int, max_keypoints: int, max_points: int):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        check(lib().ft_tracked_batch_create(ctx._h, max_frames, max_keypoints, max_points, C.byref(self._h)))
+        self.N = []
+
+    def close(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib().ft_tracked_batch_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, frames):
+        """frames: list of FrameView, or the (array, views) pair prepare_frames returned"""
+        arr, views = frames if isinstance(frames, tuple) else self.prepare_frames(frames)
+        check(lib().ft_tracked_batch_upload(self._h, len(views), arr))
+        self.N = [F.c.N for F in views]
+        self._assign = [np.zeros(max(n, 1), np.int32) for n in self.N]
+        self._assign_ptrs = (C.c_void_p * len(views))(*[ptr(a) for a in self._assign])
+        self._nm = np.zeros(len(views), np.int32)
+        self._nt = np.zeros(len(views), np.int32)
+
+    @staticmethod
+    def prepare_frames(views):
+        arr = (_capi.FrameView * len(views))(*[F.c for F in views])
+        return arr, list(views)
+
+    def holder_obs(self, f):
+        out = np.zeros(max(self.N[f], 1), np.int32)
+        check(lib().ft_tracked_batch_holder_obs(self._h, f, ptr(out)))
+        return out[:self.N[f]]
+
+    @staticmethod
+    def prepare_last(lasts, Tcws, forward=None, backward=None):
+        """lasts: list of dicts (TrackedFrame.search_last_frame's), Tcws: list of 3x4 matrices, or of SE3 (then Trl = list of SE3 or None)"""
+        n = len(lasts)
+        keep = []
+        arr = (_capi.LastPoints * n)()
+        for f, last in enumerate(lasts):
+            k = {key: np.ascontiguousarray(last[key], dt) for key, dt in
+                 (("valid", np.uint8), ("world_pos", np.float32), ("descriptors", np.uint8), ("observations", np.int32),
+                  ("octave", np.int32), ("angle", np.float32))}
+            keep.append(k)
+            arr[f].N = len(k["valid"])
+            for key in k:
+                setattr(arr[f], key, ptr(k[key]))
+        se3 = n > 0 and isinstance(Tcws[0], SE3)
+        if se3:
+            T = (_capi.SE3 * n)(*[t.c for t in Tcws])
+        else:
+            T = np.ascontiguousarray(np.stack([np.asarray(t, np.float32).reshape(3, 4) for t in Tcws]), np.float32)
+        fw = None if forward is None else np.ascontiguousarray(forward, np.int32)
+        bw = None if backward is None else np.ascontiguousarray(backward, np.int32)
+        return dict(n=n, arr=arr, keep=keep, T=T, se3=se3, fw=fw, bw=bw)
+
+    def search_last_frame(self, lasts, Tcws=None, th=7.0, forward=None, backward=None, check_orientation=True, Trl=None):
+        pl = lasts if isinstance(lasts, dict) and "arr" in lasts else self.prepare_last(lasts, Tcws, forward, backward)
+        n = pl["n"]
+        if pl["se3"]:
+            trl = None if Trl is None else (_capi.SE3 * n)(*[t.c for t in Trl])
+            check(lib().ft_tracked_batch_search_last_frame_se3(self._h, n, pl["arr"], pl["T"], trl, th, ptr(pl["fw"]), ptr(pl["bw"]),
+                                                               int(check_orientation), self._assign_ptrs, ptr(self._nm)))
+        else:
+            check(lib().ft_tracked_batch_search_last_frame(self._h, n, pl["arr"], ptr(pl["T"]), th, ptr(pl["fw"]), ptr(pl["bw"]),
+                                                           int(check_orientation), self._assign_ptrs, ptr(self._nm)))
+        return [dict(assign=self._assign[f][:self.N[f]].copy(), n=int(self._nm[f])) for f in range(n)]
+
+    @staticmethod
+    def prepare_local(poses, pts_list, want_frustum=True):
+        n = len(pts_list)
+        keep, outs = [], []
+        P = (_capi.MapPoints * n)()
+        R = (_capi.FrustumResult * n)() if want_frustum else None
+        for f, pts in enumerate(pts_list):
+            k = {}
+            Pf, M = _map_points(pts, k)
+            keep.append(k)
+            P[f] = Pf
+            if want_frustum:
+                Rf, o = _frustum_result(M)
+                R[f] = Rf
+                outs.append((M, o))
+        T = (_capi.FramePose * n)(*poses)
+        return dict(n=n, P=P, R=R, T=T, keep=keep, outs=outs)
+
+    def track_local_map(self, poses, pts_list=None, viewing_cos_limit=0.5, log_scale_factor=0.0, th=1.0, nn_ratio=0.8, far_points=False,
+                        th_far_points=0.0, copy=True):
+        pl = poses if isinstance(poses, dict) and "P" in poses else self.prepare_local(poses, pts_list)
+        n = pl["n"]
+        check(lib().ft_tracked_batch_track_local_map(self._h, n, pl["T"], pl["P"], viewing_cos_limit, log_scale_factor, th, nn_ratio,
+                                                     int(far_points), th_far_points, pl["R"], ptr(self._nt), self._assign_ptrs,
+                                                     ptr(self._nm)))
+        if not copy:
+            return None
+        res = []
+        for f in range(n):
+            r = {}
+            if pl["R"] is not None:
+                M, o = pl["outs"][f]
+                r = {k: v[:M].copy() for k, v in o.items()}
+            r.update(assign=self._assign[f][:self.N[f]].copy(), n=int(self._nm[f]), n_to_match=int(self._nt[f]))
+            res.append(r)
+        return res
 
 
 def fisheye_stereo(ctx: Context, cam1, cam2, Rlr, tlr, descL, keysL, descR, keysR, level_sigma2, precision=1e-6):

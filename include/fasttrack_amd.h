@@ -80,37 +80,32 @@ FT_API int ft_context_set_lane_map(ft_context *ctx, const int *map, int n);
 /* Tuning options.  Every switch of the library that is not a debugging aid is a named integer option of the CONTEXT.
  * ft_context_create reads the initial values from the environment, once (variable = "FT_" + upper-case name):
  *
- *   name                 default  meaning
- *   pipeline_depth       0        sub-batches a throughput batch is enqueued as (0 = automatic, 1 = no pipelining, <= 8)
- *   device_octree        1        DistributeOctTree on the device (0 = host thread pool)
- *   oct_hist             1        histogram tier of the device octree for levels above 4096 candidates
- *   oct_hist_first       1        histogram formulation for every level: 0 never, 1 latency-mode launches, 2 always
- *   oct_big              1        sorted big tier of the device octree (up to 16384 keys per level)
- *   oct_compact          1        first sorted tier in the compact LDS layout (49 instead of 64 KB per workgroup)
- *   oct_profile          0        per-level phase clocks of k_octree kept on the device
- *   oct_smem_pad         0        extra LDS bytes per k_octree workgroup (occupancy probe)
- *   fast_strips          0        FAST over 62-column strips instead of one wave per cell
- *   strip_rows           16       rows per strip of the strips form (8 .. 120)
- *   pyr_group            0        images per pyramid launch group (0 = the whole sub-batch per level)
- *   pyr_rows             1        pyramid of launches of 8+ images: 1 = one level per pass, 2 = two levels per pass, 0 = tile kernel
- *   upload_kernel        1        latency mode: frames go up through one kernel instead of DMA copies
- *   deliver_kernel       1        latency mode: one kernel writes all results into pinned host memory
- *   graph                1        latency mode: batches of <= 8 frames are captured and replayed as HIP graphs
- *   paired               1        latency-mode stereo front ends run both cameras through one set of launches
- *   pass_burst           12       projection searches, multi-launch path: claim passes per host round trip (2 .. 14)
- *   search_cache         1        projection searches: later claim passes walk the cached candidate keys
- *   search_grid          1        projection searches: CSR grid of the frame built on the device
- *   search_persistent    0        projection searches: all claim passes inside one launch with grid barriers (opt-in: slower)
- *   octree_paths, octree_hist_bins, octree_hist_strict   host test entry ft_octree_distribute only (read per call from the environment)
+ *   name                 default  range    meaning
+ *   pipeline_depth       0        0 .. 8   sub-batches a throughput batch is enqueued as (0 = automatic, 1 = no pipelining)
+ *   device_octree        1        0 .. 1   DistributeOctTree on the device (0 = host thread pool)
+ *   oct_hist             1        0 .. 1   histogram tier of the device octree for levels above 4096 candidates
+ *   oct_hist_first       1        0 .. 2   histogram formulation for every level: 0 never, 1 latency-mode launches, 2 always
+ *   oct_big              1        0 .. 1   sorted big tier of the device octree (up to 16384 keys per level)
+ *   pyr_rows             1        0 .. 1   pyramid of launches of 8+ images: 1 = row-streaming kernel, 0 = tile kernel
+ *   upload_kernel        1        0 .. 1   latency mode: frames go up through one kernel instead of DMA copies
+ *   graph                1        0 .. 1   latency mode: batches of <= 8 frames are captured and replayed as HIP graphs
+ *   paired               1        0 .. 1   latency-mode stereo front ends run both cameras through one set of launches
+ *   pass_burst           12       2 .. 14  projection searches: claim passes enqueued per host round trip
+ *   search_cache         1        0 .. 1   projection searches: later claim passes walk the cached candidate keys
+ *   search_grid          1        0 .. 1   projection searches: CSR grid of the frame built on the device
  *
+ * A value outside an option's range is FT_ERR_INVALID (from ft_context_set_option, and from ft_context_create when it comes
+ * from the environment).
  * ft_context_set_option changes the context's value; extractors, front ends and tracked frames take the switches of their
  * context when they are CREATED (the search_* and pass_burst options are read per call).  `name` is the option name or its
  * environment spelling.  ft_option_describe enumerates the table (index 0, 1, ... until FT_ERR_INVALID).
- * Only the FT_DEBUG_* aids (FT_DEBUG_REPEAT, FT_DEBUG_OCC, FT_DEBUG_FAST) and FT_LANE_MAP are read from the environment
- * anywhere else; none of them changes results. */
+ * Only the FT_DEBUG_* aids (FT_DEBUG_REPEAT, FT_DEBUG_OCC, FT_DEBUG_FAST, FT_DEBUG_OD_PROFILE, FT_DEBUG_OCT_PROFILE, and
+ * FT_DEBUG_OCTREE_PATHS / _HIST_BINS / _HIST_STRICT of the host test entry ft_octree_distribute) and FT_LANE_MAP are read from
+ * the environment anywhere else; none of them changes results. */
 FT_API int ft_context_set_option(ft_context *ctx, const char *name, int value);
 FT_API int ft_context_get_option(const ft_context *ctx, const char *name, int *value);
 FT_API int ft_option_describe(int index, const char **name, const char **env, int *default_value, const char **doc);
+FT_API int ft_option_range(const char *name, int *min_value, int *max_value);
 FT_API int ft_context_host_threads(const ft_context *ctx);
 /* per-stage wall/GPU timings of the calls made so far; the reference's REGISTER_STATS analogue
  * (include/Kernels/CudaUtils.h:14, src/Stats.cc:31-60).  Writes "<name>: <ms>" lines. */
@@ -467,6 +462,40 @@ FT_API int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame
                                             int *n_to_match, int *assign, int *n_matches);
 /* current holder_obs (size N of the resident frame) */
 FT_API int ft_tracked_frame_holder_obs(ft_tracked_frame *tf, int *holder_obs);
+
+/* ------------------------------------------------------------------------------------------------
+ * B device-resident frames per call ("Batch API (B frames per launch)").  The reference's tracking thread
+ * searches one frame at a time (Tracking::TrackWithMotionModel src/Tracking.cc:2911-2989, Tracking::SearchLocalPoints
+ * :3472-3555; one kernel launch per call: src/Kernels/SearchLocalPointsKernel.cu:351-435, PoseEstimationKernel.cu:350-371),
+ * which leaves a 256-CU device idle by construction.  A batch holds n_frames INDEPENDENT frames - the camera streams of one
+ * time step, or any frames whose inputs the caller holds - and runs every stage as ONE launch over all of them: the grid
+ * build, isInFrustum, and each pass of the two searches' in-call claiming (one workgroup row per frame, per-frame
+ * convergence; the batch runs as many passes as its slowest frame).  Per frame the results are those of the
+ * ft_tracked_frame_* call on that frame, bit for bit; the holder_obs of every frame carries over from one search to the next.
+ * Arrays indexed by frame: frames[], L[], Tcw (12 floats per frame), forward / backward (NULL = all 0), poses[], P[],
+ * frustum[] (NULL = not wanted), n_to_match[], assign[] (assign[f] has frames[f].N entries), n_matches[].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ft_tracked_batch ft_tracked_batch;
+FT_API int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, int max_points, ft_tracked_batch **out);
+FT_API int ft_tracked_batch_destroy(ft_tracked_batch *tb);
+/* ft_tracked_frame_upload for n_frames frames: one packed copy, all grids by one launch */
+FT_API int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_frame_view *frames);
+/* ft_tracked_frame_search_last_frame for every frame of the batch (n_frames = the number uploaded) */
+FT_API int ft_tracked_batch_search_last_frame(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const float *Tcw,
+                                              float th, const int *forward, const int *backward, int check_orientation,
+                                              int *const *assign, int *n_matches);
+/* the Sophus form of the poses (ft_search_last_frame_se3); Trl[] may be NULL when no frame has two cameras */
+FT_API int ft_tracked_batch_search_last_frame_se3(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const ft_se3 *Tcw,
+                                                  const ft_se3 *Trl, float th, const int *forward, const int *backward,
+                                                  int check_orientation, int *const *assign, int *n_matches);
+/* ft_tracked_frame_track_local_map for every frame of the batch */
+FT_API int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const ft_frame_pose *poses,
+                                            const ft_map_points *P, float viewing_cos_limit, float log_scale_factor, float th,
+                                            float nn_ratio, int far_points, float th_far_points,
+                                            const ft_frustum_result *frustum, int *n_to_match, int *const *assign,
+                                            int *n_matches);
+/* current holder_obs of frame `frame` (its N entries) */
+FT_API int ft_tracked_batch_holder_obs(ft_tracked_batch *tb, int frame, int *holder_obs);
 
 /* ORBmatcher::DescriptorDistance for n pairs on the device (src/ORBmatcher.cc:2256-2272,
  * device copy src/Kernels/CudaUtils.cu:42-56).  a, b: n x 32 host bytes; dist: n ints. */

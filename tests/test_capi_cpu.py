@@ -131,7 +131,7 @@ def test_path_code_octree_equals_oracle(mode):
     sorted path codes, 2 = the round formulation k_octree executes: array list + prefix sums, 3 = the same rounds over a
     histogram of the candidates per tree node instead of sorted keys, as k_octree_hist runs them - with up to 20 000
     candidates and clustered sets; a level that formulation gives up on goes to the sorted rounds, as on the device), executed
-    single-threaded on the host through ft_octree_distribute with FT_OCTREE_PATHS=<mode>, equal the oracle -
+    single-threaded on the host through ft_octree_distribute with FT_DEBUG_OCTREE_PATHS=<mode>, equal the oracle -
     in a fresh process because the switch is read once."""
     code = r'''
 import numpy as np, ctypes as C, sys, os
@@ -144,7 +144,7 @@ def octree(xys, a, b, c, d, N):
     assert L.ft_octree_distribute(_capi.ptr(xys), len(xys), a, b, c, d, N, _capi.ptr(out), len(out), C.byref(n)) == 0
     return out[:n.value].copy()
 rng = np.random.default_rng(5)
-MODE = os.environ["FT_OCTREE_PATHS"]
+MODE = os.environ["FT_DEBUG_OCTREE_PATHS"]
 for trial in range(300):
     W, H = int(rng.integers(40, 1300)), int(rng.integers(40, 720))
     if trial %% 7 == 0: W, H = int(rng.integers(300, 2000)), int(rng.integers(20, 60))  # many root nodes
@@ -159,7 +159,7 @@ for trial in range(300):
     assert np.array_equal(ob.distribute_octree(xys, 16, 16 + W, 16, 16 + H, N), octree(xys, 16, 16 + W, 16, 16 + H, N)), trial
 print("ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FT_OCTREE_PATHS=mode)
+    env = dict(os.environ, FT_DEBUG_OCTREE_PATHS=mode)
     out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
@@ -192,6 +192,22 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_option_out_of_range_in_the_environment_is_an_error():
+    """FT_<NAME> outside the option's range: ft_context_create reports FT_ERR_INVALID (before it looks for a device)"""
+    code = ("from fasttrack_amd import _capi; import ctypes as C\n"
+            "h = C.c_void_p(); rc = _capi.lib().ft_context_create(0, 1, C.byref(h))\n"
+            "print('rc', rc, _capi.lib().ft_last_error().decode())")
+    env = dict(os.environ, FT_PASS_BURST="99")
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert f"rc {_capi_const('FT_ERR_INVALID')}" in out.stdout and "FT_PASS_BURST=99 is outside [2, 14]" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+def _capi_const(name):
+    from fasttrack_amd import _capi
+    return getattr(_capi, name)
+
+
 def test_option_table_matches_the_header_documentation():
     """every tuning option of csrc/ft_host.h (FT_TUNING_OPTIONS, enumerated through ft_option_describe) is documented in
     include/fasttrack_amd.h with its default; its environment spelling is FT_ + upper-case name; and the library has ONE
@@ -199,16 +215,15 @@ def test_option_table_matches_the_header_documentation():
     import re
     from fasttrack_amd import _capi, orb
     table = orb.Context.option_table()
-    assert len(table) >= 20 and len({t[0] for t in table}) == len(table)
+    assert 8 <= len(table) <= 12 and len({t[0] for t in table}) == len(table)  # (variants that lost twice are deleted, not switched off)
     header = open(_capi.HEADER_PATH).read()
     for name, env, default, doc in table:
         assert env == "FT_" + name.upper() and doc
-        if name.startswith("octree_"):
-            assert name in header
-            continue
-        m = re.search(r"^ \*   %s\s+(-?\d+)\s" % re.escape(name), header, re.M)
+        m = re.search(r"^ \*   %s\s+(-?\d+)\s+(-?\d+) \.\. (-?\d+)\s" % re.escape(name), header, re.M)
         assert m, f"option {name} is not documented in fasttrack_amd.h"
-        assert int(m.group(1)) == default, (name, default)
+        lo, hi = orb.Context.option_range(name)
+        assert (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (default, lo, hi), (name, default, lo, hi)
+        assert lo <= default <= hi
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "fasttrack_amd", "csrc")
     n = sum(len(re.findall(r"\bgetenv\s*\(", open(os.path.join(csrc, f)).read())) for f in os.listdir(csrc)

@@ -1,0 +1,191 @@
+"""-m gpu: B frames per launch (ft_tracked_batch_*) - every frame of a batch equals the oracle running the reference's sequence on
+that frame (SearchByProjection(CurrentFrame, LastFrame), isInFrustum, SearchByProjection(Frame, local map points);
+src/ORBmatcher.cc:49-225,1775-1990, src/Frame.cc:536-610) and the single-frame path (ft_tracked_frame_*), bit for bit."""
+import numpy as np
+import pytest
+
+from fasttrack_amd import orb
+from oracle import binding as ob
+from tests import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+
+LOG_SF = float(np.float32(np.log(np.float32(1.2))))
+TRL = np.concatenate([np.eye(3), [[-0.101], [0.0], [0.0]]], 1).astype(np.float32)
+TLR = (0.101, 0.0, 0.0)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = orb.Context(0)
+    yield c
+    c.close()
+
+
+_cache = {}
+
+
+def _kb8_base(nf, seed):
+    """a two-camera KannalaBrandt8 frame (512x512, oracle extraction + fisheye match); cached per (nf, seed)"""
+    key = (nf, seed)
+    if key not in _cache:
+        _cache[key] = sc.fisheye_frame_scenario(512, 512, nf, seed)
+    return _cache[key]
+
+
+def _kb8_views(fr, sf, keep=None):
+    """oracle and device views of a base frame; keep = number of left / right keypoints kept (a smaller frame of the batch)"""
+    kL, kR, dL, dR, l2r, r2l = fr["kL"], fr["kR"], fr["dL"], fr["dR"], fr["l2r"], fr["r2l"]
+    if keep is not None:
+        nl, nr = keep
+        kL, kR, dL, dR = kL[:nl], kR[:nr], dL[:nl], dR[:nr]
+        l2r = np.where(l2r[:nl] < nr, l2r[:nl], -1).astype(np.int32)
+        r2l = np.where(r2l[:nr] < nl, r2l[:nr], -1).astype(np.int32)
+    kw = dict(keys=kL, keys_right=kR, descriptors=np.concatenate([dL, dR]), bounds=sc.frame_bounds(512, 512), left_to_right=l2r,
+              right_to_left=r2l, cam_model=1, cam=list(sc.KB8_CAM), Trl=TRL)
+    return ob.FrameView(scale_factors_=sf, **kw), orb.FrameView(scale_factors=sf, **kw), kL, dL
+
+
+def _kb8_inputs(kL, dL, sf, seed, M):
+    intr = dict(fx=sc.KB8_CAM[0], fy=sc.KB8_CAM[1], cx=sc.KB8_CAM[2], cy=sc.KB8_CAM[3])
+    depth = np.zeros(len(kL), np.float32)
+    last, Tcw = sc.last_frame_scenario(kL, dL, None, depth, intr, 512, 512, seed=seed)
+    pts, Rcw, tcw = sc.map_points_scenario(kL, dL, depth, intr, 8, sf, seed + 500, M=M)
+    return last, Tcw, pts, Rcw, tcw
+
+
+def _check_frame(tag, g1, g2, gh, o1, ofr, o2, oF):
+    assert g1["n"] == o1["n"] and np.array_equal(g1["assign"], o1["assign"]), f"{tag}: last-frame search"
+    for k, _ in ob.FRUSTUM_FIELDS:
+        assert np.array_equal(g2[k], ofr[k]), f"{tag}: frustum field {k}"
+    assert g2["n_to_match"] == ofr["n"], f"{tag}: nToMatch"
+    assert g2["n"] == o2["n"] and np.array_equal(g2["assign"], o2["assign"]), f"{tag}: local-map search"
+    assert np.array_equal(gh, oF.holder_obs), f"{tag}: holder_obs"
+
+
+@pytest.mark.parametrize("nf,th", [(2000, 7.0), (2000, 15.0), (1500, 7.0)])
+def test_tracked_batch_kb8_equals_oracle_and_single_frame(ctx, nf, th):
+    """B = 32 two-camera KannalaBrandt8 frames (BASELINE configs[3]: 512x512, nFeatures 2000) through one set of launches:
+    every frame's assignments, frustum fields, nToMatch and final holder_obs equal the oracle's sequence on that frame; four of
+    them are also run through ft_tracked_frame_* (the single-frame path) and compared.  The batch mixes frame sizes (frames
+    cut down to fewer keypoints), point counts (down to none) and poses."""
+    B, D = 32, 4
+    sf, _ = ob.scale_factors(1.2, 8)
+    bases = [_kb8_base(nf, 10 + k) for k in range(D)]
+    rng = np.random.default_rng(int(nf + th))
+    frames, lasts, Tcws, ptss, poses, oracle = [], [], [], [], [], []
+    for f in range(B):
+        fr = bases[f % D]
+        keep = None
+        if f % 7 == 3:
+            keep = (int(len(fr["kL"]) * rng.uniform(0.3, 0.9)), int(len(fr["kR"]) * rng.uniform(0.3, 0.9)))
+        oF, gF, kL, dL = _kb8_views(fr, sf, keep)
+        M = 0 if f == 5 else int(rng.integers(300, 2001))
+        last, Tcw, pts, Rcw, tcw = _kb8_inputs(kL, dL, sf, 1000 + f, max(M, 1))
+        if f == 5:   # a frame without last-frame points and without local map points
+            last = {k: v[:0] for k, v in last.items()}
+            pts = {k: v[:0] for k, v in pts.items()}
+        if f == 9:   # no valid last-frame point
+            last["valid"][:] = 0
+        o1 = ob.search_last_frame(oF, last, Tcw, th, False, False, True)
+        ofr = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, TLR), pts, 0.5, LOG_SF)
+        o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, pts), th)
+        frames.append(gF); lasts.append(last); Tcws.append(Tcw); ptss.append(pts)
+        poses.append(orb.make_pose(Rcw, tcw, TLR))
+        oracle.append((o1, ofr, o2, oF))
+    maxkp = max(F.c.N for F in frames) + 8
+    tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=maxkp, max_points=2048)
+    tb.upload(frames)
+    g1 = tb.search_last_frame(lasts, Tcws, th)
+    g2 = tb.track_local_map(poses, ptss, 0.5, LOG_SF, th)
+    nmatch = 0
+    for f in range(B):
+        o1, ofr, o2, oF = oracle[f]
+        _check_frame(f"frame {f}", g1[f], g2[f], tb.holder_obs(f), o1, ofr, o2, oF)
+        nmatch += o1["n"] + o2["n"]
+    assert nmatch > 200 * B
+    # the single-frame path on a few frames of the batch
+    tf = orb.TrackedFrame(ctx, max_keypoints=maxkp, max_points=2048)
+    for f in (0, 3, 5, 17):
+        _, gF, kL, dL = _kb8_views(bases[f % D], sf, None if f % 7 != 3 else (frames[f].c.Nleft, frames[f].c.N - frames[f].c.Nleft))
+        tf.upload(gF)
+        s1 = tf.search_last_frame(lasts[f], Tcws[f], th)
+        s2 = tf.track_local_map(poses[f], ptss[f], 0.5, LOG_SF, th)
+        assert s1["n"] == g1[f]["n"] and np.array_equal(s1["assign"], g1[f]["assign"])
+        assert s2["n"] == g2[f]["n"] and np.array_equal(s2["assign"], g2[f]["assign"]) and s2["n_to_match"] == g2[f]["n_to_match"]
+        assert np.array_equal(tf.holder_obs(), tb.holder_obs(f))
+    tf.close()
+    # a second batch through the same object (fewer frames), and the same batch again: identical results
+    tb.upload(frames[:5])
+    h1 = tb.search_last_frame(lasts[:5], Tcws[:5], th)
+    h2 = tb.track_local_map(poses[:5], ptss[:5], 0.5, LOG_SF, th)
+    for f in range(5):
+        assert np.array_equal(h1[f]["assign"], g1[f]["assign"]) and np.array_equal(h2[f]["assign"], g2[f]["assign"])
+    tb.close()
+
+
+def test_tracked_batch_mixed_camera_models_and_pose_forms(ctx):
+    """one batch holding rectified pinhole stereo frames (Nleft == -1, mvuRight test) and two-camera KB8 frames, searched with
+    far-point rejection; then the Sophus form of the poses (ft_tracked_batch_search_last_frame_se3) on the pinhole frames"""
+    w, h, nf = 752, 480, 1200
+    sf, _ = ob.scale_factors(1.2, 8)
+    frames, lasts, Tcws, ptss, poses, oracle = [], [], [], [], [], []
+    pin = []
+    th_far = 9.0   # one mThFarPoints for the call (a property of the tracker, not of the frame)
+    for f in range(6):
+        if f % 2 == 0:
+            fr = sc.oracle_stereo_frame(w, h, nf, 40 + f)
+            sm = ob.stereo_match(fr["exL"], fr["exR"], fr["kL"], fr["kR"], fr["dL"], fr["dR"], fr["intr"]["mbf"], fr["intr"]["mb"])
+            args = dict(keys=fr["kL"], descriptors=fr["dL"], bounds=sc.frame_bounds(w, h), mbf=fr["intr"]["mbf"], mb=fr["intr"]["mb"],
+                        uright=sm["uright"], cam=[fr["intr"][k] for k in ("fx", "fy", "cx", "cy")])
+            oF, gF = ob.FrameView(scale_factors_=sf, **args), orb.FrameView(scale_factors=sf, **args)
+            last, Tcw = sc.last_frame_scenario(fr["kL"], fr["dL"], sm["uright"], sm["depth"], fr["intr"], w, h, seed=60 + f)
+            pts, Rcw, tcw = sc.map_points_scenario(fr["kL"], fr["dL"], sm["depth"], fr["intr"], 8, sf, 70 + f)
+            tlr = (0, 0, 0)
+            pin.append((f, args, last))
+        else:
+            oF, gF, kL, dL = _kb8_views(_kb8_base(1500, 10), sf)
+            last, Tcw, pts, Rcw, tcw = _kb8_inputs(kL, dL, sf, 80 + f, 1500)
+            tlr = TLR
+        o1 = ob.search_last_frame(oF, last, Tcw, 15.0, False, False, True)
+        ofr = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, tlr), pts, 0.5, LOG_SF)
+        o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, pts, True, th_far), 3.0)
+        frames.append(gF); lasts.append(last); Tcws.append(Tcw); ptss.append(pts); poses.append(orb.make_pose(Rcw, tcw, tlr))
+        oracle.append((o1, ofr, o2, oF))
+    tb = orb.TrackedBatch(ctx, max_frames=8, max_keypoints=4096, max_points=4096)
+    tb.upload(frames)
+    g1 = tb.search_last_frame(lasts, Tcws, 15.0)
+    g2 = tb.track_local_map(poses, ptss, 0.5, LOG_SF, 3.0, far_points=True, th_far_points=th_far)
+    for f in range(6):
+        _check_frame(f"frame {f}", g1[f], g2[f], tb.holder_obs(f), *oracle[f])
+    # Sophus-form poses, forward / backward per frame
+    views, ls, Ts, fw, bw, oo = [], [], [], [], [], []
+    for j, (f, args, last) in enumerate(pin):
+        q, t = sc.random_se3(np.random.default_rng(90 + f), 0.03, 0.006)
+        oF, gF = ob.FrameView(scale_factors_=sf, **args), orb.FrameView(scale_factors=sf, **args)
+        fwd, bwd = j == 1, j == 2
+        oo.append(ob.search_last_frame(oF, last, ob.SE3(q, t), 15.0, fwd, bwd, True))
+        views.append(gF); ls.append(last); Ts.append(orb.SE3(q, t)); fw.append(int(fwd)); bw.append(int(bwd))
+    tb.upload(views)
+    g = tb.search_last_frame(ls, Ts, 15.0, forward=fw, backward=bw)
+    for j in range(len(pin)):
+        assert oo[j]["n"] > 50 and g[j]["n"] == oo[j]["n"] and np.array_equal(g[j]["assign"], oo[j]["assign"]), j
+    tb.close()
+
+
+def test_tracked_batch_argument_checks(ctx):
+    sf, _ = ob.scale_factors(1.2, 8)
+    _, gF, kL, dL = _kb8_views(_kb8_base(1500, 10), sf)
+    last, Tcw, pts, Rcw, tcw = _kb8_inputs(kL, dL, sf, 7, 100)
+    tb = orb.TrackedBatch(ctx, max_frames=2, max_keypoints=gF.c.N + 8, max_points=256)
+    with pytest.raises(Exception):
+        tb.upload([gF, gF, gF])            # more frames than the batch holds
+    tb.upload([gF, gF])
+    with pytest.raises(Exception):
+        tb.search_last_frame([last], [Tcw], 7.0)   # n_frames differs from the upload
+    big = {k: np.concatenate([v] * 3) for k, v in pts.items()}
+    with pytest.raises(Exception):
+        tb.track_local_map([orb.make_pose(Rcw, tcw, TLR)] * 2, [big, big], 0.5, LOG_SF, 7.0)   # beyond max_points
+    r = tb.track_local_map([orb.make_pose(Rcw, tcw, TLR)] * 2, [pts, pts], 0.5, LOG_SF, 7.0)
+    assert np.array_equal(r[0]["assign"], r[1]["assign"])
+    tb.close()

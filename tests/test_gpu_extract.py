@@ -93,25 +93,6 @@ def test_gaussian_blur_of_whole_levels_bit_exact(ctx, w, h):
             assert np.array_equal(ex.blurred_level(level), ob.gaussian_blur7(src)), f"blur of level {level}"
 
 
-@pytest.mark.parametrize("w,h,nf,rows", [(752, 480, 1200, 32), (1280, 720, 2000, 16), (333, 257, 500, 64), (97, 83, 200, 8)])
-def test_fast_strips_variant_bit_exact(ctx, w, h, nf, rows, monkeypatch):
-    """k_fast_strips (opt-in, option fast_strips=1 at creation): FAST over 62-column strips that ignore the cell grid, cell borders
-    applied as NMS masks, the per-cell threshold fallback in the compaction - same candidates, same keypoints"""
-    with ctx.options(fast_strips=1, strip_rows=rows):
-        ex = orb.ORBextractor(ctx, nf, 1.2, 8 if min(w, h) > 200 else 3, 20, 7, w, h, max_batch=3)
-    oex = ob.Extractor(nf, 1.2, ex.nlevels)
-    imgs = [synth.make_image(w, h, seed=31), synth.make_noise(w, h, seed=32), synth.make_image(w, h, seed=33, density=3.0)]
-    res = ex.extract_batch(imgs)
-    for b, img in enumerate(imgs):
-        ok, od, om = oex.extract(img)
-        _check_same(res[b][0], res[b][1], ok, od)
-    ex(imgs[0])
-    oex.extract(imgs[0])
-    for level in range(ex.nlevels):
-        gc, oc = ex.candidates(level), oex.candidates(level)
-        assert gc.shape == oc.shape and np.array_equal(gc, oc), f"FAST candidates level {level}"
-
-
 def test_equally_spaced_host_frames_go_up_as_one_copy(ctx):
     """host frames at a constant distance (a ring buffer / clip in one allocation, stride == width == slot pitch): the batch is
     uploaded by one strided copy; same results as the oracle, also with a gap between the frames and for a 3-frame batch
@@ -132,13 +113,12 @@ def test_equally_spaced_host_frames_go_up_as_one_copy(ctx):
 
 @pytest.mark.parametrize("w,h,sf,levels", [(333, 257, 1.2, 8), (1000, 96, 1.2, 2), (641, 479, 1.5, 5), (512, 512, 2.0, 4),
                                             (97, 83, 1.1, 6), (1279, 717, 1.25, 8), (406, 302, 2.4, 3), (300, 200, 3.0, 2)])
-@pytest.mark.parametrize("form", [2, 1], ids=["two-levels-per-pass", "one-level-per-pass"])
+@pytest.mark.parametrize("form", [1, 0], ids=["row-streaming", "tile-kernel"])
 def test_row_streaming_pyramid_bit_exact(ctx, w, h, sf, levels, form):
-    """launches of 8+ images build the pyramid with k_pyr_rows2 (two levels per pass: level l + 1 from the rows of level l the
-    wave keeps in LDS; strips overlapping by a column and a row) or k_pyr_rows (one level per pass; option pyr_rows = 1): a lane
-    owns two output columns, rows streamed top to bottom; every level of the first and the last image equals the oracle's
-    cv::resize chain - odd sizes, INTER_AREA at exactly 2.0, other scale factors (3.0 takes the tile kernel: its taps do not
-    fit the 8-byte window)"""
+    """launches of 8+ images build the pyramid with k_pyr_rows (option pyr_rows = 1, the default: a lane owns two output columns,
+    rows streamed top to bottom) or with the tile kernel k_pyr_down (pyr_rows = 0): every level of the first and the last
+    image equals the oracle's cv::resize chain - odd sizes, INTER_AREA at exactly 2.0, other scale factors (3.0 takes the
+    tile kernel either way: its taps do not fit the 8-byte window)"""
     nf = 300
     with ctx.options(pyr_rows=form):
         ex = orb.ORBextractor(ctx, nf, sf, levels, 20, 7, w, h, max_batch=9)

@@ -24,20 +24,6 @@ def _calls(ctx, name):
         return 0
 
 
-@pytest.fixture(params=[1, 0], ids=["one-launch", "launch-per-pass"])
-def search_form(ctx, request):
-    """the two forms of the claim iteration of the projection searches: a launch per pass driven by the host (default), or
-    every pass inside ONE persistent launch with grid barriers (option search_persistent=1; correct, but measured slower:
-    a barrier costs more than a launch boundary).  Read per call; the test asserts which one ran."""
-    ctx.set_option("search_persistent", request.param)
-    before = [_calls(ctx, "search.persistent_" + k) for k in ("launches", "timeouts", "fallbacks")]
-    yield request.param
-    after = [_calls(ctx, "search.persistent_" + k) for k in ("launches", "timeouts", "fallbacks")]
-    ctx.set_option("search_persistent", 0)
-    assert after[1] == before[1] and after[2] == before[2], "a persistent search timed out or hit its pass bound"
-    assert (after[0] > before[0]) == bool(request.param), "the requested form of the claim iteration did not run"
-
-
 def test_descriptor_distance(ctx):
     rng = np.random.default_rng(0)
     a = rng.integers(0, 256, (5000, 32), dtype=np.uint8)
@@ -358,7 +344,7 @@ def _frame_views(fr, sf, w, h, uright=None, holder=None):
 
 
 @pytest.mark.parametrize("th,dense", [(1.0, False), (3.0, False), (7.0, True), (15.0, True), (60.0, True)])
-def test_search_local_points_mono_stereo(ctx, th, dense, search_form):
+def test_search_local_points_mono_stereo(ctx, th, dense):
     """(th 60: windows with more candidates than the claim iteration's candidate cache holds per point - those points scan
     their window again in every pass, the others walk their cached keys)"""
     w, h, nf = 752, 480, 1200
@@ -378,7 +364,7 @@ def test_search_local_points_mono_stereo(ctx, th, dense, search_form):
         assert np.array_equal(g[k], o[k]), k
 
 
-def test_search_local_points_two_cameras(ctx, search_form):
+def test_search_local_points_two_cameras(ctx):
     w, h, nf = 512, 512, 1500
     fr = sc.fisheye_frame_scenario(w, h, nf, 9)
     sf, _ = ob.scale_factors(1.2, 8)
@@ -399,7 +385,7 @@ def test_search_local_points_two_cameras(ctx, search_form):
 
 @pytest.mark.parametrize("th,fwd,bwd,ori", [(7.0, False, False, True), (15.0, True, False, True), (15.0, False, True, False),
                                            (90.0, False, True, True)])
-def test_search_last_frame_pinhole(ctx, th, fwd, bwd, ori, search_form):
+def test_search_last_frame_pinhole(ctx, th, fwd, bwd, ori):
     w, h, nf = 752, 480, 1200
     fr = sc.oracle_stereo_frame(w, h, nf, 14)
     sf, _ = ob.scale_factors(1.2, 8)
@@ -414,7 +400,7 @@ def test_search_last_frame_pinhole(ctx, th, fwd, bwd, ori, search_form):
     assert np.array_equal(gF.holder_obs, oF.holder_obs)
 
 
-def test_search_last_frame_two_cameras_kb8(ctx, search_form):
+def test_search_last_frame_two_cameras_kb8(ctx):
     """fisheye stereo (config 4): KannalaBrandt8 projection (atan2f / cosf / sinf as glibc evaluates them, libm_f32.h),
     right-camera search through Trl: assignments, distances and indices equal the oracle's."""
     w, h, nf = 512, 512, 1500
@@ -446,7 +432,7 @@ def test_search_last_frame_two_cameras_kb8(ctx, search_form):
 
 
 @pytest.mark.parametrize("th,fwd,bwd,ori", [(7.0, False, False, True), (15.0, True, False, False), (30.0, False, True, True)])
-def test_search_last_frame_sophus_pose_form(ctx, th, fwd, bwd, ori, search_form):
+def test_search_last_frame_sophus_pose_form(ctx, th, fwd, bwd, ori):
     """the poses as Sophus::SE3f holds and applies them (ft_search_last_frame_se3): `Tcw * x3Dw` of the CPU branch
     (src/ORBmatcher.cc:1805) is a quaternion rotation, not a matrix product - device and oracle evaluate the same operations,
     one-shot and on a resident frame"""
@@ -473,7 +459,7 @@ def test_search_last_frame_sophus_pose_form(ctx, th, fwd, bwd, ori, search_form)
         orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, orb.SE3([0.5, 0, 0, 0.5], t), th)  # not a unit quaternion
 
 
-def test_search_last_frame_sophus_pose_form_two_cameras_kb8(ctx, search_form):
+def test_search_last_frame_sophus_pose_form_two_cameras_kb8(ctx):
     """two-camera KB8 frame: Tcw and GetRelativePoseTrl() both in the Sophus form"""
     w, h, nf = 512, 512, 1500
     fr = sc.fisheye_frame_scenario(w, h, nf, 11)
@@ -568,7 +554,7 @@ def _oracle_tracking_sequence(oF, last, Tcw_last, pts, Rcw, tcw, th_last, th_loc
 
 
 @pytest.mark.parametrize("far", [False, True])
-def test_tracked_frame_sequence_equals_oracle(ctx, far, search_form):
+def test_tracked_frame_sequence_equals_oracle(ctx, far):
     """ft_tracked_frame: upload once, then SearchByProjection(last frame) and isInFrustum + SearchByProjection(local
     map) on the resident frame - assignments, frustum fields and the final mvpMapPoints occupancy equal the oracle
     running the same sequence; the frustum outputs never visit the host between the two kernels."""

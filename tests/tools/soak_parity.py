@@ -52,11 +52,8 @@ def main():
         if min(w, h) / (sfac ** (nlevels - 1)) < 40:
             nlevels = max(1, int(np.log(min(w, h) / 40.0) / np.log(sfac)) + 1)
         dens = float(rng.choice([0.0, 0.1, 0.3, 1.0, 2.5, 6.0]))
-        strips = rng.random() < 0.25  # the strips form of FAST (read when the extractor is created)
         mosaic = int(rng.choice([0, 0, 0, 6, 9, 14]))  # dense mosaics: levels of 4 k .. 30 k candidates (second octree tier / repair)
-        cfg = dict(w=w, h=h, nf=nf, nlevels=nlevels, sfac=sfac, ini=ini, mn=mn, dens=dens, trial=trial, strips=strips, mosaic=mosaic)
-        os.environ["FT_FAST_STRIPS"] = "1" if strips else "0"
-        os.environ["FT_STRIP_ROWS"] = str(int(rng.choice([8, 16, 32, 48])))
+        cfg = dict(w=w, h=h, nf=nf, nlevels=nlevels, sfac=sfac, ini=ini, mn=mn, dens=dens, trial=trial, mosaic=mosaic)
         try:
             img = synth.make_image(w, h, seed=int(rng.integers(1 << 30)), density=dens)
             if mosaic:

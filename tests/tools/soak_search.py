@@ -75,8 +75,6 @@ def main():
             print(f"MISMATCH trial {trial} {tag}: {what}", flush=True)
 
     for t in range(args.trials):
-        # every third trial runs the claim iteration in its persistent one-launch form (option search_persistent; read per call)
-        ctx.set_option("search_persistent", 1 if t % 3 == 2 else 0)
         w, h = sizes[int(rng.integers(0, len(sizes)))]
         nf = int(rng.integers(300, 2001))
         seed = int(rng.integers(0, 1 << 30))
@@ -241,9 +239,7 @@ def main():
             return 0
     print(f"KannalaBrandt8, all bit-exact comparisons: {kb8_frustum_points} frustum points, {kb8_pairs} triangulated pairs; "
           f"{se3_searches} last-frame searches with Sophus-form poses")
-    print(f"{args.trials} trials, {searches} searches, {matched} matches, {fails} mismatches, {time.time() - t0:.0f} s; "
-          f"persistent launches {calls('search.persistent_launches')}, timeouts {calls('search.persistent_timeouts')}, "
-          f"fallbacks {calls('search.persistent_fallbacks')}")
+    print(f"{args.trials} trials, {searches} searches, {matched} matches, {fails} mismatches, {time.time() - t0:.0f} s")
     return 1 if fails else 0
 
 

@@ -1,6 +1,6 @@
-"""Phase times of the device octree kernel (FT_OCT_PROFILE=1): one 16-pair batch of the bench workload."""
+"""Phase times of the device octree kernel (FT_DEBUG_OCT_PROFILE=1): one 16-pair batch of the bench workload."""
 import os, sys
-os.environ["FT_OCT_PROFILE"] = "1"
+os.environ["FT_DEBUG_OCT_PROFILE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fasttrack_amd import orb, synth
