@@ -341,6 +341,119 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
     return out
 
 
+def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.0)):
+    """BASELINE.json configs[3] as a THROUGHPUT workload: B independent 512x512 KannalaBrandt8 stereo frames per step (the
+    frames B camera streams deliver for one time step), every stage ONE launch over all of them (ft_tracked_batch_*):
+      extraction of the B left and the B right images, frames resident in HBM, lapping areas [0, 511]      (ft_extract_batch x 2)
+      keypoints into the reference's order + left <-> right matching of the lapping subsets + grids, on the device,
+      from what the extractors left in HBM                                                                   (ft_tracked_batch_bind_fisheye)
+      SearchByProjection(CurrentFrame, LastFrame, th)                                                       (ft_tracked_batch_search_last_frame)
+      isInFrustum + SearchByProjection(CurrentFrame, local map points, th)                                   (ft_tracked_batch_track_local_map)
+    Host in / out per step: the map points of every frame up (pageable host arrays), keypoints, descriptors, match tables'
+    consumers (assign, n_matches, frustum fields) down.  Every frame of the batch is a distinct image pair with its own
+    last-frame points, local map (M points) and poses, built once from the frame's own keypoints (untimed)."""
+    import ctypes as C
+    from fasttrack_amd import scenarios as sc
+    w, h, nf = 512, 512, 2000
+    lap = (0, 511)
+    cam = list(sc.KB8_CAM)
+    intr = dict(fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+    Trl = np.concatenate([np.eye(3), [[-0.101], [0.0], [0.0]]], 1).astype(np.float32)
+    TLR = (0.101, 0.0, 0.0)
+    LOG_SF = float(np.float32(np.log(np.float32(SCALE))))
+    exL = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=B)
+    exR = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=B)
+    sf = np.asarray(exL.GetScaleFactors(), np.float32)
+    cap = exL.max_keypoints
+    pairs = [synth.make_planes_pair(w, h, seed=7000 + i) for i in range(B)]
+    devL, devR = ctx.to_device(np.stack([p[0] for p in pairs])), ctx.to_device(np.stack([p[1] for p in pairs]))
+    fb = w * h
+    pL = (C.c_void_p * B)(*[devL.ptr.value + b * fb for b in range(B)])
+    pR = (C.c_void_p * B)(*[devR.ptr.value + b * fb for b in range(B)])
+    kL, kR = np.zeros((B, cap), orb.KP_DTYPE), np.zeros((B, cap), orb.KP_DTYPE)
+    dL, dR = np.zeros((B, cap, 32), np.uint8), np.zeros((B, cap, 32), np.uint8)
+    nL, nR, mL, mR = (np.zeros(B, np.int32) for _ in range(4))
+    tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=2 * cap + 64, max_points=max(M, cap) + 64)
+
+    import concurrent.futures
+    two = concurrent.futures.ThreadPoolExecutor(2)
+
+    def extract():
+        # the two cameras on two host threads, as Frame's constructor runs them (src/Frame.cc:1144-1147)
+        a = two.submit(exL.extract_batch_into, pL, B, True, w, h, w, lap, kL, dL, nL, mL)
+        b = two.submit(exR.extract_batch_into, pR, B, True, w, h, w, lap, kR, dR, nR, mR)
+        a.result()
+        b.result()
+    extract()
+    # the frame views of the batch: constants + the host copies of the keypoints (extraction is deterministic: the counts and
+    # the arrays the views point to are the same in every step)
+    views = [orb.FrameView(keys=kL[f, :nL[f]], keys_right=kR[f, :nR[f]], descriptors=np.zeros((int(nL[f] + nR[f]), 32), np.uint8),
+                           scale_factors=sf, bounds=sc.frame_bounds(w, h), left_to_right=np.zeros(max(int(nL[f]), 1), np.int32),
+                           right_to_left=np.zeros(max(int(nR[f]), 1), np.int32), cam_model=1, cam=cam, Trl=Trl) for f in range(B)]
+    meta = tb.prepare_frames(views)
+    counts = (nL.copy(), nR.copy())
+    scen = []
+    for f in range(B):
+        depth = np.zeros(int(nL[f]), np.float32)
+        last, Tcw_last = sc.last_frame_scenario(kL[f, :nL[f]], dL[f, :nL[f]], None, depth, intr, w, h, seed=40 + f)
+        pts, Rcw, tcw = sc.map_points_scenario(kL[f, :nL[f]], dL[f, :nL[f]], depth, intr, NLEVELS, sf, 90 + f, M=M)
+        scen.append((last, Tcw_last, pts, Rcw, tcw))
+    pl_last = tb.prepare_last([s_[0] for s_ in scen], [s_[1] for s_ in scen])
+    pl_local = tb.prepare_local([orb.make_pose(s_[3], s_[4], TLR) for s_ in scen], [s_[2] for s_ in scen])
+    part = {"extract_left_right": 0.0, "bind_fisheye (order, match, grids)": 0.0, "search_last_frame": 0.0, "track_local_map": 0.0}
+
+    def step(th):
+        t0 = time.perf_counter()
+        extract()
+        t1 = time.perf_counter()
+        tb.bind_fisheye(exL, exR, meta, lap, lap, want_tables=False)
+        t2 = time.perf_counter()
+        tb.search_last_frame(pl_last, th=th, copy=False)
+        t3 = time.perf_counter()
+        tb.track_local_map(pl_local, viewing_cos_limit=0.5, log_scale_factor=LOG_SF, th=th, copy=False)
+        t4 = time.perf_counter()
+        for k_, v_ in zip(part, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+            part[k_] += v_
+    out = {"metric": "frames/sec extract + SearchByProjection (last frame, local map), B frames per launch", "unit": "frames/s",
+           "batch_frames": B, "distinct_frames": B, "image": [w, h], "nfeatures": nf, "local_map_points": M,
+           "inputs": "images resident in HBM before the timed region; map points in pageable host memory, uploaded inside it",
+           "outputs": "keypoints, descriptors, assignments, match counts, frustum fields in host memory", "by_th": {}}
+    for th in ths:
+        for _ in range(max(warmup, 1)):
+            step(th)
+        assert np.array_equal(nL, counts[0]) and np.array_equal(nR, counts[1])
+        ctx.synchronize()
+        ctx.reset_stats()
+        for k_ in part:
+            part[k_] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(th)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        stats = {}
+        for nm_ in ("tracked_batch.search_last_frame.passes", "tracked_batch.track_local_map.passes"):
+            tot_, n_ = ctx.get_stat(nm_)
+            stats[nm_ + "_per_call"] = tot_ / n_ if n_ else None
+        nmatch = int(tb._nm.sum())
+        out["by_th"][str(int(th))] = {"value": B * steps / dt, "ms_per_step": 1e3 * dt / steps, "us_per_frame": 1e6 * dt / (B * steps),
+                                      "map_points_per_s": (int(nL.sum()) + B * M) * steps / dt,
+                                      "local_map_matches_per_frame": nmatch / B,
+                                      "ms_per_step_by_part": {k_: 1e3 * v_ / steps for k_, v_ in part.items()},
+                                      "inside_the_library": stats,
+                                      "launches_per_frame": None}
+    out["value"] = out["by_th"][str(int(ths[0]))]["value"]
+    out["keypoints_per_frame"] = float(nL.sum() + nR.sum()) / B
+    out["_scen"] = scen
+    out["_views"] = (kL, kR, dL, dR, nL, nR)
+    tb.close()
+    exL.close()
+    exR.close()
+    devL.free()
+    devR.free()
+    return out
+
+
 def count_compares(orb, ctx, F, sf, scen, b, th, cam, Trl):
     """DescriptorDistance calls of the two searches of one frame = keypoints GetFeaturesInArea returns for every searched point:
     last frame (ORBmatcher.cc:1830-1846, 1905-1915: radius th * sf[octave], levels [octave - 1, octave + 1], left and right

@@ -710,12 +710,14 @@ int ft_extract_download(ft_extractor *ex, int b0, int nb, hipStream_t st) {
 static int assembleOutputs(ft_extractor *ex, int batch, int lap0, int lap1, ft_keypoint *keypoints,
                            uint8_t *descriptors, int capacity, int *n_keypoints, int *n_mono) {
     const FtGeom &g = ex->geom;
-    for (int b = 0; b < batch; b++) {
-        const int n = ex->h_nSel[b];
-        if (n > capacity) {
+    for (int b = 0; b < batch; b++)
+        if (ex->h_nSel[b] > capacity) {
             ft_set_error("extract: output capacity too small (use ft_extractor_max_keypoints)");
             return FT_ERR_CAPACITY;
         }
+    // (a wide batch is 10+ MB of keypoints and descriptors: one image per host thread of the context)
+    const std::function<void(int, int)> one = [&](int b, int) {
+        const int n = ex->h_nSel[b];
         const ft_keypoint *src = ex->h_keys + (size_t)b * g.maxKp;
         const uint8_t *sd = ex->h_desc + (size_t)b * g.maxKp * 32;
         ft_keypoint *dk = keypoints ? keypoints + (size_t)b * capacity : nullptr;
@@ -731,7 +733,10 @@ static int assembleOutputs(ft_extractor *ex, int batch, int lap0, int lap1, ft_k
         }
         if (n_keypoints) n_keypoints[b] = n;
         if (n_mono) n_mono[b] = monoIndex;
-    }
+    };
+    if (batch >= 16) ex->ctx->pool->parallel_for(batch, one);
+    else
+        for (int b = 0; b < batch; b++) one(b, 0);
     return FT_OK;
 }
 

@@ -119,10 +119,12 @@ struct FtFrustumOut {
 // One frame of a batch of searches (ft_tracked_batch, search.cpp): what the batch kernels read of frame blockIdx.y, resident
 // in HBM.  Every pointer of a job points into the device arena of its batch (`arena` of the launchers below: the kernels
 // re-derive the pointers from it, see Rebase in kernels_search.hip).  The rotating buffers of the claim iteration are addressed by pass number (job_claims, kernels_search.hip):
-// res 2 x 4 nPoints | head 3 x K | next 2 x 4 nPoints | tab 3 x 8 K (K = keypoints rounded up to 8) | flags 32.
+// res 2 x 4 nPoints | head 3 x K | next 2 x 4 nPoints | tab 3 x 8 K (K = keypoints rounded up to 8) | flags FT_BATCH_FLAGS.
+#define FT_BATCH_FLAGS 64  // flag words per frame of a batch: two burst parities x 32 positions (a power of two)
 struct FtBatchJob {
     FtDevFrame F;
     int *res, *head, *next, *tab, *flags;
+    int *slow;                  // [0], [1]: lengths of the slow lists of even / odd passes, then 2 x nPoints entries from word 16
     const int *obs;             // Observations() per point of the running search
     unsigned long long *cache;  // FT_CACHE_WORDS per point, or null
     int K, nKp, nPoints;
@@ -143,6 +145,18 @@ struct FtDeliverRec {
     const void *src[2];
     int words;
 };
+// what two extractors left in HBM (slot slot0 + f = left / right image of frame f of the batch), the lapping areas, and the
+// per-frame (monoLeft, monoRight) counts the gather leaves for the matching
+struct FtBindArgs {
+    const ft_keypoint *keysL, *keysR;
+    const uint8_t *descL, *descR;
+    int strideL, strideR;  // keypoints per slot
+    int slot0;
+    int lapL0, lapL1, lapR0, lapR1;
+    int *mono;  // [nFrames][2], device
+};
+// keypoints / descriptors of every frame into the reference's order, then the 2-NN + ratio matching of the lapping subsets
+int ft_launch_bind_fisheye_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxKp, const FtBindArgs &A);
 int ft_launch_fill_claims_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxWords);
 int ft_launch_deliver_batch(hipStream_t st, const FtDeliverRec *recs, int nRecs, int maxWords, int parity);
 int ft_launch_build_grid_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxLevels, bool twoCam);
@@ -153,6 +167,11 @@ int ft_launch_search_last_batch(hipStream_t st, void *arena, const FtBatchJob *j
                                 int fReset, float th);
 int ft_launch_search_local_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur, int fPrev,
                                  int fReset, float th, float nnRatio);
+// a pass behind the first one: lean kernel (four points per wave from the candidate cache) + the general kernel on its slow list
+int ft_launch_search_last_batch_lean(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur,
+                                     int fPrev, int fReset, float th);
+int ft_launch_search_local_batch_lean(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur,
+                                      int fPrev, int fReset, float th, float nnRatio);
 int ft_launch_fill_i32(hipStream_t st, int *p, int n, int v);
 // p[0 .. n) = -1 and meta[i * strideWords] = ~0 for i < nMeta (meta may be null): the start of a claim iteration, one launch
 int ft_launch_fill_claims(hipStream_t st, int *p, int n, unsigned long long *meta, int nMeta, int strideWords);

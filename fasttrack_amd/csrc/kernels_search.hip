@@ -124,7 +124,7 @@ __device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) {
         // batch form, first pass of a later burst: the frame had converged before this burst began.  Its flag words of this
         // burst's parity still hold what an earlier burst left there ("changed" for the passes it ran then): they all read
         // "unchanged" from here on, so that every later pass of the burst returns here as well.
-        if (C.flagStick && blockIdx.x == 0 && threadIdx.x < 16) shared_store(C.flagStick + threadIdx.x, -1);
+        if (C.flagStick && blockIdx.x == 0 && threadIdx.x < FT_BATCH_FLAGS / 2) shared_store(C.flagStick + threadIdx.x, -1);
         return false;
     }
     const int t = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
@@ -948,43 +948,54 @@ __device__ __forceinline__ FtClaims job_claims(const FtBatchJob &J, const Rebase
     C.flagCur = flags + fCur;
     C.flagPrev = fPrev >= 0 ? flags + fPrev : nullptr;
     C.flagReset = flags + fReset;
-    C.flagStick = (fPrev >= 0 && (fPrev >> 4) != (fCur >> 4)) ? flags + (fCur & ~15) : nullptr;
+    C.flagStick = (fPrev >= 0 && (fPrev / (FT_BATCH_FLAGS / 2)) != (fCur / (FT_BATCH_FLAGS / 2))) ? flags + (fCur & ~(FT_BATCH_FLAGS / 2 - 1)) : nullptr;
     C.cache = rb(J.cache);
     res = resB + (size_t)(pass & 1) * R;
     return C;
 }
 
+// slowList != 0: a later pass - the points the lean kernel (k_search_*_lean, below) could not serve from the candidate cache, by
+// a grid-stride loop over the frame's slow list of this pass's parity; the pass's clears were done by the lean kernel
 __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur,
-                                                                          int fPrev, int fReset, float th) {
+                                                                          int fPrev, int fReset, float th, int slowList) {
     const FtBatchJob &J = jobs[blockIdx.y];
     if (J.nPoints <= 0) return;
     int *res;
     const FtClaims C = job_claims(J, rb, pass, fCur, fPrev, fReset, res);
-    if (!claims_begin_pass(C)) return;
     const int lane = threadIdx.x & 63, wave = wave_index();
-    const int i = blockIdx.x * FT_SEARCH_WPB + wave;
-    if (i >= J.L.N) return;
     __shared__ int cacheCounter[FT_SEARCH_WPB];
-    int r4[4];
     const FtLastRaw raw = {nullptr, nullptr, nullptr, nullptr};
     FtDevLastPoints L = J.L;
     L.valid = rb(L.valid); L.worldPos = rb(L.worldPos); L.desc = rb(L.desc); L.octave = rb(L.octave);
-    last_point(J.F, frame_ptrs(J.F, rb), L, C, J.Tcw, th, J.forward, J.backward, i, lane, r4, raw, &cacheCounter[wave]);
-    claims_file(C, res, i, lane, r4);
+    const FramePtrs Q = frame_ptrs(J.F, rb);
+    if (!slowList) {
+        if (!claims_begin_pass(C)) return;
+        const int i = blockIdx.x * FT_SEARCH_WPB + wave;
+        if (i >= J.L.N) return;
+        int r4[4];
+        last_point(J.F, Q, L, C, J.Tcw, th, J.forward, J.backward, i, lane, r4, raw, &cacheCounter[wave]);
+        claims_file(C, res, i, lane, r4);
+        return;
+    }
+    if (C.flagPrev && shared_load(C.flagPrev) == -1) return;
+    const int *slow = rb(J.slow);
+    const int count = slow[pass & 1];
+    for (int k = blockIdx.x * FT_SEARCH_WPB + wave; k < count; k += gridDim.x * FT_SEARCH_WPB) {
+        const int i = slow[16 + (size_t)(pass & 1) * J.nPoints + k];
+        int r4[4];
+        last_point(J.F, Q, L, C, J.Tcw, th, J.forward, J.backward, i, lane, r4, raw, &cacheCounter[wave]);
+        claims_file(C, res, i, lane, r4);
+    }
 }
 
 __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_local_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur,
-                                                                           int fPrev, int fReset, float th, float nnRatio) {
+                                                                           int fPrev, int fReset, float th, float nnRatio, int slowList) {
     const FtBatchJob &J = jobs[blockIdx.y];
     if (J.nPoints <= 0) return;
     int *res;
     const FtClaims C = job_claims(J, rb, pass, fCur, fPrev, fReset, res);
-    if (!claims_begin_pass(C)) return;
     const int lane = threadIdx.x & 63, wave = wave_index();
-    const int i = blockIdx.x * FT_SEARCH_WPB + wave;
-    if (i >= J.P.M) return;
     __shared__ int cacheCounter[FT_SEARCH_WPB];
-    int r4[4];
     FtLocalRaw raw;
     raw.bestDist = nullptr;
     FtDevLocalPoints P = J.P;
@@ -993,8 +1004,198 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_local_batch(const
     P.viewCos = rb(P.viewCos); P.viewCosR = rb(P.viewCosR);
     P.projX = rb(P.projX); P.projY = rb(P.projY); P.projXR = rb(P.projXR); P.projYR = rb(P.projYR);
     P.desc = rb(P.desc);
-    local_point(J.F, frame_ptrs(J.F, rb), P, C, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
-    claims_file(C, res, i, lane, r4);
+    const FramePtrs Q = frame_ptrs(J.F, rb);
+    if (!slowList) {
+        if (!claims_begin_pass(C)) return;
+        const int i = blockIdx.x * FT_SEARCH_WPB + wave;
+        if (i >= J.P.M) return;
+        int r4[4];
+        local_point(J.F, Q, P, C, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
+        claims_file(C, res, i, lane, r4);
+        return;
+    }
+    if (C.flagPrev && shared_load(C.flagPrev) == -1) return;
+    const int *slow = rb(J.slow);
+    const int count = slow[pass & 1];
+    for (int k = blockIdx.x * FT_SEARCH_WPB + wave; k < count; k += gridDim.x * FT_SEARCH_WPB) {
+        const int i = slow[16 + (size_t)(pass & 1) * J.nPoints + k];
+        int r4[4];
+        local_point(J.F, Q, P, C, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
+        claims_file(C, res, i, lane, r4);
+    }
+}
+
+// ---- later passes of a batch: the lean kernels --------------------------------------------------------------------------------
+// From the second pass on nearly every point finds its candidates in the cache the first pass filed, and its turn is a
+// handful of loads: the cached keys, the 32-byte writer records of their keypoints, a minimum.  The general kernels above
+// spend a whole wave (and ~90 registers, 30 KB of code) on it.  Here a point is a ROW of 16 lanes - four points per wave, the
+// keys 16 at a time, the two smallest by DPP steps that never leave the row - and a point the cache cannot serve (a camera's
+// candidates not filed yet: the right block is reached for the first time; more candidates than the cache holds) is handed
+// to the general kernel through the frame's slow list (launched behind this one with slowList = 1).  Same reads of the
+// previous pass's records, same keys, same comparisons: the results are those of the general kernel.
+__device__ __forceinline__ void row_two_min(unsigned long long &k0, unsigned long long &k1) {
+    const unsigned long long m0 = row_min_u64(k0);
+    const unsigned long long cand = (k0 == m0) ? k1 : k0;
+    k1 = row_min_u64(cand);
+    k0 = m0;
+}
+// claims_file for the point of a row: lane `sub` (0 .. 3) of the row files write kind sub
+__device__ __forceinline__ void claims_file_row(const FtClaims &C, int *res, int i, int sub, const int r4[4]) {
+    if (sub < 4) {
+        const int kp = sub == 0 ? r4[0] : sub == 1 ? r4[1] : sub == 2 ? r4[2] : r4[3];
+        const int s = 4 * i + sub;
+        const int prev = shared_load(&C.resPrev[s]);
+        if (kp != prev) atomicAnd(C.flagCur, 0);
+        shared_store(&res[s], kp);
+        if (kp >= 0) {
+            const int e = (s << 1) | (C.obs[i] > 0 ? 1 : 0);
+            int *rec = C.tabWrite + 8 * (size_t)kp;
+            const int pos = atomicAdd(rec, 1) + 1;
+            if (pos < FT_TAB_ENTRIES) shared_store(rec + 1 + pos, e);
+            else shared_store(&C.nextWrite[s], atomicExch(&C.headWrite[kp], e));
+        }
+    }
+}
+__device__ __forceinline__ void slow_append(int *slow, int pass, int nPoints, int i) {
+    const int pos = atomicAdd(&slow[pass & 1], 1);
+    slow[16 + (size_t)(pass & 1) * nPoints + pos] = i;
+}
+#define FT_LEAN_PPB 16  // points per workgroup of the lean kernels: 4 waves x 4 rows
+
+__global__ __launch_bounds__(256) void k_search_local_lean(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur, int fPrev,
+                                                           int fReset, float nnRatio) {
+    const FtBatchJob &J = jobs[blockIdx.y];
+    if (J.nPoints <= 0) return;
+    int *res;
+    const FtClaims C = job_claims(J, rb, pass, fCur, fPrev, fReset, res);
+    if (!claims_begin_pass(C)) return;
+    int *slow = rb(J.slow);
+    if (blockIdx.x == 0 && threadIdx.x == 0) slow[(pass + 1) & 1] = 0;  // the next pass's list starts empty
+    const int sub = threadIdx.x & 15;
+    const int i = blockIdx.x * FT_LEAN_PPB + (threadIdx.x >> 4);
+    if (i >= J.P.M) return;
+    const FtDevFrame &F = J.F;
+    const bool twoCam = F.Nleft != -1;
+    const uint8_t *skipP = rb(J.P.skip), *inViewP = rb(J.P.inView), *inViewRP = rb(J.P.inViewR);
+    const int *levelRP = rb(J.P.levelR);
+    const unsigned long long *slotL = C.cache + (size_t)i * FT_CACHE_WORDS, *slotR = slotL + (FT_CACHE_CAP + 1);
+    const uint8_t skipV = skipP[i], inViewV = inViewP[i], inViewRV = twoCam ? inViewRP[i] : (uint8_t)0;
+    const int levelRV = twoCam ? levelRP[i] : -1;
+    const unsigned long long metaL = slotL[0], metaR = twoCam ? slotR[0] : KEY_NONE;
+    const int obsI = C.obs[i];
+    int primL = -1, sideL = -1, primR = -1, sideR = -1;
+    bool skipRight = false, slowPoint = false;
+    if (!skipV) {
+        if (inViewV) {
+            int nCached;
+            bool anyBox;
+            if (cache_state_of(metaL, nCached, anyBox) != 1) slowPoint = true;
+            else {
+                unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
+                for (int t = sub; t < nCached; t += 16) {
+                    const unsigned long long key = slotL[1 + t];
+                    if (is_locked(C, key_idx(key), i, key_held(key))) continue;
+                    two_min_insert(k0, k1, key);
+                }
+                row_two_min(k0, k1);
+                int bd = 256, bd2 = 256, bl = -1, bl2 = -1, bi = -1;
+                if (k0 != KEY_NONE) { bd = key_dist(k0); bi = key_idx(k0); bl = key_octave(k0); }
+                if (k1 != KEY_NONE) { bd2 = key_dist(k1); bl2 = key_octave(k1); }
+                if (bd <= FT_TH_HIGH) {
+                    if (bl == bl2 && (float)bd > __fmul_rn(nnRatio, (float)bd2)) skipRight = true;
+                    else {
+                        primL = bi;
+                        if (twoCam) {
+                            const int m = rb(F.l2r)[bi];
+                            if (m != -1) sideL = m + F.Nleft;
+                        }
+                    }
+                }
+            }
+        }
+        if (!slowPoint && twoCam && inViewRV && !skipRight && levelRV != -1) {
+            int nCached;
+            bool anyBox;
+            if (cache_state_of(metaR, nCached, anyBox) != 1) slowPoint = true;
+            else {
+                unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
+                for (int t = sub; t < nCached; t += 16) {
+                    const unsigned long long key = slotR[1 + t];
+                    const int g = key_idx(key) + F.Nleft;
+                    const bool locked = (g == sideL) ? (obsI > 0) : is_locked(C, g, i, key_held(key));
+                    if (locked) continue;
+                    two_min_insert(k0, k1, key);
+                }
+                row_two_min(k0, k1);
+                int bdr = 256, bd2r = 256, blr = -1, bl2r = -1, bir = -1;
+                if (k0 != KEY_NONE) { bdr = key_dist(k0); bir = key_idx(k0); blr = key_octave(k0); }
+                if (k1 != KEY_NONE) { bd2r = key_dist(k1); bl2r = key_octave(k1); }
+                if (bdr <= FT_TH_HIGH && !(blr == bl2r && (float)bdr > __fmul_rn(nnRatio, (float)bd2r))) {
+                    const int m = rb(F.r2l)[bir];
+                    if (m != -1) sideR = m;
+                    primR = bir + F.Nleft;
+                }
+            }
+        }
+    }
+    if (slowPoint) {
+        if (sub == 0) slow_append(slow, pass, J.nPoints, i);
+        return;
+    }
+    const int r4[4] = {primL, sideL, primR, sideR};
+    claims_file_row(C, res, i, sub, r4);
+}
+
+__global__ __launch_bounds__(256) void k_search_last_lean(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur, int fPrev,
+                                                          int fReset) {
+    const FtBatchJob &J = jobs[blockIdx.y];
+    if (J.nPoints <= 0) return;
+    int *res;
+    const FtClaims C = job_claims(J, rb, pass, fCur, fPrev, fReset, res);
+    if (!claims_begin_pass(C)) return;
+    int *slow = rb(J.slow);
+    if (blockIdx.x == 0 && threadIdx.x == 0) slow[(pass + 1) & 1] = 0;
+    const int sub = threadIdx.x & 15;
+    const int i = blockIdx.x * FT_LEAN_PPB + (threadIdx.x >> 4);
+    if (i >= J.L.N) return;
+    const FtDevFrame &F = J.F;
+    const bool twoCam = F.Nleft != -1;
+    const unsigned long long *slotL = C.cache + (size_t)i * FT_CACHE_WORDS, *slotR = slotL + (FT_CACHE_CAP + 1);
+    const uint8_t validV = rb(J.L.valid)[i];
+    const unsigned long long metaL = slotL[0], metaR = twoCam ? slotR[0] : KEY_NONE;
+    int primL = -1, primR = -1;
+    if (validV) {
+        int nCachedL = 0, nCachedR = 0;
+        bool anyBoxL = false, anyBoxR = false;
+        bool fromCache = false;
+        if (cache_state_of(metaL, nCachedL, anyBoxL) == 1) fromCache = !twoCam || !anyBoxL || cache_state_of(metaR, nCachedR, anyBoxR) == 1;
+        if (!fromCache) {
+            if (sub == 0) slow_append(slow, pass, J.nPoints, i);
+            return;
+        }
+        unsigned long long k0 = KEY_NONE;
+        for (int t = sub; t < nCachedL; t += 16) {
+            const unsigned long long key = slotL[1 + t];
+            if (is_locked(C, key_idx(key), i, key_held(key))) continue;
+            k0 = key < k0 ? key : k0;
+        }
+        k0 = row_min_u64(k0);
+        if (anyBoxL) {
+            if (k0 != KEY_NONE && key_dist(k0) <= FT_TH_HIGH) primL = key_idx(k0);
+            if (twoCam) {
+                unsigned long long kr = KEY_NONE;
+                for (int t = sub; t < nCachedR; t += 16) {
+                    const unsigned long long key = slotR[1 + t];
+                    if (is_locked(C, key_idx(key) + F.Nleft, i, key_held(key))) continue;
+                    kr = key < kr ? key : kr;
+                }
+                kr = row_min_u64(kr);
+                if (kr != KEY_NONE && key_dist(kr) <= FT_TH_HIGH) primR = key_idx(kr) + F.Nleft;
+            }
+        }
+    }
+    const int r4[4] = {primL, -1, primR, -1};
+    claims_file_row(C, res, i, sub, r4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1140,20 +1341,125 @@ __global__ __launch_bounds__(256) void k_fill_i32(int *p, int n, int v) {
 }
 
 // start of the claim iteration of every frame of a batch (blockIdx.y = frame): list heads and writer table = -1 (27 K words
-// behind J.head: layoutBatch, search.cpp), the frame's 32 flag words = -1, the cache's meta words = ~0, the frustum count = 0
+// behind J.head: layoutBatch, search.cpp), the frame's FT_BATCH_FLAGS flag words = -1, the cache's meta words = ~0, the frustum count = 0
 __global__ __launch_bounds__(256) void k_fill_claims_batch(const FtBatchJob *__restrict__ jobs, Rebase rb) {
     const FtBatchJob &J = jobs[blockIdx.y];
     const int t = blockIdx.x * 256 + threadIdx.x, T = gridDim.x * 256;
     int *count = rb(J.O.count);
     if (t == 0 && count) *count = 0;
     int *head = rb(J.head), *flags = rb(J.flags);
-    if (t < 32) flags[t] = -1;  // (also of a frame without points: "converged" is what the host reads there)
+    if (t < FT_BATCH_FLAGS) flags[t] = -1;  // (also of a frame without points: "converged" is what the host reads there)
     if (J.nPoints <= 0) return;
+    int *slow = rb(J.slow);
+    if (t < 16) slow[t] = 0;
     unsigned long long *cache = rb(J.cache);
     const int words = 27 * J.K;
     for (int i = t; i < words; i += T) head[i] = -1;
     if (cache)
         for (int i = t; i < 2 * J.nPoints; i += T) cache[(size_t)i * (FT_CACHE_CAP + 1)] = ~0ull;
+}
+
+// ---- two-camera frames of a batch straight from what two extractors left in HBM (ft_tracked_batch_bind_fisheye) ----
+// Step 1, workgroup (camera, frame): the keypoints and descriptors of the extractor's slot into the frame's arrays in the
+// REFERENCE's order - ORBextractor::operator() fills keypoints inside the lapping area from the back and the others from the
+// front (src/ORBextractor.cc:1466-1487; assembleOutputs, extractor.cpp, does the same for the host copies) - a stable
+// partition by ranks from ballots; also: the camera's match table = -1, and the number of keypoints outside the lapping
+// area (monoLeft / monoRight, src/Frame.cc:1144-1147) for step 2.
+__global__ __launch_bounds__(256) void k_lap_gather_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, FtBindArgs A) {
+    const int cam = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FtDevFrame &F = jobs[f].F;
+    const int slot = A.slot0 + f;
+    const int n = cam == 0 ? F.Nleft : F.N - F.Nleft;
+    const ft_keypoint *src = (cam == 0 ? A.keysL : A.keysR) + (size_t)slot * (cam == 0 ? A.strideL : A.strideR);
+    const uint4 *srcD = (const uint4 *)((cam == 0 ? A.descL : A.descR) + (size_t)slot * (cam == 0 ? A.strideL : A.strideR) * 32);
+    ft_keypoint *dst = (ft_keypoint *)rb(cam == 0 ? F.keys : F.keysR);
+    uint4 *dstD = (uint4 *)(rb((uint8_t *)F.desc) + (cam == 0 ? 0 : (size_t)F.Nleft * 32));
+    int *tab = (int *)rb(cam == 0 ? F.l2r : F.r2l);
+    const float lap0 = (float)(cam == 0 ? A.lapL0 : A.lapR0), lap1 = (float)(cam == 0 ? A.lapL1 : A.lapR1);
+    __shared__ int wLap[4];
+    int lapBefore = 0;  // lapping-area keypoints in front of this chunk
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        ft_keypoint kp;
+        bool inLap = false;
+        if (i < n) {
+            kp = src[i];
+            inLap = kp.x >= lap0 && kp.x <= lap1;
+        }
+        const unsigned long long b = __ballot(inLap);
+        if (lane == 0) wLap[wave] = __popcll(b);
+        __syncthreads();
+        int before = lapBefore;
+        for (int w = 0; w < wave; w++) before += wLap[w];
+        const int chunkLap = wLap[0] + wLap[1] + wLap[2] + wLap[3];
+        __syncthreads();
+        if (i < n) {
+            const int rankLap = before + __popcll(b & ((1ull << lane) - 1ull));
+            const int d = inLap ? n - 1 - rankLap : i - rankLap;
+            dst[d] = kp;
+            dstD[2 * (size_t)d] = srcD[2 * (size_t)i];
+            dstD[2 * (size_t)d + 1] = srcD[2 * (size_t)i + 1];
+            tab[i] = -1;
+        }
+        lapBefore += chunkLap;
+    }
+    if (tid == 0) A.mono[2 * f + cam] = n - lapBefore;
+}
+
+// Step 2: the matching part of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1231-1255; the seam of the reference's
+// launchFisheyeStereoMatchKernel, include/Kernels/KernelController.h:38) for every frame of the batch: BFMatcher(NORM_HAMMING)
+// .knnMatch(k = 2) of the left lapping subset [monoLeft, Nleft) against the right one + Lowe's ratio 0.7, written as
+// mvLeftToRightMatch / mvRightToLeftMatch (a right keypoint matched by several left ones keeps the last = largest index, as the
+// reference's loop does).  A wave takes FE_Q queries: a lane holds one train descriptor of the current 64 in registers and
+// meets the queries through LDS broadcasts, so a train descriptor is fetched once per FE_Q queries (the one-query-per-wave
+// form of k_fisheye_2nn reads the whole train set per query: 128 MB of L2 traffic per 2000 x 2000 frame); keys
+// (distance << 20 | train index), two smallest per lane and query, one wave reduction per query at the end.
+#define FE_Q 16
+__global__ __launch_bounds__(256) void k_fisheye_2nn_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, const int *__restrict__ mono) {
+    const int f = blockIdx.y, lane = threadIdx.x & 63, wave = wave_index();
+    const FtDevFrame &F = jobs[f].F;
+    const int monoL = mono[2 * f], monoR = mono[2 * f + 1];
+    const int nQ = F.Nleft - monoL, nT = (F.N - F.Nleft) - monoR;
+    const int q0 = (blockIdx.x * 4 + wave) * FE_Q;
+    if (q0 >= nQ) return;
+    const uint8_t *desc = rb(F.desc);
+    const uint4 *qd = (const uint4 *)(desc + (size_t)(monoL + q0) * 32);
+    const uint4 *td = (const uint4 *)(desc + (size_t)(F.Nleft + monoR) * 32);
+    __shared__ uint4 qs[4][FE_Q * 2];
+    const int nq = min(FE_Q, nQ - q0);
+    if (lane < 2 * nq) qs[wave][lane] = qd[lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned k0[FE_Q], k1[FE_Q];
+#pragma unroll
+    for (int q = 0; q < FE_Q; q++) k0[q] = k1[q] = 0xffffffffu;
+    for (int j = lane; j < nT; j += 64) {
+        const uint4 a = td[2 * (size_t)j], b = td[2 * (size_t)j + 1];
+#pragma unroll
+        for (int q = 0; q < FE_Q; q++) {
+            const uint4 x = qs[wave][2 * q], y = qs[wave][2 * q + 1];  // (same address in every lane: a broadcast)
+            const unsigned d = __popc(a.x ^ x.x) + __popc(a.y ^ x.y) + __popc(a.z ^ x.z) + __popc(a.w ^ x.w) + __popc(b.x ^ y.x) +
+                               __popc(b.y ^ y.y) + __popc(b.z ^ y.z) + __popc(b.w ^ y.w);
+            const unsigned key = (d << 20) | (unsigned)j;
+            k1[q] = min(k1[q], max(k0[q], key));
+            k0[q] = min(k0[q], key);
+        }
+    }
+    int *l2r = (int *)rb(F.l2r), *r2l = (int *)rb(F.r2l);
+#pragma unroll
+    for (int q = 0; q < FE_Q; q++) {
+        const unsigned m0 = wave_min_u32(k0[q]);
+        const unsigned cand = (k0[q] == m0) ? k1[q] : k0[q];
+        const unsigned m1 = wave_min_u32(cand);
+        if (lane == 0 && q < nq) {
+            const int d0 = (int)(m0 >> 20), d1 = (int)(m1 >> 20);
+            if (nT >= 2 && (double)(float)d0 < (double)(float)d1 * 0.7) {
+                const int t = monoR + (int)(m0 & 0xfffffu), qi = monoL + q0 + q;
+                l2r[qi] = t;
+                atomicMax(&r2l[t], qi);
+            }
+        }
+    }
 }
 
 // Result delivery of a batch: record r (blockIdx.y) = one block of dwords written into pinned host memory; src[parity] lets a
@@ -1250,6 +1556,7 @@ int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPo
 
 // ---- launches of a batch of frames (ft_tracked_batch, search.cpp) ----
 int ft_launch_fill_claims_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxWords);
+#define FT_SLOW_BLOCKS 16  // workgroups per frame of a slow-list launch (a grid-stride loop serves longer lists)
 static Rebase rebase_of(void *arena) { return Rebase{(uint8_t *)arena, (unsigned long long)(uintptr_t)arena}; }
 
 int ft_launch_build_grid_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxLevels, bool twoCam) {
@@ -1272,7 +1579,18 @@ int ft_launch_search_last_batch(hipStream_t st, void *arena, const FtBatchJob *j
                                 int fReset, float th) {
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
     hipLaunchKernelGGL(k_search_last_batch, dim3((maxPoints + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st,
-                       jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th);
+                       jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th, 0);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+// a later pass: the lean kernel for the points the candidate cache serves, the general kernel for its slow list
+int ft_launch_search_last_batch_lean(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur,
+                                     int fPrev, int fReset, float th) {
+    if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_search_last_lean, dim3((maxPoints + FT_LEAN_PPB - 1) / FT_LEAN_PPB, nFrames), dim3(256), 0, st, jobs,
+                       rebase_of(arena), pass, fCur, fPrev, fReset);
+    hipLaunchKernelGGL(k_search_last_batch, dim3(FT_SLOW_BLOCKS, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st, jobs, rebase_of(arena), pass, fCur,
+                       fPrev, fReset, th, 1);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
@@ -1281,7 +1599,17 @@ int ft_launch_search_local_batch(hipStream_t st, void *arena, const FtBatchJob *
                                  int fReset, float th, float nnRatio) {
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
     hipLaunchKernelGGL(k_search_local_batch, dim3((maxPoints + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB, nFrames), dim3(64 * FT_SEARCH_WPB), 0,
-                       st, jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th, nnRatio);
+                       st, jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th, nnRatio, 0);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+int ft_launch_search_local_batch_lean(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur,
+                                      int fPrev, int fReset, float th, float nnRatio) {
+    if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_search_local_lean, dim3((maxPoints + FT_LEAN_PPB - 1) / FT_LEAN_PPB, nFrames), dim3(256), 0, st, jobs,
+                       rebase_of(arena), pass, fCur, fPrev, fReset, nnRatio);
+    hipLaunchKernelGGL(k_search_local_batch, dim3(FT_SLOW_BLOCKS, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st, jobs, rebase_of(arena), pass,
+                       fCur, fPrev, fReset, th, nnRatio, 1);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
@@ -1297,6 +1625,15 @@ int ft_launch_fill_claims_batch(hipStream_t st, void *arena, const FtBatchJob *j
 int ft_launch_deliver_batch(hipStream_t st, const FtDeliverRec *recs, int nRecs, int maxWords, int parity) {
     if (nRecs <= 0 || maxWords <= 0) return FT_OK;
     hipLaunchKernelGGL(k_deliver_batch, dim3(std::max(1, std::min(16, (maxWords + 1023) / 1024)), nRecs), dim3(256), 0, st, recs, parity);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_bind_fisheye_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxKp, const FtBindArgs &A) {
+    if (nFrames <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_lap_gather_batch, dim3(2, nFrames), dim3(256), 0, st, jobs, rebase_of(arena), A);
+    hipLaunchKernelGGL(k_fisheye_2nn_batch, dim3((maxKp + 4 * FE_Q - 1) / (4 * FE_Q), nFrames), dim3(256), 0, st, jobs, rebase_of(arena),
+                       (const int *)A.mono);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

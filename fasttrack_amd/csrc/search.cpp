@@ -1193,7 +1193,7 @@ namespace {
 
 size_t batchClaimBytes(int maxKp, int maxPts) {
     const size_t K = passK(maxKp);
-    return ((32 * (size_t)maxPts + 63) & ~(size_t)63) * 2 + ((4 * 27 * K + 63) & ~(size_t)63);
+    return ((32 * (size_t)maxPts + 63) & ~(size_t)63) * 2 + ((4 * 27 * K + 63) & ~(size_t)63) + 4 * (16 + 2 * (size_t)maxPts) + 64;
 }
 // bytes of one frame's arrays in the frames region, upper bound
 size_t batchFrameBytes(int maxKp) {
@@ -1213,27 +1213,30 @@ void batchClaims(const ft_tracked_batch *tb, int f, int nKp, int nPoints, FtBatc
     J.head = (int *)(c + 2 * resBytes);
     J.K = (int)passK(nKp);
     J.tab = J.head + 3 * (size_t)J.K;
-    J.flags = (int *)(tb->d_arena + tb->oFlags) + 32 * (size_t)f;
+    J.slow = (int *)(c + 2 * resBytes + ((4 * 27 * passK(tb->maxKp) + 63) & ~(size_t)63));
+    J.flags = (int *)(tb->d_arena + tb->oFlags) + FT_BATCH_FLAGS * (size_t)f;
     J.cache = tb->oCache ? (unsigned long long *)(tb->d_arena + tb->oCache + (size_t)f * tb->cacheStride) : nullptr;
     J.nKp = nKp;
     J.nPoints = nPoints;
 }
 
 // The claim iteration of every frame of the batch (see fixedPoint): bursts of passes, one launch per pass for ALL frames, one
-// delivery + one synchronisation per burst.  launchPass(pass, fCur, fPrev, fReset); deliver(parity) writes every frame's
-// results of that parity and all flag words into tb->h_out (flags at hostFlags[32 f ...]).
+// delivery + one synchronisation per burst.  launchPass(pass, fCur, fPrev, fReset); deliver(parity, burst) writes every frame's
+// results of that parity and all flag words into tb->h_out (flags at hostFlags[FT_BATCH_FLAGS f ...]).  A batch has 32 flag
+// positions per burst parity: bursts of up to 30 passes (the slowest of many frames needs more passes than one frame does).
 template <typename PassFn, typename DeliverFn>
 int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJobs, int n, int maxPoints, int maxK, PassFn launchPass,
                     DeliverFn deliver, const int *hostFlags, int *parityFinal, int *passes, int *burstHint) {
     ft_context *ctx = tb->ctx;
-    const int burstMax = passBurst(ctx);
-    int len = burstHint && *burstHint > 0 ? std::min(std::max(*burstHint + 1, 4), FT_PASS_BURST_MAX) : burstMax;
+    const int half = FT_BATCH_FLAGS / 2, lenMax = half - 2;
+    const int burstMax = std::min(passBurst(ctx) + 4, lenMax);
+    int len = burstHint && *burstHint > 0 ? std::min(std::max(*burstHint + 1, 4), lenMax) : burstMax;
     *parityFinal = 0;
     *passes = 0;
     int rc = ft_launch_fill_claims_batch(st, tb->d_arena, dJobs, n, 27 * maxK);
     if (rc != FT_OK) return rc;
     if (maxPoints <= 0) {
-        rc = deliver(0);
+        rc = deliver(0, 0);
         if (rc != FT_OK) return rc;
         FT_HIP(hipStreamSynchronize(st));
         return FT_OK;
@@ -1241,20 +1244,20 @@ int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJob
     const int maxPasses = 2 * maxPoints + 4 + burstMax;
     int pass = 0, prevLen = 0, parity = 0;
     for (int burst = 0;; burst++) {
-        const int base = 16 * (burst & 1), other = 16 * ((burst + 1) & 1);
+        const int base = half * (burst & 1), other = half * ((burst + 1) & 1);
         for (int b = 0; b < len; b++, pass++) {
             const int fPrev = b > 0 ? base + b - 1 : (burst > 0 ? other + prevLen - 1 : -1);
             rc = launchPass(pass, base + b, fPrev, other + b);
             if (rc != FT_OK) return rc;
             parity = pass & 1;
         }
-        rc = deliver(parity);
+        rc = deliver(parity, burst);
         if (rc != FT_OK) return rc;
         FT_HIP(hipStreamSynchronize(st));
         bool all = true;
         int ranMax = 0;
         for (int f = 0; f < n; f++) {
-            const int *h = hostFlags + 32 * (size_t)f + base;
+            const int *h = hostFlags + FT_BATCH_FLAGS * (size_t)f + base;
             if (h[len - 1] != -1) all = false;
             int ran = 0;
             while (ran < len && h[ran] != -1) ran++;
@@ -1269,8 +1272,8 @@ int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJob
             return FT_ERR_HIP;
         }
         prevLen = len;
-        if (burstHint) len = std::min(len, 4);  // the hint fell short: short bursts from here (never longer than the one before:
-                                                // the flag words beyond a burst's length are not reset by the next one)
+        len = std::min(len, 6);  // the first burst fell short: short bursts from here (never longer than the one before: the
+                                 // flag words beyond a burst's length are not reset by the next one)
     }
     *parityFinal = parity;
     *passes = pass;
@@ -1320,7 +1323,7 @@ int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, 
     tb->oWork = a.take(tb->workBytes);
     tb->framesBytes = (B * batchFrameBytes(max_keypoints) + 4095) & ~(size_t)4095;
     tb->oFrames = a.take(tb->framesBytes);
-    tb->oFlags = a.take(B * 32 * sizeof(int));
+    tb->oFlags = a.take(B * FT_BATCH_FLAGS * sizeof(int));
     tb->oCounts = a.take(B * sizeof(int));
     tb->gridStride = (gridBytes(max_keypoints) + 255) & ~(size_t)255;
     tb->oGrid = a.take(B * tb->gridStride);
@@ -1331,7 +1334,7 @@ int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, 
         tb->oCache = a.take(B * tb->cacheStride);
     }
     tb->arenaBytes = a.off;
-    tb->outBytes = B * batchOutBytes(max_points) + B * 32 * sizeof(int) + 4096;
+    tb->outBytes = B * batchOutBytes(max_points) + B * FT_BATCH_FLAGS * sizeof(int) + 4096;
     hipError_t e = hipMalloc((void **)&tb->d_arena, tb->arenaBytes);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_in, tb->workBytes + tb->framesBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_out, tb->outBytes, hipHostMallocDefault);
@@ -1495,7 +1498,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     };
     std::vector<Lay> lay(n);
     Arena o;  // results in tb->h_out
-    const size_t oFlagsOut = o.take((size_t)n * 32 * sizeof(int));
+    const size_t oFlagsOut = o.take((size_t)n * FT_BATCH_FLAGS * sizeof(int));
     int maxPoints = 0, maxK = 8;
     for (int f = 0; f < n; f++) {
         const size_t M = (size_t)std::max(L[f].N, 1);
@@ -1550,7 +1553,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     }
     hRecs[n].dst = tb->h_out + oFlagsOut;
     hRecs[n].src[0] = hRecs[n].src[1] = tb->d_arena + tb->oFlags;
-    hRecs[n].words = 32 * n;
+    hRecs[n].words = FT_BATCH_FLAGS * n;
     FT_HIP(hipMemcpyAsync(dev, pin, a.off, hipMemcpyHostToDevice, st));
     const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
     const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
@@ -1558,9 +1561,11 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     rc = fixedPointBatch(
         tb, st, dJobs, n, maxPoints, maxK,
         [&](int pass, int fCur, int fPrev, int fReset) {
+            if (pass > 0 && tb->oCache)
+                return ft_launch_search_last_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
             return ft_launch_search_last_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
         },
-        [&](int par) { return ft_launch_deliver_batch(st, dRecs, n + 1, std::max(4 * maxPoints, 32 * n), par); },
+        [&](int par, int) { return ft_launch_deliver_batch(st, dRecs, n + 1, std::max(4 * maxPoints, FT_BATCH_FLAGS * n), par); },
         (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLast);
     if (rc != FT_OK) return rc;
     const std::function<void(int, int)> replay = [&](int f, int) {
@@ -1635,7 +1640,7 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
     };
     std::vector<Lay> lay(n);
     Arena o;
-    const size_t oFlagsOut = o.take((size_t)n * 32 * sizeof(int));
+    const size_t oFlagsOut = o.take((size_t)n * FT_BATCH_FLAGS * sizeof(int));
     const size_t oCountsOut = o.take((size_t)n * sizeof(int));
     // inputs of all frames first (one H2D copy), then the frustum outputs (device only)
     for (int f = 0; f < n; f++) {
@@ -1680,12 +1685,12 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
         J.P.viewCos = J.O.viewCos; J.P.viewCosR = J.O.viewCosR;
         J.P.projX = J.O.projX; J.P.projY = J.O.projY; J.P.projXR = J.O.projXR; J.P.projYR = J.O.projYR;
         J.P.desc = dev + lay[f].desc;
-        FtDeliverRec &R = hRecs[2 * f];
+        FtDeliverRec &R = hRecs[f];
         R.dst = tb->h_out + lay[f].outRes;
         R.src[0] = J.res;
         R.src[1] = J.res + 4 * (size_t)J.nPoints;
         R.words = 4 * J.nPoints;
-        FtDeliverRec &R2 = hRecs[2 * f + 1];
+        FtDeliverRec &R2 = hRecs[n + 2 + f];  // (the frustum fields do not change from burst to burst: delivered with the first one)
         R2.dst = tb->h_out + lay[f].outFr;
         R2.src[0] = R2.src[1] = dev + lay[f].fInEnd;
         R2.words = M ? (int)((lay[f].fOutEnd - lay[f].fInEnd) / 4) : 0;
@@ -1697,14 +1702,14 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
         maxPoints = std::max(maxPoints, hJobs[f].nPoints);
         maxM = std::max(maxM, P[f].M);
         if (hJobs[f].nPoints > 0) maxK = std::max(maxK, hJobs[f].K);
-        maxFrWords = std::max(maxFrWords, hRecs[2 * f + 1].words);
+        maxFrWords = std::max(maxFrWords, hRecs[n + 2 + f].words);
     }
-    hRecs[2 * n].dst = tb->h_out + oFlagsOut;
-    hRecs[2 * n].src[0] = hRecs[2 * n].src[1] = tb->d_arena + tb->oFlags;
-    hRecs[2 * n].words = 32 * n;
-    hRecs[2 * n + 1].dst = tb->h_out + oCountsOut;
-    hRecs[2 * n + 1].src[0] = hRecs[2 * n + 1].src[1] = tb->d_arena + tb->oCounts;
-    hRecs[2 * n + 1].words = n;
+    hRecs[n].dst = tb->h_out + oFlagsOut;
+    hRecs[n].src[0] = hRecs[n].src[1] = tb->d_arena + tb->oFlags;
+    hRecs[n].words = FT_BATCH_FLAGS * n;
+    hRecs[n + 1].dst = tb->h_out + oCountsOut;
+    hRecs[n + 1].src[0] = hRecs[n + 1].src[1] = tb->d_arena + tb->oCounts;
+    hRecs[n + 1].words = n;
     FT_HIP(hipMemcpyAsync(dev, pin, a.off, hipMemcpyHostToDevice, st));
     const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
     const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
@@ -1719,16 +1724,19 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
                                                       th_far_points);
                 if (r != FT_OK) return r;
             }
+            if (pass > 0 && tb->oCache)
+                return ft_launch_search_local_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
             return ft_launch_search_local_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
         },
-        [&](int par) {
+        [&](int par, int burst) {
             if (!frustumDone) {  // no frame has keypoints: the frustum fields are still the call's result
                 frustumDone = true;
                 const int r = ft_launch_frustum_batch(st, tb->d_arena, dJobs, n, maxM, viewing_cos_limit, log_scale_factor, far_points,
                                                       th_far_points);
                 if (r != FT_OK) return r;
             }
-            return ft_launch_deliver_batch(st, dRecs, 2 * n + 2, std::max(std::max(4 * maxPoints, maxFrWords), 32 * n), par);
+            return ft_launch_deliver_batch(st, dRecs, burst == 0 ? 2 * n + 2 : n + 2,
+                                           std::max(std::max(4 * maxPoints, burst == 0 ? maxFrWords : 0), FT_BATCH_FLAGS * n), par);
         },
         (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLocal);
     if (rc != FT_OK) return rc;
@@ -1753,6 +1761,144 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
     ctx->addStat("tracked_batch.track_local_map.total", tAll.ms());
     ctx->addStat("tracked_batch.track_local_map.passes", passes);
     ctx->addStat("tracked_batch.track_local_map.frames", n);
+    return FT_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_extractor *exR, int slot0, int n_frames, int lap_l0,
+                                  int lap_l1, int lap_r0, int lap_r1, const ft_frame_view *meta, int *const *left_to_right,
+                                  int *const *right_to_left) {
+    FT_REQUIRE(tb && exL && exR && meta && n_frames > 0 && n_frames <= tb->maxFrames && slot0 >= 0,
+               "ft_tracked_batch_bind_fisheye: bad argument");
+    FT_REQUIRE(exL->ctx == tb->ctx && exR->ctx == tb->ctx, "ft_tracked_batch_bind_fisheye: extractors of another context");
+    FT_REQUIRE(slot0 + n_frames <= exL->lastBatch && slot0 + n_frames <= exR->lastBatch,
+               "ft_tracked_batch_bind_fisheye: the extractors' last batches hold fewer images");
+    int nlevelsMax = 1, maxKp = 1;
+    for (int f = 0; f < n_frames; f++) {
+        const ft_frame_view &F = meta[f];
+        FT_REQUIRE(F.Nleft >= 0 && F.N >= F.Nleft && F.N <= tb->maxKp, "ft_tracked_batch_bind_fisheye: keypoint counts out of range");
+        FT_REQUIRE(F.Nleft == exL->h_nSel[slot0 + f] && F.N - F.Nleft == exR->h_nSel[slot0 + f],
+                   "ft_tracked_batch_bind_fisheye: meta's keypoint counts differ from the extractors' slots");
+        FT_REQUIRE(F.N == 0 || (F.keys && (F.N == F.Nleft || F.keys_right)), "ft_tracked_batch_bind_fisheye: meta->keys / keys_right (host copies) are null");
+        FT_REQUIRE(F.scale_factors && F.nlevels >= 1 && F.nlevels <= FT_MAX_LEVELS, "scale factors missing");
+        FT_REQUIRE(F.cam_model == 0 || F.cam_model == 1, "unknown camera model");
+        nlevelsMax = std::max(nlevelsMax, F.nlevels);
+        maxKp = std::max(maxKp, F.Nleft);
+    }
+    ft_context *ctx = tb->ctx;
+    int rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    FtTimer tAll;
+    hipStream_t st = ctx->stream;
+    FT_HIP(hipStreamSynchronize(st));
+    // frames region: holder_obs of all frames, the (monoLeft, monoRight) counts, then every frame's arrays (as ft_tracked_batch_upload)
+    Arena a;
+    tb->holderOff.assign(n_frames, 0);
+    tb->holderBegin = a.off;
+    for (int f = 0; f < n_frames; f++) tb->holderOff[f] = a.take(sizeof(int) * std::max(meta[f].N, 1));
+    tb->holderEnd = a.off;
+    const size_t oMono = a.take(sizeof(int) * 2 * (size_t)n_frames);
+    struct Lay {
+        size_t keys, keysR, desc, l2r, r2l;
+    };
+    std::vector<Lay> lay(n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        const int nL = meta[f].Nleft, nR = meta[f].N - nL;
+        lay[f].keys = a.take(sizeof(ft_keypoint) * std::max(nL, 1));
+        lay[f].keysR = a.take(sizeof(ft_keypoint) * std::max(nR, 1));
+        lay[f].desc = a.take((size_t)32 * std::max(meta[f].N, 1));
+        lay[f].l2r = a.take(sizeof(int) * std::max(nL, 1));
+        lay[f].r2l = a.take(sizeof(int) * std::max(nR, 1));
+    }
+    FT_REQUIRE(a.off <= tb->framesBytes, "ft_tracked_batch_bind_fisheye: frames region too small");
+    const bool wantTables = left_to_right && right_to_left;
+    Arena o;
+    std::vector<size_t> outL(n_frames), outR(n_frames);
+    for (int f = 0; f < n_frames && wantTables; f++) {
+        outL[f] = o.take(sizeof(int) * std::max(meta[f].Nleft, 1));
+        outR[f] = o.take(sizeof(int) * std::max(meta[f].N - meta[f].Nleft, 1));
+    }
+    FT_REQUIRE(o.off <= tb->outBytes, "ft_tracked_batch_bind_fisheye: result buffer too small");
+    tb->nFrames = n_frames;
+    tb->DF.assign(n_frames, FtDevFrame());
+    tb->angles.resize(n_frames);
+    tb->holder.resize(n_frames);
+    uint8_t *pinF = tb->h_in + tb->workBytes, *devF = tb->d_arena + tb->oFrames;
+    FtBatchJob *hJobs = (FtBatchJob *)tb->h_in;
+    FtDeliverRec *hRecs = (FtDeliverRec *)(tb->h_in + (((size_t)n_frames * sizeof(FtBatchJob) + 63) & ~(size_t)63));
+    FT_REQUIRE((size_t)n_frames * (sizeof(FtBatchJob) + 2 * sizeof(FtDeliverRec)) + 64 <= tb->workBytes, "ft_tracked_batch_bind_fisheye: work region too small");
+    const std::function<void(int, int)> stage = [&](int f, int) {
+        const ft_frame_view &F = meta[f];
+        const int nL = F.Nleft, nR = F.N - nL;
+        int *hold = (int *)(pinF + tb->holderOff[f]);
+        for (int i = 0; i < F.N; i++) hold[i] = F.holder_obs ? F.holder_obs[i] : -1;
+        FtDevFrame &D = tb->DF[f];
+        D = devFrameConstants(&F);
+        D.keys = (const ft_keypoint *)(devF + lay[f].keys);
+        D.keysR = (const ft_keypoint *)(devF + lay[f].keysR);
+        D.desc = devF + lay[f].desc;
+        D.uright = nullptr;
+        D.holderObs = (const int *)(devF + tb->holderOff[f]);
+        D.l2r = (const int *)(devF + lay[f].l2r);
+        D.r2l = (const int *)(devF + lay[f].r2l);
+        if (ctx->tuning.search_grid) {
+            int *grid = (int *)(tb->d_arena + tb->oGrid + (size_t)f * tb->gridStride);
+            float4 *rec = (float4 *)((uint8_t *)grid + gridIntBytes(D.N));
+            uint8_t *gdesc = (uint8_t *)(rec + std::max(D.N, 1));
+            D.gridStart[0] = grid;
+            D.gridStart[1] = grid + (size_t)FT_MAX_LEVELS * (FT_GRID_CELLS + 1);
+            D.gridRec[0] = rec;
+            D.gridDesc[0] = gdesc;
+            D.gridRec[1] = rec + nL;
+            D.gridDesc[1] = gdesc + (size_t)32 * nL;
+        }
+        memset(&hJobs[f], 0, sizeof(FtBatchJob));
+        hJobs[f].F = D;
+        tb->angles[f].resize(F.N);
+        for (int i = 0; i < nL; i++) tb->angles[f][i] = F.keys[i].angle;
+        for (int i = 0; i < nR; i++) tb->angles[f][nL + i] = F.keys_right[i].angle;
+        tb->holder[f].assign(hold, hold + F.N);
+        if (wantTables) {
+            hRecs[2 * f].dst = tb->h_out + outL[f];
+            hRecs[2 * f].src[0] = hRecs[2 * f].src[1] = D.l2r;
+            hRecs[2 * f].words = nL;
+            hRecs[2 * f + 1].dst = tb->h_out + outR[f];
+            hRecs[2 * f + 1].src[0] = hRecs[2 * f + 1].src[1] = D.r2l;
+            hRecs[2 * f + 1].words = nR;
+        }
+    };
+    ctx->pool->parallel_for(n_frames, stage);
+    const size_t headBytes = (size_t)((uint8_t *)(hRecs + 2 * (size_t)n_frames) - tb->h_in);
+    FT_HIP(hipMemcpyAsync(tb->d_arena + tb->oWork, tb->h_in, headBytes, hipMemcpyHostToDevice, st));
+    if (tb->holderEnd > tb->holderBegin)
+        FT_HIP(hipMemcpyAsync(devF + tb->holderBegin, pinF + tb->holderBegin, tb->holderEnd - tb->holderBegin, hipMemcpyHostToDevice, st));
+    const FtBatchJob *dJobs = (const FtBatchJob *)(tb->d_arena + tb->oWork);
+    FtBindArgs A;
+    A.keysL = exL->d_keys; A.keysR = exR->d_keys;
+    A.descL = exL->d_desc; A.descR = exR->d_desc;
+    A.strideL = exL->geom.maxKp; A.strideR = exR->geom.maxKp;
+    A.slot0 = slot0;
+    A.lapL0 = lap_l0; A.lapL1 = lap_l1; A.lapR0 = lap_r0; A.lapR1 = lap_r1;
+    A.mono = (int *)(devF + oMono);
+    rc = ft_launch_bind_fisheye_batch(st, tb->d_arena, dJobs, n_frames, maxKp, A);
+    if (rc == FT_OK && ctx->tuning.search_grid) rc = ft_launch_build_grid_batch(st, tb->d_arena, dJobs, n_frames, nlevelsMax, true);
+    if (rc != FT_OK) return rc;
+    if (wantTables) {
+        const FtDeliverRec *dRecs = (const FtDeliverRec *)(tb->d_arena + tb->oWork + ((uint8_t *)hRecs - tb->h_in));
+        rc = ft_launch_deliver_batch(st, dRecs, 2 * n_frames, maxKp, 0);
+        if (rc != FT_OK) return rc;
+        FT_HIP(hipStreamSynchronize(st));
+        for (int f = 0; f < n_frames; f++) {
+            const int nL = meta[f].Nleft, nR = meta[f].N - nL;
+            if (left_to_right[f] && nL) memcpy(left_to_right[f], tb->h_out + outL[f], sizeof(int) * nL);
+            if (right_to_left[f] && nR) memcpy(right_to_left[f], tb->h_out + outR[f], sizeof(int) * nR);
+        }
+    }
+    ctx->addStat("tracked_batch.bind_fisheye.total", tAll.ms());
     return FT_OK;
 }
 

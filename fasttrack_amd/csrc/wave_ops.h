@@ -62,6 +62,20 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return best;
 }
 
+// minimum over the 16 lanes of a ROW, returned in every lane of the row (the four DPP steps above stay inside a row)
+__device__ __forceinline__ unsigned long long row_min_u64(unsigned long long v) {
+#define FT_MIN64_STEP(ctrl)                                                                                   \
+    {                                                                                                         \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, ctrl, 0xF, 0xF, true); \
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v >> 32), ctrl, 0xF, 0xF, true);   \
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;                                     \
+        v = w < v ? w : v;                                                                                    \
+    }
+    FT_MIN64_STEP(0xB1) FT_MIN64_STEP(0x4E) FT_MIN64_STEP(0x141) FT_MIN64_STEP(0x140)
+#undef FT_MIN64_STEP
+    return v;
+}
+
 // Low 32 bits of the product of two operands that fit 24 bits, as ONE full-rate instruction.  (__mul24 is dissolved
 // into a plain multiply once the optimiser has proven the operand ranges, and instruction selection then falls back
 // to the quarter-rate 32-bit v_mul_lo_u32 whenever it cannot re-derive them.)

@@ -265,6 +265,16 @@ class ORBextractor:
                                      lapping_area[1], ptr(kps), ptr(desc), cap, ptr(n), ptr(nm)))
         return [(kps[b, :n[b]].copy(), desc[b, :n[b]].copy(), int(nm[b])) for b in range(B)]
 
+    def extract_batch_into(self, ptrs, B, on_device, width, height, stride, lapping_area, kps, desc, n, nm):
+        """ft_extract_batch into arrays the caller keeps (kps [B, cap] KP_DTYPE, desc [B, cap, 32], n / nm [B] int32): the lean form
+        for loops that must not time Python; ptrs = the (pointer array, keep-alive) pair of image_ptrs()"""
+        check(lib().ft_extract_batch(self._h, ptrs, B, int(on_device), width, height, stride, lapping_area[0], lapping_area[1],
+                                     ptr(kps), ptr(desc), kps.shape[1], ptr(n), ptr(nm)))
+
+    @staticmethod
+    def image_ptrs(images, on_device):
+        return _image_ptrs(images, on_device)
+
     # mvImagePyramid[level] (host copy) of image slot `slot`
     def image_pyramid_level(self, level, slot=0) -> np.ndarray:
         w, h = self.level_size(level)
@@ -711,16 +721,38 @@ class TrackedBatch:
         """frames: list of FrameView, or the (array, views) pair prepare_frames returned"""
         arr, views = frames if isinstance(frames, tuple) else self.prepare_frames(frames)
         check(lib().ft_tracked_batch_upload(self._h, len(views), arr))
-        self.N = [F.c.N for F in views]
-        self._assign = [np.zeros(max(n, 1), np.int32) for n in self.N]
-        self._assign_ptrs = (C.c_void_p * len(views))(*[ptr(a) for a in self._assign])
-        self._nm = np.zeros(len(views), np.int32)
-        self._nt = np.zeros(len(views), np.int32)
+        self._after_load([F.c.N for F in views])
 
     @staticmethod
     def prepare_frames(views):
         arr = (_capi.FrameView * len(views))(*[F.c for F in views])
         return arr, list(views)
+
+    def _after_load(self, counts):
+        self.N = list(counts)
+        self._assign = [np.zeros(max(n, 1), np.int32) for n in self.N]
+        self._assign_ptrs = (C.c_void_p * len(self.N))(*[ptr(a) for a in self._assign])
+        self._nm = np.zeros(len(self.N), np.int32)
+        self._nt = np.zeros(len(self.N), np.int32)
+
+    def bind_fisheye(self, exL, exR, views, lap_l, lap_r, slot0=0, want_tables=True):
+        """ft_tracked_batch_bind_fisheye: views = FrameViews (or the pair prepare_frames returned) whose keys / keys_right are the
+        host copies of what exL / exR extracted last (slots slot0 ...); -> [(left_to_right, right_to_left)] or None"""
+        arr, vs = views if isinstance(views, tuple) else self.prepare_frames(views)
+        n = len(vs)
+        l2r = r2l = None
+        pl = pr = None
+        if want_tables:
+            l2r = [np.full(max(F.c.Nleft, 1), -1, np.int32) for F in vs]
+            r2l = [np.full(max(F.c.N - F.c.Nleft, 1), -1, np.int32) for F in vs]
+            pl = (C.c_void_p * n)(*[ptr(a) for a in l2r])
+            pr = (C.c_void_p * n)(*[ptr(a) for a in r2l])
+        check(lib().ft_tracked_batch_bind_fisheye(self._h, exL._h, exR._h, slot0, n, lap_l[0], lap_l[1], lap_r[0], lap_r[1], arr, pl, pr))
+        if [F.c.N for F in vs] != self.N:
+            self._after_load([F.c.N for F in vs])
+        if want_tables:
+            return [(l2r[f][:vs[f].c.Nleft], r2l[f][:vs[f].c.N - vs[f].c.Nleft]) for f in range(n)]
+        return None
 
     def holder_obs(self, f):
         out = np.zeros(max(self.N[f], 1), np.int32)
@@ -750,7 +782,7 @@ class TrackedBatch:
         bw = None if backward is None else np.ascontiguousarray(backward, np.int32)
         return dict(n=n, arr=arr, keep=keep, T=T, se3=se3, fw=fw, bw=bw)
 
-    def search_last_frame(self, lasts, Tcws=None, th=7.0, forward=None, backward=None, check_orientation=True, Trl=None):
+    def search_last_frame(self, lasts, Tcws=None, th=7.0, forward=None, backward=None, check_orientation=True, Trl=None, copy=True):
         pl = lasts if isinstance(lasts, dict) and "arr" in lasts else self.prepare_last(lasts, Tcws, forward, backward)
         n = pl["n"]
         if pl["se3"]:
@@ -760,6 +792,8 @@ class TrackedBatch:
         else:
             check(lib().ft_tracked_batch_search_last_frame(self._h, n, pl["arr"], ptr(pl["T"]), th, ptr(pl["fw"]), ptr(pl["bw"]),
                                                            int(check_orientation), self._assign_ptrs, ptr(self._nm)))
+        if not copy:
+            return None
         return [dict(assign=self._assign[f][:self.N[f]].copy(), n=int(self._nm[f])) for f in range(n)]
 
     @staticmethod

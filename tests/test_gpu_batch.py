@@ -189,3 +189,76 @@ def test_tracked_batch_argument_checks(ctx):
     r = tb.track_local_map([orb.make_pose(Rcw, tcw, TLR)] * 2, [pts, pts], 0.5, LOG_SF, 7.0)
     assert np.array_equal(r[0]["assign"], r[1]["assign"])
     tb.close()
+
+
+@pytest.mark.parametrize("lap", [(0, 511), (120, 420)])
+def test_tracked_batch_bound_to_extractors_equals_uploaded_batch(ctx, lap):
+    """ft_tracked_batch_bind_fisheye: the two-camera frames of a batch straight from what two throughput extractors left in HBM
+    (keypoints into the reference's lapping-area order on the device, 2-NN + ratio matching of the lapping subsets, grids) -
+    the match tables equal the oracle's ComputeStereoFishEyeMatches matching on the host copies, and both searches give what
+    the same frames give when they are uploaded from host arrays (hence the oracle's results: the tests above)."""
+    from fasttrack_amd import synth
+    B, w, h, nf = 24, 512, 512, 2000
+    sf, _ = ob.scale_factors(1.2, 8)
+    exL = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=B)
+    exR = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=B)
+    pairs = [synth.make_planes_pair(w, h, seed=300 + i) for i in range(B)]
+    pairs[7] = (np.full((h, w), 90, np.uint8), pairs[7][1])     # a frame whose left image has no keypoint
+    rL = exL.extract_batch([p[0] for p in pairs], lap)
+    rR = exR.extract_batch([p[1] for p in pairs], lap)
+    views, tables, lasts, Tcws, ptss, poses = [], [], [], [], [], []
+    for f in range(B):
+        (kL, dL, mL), (kR, dR, mR) = rL[f], rR[f]
+        m = ob.fisheye_match(dL[mL:], dR[mR:])["matches"] if len(dL) > mL and len(dR) > mR else np.zeros(0, np.int32)
+        l2r = np.full(len(kL), -1, np.int32)
+        r2l = np.full(len(kR), -1, np.int32)
+        for i, j in enumerate(m):
+            if j >= 0:
+                l2r[mL + i] = mR + j
+                r2l[mR + j] = mL + i      # the last left keypoint that matches a right one keeps it (src/Frame.cc:1262)
+        tables.append((l2r, r2l))
+        kw = dict(keys=kL, keys_right=kR, descriptors=np.concatenate([dL, dR]), bounds=sc.frame_bounds(w, h), left_to_right=l2r,
+                  right_to_left=r2l, cam_model=1, cam=list(sc.KB8_CAM), Trl=TRL)
+        views.append(orb.FrameView(scale_factors=sf, **kw))
+        if len(kL):
+            last, Tcw, pts, Rcw, tcw = _kb8_inputs(kL, dL, sf, 2000 + f, 1200)
+        else:
+            last, Tcw, pts, Rcw, tcw = _kb8_inputs(rL[0][0], rL[0][1], sf, 2000 + f, 1200)
+            last = {k: v[:0] for k, v in last.items()}
+        lasts.append(last); Tcws.append(Tcw); ptss.append(pts); poses.append(orb.make_pose(Rcw, tcw, TLR))
+    if lap == (120, 420):
+        assert any(0 < rL[f][2] < len(rL[f][0]) for f in range(B))   # keypoints on both sides of the lapping area
+    cap = 2 * exL.max_keypoints + 64
+    ta = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=cap, max_points=2048)
+    t = ta.bind_fisheye(exL, exR, views, lap, lap)
+    nm = 0
+    for f in range(B):
+        assert np.array_equal(t[f][0], tables[f][0]), f"frame {f}: mvLeftToRightMatch"
+        assert np.array_equal(t[f][1], tables[f][1]), f"frame {f}: mvRightToLeftMatch"
+        nm += int((tables[f][0] >= 0).sum())
+    assert nm > 20 * B
+    a1 = ta.search_last_frame(lasts, Tcws, 7.0)
+    a2 = ta.track_local_map(poses, ptss, 0.5, LOG_SF, 7.0)
+    tu = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=cap, max_points=2048)
+    tu.upload(views)
+    u1 = tu.search_last_frame(lasts, Tcws, 7.0)
+    u2 = tu.track_local_map(poses, ptss, 0.5, LOG_SF, 7.0)
+    for f in range(B):
+        assert a1[f]["n"] == u1[f]["n"] and np.array_equal(a1[f]["assign"], u1[f]["assign"]), f
+        assert a2[f]["n"] == u2[f]["n"] and np.array_equal(a2[f]["assign"], u2[f]["assign"]) and a2[f]["n_to_match"] == u2[f]["n_to_match"], f
+        for k, _ in ob.FRUSTUM_FIELDS:
+            assert np.array_equal(a2[f][k], u2[f][k]), (f, k)
+        assert np.array_equal(ta.holder_obs(f), tu.holder_obs(f))
+    # the oracle's sequence on two frames of the bound batch (the rest is covered through the uploaded form above)
+    for f in (0, 11):
+        (kL, dL, _), (kR, dR, _) = rL[f], rR[f]
+        kw = dict(keys=kL, keys_right=kR, descriptors=np.concatenate([dL, dR]), bounds=sc.frame_bounds(w, h), left_to_right=tables[f][0],
+                  right_to_left=tables[f][1], cam_model=1, cam=list(sc.KB8_CAM), Trl=TRL)
+        oF = ob.FrameView(scale_factors_=sf, **kw)
+        o1 = ob.search_last_frame(oF, lasts[f], Tcws[f], 7.0, False, False, True)
+        pose = ob.make_pose(*[np.asarray(x) for x in (np.array(poses[f].Rcw).reshape(3, 3), np.array(poses[f].tcw))], TLR)
+        ofr = ob.is_in_frustum(oF, pose, ptss[f], 0.5, LOG_SF)
+        o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, ptss[f]), 7.0)
+        _check_frame(f"bound frame {f}", a1[f], a2[f], ta.holder_obs(f), o1, ofr, o2, oF)
+    for o in (ta, tu, exL, exR):
+        o.close()
