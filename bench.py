@@ -341,18 +341,22 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
     return out
 
 
-def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.0)):
+def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.0), pipelined=True):
     """BASELINE.json configs[3] as a THROUGHPUT workload: B independent 512x512 KannalaBrandt8 stereo frames per step (the
     frames B camera streams deliver for one time step), every stage ONE launch over all of them (ft_tracked_batch_*):
-      extraction of the B left and the B right images, frames resident in HBM, lapping areas [0, 511]      (ft_extract_batch x 2)
+      extraction of the B left and the B right images, frames resident in HBM, lapping areas [0, 511]      (ft_extract_batch x 2,
+                                                                             two host threads as in Frame's constructor)
       keypoints into the reference's order + left <-> right matching of the lapping subsets + grids, on the device,
       from what the extractors left in HBM                                                                   (ft_tracked_batch_bind_fisheye)
       SearchByProjection(CurrentFrame, LastFrame, th)                                                       (ft_tracked_batch_search_last_frame)
       isInFrustum + SearchByProjection(CurrentFrame, local map points, th)                                   (ft_tracked_batch_track_local_map)
-    Host in / out per step: the map points of every frame up (pageable host arrays), keypoints, descriptors, match tables'
-    consumers (assign, n_matches, frustum fields) down.  Every frame of the batch is a distinct image pair with its own
-    last-frame points, local map (M points) and poses, built once from the frame's own keypoints (untimed)."""
+    pipelined: the extraction of step k + 1 (a second pair of extractors, a worker thread) runs while step k is searched - two
+    steps in flight, like the two stereo front ends of the headline.  Host in / out per step: the map points of every frame up
+    (pageable host arrays), keypoints, descriptors, assignments, match counts and frustum fields down.  Every frame of the
+    batch is a distinct image pair with its own last-frame points, local map (M points) and poses, built once from the frame's
+    own keypoints (untimed)."""
     import ctypes as C
+    import concurrent.futures
     from fasttrack_amd import scenarios as sc
     w, h, nf = 512, 512, 2000
     lap = (0, 511)
@@ -361,96 +365,169 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
     Trl = np.concatenate([np.eye(3), [[-0.101], [0.0], [0.0]]], 1).astype(np.float32)
     TLR = (0.101, 0.0, 0.0)
     LOG_SF = float(np.float32(np.log(np.float32(SCALE))))
-    exL = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=B)
-    exR = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=B)
-    sf = np.asarray(exL.GetScaleFactors(), np.float32)
-    cap = exL.max_keypoints
+    nlanes = 2 if pipelined else 1
     pairs = [synth.make_planes_pair(w, h, seed=7000 + i) for i in range(B)]
     devL, devR = ctx.to_device(np.stack([p[0] for p in pairs])), ctx.to_device(np.stack([p[1] for p in pairs]))
     fb = w * h
     pL = (C.c_void_p * B)(*[devL.ptr.value + b * fb for b in range(B)])
     pR = (C.c_void_p * B)(*[devR.ptr.value + b * fb for b in range(B)])
-    kL, kR = np.zeros((B, cap), orb.KP_DTYPE), np.zeros((B, cap), orb.KP_DTYPE)
-    dL, dR = np.zeros((B, cap, 32), np.uint8), np.zeros((B, cap, 32), np.uint8)
-    nL, nR, mL, mR = (np.zeros(B, np.int32) for _ in range(4))
+
+    class Lane:
+        pass
+    lanes = []
+    for _ in range(nlanes):
+        ln = Lane()
+        ln.exL = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=B)
+        ln.exR = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=B)
+        cap = ln.exL.max_keypoints
+        ln.kL, ln.kR = np.zeros((B, cap), orb.KP_DTYPE), np.zeros((B, cap), orb.KP_DTYPE)
+        ln.dL, ln.dR = np.zeros((B, cap, 32), np.uint8), np.zeros((B, cap, 32), np.uint8)
+        ln.nL, ln.nR, ln.mL, ln.mR = (np.zeros(B, np.int32) for _ in range(4))
+        lanes.append(ln)
+    sf = np.asarray(lanes[0].exL.GetScaleFactors(), np.float32)
+    cap = lanes[0].exL.max_keypoints
     tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=2 * cap + 64, max_points=max(M, cap) + 64)
-
-    import concurrent.futures
     two = concurrent.futures.ThreadPoolExecutor(2)
+    ahead = concurrent.futures.ThreadPoolExecutor(1)
 
-    def extract():
+    def extract(ln):
         # the two cameras on two host threads, as Frame's constructor runs them (src/Frame.cc:1144-1147)
-        a = two.submit(exL.extract_batch_into, pL, B, True, w, h, w, lap, kL, dL, nL, mL)
-        b = two.submit(exR.extract_batch_into, pR, B, True, w, h, w, lap, kR, dR, nR, mR)
+        a = two.submit(ln.exL.extract_batch_into, pL, B, True, w, h, w, lap, ln.kL, ln.dL, ln.nL, ln.mL)
+        b = two.submit(ln.exR.extract_batch_into, pR, B, True, w, h, w, lap, ln.kR, ln.dR, ln.nR, ln.mR)
         a.result()
         b.result()
-    extract()
-    # the frame views of the batch: constants + the host copies of the keypoints (extraction is deterministic: the counts and
-    # the arrays the views point to are the same in every step)
-    views = [orb.FrameView(keys=kL[f, :nL[f]], keys_right=kR[f, :nR[f]], descriptors=np.zeros((int(nL[f] + nR[f]), 32), np.uint8),
-                           scale_factors=sf, bounds=sc.frame_bounds(w, h), left_to_right=np.zeros(max(int(nL[f]), 1), np.int32),
-                           right_to_left=np.zeros(max(int(nR[f]), 1), np.int32), cam_model=1, cam=cam, Trl=Trl) for f in range(B)]
-    meta = tb.prepare_frames(views)
-    counts = (nL.copy(), nR.copy())
+    for ln in lanes:
+        extract(ln)
+        # the frame views of the lane: constants + the host copies of the keypoints (extraction is deterministic: the counts and
+        # the arrays the views point to are the same in every step)
+        views = [orb.FrameView(keys=ln.kL[f, :ln.nL[f]], keys_right=ln.kR[f, :ln.nR[f]],
+                               descriptors=np.zeros((int(ln.nL[f] + ln.nR[f]), 32), np.uint8), scale_factors=sf, bounds=sc.frame_bounds(w, h),
+                               left_to_right=np.zeros(max(int(ln.nL[f]), 1), np.int32), right_to_left=np.zeros(max(int(ln.nR[f]), 1), np.int32),
+                               cam_model=1, cam=cam, Trl=Trl) for f in range(B)]
+        ln.meta = tb.prepare_frames(views)
+    l0 = lanes[0]
+    nL, nR = l0.nL.copy(), l0.nR.copy()
     scen = []
     for f in range(B):
         depth = np.zeros(int(nL[f]), np.float32)
-        last, Tcw_last = sc.last_frame_scenario(kL[f, :nL[f]], dL[f, :nL[f]], None, depth, intr, w, h, seed=40 + f)
-        pts, Rcw, tcw = sc.map_points_scenario(kL[f, :nL[f]], dL[f, :nL[f]], depth, intr, NLEVELS, sf, 90 + f, M=M)
+        last, Tcw_last = sc.last_frame_scenario(l0.kL[f, :nL[f]], l0.dL[f, :nL[f]], None, depth, intr, w, h, seed=40 + f)
+        pts, Rcw, tcw = sc.map_points_scenario(l0.kL[f, :nL[f]], l0.dL[f, :nL[f]], depth, intr, NLEVELS, sf, 90 + f, M=M)
         scen.append((last, Tcw_last, pts, Rcw, tcw))
     pl_last = tb.prepare_last([s_[0] for s_ in scen], [s_[1] for s_ in scen])
     pl_local = tb.prepare_local([orb.make_pose(s_[3], s_[4], TLR) for s_ in scen], [s_[2] for s_ in scen])
-    part = {"extract_left_right": 0.0, "bind_fisheye (order, match, grids)": 0.0, "search_last_frame": 0.0, "track_local_map": 0.0}
+    part = {"extract_left_right (wait)": 0.0, "bind_fisheye (order, match, grids)": 0.0, "search_last_frame": 0.0, "track_local_map": 0.0}
 
-    def step(th):
-        t0 = time.perf_counter()
-        extract()
-        t1 = time.perf_counter()
-        tb.bind_fisheye(exL, exR, meta, lap, lap, want_tables=False)
-        t2 = time.perf_counter()
-        tb.search_last_frame(pl_last, th=th, copy=False)
-        t3 = time.perf_counter()
-        tb.track_local_map(pl_local, viewing_cos_limit=0.5, log_scale_factor=LOG_SF, th=th, copy=False)
-        t4 = time.perf_counter()
-        for k_, v_ in zip(part, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
-            part[k_] += v_
+    def run(n, th):
+        """n steps; with two lanes the extraction of step k + 1 is in flight while step k is searched"""
+        fut = ahead.submit(extract, lanes[0]) if pipelined else None
+        for k in range(n):
+            ln = lanes[k % nlanes]
+            t0 = time.perf_counter()
+            if pipelined:
+                fut.result()
+                fut = ahead.submit(extract, lanes[(k + 1) % nlanes]) if k + 1 < n else None
+            else:
+                extract(ln)
+            t1 = time.perf_counter()
+            tb.bind_fisheye(ln.exL, ln.exR, ln.meta, lap, lap, want_tables=False)
+            t2 = time.perf_counter()
+            tb.search_last_frame(pl_last, th=th, copy=False)
+            t3 = time.perf_counter()
+            tb.track_local_map(pl_local, viewing_cos_limit=0.5, log_scale_factor=LOG_SF, th=th, copy=False)
+            t4 = time.perf_counter()
+            for k_, v_ in zip(part, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                part[k_] += v_
     out = {"metric": "frames/sec extract + SearchByProjection (last frame, local map), B frames per launch", "unit": "frames/s",
-           "batch_frames": B, "distinct_frames": B, "image": [w, h], "nfeatures": nf, "local_map_points": M,
+           "batch_frames": B, "distinct_frames": B, "steps": steps, "image": [w, h], "nfeatures": nf, "local_map_points": M,
+           "mode": "two steps in flight (extraction of step k + 1 beside the searches of step k)" if pipelined else "one step at a time",
            "inputs": "images resident in HBM before the timed region; map points in pageable host memory, uploaded inside it",
            "outputs": "keypoints, descriptors, assignments, match counts, frustum fields in host memory", "by_th": {}}
     for th in ths:
-        for _ in range(max(warmup, 1)):
-            step(th)
-        assert np.array_equal(nL, counts[0]) and np.array_equal(nR, counts[1])
+        run(max(warmup, 2), th)
+        for ln in lanes:
+            assert np.array_equal(ln.nL, nL) and np.array_equal(ln.nR, nR)
         ctx.synchronize()
         ctx.reset_stats()
         for k_ in part:
             part[k_] = 0.0
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step(th)
+        run(steps, th)
         ctx.synchronize()
         dt = time.perf_counter() - t0
         stats = {}
-        for nm_ in ("tracked_batch.search_last_frame.passes", "tracked_batch.track_local_map.passes"):
-            tot_, n_ = ctx.get_stat(nm_)
-            stats[nm_ + "_per_call"] = tot_ / n_ if n_ else None
+        for nm_ in ("tracked_batch.search_last_frame.passes", "tracked_batch.track_local_map.passes", "tracked_batch.search_last_frame.total",
+                    "tracked_batch.track_local_map.total", "tracked_batch.search_last_frame.stage", "tracked_batch.search_last_frame.device",
+                    "tracked_batch.search_last_frame.replay", "tracked_batch.track_local_map.stage", "tracked_batch.track_local_map.device",
+                    "tracked_batch.track_local_map.replay", "tracked_batch.bind_fisheye.total"):
+            try:
+                tot_, n_ = ctx.get_stat(nm_)
+            except Exception:
+                continue
+            stats[nm_ + ("_per_call" if nm_.endswith("passes") else "_ms_per_call")] = tot_ / n_ if n_ else None
         nmatch = int(tb._nm.sum())
         out["by_th"][str(int(th))] = {"value": B * steps / dt, "ms_per_step": 1e3 * dt / steps, "us_per_frame": 1e6 * dt / (B * steps),
                                       "map_points_per_s": (int(nL.sum()) + B * M) * steps / dt,
                                       "local_map_matches_per_frame": nmatch / B,
                                       "ms_per_step_by_part": {k_: 1e3 * v_ / steps for k_, v_ in part.items()},
-                                      "inside_the_library": stats,
-                                      "launches_per_frame": None}
+                                      "inside_the_library": stats}
     out["value"] = out["by_th"][str(int(ths[0]))]["value"]
     out["keypoints_per_frame"] = float(nL.sum() + nR.sum()) / B
+    # ---- what the kernels do with it: durations by HIP events on the launching stream (a run of its own, th = ths[0]), the
+    # Hamming compares of a step, and the issue bound they are priced against ----
+    th0 = ths[0]
+    ctx.reset_stats()
+    ctx.set_kernel_timing(True)
+    run(2, th0)
+    ctx.synchronize()
+    ctx.set_kernel_timing(False)
+    kern = {}
+    for nm_ in ("kernel.lap_gather+fisheye_2nn_batch", "kernel.build_grid_batch", "kernel.frustum_batch", "kernel.search_last_batch(first pass)",
+                "kernel.search_last_batch(later pass)", "kernel.search_local_batch(first pass)", "kernel.search_local_batch(later pass)"):
+        try:
+            tot_, n_ = ctx.get_stat(nm_)
+        except Exception:
+            continue
+        if n_:
+            kern[nm_[7:]] = {"launches_per_step": n_ / 2.0, "avg_launch_ms": tot_ / n_, "ms_per_step": tot_ / 2.0}
+    # compares of the searches = keypoints GetFeaturesInArea returns for the searched points' windows (count_compares), a sample of frames
+    fr = tb.track_local_map(pl_local, viewing_cos_limit=0.5, log_scale_factor=LOG_SF, th=th0, copy=True)
+    sample = list(range(0, B, max(B // 8, 1)))[:8]
+    views0 = lanes[0].meta[1]
+    cmp_search = float(np.mean([count_compares(orb, ctx, views0[f], sf, scen[f], fr[f], th0, cam, Trl) for f in sample]))
+    cmp_2nn = float(np.mean(nL.astype(np.float64) * nR.astype(np.float64)))   # lapping areas cover the images: every left x every right keypoint
+    fps = out["value"]
+    # 256-bit Hamming distance = 8 v_xor_b32 + 8 v_bcnt_u32_b32 (accumulating) per lane; a wave instruction occupies a 16-lane SIMD
+    # for 4 cycles (profiles/r02_valu_rates.txt) -> 64 compares per 64 cycles and SIMD: 1 024 SIMDs x 2.4 GHz compares/s
+    VALU_COMPARES_PER_S = 1024 * 2.4e9
+    k2 = kern.get("lap_gather+fisheye_2nn_batch")
+    out["kernels"] = kern
+    out["hamming_compares_per_frame"] = {"fisheye_2nn": cmp_2nn, "searches(first passes)": cmp_search}
+    out["hamming_compares_per_s"] = (cmp_2nn + cmp_search) * fps
+    if k2:
+        ach = cmp_2nn * B / (k2["avg_launch_ms"] / 1e3)
+        out["roofline"] = {"bound": "valu", "kernel": "k_fisheye_2nn_batch (timed together with k_lap_gather_batch, ~10 % of the pair)",
+                           "achieved": ach / 1e9, "peak": VALU_COMPARES_PER_S / 1e9, "unit": "G Hamming compares/s", "frac": ach / VALU_COMPARES_PER_S,
+                           "traffic": None, "compares_per_launch": cmp_2nn * B, "avg_launch_ms": k2["avg_launch_ms"],
+                           "peak_source": "16 vector instructions (8 v_xor_b32 + 8 v_bcnt_u32_b32) per 256-bit compare and lane, 4 cycles per "
+                                          "wave instruction on a 16-lane SIMD (profiles/r02_valu_rates.txt), 1 024 SIMDs x 2.4 GHz"}
+    first = [kern.get("search_last_batch(first pass)"), kern.get("search_local_batch(first pass)")]
+    if all(first):
+        ms = first[0]["avg_launch_ms"] + first[1]["avg_launch_ms"]
+        ach = cmp_search * B / (ms / 1e3)
+        out["searches_first_pass"] = {"compares_per_s": ach, "frac_of_valu_bound": ach / VALU_COMPARES_PER_S, "ms_per_step": ms,
+                                      "note": "window scans: grid ranges, records, descriptors of ~%d candidates per frame behind dependent loads - latency, not issue" % int(cmp_search)}
+    launches = sum(v_["launches_per_step"] for v_ in kern.values()) + 2 * 8 + 26 + 10   # + pyramid / FAST / octree / descriptors of the two extractor pairs, copies, fills, deliveries
+    out["launches_per_frame"] = launches / B
     out["_scen"] = scen
-    out["_views"] = (kL, kR, dL, dR, nL, nR)
+    out["_frames"] = (l0.kL, l0.kR, l0.dL, l0.dR, nL, nR)
     tb.close()
-    exL.close()
-    exR.close()
+    for ln in lanes:
+        ln.exL.close()
+        ln.exR.close()
     devL.free()
     devR.free()
+    two.shutdown()
+    ahead.shutdown()
     return out
 
 
@@ -533,6 +610,7 @@ def main():
     ap.add_argument("--no-workloads", action="store_true", help="skip the extra workloads (752x480, tracking 512x512, dense, planes)")
     ap.add_argument("--workload-batch", type=int, default=512, help="pairs per step of the extra stereo workloads")
     ap.add_argument("--workload-frames", type=int, default=48, help="frames per threshold of the tracking workload")
+    ap.add_argument("--tracking-batch", type=int, default=128, help="frames per launch of the tracking workload's throughput form (ft_tracked_batch)")
     ap.add_argument("--mosaic", type=int, default=0, metavar="BLOCK",
                     help="dense-corner scenes instead (synth.make_mosaic_pair with tiles of BLOCK px: 8 gives > 8 k FAST "
                          "candidates at level 0 of a 1280x720 frame)")
@@ -809,6 +887,11 @@ def main():
             WB = args.workload_batch
             wl["stereo_752x480_nf1200"] = stereo_leg(orb, ctx, "stereo_752x480_nf1200", 752, 480, 1200, WB, 48, 5, cpu=cpu)
             wl["tracking_512x512_nf2000"] = tracking_leg(orb, ctx, frames=args.workload_frames, cpu=cpu)
+            thr = tracking_batch_leg(orb, ctx, B=args.tracking_batch, steps=6, warmup=2)
+            thr = {k_: v_ for k_, v_ in thr.items() if not k_.startswith("_")}
+            if "cpu_baseline" in wl["tracking_512x512_nf2000"]:
+                thr["gpu_over_cpu"] = thr["value"] / wl["tracking_512x512_nf2000"]["cpu_baseline"]["value"]
+            wl["tracking_512x512_nf2000"]["throughput"] = thr
             wl["dense_1280x720_nf2000"] = stereo_leg(orb, ctx, "dense", 1280, 720, 2000, WB, 16, 4, mosaic=10, cpu=cpu, cpu_budget_s=3.0)
             wl["planes_1280x720_nf2000"] = stereo_leg(orb, ctx, "planes", 1280, 720, 2000, WB, 16, 4, planes=True, cpu=cpu, cpu_budget_s=3.0)
             out["workloads"] = wl

@@ -1187,6 +1187,7 @@ struct ft_tracked_batch {
     std::vector<std::vector<float>> angles;
     std::vector<std::vector<int>> holder;
     int passesLast = 0, passesLocal = 0;
+    FtEventTimer evt;  // ft_context_set_kernel_timing: HIP events around the batch's launches on the context's stream
 };
 
 namespace {
@@ -1355,6 +1356,7 @@ int ft_tracked_batch_destroy(ft_tracked_batch *tb) {
     if (tb->d_arena) hipFree(tb->d_arena);
     if (tb->h_in) hipHostFree(tb->h_in);
     if (tb->h_out) hipHostFree(tb->h_out);
+    tb->evt.destroy();
     if (tb->counted) tb->ctx->liveObjects--;
     delete tb;
     return FT_OK;
@@ -1554,6 +1556,8 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     hRecs[n].dst = tb->h_out + oFlagsOut;
     hRecs[n].src[0] = hRecs[n].src[1] = tb->d_arena + tb->oFlags;
     hRecs[n].words = FT_BATCH_FLAGS * n;
+    ctx->addStat("tracked_batch.search_last_frame.stage", tAll.ms());
+    FtTimer tDev;
     FT_HIP(hipMemcpyAsync(dev, pin, a.off, hipMemcpyHostToDevice, st));
     const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
     const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
@@ -1561,13 +1565,19 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     rc = fixedPointBatch(
         tb, st, dJobs, n, maxPoints, maxK,
         [&](int pass, int fCur, int fPrev, int fReset) {
-            if (pass > 0 && tb->oCache)
-                return ft_launch_search_last_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
-            return ft_launch_search_last_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
+            const bool lean = pass > 0 && tb->oCache;
+            tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_last_batch(later pass)" : "kernel.search_last_batch(first pass)", st);
+            const int r = lean ? ft_launch_search_last_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th)
+                               : ft_launch_search_last_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
+            tb->evt.end(ctx->kernelTiming, st);
+            return r;
         },
         [&](int par, int) { return ft_launch_deliver_batch(st, dRecs, n + 1, std::max(4 * maxPoints, FT_BATCH_FLAGS * n), par); },
         (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLast);
     if (rc != FT_OK) return rc;
+    ctx->addStat("tracked_batch.search_last_frame.device", tDev.ms());
+    tb->evt.resolve(ctx);
+    FtTimer tRep;
     const std::function<void(int, int)> replay = [&](int f, int) {
         const int nm = hJobs[f].nPoints > 0
                            ? replayLastFrameWrites((const int *)(tb->h_out + lay[f].out), L[f].N, &L[f], [&](int idx) { return tb->angles[f][idx]; },
@@ -1578,6 +1588,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     ctx->pool->parallel_for(n, replay);
     rc = uploadBatchHolders(tb, st);
     if (rc != FT_OK) return rc;
+    ctx->addStat("tracked_batch.search_last_frame.replay", tRep.ms());
     ctx->addStat("tracked_batch.search_last_frame.total", tAll.ms());
     ctx->addStat("tracked_batch.search_last_frame.passes", passes);
     ctx->addStat("tracked_batch.search_last_frame.frames", n);
@@ -1710,6 +1721,8 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
     hRecs[n + 1].dst = tb->h_out + oCountsOut;
     hRecs[n + 1].src[0] = hRecs[n + 1].src[1] = tb->d_arena + tb->oCounts;
     hRecs[n + 1].words = n;
+    ctx->addStat("tracked_batch.track_local_map.stage", tAll.ms());
+    FtTimer tDev;
     FT_HIP(hipMemcpyAsync(dev, pin, a.off, hipMemcpyHostToDevice, st));
     const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
     const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
@@ -1720,13 +1733,18 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
         [&](int pass, int fCur, int fPrev, int fReset) {
             if (!frustumDone) {  // behind the fill of the claim iteration (which zeroes the counts), in front of the first pass
                 frustumDone = true;
+                tb->evt.begin(ctx->kernelTiming, "kernel.frustum_batch", st);
                 const int r = ft_launch_frustum_batch(st, tb->d_arena, dJobs, n, maxM, viewing_cos_limit, log_scale_factor, far_points,
                                                       th_far_points);
+                tb->evt.end(ctx->kernelTiming, st);
                 if (r != FT_OK) return r;
             }
-            if (pass > 0 && tb->oCache)
-                return ft_launch_search_local_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
-            return ft_launch_search_local_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
+            const bool lean = pass > 0 && tb->oCache;
+            tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_local_batch(later pass)" : "kernel.search_local_batch(first pass)", st);
+            const int r = lean ? ft_launch_search_local_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio)
+                               : ft_launch_search_local_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
+            tb->evt.end(ctx->kernelTiming, st);
+            return r;
         },
         [&](int par, int burst) {
             if (!frustumDone) {  // no frame has keypoints: the frustum fields are still the call's result
@@ -1740,6 +1758,9 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
         },
         (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLocal);
     if (rc != FT_OK) return rc;
+    ctx->addStat("tracked_batch.track_local_map.device", tDev.ms());
+    tb->evt.resolve(ctx);
+    FtTimer tRep;
     const int *hCounts = (const int *)(tb->h_out + oCountsOut);
     const std::function<void(int, int)> replay = [&](int f, int) {
         const int M = P[f].M;
@@ -1758,6 +1779,7 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
     ctx->pool->parallel_for(n, replay);
     rc = uploadBatchHolders(tb, st);
     if (rc != FT_OK) return rc;
+    ctx->addStat("tracked_batch.track_local_map.replay", tRep.ms());
     ctx->addStat("tracked_batch.track_local_map.total", tAll.ms());
     ctx->addStat("tracked_batch.track_local_map.passes", passes);
     ctx->addStat("tracked_batch.track_local_map.frames", n);
@@ -1884,8 +1906,12 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     A.slot0 = slot0;
     A.lapL0 = lap_l0; A.lapL1 = lap_l1; A.lapR0 = lap_r0; A.lapR1 = lap_r1;
     A.mono = (int *)(devF + oMono);
+    tb->evt.begin(ctx->kernelTiming, "kernel.lap_gather+fisheye_2nn_batch", st);
     rc = ft_launch_bind_fisheye_batch(st, tb->d_arena, dJobs, n_frames, maxKp, A);
+    tb->evt.end(ctx->kernelTiming, st);
+    tb->evt.begin(ctx->kernelTiming, "kernel.build_grid_batch", st);
     if (rc == FT_OK && ctx->tuning.search_grid) rc = ft_launch_build_grid_batch(st, tb->d_arena, dJobs, n_frames, nlevelsMax, true);
+    tb->evt.end(ctx->kernelTiming, st);
     if (rc != FT_OK) return rc;
     if (wantTables) {
         const FtDeliverRec *dRecs = (const FtDeliverRec *)(tb->d_arena + tb->oWork + ((uint8_t *)hRecs - tb->h_in));

@@ -12,3 +12,4 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 out = bench.tracking_batch_leg(orb, ctx, B=B, steps=steps)
 out = {k: v for k, v in out.items() if not k.startswith("_")}
 print(json.dumps(out))
+
