@@ -49,7 +49,25 @@ WORKLOADS = {
 }
 NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_JSON = "r04_traffic.json"
+TRAFFIC_JSON = "r05_traffic.json"
+MARGINAL_JSON = "r05_marginal_costs.json"
+
+
+def csrc_stamp(version: str) -> str:
+    """the hash of fasttrack_amd/csrc a library was built from (ft_version: '... csrc:<hash>')"""
+    return version.rsplit("csrc:", 1)[1].strip() if "csrc:" in version else ""
+
+
+def load_profile(name, lib_stamp):
+    """a committed profile artefact (profiles/<name>) - only if it was measured on THIS library: traffic per launch and marginal
+    costs are properties of the kernels' code, so an artefact stamped with another csrc hash (or with none) yields {}"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}, "missing"
+    if not lib_stamp or d.get("csrc") != lib_stamp:
+        return {}, f"stale: profiled on csrc {d.get('csrc')}, this library is {lib_stamp}"
+    return d, "current"
 
 
 def usable_cpus():
@@ -202,6 +220,24 @@ def stereo_leg(orb, ctx, name, w, h, nf, B, steps, warmup, mosaic=0, planes=Fals
     run(steps)
     ctx.synchronize()
     dt = time.perf_counter() - t0
+    # the leg's dominant kernel against its roofline: a short run of its own with HIP events on the launching streams
+    ctx.reset_stats()
+    ctx.set_kernel_timing(True)
+    run(4)
+    ctx.synchronize()
+    ctx.set_kernel_timing(False)
+    roof = None
+    try:
+        tot_, n_ = ctx.get_stat("kernel.fast_cells")
+        if n_:
+            bytes_per_launch = 4.0 * 2.0 * B * sum(level_pixels(w, h)) / n_   # 4 steps x 2 B images, every pyramid pixel read once
+            ach = bytes_per_launch / (tot_ / n_ / 1e3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": tot_ / n_, "launches_timed": n_,
+                    "note": "algorithmic bytes (every pyramid pixel once) / HIP-event duration on the launching stream; the duration is the "
+                            "kernel's residency beside the other lanes' kernels"}
+    except Exception:
+        pass
     fe = fes[(steps - 1) % 2]
     kps = int(fe._nL[:B].sum() + fe._nR[:B].sum())
     nL = int(fe._nL[:B].sum())
@@ -214,7 +250,7 @@ def stereo_leg(orb, ctx, name, w, h, nf, B, steps, warmup, mosaic=0, planes=Fals
            "inputs": "resident in HBM before the timed region", "keypoints_per_s": kps * steps / dt, "keypoints_per_frame": kps / B,
            "stereo_matches_per_frame": matches / B, "stereo_match_fraction": matches / max(nL, 1),
            "device_octree_fallbacks": ctx.get_stat("stereo.device_octree_fallbacks")[1] - f1,
-           "device_octree_fallbacks_during_warmup": f1 - f0,
+           "device_octree_fallbacks_during_warmup": f1 - f0, "roofline": roof,
            "pipeline_hbm_read_frac": (B * steps / dt) * 2 * (3 * sum(level_pixels(w, h)) - level_pixels(w, h)[-1]) / (HBM_PEAK_GBS * 1e9)}
     for f in fes:
         f.close()
@@ -223,6 +259,32 @@ def stereo_leg(orb, ctx, name, w, h, nf, B, steps, warmup, mosaic=0, planes=Fals
     if cpu:
         out["cpu_baseline"] = cpu_baseline(w, h, nf, pairs, budget_s=cpu_budget_s)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def latency_leg(orb, ctx, reps=40):
+    """The reference's real call shape: ONE stereo pair in, results out (Frame::Frame, src/Frame.cc:102-147) - host images in
+    pageable and in pinned memory, keypoints / descriptors / mvuRight / mvDepth in host arrays on return; median of `reps` calls
+    through the latency-mode front end (one captured HIP graph per call shape)."""
+    out = {"metric": "latency of one stereo pair, extract + ComputeStereoMatches", "unit": "ms", "statistic": f"median of {reps} calls"}
+    for (w, h, nf) in ((752, 480, 1200), (1280, 720, 2000)):
+        intr = synth.intrinsics(w, h)
+        L, R = synth.make_stereo_pair(w, h, 5)
+        fe = orb.StereoFrontend(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, 1, intr["mbf"], intr["mb"])
+        Lp, Rp = ctx.pinned_array(L.shape, np.uint8), ctx.pinned_array(R.shape, np.uint8)
+        Lp[:], Rp[:] = L, R
+
+        def med(fn):
+            for _ in range(5):
+                fn()
+            t = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn()
+                t.append(time.perf_counter() - t0)
+            return 1e3 * float(np.median(t))
+        out[f"{w}x{h}_nf{nf}"] = {"pageable_frames_ms": med(lambda: fe.process([L], [R])), "pinned_frames_ms": med(lambda: fe.process([Lp], [Rp]))}
+        fe.close()
     return out
 
 
@@ -771,10 +833,8 @@ def main():
         # `roofline` is k_fast_cells (see below), the others follow in roofline_other_kernels.  HBM-side traffic per launch
         # comes from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live; FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes) and is reported when this run's launch shape equals the profiled one.
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))
-        except Exception:
-            tj = {}
+        lib_stamp = csrc_stamp(orb.version())
+        tj, tj_state = load_profile(TRAFFIC_JSON, lib_stamp)
         tk = tj.get("kernels", {})
         same_inputs = (tj.get("distinct_pairs") == D and tj.get("batch_pairs") == B and tj.get("workload") == args.workload and
                        not args.mosaic and args.density == 1.0 and args.scene == "objects")  # the profiled scenes are the default ones
@@ -810,15 +870,12 @@ def main():
         # committed measurement of the same workload.
         legs = [x for x in legs if x]
         roof = legs[0] if legs else None
-        try:
-            mc = json.load(open(os.path.join(ROOT, "profiles", "r04_marginal_costs.json")))
-        except Exception:
-            mc = {}
+        mc, mc_state = load_profile(MARGINAL_JSON, lib_stamp)
         if roof and mc.get("workload") == args.workload and mc.get("batch_pairs") == B and not args.mosaic and args.scene == "objects":
             ms = mc["marginal_ms_per_step"]["k_fast_cells"] / (roof["launches_timed"] / args.steps)
             ach = roof["bytes_per_launch"] / (ms / 1e3) / 1e9
             roof["at_marginal_cost"] = {"ms_per_launch": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-                                        "source": "profiles/r04_marginal_costs.json (tools/marginal_costs.py: FT_DEBUG_REPEAT=fast, same workload)"}
+                                        "source": f"profiles/{MARGINAL_JSON} (tools/marginal_costs.py: FT_DEBUG_REPEAT=fast, same workload, same csrc)"}
             # the same for the vector-issue bound: the launch's vector instructions (committed SQ pass) x 4 cycles on a
             # 16-lane SIMD / (1 024 SIMDs x 2.4 GHz x the launch's cost inside the pipeline) - ~1.0 says the kernel is priced
             # at its instruction stream, which is what "the chip is full" means for it
@@ -872,11 +929,14 @@ def main():
             "kernels": kern, "host_ms_per_step": host,
             "roofline": roof,
             "roofline_other_kernels": also,
+            "library": orb.version(),
+            "profiles": {TRAFFIC_JSON: tj_state, MARGINAL_JSON: mc_state},
             "host_in": host_in,
         }
         # The other workloads north_star names (N = 1 only: they are this box's numbers, not part of the scaling curve).  The
         # headline's buffers are released first; every leg builds and releases its own.
         out["workloads"] = None
+        out["latency"] = None
         if world == 1 and not args.no_workloads:
             for f in fes:
                 f.close()
@@ -895,6 +955,7 @@ def main():
             wl["dense_1280x720_nf2000"] = stereo_leg(orb, ctx, "dense", 1280, 720, 2000, WB, 16, 4, mosaic=10, cpu=cpu, cpu_budget_s=3.0)
             wl["planes_1280x720_nf2000"] = stereo_leg(orb, ctx, "planes", 1280, 720, 2000, WB, 16, 4, planes=True, cpu=cpu, cpu_budget_s=3.0)
             out["workloads"] = wl
+            out["latency"] = latency_leg(orb, ctx)
         if not args.no_cpu_baseline:  # rank 0, after the last barrier: the other ranks are done and the host cores are free
             out["cpu_baseline"] = cpu_baseline(w, h, nf, pairs)
             out["gpu_over_cpu_per_gpu"] = fps / world / out["cpu_baseline"]["value"]

@@ -198,7 +198,8 @@ bool ft_parse_lane_map(const char *text, std::vector<int> &map, std::string &err
 
 extern "C" {
 
-const char *ft_version(void) { return "fasttrack_amd 0.1 (gfx950)"; }
+#include "version.inc"  // FT_CSRC_HASH: sha1 of the csrc sources this library was built from (Makefile)
+const char *ft_version(void) { return "fasttrack_amd 0.5 (gfx950) csrc:" FT_CSRC_HASH; }
 
 const char *ft_last_error(void) { return g_lastError.c_str(); }
 

@@ -158,6 +158,11 @@ class DeviceBuffer:
             pass
 
 
+def version() -> str:
+    """ft_version(): library version and the hash of the csrc sources it was built from ('... csrc:<hash>')"""
+    return lib().ft_version().decode()
+
+
 def _image_ptrs(images, on_device):
     n = len(images)
     arr = (C.c_void_p * n)()

@@ -58,7 +58,7 @@ def test_bench_four_ranks_folded_onto_one_device():
 
 def test_bench_single_rank_line_has_the_contract_fields():
     r = _run(["--steps", "3", "--warmup", "1", "--batch", "32", "--workload", "stereo_752x480_nf1200", "--no-cpu-baseline",
-              "--workload-batch", "20", "--workload-frames", "6"])
+              "--workload-batch", "20", "--workload-frames", "6", "--tracking-batch", "24"])
     assert r["n_gpus"] == 1 and r["metric"] == "frames/sec extract+match" and r["unit"] == "frames/s"
     assert r["dtype"] == "u8" and r["vs_baseline"] is None and r["higher_is_better"] is True
     roof = r["roofline"]
@@ -77,3 +77,28 @@ def test_bench_single_rank_line_has_the_contract_fields():
     for th in ("7", "15"):
         assert t["by_th"][th]["map_points_per_s"] > 0 and t["by_th"][th]["hamming_compares_per_frame"] > 1000 and t["by_th"][th]["matches_per_frame"] > 50
     assert t["by_th"]["15"]["hamming_compares_per_frame"] > t["by_th"]["7"]["hamming_compares_per_frame"]  # wider windows
+    # ... every stereo leg with the roofline of its dominant kernel
+    for k in ("stereo_752x480_nf1200", "dense_1280x720_nf2000", "planes_1280x720_nf2000"):
+        ro = wl[k]["roofline"]
+        assert ro["bound"] == "hbm" and ro["kernel"] == "k_fast_cells" and ro["peak"] == 8000.0 and 0 < ro["frac"] < 1
+        assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12 and ro["avg_launch_ms"] > 0
+    # configs[3] in its throughput form: B frames per launch (ft_tracked_batch), its kernels' event times and its roofline
+    thr = t["throughput"]
+    assert thr["batch_frames"] == thr["distinct_frames"] == 24 and set(thr["by_th"]) == {"7", "15"}
+    assert thr["value"] == thr["by_th"]["7"]["value"] > t["value"]          # one launch set for 24 frames beats a frame at a time
+    assert thr["launches_per_frame"] < 8
+    ro = thr["roofline"]
+    assert ro["bound"] == "valu" and "k_fisheye_2nn_batch" in ro["kernel"] and 0 < ro["frac"] < 1 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+    assert thr["hamming_compares_per_frame"]["fisheye_2nn"] > 1e6 and thr["hamming_compares_per_frame"]["searches(first passes)"] > 1e4
+    for kname in ("search_last_batch(first pass)", "search_local_batch(first pass)", "lap_gather+fisheye_2nn_batch"):
+        assert thr["kernels"][kname]["avg_launch_ms"] > 0, kname
+    # the reference's real call shape: one stereo pair in, results out
+    lat = r["latency"]
+    for shape in ("752x480_nf1200", "1280x720_nf2000"):
+        assert 0 < lat[shape]["pinned_frames_ms"] < 20 and 0 < lat[shape]["pageable_frames_ms"] < 20
+    # the line names the library it ran and says whether the committed profile artefacts belong to it
+    assert "csrc:" in r["library"] and set(r["profiles"]) == {"r05_traffic.json", "r05_marginal_costs.json"}
+    for state in r["profiles"].values():
+        assert state == "current" or state == "missing" or state.startswith("stale")
+    if not all(v == "current" for v in r["profiles"].values()):
+        assert roof["traffic"] is None or r["profiles"]["r05_traffic.json"] == "current"

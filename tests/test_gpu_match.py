@@ -364,8 +364,9 @@ def test_search_local_points_mono_stereo(ctx, th, dense):
         assert np.array_equal(g[k], o[k]), k
 
 
-def test_search_local_points_two_cameras(ctx):
-    w, h, nf = 512, 512, 1500
+@pytest.mark.parametrize("nf", [1500, 2000])  # 2000 = BASELINE configs[3] (TUM-VI: nFeatures 2000)
+def test_search_local_points_two_cameras(ctx, nf):
+    w, h = 512, 512
     fr = sc.fisheye_frame_scenario(w, h, nf, 9)
     sf, _ = ob.scale_factors(1.2, 8)
     pts = sc.two_camera_points(fr, sf, 3)
@@ -400,10 +401,11 @@ def test_search_last_frame_pinhole(ctx, th, fwd, bwd, ori):
     assert np.array_equal(gF.holder_obs, oF.holder_obs)
 
 
-def test_search_last_frame_two_cameras_kb8(ctx):
+@pytest.mark.parametrize("nf", [1500, 2000])  # 2000 = BASELINE configs[3] (TUM-VI: nFeatures 2000)
+def test_search_last_frame_two_cameras_kb8(ctx, nf):
     """fisheye stereo (config 4): KannalaBrandt8 projection (atan2f / cosf / sinf as glibc evaluates them, libm_f32.h),
     right-camera search through Trl: assignments, distances and indices equal the oracle's."""
-    w, h, nf = 512, 512, 1500
+    w, h = 512, 512
     fr = sc.fisheye_frame_scenario(w, h, nf, 10)
     sf, _ = ob.scale_factors(1.2, 8)
     cam = [190.978, 190.973, 254.93, 256.90, 0.0034, 0.0007, -0.0020, 0.00020]  # TUM-VI-like KB8
@@ -459,9 +461,10 @@ def test_search_last_frame_sophus_pose_form(ctx, th, fwd, bwd, ori):
         orb.KernelController.launchPoseEstimationKernel(ctx, gF, last, orb.SE3([0.5, 0, 0, 0.5], t), th)  # not a unit quaternion
 
 
-def test_search_last_frame_sophus_pose_form_two_cameras_kb8(ctx):
+@pytest.mark.parametrize("nf", [1500, 2000])  # 2000 = BASELINE configs[3] (TUM-VI: nFeatures 2000)
+def test_search_last_frame_sophus_pose_form_two_cameras_kb8(ctx, nf):
     """two-camera KB8 frame: Tcw and GetRelativePoseTrl() both in the Sophus form"""
-    w, h, nf = 512, 512, 1500
+    w, h = 512, 512
     fr = sc.fisheye_frame_scenario(w, h, nf, 11)
     sf, _ = ob.scale_factors(1.2, 8)
     cam = list(sc.KB8_CAM)
@@ -517,13 +520,14 @@ def test_is_in_frustum_pinhole_bit_exact(ctx):
     assert orb.is_in_frustum(ctx, gF, orb.make_pose(Rcw, tcw), empty, 0.5, LOG_SF)["n"] == 0
 
 
-def test_is_in_frustum_two_cameras_kb8(ctx):
+@pytest.mark.parametrize("nf", [1500, 2000])  # 2000 = BASELINE configs[3] (TUM-VI: nFeatures 2000)
+def test_is_in_frustum_two_cameras_kb8(ctx, nf):
     """fisheye stereo (Nleft != -1): both cameras through isInFrustumChecks, right camera pose composed from Trl / Tlr.
     KannalaBrandt8::project uses atan2f / cosf / sinf of the host libm; the device evaluates glibc's algorithms for the
     three (libm_f32.h, checked against the host on every argument), so every flag, level and float equals the oracle's
     bit for bit - as for the pinhole model."""
     w, h = 512, 512
-    fr = sc.fisheye_frame_scenario(w, h, 1500, 10)
+    fr = sc.fisheye_frame_scenario(w, h, nf, 10)
     sf, _ = ob.scale_factors(1.2, 8)
     cam = [190.978, 190.973, 254.93, 256.90, 0.0034, 0.0007, -0.0020, 0.00020]
     Trl = np.concatenate([np.eye(3), [[-0.1], [0.0], [0.0]]], 1).astype(np.float32)
@@ -864,3 +868,17 @@ print("HASH", hs.hexdigest(), ctx.get_stat("tracked.track_local_map.passes")[0])
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][-1])
     assert outs[0] == outs[1], outs
+
+
+def test_randomized_soaks_replayed_in_the_suite():
+    """50 trials of tests/tools/soak_search.py (random frame sizes, feature counts up to 2000, two-camera KB8 frames, both
+    searches, the frustum, the resident frame, Sophus-form poses) and 4 batches of tests/tools/soak_batch.py (B frames per launch),
+    all compared with the oracle for equality"""
+    import importlib.util
+    import os
+    tools = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools")
+    for name, argv in (("soak_search", ["--trials", "50", "--seed", "5"]), ("soak_batch", ["--trials", "4", "--seed", "5", "--frames", "12"])):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(tools, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert mod.main(argv) == 0, name

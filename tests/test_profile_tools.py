@@ -36,3 +36,32 @@ def test_bench_line_reports_the_committed_traffic(tag):
     assert abs(r["traffic"] - t["traffic_bytes_per_launch"]) / t["traffic_bytes_per_launch"] < 0.01
     assert d["config"]["distinct_pairs"] == d["config"]["batch_pairs_per_gpu"] == 512
     assert d["host_in"]["value"] < d["value"] and d["cpu_baseline"]["kind"] == "port" and d["device_octree_fallbacks"] == 0
+
+
+def test_a_profile_of_another_library_build_is_dropped(tmp_path, monkeypatch):
+    """bench.py reports PMC traffic / marginal costs from committed artefacts only while it runs the library they were measured
+    on: the artefacts carry the hash of fasttrack_amd/csrc (ft_version), a stale or unstamped one yields nothing"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.csrc_stamp("fasttrack_amd 0.5 (gfx950) csrc:0123456789ab") == "0123456789ab" and bench.csrc_stamp("old library") == ""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "a.json").write_text(json.dumps({"csrc": "0123456789ab", "kernels": {"k": {"traffic_bytes_per_launch": 1}}}))
+    (prof / "b.json").write_text(json.dumps({"kernels": {}}))
+    d, state = bench.load_profile("a.json", "0123456789ab")
+    assert state == "current" and d["kernels"]["k"]["traffic_bytes_per_launch"] == 1
+    d, state = bench.load_profile("a.json", "ffffffffffff")
+    assert d == {} and state.startswith("stale")
+    assert bench.load_profile("b.json", "0123456789ab")[0] == {}           # never stamped
+    assert bench.load_profile("a.json", "")[0] == {}                        # a library without a stamp
+    assert bench.load_profile("missing.json", "0123456789ab") == ({}, "missing")
+    # the library's own stamp is what its Makefile computes: the hash of the csrc sources
+    from fasttrack_amd import orb
+    import hashlib, glob
+    csrc = os.path.join(ROOT, "fasttrack_amd", "csrc")
+    files = sorted(f for ext in ("*.cpp", "*.hip", "*.h", "*.inc") for f in glob.glob(os.path.join(csrc, ext)) if not f.endswith("version.inc"))
+    h = hashlib.sha1(b"".join(open(f, "rb").read() for f in files)).hexdigest()[:12]
+    assert bench.csrc_stamp(orb.version()) == h

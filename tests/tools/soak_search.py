@@ -56,11 +56,11 @@ def diff(g, o, keys):
     return None
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=50)
     ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
     ctx = orb.Context(0)
     sf, _ = ob.scale_factors(1.2, 8)

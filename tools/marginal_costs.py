@@ -37,7 +37,9 @@ for key, name in names.items():
     doubled[key] = d["ms_per_step"]
     marg[name] = d["ms_per_step"] - base["ms_per_step"]
 B = base["config"]["batch_pairs_per_gpu"]
-json.dump({"method": __doc__.split("usage")[0].strip(), "workload": base["config"]["workload"], "batch_pairs": B,
+lib = base.get("library", "")
+json.dump({"method": __doc__.split("usage")[0].strip(), "csrc": lib.rsplit("csrc:", 1)[1].strip() if "csrc:" in lib else None,
+           "workload": base["config"]["workload"], "batch_pairs": B,
            "distinct_pairs": base["config"]["distinct_pairs"], "baseline_ms_per_step": base["ms_per_step"],
            "baseline_frames_per_s": base["value"], "ms_per_step_with_kernel_doubled": doubled, "marginal_ms_per_step": marg,
            "marginal_ms_per_128_pairs": {k: v * 128.0 / B for k, v in marg.items()},

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="pairs per step")
     ap.add_argument("--distinct", type=int, default=512)
     ap.add_argument("--steps", type=int, default=7, help="passes over the batch the profiled run made (warmup + steps)")
+    ap.add_argument("--csrc", default=None, help="hash of fasttrack_amd/csrc the profiled library was built from (ft_version); bench.py "
+                                                 "uses the file only while it runs that library")
     a = ap.parse_args()
     d = {}
     for line in open(a.summary):
@@ -50,7 +52,7 @@ def main():
             e["images_per_launch"] = images_per_step * a.steps / e["launches"] if e["launches"] else None
         if "valu_per_launch" in e and e.get("avg_us"):
             e["valu_issue_frac"] = e["valu_per_launch"] * 4 / (SIMDS * e["avg_us"] * 1e-6 * CLOCK_HZ)
-    json.dump({"source": a.summary, "workload": a.workload, "batch_pairs": a.batch, "distinct_pairs": a.distinct,
+    json.dump({"source": a.summary, "csrc": a.csrc, "workload": a.workload, "batch_pairs": a.batch, "distinct_pairs": a.distinct,
                "note": "per launch; bench of %d pairs per step, %d passes profiled; FETCH_SIZE doubled (128-B requests counted at 64 B)"
                        % (a.batch, a.steps), "kernels": d}, open(a.out, "w"), indent=1)
     print(json.dumps(d.get("k_fast_cells"), indent=1))
