@@ -403,7 +403,7 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
     return out
 
 
-def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.0), pipelined=True):
+def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.0), pipelined=True, in_flight=3):
     """BASELINE.json configs[3] as a THROUGHPUT workload: B independent 512x512 KannalaBrandt8 stereo frames per step (the
     frames B camera streams deliver for one time step), every stage ONE launch over all of them (ft_tracked_batch_*):
       extraction of the B left and the B right images, frames resident in HBM, lapping areas [0, 511]      (ft_extract_batch x 2,
@@ -412,8 +412,9 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
       from what the extractors left in HBM                                                                   (ft_tracked_batch_bind_fisheye)
       SearchByProjection(CurrentFrame, LastFrame, th)                                                       (ft_tracked_batch_search_last_frame)
       isInFrustum + SearchByProjection(CurrentFrame, local map points, th)                                   (ft_tracked_batch_track_local_map)
-    pipelined: the extraction of step k + 1 (a second pair of extractors, a worker thread) runs while step k is searched - two
-    steps in flight, like the two stereo front ends of the headline.  Host in / out per step: the map points of every frame up
+    pipelined: `in_flight` steps in flight, like the two stereo front ends of the headline - that many host threads, each with its
+    own pair of extractors and its own batch object (a batch has a stream of its own), take the steps in turn, so that the passes
+    of one step run beside the extraction and the host side (staging of the map points, replay of the writes) of the others.  Host in / out per step: the map points of every frame up
     (pageable host arrays), keypoints, descriptors, assignments, match counts and frustum fields down.  Every frame of the
     batch is a distinct image pair with its own last-frame points, local map (M points) and poses, built once from the frame's
     own keypoints (untimed)."""
@@ -427,7 +428,7 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
     Trl = np.concatenate([np.eye(3), [[-0.101], [0.0], [0.0]]], 1).astype(np.float32)
     TLR = (0.101, 0.0, 0.0)
     LOG_SF = float(np.float32(np.log(np.float32(SCALE))))
-    nlanes = 2 if pipelined else 1
+    nlanes = max(in_flight, 1) if pipelined else 1
     pairs = [synth.make_planes_pair(w, h, seed=7000 + i) for i in range(B)]
     devL, devR = ctx.to_device(np.stack([p[0] for p in pairs])), ctx.to_device(np.stack([p[1] for p in pairs]))
     fb = w * h
@@ -448,9 +449,12 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
         lanes.append(ln)
     sf = np.asarray(lanes[0].exL.GetScaleFactors(), np.float32)
     cap = lanes[0].exL.max_keypoints
-    tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=2 * cap + 64, max_points=max(M, cap) + 64)
-    two = concurrent.futures.ThreadPoolExecutor(2)
-    ahead = concurrent.futures.ThreadPoolExecutor(1)
+    for ln in lanes:
+        ln.tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=2 * cap + 64, max_points=max(M, cap) + 64)
+        ln.part = {"extract_left_right": 0.0, "bind_fisheye (order, match, grids)": 0.0, "search_last_frame": 0.0, "track_local_map": 0.0}
+    tb = lanes[0].tb
+    two = concurrent.futures.ThreadPoolExecutor(2 * nlanes)
+    ahead = concurrent.futures.ThreadPoolExecutor(nlanes)
 
     def extract(ln):
         # the two cameras on two host threads, as Frame's constructor runs them (src/Frame.cc:1144-1147)
@@ -466,7 +470,7 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
                                descriptors=np.zeros((int(ln.nL[f] + ln.nR[f]), 32), np.uint8), scale_factors=sf, bounds=sc.frame_bounds(w, h),
                                left_to_right=np.zeros(max(int(ln.nL[f]), 1), np.int32), right_to_left=np.zeros(max(int(ln.nR[f]), 1), np.int32),
                                cam_model=1, cam=cam, Trl=Trl) for f in range(B)]
-        ln.meta = tb.prepare_frames(views)
+        ln.meta = ln.tb.prepare_frames(views)
     l0 = lanes[0]
     nL, nR = l0.nL.copy(), l0.nR.copy()
     scen = []
@@ -477,31 +481,28 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
         scen.append((last, Tcw_last, pts, Rcw, tcw))
     pl_last = tb.prepare_last([s_[0] for s_ in scen], [s_[1] for s_ in scen])
     pl_local = tb.prepare_local([orb.make_pose(s_[3], s_[4], TLR) for s_ in scen], [s_[2] for s_ in scen])
-    part = {"extract_left_right (wait)": 0.0, "bind_fisheye (order, match, grids)": 0.0, "search_last_frame": 0.0, "track_local_map": 0.0}
+    def pipeline(ln, n, th):
+        for _ in range(n):
+            t0 = time.perf_counter()
+            extract(ln)
+            t1 = time.perf_counter()
+            ln.tb.bind_fisheye(ln.exL, ln.exR, ln.meta, lap, lap, want_tables=False)
+            t2 = time.perf_counter()
+            ln.tb.search_last_frame(pl_last, th=th, copy=False)
+            t3 = time.perf_counter()
+            ln.tb.track_local_map(pl_local, viewing_cos_limit=0.5, log_scale_factor=LOG_SF, th=th, copy=False)
+            t4 = time.perf_counter()
+            for k_, v_ in zip(ln.part, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                ln.part[k_] += v_
 
     def run(n, th):
-        """n steps; with two lanes the extraction of step k + 1 is in flight while step k is searched"""
-        fut = ahead.submit(extract, lanes[0]) if pipelined else None
-        for k in range(n):
-            ln = lanes[k % nlanes]
-            t0 = time.perf_counter()
-            if pipelined:
-                fut.result()
-                fut = ahead.submit(extract, lanes[(k + 1) % nlanes]) if k + 1 < n else None
-            else:
-                extract(ln)
-            t1 = time.perf_counter()
-            tb.bind_fisheye(ln.exL, ln.exR, ln.meta, lap, lap, want_tables=False)
-            t2 = time.perf_counter()
-            tb.search_last_frame(pl_last, th=th, copy=False)
-            t3 = time.perf_counter()
-            tb.track_local_map(pl_local, viewing_cos_limit=0.5, log_scale_factor=LOG_SF, th=th, copy=False)
-            t4 = time.perf_counter()
-            for k_, v_ in zip(part, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
-                part[k_] += v_
+        """n steps, dealt to the lanes; every lane works through its steps on a host thread of its own"""
+        futs = [ahead.submit(pipeline, ln, n // nlanes + (1 if i < n % nlanes else 0), th) for i, ln in enumerate(lanes)]
+        for f_ in futs:
+            f_.result()
     out = {"metric": "frames/sec extract + SearchByProjection (last frame, local map), B frames per launch", "unit": "frames/s",
            "batch_frames": B, "distinct_frames": B, "steps": steps, "image": [w, h], "nfeatures": nf, "local_map_points": M,
-           "mode": "two steps in flight (extraction of step k + 1 beside the searches of step k)" if pipelined else "one step at a time",
+           "mode": f"{nlanes} steps in flight ({nlanes} host threads, each with its extractors and its batch)" if nlanes > 1 else "one step at a time",
            "inputs": "images resident in HBM before the timed region; map points in pageable host memory, uploaded inside it",
            "outputs": "keypoints, descriptors, assignments, match counts, frustum fields in host memory", "by_th": {}}
     for th in ths:
@@ -510,8 +511,9 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
             assert np.array_equal(ln.nL, nL) and np.array_equal(ln.nR, nR)
         ctx.synchronize()
         ctx.reset_stats()
-        for k_ in part:
-            part[k_] = 0.0
+        for ln in lanes:
+            for k_ in ln.part:
+                ln.part[k_] = 0.0
         t0 = time.perf_counter()
         run(steps, th)
         ctx.synchronize()
@@ -527,6 +529,7 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
                 continue
             stats[nm_ + ("_per_call" if nm_.endswith("passes") else "_ms_per_call")] = tot_ / n_ if n_ else None
         nmatch = int(tb._nm.sum())
+        part = {k_: sum(ln.part[k_] for ln in lanes) for k_ in lanes[0].part}   # host-thread time per step (the lanes' steps overlap)
         out["by_th"][str(int(th))] = {"value": B * steps / dt, "ms_per_step": 1e3 * dt / steps, "us_per_frame": 1e6 * dt / (B * steps),
                                       "map_points_per_s": (int(nL.sum()) + B * M) * steps / dt,
                                       "local_map_matches_per_frame": nmatch / B,
@@ -539,7 +542,7 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
     th0 = ths[0]
     ctx.reset_stats()
     ctx.set_kernel_timing(True)
-    run(2, th0)
+    pipeline(lanes[0], 2, th0)   # (one lane alone: an event pair brackets the kernels of ONE stream)
     ctx.synchronize()
     ctx.set_kernel_timing(False)
     kern = {}
@@ -582,8 +585,8 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
     out["launches_per_frame"] = launches / B
     out["_scen"] = scen
     out["_frames"] = (l0.kL, l0.kR, l0.dL, l0.dR, nL, nR)
-    tb.close()
     for ln in lanes:
+        ln.tb.close()
         ln.exL.close()
         ln.exR.close()
     devL.free()

@@ -158,6 +158,8 @@ struct FtBindArgs {
 // keypoints / descriptors of every frame into the reference's order, then the 2-NN + ratio matching of the lapping subsets
 int ft_launch_bind_fisheye_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxKp, const FtBindArgs &A);
 int ft_launch_fill_claims_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxWords);
+// behind the first pass of a batch: every candidate list with its best candidates at the front (cache_partition, kernels_search.hip)
+int ft_launch_cache_partition_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints);
 int ft_launch_deliver_batch(hipStream_t st, const FtDeliverRec *recs, int nRecs, int maxWords, int parity);
 int ft_launch_build_grid_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxLevels, bool twoCam);
 int ft_launch_frustum_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxM, float viewingCosLimit, float logScaleFactor,

@@ -269,12 +269,59 @@ __device__ __forceinline__ void cache_append(const CacheBuild &B, unsigned long 
     const int pos = atomicAdd(B.counter, 1);
     if (pos < FT_CACHE_CAP) B.slot[1 + pos] = key;
 }
+// The best candidates first.  A later pass needs the smallest (two smallest) UNLOCKED keys of a list, and a key's order is
+// its distance before anything else: with the keys of the FT_CACHE_HEAD (or a few more) smallest distances at the front of
+// the list, a pass that finds enough unlocked keys among them need not look at the rest - at th 15 a window holds ~190
+// candidates, and every candidate looked at is a 32-byte record read.  A kernel of its own does it once behind the first pass
+// of a batch (k_cache_partition_batch; inside the search kernels it cost them 45 registers): the smallest distance D with at
+// least FT_CACHE_HEAD keys <= D by bisection over the 9 bits of the distance (a count per step), then a stable partition of
+// the list by dist <= D.  The head's length goes into the meta word; a list that is short, or whose head would not be short
+// (many equal distances), keeps head = count - as every list of the single-frame path does.
+#define FT_CACHE_HEAD 16
+#define FT_CACHE_HEAD_MAX 48
+__device__ __forceinline__ int cache_partition(unsigned long long *slot, int n, int lane) {
+    constexpr int PER = (FT_CACHE_CAP + 63) / 64;
+    unsigned long long k[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) k[j] = (lane + 64 * j < n) ? slot[1 + lane + 64 * j] : KEY_NONE;
+    int lo = 0, hi = 256;  // smallest D in [0, 256] with count(dist <= D) >= FT_CACHE_HEAD (every distance is <= 256)
+    while (lo < hi) {      // wave-uniform
+        const int mid = (lo + hi) >> 1;
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) c += (k[j] != KEY_NONE && key_dist(k[j]) <= mid) ? 1 : 0;
+        if (wave_sum_i32(c) >= FT_CACHE_HEAD) hi = mid;
+        else lo = mid + 1;
+    }
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) c += (k[j] != KEY_NONE && key_dist(k[j]) <= lo) ? 1 : 0;
+    const int head = wave_sum_i32(c);
+    if (head > FT_CACHE_HEAD_MAX || head >= n) return n;
+    int front = 0, back = head;  // next free position of the two parts
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const bool have = k[j] != KEY_NONE, sel = have && key_dist(k[j]) <= lo;
+        const unsigned long long bs = __ballot(sel), bo = __ballot(have && !sel);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (sel) slot[1 + front + __popcll(bs & below)] = k[j];
+        else if (have) slot[1 + back + __popcll(bo & below)] = k[j];
+        front += __popcll(bs);
+        back += __popcll(bo);
+    }
+    return head;
+}
 __device__ __forceinline__ void cache_end(const CacheBuild &B, int lane, bool anyInBox) {
     if (B.build) {
         wave_lds_sync();
-        if (lane == 0) B.slot[0] = (unsigned long long)(unsigned)*B.counter | ((unsigned long long)(anyInBox ? 1 : 0) << 32);
+        const int n = *B.counter;
+        if (lane == 0)  // (head = count: not partitioned)
+            B.slot[0] = (unsigned long long)(unsigned)n | ((unsigned long long)(anyInBox ? 1 : 0) << 32) |
+                        ((unsigned long long)(unsigned)min(n, FT_CACHE_CAP) << 40);
     }
 }
+// length of the list's head (cache_partition): <= the count
+__device__ __forceinline__ int cache_head(unsigned long long meta) { return (int)((meta >> 40) & 0x3ffull); }
 // 0 = not built yet, 1 = usable (count = candidates filed), 2 = built but too many candidates: scan the window again
 // the same from a meta word that is already in a register (slot != null)
 __device__ __forceinline__ int cache_state_of(unsigned long long meta, int &count, bool &anyInBox) {
@@ -282,7 +329,7 @@ __device__ __forceinline__ int cache_state_of(unsigned long long meta, int &coun
     anyInBox = false;
     if (meta == KEY_NONE) return 0;
     count = (int)(unsigned)meta;
-    anyInBox = (meta >> 32) != 0;
+    anyInBox = ((meta >> 32) & 1ull) != 0;
     return count <= FT_CACHE_CAP ? 1 : 2;
 }
 __device__ __forceinline__ int cache_state(const unsigned long long *slot, int &count, bool &anyInBox) {
@@ -292,7 +339,7 @@ __device__ __forceinline__ int cache_state(const unsigned long long *slot, int &
     const unsigned long long meta = slot[0];
     if (meta == KEY_NONE) return 0;
     count = (int)(unsigned)meta;
-    anyInBox = (meta >> 32) != 0;
+    anyInBox = ((meta >> 32) & 1ull) != 0;
     return count <= FT_CACHE_CAP ? 1 : 2;
 }
 
@@ -956,8 +1003,9 @@ __device__ __forceinline__ FtClaims job_claims(const FtBatchJob &J, const Rebase
 
 // slowList != 0: a later pass - the points the lean kernel (k_search_*_lean, below) could not serve from the candidate cache, by
 // a grid-stride loop over the frame's slow list of this pass's parity; the pass's clears were done by the lean kernel
+template <bool slowList>
 __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur,
-                                                                          int fPrev, int fReset, float th, int slowList) {
+                                                                          int fPrev, int fReset, float th) {
     const FtBatchJob &J = jobs[blockIdx.y];
     if (J.nPoints <= 0) return;
     int *res;
@@ -968,7 +1016,7 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last_batch(const 
     FtDevLastPoints L = J.L;
     L.valid = rb(L.valid); L.worldPos = rb(L.worldPos); L.desc = rb(L.desc); L.octave = rb(L.octave);
     const FramePtrs Q = frame_ptrs(J.F, rb);
-    if (!slowList) {
+    if constexpr (!slowList) {
         if (!claims_begin_pass(C)) return;
         const int i = blockIdx.x * FT_SEARCH_WPB + wave;
         if (i >= J.L.N) return;
@@ -976,7 +1024,7 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last_batch(const 
         last_point(J.F, Q, L, C, J.Tcw, th, J.forward, J.backward, i, lane, r4, raw, &cacheCounter[wave]);
         claims_file(C, res, i, lane, r4);
         return;
-    }
+    } else {
     if (C.flagPrev && shared_load(C.flagPrev) == -1) return;
     const int *slow = rb(J.slow);
     const int count = slow[pass & 1];
@@ -986,10 +1034,12 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last_batch(const 
         last_point(J.F, Q, L, C, J.Tcw, th, J.forward, J.backward, i, lane, r4, raw, &cacheCounter[wave]);
         claims_file(C, res, i, lane, r4);
     }
+    }
 }
 
+template <bool slowList>
 __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_local_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur,
-                                                                           int fPrev, int fReset, float th, float nnRatio, int slowList) {
+                                                                           int fPrev, int fReset, float th, float nnRatio) {
     const FtBatchJob &J = jobs[blockIdx.y];
     if (J.nPoints <= 0) return;
     int *res;
@@ -1005,7 +1055,7 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_local_batch(const
     P.projX = rb(P.projX); P.projY = rb(P.projY); P.projXR = rb(P.projXR); P.projYR = rb(P.projYR);
     P.desc = rb(P.desc);
     const FramePtrs Q = frame_ptrs(J.F, rb);
-    if (!slowList) {
+    if constexpr (!slowList) {
         if (!claims_begin_pass(C)) return;
         const int i = blockIdx.x * FT_SEARCH_WPB + wave;
         if (i >= J.P.M) return;
@@ -1013,7 +1063,7 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_local_batch(const
         local_point(J.F, Q, P, C, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
         claims_file(C, res, i, lane, r4);
         return;
-    }
+    } else {
     if (C.flagPrev && shared_load(C.flagPrev) == -1) return;
     const int *slow = rb(J.slow);
     const int count = slow[pass & 1];
@@ -1022,6 +1072,7 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_local_batch(const
         int r4[4];
         local_point(J.F, Q, P, C, th, nnRatio, i, lane, r4, raw, &cacheCounter[wave]);
         claims_file(C, res, i, lane, r4);
+    }
     }
 }
 
@@ -1092,12 +1143,21 @@ __global__ __launch_bounds__(256) void k_search_local_lean(const FtBatchJob *__r
             if (cache_state_of(metaL, nCached, anyBox) != 1) slowPoint = true;
             else {
                 unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
-                for (int t = sub; t < nCached; t += 16) {
+                const int head = cache_head(metaL);
+                for (int t = sub; t < head; t += 16) {
                     const unsigned long long key = slotL[1 + t];
                     if (is_locked(C, key_idx(key), i, key_held(key))) continue;
                     two_min_insert(k0, k1, key);
                 }
                 row_two_min(k0, k1);
+                if (k1 == KEY_NONE && head < nCached) {  // fewer than two unlocked keys in the head: the rest of the list decides
+                    for (int t = head + sub; t < nCached; t += 16) {
+                        const unsigned long long key = slotL[1 + t];
+                        if (is_locked(C, key_idx(key), i, key_held(key))) continue;
+                        two_min_insert(k0, k1, key);
+                    }
+                    row_two_min(k0, k1);
+                }
                 int bd = 256, bd2 = 256, bl = -1, bl2 = -1, bi = -1;
                 if (k0 != KEY_NONE) { bd = key_dist(k0); bi = key_idx(k0); bl = key_octave(k0); }
                 if (k1 != KEY_NONE) { bd2 = key_dist(k1); bl2 = key_octave(k1); }
@@ -1119,14 +1179,19 @@ __global__ __launch_bounds__(256) void k_search_local_lean(const FtBatchJob *__r
             if (cache_state_of(metaR, nCached, anyBox) != 1) slowPoint = true;
             else {
                 unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
-                for (int t = sub; t < nCached; t += 16) {
-                    const unsigned long long key = slotR[1 + t];
-                    const int g = key_idx(key) + F.Nleft;
-                    const bool locked = (g == sideL) ? (obsI > 0) : is_locked(C, g, i, key_held(key));
-                    if (locked) continue;
-                    two_min_insert(k0, k1, key);
-                }
-                row_two_min(k0, k1);
+                const int head = cache_head(metaR);
+                auto scan = [&](int from, int to) {
+                    for (int t = from + sub; t < to; t += 16) {
+                        const unsigned long long key = slotR[1 + t];
+                        const int g = key_idx(key) + F.Nleft;
+                        const bool locked = (g == sideL) ? (obsI > 0) : is_locked(C, g, i, key_held(key));
+                        if (locked) continue;
+                        two_min_insert(k0, k1, key);
+                    }
+                    row_two_min(k0, k1);
+                };
+                scan(0, head);
+                if (k1 == KEY_NONE && head < nCached) scan(head, nCached);
                 int bdr = 256, bd2r = 256, blr = -1, bl2r = -1, bir = -1;
                 if (k0 != KEY_NONE) { bdr = key_dist(k0); bir = key_idx(k0); blr = key_octave(k0); }
                 if (k1 != KEY_NONE) { bd2r = key_dist(k1); bl2r = key_octave(k1); }
@@ -1173,23 +1238,25 @@ __global__ __launch_bounds__(256) void k_search_last_lean(const FtBatchJob *__re
             if (sub == 0) slow_append(slow, pass, J.nPoints, i);
             return;
         }
-        unsigned long long k0 = KEY_NONE;
-        for (int t = sub; t < nCachedL; t += 16) {
-            const unsigned long long key = slotL[1 + t];
-            if (is_locked(C, key_idx(key), i, key_held(key))) continue;
-            k0 = key < k0 ? key : k0;
-        }
-        k0 = row_min_u64(k0);
+        auto scanMin = [&](const unsigned long long *slot, int from, int to, int base) -> unsigned long long {
+            unsigned long long m = KEY_NONE;
+            for (int t = from + sub; t < to; t += 16) {
+                const unsigned long long key = slot[1 + t];
+                if (is_locked(C, key_idx(key) + base, i, key_held(key))) continue;
+                m = key < m ? key : m;
+            }
+            return row_min_u64(m);
+        };
+        // the head of the list first (cache_partition): an unlocked key there is smaller than every key behind it
+        const int headL = cache_head(metaL);
+        unsigned long long k0 = scanMin(slotL, 0, headL, 0);
+        if (k0 == KEY_NONE && headL < nCachedL) k0 = scanMin(slotL, headL, nCachedL, 0);
         if (anyBoxL) {
             if (k0 != KEY_NONE && key_dist(k0) <= FT_TH_HIGH) primL = key_idx(k0);
             if (twoCam) {
-                unsigned long long kr = KEY_NONE;
-                for (int t = sub; t < nCachedR; t += 16) {
-                    const unsigned long long key = slotR[1 + t];
-                    if (is_locked(C, key_idx(key) + F.Nleft, i, key_held(key))) continue;
-                    kr = key < kr ? key : kr;
-                }
-                kr = row_min_u64(kr);
+                const int headR = cache_head(metaR);
+                unsigned long long kr = scanMin(slotR, 0, headR, F.Nleft);
+                if (kr == KEY_NONE && headR < nCachedR) kr = scanMin(slotR, headR, nCachedR, F.Nleft);
                 if (kr != KEY_NONE && key_dist(kr) <= FT_TH_HIGH) primR = key_idx(kr) + F.Nleft;
             }
         }
@@ -1462,6 +1529,20 @@ __global__ __launch_bounds__(256) void k_fisheye_2nn_batch(const FtBatchJob *__r
     }
 }
 
+// the candidate lists the first pass of a batch filed: the best candidates to the front (cache_partition); one wave per list
+__global__ __launch_bounds__(256) void k_cache_partition_batch(const FtBatchJob *__restrict__ jobs, Rebase rb) {
+    const FtBatchJob &J = jobs[blockIdx.y];
+    const int lane = threadIdx.x & 63, li = blockIdx.x * 4 + wave_index();
+    if (li >= 2 * J.nPoints) return;
+    unsigned long long *slot = rb(J.cache) + (size_t)(li >> 1) * FT_CACHE_WORDS + (size_t)(li & 1) * (FT_CACHE_CAP + 1);
+    const unsigned long long meta = slot[0];
+    int n;
+    bool anyBox;
+    if (cache_state_of(meta, n, anyBox) != 1 || n <= FT_CACHE_HEAD_MAX || cache_head(meta) != n) return;
+    const int head = cache_partition(slot, n, lane);
+    if (lane == 0) slot[0] = (meta & ~(0x3ffull << 40)) | ((unsigned long long)(unsigned)head << 40);
+}
+
 // Result delivery of a batch: record r (blockIdx.y) = one block of dwords written into pinned host memory; src[parity] lets a
 // record follow the result buffer of the pass that ran last.
 __global__ __launch_bounds__(256) void k_deliver_batch(const FtDeliverRec *__restrict__ recs, int parity) {
@@ -1578,8 +1659,8 @@ int ft_launch_frustum_batch(hipStream_t st, void *arena, const FtBatchJob *jobs,
 int ft_launch_search_last_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur, int fPrev,
                                 int fReset, float th) {
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
-    hipLaunchKernelGGL(k_search_last_batch, dim3((maxPoints + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st,
-                       jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th, 0);
+    hipLaunchKernelGGL(k_search_last_batch<false>, dim3((maxPoints + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st,
+                       jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
@@ -1589,8 +1670,8 @@ int ft_launch_search_last_batch_lean(hipStream_t st, void *arena, const FtBatchJ
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
     hipLaunchKernelGGL(k_search_last_lean, dim3((maxPoints + FT_LEAN_PPB - 1) / FT_LEAN_PPB, nFrames), dim3(256), 0, st, jobs,
                        rebase_of(arena), pass, fCur, fPrev, fReset);
-    hipLaunchKernelGGL(k_search_last_batch, dim3(FT_SLOW_BLOCKS, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st, jobs, rebase_of(arena), pass, fCur,
-                       fPrev, fReset, th, 1);
+    hipLaunchKernelGGL(k_search_last_batch<true>, dim3(FT_SLOW_BLOCKS, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st, jobs, rebase_of(arena), pass,
+                       fCur, fPrev, fReset, th);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
@@ -1598,8 +1679,8 @@ int ft_launch_search_last_batch_lean(hipStream_t st, void *arena, const FtBatchJ
 int ft_launch_search_local_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur, int fPrev,
                                  int fReset, float th, float nnRatio) {
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
-    hipLaunchKernelGGL(k_search_local_batch, dim3((maxPoints + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB, nFrames), dim3(64 * FT_SEARCH_WPB), 0,
-                       st, jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th, nnRatio, 0);
+    hipLaunchKernelGGL(k_search_local_batch<false>, dim3((maxPoints + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB, nFrames), dim3(64 * FT_SEARCH_WPB), 0,
+                       st, jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th, nnRatio);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
@@ -1608,8 +1689,8 @@ int ft_launch_search_local_batch_lean(hipStream_t st, void *arena, const FtBatch
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
     hipLaunchKernelGGL(k_search_local_lean, dim3((maxPoints + FT_LEAN_PPB - 1) / FT_LEAN_PPB, nFrames), dim3(256), 0, st, jobs,
                        rebase_of(arena), pass, fCur, fPrev, fReset, nnRatio);
-    hipLaunchKernelGGL(k_search_local_batch, dim3(FT_SLOW_BLOCKS, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st, jobs, rebase_of(arena), pass,
-                       fCur, fPrev, fReset, th, nnRatio, 1);
+    hipLaunchKernelGGL(k_search_local_batch<true>, dim3(FT_SLOW_BLOCKS, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st, jobs, rebase_of(arena), pass,
+                       fCur, fPrev, fReset, th, nnRatio);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
@@ -1634,6 +1715,13 @@ int ft_launch_bind_fisheye_batch(hipStream_t st, void *arena, const FtBatchJob *
     hipLaunchKernelGGL(k_lap_gather_batch, dim3(2, nFrames), dim3(256), 0, st, jobs, rebase_of(arena), A);
     hipLaunchKernelGGL(k_fisheye_2nn_batch, dim3((maxKp + 4 * FE_Q - 1) / (4 * FE_Q), nFrames), dim3(256), 0, st, jobs, rebase_of(arena),
                        (const int *)A.mono);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
+int ft_launch_cache_partition_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints) {
+    if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_cache_partition_batch, dim3((2 * maxPoints + 3) / 4, nFrames), dim3(256), 0, st, jobs, rebase_of(arena));
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -1187,6 +1187,10 @@ struct ft_tracked_batch {
     std::vector<std::vector<float>> angles;
     std::vector<std::vector<int>> holder;
     int passesLast = 0, passesLocal = 0;
+    // a stream and a lock of the batch's own: two batches of one context used from two host threads are two batches in flight -
+    // the passes of one run beside the host side (staging, replay) of the other
+    hipStream_t stream = nullptr;
+    std::mutex mu;
     FtEventTimer evt;  // ft_context_set_kernel_timing: HIP events around the batch's launches on the context's stream
 };
 
@@ -1339,6 +1343,7 @@ int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, 
     hipError_t e = hipMalloc((void **)&tb->d_arena, tb->arenaBytes);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_in, tb->workBytes + tb->framesBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_out, tb->outBytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&tb->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         ft_tracked_batch_destroy(tb);
         return ft_hip_fail(e, "ft_tracked_batch_create", __FILE__, __LINE__);
@@ -1352,7 +1357,10 @@ int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, 
 int ft_tracked_batch_destroy(ft_tracked_batch *tb) {
     if (!tb) return FT_OK;
     ft_set_device(tb->ctx);
-    hipStreamSynchronize(tb->ctx->stream);
+    if (tb->stream) {
+        hipStreamSynchronize(tb->stream);
+        hipStreamDestroy(tb->stream);
+    }
     if (tb->d_arena) hipFree(tb->d_arena);
     if (tb->h_in) hipHostFree(tb->h_in);
     if (tb->h_out) hipHostFree(tb->h_out);
@@ -1376,9 +1384,9 @@ int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_frame_v
     ft_context *ctx = tb->ctx;
     int rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
-    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    std::lock_guard<std::mutex> lk(tb->mu);
     FtTimer tAll;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = tb->stream;
     FT_HIP(hipStreamSynchronize(st));  // the pinned mirror is repacked: nothing of an earlier call may still read it
     // layout of the frames region: the holder_obs arrays of all frames first (contiguous: refreshed after every search by one
     // copy), then every frame's arrays
@@ -1488,9 +1496,9 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     }
     rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
-    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    std::lock_guard<std::mutex> lk(tb->mu);
     FtTimer tAll;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = tb->stream;
     // layout of the call: job records | delivery records | per frame the point arrays
     Arena a;
     const size_t oJobs = a.take((size_t)n * sizeof(FtBatchJob));
@@ -1567,9 +1575,14 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         [&](int pass, int fCur, int fPrev, int fReset) {
             const bool lean = pass > 0 && tb->oCache;
             tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_last_batch(later pass)" : "kernel.search_last_batch(first pass)", st);
-            const int r = lean ? ft_launch_search_last_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th)
-                               : ft_launch_search_last_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
+            int r = lean ? ft_launch_search_last_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th)
+                         : ft_launch_search_last_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
             tb->evt.end(ctx->kernelTiming, st);
+            if (r == FT_OK && pass == 0 && tb->oCache) {
+                tb->evt.begin(ctx->kernelTiming, "kernel.cache_partition_batch", st);
+                r = ft_launch_cache_partition_batch(st, tb->d_arena, dJobs, n, maxPoints);
+                tb->evt.end(ctx->kernelTiming, st);
+            }
             return r;
         },
         [&](int par, int) { return ft_launch_deliver_batch(st, dRecs, n + 1, std::max(4 * maxPoints, FT_BATCH_FLAGS * n), par); },
@@ -1639,9 +1652,9 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
     ft_context *ctx = tb->ctx;
     rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
-    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    std::lock_guard<std::mutex> lk(tb->mu);
     FtTimer tAll;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = tb->stream;
     Arena a;
     const size_t oJobs = a.take((size_t)n * sizeof(FtBatchJob));
     const size_t oRecs = a.take((size_t)(2 * n + 2) * sizeof(FtDeliverRec));
@@ -1741,9 +1754,14 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
             }
             const bool lean = pass > 0 && tb->oCache;
             tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_local_batch(later pass)" : "kernel.search_local_batch(first pass)", st);
-            const int r = lean ? ft_launch_search_local_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio)
-                               : ft_launch_search_local_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
+            int r = lean ? ft_launch_search_local_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio)
+                         : ft_launch_search_local_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
             tb->evt.end(ctx->kernelTiming, st);
+            if (r == FT_OK && pass == 0 && tb->oCache) {
+                tb->evt.begin(ctx->kernelTiming, "kernel.cache_partition_batch", st);
+                r = ft_launch_cache_partition_batch(st, tb->d_arena, dJobs, n, maxPoints);
+                tb->evt.end(ctx->kernelTiming, st);
+            }
             return r;
         },
         [&](int par, int burst) {
@@ -1813,9 +1831,9 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     ft_context *ctx = tb->ctx;
     int rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
-    std::lock_guard<std::mutex> lk(ctx->matchMutex);
+    std::lock_guard<std::mutex> lk(tb->mu);
     FtTimer tAll;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = tb->stream;
     FT_HIP(hipStreamSynchronize(st));
     // frames region: holder_obs of all frames, the (monoLeft, monoRight) counts, then every frame's arrays (as ft_tracked_batch_upload)
     Arena a;

@@ -474,6 +474,8 @@ FT_API int ft_tracked_frame_holder_obs(ft_tracked_frame *tf, int *holder_obs);
  * ft_tracked_frame_* call on that frame, bit for bit; the holder_obs of every frame carries over from one search to the next.
  * Arrays indexed by frame: frames[], L[], Tcw (12 floats per frame), forward / backward (NULL = all 0), poses[], P[],
  * frustum[] (NULL = not wanted), n_to_match[], assign[] (assign[f] has frames[f].N entries), n_matches[].
+ * A batch object has a stream and a lock of its own: calls on one batch are serialised, two batches of one context used from
+ * two host threads are two batches in flight - the passes of one run beside the host side (staging, replay) of the other.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ft_tracked_batch ft_tracked_batch;
 FT_API int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, int max_points, ft_tracked_batch **out);

@@ -9,7 +9,8 @@ from fasttrack_amd import orb
 ctx = orb.Context(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-out = bench.tracking_batch_leg(orb, ctx, B=B, steps=steps)
+lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+out = bench.tracking_batch_leg(orb, ctx, B=B, steps=steps, in_flight=lanes)
 out = {k: v for k, v in out.items() if not k.startswith("_")}
 print(json.dumps(out))
 
