@@ -350,6 +350,79 @@ private:
     int N_ = 0;
 };
 
+// B frames per launch (ft_tracked_batch_*): the frames B camera streams deliver for one time step - or any B frames whose
+// inputs the caller holds - searched through ONE set of launches; per frame the results of TrackedFrame's calls.  A batch has
+// a stream of its own: several batches used from several host threads are several steps in flight.
+class TrackedBatch {
+public:
+    TrackedBatch(Context &ctx, int maxFrames, int maxKeypoints, int maxPoints) {
+        check(ft_tracked_batch_create(ctx.handle(), maxFrames, maxKeypoints, maxPoints, &h_));
+    }
+    ~TrackedBatch() { ft_tracked_batch_destroy(h_); }
+    TrackedBatch(const TrackedBatch &) = delete;
+    TrackedBatch &operator=(const TrackedBatch &) = delete;
+    void upload(const std::vector<ft_frame_view> &frames) {
+        check(ft_tracked_batch_upload(h_, (int)frames.size(), frames.data()));
+        loaded(frames);
+    }
+    // the two-camera frames of the batch from what two extractors left in HBM (their last operator() batches): keypoints into
+    // the reference's lapping-area order, the matching of Frame::ComputeStereoFishEyeMatches, the grids - all on the device
+    void bindFisheye(ft_extractor *left, ft_extractor *right, int slot0, const int lapLeft[2], const int lapRight[2],
+                     const std::vector<ft_frame_view> &meta, int *const *leftToRight = nullptr, int *const *rightToLeft = nullptr) {
+        check(ft_tracked_batch_bind_fisheye(h_, left, right, slot0, (int)meta.size(), lapLeft[0], lapLeft[1], lapRight[0], lapRight[1],
+                                            meta.data(), leftToRight, rightToLeft));
+        loaded(meta);
+    }
+    // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) for every frame; Tcw: 12 floats per frame     ORBmatcher.cc:1775
+    void SearchByProjection(const std::vector<ft_last_points> &LastFrames, const float *Tcw, float th, bool mbCheckOrientation,
+                            std::vector<std::vector<int>> &assign, std::vector<int> &nmatches, const int *bForward = nullptr,
+                            const int *bBackward = nullptr) {
+        prepare(assign, nmatches);
+        check(ft_tracked_batch_search_last_frame(h_, (int)N_.size(), LastFrames.data(), Tcw, th, bForward, bBackward, mbCheckOrientation,
+                                                 ptrs_.data(), nmatches.data()));
+        finish(assign);
+    }
+    // Tracking::SearchLocalPoints for every frame: isInFrustum + SearchByProjection(F, points, th, ...)              Tracking.cc:3472
+    void SearchLocalPoints(const std::vector<ft_frame_pose> &poses, const std::vector<ft_map_points> &P, float viewingCosLimit,
+                           float mfLogScaleFactor, float th, float mfNNratio, bool bFarPoints, float thFarPoints,
+                           const ft_frustum_result *fields, std::vector<int> &nToMatch, std::vector<std::vector<int>> &assign,
+                           std::vector<int> &nmatches) {
+        prepare(assign, nmatches);
+        nToMatch.assign(N_.size(), 0);
+        check(ft_tracked_batch_track_local_map(h_, (int)N_.size(), poses.data(), P.data(), viewingCosLimit, mfLogScaleFactor, th, mfNNratio,
+                                               bFarPoints, thFarPoints, fields, nToMatch.data(), ptrs_.data(), nmatches.data()));
+        finish(assign);
+    }
+    std::vector<int> holderObservations(int frame) {
+        std::vector<int> h(N_[frame] > 0 ? N_[frame] : 1);
+        check(ft_tracked_batch_holder_obs(h_, frame, h.data()));
+        h.resize(N_[frame]);
+        return h;
+    }
+    ft_tracked_batch *handle() { return h_; }
+
+private:
+    void loaded(const std::vector<ft_frame_view> &frames) {
+        N_.clear();
+        for (const ft_frame_view &F : frames) N_.push_back(F.N);
+    }
+    void prepare(std::vector<std::vector<int>> &assign, std::vector<int> &nmatches) {
+        assign.resize(N_.size());
+        ptrs_.resize(N_.size());
+        nmatches.assign(N_.size(), 0);
+        for (size_t f = 0; f < N_.size(); f++) {
+            assign[f].assign(N_[f] > 0 ? N_[f] : 1, -1);
+            ptrs_[f] = assign[f].data();
+        }
+    }
+    void finish(std::vector<std::vector<int>> &assign) {
+        for (size_t f = 0; f < N_.size(); f++) assign[f].resize(N_[f]);
+    }
+    ft_tracked_batch *h_ = nullptr;
+    std::vector<int> N_;
+    std::vector<int *> ptrs_;
+};
+
 // ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) for Frame::ComputeBoW: same call as
 // mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4) (src/Frame.cc:762-769), with the tree walk on the
 // device.  BowVector / FeatureVector are the std::map types of DBoW2 (BowVector.h:59, FeatureVector.h:24).

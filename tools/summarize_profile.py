@@ -11,7 +11,8 @@ import sys
 
 
 def short(name):
-    name = name.split("(anonymous namespace)::")[-1]
+    # "void (anonymous namespace)::k_name<true>((anonymous namespace)::Rebase, int, ...)" -> "k_name<true>"
+    name = name.split("(anonymous namespace)::", 1)[-1]
     return name.split("(")[0][:48]
 
 

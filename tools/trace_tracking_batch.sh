@@ -20,7 +20,7 @@ for f in glob.glob("$OUT/trace/**/*.db", recursive=True):
     t0 = rows[0][1]
     prev = t0
     for n, s, e in rows:
-        n = n.split("(anonymous namespace)::")[-1].split("(")[0][:40]
+        n = n.split("(anonymous namespace)::", 1)[-1].split("(")[0][:40]
         print(f"{(s-t0)/1e3:10.1f} us  gap {(s-prev)/1e3:7.1f}  dur {(e-s)/1e3:7.1f}  {n}")
         prev = e
 PY
