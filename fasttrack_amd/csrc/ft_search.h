@@ -154,9 +154,17 @@ struct FtBindArgs {
     int slot0;
     int lapL0, lapL1, lapR0, lapR1;
     int *mono;  // [nFrames][2], device
+    // the triangulation filter of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1256-1271): 0 = the matching alone
+    int triangulate;
+    FtFisheyeRig rig;
+    int *nMatches;      // [nFrames], device (zeroed by the gather)
+    float *const *depth, *const *p3d;  // device tables of per-frame device arrays (mvDepth [Nleft], mvStereo3Dpoints [3 Nleft]), or null
 };
 // keypoints / descriptors of every frame into the reference's order, then the 2-NN + ratio matching of the lapping subsets
 int ft_launch_bind_fisheye_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxKp, const FtBindArgs &A);
+// KannalaBrandt8::TriangulateMatches for every ratio-test survivor of every frame (kernels_match.hip): keeps mvLeftToRightMatch
+// where the depth is > 0.0001, fills mvRightToLeftMatch, mvDepth, mvStereo3Dpoints and the frame's match count
+int ft_launch_fisheye_triangulate_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxKp, const FtBindArgs &A);
 int ft_launch_fill_claims_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxWords);
 // behind the first pass of a batch: every candidate list with its best candidates at the front (cache_partition, kernels_search.hip)
 int ft_launch_cache_partition_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints);
@@ -193,3 +201,16 @@ int ft_launch_search_last(hipStream_t st, const FtDevFrame &F, const FtDevLastPo
                           const FtPose &Tcw, float th, int forward, int backward, int *res, const FtLastRaw &raw);
 int ft_launch_build_grid(hipStream_t st, const FtDevFrame &F, int *gridStartL, int *gridStartR, float4 *recL, uint8_t *descL,
                          float4 *recR, uint8_t *descR);
+
+#ifdef __HIPCC__
+// Re-derives a pointer read from a job record from the arena pointer the kernel got as an argument (kernels_search.hip: a
+// pointer out of memory is a generic pointer to the compiler): arena + (p - address of the arena, passed as an integer)
+struct Rebase {
+    uint8_t *arena;
+    unsigned long long addr;  // (unsigned long long)arena
+    template <class T>
+    __device__ __forceinline__ T *operator()(T *p) const {
+        return p ? (T *)(arena + ((unsigned long long)p - addr)) : nullptr;
+    }
+};
+#endif

@@ -6,6 +6,7 @@
 //   k_fisheye_2nn    BFMatcher knnMatch(k=2)+ratio (src/Frame.cc:1231-1255)
 //   k_hamming_pairs  ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2256-2272)
 #include "ft_internal.h"
+#include "ft_search.h"
 #include "kb8_math.h"
 #include "wave_ops.h"
 
@@ -599,7 +600,46 @@ __global__ __launch_bounds__(64) void k_fisheye_triangulate(FtFisheyeRig rig, co
     p3d[3 * i + 2] = p[2];
 }
 
+// The same for every frame of a tracked batch (blockIdx.y = frame): the pairs k_fisheye_2nn_batch left in mvLeftToRightMatch
+// (right-camera indices) are triangulated; a pair that fails loses its entry, a pair that stays enters mvRightToLeftMatch (the
+// largest left index per right keypoint = the last writer of the reference's loop, src/Frame.cc:1262) and mvDepth / mvStereo3Dpoints
+__global__ __launch_bounds__(256) void k_fisheye_triangulate_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, FtBindArgs A) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const FtDevFrame &F = jobs[f].F;
+    if (i >= F.Nleft) return;
+    int *l2r = (int *)rb(F.l2r), *r2l = (int *)rb(F.r2l);
+    const int j = l2r[i];
+    float d = -1.0f, p[3] = {0.f, 0.f, 0.f};
+    if (j >= 0) {
+        const ft_keypoint a = rb(F.keys)[i], b = rb(F.keysR)[j];
+        const float z = kb8_triangulate_matches(A.rig, a.x, a.y, b.x, b.y, A.rig.sigma2[a.octave], A.rig.sigma2[b.octave], p);
+        if (z > 0.0001f) {  // Frame.cc:1263
+            d = z;
+            atomicMax(&r2l[j], i);
+            atomicAdd(&A.nMatches[f], 1);
+        } else {
+            p[0] = p[1] = p[2] = 0.f;
+            l2r[i] = -1;
+        }
+    }
+    if (A.depth) {
+        float *dep = rb(A.depth[f]), *pp = rb(A.p3d[f]);
+        dep[i] = d;
+        pp[3 * i] = p[0];
+        pp[3 * i + 1] = p[1];
+        pp[3 * i + 2] = p[2];
+    }
+}
+
 }  // namespace
+
+int ft_launch_fisheye_triangulate_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxKp, const FtBindArgs &A) {
+    if (nFrames <= 0 || maxKp <= 0) return FT_OK;
+    const Rebase rb{(uint8_t *)arena, (unsigned long long)(uintptr_t)arena};
+    hipLaunchKernelGGL(k_fisheye_triangulate_batch, dim3((maxKp + 255) / 256, nFrames), dim3(256), 0, st, jobs, rb, A);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
 
 namespace {
 // grid (DL_BLOCKS, batch): the blocks of an image share the rows of its six result arrays dword by dword (every record

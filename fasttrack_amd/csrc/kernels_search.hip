@@ -35,14 +35,6 @@ __device__ __forceinline__ int hamming256(const unsigned long long a[4], const u
 // re-deriving the pointer from a pointer that IS a kernel argument - the batch's device arena, with the arena's address
 // passed a second time as a plain integer, so that arena + (p - address) cannot be folded back into p.  Everything a job
 // record points to lies inside the arena of its batch (search.cpp).
-struct Rebase {
-    uint8_t *arena;
-    unsigned long long addr;  // (unsigned long long)arena
-    template <class T>
-    __device__ __forceinline__ T *operator()(T *p) const {
-        return p ? (T *)(arena + ((unsigned long long)p - addr)) : nullptr;
-    }
-};
 struct NoRebase {  // the pointers are kernel arguments already
     template <class T>
     __device__ __forceinline__ T *operator()(T *p) const {
@@ -1470,7 +1462,10 @@ __global__ __launch_bounds__(256) void k_lap_gather_batch(const FtBatchJob *__re
         }
         lapBefore += chunkLap;
     }
-    if (tid == 0) A.mono[2 * f + cam] = n - lapBefore;
+    if (tid == 0) {
+        A.mono[2 * f + cam] = n - lapBefore;
+        if (cam == 0 && A.nMatches) A.nMatches[f] = 0;
+    }
 }
 
 // Step 2: the matching part of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1231-1255; the seam of the reference's
@@ -1482,7 +1477,9 @@ __global__ __launch_bounds__(256) void k_lap_gather_batch(const FtBatchJob *__re
 // form of k_fisheye_2nn reads the whole train set per query: 128 MB of L2 traffic per 2000 x 2000 frame); keys
 // (distance << 20 | train index), two smallest per lane and query, one wave reduction per query at the end.
 #define FE_Q 16
-__global__ __launch_bounds__(256) void k_fisheye_2nn_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, const int *__restrict__ mono) {
+// fillR2l = 0: the triangulation filter follows (k_fisheye_triangulate_batch), which writes mvRightToLeftMatch for the pairs it keeps
+__global__ __launch_bounds__(256) void k_fisheye_2nn_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, const int *__restrict__ mono,
+                                                           int fillR2l) {
     const int f = blockIdx.y, lane = threadIdx.x & 63, wave = wave_index();
     const FtDevFrame &F = jobs[f].F;
     const int monoL = mono[2 * f], monoR = mono[2 * f + 1];
@@ -1523,7 +1520,7 @@ __global__ __launch_bounds__(256) void k_fisheye_2nn_batch(const FtBatchJob *__r
             if (nT >= 2 && (double)(float)d0 < (double)(float)d1 * 0.7) {
                 const int t = monoR + (int)(m0 & 0xfffffu), qi = monoL + q0 + q;
                 l2r[qi] = t;
-                atomicMax(&r2l[t], qi);
+                if (fillR2l) atomicMax(&r2l[t], qi);
             }
         }
     }
@@ -1714,7 +1711,7 @@ int ft_launch_bind_fisheye_batch(hipStream_t st, void *arena, const FtBatchJob *
     if (nFrames <= 0) return FT_OK;
     hipLaunchKernelGGL(k_lap_gather_batch, dim3(2, nFrames), dim3(256), 0, st, jobs, rebase_of(arena), A);
     hipLaunchKernelGGL(k_fisheye_2nn_batch, dim3((maxKp + 4 * FE_Q - 1) / (4 * FE_Q), nFrames), dim3(256), 0, st, jobs, rebase_of(arena),
-                       (const int *)A.mono);
+                       (const int *)A.mono, A.triangulate ? 0 : 1);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

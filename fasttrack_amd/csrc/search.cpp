@@ -1339,7 +1339,8 @@ int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, 
         tb->oCache = a.take(B * tb->cacheStride);
     }
     tb->arenaBytes = a.off;
-    tb->outBytes = B * batchOutBytes(max_points) + B * FT_BATCH_FLAGS * sizeof(int) + 4096;
+    // results of a search (per point) or of bind_fisheye (per keypoint: match tables, mvDepth, mvStereo3Dpoints)
+    tb->outBytes = B * std::max(batchOutBytes(max_points), 20 * (size_t)max_keypoints + 8 * 64) + B * FT_BATCH_FLAGS * sizeof(int) + 4096;
     hipError_t e = hipMalloc((void **)&tb->d_arena, tb->arenaBytes);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_in, tb->workBytes + tb->framesBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_out, tb->outBytes, hipHostMallocDefault);
@@ -1809,13 +1810,17 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
 extern "C" {
 
 int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_extractor *exR, int slot0, int n_frames, int lap_l0,
-                                  int lap_l1, int lap_r0, int lap_r1, const ft_frame_view *meta, int *const *left_to_right,
-                                  int *const *right_to_left) {
+                                  int lap_l1, int lap_r0, int lap_r1, const ft_frame_view *meta, const ft_fisheye_rig *rig,
+                                  const float *level_sigma2, int *const *left_to_right, int *const *right_to_left, float *const *depth,
+                                  float *const *p3d, int *n_stereo) {
     FT_REQUIRE(tb && exL && exR && meta && n_frames > 0 && n_frames <= tb->maxFrames && slot0 >= 0,
                "ft_tracked_batch_bind_fisheye: bad argument");
     FT_REQUIRE(exL->ctx == tb->ctx && exR->ctx == tb->ctx, "ft_tracked_batch_bind_fisheye: extractors of another context");
     FT_REQUIRE(slot0 + n_frames <= exL->lastBatch && slot0 + n_frames <= exR->lastBatch,
                "ft_tracked_batch_bind_fisheye: the extractors' last batches hold fewer images");
+    FT_REQUIRE(!rig || level_sigma2, "ft_tracked_batch_bind_fisheye: a rig needs level_sigma2 (mvLevelSigma2)");
+    FT_REQUIRE((!depth && !p3d && !n_stereo) || rig, "ft_tracked_batch_bind_fisheye: depth / p3d / n_stereo come from the triangulation: pass a rig");
+    FT_REQUIRE(!depth == !p3d, "ft_tracked_batch_bind_fisheye: depth and p3d go together");
     int nlevelsMax = 1, maxKp = 1;
     for (int f = 0; f < n_frames; f++) {
         const ft_frame_view &F = meta[f];
@@ -1842,8 +1847,9 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     for (int f = 0; f < n_frames; f++) tb->holderOff[f] = a.take(sizeof(int) * std::max(meta[f].N, 1));
     tb->holderEnd = a.off;
     const size_t oMono = a.take(sizeof(int) * 2 * (size_t)n_frames);
+    const size_t oNst = a.take(sizeof(int) * (size_t)n_frames);
     struct Lay {
-        size_t keys, keysR, desc, l2r, r2l;
+        size_t keys, keysR, desc, l2r, r2l, depth, p3d;
     };
     std::vector<Lay> lay(n_frames);
     for (int f = 0; f < n_frames; f++) {
@@ -1853,14 +1859,24 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
         lay[f].desc = a.take((size_t)32 * std::max(meta[f].N, 1));
         lay[f].l2r = a.take(sizeof(int) * std::max(nL, 1));
         lay[f].r2l = a.take(sizeof(int) * std::max(nR, 1));
+        lay[f].depth = depth ? a.take(sizeof(float) * std::max(nL, 1)) : 0;   // (inside the uright / slack share of the frame's budget)
+        lay[f].p3d = depth ? a.take(3 * sizeof(float) * std::max(nL, 1)) : 0;
     }
     FT_REQUIRE(a.off <= tb->framesBytes, "ft_tracked_batch_bind_fisheye: frames region too small");
     const bool wantTables = left_to_right && right_to_left;
+    const bool wantOut = wantTables || depth || n_stereo;
     Arena o;
-    std::vector<size_t> outL(n_frames), outR(n_frames);
-    for (int f = 0; f < n_frames && wantTables; f++) {
-        outL[f] = o.take(sizeof(int) * std::max(meta[f].Nleft, 1));
-        outR[f] = o.take(sizeof(int) * std::max(meta[f].N - meta[f].Nleft, 1));
+    std::vector<size_t> outL(n_frames), outR(n_frames), outD(n_frames), outP(n_frames);
+    const size_t outN = o.take(sizeof(int) * (size_t)n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        if (wantTables) {
+            outL[f] = o.take(sizeof(int) * std::max(meta[f].Nleft, 1));
+            outR[f] = o.take(sizeof(int) * std::max(meta[f].N - meta[f].Nleft, 1));
+        }
+        if (depth) {
+            outD[f] = o.take(sizeof(float) * std::max(meta[f].Nleft, 1));
+            outP[f] = o.take(3 * sizeof(float) * std::max(meta[f].Nleft, 1));
+        }
     }
     FT_REQUIRE(o.off <= tb->outBytes, "ft_tracked_batch_bind_fisheye: result buffer too small");
     tb->nFrames = n_frames;
@@ -1870,7 +1886,12 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     uint8_t *pinF = tb->h_in + tb->workBytes, *devF = tb->d_arena + tb->oFrames;
     FtBatchJob *hJobs = (FtBatchJob *)tb->h_in;
     FtDeliverRec *hRecs = (FtDeliverRec *)(tb->h_in + (((size_t)n_frames * sizeof(FtBatchJob) + 63) & ~(size_t)63));
-    FT_REQUIRE((size_t)n_frames * (sizeof(FtBatchJob) + 2 * sizeof(FtDeliverRec)) + 64 <= tb->workBytes, "ft_tracked_batch_bind_fisheye: work region too small");
+    // records per frame: l2r, r2l, depth, p3d (unused ones have 0 words); then the match counts; then the two tables of depth /
+    // p3d pointers the triangulation kernel reads
+    const int nRecs = 4 * n_frames + 1;
+    float **hDepthTab = (float **)(hRecs + nRecs), **hP3dTab = hDepthTab + n_frames;
+    const size_t headBytes = (size_t)((uint8_t *)(hP3dTab + n_frames) - tb->h_in);
+    FT_REQUIRE(headBytes <= tb->workBytes, "ft_tracked_batch_bind_fisheye: work region too small");
     const std::function<void(int, int)> stage = [&](int f, int) {
         const ft_frame_view &F = meta[f];
         const int nL = F.Nleft, nR = F.N - nL;
@@ -1902,17 +1923,32 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
         for (int i = 0; i < nL; i++) tb->angles[f][i] = F.keys[i].angle;
         for (int i = 0; i < nR; i++) tb->angles[f][nL + i] = F.keys_right[i].angle;
         tb->holder[f].assign(hold, hold + F.N);
+        FtDeliverRec *R = hRecs + 4 * (size_t)f;
+        memset(R, 0, 4 * sizeof(FtDeliverRec));
         if (wantTables) {
-            hRecs[2 * f].dst = tb->h_out + outL[f];
-            hRecs[2 * f].src[0] = hRecs[2 * f].src[1] = D.l2r;
-            hRecs[2 * f].words = nL;
-            hRecs[2 * f + 1].dst = tb->h_out + outR[f];
-            hRecs[2 * f + 1].src[0] = hRecs[2 * f + 1].src[1] = D.r2l;
-            hRecs[2 * f + 1].words = nR;
+            R[0].dst = tb->h_out + outL[f];
+            R[0].src[0] = R[0].src[1] = D.l2r;
+            R[0].words = nL;
+            R[1].dst = tb->h_out + outR[f];
+            R[1].src[0] = R[1].src[1] = D.r2l;
+            R[1].words = nR;
+        }
+        hDepthTab[f] = hP3dTab[f] = nullptr;
+        if (depth) {
+            hDepthTab[f] = (float *)(devF + lay[f].depth);
+            hP3dTab[f] = (float *)(devF + lay[f].p3d);
+            R[2].dst = tb->h_out + outD[f];
+            R[2].src[0] = R[2].src[1] = hDepthTab[f];
+            R[2].words = nL;
+            R[3].dst = tb->h_out + outP[f];
+            R[3].src[0] = R[3].src[1] = hP3dTab[f];
+            R[3].words = 3 * nL;
         }
     };
     ctx->pool->parallel_for(n_frames, stage);
-    const size_t headBytes = (size_t)((uint8_t *)(hRecs + 2 * (size_t)n_frames) - tb->h_in);
+    hRecs[4 * (size_t)n_frames].dst = tb->h_out + outN;
+    hRecs[4 * (size_t)n_frames].src[0] = hRecs[4 * (size_t)n_frames].src[1] = devF + oNst;
+    hRecs[4 * (size_t)n_frames].words = n_frames;
     FT_HIP(hipMemcpyAsync(tb->d_arena + tb->oWork, tb->h_in, headBytes, hipMemcpyHostToDevice, st));
     if (tb->holderEnd > tb->holderBegin)
         FT_HIP(hipMemcpyAsync(devF + tb->holderBegin, pinF + tb->holderBegin, tb->holderEnd - tb->holderBegin, hipMemcpyHostToDevice, st));
@@ -1924,22 +1960,45 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     A.slot0 = slot0;
     A.lapL0 = lap_l0; A.lapL1 = lap_l1; A.lapR0 = lap_r0; A.lapR1 = lap_r1;
     A.mono = (int *)(devF + oMono);
+    A.triangulate = rig ? 1 : 0;
+    memset(&A.rig, 0, sizeof A.rig);
+    if (rig) {
+        memcpy(A.rig.cam1, rig->cam1, sizeof A.rig.cam1);
+        memcpy(A.rig.cam2, rig->cam2, sizeof A.rig.cam2);
+        A.rig.precision = rig->precision;
+        memcpy(A.rig.Rlr, rig->Rlr, sizeof A.rig.Rlr);
+        memcpy(A.rig.tlr, rig->tlr, sizeof A.rig.tlr);
+        for (int i = 0; i < nlevelsMax; i++) A.rig.sigma2[i] = level_sigma2[i];
+    }
+    A.nMatches = (int *)(devF + oNst);
+    const uint8_t *dWork = tb->d_arena + tb->oWork;
+    A.depth = depth ? (float *const *)(dWork + ((uint8_t *)hDepthTab - tb->h_in)) : nullptr;
+    A.p3d = depth ? (float *const *)(dWork + ((uint8_t *)hP3dTab - tb->h_in)) : nullptr;
     tb->evt.begin(ctx->kernelTiming, "kernel.lap_gather+fisheye_2nn_batch", st);
     rc = ft_launch_bind_fisheye_batch(st, tb->d_arena, dJobs, n_frames, maxKp, A);
     tb->evt.end(ctx->kernelTiming, st);
+    if (rc == FT_OK && rig) {
+        tb->evt.begin(ctx->kernelTiming, "kernel.fisheye_triangulate_batch", st);
+        rc = ft_launch_fisheye_triangulate_batch(st, tb->d_arena, dJobs, n_frames, maxKp, A);
+        tb->evt.end(ctx->kernelTiming, st);
+    }
+    if (rc != FT_OK) return rc;
     tb->evt.begin(ctx->kernelTiming, "kernel.build_grid_batch", st);
     if (rc == FT_OK && ctx->tuning.search_grid) rc = ft_launch_build_grid_batch(st, tb->d_arena, dJobs, n_frames, nlevelsMax, true);
     tb->evt.end(ctx->kernelTiming, st);
     if (rc != FT_OK) return rc;
-    if (wantTables) {
+    if (wantOut) {
         const FtDeliverRec *dRecs = (const FtDeliverRec *)(tb->d_arena + tb->oWork + ((uint8_t *)hRecs - tb->h_in));
-        rc = ft_launch_deliver_batch(st, dRecs, 2 * n_frames, maxKp, 0);
+        rc = ft_launch_deliver_batch(st, dRecs, nRecs, 3 * maxKp, 0);
         if (rc != FT_OK) return rc;
         FT_HIP(hipStreamSynchronize(st));
         for (int f = 0; f < n_frames; f++) {
             const int nL = meta[f].Nleft, nR = meta[f].N - nL;
-            if (left_to_right[f] && nL) memcpy(left_to_right[f], tb->h_out + outL[f], sizeof(int) * nL);
-            if (right_to_left[f] && nR) memcpy(right_to_left[f], tb->h_out + outR[f], sizeof(int) * nR);
+            if (wantTables && left_to_right[f] && nL) memcpy(left_to_right[f], tb->h_out + outL[f], sizeof(int) * nL);
+            if (wantTables && right_to_left[f] && nR) memcpy(right_to_left[f], tb->h_out + outR[f], sizeof(int) * nR);
+            if (depth && depth[f] && nL) memcpy(depth[f], tb->h_out + outD[f], sizeof(float) * nL);
+            if (depth && p3d[f] && nL) memcpy(p3d[f], tb->h_out + outP[f], 3 * sizeof(float) * nL);
+            if (n_stereo) n_stereo[f] = ((const int *)(tb->h_out + outN))[f];
         }
     }
     ctx->addStat("tracked_batch.bind_fisheye.total", tAll.ms());

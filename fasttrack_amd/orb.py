@@ -740,24 +740,37 @@ class TrackedBatch:
         self._nm = np.zeros(len(self.N), np.int32)
         self._nt = np.zeros(len(self.N), np.int32)
 
-    def bind_fisheye(self, exL, exR, views, lap_l, lap_r, slot0=0, want_tables=True):
+    def bind_fisheye(self, exL, exR, views, lap_l, lap_r, slot0=0, want_tables=True, rig=None, level_sigma2=None):
         """ft_tracked_batch_bind_fisheye: views = FrameViews (or the pair prepare_frames returned) whose keys / keys_right are the
-        host copies of what exL / exR extracted last (slots slot0 ...); -> [(left_to_right, right_to_left)] or None"""
+        host copies of what exL / exR extracted last (slots slot0 ...).  rig = make_fisheye_rig(...): with the triangulation filter
+        of Frame::ComputeStereoFishEyeMatches.  -> [(left_to_right, right_to_left)] (with a rig: [(l2r, r2l, depth, p3d, n)]) or None"""
         arr, vs = views if isinstance(views, tuple) else self.prepare_frames(views)
         n = len(vs)
-        l2r = r2l = None
-        pl = pr = None
+        l2r = r2l = dep = p3 = None
+        pl = pr = pd = pp = None
+        nst = None
+        ls2 = None if level_sigma2 is None else np.ascontiguousarray(level_sigma2, np.float32)
         if want_tables:
             l2r = [np.full(max(F.c.Nleft, 1), -1, np.int32) for F in vs]
             r2l = [np.full(max(F.c.N - F.c.Nleft, 1), -1, np.int32) for F in vs]
             pl = (C.c_void_p * n)(*[ptr(a) for a in l2r])
             pr = (C.c_void_p * n)(*[ptr(a) for a in r2l])
-        check(lib().ft_tracked_batch_bind_fisheye(self._h, exL._h, exR._h, slot0, n, lap_l[0], lap_l[1], lap_r[0], lap_r[1], arr, pl, pr))
+            if rig is not None:
+                dep = [np.zeros(max(F.c.Nleft, 1), np.float32) for F in vs]
+                p3 = [np.zeros((max(F.c.Nleft, 1), 3), np.float32) for F in vs]
+                pd = (C.c_void_p * n)(*[ptr(a) for a in dep])
+                pp = (C.c_void_p * n)(*[ptr(a) for a in p3])
+                nst = np.zeros(n, np.int32)
+        check(lib().ft_tracked_batch_bind_fisheye(self._h, exL._h, exR._h, slot0, n, lap_l[0], lap_l[1], lap_r[0], lap_r[1], arr,
+                                                  None if rig is None else C.byref(rig), ptr(ls2), pl, pr, pd, pp, ptr(nst)))
         if [F.c.N for F in vs] != self.N:
             self._after_load([F.c.N for F in vs])
-        if want_tables:
+        if not want_tables:
+            return None
+        if rig is None:
             return [(l2r[f][:vs[f].c.Nleft], r2l[f][:vs[f].c.N - vs[f].c.Nleft]) for f in range(n)]
-        return None
+        return [(l2r[f][:vs[f].c.Nleft], r2l[f][:vs[f].c.N - vs[f].c.Nleft], dep[f][:vs[f].c.Nleft], p3[f][:vs[f].c.Nleft], int(nst[f]))
+                for f in range(n)]
 
     def holder_obs(self, f):
         out = np.zeros(max(self.N[f], 1), np.int32)
@@ -839,14 +852,20 @@ class TrackedBatch:
         return res
 
 
-def fisheye_stereo(ctx: Context, cam1, cam2, Rlr, tlr, descL, keysL, descR, keysR, level_sigma2, precision=1e-6):
-    """Frame::ComputeStereoFishEyeMatches on the lapping-area subsets (ft_fisheye_stereo)."""
+def make_fisheye_rig(cam1, cam2, Rlr, tlr, precision=1e-6):
+    """ft_fisheye_rig: mpCamera / mpCamera2 (fx fy cx cy k1..k4), mRlr, mtlr, KannalaBrandt8::precision"""
     rig = _capi.FisheyeRig()
     rig.cam1[:] = [float(v) for v in cam1]
     rig.cam2[:] = [float(v) for v in cam2]
     rig.precision = precision
     rig.Rlr[:] = [float(v) for v in np.asarray(Rlr, np.float32).reshape(-1)]
     rig.tlr[:] = [float(v) for v in np.asarray(tlr, np.float32).reshape(-1)]
+    return rig
+
+
+def fisheye_stereo(ctx: Context, cam1, cam2, Rlr, tlr, descL, keysL, descR, keysR, level_sigma2, precision=1e-6):
+    """Frame::ComputeStereoFishEyeMatches on the lapping-area subsets (ft_fisheye_stereo)."""
+    rig = make_fisheye_rig(cam1, cam2, Rlr, tlr, precision)
     descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
     keysL = np.ascontiguousarray(keysL); keysR = np.ascontiguousarray(keysR)
     ls2 = np.ascontiguousarray(level_sigma2, np.float32)

@@ -485,16 +485,20 @@ FT_API int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_
 /* The frames of the batch straight from what two extractors left in HBM - no keypoint or descriptor crosses PCIe again.
  * Slot slot0 + f of exL / exR holds the left / right image of two-camera frame f (their last ft_extract_batch calls; lapping areas
  * [lap_l0, lap_l1] / [lap_r0, lap_r1] as passed there).  On the device: keypoints and descriptors are put into the reference's
- * order (lapping-area keypoints filled from the back, src/ORBextractor.cc:1466-1487), the matching part of
- * Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1231-1255: 2-NN + ratio 0.7 between the lapping subsets = the seam of
- * launchFisheyeStereoMatchKernel, include/Kernels/KernelController.h:38; NOT the triangulation filter of :1256-1271, see
- * ft_fisheye_stereo) fills mvLeftToRightMatch / mvRightToLeftMatch, and the grids are built.  meta[f]: the frame constants,
- * N / Nleft (= the counts ft_extract_batch returned), keys / keys_right = the host copies it returned (angles for the rotation
- * histogram), holder_obs or NULL (all -1); its descriptors / match tables are not read.  left_to_right[f] / right_to_left[f]
- * (both arrays NULL = not wanted) receive the match tables; without them the call does not wait for the device. */
+ * order (lapping-area keypoints filled from the back, src/ORBextractor.cc:1466-1487); Frame::ComputeStereoFishEyeMatches
+ * (src/Frame.cc:1231-1271) for every frame - 2-NN + ratio 0.7 between the lapping subsets (the seam of
+ * launchFisheyeStereoMatchKernel, include/Kernels/KernelController.h:38) and, when `rig` is given, KannalaBrandt8::
+ * TriangulateMatches on every surviving pair (depth > 0.0001 keeps it; level_sigma2 = mvLevelSigma2, nlevels floats) - fills
+ * mvLeftToRightMatch / mvRightToLeftMatch; the grids are built.  rig == NULL: the matching alone (every ratio-test survivor stays).
+ * meta[f]: the frame constants, N / Nleft (= the counts ft_extract_batch returned), keys / keys_right = the host copies it
+ * returned (angles for the rotation histogram), holder_obs or NULL (all -1); its descriptors / match tables are not read.
+ * Outputs, each an array of n_frames pointers or NULL: left_to_right[f] / right_to_left[f] (the match tables; both or neither),
+ * depth[f] / p3d[f] (mvDepth [Nleft], mvStereo3Dpoints [3 Nleft]; with a rig only), n_stereo[f] (the frame's nMatches).  Without
+ * outputs the call does not wait for the device. */
 FT_API int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_extractor *exR, int slot0, int n_frames,
                                          int lap_l0, int lap_l1, int lap_r0, int lap_r1, const ft_frame_view *meta,
-                                         int *const *left_to_right, int *const *right_to_left);
+                                         const ft_fisheye_rig *rig, const float *level_sigma2, int *const *left_to_right,
+                                         int *const *right_to_left, float *const *depth, float *const *p3d, int *n_stereo);
 /* ft_tracked_frame_search_last_frame for every frame of the batch (n_frames = the number uploaded) */
 FT_API int ft_tracked_batch_search_last_frame(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const float *Tcw,
                                               float th, const int *forward, const int *backward, int check_orientation,

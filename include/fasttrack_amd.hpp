@@ -367,10 +367,14 @@ public:
     }
     // the two-camera frames of the batch from what two extractors left in HBM (their last operator() batches): keypoints into
     // the reference's lapping-area order, the matching of Frame::ComputeStereoFishEyeMatches, the grids - all on the device
+    // rig != nullptr: with KannalaBrandt8::TriangulateMatches on every matched pair (mvLevelSigma2 = levelSigma2), as
+    // Frame::ComputeStereoFishEyeMatches; mvDepth / mvStereo3Dpoints / nMatches per frame on request
     void bindFisheye(ft_extractor *left, ft_extractor *right, int slot0, const int lapLeft[2], const int lapRight[2],
-                     const std::vector<ft_frame_view> &meta, int *const *leftToRight = nullptr, int *const *rightToLeft = nullptr) {
+                     const std::vector<ft_frame_view> &meta, const ft_fisheye_rig *rig = nullptr, const float *levelSigma2 = nullptr,
+                     int *const *leftToRight = nullptr, int *const *rightToLeft = nullptr, float *const *mvDepth = nullptr,
+                     float *const *mvStereo3Dpoints = nullptr, int *nMatches = nullptr) {
         check(ft_tracked_batch_bind_fisheye(h_, left, right, slot0, (int)meta.size(), lapLeft[0], lapLeft[1], lapRight[0], lapRight[1],
-                                            meta.data(), leftToRight, rightToLeft));
+                                            meta.data(), rig, levelSigma2, leftToRight, rightToLeft, mvDepth, mvStereo3Dpoints, nMatches));
         loaded(meta);
     }
     // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) for every frame; Tcw: 12 floats per frame     ORBmatcher.cc:1775

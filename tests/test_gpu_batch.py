@@ -262,3 +262,83 @@ def test_tracked_batch_bound_to_extractors_equals_uploaded_batch(ctx, lap):
         _check_frame(f"bound frame {f}", a1[f], a2[f], ta.holder_obs(f), o1, ofr, o2, oF)
     for o in (ta, tu, exL, exR):
         o.close()
+
+
+@pytest.mark.parametrize("opts", [dict(search_cache=0), dict(search_grid=0), dict(pass_burst=2)])
+def test_tracked_batch_without_cache_without_grid_with_short_bursts(ctx, opts):
+    """the batch under the context's search options: no candidate cache (every pass is the general kernel), no CSR grid (every
+    keypoint's cell is computed), bursts of two passes (many host round trips: the flag rows of converged frames must stick) -
+    the same assignments as the oracle every time"""
+    sf, _ = ob.scale_factors(1.2, 8)
+    B = 6
+    frames, lasts, Tcws, ptss, poses, oracle = [], [], [], [], [], []
+    for f in range(B):
+        oF, gF, kL, dL = _kb8_views(_kb8_base(1500, 10 + f % 2), sf)
+        last, Tcw, pts, Rcw, tcw = _kb8_inputs(kL, dL, sf, 3000 + f, 400 + 300 * f)
+        o1 = ob.search_last_frame(oF, last, Tcw, 15.0, False, False, True)
+        ofr = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, TLR), pts, 0.5, LOG_SF)
+        o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, pts), 15.0)
+        frames.append(gF); lasts.append(last); Tcws.append(Tcw); ptss.append(pts); poses.append(orb.make_pose(Rcw, tcw, TLR))
+        oracle.append((o1, ofr, o2, oF))
+    with ctx.options(**opts):
+        tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=frames[0].c.N + 8, max_points=2048)
+        tb.upload(frames)
+        g1 = tb.search_last_frame(lasts, Tcws, 15.0)
+        g2 = tb.track_local_map(poses, ptss, 0.5, LOG_SF, 15.0)
+        for f in range(B):
+            _check_frame(f"{opts} frame {f}", g1[f], g2[f], tb.holder_obs(f), *oracle[f])
+        tb.close()
+
+
+def test_tracked_batch_bind_with_triangulation_equals_oracle_fisheye_stereo(ctx):
+    """bind_fisheye with a rig = the whole Frame::ComputeStereoFishEyeMatches per frame (src/Frame.cc:1231-1271): the ratio-test
+    survivors go through KannalaBrandt8::TriangulateMatches; mvLeftToRightMatch / mvRightToLeftMatch / mvDepth / mvStereo3Dpoints /
+    nMatches equal the oracle's on the host copies of the same keypoints, bit for bit"""
+    from fasttrack_amd import synth
+    B, w, h, nf = 10, 512, 512, 1500
+    lap = (60, 470)
+    sf, sig2 = ob.scale_factors(1.2, 8)
+    S = sc.fisheye_rig_scenario(5)
+    cam = list(sc.KB8_CAM)
+    exL = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=B)
+    exR = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=B)
+    pairs = [synth.make_planes_pair(w, h, seed=500 + i) for i in range(B)]
+    rL = exL.extract_batch([p[0] for p in pairs], lap)
+    rR = exR.extract_batch([p[1] for p in pairs], lap)
+    orig = ob.FisheyeRig()
+    grig = orb.make_fisheye_rig(cam, cam, S["Rlr"], S["tlr"])
+    for name in ("cam1", "cam2", "Rlr", "tlr"):
+        getattr(orig, name)[:] = list(getattr(grig, name))
+    orig.precision = grig.precision
+    views, want = [], []
+    for f in range(B):
+        (kL, dL, mL), (kR, dR, mR) = rL[f], rR[f]
+        o = ob.fisheye_stereo(orig, dL[mL:], kL[mL:], dR[mR:], kR[mR:], sig2)
+        l2r = np.full(len(kL), -1, np.int32); r2l = np.full(len(kR), -1, np.int32)
+        dep = np.full(len(kL), -1, np.float32); p3 = np.zeros((len(kL), 3), np.float32)
+        for i, j in enumerate(o["matches"]):
+            if j >= 0:
+                l2r[mL + i] = mR + j
+                r2l[mR + j] = mL + i
+        dep[mL:] = o["depth"]
+        p3[mL:] = o["p3d"]
+        want.append((l2r, r2l, dep, p3, o["n"]))
+        kw = dict(keys=kL, keys_right=kR, descriptors=np.concatenate([dL, dR]), bounds=sc.frame_bounds(w, h), left_to_right=l2r,
+                  right_to_left=r2l, cam_model=1, cam=cam, Trl=TRL)
+        views.append(orb.FrameView(scale_factors=sf, **kw))
+    tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=2 * exL.max_keypoints + 64, max_points=512)
+    got = tb.bind_fisheye(exL, exR, views, lap, lap, rig=grig, level_sigma2=sig2)
+    kept = dropped = 0
+    for f in range(B):
+        l2r, r2l, dep, p3, n = want[f]
+        assert np.array_equal(got[f][0], l2r), f"frame {f}: mvLeftToRightMatch"
+        assert np.array_equal(got[f][1], r2l), f"frame {f}: mvRightToLeftMatch"
+        assert np.array_equal(got[f][2], dep), f"frame {f}: mvDepth"
+        assert np.array_equal(got[f][3], p3), f"frame {f}: mvStereo3Dpoints"
+        assert got[f][4] == n
+        kept += n
+        m = ob.fisheye_match(rL[f][1][rL[f][2]:], rR[f][1][rR[f][2]:])["matches"]
+        dropped += int((m >= 0).sum()) - n
+    assert kept > 5 * B and dropped > 0      # the filter keeps pairs and rejects pairs
+    for o in (tb, exL, exR):
+        o.close()
