@@ -120,6 +120,11 @@ struct FtFrustumOut {
 // in HBM.  Every pointer of a job points into the device arena of its batch (`arena` of the launchers below: the kernels
 // re-derive the pointers from it, see Rebase in kernels_search.hip).  The rotating buffers of the claim iteration are addressed by pass number (job_claims, kernels_search.hip):
 // res 2 x 4 nPoints | head 3 x K | next 2 x 4 nPoints | tab 3 x 8 K (K = keypoints rounded up to 8) | flags FT_BATCH_FLAGS.
+// projection of a last-frame point into the current frame's camera(s) (k_last_project_batch, kernels_search.hip)
+struct FtLastProj {
+    float u, v, invzc, ur, vr;
+    int go;  // projects into the image (src/ORBmatcher.cc:1807-1822)
+};
 #define FT_BATCH_FLAGS 64  // flag words per frame of a batch: two burst parities x 32 positions (a power of two)
 struct FtBatchJob {
     FtDevFrame F;
@@ -132,6 +137,7 @@ struct FtBatchJob {
     FtDevLastPoints L;
     FtPose Tcw;
     int forward, backward;
+    FtLastProj *proj;  // [L.N], written by the first pass's projection launch
     // isInFrustum + SearchByProjection(Frame, local map points)
     FtDevMapPoints MP;
     FtFrustumPose T;

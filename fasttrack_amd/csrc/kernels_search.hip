@@ -269,8 +269,12 @@ __device__ __forceinline__ void cache_append(const CacheBuild &B, unsigned long 
 // least FT_CACHE_HEAD keys <= D by bisection over the 9 bits of the distance (a count per step), then a stable partition of
 // the list by dist <= D.  The head's length goes into the meta word; a list that is short, or whose head would not be short
 // (many equal distances), keeps head = count - as every list of the single-frame path does.
+#ifndef FT_CACHE_HEAD
 #define FT_CACHE_HEAD 16
+#endif
+#ifndef FT_CACHE_HEAD_MAX
 #define FT_CACHE_HEAD_MAX 48
+#endif
 __device__ __forceinline__ int cache_partition(unsigned long long *slot, int n, int lane) {
     constexpr int PER = (FT_CACHE_CAP + 63) / 64;
     unsigned long long k[PER];
@@ -769,9 +773,12 @@ __device__ __forceinline__ void transform_pose(const float *m, const float *q, i
 
 // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) for last-frame point i by one wave (src/ORBmatcher.cc:
 // 1775-1960): r = (left keypoint written, -1, right keypoint written, -1)
+// pre (may be null): the projections of the points, computed once per point by k_last_project_batch - the pose transform and the
+// camera model (two atan2f, a cosf and a sinf per camera for KannalaBrandt8) are the same number in all 64 lanes of a point's wave
+template <bool PRE = false>
 __device__ __forceinline__ void last_point(const FtDevFrame &F, const FramePtrs &Q, const FtDevLastPoints &Lp, const FtClaims &C, const FtPose &Tcw,
                                            float th, int bForward, int bBackward, int i, int lane, int r4[4], const FtLastRaw &raw,
-                                           int *ldsCounter) {
+                                           int *ldsCounter, const FtLastProj *pre = nullptr) {
     int primL = -1, primR = -1;
     int bd = 256, bi = -1, bdr = 256, bir = -1;
     // Later passes of the claim iteration on a point whose candidates are cached need neither the pose transform nor the camera
@@ -819,16 +826,23 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FramePtrs 
             }
         }
     } else if (validV) {
-        float xw[3] = {Lp.worldPos[3 * i], Lp.worldPos[3 * i + 1], Lp.worldPos[3 * i + 2]};
-        float xc[3];
-        transform_pose(Tcw.m, Tcw.q, Tcw.quat, xw, xc);
-        const float invzc = (float)(1.0 / (double)xc[2]);
-        float uv[2];
-        bool go = !(invzc < 0);
-        if (go) {
-            project_cam(F, xc, uv);
-            if (uv[0] < F.mnMinX || uv[0] > F.mnMaxX) go = false;
-            if (uv[1] < F.mnMinY || uv[1] > F.mnMaxY) go = false;
+        float xc[3] = {0.f, 0.f, 0.f}, uv[2] = {0.f, 0.f}, uvrPre[2] = {0.f, 0.f};
+        float invzc;
+        bool go;
+        if constexpr (PRE) {
+            const FtLastProj pj = pre[i];
+            uv[0] = pj.u; uv[1] = pj.v; invzc = pj.invzc; uvrPre[0] = pj.ur; uvrPre[1] = pj.vr;
+            go = pj.go != 0;
+        } else {
+            float xw[3] = {Lp.worldPos[3 * i], Lp.worldPos[3 * i + 1], Lp.worldPos[3 * i + 2]};
+            transform_pose(Tcw.m, Tcw.q, Tcw.quat, xw, xc);
+            invzc = (float)(1.0 / (double)xc[2]);
+            go = !(invzc < 0);
+            if (go) {
+                project_cam(F, xc, uv);
+                if (uv[0] < F.mnMinX || uv[0] > F.mnMaxX) go = false;
+                if (uv[1] < F.mnMinY || uv[1] > F.mnMaxY) go = false;
+            }
         }
         // a point that does not project into the image: an empty cache entry spares the later passes the projection
         if (!go && slotL && lane == 0 && metaL == KEY_NONE) slotL[0] = 0ull;
@@ -897,8 +911,13 @@ __device__ __forceinline__ void last_point(const FtDevFrame &F, const FramePtrs 
                 if (bd <= FT_TH_HIGH) primL = bi;
                 if (F.Nleft != -1) {
                     float xr[3], uvr[2];
-                    transform_pose(F.Trl, F.TrlQ, F.trlQuat, xc, xr);
-                    project_cam(F, xr, uvr);
+                    if constexpr (PRE) {
+                        uvr[0] = uvrPre[0];
+                        uvr[1] = uvrPre[1];
+                    } else {
+                        transform_pose(F.Trl, F.TrlQ, F.trlQuat, xc, xr);
+                        project_cam(F, xr, uvr);
+                    }
                     const Window wr = cell_window(F, uvr[0], uvr[1], radius);
                     const int nRight = F.N - F.Nleft;
                     unsigned long long kr = KEY_NONE;
@@ -961,6 +980,41 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last(FtDevFrame F
     claims_file(C, res, i, lane, r4);
 }
 
+// the projections of SearchByProjection(CurrentFrame, LastFrame) once per point (thread per point, blockIdx.y = frame): exactly the
+// expressions of last_point - Tcw * x3Dw, 1 / z, mpCamera->project, the bounds test, and for two-camera frames Trl * x3Dc and
+// mpCamera2->project (src/ORBmatcher.cc:1805-1822, 1900-1902)
+__global__ __launch_bounds__(256) void k_last_project_batch(const FtBatchJob *__restrict__ jobs, Rebase rb) {
+    const FtBatchJob &J = jobs[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= J.L.N || J.nPoints <= 0) return;
+    const FtDevFrame &F = J.F;
+    FtLastProj pj;
+    pj.u = pj.v = pj.invzc = pj.ur = pj.vr = 0.f;
+    pj.go = 0;
+    if (rb(J.L.valid)[i]) {
+        const float *wp = rb(J.L.worldPos);
+        const float xw[3] = {wp[3 * i], wp[3 * i + 1], wp[3 * i + 2]};
+        float xc[3], uv[2] = {0.f, 0.f};
+        transform_pose(J.Tcw.m, J.Tcw.q, J.Tcw.quat, xw, xc);
+        const float invzc = (float)(1.0 / (double)xc[2]);
+        bool go = !(invzc < 0);
+        if (go) {
+            project_cam(F, xc, uv);
+            if (uv[0] < F.mnMinX || uv[0] > F.mnMaxX) go = false;
+            if (uv[1] < F.mnMinY || uv[1] > F.mnMaxY) go = false;
+        }
+        pj.u = uv[0]; pj.v = uv[1]; pj.invzc = invzc;
+        pj.go = go ? 1 : 0;
+        if (go && F.Nleft != -1) {
+            float xr[3], uvr[2];
+            transform_pose(F.Trl, F.TrlQ, F.trlQuat, xc, xr);
+            project_cam(F, xr, uvr);
+            pj.ur = uvr[0]; pj.vr = uvr[1];
+        }
+    }
+    rb(J.proj)[i] = pj;
+}
+
 // ---- B frames per launch (ft_tracked_batch) --------------------------------------------------------------------------------
 // One frame at a time leaves the chip idle by construction: a pass of the claim iteration is ~500 workgroups and a handful
 // of dependent L2 round trips, 9 - 13 passes per search, each a launch.  Here blockIdx.y is the FRAME: everything a pass
@@ -1013,7 +1067,7 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last_batch(const 
         const int i = blockIdx.x * FT_SEARCH_WPB + wave;
         if (i >= J.L.N) return;
         int r4[4];
-        last_point(J.F, Q, L, C, J.Tcw, th, J.forward, J.backward, i, lane, r4, raw, &cacheCounter[wave]);
+        last_point<true>(J.F, Q, L, C, J.Tcw, th, J.forward, J.backward, i, lane, r4, raw, &cacheCounter[wave], rb(J.proj));
         claims_file(C, res, i, lane, r4);
         return;
     } else {
@@ -1023,7 +1077,7 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last_batch(const 
     for (int k = blockIdx.x * FT_SEARCH_WPB + wave; k < count; k += gridDim.x * FT_SEARCH_WPB) {
         const int i = slow[16 + (size_t)(pass & 1) * J.nPoints + k];
         int r4[4];
-        last_point(J.F, Q, L, C, J.Tcw, th, J.forward, J.backward, i, lane, r4, raw, &cacheCounter[wave]);
+        last_point<true>(J.F, Q, L, C, J.Tcw, th, J.forward, J.backward, i, lane, r4, raw, &cacheCounter[wave], rb(J.proj));
         claims_file(C, res, i, lane, r4);
     }
     }
@@ -1656,6 +1710,8 @@ int ft_launch_frustum_batch(hipStream_t st, void *arena, const FtBatchJob *jobs,
 int ft_launch_search_last_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur, int fPrev,
                                 int fReset, float th) {
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
+    if (pass == 0)  // the points' projections, once (J.proj; the later passes and the slow lists read them too)
+        hipLaunchKernelGGL(k_last_project_batch, dim3((maxPoints + 255) / 256, nFrames), dim3(256), 0, st, jobs, rebase_of(arena));
     hipLaunchKernelGGL(k_search_last_batch<false>, dim3((maxPoints + FT_SEARCH_WPB - 1) / FT_SEARCH_WPB, nFrames), dim3(64 * FT_SEARCH_WPB), 0, st,
                        jobs, rebase_of(arena), pass, fCur, fPrev, fReset, th);
     FT_HIP(hipGetLastError());

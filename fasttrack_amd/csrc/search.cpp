@@ -1206,7 +1206,7 @@ size_t batchFrameBytes(int maxKp) {
     return (2 * sizeof(ft_keypoint) + 32 + 4 * 4) * K + 8 * 64;
 }
 // per call and frame: point inputs (<= 69 B), frustum outputs (<= 47 B) per point + alignment slack
-size_t batchWorkBytes(int maxPts) { return 128 * (size_t)maxPts + 24 * 64 + sizeof(FtBatchJob) + 4 * sizeof(FtDeliverRec); }
+size_t batchWorkBytes(int maxPts) { return 128 * (size_t)maxPts + 26 * 64 + sizeof(FtBatchJob) + 4 * sizeof(FtDeliverRec); }
 size_t batchOutBytes(int maxPts) { return (16 + 47) * (size_t)maxPts + 20 * 64; }
 
 // the claim buffers of frame f for a search of nPoints points on nKp keypoints
@@ -1505,7 +1505,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     const size_t oJobs = a.take((size_t)n * sizeof(FtBatchJob));
     const size_t oRecs = a.take((size_t)(n + 1) * sizeof(FtDeliverRec));
     struct Lay {
-        size_t valid, pos, desc, obs, oct, out;
+        size_t valid, pos, desc, obs, oct, out, proj;
     };
     std::vector<Lay> lay(n);
     Arena o;  // results in tb->h_out
@@ -1520,6 +1520,8 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         lay[f].oct = a.take(4 * M);
         lay[f].out = o.take(16 * M);
     }
+    const size_t inputEnd = a.off;  // what follows is device-only: the projections
+    for (int f = 0; f < n; f++) lay[f].proj = a.take(sizeof(FtLastProj) * (size_t)std::max(L[f].N, 1));
     FT_REQUIRE(a.off <= tb->workBytes && o.off <= tb->outBytes, "tracked batch work arena too small");
     uint8_t *pin = tb->h_in, *dev = tb->d_arena + tb->oWork;
     FtBatchJob *hJobs = (FtBatchJob *)(pin + oJobs);
@@ -1547,6 +1549,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         J.L.worldPos = (const float *)(dev + lay[f].pos);
         J.L.desc = dev + lay[f].desc;
         J.L.octave = (const int *)(dev + lay[f].oct);
+        J.proj = (FtLastProj *)(dev + lay[f].proj);
         J.Tcw = poses[f];
         J.forward = forward ? forward[f] : 0;
         J.backward = backward ? backward[f] : 0;
@@ -1567,7 +1570,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     hRecs[n].words = FT_BATCH_FLAGS * n;
     ctx->addStat("tracked_batch.search_last_frame.stage", tAll.ms());
     FtTimer tDev;
-    FT_HIP(hipMemcpyAsync(dev, pin, a.off, hipMemcpyHostToDevice, st));
+    FT_HIP(hipMemcpyAsync(dev, pin, inputEnd, hipMemcpyHostToDevice, st));
     const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
     const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
     int parity = 0, passes = 0;
