@@ -342,3 +342,45 @@ def test_tracked_batch_bind_with_triangulation_equals_oracle_fisheye_stereo(ctx)
     assert kept > 5 * B and dropped > 0      # the filter keeps pairs and rejects pairs
     for o in (tb, exL, exR):
         o.close()
+
+
+def test_two_batches_in_flight_from_two_threads(ctx):
+    """a batch object has a stream and a lock of its own: two batches of one context driven by two host threads at the same time
+    (the passes of one beside the staging / replay of the other) each give the oracle's results, call after call"""
+    import threading
+    sf, _ = ob.scale_factors(1.2, 8)
+    B = 12
+    sets = []
+    for t in range(2):
+        frames, lasts, Tcws, ptss, poses, oracle = [], [], [], [], [], []
+        for f in range(B):
+            oF, gF, kL, dL = _kb8_views(_kb8_base(2000, 10 + (f + t) % 4), sf)
+            last, Tcw, pts, Rcw, tcw = _kb8_inputs(kL, dL, sf, 5000 + 100 * t + f, 1500)
+            o1 = ob.search_last_frame(oF, last, Tcw, 7.0, False, False, True)
+            ofr = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, TLR), pts, 0.5, LOG_SF)
+            o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, pts), 7.0)
+            frames.append(gF); lasts.append(last); Tcws.append(Tcw); ptss.append(pts); poses.append(orb.make_pose(Rcw, tcw, TLR))
+            oracle.append((o1, ofr, o2, oF))
+        sets.append((frames, lasts, Tcws, ptss, poses, oracle))
+    tbs = [orb.TrackedBatch(ctx, max_frames=B, max_keypoints=sets[t][0][0].c.N + 64, max_points=2048) for t in range(2)]
+    errors = []
+
+    def work(t):
+        try:
+            frames, lasts, Tcws, ptss, poses, oracle = sets[t]
+            for rep in range(6):
+                tbs[t].upload(frames)
+                g1 = tbs[t].search_last_frame(lasts, Tcws, 7.0)
+                g2 = tbs[t].track_local_map(poses, ptss, 0.5, LOG_SF, 7.0)
+                for f in range(B):
+                    _check_frame(f"thread {t} rep {rep} frame {f}", g1[f], g2[f], tbs[t].holder_obs(f), *oracle[f])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for tb in tbs:
+        tb.close()
+    assert not errors, errors
