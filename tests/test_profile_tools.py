@@ -65,3 +65,22 @@ def test_a_profile_of_another_library_build_is_dropped(tmp_path, monkeypatch):
     files = sorted(f for ext in ("*.cpp", "*.hip", "*.h", "*.inc") for f in glob.glob(os.path.join(csrc, ext)) if not f.endswith("version.inc"))
     h = hashlib.sha1(b"".join(open(f, "rb").read() for f in files)).hexdigest()[:12]
     assert bench.csrc_stamp(orb.version()) == h
+
+
+def test_committed_r05_artefacts_belong_to_this_library():
+    """the round's traffic / marginal-cost artefacts were measured on the library this tree builds (same csrc hash): bench.py's
+    driver line will carry them; and the committed bench line reports them as current"""
+    import importlib.util
+    from fasttrack_amd import orb
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stamp = bench.csrc_stamp(orb.version())
+    for name in (bench.TRAFFIC_JSON, bench.MARGINAL_JSON):
+        d, state = bench.load_profile(name, stamp)
+        assert state == "current", (name, state)
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    assert bench.csrc_stamp(line["library"]) == stamp and set(line["profiles"].values()) == {"current"}
+    assert line["roofline"]["traffic"] and 0.9 < line["roofline"]["traffic_over_algorithmic"] < 1.1
+    thr = line["workloads"]["tracking_512x512_nf2000"]["throughput"]
+    assert thr["by_th"]["7"]["value"] >= 15000 and thr["batch_frames"] >= 64 and thr["launches_per_frame"] < 2
