@@ -77,11 +77,14 @@ __device__ __forceinline__ int key_idx(unsigned long long k) { return (int)((k >
 __device__ __forceinline__ int key_octave(unsigned long long k) { return (int)((k >> 1) & 15ull); }
 __device__ __forceinline__ bool key_held(unsigned long long k) { return (k & 1ull) != 0; }
 
-// The words one pass of the claim iteration hands to the next - writer lists, results, flags - are written and read by
-// DIFFERENT workgroups of consecutive launches: every access to them is an agent-scope relaxed atomic (sc1: stores write
-// through, loads are served by the L2, never by a CU's L1, which no other CU's store ever refreshes).
-__device__ __forceinline__ int shared_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void shared_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The words one pass of the claim iteration hands to the next - writer records, lists, results, flags - are written and read by
+// DIFFERENT workgroups, but of DIFFERENT launches: a pass reads what the previous launch wrote (its own L1 starts empty) and
+// writes what the next launch reads, never a word it also reads.  Plain loads and stores therefore do (rounds 3 - 4 kept them
+// agent-scope atomics, sc1, for the sake of the persistent single-launch form, deleted in round 5): a record is two 16-byte
+// loads that the L1 may keep for the other points of the CU that look at the same keypoint, a clear is 16-byte stores.  Only the
+// read-modify-writes are atomics (record positions, list heads, the "changed" flag).
+__device__ __forceinline__ int shared_load(const int *p) { return *p; }
+__device__ __forceinline__ void shared_store(int *p, int v) { *p = v; }
 
 // Writer table of a pass: per keypoint a 32-byte record {last position handed out, 7 entries}, entry = (4 * point + write
 // kind) << 1 | (Observations() of the point > 0), -1 = empty; an eighth and later writer of one keypoint (never seen outside
@@ -89,15 +92,24 @@ __device__ __forceinline__ void shared_store(int *p, int v) { __hip_atomic_store
 // pass everything about a keypoint - where the linked lists of rounds 1-3 cost a dependent load per writer plus one for the
 // writer's Observations() (a later pass is nothing but a chain of such round trips, ~1 us each).
 #define FT_TAB_ENTRIES 7
-__device__ __forceinline__ unsigned long long shared_load64(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // F.mvpMapPoints[kp] && ->Observations() > 0 as seen by map point i: the last writer j < i of the previous pass decides,
 // else the pre-call holder (heldBefore)
-__device__ __forceinline__ bool is_locked(const FtClaims &C, int kp, int i, bool heldBefore) {
-    if (C.firstPass) return heldBefore;
-    const unsigned long long *rec = (const unsigned long long *)(C.tab + 8 * (size_t)kp);
-    const unsigned long long a = shared_load64(rec), b = shared_load64(rec + 1), c = shared_load64(rec + 2), d = shared_load64(rec + 3);
+struct LockRec {
+    unsigned long long a, b, c, d;
+};
+__device__ __forceinline__ LockRec lock_record(const FtClaims &C, int kp) {
+    const uint4 *rec = (const uint4 *)(C.tab + 8 * (size_t)kp);
+    const uint4 lo = rec[0], hi = rec[1];
+    LockRec r;
+    r.a = (unsigned long long)lo.x | ((unsigned long long)lo.y << 32);
+    r.b = (unsigned long long)lo.z | ((unsigned long long)lo.w << 32);
+    r.c = (unsigned long long)hi.x | ((unsigned long long)hi.y << 32);
+    r.d = (unsigned long long)hi.z | ((unsigned long long)hi.w << 32);
+    return r;
+}
+// the decision of is_locked on a record that is already in registers (not a first pass)
+__device__ __forceinline__ bool locked_by(const FtClaims &C, const LockRec &r, int kp, int i, bool heldBefore) {
+    const unsigned long long a = r.a, b = r.b, c = r.c, d = r.d;
     const int last = (int)(unsigned)a;
     int best = -1;
     auto take = [&](int e) {
@@ -108,6 +120,10 @@ __device__ __forceinline__ bool is_locked(const FtClaims &C, int kp, int i, bool
     if (last >= FT_TAB_ENTRIES)
         for (int e = shared_load(&C.head[kp]); e >= 0; e = shared_load(&C.next[e >> 1])) take(e);
     return best >= 0 ? (best & 1) != 0 : heldBefore;
+}
+__device__ __forceinline__ bool is_locked(const FtClaims &C, int kp, int i, bool heldBefore) {
+    if (C.firstPass) return heldBefore;
+    return locked_by(C, lock_record(C, kp), kp, i, heldBefore);
 }
 
 // start of a claim-iteration pass (see FtClaims): false = the iteration has converged, nothing to do
@@ -121,8 +137,8 @@ __device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) {
     }
     const int t = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
     for (int k = t; k < C.nKp; k += T) shared_store(&C.headClear[k], -1);
-    unsigned long long *tc = (unsigned long long *)C.tabClear;
-    for (int k = t; k < 4 * C.nKp; k += T) __hip_atomic_store(&tc[k], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint4 *tc = (uint4 *)C.tabClear;  // (32-byte records, 32-byte aligned)
+    for (int k = t; k < 2 * C.nKp; k += T) tc[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
     if (t == 0) {
         shared_store(C.flagReset, -1);
         if (C.firstPass) shared_store(C.flagCur, 0);  // the first pass always "changes" its input
@@ -1180,6 +1196,15 @@ __global__ __launch_bounds__(256) void k_search_local_lean(const FtBatchJob *__r
     const int levelRV = twoCam ? levelRP[i] : -1;
     const unsigned long long metaL = slotL[0], metaR = twoCam ? slotR[0] : KEY_NONE;
     const int obsI = C.obs[i];
+    // A pass is a chain of dependent round trips, and the chip is full of such chains: the first 16 keys of both cameras'
+    // lists are requested together with the flags and the meta words, and the lock records of both - the right camera's on
+    // the chance that its block is reached - in ONE further trip (flags -> meta -> keys -> records left -> l2r -> records right
+    // used to be six).  A key beyond a list's head is not a key: its "record" is the one of keypoint 0, read and dropped.
+    const unsigned long long keyL0 = slotL[1 + sub], keyR0 = twoCam ? slotR[1 + sub] : KEY_NONE;
+    const int headL0 = metaL == KEY_NONE ? 0 : min(cache_head(metaL), FT_CACHE_CAP), headR0 = metaR == KEY_NONE ? 0 : min(cache_head(metaR), FT_CACHE_CAP);
+    const bool haveL0 = sub < headL0, haveR0 = sub < headR0;
+    const int kpL0 = haveL0 ? key_idx(keyL0) : 0, kpR0 = haveR0 ? key_idx(keyR0) + F.Nleft : 0;
+    const LockRec recL0 = lock_record(C, kpL0), recR0 = lock_record(C, kpR0);
     int primL = -1, sideL = -1, primR = -1, sideR = -1;
     bool skipRight = false, slowPoint = false;
     if (!skipV) {
@@ -1190,7 +1215,8 @@ __global__ __launch_bounds__(256) void k_search_local_lean(const FtBatchJob *__r
             else {
                 unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
                 const int head = cache_head(metaL);
-                for (int t = sub; t < head; t += 16) {
+                if (haveL0 && !locked_by(C, recL0, kpL0, i, key_held(keyL0))) k0 = keyL0;
+                for (int t = 16 + sub; t < head; t += 16) {
                     const unsigned long long key = slotL[1 + t];
                     if (is_locked(C, key_idx(key), i, key_held(key))) continue;
                     two_min_insert(k0, k1, key);
@@ -1236,7 +1262,8 @@ __global__ __launch_bounds__(256) void k_search_local_lean(const FtBatchJob *__r
                     }
                     row_two_min(k0, k1);
                 };
-                scan(0, head);
+                if (haveR0 && !((kpR0 == sideL) ? (obsI > 0) : locked_by(C, recR0, kpR0, i, key_held(keyR0)))) k0 = keyR0;
+                scan(16, head);
                 if (k1 == KEY_NONE && head < nCached) scan(head, nCached);
                 int bdr = 256, bd2r = 256, blr = -1, bl2r = -1, bir = -1;
                 if (k0 != KEY_NONE) { bdr = key_dist(k0); bir = key_idx(k0); blr = key_octave(k0); }
@@ -1274,6 +1301,12 @@ __global__ __launch_bounds__(256) void k_search_last_lean(const FtBatchJob *__re
     const unsigned long long *slotL = C.cache + (size_t)i * FT_CACHE_WORDS, *slotR = slotL + (FT_CACHE_CAP + 1);
     const uint8_t validV = rb(J.L.valid)[i];
     const unsigned long long metaL = slotL[0], metaR = twoCam ? slotR[0] : KEY_NONE;
+    // (as in k_search_local_lean: the first 16 keys of both lists with the meta words, their lock records in one further trip)
+    const unsigned long long keyL0 = slotL[1 + sub], keyR0 = twoCam ? slotR[1 + sub] : KEY_NONE;
+    const int headL0 = metaL == KEY_NONE ? 0 : min(cache_head(metaL), FT_CACHE_CAP), headR0 = metaR == KEY_NONE ? 0 : min(cache_head(metaR), FT_CACHE_CAP);
+    const bool haveL0 = sub < headL0, haveR0 = sub < headR0;
+    const int kpL0 = haveL0 ? key_idx(keyL0) : 0, kpR0 = haveR0 ? key_idx(keyR0) + F.Nleft : 0;
+    const LockRec recL0 = lock_record(C, kpL0), recR0 = lock_record(C, kpR0);
     int primL = -1, primR = -1;
     if (validV) {
         int nCachedL = 0, nCachedR = 0;
@@ -1295,13 +1328,23 @@ __global__ __launch_bounds__(256) void k_search_last_lean(const FtBatchJob *__re
         };
         // the head of the list first (cache_partition): an unlocked key there is smaller than every key behind it
         const int headL = cache_head(metaL);
-        unsigned long long k0 = scanMin(slotL, 0, headL, 0);
+        const unsigned long long firstL = (haveL0 && !locked_by(C, recL0, kpL0, i, key_held(keyL0))) ? keyL0 : KEY_NONE;
+        unsigned long long k0 = headL > 16 ? scanMin(slotL, 16, headL, 0) : KEY_NONE;
+        {
+            const unsigned long long m = row_min_u64(firstL);
+            k0 = m < k0 ? m : k0;
+        }
         if (k0 == KEY_NONE && headL < nCachedL) k0 = scanMin(slotL, headL, nCachedL, 0);
         if (anyBoxL) {
             if (k0 != KEY_NONE && key_dist(k0) <= FT_TH_HIGH) primL = key_idx(k0);
             if (twoCam) {
                 const int headR = cache_head(metaR);
-                unsigned long long kr = scanMin(slotR, 0, headR, F.Nleft);
+                const unsigned long long firstR = (haveR0 && !locked_by(C, recR0, kpR0, i, key_held(keyR0))) ? keyR0 : KEY_NONE;
+                unsigned long long kr = headR > 16 ? scanMin(slotR, 16, headR, F.Nleft) : KEY_NONE;
+                {
+                    const unsigned long long m = row_min_u64(firstR);
+                    kr = m < kr ? m : kr;
+                }
                 if (kr == KEY_NONE && headR < nCachedR) kr = scanMin(slotR, headR, nCachedR, F.Nleft);
                 if (kr != KEY_NONE && key_dist(kr) <= FT_TH_HIGH) primR = key_idx(kr) + F.Nleft;
             }
@@ -1551,8 +1594,19 @@ __global__ __launch_bounds__(256) void k_fisheye_2nn_batch(const FtBatchJob *__r
     unsigned k0[FE_Q], k1[FE_Q];
 #pragma unroll
     for (int q = 0; q < FE_Q; q++) k0[q] = k1[q] = 0xffffffffu;
+    // (the next train descriptor is requested before the current one is compared with the sixteen queries: 320 vector
+    // instructions cover its round trip, where two waves per SIMD - 175 registers - could not)
+    uint4 an = make_uint4(0, 0, 0, 0), bn = an;
+    if (lane < nT) {
+        an = td[2 * (size_t)lane];
+        bn = td[2 * (size_t)lane + 1];
+    }
     for (int j = lane; j < nT; j += 64) {
-        const uint4 a = td[2 * (size_t)j], b = td[2 * (size_t)j + 1];
+        const uint4 a = an, b = bn;
+        if (j + 64 < nT) {
+            an = td[2 * (size_t)(j + 64)];
+            bn = td[2 * (size_t)(j + 64) + 1];
+        }
 #pragma unroll
         for (int q = 0; q < FE_Q; q++) {
             const uint4 x = qs[wave][2 * q], y = qs[wave][2 * q + 1];  // (same address in every lane: a broadcast)
