@@ -1065,8 +1065,11 @@ __device__ __forceinline__ FtClaims job_claims(const FtBatchJob &J, const Rebase
 
 // slowList != 0: a later pass - the points the lean kernel (k_search_*_lean, below) could not serve from the candidate cache, by
 // a grid-stride loop over the frame's slow list of this pass's parity; the pass's clears were done by the lean kernel
+#ifndef FT_BATCH_WAVES
+#define FT_BATCH_WAVES 6  // waves per SIMD the first-pass kernels are compiled for (80 registers, 12 - 32 bytes of scratch: 0.60 -> 0.545 ms; 8: spills, 0.82 ms)
+#endif
 template <bool slowList>
-__global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur,
+__global__ __launch_bounds__(64 * FT_SEARCH_WPB) __attribute__((amdgpu_waves_per_eu(FT_BATCH_WAVES, 8))) void k_search_last_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur,
                                                                           int fPrev, int fReset, float th) {
     const FtBatchJob &J = jobs[blockIdx.y];
     if (J.nPoints <= 0) return;
@@ -1100,7 +1103,7 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_last_batch(const 
 }
 
 template <bool slowList>
-__global__ __launch_bounds__(64 * FT_SEARCH_WPB) void k_search_local_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur,
+__global__ __launch_bounds__(64 * FT_SEARCH_WPB) __attribute__((amdgpu_waves_per_eu(FT_BATCH_WAVES, 8))) void k_search_local_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int pass, int fCur,
                                                                            int fPrev, int fReset, float th, float nnRatio) {
     const FtBatchJob &J = jobs[blockIdx.y];
     if (J.nPoints <= 0) return;
