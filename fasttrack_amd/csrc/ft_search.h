@@ -183,6 +183,10 @@ int ft_launch_search_last_batch(hipStream_t st, void *arena, const FtBatchJob *j
                                 int fReset, float th);
 int ft_launch_search_local_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur, int fPrev,
                                  int fReset, float th, float nnRatio);
+// the first pass with four points per wave (a point = a row of 16 lanes): every frame needs its grid and the candidate cache;
+// fills the lists, results and writer table exactly as pass 0 of ft_launch_search_*_batch does
+int ft_launch_search_last_first(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, float th);
+int ft_launch_search_local_first(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, float th, float nnRatio);
 // a pass behind the first one: lean kernel (four points per wave from the candidate cache) + the general kernel on its slow list
 int ft_launch_search_last_batch_lean(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur,
                                      int fPrev, int fReset, float th);

@@ -1141,6 +1141,286 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) __attribute__((amdgpu_waves_per
     }
 }
 
+// ---- first pass of a batch, four points per wave --------------------------------------------------------------------------
+// The general kernel gives the window scan of ONE point a whole wave: at th 7 a window holds ~50 candidates of a few (octave,
+// column) ranges - most lanes idle through ~600 instructions per point.  Here a point is a ROW of 16 lanes from the start
+// (as in the lean kernels of the later passes): the ranges of its window one per lane (a DPP scan inside the row lays them end
+// to end), the entries 16 at a time (the range of an entry by a few row-local shuffles), the candidates filed in the point's
+// cache at positions handed out by a ballot of the row (no LDS counter), the minimum (two minima) by DPP steps inside the row.
+// What is computed per entry - box, level band, uright test, Hamming distance, key - and what is filed are exactly the
+// general kernel's (the order of a list is free), so the later passes cannot tell which kernel ran the first one.  First pass:
+// nothing is locked but what was held before the call.
+__device__ __forceinline__ int row_shfl(int v, int srcLane) { return __shfl(v, srcLane); }
+// the two smallest keys of a row, in every lane of it
+__device__ __forceinline__ void row_two_min(unsigned long long &k0, unsigned long long &k1) {
+    const unsigned long long m0 = row_min_u64(k0);
+    const unsigned long long cand = (k0 == m0) ? k1 : k0;
+    k1 = row_min_u64(cand);
+    k0 = m0;
+}
+
+template <class Fn>
+__device__ __forceinline__ void row_for_window(const FtDevFrame &F, const FramePtrs &Q, int cam, const Window &w, int minLevel, int maxLevel,
+                                               int sub, int rowBase, Fn fn) {
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    const int lo = checkLevels ? min(max(minLevel, 0), F.nlevels - 1) : 0;
+    const int hi = (checkLevels && maxLevel >= 0) ? min(maxLevel, F.nlevels - 1) : F.nlevels - 1;
+    const int ncolsW = w.maxCX - w.minCX + 1;
+    const int npairs = (hi - lo + 1) * ncolsW;  // (<= 0: an empty band)
+    const int *gs = Q.gridStart[cam];
+    const float4 *rec = Q.gridRec[cam];
+    const uint4 *gd = (const uint4 *)Q.gridDesc[cam];
+    const unsigned colMagic = div_magic_u(ncolsW);
+    for (int p0 = 0; p0 < npairs; p0 += 16) {  // (row-uniform)
+        const int np = min(16, npairs - p0);
+        int b = 0, cnt = 0, myCol = 0;
+        if (sub < np) {
+            const int pidx = p0 + sub;
+            const int oi = colMagic ? (int)__umulhi((unsigned)pidx, colMagic) : pidx;
+            myCol = w.minCX + (pidx - oi * ncolsW);
+            const int *col = gs + (size_t)(lo + oi) * (FT_GRID_CELLS + 1) + myCol * FT_GRID_ROWS;
+            b = col[w.minCY];
+            cnt = col[w.maxCY + 1] - b;
+        }
+        int incl = cnt;  // inclusive scan over the 16 lanes of the row (lanes shifted in from outside the row read 0)
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);  // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);  // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);  // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr:8
+        const int total = row_shfl(incl, rowBase + 15);
+        for (int t0 = 0; t0 < total; t0 += 16) {  // (row-uniform)
+            const int t = t0 + sub, tt = min(t, total - 1);
+            int r = 0;  // the range entry tt falls into: the number of ranges that end at or before tt
+            for (int c = 0; c < np - 1; c++) r += tt >= row_shfl(incl, rowBase + c) ? 1 : 0;
+            const int cb = row_shfl(b, rowBase + r), cEnd = row_shfl(incl, rowBase + r), cCnt = row_shfl(cnt, rowBase + r);
+            const int cx = row_shfl(myCol, rowBase + r);
+            const int pos = cb + (tt - (cEnd - cCnt));
+            const float4 rr = rec[pos];
+            const uint4 d0 = gd[2 * (size_t)pos], d1 = gd[2 * (size_t)pos + 1];
+            WinEntry e;
+            e.x = rr.x; e.y = rr.y; e.uright = rr.z;
+            const int io = __float_as_int(rr.w);
+            e.idx = io & 0xffffff;
+            e.octave = io >> 24;
+            e.cx = cx;
+            e.cy = (int)roundf(__fmul_rn(__fsub_rn(rr.y, F.mnMinY), F.invH));
+            e.d[0] = (unsigned long long)d0.x | ((unsigned long long)d0.y << 32);
+            e.d[1] = (unsigned long long)d0.z | ((unsigned long long)d0.w << 32);
+            e.d[2] = (unsigned long long)d1.x | ((unsigned long long)d1.y << 32);
+            e.d[3] = (unsigned long long)d1.z | ((unsigned long long)d1.w << 32);
+            fn(e, t < total);
+        }
+    }
+}
+// a candidate key into the point's list: positions by a ballot of the row (n = candidates filed so far, row-uniform)
+__device__ __forceinline__ void row_cache_append(unsigned long long *slot, int &n, bool cand, unsigned long long key, int sub, int rowBase) {
+    const unsigned bits = (unsigned)(__ballot(cand) >> rowBase) & 0xffffu;
+    if (cand) {
+        const int pos = n + __popc(bits & ((1u << sub) - 1u));
+        if (pos < FT_CACHE_CAP) slot[1 + pos] = key;
+    }
+    n += __popc(bits);
+}
+__device__ __forceinline__ void row_cache_end(unsigned long long *slot, int n, bool anyInBox, int sub) {
+    if (sub == 0)
+        slot[0] = (unsigned long long)(unsigned)n | ((unsigned long long)(anyInBox ? 1 : 0) << 32) | ((unsigned long long)(unsigned)min(n, FT_CACHE_CAP) << 40);
+}
+__device__ __forceinline__ bool row_any(bool v, int rowBase) { return ((unsigned)(__ballot(v) >> rowBase) & 0xffffu) != 0u; }
+// the first pass's claims_file for the point of a row: no previous results, every result counts as changed (the flag was set by
+// claims_begin_pass)
+__device__ __forceinline__ void claims_file_row_first(const FtClaims &C, int *res, int i, int sub, const int r4[4]) {
+    if (sub < 4) {
+        const int kp = sub == 0 ? r4[0] : sub == 1 ? r4[1] : sub == 2 ? r4[2] : r4[3];
+        const int s = 4 * i + sub;
+        res[s] = kp;
+        if (kp >= 0) {
+            const int e = (s << 1) | (C.obs[i] > 0 ? 1 : 0);
+            int *rec = C.tabWrite + 8 * (size_t)kp;
+            const int pos = atomicAdd(rec, 1) + 1;
+            if (pos < FT_TAB_ENTRIES) rec[1 + pos] = e;
+            else C.nextWrite[s] = atomicExch(&C.headWrite[kp], e);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_search_last_first(const FtBatchJob *__restrict__ jobs, Rebase rb, float th) {
+    const FtBatchJob &J = jobs[blockIdx.y];
+    if (J.nPoints <= 0) return;
+    int *res;
+    const FtClaims C = job_claims(J, rb, 0, 0, -1, FT_BATCH_FLAGS / 2, res);
+    claims_begin_pass(C);
+    const int lane = threadIdx.x & 63, sub = lane & 15, rowBase = lane & 48;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= J.L.N) return;
+    const FtDevFrame &F = J.F;
+    const FramePtrs Q = frame_ptrs(F, rb);
+    const bool twoCam = F.Nleft != -1;
+    unsigned long long *slotL = C.cache + (size_t)i * FT_CACHE_WORDS, *slotR = slotL + (FT_CACHE_CAP + 1);
+    int primL = -1, primR = -1;
+    if (rb(J.L.valid)[i]) {
+        const FtLastProj pj = rb(J.proj)[i];
+        if (!pj.go) {
+            if (sub == 0) slotL[0] = 0ull;  // does not project into the image: an empty list spares the later passes the question
+        } else {
+            const int oct = rb(J.L.octave)[i];
+            const float radius = __fmul_rn(th, F.sf[oct]);
+            int minLevel, maxLevel;
+            if (J.forward) { minLevel = oct; maxLevel = -1; }
+            else if (J.backward) { minLevel = 0; maxLevel = oct; }
+            else { minLevel = oct - 1; maxLevel = oct + 1; }
+            unsigned long long q[4];
+            {
+                const unsigned long long *p = (const unsigned long long *)(rb(J.L.desc) + (size_t)i * 32);
+                q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
+            }
+            const float u = pj.u, v = pj.v;
+            const Window w = cell_window(F, u, v, radius);
+            unsigned long long k0 = KEY_NONE;
+            int n = 0;
+            bool anyCand = false;
+            if (!w.empty) {
+                row_for_window(F, Q, 0, w, minLevel, maxLevel, sub, rowBase, [&](const WinEntry &kp, bool real) {
+                    const bool inb = real && in_box(kp, u, v, radius, minLevel, maxLevel);
+                    anyCand = anyCand || inb;
+                    bool cand = inb;
+                    if (cand && kp.uright > 0) {
+                        const float ur = __fsub_rn(u, __fmul_rn(F.mbf, pj.invzc));
+                        if (fabsf(__fsub_rn(ur, kp.uright)) > radius) cand = false;
+                    }
+                    const bool held = cand && Q.holderObs[cand ? kp.idx : 0] > 0;
+                    const unsigned long long key = make_key(hamming256(q, kp.d), kp.cx, kp.cy, kp.idx, kp.octave, held);
+                    row_cache_append(slotL, n, cand, key, sub, rowBase);
+                    if (cand && !held) k0 = key < k0 ? key : k0;
+                });
+            }
+            anyCand = row_any(anyCand, rowBase);
+            row_cache_end(slotL, n, anyCand, sub);
+            k0 = row_min_u64(k0);
+            if (anyCand) {  // `if(vIndices2.empty()) continue;` (ORBmatcher.cc:1836) also skips the right-camera block
+                if (k0 != KEY_NONE && key_dist(k0) <= FT_TH_HIGH) primL = key_idx(k0);
+                if (twoCam) {
+                    const float ur = pj.ur, vr = pj.vr;
+                    const Window wr = cell_window(F, ur, vr, radius);
+                    unsigned long long kr = KEY_NONE;
+                    int nr = 0;
+                    if (!wr.empty) {
+                        row_for_window(F, Q, 1, wr, minLevel, maxLevel, sub, rowBase, [&](const WinEntry &kp, bool real) {
+                            const bool cand = real && in_box(kp, ur, vr, radius, minLevel, maxLevel);
+                            const bool held = cand && Q.holderObs[(cand ? kp.idx : 0) + F.Nleft] > 0;
+                            const unsigned long long key = make_key(hamming256(q, kp.d), kp.cx, kp.cy, kp.idx, kp.octave, held);
+                            row_cache_append(slotR, nr, cand, key, sub, rowBase);
+                            if (cand && !held) kr = key < kr ? key : kr;
+                        });
+                    }
+                    row_cache_end(slotR, nr, false, sub);
+                    kr = row_min_u64(kr);
+                    if (kr != KEY_NONE && key_dist(kr) <= FT_TH_HIGH) primR = key_idx(kr) + F.Nleft;
+                }
+            }
+        }
+    }
+    const int r4[4] = {primL, -1, primR, -1};
+    claims_file_row_first(C, res, i, sub, r4);
+}
+
+__global__ __launch_bounds__(256) void k_search_local_first(const FtBatchJob *__restrict__ jobs, Rebase rb, float th, float nnRatio) {
+    const FtBatchJob &J = jobs[blockIdx.y];
+    if (J.nPoints <= 0) return;
+    int *res;
+    const FtClaims C = job_claims(J, rb, 0, 0, -1, FT_BATCH_FLAGS / 2, res);
+    claims_begin_pass(C);
+    const int lane = threadIdx.x & 63, sub = lane & 15, rowBase = lane & 48;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= J.P.M) return;
+    const FtDevFrame &F = J.F;
+    const FramePtrs Q = frame_ptrs(F, rb);
+    const bool twoCam = F.Nleft != -1;
+    unsigned long long *slotL = C.cache + (size_t)i * FT_CACHE_WORDS, *slotR = slotL + (FT_CACHE_CAP + 1);
+    const uint8_t skipV = rb(J.P.skip)[i], inViewV = rb(J.P.inView)[i], inViewRV = twoCam ? rb(J.P.inViewR)[i] : (uint8_t)0;
+    const int levelRV = twoCam ? rb(J.P.levelR)[i] : -1;
+    const int obsI = C.obs[i];
+    int primL = -1, sideL = -1, primR = -1, sideR = -1;
+    bool skipRight = false;
+    if (!skipV) {
+        unsigned long long q[4];
+        {
+            const unsigned long long *p = (const unsigned long long *)(rb(J.P.desc) + (size_t)i * 32);
+            q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
+        }
+        if (inViewV) {
+            const int level = rb(J.P.level)[i];
+            float r = ((double)rb(J.P.viewCos)[i] > 0.998) ? 2.5f : 4.0f;  // RadiusByViewingCos, ORBmatcher.cc:314-320
+            if ((double)th != 1.0) r = __fmul_rn(r, th);
+            const float rad = __fmul_rn(r, F.sf[level]);
+            const float x = rb(J.P.projX)[i], y = rb(J.P.projY)[i];
+            const Window w = cell_window(F, x, y, rad);
+            unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
+            int n = 0;
+            if (!w.empty) {
+                const float pxr = (F.Nleft == -1 && Q.uright) ? rb(J.P.projXR)[i] : 0.f;
+                row_for_window(F, Q, 0, w, level - 1, level, sub, rowBase, [&](const WinEntry &kp, bool real) {
+                    bool cand = real && in_box(kp, x, y, rad, level - 1, level);
+                    if (cand && kp.uright > 0 && fabsf(__fsub_rn(pxr, kp.uright)) > rad) cand = false;  // (mono-stereo frames only)
+                    const bool held = cand && Q.holderObs[cand ? kp.idx : 0] > 0;
+                    const unsigned long long key = make_key(hamming256(q, kp.d), kp.cx, kp.cy, kp.idx, kp.octave, held);
+                    row_cache_append(slotL, n, cand, key, sub, rowBase);
+                    if (cand && !held) two_min_insert(k0, k1, key);
+                });
+            }
+            row_cache_end(slotL, n, false, sub);
+            row_two_min(k0, k1);
+            int bd = 256, bd2 = 256, bl = -1, bl2 = -1, bi = -1;
+            if (k0 != KEY_NONE) { bd = key_dist(k0); bi = key_idx(k0); bl = key_octave(k0); }
+            if (k1 != KEY_NONE) { bd2 = key_dist(k1); bl2 = key_octave(k1); }
+            if (bd <= FT_TH_HIGH) {
+                if (bl == bl2 && (float)bd > __fmul_rn(nnRatio, (float)bd2)) skipRight = true;
+                else {
+                    primL = bi;
+                    if (twoCam) {
+                        const int m = Q.l2r[bi];
+                        if (m != -1) sideL = m + F.Nleft;
+                    }
+                }
+            }
+        }
+        // (a point whose left block ended in the ratio test's `continue` files its right-camera candidates all the same: a later
+        // pass may get past the test - the locks decide - and would otherwise have to come back here through the slow list)
+        if (twoCam && inViewRV && levelRV != -1) {
+            const int level = levelRV;
+            const float r = ((double)rb(J.P.viewCosR)[i] > 0.998) ? 2.5f : 4.0f;
+            const float rad = __fmul_rn(r, F.sf[level]);
+            const float x = rb(J.P.projXR)[i], y = rb(J.P.projYR)[i];
+            const Window w = cell_window(F, x, y, rad);
+            unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
+            int n = 0;
+            if (!w.empty) {
+                row_for_window(F, Q, 1, w, level - 1, level, sub, rowBase, [&](const WinEntry &kp, bool real) {
+                    const bool cand = real && in_box(kp, x, y, rad, level - 1, level);
+                    const int g = kp.idx + F.Nleft;
+                    const bool held = cand && Q.holderObs[cand ? g : 0] > 0;
+                    // this point's own left-block side write precedes its right-block search
+                    const bool locked = (g == sideL) ? (obsI > 0) : held;
+                    const unsigned long long key = make_key(hamming256(q, kp.d), kp.cx, kp.cy, kp.idx, kp.octave, held);
+                    row_cache_append(slotR, n, cand, key, sub, rowBase);
+                    if (cand && !locked) two_min_insert(k0, k1, key);
+                });
+            }
+            row_cache_end(slotR, n, false, sub);
+            row_two_min(k0, k1);
+            int bdr = 256, bd2r = 256, blr = -1, bl2r = -1, bir = -1;
+            if (k0 != KEY_NONE) { bdr = key_dist(k0); bir = key_idx(k0); blr = key_octave(k0); }
+            if (k1 != KEY_NONE) { bd2r = key_dist(k1); bl2r = key_octave(k1); }
+            if (!skipRight && bdr <= FT_TH_HIGH && !(blr == bl2r && (float)bdr > __fmul_rn(nnRatio, (float)bd2r))) {
+                const int m = Q.r2l[bir];
+                if (m != -1) sideR = m;
+                primR = bir + F.Nleft;
+            }
+        }
+    }
+    const int r4[4] = {primL, sideL, primR, sideR};
+    claims_file_row_first(C, res, i, sub, r4);
+}
+
 // ---- later passes of a batch: the lean kernels --------------------------------------------------------------------------------
 // From the second pass on nearly every point finds its candidates in the cache the first pass filed, and its turn is a
 // handful of loads: the cached keys, the 32-byte writer records of their keypoints, a minimum.  The general kernels above
@@ -1149,12 +1429,6 @@ __global__ __launch_bounds__(64 * FT_SEARCH_WPB) __attribute__((amdgpu_waves_per
 // candidates not filed yet: the right block is reached for the first time; more candidates than the cache holds) is handed
 // to the general kernel through the frame's slow list (launched behind this one with slowList = 1).  Same reads of the
 // previous pass's records, same keys, same comparisons: the results are those of the general kernel.
-__device__ __forceinline__ void row_two_min(unsigned long long &k0, unsigned long long &k1) {
-    const unsigned long long m0 = row_min_u64(k0);
-    const unsigned long long cand = (k0 == m0) ? k1 : k0;
-    k1 = row_min_u64(cand);
-    k0 = m0;
-}
 // claims_file for the point of a row: lane `sub` (0 .. 3) of the row files write kind sub
 __device__ __forceinline__ void claims_file_row(const FtClaims &C, int *res, int i, int sub, const int r4[4]) {
     if (sub < 4) {
@@ -1653,12 +1927,20 @@ __global__ __launch_bounds__(256) void k_cache_partition_batch(const FtBatchJob 
 
 // Result delivery of a batch: record r (blockIdx.y) = one block of dwords written into pinned host memory; src[parity] lets a
 // record follow the result buffer of the pass that ran last.
+// The copy is bound by PCIe (a few hundred workgroups' stores in flight saturate it), so a record gets few workgroups that move
+// 16 bytes per lane: the rest of the chip stays free for the kernels of the other batches in flight.
 __global__ __launch_bounds__(256) void k_deliver_batch(const FtDeliverRec *__restrict__ recs, int parity) {
     const FtDeliverRec &R = recs[blockIdx.y];
     unsigned *d = (unsigned *)R.dst;
     const unsigned *s = (const unsigned *)R.src[parity];
     const int t = blockIdx.x * 256 + threadIdx.x, T = gridDim.x * 256;
-    for (int i = t; i < R.words; i += T) d[i] = s[i];
+    int done = 0;
+    if ((((unsigned long long)(size_t)d | (unsigned long long)(size_t)s) & 15ull) == 0ull) {  // (uniform)
+        const int quads = R.words >> 2;
+        for (int i = t; i < quads; i += T) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+        done = quads << 2;
+    }
+    for (int i = done + t; i < R.words; i += T) d[i] = s[i];
 }
 
 }  // namespace
@@ -1764,6 +2046,21 @@ int ft_launch_frustum_batch(hipStream_t st, void *arena, const FtBatchJob *jobs,
     return FT_OK;
 }
 
+// the first pass with four points per wave (k_search_*_first): needs the candidate cache and the grid of every frame
+int ft_launch_search_last_first(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, float th) {
+    if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_last_project_batch, dim3((maxPoints + 255) / 256, nFrames), dim3(256), 0, st, jobs, rebase_of(arena));
+    hipLaunchKernelGGL(k_search_last_first, dim3((maxPoints + 15) / 16, nFrames), dim3(256), 0, st, jobs, rebase_of(arena), th);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+int ft_launch_search_local_first(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, float th, float nnRatio) {
+    if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_search_local_first, dim3((maxPoints + 15) / 16, nFrames), dim3(256), 0, st, jobs, rebase_of(arena), th, nnRatio);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
 int ft_launch_search_last_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur, int fPrev,
                                 int fReset, float th) {
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
@@ -1813,9 +2110,12 @@ int ft_launch_fill_claims_batch(hipStream_t st, void *arena, const FtBatchJob *j
     return FT_OK;
 }
 
+#ifndef FT_DELIVER_BLOCKS
+#define FT_DELIVER_BLOCKS 2  // workgroups per record
+#endif
 int ft_launch_deliver_batch(hipStream_t st, const FtDeliverRec *recs, int nRecs, int maxWords, int parity) {
     if (nRecs <= 0 || maxWords <= 0) return FT_OK;
-    hipLaunchKernelGGL(k_deliver_batch, dim3(std::max(1, std::min(16, (maxWords + 1023) / 1024)), nRecs), dim3(256), 0, st, recs, parity);
+    hipLaunchKernelGGL(k_deliver_batch, dim3(std::max(1, std::min(FT_DELIVER_BLOCKS, (maxWords + 1023) / 1024)), nRecs), dim3(256), 0, st, recs, parity);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

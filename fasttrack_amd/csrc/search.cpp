@@ -1230,6 +1230,10 @@ void batchClaims(const ft_tracked_batch *tb, int f, int nKp, int nPoints, FtBatc
 // results of that parity and all flag words into tb->h_out (flags at hostFlags[FT_BATCH_FLAGS f ...]).  A batch has 32 flag
 // positions per burst parity: bursts of up to 30 passes (the slowest of many frames needs more passes than one frame does).
 template <typename PassFn, typename DeliverFn>
+// first pass of a batched search by the four-points-per-wave kernels (k_search_*_first) where the cache and the grid exist
+#ifndef FT_ROW_FIRST
+#define FT_ROW_FIRST 1
+#endif
 int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJobs, int n, int maxPoints, int maxK, PassFn launchPass,
                     DeliverFn deliver, const int *hostFlags, int *parityFinal, int *passes, int *burstHint) {
     ft_context *ctx = tb->ctx;
@@ -1579,8 +1583,10 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         [&](int pass, int fCur, int fPrev, int fReset) {
             const bool lean = pass > 0 && tb->oCache;
             tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_last_batch(later pass)" : "kernel.search_last_batch(first pass)", st);
-            int r = lean ? ft_launch_search_last_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th)
-                         : ft_launch_search_last_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
+            const bool rows = FT_ROW_FIRST && pass == 0 && tb->oCache && ctx->tuning.search_grid;  // (fCur 0, fPrev -1, fReset = half: the kernel's own)
+            int r = rows   ? ft_launch_search_last_first(st, tb->d_arena, dJobs, n, maxPoints, th)
+                    : lean ? ft_launch_search_last_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th)
+                           : ft_launch_search_last_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
             tb->evt.end(ctx->kernelTiming, st);
             if (r == FT_OK && pass == 0 && tb->oCache) {
                 tb->evt.begin(ctx->kernelTiming, "kernel.cache_partition_batch", st);
@@ -1758,8 +1764,10 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
             }
             const bool lean = pass > 0 && tb->oCache;
             tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_local_batch(later pass)" : "kernel.search_local_batch(first pass)", st);
-            int r = lean ? ft_launch_search_local_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio)
-                         : ft_launch_search_local_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
+            const bool rows = FT_ROW_FIRST && pass == 0 && tb->oCache && ctx->tuning.search_grid;
+            int r = rows   ? ft_launch_search_local_first(st, tb->d_arena, dJobs, n, maxPoints, th, nn_ratio)
+                    : lean ? ft_launch_search_local_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio)
+                           : ft_launch_search_local_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
             tb->evt.end(ctx->kernelTiming, st);
             if (r == FT_OK && pass == 0 && tb->oCache) {
                 tb->evt.begin(ctx->kernelTiming, "kernel.cache_partition_batch", st);
