@@ -187,6 +187,9 @@ int ft_launch_search_local_batch(hipStream_t st, void *arena, const FtBatchJob *
 // fills the lists, results and writer table exactly as pass 0 of ft_launch_search_*_batch does
 int ft_launch_search_last_first(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, float th);
 int ft_launch_search_local_first(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, float th, float nnRatio);
+// everything behind that first pass in one launch: a workgroup per frame walks the frame's points in index order (k_resolve_batch);
+// a frame it resolves has all its flag words at -1 and its results in both result buffers, a frame it gives up on is untouched
+int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, float nnRatio);
 // a pass behind the first one: lean kernel (four points per wave from the candidate cache) + the general kernel on its slow list
 int ft_launch_search_last_batch_lean(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur,
                                      int fPrev, int fReset, float th);

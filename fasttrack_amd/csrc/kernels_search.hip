@@ -1631,6 +1631,324 @@ __global__ __launch_bounds__(256) void k_search_last_lean(const FtBatchJob *__re
     claims_file_row(C, res, i, sub, r4);
 }
 
+// ---- a batch's claims resolved in ONE launch: the points of a frame in index order, a chunk at a time --------------------------
+// The passes above are a Jacobi iteration over ALL points of a frame: a point's locks depend on the writes of the points in
+// front of it, a dependency chain of length c takes c passes, and every pass re-evaluates every point (13 - 20 passes of a batch
+// at configs[3]).  But the dependency is triangular, and a batch has parallelism to spare ACROSS its frames.  So: one workgroup
+// per frame walks the frame's points in index order, FT_RS_ROWS at a time (a point = a row of 16 lanes, as in the lean kernels).
+// When a chunk is evaluated every point in front of it is FINAL: of their writes a keypoint needs to remember only the last
+// (lastW[kp], an atomicMax of the writer-table entry: the largest (4 point + kind) - what locked_by picks from a record), and
+// only the writes of the chunk's own points are still in motion - they are iterated inside the workgroup, on a hash table in
+// LDS (keypoint -> bit mask of the chunk's rows that write it), until an iteration changes nothing.  An iteration after the
+// first touches LDS only (keys and lastW values stay in registers).  A point is evaluated 2 - 3 times instead of 13 - 20, and
+// a search is the first pass (window scans, k_search_*_first), the partition of the lists and this.
+// It reads the candidate lists the first pass filed; a point whose list is not usable (more candidates than the cache holds)
+// makes the workgroup give up on its frame: the frame's flag words stay as the first pass left them, the host sees it and
+// continues with the passes above for such frames (resolved frames are inert there: all their flag words read "converged").
+#define FT_RS_ROWS 64    // points per chunk: a workgroup of 1024 lanes
+#define FT_RS_SLOTS 512  // hash slots (<= 256 writes per chunk)
+#define FT_RS_REG 3      // keys of a list's head a lane keeps in registers (x 16 lanes = FT_CACHE_HEAD_MAX)
+struct RsShared {
+    int kp[FT_RS_SLOTS];
+    unsigned lo[FT_RS_SLOTS], hi[FT_RS_SLOTS];  // rows of the chunk that write the slot's keypoint (their results of the previous iteration)
+    unsigned char obs[FT_RS_ROWS];               // Observations() > 0 of the chunk's points
+    int vote[2];                                 // "an iteration changed a result", by iteration parity
+};
+__device__ __forceinline__ unsigned rs_hash(int kp) { return ((unsigned)kp * 2654435761u) >> 23; }
+__device__ __forceinline__ void rs_clear(RsShared &S) {
+    for (int t = threadIdx.x; t < FT_RS_SLOTS; t += FT_RS_ROWS * 16) {
+        S.kp[t] = -1;
+        S.lo[t] = 0u;
+        S.hi[t] = 0u;
+    }
+}
+// a barrier for what the workgroup exchanges through LDS: outstanding loads from memory (the next chunk's prefetch) stay outstanding
+__device__ __forceinline__ void rs_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ void rs_insert(RsShared &S, int kp, int row) {
+    unsigned h = rs_hash(kp);
+    for (;;) {
+        const int old = atomicCAS(&S.kp[h], -1, kp);
+        if (old == -1 || old == kp) break;
+        h = (h + 1) & (FT_RS_SLOTS - 1);
+    }
+    if (row < 32) atomicOr(&S.lo[h], 1u << row);
+    else atomicOr(&S.hi[h], 1u << (row - 32));
+}
+// F.mvpMapPoints[kp] && ->Observations() > 0 as the point of row `row` sees it: the last writer in front of it - of this chunk
+// (hash; useHash = 0: the chunk's first iteration, no writes of the chunk yet) or, if none, of the chunks before (lw = lastW[kp]) -
+// decides, else the pre-call holder
+__device__ __forceinline__ bool rs_locked(const RsShared &S, bool useHash, int kp, int lw, bool held, int row) {
+    if (useHash) {
+        unsigned h = rs_hash(kp);
+        for (;;) {
+            const int k = S.kp[h];
+            if (k == -1) break;
+            if (k == kp) {
+                const unsigned long long m = ((unsigned long long)S.lo[h] | ((unsigned long long)S.hi[h] << 32)) & ((1ull << row) - 1ull);
+                if (m) return S.obs[63 - __clzll((long long)m)] != 0;
+                break;
+            }
+            h = (h + 1) & (FT_RS_SLOTS - 1);
+        }
+    }
+    return lw >= 0 ? (lw & 1) != 0 : held;
+}
+__device__ __forceinline__ int rs_last_writer(const int *lastW, int kp) { return __hip_atomic_load(lastW + kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// results of a converged chunk: both result buffers (the host reads the one of the parity it is told), lastW for the chunks behind
+__device__ __forceinline__ void rs_publish(int *res0, int *res1, int *lastW, int i, int sub, bool obsI, const int r4[4]) {
+    if (sub < 4) {
+        const int kp = sub == 0 ? r4[0] : sub == 1 ? r4[1] : sub == 2 ? r4[2] : r4[3];
+        const int s = 4 * i + sub;
+        res0[s] = kp;
+        res1[s] = kp;
+        if (kp >= 0) atomicMax(lastW + kp, (s << 1) | (obsI ? 1 : 0));
+    }
+}
+// what a point's turn needs that no other point's result changes - requested a chunk ahead
+struct RsStatic {
+    unsigned long long metaL, metaR, kL[FT_RS_REG], kR[FT_RS_REG];
+    int obs;
+    unsigned char f0, f1, f2;  // local map: skip, inView, inViewR; last frame: valid
+    int levelR;
+};
+template <bool LOCAL>
+__device__ __forceinline__ RsStatic rs_fetch(const FtBatchJob &J, const Rebase &rb, const unsigned long long *cache, const int *obsP, bool twoCam,
+                                             int i, int sub) {
+    RsStatic T;
+    const unsigned long long *slotL = cache + (size_t)i * FT_CACHE_WORDS, *slotR = slotL + (FT_CACHE_CAP + 1);
+    T.metaL = slotL[0];
+    T.metaR = twoCam ? slotR[0] : KEY_NONE;
+#pragma unroll
+    for (int j = 0; j < FT_RS_REG; j++) {  // (whatever the lists' lengths: a key beyond a head is dropped when the meta word is there)
+        T.kL[j] = slotL[1 + sub + 16 * j];
+        T.kR[j] = twoCam ? slotR[1 + sub + 16 * j] : KEY_NONE;
+    }
+    T.obs = obsP[i];
+    T.levelR = -1;
+    if constexpr (LOCAL) {
+        T.f0 = rb(J.P.skip)[i];
+        T.f1 = rb(J.P.inView)[i];
+        T.f2 = twoCam ? rb(J.P.inViewR)[i] : (unsigned char)0;
+        if (twoCam) T.levelR = rb(J.P.levelR)[i];
+    } else {
+        T.f0 = rb(J.L.valid)[i];
+        T.f1 = T.f2 = 0;
+    }
+    return T;
+}
+
+template <bool LOCAL>
+__global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, float nnRatio) {
+    const FtBatchJob &J = jobs[blockIdx.x];
+    if (J.nPoints <= 0) return;
+    __shared__ RsShared S;
+    const FtDevFrame &F = J.F;
+    const bool twoCam = F.Nleft != -1;
+    const int M = LOCAL ? J.P.M : J.L.N;
+    const int row = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    int *res0 = rb(J.res), *res1 = res0 + 4 * (size_t)J.nPoints;
+    int *lastW = rb(J.head);  // (buffer 0 of the list heads: all -1 after k_fill_claims_batch, not written by a first pass)
+    const int *obsP = rb(J.obs);
+    const unsigned long long *cache = rb(J.cache);
+    const int *l2r = rb(F.l2r), *r2l = rb(F.r2l);
+    if (threadIdx.x < 2) S.vote[threadIdx.x] = 0;
+    RsStatic T = rs_fetch<LOCAL>(J, rb, cache, obsP, twoCam, min(row, M - 1), sub);
+    for (int base = 0; base < M; base += FT_RS_ROWS) {  // (uniform)
+        const int i = base + row;
+        const bool act = i < M;
+        const int ii = act ? i : M - 1;
+        const unsigned long long *slotL = cache + (size_t)ii * FT_CACHE_WORDS, *slotR = slotL + (FT_CACHE_CAP + 1);
+        bool wantL, wantR;
+        if constexpr (LOCAL) {
+            wantL = act && !T.f0 && T.f1;
+            wantR = act && !T.f0 && twoCam && T.f2 && T.levelR != -1;
+        } else {
+            wantL = act && T.f0;
+            wantR = wantL && twoCam;
+        }
+        const bool obsI = T.obs > 0;
+        int nL = 0, nR = 0;
+        bool anyBoxL = false, anyBoxR = false;
+        const int stL = cache_state_of(T.metaL, nL, anyBoxL), stR = cache_state_of(T.metaR, nR, anyBoxR);
+        if constexpr (!LOCAL) wantR = wantR && stL == 1 && anyBoxL;  // (`if(vIndices2.empty()) continue;` skips the right-camera block)
+        const bool unusable = (wantL && stL != 1) || (wantR && stR != 1);
+        if (__syncthreads_or(unusable ? 1 : 0)) return;  // (the frame's flag words untouched: the host goes on with the passes)
+        const int headL = wantL ? cache_head(T.metaL) : 0, headR = wantR ? cache_head(T.metaR) : 0;
+        if (!wantL) nL = 0;
+        if (!wantR) nR = 0;
+        unsigned long long kL[FT_RS_REG], kR[FT_RS_REG];
+        int wL[FT_RS_REG], wR[FT_RS_REG], mL[FT_RS_REG], mR[FT_RS_REG];  // last writers; the keypoints' entries of the match tables
+#pragma unroll
+        for (int j = 0; j < FT_RS_REG; j++) {
+            kL[j] = (sub + 16 * j < headL) ? T.kL[j] : KEY_NONE;
+            kR[j] = (sub + 16 * j < headR) ? T.kR[j] : KEY_NONE;
+        }
+#pragma unroll
+        for (int j = 0; j < FT_RS_REG; j++) {
+            wL[j] = kL[j] != KEY_NONE ? rs_last_writer(lastW, key_idx(kL[j])) : -1;
+            wR[j] = kR[j] != KEY_NONE ? rs_last_writer(lastW, key_idx(kR[j]) + F.Nleft) : -1;
+            mL[j] = mR[j] = -1;
+            if constexpr (LOCAL) {
+                if (twoCam) {
+                    if (kL[j] != KEY_NONE) mL[j] = l2r[key_idx(kL[j])];
+                    if (kR[j] != KEY_NONE) mR[j] = r2l[key_idx(kR[j])];
+                }
+            }
+        }
+        if (base + FT_RS_ROWS < M) T = rs_fetch<LOCAL>(J, rb, cache, obsP, twoCam, min(i + FT_RS_ROWS, M - 1), sub);  // the next chunk's
+        rs_clear(S);
+        if (sub == 0) S.obs[row] = obsI ? 1 : 0;
+        int r4[4] = {-1, -1, -1, -1};
+        for (int it = 0;; it++) {  // (uniform)
+            const bool useHash = it > 0;
+            if (it > 0) {  // the hash of the previous iteration's writes
+                if (it > 1) {
+                    rs_barrier();  // (every row has read the hash of the iteration before)
+                    rs_clear(S);
+                }
+                rs_barrier();
+                if (act && sub < 4) {
+                    const int kp = sub == 0 ? r4[0] : sub == 1 ? r4[1] : sub == 2 ? r4[2] : r4[3];
+                    if (kp >= 0) rs_insert(S, kp, row);
+                }
+                if (threadIdx.x == 0) S.vote[(it + 1) & 1] = 0;
+                rs_barrier();
+            }
+            int primL = -1, sideL = -1, primR = -1, sideR = -1;
+            if constexpr (LOCAL) {
+                bool skipRight = false;
+                if (wantL) {
+                    unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
+#pragma unroll
+                    for (int j = 0; j < FT_RS_REG; j++)
+                        if (kL[j] != KEY_NONE && !rs_locked(S, useHash, key_idx(kL[j]), wL[j], key_held(kL[j]), row)) two_min_insert(k0, k1, kL[j]);
+                    auto scan = [&](int from, int to) {
+                        for (int t = from + sub; t < to; t += 16) {
+                            const unsigned long long key = slotL[1 + t];
+                            const int kp = key_idx(key);
+                            if (rs_locked(S, useHash, kp, rs_last_writer(lastW, kp), key_held(key), row)) continue;
+                            two_min_insert(k0, k1, key);
+                        }
+                    };
+                    if (headL > 16 * FT_RS_REG) scan(16 * FT_RS_REG, headL);
+                    row_two_min(k0, k1);
+                    if (k1 == KEY_NONE && headL < nL) {  // fewer than two unlocked keys in the head: the rest of the list decides
+                        scan(headL, nL);
+                        row_two_min(k0, k1);
+                    }
+                    int bd = 256, bd2 = 256, bl = -1, bl2 = -1, bi = -1;
+                    if (k0 != KEY_NONE) { bd = key_dist(k0); bi = key_idx(k0); bl = key_octave(k0); }
+                    if (k1 != KEY_NONE) { bd2 = key_dist(k1); bl2 = key_octave(k1); }
+                    if (bd <= FT_TH_HIGH) {
+                        if (bl == bl2 && (float)bd > __fmul_rn(nnRatio, (float)bd2)) skipRight = true;
+                        else {
+                            primL = bi;
+                            if (twoCam) {  // l2r[bi]: with the winner's lane, or (a key from beyond the registers) in memory
+                                int m = INT_MIN;
+#pragma unroll
+                                for (int j = 0; j < FT_RS_REG; j++) m = kL[j] == k0 ? mL[j] : m;
+                                m = row_max_i32(m);
+                                if (m == INT_MIN) m = l2r[bi];
+                                if (m != -1) sideL = m + F.Nleft;
+                            }
+                        }
+                    }
+                }
+                if (wantR && !skipRight) {
+                    unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
+                    // this point's own left-block side write precedes its right-block search
+                    auto lockedR = [&](int g, int lw, bool held) -> bool { return (g == sideL) ? obsI : rs_locked(S, useHash, g, lw, held, row); };
+#pragma unroll
+                    for (int j = 0; j < FT_RS_REG; j++)
+                        if (kR[j] != KEY_NONE && !lockedR(key_idx(kR[j]) + F.Nleft, wR[j], key_held(kR[j]))) two_min_insert(k0, k1, kR[j]);
+                    auto scan = [&](int from, int to) {
+                        for (int t = from + sub; t < to; t += 16) {
+                            const unsigned long long key = slotR[1 + t];
+                            const int g = key_idx(key) + F.Nleft;
+                            if (lockedR(g, rs_last_writer(lastW, g), key_held(key))) continue;
+                            two_min_insert(k0, k1, key);
+                        }
+                    };
+                    if (headR > 16 * FT_RS_REG) scan(16 * FT_RS_REG, headR);
+                    row_two_min(k0, k1);
+                    if (k1 == KEY_NONE && headR < nR) {
+                        scan(headR, nR);
+                        row_two_min(k0, k1);
+                    }
+                    int bdr = 256, bd2r = 256, blr = -1, bl2r = -1, bir = -1;
+                    if (k0 != KEY_NONE) { bdr = key_dist(k0); bir = key_idx(k0); blr = key_octave(k0); }
+                    if (k1 != KEY_NONE) { bd2r = key_dist(k1); bl2r = key_octave(k1); }
+                    if (bdr <= FT_TH_HIGH && !(blr == bl2r && (float)bdr > __fmul_rn(nnRatio, (float)bd2r))) {
+                        int m = INT_MIN;
+#pragma unroll
+                        for (int j = 0; j < FT_RS_REG; j++) m = kR[j] == k0 ? mR[j] : m;
+                        m = row_max_i32(m);
+                        if (m == INT_MIN) m = r2l[bir];
+                        if (m != -1) sideR = m;
+                        primR = bir + F.Nleft;
+                    }
+                }
+            } else {
+                auto listMin = [&](const unsigned long long *slot, const unsigned long long *kReg, const int *wReg, int head, int n, int off) {
+                    unsigned long long m = KEY_NONE;
+#pragma unroll
+                    for (int j = 0; j < FT_RS_REG; j++)
+                        if (kReg[j] != KEY_NONE && !rs_locked(S, useHash, key_idx(kReg[j]) + off, wReg[j], key_held(kReg[j]), row))
+                            m = kReg[j] < m ? kReg[j] : m;
+                    auto scan = [&](int from, int to) {
+                        for (int t = from + sub; t < to; t += 16) {
+                            const unsigned long long key = slot[1 + t];
+                            const int g = key_idx(key) + off;
+                            if (rs_locked(S, useHash, g, rs_last_writer(lastW, g), key_held(key), row)) continue;
+                            m = key < m ? key : m;
+                        }
+                    };
+                    if (head > 16 * FT_RS_REG) scan(16 * FT_RS_REG, head);
+                    m = row_min_u64(m);
+                    // the head of the list first (cache_partition): an unlocked key there is smaller than every key behind it
+                    if (m == KEY_NONE && head < n) {
+                        scan(head, n);
+                        m = row_min_u64(m);
+                    }
+                    return m;
+                };
+                if (wantL && anyBoxL) {
+                    const unsigned long long k0 = listMin(slotL, kL, wL, headL, nL, 0);
+                    if (k0 != KEY_NONE && key_dist(k0) <= FT_TH_HIGH) primL = key_idx(k0);
+                    if (wantR) {
+                        const unsigned long long kr = listMin(slotR, kR, wR, headR, nR, F.Nleft);
+                        if (kr != KEY_NONE && key_dist(kr) <= FT_TH_HIGH) primR = key_idx(kr) + F.Nleft;
+                    }
+                }
+            }
+            const bool changed = act && (primL != r4[0] || sideL != r4[1] || primR != r4[2] || sideR != r4[3]);
+            r4[0] = primL; r4[1] = sideL; r4[2] = primR; r4[3] = sideR;
+            if (it == 0) continue;  // (the first iteration's results are what the second one starts from, changed or not)
+            if (changed && sub == 0) S.vote[it & 1] = 1;
+            rs_barrier();
+            if (!S.vote[it & 1]) break;
+#ifdef FT_RS_MAXIT
+            if (it >= FT_RS_MAXIT) break;
+#endif
+        }
+#ifndef FT_RS_NOPUB
+        if (act) rs_publish(res0, res1, lastW, i, sub, obsI, r4);
+#endif
+        // the chunk's atomics have landed in L2 before the next chunk asks for lastW (loads that go to L2: rs_last_writer).  A
+        // workgroup-scope release is a wait for the outstanding memory operations - an agent-scope fence (__threadfence) writes the
+        // L2 back, 30 us a time
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+    }
+    // resolved: every flag word of the frame reads "converged"
+    int *flags = rb(J.flags);
+    if (threadIdx.x < FT_BATCH_FLAGS) flags[threadIdx.x] = -1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Frame::isInFrustum / isInFrustumChecks (src/Frame.cc:536-610, 1308-1382) with MapPoint::PredictScale
 // (src/MapPoint.cc:531-546): one thread per local map point.  Float expressions are evaluated in the
@@ -2046,6 +2364,14 @@ int ft_launch_frustum_batch(hipStream_t st, void *arena, const FtBatchJob *jobs,
     return FT_OK;
 }
 
+// everything behind the first pass of a batch in one launch (k_resolve_batch): a workgroup per frame
+int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, float nnRatio) {
+    if (nFrames <= 0) return FT_OK;
+    if (local) hipLaunchKernelGGL(k_resolve_batch<true>, dim3(nFrames), dim3(FT_RS_ROWS * 16), 0, st, jobs, rebase_of(arena), nnRatio);
+    else hipLaunchKernelGGL(k_resolve_batch<false>, dim3(nFrames), dim3(FT_RS_ROWS * 16), 0, st, jobs, rebase_of(arena), nnRatio);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
 // the first pass with four points per wave (k_search_*_first): needs the candidate cache and the grid of every frame
 int ft_launch_search_last_first(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, float th) {
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;

@@ -1225,17 +1225,22 @@ void batchClaims(const ft_tracked_batch *tb, int f, int nKp, int nPoints, FtBatc
     J.nPoints = nPoints;
 }
 
+// first pass of a batched search by the four-points-per-wave kernels (k_search_*_first) where the cache and the grid exist (and
+// under search_cache = 2 the rest of the search by k_resolve_batch)
+#ifndef FT_ROW_FIRST
+#define FT_ROW_FIRST 1
+#endif
 // The claim iteration of every frame of the batch (see fixedPoint): bursts of passes, one launch per pass for ALL frames, one
 // delivery + one synchronisation per burst.  launchPass(pass, fCur, fPrev, fReset); deliver(parity, burst) writes every frame's
 // results of that parity and all flag words into tb->h_out (flags at hostFlags[FT_BATCH_FLAGS f ...]).  A batch has 32 flag
 // positions per burst parity: bursts of up to 30 passes (the slowest of many frames needs more passes than one frame does).
+// resolve (may be empty): everything behind the first pass in ONE launch (k_resolve_batch: a workgroup per frame walks its points in
+// index order).  Launched behind pass 0; a frame it resolved has all its flag words at -1 and is inert in later passes, and only
+// if it gave up on a frame (a candidate list the cache could not hold) do the passes go on - for those frames.
 template <typename PassFn, typename DeliverFn>
-// first pass of a batched search by the four-points-per-wave kernels (k_search_*_first) where the cache and the grid exist
-#ifndef FT_ROW_FIRST
-#define FT_ROW_FIRST 1
-#endif
 int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJobs, int n, int maxPoints, int maxK, PassFn launchPass,
-                    DeliverFn deliver, const int *hostFlags, int *parityFinal, int *passes, int *burstHint) {
+                    DeliverFn deliver, const int *hostFlags, int *parityFinal, int *passes, int *burstHint,
+                    const std::function<int()> &resolve = nullptr) {
     ft_context *ctx = tb->ctx;
     const int half = FT_BATCH_FLAGS / 2, lenMax = half - 2;
     const int burstMax = std::min(passBurst(ctx) + 4, lenMax);
@@ -1259,6 +1264,20 @@ int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJob
             rc = launchPass(pass, base + b, fPrev, other + b);
             if (rc != FT_OK) return rc;
             parity = pass & 1;
+            if (pass == 0 && resolve) {
+                rc = resolve();
+                if (rc == FT_OK) rc = deliver(0, 0);
+                if (rc != FT_OK) return rc;
+                FT_HIP(hipStreamSynchronize(st));
+                bool all = true;
+                for (int f = 0; f < n && all; f++) all = hostFlags[FT_BATCH_FLAGS * (size_t)f] == -1;
+                if (all) {
+                    *parityFinal = 0;
+                    *passes = 2;
+                    return FT_OK;
+                }
+                ctx->addStat("tracked_batch.resolve_fallbacks", 1);
+            }
         }
         rc = deliver(parity, burst);
         if (rc != FT_OK) return rc;
@@ -1596,7 +1615,15 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
             return r;
         },
         [&](int par, int) { return ft_launch_deliver_batch(st, dRecs, n + 1, std::max(4 * maxPoints, FT_BATCH_FLAGS * n), par); },
-        (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLast);
+        (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLast,
+        (FT_ROW_FIRST && ctx->tuning.search_cache >= 2 && tb->oCache && ctx->tuning.search_grid)
+            ? std::function<int()>([&]() {
+                  tb->evt.begin(ctx->kernelTiming, "kernel.resolve_batch(last frame)", st);
+                  const int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 0, 0.f);
+                  tb->evt.end(ctx->kernelTiming, st);
+                  return r;
+              })
+            : std::function<int()>());
     if (rc != FT_OK) return rc;
     ctx->addStat("tracked_batch.search_last_frame.device", tDev.ms());
     tb->evt.resolve(ctx);
@@ -1786,7 +1813,15 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
             return ft_launch_deliver_batch(st, dRecs, burst == 0 ? 2 * n + 2 : n + 2,
                                            std::max(std::max(4 * maxPoints, burst == 0 ? maxFrWords : 0), FT_BATCH_FLAGS * n), par);
         },
-        (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLocal);
+        (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLocal,
+        (FT_ROW_FIRST && ctx->tuning.search_cache >= 2 && tb->oCache && ctx->tuning.search_grid)
+            ? std::function<int()>([&]() {
+                  tb->evt.begin(ctx->kernelTiming, "kernel.resolve_batch(local map)", st);
+                  const int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 1, nn_ratio);
+                  tb->evt.end(ctx->kernelTiming, st);
+                  return r;
+              })
+            : std::function<int()>());
     if (rc != FT_OK) return rc;
     ctx->addStat("tracked_batch.track_local_map.device", tDev.ms());
     tb->evt.resolve(ctx);

@@ -76,6 +76,15 @@ __device__ __forceinline__ unsigned long long row_min_u64(unsigned long long v) 
     return v;
 }
 
+// maximum over the row of 16 lanes, in every lane of it
+__device__ __forceinline__ int row_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    return v;
+}
+
 // Low 32 bits of the product of two operands that fit 24 bits, as ONE full-rate instruction.  (__mul24 is dissolved
 // into a plain multiply once the optimiser has proven the operand ranges, and instruction selection then falls back
 // to the quarter-rate 32-bit v_mul_lo_u32 whenever it cannot re-derive them.)

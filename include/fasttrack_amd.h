@@ -91,7 +91,8 @@ FT_API int ft_context_set_lane_map(ft_context *ctx, const int *map, int n);
  *   graph                1        0 .. 1   latency mode: batches of <= 8 frames are captured and replayed as HIP graphs
  *   paired               1        0 .. 1   latency-mode stereo front ends run both cameras through one set of launches
  *   pass_burst           12       2 .. 14  projection searches: claim passes enqueued per host round trip
- *   search_cache         1        0 .. 1   projection searches: later claim passes walk the cached candidate keys
+ *   search_cache         2        0 .. 2   projection searches: 1 = later claim passes walk the cached candidate keys; 2 = and a
+ *                                          batch resolves its claims in one launch behind the first pass (a workgroup per frame)
  *   search_grid          1        0 .. 1   projection searches: CSR grid of the frame built on the device
  *
  * A value outside an option's range is FT_ERR_INVALID (from ft_context_set_option, and from ft_context_create when it comes

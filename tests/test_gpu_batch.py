@@ -264,11 +264,13 @@ def test_tracked_batch_bound_to_extractors_equals_uploaded_batch(ctx, lap):
         o.close()
 
 
-@pytest.mark.parametrize("opts", [dict(search_cache=0), dict(search_grid=0), dict(pass_burst=2)])
+@pytest.mark.parametrize("opts", [dict(search_cache=0), dict(search_grid=0), dict(search_cache=1), dict(search_cache=1, pass_burst=2),
+                                  dict(search_cache=0, pass_burst=2)])
 def test_tracked_batch_without_cache_without_grid_with_short_bursts(ctx, opts):
     """the batch under the context's search options: no candidate cache (every pass is the general kernel), no CSR grid (every
-    keypoint's cell is computed), bursts of two passes (many host round trips: the flag rows of converged frames must stick) -
-    the same assignments as the oracle every time"""
+    keypoint's cell is computed), search_cache = 1 (the claim passes instead of the one-launch resolution: lean kernels + slow
+    lists), bursts of two passes (many host round trips: the flag rows of converged frames must stick) - the same assignments as
+    the oracle every time"""
     sf, _ = ob.scale_factors(1.2, 8)
     B = 6
     frames, lasts, Tcws, ptss, poses, oracle = [], [], [], [], [], []
@@ -287,6 +289,51 @@ def test_tracked_batch_without_cache_without_grid_with_short_bursts(ctx, opts):
         g2 = tb.track_local_map(poses, ptss, 0.5, LOG_SF, 15.0)
         for f in range(B):
             _check_frame(f"{opts} frame {f}", g1[f], g2[f], tb.holder_obs(f), *oracle[f])
+        tb.close()
+
+
+@pytest.mark.parametrize("burst", [12, 2])
+def test_tracked_batch_lists_beyond_the_cache_fall_back_to_the_passes(ctx, burst):
+    """windows so wide (th 400 / 120: most of the image) that a point's candidates outgrow its cache list (511 keys): k_resolve_batch
+    gives up on such a frame and the claim passes take over for it (slow lists: the general kernel scans the window again every
+    pass), while the small frames of the same batch - cut down to 300 keypoints per camera, every list fits - stay resolved.
+    Same assignments as the oracle on every frame."""
+    sf, _ = ob.scale_factors(1.2, 8)
+    B, th1, th = 6, 400.0, 120.0
+    frames, lasts, Tcws, ptss, poses, oracle = [], [], [], [], [], []
+    for f in range(B):
+        fr = _kb8_base(2000, 10 + f % 2)
+        oF, gF, kL, dL = _kb8_views(fr, sf, (300, 300) if f % 2 else None)
+        last, Tcw, pts, Rcw, tcw = _kb8_inputs(kL, dL, sf, 4000 + f, 150 + 60 * f)
+        for d in (last, ):  # a short last frame keeps the oracle's share of the test short
+            for k in d:
+                d[k] = d[k][:250]
+        o1 = ob.search_last_frame(oF, last, Tcw, th1, False, False, True)
+        ofr = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, TLR), pts, 0.5, LOG_SF)
+        o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, pts), th)
+        frames.append(gF); lasts.append(last); Tcws.append(Tcw); ptss.append(pts); poses.append(orb.make_pose(Rcw, tcw, TLR))
+        oracle.append((o1, ofr, o2, oF))
+    with ctx.options(pass_burst=burst):
+        ctx.reset_stats()
+        tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=frames[0].c.N + 8, max_points=2048)
+        tb.upload(frames)
+        g1 = tb.search_last_frame(lasts, Tcws, th1)
+        g2 = tb.track_local_map(poses, ptss, 0.5, LOG_SF, th)
+        assert ctx.get_stat("tracked_batch.resolve_fallbacks")[1] == 2   # both searches
+        for f in range(B):
+            _check_frame(f"burst {burst} frame {f}", g1[f], g2[f], tb.holder_obs(f), *oracle[f])
+        # the small frames alone: resolved, no fallback
+        ctx.reset_stats()
+        small = [f for f in range(B) if f % 2]
+        tb.upload([frames[f] for f in small])
+        h1 = tb.search_last_frame([lasts[f] for f in small], [Tcws[f] for f in small], th1)
+        h2 = tb.track_local_map([poses[f] for f in small], [ptss[f] for f in small], 0.5, LOG_SF, th)
+        try:
+            assert ctx.get_stat("tracked_batch.resolve_fallbacks")[1] == 0
+        except orb.FastTrackError:
+            pass  # (a series nobody added to since the reset)
+        for k, f in enumerate(small):
+            assert np.array_equal(h1[k]["assign"], g1[f]["assign"]) and np.array_equal(h2[k]["assign"], g2[f]["assign"])
         tb.close()
 
 

@@ -33,8 +33,8 @@ def test_options_round_trip_and_scope():
     # a second context has its own values
     ctx2 = orb.Context(0)
     ctx.set_option("search_cache", 0)
-    assert ctx2.get_option("search_cache") == 1
-    ctx.set_option("search_cache", 1)
+    assert ctx2.get_option("search_cache") == 2
+    ctx.set_option("search_cache", 2)
     ex_host.close()
     ex_dev.close()
     ctx2.close()
