@@ -403,7 +403,7 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
     return out
 
 
-def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.0), pipelined=True, in_flight=3):
+def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.0), pipelined=True, in_flight=4):
     """BASELINE.json configs[3] as a THROUGHPUT workload: B independent 512x512 KannalaBrandt8 stereo frames per step (the
     frames B camera streams deliver for one time step), every stage ONE launch over all of them (ft_tracked_batch_*):
       extraction of the B left and the B right images, frames resident in HBM, lapping areas [0, 511]      (ft_extract_batch x 2,
@@ -547,7 +547,8 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
     ctx.set_kernel_timing(False)
     kern = {}
     for nm_ in ("kernel.lap_gather+fisheye_2nn_batch", "kernel.build_grid_batch", "kernel.frustum_batch", "kernel.search_last_batch(first pass)",
-                "kernel.search_last_batch(later pass)", "kernel.search_local_batch(first pass)", "kernel.search_local_batch(later pass)"):
+                "kernel.search_last_batch(later pass)", "kernel.search_local_batch(first pass)", "kernel.search_local_batch(later pass)",
+                "kernel.cache_partition_batch", "kernel.resolve_batch(last frame)", "kernel.resolve_batch(local map)"):
         try:
             tot_, n_ = ctx.get_stat(nm_)
         except Exception:

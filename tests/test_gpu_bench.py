@@ -86,11 +86,12 @@ def test_bench_single_rank_line_has_the_contract_fields():
     thr = t["throughput"]
     assert thr["batch_frames"] == thr["distinct_frames"] == 24 and set(thr["by_th"]) == {"7", "15"}
     assert thr["value"] == thr["by_th"]["7"]["value"] > t["value"]          # one launch set for 24 frames beats a frame at a time
-    assert thr["launches_per_frame"] < 8
+    assert thr["launches_per_frame"] < 4
     ro = thr["roofline"]
     assert ro["bound"] == "valu" and "k_fisheye_2nn_batch" in ro["kernel"] and 0 < ro["frac"] < 1 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
     assert thr["hamming_compares_per_frame"]["fisheye_2nn"] > 1e6 and thr["hamming_compares_per_frame"]["searches(first passes)"] > 1e4
-    for kname in ("search_last_batch(first pass)", "search_local_batch(first pass)", "lap_gather+fisheye_2nn_batch"):
+    for kname in ("search_last_batch(first pass)", "search_local_batch(first pass)", "lap_gather+fisheye_2nn_batch", "cache_partition_batch",
+                  "resolve_batch(last frame)", "resolve_batch(local map)"):
         assert thr["kernels"][kname]["avg_launch_ms"] > 0, kname
     # the reference's real call shape: one stereo pair in, results out
     lat = r["latency"]
