@@ -951,7 +951,7 @@ def main():
             WB = args.workload_batch
             wl["stereo_752x480_nf1200"] = stereo_leg(orb, ctx, "stereo_752x480_nf1200", 752, 480, 1200, WB, 48, 5, cpu=cpu)
             wl["tracking_512x512_nf2000"] = tracking_leg(orb, ctx, frames=args.workload_frames, cpu=cpu)
-            thr = tracking_batch_leg(orb, ctx, B=args.tracking_batch, steps=6, warmup=2)
+            thr = tracking_batch_leg(orb, ctx, B=args.tracking_batch, steps=16, warmup=4)
             thr = {k_: v_ for k_, v_ in thr.items() if not k_.startswith("_")}
             if "cpu_baseline" in wl["tracking_512x512_nf2000"]:
                 thr["gpu_over_cpu"] = thr["value"] / wl["tracking_512x512_nf2000"]["cpu_baseline"]["value"]

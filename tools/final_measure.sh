@@ -29,7 +29,7 @@ bash tools/trace_tracking_batch.sh final/trk_batch 128 4 > /dev/null 2>&1
 cp $F/trk_batch/summary.txt $F/${R}_tracking_batch_rocprof_summary.txt
 head -150 $F/trk_batch/timeline.txt > $F/${R}_tracking_batch_timeline.txt
 grep -a '^{"metric"' $F/trk_batch/trace.log | tail -1 > $F/${R}_tracking_batch_under_profiler.json
-python3 tests/tools/bench_tracking_batch.py 128 12 3 2>/dev/null | tail -1 > $F/${R}_tracking_batch.json
+python3 tests/tools/bench_tracking_batch.py 128 12 4 2>/dev/null | tail -1 > $F/${R}_tracking_batch.json
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$F/trk_single/trace -o trace -- python3 $GRAFT_REPO_ROOT/tools/profile_tracking_leg.py 24 > $GRAFT_REPO_ROOT/$F/trk_single.log 2>&1 )
 { echo "# rocprofv3 --kernel-trace --stats -- python3 tools/profile_tracking_leg.py 24   (configs[3] one frame at a time: 512x512 KB8 two-camera frames,"
   echo "# nFeatures 2000, th 7 and th 15, 24 frames each + warm-up)"
