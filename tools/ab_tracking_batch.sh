@@ -4,6 +4,6 @@
 ROUNDS=${1:-3}; shift
 for r in $(seq 1 $ROUNDS); do for v in "$@"; do
   name=${v%%=*}; envs=${v#*=}
-  env $envs python3 tests/tools/bench_tracking_batch.py 128 12 3 2>/dev/null | tail -1 | python3 -c "
+  env $envs python3 tests/tools/bench_tracking_batch.py 128 12 4 2>/dev/null | tail -1 | python3 -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('$name', round(d['by_th']['7']['value']), round(d['by_th']['15']['value']))"
 done; done | sort
