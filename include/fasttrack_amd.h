@@ -470,8 +470,9 @@ FT_API int ft_tracked_frame_holder_obs(ft_tracked_frame *tf, int *holder_obs);
  * :3472-3555; one kernel launch per call: src/Kernels/SearchLocalPointsKernel.cu:351-435, PoseEstimationKernel.cu:350-371),
  * which leaves a 256-CU device idle by construction.  A batch holds n_frames INDEPENDENT frames - the camera streams of one
  * time step, or any frames whose inputs the caller holds - and runs every stage as ONE launch over all of them: the grid
- * build, isInFrustum, and each pass of the two searches' in-call claiming (one workgroup row per frame, per-frame
- * convergence; the batch runs as many passes as its slowest frame).  Per frame the results are those of the
+ * build, isInFrustum, the window scans of a search, and the in-call claiming of all frames (option search_cache = 2: one launch,
+ * a workgroup per frame walks the frame's points in index order; search_cache <= 1, or a frame with a window of more than 511
+ * candidates: claim passes, one launch per pass for all frames, per-frame convergence).  Per frame the results are those of the
  * ft_tracked_frame_* call on that frame, bit for bit; the holder_obs of every frame carries over from one search to the next.
  * Arrays indexed by frame: frames[], L[], Tcw (12 floats per frame), forward / backward (NULL = all 0), poses[], P[],
  * frustum[] (NULL = not wanted), n_to_match[], assign[] (assign[f] has frames[f].N entries), n_matches[].
