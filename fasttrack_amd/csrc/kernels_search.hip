@@ -291,8 +291,9 @@ __device__ __forceinline__ void cache_append(const CacheBuild &B, unsigned long 
 #ifndef FT_CACHE_HEAD_MAX
 #define FT_CACHE_HEAD_MAX 48
 #endif
+// (PER = keys per lane: 64 PER >= n)
+template <int PER>
 __device__ __forceinline__ int cache_partition(unsigned long long *slot, int n, int lane) {
-    constexpr int PER = (FT_CACHE_CAP + 63) / 64;
     unsigned long long k[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) k[j] = (lane + 64 * j < n) ? slot[1 + lane + 64 * j] : KEY_NONE;
@@ -2229,18 +2230,33 @@ __global__ __launch_bounds__(256) void k_fisheye_2nn_batch(const FtBatchJob *__r
     }
 }
 
-// the candidate lists the first pass of a batch filed: the best candidates to the front (cache_partition); one wave per list
+// the candidate lists the first pass of a batch filed: the best candidates to the front (cache_partition).  A wave takes
+// FT_PART_LISTS lists one after the other (their meta words requested together: most lists are short and need nothing - a wave
+// per list was bound by the rate waves can be launched at), with as many keys per lane as the list's length asks for
+#define FT_PART_LISTS 4
 __global__ __launch_bounds__(256) void k_cache_partition_batch(const FtBatchJob *__restrict__ jobs, Rebase rb) {
     const FtBatchJob &J = jobs[blockIdx.y];
-    const int lane = threadIdx.x & 63, li = blockIdx.x * 4 + wave_index();
-    if (li >= 2 * J.nPoints) return;
-    unsigned long long *slot = rb(J.cache) + (size_t)(li >> 1) * FT_CACHE_WORDS + (size_t)(li & 1) * (FT_CACHE_CAP + 1);
-    const unsigned long long meta = slot[0];
-    int n;
-    bool anyBox;
-    if (cache_state_of(meta, n, anyBox) != 1 || n <= FT_CACHE_HEAD_MAX || cache_head(meta) != n) return;
-    const int head = cache_partition(slot, n, lane);
-    if (lane == 0) slot[0] = (meta & ~(0x3ffull << 40)) | ((unsigned long long)(unsigned)head << 40);
+    const int lane = threadIdx.x & 63, li0 = (blockIdx.x * 4 + wave_index()) * FT_PART_LISTS;
+    const int nLists = 2 * J.nPoints;
+    if (li0 >= nLists) return;
+    unsigned long long *cache = rb(J.cache);
+    auto slot_of = [&](int li) { return cache + (size_t)(li >> 1) * FT_CACHE_WORDS + (size_t)(li & 1) * (FT_CACHE_CAP + 1); };
+    unsigned long long metas[FT_PART_LISTS];
+#pragma unroll
+    for (int k = 0; k < FT_PART_LISTS; k++) metas[k] = li0 + k < nLists ? slot_of(li0 + k)[0] : KEY_NONE;
+#pragma unroll
+    for (int k = 0; k < FT_PART_LISTS; k++) {
+        const unsigned long long meta = metas[k];
+        int n;
+        bool anyBox;
+        if (cache_state_of(meta, n, anyBox) != 1 || n <= FT_CACHE_HEAD_MAX || cache_head(meta) != n) continue;  // (wave-uniform)
+        unsigned long long *slot = slot_of(li0 + k);
+        int head;
+        if (n <= 128) head = cache_partition<2>(slot, n, lane);
+        else if (n <= 256) head = cache_partition<4>(slot, n, lane);
+        else head = cache_partition<(FT_CACHE_CAP + 63) / 64>(slot, n, lane);
+        if (lane == 0) slot[0] = (meta & ~(0x3ffull << 40)) | ((unsigned long long)(unsigned)head << 40);
+    }
 }
 
 // Result delivery of a batch: record r (blockIdx.y) = one block of dwords written into pinned host memory; src[parity] lets a
@@ -2457,7 +2473,8 @@ int ft_launch_bind_fisheye_batch(hipStream_t st, void *arena, const FtBatchJob *
 
 int ft_launch_cache_partition_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints) {
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
-    hipLaunchKernelGGL(k_cache_partition_batch, dim3((2 * maxPoints + 3) / 4, nFrames), dim3(256), 0, st, jobs, rebase_of(arena));
+    hipLaunchKernelGGL(k_cache_partition_batch, dim3((2 * maxPoints + 4 * FT_PART_LISTS - 1) / (4 * FT_PART_LISTS), nFrames), dim3(256), 0, st, jobs,
+                       rebase_of(arena));
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
