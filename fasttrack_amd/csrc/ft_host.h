@@ -50,7 +50,7 @@
     X(graph, "FT_GRAPH", 1, 0, 1, "latency mode: batches of <= 8 frames are captured and replayed as HIP graphs")            \
     X(paired, "FT_PAIRED", 1, 0, 1, "latency-mode stereo front ends run both cameras through one set of launches")           \
     X(pass_burst, "FT_PASS_BURST", 12, 2, 14, "projection searches: claim passes enqueued per host round trip")              \
-    X(search_cache, "FT_SEARCH_CACHE", 2, 0, 2, "projection searches: 1 = later claim passes walk the cached candidate keys, 2 = and a batch resolves its claims in one launch") \
+    X(search_cache, "FT_SEARCH_CACHE", 2, 0, 3, "projection searches: 1 = later claim passes walk the cached candidate keys, 2 = and a batch of 24+ frames resolves its claims in one launch, 3 = every batch does") \
     X(search_grid, "FT_SEARCH_GRID", 1, 0, 1, "projection searches: CSR grid of the frame built on the device")
 
 struct ft_tuning {

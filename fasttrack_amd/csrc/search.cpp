@@ -1230,6 +1230,18 @@ void batchClaims(const ft_tracked_batch *tb, int f, int nKp, int nPoints, FtBatc
 #ifndef FT_ROW_FIRST
 #define FT_ROW_FIRST 1
 #endif
+// search_cache 2: the one-launch resolution for batches of FT_RESOLVE_MIN_FRAMES frames and more.  Its chain is as long for one
+// frame as for 256 (a workgroup per frame: 0.26 / 0.5 ms per search at configs[3]) while a claim pass over few frames is a
+// 10-us launch: one batch alone is served sooner by the passes up to ~56 frames (1 frame 0.19 against 0.33 ms, 32 frames 0.57
+// against 0.65), several batches in flight more cheaply by the resolution from ~24 on (32 frames x 4 lanes: 22.4 k against
+// 17.4 k frames/s) - EXPERIMENTS 10.8.  search_cache 3: every batch.
+#ifndef FT_RESOLVE_MIN_FRAMES
+#define FT_RESOLVE_MIN_FRAMES 24
+#endif
+bool resolveWanted(const ft_context *ctx, int nFrames) {
+    const int sc = ctx->tuning.search_cache;
+    return sc >= 3 || (sc == 2 && nFrames >= FT_RESOLVE_MIN_FRAMES);
+}
 // The claim iteration of every frame of the batch (see fixedPoint): bursts of passes, one launch per pass for ALL frames, one
 // delivery + one synchronisation per burst.  launchPass(pass, fCur, fPrev, fReset); deliver(parity, burst) writes every frame's
 // results of that parity and all flag words into tb->h_out (flags at hostFlags[FT_BATCH_FLAGS f ...]).  A batch has 32 flag
@@ -1616,7 +1628,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         },
         [&](int par, int) { return ft_launch_deliver_batch(st, dRecs, n + 1, std::max(4 * maxPoints, FT_BATCH_FLAGS * n), par); },
         (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLast,
-        (FT_ROW_FIRST && ctx->tuning.search_cache >= 2 && tb->oCache && ctx->tuning.search_grid)
+        (FT_ROW_FIRST && resolveWanted(ctx, n) && tb->oCache && ctx->tuning.search_grid)
             ? std::function<int()>([&]() {
                   tb->evt.begin(ctx->kernelTiming, "kernel.resolve_batch(last frame)", st);
                   const int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 0, 0.f);
@@ -1814,7 +1826,7 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
                                            std::max(std::max(4 * maxPoints, burst == 0 ? maxFrWords : 0), FT_BATCH_FLAGS * n), par);
         },
         (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLocal,
-        (FT_ROW_FIRST && ctx->tuning.search_cache >= 2 && tb->oCache && ctx->tuning.search_grid)
+        (FT_ROW_FIRST && resolveWanted(ctx, n) && tb->oCache && ctx->tuning.search_grid)
             ? std::function<int()>([&]() {
                   tb->evt.begin(ctx->kernelTiming, "kernel.resolve_batch(local map)", st);
                   const int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 1, nn_ratio);

@@ -91,8 +91,9 @@ FT_API int ft_context_set_lane_map(ft_context *ctx, const int *map, int n);
  *   graph                1        0 .. 1   latency mode: batches of <= 8 frames are captured and replayed as HIP graphs
  *   paired               1        0 .. 1   latency-mode stereo front ends run both cameras through one set of launches
  *   pass_burst           12       2 .. 14  projection searches: claim passes enqueued per host round trip
- *   search_cache         2        0 .. 2   projection searches: 1 = later claim passes walk the cached candidate keys; 2 = and a
- *                                          batch resolves its claims in one launch behind the first pass (a workgroup per frame)
+ *   search_cache         2        0 .. 3   projection searches: 1 = later claim passes walk the cached candidate keys; 2 = and a
+ *                                          batch of 24 or more frames resolves its claims in one launch behind the first pass (a
+ *                                          workgroup per frame); 3 = every batch does
  *   search_grid          1        0 .. 1   projection searches: CSR grid of the frame built on the device
  *
  * A value outside an option's range is FT_ERR_INVALID (from ft_context_set_option, and from ft_context_create when it comes
@@ -470,9 +471,10 @@ FT_API int ft_tracked_frame_holder_obs(ft_tracked_frame *tf, int *holder_obs);
  * :3472-3555; one kernel launch per call: src/Kernels/SearchLocalPointsKernel.cu:351-435, PoseEstimationKernel.cu:350-371),
  * which leaves a 256-CU device idle by construction.  A batch holds n_frames INDEPENDENT frames - the camera streams of one
  * time step, or any frames whose inputs the caller holds - and runs every stage as ONE launch over all of them: the grid
- * build, isInFrustum, the window scans of a search, and the in-call claiming of all frames (option search_cache = 2: one launch,
- * a workgroup per frame walks the frame's points in index order; search_cache <= 1, or a frame with a window of more than 511
- * candidates: claim passes, one launch per pass for all frames, per-frame convergence).  Per frame the results are those of the
+ * build, isInFrustum, the window scans of a search, and the in-call claiming of all frames (option search_cache = 2, batches of
+ * 24 frames and more: one launch, a workgroup per frame walks the frame's points in index order; smaller batches, search_cache
+ * <= 1, or a frame with a window of more than 511 candidates: claim passes, one launch per pass for all frames, per-frame
+ * convergence).  Per frame the results are those of the
  * ft_tracked_frame_* call on that frame, bit for bit; the holder_obs of every frame carries over from one search to the next.
  * Arrays indexed by frame: frames[], L[], Tcw (12 floats per frame), forward / backward (NULL = all 0), poses[], P[],
  * frustum[] (NULL = not wanted), n_to_match[], assign[] (assign[f] has frames[f].N entries), n_matches[].

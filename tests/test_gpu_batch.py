@@ -265,12 +265,12 @@ def test_tracked_batch_bound_to_extractors_equals_uploaded_batch(ctx, lap):
 
 
 @pytest.mark.parametrize("opts", [dict(search_cache=0), dict(search_grid=0), dict(search_cache=1), dict(search_cache=1, pass_burst=2),
-                                  dict(search_cache=0, pass_burst=2)])
+                                  dict(search_cache=0, pass_burst=2), dict(search_cache=3), dict(search_cache=2, pass_burst=2)])
 def test_tracked_batch_without_cache_without_grid_with_short_bursts(ctx, opts):
     """the batch under the context's search options: no candidate cache (every pass is the general kernel), no CSR grid (every
     keypoint's cell is computed), search_cache = 1 (the claim passes instead of the one-launch resolution: lean kernels + slow
-    lists), bursts of two passes (many host round trips: the flag rows of converged frames must stick) - the same assignments as
-    the oracle every time"""
+    lists), 3 (the resolution for this batch of six frames too; 2 leaves it to batches of 24 and more), bursts of two passes
+    (many host round trips: the flag rows of converged frames must stick) - the same assignments as the oracle every time"""
     sf, _ = ob.scale_factors(1.2, 8)
     B = 6
     frames, lasts, Tcws, ptss, poses, oracle = [], [], [], [], [], []
@@ -313,7 +313,7 @@ def test_tracked_batch_lists_beyond_the_cache_fall_back_to_the_passes(ctx, burst
         o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, pts), th)
         frames.append(gF); lasts.append(last); Tcws.append(Tcw); ptss.append(pts); poses.append(orb.make_pose(Rcw, tcw, TLR))
         oracle.append((o1, ofr, o2, oF))
-    with ctx.options(pass_burst=burst):
+    with ctx.options(pass_burst=burst, search_cache=3):
         ctx.reset_stats()
         tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=frames[0].c.N + 8, max_points=2048)
         tb.upload(frames)

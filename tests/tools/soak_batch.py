@@ -4,7 +4,8 @@ random kinds - two-camera KannalaBrandt8 frames and rectified pinhole stereo fra
 down to random keypoint counts - with random last-frame points, local maps (0 .. 2000 points), poses, window factors and
 occupancies, runs the reference's sequence on all of them through ONE batch (search last frame -> isInFrustum -> local map) and
 compares every frame's assignments, frustum fields, nToMatch and final holder_obs with the oracle's sequence on that frame.
-A trial runs under search_cache 2 (one-launch resolution, k_resolve_batch) or 1 (claim passes) and a random burst length; 5 % of the
+A trial runs under search_cache 3 (one-launch resolution, k_resolve_batch), 2 (the same for 24 frames and more) or 1 (claim passes)
+and a random burst length; 5 % of the
 trials use windows so wide that candidate lists outgrow the cache (resolution falls back to the passes for those frames).
 usage: tests/tools/soak_batch.py [--trials N] [--seed S] [--frames B]      exit code 1 on any mismatch"""
 import argparse
@@ -38,7 +39,7 @@ def main(argv=None):
     B = args.frames
     tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=4400, max_points=2304)
     fails = frames_n = matches = 0
-    modes = {1: 0, 2: 0}
+    modes = {1: 0, 2: 0, 3: 0}
     t0 = time.time()
     bases = {}
 
@@ -54,7 +55,7 @@ def main(argv=None):
         return bases[key]
     for t in range(args.trials):
         th = float(rng.choice([1.0, 3.0, 7.0, 15.0, 30.0, 150.0], p=[0.19, 0.19, 0.19, 0.19, 0.19, 0.05]))  # (150: lists beyond the cache)
-        opts = dict(search_cache=int(rng.choice([2, 2, 2, 1])), pass_burst=int(rng.choice([12, 12, 5, 2])))
+        opts = dict(search_cache=int(rng.choice([3, 3, 2, 1])), pass_burst=int(rng.choice([12, 12, 5, 2])))
         far = bool(rng.random() < 0.3)
         th_far = float(rng.uniform(4, 12))
         nn = float(rng.choice([0.8, 0.6, 0.9]))
@@ -94,7 +95,7 @@ def main(argv=None):
             o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, pts, far, th_far), th, nn)
             views.append(gF); lasts.append(last); Tcws.append(Tcw); ptss.append(pts); poses.append(orb.make_pose(Rcw, tcw, tlr))
             orc.append((o1, ofr, o2, oF))
-        with ctx.options(**opts):  # one-launch resolution (2) or the claim passes (1), long and short bursts
+        with ctx.options(**opts):  # one-launch resolution (3; 2 from 24 frames on) or the claim passes (1), long and short bursts
             tb.upload(views)
             g1 = tb.search_last_frame(lasts, Tcws, th)
             g2 = tb.track_local_map(poses, ptss, 0.5, LOG_SF, th, nn_ratio=nn, far_points=far, th_far_points=th_far)
@@ -123,8 +124,9 @@ def main(argv=None):
         fallbacks = ctx.get_stat("tracked_batch.resolve_fallbacks")[1]
     except orb.FastTrackError:
         fallbacks = 0
-    print(f"{args.trials} batches of {B} frames ({modes[2]} resolved in one launch, {fallbacks} searches of those fell back to the passes; "
-          f"{modes[1]} by the passes): {frames_n} frames, {2 * frames_n} searches, {matches} matches, {fails} mismatches, {time.time() - t0:.0f} s")
+    one = modes[3] + (modes[2] if B >= 24 else 0)
+    print(f"{args.trials} batches of {B} frames ({one} resolved in one launch, {fallbacks} searches of those fell back to the passes; "
+          f"{args.trials - one} by the passes): {frames_n} frames, {2 * frames_n} searches, {matches} matches, {fails} mismatches, {time.time() - t0:.0f} s")
     return 1 if fails else 0
 
 
