@@ -3,6 +3,8 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <cerrno>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -146,7 +148,16 @@ bool ft_tuning_from_env(ft_tuning &t, std::string &err) {
     for (int i = 0; i < kTuningCount; i++) {
         const char *e = ft_read_env(kTuningTable[i].env);
         if (!e || !*e) continue;
-        const int v = atoi(e);
+        // the whole text must be a number: "abc" or "1x" is an error, not 0 or 1
+        char *end = nullptr;
+        errno = 0;
+        const long lv = strtol(e, &end, 10);
+        while (end && (*end == ' ' || *end == '\t')) end++;
+        if (end == e || (end && *end) || errno == ERANGE) {
+            err = std::string(kTuningTable[i].env) + "=" + e + " is not an integer";
+            return false;
+        }
+        const int v = lv < INT_MIN ? INT_MIN : lv > INT_MAX ? INT_MAX : (int)lv;
         if (v < kTuningTable[i].lo || v > kTuningTable[i].hi) {
             err = std::string(kTuningTable[i].env) + "=" + e + " is outside [" + std::to_string(kTuningTable[i].lo) + ", " +
                   std::to_string(kTuningTable[i].hi) + "]";
@@ -330,6 +341,7 @@ int ft_context_destroy(ft_context *ctx) {
     if (ctx->scratchDev) hipFree(ctx->scratchDev);
     if (ctx->scratchPin) hipHostFree(ctx->scratchPin);
     for (void *p : ctx->hostAllocs) hipHostFree(p);  // ft_host_malloc blocks the caller did not free: they go with the context
+    for (hipEvent_t e : ctx->retiredEvents) hipEventDestroy(e);
     delete ctx->pool;
     delete ctx;
     return FT_OK;

@@ -247,6 +247,16 @@ int ft_pipeline_depth(const ft_tuning &t, int batch, bool deviceOctree) {
     return std::max(1, std::min(FT_PIPE_MAX, batch / 16));
 }
 
+// The next batch overwrites the keypoint / descriptor slots: behind whoever still reads them.  The event belongs to the reader (a
+// tracked batch); it is waited for on the stage-A stream, which every other stream of the extractor follows through events.
+int ft_extract_foreign_wait(ft_extractor *ex) {
+    if (!ex->foreignReader) return FT_OK;
+    hipEvent_t ev = ex->foreignReader;
+    ex->foreignReader = nullptr;
+    FT_HIP(hipStreamWaitEvent(ex->stream, ev, 0));
+    return FT_OK;
+}
+
 int ft_extract_prepare(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
                        int height, int stride) {
     FT_REQUIRE(ex && images, "extract: null handle or image list");
@@ -1049,6 +1059,8 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
     }
     FtTimer tAll;
     int rc = ft_set_device(ex->ctx);
+    if (rc != FT_OK) return rc;
+    rc = ft_extract_foreign_wait(ex);  // (in front of any capture: the graph launch is enqueued behind it)
     if (rc != FT_OK) return rc;
     const int S = ft_pipeline_depth(ex->tune, batch, ex->deviceOctree);
     const int sb = (batch + S - 1) / S;

@@ -85,6 +85,8 @@ struct ft_context {
     void *scratchDev = nullptr, *scratchPin = nullptr;
     size_t scratchDevBytes = 0, scratchPinBytes = 0;
     std::mutex hostAllocMutex;
+    // events of destroyed tracked batches that an extractor may still hold as its foreignReader: destroyed with the context
+    std::vector<hipEvent_t> retiredEvents;
     std::vector<void *> hostAllocs;  // live ft_host_malloc blocks
     bool kernelTiming = false;  // ft_context_set_kernel_timing
     ft_tuning tuning;           // FT_TUNING_OPTIONS: read from the environment by ft_context_create, changed by ft_context_set_option
@@ -179,6 +181,9 @@ struct ft_extractor {
     bool graphDisabled = false;
     hipEvent_t evJoin = nullptr;
     hipEvent_t evUp = nullptr;  // the batch of host frames has arrived (recorded on the upload stream of the context)
+    // somebody else's kernel still reads this extractor's keypoint / descriptor slots (ft_tracked_batch_bind_fisheye's gather on the
+    // batch's stream): recorded there, waited for by the extractor's next batch before it overwrites them (ft_extract_foreign_wait)
+    hipEvent_t foreignReader = nullptr;
     // device buffers
     uint8_t *d_pyr = nullptr;
     FtTap *d_taps = nullptr;
@@ -291,6 +296,7 @@ int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, int width, int heig
 int ft_context_upload_stream(ft_context *ctx, hipStream_t *out);  // the copy-only stream of the context (created on demand)
 bool ft_is_pinned_host(const void *p);  // null counts as pinned (nothing to copy)
 bool ft_is_pinned_host_range(const void *p, size_t bytes);  // [p, p + bytes) inside ONE pinned host allocation
+int ft_extract_foreign_wait(ft_extractor *ex);  // orders the extractor's next batch behind ex->foreignReader (never inside a stream capture)
 int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes);  // grow-only matcher scratch (hold matchMutex)
 int ft_usable_cpus();
 int ft_hw_queues_hint();

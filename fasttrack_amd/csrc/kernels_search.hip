@@ -1758,6 +1758,31 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
     const int *l2r = rb(F.l2r), *r2l = rb(F.r2l);
     if (threadIdx.x < 2) S.vote[threadIdx.x] = 0;
     RsStatic T = rs_fetch<LOCAL>(J, rb, cache, obsP, twoCam, min(row, M - 1), sub);
+    // Usable or not is decided for the WHOLE frame before the first chunk publishes anything (results, last writers): the meta
+    // words of every list the frame's points will want, a point per lane.  A frame the kernel gives up on is untouched - the
+    // claim passes that take over read the first pass's results and an all -1 last-writer buffer, as if this kernel had not run.
+    // (Round 5 tested chunk by chunk: a list beyond the cache in a later chunk left the earlier chunks published.)
+    {
+        bool unusable = false;
+        for (int p = threadIdx.x; p < M; p += FT_RS_ROWS * 16) {
+            const unsigned long long *slotL = cache + (size_t)p * FT_CACHE_WORDS;
+            const unsigned long long mL = slotL[0], mR = twoCam ? slotL[FT_CACHE_CAP + 1] : KEY_NONE;
+            int nL = 0, nR = 0;
+            bool boxL = false, boxR = false;
+            const int stL = cache_state_of(mL, nL, boxL), stR = cache_state_of(mR, nR, boxR);
+            bool wantL, wantR;
+            if constexpr (LOCAL) {
+                const bool skip = rb(J.P.skip)[p] != 0;
+                wantL = !skip && rb(J.P.inView)[p] != 0;
+                wantR = !skip && twoCam && rb(J.P.inViewR)[p] != 0 && rb(J.P.levelR)[p] != -1;
+            } else {
+                wantL = rb(J.L.valid)[p] != 0;
+                wantR = wantL && twoCam && stL == 1 && boxL;
+            }
+            unusable = unusable || (wantL && stL != 1) || (wantR && stR != 1);
+        }
+        if (__syncthreads_or(unusable ? 1 : 0)) return;  // (the frame's flag words untouched: the host goes on with the passes)
+    }
     for (int base = 0; base < M; base += FT_RS_ROWS) {  // (uniform)
         const int i = base + row;
         const bool act = i < M;
@@ -1775,9 +1800,8 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
         int nL = 0, nR = 0;
         bool anyBoxL = false, anyBoxR = false;
         const int stL = cache_state_of(T.metaL, nL, anyBoxL), stR = cache_state_of(T.metaR, nR, anyBoxR);
+        (void)stR;
         if constexpr (!LOCAL) wantR = wantR && stL == 1 && anyBoxL;  // (`if(vIndices2.empty()) continue;` skips the right-camera block)
-        const bool unusable = (wantL && stL != 1) || (wantR && stR != 1);
-        if (__syncthreads_or(unusable ? 1 : 0)) return;  // (the frame's flag words untouched: the host goes on with the passes)
         const int headL = wantL ? cache_head(T.metaL) : 0, headR = wantR ? cache_head(T.metaR) : 0;
         if (!wantL) nL = 0;
         if (!wantR) nR = 0;
@@ -1939,9 +1963,15 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
 #ifndef FT_RS_NOPUB
         if (act) rs_publish(res0, res1, lastW, i, sub, obsI, r4);
 #endif
-        // the chunk's atomics have landed in L2 before the next chunk asks for lastW (loads that go to L2: rs_last_writer).  A
-        // workgroup-scope release is a wait for the outstanding memory operations - an agent-scope fence (__threadfence) writes the
-        // L2 back, 30 us a time
+        // The next chunk's rs_last_writer loads must see this chunk's atomicMax.  Both are device-scope operations that execute in
+        // L2 (the atomic there, the sc1 load from there), issued by waves of ONE workgroup = one CU, and what orders them is the
+        // CU's in-order vector-memory path: the ISA of the fence + barrier below is `s_waitcnt lgkmcnt(0) ; s_barrier` - NO
+        // `vmcnt(0)`, the workgroup-scope release waits for nothing of the atomics - so a load issued behind the barrier is behind
+        // every atomic issued in front of it in the same CU's queue to the same L2 channel (the same address).  LLVM's AMDGPU
+        // memory model guarantees that order only in non-threadgroup-split mode (tgsplit: the waves of a workgroup may sit on
+        // different CUs and a workgroup-scope release becomes a real wait); the build refuses tgsplit (csrc/Makefile: check-tgsplit,
+        // tests/test_build_flags.py - the compiler defines no macro a static_assert could test).  An
+        // agent-scope fence (__threadfence) would be safe everywhere and writes the L2 back, 30 us a time (EXPERIMENTS 10.7).
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
     }

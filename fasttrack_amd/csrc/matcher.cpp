@@ -478,6 +478,9 @@ int ft_stereo_frontend_submit(ft_stereo_frontend *fe, const uint8_t *const *imag
     int rc = ft_set_device(fe->ctx);
     if (rc != FT_OK) return rc;
     FT_REQUIRE(batch >= 1 && batch <= fe->maxBatch, "stereo front end: batch outside [1, max_batch]");
+    rc = ft_extract_foreign_wait(L);  // (a tracked batch bound to these extractors may still read their slots; never inside a capture)
+    if (rc == FT_OK) rc = ft_extract_foreign_wait(R);
+    if (rc != FT_OK) return rc;
     const bool dev = L->deviceOctree && R->deviceOctree;
     const bool paired = fe->pairedCapable && dev && batch <= FT_GRAPH_MAX_BATCH && 2 * batch <= L->maxBatch;
     const bool direct = isPinnedHost(keysL) && isPinnedHost(descL) && isPinnedHost(keysR) && isPinnedHost(descR) &&

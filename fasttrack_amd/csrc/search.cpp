@@ -1187,11 +1187,16 @@ struct ft_tracked_batch {
     std::vector<std::vector<float>> angles;
     std::vector<std::vector<int>> holder;
     int passesLast = 0, passesLocal = 0;
+    bool hasGrid = false;  // the frames' CSR grids were laid out and built at upload / bind time (search_grid as it was THEN)
+    // the context's search options as the current call saw them (snapshotTuning, under ctx->matchMutex): the option may be set
+    // from another thread while a call runs, and a call must not see two values of it
+    int optSearchCache = 0, optPassBurst = 0;
     // a stream and a lock of the batch's own: two batches of one context used from two host threads are two batches in flight -
     // the passes of one run beside the host side (staging, replay) of the other
     hipStream_t stream = nullptr;
     std::mutex mu;
     FtEventTimer evt;  // ft_context_set_kernel_timing: HIP events around the batch's launches on the context's stream
+    hipEvent_t evGather = nullptr;  // bind_fisheye: the gather from the extractors' slots has run (the extractors' next batch waits for it)
 };
 
 namespace {
@@ -1238,10 +1243,19 @@ void batchClaims(const ft_tracked_batch *tb, int f, int nKp, int nPoints, FtBatc
 #ifndef FT_RESOLVE_MIN_FRAMES
 #define FT_RESOLVE_MIN_FRAMES 24
 #endif
-bool resolveWanted(const ft_context *ctx, int nFrames) {
-    const int sc = ctx->tuning.search_cache;
+// (callers hold tb->mu) the options a batch call works with: read once per call under the mutex ft_context_set_option writes under
+void snapshotTuning(ft_tracked_batch *tb) {
+    std::lock_guard<std::mutex> lk(tb->ctx->matchMutex);
+    tb->optSearchCache = tb->ctx->tuning.search_cache;
+    tb->optPassBurst = std::min(std::max(tb->ctx->tuning.pass_burst, 2), FT_PASS_BURST_MAX);
+}
+bool resolveWanted(const ft_tracked_batch *tb, int nFrames) {
+    const int sc = tb->optSearchCache;
     return sc >= 3 || (sc == 2 && nFrames >= FT_RESOLVE_MIN_FRAMES);
 }
+// the row-first kernels and the one-launch resolution read the candidate cache AND the frames' grids: both must have been laid out
+// when the batch was created / the frames were uploaded - the options' CURRENT values say nothing about that
+bool rowsUsable(const ft_tracked_batch *tb) { return FT_ROW_FIRST && tb->oCache && tb->hasGrid; }
 // The claim iteration of every frame of the batch (see fixedPoint): bursts of passes, one launch per pass for ALL frames, one
 // delivery + one synchronisation per burst.  launchPass(pass, fCur, fPrev, fReset); deliver(parity, burst) writes every frame's
 // results of that parity and all flag words into tb->h_out (flags at hostFlags[FT_BATCH_FLAGS f ...]).  A batch has 32 flag
@@ -1255,7 +1269,7 @@ int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJob
                     const std::function<int()> &resolve = nullptr) {
     ft_context *ctx = tb->ctx;
     const int half = FT_BATCH_FLAGS / 2, lenMax = half - 2;
-    const int burstMax = std::min(passBurst(ctx) + 4, lenMax);
+    const int burstMax = std::min(tb->optPassBurst + 4, lenMax);
     int len = burstHint && *burstHint > 0 ? std::min(std::max(*burstHint + 1, 4), lenMax) : burstMax;
     *parityFinal = 0;
     *passes = 0;
@@ -1380,6 +1394,7 @@ int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, 
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_in, tb->workBytes + tb->framesBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_out, tb->outBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&tb->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&tb->evGather, hipEventDisableTiming);
     if (e != hipSuccess) {
         ft_tracked_batch_destroy(tb);
         return ft_hip_fail(e, "ft_tracked_batch_create", __FILE__, __LINE__);
@@ -1396,6 +1411,10 @@ int ft_tracked_batch_destroy(ft_tracked_batch *tb) {
     if (tb->stream) {
         hipStreamSynchronize(tb->stream);
         hipStreamDestroy(tb->stream);
+    }
+    if (tb->evGather) {  // an extractor bound to this batch may still hold the event for its next batch: it goes with the context
+        std::lock_guard<std::mutex> lk(tb->ctx->hostAllocMutex);
+        tb->ctx->retiredEvents.push_back(tb->evGather);
     }
     if (tb->d_arena) hipFree(tb->d_arena);
     if (tb->h_in) hipHostFree(tb->h_in);
@@ -1423,6 +1442,12 @@ int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_frame_v
     std::lock_guard<std::mutex> lk(tb->mu);
     FtTimer tAll;
     hipStream_t st = tb->stream;
+    bool wantGrid;
+    {
+        std::lock_guard<std::mutex> lo(ctx->matchMutex);
+        wantGrid = ctx->tuning.search_grid != 0;
+    }
+    tb->hasGrid = false;  // (until the launch that builds the grids of THESE frames is enqueued)
     FT_HIP(hipStreamSynchronize(st));  // the pinned mirror is repacked: nothing of an earlier call may still read it
     // layout of the frames region: the holder_obs arrays of all frames first (contiguous: refreshed after every search by one
     // copy), then every frame's arrays
@@ -1475,7 +1500,7 @@ int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_frame_v
         D.holderObs = (const int *)(devF + tb->holderOff[f]);
         D.l2r = F.Nleft != -1 ? (const int *)(devF + lay[f].l2r) : nullptr;
         D.r2l = F.Nleft != -1 ? (const int *)(devF + lay[f].r2l) : nullptr;
-        if (ctx->tuning.search_grid) {  // the arrays k_build_grid_batch fills (buildGrid's layout, per frame)
+        if (wantGrid) {  // the arrays k_build_grid_batch fills (buildGrid's layout, per frame)
             int *grid = (int *)(tb->d_arena + tb->oGrid + (size_t)f * tb->gridStride);
             const bool two = D.Nleft != -1;
             float4 *rec = (float4 *)((uint8_t *)grid + gridIntBytes(D.N));
@@ -1497,16 +1522,19 @@ int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_frame_v
     ctx->pool->parallel_for(n_frames, stage);
     FT_HIP(hipMemcpyAsync(tb->d_arena + tb->oWork, tb->h_in, (size_t)n_frames * sizeof(FtBatchJob), hipMemcpyHostToDevice, st));
     FT_HIP(hipMemcpyAsync(devF, pinF, a.off, hipMemcpyHostToDevice, st));
-    if (ctx->tuning.search_grid) {
+    if (wantGrid) {
         rc = ft_launch_build_grid_batch(st, tb->d_arena, (const FtBatchJob *)(tb->d_arena + tb->oWork), n_frames, nlevelsMax, twoCam);
         if (rc != FT_OK) return rc;
+        tb->hasGrid = true;
     }
     ctx->addStat("tracked_batch.upload.total", tAll.ms());
     return FT_OK;
 }
 
 int ft_tracked_batch_holder_obs(ft_tracked_batch *tb, int frame, int *holder_obs) {
-    FT_REQUIRE(tb && frame >= 0 && frame < tb->nFrames && holder_obs, "ft_tracked_batch_holder_obs: bad argument");
+    FT_REQUIRE(tb && holder_obs, "ft_tracked_batch_holder_obs: bad argument");
+    std::lock_guard<std::mutex> lk(tb->mu);  // (upload / bind_fisheye reassign the vectors)
+    FT_REQUIRE(frame >= 0 && frame < tb->nFrames, "ft_tracked_batch_holder_obs: bad argument");
     const std::vector<int> &h = tb->holder[frame];
     if (!h.empty()) memcpy(holder_obs, h.data(), sizeof(int) * h.size());
     return FT_OK;
@@ -1515,13 +1543,17 @@ int ft_tracked_batch_holder_obs(ft_tracked_batch *tb, int frame, int *holder_obs
 }  // extern "C"
 
 namespace {
-int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, const FtPose *poses, const FtPose *trls, float th,
+int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, const FtPose *poses, const FtPose *trls, bool needTrl, float th,
                          const int *forward, const int *backward, int check_orientation, int *const *assign, int *n_matches) {
+    FT_REQUIRE(tb, "ft_tracked_batch_search_last_frame: null batch");
+    std::lock_guard<std::mutex> lk(tb->mu);  // (before anything of the batch is read: upload / bind_fisheye reassign it)
     int rc = checkBatch(tb, n, "ft_tracked_batch_search_last_frame");
     if (rc != FT_OK) return rc;
     FT_REQUIRE(L && assign, "ft_tracked_batch_search_last_frame: null argument");
     ft_context *ctx = tb->ctx;
+    snapshotTuning(tb);
     for (int f = 0; f < n; f++) {
+        FT_REQUIRE(!needTrl || trls || tb->DF[f].Nleft == -1, "ft_tracked_batch_search_last_frame_se3: a two-camera frame needs Trl");
         const int M = L[f].N;
         FT_REQUIRE(assign[f], "ft_tracked_batch_search_last_frame: null assign array");
         FT_REQUIRE(M >= 0 && M <= tb->maxPts, "last-frame point count beyond the batch's capacity");
@@ -1532,7 +1564,6 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     }
     rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
-    std::lock_guard<std::mutex> lk(tb->mu);
     FtTimer tAll;
     hipStream_t st = tb->stream;
     // layout of the call: job records | delivery records | per frame the point arrays
@@ -1614,7 +1645,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         [&](int pass, int fCur, int fPrev, int fReset) {
             const bool lean = pass > 0 && tb->oCache;
             tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_last_batch(later pass)" : "kernel.search_last_batch(first pass)", st);
-            const bool rows = FT_ROW_FIRST && pass == 0 && tb->oCache && ctx->tuning.search_grid;  // (fCur 0, fPrev -1, fReset = half: the kernel's own)
+            const bool rows = pass == 0 && rowsUsable(tb);  // (fCur 0, fPrev -1, fReset = half: the kernel's own)
             int r = rows   ? ft_launch_search_last_first(st, tb->d_arena, dJobs, n, maxPoints, th)
                     : lean ? ft_launch_search_last_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th)
                            : ft_launch_search_last_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
@@ -1628,7 +1659,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         },
         [&](int par, int) { return ft_launch_deliver_batch(st, dRecs, n + 1, std::max(4 * maxPoints, FT_BATCH_FLAGS * n), par); },
         (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLast,
-        (FT_ROW_FIRST && resolveWanted(ctx, n) && tb->oCache && ctx->tuning.search_grid)
+        (rowsUsable(tb) && resolveWanted(tb, n))
             ? std::function<int()>([&]() {
                   tb->evt.begin(ctx->kernelTiming, "kernel.resolve_batch(last frame)", st);
                   const int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 0, 0.f);
@@ -1666,21 +1697,20 @@ int ft_tracked_batch_search_last_frame(ft_tracked_batch *tb, int n_frames, const
     FT_REQUIRE(Tcw && n_frames > 0, "ft_tracked_batch_search_last_frame: null pose");
     std::vector<FtPose> poses(n_frames);
     for (int f = 0; f < n_frames; f++) poses[f] = poseOfMatrix(Tcw + 12 * (size_t)f);
-    return batchSearchLastFrame(tb, n_frames, L, poses.data(), nullptr, th, forward, backward, check_orientation, assign, n_matches);
+    return batchSearchLastFrame(tb, n_frames, L, poses.data(), nullptr, false, th, forward, backward, check_orientation, assign, n_matches);
 }
 
 int ft_tracked_batch_search_last_frame_se3(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const ft_se3 *Tcw,
                                            const ft_se3 *Trl, float th, const int *forward, const int *backward,
                                            int check_orientation, int *const *assign, int *n_matches) {
-    FT_REQUIRE(tb && Tcw && n_frames > 0 && n_frames == tb->nFrames, "ft_tracked_batch_search_last_frame_se3: bad argument");
+    FT_REQUIRE(tb && Tcw && n_frames > 0, "ft_tracked_batch_search_last_frame_se3: bad argument");
     std::vector<FtPose> poses(n_frames), trls(n_frames);
-    for (int f = 0; f < n_frames; f++) {
-        FT_REQUIRE(Trl || tb->DF[f].Nleft == -1, "ft_tracked_batch_search_last_frame_se3: a two-camera frame needs Trl");
+    for (int f = 0; f < n_frames; f++) {  // (the batch's own state - frame count, camera counts - is checked under its lock)
         int rc = poseOfSe3(&Tcw[f], poses[f]);
         if (rc == FT_OK && Trl) rc = poseOfSe3(&Trl[f], trls[f]);
         if (rc != FT_OK) return rc;
     }
-    return batchSearchLastFrame(tb, n_frames, L, poses.data(), Trl ? trls.data() : nullptr, th, forward, backward, check_orientation,
+    return batchSearchLastFrame(tb, n_frames, L, poses.data(), Trl ? trls.data() : nullptr, true, th, forward, backward, check_orientation,
                                 assign, n_matches);
 }
 
@@ -1688,8 +1718,11 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
                                      float viewing_cos_limit, float log_scale_factor, float th, float nn_ratio, int far_points,
                                      float th_far_points, const ft_frustum_result *frustum, int *n_to_match, int *const *assign,
                                      int *n_matches) {
+    FT_REQUIRE(tb, "ft_tracked_batch_track_local_map: null batch");
+    std::lock_guard<std::mutex> lk(tb->mu);
     int rc = checkBatch(tb, n_frames, "ft_tracked_batch_track_local_map");
     if (rc != FT_OK) return rc;
+    snapshotTuning(tb);
     FT_REQUIRE(poses && P && assign, "ft_tracked_batch_track_local_map: null argument");
     const int n = n_frames;
     for (int f = 0; f < n; f++) {
@@ -1701,7 +1734,6 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
     ft_context *ctx = tb->ctx;
     rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
-    std::lock_guard<std::mutex> lk(tb->mu);
     FtTimer tAll;
     hipStream_t st = tb->stream;
     Arena a;
@@ -1803,7 +1835,7 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
             }
             const bool lean = pass > 0 && tb->oCache;
             tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_local_batch(later pass)" : "kernel.search_local_batch(first pass)", st);
-            const bool rows = FT_ROW_FIRST && pass == 0 && tb->oCache && ctx->tuning.search_grid;
+            const bool rows = pass == 0 && rowsUsable(tb);
             int r = rows   ? ft_launch_search_local_first(st, tb->d_arena, dJobs, n, maxPoints, th, nn_ratio)
                     : lean ? ft_launch_search_local_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio)
                            : ft_launch_search_local_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
@@ -1826,7 +1858,7 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
                                            std::max(std::max(4 * maxPoints, burst == 0 ? maxFrWords : 0), FT_BATCH_FLAGS * n), par);
         },
         (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLocal,
-        (FT_ROW_FIRST && resolveWanted(ctx, n) && tb->oCache && ctx->tuning.search_grid)
+        (rowsUsable(tb) && resolveWanted(tb, n))
             ? std::function<int()>([&]() {
                   tb->evt.begin(ctx->kernelTiming, "kernel.resolve_batch(local map)", st);
                   const int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 1, nn_ratio);
@@ -1897,6 +1929,12 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     std::lock_guard<std::mutex> lk(tb->mu);
     FtTimer tAll;
     hipStream_t st = tb->stream;
+    bool wantGrid;
+    {
+        std::lock_guard<std::mutex> lo(ctx->matchMutex);
+        wantGrid = ctx->tuning.search_grid != 0;
+    }
+    tb->hasGrid = false;
     FT_HIP(hipStreamSynchronize(st));
     // frames region: holder_obs of all frames, the (monoLeft, monoRight) counts, then every frame's arrays (as ft_tracked_batch_upload)
     Arena a;
@@ -1964,7 +2002,7 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
         D.holderObs = (const int *)(devF + tb->holderOff[f]);
         D.l2r = (const int *)(devF + lay[f].l2r);
         D.r2l = (const int *)(devF + lay[f].r2l);
-        if (ctx->tuning.search_grid) {
+        if (wantGrid) {
             int *grid = (int *)(tb->d_arena + tb->oGrid + (size_t)f * tb->gridStride);
             float4 *rec = (float4 *)((uint8_t *)grid + gridIntBytes(D.N));
             uint8_t *gdesc = (uint8_t *)(rec + std::max(D.N, 1));
@@ -2041,8 +2079,16 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
         tb->evt.end(ctx->kernelTiming, st);
     }
     if (rc != FT_OK) return rc;
+    // the extractors' slots have been read: their next batch (which overwrites them) is ordered behind this point - the call may
+    // return before the gather has run (no outputs asked for), and nothing else ties the extractors' streams to this one
+    FT_HIP(hipEventRecord(tb->evGather, st));
+    exL->foreignReader = tb->evGather;
+    exR->foreignReader = tb->evGather;
     tb->evt.begin(ctx->kernelTiming, "kernel.build_grid_batch", st);
-    if (rc == FT_OK && ctx->tuning.search_grid) rc = ft_launch_build_grid_batch(st, tb->d_arena, dJobs, n_frames, nlevelsMax, true);
+    if (rc == FT_OK && wantGrid) {
+        rc = ft_launch_build_grid_batch(st, tb->d_arena, dJobs, n_frames, nlevelsMax, true);
+        if (rc == FT_OK) tb->hasGrid = true;
+    }
     tb->evt.end(ctx->kernelTiming, st);
     if (rc != FT_OK) return rc;
     if (wantOut) {

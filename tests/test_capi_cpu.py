@@ -203,6 +203,33 @@ def test_option_out_of_range_in_the_environment_is_an_error():
     assert f"rc {_capi_const('FT_ERR_INVALID')}" in out.stdout and "FT_PASS_BURST=99 is outside [2, 14]" in out.stdout, out.stdout + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("bad", ["abc", "1x", "", " 7 7"])
+def test_option_text_in_the_environment_must_be_an_integer(bad):
+    """FT_GRAPH=abc / =1x: FT_ERR_INVALID, not atoi's 0 or 1; an empty value is "unset" """
+    code = ("from fasttrack_amd import _capi; import ctypes as C\n"
+            "h = C.c_void_p(); rc = _capi.lib().ft_context_create(0, 1, C.byref(h))\n"
+            "print('rc', rc, _capi.lib().ft_last_error().decode())")
+    env = dict(os.environ, FT_GRAPH=bad)
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if bad == "":
+        assert "is not an integer" not in out.stdout
+    else:
+        assert f"rc {_capi_const('FT_ERR_INVALID')}" in out.stdout and "is not an integer" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+def test_library_is_not_built_with_threadgroup_split():
+    """k_resolve_batch orders a chunk's atomics before the next chunk's loads through ONE CU's in-order vector-memory path
+    (kernels_search.hip): the kernel descriptors the Makefile's flags produce must say tg_split 0, and the Makefile refuses
+    -mtgsplit"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "fasttrack_amd", "csrc")
+    out = subprocess.run(["make", "-C", csrc, "check-tgsplit"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "tg_split 0" in out.stdout, out.stdout + out.stderr[-2000:]
+    bad = subprocess.run(["make", "-C", csrc, "-n", "CXXFLAGS=-O3 -mtgsplit"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "tgsplit" in bad.stderr
+
+
 def _capi_const(name):
     from fasttrack_amd import _capi
     return getattr(_capi, name)

@@ -337,6 +337,63 @@ def test_tracked_batch_lists_beyond_the_cache_fall_back_to_the_passes(ctx, burst
         tb.close()
 
 
+def test_resolution_gives_up_on_a_frame_before_it_publishes_anything(ctx):
+    """ONE candidate list beyond the cache in a LATE chunk of k_resolve_batch's walk: every last-frame point sits at
+    octave 7 (level band 6 .. 7: at most ~270 candidates even when the window is the whole image - usable lists) except point
+    200 (chunk 3 of 64-point chunks), which sits at octave 1 (band 0 .. 2, ~1 100 keypoints at th 400: beyond the 511 keys of a
+    list).  Round 5 tested usability chunk by chunk and had published chunks 0 - 2 (results of both parities, last writers) when
+    it gave up; the claim passes that take over then compared against final values.  Now the whole frame is tested first: the
+    frame falls back untouched, and the assignments equal the oracle's.  A second frame of the same batch (every point at octave
+    7) stays resolved."""
+    sf, _ = ob.scale_factors(1.2, 8)
+    th1 = 400.0
+    for burst in (12, 2):
+        frames, lasts, Tcws, oracle = [], [], [], []
+        for f in range(2):
+            oF, gF, kL, dL = _kb8_views(_kb8_base(2000, 10 + f), sf)
+            last, Tcw, _, _, _ = _kb8_inputs(kL, dL, sf, 5000 + f, 10)
+            last = {k: v[:256].copy() for k, v in last.items()}
+            last["octave"][:] = 7
+            last["valid"][:] = 1
+            if f == 0:
+                last["octave"][200] = 1
+            o1 = ob.search_last_frame(oF, last, Tcw, th1, False, False, True)
+            frames.append(gF); lasts.append(last); Tcws.append(Tcw); oracle.append((o1, oF))
+        with ctx.options(pass_burst=burst, search_cache=3):
+            ctx.reset_stats()
+            tb = orb.TrackedBatch(ctx, max_frames=2, max_keypoints=frames[0].c.N + 8, max_points=2048)
+            tb.upload(frames)
+            g1 = tb.search_last_frame(lasts, Tcws, th1)
+            assert ctx.get_stat("tracked_batch.resolve_fallbacks")[1] == 1
+            for f in range(2):
+                o1, oF = oracle[f]
+                assert g1[f]["n"] == o1["n"] and np.array_equal(g1[f]["assign"], o1["assign"]), f"burst {burst} frame {f}"
+                assert np.array_equal(tb.holder_obs(f), oF.holder_obs), f"burst {burst} frame {f}: holder_obs"
+            assert oracle[0][0]["n"] > 20
+            tb.close()
+
+
+def test_search_grid_switched_between_upload_and_search(ctx):
+    """search_* options are read per call, but the grids exist only if search_grid was on when the frames went up (ADVICE r5:
+    the row-first kernels read the grid pointers without a null check).  Upload without grids, switch the option on, search:
+    the batch takes the kernels that need no grid, same assignments as the oracle - and the other way round."""
+    sf, _ = ob.scale_factors(1.2, 8)
+    for at_upload, at_search in ((0, 1), (1, 0)):
+        oF, gF, kL, dL = _kb8_views(_kb8_base(1500, 10), sf)
+        last, Tcw, pts, Rcw, tcw = _kb8_inputs(kL, dL, sf, 6000, 700)
+        o1 = ob.search_last_frame(oF, last, Tcw, 7.0, False, False, True)
+        ofr = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, TLR), pts, 0.5, LOG_SF)
+        o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, pts), 7.0)
+        with ctx.options(search_cache=3, search_grid=at_upload):
+            tb = orb.TrackedBatch(ctx, max_frames=1, max_keypoints=gF.c.N + 8, max_points=2048)
+            tb.upload([gF])
+            with ctx.options(search_grid=at_search):
+                g1 = tb.search_last_frame([last], [Tcw], 7.0)
+                g2 = tb.track_local_map([orb.make_pose(Rcw, tcw, TLR)], [pts], 0.5, LOG_SF, 7.0)
+            _check_frame(f"grid {at_upload} -> {at_search}", g1[0], g2[0], tb.holder_obs(0), o1, ofr, o2, oF)
+            tb.close()
+
+
 def test_tracked_batch_bind_with_triangulation_equals_oracle_fisheye_stereo(ctx):
     """bind_fisheye with a rig = the whole Frame::ComputeStereoFishEyeMatches per frame (src/Frame.cc:1231-1271): the ratio-test
     survivors go through KannalaBrandt8::TriangulateMatches; mvLeftToRightMatch / mvRightToLeftMatch / mvDepth / mvStereo3Dpoints /
