@@ -49,8 +49,29 @@ WORKLOADS = {
 }
 NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_JSON = "r05_traffic.json"
-MARGINAL_JSON = "r05_marginal_costs.json"
+TRAFFIC_JSON = "r06_traffic.json"
+MARGINAL_JSON = "r06_marginal_costs.json"
+VALU_MIX_JSON = "r06_valu_mix.json"   # tools/valu_mix.py: mean issue cycles per vector instruction of each kernel's stream
+VALU_DEAR_CYCLES = 4.33               # profiles/r06_valu_rates.txt: the dear class (v_sad, v_pk_*, v_perm, v_dot*, v_cmp, ...) at 2.4 GHz
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+_valu_mix = None
+
+
+def valu_cycles(kernel):
+    """mean cycles (at the nominal 2.4 GHz) a SIMD spends issuing one vector instruction of `kernel`: the opcode-weighted cost of its
+    instruction stream by the issue-cost table measured on this chip (profiles/r06_valu_rates.txt -> tools/valu_mix.py).  Rounds 1 - 5
+    priced every instruction at 4 cycles; the table has a ~2.3 - 3.2-cycle class (v_mov, 32-bit add / logic, f32) beside the ~4.3-cycle
+    one the hot loops are built from.  A kernel the file does not hold is priced at the dear class."""
+    global _valu_mix
+    if _valu_mix is None:
+        try:
+            _valu_mix = json.load(open(os.path.join(ROOT, "profiles", VALU_MIX_JSON)))["kernels"]
+        except Exception:
+            _valu_mix = {}
+    for k, v in _valu_mix.items():
+        if k == kernel or k.split("<")[0] == kernel:
+            return float(v["mean_cycles_per_valu"])
+    return VALU_DEAR_CYCLES
 
 
 def csrc_stamp(version: str) -> str:
@@ -562,9 +583,11 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
     cmp_search = float(np.mean([count_compares(orb, ctx, views0[f], sf, scen[f], fr[f], th0, cam, Trl) for f in sample]))
     cmp_2nn = float(np.mean(nL.astype(np.float64) * nR.astype(np.float64)))   # lapping areas cover the images: every left x every right keypoint
     fps = out["value"]
-    # 256-bit Hamming distance = 8 v_xor_b32 + 8 v_bcnt_u32_b32 (accumulating) per lane; a wave instruction occupies a 16-lane SIMD
-    # for 4 cycles (profiles/r02_valu_rates.txt) -> 64 compares per 64 cycles and SIMD: 1 024 SIMDs x 2.4 GHz compares/s
-    VALU_COMPARES_PER_S = 1024 * 2.4e9
+    # 256-bit Hamming distance = 8 v_xor_b32 + 8 v_bcnt_u32_b32 (accumulating) per lane.  Measured as an alternating pair on this chip
+    # (profiles/r06_valu_rates.txt, "pair v_xor_b32 + v_bcnt_u32_b32"): 3.20 cycles at 2.4 GHz per instruction of the pair - the xor is
+    # of the cheap class, the popcount of the dear one - so a wave's 64 compares cost 16 x 3.20 = 51.2 cycles of its SIMD
+    XOR_BCNT_PAIR_CYCLES = 3.20
+    VALU_COMPARES_PER_S = SIMDS * CLOCK_HZ * 64 / (16 * XOR_BCNT_PAIR_CYCLES)
     k2 = kern.get("lap_gather+fisheye_2nn_batch")
     out["kernels"] = kern
     out["hamming_compares_per_frame"] = {"fisheye_2nn": cmp_2nn, "searches(first passes)": cmp_search}
@@ -574,8 +597,9 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
         out["roofline"] = {"bound": "valu", "kernel": "k_fisheye_2nn_batch (timed together with k_lap_gather_batch, ~10 % of the pair)",
                            "achieved": ach / 1e9, "peak": VALU_COMPARES_PER_S / 1e9, "unit": "G Hamming compares/s", "frac": ach / VALU_COMPARES_PER_S,
                            "traffic": None, "compares_per_launch": cmp_2nn * B, "avg_launch_ms": k2["avg_launch_ms"],
-                           "peak_source": "16 vector instructions (8 v_xor_b32 + 8 v_bcnt_u32_b32) per 256-bit compare and lane, 4 cycles per "
-                                          "wave instruction on a 16-lane SIMD (profiles/r02_valu_rates.txt), 1 024 SIMDs x 2.4 GHz"}
+                           "peak_source": "16 vector instructions (8 v_xor_b32 + 8 v_bcnt_u32_b32) per 256-bit compare and lane at the measured "
+                                          "3.20 cycles per instruction of the alternating pair (profiles/r06_valu_rates.txt), 1 024 SIMDs x 2.4 GHz "
+                                          "= 3.07 T compares/s (rounds 1 - 5 priced both opcodes at 4 cycles: 2.46 T)"}
     first = [kern.get("search_last_batch(first pass)"), kern.get("search_local_batch(first pass)")]
     if all(first):
         ms = first[0]["avg_launch_ms"] + first[1]["avg_launch_ms"]
@@ -880,16 +904,18 @@ def main():
             ach = roof["bytes_per_launch"] / (ms / 1e3) / 1e9
             roof["at_marginal_cost"] = {"ms_per_launch": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                                         "source": f"profiles/{MARGINAL_JSON} (tools/marginal_costs.py: FT_DEBUG_REPEAT=fast, same workload, same csrc)"}
-            # the same for the vector-issue bound: the launch's vector instructions (committed SQ pass) x 4 cycles on a
-            # 16-lane SIMD / (1 024 SIMDs x 2.4 GHz x the launch's cost inside the pipeline) - ~1.0 says the kernel is priced
-            # at its instruction stream, which is what "the chip is full" means for it
+            # the same for the vector-issue bound: the launch's vector instructions (committed SQ pass) x the opcode-weighted
+            # cycles of the kernel's stream (valu_cycles) / (1 024 SIMDs x 2.4 GHz x the launch's cost inside the pipeline) -
+            # ~1.0 says the kernel is priced at its instruction stream, which is what "the chip is full" means for it
             tkf = tk.get("k_fast_cells") or {}
             if same_inputs and tkf.get("valu_per_launch"):
-                roof["at_marginal_cost"]["valu_issue_frac"] = tkf["valu_per_launch"] * 4.0 / (1024 * 2.4e9 * ms / 1e3)
+                roof["at_marginal_cost"]["valu_issue_frac"] = tkf["valu_per_launch"] * valu_cycles("k_fast_cells") / (SIMDS * CLOCK_HZ * ms / 1e3)
+                roof["at_marginal_cost"]["valu_cycles_per_instruction"] = valu_cycles("k_fast_cells")
         also = sorted(legs[1:], key=lambda x: -x["total_ms"])
         # The ceiling this integer / bitwise path really works against: vector-instruction issue.  Wave-level vector
-        # instructions of the timed region (per-launch counts of the committed SQ pass x this run's launches) x 4 cycles each
-        # on a 16-lane SIMD / (1 024 SIMDs x 2.4 GHz x elapsed).  Reported when the run's inputs equal the profiled ones.
+        # instructions of the timed region (per-launch counts of the committed SQ pass x this run's launches) x the mean issue
+        # cycles of each kernel's opcode mix (valu_cycles: 3.9 - 4.3 for these kernels - they are built from the dear class)
+        # / (1 024 SIMDs x 2.4 GHz x elapsed).  Reported when the run's inputs equal the profiled ones.
         valu_frac = None
         if same_inputs:
             pairs_ = (("kernel.fast_cells", "k_fast_cells"), ("kernel.orient_desc", "k_orient_desc"), ("kernel.pyr_down(all levels)", "k_pyr_rows"),
@@ -901,9 +927,9 @@ def main():
                 if not t or not n or "valu_per_launch" not in t:
                     tot_valu = None
                     break
-                tot_valu += t["valu_per_launch"] * n * (7 if kname == "k_pyr_rows" else 1)  # the pyramid stat groups 7 launches
+                tot_valu += t["valu_per_launch"] * n * (7 if kname == "k_pyr_rows" else 1) * valu_cycles(kname)  # the pyramid stat groups 7 launches
             if tot_valu:
-                valu_frac = tot_valu * 4.0 / (1024 * 2.4e9 * elapsed_rank)
+                valu_frac = tot_valu / (SIMDS * CLOCK_HZ * elapsed_rank)
         R_pair = 2 * (3 * sumP - P[-1])  # read bytes per stereo pair, unfused accounting
         out = {
             "metric": "frames/sec extract+match", "value": fps, "unit": "frames/s", "n_gpus": world,
@@ -935,6 +961,8 @@ def main():
             "roofline_other_kernels": also,
             "library": orb.version(),
             "profiles": {TRAFFIC_JSON: tj_state, MARGINAL_JSON: mc_state},
+            "valu_issue_pricing": {"source": f"profiles/{VALU_MIX_JSON} (tools/valu_mix.py over profiles/r06_valu_rates.txt)",
+                                   "cycles_per_instruction": {k: valu_cycles(k) for k in ("k_fast_cells", "k_orient_desc", "k_pyr_rows", "k_octree", "k_stereo_match")}},
             "host_in": host_in,
         }
         # The other workloads north_star names (N = 1 only: they are this box's numbers, not part of the scaling curve).  The

@@ -361,16 +361,18 @@ def test_resolution_gives_up_on_a_frame_before_it_publishes_anything(ctx):
             frames.append(gF); lasts.append(last); Tcws.append(Tcw); oracle.append((o1, oF))
         with ctx.options(pass_burst=burst, search_cache=3):
             ctx.reset_stats()
-            tb = orb.TrackedBatch(ctx, max_frames=2, max_keypoints=frames[0].c.N + 8, max_points=2048)
-            tb.upload(frames)
-            g1 = tb.search_last_frame(lasts, Tcws, th1)
-            assert ctx.get_stat("tracked_batch.resolve_fallbacks")[1] == 1
-            for f in range(2):
-                o1, oF = oracle[f]
-                assert g1[f]["n"] == o1["n"] and np.array_equal(g1[f]["assign"], o1["assign"]), f"burst {burst} frame {f}"
-                assert np.array_equal(tb.holder_obs(f), oF.holder_obs), f"burst {burst} frame {f}: holder_obs"
-            assert oracle[0][0]["n"] > 20
-            tb.close()
+            tb = orb.TrackedBatch(ctx, max_frames=2, max_keypoints=max(F.c.N for F in frames) + 8, max_points=2048)
+            try:
+                tb.upload(frames)
+                g1 = tb.search_last_frame(lasts, Tcws, th1)
+                assert ctx.get_stat("tracked_batch.resolve_fallbacks")[1] == 1
+                for f in range(2):
+                    o1, oF = oracle[f]
+                    assert g1[f]["n"] == o1["n"] and np.array_equal(g1[f]["assign"], o1["assign"]), f"burst {burst} frame {f}"
+                    assert np.array_equal(tb.holder_obs(f), oF.holder_obs), f"burst {burst} frame {f}: holder_obs"
+                assert oracle[0][0]["n"] > 20
+            finally:
+                tb.close()
 
 
 def test_search_grid_switched_between_upload_and_search(ctx):

@@ -98,8 +98,8 @@ def test_bench_single_rank_line_has_the_contract_fields():
     for shape in ("752x480_nf1200", "1280x720_nf2000"):
         assert 0 < lat[shape]["pinned_frames_ms"] < 20 and 0 < lat[shape]["pageable_frames_ms"] < 20
     # the line names the library it ran and says whether the committed profile artefacts belong to it
-    assert "csrc:" in r["library"] and set(r["profiles"]) == {"r05_traffic.json", "r05_marginal_costs.json"}
+    assert "csrc:" in r["library"] and set(r["profiles"]) == {"r06_traffic.json", "r06_marginal_costs.json"}
     for state in r["profiles"].values():
         assert state == "current" or state == "missing" or state.startswith("stale")
     if not all(v == "current" for v in r["profiles"].values()):
-        assert roof["traffic"] is None or r["profiles"]["r05_traffic.json"] == "current"
+        assert roof["traffic"] is None or r["profiles"]["r06_traffic.json"] == "current"

@@ -2,9 +2,9 @@
 # The round's measurement set (runs on the GPU box): rocprofv3 profiles (kernel trace + FETCH / WRITE / SQ passes) of the default
 # bench, the dense and the planes scenes, with the per-launch traffic stamped with the library's csrc hash; marginal costs; the
 # driver's default line and a long run; the configs[3] legs (one frame at a time, and B frames per launch) as kernel traces; the
-# LDS / issue counters of the pipeline.  usage: bash tools/final_measure.sh [r05]     -> gpurun_out/final/
+# LDS / issue counters of the pipeline.  usage: bash tools/final_measure.sh [r06]     -> gpurun_out/final/
 set -u
-R=${1:-r05}
+R=${1:-r06}
 cd $GRAFT_REPO_ROOT
 F=gpurun_out/final
 mkdir -p $F

@@ -4,15 +4,30 @@ from the FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescr
 128-byte read requests at 64 bytes each, so it is DOUBLED for every kernel (tools/hbm_calib.sh confirms it for the
 access patterns of this repo: a coalesced dword / 16-byte stream and the 48-byte row segments of the tile loads both
 read back as half of the 128-byte requests they touch); WRITE_SIZE is exact.  Also records, per kernel, the average
-rocprofv3 duration and the VALU issue fraction = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x duration x 2.4 GHz).
+rocprofv3 duration and the VALU issue fraction = SQ_INSTS_VALU x the mean issue cycles of the kernel's opcode mix
+(profiles/r06_valu_mix.json: tools/valu_mix.py over the measured table profiles/r06_valu_rates.txt; 4.33 - the dear class - for a
+kernel the file does not hold; rounds 1 - 5 priced every instruction at 4) / (1024 SIMDs x duration x 2.4 GHz).
 
 usage: traffic_from_profile.py <summary.txt> <out.json> --workload W --batch B --distinct D --steps S"""
 import argparse
 import json
+import os
 import re
 
 FETCH_FACTOR = 2.0
 SIMDS, CLOCK_HZ = 1024, 2.4e9
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def valu_cycles(kernel):
+    try:
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r06_valu_mix.json")))["kernels"]
+    except Exception:
+        mix = {}
+    for k, v in mix.items():
+        if k == kernel or k.split("<")[0] == kernel:
+            return float(v["mean_cycles_per_valu"])
+    return 4.33
 
 
 def main():
@@ -51,7 +66,8 @@ def main():
             e["traffic_bytes_per_launch"] = (e.get("fetch_kb_raw", 0) * FETCH_FACTOR + e.get("write_kb", 0)) * 1024
             e["images_per_launch"] = images_per_step * a.steps / e["launches"] if e["launches"] else None
         if "valu_per_launch" in e and e.get("avg_us"):
-            e["valu_issue_frac"] = e["valu_per_launch"] * 4 / (SIMDS * e["avg_us"] * 1e-6 * CLOCK_HZ)
+            e["valu_cycles_per_instruction"] = valu_cycles(k)
+            e["valu_issue_frac"] = e["valu_per_launch"] * e["valu_cycles_per_instruction"] / (SIMDS * e["avg_us"] * 1e-6 * CLOCK_HZ)
     json.dump({"source": a.summary, "csrc": a.csrc, "workload": a.workload, "batch_pairs": a.batch, "distinct_pairs": a.distinct,
                "note": "per launch; bench of %d pairs per step, %d passes profiled; FETCH_SIZE doubled (128-B requests counted at 64 B)"
                        % (a.batch, a.steps), "kernels": d}, open(a.out, "w"), indent=1)
