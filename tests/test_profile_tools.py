@@ -17,13 +17,19 @@ def test_traffic_json_follows_from_the_rocprof_summary(tmp_path, tag):
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_from_profile.py"),
                     os.path.join(ROOT, "profiles", tag + "_rocprof_summary.txt"), str(out), "--steps", "7"], check=True, capture_output=True)
     new, old = json.load(open(out)), json.load(open(os.path.join(ROOT, "profiles", tag + "_traffic.json")))
-    assert new["kernels"] == old["kernels"] and new["batch_pairs"] == old["batch_pairs"] == 512 and old["distinct_pairs"] == 512
+    # (rounds 1 - 5 priced a vector instruction at 4 cycles; from round 6 on the tool prices it with the measured opcode mix:
+    # everything else of a regenerated file equals the committed one)
+    strip = lambda ks: {k: {f: v for f, v in e.items() if f not in ("valu_issue_frac", "valu_cycles_per_instruction")} for k, e in ks.items()}
+    assert strip(new["kernels"]) == strip(old["kernels"]) and new["batch_pairs"] == old["batch_pairs"] == 512 and old["distinct_pairs"] == 512
+    for k, e in new["kernels"].items():
+        if "valu_issue_frac" in e:
+            assert abs(e["valu_issue_frac"] / old["kernels"][k]["valu_issue_frac"] - e["valu_cycles_per_instruction"] / 4.0) < 1e-6
     f = new["kernels"]["k_fast_cells"]
     assert f["fetch_factor"] == 2.0 and f["images_per_launch"] == 256.0
     assert abs(f["traffic_bytes_per_launch"] - (2 * f["fetch_kb_raw"] + f["write_kb"]) * 1024) < 1
     # FAST + NMS reads every pyramid pixel once: 256 images x 2 853 088 px; the memory side sees about that, not a third of it
     assert 0.9 < f["traffic_bytes_per_launch"] / (256 * 2853088) < 1.15
-    assert 0.5 < f["valu_issue_frac"] < 1.0 and f["valu_per_wave"] > 500 and f["salu_per_wave"] > 100
+    assert 0.5 < f["valu_issue_frac"] < 1.05 and 4.0 < f["valu_cycles_per_instruction"] < 4.5 and f["valu_per_wave"] > 500 and f["salu_per_wave"] > 100
 
 
 @pytest.mark.parametrize("tag", ["r02", "r04"])
