@@ -45,6 +45,7 @@ struct FtDevLastPoints {
     const float *worldPos;
     const uint8_t *desc;
     const int *octave;
+    const float *angle;  // batch form only: the last-frame keypoints' angles (rotation histogram of k_replay_batch), may be null
 };
 
 // The claim iteration (Jacobi passes over the sequential claiming of SearchByProjection): a pass reads the writer lists
@@ -143,6 +144,10 @@ struct FtBatchJob {
     FtFrustumPose T;
     FtFrustumOut O;
     FtDevLocalPoints P;
+    // what the search leaves behind (k_replay_batch): assignOut [F.N] and nmOut [1] are PINNED HOST memory the kernel writes
+    // directly (not in the arena: never rebased), replayed [1] (arena) is the frame's "done" marker: -1 until the frame's writes
+    // have been replayed, then its match count
+    int *assignOut, *nmOut, *replayed;
 };
 
 // a block of dwords delivered into pinned host memory by k_deliver_batch; src[parity of the last pass]
@@ -190,6 +195,13 @@ int ft_launch_search_local_first(hipStream_t st, void *arena, const FtBatchJob *
 // everything behind that first pass in one launch: a workgroup per frame walks the frame's points in index order (k_resolve_batch);
 // a frame it resolves has all its flag words at -1 and its results in both result buffers, a frame it gives up on is untouched
 int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, float nnRatio);
+// The writes of a converged search replayed on the device, a workgroup per frame (k_replay_batch): assign[keypoint] = the last
+// point that wrote it, holder_obs updated in place in HBM, the match count; last frame: with the rotation histogram and
+// ComputeThreeMaxima when checkOrientation.  Only frames that have not been replayed yet and - resolvedOnly - whose flag word says
+// "resolved" (the launch right behind k_resolve_batch); parity = result buffer of the last pass (a resolved frame holds its results in both).  sharedInts = ints of LDS per workgroup
+// for the last-writer table (>= the largest F.N), 0 = frames too large for the LDS: the table lives in the frame's writer table
+int ft_launch_replay_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, int parity, int checkOrientation,
+                           int sharedInts, int resolvedOnly);
 // a pass behind the first one: lean kernel (four points per wave from the candidate cache) + the general kernel on its slow list
 int ft_launch_search_last_batch_lean(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur,
                                      int fPrev, int fReset, float th);

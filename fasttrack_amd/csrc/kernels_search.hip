@@ -1980,6 +1980,127 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
     if (threadIdx.x < FT_BATCH_FLAGS) flags[threadIdx.x] = -1;
 }
 
+// ---- the writes of a converged search, replayed where the results are ------------------------------------------------------------
+// What the host did with a search's results until round 5 (replayLocalWrites / replayLastFrameWrites, search.cpp) - and what
+// the reference does while it searches: CurrentFrame.mvpMapPoints[kp] = pMP in point order (src/ORBmatcher.cc:134-148, 203-214;
+// 1860-1879, 1934-1941), the rotation histogram (:1880-1896, 1942-1957), ComputeThreeMaxima (:2210-2251) and the removal of
+// the matches outside the three dominant bins (:1966-1987).  A workgroup per frame:
+//   assign[kp]  = the LAST point that wrote keypoint kp (atomicMax of the point index over all writes), -1 if none - or if ANY
+//                 write to kp fell into a removed histogram bin (the reference clears mvpMapPoints[kp] for every entry of such a bin,
+//                 whoever wrote the keypoint last);
+//   holder[kp]  = Observations() of that point, -1 where the histogram removed the keypoint, unchanged where nobody wrote;
+//   nm          = writes - writes in removed bins (nmatches++ per write, nmatches-- per removed entry).
+// The frame's holder_obs stays in HBM (the next search of the batch reads it there), assign and nm go straight into pinned host
+// memory.  The last-writer table lives in LDS (F.N ints) or, for frames beyond it, in the frame's writer table (dead by now).
+#define FT_REPLAY_REMOVED 0x40000000
+template <bool LOCAL, bool INLDS>
+__global__ __launch_bounds__(256) void k_replay_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int parity, int checkOrientation,
+                                                      int resolvedOnly) {
+    const FtBatchJob &J = jobs[blockIdx.x];
+    extern __shared__ int rp_last[];
+    __shared__ int rp_hist[FT_HISTO_LENGTH], rp_keep, rp_sum[4];
+    int *replayed = rb(J.replayed);
+    const int *flags = rb(J.flags);
+    const int N = J.F.N, M = J.nPoints;
+    // (uniform) a frame that has been replayed already; resolvedOnly (the launch right behind k_resolve_batch, before the host has
+    // seen the flags): a frame the resolution gave up on - its flag word is not -1 - waits for the claim passes
+    if (*replayed >= 0 || (resolvedOnly && M > 0 && flags[0] != -1)) return;
+    const int tid = threadIdx.x;
+    int *last = INLDS ? rp_last : rb(J.tab);
+    int *assign = J.assignOut;
+    int *holder = const_cast<int *>(rb(J.F.holderObs));
+    const int *res = rb(J.res) + (size_t)parity * 4 * (size_t)M;
+    const int *obs = rb(J.obs);
+    const bool hist = !LOCAL && checkOrientation != 0;
+    const int nLk = J.F.Nleft == -1 ? N : J.F.Nleft;
+    const ft_keypoint *keys = rb(J.F.keys), *keysR = rb(J.F.keysR);
+    const float *lastAngle = LOCAL ? nullptr : rb(J.L.angle);
+    for (int kp = tid; kp < N; kp += 256) last[kp] = -1;
+    if (tid < FT_HISTO_LENGTH) rp_hist[tid] = 0;
+    if (!INLDS) __threadfence();
+    __syncthreads();
+    // rotation bin of the write (point i -> keypoint kp): src/ORBmatcher.cc:1882-1890, the host replay's expression operation by operation
+    auto bin_of = [&](int i, int kp) -> int {
+        const float cur = kp < nLk ? keys[kp].angle : keysR[kp - nLk].angle;
+        float rot = __fsub_rn(lastAngle[i], cur);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        int bin = (int)roundf(__fmul_rn(rot, 1.0f / FT_HISTO_LENGTH));
+        if (bin == FT_HISTO_LENGTH) bin = 0;
+        return bin;
+    };
+    int nm = 0;
+    for (int s = tid; s < 4 * M; s += 256) {
+        if (!LOCAL && (s & 1)) continue;  // last frame: the primary writes of the two cameras (res[4 i], res[4 i + 2])
+        const int kp = res[s];
+        if (kp < 0) continue;
+        const int i = s >> 2;
+        nm++;
+        atomicMax(&last[kp], i);
+        if (hist) {
+            const int bin = bin_of(i, kp);
+            if (bin >= 0 && bin < FT_HISTO_LENGTH) atomicAdd(&rp_hist[bin], 1);
+        }
+    }
+    if (!INLDS) __threadfence();
+    __syncthreads();
+    if (hist) {
+        if (tid == 0) {  // ComputeThreeMaxima (src/ORBmatcher.cc:2210-2251)
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int b = 0; b < FT_HISTO_LENGTH; b++) {
+                const int sz = rp_hist[b];
+                if (sz > max1) {
+                    max3 = max2; max2 = max1; max1 = sz;
+                    ind3 = ind2; ind2 = ind1; ind1 = b;
+                } else if (sz > max2) {
+                    max3 = max2; max2 = sz;
+                    ind3 = ind2; ind2 = b;
+                } else if (sz > max3) {
+                    max3 = sz; ind3 = b;
+                }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+            int keep = 0;
+            if (ind1 >= 0) keep |= 1 << ind1;
+            if (ind2 >= 0) keep |= 1 << ind2;
+            if (ind3 >= 0) keep |= 1 << ind3;
+            rp_keep = keep;
+        }
+        __syncthreads();
+        const int keep = rp_keep;
+        for (int s = tid; s < 4 * M; s += 256) {
+            if (s & 1) continue;
+            const int kp = res[s];
+            if (kp < 0) continue;
+            const int bin = bin_of(s >> 2, kp);
+            if (bin >= 0 && bin < FT_HISTO_LENGTH && !((keep >> bin) & 1)) {
+                atomicMax(&last[kp], FT_REPLAY_REMOVED);
+                nm--;
+            }
+        }
+        if (!INLDS) __threadfence();
+        __syncthreads();
+    }
+    for (int kp = tid; kp < N; kp += 256) {
+        const int a = INLDS ? last[kp] : __hip_atomic_load(last + kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int out = -1;
+        if (a >= FT_REPLAY_REMOVED) holder[kp] = -1;
+        else if (a >= 0) {
+            out = a;
+            holder[kp] = obs[a];
+        }
+        assign[kp] = out;
+    }
+    nm = wave_sum_i32(nm);
+    if ((tid & 63) == 0) rp_sum[tid >> 6] = nm;
+    __syncthreads();
+    if (tid == 0) {
+        const int total = rp_sum[0] + rp_sum[1] + rp_sum[2] + rp_sum[3];
+        *J.nmOut = total;
+        *replayed = total;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Frame::isInFrustum / isInFrustumChecks (src/Frame.cc:536-610, 1308-1382) with MapPoint::PredictScale
 // (src/MapPoint.cc:531-546): one thread per local map point.  Float expressions are evaluated in the
@@ -2129,6 +2250,8 @@ __global__ __launch_bounds__(256) void k_fill_claims_batch(const FtBatchJob *__r
     const int t = blockIdx.x * 256 + threadIdx.x, T = gridDim.x * 256;
     int *count = rb(J.O.count);
     if (t == 0 && count) *count = 0;
+    int *replayed = rb(J.replayed);
+    if (t == 0 && replayed) *replayed = -1;  // (k_replay_batch: this search's writes have not been replayed yet)
     int *head = rb(J.head), *flags = rb(J.flags);
     if (t < FT_BATCH_FLAGS) flags[t] = -1;  // (also of a frame without points: "converged" is what the host reads there)
     if (J.nPoints <= 0) return;
@@ -2415,6 +2538,21 @@ int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs,
     if (nFrames <= 0) return FT_OK;
     if (local) hipLaunchKernelGGL(k_resolve_batch<true>, dim3(nFrames), dim3(FT_RS_ROWS * 16), 0, st, jobs, rebase_of(arena), nnRatio);
     else hipLaunchKernelGGL(k_resolve_batch<false>, dim3(nFrames), dim3(FT_RS_ROWS * 16), 0, st, jobs, rebase_of(arena), nnRatio);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+int ft_launch_replay_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, int parity, int checkOrientation,
+                           int sharedInts, int resolvedOnly) {
+    if (nFrames <= 0) return FT_OK;
+    const Rebase rb = rebase_of(arena);
+    const size_t sh = sizeof(int) * (size_t)sharedInts;
+    if (sharedInts > 0) {
+        if (local) hipLaunchKernelGGL((k_replay_batch<true, true>), dim3(nFrames), dim3(256), sh, st, jobs, rb, parity, checkOrientation, resolvedOnly);
+        else hipLaunchKernelGGL((k_replay_batch<false, true>), dim3(nFrames), dim3(256), sh, st, jobs, rb, parity, checkOrientation, resolvedOnly);
+    } else {
+        if (local) hipLaunchKernelGGL((k_replay_batch<true, false>), dim3(nFrames), dim3(256), 0, st, jobs, rb, parity, checkOrientation, resolvedOnly);
+        else hipLaunchKernelGGL((k_replay_batch<false, false>), dim3(nFrames), dim3(256), 0, st, jobs, rb, parity, checkOrientation, resolvedOnly);
+    }
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -1182,10 +1182,11 @@ struct ft_tracked_batch {
     // the uploaded frames
     int nFrames = 0;
     std::vector<FtDevFrame> DF;
+    // holder_obs (Observations() of mvpMapPoints[i], -1 = none) lives in HBM from the upload on: the searches read it there and
+    // k_replay_batch updates it there; ft_tracked_batch_holder_obs copies a frame's array down on request
     std::vector<size_t> holderOff;  // byte offset of frame f's holder_obs inside the frames region
-    size_t holderBegin = 0, holderEnd = 0;  // the holder_obs arrays of all frames are contiguous: one copy refreshes them
-    std::vector<std::vector<float>> angles;
-    std::vector<std::vector<int>> holder;
+    size_t holderBegin = 0, holderEnd = 0;  // the holder_obs arrays of all frames are contiguous: one copy takes them up
+    size_t oReplayed = 0;  // one int per frame: k_replay_batch's "this search's writes have been replayed" marker
     int passesLast = 0, passesLocal = 0;
     bool hasGrid = false;  // the frames' CSR grids were laid out and built at upload / bind time (search_grid as it was THEN)
     // the context's search options as the current call saw them (snapshotTuning, under ctx->matchMutex): the option may be set
@@ -1228,6 +1229,7 @@ void batchClaims(const ft_tracked_batch *tb, int f, int nKp, int nPoints, FtBatc
     J.cache = tb->oCache ? (unsigned long long *)(tb->d_arena + tb->oCache + (size_t)f * tb->cacheStride) : nullptr;
     J.nKp = nKp;
     J.nPoints = nPoints;
+    J.replayed = (int *)(tb->d_arena + tb->oReplayed) + f;
 }
 
 // first pass of a batched search by the four-points-per-wave kernels (k_search_*_first) where the cache and the grid exist (and
@@ -1266,13 +1268,14 @@ bool rowsUsable(const ft_tracked_batch *tb) { return FT_ROW_FIRST && tb->oCache 
 template <typename PassFn, typename DeliverFn>
 int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJobs, int n, int maxPoints, int maxK, PassFn launchPass,
                     DeliverFn deliver, const int *hostFlags, int *parityFinal, int *passes, int *burstHint,
-                    const std::function<int()> &resolve = nullptr) {
+                    const std::function<int()> &resolve = nullptr, bool *resolvedAll = nullptr) {
     ft_context *ctx = tb->ctx;
     const int half = FT_BATCH_FLAGS / 2, lenMax = half - 2;
     const int burstMax = std::min(tb->optPassBurst + 4, lenMax);
     int len = burstHint && *burstHint > 0 ? std::min(std::max(*burstHint + 1, 4), lenMax) : burstMax;
     *parityFinal = 0;
     *passes = 0;
+    if (resolvedAll) *resolvedAll = false;
     int rc = ft_launch_fill_claims_batch(st, tb->d_arena, dJobs, n, 27 * maxK);
     if (rc != FT_OK) return rc;
     if (maxPoints <= 0) {
@@ -1300,6 +1303,7 @@ int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJob
                 if (all) {
                     *parityFinal = 0;
                     *passes = 2;
+                    if (resolvedAll) *resolvedAll = true;
                     return FT_OK;
                 }
                 ctx->addStat("tracked_batch.resolve_fallbacks", 1);
@@ -1347,14 +1351,11 @@ int checkBatch(const ft_tracked_batch *tb, int n, const char *what) {
     return FT_OK;
 }
 
-// holder_obs of all frames to the device: the arrays are contiguous in the frames region, one copy from the pinned mirror
-int uploadBatchHolders(ft_tracked_batch *tb, hipStream_t st) {
-    for (int f = 0; f < tb->nFrames; f++)
-        if (!tb->holder[f].empty()) memcpy(tb->h_in + tb->workBytes + tb->holderOff[f], tb->holder[f].data(), sizeof(int) * tb->holder[f].size());
-    if (tb->holderEnd > tb->holderBegin)
-        FT_HIP(hipMemcpyAsync(tb->d_arena + tb->oFrames + tb->holderBegin, tb->h_in + tb->workBytes + tb->holderBegin,
-                              tb->holderEnd - tb->holderBegin, hipMemcpyHostToDevice, st));
-    return FT_OK;
+// LDS ints of k_replay_batch's last-writer table for the uploaded frames (0: a frame beyond the LDS, the table lives in HBM)
+int replayShared(const ft_tracked_batch *tb) {
+    int maxN = 1;
+    for (const FtDevFrame &D : tb->DF) maxN = std::max(maxN, D.N);
+    return maxN <= 15360 ? maxN : 0;
 }
 
 }  // namespace
@@ -1379,6 +1380,7 @@ int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, 
     tb->oFrames = a.take(tb->framesBytes);
     tb->oFlags = a.take(B * FT_BATCH_FLAGS * sizeof(int));
     tb->oCounts = a.take(B * sizeof(int));
+    tb->oReplayed = a.take(B * sizeof(int));
     tb->gridStride = (gridBytes(max_keypoints) + 255) & ~(size_t)255;
     tb->oGrid = a.take(B * tb->gridStride);
     tb->claimStride = (batchClaimBytes(max_keypoints, max_points) + 255) & ~(size_t)255;
@@ -1389,7 +1391,9 @@ int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, 
     }
     tb->arenaBytes = a.off;
     // results of a search (per point) or of bind_fisheye (per keypoint: match tables, mvDepth, mvStereo3Dpoints)
-    tb->outBytes = B * std::max(batchOutBytes(max_points), 20 * (size_t)max_keypoints + 8 * 64) + B * FT_BATCH_FLAGS * sizeof(int) + 4096;
+    // (+ a search's assignments: 4 bytes per keypoint, and its match count)
+    tb->outBytes = B * (std::max(batchOutBytes(max_points), 20 * (size_t)max_keypoints + 8 * 64) + 4 * (size_t)max_keypoints + 128) +
+                   B * FT_BATCH_FLAGS * sizeof(int) + 4096;
     hipError_t e = hipMalloc((void **)&tb->d_arena, tb->arenaBytes);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_in, tb->workBytes + tb->framesBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_out, tb->outBytes, hipHostMallocDefault);
@@ -1473,8 +1477,6 @@ int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_frame_v
     FT_REQUIRE(a.off <= tb->framesBytes, "ft_tracked_batch_upload: frames region too small");
     tb->nFrames = n_frames;
     tb->DF.assign(n_frames, FtDevFrame());
-    tb->angles.resize(n_frames);
-    tb->holder.resize(n_frames);
     uint8_t *pinF = tb->h_in + tb->workBytes, *devF = tb->d_arena + tb->oFrames;
     FtBatchJob *hJobs = (FtBatchJob *)tb->h_in;
     FT_REQUIRE((size_t)n_frames * sizeof(FtBatchJob) <= tb->workBytes, "ft_tracked_batch_upload: work region too small");
@@ -1514,10 +1516,6 @@ int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_frame_v
         }
         memset(&hJobs[f], 0, sizeof(FtBatchJob));
         hJobs[f].F = D;
-        tb->angles[f].resize(F.N);
-        for (int i = 0; i < nL; i++) tb->angles[f][i] = F.keys[i].angle;
-        for (int i = 0; i < nR; i++) tb->angles[f][nL + i] = F.keys_right[i].angle;
-        tb->holder[f].assign(F.holder_obs, F.holder_obs + F.N);
     };
     ctx->pool->parallel_for(n_frames, stage);
     FT_HIP(hipMemcpyAsync(tb->d_arena + tb->oWork, tb->h_in, (size_t)n_frames * sizeof(FtBatchJob), hipMemcpyHostToDevice, st));
@@ -1535,8 +1533,13 @@ int ft_tracked_batch_holder_obs(ft_tracked_batch *tb, int frame, int *holder_obs
     FT_REQUIRE(tb && holder_obs, "ft_tracked_batch_holder_obs: bad argument");
     std::lock_guard<std::mutex> lk(tb->mu);  // (upload / bind_fisheye reassign the vectors)
     FT_REQUIRE(frame >= 0 && frame < tb->nFrames, "ft_tracked_batch_holder_obs: bad argument");
-    const std::vector<int> &h = tb->holder[frame];
-    if (!h.empty()) memcpy(holder_obs, h.data(), sizeof(int) * h.size());
+    int rc = ft_set_device(tb->ctx);
+    if (rc != FT_OK) return rc;
+    const int N = tb->DF[frame].N;
+    if (N > 0) {  // (the array lives in HBM; the copy is ordered behind the batch's searches on its stream)
+        FT_HIP(hipMemcpyAsync(holder_obs, tb->d_arena + tb->oFrames + tb->holderOff[frame], sizeof(int) * (size_t)N, hipMemcpyDeviceToHost, tb->stream));
+        FT_HIP(hipStreamSynchronize(tb->stream));
+    }
     return FT_OK;
 }
 
@@ -1571,11 +1574,12 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     const size_t oJobs = a.take((size_t)n * sizeof(FtBatchJob));
     const size_t oRecs = a.take((size_t)(n + 1) * sizeof(FtDeliverRec));
     struct Lay {
-        size_t valid, pos, desc, obs, oct, out, proj;
+        size_t valid, pos, desc, obs, oct, ang, out, proj;
     };
     std::vector<Lay> lay(n);
-    Arena o;  // results in tb->h_out
+    Arena o;  // results in tb->h_out: the flag words, the match counts, every frame's assignments (k_replay_batch writes them there)
     const size_t oFlagsOut = o.take((size_t)n * FT_BATCH_FLAGS * sizeof(int));
+    const size_t oNmOut = o.take((size_t)n * sizeof(int));
     int maxPoints = 0, maxK = 8;
     for (int f = 0; f < n; f++) {
         const size_t M = (size_t)std::max(L[f].N, 1);
@@ -1584,7 +1588,8 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         lay[f].desc = a.take(32 * M);
         lay[f].obs = a.take(4 * M);
         lay[f].oct = a.take(4 * M);
-        lay[f].out = o.take(16 * M);
+        lay[f].ang = a.take(4 * M);
+        lay[f].out = o.take(4 * (size_t)std::max(tb->DF[f].N, 1));
     }
     const size_t inputEnd = a.off;  // what follows is device-only: the projections
     for (int f = 0; f < n; f++) lay[f].proj = a.take(sizeof(FtLastProj) * (size_t)std::max(L[f].N, 1));
@@ -1603,6 +1608,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
             memcpy(pin + lay[f].desc, P.descriptors, 32 * M);
             memcpy(pin + lay[f].obs, P.observations, 4 * M);
             memcpy(pin + lay[f].oct, P.octave, 4 * M);
+            memcpy(pin + lay[f].ang, P.angle, 4 * M);
         }
         FtBatchJob &J = hJobs[f];
         memset(&J, 0, sizeof J);
@@ -1615,16 +1621,17 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         J.L.worldPos = (const float *)(dev + lay[f].pos);
         J.L.desc = dev + lay[f].desc;
         J.L.octave = (const int *)(dev + lay[f].oct);
+        J.L.angle = (const float *)(dev + lay[f].ang);
         J.proj = (FtLastProj *)(dev + lay[f].proj);
         J.Tcw = poses[f];
         J.forward = forward ? forward[f] : 0;
         J.backward = backward ? backward[f] : 0;
-        FtDeliverRec &R = hRecs[f];
+        J.assignOut = (int *)(tb->h_out + lay[f].out);
+        J.nmOut = (int *)(tb->h_out + oNmOut) + f;
+        FtDeliverRec &R = hRecs[f];  // (the points' results stay on the device: k_replay_batch turns them into assignments there)
         R.dst = tb->h_out + lay[f].out;
-        R.src[0] = J.res;
-        R.src[1] = J.res + 4 * (size_t)J.nPoints;
-        R.words = 4 * J.nPoints;
-        for (int i = 0; i < N; i++) assign[f][i] = -1;
+        R.src[0] = R.src[1] = J.res;
+        R.words = 0;
     };
     ctx->pool->parallel_for(n, stage);
     for (int f = 0; f < n; f++) {
@@ -1640,6 +1647,8 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
     const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
     const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
     int parity = 0, passes = 0;
+    bool resolvedAll = false;
+    const int shInts = replayShared(tb);
     rc = fixedPointBatch(
         tb, st, dJobs, n, maxPoints, maxK,
         [&](int pass, int fCur, int fPrev, int fReset) {
@@ -1657,30 +1666,38 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
             }
             return r;
         },
-        [&](int par, int) { return ft_launch_deliver_batch(st, dRecs, n + 1, std::max(4 * maxPoints, FT_BATCH_FLAGS * n), par); },
+        [&](int par, int) { return ft_launch_deliver_batch(st, dRecs + n, 1, FT_BATCH_FLAGS * n, par); },  // (the flag words)
         (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLast,
         (rowsUsable(tb) && resolveWanted(tb, n))
             ? std::function<int()>([&]() {
                   tb->evt.begin(ctx->kernelTiming, "kernel.resolve_batch(last frame)", st);
-                  const int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 0, 0.f);
+                  int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 0, 0.f);
+                  tb->evt.end(ctx->kernelTiming, st);
+                  // the writes of the frames it resolved, replayed right behind it (a frame it gave up on waits for the passes)
+                  tb->evt.begin(ctx->kernelTiming, "kernel.replay_batch(last frame)", st);
+                  if (r == FT_OK) r = ft_launch_replay_batch(st, tb->d_arena, dJobs, n, 0, 0, check_orientation, shInts, 1);
                   tb->evt.end(ctx->kernelTiming, st);
                   return r;
               })
-            : std::function<int()>());
+            : std::function<int()>(),
+        &resolvedAll);
     if (rc != FT_OK) return rc;
+    if (!resolvedAll) {  // the claim passes finished (some of) the frames: their writes now, from the result buffer of the last pass
+        rc = ft_launch_replay_batch(st, tb->d_arena, dJobs, n, 0, parity, check_orientation, shInts, 0);
+        if (rc != FT_OK) return rc;
+        FT_HIP(hipStreamSynchronize(st));
+    }
     ctx->addStat("tracked_batch.search_last_frame.device", tDev.ms());
     tb->evt.resolve(ctx);
     FtTimer tRep;
-    const std::function<void(int, int)> replay = [&](int f, int) {
-        const int nm = hJobs[f].nPoints > 0
-                           ? replayLastFrameWrites((const int *)(tb->h_out + lay[f].out), L[f].N, &L[f], [&](int idx) { return tb->angles[f][idx]; },
-                                                   check_orientation != 0, tb->holder[f].data(), assign[f])
-                           : 0;
-        if (n_matches) n_matches[f] = nm;
+    // what is left for the host: the assignments out of the pinned result buffer into the caller's arrays
+    const int *hNm = (const int *)(tb->h_out + oNmOut);
+    const std::function<void(int, int)> finish = [&](int f, int) {
+        const int N = tb->DF[f].N;
+        if (N > 0) memcpy(assign[f], tb->h_out + lay[f].out, sizeof(int) * (size_t)N);
+        if (n_matches) n_matches[f] = hNm[f];
     };
-    ctx->pool->parallel_for(n, replay);
-    rc = uploadBatchHolders(tb, st);
-    if (rc != FT_OK) return rc;
+    ctx->pool->parallel_for(n, finish);
     ctx->addStat("tracked_batch.search_last_frame.replay", tRep.ms());
     ctx->addStat("tracked_batch.search_last_frame.total", tAll.ms());
     ctx->addStat("tracked_batch.search_last_frame.passes", passes);
@@ -1747,6 +1764,7 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
     Arena o;
     const size_t oFlagsOut = o.take((size_t)n * FT_BATCH_FLAGS * sizeof(int));
     const size_t oCountsOut = o.take((size_t)n * sizeof(int));
+    const size_t oNmOut = o.take((size_t)n * sizeof(int));
     // inputs of all frames first (one H2D copy), then the frustum outputs (device only)
     for (int f = 0; f < n; f++) {
         const size_t M = (size_t)std::max(P[f].M, 1);
@@ -1758,7 +1776,7 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
         lay[f].fIn0 = a.off;
         layoutFrustum(P[f].M, P[f].skip != nullptr, a, lay[f].FL, &lay[f].fInEnd);
         lay[f].fOutEnd = a.off;
-        lay[f].outRes = o.take(16 * (size_t)std::max(P[f].M, 1));
+        lay[f].outRes = o.take(4 * (size_t)std::max(tb->DF[f].N, 1));  // the frame's assignments (k_replay_batch)
         lay[f].outFr = o.take(lay[f].fOutEnd - lay[f].fInEnd);
     }
     FT_REQUIRE(a.off <= tb->workBytes && o.off <= tb->outBytes, "tracked batch work arena too small");
@@ -1790,16 +1808,16 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
         J.P.viewCos = J.O.viewCos; J.P.viewCosR = J.O.viewCosR;
         J.P.projX = J.O.projX; J.P.projY = J.O.projY; J.P.projXR = J.O.projXR; J.P.projYR = J.O.projYR;
         J.P.desc = dev + lay[f].desc;
-        FtDeliverRec &R = hRecs[f];
+        J.assignOut = (int *)(tb->h_out + lay[f].outRes);
+        J.nmOut = (int *)(tb->h_out + oNmOut) + f;
+        FtDeliverRec &R = hRecs[f];  // (the points' results stay on the device: k_replay_batch turns them into assignments there)
         R.dst = tb->h_out + lay[f].outRes;
-        R.src[0] = J.res;
-        R.src[1] = J.res + 4 * (size_t)J.nPoints;
-        R.words = 4 * J.nPoints;
+        R.src[0] = R.src[1] = J.res;
+        R.words = 0;
         FtDeliverRec &R2 = hRecs[n + 2 + f];  // (the frustum fields do not change from burst to burst: delivered with the first one)
         R2.dst = tb->h_out + lay[f].outFr;
         R2.src[0] = R2.src[1] = dev + lay[f].fInEnd;
         R2.words = M ? (int)((lay[f].fOutEnd - lay[f].fInEnd) / 4) : 0;
-        for (int i = 0; i < N; i++) assign[f][i] = -1;
     };
     ctx->pool->parallel_for(n, stage);
     int maxPoints = 0, maxM = 0, maxK = 8, maxFrWords = 0;
@@ -1821,7 +1839,8 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
     const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
     const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
     int parity = 0, passes = 0;
-    bool frustumDone = false;
+    bool frustumDone = false, resolvedAll = false;
+    const int shInts = replayShared(tb);
     rc = fixedPointBatch(
         tb, st, dJobs, n, maxPoints, maxK,
         [&](int pass, int fCur, int fPrev, int fReset) {
@@ -1854,23 +1873,32 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
                                                       th_far_points);
                 if (r != FT_OK) return r;
             }
-            return ft_launch_deliver_batch(st, dRecs, burst == 0 ? 2 * n + 2 : n + 2,
-                                           std::max(std::max(4 * maxPoints, burst == 0 ? maxFrWords : 0), FT_BATCH_FLAGS * n), par);
+            // the flag words and the counts; with the first burst the frustum fields (records n .. 2 n + 1)
+            return ft_launch_deliver_batch(st, dRecs + n, burst == 0 ? n + 2 : 2, std::max(burst == 0 ? maxFrWords : 0, FT_BATCH_FLAGS * n), par);
         },
         (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLocal,
         (rowsUsable(tb) && resolveWanted(tb, n))
             ? std::function<int()>([&]() {
                   tb->evt.begin(ctx->kernelTiming, "kernel.resolve_batch(local map)", st);
-                  const int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 1, nn_ratio);
+                  int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 1, nn_ratio);
+                  tb->evt.end(ctx->kernelTiming, st);
+                  tb->evt.begin(ctx->kernelTiming, "kernel.replay_batch(local map)", st);
+                  if (r == FT_OK) r = ft_launch_replay_batch(st, tb->d_arena, dJobs, n, 1, 0, 0, shInts, 1);
                   tb->evt.end(ctx->kernelTiming, st);
                   return r;
               })
-            : std::function<int()>());
+            : std::function<int()>(),
+        &resolvedAll);
     if (rc != FT_OK) return rc;
+    if (!resolvedAll) {
+        rc = ft_launch_replay_batch(st, tb->d_arena, dJobs, n, 1, parity, 0, shInts, 0);
+        if (rc != FT_OK) return rc;
+        FT_HIP(hipStreamSynchronize(st));
+    }
     ctx->addStat("tracked_batch.track_local_map.device", tDev.ms());
     tb->evt.resolve(ctx);
     FtTimer tRep;
-    const int *hCounts = (const int *)(tb->h_out + oCountsOut);
+    const int *hCounts = (const int *)(tb->h_out + oCountsOut), *hNm = (const int *)(tb->h_out + oNmOut);
     const std::function<void(int, int)> replay = [&](int f, int) {
         const int M = P[f].M;
         int nToMatch = 0;
@@ -1880,14 +1908,11 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
             nToMatch = hCounts[f];
         }
         if (n_to_match) n_to_match[f] = nToMatch;
-        const int nm = hJobs[f].nPoints > 0 ? replayLocalWrites((const int *)(tb->h_out + lay[f].outRes), M, P[f].observations,
-                                                                 tb->holder[f].data(), assign[f])
-                                            : 0;
-        if (n_matches) n_matches[f] = nm;
+        const int N = tb->DF[f].N;
+        if (N > 0) memcpy(assign[f], tb->h_out + lay[f].outRes, sizeof(int) * (size_t)N);
+        if (n_matches) n_matches[f] = hNm[f];
     };
     ctx->pool->parallel_for(n, replay);
-    rc = uploadBatchHolders(tb, st);
-    if (rc != FT_OK) return rc;
     ctx->addStat("tracked_batch.track_local_map.replay", tRep.ms());
     ctx->addStat("tracked_batch.track_local_map.total", tAll.ms());
     ctx->addStat("tracked_batch.track_local_map.passes", passes);
@@ -1917,7 +1942,6 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
         FT_REQUIRE(F.Nleft >= 0 && F.N >= F.Nleft && F.N <= tb->maxKp, "ft_tracked_batch_bind_fisheye: keypoint counts out of range");
         FT_REQUIRE(F.Nleft == exL->h_nSel[slot0 + f] && F.N - F.Nleft == exR->h_nSel[slot0 + f],
                    "ft_tracked_batch_bind_fisheye: meta's keypoint counts differ from the extractors' slots");
-        FT_REQUIRE(F.N == 0 || (F.keys && (F.N == F.Nleft || F.keys_right)), "ft_tracked_batch_bind_fisheye: meta->keys / keys_right (host copies) are null");
         FT_REQUIRE(F.scale_factors && F.nlevels >= 1 && F.nlevels <= FT_MAX_LEVELS, "scale factors missing");
         FT_REQUIRE(F.cam_model == 0 || F.cam_model == 1, "unknown camera model");
         nlevelsMax = std::max(nlevelsMax, F.nlevels);
@@ -1977,8 +2001,6 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     FT_REQUIRE(o.off <= tb->outBytes, "ft_tracked_batch_bind_fisheye: result buffer too small");
     tb->nFrames = n_frames;
     tb->DF.assign(n_frames, FtDevFrame());
-    tb->angles.resize(n_frames);
-    tb->holder.resize(n_frames);
     uint8_t *pinF = tb->h_in + tb->workBytes, *devF = tb->d_arena + tb->oFrames;
     FtBatchJob *hJobs = (FtBatchJob *)tb->h_in;
     FtDeliverRec *hRecs = (FtDeliverRec *)(tb->h_in + (((size_t)n_frames * sizeof(FtBatchJob) + 63) & ~(size_t)63));
@@ -2015,10 +2037,6 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
         }
         memset(&hJobs[f], 0, sizeof(FtBatchJob));
         hJobs[f].F = D;
-        tb->angles[f].resize(F.N);
-        for (int i = 0; i < nL; i++) tb->angles[f][i] = F.keys[i].angle;
-        for (int i = 0; i < nR; i++) tb->angles[f][nL + i] = F.keys_right[i].angle;
-        tb->holder[f].assign(hold, hold + F.N);
         FtDeliverRec *R = hRecs + 4 * (size_t)f;
         memset(R, 0, 4 * sizeof(FtDeliverRec));
         if (wantTables) {
