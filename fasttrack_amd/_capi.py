@@ -210,6 +210,10 @@ def lib() -> C.CDLL:
                                                          C.POINTER(vp), vp]
     L.ft_tracked_batch_track_local_map.argtypes = [vp, i, C.POINTER(FramePose), C.POINTER(MapPoints), f, f, f, f, i, f,
                                                    C.POINTER(FrustumResult), vp, C.POINTER(vp), vp]
+    L.ft_tracked_batch_submit_search_last_frame.argtypes = L.ft_tracked_batch_search_last_frame.argtypes
+    L.ft_tracked_batch_submit_search_last_frame_se3.argtypes = L.ft_tracked_batch_search_last_frame_se3.argtypes
+    L.ft_tracked_batch_submit_track_local_map.argtypes = L.ft_tracked_batch_track_local_map.argtypes
+    L.ft_tracked_batch_wait.argtypes = [vp]
     L.ft_tracked_batch_holder_obs.argtypes = [vp, i, vp]
     L.ft_tracked_batch_bind_fisheye.argtypes = [vp, vp, vp, i, i, i, i, i, i, C.POINTER(FrameView), C.POINTER(FisheyeRig), vp, C.POINTER(vp),
                                                 C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]

@@ -485,6 +485,7 @@ int ft_host_malloc(ft_context *ctx, size_t bytes, void **ptr) {
     FT_HIP(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
     std::lock_guard<std::mutex> lk(ctx->hostAllocMutex);
     ctx->hostAllocs.push_back(*ptr);  // released by ft_host_free, or with the context
+    ctx->hostBlocks.emplace_back((uintptr_t)*ptr, bytes ? bytes : 1);
     return FT_OK;
 }
 
@@ -495,6 +496,11 @@ int ft_host_free(ft_context *ctx, void *ptr) {
         std::lock_guard<std::mutex> lk(ctx->hostAllocMutex);
         auto it = std::find(ctx->hostAllocs.begin(), ctx->hostAllocs.end(), ptr);
         if (it != ctx->hostAllocs.end()) ctx->hostAllocs.erase(it);
+        for (size_t i = 0; i < ctx->hostBlocks.size(); i++)
+            if (ctx->hostBlocks[i].first == (uintptr_t)ptr) {
+                ctx->hostBlocks.erase(ctx->hostBlocks.begin() + (long)i);
+                break;
+            }
     }
     FT_HIP(hipHostFree(ptr));
     return FT_OK;
@@ -538,6 +544,17 @@ bool ft_is_pinned_host(const void *p) {
         return false;
     }
     return at.type == hipMemoryTypeHost;
+}
+
+// [p, p + bytes) inside a block of ft_host_malloc: pinned for certain, and known without asking the runtime (a call that checks
+// hundreds of arrays - ft_tracked_batch_submit_* - cannot afford a hipPointerGetAttributes each)
+bool ft_host_block_contains(ft_context *ctx, const void *p, size_t bytes) {
+    if (!ctx || !p) return false;
+    const uintptr_t a = (uintptr_t)p;
+    std::lock_guard<std::mutex> lk(ctx->hostAllocMutex);
+    for (const auto &b : ctx->hostBlocks)
+        if (a >= b.first && a + bytes <= b.first + b.second) return true;
+    return false;
 }
 
 // A frame the device may read in place: first AND last byte lie in the same pinned / registered host allocation.

@@ -87,6 +87,7 @@ struct ft_context {
     std::mutex hostAllocMutex;
     // events of destroyed tracked batches that an extractor may still hold as its foreignReader: destroyed with the context
     std::vector<hipEvent_t> retiredEvents;
+    std::vector<std::pair<uintptr_t, size_t>> hostBlocks;  // (address, bytes) of the live ft_host_malloc blocks (ft_host_block_contains)
     std::vector<void *> hostAllocs;  // live ft_host_malloc blocks
     bool kernelTiming = false;  // ft_context_set_kernel_timing
     ft_tuning tuning;           // FT_TUNING_OPTIONS: read from the environment by ft_context_create, changed by ft_context_set_option
@@ -296,6 +297,7 @@ int ft_context_take_lanes(ft_context *ctx, bool wantPrivate, int width, int heig
 int ft_context_upload_stream(ft_context *ctx, hipStream_t *out);  // the copy-only stream of the context (created on demand)
 bool ft_is_pinned_host(const void *p);  // null counts as pinned (nothing to copy)
 bool ft_is_pinned_host_range(const void *p, size_t bytes);  // [p, p + bytes) inside ONE pinned host allocation
+bool ft_host_block_contains(ft_context *ctx, const void *p, size_t bytes);
 int ft_extract_foreign_wait(ft_extractor *ex);  // orders the extractor's next batch behind ex->foreignReader (never inside a stream capture)
 int ft_ensure_scratch(ft_context *ctx, size_t devBytes, size_t pinBytes);  // grow-only matcher scratch (hold matchMutex)
 int ft_usable_cpus();

@@ -148,8 +148,17 @@ struct FtBatchJob {
     // directly (not in the arena: never rebased), replayed [1] (arena) is the frame's "done" marker: -1 until the frame's writes
     // have been replayed, then its match count
     int *assignOut, *nmOut, *replayed;
+    int *err;  // [1] (arena), zeroed with the claim buffers: an input error a kernel found (FT_JOB_ERR_*), reported by the call's second half
 };
+#define FT_JOB_ERR_OCTAVE 1  // a valid last-frame point whose octave lies outside the frame's levels (the point is dropped)
 
+// a block of bytes of PINNED HOST memory (the caller's arrays, read in place) gathered into the batch's arena by k_gather_batch
+struct FtGatherRec {
+    void *dst;        // device (arena)
+    const void *src;  // pinned host
+    unsigned bytes;
+};
+int ft_launch_gather_batch(hipStream_t st, const FtGatherRec *recs, int nRecs);
 // a block of dwords delivered into pinned host memory by k_deliver_batch; src[parity of the last pass]
 struct FtDeliverRec {
     void *dst;

@@ -1008,7 +1008,16 @@ __global__ __launch_bounds__(256) void k_last_project_batch(const FtBatchJob *__
     FtLastProj pj;
     pj.u = pj.v = pj.invzc = pj.ur = pj.vr = 0.f;
     pj.go = 0;
-    if (rb(J.L.valid)[i]) {
+    uint8_t *valid = const_cast<uint8_t *>(rb(J.L.valid));
+    // a valid point's octave indexes the frame's scale factors in every kernel behind this one: a value outside the levels
+    // (the host checks it when it copies the points; arrays read in place from pinned memory are checked here) drops the point
+    // and marks the frame - the call's second half reports FT_ERR_INVALID
+    if (valid[i] && ((unsigned)rb(J.L.octave)[i] >= (unsigned)F.nlevels)) {
+        valid[i] = 0;
+        int *err = rb(J.err);
+        if (err) atomicOr(err, FT_JOB_ERR_OCTAVE);
+    }
+    if (valid[i]) {
         const float *wp = rb(J.L.worldPos);
         const float xw[3] = {wp[3 * i], wp[3 * i + 1], wp[3 * i + 2]};
         float xc[3], uv[2] = {0.f, 0.f};
@@ -2252,6 +2261,8 @@ __global__ __launch_bounds__(256) void k_fill_claims_batch(const FtBatchJob *__r
     if (t == 0 && count) *count = 0;
     int *replayed = rb(J.replayed);
     if (t == 0 && replayed) *replayed = -1;  // (k_replay_batch: this search's writes have not been replayed yet)
+    int *err = rb(J.err);
+    if (t == 0 && err) *err = 0;
     int *head = rb(J.head), *flags = rb(J.flags);
     if (t < FT_BATCH_FLAGS) flags[t] = -1;  // (also of a frame without points: "converged" is what the host reads there)
     if (J.nPoints <= 0) return;
@@ -2430,7 +2441,35 @@ __global__ __launch_bounds__(256) void k_deliver_batch(const FtDeliverRec *__res
     for (int i = done + t; i < R.words; i += T) d[i] = s[i];
 }
 
+// The caller's point arrays, read in place out of pinned host memory, into the batch's arena: record r (blockIdx.y) = one array.
+// 16 bytes per lane where source and destination allow it; the copy is PCIe-bound like the delivery, few workgroups per record.
+__global__ __launch_bounds__(256) void k_gather_batch(const FtGatherRec *__restrict__ recs) {
+    const FtGatherRec &R = recs[blockIdx.y];
+    uint8_t *d = (uint8_t *)R.dst;
+    const uint8_t *s = (const uint8_t *)R.src;
+    const unsigned bytes = R.bytes;
+    const unsigned t = blockIdx.x * 256 + threadIdx.x, T = gridDim.x * 256;
+    unsigned done = 0;
+    if ((((unsigned long long)(size_t)d | (unsigned long long)(size_t)s) & 15ull) == 0ull) {  // (uniform)
+        const unsigned quads = bytes >> 4;
+        for (unsigned i = t; i < quads; i += T) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+        done = quads << 4;
+    } else if ((((unsigned long long)(size_t)d | (unsigned long long)(size_t)s) & 3ull) == 0ull) {
+        const unsigned words = bytes >> 2;
+        for (unsigned i = t; i < words; i += T) ((unsigned *)d)[i] = ((const unsigned *)s)[i];
+        done = words << 2;
+    }
+    for (unsigned i = done + t; i < bytes; i += T) d[i] = s[i];
+}
+
 }  // namespace
+
+int ft_launch_gather_batch(hipStream_t st, const FtGatherRec *recs, int nRecs) {
+    if (nRecs <= 0) return FT_OK;
+    hipLaunchKernelGGL(k_gather_batch, dim3(2, nRecs), dim3(256), 0, st, recs);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
 
 int ft_launch_deliver_blocks(hipStream_t st, void *d0, const void *s0, size_t bytes0, void *d1, const void *s1, size_t bytes1,
                              void *d2, const void *s2, size_t bytes2) {

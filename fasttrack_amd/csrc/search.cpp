@@ -1168,6 +1168,33 @@ int ft_tracked_frame_track_local_map(ft_tracked_frame *tf, const ft_frame_pose *
 //   flags  | 32 words per frame;  counts | 1 word per frame (isInFrustum's nToMatch)
 //   grid   | Frame::mGrid as CSR, per frame;  claims | res, list heads + writer table, next, per frame;  cache | per frame
 // and two pinned buffers: the mirror of `work` + `frames` (inputs: one H2D copy per call) and the results.
+// One search of a batch between its two halves (submit: everything up to the first point where the host must look at the flag
+// words, enqueued; wait: the rest).  Holds what the second half needs of the call: nothing of the caller's argument arrays is
+// referenced after submit except the OUTPUT arrays, whose pointers are copied here.
+struct FtBatchCall {
+    int kind = 0;  // 0 = none in flight, 1 = SearchByProjection(CurrentFrame, LastFrame), 2 = isInFrustum + SearchByProjection(Frame, points)
+    int n = 0, maxPoints = 0, maxK = 8, maxM = 0, maxFrWords = 0, shInts = 0;
+    const FtBatchJob *dJobs = nullptr;
+    const FtDeliverRec *dRecs = nullptr;
+    float th = 0.f, nnRatio = 0.f, viewingCosLimit = 0.f, logScaleFactor = 0.f, thFar = 0.f;
+    int farPoints = 0, checkOrientation = 0;
+    bool useResolve = false, frustumDone = false;
+    // the claim iteration, split where the host first waits for the device
+    int pass = 0, burst = 0, len = 0, prevLen = 0, parity = 0, nextB = 0;
+    bool simple = false, awaitResolve = false, resolvedAll = false;
+    // results in tb->h_out
+    size_t oFlagsOut = 0, oNmOut = 0, oCountsOut = 0, oErrOut = 0;
+    std::vector<size_t> outAssign, outFr, fInEnd;
+    std::vector<FrustumLayout> FL;
+    std::vector<int> M;
+    // the caller's output arrays
+    std::vector<int *> assign;
+    int *nMatches = nullptr, *nToMatch = nullptr;
+    std::vector<ft_frustum_result> frustum;
+    bool haveFrustum = false;
+    FtTimer tAll;
+};
+
 struct ft_tracked_batch {
     ft_context *ctx = nullptr;
     bool counted = false;
@@ -1198,6 +1225,8 @@ struct ft_tracked_batch {
     std::mutex mu;
     FtEventTimer evt;  // ft_context_set_kernel_timing: HIP events around the batch's launches on the context's stream
     hipEvent_t evGather = nullptr;  // bind_fisheye: the gather from the extractors' slots has run (the extractors' next batch waits for it)
+    FtBatchCall call;  // the search between ft_tracked_batch_submit_* and ft_tracked_batch_wait (kind 0: none)
+    size_t oErr = 0;   // one int per frame: input errors the kernels found (a last-frame octave outside the frame's levels)
 };
 
 namespace {
@@ -1230,6 +1259,7 @@ void batchClaims(const ft_tracked_batch *tb, int f, int nKp, int nPoints, FtBatc
     J.nKp = nKp;
     J.nPoints = nPoints;
     J.replayed = (int *)(tb->d_arena + tb->oReplayed) + f;
+    J.err = (int *)(tb->d_arena + tb->oErr) + f;
 }
 
 // first pass of a batched search by the four-points-per-wave kernels (k_search_*_first) where the cache and the grid exist (and
@@ -1259,83 +1289,178 @@ bool resolveWanted(const ft_tracked_batch *tb, int nFrames) {
 // when the batch was created / the frames were uploaded - the options' CURRENT values say nothing about that
 bool rowsUsable(const ft_tracked_batch *tb) { return FT_ROW_FIRST && tb->oCache && tb->hasGrid; }
 // The claim iteration of every frame of the batch (see fixedPoint): bursts of passes, one launch per pass for ALL frames, one
-// delivery + one synchronisation per burst.  launchPass(pass, fCur, fPrev, fReset); deliver(parity, burst) writes every frame's
-// results of that parity and all flag words into tb->h_out (flags at hostFlags[FT_BATCH_FLAGS f ...]).  A batch has 32 flag
-// positions per burst parity: bursts of up to 30 passes (the slowest of many frames needs more passes than one frame does).
-// resolve (may be empty): everything behind the first pass in ONE launch (k_resolve_batch: a workgroup per frame walks its points in
-// index order).  Launched behind pass 0; a frame it resolved has all its flag words at -1 and is inert in later passes, and only
-// if it gave up on a frame (a candidate list the cache could not hold) do the passes go on - for those frames.
-template <typename PassFn, typename DeliverFn>
-int fixedPointBatch(ft_tracked_batch *tb, hipStream_t st, const FtBatchJob *dJobs, int n, int maxPoints, int maxK, PassFn launchPass,
-                    DeliverFn deliver, const int *hostFlags, int *parityFinal, int *passes, int *burstHint,
-                    const std::function<int()> &resolve = nullptr, bool *resolvedAll = nullptr) {
+// delivery of the flag words + one synchronisation per burst.  A batch has 32 flag positions per burst parity: bursts of up to
+// 30 passes (the slowest of many frames needs more passes than one frame does).  With the one-launch resolution
+// (c.useResolve; k_resolve_batch: a workgroup per frame walks its points in index order) everything behind the first pass is ONE
+// launch; a frame it resolved has all its flag words at -1 and is inert in later passes, and only if it gave up on a frame (a
+// candidate list the cache could not hold) do the passes go on - for those frames.
+// The iteration is written as two halves around its FIRST host synchronisation: callBegin enqueues everything up to it (the
+// whole search when the resolution resolves every frame - the usual case) and returns; callFinish waits, looks at the flag
+// words and runs whatever is left.  ft_tracked_batch_submit_* = callBegin, ft_tracked_batch_wait = callFinish.
+int callLaunchPass(ft_tracked_batch *tb, FtBatchCall &c, int pass, int fCur, int fPrev, int fReset) {
     ft_context *ctx = tb->ctx;
-    const int half = FT_BATCH_FLAGS / 2, lenMax = half - 2;
-    const int burstMax = std::min(tb->optPassBurst + 4, lenMax);
-    int len = burstHint && *burstHint > 0 ? std::min(std::max(*burstHint + 1, 4), lenMax) : burstMax;
-    *parityFinal = 0;
-    *passes = 0;
-    if (resolvedAll) *resolvedAll = false;
-    int rc = ft_launch_fill_claims_batch(st, tb->d_arena, dJobs, n, 27 * maxK);
-    if (rc != FT_OK) return rc;
-    if (maxPoints <= 0) {
-        rc = deliver(0, 0);
-        if (rc != FT_OK) return rc;
-        FT_HIP(hipStreamSynchronize(st));
-        return FT_OK;
+    hipStream_t st = tb->stream;
+    const bool local = c.kind == 2;
+    if (local && !c.frustumDone) {  // behind the fill of the claim iteration (which zeroes the counts), in front of the first pass
+        c.frustumDone = true;
+        tb->evt.begin(ctx->kernelTiming, "kernel.frustum_batch", st);
+        const int r = ft_launch_frustum_batch(st, tb->d_arena, c.dJobs, c.n, c.maxM, c.viewingCosLimit, c.logScaleFactor, c.farPoints, c.thFar);
+        tb->evt.end(ctx->kernelTiming, st);
+        if (r != FT_OK) return r;
     }
-    const int maxPasses = 2 * maxPoints + 4 + burstMax;
-    int pass = 0, prevLen = 0, parity = 0;
-    for (int burst = 0;; burst++) {
-        const int base = half * (burst & 1), other = half * ((burst + 1) & 1);
-        for (int b = 0; b < len; b++, pass++) {
-            const int fPrev = b > 0 ? base + b - 1 : (burst > 0 ? other + prevLen - 1 : -1);
-            rc = launchPass(pass, base + b, fPrev, other + b);
-            if (rc != FT_OK) return rc;
-            parity = pass & 1;
-            if (pass == 0 && resolve) {
-                rc = resolve();
-                if (rc == FT_OK) rc = deliver(0, 0);
-                if (rc != FT_OK) return rc;
-                FT_HIP(hipStreamSynchronize(st));
-                bool all = true;
-                for (int f = 0; f < n && all; f++) all = hostFlags[FT_BATCH_FLAGS * (size_t)f] == -1;
-                if (all) {
-                    *parityFinal = 0;
-                    *passes = 2;
-                    if (resolvedAll) *resolvedAll = true;
-                    return FT_OK;
-                }
-                ctx->addStat("tracked_batch.resolve_fallbacks", 1);
-            }
+    const bool lean = pass > 0 && tb->oCache;
+    const bool rows = pass == 0 && rowsUsable(tb);  // (fCur 0, fPrev -1, fReset = half: the kernel's own)
+    int r;
+    if (local) {
+        tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_local_batch(later pass)" : "kernel.search_local_batch(first pass)", st);
+        r = rows   ? ft_launch_search_local_first(st, tb->d_arena, c.dJobs, c.n, c.maxPoints, c.th, c.nnRatio)
+            : lean ? ft_launch_search_local_batch_lean(st, tb->d_arena, c.dJobs, c.n, c.maxPoints, pass, fCur, fPrev, fReset, c.th, c.nnRatio)
+                   : ft_launch_search_local_batch(st, tb->d_arena, c.dJobs, c.n, c.maxPoints, pass, fCur, fPrev, fReset, c.th, c.nnRatio);
+    } else {
+        tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_last_batch(later pass)" : "kernel.search_last_batch(first pass)", st);
+        r = rows   ? ft_launch_search_last_first(st, tb->d_arena, c.dJobs, c.n, c.maxPoints, c.th)
+            : lean ? ft_launch_search_last_batch_lean(st, tb->d_arena, c.dJobs, c.n, c.maxPoints, pass, fCur, fPrev, fReset, c.th)
+                   : ft_launch_search_last_batch(st, tb->d_arena, c.dJobs, c.n, c.maxPoints, pass, fCur, fPrev, fReset, c.th);
+    }
+    tb->evt.end(ctx->kernelTiming, st);
+    if (r == FT_OK && pass == 0 && tb->oCache) {
+        tb->evt.begin(ctx->kernelTiming, "kernel.cache_partition_batch", st);
+        r = ft_launch_cache_partition_batch(st, tb->d_arena, c.dJobs, c.n, c.maxPoints);
+        tb->evt.end(ctx->kernelTiming, st);
+    }
+    return r;
+}
+
+// the flag words, the error words (and the counts) of every frame into pinned host memory; a local-map search's first delivery
+// also carries the frustum fields (they do not change from burst to burst).  Records: [n] flags, [n + 1] errors, [n + 2] counts,
+// [n + 3 + f] frustum fields of frame f.
+int callDeliver(ft_tracked_batch *tb, FtBatchCall &c, int parity, bool first) {
+    hipStream_t st = tb->stream;
+    if (c.kind == 2 && !c.frustumDone) {  // no frame has keypoints: the frustum fields are still the call's result
+        c.frustumDone = true;
+        const int r = ft_launch_frustum_batch(st, tb->d_arena, c.dJobs, c.n, c.maxM, c.viewingCosLimit, c.logScaleFactor, c.farPoints, c.thFar);
+        if (r != FT_OK) return r;
+    }
+    const int nRecs = c.kind == 2 ? (first ? c.n + 3 : 3) : 2;
+    return ft_launch_deliver_batch(st, c.dRecs + c.n, nRecs, std::max(c.kind == 2 && first ? c.maxFrWords : 0, FT_BATCH_FLAGS * c.n), parity);
+}
+
+int callResolve(ft_tracked_batch *tb, FtBatchCall &c) {
+    ft_context *ctx = tb->ctx;
+    hipStream_t st = tb->stream;
+    const bool local = c.kind == 2;
+    tb->evt.begin(ctx->kernelTiming, local ? "kernel.resolve_batch(local map)" : "kernel.resolve_batch(last frame)", st);
+    int r = ft_launch_resolve_batch(st, tb->d_arena, c.dJobs, c.n, local ? 1 : 0, c.nnRatio);
+    tb->evt.end(ctx->kernelTiming, st);
+    // the writes of the frames it resolved, replayed right behind it (a frame it gave up on waits for the passes)
+    tb->evt.begin(ctx->kernelTiming, local ? "kernel.replay_batch(local map)" : "kernel.replay_batch(last frame)", st);
+    if (r == FT_OK) r = ft_launch_replay_batch(st, tb->d_arena, c.dJobs, c.n, local ? 1 : 0, 0, c.checkOrientation, c.shInts, 1);
+    tb->evt.end(ctx->kernelTiming, st);
+    return r;
+}
+
+constexpr int kFlagHalf = FT_BATCH_FLAGS / 2, kLenMax = kFlagHalf - 2;
+
+// passes [c.nextB, c.len) of burst c.burst, then its delivery
+int callRunBurst(ft_tracked_batch *tb, FtBatchCall &c) {
+    const int base = kFlagHalf * (c.burst & 1), other = kFlagHalf * ((c.burst + 1) & 1);
+    for (int b = c.nextB; b < c.len; b++, c.pass++) {
+        const int fPrev = b > 0 ? base + b - 1 : (c.burst > 0 ? other + c.prevLen - 1 : -1);
+        int rc = callLaunchPass(tb, c, c.pass, base + b, fPrev, other + b);
+        if (rc != FT_OK) return rc;
+        c.parity = c.pass & 1;
+        if (c.pass == 0 && c.useResolve) {  // the rest of the search in one launch; the host looks at the flag words before it goes on
+            rc = callResolve(tb, c);
+            if (rc == FT_OK) rc = callDeliver(tb, c, 0, true);
+            c.pass++;
+            c.nextB = b + 1;
+            c.awaitResolve = true;
+            return rc;
         }
-        rc = deliver(parity, burst);
+    }
+    c.nextB = c.len;
+    return callDeliver(tb, c, c.parity, c.burst == 0 && !c.awaitResolve);
+}
+
+int callBegin(ft_tracked_batch *tb, FtBatchCall &c, int burstHint) {
+    hipStream_t st = tb->stream;
+    const int burstMax = std::min(tb->optPassBurst + 4, kLenMax);
+    c.len = burstHint > 0 ? std::min(std::max(burstHint + 1, 4), kLenMax) : burstMax;
+    c.pass = c.burst = c.prevLen = c.parity = c.nextB = 0;
+    c.simple = c.awaitResolve = c.resolvedAll = false;
+    int rc = ft_launch_fill_claims_batch(st, tb->d_arena, c.dJobs, c.n, 27 * c.maxK);
+    if (rc != FT_OK) return rc;
+    if (c.maxPoints <= 0) {  // nothing to search in any frame: the (empty) results and, for a local-map call, the frustum fields
+        c.simple = true;
+        rc = ft_launch_replay_batch(st, tb->d_arena, c.dJobs, c.n, c.kind == 2 ? 1 : 0, 0, c.checkOrientation, c.shInts, 0);
+        if (rc == FT_OK) rc = callDeliver(tb, c, 0, true);
+        c.resolvedAll = true;
+        return rc;
+    }
+    return callRunBurst(tb, c);
+}
+
+// the second half: waits for what callBegin enqueued, runs the bursts that are left (none when the resolution resolved every
+// frame), has the writes of the frames the passes finished replayed; *passes = claim passes the search took
+int callFinish(ft_tracked_batch *tb, FtBatchCall &c, int *passes) {
+    ft_context *ctx = tb->ctx;
+    hipStream_t st = tb->stream;
+    const int *hostFlags = (const int *)(tb->h_out + c.oFlagsOut);
+    const int burstMax = std::min(tb->optPassBurst + 4, kLenMax);
+    const int maxPasses = 2 * c.maxPoints + 4 + burstMax;
+    FT_HIP(hipStreamSynchronize(st));
+    *passes = 0;
+    if (c.simple) return FT_OK;
+    bool firstDelivered = true;  // (callBegin's delivery carried the frustum fields)
+    if (c.awaitResolve) {
+        bool all = true;
+        for (int f = 0; f < c.n && all; f++) all = hostFlags[FT_BATCH_FLAGS * (size_t)f] == -1;
+        if (all) {
+            c.resolvedAll = true;
+            *passes = 2;
+            return FT_OK;
+        }
+        ctx->addStat("tracked_batch.resolve_fallbacks", 1);
+        c.awaitResolve = false;
+        c.pass = 1;
+        int rc = callRunBurst(tb, c);  // the rest of the first burst
         if (rc != FT_OK) return rc;
         FT_HIP(hipStreamSynchronize(st));
+    }
+    (void)firstDelivered;
+    for (;;) {
+        const int base = kFlagHalf * (c.burst & 1);
         bool all = true;
         int ranMax = 0;
-        for (int f = 0; f < n; f++) {
+        for (int f = 0; f < c.n; f++) {
             const int *h = hostFlags + FT_BATCH_FLAGS * (size_t)f + base;
-            if (h[len - 1] != -1) all = false;
+            if (h[c.len - 1] != -1) all = false;
             int ran = 0;
-            while (ran < len && h[ran] != -1) ran++;
-            ranMax = std::max(ranMax, std::min(ran + 1, len));
+            while (ran < c.len && h[ran] != -1) ran++;
+            ranMax = std::max(ranMax, std::min(ran + 1, c.len));
         }
         if (all) {
-            pass = pass - len + ranMax;
+            c.pass = c.pass - c.len + ranMax;
             break;
         }
-        if (pass >= maxPasses) {
+        if (c.pass >= maxPasses) {
             ft_set_error("projection search (batch): claim resolution did not converge");
             return FT_ERR_HIP;
         }
-        prevLen = len;
-        len = std::min(len, 6);  // the first burst fell short: short bursts from here (never longer than the one before: the
-                                 // flag words beyond a burst's length are not reset by the next one)
+        c.prevLen = c.len;
+        c.len = std::min(c.len, 6);  // the first burst fell short: short bursts from here (never longer than the one before: the
+                                     // flag words beyond a burst's length are not reset by the next one)
+        c.burst++;
+        c.nextB = 0;
+        int rc = callRunBurst(tb, c);
+        if (rc != FT_OK) return rc;
+        FT_HIP(hipStreamSynchronize(st));
     }
-    *parityFinal = parity;
-    *passes = pass;
-    if (burstHint) *burstHint = pass;
+    *passes = c.pass;
+    // the claim passes finished (some of) the frames: their writes now, from the result buffer of the last pass
+    int rc = ft_launch_replay_batch(st, tb->d_arena, c.dJobs, c.n, c.kind == 2 ? 1 : 0, c.parity, c.checkOrientation, c.shInts, 0);
+    if (rc != FT_OK) return rc;
+    FT_HIP(hipStreamSynchronize(st));
     return FT_OK;
 }
 
@@ -1381,6 +1506,7 @@ int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, 
     tb->oFlags = a.take(B * FT_BATCH_FLAGS * sizeof(int));
     tb->oCounts = a.take(B * sizeof(int));
     tb->oReplayed = a.take(B * sizeof(int));
+    tb->oErr = a.take(B * sizeof(int));
     tb->gridStride = (gridBytes(max_keypoints) + 255) & ~(size_t)255;
     tb->oGrid = a.take(B * tb->gridStride);
     tb->claimStride = (batchClaimBytes(max_keypoints, max_points) + 255) & ~(size_t)255;
@@ -1444,6 +1570,7 @@ int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_frame_v
     int rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
     std::lock_guard<std::mutex> lk(tb->mu);
+    FT_REQUIRE(tb->call.kind == 0, "ft_tracked_batch_upload: a submitted search of this batch has not been waited for (ft_tracked_batch_wait)");
     FtTimer tAll;
     hipStream_t st = tb->stream;
     bool wantGrid;
@@ -1533,6 +1660,7 @@ int ft_tracked_batch_holder_obs(ft_tracked_batch *tb, int frame, int *holder_obs
     FT_REQUIRE(tb && holder_obs, "ft_tracked_batch_holder_obs: bad argument");
     std::lock_guard<std::mutex> lk(tb->mu);  // (upload / bind_fisheye reassign the vectors)
     FT_REQUIRE(frame >= 0 && frame < tb->nFrames, "ft_tracked_batch_holder_obs: bad argument");
+    FT_REQUIRE(tb->call.kind == 0, "ft_tracked_batch_holder_obs: a submitted search of this batch has not been waited for (ft_tracked_batch_wait)");
     int rc = ft_set_device(tb->ctx);
     if (rc != FT_OK) return rc;
     const int N = tb->DF[frame].N;
@@ -1546,15 +1674,54 @@ int ft_tracked_batch_holder_obs(ft_tracked_batch *tb, int frame, int *holder_obs
 }  // extern "C"
 
 namespace {
-int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, const FtPose *poses, const FtPose *trls, bool needTrl, float th,
-                         const int *forward, const int *backward, int check_orientation, int *const *assign, int *n_matches) {
-    FT_REQUIRE(tb, "ft_tracked_batch_search_last_frame: null batch");
-    std::lock_guard<std::mutex> lk(tb->mu);  // (before anything of the batch is read: upload / bind_fisheye reassign it)
-    int rc = checkBatch(tb, n, "ft_tracked_batch_search_last_frame");
+
+// May the device read [p, p + bytes) in place?  A block of ft_host_malloc is known without asking the runtime; anything else is
+// asked about (hipHostMalloc / hipHostRegister memory of the application qualifies, at a few microseconds per array).
+bool readableInPlace(ft_context *ctx, const void *p, size_t bytes) {
+    if (!p || bytes == 0) return true;
+    return ft_host_block_contains(ctx, p, bytes) || ft_is_pinned_host_range(p, bytes);
+}
+
+// the records of a call's head in the pinned mirror: jobs | delivery records | gather records (the gather records only when the
+// caller's arrays are read in place)
+struct CallHead {
+    size_t oJobs, oRecs, oGather;
+    FtBatchJob *hJobs;
+    FtDeliverRec *hRecs;
+    FtGatherRec *hGather;
+};
+CallHead layoutHead(ft_tracked_batch *tb, Arena &a, int n, int nRecs, int nGather) {
+    CallHead H;
+    H.oJobs = a.take((size_t)n * sizeof(FtBatchJob));
+    H.oRecs = a.take((size_t)nRecs * sizeof(FtDeliverRec));
+    H.oGather = a.take((size_t)std::max(nGather, 1) * sizeof(FtGatherRec));
+    H.hJobs = (FtBatchJob *)(tb->h_in + H.oJobs);
+    H.hRecs = (FtDeliverRec *)(tb->h_in + H.oRecs);
+    H.hGather = (FtGatherRec *)(tb->h_in + H.oGather);
+    return H;
+}
+
+int requireIdle(ft_tracked_batch *tb, const char *what) {
+    if (tb->call.kind != 0) {
+        ft_set_error(std::string(what) + ": a submitted search of this batch has not been waited for (ft_tracked_batch_wait)");
+        return FT_ERR_INVALID;
+    }
+    return FT_OK;
+}
+
+// SearchByProjection(CurrentFrame, LastFrame) of every frame, first half.  The point arrays are read IN PLACE by the device when
+// every one of them lies in pinned host memory (one gather launch, no host copy; they must then stay unchanged until the wait
+// returns); otherwise the host threads of the context pack them into the batch's pinned mirror and one copy takes them up.
+int submitLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, const FtPose *poses, const FtPose *trls, bool needTrl, float th,
+                    const int *forward, const int *backward, int check_orientation, int *const *assign, int *n_matches) {
+    int rc = requireIdle(tb, "ft_tracked_batch_search_last_frame");
+    if (rc != FT_OK) return rc;
+    rc = checkBatch(tb, n, "ft_tracked_batch_search_last_frame");
     if (rc != FT_OK) return rc;
     FT_REQUIRE(L && assign, "ft_tracked_batch_search_last_frame: null argument");
     ft_context *ctx = tb->ctx;
     snapshotTuning(tb);
+    bool inPlace = true;
     for (int f = 0; f < n; f++) {
         FT_REQUIRE(!needTrl || trls || tb->DF[f].Nleft == -1, "ft_tracked_batch_search_last_frame_se3: a two-camera frame needs Trl");
         const int M = L[f].N;
@@ -1562,25 +1729,33 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         FT_REQUIRE(M >= 0 && M <= tb->maxPts, "last-frame point count beyond the batch's capacity");
         FT_REQUIRE(M == 0 || (L[f].valid && L[f].world_pos && L[f].descriptors && L[f].observations && L[f].octave && L[f].angle),
                    "last-frame arrays are null");
-        for (int i = 0; i < M; i++)
-            FT_REQUIRE(!L[f].valid[i] || (L[f].octave[i] >= 0 && L[f].octave[i] < tb->DF[f].nlevels), "last-frame octave out of range");
+        const size_t m = (size_t)M;
+        inPlace = inPlace && readableInPlace(ctx, L[f].valid, m) && readableInPlace(ctx, L[f].world_pos, 12 * m) &&
+                  readableInPlace(ctx, L[f].descriptors, 32 * m) && readableInPlace(ctx, L[f].observations, 4 * m) &&
+                  readableInPlace(ctx, L[f].octave, 4 * m) && readableInPlace(ctx, L[f].angle, 4 * m);
     }
+    if (!inPlace)  // the host reads the arrays anyway: octaves checked here (in place: k_last_project_batch checks them, the wait reports)
+        for (int f = 0; f < n; f++)
+            for (int i = 0; i < L[f].N; i++)
+                FT_REQUIRE(!L[f].valid[i] || (L[f].octave[i] >= 0 && L[f].octave[i] < tb->DF[f].nlevels), "last-frame octave out of range");
     rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
-    FtTimer tAll;
+    FtBatchCall &c = tb->call;
+    c = FtBatchCall();
     hipStream_t st = tb->stream;
-    // layout of the call: job records | delivery records | per frame the point arrays
+    // layout of the call in the work region: job records | delivery records | gather records | per frame the point arrays
     Arena a;
-    const size_t oJobs = a.take((size_t)n * sizeof(FtBatchJob));
-    const size_t oRecs = a.take((size_t)(n + 1) * sizeof(FtDeliverRec));
+    const CallHead H = layoutHead(tb, a, n, n + 2, inPlace ? 6 * n : 0);
+    const size_t headEnd = a.off;
     struct Lay {
-        size_t valid, pos, desc, obs, oct, ang, out, proj;
+        size_t valid, pos, desc, obs, oct, ang, proj;
     };
     std::vector<Lay> lay(n);
-    Arena o;  // results in tb->h_out: the flag words, the match counts, every frame's assignments (k_replay_batch writes them there)
-    const size_t oFlagsOut = o.take((size_t)n * FT_BATCH_FLAGS * sizeof(int));
-    const size_t oNmOut = o.take((size_t)n * sizeof(int));
-    int maxPoints = 0, maxK = 8;
+    Arena o;  // results in tb->h_out: flag words, error words, match counts, every frame's assignments (k_replay_batch writes them there)
+    c.oFlagsOut = o.take((size_t)n * FT_BATCH_FLAGS * sizeof(int));
+    c.oErrOut = o.take((size_t)n * sizeof(int));
+    c.oNmOut = o.take((size_t)n * sizeof(int));
+    c.outAssign.resize(n);
     for (int f = 0; f < n; f++) {
         const size_t M = (size_t)std::max(L[f].N, 1);
         lay[f].valid = a.take(M);
@@ -1589,20 +1764,26 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         lay[f].obs = a.take(4 * M);
         lay[f].oct = a.take(4 * M);
         lay[f].ang = a.take(4 * M);
-        lay[f].out = o.take(4 * (size_t)std::max(tb->DF[f].N, 1));
+        c.outAssign[f] = o.take(4 * (size_t)std::max(tb->DF[f].N, 1));
     }
     const size_t inputEnd = a.off;  // what follows is device-only: the projections
     for (int f = 0; f < n; f++) lay[f].proj = a.take(sizeof(FtLastProj) * (size_t)std::max(L[f].N, 1));
     FT_REQUIRE(a.off <= tb->workBytes && o.off <= tb->outBytes, "tracked batch work arena too small");
     uint8_t *pin = tb->h_in, *dev = tb->d_arena + tb->oWork;
-    FtBatchJob *hJobs = (FtBatchJob *)(pin + oJobs);
-    FtDeliverRec *hRecs = (FtDeliverRec *)(pin + oRecs);
     FT_HIP(hipStreamSynchronize(st));  // (the pinned mirror of the previous call)
     const std::function<void(int, int)> stage = [&](int f, int) {
         const ft_last_points &P = L[f];
         const size_t M = (size_t)P.N;
         const int N = tb->DF[f].N;
-        if (M) {
+        if (inPlace) {
+            FtGatherRec *G = H.hGather + 6 * (size_t)f;
+            G[0] = {dev + lay[f].valid, P.valid, (unsigned)M};
+            G[1] = {dev + lay[f].pos, P.world_pos, (unsigned)(12 * M)};
+            G[2] = {dev + lay[f].desc, P.descriptors, (unsigned)(32 * M)};
+            G[3] = {dev + lay[f].obs, P.observations, (unsigned)(4 * M)};
+            G[4] = {dev + lay[f].oct, P.octave, (unsigned)(4 * M)};
+            G[5] = {dev + lay[f].ang, P.angle, (unsigned)(4 * M)};
+        } else if (M) {
             memcpy(pin + lay[f].valid, P.valid, M);
             memcpy(pin + lay[f].pos, P.world_pos, 12 * M);
             memcpy(pin + lay[f].desc, P.descriptors, 32 * M);
@@ -1610,7 +1791,7 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
             memcpy(pin + lay[f].oct, P.octave, 4 * M);
             memcpy(pin + lay[f].ang, P.angle, 4 * M);
         }
-        FtBatchJob &J = hJobs[f];
+        FtBatchJob &J = H.hJobs[f];
         memset(&J, 0, sizeof J);
         J.F = tb->DF[f];
         if (trls) setTrl(J.F, trls[f]);
@@ -1626,109 +1807,319 @@ int batchSearchLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, c
         J.Tcw = poses[f];
         J.forward = forward ? forward[f] : 0;
         J.backward = backward ? backward[f] : 0;
-        J.assignOut = (int *)(tb->h_out + lay[f].out);
-        J.nmOut = (int *)(tb->h_out + oNmOut) + f;
-        FtDeliverRec &R = hRecs[f];  // (the points' results stay on the device: k_replay_batch turns them into assignments there)
-        R.dst = tb->h_out + lay[f].out;
-        R.src[0] = R.src[1] = J.res;
-        R.words = 0;
+        J.assignOut = (int *)(tb->h_out + c.outAssign[f]);
+        J.nmOut = (int *)(tb->h_out + c.oNmOut) + f;
+        memset(&H.hRecs[f], 0, sizeof(FtDeliverRec));  // (the points' results stay on the device: k_replay_batch turns them into assignments there)
     };
-    ctx->pool->parallel_for(n, stage);
+    if (inPlace)
+        for (int f = 0; f < n; f++) stage(f, 0);  // (a few hundred bytes per frame: not worth waking the pool)
+    else
+        ctx->pool->parallel_for(n, stage);
     for (int f = 0; f < n; f++) {
-        maxPoints = std::max(maxPoints, hJobs[f].nPoints);
-        if (hJobs[f].nPoints > 0) maxK = std::max(maxK, hJobs[f].K);
+        c.maxPoints = std::max(c.maxPoints, H.hJobs[f].nPoints);
+        if (H.hJobs[f].nPoints > 0) c.maxK = std::max(c.maxK, H.hJobs[f].K);
     }
-    hRecs[n].dst = tb->h_out + oFlagsOut;
-    hRecs[n].src[0] = hRecs[n].src[1] = tb->d_arena + tb->oFlags;
-    hRecs[n].words = FT_BATCH_FLAGS * n;
-    ctx->addStat("tracked_batch.search_last_frame.stage", tAll.ms());
-    FtTimer tDev;
-    FT_HIP(hipMemcpyAsync(dev, pin, inputEnd, hipMemcpyHostToDevice, st));
-    const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
-    const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
-    int parity = 0, passes = 0;
-    bool resolvedAll = false;
-    const int shInts = replayShared(tb);
-    rc = fixedPointBatch(
-        tb, st, dJobs, n, maxPoints, maxK,
-        [&](int pass, int fCur, int fPrev, int fReset) {
-            const bool lean = pass > 0 && tb->oCache;
-            tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_last_batch(later pass)" : "kernel.search_last_batch(first pass)", st);
-            const bool rows = pass == 0 && rowsUsable(tb);  // (fCur 0, fPrev -1, fReset = half: the kernel's own)
-            int r = rows   ? ft_launch_search_last_first(st, tb->d_arena, dJobs, n, maxPoints, th)
-                    : lean ? ft_launch_search_last_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th)
-                           : ft_launch_search_last_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th);
-            tb->evt.end(ctx->kernelTiming, st);
-            if (r == FT_OK && pass == 0 && tb->oCache) {
-                tb->evt.begin(ctx->kernelTiming, "kernel.cache_partition_batch", st);
-                r = ft_launch_cache_partition_batch(st, tb->d_arena, dJobs, n, maxPoints);
-                tb->evt.end(ctx->kernelTiming, st);
-            }
-            return r;
-        },
-        [&](int par, int) { return ft_launch_deliver_batch(st, dRecs + n, 1, FT_BATCH_FLAGS * n, par); },  // (the flag words)
-        (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLast,
-        (rowsUsable(tb) && resolveWanted(tb, n))
-            ? std::function<int()>([&]() {
-                  tb->evt.begin(ctx->kernelTiming, "kernel.resolve_batch(last frame)", st);
-                  int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 0, 0.f);
-                  tb->evt.end(ctx->kernelTiming, st);
-                  // the writes of the frames it resolved, replayed right behind it (a frame it gave up on waits for the passes)
-                  tb->evt.begin(ctx->kernelTiming, "kernel.replay_batch(last frame)", st);
-                  if (r == FT_OK) r = ft_launch_replay_batch(st, tb->d_arena, dJobs, n, 0, 0, check_orientation, shInts, 1);
-                  tb->evt.end(ctx->kernelTiming, st);
-                  return r;
-              })
-            : std::function<int()>(),
-        &resolvedAll);
-    if (rc != FT_OK) return rc;
-    if (!resolvedAll) {  // the claim passes finished (some of) the frames: their writes now, from the result buffer of the last pass
-        rc = ft_launch_replay_batch(st, tb->d_arena, dJobs, n, 0, parity, check_orientation, shInts, 0);
+    H.hRecs[n] = {tb->h_out + c.oFlagsOut, {tb->d_arena + tb->oFlags, tb->d_arena + tb->oFlags}, FT_BATCH_FLAGS * n};
+    H.hRecs[n + 1] = {tb->h_out + c.oErrOut, {tb->d_arena + tb->oErr, tb->d_arena + tb->oErr}, n};
+    ctx->addStat("tracked_batch.search_last_frame.stage", c.tAll.ms());
+    FT_HIP(hipMemcpyAsync(dev, pin, inPlace ? headEnd : inputEnd, hipMemcpyHostToDevice, st));
+    if (inPlace) {
+        rc = ft_launch_gather_batch(st, (const FtGatherRec *)(dev + H.oGather), 6 * n);
         if (rc != FT_OK) return rc;
-        FT_HIP(hipStreamSynchronize(st));
     }
-    ctx->addStat("tracked_batch.search_last_frame.device", tDev.ms());
+    c.n = n;
+    c.dJobs = (const FtBatchJob *)(dev + H.oJobs);
+    c.dRecs = (const FtDeliverRec *)(dev + H.oRecs);
+    c.th = th;
+    c.checkOrientation = check_orientation;
+    c.useResolve = rowsUsable(tb) && resolveWanted(tb, n);
+    c.shInts = replayShared(tb);
+    c.assign.assign(assign, assign + n);
+    c.nMatches = n_matches;
+    c.kind = 1;
+    rc = callBegin(tb, c, tb->passesLast);
+    if (rc != FT_OK) c.kind = 0;
+    return rc;
+}
+
+// isInFrustum + SearchByProjection(Frame, local map points) of every frame, first half (inputs as submitLastFrame)
+int submitLocalMap(ft_tracked_batch *tb, int n, const ft_frame_pose *poses, const ft_map_points *P, float viewing_cos_limit,
+                   float log_scale_factor, float th, float nn_ratio, int far_points, float th_far_points,
+                   const ft_frustum_result *frustum, int *n_to_match, int *const *assign, int *n_matches) {
+    int rc = requireIdle(tb, "ft_tracked_batch_track_local_map");
+    if (rc != FT_OK) return rc;
+    rc = checkBatch(tb, n, "ft_tracked_batch_track_local_map");
+    if (rc != FT_OK) return rc;
+    snapshotTuning(tb);
+    FT_REQUIRE(poses && P && assign, "ft_tracked_batch_track_local_map: null argument");
+    ft_context *ctx = tb->ctx;
+    bool inPlace = true;
+    for (int f = 0; f < n; f++) {
+        rc = checkMapPoints(&P[f], true);
+        if (rc != FT_OK) return rc;
+        FT_REQUIRE(P[f].M <= tb->maxPts, "map point count beyond the batch's capacity");
+        FT_REQUIRE(assign[f], "ft_tracked_batch_track_local_map: null assign array");
+        const size_t m = (size_t)P[f].M;
+        inPlace = inPlace && readableInPlace(ctx, P[f].skip, m) && readableInPlace(ctx, P[f].world_pos, 12 * m) &&
+                  readableInPlace(ctx, P[f].normal, 12 * m) && readableInPlace(ctx, P[f].max_distance, 4 * m) &&
+                  readableInPlace(ctx, P[f].min_distance, 4 * m) && readableInPlace(ctx, P[f].descriptors, 32 * m) &&
+                  readableInPlace(ctx, P[f].observations, 4 * m);
+    }
+    rc = ft_set_device(ctx);
+    if (rc != FT_OK) return rc;
+    FtBatchCall &c = tb->call;
+    c = FtBatchCall();
+    hipStream_t st = tb->stream;
+    Arena a;
+    const CallHead H = layoutHead(tb, a, n, 2 * n + 3, inPlace ? 7 * n : 0);
+    const size_t headEnd = a.off;
+    struct Lay {
+        size_t fIn0, fOutEnd, desc, obs;
+    };
+    std::vector<Lay> lay(n);
+    c.FL.resize(n);
+    c.fInEnd.resize(n);
+    c.outAssign.resize(n);
+    c.outFr.resize(n);
+    c.M.resize(n);
+    Arena o;
+    c.oFlagsOut = o.take((size_t)n * FT_BATCH_FLAGS * sizeof(int));
+    c.oErrOut = o.take((size_t)n * sizeof(int));
+    c.oCountsOut = o.take((size_t)n * sizeof(int));
+    c.oNmOut = o.take((size_t)n * sizeof(int));
+    // inputs of all frames first (one H2D copy when they are staged), then the frustum outputs (device only)
+    for (int f = 0; f < n; f++) {
+        const size_t M = (size_t)std::max(P[f].M, 1);
+        lay[f].desc = a.take(32 * M);
+        lay[f].obs = a.take(4 * M);
+        c.M[f] = P[f].M;
+    }
+    // (FrustumLayout interleaves a frame's inputs and outputs: a staged copy covers both, the outputs' share is ~40 %)
+    for (int f = 0; f < n; f++) {
+        lay[f].fIn0 = a.off;
+        layoutFrustum(P[f].M, P[f].skip != nullptr, a, c.FL[f], &c.fInEnd[f]);
+        lay[f].fOutEnd = a.off;
+        c.outAssign[f] = o.take(4 * (size_t)std::max(tb->DF[f].N, 1));
+        c.outFr[f] = o.take(lay[f].fOutEnd - c.fInEnd[f]);
+    }
+    FT_REQUIRE(a.off <= tb->workBytes && o.off <= tb->outBytes, "tracked batch work arena too small");
+    uint8_t *pin = tb->h_in, *dev = tb->d_arena + tb->oWork;
+    FT_HIP(hipStreamSynchronize(st));
+    const std::function<void(int, int)> stage = [&](int f, int) {
+        const ft_map_points &Q = P[f];
+        const size_t M = (size_t)Q.M;
+        const int N = tb->DF[f].N;
+        const FrustumLayout &FL = c.FL[f];
+        if (inPlace) {
+            FtGatherRec *G = H.hGather + 7 * (size_t)f;
+            G[0] = {dev + FL.skip, Q.skip, (unsigned)(Q.skip ? M : 0)};
+            G[1] = {dev + FL.pos, Q.world_pos, (unsigned)(12 * M)};
+            G[2] = {dev + FL.nrm, Q.normal, (unsigned)(12 * M)};
+            G[3] = {dev + FL.maxd, Q.max_distance, (unsigned)(4 * M)};
+            G[4] = {dev + FL.mind, Q.min_distance, (unsigned)(4 * M)};
+            G[5] = {dev + lay[f].desc, Q.descriptors, (unsigned)(32 * M)};
+            G[6] = {dev + lay[f].obs, Q.observations, (unsigned)(4 * M)};
+        } else {
+            stageFrustum(&Q, FL, pin);
+            if (M) {
+                memcpy(pin + lay[f].desc, Q.descriptors, 32 * M);
+                memcpy(pin + lay[f].obs, Q.observations, 4 * M);
+            }
+        }
+        FtBatchJob &J = H.hJobs[f];
+        memset(&J, 0, sizeof J);
+        J.F = tb->DF[f];
+        batchClaims(tb, f, N, N > 0 ? (int)M : 0, J);
+        J.obs = (const int *)(dev + lay[f].obs);
+        J.MP = devMapPoints(&Q, FL, dev);
+        J.T = frustumPose_fromDev(J.F, &poses[f]);
+        J.O = devFrustumOut(FL, dev);
+        J.O.count = (int *)(tb->d_arena + tb->oCounts) + f;
+        J.P.M = (int)M;
+        J.P.skip = J.O.searchSkip; J.P.inView = J.O.inView; J.P.inViewR = J.O.inViewR;
+        J.P.level = J.O.level; J.P.levelR = J.O.levelR;
+        J.P.viewCos = J.O.viewCos; J.P.viewCosR = J.O.viewCosR;
+        J.P.projX = J.O.projX; J.P.projY = J.O.projY; J.P.projXR = J.O.projXR; J.P.projYR = J.O.projYR;
+        J.P.desc = dev + lay[f].desc;
+        J.assignOut = (int *)(tb->h_out + c.outAssign[f]);
+        J.nmOut = (int *)(tb->h_out + c.oNmOut) + f;
+        memset(&H.hRecs[f], 0, sizeof(FtDeliverRec));
+        FtDeliverRec &R2 = H.hRecs[n + 3 + f];  // (the frustum fields do not change from burst to burst: delivered with the first one)
+        R2.dst = tb->h_out + c.outFr[f];
+        R2.src[0] = R2.src[1] = dev + c.fInEnd[f];
+        R2.words = M ? (int)((lay[f].fOutEnd - c.fInEnd[f]) / 4) : 0;
+    };
+    if (inPlace)
+        for (int f = 0; f < n; f++) stage(f, 0);
+    else
+        ctx->pool->parallel_for(n, stage);
+    for (int f = 0; f < n; f++) {
+        c.maxPoints = std::max(c.maxPoints, H.hJobs[f].nPoints);
+        c.maxM = std::max(c.maxM, P[f].M);
+        if (H.hJobs[f].nPoints > 0) c.maxK = std::max(c.maxK, H.hJobs[f].K);
+        c.maxFrWords = std::max(c.maxFrWords, H.hRecs[n + 3 + f].words);
+    }
+    H.hRecs[n] = {tb->h_out + c.oFlagsOut, {tb->d_arena + tb->oFlags, tb->d_arena + tb->oFlags}, FT_BATCH_FLAGS * n};
+    H.hRecs[n + 1] = {tb->h_out + c.oErrOut, {tb->d_arena + tb->oErr, tb->d_arena + tb->oErr}, n};
+    H.hRecs[n + 2] = {tb->h_out + c.oCountsOut, {tb->d_arena + tb->oCounts, tb->d_arena + tb->oCounts}, n};
+    ctx->addStat("tracked_batch.track_local_map.stage", c.tAll.ms());
+    FT_HIP(hipMemcpyAsync(dev, pin, inPlace ? headEnd : a.off, hipMemcpyHostToDevice, st));
+    if (inPlace) {
+        rc = ft_launch_gather_batch(st, (const FtGatherRec *)(dev + H.oGather), 7 * n);
+        if (rc != FT_OK) return rc;
+    }
+    c.n = n;
+    c.dJobs = (const FtBatchJob *)(dev + H.oJobs);
+    c.dRecs = (const FtDeliverRec *)(dev + H.oRecs);
+    c.th = th;
+    c.nnRatio = nn_ratio;
+    c.viewingCosLimit = viewing_cos_limit;
+    c.logScaleFactor = log_scale_factor;
+    c.farPoints = far_points;
+    c.thFar = th_far_points;
+    c.useResolve = rowsUsable(tb) && resolveWanted(tb, n);
+    c.shInts = replayShared(tb);
+    c.assign.assign(assign, assign + n);
+    c.nMatches = n_matches;
+    c.nToMatch = n_to_match;
+    c.haveFrustum = frustum != nullptr;
+    if (frustum) c.frustum.assign(frustum, frustum + n);
+    c.kind = 2;
+    rc = callBegin(tb, c, tb->passesLocal);
+    if (rc != FT_OK) c.kind = 0;
+    return rc;
+}
+
+// the second half of either search: waits for the device, runs the claim passes the resolution left (none as a rule), hands the
+// results to the caller's arrays
+int waitCall(ft_tracked_batch *tb) {
+    FtBatchCall &c = tb->call;
+    if (c.kind == 0) return FT_OK;
+    ft_context *ctx = tb->ctx;
+    int rc = ft_set_device(ctx);
+    const int kind = c.kind, n = c.n;
+    const char *name = kind == 1 ? "search_last_frame" : "track_local_map";
+    if (rc != FT_OK) {
+        c.kind = 0;
+        return rc;
+    }
+    FtTimer tDev;
+    int passes = 0;
+    rc = callFinish(tb, c, &passes);
+    c.kind = 0;  // (whatever happened, the batch is free for the next call)
+    if (rc != FT_OK) return rc;
+    ctx->addStat((std::string("tracked_batch.") + name + ".device").c_str(), tDev.ms());
     tb->evt.resolve(ctx);
+    (kind == 1 ? tb->passesLast : tb->passesLocal) = passes;
     FtTimer tRep;
-    // what is left for the host: the assignments out of the pinned result buffer into the caller's arrays
-    const int *hNm = (const int *)(tb->h_out + oNmOut);
+    const int *hErr = (const int *)(tb->h_out + c.oErrOut);
+    for (int f = 0; f < n; f++)
+        if (hErr[f] & FT_JOB_ERR_OCTAVE) {
+            ft_set_error("last-frame octave out of range");
+            return FT_ERR_INVALID;
+        }
+    // what is left for the host: the assignments (and frustum fields) out of the pinned result buffer into the caller's arrays
+    const int *hNm = (const int *)(tb->h_out + c.oNmOut), *hCounts = (const int *)(tb->h_out + c.oCountsOut);
     const std::function<void(int, int)> finish = [&](int f, int) {
         const int N = tb->DF[f].N;
-        if (N > 0) memcpy(assign[f], tb->h_out + lay[f].out, sizeof(int) * (size_t)N);
-        if (n_matches) n_matches[f] = hNm[f];
+        if (N > 0) memcpy(c.assign[f], tb->h_out + c.outAssign[f], sizeof(int) * (size_t)N);
+        if (c.nMatches) c.nMatches[f] = hNm[f];
+        if (kind == 2) {
+            const int M = c.M[f];
+            // unpackFrustum reads the count through the layout; the batch keeps the counts of all frames in one block
+            if (M > 0) unpackFrustum(M, c.FL[f], c.fInEnd[f], tb->h_out + c.outFr[f], c.haveFrustum ? &c.frustum[f] : nullptr, nullptr);
+            if (c.nToMatch) c.nToMatch[f] = M > 0 ? hCounts[f] : 0;
+        }
     };
-    ctx->pool->parallel_for(n, finish);
-    ctx->addStat("tracked_batch.search_last_frame.replay", tRep.ms());
-    ctx->addStat("tracked_batch.search_last_frame.total", tAll.ms());
-    ctx->addStat("tracked_batch.search_last_frame.passes", passes);
-    ctx->addStat("tracked_batch.search_last_frame.frames", n);
+    if (n <= 8) for (int f = 0; f < n; f++) finish(f, 0);
+    else ctx->pool->parallel_for(n, finish);
+    ctx->addStat((std::string("tracked_batch.") + name + ".replay").c_str(), tRep.ms());
+    ctx->addStat((std::string("tracked_batch.") + name + ".total").c_str(), c.tAll.ms());
+    ctx->addStat((std::string("tracked_batch.") + name + ".passes").c_str(), passes);
+    ctx->addStat((std::string("tracked_batch.") + name + ".frames").c_str(), n);
+    return FT_OK;
+}
+
+int posesOfMatrices(const float *Tcw, int n, std::vector<FtPose> &poses) {
+    poses.resize(n);
+    for (int f = 0; f < n; f++) poses[f] = poseOfMatrix(Tcw + 12 * (size_t)f);
+    return FT_OK;
+}
+int posesOfSe3(const ft_se3 *Tcw, const ft_se3 *Trl, int n, std::vector<FtPose> &poses, std::vector<FtPose> &trls) {
+    poses.resize(n);
+    trls.resize(n);
+    for (int f = 0; f < n; f++) {  // (the batch's own state - frame count, camera counts - is checked under its lock)
+        int rc = poseOfSe3(&Tcw[f], poses[f]);
+        if (rc == FT_OK && Trl) rc = poseOfSe3(&Trl[f], trls[f]);
+        if (rc != FT_OK) return rc;
+    }
     return FT_OK;
 }
 }  // namespace
 
 extern "C" {
 
+int ft_tracked_batch_submit_search_last_frame(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const float *Tcw, float th,
+                                              const int *forward, const int *backward, int check_orientation, int *const *assign,
+                                              int *n_matches) {
+    FT_REQUIRE(tb && Tcw && n_frames > 0, "ft_tracked_batch_search_last_frame: null batch or pose");
+    std::vector<FtPose> poses;
+    posesOfMatrices(Tcw, n_frames, poses);
+    std::lock_guard<std::mutex> lk(tb->mu);  // (before anything of the batch is read: upload / bind_fisheye reassign it)
+    return submitLastFrame(tb, n_frames, L, poses.data(), nullptr, false, th, forward, backward, check_orientation, assign, n_matches);
+}
+
+int ft_tracked_batch_submit_search_last_frame_se3(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const ft_se3 *Tcw,
+                                                  const ft_se3 *Trl, float th, const int *forward, const int *backward,
+                                                  int check_orientation, int *const *assign, int *n_matches) {
+    FT_REQUIRE(tb && Tcw && n_frames > 0, "ft_tracked_batch_search_last_frame_se3: bad argument");
+    std::vector<FtPose> poses, trls;
+    int rc = posesOfSe3(Tcw, Trl, n_frames, poses, trls);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(tb->mu);
+    return submitLastFrame(tb, n_frames, L, poses.data(), Trl ? trls.data() : nullptr, true, th, forward, backward, check_orientation, assign,
+                           n_matches);
+}
+
+int ft_tracked_batch_submit_track_local_map(ft_tracked_batch *tb, int n_frames, const ft_frame_pose *poses, const ft_map_points *P,
+                                            float viewing_cos_limit, float log_scale_factor, float th, float nn_ratio, int far_points,
+                                            float th_far_points, const ft_frustum_result *frustum, int *n_to_match, int *const *assign,
+                                            int *n_matches) {
+    FT_REQUIRE(tb, "ft_tracked_batch_track_local_map: null batch");
+    std::lock_guard<std::mutex> lk(tb->mu);
+    return submitLocalMap(tb, n_frames, poses, P, viewing_cos_limit, log_scale_factor, th, nn_ratio, far_points, th_far_points, frustum,
+                          n_to_match, assign, n_matches);
+}
+
+int ft_tracked_batch_wait(ft_tracked_batch *tb) {
+    FT_REQUIRE(tb, "ft_tracked_batch_wait: null batch");
+    std::lock_guard<std::mutex> lk(tb->mu);
+    return waitCall(tb);
+}
+
+// the blocking forms: submit + wait
 int ft_tracked_batch_search_last_frame(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const float *Tcw, float th,
                                        const int *forward, const int *backward, int check_orientation, int *const *assign,
                                        int *n_matches) {
-    FT_REQUIRE(Tcw && n_frames > 0, "ft_tracked_batch_search_last_frame: null pose");
-    std::vector<FtPose> poses(n_frames);
-    for (int f = 0; f < n_frames; f++) poses[f] = poseOfMatrix(Tcw + 12 * (size_t)f);
-    return batchSearchLastFrame(tb, n_frames, L, poses.data(), nullptr, false, th, forward, backward, check_orientation, assign, n_matches);
+    FT_REQUIRE(tb && Tcw && n_frames > 0, "ft_tracked_batch_search_last_frame: null batch or pose");
+    std::vector<FtPose> poses;
+    posesOfMatrices(Tcw, n_frames, poses);
+    std::lock_guard<std::mutex> lk(tb->mu);
+    int rc = submitLastFrame(tb, n_frames, L, poses.data(), nullptr, false, th, forward, backward, check_orientation, assign, n_matches);
+    return rc == FT_OK ? waitCall(tb) : rc;
 }
 
 int ft_tracked_batch_search_last_frame_se3(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const ft_se3 *Tcw,
                                            const ft_se3 *Trl, float th, const int *forward, const int *backward,
                                            int check_orientation, int *const *assign, int *n_matches) {
     FT_REQUIRE(tb && Tcw && n_frames > 0, "ft_tracked_batch_search_last_frame_se3: bad argument");
-    std::vector<FtPose> poses(n_frames), trls(n_frames);
-    for (int f = 0; f < n_frames; f++) {  // (the batch's own state - frame count, camera counts - is checked under its lock)
-        int rc = poseOfSe3(&Tcw[f], poses[f]);
-        if (rc == FT_OK && Trl) rc = poseOfSe3(&Trl[f], trls[f]);
-        if (rc != FT_OK) return rc;
-    }
-    return batchSearchLastFrame(tb, n_frames, L, poses.data(), Trl ? trls.data() : nullptr, true, th, forward, backward, check_orientation,
-                                assign, n_matches);
+    std::vector<FtPose> poses, trls;
+    int rc = posesOfSe3(Tcw, Trl, n_frames, poses, trls);
+    if (rc != FT_OK) return rc;
+    std::lock_guard<std::mutex> lk(tb->mu);
+    rc = submitLastFrame(tb, n_frames, L, poses.data(), Trl ? trls.data() : nullptr, true, th, forward, backward, check_orientation, assign,
+                         n_matches);
+    return rc == FT_OK ? waitCall(tb) : rc;
 }
 
 int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const ft_frame_pose *poses, const ft_map_points *P,
@@ -1737,187 +2128,9 @@ int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, const f
                                      int *n_matches) {
     FT_REQUIRE(tb, "ft_tracked_batch_track_local_map: null batch");
     std::lock_guard<std::mutex> lk(tb->mu);
-    int rc = checkBatch(tb, n_frames, "ft_tracked_batch_track_local_map");
-    if (rc != FT_OK) return rc;
-    snapshotTuning(tb);
-    FT_REQUIRE(poses && P && assign, "ft_tracked_batch_track_local_map: null argument");
-    const int n = n_frames;
-    for (int f = 0; f < n; f++) {
-        rc = checkMapPoints(&P[f], true);
-        if (rc != FT_OK) return rc;
-        FT_REQUIRE(P[f].M <= tb->maxPts, "map point count beyond the batch's capacity");
-        FT_REQUIRE(assign[f], "ft_tracked_batch_track_local_map: null assign array");
-    }
-    ft_context *ctx = tb->ctx;
-    rc = ft_set_device(ctx);
-    if (rc != FT_OK) return rc;
-    FtTimer tAll;
-    hipStream_t st = tb->stream;
-    Arena a;
-    const size_t oJobs = a.take((size_t)n * sizeof(FtBatchJob));
-    const size_t oRecs = a.take((size_t)(2 * n + 2) * sizeof(FtDeliverRec));
-    struct Lay {
-        FrustumLayout FL;
-        size_t fIn0, fInEnd, fOutEnd, desc, obs, outRes, outFr;
-    };
-    std::vector<Lay> lay(n);
-    Arena o;
-    const size_t oFlagsOut = o.take((size_t)n * FT_BATCH_FLAGS * sizeof(int));
-    const size_t oCountsOut = o.take((size_t)n * sizeof(int));
-    const size_t oNmOut = o.take((size_t)n * sizeof(int));
-    // inputs of all frames first (one H2D copy), then the frustum outputs (device only)
-    for (int f = 0; f < n; f++) {
-        const size_t M = (size_t)std::max(P[f].M, 1);
-        lay[f].desc = a.take(32 * M);
-        lay[f].obs = a.take(4 * M);
-    }
-    // (FrustumLayout interleaves a frame's inputs and outputs: the copy covers both, the outputs' share is ~40 %)
-    for (int f = 0; f < n; f++) {
-        lay[f].fIn0 = a.off;
-        layoutFrustum(P[f].M, P[f].skip != nullptr, a, lay[f].FL, &lay[f].fInEnd);
-        lay[f].fOutEnd = a.off;
-        lay[f].outRes = o.take(4 * (size_t)std::max(tb->DF[f].N, 1));  // the frame's assignments (k_replay_batch)
-        lay[f].outFr = o.take(lay[f].fOutEnd - lay[f].fInEnd);
-    }
-    FT_REQUIRE(a.off <= tb->workBytes && o.off <= tb->outBytes, "tracked batch work arena too small");
-    uint8_t *pin = tb->h_in, *dev = tb->d_arena + tb->oWork;
-    FtBatchJob *hJobs = (FtBatchJob *)(pin + oJobs);
-    FtDeliverRec *hRecs = (FtDeliverRec *)(pin + oRecs);
-    FT_HIP(hipStreamSynchronize(st));
-    const std::function<void(int, int)> stage = [&](int f, int) {
-        const ft_map_points &Q = P[f];
-        const size_t M = (size_t)Q.M;
-        const int N = tb->DF[f].N;
-        stageFrustum(&Q, lay[f].FL, pin);
-        if (M) {
-            memcpy(pin + lay[f].desc, Q.descriptors, 32 * M);
-            memcpy(pin + lay[f].obs, Q.observations, 4 * M);
-        }
-        FtBatchJob &J = hJobs[f];
-        memset(&J, 0, sizeof J);
-        J.F = tb->DF[f];
-        batchClaims(tb, f, N, N > 0 ? (int)M : 0, J);
-        J.obs = (const int *)(dev + lay[f].obs);
-        J.MP = devMapPoints(&Q, lay[f].FL, dev);
-        J.T = frustumPose_fromDev(J.F, &poses[f]);
-        J.O = devFrustumOut(lay[f].FL, dev);
-        J.O.count = (int *)(tb->d_arena + tb->oCounts) + f;
-        J.P.M = (int)M;
-        J.P.skip = J.O.searchSkip; J.P.inView = J.O.inView; J.P.inViewR = J.O.inViewR;
-        J.P.level = J.O.level; J.P.levelR = J.O.levelR;
-        J.P.viewCos = J.O.viewCos; J.P.viewCosR = J.O.viewCosR;
-        J.P.projX = J.O.projX; J.P.projY = J.O.projY; J.P.projXR = J.O.projXR; J.P.projYR = J.O.projYR;
-        J.P.desc = dev + lay[f].desc;
-        J.assignOut = (int *)(tb->h_out + lay[f].outRes);
-        J.nmOut = (int *)(tb->h_out + oNmOut) + f;
-        FtDeliverRec &R = hRecs[f];  // (the points' results stay on the device: k_replay_batch turns them into assignments there)
-        R.dst = tb->h_out + lay[f].outRes;
-        R.src[0] = R.src[1] = J.res;
-        R.words = 0;
-        FtDeliverRec &R2 = hRecs[n + 2 + f];  // (the frustum fields do not change from burst to burst: delivered with the first one)
-        R2.dst = tb->h_out + lay[f].outFr;
-        R2.src[0] = R2.src[1] = dev + lay[f].fInEnd;
-        R2.words = M ? (int)((lay[f].fOutEnd - lay[f].fInEnd) / 4) : 0;
-    };
-    ctx->pool->parallel_for(n, stage);
-    int maxPoints = 0, maxM = 0, maxK = 8, maxFrWords = 0;
-    for (int f = 0; f < n; f++) {
-        maxPoints = std::max(maxPoints, hJobs[f].nPoints);
-        maxM = std::max(maxM, P[f].M);
-        if (hJobs[f].nPoints > 0) maxK = std::max(maxK, hJobs[f].K);
-        maxFrWords = std::max(maxFrWords, hRecs[n + 2 + f].words);
-    }
-    hRecs[n].dst = tb->h_out + oFlagsOut;
-    hRecs[n].src[0] = hRecs[n].src[1] = tb->d_arena + tb->oFlags;
-    hRecs[n].words = FT_BATCH_FLAGS * n;
-    hRecs[n + 1].dst = tb->h_out + oCountsOut;
-    hRecs[n + 1].src[0] = hRecs[n + 1].src[1] = tb->d_arena + tb->oCounts;
-    hRecs[n + 1].words = n;
-    ctx->addStat("tracked_batch.track_local_map.stage", tAll.ms());
-    FtTimer tDev;
-    FT_HIP(hipMemcpyAsync(dev, pin, a.off, hipMemcpyHostToDevice, st));
-    const FtBatchJob *dJobs = (const FtBatchJob *)(dev + oJobs);
-    const FtDeliverRec *dRecs = (const FtDeliverRec *)(dev + oRecs);
-    int parity = 0, passes = 0;
-    bool frustumDone = false, resolvedAll = false;
-    const int shInts = replayShared(tb);
-    rc = fixedPointBatch(
-        tb, st, dJobs, n, maxPoints, maxK,
-        [&](int pass, int fCur, int fPrev, int fReset) {
-            if (!frustumDone) {  // behind the fill of the claim iteration (which zeroes the counts), in front of the first pass
-                frustumDone = true;
-                tb->evt.begin(ctx->kernelTiming, "kernel.frustum_batch", st);
-                const int r = ft_launch_frustum_batch(st, tb->d_arena, dJobs, n, maxM, viewing_cos_limit, log_scale_factor, far_points,
-                                                      th_far_points);
-                tb->evt.end(ctx->kernelTiming, st);
-                if (r != FT_OK) return r;
-            }
-            const bool lean = pass > 0 && tb->oCache;
-            tb->evt.begin(ctx->kernelTiming, lean ? "kernel.search_local_batch(later pass)" : "kernel.search_local_batch(first pass)", st);
-            const bool rows = pass == 0 && rowsUsable(tb);
-            int r = rows   ? ft_launch_search_local_first(st, tb->d_arena, dJobs, n, maxPoints, th, nn_ratio)
-                    : lean ? ft_launch_search_local_batch_lean(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio)
-                           : ft_launch_search_local_batch(st, tb->d_arena, dJobs, n, maxPoints, pass, fCur, fPrev, fReset, th, nn_ratio);
-            tb->evt.end(ctx->kernelTiming, st);
-            if (r == FT_OK && pass == 0 && tb->oCache) {
-                tb->evt.begin(ctx->kernelTiming, "kernel.cache_partition_batch", st);
-                r = ft_launch_cache_partition_batch(st, tb->d_arena, dJobs, n, maxPoints);
-                tb->evt.end(ctx->kernelTiming, st);
-            }
-            return r;
-        },
-        [&](int par, int burst) {
-            if (!frustumDone) {  // no frame has keypoints: the frustum fields are still the call's result
-                frustumDone = true;
-                const int r = ft_launch_frustum_batch(st, tb->d_arena, dJobs, n, maxM, viewing_cos_limit, log_scale_factor, far_points,
-                                                      th_far_points);
-                if (r != FT_OK) return r;
-            }
-            // the flag words and the counts; with the first burst the frustum fields (records n .. 2 n + 1)
-            return ft_launch_deliver_batch(st, dRecs + n, burst == 0 ? n + 2 : 2, std::max(burst == 0 ? maxFrWords : 0, FT_BATCH_FLAGS * n), par);
-        },
-        (const int *)(tb->h_out + oFlagsOut), &parity, &passes, &tb->passesLocal,
-        (rowsUsable(tb) && resolveWanted(tb, n))
-            ? std::function<int()>([&]() {
-                  tb->evt.begin(ctx->kernelTiming, "kernel.resolve_batch(local map)", st);
-                  int r = ft_launch_resolve_batch(st, tb->d_arena, dJobs, n, 1, nn_ratio);
-                  tb->evt.end(ctx->kernelTiming, st);
-                  tb->evt.begin(ctx->kernelTiming, "kernel.replay_batch(local map)", st);
-                  if (r == FT_OK) r = ft_launch_replay_batch(st, tb->d_arena, dJobs, n, 1, 0, 0, shInts, 1);
-                  tb->evt.end(ctx->kernelTiming, st);
-                  return r;
-              })
-            : std::function<int()>(),
-        &resolvedAll);
-    if (rc != FT_OK) return rc;
-    if (!resolvedAll) {
-        rc = ft_launch_replay_batch(st, tb->d_arena, dJobs, n, 1, parity, 0, shInts, 0);
-        if (rc != FT_OK) return rc;
-        FT_HIP(hipStreamSynchronize(st));
-    }
-    ctx->addStat("tracked_batch.track_local_map.device", tDev.ms());
-    tb->evt.resolve(ctx);
-    FtTimer tRep;
-    const int *hCounts = (const int *)(tb->h_out + oCountsOut), *hNm = (const int *)(tb->h_out + oNmOut);
-    const std::function<void(int, int)> replay = [&](int f, int) {
-        const int M = P[f].M;
-        int nToMatch = 0;
-        if (M > 0) {
-            // unpackFrustum reads the count through the layout; the batch keeps the counts of all frames in one block
-            unpackFrustum(M, lay[f].FL, lay[f].fInEnd, tb->h_out + lay[f].outFr, frustum ? &frustum[f] : nullptr, nullptr);
-            nToMatch = hCounts[f];
-        }
-        if (n_to_match) n_to_match[f] = nToMatch;
-        const int N = tb->DF[f].N;
-        if (N > 0) memcpy(assign[f], tb->h_out + lay[f].outRes, sizeof(int) * (size_t)N);
-        if (n_matches) n_matches[f] = hNm[f];
-    };
-    ctx->pool->parallel_for(n, replay);
-    ctx->addStat("tracked_batch.track_local_map.replay", tRep.ms());
-    ctx->addStat("tracked_batch.track_local_map.total", tAll.ms());
-    ctx->addStat("tracked_batch.track_local_map.passes", passes);
-    ctx->addStat("tracked_batch.track_local_map.frames", n);
-    return FT_OK;
+    int rc = submitLocalMap(tb, n_frames, poses, P, viewing_cos_limit, log_scale_factor, th, nn_ratio, far_points, th_far_points, frustum,
+                            n_to_match, assign, n_matches);
+    return rc == FT_OK ? waitCall(tb) : rc;
 }
 
 }  // extern "C"
@@ -1951,6 +2164,7 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     int rc = ft_set_device(ctx);
     if (rc != FT_OK) return rc;
     std::lock_guard<std::mutex> lk(tb->mu);
+    FT_REQUIRE(tb->call.kind == 0, "ft_tracked_batch_bind_fisheye: a submitted search of this batch has not been waited for (ft_tracked_batch_wait)");
     FtTimer tAll;
     hipStream_t st = tb->stream;
     bool wantGrid;

@@ -593,7 +593,7 @@ def make_pose(Rcw, tcw, tlr=(0, 0, 0)):
     return T
 
 
-def _map_points(pts: dict, keep: dict):
+def _map_points(pts: dict, keep: dict, ctx=None):
     M = len(pts["world_pos"])
     P = _capi.MapPoints()
     P.M = M
@@ -601,7 +601,7 @@ def _map_points(pts: dict, keep: dict):
     def arr(k, dt):
         if pts.get(k) is None:
             return None
-        keep[k] = np.ascontiguousarray(pts[k], dt)
+        keep[k] = _pinned_copy(ctx, pts[k], dt)
         return ptr(keep[k])
     P.skip = arr("skip", np.uint8)
     P.world_pos, P.normal = arr("world_pos", np.float32), arr("normal", np.float32)
@@ -778,13 +778,14 @@ class TrackedBatch:
         return out[:self.N[f]]
 
     @staticmethod
-    def prepare_last(lasts, Tcws, forward=None, backward=None):
-        """lasts: list of dicts (TrackedFrame.search_last_frame's), Tcws: list of 3x4 matrices, or of SE3 (then Trl = list of SE3 or None)"""
+    def prepare_last(lasts, Tcws, forward=None, backward=None, ctx=None):
+        """lasts: list of dicts (TrackedFrame.search_last_frame's), Tcws: list of 3x4 matrices, or of SE3 (then Trl = list of SE3 or None).
+        ctx: the point arrays are copied into pinned host memory of that context (ft_host_malloc) - the device reads them in place"""
         n = len(lasts)
         keep = []
         arr = (_capi.LastPoints * n)()
         for f, last in enumerate(lasts):
-            k = {key: np.ascontiguousarray(last[key], dt) for key, dt in
+            k = {key: _pinned_copy(ctx, last[key], dt) for key, dt in
                  (("valid", np.uint8), ("world_pos", np.float32), ("descriptors", np.uint8), ("observations", np.int32),
                   ("octave", np.int32), ("angle", np.float32))}
             keep.append(k)
@@ -800,29 +801,46 @@ class TrackedBatch:
         bw = None if backward is None else np.ascontiguousarray(backward, np.int32)
         return dict(n=n, arr=arr, keep=keep, T=T, se3=se3, fw=fw, bw=bw)
 
-    def search_last_frame(self, lasts, Tcws=None, th=7.0, forward=None, backward=None, check_orientation=True, Trl=None, copy=True):
-        pl = lasts if isinstance(lasts, dict) and "arr" in lasts else self.prepare_last(lasts, Tcws, forward, backward)
+    def search_last_frame(self, lasts, Tcws=None, th=7.0, forward=None, backward=None, check_orientation=True, Trl=None, copy=True,
+                          submit=False):
+        """submit=True: ft_tracked_batch_submit_search_last_frame - returns at once, wait() delivers the results"""
+        pl = lasts if isinstance(lasts, dict) and "arr" in lasts else self.prepare_last(lasts, Tcws, forward, backward, ctx=getattr(self, "_pin_ctx", None))
         n = pl["n"]
+        L = lib()
         if pl["se3"]:
             trl = None if Trl is None else (_capi.SE3 * n)(*[t.c for t in Trl])
-            check(lib().ft_tracked_batch_search_last_frame_se3(self._h, n, pl["arr"], pl["T"], trl, th, ptr(pl["fw"]), ptr(pl["bw"]),
-                                                               int(check_orientation), self._assign_ptrs, ptr(self._nm)))
+            fn = L.ft_tracked_batch_submit_search_last_frame_se3 if submit else L.ft_tracked_batch_search_last_frame_se3
+            check(fn(self._h, n, pl["arr"], pl["T"], trl, th, ptr(pl["fw"]), ptr(pl["bw"]), int(check_orientation), self._assign_ptrs, ptr(self._nm)))
         else:
-            check(lib().ft_tracked_batch_search_last_frame(self._h, n, pl["arr"], ptr(pl["T"]), th, ptr(pl["fw"]), ptr(pl["bw"]),
-                                                           int(check_orientation), self._assign_ptrs, ptr(self._nm)))
-        if not copy:
+            fn = L.ft_tracked_batch_submit_search_last_frame if submit else L.ft_tracked_batch_search_last_frame
+            check(fn(self._h, n, pl["arr"], ptr(pl["T"]), th, ptr(pl["fw"]), ptr(pl["bw"]), int(check_orientation), self._assign_ptrs, ptr(self._nm)))
+        self._pending = (pl, "last")   # (the arrays of a submitted call stay referenced until the wait)
+        if submit or not copy:
             return None
+        return self._results_last(n)
+
+    def _results_last(self, n):
         return [dict(assign=self._assign[f][:self.N[f]].copy(), n=int(self._nm[f])) for f in range(n)]
 
+    def wait(self, copy=True):
+        """ft_tracked_batch_wait: the results of the submitted search (as the blocking call returns them), or None"""
+        check(lib().ft_tracked_batch_wait(self._h))
+        pend, self._pending = getattr(self, "_pending", None), None
+        if pend is None or not copy:
+            return None
+        pl, kind = pend
+        return self._results_last(pl["n"]) if kind == "last" else self._results_local(pl)
+
     @staticmethod
-    def prepare_local(poses, pts_list, want_frustum=True):
+    def prepare_local(poses, pts_list, want_frustum=True, ctx=None):
+        """ctx: the point arrays are copied into pinned host memory of that context - the device reads them in place"""
         n = len(pts_list)
         keep, outs = [], []
         P = (_capi.MapPoints * n)()
         R = (_capi.FrustumResult * n)() if want_frustum else None
         for f, pts in enumerate(pts_list):
             k = {}
-            Pf, M = _map_points(pts, k)
+            Pf, M = _map_points(pts, k, ctx)
             keep.append(k)
             P[f] = Pf
             if want_frustum:
@@ -833,14 +851,19 @@ class TrackedBatch:
         return dict(n=n, P=P, R=R, T=T, keep=keep, outs=outs)
 
     def track_local_map(self, poses, pts_list=None, viewing_cos_limit=0.5, log_scale_factor=0.0, th=1.0, nn_ratio=0.8, far_points=False,
-                        th_far_points=0.0, copy=True):
-        pl = poses if isinstance(poses, dict) and "P" in poses else self.prepare_local(poses, pts_list)
+                        th_far_points=0.0, copy=True, submit=False):
+        pl = poses if isinstance(poses, dict) and "P" in poses else self.prepare_local(poses, pts_list, ctx=getattr(self, "_pin_ctx", None))
         n = pl["n"]
-        check(lib().ft_tracked_batch_track_local_map(self._h, n, pl["T"], pl["P"], viewing_cos_limit, log_scale_factor, th, nn_ratio,
-                                                     int(far_points), th_far_points, pl["R"], ptr(self._nt), self._assign_ptrs,
-                                                     ptr(self._nm)))
-        if not copy:
+        fn = lib().ft_tracked_batch_submit_track_local_map if submit else lib().ft_tracked_batch_track_local_map
+        check(fn(self._h, n, pl["T"], pl["P"], viewing_cos_limit, log_scale_factor, th, nn_ratio, int(far_points), th_far_points, pl["R"],
+                 ptr(self._nt), self._assign_ptrs, ptr(self._nm)))
+        self._pending = (pl, "local")
+        if submit or not copy:
             return None
+        return self._results_local(pl)
+
+    def _results_local(self, pl):
+        n = pl["n"]
         res = []
         for f in range(n):
             r = {}
@@ -850,6 +873,18 @@ class TrackedBatch:
             r.update(assign=self._assign[f][:self.N[f]].copy(), n=int(self._nm[f]), n_to_match=int(self._nt[f]))
             res.append(r)
         return res
+
+
+def _pinned_copy(ctx, a, dtype):
+    """a contiguous copy of `a`: in pinned host memory of ctx (Context.pinned_array) when ctx is given"""
+    a = np.ascontiguousarray(a, dtype)
+    if ctx is None:
+        return a
+    p = ctx.pinned_array(a.shape if a.size else (1,), a.dtype)
+    if a.size:
+        p[...] = a
+        return p
+    return p[:0]
 
 
 def make_fisheye_rig(cam1, cam2, Rlr, tlr, precision=1e-6):

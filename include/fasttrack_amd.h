@@ -479,7 +479,13 @@ FT_API int ft_tracked_frame_holder_obs(ft_tracked_frame *tf, int *holder_obs);
  * Arrays indexed by frame: frames[], L[], Tcw (12 floats per frame), forward / backward (NULL = all 0), poses[], P[],
  * frustum[] (NULL = not wanted), n_to_match[], assign[] (assign[f] has frames[f].N entries), n_matches[].
  * A batch object has a stream and a lock of its own: calls on one batch are serialised, two batches of one context used from
- * two host threads are two batches in flight - the passes of one run beside the host side (staging, replay) of the other.
+ * two host threads are two batches in flight.
+ * The host's share of a search: the writes of a search (mvpMapPoints[kp] = pMP in point order, the rotation histogram and
+ * ComputeThreeMaxima of SearchByProjection(CurrentFrame, LastFrame), src/ORBmatcher.cc:1880-1896, 1966-1987, 2210-2251) are
+ * replayed ON THE DEVICE, the frames' holder_obs live in HBM, and the assignments come back through pinned memory - the host
+ * builds the job records, enqueues, and copies the assignments into the caller's arrays.  Point arrays (ft_last_points /
+ * ft_map_points) that ALL lie in pinned host memory (ft_host_malloc, hipHostMalloc, hipHostRegister) are read in place by the
+ * device - no host copy; pageable ones are packed into the batch's pinned staging by the context's host threads first.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ft_tracked_batch ft_tracked_batch;
 FT_API int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, int max_points, ft_tracked_batch **out);
@@ -494,8 +500,9 @@ FT_API int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_
  * launchFisheyeStereoMatchKernel, include/Kernels/KernelController.h:38) and, when `rig` is given, KannalaBrandt8::
  * TriangulateMatches on every surviving pair (depth > 0.0001 keeps it; level_sigma2 = mvLevelSigma2, nlevels floats) - fills
  * mvLeftToRightMatch / mvRightToLeftMatch; the grids are built.  rig == NULL: the matching alone (every ratio-test survivor stays).
- * meta[f]: the frame constants, N / Nleft (= the counts ft_extract_batch returned), keys / keys_right = the host copies it
- * returned (angles for the rotation histogram), holder_obs or NULL (all -1); its descriptors / match tables are not read.
+ * meta[f]: the frame constants, N / Nleft (= the counts ft_extract_batch returned), holder_obs or NULL (all -1); its keys /
+ * keys_right / descriptors / match tables are not read (the angles of the rotation histogram are read on the device).
+ * exL / exR must not be used by another thread during the call; their next batch is ordered behind this call's reads of their slots.
  * Outputs, each an array of n_frames pointers or NULL: left_to_right[f] / right_to_left[f] (the match tables; both or neither),
  * depth[f] / p3d[f] (mvDepth [Nleft], mvStereo3Dpoints [3 Nleft]; with a rig only), n_stereo[f] (the frame's nMatches).  Without
  * outputs the call does not wait for the device. */
@@ -517,7 +524,29 @@ FT_API int ft_tracked_batch_track_local_map(ft_tracked_batch *tb, int n_frames, 
                                             float nn_ratio, int far_points, float th_far_points,
                                             const ft_frustum_result *frustum, int *n_to_match, int *const *assign,
                                             int *n_matches);
-/* current holder_obs of frame `frame` (its N entries) */
+/* The two halves of the three searches above, like ft_stereo_frontend_submit / _wait: submit_* enqueues the search (the claim
+ * iteration up to the first point where the host has to look at the device's flag words - the whole search when the one-launch
+ * resolution resolves every frame, the usual case) and returns; ft_tracked_batch_wait waits for the device, runs what is left
+ * (claim passes for frames the resolution gave up on, small batches), and fills assign / n_matches / n_to_match / frustum.  One
+ * search per batch may be in flight: a second submit (or upload / bind_fisheye) before the wait is FT_ERR_INVALID.  Between
+ * submit and wait the OUTPUT arrays must stay untouched and point arrays in pinned memory (read in place, see above) must
+ * stay valid and UNCHANGED; everything else of the arguments is copied before submit returns.  An input error only the device
+ * sees when it reads the arrays in place (a last-frame octave outside the frame's levels) is reported by the wait.
+ * ft_tracked_batch_wait without a submitted search returns FT_OK. */
+FT_API int ft_tracked_batch_submit_search_last_frame(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const float *Tcw,
+                                                     float th, const int *forward, const int *backward, int check_orientation,
+                                                     int *const *assign, int *n_matches);
+FT_API int ft_tracked_batch_submit_search_last_frame_se3(ft_tracked_batch *tb, int n_frames, const ft_last_points *L,
+                                                         const ft_se3 *Tcw, const ft_se3 *Trl, float th, const int *forward,
+                                                         const int *backward, int check_orientation, int *const *assign,
+                                                         int *n_matches);
+FT_API int ft_tracked_batch_submit_track_local_map(ft_tracked_batch *tb, int n_frames, const ft_frame_pose *poses,
+                                                   const ft_map_points *P, float viewing_cos_limit, float log_scale_factor,
+                                                   float th, float nn_ratio, int far_points, float th_far_points,
+                                                   const ft_frustum_result *frustum, int *n_to_match, int *const *assign,
+                                                   int *n_matches);
+FT_API int ft_tracked_batch_wait(ft_tracked_batch *tb);
+/* current holder_obs of frame `frame` (its N entries): copied down from HBM, where the searches keep it */
 FT_API int ft_tracked_batch_holder_obs(ft_tracked_batch *tb, int frame, int *holder_obs);
 
 /* ORBmatcher::DescriptorDistance for n pairs on the device (src/ORBmatcher.cc:2256-2272,

@@ -397,6 +397,31 @@ public:
                                                bFarPoints, thFarPoints, fields, nToMatch.data(), ptrs_.data(), nmatches.data()));
         finish(assign);
     }
+    // The same two searches in two halves (ft_tracked_batch_submit_* / ft_tracked_batch_wait): submit enqueues and returns, Wait() fills
+    // assign / nmatches (/ nToMatch) - they and the point arrays (when those lie in pinned memory) must stay as they are until then.
+    void SubmitSearchByProjection(const std::vector<ft_last_points> &LastFrames, const float *Tcw, float th, bool mbCheckOrientation,
+                                  std::vector<std::vector<int>> &assign, std::vector<int> &nmatches, const int *bForward = nullptr,
+                                  const int *bBackward = nullptr) {
+        prepare(assign, nmatches);
+        pending_ = &assign;
+        check(ft_tracked_batch_submit_search_last_frame(h_, (int)N_.size(), LastFrames.data(), Tcw, th, bForward, bBackward, mbCheckOrientation,
+                                                        ptrs_.data(), nmatches.data()));
+    }
+    void SubmitSearchLocalPoints(const std::vector<ft_frame_pose> &poses, const std::vector<ft_map_points> &P, float viewingCosLimit,
+                                 float mfLogScaleFactor, float th, float mfNNratio, bool bFarPoints, float thFarPoints,
+                                 const ft_frustum_result *fields, std::vector<int> &nToMatch, std::vector<std::vector<int>> &assign,
+                                 std::vector<int> &nmatches) {
+        prepare(assign, nmatches);
+        nToMatch.assign(N_.size(), 0);
+        pending_ = &assign;
+        check(ft_tracked_batch_submit_track_local_map(h_, (int)N_.size(), poses.data(), P.data(), viewingCosLimit, mfLogScaleFactor, th,
+                                                      mfNNratio, bFarPoints, thFarPoints, fields, nToMatch.data(), ptrs_.data(), nmatches.data()));
+    }
+    void Wait() {
+        check(ft_tracked_batch_wait(h_));
+        if (pending_) finish(*pending_);
+        pending_ = nullptr;
+    }
     std::vector<int> holderObservations(int frame) {
         std::vector<int> h(N_[frame] > 0 ? N_[frame] : 1);
         check(ft_tracked_batch_holder_obs(h_, frame, h.data()));
@@ -425,6 +450,7 @@ private:
     ft_tracked_batch *h_ = nullptr;
     std::vector<int> N_;
     std::vector<int *> ptrs_;
+    std::vector<std::vector<int>> *pending_ = nullptr;
 };
 
 // ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) for Frame::ComputeBoW: same call as

@@ -396,6 +396,74 @@ def test_search_grid_switched_between_upload_and_search(ctx):
             tb.close()
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+def test_submit_and_wait_equal_the_blocking_calls(ctx, pinned):
+    """ft_tracked_batch_submit_* / ft_tracked_batch_wait: the same results as the oracle (and so as the blocking calls); with the
+    point arrays in pinned host memory the device reads them in place (k_gather_batch: no host copy), pageable ones are staged.
+    One search per batch in flight: a second submit, an upload or holder_obs before the wait are FT_ERR_INVALID; a wait without a
+    submitted search is a no-op.  32 frames: the one-launch resolution (everything enqueued by the submit)."""
+    sf, _ = ob.scale_factors(1.2, 8)
+    B = 32
+    frames, lasts, Tcws, ptss, poses, oracle = [], [], [], [], [], []
+    for f in range(B):
+        oF, gF, kL, dL = _kb8_views(_kb8_base(1500, 10 + f % 2), sf, (700 + 20 * f, 650) if f % 3 == 1 else None)
+        last, Tcw, pts, Rcw, tcw = _kb8_inputs(kL, dL, sf, 7000 + f, 300 + 40 * f)
+        o1 = ob.search_last_frame(oF, last, Tcw, 7.0, False, False, True)
+        ofr = ob.is_in_frustum(oF, ob.make_pose(Rcw, tcw, TLR), pts, 0.5, LOG_SF)
+        o2 = ob.search_local_points(oF, sc.local_points_from_frustum(ofr, pts), 7.0)
+        frames.append(gF); lasts.append(last); Tcws.append(Tcw); ptss.append(pts); poses.append(orb.make_pose(Rcw, tcw, TLR))
+        oracle.append((o1, ofr, o2, oF))
+    tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=max(F.c.N for F in frames) + 8, max_points=2048)
+    try:
+        tb.upload(frames)
+        pc = ctx if pinned else None
+        pl_last = tb.prepare_last(lasts, Tcws, ctx=pc)
+        pl_local = tb.prepare_local(poses, ptss, ctx=pc)
+        tb.wait()                                            # nothing submitted: a no-op
+        ctx.reset_stats()
+        assert tb.search_last_frame(pl_last, th=7.0, submit=True) is None
+        for call in (lambda: tb.search_last_frame(pl_last, th=7.0, submit=True), lambda: tb.upload(frames), lambda: tb.holder_obs(0)):
+            with pytest.raises(orb.FastTrackError, match="has not been waited for"):
+                call()
+        g1 = tb.wait()
+        tb.track_local_map(pl_local, viewing_cos_limit=0.5, log_scale_factor=LOG_SF, th=7.0, submit=True)
+        g2 = tb.wait()
+        for f in range(B):
+            _check_frame(f"pinned {pinned} frame {f}", g1[f], g2[f], tb.holder_obs(f), *oracle[f])
+        # a pinned call stages nothing on the host: a few job records per frame (the pageable one copies 53 bytes per point)
+        stage = ctx.get_stat("tracked_batch.search_last_frame.stage")
+        assert stage[1] == 1
+    finally:
+        tb.close()
+
+
+def test_octave_out_of_range_in_arrays_read_in_place_is_reported_by_the_wait(ctx):
+    """a valid last-frame point whose octave lies outside the frame's levels: FT_ERR_INVALID from the blocking call when the host
+    copies the arrays (checked while it reads them), from the WAIT when the device reads them in place (k_last_project_batch
+    drops the point and marks the frame); the batch stays usable"""
+    sf, _ = ob.scale_factors(1.2, 8)
+    oF, gF, kL, dL = _kb8_views(_kb8_base(1500, 10), sf)
+    last, Tcw, _, _, _ = _kb8_inputs(kL, dL, sf, 7100, 10)
+    good = {k: v.copy() for k, v in last.items()}
+    last["valid"][5] = 1
+    last["octave"][5] = 8
+    tb = orb.TrackedBatch(ctx, max_frames=1, max_keypoints=gF.c.N + 8, max_points=2048)
+    try:
+        tb.upload([gF])
+        with pytest.raises(orb.FastTrackError, match="octave out of range"):
+            tb.search_last_frame([last], [Tcw], 7.0)
+        pl = tb.prepare_last([last], [Tcw], ctx=ctx)
+        tb.search_last_frame(pl, th=7.0, submit=True)
+        with pytest.raises(orb.FastTrackError, match="octave out of range"):
+            tb.wait()
+        o1 = ob.search_last_frame(oF, good, Tcw, 7.0, False, False, True)
+        tb.upload([gF])
+        g1 = tb.search_last_frame(tb.prepare_last([good], [Tcw], ctx=ctx), th=7.0)
+        assert g1[0]["n"] == o1["n"] and np.array_equal(g1[0]["assign"], o1["assign"])
+    finally:
+        tb.close()
+
+
 def test_tracked_batch_bind_with_triangulation_equals_oracle_fisheye_stereo(ctx):
     """bind_fisheye with a rig = the whole Frame::ComputeStereoFishEyeMatches per frame (src/Frame.cc:1231-1271): the ratio-test
     survivors go through KannalaBrandt8::TriangulateMatches; mvLeftToRightMatch / mvRightToLeftMatch / mvDepth / mvStereo3Dpoints /
