@@ -424,7 +424,8 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
     return out
 
 
-def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.0), pipelined=True, in_flight=4):
+def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.0), pipelined=True, in_flight=4, pinned=True,
+                       one_thread_per_lane=False):
     """BASELINE.json configs[3] as a THROUGHPUT workload: B independent 512x512 KannalaBrandt8 stereo frames per step (the
     frames B camera streams deliver for one time step), every stage ONE launch over all of them (ft_tracked_batch_*):
       extraction of the B left and the B right images, frames resident in HBM, lapping areas [0, 511]      (ft_extract_batch x 2,
@@ -434,9 +435,12 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
       SearchByProjection(CurrentFrame, LastFrame, th)                                                       (ft_tracked_batch_search_last_frame)
       isInFrustum + SearchByProjection(CurrentFrame, local map points, th)                                   (ft_tracked_batch_track_local_map)
     pipelined: `in_flight` steps in flight, like the two stereo front ends of the headline - that many host threads, each with its
-    own pair of extractors and its own batch object (a batch has a stream of its own), take the steps in turn, so that the passes
-    of one step run beside the extraction and the host side (staging of the map points, replay of the writes) of the others.  Host in / out per step: the map points of every frame up
-    (pageable host arrays), keypoints, descriptors, assignments, match counts and frustum fields down.  Every frame of the
+    own pair of extractors and its own batch object (a batch has a stream of its own), take the steps in turn, so that the kernels
+    of one step run beside the extraction and the host side of the others.  Host in / out per step: the map points of every frame up
+    (pinned = True: arrays in pinned host memory, read in place by the device - the host stages nothing and the writes of a search
+    are replayed on the device; False: pageable arrays, packed into pinned staging by the context's host threads), keypoints,
+    descriptors, assignments, match counts and frustum fields down.  one_thread_per_lane: the lane's thread runs the two
+    extractions itself, one after the other (otherwise two helper threads per lane, as Frame's constructor has them).  Every frame of the
     batch is a distinct image pair with its own last-frame points, local map (M points) and poses, built once from the frame's
     own keypoints (untimed)."""
     import ctypes as C
@@ -471,13 +475,17 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
     sf = np.asarray(lanes[0].exL.GetScaleFactors(), np.float32)
     cap = lanes[0].exL.max_keypoints
     for ln in lanes:
-        ln.tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=2 * cap + 64, max_points=max(M, cap) + 64)
+        ln.tb = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=2 * cap + 64, max_points=max(M, cap) + 64, pinned=pinned)
         ln.part = {"extract_left_right": 0.0, "bind_fisheye (order, match, grids)": 0.0, "search_last_frame": 0.0, "track_local_map": 0.0}
     tb = lanes[0].tb
     two = concurrent.futures.ThreadPoolExecutor(2 * nlanes)
     ahead = concurrent.futures.ThreadPoolExecutor(nlanes)
 
     def extract(ln):
+        if one_thread_per_lane:
+            ln.exL.extract_batch_into(pL, B, True, w, h, w, lap, ln.kL, ln.dL, ln.nL, ln.mL)
+            ln.exR.extract_batch_into(pR, B, True, w, h, w, lap, ln.kR, ln.dR, ln.nR, ln.mR)
+            return
         # the two cameras on two host threads, as Frame's constructor runs them (src/Frame.cc:1144-1147)
         a = two.submit(ln.exL.extract_batch_into, pL, B, True, w, h, w, lap, ln.kL, ln.dL, ln.nL, ln.mL)
         b = two.submit(ln.exR.extract_batch_into, pR, B, True, w, h, w, lap, ln.kR, ln.dR, ln.nR, ln.mR)
@@ -500,8 +508,9 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
         last, Tcw_last = sc.last_frame_scenario(l0.kL[f, :nL[f]], l0.dL[f, :nL[f]], None, depth, intr, w, h, seed=40 + f)
         pts, Rcw, tcw = sc.map_points_scenario(l0.kL[f, :nL[f]], l0.dL[f, :nL[f]], depth, intr, NLEVELS, sf, 90 + f, M=M)
         scen.append((last, Tcw_last, pts, Rcw, tcw))
-    pl_last = tb.prepare_last([s_[0] for s_ in scen], [s_[1] for s_ in scen])
-    pl_local = tb.prepare_local([orb.make_pose(s_[3], s_[4], TLR) for s_ in scen], [s_[2] for s_ in scen])
+    pc = ctx if pinned else None
+    pl_last = tb.prepare_last([s_[0] for s_ in scen], [s_[1] for s_ in scen], ctx=pc)
+    pl_local = tb.prepare_local([orb.make_pose(s_[3], s_[4], TLR) for s_ in scen], [s_[2] for s_ in scen], ctx=pc)
     def pipeline(ln, n, th):
         for _ in range(n):
             t0 = time.perf_counter()
@@ -524,7 +533,8 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
     out = {"metric": "frames/sec extract + SearchByProjection (last frame, local map), B frames per launch", "unit": "frames/s",
            "batch_frames": B, "distinct_frames": B, "steps": steps, "image": [w, h], "nfeatures": nf, "local_map_points": M,
            "mode": f"{nlanes} steps in flight ({nlanes} host threads, each with its extractors and its batch)" if nlanes > 1 else "one step at a time",
-           "inputs": "images resident in HBM before the timed region; map points in pageable host memory, uploaded inside it",
+           "host_threads": nlanes * (1 if one_thread_per_lane else 3),
+           "inputs": "images resident in HBM before the timed region; map points in %s host memory, uploaded inside it" % ("pinned" if pinned else "pageable"),
            "outputs": "keypoints, descriptors, assignments, match counts, frustum fields in host memory", "by_th": {}}
     for th in ths:
         run(max(warmup, 2), th)

@@ -278,6 +278,13 @@ int ft_context_create(int device, int host_threads, ft_context **out) {
         return FT_ERR_INVALID;
     }
     FT_HIP(hipSetDevice(device));
+    // How a host thread waits for the device.  The runtime's default spins: fine while every waiting thread has a core of its
+    // own, ruinous when more threads wait than the process has cores (a spinning waiter keeps the thread that has launches
+    // to make off the core for a scheduler slice).  A device flag of the whole process; a process that has set its own
+    // keeps it (the call then fails and is ignored).
+    if (tuning.blocking_sync == 1 || (tuning.blocking_sync == 2 && ft_usable_cpus() < 8)) {
+        if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
+    }
     hipDeviceProp_t prop;
     FT_HIP(hipGetDeviceProperties(&prop, device));
     ft_context *ctx = new ft_context();
@@ -485,7 +492,7 @@ int ft_host_malloc(ft_context *ctx, size_t bytes, void **ptr) {
     FT_HIP(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
     std::lock_guard<std::mutex> lk(ctx->hostAllocMutex);
     ctx->hostAllocs.push_back(*ptr);  // released by ft_host_free, or with the context
-    ctx->hostBlocks.emplace_back((uintptr_t)*ptr, bytes ? bytes : 1);
+    ctx->hostBlocks[(uintptr_t)*ptr] = bytes ? bytes : 1;
     return FT_OK;
 }
 
@@ -496,11 +503,7 @@ int ft_host_free(ft_context *ctx, void *ptr) {
         std::lock_guard<std::mutex> lk(ctx->hostAllocMutex);
         auto it = std::find(ctx->hostAllocs.begin(), ctx->hostAllocs.end(), ptr);
         if (it != ctx->hostAllocs.end()) ctx->hostAllocs.erase(it);
-        for (size_t i = 0; i < ctx->hostBlocks.size(); i++)
-            if (ctx->hostBlocks[i].first == (uintptr_t)ptr) {
-                ctx->hostBlocks.erase(ctx->hostBlocks.begin() + (long)i);
-                break;
-            }
+        ctx->hostBlocks.erase((uintptr_t)ptr);
     }
     FT_HIP(hipHostFree(ptr));
     return FT_OK;
@@ -552,9 +555,10 @@ bool ft_host_block_contains(ft_context *ctx, const void *p, size_t bytes) {
     if (!ctx || !p) return false;
     const uintptr_t a = (uintptr_t)p;
     std::lock_guard<std::mutex> lk(ctx->hostAllocMutex);
-    for (const auto &b : ctx->hostBlocks)
-        if (a >= b.first && a + bytes <= b.first + b.second) return true;
-    return false;
+    auto it = ctx->hostBlocks.upper_bound(a);  // the first block that starts behind a: the one in front of it may hold a
+    if (it == ctx->hostBlocks.begin()) return false;
+    --it;
+    return a + bytes <= it->first + it->second;
 }
 
 // A frame the device may read in place: first AND last byte lie in the same pinned / registered host allocation.

@@ -51,7 +51,8 @@
     X(paired, "FT_PAIRED", 1, 0, 1, "latency-mode stereo front ends run both cameras through one set of launches")           \
     X(pass_burst, "FT_PASS_BURST", 12, 2, 14, "projection searches: claim passes enqueued per host round trip")              \
     X(search_cache, "FT_SEARCH_CACHE", 2, 0, 3, "projection searches: 1 = later claim passes walk the cached candidate keys, 2 = and a batch of 24+ frames resolves its claims in one launch, 3 = every batch does") \
-    X(search_grid, "FT_SEARCH_GRID", 1, 0, 1, "projection searches: CSR grid of the frame built on the device")
+    X(search_grid, "FT_SEARCH_GRID", 1, 0, 1, "projection searches: CSR grid of the frame built on the device") \
+    X(blocking_sync, "FT_BLOCKING_SYNC", 2, 0, 2, "host waits for the device: 0 = the runtime's default (it spins), 1 = sleeping (hipDeviceScheduleBlockingSync), 2 = sleeping when the process may use fewer than 8 CPUs")
 
 struct ft_tuning {
 #define FT_X(field, env, def, lo, hi, doc) int field = def;
@@ -87,7 +88,7 @@ struct ft_context {
     std::mutex hostAllocMutex;
     // events of destroyed tracked batches that an extractor may still hold as its foreignReader: destroyed with the context
     std::vector<hipEvent_t> retiredEvents;
-    std::vector<std::pair<uintptr_t, size_t>> hostBlocks;  // (address, bytes) of the live ft_host_malloc blocks (ft_host_block_contains)
+    std::map<uintptr_t, size_t> hostBlocks;  // address -> bytes of the live ft_host_malloc blocks (ft_host_block_contains)
     std::vector<void *> hostAllocs;  // live ft_host_malloc blocks
     bool kernelTiming = false;  // ft_context_set_kernel_timing
     ft_tuning tuning;           // FT_TUNING_OPTIONS: read from the environment by ft_context_create, changed by ft_context_set_option

@@ -1189,6 +1189,10 @@ struct FtBatchCall {
     std::vector<int> M;
     // the caller's output arrays
     std::vector<int *> assign;
+    bool assignDirect = false;  // every assign[f] lies in pinned memory: k_replay_batch writes there, the wait copies nothing
+    bool frustumDirect = false;  // every array of every frustum[f] lies in pinned memory: a scatter launch behind k_frustum_batch fills them
+    const FtGatherRec *dFrRecs = nullptr;
+    int nFrRecs = 0;
     int *nMatches = nullptr, *nToMatch = nullptr;
     std::vector<ft_frustum_result> frustum;
     bool haveFrustum = false;
@@ -1225,6 +1229,7 @@ struct ft_tracked_batch {
     std::mutex mu;
     FtEventTimer evt;  // ft_context_set_kernel_timing: HIP events around the batch's launches on the context's stream
     hipEvent_t evGather = nullptr;  // bind_fisheye: the gather from the extractors' slots has run (the extractors' next batch waits for it)
+    hipEvent_t evMirror = nullptr;  // the last copy out of the pinned mirror h_in has run: the next call may repack it
     FtBatchCall call;  // the search between ft_tracked_batch_submit_* and ft_tracked_batch_wait (kind 0: none)
     size_t oErr = 0;   // one int per frame: input errors the kernels found (a last-frame octave outside the frame's levels)
 };
@@ -1341,8 +1346,13 @@ int callDeliver(ft_tracked_batch *tb, FtBatchCall &c, int parity, bool first) {
         const int r = ft_launch_frustum_batch(st, tb->d_arena, c.dJobs, c.n, c.maxM, c.viewingCosLimit, c.logScaleFactor, c.farPoints, c.thFar);
         if (r != FT_OK) return r;
     }
-    const int nRecs = c.kind == 2 ? (first ? c.n + 3 : 3) : 2;
-    return ft_launch_deliver_batch(st, c.dRecs + c.n, nRecs, std::max(c.kind == 2 && first ? c.maxFrWords : 0, FT_BATCH_FLAGS * c.n), parity);
+    const bool frRecs = c.kind == 2 && first && c.haveFrustum && !c.frustumDirect;
+    if (c.kind == 2 && first && c.frustumDirect) {
+        const int r = ft_launch_gather_batch(st, c.dFrRecs, c.nFrRecs);
+        if (r != FT_OK) return r;
+    }
+    const int nRecs = c.kind == 2 ? (frRecs ? c.n + 3 : 3) : 2;
+    return ft_launch_deliver_batch(st, c.dRecs + c.n, nRecs, std::max(frRecs ? c.maxFrWords : 0, FT_BATCH_FLAGS * c.n), parity);
 }
 
 int callResolve(ft_tracked_batch *tb, FtBatchCall &c) {
@@ -1525,6 +1535,7 @@ int ft_tracked_batch_create(ft_context *ctx, int max_frames, int max_keypoints, 
     if (e == hipSuccess) e = hipHostMalloc((void **)&tb->h_out, tb->outBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&tb->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&tb->evGather, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&tb->evMirror, hipEventDisableTiming);
     if (e != hipSuccess) {
         ft_tracked_batch_destroy(tb);
         return ft_hip_fail(e, "ft_tracked_batch_create", __FILE__, __LINE__);
@@ -1542,6 +1553,7 @@ int ft_tracked_batch_destroy(ft_tracked_batch *tb) {
         hipStreamSynchronize(tb->stream);
         hipStreamDestroy(tb->stream);
     }
+    if (tb->evMirror) hipEventDestroy(tb->evMirror);
     if (tb->evGather) {  // an extractor bound to this batch may still hold the event for its next batch: it goes with the context
         std::lock_guard<std::mutex> lk(tb->ctx->hostAllocMutex);
         tb->ctx->retiredEvents.push_back(tb->evGather);
@@ -1647,6 +1659,7 @@ int ft_tracked_batch_upload(ft_tracked_batch *tb, int n_frames, const ft_frame_v
     ctx->pool->parallel_for(n_frames, stage);
     FT_HIP(hipMemcpyAsync(tb->d_arena + tb->oWork, tb->h_in, (size_t)n_frames * sizeof(FtBatchJob), hipMemcpyHostToDevice, st));
     FT_HIP(hipMemcpyAsync(devF, pinF, a.off, hipMemcpyHostToDevice, st));
+    FT_HIP(hipEventRecord(tb->evMirror, st));
     if (wantGrid) {
         rc = ft_launch_build_grid_batch(st, tb->d_arena, (const FtBatchJob *)(tb->d_arena + tb->oWork), n_frames, nlevelsMax, twoCam);
         if (rc != FT_OK) return rc;
@@ -1742,6 +1755,8 @@ int submitLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, const 
     if (rc != FT_OK) return rc;
     FtBatchCall &c = tb->call;
     c = FtBatchCall();
+    c.assignDirect = true;
+    for (int f = 0; f < n; f++) c.assignDirect = c.assignDirect && readableInPlace(ctx, assign[f], 4 * (size_t)std::max(tb->DF[f].N, 1));
     hipStream_t st = tb->stream;
     // layout of the call in the work region: job records | delivery records | gather records | per frame the point arrays
     Arena a;
@@ -1770,7 +1785,8 @@ int submitLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, const 
     for (int f = 0; f < n; f++) lay[f].proj = a.take(sizeof(FtLastProj) * (size_t)std::max(L[f].N, 1));
     FT_REQUIRE(a.off <= tb->workBytes && o.off <= tb->outBytes, "tracked batch work arena too small");
     uint8_t *pin = tb->h_in, *dev = tb->d_arena + tb->oWork;
-    FT_HIP(hipStreamSynchronize(st));  // (the pinned mirror of the previous call)
+    FT_HIP(hipEventSynchronize(tb->evMirror));  // (the pinned mirror: the previous call's copy out of it - not the whole stream, whose
+                                                // kernels - a bind_fisheye enqueued just before - may run on while this call is staged)
     const std::function<void(int, int)> stage = [&](int f, int) {
         const ft_last_points &P = L[f];
         const size_t M = (size_t)P.N;
@@ -1807,7 +1823,7 @@ int submitLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, const 
         J.Tcw = poses[f];
         J.forward = forward ? forward[f] : 0;
         J.backward = backward ? backward[f] : 0;
-        J.assignOut = (int *)(tb->h_out + c.outAssign[f]);
+        J.assignOut = c.assignDirect ? assign[f] : (int *)(tb->h_out + c.outAssign[f]);
         J.nmOut = (int *)(tb->h_out + c.oNmOut) + f;
         memset(&H.hRecs[f], 0, sizeof(FtDeliverRec));  // (the points' results stay on the device: k_replay_batch turns them into assignments there)
     };
@@ -1823,6 +1839,7 @@ int submitLastFrame(ft_tracked_batch *tb, int n, const ft_last_points *L, const 
     H.hRecs[n + 1] = {tb->h_out + c.oErrOut, {tb->d_arena + tb->oErr, tb->d_arena + tb->oErr}, n};
     ctx->addStat("tracked_batch.search_last_frame.stage", c.tAll.ms());
     FT_HIP(hipMemcpyAsync(dev, pin, inPlace ? headEnd : inputEnd, hipMemcpyHostToDevice, st));
+    FT_HIP(hipEventRecord(tb->evMirror, st));
     if (inPlace) {
         rc = ft_launch_gather_batch(st, (const FtGatherRec *)(dev + H.oGather), 6 * n);
         if (rc != FT_OK) return rc;
@@ -1869,9 +1886,24 @@ int submitLocalMap(ft_tracked_batch *tb, int n, const ft_frame_pose *poses, cons
     if (rc != FT_OK) return rc;
     FtBatchCall &c = tb->call;
     c = FtBatchCall();
+    c.assignDirect = true;
+    for (int f = 0; f < n; f++) c.assignDirect = c.assignDirect && readableInPlace(ctx, assign[f], 4 * (size_t)std::max(tb->DF[f].N, 1));
     hipStream_t st = tb->stream;
     Arena a;
-    const CallHead H = layoutHead(tb, a, n, 2 * n + 3, inPlace ? 7 * n : 0);
+    // the frustum fields: straight into the caller's arrays when every one of them lies in pinned memory (a scatter launch, 12
+    // records per frame, behind k_frustum_batch), else through the batch's result buffer and the host's copies (unpackFrustum)
+    bool frDirect = frustum != nullptr;
+    auto field_ptrs = [](const ft_frustum_result &R, void *out[12]) {
+        void *p[12] = {R.in_view, R.in_view_r, R.level, R.level_r, R.view_cos, R.view_cos_r, R.proj_x, R.proj_y, R.proj_xr, R.proj_yr, R.depth, R.depth_r};
+        for (int k = 0; k < 12; k++) out[k] = p[k];
+    };
+    static const int kFieldBytes[12] = {1, 1, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4};
+    for (int f = 0; f < n && frDirect; f++) {
+        void *fp[12];
+        field_ptrs(frustum[f], fp);
+        for (int k = 0; k < 12; k++) frDirect = frDirect && readableInPlace(ctx, fp[k], (size_t)kFieldBytes[k] * (size_t)P[f].M);
+    }
+    const CallHead H = layoutHead(tb, a, n, 2 * n + 3, (inPlace ? 7 * n : 0) + (frDirect ? 12 * n : 0));
     const size_t headEnd = a.off;
     struct Lay {
         size_t fIn0, fOutEnd, desc, obs;
@@ -1904,7 +1936,7 @@ int submitLocalMap(ft_tracked_batch *tb, int n, const ft_frame_pose *poses, cons
     }
     FT_REQUIRE(a.off <= tb->workBytes && o.off <= tb->outBytes, "tracked batch work arena too small");
     uint8_t *pin = tb->h_in, *dev = tb->d_arena + tb->oWork;
-    FT_HIP(hipStreamSynchronize(st));
+    FT_HIP(hipEventSynchronize(tb->evMirror));
     const std::function<void(int, int)> stage = [&](int f, int) {
         const ft_map_points &Q = P[f];
         const size_t M = (size_t)Q.M;
@@ -1941,8 +1973,15 @@ int submitLocalMap(ft_tracked_batch *tb, int n, const ft_frame_pose *poses, cons
         J.P.viewCos = J.O.viewCos; J.P.viewCosR = J.O.viewCosR;
         J.P.projX = J.O.projX; J.P.projY = J.O.projY; J.P.projXR = J.O.projXR; J.P.projYR = J.O.projYR;
         J.P.desc = dev + lay[f].desc;
-        J.assignOut = (int *)(tb->h_out + c.outAssign[f]);
+        J.assignOut = c.assignDirect ? assign[f] : (int *)(tb->h_out + c.outAssign[f]);
         J.nmOut = (int *)(tb->h_out + c.oNmOut) + f;
+        if (frDirect) {
+            FtGatherRec *G = H.hGather + (inPlace ? 7 * (size_t)n : 0) + 12 * (size_t)f;
+            void *fp[12];
+            field_ptrs(frustum[f], fp);
+            const size_t srcOff[12] = {FL.inV, FL.inVR, FL.lvl, FL.lvlR, FL.vc, FL.vcR, FL.px, FL.py, FL.pxr, FL.pyr, FL.dep, FL.depR};
+            for (int k = 0; k < 12; k++) G[k] = {fp[k], dev + srcOff[k], (unsigned)(fp[k] ? (size_t)kFieldBytes[k] * M : 0)};
+        }
         memset(&H.hRecs[f], 0, sizeof(FtDeliverRec));
         FtDeliverRec &R2 = H.hRecs[n + 3 + f];  // (the frustum fields do not change from burst to burst: delivered with the first one)
         R2.dst = tb->h_out + c.outFr[f];
@@ -1964,6 +2003,7 @@ int submitLocalMap(ft_tracked_batch *tb, int n, const ft_frame_pose *poses, cons
     H.hRecs[n + 2] = {tb->h_out + c.oCountsOut, {tb->d_arena + tb->oCounts, tb->d_arena + tb->oCounts}, n};
     ctx->addStat("tracked_batch.track_local_map.stage", c.tAll.ms());
     FT_HIP(hipMemcpyAsync(dev, pin, inPlace ? headEnd : a.off, hipMemcpyHostToDevice, st));
+    FT_HIP(hipEventRecord(tb->evMirror, st));
     if (inPlace) {
         rc = ft_launch_gather_batch(st, (const FtGatherRec *)(dev + H.oGather), 7 * n);
         if (rc != FT_OK) return rc;
@@ -1983,6 +2023,9 @@ int submitLocalMap(ft_tracked_batch *tb, int n, const ft_frame_pose *poses, cons
     c.nMatches = n_matches;
     c.nToMatch = n_to_match;
     c.haveFrustum = frustum != nullptr;
+    c.frustumDirect = frDirect;
+    c.dFrRecs = (const FtGatherRec *)(dev + H.oGather) + (inPlace ? 7 * (size_t)n : 0);
+    c.nFrRecs = frDirect ? 12 * n : 0;
     if (frustum) c.frustum.assign(frustum, frustum + n);
     c.kind = 2;
     rc = callBegin(tb, c, tb->passesLocal);
@@ -2022,12 +2065,12 @@ int waitCall(ft_tracked_batch *tb) {
     const int *hNm = (const int *)(tb->h_out + c.oNmOut), *hCounts = (const int *)(tb->h_out + c.oCountsOut);
     const std::function<void(int, int)> finish = [&](int f, int) {
         const int N = tb->DF[f].N;
-        if (N > 0) memcpy(c.assign[f], tb->h_out + c.outAssign[f], sizeof(int) * (size_t)N);
+        if (N > 0 && !c.assignDirect) memcpy(c.assign[f], tb->h_out + c.outAssign[f], sizeof(int) * (size_t)N);
         if (c.nMatches) c.nMatches[f] = hNm[f];
         if (kind == 2) {
             const int M = c.M[f];
             // unpackFrustum reads the count through the layout; the batch keeps the counts of all frames in one block
-            if (M > 0) unpackFrustum(M, c.FL[f], c.fInEnd[f], tb->h_out + c.outFr[f], c.haveFrustum ? &c.frustum[f] : nullptr, nullptr);
+            if (M > 0 && c.haveFrustum && !c.frustumDirect) unpackFrustum(M, c.FL[f], c.fInEnd[f], tb->h_out + c.outFr[f], &c.frustum[f], nullptr);
             if (c.nToMatch) c.nToMatch[f] = M > 0 ? hCounts[f] : 0;
         }
     };
@@ -2280,6 +2323,7 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     FT_HIP(hipMemcpyAsync(tb->d_arena + tb->oWork, tb->h_in, headBytes, hipMemcpyHostToDevice, st));
     if (tb->holderEnd > tb->holderBegin)
         FT_HIP(hipMemcpyAsync(devF + tb->holderBegin, pinF + tb->holderBegin, tb->holderEnd - tb->holderBegin, hipMemcpyHostToDevice, st));
+    FT_HIP(hipEventRecord(tb->evMirror, st));
     const FtBatchJob *dJobs = (const FtBatchJob *)(tb->d_arena + tb->oWork);
     FtBindArgs A;
     A.keysL = exL->d_keys; A.keysR = exR->d_keys;

@@ -610,8 +610,9 @@ def _map_points(pts: dict, keep: dict, ctx=None):
     return P, M
 
 
-def _frustum_result(M):
-    outs = {k: np.zeros(max(M, 1), dt) for k, dt in FRUSTUM_FIELDS}
+def _frustum_result(M, ctx=None):
+    """ctx: the arrays live in pinned host memory of that context (the device fills them directly)"""
+    outs = {k: (np.zeros(max(M, 1), dt) if ctx is None else ctx.pinned_array((max(M, 1),), dt)) for k, dt in FRUSTUM_FIELDS}
     R = _capi.FrustumResult()
     for k, _ in FRUSTUM_FIELDS:
         setattr(R, k, ptr(outs[k]))
@@ -705,11 +706,14 @@ class TrackedBatch:
     TrackedFrame's calls.  The marshalled inputs of a call (ctypes arrays of ft_last_points / ft_map_points) can be prepared
     once with prepare_last / prepare_local and handed in again, so that a benchmark loop does not time Python."""
 
-    def __init__(self, ctx: Context, max_frames: int, max_keypoints: int, max_points: int):
+    def __init__(self, ctx: Context, max_frames: int, max_keypoints: int, max_points: int, pinned=False):
+        """pinned: the assignment arrays the searches fill live in pinned host memory (the device writes them directly) and
+        prepare_last / prepare_local called on the object put the point arrays there too (the device reads them in place)"""
         self.ctx = ctx
         self._h = C.c_void_p()
         check(lib().ft_tracked_batch_create(ctx._h, max_frames, max_keypoints, max_points, C.byref(self._h)))
         self.N = []
+        self._pin_ctx = ctx if pinned else None
 
     def close(self):
         if getattr(self, "_h", None) and self.ctx._h:
@@ -735,7 +739,10 @@ class TrackedBatch:
 
     def _after_load(self, counts):
         self.N = list(counts)
-        self._assign = [np.zeros(max(n, 1), np.int32) for n in self.N]
+        if self._pin_ctx is not None:
+            self._assign = [self._pin_ctx.pinned_array((max(n, 1),), np.int32) for n in self.N]
+        else:
+            self._assign = [np.zeros(max(n, 1), np.int32) for n in self.N]
         self._assign_ptrs = (C.c_void_p * len(self.N))(*[ptr(a) for a in self._assign])
         self._nm = np.zeros(len(self.N), np.int32)
         self._nt = np.zeros(len(self.N), np.int32)
@@ -844,7 +851,7 @@ class TrackedBatch:
             keep.append(k)
             P[f] = Pf
             if want_frustum:
-                Rf, o = _frustum_result(M)
+                Rf, o = _frustum_result(M, ctx)
                 R[f] = Rf
                 outs.append((M, o))
         T = (_capi.FramePose * n)(*poses)

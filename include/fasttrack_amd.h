@@ -95,6 +95,10 @@ FT_API int ft_context_set_lane_map(ft_context *ctx, const int *map, int n);
  *                                          batch of 24 or more frames resolves its claims in one launch behind the first pass (a
  *                                          workgroup per frame); 3 = every batch does
  *   search_grid          1        0 .. 1   projection searches: CSR grid of the frame built on the device
+ *   blocking_sync        2        0 .. 2   host waits for the device: 0 = the runtime's default (it spins), 1 = sleeping
+ *                                          (hipDeviceScheduleBlockingSync: a waiting thread leaves its core to the others - 10 - 20 us
+ *                                          later wake-ups), 2 = sleeping when the process may use fewer than 8 CPUs.  Read by
+ *                                          ft_context_create only (a device flag of the whole process)
  *
  * A value outside an option's range is FT_ERR_INVALID (from ft_context_set_option, and from ft_context_create when it comes
  * from the environment).

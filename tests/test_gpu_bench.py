@@ -103,3 +103,25 @@ def test_bench_single_rank_line_has_the_contract_fields():
         assert state == "current" or state == "missing" or state.startswith("stale")
     if not all(v == "current" for v in r["profiles"].values()):
         assert roof["traffic"] is None or r["profiles"]["r06_traffic.json"] == "current"
+
+
+def test_tracking_leg_with_one_host_thread_per_lane_on_two_cpus():
+    """the batched searches without the host in them.  configs[3]'s throughput leg (64 frames per launch, four
+    lanes) with ONE host thread per lane, the point arrays in pinned memory (read in place), the process pinned to two CPUs
+    before the context exists: the host's share of a search call (staging + what is left of the replay) stays under 0.3 ms, and
+    the two-CPU process keeps at least 60 % of what the same box does with all its CPUs and three threads per lane (boxes differ
+    by 15 %, so the bound is relative)."""
+    import json, subprocess, sys
+    tool = os.path.join(ROOT, "tests", "tools", "bench_tracking_batch.py")
+
+    def run(env, *args):
+        out = subprocess.run([sys.executable, tool, *args], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().split("\n")[-1])
+    free = run({}, "64", "8", "4", "1", "0")
+    two = run({"FT_BENCH_CPUS": "0,1"}, "64", "8", "4", "1", "1")
+    lib = two["by_th"]["7"]["inside_the_library"]
+    for call in ("search_last_frame", "track_local_map"):
+        host = lib[f"tracked_batch.{call}.stage_ms_per_call"] + lib[f"tracked_batch.{call}.replay_ms_per_call"]
+        assert host < 0.3, (call, host)
+    assert two["host_threads"] == 4 and two["by_th"]["7"]["value"] > 0.6 * free["by_th"]["7"]["value"], (two["by_th"]["7"]["value"], free["by_th"]["7"]["value"])
