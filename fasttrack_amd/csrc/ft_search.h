@@ -203,7 +203,8 @@ int ft_launch_search_last_first(hipStream_t st, void *arena, const FtBatchJob *j
 int ft_launch_search_local_first(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, float th, float nnRatio);
 // everything behind that first pass in one launch: a workgroup per frame walks the frame's points in index order (k_resolve_batch);
 // a frame it resolves has all its flag words at -1 and its results in both result buffers, a frame it gives up on is untouched
-int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, float nnRatio);
+// sharedInts = ints of LDS for the frame's last-writer table (>= the largest F.N; <= 12288), 0 = frames beyond that: the table lives in HBM
+int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, float nnRatio, int sharedInts);
 // The writes of a converged search replayed on the device, a workgroup per frame (k_replay_batch): assign[keypoint] = the last
 // point that wrote it, holder_obs updated in place in HBM, the match count; last frame: with the rotation histogram and
 // ComputeThreeMaxima when checkOrientation.  Only frames that have not been replayed yet and - resolvedOnly - whose flag word says

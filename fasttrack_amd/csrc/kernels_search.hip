@@ -1659,17 +1659,19 @@ __global__ __launch_bounds__(256) void k_search_last_lean(const FtBatchJob *__re
 #define FT_RS_SLOTS 512  // hash slots (<= 256 writes per chunk)
 #define FT_RS_REG 3      // keys of a list's head a lane keeps in registers (x 16 lanes = FT_CACHE_HEAD_MAX)
 struct RsShared {
-    int kp[FT_RS_SLOTS];
-    unsigned lo[FT_RS_SLOTS], hi[FT_RS_SLOTS];  // rows of the chunk that write the slot's keypoint (their results of the previous iteration)
-    unsigned char obs[FT_RS_ROWS];               // Observations() > 0 of the chunk's points
-    int vote[2];                                 // "an iteration changed a result", by iteration parity
+    // two hash tables used alternately by the iterations of a chunk (iteration `it` reads table it & 1 and clears the other
+    // one for its successor): keypoint -> rows of the chunk that write it (their results of the previous iteration)
+    int kp[2][FT_RS_SLOTS];
+    unsigned lo[2][FT_RS_SLOTS], hi[2][FT_RS_SLOTS];
+    unsigned char obs[FT_RS_ROWS];  // Observations() > 0 of the chunk's points
+    int vote[3];                    // "iteration it changed a result", slot it % 3
 };
 __device__ __forceinline__ unsigned rs_hash(int kp) { return ((unsigned)kp * 2654435761u) >> 23; }
-__device__ __forceinline__ void rs_clear(RsShared &S) {
-    for (int t = threadIdx.x; t < FT_RS_SLOTS; t += FT_RS_ROWS * 16) {
-        S.kp[t] = -1;
-        S.lo[t] = 0u;
-        S.hi[t] = 0u;
+__device__ __forceinline__ void rs_clear(RsShared &S, int t) {
+    for (int k = threadIdx.x; k < FT_RS_SLOTS; k += FT_RS_ROWS * 16) {
+        S.kp[t][k] = -1;
+        S.lo[t][k] = 0u;
+        S.hi[t][k] = 0u;
     }
 }
 // a barrier for what the workgroup exchanges through LDS: outstanding loads from memory (the next chunk's prefetch) stay outstanding
@@ -1678,27 +1680,27 @@ __device__ __forceinline__ void rs_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-__device__ __forceinline__ void rs_insert(RsShared &S, int kp, int row) {
+__device__ __forceinline__ void rs_insert(RsShared &S, int t, int kp, int row) {
     unsigned h = rs_hash(kp);
     for (;;) {
-        const int old = atomicCAS(&S.kp[h], -1, kp);
+        const int old = atomicCAS(&S.kp[t][h], -1, kp);
         if (old == -1 || old == kp) break;
         h = (h + 1) & (FT_RS_SLOTS - 1);
     }
-    if (row < 32) atomicOr(&S.lo[h], 1u << row);
-    else atomicOr(&S.hi[h], 1u << (row - 32));
+    if (row < 32) atomicOr(&S.lo[t][h], 1u << row);
+    else atomicOr(&S.hi[t][h], 1u << (row - 32));
 }
 // F.mvpMapPoints[kp] && ->Observations() > 0 as the point of row `row` sees it: the last writer in front of it - of this chunk
-// (hash; useHash = 0: the chunk's first iteration, no writes of the chunk yet) or, if none, of the chunks before (lw = lastW[kp]) -
+// (hash table t; useHash = 0: the chunk's first iteration, no writes of the chunk yet) or, if none, of the chunks before (lw = lastW[kp]) -
 // decides, else the pre-call holder
-__device__ __forceinline__ bool rs_locked(const RsShared &S, bool useHash, int kp, int lw, bool held, int row) {
+__device__ __forceinline__ bool rs_locked(const RsShared &S, int t, bool useHash, int kp, int lw, bool held, int row) {
     if (useHash) {
         unsigned h = rs_hash(kp);
         for (;;) {
-            const int k = S.kp[h];
+            const int k = S.kp[t][h];
             if (k == -1) break;
             if (k == kp) {
-                const unsigned long long m = ((unsigned long long)S.lo[h] | ((unsigned long long)S.hi[h] << 32)) & ((1ull << row) - 1ull);
+                const unsigned long long m = ((unsigned long long)S.lo[t][h] | ((unsigned long long)S.hi[t][h] << 32)) & ((1ull << row) - 1ull);
                 if (m) return S.obs[63 - __clzll((long long)m)] != 0;
                 break;
             }
@@ -1707,7 +1709,16 @@ __device__ __forceinline__ bool rs_locked(const RsShared &S, bool useHash, int k
     }
     return lw >= 0 ? (lw & 1) != 0 : held;
 }
-__device__ __forceinline__ int rs_last_writer(const int *lastW, int kp) { return __hip_atomic_load(lastW + kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The last writers of the points in front of the running chunk, one word per keypoint of the frame.  LWLDS (round 6): the table
+// lives in the workgroup's LDS for the whole walk (F.N ints: 16 KB at configs[3]) - a chunk's publication is an LDS atomic and
+// the next chunk's look-ups are LDS reads, where round 5 went through L2 both ways (atomicMax, then device-scope loads that had
+// to wait for it: one memory round trip on every chunk's critical path, 32 chunks per frame).  Frames too large for the LDS
+// keep the table in HBM (buffer 0 of the list heads).
+template <bool LWLDS>
+__device__ __forceinline__ int rs_last_writer(const int *lastW, int kp) {
+    if constexpr (LWLDS) return lastW[kp];
+    else return __hip_atomic_load(lastW + kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // results of a converged chunk: both result buffers (the host reads the one of the parity it is told), lastW for the chunks behind
 __device__ __forceinline__ void rs_publish(int *res0, int *res1, int *lastW, int i, int sub, bool obsI, const int r4[4]) {
     if (sub < 4) {
@@ -1715,7 +1726,7 @@ __device__ __forceinline__ void rs_publish(int *res0, int *res1, int *lastW, int
         const int s = 4 * i + sub;
         res0[s] = kp;
         res1[s] = kp;
-        if (kp >= 0) atomicMax(lastW + kp, (s << 1) | (obsI ? 1 : 0));
+        if (kp >= 0) atomicMax(lastW + kp, (s << 1) | (obsI ? 1 : 0));  // (LDS or HBM: the address space decides the instruction)
     }
 }
 // what a point's turn needs that no other point's result changes - requested a chunk ahead
@@ -1751,21 +1762,26 @@ __device__ __forceinline__ RsStatic rs_fetch(const FtBatchJob &J, const Rebase &
     return T;
 }
 
-template <bool LOCAL>
+template <bool LOCAL, bool LWLDS>
 __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, float nnRatio) {
     const FtBatchJob &J = jobs[blockIdx.x];
     if (J.nPoints <= 0) return;
     __shared__ RsShared S;
+    extern __shared__ int rs_lw[];  // LWLDS: the frame's last-writer table
     const FtDevFrame &F = J.F;
     const bool twoCam = F.Nleft != -1;
     const int M = LOCAL ? J.P.M : J.L.N;
     const int row = threadIdx.x >> 4, sub = threadIdx.x & 15;
     int *res0 = rb(J.res), *res1 = res0 + 4 * (size_t)J.nPoints;
-    int *lastW = rb(J.head);  // (buffer 0 of the list heads: all -1 after k_fill_claims_batch, not written by a first pass)
+    // (HBM form: buffer 0 of the list heads, all -1 after k_fill_claims_batch and not written by a first pass)
+    int *lastW = LWLDS ? rs_lw : rb(J.head);
+    if constexpr (LWLDS)
+        for (int k = threadIdx.x; k < F.N; k += FT_RS_ROWS * 16) rs_lw[k] = -1;  // (the pre-scan's barrier below orders it)
     const int *obsP = rb(J.obs);
     const unsigned long long *cache = rb(J.cache);
     const int *l2r = rb(F.l2r), *r2l = rb(F.r2l);
-    if (threadIdx.x < 2) S.vote[threadIdx.x] = 0;
+    if (threadIdx.x < 3) S.vote[threadIdx.x] = 0;
+    rs_clear(S, 1);  // (the table of a chunk's second iteration; the pre-scan's barrier below orders it)
     RsStatic T = rs_fetch<LOCAL>(J, rb, cache, obsP, twoCam, min(row, M - 1), sub);
     // Usable or not is decided for the WHOLE frame before the first chunk publishes anything (results, last writers): the meta
     // words of every list the frame's points will want, a point per lane.  A frame the kernel gives up on is untouched - the
@@ -1823,8 +1839,8 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
         }
 #pragma unroll
         for (int j = 0; j < FT_RS_REG; j++) {
-            wL[j] = kL[j] != KEY_NONE ? rs_last_writer(lastW, key_idx(kL[j])) : -1;
-            wR[j] = kR[j] != KEY_NONE ? rs_last_writer(lastW, key_idx(kR[j]) + F.Nleft) : -1;
+            wL[j] = kL[j] != KEY_NONE ? rs_last_writer<LWLDS>(lastW, key_idx(kL[j])) : -1;
+            wR[j] = kR[j] != KEY_NONE ? rs_last_writer<LWLDS>(lastW, key_idx(kR[j]) + F.Nleft) : -1;
             mL[j] = mR[j] = -1;
             if constexpr (LOCAL) {
                 if (twoCam) {
@@ -1834,22 +1850,24 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
             }
         }
         if (base + FT_RS_ROWS < M) T = rs_fetch<LOCAL>(J, rb, cache, obsP, twoCam, min(i + FT_RS_ROWS, M - 1), sub);  // the next chunk's
-        rs_clear(S);
-        if (sub == 0) S.obs[row] = obsI ? 1 : 0;
+        if (sub == 0) S.obs[row] = obsI ? 1 : 0;  // (read behind the barrier of the second iteration)
+        if (threadIdx.x == 0) S.vote[1] = 0;      // (the second iteration's slot; the later ones are reset an iteration ahead)
         int r4[4] = {-1, -1, -1, -1};
-        for (int it = 0;; it++) {  // (uniform)
+        int it = 0;
+        for (;; it++) {  // (uniform)
             const bool useHash = it > 0;
-            if (it > 0) {  // the hash of the previous iteration's writes
-                if (it > 1) {
-                    rs_barrier();  // (every row has read the hash of the iteration before)
-                    rs_clear(S);
-                }
-                rs_barrier();
+            const int ht = it & 1;
+            // Two barriers per iteration behind the first: table ht is CLEAN here (cleared while the iteration before the last
+            // one - or the previous chunk - was inserting: a barrier ago at least), the rows file their writes of the previous
+            // iteration in it and clear the other table for the next iteration, barrier, everybody evaluates against it, barrier,
+            // the vote.  (Round 5: one table, cleared between two barriers of its own - four barriers per iteration.)
+            if (it > 0) {
                 if (act && sub < 4) {
                     const int kp = sub == 0 ? r4[0] : sub == 1 ? r4[1] : sub == 2 ? r4[2] : r4[3];
-                    if (kp >= 0) rs_insert(S, kp, row);
+                    if (kp >= 0) rs_insert(S, ht, kp, row);
                 }
-                if (threadIdx.x == 0) S.vote[(it + 1) & 1] = 0;
+                rs_clear(S, ht ^ 1);
+                if (threadIdx.x == 0) S.vote[(it + 1) % 3] = 0;  // (slot of the next iteration: last read two barriers ago)
                 rs_barrier();
             }
             int primL = -1, sideL = -1, primR = -1, sideR = -1;
@@ -1859,12 +1877,12 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
                     unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
 #pragma unroll
                     for (int j = 0; j < FT_RS_REG; j++)
-                        if (kL[j] != KEY_NONE && !rs_locked(S, useHash, key_idx(kL[j]), wL[j], key_held(kL[j]), row)) two_min_insert(k0, k1, kL[j]);
+                        if (kL[j] != KEY_NONE && !rs_locked(S, ht, useHash, key_idx(kL[j]), wL[j], key_held(kL[j]), row)) two_min_insert(k0, k1, kL[j]);
                     auto scan = [&](int from, int to) {
                         for (int t = from + sub; t < to; t += 16) {
                             const unsigned long long key = slotL[1 + t];
                             const int kp = key_idx(key);
-                            if (rs_locked(S, useHash, kp, rs_last_writer(lastW, kp), key_held(key), row)) continue;
+                            if (rs_locked(S, ht, useHash, kp, rs_last_writer<LWLDS>(lastW, kp), key_held(key), row)) continue;
                             two_min_insert(k0, k1, key);
                         }
                     };
@@ -1895,7 +1913,7 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
                 if (wantR && !skipRight) {
                     unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
                     // this point's own left-block side write precedes its right-block search
-                    auto lockedR = [&](int g, int lw, bool held) -> bool { return (g == sideL) ? obsI : rs_locked(S, useHash, g, lw, held, row); };
+                    auto lockedR = [&](int g, int lw, bool held) -> bool { return (g == sideL) ? obsI : rs_locked(S, ht, useHash, g, lw, held, row); };
 #pragma unroll
                     for (int j = 0; j < FT_RS_REG; j++)
                         if (kR[j] != KEY_NONE && !lockedR(key_idx(kR[j]) + F.Nleft, wR[j], key_held(kR[j]))) two_min_insert(k0, k1, kR[j]);
@@ -1903,7 +1921,7 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
                         for (int t = from + sub; t < to; t += 16) {
                             const unsigned long long key = slotR[1 + t];
                             const int g = key_idx(key) + F.Nleft;
-                            if (lockedR(g, rs_last_writer(lastW, g), key_held(key))) continue;
+                            if (lockedR(g, rs_last_writer<LWLDS>(lastW, g), key_held(key))) continue;
                             two_min_insert(k0, k1, key);
                         }
                     };
@@ -1931,13 +1949,13 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
                     unsigned long long m = KEY_NONE;
 #pragma unroll
                     for (int j = 0; j < FT_RS_REG; j++)
-                        if (kReg[j] != KEY_NONE && !rs_locked(S, useHash, key_idx(kReg[j]) + off, wReg[j], key_held(kReg[j]), row))
+                        if (kReg[j] != KEY_NONE && !rs_locked(S, ht, useHash, key_idx(kReg[j]) + off, wReg[j], key_held(kReg[j]), row))
                             m = kReg[j] < m ? kReg[j] : m;
                     auto scan = [&](int from, int to) {
                         for (int t = from + sub; t < to; t += 16) {
                             const unsigned long long key = slot[1 + t];
                             const int g = key_idx(key) + off;
-                            if (rs_locked(S, useHash, g, rs_last_writer(lastW, g), key_held(key), row)) continue;
+                            if (rs_locked(S, ht, useHash, g, rs_last_writer<LWLDS>(lastW, g), key_held(key), row)) continue;
                             m = key < m ? key : m;
                         }
                     };
@@ -1962,9 +1980,9 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
             const bool changed = act && (primL != r4[0] || sideL != r4[1] || primR != r4[2] || sideR != r4[3]);
             r4[0] = primL; r4[1] = sideL; r4[2] = primR; r4[3] = sideR;
             if (it == 0) continue;  // (the first iteration's results are what the second one starts from, changed or not)
-            if (changed && sub == 0) S.vote[it & 1] = 1;
+            if (changed && sub == 0) S.vote[it % 3] = 1;
             rs_barrier();
-            if (!S.vote[it & 1]) break;
+            if (!S.vote[it % 3]) break;
 #ifdef FT_RS_MAXIT
             if (it >= FT_RS_MAXIT) break;
 #endif
@@ -1981,8 +1999,14 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
         // different CUs and a workgroup-scope release becomes a real wait); the build refuses tgsplit (csrc/Makefile: check-tgsplit,
         // tests/test_build_flags.py - the compiler defines no macro a static_assert could test).  An
         // agent-scope fence (__threadfence) would be safe everywhere and writes the L2 back, 30 us a time (EXPERIMENTS 10.7).
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
+        // The next chunk's second iteration files into table 1: dirty when this chunk ended in an odd iteration (an even one cleared it)
+        if (it & 1) rs_clear(S, 1);
+        // (LWLDS: the table is in LDS - an LDS-only barrier, and none of the above applies)
+        if constexpr (LWLDS) rs_barrier();
+        else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+        }
     }
     // resolved: every flag word of the frame reads "converged"
     int *flags = rb(J.flags);
@@ -2573,10 +2597,16 @@ int ft_launch_frustum_batch(hipStream_t st, void *arena, const FtBatchJob *jobs,
 }
 
 // everything behind the first pass of a batch in one launch (k_resolve_batch): a workgroup per frame
-int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, float nnRatio) {
+int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, float nnRatio, int sharedInts) {
     if (nFrames <= 0) return FT_OK;
-    if (local) hipLaunchKernelGGL(k_resolve_batch<true>, dim3(nFrames), dim3(FT_RS_ROWS * 16), 0, st, jobs, rebase_of(arena), nnRatio);
-    else hipLaunchKernelGGL(k_resolve_batch<false>, dim3(nFrames), dim3(FT_RS_ROWS * 16), 0, st, jobs, rebase_of(arena), nnRatio);
+    const size_t sh = sizeof(int) * (size_t)sharedInts;  // the last-writer table of the largest frame; 0: frames beyond the LDS
+    if (sharedInts > 0) {
+        if (local) hipLaunchKernelGGL((k_resolve_batch<true, true>), dim3(nFrames), dim3(FT_RS_ROWS * 16), sh, st, jobs, rebase_of(arena), nnRatio);
+        else hipLaunchKernelGGL((k_resolve_batch<false, true>), dim3(nFrames), dim3(FT_RS_ROWS * 16), sh, st, jobs, rebase_of(arena), nnRatio);
+    } else {
+        if (local) hipLaunchKernelGGL((k_resolve_batch<true, false>), dim3(nFrames), dim3(FT_RS_ROWS * 16), 0, st, jobs, rebase_of(arena), nnRatio);
+        else hipLaunchKernelGGL((k_resolve_batch<false, false>), dim3(nFrames), dim3(FT_RS_ROWS * 16), 0, st, jobs, rebase_of(arena), nnRatio);
+    }
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

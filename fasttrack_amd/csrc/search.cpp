@@ -1360,7 +1360,7 @@ int callResolve(ft_tracked_batch *tb, FtBatchCall &c) {
     hipStream_t st = tb->stream;
     const bool local = c.kind == 2;
     tb->evt.begin(ctx->kernelTiming, local ? "kernel.resolve_batch(local map)" : "kernel.resolve_batch(last frame)", st);
-    int r = ft_launch_resolve_batch(st, tb->d_arena, c.dJobs, c.n, local ? 1 : 0, c.nnRatio);
+    int r = ft_launch_resolve_batch(st, tb->d_arena, c.dJobs, c.n, local ? 1 : 0, c.nnRatio, c.shInts <= 12288 ? c.shInts : 0);
     tb->evt.end(ctx->kernelTiming, st);
     // the writes of the frames it resolved, replayed right behind it (a frame it gave up on waits for the passes)
     tb->evt.begin(ctx->kernelTiming, local ? "kernel.replay_batch(local map)" : "kernel.replay_batch(last frame)", st);

@@ -39,8 +39,8 @@ KERNELS = [
     ("kernels_octree.hip", "8k_octreeE", "k_octree"),
     ("kernels_match.hip", "14k_stereo_matchE", "k_stereo_match"),
     ("kernels_search.hip", "19k_fisheye_2nn_batchE", "k_fisheye_2nn_batch"),
-    ("kernels_search.hip", "15k_resolve_batchILb0EE", "k_resolve_batch<false>"),
-    ("kernels_search.hip", "15k_resolve_batchILb1EE", "k_resolve_batch<true>"),
+    ("kernels_search.hip", "15k_resolve_batchILb0ELb1EE", "k_resolve_batch<false>"),
+    ("kernels_search.hip", "15k_resolve_batchILb1ELb1EE", "k_resolve_batch<true>"),
     ("kernels_search.hip", "19k_search_last_firstE", "k_search_last_first"),
     ("kernels_search.hip", "20k_search_local_firstE", "k_search_local_first"),
 ]
