@@ -187,6 +187,10 @@ const char *ft_debug_env(const char *name);  // FT_DEBUG_* aids only (context.cp
 // l0: device array [batch] of level-0 pointers; pyr: base of the slot pyramids
 int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                       uint8_t *pyr, const FtTap *taps, int alignedLoads, int rowsKernel);
+// the cells a k_fast_cells launch covers: up to two runs of consecutive cells of the per-image cell table
+struct FtCellRanges {
+    int lo0, n0, lo1, n1;
+};
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
                          uint32_t *stage, int ordered, const FtCellRec *cellTab);

@@ -564,7 +564,7 @@ template <int TP, bool ORDERED>
 __global__ __launch_bounds__(64, FC_WAVES_PER_EU) void k_fast_cells(FtGeom g, const uint8_t *const *l0, int l0pitch, const uint8_t *pyr,
                                                    int iniTh, int minTh, int alignedLoads, int *cellCount,
                                                    uint32_t *stage, const FtCellRec *cellTab, FtSlotGrid sg, int dbg, int tileBytes,
-                                                   int scoreBytesMax) {
+                                                   int scoreBytesMax, FtCellRanges cr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
     int slot = blockIdx.y, cellSg = 0;
@@ -576,8 +576,11 @@ __global__ __launch_bounds__(64, FC_WAVES_PER_EU) void k_fast_cells(FtGeom g, co
     // the pyramid kernel wrote for that image.  Smaller launches deal runs of FC_XCD_RUN consecutive cells round-robin
     // to the XCDs, so that at least horizontal neighbours share an L2 while all XCDs stay busy on the few images.
     const int j = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
-    const int cell = sg.xcdMap ? cellSg : ((j / FC_XCD_RUN) * 8 + xcd) * FC_XCD_RUN + (j % FC_XCD_RUN);
-    if (cell >= g.totalCells) return;
+    // the launch's cells: one or two runs of consecutive cells of the image's cell table (ft_launch_fast_cells: the levels whose
+    // tiles fit this variant's pitch)
+    const int cj = sg.xcdMap ? cellSg : ((j / FC_XCD_RUN) * 8 + xcd) * FC_XCD_RUN + (j % FC_XCD_RUN);
+    if (cj >= cr.n0 + cr.n1) return;
+    const int cell = cj < cr.n0 ? cr.lo0 + cj : cr.lo1 + (cj - cr.n0);
     // the cell's record, built with the extractor: origin, tile size, level, source and staging offsets in one scalar load
     const FtCellRec rec = cellTab[cell];
     const int iniX = (int)(rec.origin & 0xffffu), iniY = (int)(rec.origin >> 16);
@@ -1649,40 +1652,109 @@ int ft_launch_pyramid(hipStream_t st, const FtGeom &g, int batch, const uint8_t 
     return FT_OK;
 }
 
+// LDS of a launch over the levels of `mask` at pitch TP (fixed-pitch variants: the largest tile and the largest score plane of
+// those levels; the any-size variant: the largest sum)
+static size_t fast_smem_of(const FtGeom &g, unsigned mask, int TP, int *tileBytes, int *scoreBytes) {
+    size_t mxTile = 0, mxScore = 0, mxSum = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const FtLevelGeom &L = g.lv[l];
+        if (!((mask >> l) & 1u) || L.nCols * L.nRows <= 0) continue;
+        const size_t t = (size_t)fc_tile_bytes(L.wCell, L.hCell, TP), sc = (size_t)fc_score_bytes(L.wCell, L.hCell, TP);
+        mxTile = std::max(mxTile, t);
+        mxScore = std::max(mxScore, sc);
+        mxSum = std::max(mxSum, t + sc);
+    }
+    if (tileBytes) *tileBytes = (int)mxTile;
+    if (scoreBytes) *scoreBytes = (int)mxScore;
+    return (TP ? mxTile + mxScore : mxSum) + fc_list_bytes();
+}
+
+// the cells of the levels of `mask` as runs of consecutive cells; false: more than two runs (or none)
+static bool fast_cell_ranges(const FtGeom &g, unsigned mask, FtCellRanges &cr) {
+    int runs = 0, lo[2] = {0, 0}, n[2] = {0, 0};
+    bool open = false;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int cells = g.lv[l].nCols * g.lv[l].nRows;
+        if (cells <= 0) continue;  // (no cells: the level neither starts nor ends a run)
+        if ((mask >> l) & 1u) {
+            if (!open) {
+                if (runs == 2) return false;
+                lo[runs] = g.lv[l].cellBase;
+                n[runs] = 0;
+                runs++;
+                open = true;
+            }
+            n[runs - 1] += cells;
+        } else {
+            open = false;
+        }
+    }
+    cr.lo0 = lo[0]; cr.n0 = n[0]; cr.lo1 = lo[1]; cr.n1 = n[1];
+    return runs > 0;
+}
+
 int ft_launch_fast_cells(hipStream_t st, const FtGeom &g, int batch, const uint8_t *const *l0, int l0pitch,
                          const uint8_t *pyr, int iniTh, int minTh, int alignedLoads, int *cellCount,
                          uint32_t *stage, int ordered, const FtCellRec *cellTab) {
     if (g.totalCells == 0) return FT_OK;  // every level is too small for a 35-px cell: no candidates
-    const int runBlock = 8 * FC_XCD_RUN;  // grid padded to whole rounds of the XCD mapping
-    dim3 grid(((g.totalCells + runBlock - 1) / runBlock) * runBlock, batch, 1), block(64, 1, 1);
-    const size_t smem = ft_fast_smem_bytes(g);
-    const int TP = fast_tile_pitch(g);
-    // LDS carve of the fixed-pitch variants: the largest tile and score plane of any level (the allocation is sized by them)
-    int tileBytes = 0, scoreBytes = 0;
-    for (int l = 0; l < g.nlevels; l++) {
-        tileBytes = std::max(tileBytes, fc_tile_bytes(g.lv[l].wCell, g.lv[l].hCell, TP));
-        scoreBytes = std::max(scoreBytes, fc_score_bytes(g.lv[l].wCell, g.lv[l].hCell, TP));
-    }
     typedef void (*FastFn)(FtGeom, const uint8_t *const *, int, const uint8_t *, int, int, int, int *, uint32_t *, const FtCellRec *,
-                           FtSlotGrid, int, int, int);
+                           FtSlotGrid, int, int, int, FtCellRanges);
     static const int dbg = ft_debug_env("FT_DEBUG_FAST") ? atoi(ft_debug_env("FT_DEBUG_FAST")) : 0;
-    FtSlotGrid sg;
-    sg.blocksPerSlot = 0; sg.batch = batch; sg.xcdMap = 0; sg.magic = 0;
-    if (batch >= 8) sg = ft_slot_grid(g.totalCells, batch, grid);  // image -> XCD; smaller launches keep the cell-run mapping
-    const FastFn fn = TP == 48 ? (ordered ? k_fast_cells<48, true> : k_fast_cells<48, false>)
-                      : TP == 64 ? (ordered ? k_fast_cells<64, true> : k_fast_cells<64, false>)
-                                 : k_fast_cells<0, true>;  // any-size cells: the linear pass is ordered anyway
-    if (smem > 64 * 1024)  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
-        FT_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     static const bool occDbg = ft_debug_env("FT_DEBUG_OCC") != nullptr;  // resident workgroups per CU as the runtime computes them
-    if (occDbg) {
-        int nb = 0;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fn, 64, smem);
-        fprintf(stderr, "[ft] k_fast_cells<%d,%d>: %zu B of LDS per wave, %d waves per CU\n", TP, ordered, smem, nb);
+    static const bool noSplit = ft_debug_env("FT_DEBUG_FAST_NOSPLIT") != nullptr;  // A/B aid: one launch at the widest pitch
+    const unsigned all = (1u << g.nlevels) - 1u;
+    // One launch per tile pitch.  The pitch of a launch is that of its widest cell (every ring offset an instruction
+    // immediate), and with it the LDS per wave: an image size whose small levels need 64 bytes (512 x 512: cells of 44 and 47
+    // pixels on levels 5 and 6, 25 of 490 cells) used to put EVERY cell at 64 - 19 waves per CU instead of 25.  Now the
+    // levels that fit 48 bytes run at 48 and the few others in a launch of their own (the same stream: no ordering needed,
+    // the cells write disjoint staging slots).
+    unsigned mask48 = 0, mask64 = 0, maskAny = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        if (g.lv[l].nCols * g.lv[l].nRows <= 0) continue;
+        const int need = g.lv[l].wCell + 9;
+        (need <= 48 ? mask48 : need <= 64 ? mask64 : maskAny) |= 1u << l;
     }
-    for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
-        hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab, sg, dbg,
-                           tileBytes, scoreBytes);
+    struct Part { unsigned mask; int TP; };
+    Part parts[3];
+    int nParts = 0;
+    FtCellRanges probe;
+    const bool splittable = !noSplit && !maskAny && mask48 && mask64 && fast_cell_ranges(g, mask48, probe) && fast_cell_ranges(g, mask64, probe);
+    if (splittable) {
+        parts[nParts++] = {mask48, 48};
+        parts[nParts++] = {mask64, 64};
+    } else {
+        parts[nParts++] = {all, fast_tile_pitch(g)};
+    }
+    const int runBlock = 8 * FC_XCD_RUN;  // grid padded to whole rounds of the XCD mapping
+    for (int pi = 0; pi < nParts; pi++) {
+        const int TP = parts[pi].TP;
+        FtCellRanges cr;
+        if (!fast_cell_ranges(g, parts[pi].mask, cr)) {  // (the unsplit launch: all cells, one run)
+            cr.lo0 = 0; cr.n0 = g.totalCells; cr.lo1 = 0; cr.n1 = 0;
+        }
+        if (nParts == 1) { cr.lo0 = 0; cr.n0 = g.totalCells; cr.lo1 = 0; cr.n1 = 0; }
+        const int nCells = cr.n0 + cr.n1;
+        // LDS carve of the fixed-pitch variants: the largest tile and score plane of the launch's levels
+        int tileBytes = 0, scoreBytes = 0;
+        const size_t smem = fast_smem_of(g, parts[pi].mask, TP, &tileBytes, &scoreBytes);
+        dim3 grid(((nCells + runBlock - 1) / runBlock) * runBlock, batch, 1), block(64, 1, 1);
+        FtSlotGrid sg;
+        sg.blocksPerSlot = 0; sg.batch = batch; sg.xcdMap = 0; sg.magic = 0;
+        if (batch >= 8) sg = ft_slot_grid(nCells, batch, grid);  // image -> XCD; smaller launches keep the cell-run mapping
+        const FastFn fn = TP == 48 ? (ordered ? k_fast_cells<48, true> : k_fast_cells<48, false>)
+                          : TP == 64 ? (ordered ? k_fast_cells<64, true> : k_fast_cells<64, false>)
+                                     : k_fast_cells<0, true>;  // any-size cells: the linear pass is ordered anyway
+        if (smem > 64 * 1024)  // very wide cells (tiny images with one cell column): raise the dynamic LDS limit
+            FT_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (occDbg) {
+            int nb = 0;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fn, 64, smem);
+            fprintf(stderr, "[ft] k_fast_cells<%d,%d>: %d cells per image, %zu B of LDS per wave, %d waves per CU\n", TP, ordered, nCells, smem, nb);
+        }
+        for (int rep = ft_debug_repeat("fast"); rep > 0; rep--)
+            hipLaunchKernelGGL(fn, grid, block, smem, st, g, l0, l0pitch, pyr, iniTh, minTh, alignedLoads, cellCount, stage, cellTab, sg, dbg,
+                               tileBytes, scoreBytes, cr);
+    }
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
