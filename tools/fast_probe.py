@@ -6,7 +6,7 @@ import sys, os, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from fasttrack_amd import orb, synth
 ctx = orb.Context(0)
-w, h, B = 1280, 720, 256
+w, h, B = int(os.environ.get("FP_W", "1280")), int(os.environ.get("FP_H", "720")), int(os.environ.get("FP_B", "256"))  # FP_W=512 FP_H=512: configs[3]'s images
 mosaic = int(os.environ.get("FP_MOSAIC", "0"))  # dense-corner frames instead (bench.py --mosaic)
 base = [synth.make_mosaic_pair(w, h, seed=s, block=mosaic)[0] if mosaic else synth.make_image(w, h, seed=s) for s in range(8)]
 arr = np.stack([np.roll(base[b % 8], (29 * (b // 8), 53 * (b // 8)), (0, 1)) for b in range(B)])
