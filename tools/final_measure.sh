@@ -22,6 +22,10 @@ done
 # the traffic / marginal costs of the default workload are what bench.py reports beside its live numbers
 mkdir -p profiles
 cp $F/${R}_traffic.json $F/${R}_marginal_costs.json profiles/ 2>/dev/null
+# the SQ instruction counts of the tracking leg's kernels (bench.py prices k_resolve_batch and the leg's extraction with them)
+bash tools/pmc_tracking_batch.sh final/trk_sq 128 > $F/trk_sq.log 2>&1
+cp $F/trk_sq/tracking_sq.json profiles/${R}_tracking_sq.json 2>/dev/null
+cp $F/trk_sq/tracking_sq.json $F/${R}_tracking_sq.json 2>/dev/null
 python3 bench.py > $F/${R}_bench_line.json 2> $F/bench_line.err
 python3 bench.py --steps 300 --warmup 10 --no-cpu-baseline --no-host-in --no-workloads > $F/${R}_bench_long.json 2>/dev/null
 python3 tools/bench_latency.py > $F/${R}_latency.json 2>/dev/null
