@@ -260,15 +260,11 @@ typedef unsigned ft_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned udot2_u16(unsigned a, unsigned b) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(ft_us2, a), __builtin_bit_cast(ft_us2, b), 0u, false);
 }
-// b (wave-uniform, < 2^24) * a (< 2^24) [+ c]: full-rate 24-bit multiplies with the uniform factor as scalar operand
-__device__ __forceinline__ unsigned umul24_su(unsigned bUniform, unsigned a) {
+// (b * a) >> 16 for a wave-uniform b < 2^11 handed in as b << 16 and a < 2^16: the high half of a 32 x 32-bit product - one
+// instruction where a 24-bit multiply and a shift took two
+__device__ __forceinline__ unsigned umulhi_su(unsigned bShifted16, unsigned a) {
     unsigned r;
-    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(bUniform), "v"(a));
-    return r;
-}
-__device__ __forceinline__ unsigned umad24_su(unsigned bUniform, unsigned a, unsigned c) {
-    unsigned r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(bUniform), "v"(a), "v"(c));
+    asm("v_mul_hi_u32 %0, %1, %2" : "=v"(r) : "s"(bShifted16), "v"(a));
     return r;
 }
 template <bool AREA>
@@ -323,7 +319,7 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
         } else {
             const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)rowW0, r), w1 = (unsigned)__builtin_amdgcn_readlane((int)rowW1, r);
             sy0 = (int)(w0 & 0xffffu); sy1 = (int)(w0 >> 16);
-            b0 = w1 & 0xffffu; b1 = w1 >> 16;
+            b0 = w1 << 16; b1 = w1 & 0xffff0000u;  // the weights as b << 16 (umulhi_su)
         }
     };
     int jr = 0, sy0, sy1;
@@ -343,7 +339,6 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
     unsigned dOff = 0;
     const unsigned laneSrc = (unsigned)base, laneDst = (unsigned)dx;
     const bool store2 = dx + 1 < D.w, store1 = dx < D.w;
-    const unsigned round2 = 0x20000u;
     // PR_PF source rows are in flight ahead of the one being used (a ring of registers, the loop unrolled over it): a
     // wave's life is a chain of dependent row loads, and a store counts on the same counter as a load, so with one row
     // in flight every wait would also wait for the stores just issued.
@@ -387,9 +382,11 @@ __global__ __launch_bounds__(64) void k_pyr_rows(FtGeom g, int level, const uint
                 if constexpr (AREA) {
                     oA = (hpA + hcA + 2u) >> 2; oB = (hpB + hcB + 2u) >> 2;
                 } else {
-                    // ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2; the + 2 rides in the first product
-                    oA = ((umad24_su(b0, hpA, round2) >> 16) + (umul24_su(b1, hcA) >> 16)) >> 2;
-                    oB = ((umad24_su(b0, hpB, round2) >> 16) + (umul24_su(b1, hcB) >> 16)) >> 2;
+                    // ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2: each product's high half in one instruction
+                    // (v_mul_hi_u32 with the weight as b << 16), one three-operand add, one shift - four instructions per
+                    // output value where round 5 had six (24-bit multiply-add, shift, multiply, shift, add, shift)
+                    oA = (umulhi_su(b0, hpA) + umulhi_su(b1, hcA) + 2u) >> 2;
+                    oB = (umulhi_su(b0, hpB) + umulhi_su(b1, hcB) + 2u) >> 2;
                 }
                 unsigned offD = laneDst + dOff;
                 asm volatile("" : "+v"(offD));
