@@ -1655,23 +1655,33 @@ __global__ __launch_bounds__(256) void k_search_last_lean(const FtBatchJob *__re
 // It reads the candidate lists the first pass filed; a point whose list is not usable (more candidates than the cache holds)
 // makes the workgroup give up on its frame: the frame's flag words stay as the first pass left them, the host sees it and
 // continues with the passes above for such frames (resolved frames are inert there: all their flag words read "converged").
-#define FT_RS_ROWS 64    // points per chunk: a workgroup of 1024 lanes
-#define FT_RS_SLOTS 512  // hash slots (<= 256 writes per chunk)
-#define FT_RS_REG 3      // keys of a list's head a lane keeps in registers (x 16 lanes = FT_CACHE_HEAD_MAX)
+#ifndef FT_RS_W
+#define FT_RS_W 16                       // lanes per point (a GROUP of lanes inside a DPP row): 16 or 8
+#endif
+#define FT_RS_LANES 1024                 // a workgroup
+#define FT_RS_ROWS (FT_RS_LANES / FT_RS_W)   // points per chunk: 64 (128 with 8 lanes per point)
+#define FT_RS_SLOTS (8 * FT_RS_ROWS)     // hash slots (<= 4 writes per point and chunk): a power of two
+#define FT_RS_REG (48 / FT_RS_W)         // keys of a list's head a lane keeps in registers (x FT_RS_W lanes = FT_CACHE_HEAD_MAX)
+#define FT_RS_MW (FT_RS_ROWS / 32)       // 32-bit words of a row mask
+static_assert((FT_RS_W == 8 || FT_RS_W == 16) && FT_RS_W * FT_RS_REG == FT_CACHE_HEAD_MAX, "k_resolve_batch: a point is 8 or 16 lanes");
+// (Round 6 measured 8 lanes per point - eight points per wave, 16 chunks of 128 points instead of 32 of 64: the last-frame
+// resolution took the same 0.24 ms, the local-map one 0.63 instead of 0.46 (th 15: 0.50 / 1.20 against 0.41 / 0.94) - twice the
+// points per chunk are more than twice the chunk: more of them collide inside it (more iterations), and six key registers per
+// lane and camera spill.  EXPERIMENTS 11.9.)
 struct RsShared {
     // two hash tables used alternately by the iterations of a chunk (iteration `it` reads table it & 1 and clears the other
     // one for its successor): keypoint -> rows of the chunk that write it (their results of the previous iteration)
     int kp[2][FT_RS_SLOTS];
-    unsigned lo[2][FT_RS_SLOTS], hi[2][FT_RS_SLOTS];
+    unsigned mask[2][FT_RS_MW][FT_RS_SLOTS];
     unsigned char obs[FT_RS_ROWS];  // Observations() > 0 of the chunk's points
     int vote[3];                    // "iteration it changed a result", slot it % 3
 };
-__device__ __forceinline__ unsigned rs_hash(int kp) { return ((unsigned)kp * 2654435761u) >> 23; }
+__device__ __forceinline__ unsigned rs_hash(int kp) { return ((unsigned)kp * 2654435761u) >> (32 - __builtin_ctz(FT_RS_SLOTS)); }
 __device__ __forceinline__ void rs_clear(RsShared &S, int t) {
-    for (int k = threadIdx.x; k < FT_RS_SLOTS; k += FT_RS_ROWS * 16) {
+    for (int k = threadIdx.x; k < FT_RS_SLOTS; k += FT_RS_LANES) {
         S.kp[t][k] = -1;
-        S.lo[t][k] = 0u;
-        S.hi[t][k] = 0u;
+#pragma unroll
+        for (int w = 0; w < FT_RS_MW; w++) S.mask[t][w][k] = 0u;
     }
 }
 // a barrier for what the workgroup exchanges through LDS: outstanding loads from memory (the next chunk's prefetch) stay outstanding
@@ -1687,8 +1697,7 @@ __device__ __forceinline__ void rs_insert(RsShared &S, int t, int kp, int row) {
         if (old == -1 || old == kp) break;
         h = (h + 1) & (FT_RS_SLOTS - 1);
     }
-    if (row < 32) atomicOr(&S.lo[t][h], 1u << row);
-    else atomicOr(&S.hi[t][h], 1u << (row - 32));
+    atomicOr(&S.mask[t][row >> 5][h], 1u << (row & 31));
 }
 // F.mvpMapPoints[kp] && ->Observations() > 0 as the point of row `row` sees it: the last writer in front of it - of this chunk
 // (hash table t; useHash = 0: the chunk's first iteration, no writes of the chunk yet) or, if none, of the chunks before (lw = lastW[kp]) -
@@ -1700,14 +1709,45 @@ __device__ __forceinline__ bool rs_locked(const RsShared &S, int t, bool useHash
             const int k = S.kp[t][h];
             if (k == -1) break;
             if (k == kp) {
-                const unsigned long long m = ((unsigned long long)S.lo[t][h] | ((unsigned long long)S.hi[t][h] << 32)) & ((1ull << row) - 1ull);
-                if (m) return S.obs[63 - __clzll((long long)m)] != 0;
+                // the highest row below `row` that writes the keypoint: the word of `row` cut off at its bit, then the words below
+                int w = row >> 5;
+                unsigned m = S.mask[t][w][h] & ((1u << (row & 31)) - 1u);
+                while (m == 0u && w > 0) m = S.mask[t][--w][h];
+                if (m) return S.obs[32 * w + 31 - __clz((int)m)] != 0;
                 break;
             }
             h = (h + 1) & (FT_RS_SLOTS - 1);
         }
     }
     return lw >= 0 ? (lw & 1) != 0 : held;
+}
+// minima / maxima over the FT_RS_W lanes of a point, in every lane of it: DPP steps that stay inside the group (lane pairs, quads,
+// halves of a row - and, for sixteen lanes, the row)
+__device__ __forceinline__ unsigned long long grp_min_u64(unsigned long long v) {
+#define FT_MIN64_STEP(ctrl)                                                                                   \
+    {                                                                                                         \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, ctrl, 0xF, 0xF, true); \
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v >> 32), ctrl, 0xF, 0xF, true);   \
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;                                     \
+        v = w < v ? w : v;                                                                                    \
+    }
+    FT_MIN64_STEP(0xB1) FT_MIN64_STEP(0x4E) FT_MIN64_STEP(0x141)
+    if constexpr (FT_RS_W == 16) FT_MIN64_STEP(0x140)
+#undef FT_MIN64_STEP
+    return v;
+}
+__device__ __forceinline__ int grp_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    if constexpr (FT_RS_W == 16) v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    return v;
+}
+__device__ __forceinline__ void grp_two_min(unsigned long long &k0, unsigned long long &k1) {
+    const unsigned long long m0 = grp_min_u64(k0);
+    const unsigned long long cand = (k0 == m0) ? k1 : k0;
+    k1 = grp_min_u64(cand);
+    k0 = m0;
 }
 // The last writers of the points in front of the running chunk, one word per keypoint of the frame.  LWLDS (round 6): the table
 // lives in the workgroup's LDS for the whole walk (F.N ints: 16 KB at configs[3]) - a chunk's publication is an LDS atomic and
@@ -1745,8 +1785,8 @@ __device__ __forceinline__ RsStatic rs_fetch(const FtBatchJob &J, const Rebase &
     T.metaR = twoCam ? slotR[0] : KEY_NONE;
 #pragma unroll
     for (int j = 0; j < FT_RS_REG; j++) {  // (whatever the lists' lengths: a key beyond a head is dropped when the meta word is there)
-        T.kL[j] = slotL[1 + sub + 16 * j];
-        T.kR[j] = twoCam ? slotR[1 + sub + 16 * j] : KEY_NONE;
+        T.kL[j] = slotL[1 + sub + FT_RS_W * j];
+        T.kR[j] = twoCam ? slotR[1 + sub + FT_RS_W * j] : KEY_NONE;
     }
     T.obs = obsP[i];
     T.levelR = -1;
@@ -1763,7 +1803,7 @@ __device__ __forceinline__ RsStatic rs_fetch(const FtBatchJob &J, const Rebase &
 }
 
 template <bool LOCAL, bool LWLDS>
-__global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, float nnRatio) {
+__global__ __launch_bounds__(FT_RS_LANES) void k_resolve_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, float nnRatio) {
     const FtBatchJob &J = jobs[blockIdx.x];
     if (J.nPoints <= 0) return;
     __shared__ RsShared S;
@@ -1771,12 +1811,12 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
     const FtDevFrame &F = J.F;
     const bool twoCam = F.Nleft != -1;
     const int M = LOCAL ? J.P.M : J.L.N;
-    const int row = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int row = threadIdx.x / FT_RS_W, sub = threadIdx.x % FT_RS_W;
     int *res0 = rb(J.res), *res1 = res0 + 4 * (size_t)J.nPoints;
     // (HBM form: buffer 0 of the list heads, all -1 after k_fill_claims_batch and not written by a first pass)
     int *lastW = LWLDS ? rs_lw : rb(J.head);
     if constexpr (LWLDS)
-        for (int k = threadIdx.x; k < F.N; k += FT_RS_ROWS * 16) rs_lw[k] = -1;  // (the pre-scan's barrier below orders it)
+        for (int k = threadIdx.x; k < F.N; k += FT_RS_LANES) rs_lw[k] = -1;  // (the pre-scan's barrier below orders it)
     const int *obsP = rb(J.obs);
     const unsigned long long *cache = rb(J.cache);
     const int *l2r = rb(F.l2r), *r2l = rb(F.r2l);
@@ -1789,7 +1829,7 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
     // (Round 5 tested chunk by chunk: a list beyond the cache in a later chunk left the earlier chunks published.)
     {
         bool unusable = false;
-        for (int p = threadIdx.x; p < M; p += FT_RS_ROWS * 16) {
+        for (int p = threadIdx.x; p < M; p += FT_RS_LANES) {
             const unsigned long long *slotL = cache + (size_t)p * FT_CACHE_WORDS;
             const unsigned long long mL = slotL[0], mR = twoCam ? slotL[FT_CACHE_CAP + 1] : KEY_NONE;
             int nL = 0, nR = 0;
@@ -1834,8 +1874,8 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
         int wL[FT_RS_REG], wR[FT_RS_REG], mL[FT_RS_REG], mR[FT_RS_REG];  // last writers; the keypoints' entries of the match tables
 #pragma unroll
         for (int j = 0; j < FT_RS_REG; j++) {
-            kL[j] = (sub + 16 * j < headL) ? T.kL[j] : KEY_NONE;
-            kR[j] = (sub + 16 * j < headR) ? T.kR[j] : KEY_NONE;
+            kL[j] = (sub + FT_RS_W * j < headL) ? T.kL[j] : KEY_NONE;
+            kR[j] = (sub + FT_RS_W * j < headR) ? T.kR[j] : KEY_NONE;
         }
 #pragma unroll
         for (int j = 0; j < FT_RS_REG; j++) {
@@ -1879,18 +1919,18 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
                     for (int j = 0; j < FT_RS_REG; j++)
                         if (kL[j] != KEY_NONE && !rs_locked(S, ht, useHash, key_idx(kL[j]), wL[j], key_held(kL[j]), row)) two_min_insert(k0, k1, kL[j]);
                     auto scan = [&](int from, int to) {
-                        for (int t = from + sub; t < to; t += 16) {
+                        for (int t = from + sub; t < to; t += FT_RS_W) {
                             const unsigned long long key = slotL[1 + t];
                             const int kp = key_idx(key);
                             if (rs_locked(S, ht, useHash, kp, rs_last_writer<LWLDS>(lastW, kp), key_held(key), row)) continue;
                             two_min_insert(k0, k1, key);
                         }
                     };
-                    if (headL > 16 * FT_RS_REG) scan(16 * FT_RS_REG, headL);
-                    row_two_min(k0, k1);
+                    if (headL > FT_RS_W * FT_RS_REG) scan(FT_RS_W * FT_RS_REG, headL);
+                    grp_two_min(k0, k1);
                     if (k1 == KEY_NONE && headL < nL) {  // fewer than two unlocked keys in the head: the rest of the list decides
                         scan(headL, nL);
-                        row_two_min(k0, k1);
+                        grp_two_min(k0, k1);
                     }
                     int bd = 256, bd2 = 256, bl = -1, bl2 = -1, bi = -1;
                     if (k0 != KEY_NONE) { bd = key_dist(k0); bi = key_idx(k0); bl = key_octave(k0); }
@@ -1903,7 +1943,7 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
                                 int m = INT_MIN;
 #pragma unroll
                                 for (int j = 0; j < FT_RS_REG; j++) m = kL[j] == k0 ? mL[j] : m;
-                                m = row_max_i32(m);
+                                m = grp_max_i32(m);
                                 if (m == INT_MIN) m = l2r[bi];
                                 if (m != -1) sideL = m + F.Nleft;
                             }
@@ -1918,18 +1958,18 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
                     for (int j = 0; j < FT_RS_REG; j++)
                         if (kR[j] != KEY_NONE && !lockedR(key_idx(kR[j]) + F.Nleft, wR[j], key_held(kR[j]))) two_min_insert(k0, k1, kR[j]);
                     auto scan = [&](int from, int to) {
-                        for (int t = from + sub; t < to; t += 16) {
+                        for (int t = from + sub; t < to; t += FT_RS_W) {
                             const unsigned long long key = slotR[1 + t];
                             const int g = key_idx(key) + F.Nleft;
                             if (lockedR(g, rs_last_writer<LWLDS>(lastW, g), key_held(key))) continue;
                             two_min_insert(k0, k1, key);
                         }
                     };
-                    if (headR > 16 * FT_RS_REG) scan(16 * FT_RS_REG, headR);
-                    row_two_min(k0, k1);
+                    if (headR > FT_RS_W * FT_RS_REG) scan(FT_RS_W * FT_RS_REG, headR);
+                    grp_two_min(k0, k1);
                     if (k1 == KEY_NONE && headR < nR) {
                         scan(headR, nR);
-                        row_two_min(k0, k1);
+                        grp_two_min(k0, k1);
                     }
                     int bdr = 256, bd2r = 256, blr = -1, bl2r = -1, bir = -1;
                     if (k0 != KEY_NONE) { bdr = key_dist(k0); bir = key_idx(k0); blr = key_octave(k0); }
@@ -1938,7 +1978,7 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
                         int m = INT_MIN;
 #pragma unroll
                         for (int j = 0; j < FT_RS_REG; j++) m = kR[j] == k0 ? mR[j] : m;
-                        m = row_max_i32(m);
+                        m = grp_max_i32(m);
                         if (m == INT_MIN) m = r2l[bir];
                         if (m != -1) sideR = m;
                         primR = bir + F.Nleft;
@@ -1952,19 +1992,19 @@ __global__ __launch_bounds__(FT_RS_ROWS * 16) void k_resolve_batch(const FtBatch
                         if (kReg[j] != KEY_NONE && !rs_locked(S, ht, useHash, key_idx(kReg[j]) + off, wReg[j], key_held(kReg[j]), row))
                             m = kReg[j] < m ? kReg[j] : m;
                     auto scan = [&](int from, int to) {
-                        for (int t = from + sub; t < to; t += 16) {
+                        for (int t = from + sub; t < to; t += FT_RS_W) {
                             const unsigned long long key = slot[1 + t];
                             const int g = key_idx(key) + off;
                             if (rs_locked(S, ht, useHash, g, rs_last_writer<LWLDS>(lastW, g), key_held(key), row)) continue;
                             m = key < m ? key : m;
                         }
                     };
-                    if (head > 16 * FT_RS_REG) scan(16 * FT_RS_REG, head);
-                    m = row_min_u64(m);
+                    if (head > FT_RS_W * FT_RS_REG) scan(FT_RS_W * FT_RS_REG, head);
+                    m = grp_min_u64(m);
                     // the head of the list first (cache_partition): an unlocked key there is smaller than every key behind it
                     if (m == KEY_NONE && head < n) {
                         scan(head, n);
-                        m = row_min_u64(m);
+                        m = grp_min_u64(m);
                     }
                     return m;
                 };
@@ -2601,11 +2641,11 @@ int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs,
     if (nFrames <= 0) return FT_OK;
     const size_t sh = sizeof(int) * (size_t)sharedInts;  // the last-writer table of the largest frame; 0: frames beyond the LDS
     if (sharedInts > 0) {
-        if (local) hipLaunchKernelGGL((k_resolve_batch<true, true>), dim3(nFrames), dim3(FT_RS_ROWS * 16), sh, st, jobs, rebase_of(arena), nnRatio);
-        else hipLaunchKernelGGL((k_resolve_batch<false, true>), dim3(nFrames), dim3(FT_RS_ROWS * 16), sh, st, jobs, rebase_of(arena), nnRatio);
+        if (local) hipLaunchKernelGGL((k_resolve_batch<true, true>), dim3(nFrames), dim3(FT_RS_LANES), sh, st, jobs, rebase_of(arena), nnRatio);
+        else hipLaunchKernelGGL((k_resolve_batch<false, true>), dim3(nFrames), dim3(FT_RS_LANES), sh, st, jobs, rebase_of(arena), nnRatio);
     } else {
-        if (local) hipLaunchKernelGGL((k_resolve_batch<true, false>), dim3(nFrames), dim3(FT_RS_ROWS * 16), 0, st, jobs, rebase_of(arena), nnRatio);
-        else hipLaunchKernelGGL((k_resolve_batch<false, false>), dim3(nFrames), dim3(FT_RS_ROWS * 16), 0, st, jobs, rebase_of(arena), nnRatio);
+        if (local) hipLaunchKernelGGL((k_resolve_batch<true, false>), dim3(nFrames), dim3(FT_RS_LANES), 0, st, jobs, rebase_of(arena), nnRatio);
+        else hipLaunchKernelGGL((k_resolve_batch<false, false>), dim3(nFrames), dim3(FT_RS_LANES), 0, st, jobs, rebase_of(arena), nnRatio);
     }
     FT_HIP(hipGetLastError());
     return FT_OK;
