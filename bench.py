@@ -333,10 +333,12 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
     exL = ex2
     sf = np.asarray(exL.GetScaleFactors(), np.float32)
     pairs = [synth.make_planes_pair(w, h, seed=7000 + i) for i in range(D)]
-    tf = orb.TrackedFrame(ctx, max_keypoints=2 * exL.max_keypoints + 64, max_points=max(M, exL.max_keypoints) + 64)
+    # Round 6: the frame goes through the batch API with ONE frame (ft_tracked_batch_*): the keypoints stay where the extractor
+    # left them (bind_fisheye: lapping-area order, left <-> right matching and grids on the device - no fisheye-match call, no
+    # upload of the frame), the point arrays sit in pinned memory, the searches' writes are replayed on the device.
+    tb = orb.TrackedBatch(ctx, max_frames=1, max_keypoints=2 * exL.max_keypoints + 64, max_points=max(M, exL.max_keypoints) + 64, pinned=True)
 
-    part = {"extract_left_right": 0.0, "fisheye_match": 0.0, "frame_marshalling(python)": 0.0, "upload": 0.0,
-            "search_last_frame": 0.0, "track_local_map": 0.0}
+    part = {"extract_left_right": 0.0, "bind_fisheye (order, match, grids)": 0.0, "search_last_frame": 0.0, "track_local_map": 0.0}
 
     def clock(name, t0):
         t1 = time.perf_counter()
@@ -344,43 +346,48 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
         return t1
 
     def extract(i):
-        t = time.perf_counter()
         # both cameras in ONE call (a batch of two through the captured graph), as Frame's two extraction threads overlap them
         # in the reference (Frame.cc:1144-1147); the lapping areas of the two cameras are the same in TUM-VI.yaml
-        (kL, dL, _), (kR, dR, _) = ex2.extract_batch([pairs[i][0], pairs[i][1]], lap)
-        t = clock("extract_left_right", t)
+        return ex2.extract_batch([pairs[i][0], pairs[i][1]], lap)
+
+    def host_view(kL, dL, kR, dR):
+        """the frame as a host FrameView (fisheye matching through the one-shot entry point): count_compares' queries only"""
         m = orb.KernelController.launchFisheyeStereoMatchKernel(ctx, dL, dR)
-        t = clock("fisheye_match", t)
         l2r = np.ascontiguousarray(m["matches"], np.int32)
         r2l = np.full(len(kR), -1, np.int32)
         ok = l2r >= 0
         r2l[l2r[ok]] = np.nonzero(ok)[0].astype(np.int32)
-        F = orb.FrameView(keys=kL, keys_right=kR, descriptors=np.concatenate([dL, dR]), scale_factors=sf, bounds=sc.frame_bounds(w, h),
-                          left_to_right=l2r, right_to_left=r2l, cam_model=1, cam=cam, Trl=Trl)
-        clock("frame_marshalling(python)", t)
-        return kL, dL, kR, dR, F
-    # per distinct frame: the last frame's points and the local map, built from the frame's own keypoints
-    scen = []
+        return orb.FrameView(keys=kL, keys_right=kR, descriptors=np.concatenate([dL, dR]), scale_factors=sf, bounds=sc.frame_bounds(w, h),
+                             left_to_right=l2r, right_to_left=r2l, cam_model=1, cam=cam, Trl=Trl)
+    # per distinct frame: the last frame's points and the local map, built from the frame's own keypoints (SURVEY 8d); the frame
+    # constants and the marshalled point arrays (pinned) once - extraction is deterministic, the counts do not change
+    scen, metas, pl_last, pl_local, hostF = [], [], [], [], []
     for i in range(D):
-        kL, dL, kR, dR, F = extract(i)
+        (kL, dL, _), (kR, dR, _) = extract(i)
         depth = np.zeros(len(kL), np.float32)
         last, Tcw_last = sc.last_frame_scenario(kL, dL, None, depth, intr, w, h, seed=40 + i)
         pts, Rcw, tcw = sc.map_points_scenario(kL, dL, depth, intr, NLEVELS, sf, 90 + i, M=M)
         scen.append((last, Tcw_last, pts, Rcw, tcw))
+        metas.append(tb.prepare_frames([orb.FrameView(keys=kL, keys_right=kR, descriptors=np.zeros((len(kL) + len(kR), 32), np.uint8), scale_factors=sf,
+                                                     bounds=sc.frame_bounds(w, h), left_to_right=np.zeros(max(len(kL), 1), np.int32),
+                                                     right_to_left=np.zeros(max(len(kR), 1), np.int32), cam_model=1, cam=cam, Trl=Trl)]))
+        pl_last.append(tb.prepare_last([last], [Tcw_last], ctx=ctx))
+        pl_local.append(tb.prepare_local([orb.make_pose(Rcw, tcw, TLR)], [pts], ctx=ctx))
+        hostF.append(host_view(kL, dL, kR, dR))
 
     def frame(i, th):
-        kL, dL, kR, dR, F = extract(i)
-        last, Tcw_last, pts, Rcw, tcw = scen[i]
         t = time.perf_counter()
-        tf.upload(F)
-        t = clock("upload", t)
-        a = tf.search_last_frame(last, Tcw_last, th)
+        (kL, dL, _), (kR, dR, _) = extract(i)
+        t = clock("extract_left_right", t)
+        tb.bind_fisheye(ex2, ex2, metas[i], lap, lap, slot0=0, slot0_right=1, want_tables=False)
+        t = clock("bind_fisheye (order, match, grids)", t)
+        a = tb.search_last_frame(pl_last[i], th=th)[0]
         t = clock("search_last_frame", t)
-        b = tf.track_local_map(orb.make_pose(Rcw, tcw, TLR), pts, 0.5, LOG_SF, th)
+        b = tb.track_local_map(pl_local[i], viewing_cos_limit=0.5, log_scale_factor=LOG_SF, th=th)[0]
         clock("track_local_map", t)
-        return len(kL), len(kR), a, b, F
+        return len(kL), len(kR), a, b, hostF[i]
     out = {"metric": "frames/sec extract + SearchByProjection (last frame, local map)", "unit": "frames/s", "image": [w, h], "nfeatures": nf,
-           "camera": "KannalaBrandt8 stereo rig, lapping areas [0, 511]", "local_map_points": M, "mode": "one frame at a time (latency mode), host images in, host results out",
+           "camera": "KannalaBrandt8 stereo rig, lapping areas [0, 511]", "local_map_points": M, "mode": "one frame at a time (latency mode) through ft_tracked_batch_* with one frame, host images in, host results out",
            "scene_kind": "object scene on fronto-parallel planes", "distinct_frames": D, "by_th": {}}
     for th in (7.0, 15.0):
         tw0 = time.perf_counter()
@@ -404,8 +411,8 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
         # passes of the exact in-call claiming (EXPERIMENTS 3.2: one launch per pass, as many as the longest chain of map points
         # that take a keypoint from one another) and the time inside the two C entry points
         lib_stats = {}
-        for nm_ in ("tracked.search_last_frame.passes", "tracked.track_local_map.passes", "tracked.search_last_frame.total",
-                    "tracked.track_local_map.total"):
+        for nm_ in ("tracked_batch.search_last_frame.passes", "tracked_batch.track_local_map.passes", "tracked_batch.search_last_frame.total",
+                    "tracked_batch.track_local_map.total"):
             tot_, n_ = ctx.get_stat(nm_)
             lib_stats[nm_ + ("_per_call" if nm_.endswith("passes") else "_ms_per_call")] = tot_ / n_ if n_ else None
         # Hamming compares of one pass over the distinct frames, counted outside the timed region
@@ -420,7 +427,7 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
     if cpu:
         out["cpu_baseline"] = tracking_cpu_baseline(pairs, scen, cam, Trl, sf, lap, w, h, nf, LOG_SF, cpu_budget_s)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-    tf.close()
+    tb.close()
     ex2.close()
     return out
 

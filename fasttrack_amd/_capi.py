@@ -217,6 +217,8 @@ def lib() -> C.CDLL:
     L.ft_tracked_batch_holder_obs.argtypes = [vp, i, vp]
     L.ft_tracked_batch_bind_fisheye.argtypes = [vp, vp, vp, i, i, i, i, i, i, C.POINTER(FrameView), C.POINTER(FisheyeRig), vp, C.POINTER(vp),
                                                 C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]
+    L.ft_tracked_batch_bind_fisheye_slots.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, C.POINTER(FrameView), C.POINTER(FisheyeRig), vp,
+                                                      C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]
     L.ft_descriptor_distance.argtypes = [vp, vp, vp, i, vp]
     L.ft_stereo_frontend_device_descriptors.argtypes = [vp, i, i, C.POINTER(vp), ip]
     L.ft_vocabulary_create.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, C.POINTER(vp)]

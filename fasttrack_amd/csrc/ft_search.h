@@ -165,13 +165,13 @@ struct FtDeliverRec {
     const void *src[2];
     int words;
 };
-// what two extractors left in HBM (slot slot0 + f = left / right image of frame f of the batch), the lapping areas, and the
+// what two extractors left in HBM (slot slot0L + f / slot0R + f = left / right image of frame f of the batch), the lapping areas, and the
 // per-frame (monoLeft, monoRight) counts the gather leaves for the matching
 struct FtBindArgs {
     const ft_keypoint *keysL, *keysR;
     const uint8_t *descL, *descR;
     int strideL, strideR;  // keypoints per slot
-    int slot0;
+    int slot0L, slot0R;  // first slot of the left / right extractor (one extractor may serve both cameras: disjoint slot ranges)
     int lapL0, lapL1, lapR0, lapR1;
     int *mono;  // [nFrames][2], device
     // the triangulation filter of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1256-1271): 0 = the matching alone
@@ -207,11 +207,12 @@ int ft_launch_search_local_first(hipStream_t st, void *arena, const FtBatchJob *
 int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, float nnRatio, int sharedInts);
 // The writes of a converged search replayed on the device, a workgroup per frame (k_replay_batch): assign[keypoint] = the last
 // point that wrote it, holder_obs updated in place in HBM, the match count; last frame: with the rotation histogram and
-// ComputeThreeMaxima when checkOrientation.  Only frames that have not been replayed yet and - resolvedOnly - whose flag word says
-// "resolved" (the launch right behind k_resolve_batch); parity = result buffer of the last pass (a resolved frame holds its results in both).  sharedInts = ints of LDS per workgroup
+// ComputeThreeMaxima when checkOrientation.  Only frames that have not been replayed yet and - flagPos >= 0 - whose flag word at that
+// position says "converged" (a launch enqueued before the host has looked: behind k_resolve_batch position 0, behind a burst of
+// claim passes its last position; -1: every frame); parity = result buffer of the last pass (a converged frame holds its results in both).  sharedInts = ints of LDS per workgroup
 // for the last-writer table (>= the largest F.N), 0 = frames too large for the LDS: the table lives in the frame's writer table
 int ft_launch_replay_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, int parity, int checkOrientation,
-                           int sharedInts, int resolvedOnly);
+                           int sharedInts, int flagPos);
 // a pass behind the first one: lean kernel (four points per wave from the candidate cache) + the general kernel on its slow list
 int ft_launch_search_last_batch_lean(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, int pass, int fCur,
                                      int fPrev, int fReset, float th);

@@ -2068,16 +2068,17 @@ __global__ __launch_bounds__(FT_RS_LANES) void k_resolve_batch(const FtBatchJob 
 #define FT_REPLAY_REMOVED 0x40000000
 template <bool LOCAL, bool INLDS>
 __global__ __launch_bounds__(256) void k_replay_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, int parity, int checkOrientation,
-                                                      int resolvedOnly) {
+                                                      int flagPos) {
     const FtBatchJob &J = jobs[blockIdx.x];
     extern __shared__ int rp_last[];
     __shared__ int rp_hist[FT_HISTO_LENGTH], rp_keep, rp_sum[4];
     int *replayed = rb(J.replayed);
     const int *flags = rb(J.flags);
     const int N = J.F.N, M = J.nPoints;
-    // (uniform) a frame that has been replayed already; resolvedOnly (the launch right behind k_resolve_batch, before the host has
-    // seen the flags): a frame the resolution gave up on - its flag word is not -1 - waits for the claim passes
-    if (*replayed >= 0 || (resolvedOnly && M > 0 && flags[0] != -1)) return;
+    // (uniform) a frame that has been replayed already; flagPos >= 0 (a launch enqueued before the host has seen the flag words -
+    // right behind k_resolve_batch: position 0, or behind a burst of claim passes: the burst's last position): only a frame whose
+    // flag word there says "converged"; the others wait for the passes still to come
+    if (*replayed >= 0 || (flagPos >= 0 && M > 0 && flags[flagPos] != -1)) return;
     const int tid = threadIdx.x;
     int *last = INLDS ? rp_last : rb(J.tab);
     int *assign = J.assignOut;
@@ -2348,7 +2349,7 @@ __global__ __launch_bounds__(256) void k_fill_claims_batch(const FtBatchJob *__r
 __global__ __launch_bounds__(256) void k_lap_gather_batch(const FtBatchJob *__restrict__ jobs, Rebase rb, FtBindArgs A) {
     const int cam = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FtDevFrame &F = jobs[f].F;
-    const int slot = A.slot0 + f;
+    const int slot = (cam == 0 ? A.slot0L : A.slot0R) + f;
     const int n = cam == 0 ? F.Nleft : F.N - F.Nleft;
     const ft_keypoint *src = (cam == 0 ? A.keysL : A.keysR) + (size_t)slot * (cam == 0 ? A.strideL : A.strideR);
     const uint4 *srcD = (const uint4 *)((cam == 0 ? A.descL : A.descR) + (size_t)slot * (cam == 0 ? A.strideL : A.strideR) * 32);
@@ -2651,16 +2652,16 @@ int ft_launch_resolve_batch(hipStream_t st, void *arena, const FtBatchJob *jobs,
     return FT_OK;
 }
 int ft_launch_replay_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int local, int parity, int checkOrientation,
-                           int sharedInts, int resolvedOnly) {
+                           int sharedInts, int flagPos) {
     if (nFrames <= 0) return FT_OK;
     const Rebase rb = rebase_of(arena);
     const size_t sh = sizeof(int) * (size_t)sharedInts;
     if (sharedInts > 0) {
-        if (local) hipLaunchKernelGGL((k_replay_batch<true, true>), dim3(nFrames), dim3(256), sh, st, jobs, rb, parity, checkOrientation, resolvedOnly);
-        else hipLaunchKernelGGL((k_replay_batch<false, true>), dim3(nFrames), dim3(256), sh, st, jobs, rb, parity, checkOrientation, resolvedOnly);
+        if (local) hipLaunchKernelGGL((k_replay_batch<true, true>), dim3(nFrames), dim3(256), sh, st, jobs, rb, parity, checkOrientation, flagPos);
+        else hipLaunchKernelGGL((k_replay_batch<false, true>), dim3(nFrames), dim3(256), sh, st, jobs, rb, parity, checkOrientation, flagPos);
     } else {
-        if (local) hipLaunchKernelGGL((k_replay_batch<true, false>), dim3(nFrames), dim3(256), 0, st, jobs, rb, parity, checkOrientation, resolvedOnly);
-        else hipLaunchKernelGGL((k_replay_batch<false, false>), dim3(nFrames), dim3(256), 0, st, jobs, rb, parity, checkOrientation, resolvedOnly);
+        if (local) hipLaunchKernelGGL((k_replay_batch<true, false>), dim3(nFrames), dim3(256), 0, st, jobs, rb, parity, checkOrientation, flagPos);
+        else hipLaunchKernelGGL((k_replay_batch<false, false>), dim3(nFrames), dim3(256), 0, st, jobs, rb, parity, checkOrientation, flagPos);
     }
     FT_HIP(hipGetLastError());
     return FT_OK;

@@ -1364,7 +1364,7 @@ int callResolve(ft_tracked_batch *tb, FtBatchCall &c) {
     tb->evt.end(ctx->kernelTiming, st);
     // the writes of the frames it resolved, replayed right behind it (a frame it gave up on waits for the passes)
     tb->evt.begin(ctx->kernelTiming, local ? "kernel.replay_batch(local map)" : "kernel.replay_batch(last frame)", st);
-    if (r == FT_OK) r = ft_launch_replay_batch(st, tb->d_arena, c.dJobs, c.n, local ? 1 : 0, 0, c.checkOrientation, c.shInts, 1);
+    if (r == FT_OK) r = ft_launch_replay_batch(st, tb->d_arena, c.dJobs, c.n, local ? 1 : 0, 0, c.checkOrientation, c.shInts, /*flagPos=*/0);
     tb->evt.end(ctx->kernelTiming, st);
     return r;
 }
@@ -1389,6 +1389,12 @@ int callRunBurst(ft_tracked_batch *tb, FtBatchCall &c) {
         }
     }
     c.nextB = c.len;
+    // the frames this burst brought to their fixed point are replayed behind it (the kernel looks at the burst's last flag word
+    // itself), in front of the delivery: when the host then finds every frame converged the search is complete - no launch and
+    // no synchronisation of its own for the replay
+    int rc = ft_launch_replay_batch(tb->stream, tb->d_arena, c.dJobs, c.n, c.kind == 2 ? 1 : 0, c.parity, c.checkOrientation, c.shInts,
+                                    /*flagPos=*/base + c.len - 1);
+    if (rc != FT_OK) return rc;
     return callDeliver(tb, c, c.parity, c.burst == 0 && !c.awaitResolve);
 }
 
@@ -1402,7 +1408,7 @@ int callBegin(ft_tracked_batch *tb, FtBatchCall &c, int burstHint) {
     if (rc != FT_OK) return rc;
     if (c.maxPoints <= 0) {  // nothing to search in any frame: the (empty) results and, for a local-map call, the frustum fields
         c.simple = true;
-        rc = ft_launch_replay_batch(st, tb->d_arena, c.dJobs, c.n, c.kind == 2 ? 1 : 0, 0, c.checkOrientation, c.shInts, 0);
+        rc = ft_launch_replay_batch(st, tb->d_arena, c.dJobs, c.n, c.kind == 2 ? 1 : 0, 0, c.checkOrientation, c.shInts, /*flagPos=*/-1);
         if (rc == FT_OK) rc = callDeliver(tb, c, 0, true);
         c.resolvedAll = true;
         return rc;
@@ -1466,11 +1472,7 @@ int callFinish(ft_tracked_batch *tb, FtBatchCall &c, int *passes) {
         if (rc != FT_OK) return rc;
         FT_HIP(hipStreamSynchronize(st));
     }
-    *passes = c.pass;
-    // the claim passes finished (some of) the frames: their writes now, from the result buffer of the last pass
-    int rc = ft_launch_replay_batch(st, tb->d_arena, c.dJobs, c.n, c.kind == 2 ? 1 : 0, c.parity, c.checkOrientation, c.shInts, 0);
-    if (rc != FT_OK) return rc;
-    FT_HIP(hipStreamSynchronize(st));
+    *passes = c.pass;  // (every frame's writes were replayed behind the burst that brought it to its fixed point: callRunBurst)
     return FT_OK;
 }
 
@@ -2184,11 +2186,21 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
                                   int lap_l1, int lap_r0, int lap_r1, const ft_frame_view *meta, const ft_fisheye_rig *rig,
                                   const float *level_sigma2, int *const *left_to_right, int *const *right_to_left, float *const *depth,
                                   float *const *p3d, int *n_stereo) {
-    FT_REQUIRE(tb && exL && exR && meta && n_frames > 0 && n_frames <= tb->maxFrames && slot0 >= 0,
+    return ft_tracked_batch_bind_fisheye_slots(tb, exL, exR, slot0, slot0, n_frames, lap_l0, lap_l1, lap_r0, lap_r1, meta, rig, level_sigma2,
+                                               left_to_right, right_to_left, depth, p3d, n_stereo);
+}
+
+int ft_tracked_batch_bind_fisheye_slots(ft_tracked_batch *tb, ft_extractor *exL, ft_extractor *exR, int slot0, int slot0_right,
+                                        int n_frames, int lap_l0, int lap_l1, int lap_r0, int lap_r1, const ft_frame_view *meta,
+                                        const ft_fisheye_rig *rig, const float *level_sigma2, int *const *left_to_right,
+                                        int *const *right_to_left, float *const *depth, float *const *p3d, int *n_stereo) {
+    FT_REQUIRE(tb && exL && exR && meta && n_frames > 0 && n_frames <= tb->maxFrames && slot0 >= 0 && slot0_right >= 0,
                "ft_tracked_batch_bind_fisheye: bad argument");
     FT_REQUIRE(exL->ctx == tb->ctx && exR->ctx == tb->ctx, "ft_tracked_batch_bind_fisheye: extractors of another context");
-    FT_REQUIRE(slot0 + n_frames <= exL->lastBatch && slot0 + n_frames <= exR->lastBatch,
+    FT_REQUIRE(slot0 + n_frames <= exL->lastBatch && slot0_right + n_frames <= exR->lastBatch,
                "ft_tracked_batch_bind_fisheye: the extractors' last batches hold fewer images");
+    FT_REQUIRE(exL != exR || slot0 + n_frames <= slot0_right || slot0_right + n_frames <= slot0,
+               "ft_tracked_batch_bind_fisheye: one extractor for both cameras needs disjoint slot ranges");
     FT_REQUIRE(!rig || level_sigma2, "ft_tracked_batch_bind_fisheye: a rig needs level_sigma2 (mvLevelSigma2)");
     FT_REQUIRE((!depth && !p3d && !n_stereo) || rig, "ft_tracked_batch_bind_fisheye: depth / p3d / n_stereo come from the triangulation: pass a rig");
     FT_REQUIRE(!depth == !p3d, "ft_tracked_batch_bind_fisheye: depth and p3d go together");
@@ -2196,7 +2208,7 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     for (int f = 0; f < n_frames; f++) {
         const ft_frame_view &F = meta[f];
         FT_REQUIRE(F.Nleft >= 0 && F.N >= F.Nleft && F.N <= tb->maxKp, "ft_tracked_batch_bind_fisheye: keypoint counts out of range");
-        FT_REQUIRE(F.Nleft == exL->h_nSel[slot0 + f] && F.N - F.Nleft == exR->h_nSel[slot0 + f],
+        FT_REQUIRE(F.Nleft == exL->h_nSel[slot0 + f] && F.N - F.Nleft == exR->h_nSel[slot0_right + f],
                    "ft_tracked_batch_bind_fisheye: meta's keypoint counts differ from the extractors' slots");
         FT_REQUIRE(F.scale_factors && F.nlevels >= 1 && F.nlevels <= FT_MAX_LEVELS, "scale factors missing");
         FT_REQUIRE(F.cam_model == 0 || F.cam_model == 1, "unknown camera model");
@@ -2329,7 +2341,8 @@ int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL, ft_ex
     A.keysL = exL->d_keys; A.keysR = exR->d_keys;
     A.descL = exL->d_desc; A.descR = exR->d_desc;
     A.strideL = exL->geom.maxKp; A.strideR = exR->geom.maxKp;
-    A.slot0 = slot0;
+    A.slot0L = slot0;
+    A.slot0R = slot0_right;
     A.lapL0 = lap_l0; A.lapL1 = lap_l1; A.lapR0 = lap_r0; A.lapR1 = lap_r1;
     A.mono = (int *)(devF + oMono);
     A.triangulate = rig ? 1 : 0;

@@ -747,7 +747,7 @@ class TrackedBatch:
         self._nm = np.zeros(len(self.N), np.int32)
         self._nt = np.zeros(len(self.N), np.int32)
 
-    def bind_fisheye(self, exL, exR, views, lap_l, lap_r, slot0=0, want_tables=True, rig=None, level_sigma2=None):
+    def bind_fisheye(self, exL, exR, views, lap_l, lap_r, slot0=0, want_tables=True, rig=None, level_sigma2=None, slot0_right=None):
         """ft_tracked_batch_bind_fisheye: views = FrameViews (or the pair prepare_frames returned) whose keys / keys_right are the
         host copies of what exL / exR extracted last (slots slot0 ...).  rig = make_fisheye_rig(...): with the triangulation filter
         of Frame::ComputeStereoFishEyeMatches.  -> [(left_to_right, right_to_left)] (with a rig: [(l2r, r2l, depth, p3d, n)]) or None"""
@@ -768,8 +768,10 @@ class TrackedBatch:
                 pd = (C.c_void_p * n)(*[ptr(a) for a in dep])
                 pp = (C.c_void_p * n)(*[ptr(a) for a in p3])
                 nst = np.zeros(n, np.int32)
-        check(lib().ft_tracked_batch_bind_fisheye(self._h, exL._h, exR._h, slot0, n, lap_l[0], lap_l[1], lap_r[0], lap_r[1], arr,
-                                                  None if rig is None else C.byref(rig), ptr(ls2), pl, pr, pd, pp, ptr(nst)))
+        # slot0_right: the right images' first slot (exL may be exR: one extractor, e.g. a frame's two images as a batch of two)
+        check(lib().ft_tracked_batch_bind_fisheye_slots(self._h, exL._h, exR._h, slot0, slot0 if slot0_right is None else slot0_right, n,
+                                                        lap_l[0], lap_l[1], lap_r[0], lap_r[1], arr,
+                                                        None if rig is None else C.byref(rig), ptr(ls2), pl, pr, pd, pp, ptr(nst)))
         if [F.c.N for F in vs] != self.N:
             self._after_load([F.c.N for F in vs])
         if not want_tables:

@@ -514,6 +514,13 @@ FT_API int ft_tracked_batch_bind_fisheye(ft_tracked_batch *tb, ft_extractor *exL
                                          int lap_l0, int lap_l1, int lap_r0, int lap_r1, const ft_frame_view *meta,
                                          const ft_fisheye_rig *rig, const float *level_sigma2, int *const *left_to_right,
                                          int *const *right_to_left, float *const *depth, float *const *p3d, int *n_stereo);
+/* the same with a first slot per camera: exL == exR is allowed - ONE extractor whose last batch holds the left images in slots
+ * slot0 .. and the right ones in slots slot0_right .. (disjoint ranges), e.g. a two-camera frame extracted as a batch of two */
+FT_API int ft_tracked_batch_bind_fisheye_slots(ft_tracked_batch *tb, ft_extractor *exL, ft_extractor *exR, int slot0, int slot0_right,
+                                               int n_frames, int lap_l0, int lap_l1, int lap_r0, int lap_r1,
+                                               const ft_frame_view *meta, const ft_fisheye_rig *rig, const float *level_sigma2,
+                                               int *const *left_to_right, int *const *right_to_left, float *const *depth,
+                                               float *const *p3d, int *n_stereo);
 /* ft_tracked_frame_search_last_frame for every frame of the batch (n_frames = the number uploaded) */
 FT_API int ft_tracked_batch_search_last_frame(ft_tracked_batch *tb, int n_frames, const ft_last_points *L, const float *Tcw,
                                               float th, const int *forward, const int *backward, int check_orientation,

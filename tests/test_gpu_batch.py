@@ -264,6 +264,51 @@ def test_tracked_batch_bound_to_extractors_equals_uploaded_batch(ctx, lap):
         o.close()
 
 
+def test_bind_fisheye_with_one_extractor_for_both_cameras(ctx):
+    """ft_tracked_batch_bind_fisheye_slots with exL == exR: the left images in slots 0 .. 3 and the right ones in slots 4 .. 7 of ONE
+    extractor's last batch (a frame's two images extracted as one batch) - match tables and both searches equal what two
+    extractors give; overlapping slot ranges are refused"""
+    from fasttrack_amd import synth
+    B, w, h, nf = 4, 512, 512, 1500
+    lap = (0, 511)
+    sf, _ = ob.scale_factors(1.2, 8)
+    pairs = [synth.make_planes_pair(w, h, seed=900 + i) for i in range(B)]
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=2 * B)
+    exL = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=B)
+    exR = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=B)
+    r = ex.extract_batch([p[0] for p in pairs] + [p[1] for p in pairs], lap)
+    rL = exL.extract_batch([p[0] for p in pairs], lap)
+    rR = exR.extract_batch([p[1] for p in pairs], lap)
+    views, lasts, Tcws, ptss, poses = [], [], [], [], []
+    for f in range(B):
+        (kL, dL, _), (kR, dR, _) = r[f], r[B + f]
+        assert np.array_equal(kL, rL[f][0]) and np.array_equal(kR, rR[f][0])
+        views.append(orb.FrameView(keys=kL, keys_right=kR, descriptors=np.zeros((len(kL) + len(kR), 32), np.uint8), scale_factors=sf,
+                                   bounds=sc.frame_bounds(w, h), left_to_right=np.zeros(max(len(kL), 1), np.int32),
+                                   right_to_left=np.zeros(max(len(kR), 1), np.int32), cam_model=1, cam=list(sc.KB8_CAM), Trl=TRL))
+        last, Tcw, pts, Rcw, tcw = _kb8_inputs(kL, dL, sf, 8000 + f, 900)
+        lasts.append(last); Tcws.append(Tcw); ptss.append(pts); poses.append(orb.make_pose(Rcw, tcw, TLR))
+    cap = 2 * ex.max_keypoints + 64
+    t1 = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=cap, max_points=2048)
+    t2 = orb.TrackedBatch(ctx, max_frames=B, max_keypoints=cap, max_points=2048)
+    try:
+        with pytest.raises(orb.FastTrackError, match="disjoint slot ranges"):
+            t1.bind_fisheye(ex, ex, views, lap, lap, slot0=0, slot0_right=2)
+        a = t1.bind_fisheye(ex, ex, views, lap, lap, slot0=0, slot0_right=B)
+        b = t2.bind_fisheye(exL, exR, views, lap, lap)
+        for f in range(B):
+            assert np.array_equal(a[f][0], b[f][0]) and np.array_equal(a[f][1], b[f][1]) and (a[f][0] >= 0).sum() > 20
+        a1, b1 = t1.search_last_frame(lasts, Tcws, 7.0), t2.search_last_frame(lasts, Tcws, 7.0)
+        a2, b2 = t1.track_local_map(poses, ptss, 0.5, LOG_SF, 7.0), t2.track_local_map(poses, ptss, 0.5, LOG_SF, 7.0)
+        for f in range(B):
+            assert a1[f]["n"] == b1[f]["n"] and np.array_equal(a1[f]["assign"], b1[f]["assign"])
+            assert a2[f]["n"] == b2[f]["n"] and np.array_equal(a2[f]["assign"], b2[f]["assign"])
+            assert np.array_equal(t1.holder_obs(f), t2.holder_obs(f))
+    finally:
+        for o in (t1, t2, ex, exL, exR):
+            o.close()
+
+
 @pytest.mark.parametrize("opts", [dict(search_cache=0), dict(search_grid=0), dict(search_cache=1), dict(search_cache=1, pass_burst=2),
                                   dict(search_cache=0, pass_burst=2), dict(search_cache=3), dict(search_cache=2, pass_burst=2)])
 def test_tracked_batch_without_cache_without_grid_with_short_bursts(ctx, opts):
