@@ -1149,6 +1149,16 @@ __global__ __launch_bounds__(256) void k_compact(FtGeom g, const int *cellCount,
 #define OD_HB_BYTES (OD_LAYOUT ? OD_HP * OD_RP * 2 + 16 : OD_P * OD_HP * 2)  // 3536 / 3440
 #define OD_WAVE_BYTES ((OD_RAW_BYTES + OD_HB_BYTES + 15) & ~15)
 #define OD_WAVES 4
+#ifndef OD_MFMA
+#define OD_MFMA 0               // 1: horizontal 7-tap pass on the matrix pipe (v_mfma_i32_16x16x32_i8): patch rows x banded tap matrix,
+#endif                          // pixels kept in LDS as p - 128, rows kept as h - 32768.  Exact (the 47 extraction tests), 10 % fewer
+                                // vector instructions, and 0.5 % SLOWER in the pipeline: a matrix product holds the SIMD's vector
+                                // issue for its 16 cycles (tools/mfma_overlap.hip), and the banded form uses 16 % of its
+                                // multiply-adds (EXPERIMENTS 11.11).  Kept as a build option for the A/B (tools/od_ab.sh)
+#if OD_MFMA && !OD_LAYOUT
+#error "OD_MFMA writes the column-major layout"
+#endif
+#define OD_BIAS (OD_MFMA ? 0x80808080u : 0u)
 #ifndef OD_KPW_WIDE
 #define OD_KPW_WIDE 2           // keypoints per wave (1 or 2) in launches of 8+ images: loads of all of them in flight before the first is processed
 #endif
@@ -1191,6 +1201,7 @@ __device__ __forceinline__ unsigned od_vblur7(unsigned p0, unsigned p1, unsigned
 // hold them (starting at the dword that holds the first one; sh = 16 if the first value is that dword's high half, else 0)
 // -> three v_alignbit + one shift put the pairs (t0,t1) (t2,t3) (t4,t5) (t6,-) into place, four v_dot2_u32_u16 weigh them.
 typedef unsigned short od_us2 __attribute__((ext_vector_type(2)));
+typedef int od_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned od_dot2(unsigned a, unsigned w, unsigned acc) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(od_us2, a), __builtin_bit_cast(od_us2, w), acc, false);
 }
@@ -1201,6 +1212,19 @@ __device__ __forceinline__ unsigned od_vblur7_pairs(unsigned e0, unsigned e1, un
 __device__ __forceinline__ unsigned od_vblur7_dwords(unsigned d0, unsigned d1, unsigned d2, unsigned d3, unsigned sh) {
     return od_vblur7_pairs(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
                            __builtin_amdgcn_alignbit(d3, d2, sh), d3 >> (sh & 31u));  // (only the low five bits of sh count)
+}
+
+// the same from values stored as h - 32768 (signed 16 bit, what the matrix pipe leaves of the biased pixels): signed dot products,
+// the 256 * 32768 the seven taps took off added back with the rounding constant
+typedef short od_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int od_sdot2(unsigned a, unsigned w, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(od_s2, a), __builtin_bit_cast(od_s2, w), acc, false);
+}
+__device__ __forceinline__ unsigned od_vblur7_dwords_s(unsigned d0, unsigned d1, unsigned d2, unsigned d3, unsigned sh) {
+    const unsigned W01 = 18u | (34u << 16), W23 = 48u | (56u << 16), W45 = 48u | (34u << 16), W6 = 18u;
+    const unsigned e0 = __builtin_amdgcn_alignbit(d1, d0, sh), e1 = __builtin_amdgcn_alignbit(d2, d1, sh),
+                   e2 = __builtin_amdgcn_alignbit(d3, d2, sh), e3 = d3 >> (sh & 31u);
+    return (unsigned)od_sdot2(e3, W6, od_sdot2(e2, W45, od_sdot2(e1, W23, od_sdot2(e0, W01, 32768 + 256 * 32768)))) >> 16;
 }
 
 // Test tap (a7, GaussianBlur directly): the blurred image of one pyramid level, BORDER_REFLECT_101, computed with
@@ -1357,7 +1381,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
             if (lane < 60) {
 #pragma unroll
                 for (int it = 0; it < 9; it++)
-                    if (it < 8 || rrL < 3) rawLane[it * 60] = pv[q][it];
+                    if (it < 8 || rrL < 3) rawLane[it * 60] = pv[q][it] ^ OD_BIAS;
             }
         } else {
             // BORDER_REFLECT_101 of the blur at the level's edges (keypoints are >= 19 px inside, the
@@ -1366,7 +1390,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
             for (int i = lane; i < OD_P * OD_P; i += 64) {
                 const int r = i / OD_P, c = i - r * OD_P;
                 const int gy = reflect101(py0 + r, h), gx = reflect101(px0 + c, w);
-                raw[r * OD_PP + c] = gload<uint8_t>(img + (size_t)gy * pitch + gx);
+                raw[r * OD_PP + c] = gload<uint8_t>(img + (size_t)gy * pitch + gx) ^ (uint8_t)OD_BIAS;
             }
         }
         axK[q] = ax;
@@ -1385,7 +1409,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
 #pragma unroll
             for (int it = 0; it < 4; it++) {
                 const unsigned lo = w[it * 96], hi = w[it * 96 + 1];
-                const unsigned D = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                const unsigned D = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ OD_BIAS;  // (the patch holds p - 128 for the matrix pipe)
                 const int av = v < 0 ? -v : v;
                 const unsigned dw = __builtin_amdgcn_udot4(D, c_mom.W[av * 8 + jd], 0u, false);
                 const unsigned dm = __builtin_amdgcn_udot4(D, c_mom.M[av * 8 + jd], 0u, false);
@@ -1399,13 +1423,51 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
         m10K[q] = m10;
         m01K[q] = m01;
     };
+#if OD_MFMA
+    // the tap operand of the lane: bytes e = 0 .. 7 are T[k = 8 g + e][b = n] = tap[8 g + e - n] (0 outside 0 .. 6) - an
+    // 8-byte window of the tap sequence
+    long tapOp;
+    {
+        const int s8 = 8 * (8 * (lane >> 4) - (lane & 15));
+        const unsigned long long T = 0x0012223038302212ull;  // 18 34 48 56 48 34 18, lowest byte first
+        tapOp = (long)(s8 >= 0 ? (s8 < 64 ? T >> s8 : 0ull) : (s8 > -64 ? T << -s8 : 0ull));
+    }
+#endif
     auto hblur = [&]() {
         // horizontal 7-tap pass on the packed bytes: a task = (row, aligned group of 4 raw byte positions);
         // two v_dot4_u32_u8 per output on byte windows cut out with v_alignbyte.  hb[r][b] = sum_t k[t] *
         // raw[r][b + t] for raw byte positions b in [0, 40) (16 bit, <= 255 * 256); output column c of the
         // blurred window is b = ax + c.
         {
-#if OD_LAYOUT
+#if OD_MFMA
+            // hb - 32768 (43 rows x 40 positions, kept as SIGNED 16 bit: od_vblur7_dwords_s adds the 256 * 32768 back) = raw (43 x
+            // 48 signed bytes p - 128) x T (banded: T[k][b] = tap[k - b]), as nine
+            // 16 x 16 tiles with K = 32: tile (i, j) reads the bytes 16 j + 8 g .. + 7 of rows 16 i + n (lane = 16 g + n: one
+            // ds_read_b64), and because the window of a tile starts at its own first output position the tap operand is the
+            // same for all nine.  The accumulator of a lane holds rows 16 i + 4 g .. + 3 of output position 16 j + n: four
+            // consecutive u16 of a column of hbT - two v_perm and one ds_write_b64.  (Rows 43 .. 47 and positions 40 .. 47
+            // read whatever lies behind the patch - finite integers - and are not stored, row 43 - the dummy slot - aside.)
+            const int n = lane & 15, g4 = lane >> 4;
+            const uint8_t *aLane = raw + n * OD_PP + 8 * g4;
+            uint8_t *oLane = (uint8_t *)hb + 2 * OD_RP * n + 8 * g4;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                // the three tiles of a row block: operands first, the three products back to back, then the stores
+                long A[3];
+                od_v4i d[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) A[j] = *(const long *)(aLane + i * 16 * OD_PP + 16 * j);
+#pragma unroll
+                for (int j = 0; j < 3; j++) d[j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[j], tapOp, od_v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    uint2 pk;
+                    pk.x = __builtin_amdgcn_perm((unsigned)d[j].y, (unsigned)d[j].x, 0x05040100u);
+                    pk.y = __builtin_amdgcn_perm((unsigned)d[j].w, (unsigned)d[j].z, 0x05040100u);
+                    if ((i < 2 || g4 < 3) && (j < 2 || n < 8)) *(uint2 *)(oLane + j * 16 * 2 * OD_RP + 32 * i) = pk;
+                }
+            }
+#elif OD_LAYOUT
             // column-major output (hbT[column][row], OD_RP u16 slots per column): a lane takes a PAIR of rows (2P, 2P + 1) of its
             // group of four columns and stores the two values of a column as one dword; six row pairs per step on lanes 0-59
             const int rr = (lane * 13) >> 7, gq = lane - rr * 10;  // lane / 10 for lane < 64
@@ -1475,7 +1537,11 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(FtGeom g, const u
             od_lds_u32 *p = (od_lds_u32 *)(uintptr_t)(unsigned)(byteIdx & ~3);
             // (bit shift of the window: 16 if the first value is a high half.  byteIdx is even, and both v_alignbit and the
             // shift take the low five bits of their operand: byteIdx << 3 serves without masking bit 1 out first)
+#if OD_MFMA
+            return od_vblur7_dwords_s(p[0], p[1], p[2], p[3], (unsigned)byteIdx << 3);
+#else
             return od_vblur7_dwords(p[0], p[1], p[2], p[3], (unsigned)byteIdx << 3);
+#endif
         };
 #else
         const int hbase = (int)((const uint8_t *)(hb + 18 * OD_HP + ax + 18) - smem);
