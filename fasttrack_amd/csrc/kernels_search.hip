@@ -127,15 +127,16 @@ __device__ __forceinline__ bool is_locked(const FtClaims &C, int kp, int i, bool
 }
 
 // start of a claim-iteration pass (see FtClaims): false = the iteration has converged, nothing to do
-__device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) {
+// (blk of nblk: this workgroup among the frame's - the launch's own numbers unless the launcher laid the frames out itself)
+__device__ __forceinline__ bool claims_begin_pass(const FtClaims &C, int blk, int nblk) {
     if (C.flagPrev && shared_load(C.flagPrev) == -1) {
         // batch form, first pass of a later burst: the frame had converged before this burst began.  Its flag words of this
         // burst's parity still hold what an earlier burst left there ("changed" for the passes it ran then): they all read
         // "unchanged" from here on, so that every later pass of the burst returns here as well.
-        if (C.flagStick && blockIdx.x == 0 && threadIdx.x < FT_BATCH_FLAGS / 2) shared_store(C.flagStick + threadIdx.x, -1);
+        if (C.flagStick && blk == 0 && threadIdx.x < FT_BATCH_FLAGS / 2) shared_store(C.flagStick + threadIdx.x, -1);
         return false;
     }
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, T = gridDim.x * blockDim.x;
+    const int t = blk * blockDim.x + threadIdx.x, T = nblk * blockDim.x;
     for (int k = t; k < C.nKp; k += T) shared_store(&C.headClear[k], -1);
     uint4 *tc = (uint4 *)C.tabClear;  // (32-byte records, 32-byte aligned)
     for (int k = t; k < 2 * C.nKp; k += T) tc[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -145,6 +146,7 @@ __device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) {
     }
     return true;
 }
+__device__ __forceinline__ bool claims_begin_pass(const FtClaims &C) { return claims_begin_pass(C, (int)blockIdx.x, (int)gridDim.x); }
 
 // end of a point's turn in a pass: lane k files write kind k of point i - the result, the "changed" flag against the
 // previous pass, and the entry in the writer table the NEXT pass will read (so a pass is one launch)
@@ -1169,9 +1171,25 @@ __device__ __forceinline__ void row_two_min(unsigned long long &k0, unsigned lon
     k0 = m0;
 }
 
+// The window scan of a row's point, in three steps through a small LDS list of the row (FT_ROW_LIST entries; the lanes of a row
+// belong to one wave, whose LDS operations are served in order - no barrier):
+//   expand  a lane per (octave, column of cells) range, a DPP scan lays the ranges end to end, and every range lane writes the
+//           grid positions of its entries (with the column in the top byte) at their places in the list - where the first form of
+//           this loop looked the range of every entry up again, 16 entries at a time, by a chain of np - 1 shuffles;
+//   filter  16 entries at a time: the 16-byte record, level band and box test of GetFeaturesInArea (in_box), the survivors packed
+//           to the front of the list by a ballot of the row - the cell ranges of a window hold ~2.4 x the keypoints of the box, and
+//           the other 58 % leave here without their descriptor having been loaded;
+//   visit   fn(entry, real) for the survivors, 16 at a time: descriptor, cell row, and whatever the search does with them.
+// Windows with more entries than the list holds go through it in parts.  What fn sees is what it saw before minus the entries
+// in_box rejects (the order inside a list is free).
+#define FT_ROW_LIST 64
+__device__ __forceinline__ void row_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 template <class Fn>
 __device__ __forceinline__ void row_for_window(const FtDevFrame &F, const FramePtrs &Q, int cam, const Window &w, int minLevel, int maxLevel,
-                                               int sub, int rowBase, Fn fn) {
+                                               float bx, float by, float br, int sub, int rowBase, unsigned *list, Fn fn) {
     const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
     const int lo = checkLevels ? min(max(minLevel, 0), F.nlevels - 1) : 0;
     const int hi = (checkLevels && maxLevel >= 0) ? min(maxLevel, F.nlevels - 1) : F.nlevels - 1;
@@ -1198,27 +1216,50 @@ __device__ __forceinline__ void row_for_window(const FtDevFrame &F, const FrameP
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);  // row_shr:4
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr:8
         const int total = row_shfl(incl, rowBase + 15);
-        for (int t0 = 0; t0 < total; t0 += 16) {  // (row-uniform)
-            const int t = t0 + sub, tt = min(t, total - 1);
-            int r = 0;  // the range entry tt falls into: the number of ranges that end at or before tt
-            for (int c = 0; c < np - 1; c++) r += tt >= row_shfl(incl, rowBase + c) ? 1 : 0;
-            const int cb = row_shfl(b, rowBase + r), cEnd = row_shfl(incl, rowBase + r), cCnt = row_shfl(cnt, rowBase + r);
-            const int cx = row_shfl(myCol, rowBase + r);
-            const int pos = cb + (tt - (cEnd - cCnt));
-            const float4 rr = rec[pos];
-            const uint4 d0 = gd[2 * (size_t)pos], d1 = gd[2 * (size_t)pos + 1];
-            WinEntry e;
-            e.x = rr.x; e.y = rr.y; e.uright = rr.z;
-            const int io = __float_as_int(rr.w);
-            e.idx = io & 0xffffff;
-            e.octave = io >> 24;
-            e.cx = cx;
-            e.cy = (int)roundf(__fmul_rn(__fsub_rn(rr.y, F.mnMinY), F.invH));
-            e.d[0] = (unsigned long long)d0.x | ((unsigned long long)d0.y << 32);
-            e.d[1] = (unsigned long long)d0.z | ((unsigned long long)d0.w << 32);
-            e.d[2] = (unsigned long long)d1.x | ((unsigned long long)d1.y << 32);
-            e.d[3] = (unsigned long long)d1.z | ((unsigned long long)d1.w << 32);
-            fn(e, t < total);
+        const int start = incl - cnt;
+        const unsigned tag = (unsigned)b | ((unsigned)myCol << 24);  // (grid positions stay below 2^24, columns below 64)
+        for (int w0 = 0; w0 < total; w0 += FT_ROW_LIST) {  // (row-uniform)
+            const int nw = min(FT_ROW_LIST, total - w0);
+            // expand: the part of this lane's range that falls into [w0, w0 + nw)
+            for (int k = max(0, w0 - start), k1 = min(cnt, w0 + nw - start); k < k1; k++) list[start + k - w0] = tag + (unsigned)k;
+            row_lds_sync();
+            // filter: survivors of the box to the front (an entry is read before its group writes, and a group writes below its
+            // own first entry + 16)
+            int m = 0;
+            for (int t0 = 0; t0 < nw; t0 += 16) {  // (row-uniform)
+                const int t = t0 + sub;
+                const unsigned v = list[min(t, nw - 1)];
+                const float4 rr = rec[v & 0xffffffu];
+                WinEntry e;
+                e.x = rr.x; e.y = rr.y;
+                e.octave = __float_as_int(rr.w) >> 24;
+                const bool inb = t < nw && in_box(e, bx, by, br, minLevel, maxLevel);
+                const unsigned bits = (unsigned)(__ballot(inb) >> rowBase) & 0xffffu;
+                if (inb) list[m + __popc(bits & ((1u << sub) - 1u))] = v;
+                m += __popc(bits);
+            }
+            row_lds_sync();
+            // visit
+            for (int s0 = 0; s0 < m; s0 += 16) {  // (row-uniform)
+                const int sI = s0 + sub;
+                const unsigned v = list[min(sI, m - 1)];
+                const int pos = (int)(v & 0xffffffu);
+                const float4 rr = rec[pos];
+                const uint4 d0 = gd[2 * (size_t)pos], d1 = gd[2 * (size_t)pos + 1];
+                WinEntry e;
+                e.x = rr.x; e.y = rr.y; e.uright = rr.z;
+                const int io = __float_as_int(rr.w);
+                e.idx = io & 0xffffff;
+                e.octave = io >> 24;
+                e.cx = (int)(v >> 24);
+                e.cy = (int)roundf(__fmul_rn(__fsub_rn(rr.y, F.mnMinY), F.invH));
+                e.d[0] = (unsigned long long)d0.x | ((unsigned long long)d0.y << 32);
+                e.d[1] = (unsigned long long)d0.z | ((unsigned long long)d0.w << 32);
+                e.d[2] = (unsigned long long)d1.x | ((unsigned long long)d1.y << 32);
+                e.d[3] = (unsigned long long)d1.z | ((unsigned long long)d1.w << 32);
+                fn(e, sI < m);
+            }
+            row_lds_sync();  // (the next part - or the next window - overwrites the list)
         }
     }
 }
@@ -1253,14 +1294,18 @@ __device__ __forceinline__ void claims_file_row_first(const FtClaims &C, int *re
     }
 }
 
-__global__ __launch_bounds__(256) void k_search_last_first(const FtBatchJob *__restrict__ jobs, Rebase rb, float th) {
-    const FtBatchJob &J = jobs[blockIdx.y];
+__global__ __launch_bounds__(256) void k_search_last_first(const FtBatchJob *__restrict__ jobs, Rebase rb, float th, FtSlotGrid sg) {
+    int frame, blk;
+    if (!ft_slot_block(sg, frame, blk)) return;
+    const FtBatchJob &J = jobs[frame];
     if (J.nPoints <= 0) return;
     int *res;
     const FtClaims C = job_claims(J, rb, 0, 0, -1, FT_BATCH_FLAGS / 2, res);
-    claims_begin_pass(C);
+    claims_begin_pass(C, blk, sg.blocksPerSlot);
+    __shared__ unsigned rowLists[16][FT_ROW_LIST];
+    unsigned *list = rowLists[threadIdx.x >> 4];
     const int lane = threadIdx.x & 63, sub = lane & 15, rowBase = lane & 48;
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int i = blk * 16 + (threadIdx.x >> 4);
     if (i >= J.L.N) return;
     const FtDevFrame &F = J.F;
     const FramePtrs Q = frame_ptrs(F, rb);
@@ -1289,8 +1334,8 @@ __global__ __launch_bounds__(256) void k_search_last_first(const FtBatchJob *__r
             int n = 0;
             bool anyCand = false;
             if (!w.empty) {
-                row_for_window(F, Q, 0, w, minLevel, maxLevel, sub, rowBase, [&](const WinEntry &kp, bool real) {
-                    const bool inb = real && in_box(kp, u, v, radius, minLevel, maxLevel);
+                row_for_window(F, Q, 0, w, minLevel, maxLevel, u, v, radius, sub, rowBase, list, [&](const WinEntry &kp, bool real) {
+                    const bool inb = real;  // (in_box held in the filter step)
                     anyCand = anyCand || inb;
                     bool cand = inb;
                     if (cand && kp.uright > 0) {
@@ -1314,8 +1359,8 @@ __global__ __launch_bounds__(256) void k_search_last_first(const FtBatchJob *__r
                     unsigned long long kr = KEY_NONE;
                     int nr = 0;
                     if (!wr.empty) {
-                        row_for_window(F, Q, 1, wr, minLevel, maxLevel, sub, rowBase, [&](const WinEntry &kp, bool real) {
-                            const bool cand = real && in_box(kp, ur, vr, radius, minLevel, maxLevel);
+                        row_for_window(F, Q, 1, wr, minLevel, maxLevel, ur, vr, radius, sub, rowBase, list, [&](const WinEntry &kp, bool real) {
+                            const bool cand = real;
                             const bool held = cand && Q.holderObs[(cand ? kp.idx : 0) + F.Nleft] > 0;
                             const unsigned long long key = make_key(hamming256(q, kp.d), kp.cx, kp.cy, kp.idx, kp.octave, held);
                             row_cache_append(slotR, nr, cand, key, sub, rowBase);
@@ -1333,14 +1378,18 @@ __global__ __launch_bounds__(256) void k_search_last_first(const FtBatchJob *__r
     claims_file_row_first(C, res, i, sub, r4);
 }
 
-__global__ __launch_bounds__(256) void k_search_local_first(const FtBatchJob *__restrict__ jobs, Rebase rb, float th, float nnRatio) {
-    const FtBatchJob &J = jobs[blockIdx.y];
+__global__ __launch_bounds__(256) void k_search_local_first(const FtBatchJob *__restrict__ jobs, Rebase rb, float th, float nnRatio, FtSlotGrid sg) {
+    int frame, blk;
+    if (!ft_slot_block(sg, frame, blk)) return;
+    const FtBatchJob &J = jobs[frame];
     if (J.nPoints <= 0) return;
     int *res;
     const FtClaims C = job_claims(J, rb, 0, 0, -1, FT_BATCH_FLAGS / 2, res);
-    claims_begin_pass(C);
+    claims_begin_pass(C, blk, sg.blocksPerSlot);
+    __shared__ unsigned rowLists[16][FT_ROW_LIST];
+    unsigned *list = rowLists[threadIdx.x >> 4];
     const int lane = threadIdx.x & 63, sub = lane & 15, rowBase = lane & 48;
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int i = blk * 16 + (threadIdx.x >> 4);
     if (i >= J.P.M) return;
     const FtDevFrame &F = J.F;
     const FramePtrs Q = frame_ptrs(F, rb);
@@ -1368,8 +1417,8 @@ __global__ __launch_bounds__(256) void k_search_local_first(const FtBatchJob *__
             int n = 0;
             if (!w.empty) {
                 const float pxr = (F.Nleft == -1 && Q.uright) ? rb(J.P.projXR)[i] : 0.f;
-                row_for_window(F, Q, 0, w, level - 1, level, sub, rowBase, [&](const WinEntry &kp, bool real) {
-                    bool cand = real && in_box(kp, x, y, rad, level - 1, level);
+                row_for_window(F, Q, 0, w, level - 1, level, x, y, rad, sub, rowBase, list, [&](const WinEntry &kp, bool real) {
+                    bool cand = real;
                     if (cand && kp.uright > 0 && fabsf(__fsub_rn(pxr, kp.uright)) > rad) cand = false;  // (mono-stereo frames only)
                     const bool held = cand && Q.holderObs[cand ? kp.idx : 0] > 0;
                     const unsigned long long key = make_key(hamming256(q, kp.d), kp.cx, kp.cy, kp.idx, kp.octave, held);
@@ -1404,8 +1453,8 @@ __global__ __launch_bounds__(256) void k_search_local_first(const FtBatchJob *__
             unsigned long long k0 = KEY_NONE, k1 = KEY_NONE;
             int n = 0;
             if (!w.empty) {
-                row_for_window(F, Q, 1, w, level - 1, level, sub, rowBase, [&](const WinEntry &kp, bool real) {
-                    const bool cand = real && in_box(kp, x, y, rad, level - 1, level);
+                row_for_window(F, Q, 1, w, level - 1, level, x, y, rad, sub, rowBase, list, [&](const WinEntry &kp, bool real) {
+                    const bool cand = real;
                     const int g = kp.idx + F.Nleft;
                     const bool held = cand && Q.holderObs[cand ? g : 0] > 0;
                     // this point's own left-block side write precedes its right-block search
@@ -2670,13 +2719,17 @@ int ft_launch_replay_batch(hipStream_t st, void *arena, const FtBatchJob *jobs, 
 int ft_launch_search_last_first(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, float th) {
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
     hipLaunchKernelGGL(k_last_project_batch, dim3((maxPoints + 255) / 256, nFrames), dim3(256), 0, st, jobs, rebase_of(arena));
-    hipLaunchKernelGGL(k_search_last_first, dim3((maxPoints + 15) / 16, nFrames), dim3(256), 0, st, jobs, rebase_of(arena), th);
+    dim3 grid;
+    const FtSlotGrid sg = ft_slot_grid((maxPoints + 15) / 16, nFrames, grid);  // (a frame's workgroups on one XCD: its grid and its lists stay in that L2)
+    hipLaunchKernelGGL(k_search_last_first, grid, dim3(256), 0, st, jobs, rebase_of(arena), th, sg);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }
 int ft_launch_search_local_first(hipStream_t st, void *arena, const FtBatchJob *jobs, int nFrames, int maxPoints, float th, float nnRatio) {
     if (nFrames <= 0 || maxPoints <= 0) return FT_OK;
-    hipLaunchKernelGGL(k_search_local_first, dim3((maxPoints + 15) / 16, nFrames), dim3(256), 0, st, jobs, rebase_of(arena), th, nnRatio);
+    dim3 grid;
+    const FtSlotGrid sg = ft_slot_grid((maxPoints + 15) / 16, nFrames, grid);
+    hipLaunchKernelGGL(k_search_local_first, grid, dim3(256), 0, st, jobs, rebase_of(arena), th, nnRatio, sg);
     FT_HIP(hipGetLastError());
     return FT_OK;
 }

@@ -4,7 +4,7 @@
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$REPO/fasttrack_amd/csrc/$1; PFX=$2; OUT=${3:-/tmp/isa/kernel.s}
 mkdir -p "$(dirname "$OUT")" /tmp/isa
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -fno-fast-math -I$REPO/include -mllvm -amdgpu-mfma-vgpr-form -S --cuda-device-only -o /tmp/isa/_full.s "$SRC" 2>&1 | grep -E "error"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -fno-fast-math -I$REPO/include -S --cuda-device-only -o /tmp/isa/_full.s "$SRC" 2>&1 | grep -E "error"
 python3 - "$PFX" "$OUT" <<'PY'
 import re, collections, sys
 pfx, out = sys.argv[1], sys.argv[2]
