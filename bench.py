@@ -476,8 +476,10 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
         ln.exL = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=B)
         ln.exR = orb.ORBextractor(ctx, nf, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=B)
         cap = ln.exL.max_keypoints
-        ln.kL, ln.kR = np.zeros((B, cap), orb.KP_DTYPE), np.zeros((B, cap), orb.KP_DTYPE)
-        ln.dL, ln.dR = np.zeros((B, cap, 32), np.uint8), np.zeros((B, cap, 32), np.uint8)
+        # (pinned: the device writes the keypoints and descriptors of a step into these arrays itself, in the reference's output order)
+        alloc = ctx.pinned_array if pinned else (lambda shape, dt: np.zeros(shape, dt))
+        ln.kL, ln.kR = alloc((B, cap), orb.KP_DTYPE), alloc((B, cap), orb.KP_DTYPE)
+        ln.dL, ln.dR = alloc((B, cap, 32), np.uint8), alloc((B, cap, 32), np.uint8)
         ln.nL, ln.nR, ln.mL, ln.mR = (np.zeros(B, np.int32) for _ in range(4))
         lanes.append(ln)
     sf = np.asarray(lanes[0].exL.GetScaleFactors(), np.float32)

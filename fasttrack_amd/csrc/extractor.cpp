@@ -219,6 +219,7 @@ void freeAll(ft_extractor *ex) {
     hipHostFree(ex->h_candCount);
     hipHostFree(ex->h_sel);
     hipHostFree(ex->h_nSel);
+    hipHostFree(ex->h_nMono);
     hipHostFree(ex->h_keys);
     hipHostFree(ex->h_desc);
     if (ex->stream) {
@@ -840,6 +841,7 @@ int ft_extractor_create(ft_context *ctx, int nfeatures, float scale_factor, int 
     FT_TRY(pinAlloc(&ex->h_candCount, B * g.nlevels, hipHostMallocMapped | hipHostMallocCoherent));
     FT_TRY(pinAlloc(&ex->h_sel, B * g.maxKp));
     FT_TRY(pinAlloc(&ex->h_nSel, B));
+    FT_TRY(pinAlloc(&ex->h_nMono, B));
     FT_TRY(pinAlloc(&ex->h_keys, B * g.maxKp));
     FT_TRY(pinAlloc(&ex->h_desc, B * g.maxKp * 32));
     {
@@ -1067,6 +1069,29 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
     // everything a batch needs with the device octree, enqueued without a host synchronisation (capture != 0: ex->stream is
     // being captured into a graph; the octree / stage-B streams fork from it through events and are joined back)
     const bool deliver = batch <= 8;  // (FtDeliverArgs, ft_internal.h)
+    // a wide batch whose output arrays lie in pinned memory of this context (ft_host_malloc): the device writes the results there
+    // itself, in the reference's output order (k_deliver_ordered) - no staging copy, no pass of the host over the keypoints
+    static const bool stagedOnly = ft_debug_env("FT_DEBUG_STAGED_OUTPUTS") != nullptr;  // (A/B aid: the staging copy + the host's pass)
+    const bool direct = !stagedOnly && !deliver && ex->deviceOctree && capacity > 0 && (keypoints || descriptors) &&
+                        (!keypoints || ft_host_block_contains(ex->ctx, keypoints, sizeof(ft_keypoint) * (size_t)batch * capacity)) &&
+                        (!descriptors || ft_host_block_contains(ex->ctx, descriptors, (size_t)32 * batch * capacity));
+    bool deliveredDirect = false;
+    auto deliverOrdered = [&](int b0, int nb) -> int {
+        deliveredDirect = true;
+        FtOrderedArgs a;
+        a.keys = ex->d_keys;
+        a.desc = ex->d_desc;
+        a.nSel = ex->d_nSel;
+        a.oKeys = keypoints;
+        a.oDesc = descriptors;
+        a.oMono = ex->h_nMono;
+        a.srcStride = ex->geom.maxKp;
+        a.capacity = capacity;
+        a.b0 = b0;
+        a.lap0 = (float)lap0;
+        a.lap1 = (float)lap1;
+        return ft_launch_deliver_ordered(ex->streamB, nb, a);
+    };
     auto enqueueDevice = [&](int capture) -> int {
         int r = ft_extract_prepare(ex, images, batch, on_device, width, height, stride);
         if (r != FT_OK) return r;
@@ -1119,7 +1144,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
         for (int b : slots) {
             ex->ctx->addStat("extract.device_octree_fallbacks", 1);
             r = ft_extract_repair_launch(ex, b, ex->streamB);
-            if (r == FT_OK) r = ft_extract_download(ex, b, 1, ex->streamB);
+            if (r == FT_OK) r = deliveredDirect ? deliverOrdered(b, 1) : ft_extract_download(ex, b, 1, ex->streamB);
             if (r != FT_OK) return r;
         }
         FT_HIP(hipStreamSynchronize(ex->streamB));
@@ -1227,7 +1252,7 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
             }
             rc = ft_extract_launch_b(ex, b0, nb, ex->streamB);
             if (rc != FT_OK) return rc;
-            rc = ft_extract_download(ex, b0, nb, ex->streamB);
+            rc = (direct && dev) ? deliverOrdered(b0, nb) : ft_extract_download(ex, b0, nb, ex->streamB);
             if (rc != FT_OK) return rc;
         }
         rc = ft_extract_finish_counts(ex, batch, ex->streamB);
@@ -1243,7 +1268,21 @@ int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, 
         }
     }
     ex->deviceOctree = devWanted;
-    rc = assembleOutputs(ex, batch, lap0, lap1, keypoints, descriptors, capacity, n_keypoints, n_mono);
+    if (deliveredDirect) {  // (the arrays are filled; what is left is the counts)
+        for (int b = 0; b < batch; b++)
+            if (ex->h_nSel[b] > capacity) {
+                ft_set_error("extract: output capacity too small (use ft_extractor_max_keypoints)");
+                return FT_ERR_CAPACITY;
+            }
+        for (int b = 0; b < batch; b++) {
+            if (n_keypoints) n_keypoints[b] = ex->h_nSel[b];
+            if (n_mono) n_mono[b] = ex->h_nMono[b];
+        }
+        ex->ctx->addStat("extract.delivered_in_order_on_device", batch);
+        rc = FT_OK;
+    } else {
+        rc = assembleOutputs(ex, batch, lap0, lap1, keypoints, descriptors, capacity, n_keypoints, n_mono);
+    }
     ex->ctx->addStat("extract.total", tAll.ms());
     return rc;
 }

@@ -226,6 +226,7 @@ struct ft_extractor {
     // selected keypoints host -> device
     FtSelKp *h_sel = nullptr, *d_sel = nullptr;
     int *h_nSel = nullptr, *d_nSel = nullptr;
+    int *h_nMono = nullptr;  // pinned: keypoints outside the lapping area per slot (k_deliver_ordered)
     // results device -> host
     ft_keypoint *d_keys = nullptr, *h_keys = nullptr;
     uint8_t *d_desc = nullptr, *h_desc = nullptr;

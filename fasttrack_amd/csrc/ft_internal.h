@@ -249,6 +249,18 @@ struct FtDeliverArgs {
     int srcStride, dstStride;
 };
 int ft_launch_deliver(hipStream_t st, int batch, const FtDeliverArgs &a);
+// ft_extract_batch's results of slots [b0, b0 + nb) in the reference's output order, into the caller's pinned arrays (k_deliver_ordered)
+struct FtOrderedArgs {
+    const ft_keypoint *keys;  // device, rows of srcStride records per slot
+    const uint8_t *desc;
+    const int *nSel;          // device [slots]
+    ft_keypoint *oKeys;       // pinned host, rows of `capacity` records per slot (may be null)
+    uint8_t *oDesc;           // (may be null)
+    int *oMono;               // pinned host [slots]: keypoints outside the lapping area
+    int srcStride, capacity, b0;
+    float lap0, lap1;
+};
+int ft_launch_deliver_ordered(hipStream_t st, int nb, const FtOrderedArgs &a);
 // Frame upload of a small batch (latency mode): one kernel reads the frames from pinned host memory
 // and writes them as level 0 of the slot pyramids (row pitch `pitch`, `slotBytes` apart), and fills
 // the level-0 pointer table - instead of one DMA copy per frame plus one for the table.

@@ -253,8 +253,10 @@ class ORBextractor:
                                lapping_area[0], lapping_area[1], ptr(kps), ptr(desc), cap, C.byref(n), C.byref(nm)))
         return kps[:n.value].copy(), desc[:n.value].copy(), nm.value
 
-    def extract_batch(self, images, lapping_area=(0, 0), on_device=False, width=None, height=None, stride=None):
-        """images: list of host arrays or DeviceBuffers (frames already in HBM)."""
+    def extract_batch(self, images, lapping_area=(0, 0), on_device=False, width=None, height=None, stride=None, pinned=False):
+        """images: list of host arrays or DeviceBuffers (frames already in HBM).  pinned: the result arrays live in pinned host
+        memory of the context - a batch of more than eight images is then written there by the device itself, in the
+        reference's output order (k_deliver_ordered)"""
         B = len(images)
         if not on_device:
             width, height = images[0].shape[1], images[0].shape[0]
@@ -262,8 +264,9 @@ class ORBextractor:
             images = [np.ascontiguousarray(im, np.uint8) for im in images]
         ptrs, keep = _image_ptrs(images, on_device)
         cap = self.max_keypoints
-        kps = np.zeros((B, cap), KP_DTYPE)
-        desc = np.zeros((B, cap, 32), np.uint8)
+        alloc = self.ctx.pinned_array if pinned else (lambda shape, dt: np.zeros(shape, dt))
+        kps = alloc((B, cap), KP_DTYPE)
+        desc = alloc((B, cap, 32), np.uint8)
         n = np.zeros(B, np.int32)
         nm = np.zeros(B, np.int32)
         check(lib().ft_extract_batch(self._h, ptrs, B, int(on_device), width, height, stride, lapping_area[0],

@@ -173,7 +173,10 @@ FT_API int ft_extract(ft_extractor *ex, const uint8_t *image, int width, int hei
 
 /* The same for `batch` <= max_batch images of identical size.  images[b] is a host pointer
  * (on_device = 0) or a device pointer on this context's device (on_device = 1, frames already in HBM).
- * Outputs are host arrays: keypoints[b*capacity + i], descriptors[(b*capacity + i)*32]. */
+ * Outputs are host arrays: keypoints[b*capacity + i], descriptors[(b*capacity + i)*32].  Arrays in pinned memory of the
+ * context (ft_host_malloc) are written by the device itself, in the order above, for batches of more than eight images (no
+ * staging copy and no pass of the host over the keypoints; statistic "extract.delivered_in_order_on_device"); any other
+ * array is filled by the host from the library's staging.  The results are the same. */
 FT_API int ft_extract_batch(ft_extractor *ex, const uint8_t *const *images, int batch, int on_device, int width,
                             int height, int stride, int lap0, int lap1, ft_keypoint *keypoints,
                             uint8_t *descriptors, int capacity, int *n_keypoints, int *n_mono);

@@ -146,6 +146,39 @@ def test_lapping_area_partition(ctx):
     assert ex(img, (0, 1000))[2] == 0  # monocular: everything is written from the back
 
 
+def test_wide_batch_delivered_in_order_into_pinned_arrays(ctx):
+    """A batch of more than eight images whose result arrays lie in pinned memory (ft_host_malloc): the device writes keypoints and
+    descriptors there itself, in the order ORBextractor::operator() returns them (ORBextractor.cc:1466-1487) - equal to the
+    oracle and to the staged path (pageable arrays, the host's pass) for several lapping areas, a repaired image included."""
+    w, h, nf, B = 512, 512, 2000, 11
+    imgs = [synth.make_image(w, h, seed=300 + b) for b in range(B)]
+    imgs[4] = synth.make_noise(w, h, seed=9)  # more candidates in a level than the device octree's first tier sorts
+    ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h, max_batch=B)
+    oex = ob.Extractor(nf)
+    for lap in [(0, 511), (120, 420), (0, 0)]:
+        d0 = _calls(ctx, "extract.delivered_in_order_on_device")
+        got = ex.extract_batch(imgs, lap, pinned=True)
+        assert _calls(ctx, "extract.delivered_in_order_on_device") == d0 + 1
+        staged = ex.extract_batch(imgs, lap)
+        assert _calls(ctx, "extract.delivered_in_order_on_device") == d0 + 1
+        for b in range(B):
+            ok, od, om = oex.extract(imgs[b], lap)
+            _check_same(got[b][0], got[b][1], ok, od)
+            _check_same(staged[b][0], staged[b][1], ok, od)
+            assert got[b][2] == om == staged[b][2]
+    # rows too short for an image: the error of the staged path, nothing written beyond the rows
+    import ctypes as C
+    from fasttrack_amd import _capi
+    ptrs, keep = orb.ORBextractor.image_ptrs([np.ascontiguousarray(im) for im in imgs], False)
+    cap = 100
+    kps, desc = ctx.pinned_array((B + 1, cap), orb.KP_DTYPE), ctx.pinned_array((B + 1, cap, 32), np.uint8)
+    kps.view(np.uint8)[:] = 0xAB
+    n, nm = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    rc = _capi.lib().ft_extract_batch(ex._h, ptrs, B, 0, w, h, w, 0, 511, orb.ptr(kps), orb.ptr(desc), cap, orb.ptr(n), orb.ptr(nm))
+    assert rc != 0
+    assert (kps.view(np.uint8) == 0xAB).all()
+
+
 def test_edge_images(ctx):
     w, h, nf = 640, 480, 1000
     ex = orb.ORBextractor(ctx, nf, 1.2, 8, 20, 7, w, h)
