@@ -433,7 +433,7 @@ def tracking_leg(orb, ctx, frames=48, warmup=4, M=2000, cpu_budget_s=4.0, cpu=Tr
 
 
 def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.0), pipelined=True, in_flight=4, pinned=True,
-                       one_thread_per_lane=False):
+                       one_thread_per_lane=False, overlap=True):
     """BASELINE.json configs[3] as a THROUGHPUT workload: B independent 512x512 KannalaBrandt8 stereo frames per step (the
     frames B camera streams deliver for one time step), every stage ONE launch over all of them (ft_tracked_batch_*):
       extraction of the B left and the B right images, frames resident in HBM, lapping areas [0, 511]      (ft_extract_batch x 2,
@@ -448,7 +448,9 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
     (pinned = True: arrays in pinned host memory, read in place by the device - the host stages nothing and the writes of a search
     are replayed on the device; False: pageable arrays, packed into pinned staging by the context's host threads), keypoints,
     descriptors, assignments, match counts and frustum fields down.  one_thread_per_lane: the lane's thread runs the two
-    extractions itself, one after the other (otherwise two helper threads per lane, as Frame's constructor has them).  Every frame of the
+    extractions itself, one after the other (otherwise two helper threads per lane, as Frame's constructor has them).  overlap: a lane
+    enqueues the extraction of its next step beside the local-map search of its current one (the searches in their submit / wait
+    form; + 5 - 9 % on one box, EXPERIMENTS 11.15).  Every frame of the
     batch is a distinct image pair with its own last-frame points, local map (M points) and poses, built once from the frame's
     own keypoints (untimed)."""
     import ctypes as C
@@ -535,14 +537,43 @@ def tracking_batch_leg(orb, ctx, B=128, steps=6, warmup=2, M=2000, ths=(7.0, 15.
             for k_, v_ in zip(ln.part, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
                 ln.part[k_] += v_
 
+    def pipeline_overlapped(ln, n, th):
+        """the same calls, the searches in their submit / wait form: the extraction of a lane's NEXT step is enqueued beside the
+        local-map search of its current one (a frame's extraction needs nothing of the frame before it; the batch object holds the
+        current step's keypoints by then - the bind has gathered them - so the extractors' slots are free)"""
+        if n <= 0:
+            return
+        t0 = time.perf_counter()
+        extract(ln)
+        t1 = time.perf_counter()
+        ln.part["extract_left_right"] += t1 - t0
+        for k in range(n):
+            t1 = time.perf_counter()
+            ln.tb.bind_fisheye(ln.exL, ln.exR, ln.meta, lap, lap, want_tables=False)
+            t2 = time.perf_counter()
+            ln.tb.search_last_frame(pl_last, th=th, copy=False, submit=True)
+            ln.tb.wait(copy=False)
+            t3 = time.perf_counter()
+            ln.tb.track_local_map(pl_local, viewing_cos_limit=0.5, log_scale_factor=LOG_SF, th=th, copy=False, submit=True)
+            t4 = time.perf_counter()
+            if k + 1 < n:
+                extract(ln)
+            t5 = time.perf_counter()
+            ln.tb.wait(copy=False)
+            t6 = time.perf_counter()
+            for k_, v_ in zip(ln.part, (t5 - t4, t2 - t1, t3 - t2, (t4 - t3) + (t6 - t5))):
+                ln.part[k_] += v_
+
     def run(n, th):
         """n steps, dealt to the lanes; every lane works through its steps on a host thread of its own"""
-        futs = [ahead.submit(pipeline, ln, n // nlanes + (1 if i < n % nlanes else 0), th) for i, ln in enumerate(lanes)]
+        fn = pipeline_overlapped if overlap else pipeline
+        futs = [ahead.submit(fn, ln, n // nlanes + (1 if i < n % nlanes else 0), th) for i, ln in enumerate(lanes)]
         for f_ in futs:
             f_.result()
     out = {"metric": "frames/sec extract + SearchByProjection (last frame, local map), B frames per launch", "unit": "frames/s",
            "batch_frames": B, "distinct_frames": B, "steps": steps, "image": [w, h], "nfeatures": nf, "local_map_points": M,
-           "mode": f"{nlanes} steps in flight ({nlanes} host threads, each with its extractors and its batch)" if nlanes > 1 else "one step at a time",
+           "mode": (f"{nlanes} steps in flight ({nlanes} host threads, each with its extractors and its batch)" if nlanes > 1 else "one step at a time") +
+                   ("; a lane's next extraction enqueued beside its current local-map search" if overlap else ""),
            "host_threads": nlanes * (1 if one_thread_per_lane else 3),
            "inputs": "images resident in HBM before the timed region; map points in %s host memory, uploaded inside it" % ("pinned" if pinned else "pageable"),
            "outputs": "keypoints, descriptors, assignments, match counts, frustum fields in host memory", "by_th": {}}
