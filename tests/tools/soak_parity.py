@@ -74,6 +74,21 @@ def main():
                 if err:
                     err += " (second call)"
             del ex
+            if err is None and trial % 6 == 1 and w * h < 500 * 400:
+                # a wide batch into pinned arrays: the device delivers the results itself in the reference's output order
+                # (k_deliver_ordered), random lapping area; the same batch into pageable arrays (staging + the host's pass)
+                Bw = int(rng.integers(9, 15))
+                lap = (0, w) if rng.random() < 0.3 else tuple(sorted(int(v) for v in rng.integers(0, w, size=2)))
+                imgs = [img] + [synth.make_image(w, h, seed=int(rng.integers(1 << 30)), density=dens) for _ in range(Bw - 1)]
+                exw = orb.ORBextractor(ctx, nf, sfac, nlevels, ini, mn, w, h, max_batch=Bw)
+                got, staged = exw.extract_batch(imgs, lap, pinned=True), exw.extract_batch(imgs, lap)
+                for im, g, st in zip(imgs, got, staged):
+                    k2, d2, m2 = oex.extract(im, lap)
+                    err = err or same_keys(g[0], g[1], k2, d2) or same_keys(st[0], st[1], k2, d2) or (None if g[2] == m2 == st[2] else "mono count (wide batch)")
+                    kps += len(k2)
+                if err:
+                    err += " (wide batch, lapping area %s)" % (lap,)
+                del exw
             if err is None and trial % 5 == 0 and len(ok) > 0:  # Frame::ComputeBoW on this frame's descriptors
                 k, Lv = int(rng.integers(1, 21)), int(rng.integers(1, 5))
                 if k ** Lv > 20000:
