@@ -692,16 +692,18 @@ int ft_extract_launch_b(ft_extractor *ex, int b0, int nb, hipStream_t st) {
 // only at the end of the batch
 int ft_extract_finish_counts(ft_extractor *ex, int batch, hipStream_t st) {
     if (!ex->deviceOctree) return FT_OK;
-    FT_HIP(hipMemcpyAsync(ex->h_nSel, ex->d_nSel, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
-    FT_HIP(hipMemcpyAsync(ex->h_overflow, ex->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (ex->octLayout.bigN || ex->histEnabled) {  // demand for the tiers behind k_octree during this batch (ft_extract_update_big_grid)
-        for (int k = 0; k < FT_OCT_STREAMS; k++) {
-            FT_HIP(hipMemcpyAsync(ex->h_histStat + k, ex->d_bigCount + 4 * k + 2, sizeof(int), hipMemcpyDeviceToHost, st));
-            FT_HIP(hipMemcpyAsync(ex->h_bigStat + k, ex->d_bigCount + 4 * k + 3, sizeof(int), hipMemcpyDeviceToHost, st));
-            FT_HIP(hipMemsetAsync(ex->d_bigCount + 4 * k + 2, 0, 2 * sizeof(int), st));
-        }
-    }
-    return FT_OK;
+    FtCountsArgs a;
+    a.nSel = ex->d_nSel;
+    a.oNSel = ex->h_nSel;
+    a.overflow = ex->d_overflow;
+    a.oOverflow = ex->h_overflow;
+    // demand for the tiers behind k_octree during this batch (ft_extract_update_big_grid)
+    a.bigCount = (ex->octLayout.bigN || ex->histEnabled) ? ex->d_bigCount : nullptr;
+    a.oHist = ex->h_histStat;
+    a.oBig = ex->h_bigStat;
+    a.batch = batch;
+    a.nStreams = FT_OCT_STREAMS;
+    return ft_launch_finish_counts(st, a);
 }
 
 // async D2H of the keypoints / descriptors of slots [b0, b0+nb) on `st`

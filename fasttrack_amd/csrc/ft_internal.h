@@ -261,6 +261,17 @@ struct FtOrderedArgs {
     float lap0, lap1;
 };
 int ft_launch_deliver_ordered(hipStream_t st, int nb, const FtOrderedArgs &a);
+// the end-of-batch counters of an extractor into pinned host memory (k_finish_counts)
+struct FtCountsArgs {
+    const int *nSel;      // device [batch]
+    int *oNSel;           // pinned host [batch]
+    const int *overflow;  // device flag
+    int *oOverflow;       // pinned host
+    int *bigCount;        // device: per octree stream k the demand words [4 k + 2], [4 k + 3] (read and zeroed); null = none
+    int *oHist, *oBig;    // pinned host [nStreams]
+    int batch, nStreams;
+};
+int ft_launch_finish_counts(hipStream_t st, const FtCountsArgs &a);
 // Frame upload of a small batch (latency mode): one kernel reads the frames from pinned host memory
 // and writes them as level 0 of the slot pyramids (row pitch `pitch`, `slotBytes` apart), and fills
 // the level-0 pointer table - instead of one DMA copy per frame plus one for the table.

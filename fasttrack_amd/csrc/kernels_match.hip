@@ -761,6 +761,30 @@ int ft_launch_upload(hipStream_t st, int batch, const FtSrcEntry *srcTab, int wi
     return FT_OK;
 }
 
+namespace {
+// the counters the host reads at the end of a wide batch - per-image totals, the overflow flag, the demand of the octree tiers
+// behind k_octree (reset here for the next batch) - written to pinned host memory by ONE small kernel: they were six or seven
+// 4-byte copies and two fills through the DMA queue, ~18 us of link latency each, one after the other at the tail of every
+// ft_extract_batch / front-end batch
+__global__ __launch_bounds__(256) void k_finish_counts(FtCountsArgs a) {
+    for (int i = threadIdx.x; i < a.batch; i += 256) a.oNSel[i] = a.nSel[i];
+    if (threadIdx.x == 0) *a.oOverflow = *a.overflow;
+    if (a.bigCount && (int)threadIdx.x < a.nStreams) {
+        const int k = threadIdx.x;
+        a.oHist[k] = a.bigCount[4 * k + 2];
+        a.oBig[k] = a.bigCount[4 * k + 3];
+        a.bigCount[4 * k + 2] = 0;
+        a.bigCount[4 * k + 3] = 0;
+    }
+}
+}  // namespace
+
+int ft_launch_finish_counts(hipStream_t st, const FtCountsArgs &a) {
+    hipLaunchKernelGGL(k_finish_counts, dim3(1), dim3(256), 0, st, a);
+    FT_HIP(hipGetLastError());
+    return FT_OK;
+}
+
 int ft_launch_deliver_ordered(hipStream_t st, int nb, const FtOrderedArgs &a) {
     if (nb <= 0) return FT_OK;
     hipLaunchKernelGGL(k_deliver_ordered, dim3(nb), dim3(256), 0, st, a);

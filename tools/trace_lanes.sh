@@ -3,12 +3,13 @@
 # tests/tools/bench_tracking_batch.py, then (steady state = the last 60 % of the trace) the busy fraction of the device (union of
 # kernel and copy intervals), the sum of kernel durations, and the largest idle gaps with the operations on either side.
 # usage (on the GPU box): bash tools/trace_lanes.sh <tag> [B=128] [steps=10] [lanes=2]
+#        TRACE_CMD="tools/extract_512_alone.py" bash tools/trace_lanes.sh <tag>      (any other script instead of the leg)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/${1:-lanes}
 B=${2:-128}; STEPS=${3:-10}; LANES=${4:-2}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/trace -o trace -- python3 $REPO/tests/tools/bench_tracking_batch.py $B $STEPS $LANES 1 0 > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/trace -o trace -- python3 $REPO/${TRACE_CMD:-tests/tools/bench_tracking_batch.py} $B $STEPS $LANES 1 0 > $OUT/trace.log 2>&1
 timeout 200 python3 - $OUT <<'PY' > $OUT/lanes.txt
 import sqlite3, glob, sys
 out = sys.argv[1]
@@ -51,7 +52,13 @@ for f in glob.glob(out + "/trace/**/*.db", recursive=True):
         by.setdefault(a, [0, 0.0]); by[a][0] += 1; by[a][1] += g
     for b, (c, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:14]:
         print("  %-40s %5d gaps %8.2f ms" % (b, c, t / 1e6))
+    print("operations in the steady state (count, average us, total ms):")
+    agg = {}
+    for s0, e0, n, k in ss:
+        agg.setdefault(n, [0, 0.0]); agg[n][0] += 1; agg[n][1] += e0 - s0
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
+        print("  %-40s %6d %9.1f %9.2f" % (n, c, t / c / 1e3, t / 1e6))
 PY
 cat $OUT/lanes.txt
-tail -1 $OUT/trace.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print({k: round(v['value']) for k, v in d['by_th'].items()})"
+tail -1 $OUT/trace.log | cut -c1-300
 rm -rf $OUT/trace
