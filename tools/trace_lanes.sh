@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/${1:-lanes}
 B=${2:-128}; STEPS=${3:-10}; LANES=${4:-2}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/trace -o trace -- python3 $REPO/${TRACE_CMD:-tests/tools/bench_tracking_batch.py} $B $STEPS $LANES 1 0 > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/trace -o trace -- python3 $REPO/${TRACE_CMD:-tests/tools/bench_tracking_batch.py $B $STEPS $LANES 1 0} > $OUT/trace.log 2>&1
 timeout 200 python3 - $OUT <<'PY' > $OUT/lanes.txt
 import sqlite3, glob, sys
 out = sys.argv[1]
